@@ -1,0 +1,296 @@
+/*
+ * ycge.h — C-ABI of the MI355X ray-trace core for YetAnotherConsoleGameEngine.
+ *
+ * This is the drop-in boundary for ONE path of the reference: the per-pixel
+ * ray-trace loop that RaytraceEntity drives through the private seam
+ * RaytraceEntity.IConsoleRenderer (reference ConsoleGame/RaytraceEntity.cs:12-18:
+ * SetCamera / SetFov / TryFlipAndBlit / Resize).  A third IConsoleRenderer
+ * wrapper on the C# side P/Invokes the entry points below (binding source in
+ * INTEGRATION.md).  Everything is plain C: PODs, pointers and sizes; no C++
+ * or torch types cross this line.
+ *
+ * Conventions
+ *   - every function returns YCGE_OK (0) or a negative ycge_status; nothing
+ *     throws across the ABI (the reference throws on misuse, e.g.
+ *     Scenes/Scene.cs:73; the C# wrapper turns codes back into exceptions);
+ *   - the caller owns every host pointer it passes; the library copies during
+ *     the call; the context owns all device memory;
+ *   - calls on one context come from one thread (reference: the Terminal loop
+ *     thread, Renderer/Terminal.cs:136-176) except ycge_set_camera, which is
+ *     safe against a concurrent ycge_render_frame (reference lock(camLock),
+ *     RayTracing/RaytraceRenderer.cs:142-147).
+ *
+ * All float data is IEEE binary32, little endian.  "hi-res grid" below is the
+ * reference's trace grid hiW = fbW*ss, hiH = fbH*2*ss
+ * (RayTracing/RaytraceRenderer.cs:83-87); per-pixel buffers are row-major,
+ * index = x + y*hiW (RayTracing/Fast2D.cs:21-24).
+ */
+#ifndef YCGE_H
+#define YCGE_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define YCGE_ABI_VERSION 1
+
+typedef enum ycge_status {
+    YCGE_OK = 0,
+    YCGE_ERR_INVALID_ARG = -1,   /* null pointer, bad size, bad enum            */
+    YCGE_ERR_NO_SCENE = -2,      /* render before scene upload (Scene.cs:73)    */
+    YCGE_ERR_DEVICE = -3,        /* HIP runtime error; see ycge_last_error      */
+    YCGE_ERR_UNSUPPORTED = -4,   /* feature outside the path (textures, ...)    */
+    YCGE_ERR_OUT_OF_MEMORY = -5,
+    YCGE_ERR_STACK_DEPTH = -6,   /* BVH deeper than the reference's fixed stacks
+                                    (BVH.cs:118 = 128, MeshBVH.cs:150 = 64)     */
+    YCGE_ERR_NO_DEVICE_CODE = -7 /* HIP kernels missing / no gfx950 device      */
+} ycge_status;
+
+typedef struct ycge_vec3 { float x, y, z; } ycge_vec3;
+
+/* ---------------------------------------------------------------- materials
+ * The reference passes opaque delegates Func<Vec3,Vec3,float,Material>
+ * (Objects/Surfaces.cs:64) / Func<int,int,Material> (Objects/VolumeGrid.cs:189).
+ * Only three shapes occur in its scene builders (Scenes/Scenes.cs:408-428,
+ * Scenes/VoxelMaterialPalette.cs:29-98): constant, emissive constant, checker.
+ * Material doubles (Material.cs:7-18) are narrowed to float here; the tracer
+ * only ever reads them through (float) casts or compares against 0.0.
+ */
+typedef enum ycge_material_kind {
+    YCGE_MAT_CONSTANT = 0,       /* Solid / Emissive / plain Material struct    */
+    YCGE_MAT_CHECKER = 1         /* Scenes.cs:418-428: parity of floor(x/s)+floor(z/s) */
+} ycge_material_kind;
+
+typedef struct ycge_material {
+    int32_t kind;                /* ycge_material_kind                          */
+    ycge_vec3 albedo;            /* constant albedo, or checker colour A        */
+    ycge_vec3 albedo_b;          /* checker colour B                            */
+    float checker_scale;
+    float specular;              /* carried for symmetry; never read (quirk 2)  */
+    float reflectivity;
+    ycge_vec3 emission;
+    float transparency;
+    float index_of_refraction;
+    ycge_vec3 transmission_color;
+} ycge_material;
+
+/* --------------------------------------------------------------- primitives
+ * One record per entry of Scene.Objects, in Objects order (order is part of
+ * the result: BVH leaf order and tie-breaking depend on it).
+ */
+typedef enum ycge_prim_type {
+    YCGE_PRIM_SPHERE = 0,        /* p = cx,cy,cz,radius              BoundedObjects.cs:7-69   */
+    YCGE_PRIM_PLANE = 1,         /* p = px,py,pz, nx,ny,nz (n as given; normalised inside) Surfaces.cs:8-71 */
+    YCGE_PRIM_DISK = 2,          /* p = cx,cy,cz, nx,ny,nz, radius   Surfaces.cs:73-142       */
+    YCGE_PRIM_XYRECT = 3,        /* p = x0,x1,y0,y1,z                Surfaces.cs:144-214      */
+    YCGE_PRIM_XZRECT = 4,        /* p = x0,x1,z0,z1,y                Surfaces.cs:216-286      */
+    YCGE_PRIM_YZRECT = 5,        /* p = y0,y1,z0,z1,x                Surfaces.cs:288-358      */
+    YCGE_PRIM_BOX = 6,           /* p = min xyz, max xyz             BoundedObjects.cs:72-116 */
+    YCGE_PRIM_CYLINDER_Y = 7,    /* p = cx,cy,cz,radius,yMin,yMax,capped(0/1) BoundedObjects.cs:118-247 */
+    YCGE_PRIM_TRIANGLE = 8,      /* p = A xyz, B xyz, C xyz          Objects/Triangle.cs      */
+    YCGE_PRIM_MESH = 9,          /* ref = index into ycge_scene.meshes                        */
+    YCGE_PRIM_VOLUME_GRID = 10   /* ref = index into ycge_scene.grids                         */
+} ycge_prim_type;
+
+typedef struct ycge_prim {
+    int32_t type;                /* ycge_prim_type                              */
+    int32_t material;            /* index into ycge_scene.materials (unused for mesh / grid) */
+    int32_t ref;                 /* mesh / grid index                           */
+    int32_t reserved;
+    float p[12];
+    /* Plane / Disk / Rects / Box overwrite the material func's Specular and
+     * Reflectivity with their ctor arguments (Surfaces.cs:65-66,136-137,
+     * 208-209,280-281,352-353).  Ignored for the other types. */
+    float specular;
+    float reflectivity;
+} ycge_prim;
+
+/* Triangle soup of one Mesh (RayTracing/Mesh.cs:16-21): 9 floats per triangle
+ * (A, B, C), already transformed as MeshLoader.FromObj leaves them. */
+typedef struct ycge_mesh {
+    const float *triangles;      /* 9 * n_triangles floats                      */
+    int32_t n_triangles;
+    int32_t material;            /* material of every triangle                  */
+    const int32_t *tri_material; /* optional per-triangle material, or NULL     */
+} ycge_mesh;
+
+/* (matId, metaId) -> material; stands in for Func<int,int,Material>. */
+typedef struct ycge_voxel_lookup {
+    int32_t mat_id;
+    int32_t meta_id;
+    int32_t material;            /* index into ycge_scene.materials             */
+} ycge_voxel_lookup;
+
+/* One VolumeGrid (Objects/VolumeGrid.cs:55-93).  cells = the ctor's
+ * (int,int)[nx,ny,nz] in its native memory order: pair index
+ * (ix*ny + iy)*nz + iz, Item1 = matId, Item2 = metaId. */
+typedef struct ycge_grid {
+    int32_t nx, ny, nz;
+    ycge_vec3 min_corner;
+    ycge_vec3 voxel_size;
+    const int32_t *cells;        /* 2 * nx*ny*nz int32                          */
+    const ycge_voxel_lookup *lookup;
+    int32_t n_lookup;
+    int32_t default_material;    /* lookup miss -> this material; <0 = error    */
+    int32_t wireframe;           /* ctor default true                           */
+    float wire_width_fraction;   /* ctor default 0.06f                          */
+    float wire_max_distance;     /* ctor default 16.0f                          */
+} ycge_grid;
+
+typedef struct ycge_light {      /* Objects/PointLight.cs:3-15 */
+    ycge_vec3 position;
+    ycge_vec3 color;
+    float intensity;
+} ycge_light;
+
+typedef struct ycge_scene {      /* Scenes/Scene.cs:12-24 */
+    const ycge_material *materials; int32_t n_materials;
+    const ycge_prim *prims;         int32_t n_prims;
+    const ycge_mesh *meshes;        int32_t n_meshes;
+    const ycge_grid *grids;         int32_t n_grids;
+    const ycge_light *lights;       int32_t n_lights;
+    ycge_vec3 ambient_color;  float ambient_intensity;
+    ycge_vec3 background_top;
+    ycge_vec3 background_bottom;
+    int32_t is_volume_scene;     /* `scene is VolumeScene` (RaytraceRenderer.cs:761) */
+    int32_t reserved;
+} ycge_scene;
+
+/* ------------------------------------------------------------------- config */
+typedef struct ycge_config {
+    int32_t abi_version;         /* YCGE_ABI_VERSION                            */
+    int32_t fb_width;            /* chexel columns  (Framebuffer.Width)         */
+    int32_t fb_height;           /* chexel rows     (Framebuffer.Height)        */
+    int32_t super_sample;        /* ss >= 1                                     */
+    float fov_deg;
+    int32_t device;              /* HIP device ordinal                          */
+    /* framebuffer tiling across GPUs: this context traces the 32x8-pixel
+     * tiles with tile_id % world_size == rank (one process per GPU). */
+    int32_t rank;
+    int32_t world_size;
+    /* constants of RaytraceRenderer.cs:31-43,65,218 (same defaults) */
+    int32_t diffuse_bounces;     /* 1 */
+    int32_t max_mirror_bounces;  /* 2 */
+    int32_t max_refractions;     /* 2 */
+    float mirror_threshold;      /* 0.9f */
+    float eps;                   /* 1e-4f */
+    uint64_t seed_salt;          /* 0x9E3779B97F4A7C15 */
+    float taa_alpha;             /* 0.01f */
+    float motion_trans_reset;    /* 0.0025f */
+    float motion_rot_reset;      /* 0.0025f */
+    float diffuse_sigma_deg;     /* 25.0f */
+    int32_t taa_clamp_radius;    /* 1 */
+    float taa_luminance_pad;     /* 0.10f */
+    /* denoise / tonemap stage after TAA (RaytraceRenderer.cs:221-227) */
+    int32_t atrous_iterations;   /* 3 */
+    float atrous_c_phi, atrous_n_phi, atrous_z_phi, atrous_a_phi; /* 3, 0.35, 2, 0.20 */
+    int32_t capture_debug;       /* also keep rays / primId / hitT buffers      */
+    int32_t count_work;          /* keep per-frame traversal counters           */
+} ycge_config;
+
+typedef struct ycge_frame_stats {
+    int64_t frame;               /* frameCounter after the increment            */
+    int32_t history_reset;       /* TAA history was (re)initialised this frame  */
+    int32_t reserved;
+    double trace_ms;             /* device time of ray-gen + trace              */
+    double taa_ms;
+    double post_ms;              /* denoise + exposure + tonemap/downsample     */
+    double total_ms;             /* wall time of the call                       */
+    /* traversal counters; valid when config.count_work != 0 */
+    uint64_t n_rays;             /* Scene.Hit + Scene.Occluded calls            */
+    uint64_t n_box;              /* AABB evaluations as root or as child        */
+    uint64_t n_tri;              /* MeshBVH.TriHit calls                        */
+    uint64_t n_prim;             /* analytic primitive tests (box = 6 rects)    */
+    uint64_t n_vox;              /* DDA cells visited                           */
+    float exposure;              /* ToneMapper.EffectiveExposure                */
+    float reserved2;
+} ycge_frame_stats;
+
+typedef enum ycge_buffer {
+    YCGE_BUF_RAYS = 0,           /* 6 f32/px: origin, dir      (capture_debug)  */
+    YCGE_BUF_PRIM_ID = 1,        /* i32/px: Objects index of primary hit, -1 miss (capture_debug) */
+    YCGE_BUF_SUB_ID = 2,         /* i32/px: triangle index / box face / voxel cell (capture_debug) */
+    YCGE_BUF_HIT_T = 3,          /* f32/px: primary hit t, FLT_MAX miss (capture_debug) */
+    YCGE_BUF_CURRENT_HDR = 4,    /* 3 f32/px */
+    YCGE_BUF_G_ALBEDO = 5,       /* 3 f32/px */
+    YCGE_BUF_G_NORMAL = 6,       /* 3 f32/px */
+    YCGE_BUF_G_DEPTH = 7,        /* f32/px   */
+    YCGE_BUF_SKY_MASK = 8,       /* u8/px    */
+    YCGE_BUF_TAA_HISTORY = 9,    /* 3 f32/px */
+    YCGE_BUF_PREV_NORMAL = 10,   /* 3 f32/px */
+    YCGE_BUF_PREV_DEPTH = 11,    /* f32/px   */
+    YCGE_BUF_PREV_SKY = 12,      /* u8/px    */
+    YCGE_BUF_DENOISED = 13,      /* 3 f32/px */
+    YCGE_BUF_RNG_STATE = 14      /* u64/px: Rng state when the pixel finished (capture_debug) */
+} ycge_buffer;
+
+/* flattened acceleration structures, for parity tests of the builders */
+typedef enum ycge_accel {
+    YCGE_ACCEL_SCENE_NODES = 0,  /* 10 x 4 B per node: min xyz, max xyz, left, right, start, count (BVH.cs:11-20) */
+    YCGE_ACCEL_SCENE_LEAF_INDEX = 1, /* i32 leafObjIndex                        */
+    YCGE_ACCEL_MESH_NODES = 2,   /* same node record, mesh `index`              */
+    YCGE_ACCEL_MESH_LEAF_INDEX = 3   /* i32 leafTriIndex                        */
+} ycge_accel;
+
+typedef struct ycge_ctx ycge_ctx;
+
+/* Fill *cfg with the reference defaults (RaytraceRenderer.cs:31-43,65,218-224). */
+int ycge_config_default(ycge_config *cfg);
+
+/* new RaytraceRenderer(fb, scene, fov, pxW, pxH, ss)   RaytraceEntity.cs:97,240,262 */
+int ycge_create(const ycge_config *cfg, ycge_ctx **out);
+/* dispose */
+void ycge_destroy(ycge_ctx *ctx);
+/* message of the last failing call on ctx (or of ycge_create when ctx == NULL) */
+const char *ycge_last_error(const ycge_ctx *ctx);
+
+/* scene.RebuildBVH()   RaytraceRenderer.cs:107, RaytraceEntity.cs:244, Scene.cs:122-127.
+ * Builds the scene BVH (Objects/BVH.cs:258-459) and every mesh BVH
+ * (Objects/MeshBVH.cs:371-576) bit-faithfully and uploads them. */
+int ycge_scene_upload(ycge_ctx *ctx, const ycge_scene *scene);
+/* per-frame entity animation of lights / sky (Scenes/DayNightCycle.cs:80-89) */
+int ycge_scene_update_lights(ycge_ctx *ctx, const ycge_light *lights, int32_t n_lights,
+                             const ycge_vec3 *ambient_color, float ambient_intensity,
+                             const ycge_vec3 *background_top, const ycge_vec3 *background_bottom);
+
+/* Resize(fb, ss)   RaytraceEntity.cs:289; drops TAA history (RaytraceRenderer.cs:137) */
+int ycge_resize(ycge_ctx *ctx, int32_t fb_width, int32_t fb_height, int32_t super_sample);
+/* SetCamera(pos,yaw,pitch) + SetFov(deg)   RaytraceEntity.cs:229,99 */
+int ycge_set_camera(ycge_ctx *ctx, const float pos[3], float yaw, float pitch, float fov_deg);
+
+/* TryFlipAndBlit(fb)   RaytraceEntity.cs:230 / RaytraceRenderer.cs:157-267.
+ * out_top_bottom_sdr: fbW*fbH*2*3 f32, caller-owned host memory, per chexel
+ * {top rgb, bottom rgb}; the host then does fb.SetChexel(cx,cy,new Chexel('▀',
+ * top, bottom)) unchanged (RaytraceRenderer.cs:260-261).  May be NULL (frame is
+ * still rendered; read buffers with ycge_read_buffer).  stats may be NULL. */
+int ycge_render_frame(ycge_ctx *ctx, float *out_top_bottom_sdr, ycge_frame_stats *stats);
+
+/* --- multi-GPU halves of a frame (one process per GPU; the exchange between
+ * them is one all-gather of the tile slabs, done by the caller with RCCL).
+ * slab layout: for each owned tile in ascending tile_id, for each of its
+ * 32x8 pixels in row-major order: 11 f32 {hdr rgb, albedo rgb, normal xyz,
+ * depth, sky(0/1)}; ycge_tile_slab_bytes = padded per-rank size (equal on
+ * all ranks so that a plain all-gather applies). */
+int ycge_tile_slab_bytes(const ycge_ctx *ctx, size_t *bytes);
+/* steps 1-4 of TryFlipAndBlit on this rank's tiles; d_slab = DEVICE pointer */
+int ycge_trace_tiles(ycge_ctx *ctx, void *d_slab, void *hip_stream, ycge_frame_stats *stats);
+/* un-permute world_size gathered slabs (DEVICE pointer, rank-major) into the
+ * full-frame buffers, then steps 5-9 (TAA ... tonemap) on the full frame */
+int ycge_resolve_gathered(ycge_ctx *ctx, const void *d_all_slabs, void *hip_stream,
+                          float *out_top_bottom_sdr, ycge_frame_stats *stats);
+
+/* tests only */
+int ycge_read_buffer(ycge_ctx *ctx, int32_t which /* ycge_buffer */, void *dst, size_t bytes);
+int ycge_set_frame_counter(ycge_ctx *ctx, int64_t frame_counter);
+int ycge_accel_size(ycge_ctx *ctx, int32_t which /* ycge_accel */, int32_t index, size_t *bytes);
+int ycge_read_accel(ycge_ctx *ctx, int32_t which, int32_t index, void *dst, size_t bytes);
+/* name of the device the context runs on + whether the gfx950 code object loaded */
+int ycge_device_info(ycge_ctx *ctx, char *name, size_t name_bytes, int32_t *compute_units);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* YCGE_H */
