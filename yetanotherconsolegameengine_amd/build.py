@@ -1,0 +1,65 @@
+"""Builds libycge_hip.so (host C++ + gfx950 HIP kernels) in-tree with hipcc.
+
+    python -m yetanotherconsolegameengine_amd.build [--force]
+
+Flags that matter (see csrc/ycge_math.h): -ffp-contract=off keeps every fp32 operation
+individually rounded (bit-parity with the reference's scalar C#); division and sqrt stay
+on hipcc's IEEE-correct default expansions; no -ffast-math anywhere.
+"""
+from __future__ import annotations
+
+import os
+import shutil
+import subprocess
+import sys
+from pathlib import Path
+
+PKG = Path(__file__).resolve().parent
+CSRC = PKG / "csrc"
+LIB_DIR = PKG / "lib"
+LIB = LIB_DIR / "libycge_hip.so"
+SOURCES = ["ycge_host.cpp", "ycge_accel.cpp", "ycge_kernels.hip"]
+HEADERS = ["ycge_device.h", "ycge_accel.h", "ycge_math.h"]
+ARCH = "gfx950"
+
+FLAGS = [
+    f"--offload-arch={ARCH}", "-O3", "-std=c++17", "-fPIC", "-shared",
+    "-ffp-contract=off", "-fno-fast-math", "-fhip-fp32-correctly-rounded-divide-sqrt",
+    "-fno-gpu-rdc", "-Wall", "-Wno-unused-function", "-Wno-unused-variable",
+]
+
+
+def hipcc() -> str:
+    for cand in (os.environ.get("HIPCC"), shutil.which("hipcc"), "/opt/rocm/bin/hipcc"):
+        if cand and Path(cand).exists():
+            return cand
+    raise FileNotFoundError("hipcc not found (ROCm toolchain required; there is no CPU build of the kernels)")
+
+
+def is_stale() -> bool:
+    if not LIB.exists():
+        return True
+    t = LIB.stat().st_mtime
+    deps = [CSRC / n for n in SOURCES + HEADERS] + [PKG.parent / "include" / "ycge.h", Path(__file__)]
+    return any(d.stat().st_mtime > t for d in deps)
+
+
+def build_library(force: bool = False, verbose: bool = False, extra_flags=()) -> Path:
+    if not force and not is_stale():
+        return LIB
+    LIB_DIR.mkdir(exist_ok=True)
+    cmd = [hipcc(), *FLAGS, *extra_flags, "-x", "hip", *[str(CSRC / s) for s in SOURCES], "-o", str(LIB)]
+    if verbose:
+        print(" ".join(cmd))
+    r = subprocess.run(cmd, capture_output=True, text=True)
+    if r.returncode != 0:
+        sys.stderr.write(r.stdout + r.stderr)
+        raise RuntimeError("hipcc failed building libycge_hip.so")
+    if verbose and r.stderr:
+        print(r.stderr)
+    return LIB
+
+
+if __name__ == "__main__":
+    p = build_library(force="--force" in sys.argv, verbose=True)
+    print("built", p)

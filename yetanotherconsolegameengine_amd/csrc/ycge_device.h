@@ -1,0 +1,188 @@
+// ycge_device.h — data layout in HBM, shared by the host side (ycge_host.cpp,
+// ycge_accel.cpp) and the gfx950 kernels (ycge_kernels.hip).
+//
+// Every record is sized so that one lane fetches it with whole 16-byte loads
+// (global_load_dwordx4): lanes of a wavefront diverge during traversal, so the
+// unit of HBM/L2 traffic is the record, not a wave-wide row.
+//
+//   GNode   64 B  an INTERNAL node of either BVH with BOTH child boxes inline:
+//                 one fetch per visit replaces the reference's three
+//                 (own box on pop + two child boxes; BVH.cs:126-166).
+//   GTri    48 B  triangle in LEAF ORDER (leafTriIndex applied at upload):
+//                 A, e1, e2 + original index; the unit normal is recomputed
+//                 from e1 x e2 on the final hit only (MeshBVH.cs:93-97 ops).
+//   GPrim   64 B  one Scene.Objects entry with its ctor-derived constants.
+//   GMaterial 80 B, GGrid 96 B + 1 byte per voxel (bricked 8^3, Morton inside).
+#pragma once
+#include <stdint.h>
+
+namespace ycge {
+
+// ---- child / stack reference encoding (uint32) ---------------------------
+// bits 31..29 kind, bits 28..0 payload
+enum : uint32_t {
+    REF_SCENE_NODE = 0u,   // payload = index into scene_nodes
+    REF_SCENE_LEAF = 1u,   // payload = (start << 3) | count        (count 1..4, BVH.cs:7)
+    REF_MESH_NODE = 2u,    // payload = global index into mesh_nodes
+    REF_MESH_LEAF = 3u,    // payload = (global tri start << 4) | count (count 1..8, MeshBVH.cs:14)
+    REF_PRIM = 4u,         // payload = index into prims
+    REF_NONE = 7u
+};
+#define YCGE_REF(kind, payload) (((uint32_t)(kind) << 29) | (uint32_t)(payload))
+#define YCGE_REF_KIND(r) ((r) >> 29)
+#define YCGE_REF_PAYLOAD(r) ((r) & 0x1fffffffu)
+#define YCGE_REF_NONE_VALUE 0xffffffffu
+
+struct alignas(16) GNode {
+    float lmin[3], lmax[3];     // left child box
+    float rmin[3], rmax[3];     // right child box
+    uint32_t lref, rref;        // child references
+    uint32_t pad[2];
+};
+static_assert(sizeof(GNode) == 64, "GNode must be 64 B");
+
+struct alignas(16) GTri {
+    float ax, ay, az, e1x;
+    float e1y, e1z, e2x, e2y;
+    float e2z;
+    int32_t orig;               // index in the mesh's input triangle order
+    int32_t material;           // material index (per-triangle or the mesh's)
+    int32_t pad;
+};
+static_assert(sizeof(GTri) == 48, "GTri must be 48 B");
+
+// prim types: identical numbering to ycge_prim_type in include/ycge.h
+struct alignas(16) GPrim {
+    int32_t type;
+    int32_t material;
+    int32_t ref;                // mesh / grid index
+    float reflectivity;         // ctor override for plane/disk/rect/box (Surfaces.cs:65-66)
+    // per-type constants (derived on the host exactly as the C# ctors do):
+    //  SPHERE     cx cy cz radius
+    //  PLANE      nx ny nz (normalised) ndotPoint
+    //  DISK       cx cy cz nx ny nz radius2 ndotCenter
+    //  XY/XZ/YZ   a0 a1 b0 b1 k
+    //  BOX        min xyz max xyz
+    //  CYLINDER_Y cx cz radius radius2 yMin yMax capped
+    //  TRIANGLE   A xyz e1 xyz e2 xyz n xyz
+    float p[12];
+};
+static_assert(sizeof(GPrim) == 64, "GPrim must be 64 B");
+
+struct alignas(16) GMaterial {
+    int32_t kind;
+    float albedo[3];
+    float albedo_b[3];
+    float checker_scale;
+    float reflectivity;
+    float emission[3];
+    float transparency;
+    float ior;
+    float trans_color[3];
+    float pad[3];
+};
+static_assert(sizeof(GMaterial) == 80, "GMaterial must be 80 B");
+
+struct alignas(16) GMesh {
+    float root_min[3], root_max[3];
+    uint32_t root_ref;          // REF_MESH_NODE or REF_MESH_LEAF
+    uint32_t pad;
+};
+static_assert(sizeof(GMesh) == 32, "GMesh must be 32 B");
+
+struct alignas(16) GGrid {
+    int32_t nx, ny, nz;
+    int32_t nbx, nby, nbz;
+    float min_corner[3];
+    float voxel_size[3];        // already max(1e-6, v) (VolumeGrid.cs:76)
+    uint32_t cell_offset;       // byte offset of this grid's cells in grid_cells
+    int32_t wireframe;
+    float wire_width_frac;
+    float wire_max_distance;
+    uint32_t lut_offset;        // index of this grid's first entry in grid_lut (cell code -> material)
+    uint32_t pad[7];
+};
+static_assert(sizeof(GGrid) == 96, "GGrid must be 96 B");
+
+struct GLight {
+    float pos[3];
+    float color[3];
+    float intensity;
+    float pad;
+};
+
+#define YCGE_TRAVERSAL_STACK 96    // >= scene depth + 4 leaf prims + mesh depth, checked at upload
+#define YCGE_TILE_W 32
+#define YCGE_TILE_H 8
+#define YCGE_SLAB_FLOATS 11        // hdr rgb, albedo rgb, normal xyz, depth, sky
+
+// everything the trace kernel needs besides per-frame camera values
+struct SceneDev {
+    const GNode *scene_nodes;
+    const uint32_t *scene_leaf_prims;   // leafObjIndex
+    const GNode *mesh_nodes;
+    const GTri *tris;
+    const GPrim *prims;
+    const GMaterial *materials;
+    const GMesh *meshes;
+    const GGrid *grids;
+    const uint8_t *grid_cells;
+    const int32_t *grid_lut;
+    float scene_root_min[3], scene_root_max[3];
+    uint32_t scene_root_ref;            // REF_NONE when Objects is empty
+    int32_t n_lights;
+    const GLight *lights;               // n_lights records in HBM (indexed per lane)
+    float ambient[3];                   // Ambient.Color
+    float ambient_intensity;
+    float bg_top[3], bg_bottom[3];
+    int32_t is_volume_scene;
+    int32_t any_transparent;            // some material has Transparency > 0
+};
+
+struct FrameParams {
+    int32_t hiW, hiH;
+    int64_t frame;
+    int32_t frame_idx;
+    float rot_x, rot_y;                 // jitterRotX/Y
+    float cam_pos[3];
+    float fwd[3], right[3], up[3];
+    float half_w, half_h;
+    uint64_t seed_salt;
+    float eps;
+    float mirror_threshold;
+    float sigma_rad;
+    int32_t max_mirror_bounces, max_refractions, diffuse_bounces;
+    // tile partition
+    int32_t tiles_x, tiles_y;
+    int32_t rank, world_size;
+    int32_t n_owned_tiles;
+};
+
+struct TraceOut {
+    // full-frame buffers (single-GPU path) ...
+    float *current_hdr;     // 3 f32 / px
+    float *g_albedo;
+    float *g_normal;
+    float *g_depth;
+    uint8_t *sky;
+    // ... or this rank's tile slab (multi-GPU path); exactly one of the two is used
+    float *slab;
+    // debug capture (may be null)
+    float *rays;
+    int32_t *prim_id;
+    int32_t *sub_id;
+    float *hit_t;
+    uint64_t *rng_state;
+    // traversal counters (may be null): rays, box, tri, prim, vox
+    unsigned long long *counters;
+};
+
+struct TaaParams {
+    int32_t w, h;
+    float alpha;
+    int32_t radius;
+    float pad_lum;
+    int32_t reset;
+};
+
+} // namespace ycge

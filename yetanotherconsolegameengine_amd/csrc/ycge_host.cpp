@@ -1,0 +1,891 @@
+// ycge_host.cpp — host side of the C-ABI in include/ycge.h: context, scene flattening
+// and upload, frame orchestration (TryFlipAndBlit steps 1-5, 9), tile partition for
+// multi-GPU, test read-backs.  All device work is in ycge_kernels.hip; there is no CPU
+// implementation of any per-pixel stage here.
+#include <hip/hip_runtime.h>
+
+#include <chrono>
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <mutex>
+#include <string>
+#include <vector>
+
+#include "../../include/ycge.h"
+#include "ycge_accel.h"
+#include "ycge_device.h"
+#include "ycge_math.h"
+
+extern "C" {
+int ycge_launch_trace(const ycge::SceneDev *S, const ycge::FrameParams *P, const ycge::TraceOut *O, int count, int debug, int slab,
+                      hipStream_t stream);
+int ycge_launch_taa(const ycge::TaaParams *T, const float *current, const float *normal, const float *depth, const uint8_t *sky,
+                    float *hist, float *prev_normal, float *prev_depth, uint8_t *prev_sky, hipStream_t stream);
+int ycge_launch_unpermute(const float *all_slabs, size_t slab_floats_per_rank, int hiW, int hiH, int tiles_x, int n_tiles, int world_size,
+                          float *hdr, float *albedo, float *normal, float *depth, uint8_t *sky, hipStream_t stream);
+}
+
+using namespace ycge;
+
+namespace {
+
+std::string g_create_error;
+
+template <class T> struct DevBuf {
+    T *p = nullptr;
+    size_t n = 0;
+    void release() { if (p) { (void)hipFree(p); p = nullptr; } n = 0; }
+    hipError_t alloc(size_t count)
+    {
+        release();
+        n = count;
+        if (count == 0) return hipSuccess;
+        return hipMalloc((void **)&p, count * sizeof(T));
+    }
+    hipError_t upload(const std::vector<T> &v)
+    {
+        hipError_t e = alloc(v.size());
+        if (e != hipSuccess || v.empty()) return e;
+        return hipMemcpy(p, v.data(), v.size() * sizeof(T), hipMemcpyHostToDevice);
+    }
+};
+
+struct MeshHost {
+    BuiltTree tree;
+};
+
+} // namespace
+
+struct ycge_ctx {
+    ycge_config cfg;
+    std::string err;
+    int device = 0;
+    hipStream_t stream = nullptr;
+    hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
+    char device_name[256] = {0};
+    int compute_units = 0;
+
+    // geometry of the trace grid
+    int fbW = 0, fbH = 0, ss = 1, hiW = 0, hiH = 0;
+    int tiles_x = 0, tiles_y = 0, n_tiles = 0, n_owned = 0, tiles_per_rank_padded = 0;
+
+    // camera (lock(camLock), RaytraceRenderer.cs:142-147)
+    std::mutex cam_lock;
+    float cam_pos[3] = {0.0f, 1.0f, 0.0f};
+    float yaw = 0.0f, pitch = 0.0f, fov_deg = 45.0f;
+
+    int64_t frame_counter = 0;                 // RaytraceRenderer.cs:24
+    // TemporalAA camera memory (TemporalAA.cs:11-15) and history validity
+    float last_cam[3] = {NAN, NAN, NAN}, last_yaw = NAN, last_pitch = NAN;
+    bool taa_valid = false;
+
+    // per-pixel buffers in HBM (row-major, x + y*hiW)
+    DevBuf<float> current_hdr, g_albedo, g_normal, g_depth, taa_hist, prev_normal, prev_depth;
+    DevBuf<uint8_t> sky, prev_sky;
+    DevBuf<float> dbg_rays, dbg_hit_t;
+    DevBuf<int32_t> dbg_prim, dbg_sub;
+    DevBuf<uint64_t> dbg_rng;
+    DevBuf<unsigned long long> counters;
+    DevBuf<float> own_slab;                    // used when world_size > 1 and the caller passes no slab
+
+    // scene
+    bool have_scene = false;
+    SceneDev sd{};
+    DevBuf<GNode> d_scene_nodes, d_mesh_nodes;
+    DevBuf<uint32_t> d_scene_leaf;
+    DevBuf<GTri> d_tris;
+    DevBuf<GPrim> d_prims;
+    DevBuf<GMaterial> d_materials;
+    DevBuf<GMesh> d_meshes;
+    DevBuf<GGrid> d_grids;
+    DevBuf<uint8_t> d_cells;
+    DevBuf<int32_t> d_lut;
+    DevBuf<GLight> d_lights;
+    BuiltTree scene_tree;
+    std::vector<MeshHost> meshes;
+
+    int fail(int code, const char *fmt, ...)
+    {
+        char buf[512];
+        va_list ap;
+        va_start(ap, fmt);
+        vsnprintf(buf, sizeof buf, fmt, ap);
+        va_end(ap);
+        err = buf;
+        return code;
+    }
+};
+
+#define HIP_TRY(ctx, call)                                                                                   \
+    do {                                                                                                      \
+        hipError_t e_ = (call);                                                                               \
+        if (e_ != hipSuccess) return (ctx)->fail(e_ == hipErrorOutOfMemory ? YCGE_ERR_OUT_OF_MEMORY : YCGE_ERR_DEVICE, \
+                                                 "%s failed: %s", #call, hipGetErrorString(e_));            \
+    } while (0)
+
+namespace {
+
+int alloc_frame_buffers(ycge_ctx *c)
+{
+    const size_t n = (size_t)c->hiW * c->hiH;
+    HIP_TRY(c, c->current_hdr.alloc(3 * n)); HIP_TRY(c, c->g_albedo.alloc(3 * n)); HIP_TRY(c, c->g_normal.alloc(3 * n));
+    HIP_TRY(c, c->g_depth.alloc(n)); HIP_TRY(c, c->sky.alloc(n));
+    HIP_TRY(c, c->taa_hist.alloc(3 * n)); HIP_TRY(c, c->prev_normal.alloc(3 * n)); HIP_TRY(c, c->prev_depth.alloc(n));
+    HIP_TRY(c, c->prev_sky.alloc(n));
+    HIP_TRY(c, hipMemset(c->taa_hist.p, 0, 3 * n * sizeof(float)));
+    if (c->cfg.capture_debug) {
+        HIP_TRY(c, c->dbg_rays.alloc(6 * n)); HIP_TRY(c, c->dbg_prim.alloc(n)); HIP_TRY(c, c->dbg_sub.alloc(n));
+        HIP_TRY(c, c->dbg_hit_t.alloc(n)); HIP_TRY(c, c->dbg_rng.alloc(n));
+    }
+    if (c->cfg.count_work) HIP_TRY(c, c->counters.alloc(8));
+    return YCGE_OK;
+}
+
+int set_geometry(ycge_ctx *c, int fbw, int fbh, int ss)
+{
+    if (fbw <= 0 || fbh <= 0) return c->fail(YCGE_ERR_INVALID_ARG, "framebuffer size must be positive");
+    c->fbW = fbw; c->fbH = fbh; c->ss = ss < 1 ? 1 : ss;        // Math.Max(1, superSample), RaytraceRenderer.cs:81
+    c->hiW = c->fbW * c->ss; c->hiH = c->fbH * 2 * c->ss;      // :86-87
+    c->tiles_x = (c->hiW + YCGE_TILE_W - 1) / YCGE_TILE_W;
+    c->tiles_y = (c->hiH + YCGE_TILE_H - 1) / YCGE_TILE_H;
+    c->n_tiles = c->tiles_x * c->tiles_y;
+    const int world = c->cfg.world_size, rank = c->cfg.rank;
+    c->n_owned = rank < c->n_tiles ? (c->n_tiles - rank + world - 1) / world : 0;
+    c->tiles_per_rank_padded = (c->n_tiles + world - 1) / world;
+    c->taa_valid = false;                                       // Resize: taaHistoryValid = false (:137), taa.Resize (TemporalAA.cs:34-46)
+    c->last_cam[0] = c->last_cam[1] = c->last_cam[2] = NAN; c->last_yaw = c->last_pitch = NAN;
+    int rc = alloc_frame_buffers(c);
+    if (rc != YCGE_OK) return rc;
+    if (world > 1) HIP_TRY(c, c->own_slab.alloc((size_t)c->tiles_per_rank_padded * 256 * YCGE_SLAB_FLOATS));
+    return YCGE_OK;
+}
+
+bool should_reset_history(const ycge_ctx *c, const float pos[3], float yaw, float pitch)   // TemporalAA.cs:58-67
+{
+    float dx = pos[0] - c->last_cam[0], dy = pos[1] - c->last_cam[1], dz = pos[2] - c->last_cam[2];
+    float trans = is_nan(dx) ? 0.0f : cs_sqrt(dx * dx + dy * dy + dz * dz);
+    float dyaw = is_nan(c->last_yaw) ? 0.0f : cs_abs(yaw - c->last_yaw);
+    float dpitch = is_nan(c->last_pitch) ? 0.0f : cs_abs(pitch - c->last_pitch);
+    return trans > c->cfg.motion_trans_reset || dyaw > c->cfg.motion_rot_reset || dpitch > c->cfg.motion_rot_reset;
+}
+
+struct H3 { float x, y, z; };
+H3 h_norm(H3 a)
+{
+    float l = a.x * a.x + a.y * a.y + a.z * a.z;
+    if (l <= 0.0f) return a;
+    float inv = 1.0f / cs_sqrt(l);
+    return H3{a.x * inv, a.y * inv, a.z * inv};
+}
+H3 h_cross(H3 a, H3 b) { return H3{a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x * b.y - a.y * b.x}; }
+
+// per-frame constants of MakeJitteredRay (RaytraceRenderer.cs:413-434): host-side sin/cos/tan, as in the C#
+void fill_frame_params(ycge_ctx *c, FrameParams &P, int64_t frame, const float pos[3], float yaw, float pitch, float fov_deg)
+{
+    std::memset(&P, 0, sizeof P);
+    P.hiW = c->hiW; P.hiH = c->hiH;
+    P.frame = frame;
+    P.frame_idx = (int)(frame & 0x7fffffff);
+    auto fracf = [](float v) { return v - cs_floor(v); };
+    P.rot_x = fracf((float)(P.frame_idx + 1) * 0.61803398875f);
+    P.rot_y = fracf((float)(P.frame_idx + 1) * 0.38196601125f);
+    const float aspect = (float)c->hiW / (float)c->hiH;
+    const float pi = 3.14159265358979323846f;
+    float cp = cosf(pitch);
+    H3 f = H3{sinf(yaw) * cp, sinf(pitch), -cosf(yaw) * cp};
+    float fov_rad = fov_deg * (pi / 180.0f);
+    P.half_h = tanf(0.5f * fov_rad);
+    P.half_w = P.half_h * aspect;
+    H3 fwd = h_norm(f);
+    H3 right = h_norm(h_cross(fwd, H3{0.0f, 1.0f, 0.0f}));
+    H3 up = h_norm(h_cross(right, fwd));
+    P.cam_pos[0] = pos[0]; P.cam_pos[1] = pos[1]; P.cam_pos[2] = pos[2];
+    P.fwd[0] = fwd.x; P.fwd[1] = fwd.y; P.fwd[2] = fwd.z;
+    P.right[0] = right.x; P.right[1] = right.y; P.right[2] = right.z;
+    P.up[0] = up.x; P.up[1] = up.y; P.up[2] = up.z;
+    P.seed_salt = c->cfg.seed_salt;
+    P.eps = c->cfg.eps;
+    P.mirror_threshold = c->cfg.mirror_threshold;
+    P.sigma_rad = c->cfg.diffuse_sigma_deg * (pi / 180.0f);
+    P.max_mirror_bounces = c->cfg.max_mirror_bounces;
+    P.max_refractions = c->cfg.max_refractions;
+    P.diffuse_bounces = c->cfg.diffuse_bounces;
+    P.tiles_x = c->tiles_x; P.tiles_y = c->tiles_y;
+    P.rank = c->cfg.rank; P.world_size = c->cfg.world_size;
+    P.n_owned_tiles = c->n_owned;
+}
+
+// Hittable.TryGetBounds of each primitive class (see the citations in include/ycge.h)
+bool prim_bounds(const ycge_prim &q, const std::vector<MeshHost> &meshes, const ycge_scene *s, float b[6], float cen[3])
+{
+    const float *p = q.p;
+    const float eps = 1e-4f;
+    bool from_box = true;
+    switch (q.type) {
+    case YCGE_PRIM_SPHERE:
+        b[0] = p[0] - p[3]; b[1] = p[1] - p[3]; b[2] = p[2] - p[3]; b[3] = p[0] + p[3]; b[4] = p[1] + p[3]; b[5] = p[2] + p[3]; break;
+    case YCGE_PRIM_PLANE:
+        b[0] = b[1] = b[2] = -1e6f; b[3] = b[4] = b[5] = 1e6f; cen[0] = cen[1] = cen[2] = 0.0f; from_box = false; break;
+    case YCGE_PRIM_DISK:
+        b[0] = p[0] - p[6]; b[1] = p[1] - p[6]; b[2] = p[2] - p[6]; b[3] = p[0] + p[6]; b[4] = p[1] + p[6]; b[5] = p[2] + p[6]; break;
+    case YCGE_PRIM_XYRECT: b[0] = p[0]; b[1] = p[2]; b[2] = p[4] - eps; b[3] = p[1]; b[4] = p[3]; b[5] = p[4] + eps; break;
+    case YCGE_PRIM_XZRECT: b[0] = p[0]; b[1] = p[4] - eps; b[2] = p[2]; b[3] = p[1]; b[4] = p[4] + eps; b[5] = p[3]; break;
+    case YCGE_PRIM_YZRECT: b[0] = p[4] - eps; b[1] = p[0]; b[2] = p[2]; b[3] = p[4] + eps; b[4] = p[1]; b[5] = p[3]; break;
+    case YCGE_PRIM_BOX: for (int k = 0; k < 6; k++) b[k] = p[k]; break;
+    case YCGE_PRIM_CYLINDER_Y:
+        b[0] = p[0] - p[3]; b[1] = cs_min(p[4], p[5]); b[2] = p[2] - p[3]; b[3] = p[0] + p[3]; b[4] = cs_max(p[4], p[5]); b[5] = p[2] + p[3]; break;
+    case YCGE_PRIM_TRIANGLE:
+        for (int a = 0; a < 3; a++) {
+            b[a] = cs_min(p[a], cs_min(p[3 + a], p[6 + a])) - eps;
+            b[3 + a] = cs_max(p[a], cs_max(p[3 + a], p[6 + a])) + eps;
+        }
+        break;
+    case YCGE_PRIM_MESH: {
+        const BuiltTree &t = meshes[q.ref].tree;
+        if (t.root < 0) return false;
+        const RefNode &r = t.nodes[t.root];
+        for (int a = 0; a < 3; a++) { b[a] = r.mn[a]; b[3 + a] = r.mx[a]; }
+        break;
+    }
+    case YCGE_PRIM_VOLUME_GRID: {
+        const ycge_grid &g = s->grids[q.ref];
+        if (g.nx <= 0 || g.ny <= 0 || g.nz <= 0) return false;
+        const float vs[3] = {cs_max(1e-6f, g.voxel_size.x), cs_max(1e-6f, g.voxel_size.y), cs_max(1e-6f, g.voxel_size.z)};
+        b[0] = g.min_corner.x; b[1] = g.min_corner.y; b[2] = g.min_corner.z;
+        b[3] = g.min_corner.x + (float)g.nx * vs[0]; b[4] = g.min_corner.y + (float)g.ny * vs[1]; b[5] = g.min_corner.z + (float)g.nz * vs[2];
+        break;
+    }
+    default: return false;
+    }
+    if (from_box) for (int a = 0; a < 3; a++) cen[a] = 0.5f * (b[a] + b[3 + a]);
+    return true;
+}
+
+int morton3(int x, int y, int z)
+{
+    return ((x & 1) << 0) | ((y & 1) << 1) | ((z & 1) << 2) | ((x & 2) << 2) | ((y & 2) << 3) | ((z & 2) << 4) | ((x & 4) << 4) | ((y & 4) << 5) | ((z & 4) << 6);
+}
+
+} // namespace
+
+// =========================================================================== C-ABI
+extern "C" {
+
+int ycge_config_default(ycge_config *cfg)
+{
+    if (!cfg) return YCGE_ERR_INVALID_ARG;
+    std::memset(cfg, 0, sizeof *cfg);
+    cfg->abi_version = YCGE_ABI_VERSION;
+    cfg->fb_width = 80; cfg->fb_height = 45; cfg->super_sample = 1;
+    cfg->fov_deg = 45.0f;
+    cfg->device = 0; cfg->rank = 0; cfg->world_size = 1;
+    cfg->diffuse_bounces = 1; cfg->max_mirror_bounces = 2; cfg->max_refractions = 2;
+    cfg->mirror_threshold = 0.9f; cfg->eps = 1e-4f;
+    cfg->seed_salt = 0x9E3779B97F4A7C15ULL;
+    cfg->taa_alpha = 0.01f; cfg->motion_trans_reset = 0.0025f; cfg->motion_rot_reset = 0.0025f;
+    cfg->diffuse_sigma_deg = 25.0f;
+    cfg->taa_clamp_radius = 1; cfg->taa_luminance_pad = 0.10f;
+    cfg->atrous_iterations = 3; cfg->atrous_c_phi = 3.0f; cfg->atrous_n_phi = 0.35f; cfg->atrous_z_phi = 2.0f; cfg->atrous_a_phi = 0.20f;
+    return YCGE_OK;
+}
+
+int ycge_create(const ycge_config *cfg, ycge_ctx **out)
+{
+    if (!cfg || !out) { g_create_error = "null argument"; return YCGE_ERR_INVALID_ARG; }
+    *out = nullptr;
+    if (cfg->abi_version != YCGE_ABI_VERSION) { g_create_error = "abi_version mismatch"; return YCGE_ERR_INVALID_ARG; }
+    if (cfg->world_size < 1 || cfg->rank < 0 || cfg->rank >= cfg->world_size) { g_create_error = "bad rank/world_size"; return YCGE_ERR_INVALID_ARG; }
+    // the kernels implement the reference's compile-time constants (RaytraceRenderer.cs:31-36)
+    if (cfg->diffuse_bounces != 1 || cfg->max_mirror_bounces != 2 || cfg->max_refractions != 2 || cfg->taa_clamp_radius < 0) {
+        g_create_error = "DiffuseBounces/MaxMirrorBounces/MaxRefractions are compile-time constants in the reference (1/2/2)";
+        return YCGE_ERR_UNSUPPORTED;
+    }
+    int n_dev = 0;
+    hipError_t e = hipGetDeviceCount(&n_dev);
+    if (e != hipSuccess || n_dev <= 0) {
+        g_create_error = "no HIP device: the ray-trace path has no CPU fallback";
+        return YCGE_ERR_NO_DEVICE_CODE;
+    }
+    if (cfg->device < 0 || cfg->device >= n_dev) { g_create_error = "device ordinal out of range"; return YCGE_ERR_INVALID_ARG; }
+    ycge_ctx *c = new ycge_ctx();
+    c->cfg = *cfg;
+    c->device = cfg->device;
+    c->fov_deg = cfg->fov_deg;
+    auto bail = [&](int code) { g_create_error = c->err; ycge_destroy(c); return code; };
+    if (hipSetDevice(c->device) != hipSuccess) { c->err = "hipSetDevice failed"; return bail(YCGE_ERR_DEVICE); }
+    hipDeviceProp_t prop;
+    if (hipGetDeviceProperties(&prop, c->device) != hipSuccess) { c->err = "hipGetDeviceProperties failed"; return bail(YCGE_ERR_DEVICE); }
+    std::snprintf(c->device_name, sizeof c->device_name, "%s (%s)", prop.name, prop.gcnArchName);
+    c->compute_units = prop.multiProcessorCount;
+    if (std::strncmp(prop.gcnArchName, "gfx950", 6) != 0) {
+        c->err = std::string("device is ") + prop.gcnArchName + "; this library carries gfx950 code only";
+        return bail(YCGE_ERR_NO_DEVICE_CODE);
+    }
+    if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess) { c->err = "hipStreamCreate failed"; return bail(YCGE_ERR_DEVICE); }
+    for (auto &ev : c->ev)
+        if (hipEventCreate(&ev) != hipSuccess) { c->err = "hipEventCreate failed"; return bail(YCGE_ERR_DEVICE); }
+    int rc = set_geometry(c, cfg->fb_width, cfg->fb_height, cfg->super_sample);
+    if (rc != YCGE_OK) return bail(rc);
+    *out = c;
+    return YCGE_OK;
+}
+
+void ycge_destroy(ycge_ctx *c)
+{
+    if (!c) return;
+    (void)hipSetDevice(c->device);
+    c->current_hdr.release(); c->g_albedo.release(); c->g_normal.release(); c->g_depth.release(); c->taa_hist.release();
+    c->prev_normal.release(); c->prev_depth.release(); c->sky.release(); c->prev_sky.release();
+    c->dbg_rays.release(); c->dbg_hit_t.release(); c->dbg_prim.release(); c->dbg_sub.release(); c->dbg_rng.release();
+    c->counters.release(); c->own_slab.release();
+    c->d_scene_nodes.release(); c->d_mesh_nodes.release(); c->d_scene_leaf.release(); c->d_tris.release(); c->d_prims.release();
+    c->d_materials.release(); c->d_meshes.release(); c->d_grids.release(); c->d_cells.release(); c->d_lut.release(); c->d_lights.release();
+    for (auto &ev : c->ev) if (ev) (void)hipEventDestroy(ev);
+    if (c->stream) (void)hipStreamDestroy(c->stream);
+    delete c;
+}
+
+const char *ycge_last_error(const ycge_ctx *c) { return c ? c->err.c_str() : g_create_error.c_str(); }
+
+int ycge_device_info(ycge_ctx *c, char *name, size_t name_bytes, int32_t *compute_units)
+{
+    if (!c) return YCGE_ERR_INVALID_ARG;
+    if (name && name_bytes) { std::strncpy(name, c->device_name, name_bytes - 1); name[name_bytes - 1] = 0; }
+    if (compute_units) *compute_units = c->compute_units;
+    return YCGE_OK;
+}
+
+static int upload_lights(ycge_ctx *c, const ycge_light *lights, int n)
+{
+    std::vector<GLight> L(n);
+    for (int i = 0; i < n; i++) {
+        L[i].pos[0] = lights[i].position.x; L[i].pos[1] = lights[i].position.y; L[i].pos[2] = lights[i].position.z;
+        L[i].color[0] = lights[i].color.x; L[i].color[1] = lights[i].color.y; L[i].color[2] = lights[i].color.z;
+        L[i].intensity = lights[i].intensity; L[i].pad = 0.0f;
+    }
+    HIP_TRY(c, c->d_lights.upload(L));
+    c->sd.lights = c->d_lights.p;
+    c->sd.n_lights = n;
+    return YCGE_OK;
+}
+
+int ycge_scene_upload(ycge_ctx *c, const ycge_scene *s)
+{
+    if (!c) return YCGE_ERR_INVALID_ARG;
+    if (!s) return c->fail(YCGE_ERR_INVALID_ARG, "null scene");
+    if (s->n_prims < 0 || s->n_materials < 0 || s->n_lights < 0 || s->n_meshes < 0 || s->n_grids < 0)
+        return c->fail(YCGE_ERR_INVALID_ARG, "negative count");
+    HIP_TRY(c, hipSetDevice(c->device));
+    c->have_scene = false;
+
+    // ---- materials
+    std::vector<GMaterial> mats(s->n_materials);
+    bool any_transparent = false;
+    for (int i = 0; i < s->n_materials; i++) {
+        const ycge_material &m = s->materials[i];
+        GMaterial &g = mats[i];
+        std::memset(&g, 0, sizeof g);
+        if (m.kind != YCGE_MAT_CONSTANT && m.kind != YCGE_MAT_CHECKER) return c->fail(YCGE_ERR_UNSUPPORTED, "material %d: unknown kind %d", i, m.kind);
+        g.kind = m.kind;
+        g.albedo[0] = m.albedo.x; g.albedo[1] = m.albedo.y; g.albedo[2] = m.albedo.z;
+        g.albedo_b[0] = m.albedo_b.x; g.albedo_b[1] = m.albedo_b.y; g.albedo_b[2] = m.albedo_b.z;
+        g.checker_scale = m.checker_scale;
+        g.reflectivity = m.reflectivity;
+        g.emission[0] = m.emission.x; g.emission[1] = m.emission.y; g.emission[2] = m.emission.z;
+        g.transparency = m.transparency; g.ior = m.index_of_refraction;
+        g.trans_color[0] = m.transmission_color.x; g.trans_color[1] = m.transmission_color.y; g.trans_color[2] = m.transmission_color.z;
+        if (m.transparency > 0.0f) any_transparent = true;
+    }
+    auto mat_ok = [&](int mi) { return mi >= 0 && mi < s->n_materials; };
+
+    // ---- meshes: MeshBVH ctor (MeshBVH.cs:41-130) -> paired nodes + leaf-ordered triangles
+    c->meshes.assign(s->n_meshes, MeshHost{});
+    std::vector<GNode> mesh_nodes;
+    std::vector<GTri> tris;
+    std::vector<GMesh> gmeshes(s->n_meshes);
+    int max_mesh_depth = 0;
+    for (int mi = 0; mi < s->n_meshes; mi++) {
+        const ycge_mesh &m = s->meshes[mi];
+        if (m.n_triangles < 0 || (m.n_triangles > 0 && !m.triangles)) return c->fail(YCGE_ERR_INVALID_ARG, "mesh %d: bad triangle array", mi);
+        if (!m.tri_material && !mat_ok(m.material)) return c->fail(YCGE_ERR_INVALID_ARG, "mesh %d: material out of range", mi);
+        BoundsSoA items;
+        triangle_items(m.triangles, m.n_triangles, items);
+        BuiltTree &t = c->meshes[mi].tree;
+        build_tree(items, TreeFlavour::Mesh, t);
+        if (t.max_depth > 64) return c->fail(YCGE_ERR_STACK_DEPTH, "mesh %d: BVH depth %d exceeds the reference's 64-entry stack (MeshBVH.cs:150)", mi, t.max_depth);
+        if (t.max_depth > max_mesh_depth) max_mesh_depth = t.max_depth;
+        const uint32_t tri_base = (uint32_t)tris.size();
+        if ((uint64_t)tri_base + (uint64_t)m.n_triangles >= (1u << 25)) return c->fail(YCGE_ERR_UNSUPPORTED, "more than 2^25 triangles");
+        GMesh &gm = gmeshes[mi];
+        std::memset(&gm, 0, sizeof gm);
+        gm.root_ref = to_gpu_nodes(t, REF_MESH_NODE, REF_MESH_LEAF, (uint32_t)mesh_nodes.size(), tri_base, 4, mesh_nodes);
+        if (t.root >= 0) for (int a = 0; a < 3; a++) { gm.root_min[a] = t.nodes[t.root].mn[a]; gm.root_max[a] = t.nodes[t.root].mx[a]; }
+        tris.resize(tri_base + t.leaf_index.size());
+        for (size_t k = 0; k < t.leaf_index.size(); k++) {
+            const int32_t ti = t.leaf_index[k];
+            const float *v = m.triangles + 9 * (size_t)ti;
+            GTri &g = tris[tri_base + k];
+            g.ax = v[0]; g.ay = v[1]; g.az = v[2];
+            g.e1x = v[3] - v[0]; g.e1y = v[4] - v[1]; g.e1z = v[5] - v[2];        // MeshBVH.cs:87-91
+            g.e2x = v[6] - v[0]; g.e2y = v[7] - v[1]; g.e2z = v[8] - v[2];
+            g.orig = ti;
+            g.material = m.tri_material ? m.tri_material[ti] : m.material;
+            if (!mat_ok(g.material)) return c->fail(YCGE_ERR_INVALID_ARG, "mesh %d triangle %d: material out of range", mi, ti);
+            g.pad = 0;
+        }
+    }
+
+    // ---- voxel grids: VolumeGrid ctor (VolumeGrid.cs:55-93), one byte per voxel = index into a per-grid material table
+    std::vector<GGrid> ggrids(s->n_grids);
+    std::vector<uint8_t> cells;
+    std::vector<int32_t> lut;
+    for (int gi = 0; gi < s->n_grids; gi++) {
+        const ycge_grid &g = s->grids[gi];
+        if (g.nx <= 0 || g.ny <= 0 || g.nz <= 0 || !g.cells) return c->fail(YCGE_ERR_INVALID_ARG, "grid %d: empty", gi);
+        if ((uint64_t)g.nx * g.ny * g.nz >= (1u << 30)) return c->fail(YCGE_ERR_UNSUPPORTED, "grid %d: more than 2^30 cells", gi);
+        GGrid &G = ggrids[gi];
+        std::memset(&G, 0, sizeof G);
+        G.nx = g.nx; G.ny = g.ny; G.nz = g.nz;
+        G.nbx = (g.nx + 7) >> 3; G.nby = (g.ny + 7) >> 3; G.nbz = (g.nz + 7) >> 3;
+        G.min_corner[0] = g.min_corner.x; G.min_corner[1] = g.min_corner.y; G.min_corner[2] = g.min_corner.z;
+        G.voxel_size[0] = cs_max(1e-6f, g.voxel_size.x); G.voxel_size[1] = cs_max(1e-6f, g.voxel_size.y); G.voxel_size[2] = cs_max(1e-6f, g.voxel_size.z);
+        G.wireframe = g.wireframe ? 1 : 0;
+        float ww = g.wire_width_fraction; if (ww < 0.0f) ww = 0.0f; if (ww > 0.5f) ww = 0.5f;
+        G.wire_width_frac = ww;
+        float wm = g.wire_max_distance; if (wm < 0.0f) wm = 0.0f;
+        G.wire_max_distance = wm;
+        const size_t cap = (size_t)G.nbx * G.nby * G.nbz * 512;
+        const size_t off = (cells.size() + 255) & ~(size_t)255;
+        if (off + cap >= ((size_t)1 << 32)) return c->fail(YCGE_ERR_UNSUPPORTED, "voxel storage exceeds 4 GiB");
+        G.cell_offset = (uint32_t)off;
+        cells.resize(off + cap, 0);
+        G.lut_offset = (uint32_t)lut.size();
+        // code 0 = empty; codes 1.. = distinct (matId, metaId) pairs in first-seen order
+        std::vector<std::pair<int32_t, int32_t>> seen;
+        lut.push_back(-1);
+        for (int iz = 0; iz < g.nz; iz++)
+            for (int iy = 0; iy < g.ny; iy++)
+                for (int ix = 0; ix < g.nx; ix++) {
+                    const size_t src = ((size_t)ix * g.ny + iy) * g.nz + iz;
+                    const int32_t mat = g.cells[2 * src], meta = g.cells[2 * src + 1];
+                    if (mat <= 0) continue;
+                    int code = -1;
+                    for (size_t k = 0; k < seen.size(); k++) if (seen[k].first == mat && seen[k].second == meta) { code = (int)k + 1; break; }
+                    if (code < 0) {
+                        if (seen.size() >= 255) return c->fail(YCGE_ERR_UNSUPPORTED, "grid %d: more than 255 distinct (matId, metaId) pairs", gi);
+                        int material = g.default_material;
+                        for (int k = 0; k < g.n_lookup; k++) if (g.lookup[k].mat_id == mat && g.lookup[k].meta_id == meta) { material = g.lookup[k].material; break; }
+                        if (!mat_ok(material)) return c->fail(YCGE_ERR_INVALID_ARG, "grid %d: no material for (matId %d, metaId %d)", gi, mat, meta);
+                        seen.push_back({mat, meta});
+                        lut.push_back(material);
+                        code = (int)seen.size();
+                    }
+                    const int brick = (((iz >> 3) * G.nby) + (iy >> 3)) * G.nbx + (ix >> 3);
+                    cells[off + (size_t)brick * 512 + morton3(ix & 7, iy & 7, iz & 7)] = (uint8_t)code;
+                }
+    }
+
+    // ---- Scene.Objects -> device prim records + scene BVH (BVH ctor, BVH.cs:29-97)
+    std::vector<GPrim> gprims(s->n_prims);
+    BoundsSoA items;
+    items.resize(s->n_prims);
+    for (int i = 0; i < s->n_prims; i++) {
+        const ycge_prim &q = s->prims[i];
+        GPrim &g = gprims[i];
+        std::memset(&g, 0, sizeof g);
+        g.type = q.type; g.material = q.material; g.ref = q.ref; g.reflectivity = q.reflectivity;
+        const float *p = q.p;
+        switch (q.type) {
+        case YCGE_PRIM_SPHERE: for (int k = 0; k < 4; k++) g.p[k] = p[k]; break;
+        case YCGE_PRIM_PLANE: {      // Plane ctor, Surfaces.cs:19-28
+            H3 n = h_norm(H3{p[3], p[4], p[5]});
+            g.p[0] = n.x; g.p[1] = n.y; g.p[2] = n.z;
+            g.p[3] = n.x * p[0] + n.y * p[1] + n.z * p[2];
+            break;
+        }
+        case YCGE_PRIM_DISK: {       // Disk ctor, Surfaces.cs:84-94
+            H3 n = h_norm(H3{p[3], p[4], p[5]});
+            g.p[0] = p[0]; g.p[1] = p[1]; g.p[2] = p[2]; g.p[3] = n.x; g.p[4] = n.y; g.p[5] = n.z;
+            g.p[6] = p[6] * p[6];
+            g.p[7] = n.x * p[0] + n.y * p[1] + n.z * p[2];
+            break;
+        }
+        case YCGE_PRIM_XYRECT: case YCGE_PRIM_XZRECT: case YCGE_PRIM_YZRECT: for (int k = 0; k < 5; k++) g.p[k] = p[k]; break;
+        case YCGE_PRIM_BOX: for (int k = 0; k < 6; k++) g.p[k] = p[k]; break;
+        case YCGE_PRIM_CYLINDER_Y:   // CylinderY ctor, BoundedObjects.cs:128-137
+            g.p[0] = p[0]; g.p[1] = p[2]; g.p[2] = p[3]; g.p[3] = p[3] * p[3];
+            g.p[4] = cs_min(p[4], p[5]); g.p[5] = cs_max(p[4], p[5]); g.p[6] = p[6];
+            break;
+        case YCGE_PRIM_TRIANGLE: {   // Triangle ctor, Triangle.cs:36-45
+            float e1x = p[3] - p[0], e1y = p[4] - p[1], e1z = p[5] - p[2];
+            float e2x = p[6] - p[0], e2y = p[7] - p[1], e2z = p[8] - p[2];
+            float nnx = e1y * e2z - e1z * e2y, nny = e1z * e2x - e1x * e2z, nnz = e1x * e2y - e1y * e2x;
+            float inv_len = 1.0f / cs_max(1e-20f, cs_sqrt(nnx * nnx + nny * nny + nnz * nnz));
+            g.p[0] = p[0]; g.p[1] = p[1]; g.p[2] = p[2];
+            g.p[3] = e1x; g.p[4] = e1y; g.p[5] = e1z; g.p[6] = e2x; g.p[7] = e2y; g.p[8] = e2z;
+            g.p[9] = nnx * inv_len; g.p[10] = nny * inv_len; g.p[11] = nnz * inv_len;
+            break;
+        }
+        case YCGE_PRIM_MESH:
+            if (q.ref < 0 || q.ref >= s->n_meshes) return c->fail(YCGE_ERR_INVALID_ARG, "prim %d: mesh ref out of range", i);
+            break;
+        case YCGE_PRIM_VOLUME_GRID:
+            if (q.ref < 0 || q.ref >= s->n_grids) return c->fail(YCGE_ERR_INVALID_ARG, "prim %d: grid ref out of range", i);
+            break;
+        default: return c->fail(YCGE_ERR_INVALID_ARG, "prim %d: unknown type %d", i, q.type);
+        }
+        if (q.type != YCGE_PRIM_MESH && q.type != YCGE_PRIM_VOLUME_GRID && !mat_ok(q.material))
+            return c->fail(YCGE_ERR_INVALID_ARG, "prim %d: material out of range", i);
+        float b[6], cen[3];
+        if (!prim_bounds(q, c->meshes, s, b, cen)) return c->fail(YCGE_ERR_INVALID_ARG, "Unbounded Hittable (prim %d)", i);   // BVH.cs:37-40
+        for (int a = 0; a < 3; a++) { items.mn[a][i] = b[a]; items.mx[a][i] = b[3 + a]; items.c[a][i] = cen[a]; }
+    }
+    build_tree(items, TreeFlavour::Scene, c->scene_tree);
+    if (c->scene_tree.max_depth > 128) return c->fail(YCGE_ERR_STACK_DEPTH, "scene BVH depth %d exceeds the reference's 128-entry stack (BVH.cs:118)", c->scene_tree.max_depth);
+    if (c->scene_tree.max_depth + 4 + max_mesh_depth + 2 > YCGE_TRAVERSAL_STACK)
+        return c->fail(YCGE_ERR_STACK_DEPTH, "combined traversal depth %d + %d exceeds the device stack", c->scene_tree.max_depth, max_mesh_depth);
+    std::vector<GNode> scene_nodes;
+    const uint32_t scene_root = to_gpu_nodes(c->scene_tree, REF_SCENE_NODE, REF_SCENE_LEAF, 0, 0, 3, scene_nodes);
+    std::vector<uint32_t> leaf_prims(c->scene_tree.leaf_index.begin(), c->scene_tree.leaf_index.end());
+
+    // ---- upload
+    HIP_TRY(c, c->d_materials.upload(mats)); HIP_TRY(c, c->d_mesh_nodes.upload(mesh_nodes)); HIP_TRY(c, c->d_tris.upload(tris));
+    HIP_TRY(c, c->d_meshes.upload(gmeshes)); HIP_TRY(c, c->d_grids.upload(ggrids)); HIP_TRY(c, c->d_cells.upload(cells));
+    HIP_TRY(c, c->d_lut.upload(lut)); HIP_TRY(c, c->d_prims.upload(gprims)); HIP_TRY(c, c->d_scene_nodes.upload(scene_nodes));
+    HIP_TRY(c, c->d_scene_leaf.upload(leaf_prims));
+    SceneDev &sd = c->sd;
+    std::memset(&sd, 0, sizeof sd);
+    sd.scene_nodes = c->d_scene_nodes.p; sd.scene_leaf_prims = c->d_scene_leaf.p; sd.mesh_nodes = c->d_mesh_nodes.p; sd.tris = c->d_tris.p;
+    sd.prims = c->d_prims.p; sd.materials = c->d_materials.p; sd.meshes = c->d_meshes.p; sd.grids = c->d_grids.p;
+    sd.grid_cells = c->d_cells.p; sd.grid_lut = c->d_lut.p;
+    sd.scene_root_ref = scene_root;
+    if (c->scene_tree.root >= 0)
+        for (int a = 0; a < 3; a++) { sd.scene_root_min[a] = c->scene_tree.nodes[c->scene_tree.root].mn[a]; sd.scene_root_max[a] = c->scene_tree.nodes[c->scene_tree.root].mx[a]; }
+    sd.ambient[0] = s->ambient_color.x; sd.ambient[1] = s->ambient_color.y; sd.ambient[2] = s->ambient_color.z;
+    sd.ambient_intensity = s->ambient_intensity;
+    sd.bg_top[0] = s->background_top.x; sd.bg_top[1] = s->background_top.y; sd.bg_top[2] = s->background_top.z;
+    sd.bg_bottom[0] = s->background_bottom.x; sd.bg_bottom[1] = s->background_bottom.y; sd.bg_bottom[2] = s->background_bottom.z;
+    sd.is_volume_scene = s->is_volume_scene ? 1 : 0;
+    sd.any_transparent = any_transparent ? 1 : 0;
+    int rc = upload_lights(c, s->lights, s->n_lights);
+    if (rc != YCGE_OK) return rc;
+    c->have_scene = true;
+    return YCGE_OK;
+}
+
+int ycge_scene_update_lights(ycge_ctx *c, const ycge_light *lights, int32_t n_lights, const ycge_vec3 *ambient_color,
+                             float ambient_intensity, const ycge_vec3 *top, const ycge_vec3 *bottom)
+{
+    if (!c) return YCGE_ERR_INVALID_ARG;
+    if (!c->have_scene) return c->fail(YCGE_ERR_NO_SCENE, "no scene uploaded");
+    if (n_lights < 0 || (n_lights > 0 && !lights)) return c->fail(YCGE_ERR_INVALID_ARG, "bad light array");
+    HIP_TRY(c, hipSetDevice(c->device));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    int rc = upload_lights(c, lights, n_lights);
+    if (rc != YCGE_OK) return rc;
+    if (ambient_color) { c->sd.ambient[0] = ambient_color->x; c->sd.ambient[1] = ambient_color->y; c->sd.ambient[2] = ambient_color->z; c->sd.ambient_intensity = ambient_intensity; }
+    if (top) { c->sd.bg_top[0] = top->x; c->sd.bg_top[1] = top->y; c->sd.bg_top[2] = top->z; }
+    if (bottom) { c->sd.bg_bottom[0] = bottom->x; c->sd.bg_bottom[1] = bottom->y; c->sd.bg_bottom[2] = bottom->z; }
+    return YCGE_OK;
+}
+
+int ycge_resize(ycge_ctx *c, int32_t fbw, int32_t fbh, int32_t ss)
+{
+    if (!c) return YCGE_ERR_INVALID_ARG;
+    HIP_TRY(c, hipSetDevice(c->device));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    return set_geometry(c, fbw, fbh, ss);
+}
+
+int ycge_set_camera(ycge_ctx *c, const float pos[3], float yaw, float pitch, float fov_deg)
+{
+    if (!c) return YCGE_ERR_INVALID_ARG;
+    if (!pos) return c->fail(YCGE_ERR_INVALID_ARG, "null position");
+    std::lock_guard<std::mutex> g(c->cam_lock);
+    c->cam_pos[0] = pos[0]; c->cam_pos[1] = pos[1]; c->cam_pos[2] = pos[2];
+    c->yaw = yaw; c->pitch = pitch; c->fov_deg = fov_deg;
+    return YCGE_OK;
+}
+
+int ycge_set_frame_counter(ycge_ctx *c, int64_t fc)
+{
+    if (!c) return YCGE_ERR_INVALID_ARG;
+    c->frame_counter = fc;
+    return YCGE_OK;
+}
+
+int ycge_tile_slab_bytes(const ycge_ctx *c, size_t *bytes)
+{
+    if (!c || !bytes) return YCGE_ERR_INVALID_ARG;
+    *bytes = (size_t)c->tiles_per_rank_padded * 256 * YCGE_SLAB_FLOATS * sizeof(float);
+    return YCGE_OK;
+}
+
+} // extern "C"
+
+namespace {
+
+struct FrameState {
+    float pos[3], yaw, pitch, fov;
+    bool reset;
+    int64_t frame;
+};
+
+// steps 1-4 of TryFlipAndBlit (RaytraceRenderer.cs:159-216): snapshot, frame++, ray-gen + trace
+int begin_and_trace(ycge_ctx *c, float *d_slab, hipStream_t stream, FrameState &fs, bool timed)
+{
+    if (!c->have_scene) return c->fail(YCGE_ERR_NO_SCENE, "Scene BVH not built; call ycge_scene_upload first (Scene.cs:73)");
+    {
+        std::lock_guard<std::mutex> g(c->cam_lock);
+        fs.pos[0] = c->cam_pos[0]; fs.pos[1] = c->cam_pos[1]; fs.pos[2] = c->cam_pos[2];
+        fs.yaw = c->yaw; fs.pitch = c->pitch; fs.fov = c->fov_deg;
+    }
+    fs.reset = should_reset_history(c, fs.pos, fs.yaw, fs.pitch);
+    fs.frame = ++c->frame_counter;
+    FrameParams P;
+    fill_frame_params(c, P, fs.frame, fs.pos, fs.yaw, fs.pitch, fs.fov);
+    TraceOut O;
+    std::memset(&O, 0, sizeof O);
+    O.current_hdr = c->current_hdr.p; O.g_albedo = c->g_albedo.p; O.g_normal = c->g_normal.p; O.g_depth = c->g_depth.p; O.sky = c->sky.p;
+    O.slab = d_slab;
+    const bool slab = d_slab != nullptr;
+    const bool debug = c->cfg.capture_debug && !slab;
+    if (debug) { O.rays = c->dbg_rays.p; O.prim_id = c->dbg_prim.p; O.sub_id = c->dbg_sub.p; O.hit_t = c->dbg_hit_t.p; O.rng_state = c->dbg_rng.p; }
+    if (c->cfg.count_work) {
+        O.counters = c->counters.p;
+        HIP_TRY(c, hipMemsetAsync(c->counters.p, 0, 8 * sizeof(unsigned long long), stream));
+    }
+    if (timed) HIP_TRY(c, hipEventRecord(c->ev[0], stream));
+    int e = ycge_launch_trace(&c->sd, &P, &O, c->cfg.count_work, debug ? 1 : 0, slab ? 1 : 0, stream);
+    if (e != 0) return c->fail(YCGE_ERR_DEVICE, "k_trace launch failed: %s", hipGetErrorString((hipError_t)e));
+    if (timed) HIP_TRY(c, hipEventRecord(c->ev[1], stream));
+    return YCGE_OK;
+}
+
+// steps 5 and 9: TemporalBlendWithClamp + CommitCamera
+int taa_and_commit(ycge_ctx *c, hipStream_t stream, const FrameState &fs, bool &did_reset, bool timed)
+{
+    TaaParams T;
+    T.w = c->hiW; T.h = c->hiH;
+    T.alpha = cs_max(0.0f, cs_min(1.0f, c->cfg.taa_alpha));      // :305
+    T.radius = c->cfg.taa_clamp_radius > 0 ? c->cfg.taa_clamp_radius : 0;
+    T.pad_lum = c->cfg.taa_luminance_pad;
+    did_reset = !c->taa_valid || fs.reset;                        // :285
+    T.reset = did_reset ? 1 : 0;
+    int e = ycge_launch_taa(&T, c->current_hdr.p, c->g_normal.p, c->g_depth.p, c->sky.p, c->taa_hist.p, c->prev_normal.p, c->prev_depth.p,
+                            c->prev_sky.p, stream);
+    if (e != 0) return c->fail(YCGE_ERR_DEVICE, "k_taa launch failed: %s", hipGetErrorString((hipError_t)e));
+    if (timed) HIP_TRY(c, hipEventRecord(c->ev[2], stream));
+    c->taa_valid = true;
+    c->last_cam[0] = fs.pos[0]; c->last_cam[1] = fs.pos[1]; c->last_cam[2] = fs.pos[2]; c->last_yaw = fs.yaw; c->last_pitch = fs.pitch;   // :266
+    return YCGE_OK;
+}
+
+int fill_stats(ycge_ctx *c, ycge_frame_stats *st, const FrameState &fs, bool did_reset, bool have_taa, double wall_ms)
+{
+    if (!st) return YCGE_OK;
+    std::memset(st, 0, sizeof *st);
+    st->frame = fs.frame;
+    st->history_reset = did_reset ? 1 : 0;
+    float ms = 0.0f;
+    HIP_TRY(c, hipEventElapsedTime(&ms, c->ev[0], c->ev[1]));
+    st->trace_ms = ms;
+    if (have_taa) { HIP_TRY(c, hipEventElapsedTime(&ms, c->ev[1], c->ev[2])); st->taa_ms = ms; }
+    st->total_ms = wall_ms;
+    if (c->cfg.count_work) {
+        unsigned long long h[8];
+        HIP_TRY(c, hipMemcpy(h, c->counters.p, sizeof h, hipMemcpyDeviceToHost));
+        st->n_rays = h[0]; st->n_box = h[1]; st->n_tri = h[2]; st->n_prim = h[3]; st->n_vox = h[4];
+    }
+    st->exposure = 1.0f;
+    return YCGE_OK;
+}
+
+} // namespace
+
+extern "C" {
+
+int ycge_render_frame(ycge_ctx *c, float *out_sdr, ycge_frame_stats *st)
+{
+    if (!c) return YCGE_ERR_INVALID_ARG;
+    if (c->cfg.world_size != 1) return c->fail(YCGE_ERR_INVALID_ARG, "ycge_render_frame is the single-GPU entry; with world_size > 1 use ycge_trace_tiles + ycge_resolve_gathered");
+    if (out_sdr) return c->fail(YCGE_ERR_UNSUPPORTED, "denoise/tonemap stage (SURVEY 8-f1) is not built yet: pass NULL and read YCGE_BUF_TAA_HISTORY");
+    HIP_TRY(c, hipSetDevice(c->device));
+    auto t0 = std::chrono::steady_clock::now();
+    FrameState fs;
+    int rc = begin_and_trace(c, nullptr, c->stream, fs, true);
+    if (rc != YCGE_OK) return rc;
+    bool did_reset = false;
+    rc = taa_and_commit(c, c->stream, fs, did_reset, true);
+    if (rc != YCGE_OK) return rc;
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    double wall = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+    return fill_stats(c, st, fs, did_reset, true, wall);
+}
+
+int ycge_trace_tiles(ycge_ctx *c, void *d_slab, void *hip_stream, ycge_frame_stats *st)
+{
+    if (!c) return YCGE_ERR_INVALID_ARG;
+    HIP_TRY(c, hipSetDevice(c->device));
+    hipStream_t stream = hip_stream ? (hipStream_t)hip_stream : c->stream;
+    float *slab = d_slab ? (float *)d_slab : c->own_slab.p;
+    if (!slab) return c->fail(YCGE_ERR_INVALID_ARG, "no slab: pass a device pointer of ycge_tile_slab_bytes() bytes");
+    auto t0 = std::chrono::steady_clock::now();
+    FrameState fs;
+    int rc = begin_and_trace(c, slab, stream, fs, st != nullptr);
+    if (rc != YCGE_OK) return rc;
+    if (st) {
+        HIP_TRY(c, hipStreamSynchronize(stream));
+        double wall = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+        return fill_stats(c, st, fs, false, false, wall);
+    }
+    return YCGE_OK;
+}
+
+int ycge_resolve_gathered(ycge_ctx *c, const void *d_all_slabs, void *hip_stream, float *out_sdr, ycge_frame_stats *st)
+{
+    if (!c) return YCGE_ERR_INVALID_ARG;
+    if (!d_all_slabs) return c->fail(YCGE_ERR_INVALID_ARG, "null gathered slabs");
+    if (out_sdr) return c->fail(YCGE_ERR_UNSUPPORTED, "denoise/tonemap stage (SURVEY 8-f1) is not built yet");
+    HIP_TRY(c, hipSetDevice(c->device));
+    hipStream_t stream = hip_stream ? (hipStream_t)hip_stream : c->stream;
+    auto t0 = std::chrono::steady_clock::now();
+    const size_t per_rank = (size_t)c->tiles_per_rank_padded * 256 * YCGE_SLAB_FLOATS;
+    if (st) HIP_TRY(c, hipEventRecord(c->ev[1], stream));
+    int e = ycge_launch_unpermute((const float *)d_all_slabs, per_rank, c->hiW, c->hiH, c->tiles_x, c->n_tiles, c->cfg.world_size,
+                                  c->current_hdr.p, c->g_albedo.p, c->g_normal.p, c->g_depth.p, c->sky.p, stream);
+    if (e != 0) return c->fail(YCGE_ERR_DEVICE, "k_unpermute launch failed: %s", hipGetErrorString((hipError_t)e));
+    FrameState fs;
+    {
+        std::lock_guard<std::mutex> g(c->cam_lock);
+        fs.pos[0] = c->cam_pos[0]; fs.pos[1] = c->cam_pos[1]; fs.pos[2] = c->cam_pos[2]; fs.yaw = c->yaw; fs.pitch = c->pitch; fs.fov = c->fov_deg;
+    }
+    fs.reset = should_reset_history(c, fs.pos, fs.yaw, fs.pitch);
+    fs.frame = c->frame_counter;
+    bool did_reset = false;
+    int rc = taa_and_commit(c, stream, fs, did_reset, st != nullptr);
+    if (rc != YCGE_OK) return rc;
+    if (st) {
+        HIP_TRY(c, hipStreamSynchronize(stream));
+        std::memset(st, 0, sizeof *st);
+        st->frame = fs.frame; st->history_reset = did_reset ? 1 : 0;
+        float ms = 0.0f;
+        HIP_TRY(c, hipEventElapsedTime(&ms, c->ev[1], c->ev[2]));
+        st->taa_ms = ms;
+        st->total_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+        st->exposure = 1.0f;
+    }
+    return YCGE_OK;
+}
+
+int ycge_read_buffer(ycge_ctx *c, int32_t which, void *dst, size_t bytes)
+{
+    if (!c) return YCGE_ERR_INVALID_ARG;
+    if (!dst) return c->fail(YCGE_ERR_INVALID_ARG, "null destination");
+    HIP_TRY(c, hipSetDevice(c->device));
+    const size_t n = (size_t)c->hiW * c->hiH;
+    const void *src = nullptr; size_t want = 0;
+    switch (which) {
+    case YCGE_BUF_RAYS: src = c->dbg_rays.p; want = n * 24; break;
+    case YCGE_BUF_PRIM_ID: src = c->dbg_prim.p; want = n * 4; break;
+    case YCGE_BUF_SUB_ID: src = c->dbg_sub.p; want = n * 4; break;
+    case YCGE_BUF_HIT_T: src = c->dbg_hit_t.p; want = n * 4; break;
+    case YCGE_BUF_RNG_STATE: src = c->dbg_rng.p; want = n * 8; break;
+    case YCGE_BUF_CURRENT_HDR: src = c->current_hdr.p; want = n * 12; break;
+    case YCGE_BUF_G_ALBEDO: src = c->g_albedo.p; want = n * 12; break;
+    case YCGE_BUF_G_NORMAL: src = c->g_normal.p; want = n * 12; break;
+    case YCGE_BUF_G_DEPTH: src = c->g_depth.p; want = n * 4; break;
+    case YCGE_BUF_SKY_MASK: src = c->sky.p; want = n; break;
+    case YCGE_BUF_TAA_HISTORY: src = c->taa_hist.p; want = n * 12; break;
+    case YCGE_BUF_PREV_NORMAL: src = c->prev_normal.p; want = n * 12; break;
+    case YCGE_BUF_PREV_DEPTH: src = c->prev_depth.p; want = n * 4; break;
+    case YCGE_BUF_PREV_SKY: src = c->prev_sky.p; want = n; break;
+    case YCGE_BUF_DENOISED: return c->fail(YCGE_ERR_UNSUPPORTED, "denoise stage not built yet");
+    default: return c->fail(YCGE_ERR_INVALID_ARG, "unknown buffer %d", which);
+    }
+    if (!src) return c->fail(YCGE_ERR_INVALID_ARG, "buffer %d needs config.capture_debug", which);
+    if (bytes != want) return c->fail(YCGE_ERR_INVALID_ARG, "buffer %d is %zu bytes, caller passed %zu", which, want, bytes);
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    HIP_TRY(c, hipMemcpy(dst, src, want, hipMemcpyDeviceToHost));
+    return YCGE_OK;
+}
+
+static int accel_view(ycge_ctx *c, int32_t which, int32_t index, const void **p, size_t *n)
+{
+    switch (which) {
+    case YCGE_ACCEL_SCENE_NODES: *p = c->scene_tree.nodes.data(); *n = c->scene_tree.nodes.size() * sizeof(RefNode); return 0;
+    case YCGE_ACCEL_SCENE_LEAF_INDEX: *p = c->scene_tree.leaf_index.data(); *n = c->scene_tree.leaf_index.size() * 4; return 0;
+    case YCGE_ACCEL_MESH_NODES:
+        if (index < 0 || index >= (int)c->meshes.size()) return -1;
+        *p = c->meshes[index].tree.nodes.data(); *n = c->meshes[index].tree.nodes.size() * sizeof(RefNode); return 0;
+    case YCGE_ACCEL_MESH_LEAF_INDEX:
+        if (index < 0 || index >= (int)c->meshes.size()) return -1;
+        *p = c->meshes[index].tree.leaf_index.data(); *n = c->meshes[index].tree.leaf_index.size() * 4; return 0;
+    }
+    return -1;
+}
+int ycge_accel_size(ycge_ctx *c, int32_t which, int32_t index, size_t *bytes)
+{
+    const void *p; size_t n;
+    if (!c || !bytes) return YCGE_ERR_INVALID_ARG;
+    if (!c->have_scene) return c->fail(YCGE_ERR_NO_SCENE, "no scene uploaded");
+    if (accel_view(c, which, index, &p, &n)) return c->fail(YCGE_ERR_INVALID_ARG, "bad accel selector");
+    *bytes = n;
+    return YCGE_OK;
+}
+int ycge_read_accel(ycge_ctx *c, int32_t which, int32_t index, void *dst, size_t bytes)
+{
+    const void *p; size_t n;
+    if (!c || !dst) return YCGE_ERR_INVALID_ARG;
+    if (!c->have_scene) return c->fail(YCGE_ERR_NO_SCENE, "no scene uploaded");
+    if (accel_view(c, which, index, &p, &n) || n != bytes) return c->fail(YCGE_ERR_INVALID_ARG, "bad accel selector or size");
+    std::memcpy(dst, p, n);
+    return YCGE_OK;
+}
+
+// ---- host-only helpers exported for the `-m "not gpu"` tests (no device needed) -------------
+// Build a tree over caller-supplied boxes with the product builder: bounds = n*6 (min xyz, max xyz),
+// centroids = n*3.  flavour 0 = scene, 1 = mesh.  Outputs are malloc'ed by the caller:
+// nodes_out must hold 2*n records of 10 x 4 B, leaf_out n int32.  Returns node count or <0.
+int ycge_host_build_tree(const float *bounds, const float *centroids, int32_t n, int32_t flavour, void *nodes_out, int32_t *leaf_out,
+                         int32_t *stats_out /* [root, max_depth, sort_fallbacks] */)
+{
+    if (n < 0 || (n > 0 && (!bounds || !centroids || !nodes_out || !leaf_out))) return YCGE_ERR_INVALID_ARG;
+    BoundsSoA it;
+    it.resize(n);
+    for (int i = 0; i < n; i++)
+        for (int a = 0; a < 3; a++) { it.mn[a][i] = bounds[6 * i + a]; it.mx[a][i] = bounds[6 * i + 3 + a]; it.c[a][i] = centroids[3 * i + a]; }
+    BuiltTree t;
+    build_tree(it, flavour == 0 ? TreeFlavour::Scene : TreeFlavour::Mesh, t);
+    if (!t.nodes.empty()) std::memcpy(nodes_out, t.nodes.data(), t.nodes.size() * sizeof(RefNode));
+    if (!t.leaf_index.empty()) std::memcpy(leaf_out, t.leaf_index.data(), t.leaf_index.size() * 4);
+    if (stats_out) { stats_out[0] = t.root; stats_out[1] = t.max_depth; stats_out[2] = t.sort_fallbacks; }
+    return (int)t.nodes.size();
+}
+// Same for a triangle soup (MeshBVH ctor path incl. TryComputeBounds).
+int ycge_host_build_mesh(const float *tris9, int32_t n, void *nodes_out, int32_t *leaf_out, int32_t *stats_out)
+{
+    if (n < 0 || (n > 0 && (!tris9 || !nodes_out || !leaf_out))) return YCGE_ERR_INVALID_ARG;
+    BoundsSoA it;
+    triangle_items(tris9, n, it);
+    BuiltTree t;
+    build_tree(it, TreeFlavour::Mesh, t);
+    if (!t.nodes.empty()) std::memcpy(nodes_out, t.nodes.data(), t.nodes.size() * sizeof(RefNode));
+    if (!t.leaf_index.empty()) std::memcpy(leaf_out, t.leaf_index.data(), t.leaf_index.size() * 4);
+    if (stats_out) { stats_out[0] = t.root; stats_out[1] = t.max_depth; stats_out[2] = t.sort_fallbacks; }
+    return (int)t.nodes.size();
+}
+// sizeof of each ABI struct, for the ctypes mirror check
+size_t ycge_abi_sizeof(int32_t which)
+{
+    switch (which) {
+    case 0: return sizeof(ycge_vec3); case 1: return sizeof(ycge_material); case 2: return sizeof(ycge_prim); case 3: return sizeof(ycge_mesh);
+    case 4: return sizeof(ycge_voxel_lookup); case 5: return sizeof(ycge_grid); case 6: return sizeof(ycge_light); case 7: return sizeof(ycge_scene);
+    case 8: return sizeof(ycge_config); case 9: return sizeof(ycge_frame_stats);
+    }
+    return 0;
+}
+
+} // extern "C"

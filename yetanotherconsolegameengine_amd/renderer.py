@@ -1,0 +1,150 @@
+"""RaytraceRenderer — host-side mirror of the reference's render entry point.
+
+Same surface as ConsoleGame/RayTracing/RaytraceRenderer.cs (ctor :74, Resize :110,
+SetCamera :140, SetFov :150, TryFlipAndBlit :157), i.e. the IConsoleRenderer seam of
+RaytraceEntity.cs:12-18, implemented by calls through the C-ABI (include/ycge.h) into
+the gfx950 kernels.  No per-pixel work happens in Python and there is no CPU fallback:
+constructing a renderer without the built library or without an MI355X raises.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from typing import Optional
+
+import numpy as np
+
+from . import abi
+from .scene import FlatScene, Scene, flatten
+
+NODE_DTYPE = np.dtype([("min", "<f4", 3), ("max", "<f4", 3), ("left", "<i4"), ("right", "<i4"), ("start", "<i4"), ("count", "<i4")])
+
+
+class RaytraceRenderer:
+    def __init__(self, scene: Scene | FlatScene, fb_width: int, fb_height: int, fovDeg: float = 45.0, superSample: int = 1, *,
+                 cfg: Optional[abi.Config] = None, capture_debug: bool = False, count_work: bool = False, device: int = 0,
+                 rank: int = 0, world_size: int = 1, lib=None):
+        self.L = lib if lib is not None else abi.load_library()
+        c = cfg if cfg is not None else abi.default_config()
+        c.fb_width, c.fb_height, c.super_sample = fb_width, fb_height, max(1, superSample)
+        c.fov_deg = fovDeg
+        c.capture_debug, c.count_work = int(capture_debug), int(count_work)
+        c.device, c.rank, c.world_size = device, rank, world_size
+        self.cfg = c
+        self.ctx = C.c_void_p()
+        rc = self.L.ycge_create(C.byref(c), C.byref(self.ctx))
+        if rc != 0:
+            raise abi.YcgeError(rc, (self.L.ycge_last_error(None) or b"").decode())
+        self._set_dims(fb_width, fb_height, c.super_sample)
+        self._pos, self._yaw, self._pitch, self._fov = (0.0, 1.0, 0.0), 0.0, 0.0, fovDeg
+        self.flat = None
+        self.stats = abi.FrameStats()
+        if scene is not None:
+            self.UploadScene(scene)          # the C# ctor ends with scene.RebuildBVH() (:107)
+
+    # ---------------------------------------------------------------- plumbing
+    def _set_dims(self, w, h, ss):
+        self.fbW, self.fbH, self.ss = w, h, ss
+        self.hiW, self.hiH = w * ss, h * 2 * ss
+
+    def _check(self, rc: int):
+        if rc != 0:
+            raise abi.YcgeError(rc, (self.L.ycge_last_error(self.ctx) or b"").decode())
+
+    def close(self):
+        if getattr(self, "ctx", None):
+            self.L.ycge_destroy(self.ctx)
+            self.ctx = C.c_void_p()
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *a):
+        self.close()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # ---------------------------------------------------------------- reference surface
+    def UploadScene(self, scene: Scene | FlatScene):
+        """scene.RebuildBVH() + upload (RaytraceRenderer.cs:107, RaytraceEntity.cs:244)."""
+        self.flat = scene if isinstance(scene, FlatScene) else flatten(scene)
+        self._check(self.L.ycge_scene_upload(self.ctx, self.flat.byref()))
+
+    def UpdateLights(self, lights, ambient=None, background_top=None, background_bottom=None):
+        arr = (abi.Light * max(1, len(lights)))()
+        for i, l in enumerate(lights):
+            arr[i].position, arr[i].color, arr[i].intensity = abi.Vec3(*l.Position), abi.Vec3(*l.Color), float(l.Intensity)
+        amb = abi.Vec3(*ambient.Color) if ambient is not None else None
+        top = abi.Vec3(*background_top) if background_top is not None else None
+        bot = abi.Vec3(*background_bottom) if background_bottom is not None else None
+        self._check(self.L.ycge_scene_update_lights(
+            self.ctx, arr, len(lights), C.byref(amb) if amb is not None else None,
+            float(ambient.Intensity) if ambient is not None else 0.0,
+            C.byref(top) if top is not None else None, C.byref(bot) if bot is not None else None))
+
+    def Resize(self, fb_width: int, fb_height: int, superSample: int):
+        self._check(self.L.ycge_resize(self.ctx, fb_width, fb_height, superSample))
+        self._set_dims(fb_width, fb_height, max(1, superSample))
+
+    def SetCamera(self, pos, yaw: float, pitch: float):
+        self._pos, self._yaw, self._pitch = tuple(pos), yaw, pitch
+        self._push_camera()
+
+    def SetFov(self, fovDeg: float):
+        self._fov = fovDeg
+        self._push_camera()
+
+    def _push_camera(self):
+        p = (C.c_float * 3)(*self._pos)
+        self._check(self.L.ycge_set_camera(self.ctx, p, self._yaw, self._pitch, self._fov))
+
+    def TryFlipAndBlit(self, want_sdr: bool = False):
+        """One frame.  Returns the fbH x fbW x 2 x 3 SDR array (top, bottom per chexel) when
+        want_sdr, else the frame statistics."""
+        sdr = np.zeros((self.fbH, self.fbW, 2, 3), dtype=np.float32) if want_sdr else None
+        ptr = sdr.ctypes.data_as(C.POINTER(C.c_float)) if want_sdr else None
+        self._check(self.L.ycge_render_frame(self.ctx, ptr, C.byref(self.stats)))
+        return sdr if want_sdr else self.stats
+
+    # ---------------------------------------------------------------- multi-GPU halves
+    def tile_slab_bytes(self) -> int:
+        n = C.c_size_t()
+        self._check(self.L.ycge_tile_slab_bytes(self.ctx, C.byref(n)))
+        return n.value
+
+    def trace_tiles(self, d_slab_ptr: int, stream_ptr: int = 0, want_stats: bool = False):
+        st = C.byref(self.stats) if want_stats else None
+        self._check(self.L.ycge_trace_tiles(self.ctx, C.c_void_p(d_slab_ptr), C.c_void_p(stream_ptr), st))
+
+    def resolve_gathered(self, d_all_slabs_ptr: int, stream_ptr: int = 0, want_stats: bool = False):
+        st = C.byref(self.stats) if want_stats else None
+        self._check(self.L.ycge_resolve_gathered(self.ctx, C.c_void_p(d_all_slabs_ptr), C.c_void_p(stream_ptr), None, st))
+
+    # ---------------------------------------------------------------- tests only
+    def set_frame_counter(self, n: int):
+        self._check(self.L.ycge_set_frame_counter(self.ctx, n))
+
+    def read(self, which: int) -> np.ndarray:
+        dt, n = abi.BUFFER_LAYOUT[which]
+        shape = (self.hiH, self.hiW, n) if n > 1 else (self.hiH, self.hiW)
+        a = np.zeros(shape, dtype=dt)
+        self._check(self.L.ycge_read_buffer(self.ctx, which, a.ctypes.data_as(C.c_void_p), a.nbytes))
+        return a
+
+    def accel(self, which: int, index: int = 0) -> np.ndarray:
+        n = C.c_size_t()
+        self._check(self.L.ycge_accel_size(self.ctx, which, index, C.byref(n)))
+        dt = NODE_DTYPE if which in (abi.ACCEL_SCENE_NODES, abi.ACCEL_MESH_NODES) else np.dtype("<i4")
+        a = np.zeros(n.value // dt.itemsize, dtype=dt)
+        if n.value:
+            self._check(self.L.ycge_read_accel(self.ctx, which, index, a.ctypes.data_as(C.c_void_p), a.nbytes))
+        return a
+
+    def device_info(self):
+        name = C.create_string_buffer(256)
+        cu = C.c_int32()
+        self._check(self.L.ycge_device_info(self.ctx, name, 256, C.byref(cu)))
+        return name.value.decode(), cu.value
