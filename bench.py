@@ -1,0 +1,214 @@
+"""bench.py — headline benchmark of the MI355X ray-trace core (BASELINE.json metric).
+
+    python bench.py --gpus N --steps K --warmup W [--config 4]
+
+A "step" is one frame of the hot path (ray-gen + per-pixel trace + TAA; with N > 1 also the
+RCCL all-gather of the tile slabs and the un-permute) over the configuration BASELINE.json quotes
+the metric on: config 4, the Dragon-class mesh (871,200-triangle procedural stand-in for the
+missing xyzrgb_dragon.obj) at a 1920x1080 trace grid, 1 spp.  Scene, BVH and all per-pixel buffers
+are resident in HBM before the timed region.  Prints ONE JSON line (rank 0).
+
+value   = Mrays/s over ALL rays: calls to Scene.Hit + Scene.Occluded (primary, shadow, bounce) per
+          frame / frame time, whole job (all ranks).  Ray counts are exact: the timed frames are
+          re-run with the counting kernel variant afterwards (same frame numbers, untimed).
+roofline= algorithmic bytes of k_trace per launch (32*N_box + 48*N_tri + 64*N_prim +
+          1*N_vox + 118*pixels, counters from the counting replay) / its mean launch duration from
+          HIP events recorded around the kernel on its own stream inside the timed region.
+cpu_baseline = the oracle (scalar C++ restatement of the reference, all host threads) on a bounded
+          sample of the same workload, rank 0, N = 1 only.  A reported baseline, not the target.
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+from pathlib import Path
+
+ROOT = Path(__file__).resolve().parent
+for p in (str(ROOT), str(ROOT / "tests")):
+    if p not in sys.path:
+        sys.path.insert(0, p)
+
+import numpy as np  # noqa: E402
+
+HBM_PEAK_GBS = 8000.0       # MI355X HBM3E spec peak (MI355X_MICROARCH.md: 8.0 TB/s; ~6.3 TB/s achievable)
+
+
+def algorithmic_bytes(st, pixels):
+    return 32 * st["n_box"] + 48 * st["n_tri"] + 64 * st["n_prim"] + 1 * st["n_vox"] + 118 * pixels
+
+
+def stats_dict(s):
+    return {k: int(getattr(s, k)) for k in ("n_rays", "n_box", "n_tri", "n_prim", "n_vox")}
+
+
+def load_traffic_hint():
+    """HBM bytes per k_trace launch from the committed PMC pass (profiles/), or None."""
+    p = ROOT / "profiles" / "trace_hbm_traffic.json"
+    if p.exists():
+        try:
+            return json.loads(p.read_text()).get("hbm_bytes_per_launch")
+        except Exception:
+            return None
+    return None
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--config", type=int, default=4)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-seconds", type=float, default=12.0)
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus and world > 1:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    multi = world > 1
+
+    import torch
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X: the ray-trace path has no CPU fallback")
+    torch.cuda.set_device(local_rank)
+    if multi:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+
+    from yetanotherconsolegameengine_amd import abi, build, scenes
+    from yetanotherconsolegameengine_amd.renderer import RaytraceRenderer
+    from yetanotherconsolegameengine_amd.scene import flatten
+    if rank == 0:
+        build.build_library()
+    if multi:
+        dist.barrier()
+
+    scene, fbw, fbh, ss, pose = scenes.config_scene(args.config)
+    flat = flatten(scene)
+    hiW, hiH = fbw * ss, fbh * 2 * ss
+    pixels = hiW * hiH
+
+    def make(count):
+        r = RaytraceRenderer(flat, fbw, fbh, pose["fov"], ss, count_work=count, device=local_rank, rank=rank, world_size=world)
+        r.SetCamera(pose["pos"], pose["yaw"], pose["pitch"])
+        return r
+
+    r = make(False)
+    stream = torch.cuda.current_stream()
+    slab = all_slabs = None
+    if multi:
+        nb = r.tile_slab_bytes()
+        slab = torch.empty(nb // 4, dtype=torch.float32, device="cuda")
+        all_slabs = torch.empty(world * (nb // 4), dtype=torch.float32, device="cuda")
+
+    def step(rr, want_stats=False):
+        if not multi:
+            rr.TryFlipAndBlit()
+            return rr.stats.trace_ms
+        rr.trace_tiles(slab.data_ptr(), stream.cuda_stream, want_stats=want_stats)
+        t = rr.stats.trace_ms if want_stats else 0.0
+        dist.all_gather_into_tensor(all_slabs, slab)
+        rr.resolve_gathered(all_slabs.data_ptr(), stream.cuda_stream)
+        return t
+
+    def fence():
+        if multi:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step(r)
+    fence()
+    first_frame = args.warmup + 1
+    trace_ms = []
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        trace_ms.append(step(r, want_stats=True))
+    fence()
+    elapsed = time.perf_counter() - t0
+    if multi:
+        te = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        dist.all_reduce(te, op=dist.ReduceOp.MAX)
+        elapsed = float(te.item())
+
+    # ---- exact work of the timed frames: counting replay (untimed)
+    rc = make(True)
+    rc.set_frame_counter(first_frame - 1)
+    tot = {k: 0 for k in ("n_rays", "n_box", "n_tri", "n_prim", "n_vox")}
+    for _ in range(args.steps):
+        if multi:
+            rc.trace_tiles(slab.data_ptr(), stream.cuda_stream, want_stats=True)
+        else:
+            rc.TryFlipAndBlit()
+        for k, v in stats_dict(rc.stats).items():
+            tot[k] += v
+    if multi:
+        tt = torch.tensor([tot[k] for k in sorted(tot)], dtype=torch.int64, device="cuda")
+        dist.all_reduce(tt)
+        tot = dict(zip(sorted(tot), [int(x) for x in tt.tolist()]))
+    rc.close()
+
+    per_frame = {k: v / args.steps for k, v in tot.items()}
+    mrays = tot["n_rays"] / elapsed / 1e6
+    ms_per_step = elapsed / args.steps * 1e3
+    mean_trace_ms = float(np.mean(trace_ms)) if trace_ms and trace_ms[0] > 0 else None
+    # roofline of the dominant kernel (k_trace) on THIS rank's share of the frame
+    my_alg = algorithmic_bytes({k: v / world for k, v in per_frame.items()}, pixels / world)
+    roof = None
+    if mean_trace_ms:
+        ach = my_alg / (mean_trace_ms * 1e-3) / 1e9
+        roof = {"bound": "hbm", "kernel": "k_trace", "achieved": round(ach, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                "frac": round(ach / HBM_PEAK_GBS, 5), "traffic": load_traffic_hint() if world == 1 else None,
+                "algorithmic_bytes_per_launch": int(my_alg), "mean_launch_ms": round(mean_trace_ms, 4)}
+
+    cpu = None
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        import oracle_binding as ob
+        threads = os.cpu_count() or 1
+        o = ob.OracleRenderer(scene, fbw, fbh, ss, pose, flat=flat)
+        o.set_frame_counter(first_frame - 1)
+        rays = 0; secs = 0.0; frames = 0
+        while secs < args.cpu_seconds and frames < args.steps:
+            o.render(stages=1, threads=threads)
+            rays += int(o.stats.n_rays); secs += (o.stats.trace_ms + o.stats.taa_ms) * 1e-3; frames += 1
+        o.close()
+        cpu = {"value": round(rays / secs / 1e6, 3), "unit": "Mrays/s", "cores": threads, "kind": "port",
+               "sample": f"{frames} frame(s) of the same workload (frame numbers {first_frame}..{first_frame + frames - 1}), "
+                         f"ray-gen + trace + serial TAA, {secs:.1f} s of host time",
+               "ms_per_frame": round(secs / frames * 1e3, 2)}
+
+    if rank == 0:
+        name, cus = r.device_info()
+        out = {
+            "metric": "Mrays/s (all rays: Scene.Hit + Scene.Occluded calls) and ms/frame, Dragon-class BVH 1920x1080 1spp",
+            "value": round(mrays, 2), "unit": "Mrays/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(ms_per_step, 4), "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
+            "dtype": "f32", "data": "synthetic",
+            "config": {"workload": f"config {args.config}: " + {1: "Cornell box", 2: "mirror spheres on checker", 3: "Stanford bunny 69,451 tris",
+                                                               4: "Dragon-class stand-in mesh 871,200 tris (seeded torus-knot, dragon OBJ is a missing blob)",
+                                                               5: "voxel world 544x256x544"}[args.config],
+                       "trace_grid": f"{hiW}x{hiH}", "spp": ss * ss, "triangles": flat.n_triangles,
+                       "frame": "ray-gen + trace + TAA" + (" + RCCL all-gather of tile slabs + un-permute" if multi else ""),
+                       "parallelism": f"framebuffer tiles 32x8 round-robin over {world} GPU(s)", "device": name, "compute_units": cus},
+            "primary_mrays_per_s": round(pixels * args.steps / elapsed / 1e6, 2),
+            "rays_per_frame": round(per_frame["n_rays"], 1),
+            "work_per_frame": {k: round(v, 1) for k, v in per_frame.items()},
+            "roofline": roof, "cpu_baseline": cpu,
+        }
+        if cpu:
+            out["gpu_over_cpu"] = round(mrays / cpu["value"], 2)
+        print(json.dumps(out))
+    r.close()
+    if multi:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()
