@@ -860,6 +860,21 @@ int orc_scene_hit(void *ctx, const float o[3], const float d[3], float t_min, fl
     out[10] = h.m.albedo.x; out[11] = h.m.albedo.y; out[12] = h.m.albedo.z;
     return YCGE_OK;
 }
+/* closest hits of n rays with per-ray work counters: counts = n x {box, tri, prim, vox} (analysis aid) */
+int orc_scene_hit_many(void *ctx, const float *od /* n x 6 */, int n, float t_min, float t_max, float *t_out, int32_t *prim_out, uint32_t *counts)
+{
+    Renderer *r = (Renderer *)ctx;
+    if (!r || !r->have_scene) return YCGE_ERR_NO_SCENE;
+    for (int i = 0; i < n; i++) {
+        orc::Counters c; orc::Hit h{};
+        orc::Ray ray = orc::make_ray(orc::v3(od[6 * i], od[6 * i + 1], od[6 * i + 2]), orc::v3(od[6 * i + 3], od[6 * i + 4], od[6 * i + 5]));
+        bool hit = r->scene.hit(ray, t_min, t_max, h, c);
+        if (t_out) t_out[i] = hit ? h.t : t_max;
+        if (prim_out) prim_out[i] = hit ? h.prim : -1;
+        if (counts) { counts[4 * i] = (uint32_t)c.box; counts[4 * i + 1] = (uint32_t)c.tri; counts[4 * i + 2] = (uint32_t)c.prim; counts[4 * i + 3] = (uint32_t)c.vox; }
+    }
+    return YCGE_OK;
+}
 /* brute-force closest hit over Scene.Objects in order (no BVH), same tie rule */
 int orc_scene_hit_bruteforce(void *ctx, const float o[3], const float d[3], float t_min, float t_max, float out[4])
 {

@@ -151,6 +151,7 @@ struct FrameParams {
     float eps;
     float mirror_threshold;
     float sigma_rad;
+    float on_a, on_b;                   // Oren-Nayar A, B of sigma (RaytraceRenderer.cs:823-825)
     int32_t max_mirror_bounces, max_refractions, diffuse_bounces;
     // tile partition
     int32_t tiles_x, tiles_y;
@@ -159,20 +160,24 @@ struct FrameParams {
 };
 
 struct TraceOut {
-    // full-frame buffers (single-GPU path) ...
+    // full-frame buffers (row-major x + y*hiW); with several GPUs only the owned tiles are written
     float *current_hdr;     // 3 f32 / px
     float *g_albedo;
     float *g_normal;
     float *g_depth;
     uint8_t *sky;
-    // ... or this rank's tile slab (multi-GPU path); exactly one of the two is used
-    float *slab;
     // debug capture (may be null)
     float *rays;
     int32_t *prim_id;
     int32_t *sub_id;
     float *hit_t;
     uint64_t *rng_state;
+    // traversal-stack overflow area [level][global lane] and refraction path stack [slot][field][global lane]
+    void *stack_spill;                  // uint2 entries {ref, tNear}
+    uint32_t stack_lanes;
+    float *path_stack;
+    // per-wavefront profile of k_wf_primary (COUNT variant; may be null): 4 x u64 {start, end, node iters, leaf phases}
+    unsigned long long *wave_prof;
     // traversal counters (may be null): rays, box, tri, prim, vox
     unsigned long long *counters;
 };

@@ -8,6 +8,7 @@
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <mutex>
 #include <string>
@@ -19,10 +20,14 @@
 #include "ycge_math.h"
 
 extern "C" {
-int ycge_launch_trace(const ycge::SceneDev *S, const ycge::FrameParams *P, const ycge::TraceOut *O, int count, int debug, int slab,
-                      hipStream_t stream);
+size_t ycge_wf_sizes(int which);
+int ycge_launch_trace(const ycge::SceneDev *S, const ycge::FrameParams *P, const ycge::TraceOut *O, int count, int flat, hipStream_t stream);
+int ycge_launch_wavefront(const ycge::SceneDev *S, const ycge::FrameParams *P, const ycge::TraceOut *O, void *const bufs[6], int rounds,
+                          int has_grid, int flat, int count, hipStream_t stream);
 int ycge_launch_taa(const ycge::TaaParams *T, const float *current, const float *normal, const float *depth, const uint8_t *sky,
                     float *hist, float *prev_normal, float *prev_depth, uint8_t *prev_sky, hipStream_t stream);
+int ycge_launch_pack_slab(const ycge::FrameParams *P, const float *hdr, const float *albedo, const float *normal, const float *depth,
+                          const uint8_t *sky, float *slab, hipStream_t stream);
 int ycge_launch_unpermute(const float *all_slabs, size_t slab_floats_per_rank, int hiW, int hiH, int tiles_x, int n_tiles, int world_size,
                           float *hdr, float *albedo, float *normal, float *depth, uint8_t *sky, hipStream_t stream);
 }
@@ -87,8 +92,17 @@ struct ycge_ctx {
     DevBuf<float> dbg_rays, dbg_hit_t;
     DevBuf<int32_t> dbg_prim, dbg_sub;
     DevBuf<uint64_t> dbg_rng;
-    DevBuf<unsigned long long> counters;
+    DevBuf<unsigned long long> counters, wave_prof;
     DevBuf<float> own_slab;                    // used when world_size > 1 and the caller passes no slab
+    // wavefront pipeline storage (ycge_kernels.hip: QEntry / HitRec / LEntry), sized for one ray per pixel
+    DevBuf<uint8_t> wf_q0, wf_q1, wf_hit, wf_lq;
+    DevBuf<uint32_t> wf_counts;
+    DevBuf<uint64_t> stack_spill;                 // [YCGE_TRAVERSAL_STACK - 12][persistent lanes]
+    DevBuf<float> path_stack;                  // [3][11][persistent lanes], only for scenes with transparent materials
+    int spill_levels = 0;                      // traversal depth beyond the 12 LDS levels, from the uploaded trees
+    bool force_megakernel = false;
+    int wf_rounds = 2;                         // 2 = primary + diffuse bounce; 4 when a surface can mirror (<= 2 mirror bounces)
+    bool has_grid = false;
 
     // scene
     bool have_scene = false;
@@ -143,6 +157,18 @@ int alloc_frame_buffers(ycge_ctx *c)
     return YCGE_OK;
 }
 
+// queue segments, hit records and stack-spill columns: one 256-entry segment per owned tile
+int alloc_tile_buffers(ycge_ctx *c)
+{
+    const size_t lanes = (size_t)(c->n_owned > 0 ? c->n_owned : 1) * 256;
+    HIP_TRY(c, c->wf_q0.alloc(lanes * ycge_wf_sizes(0))); HIP_TRY(c, c->wf_q1.alloc(lanes * ycge_wf_sizes(0)));
+    HIP_TRY(c, c->wf_hit.alloc(lanes * ycge_wf_sizes(1))); HIP_TRY(c, c->wf_lq.alloc(lanes * ycge_wf_sizes(2)));
+    HIP_TRY(c, c->wf_counts.alloc((size_t)(c->n_owned > 0 ? c->n_owned : 1) * 8));
+    HIP_TRY(c, c->stack_spill.alloc((size_t)(c->spill_levels > 0 ? c->spill_levels : 1) * lanes));
+    c->path_stack.release();
+    return YCGE_OK;
+}
+
 int set_geometry(ycge_ctx *c, int fbw, int fbh, int ss)
 {
     if (fbw <= 0 || fbh <= 0) return c->fail(YCGE_ERR_INVALID_ARG, "framebuffer size must be positive");
@@ -157,6 +183,8 @@ int set_geometry(ycge_ctx *c, int fbw, int fbh, int ss)
     c->taa_valid = false;                                       // Resize: taaHistoryValid = false (:137), taa.Resize (TemporalAA.cs:34-46)
     c->last_cam[0] = c->last_cam[1] = c->last_cam[2] = NAN; c->last_yaw = c->last_pitch = NAN;
     int rc = alloc_frame_buffers(c);
+    if (rc != YCGE_OK) return rc;
+    rc = alloc_tile_buffers(c);
     if (rc != YCGE_OK) return rc;
     if (world > 1) HIP_TRY(c, c->own_slab.alloc((size_t)c->tiles_per_rank_padded * 256 * YCGE_SLAB_FLOATS));
     return YCGE_OK;
@@ -209,6 +237,11 @@ void fill_frame_params(ycge_ctx *c, FrameParams &P, int64_t frame, const float p
     P.eps = c->cfg.eps;
     P.mirror_threshold = c->cfg.mirror_threshold;
     P.sigma_rad = c->cfg.diffuse_sigma_deg * (pi / 180.0f);
+    {   // OrenNayarBRDF's sigma-only terms, same fp32 expressions as RaytraceRenderer.cs:823-825
+        const float sigma2 = P.sigma_rad * P.sigma_rad;
+        P.on_a = 1.0f - (sigma2 / (2.0f * (sigma2 + 0.33f)));
+        P.on_b = 0.45f * sigma2 / (sigma2 + 0.09f);
+    }
     P.max_mirror_bounces = c->cfg.max_mirror_bounces;
     P.max_refractions = c->cfg.max_refractions;
     P.diffuse_bounces = c->cfg.diffuse_bounces;
@@ -313,6 +346,7 @@ int ycge_create(const ycge_config *cfg, ycge_ctx **out)
     c->cfg = *cfg;
     c->device = cfg->device;
     c->fov_deg = cfg->fov_deg;
+    { const char *e = getenv("YCGE_FORCE_MEGAKERNEL"); c->force_megakernel = e && e[0] == '1'; }
     auto bail = [&](int code) { g_create_error = c->err; ycge_destroy(c); return code; };
     if (hipSetDevice(c->device) != hipSuccess) { c->err = "hipSetDevice failed"; return bail(YCGE_ERR_DEVICE); }
     hipDeviceProp_t prop;
@@ -339,7 +373,8 @@ void ycge_destroy(ycge_ctx *c)
     c->current_hdr.release(); c->g_albedo.release(); c->g_normal.release(); c->g_depth.release(); c->taa_hist.release();
     c->prev_normal.release(); c->prev_depth.release(); c->sky.release(); c->prev_sky.release();
     c->dbg_rays.release(); c->dbg_hit_t.release(); c->dbg_prim.release(); c->dbg_sub.release(); c->dbg_rng.release();
-    c->counters.release(); c->own_slab.release();
+    c->counters.release(); c->wave_prof.release(); c->own_slab.release();
+    c->wf_q0.release(); c->wf_q1.release(); c->wf_hit.release(); c->wf_lq.release(); c->wf_counts.release(); c->stack_spill.release(); c->path_stack.release();
     c->d_scene_nodes.release(); c->d_mesh_nodes.release(); c->d_scene_leaf.release(); c->d_tris.release(); c->d_prims.release();
     c->d_materials.release(); c->d_meshes.release(); c->d_grids.release(); c->d_cells.release(); c->d_lut.release(); c->d_lights.release();
     for (auto &ev : c->ev) if (ev) (void)hipEventDestroy(ev);
@@ -528,9 +563,13 @@ int ycge_scene_upload(ycge_ctx *c, const ycge_scene *s)
             g.p[9] = nnx * inv_len; g.p[10] = nny * inv_len; g.p[11] = nnz * inv_len;
             break;
         }
-        case YCGE_PRIM_MESH:
+        case YCGE_PRIM_MESH: {      // root box + root reference ride in the object record (one fetch less per query)
             if (q.ref < 0 || q.ref >= s->n_meshes) return c->fail(YCGE_ERR_INVALID_ARG, "prim %d: mesh ref out of range", i);
+            const GMesh &gm = gmeshes[q.ref];
+            for (int a = 0; a < 3; a++) { g.p[a] = gm.root_min[a]; g.p[3 + a] = gm.root_max[a]; }
+            g.p[6] = u2f(gm.root_ref);
             break;
+        }
         case YCGE_PRIM_VOLUME_GRID:
             if (q.ref < 0 || q.ref >= s->n_grids) return c->fail(YCGE_ERR_INVALID_ARG, "prim %d: grid ref out of range", i);
             break;
@@ -542,10 +581,29 @@ int ycge_scene_upload(ycge_ctx *c, const ycge_scene *s)
         if (!prim_bounds(q, c->meshes, s, b, cen)) return c->fail(YCGE_ERR_INVALID_ARG, "Unbounded Hittable (prim %d)", i);   // BVH.cs:37-40
         for (int a = 0; a < 3; a++) { items.mn[a][i] = b[a]; items.mx[a][i] = b[3 + a]; items.c[a][i] = cen[a]; }
     }
+    // can any surface take the mirror branch (Reflectivity >= MirrorThreshold, RaytraceRenderer.cs:559)?
+    bool can_mirror = false;
+    for (int i = 0; i < s->n_materials; i++) if (s->materials[i].reflectivity >= c->cfg.mirror_threshold) can_mirror = true;
+    for (int i = 0; i < s->n_prims; i++) {
+        const int ty = s->prims[i].type;
+        const bool overrides = ty == YCGE_PRIM_PLANE || ty == YCGE_PRIM_DISK || ty == YCGE_PRIM_XYRECT || ty == YCGE_PRIM_XZRECT || ty == YCGE_PRIM_YZRECT || ty == YCGE_PRIM_BOX;
+        if (overrides && s->prims[i].reflectivity >= c->cfg.mirror_threshold) can_mirror = true;
+    }
+    c->wf_rounds = can_mirror ? 2 + c->cfg.max_mirror_bounces : 2;
+    c->has_grid = s->n_grids > 0;
     build_tree(items, TreeFlavour::Scene, c->scene_tree);
     if (c->scene_tree.max_depth > 128) return c->fail(YCGE_ERR_STACK_DEPTH, "scene BVH depth %d exceeds the reference's 128-entry stack (BVH.cs:118)", c->scene_tree.max_depth);
     if (c->scene_tree.max_depth + 4 + max_mesh_depth + 2 > YCGE_TRAVERSAL_STACK)
         return c->fail(YCGE_ERR_STACK_DEPTH, "combined traversal depth %d + %d exceeds the device stack", c->scene_tree.max_depth, max_mesh_depth);
+    {   // levels the per-lane stack can need beyond its LDS part: scene depth + 4 leaf objects + deepest mesh
+        const int need = c->scene_tree.max_depth + 4 + max_mesh_depth + 2 - 12;
+        const int levels = need > 0 ? need : 0;
+        if (levels != c->spill_levels) {
+            c->spill_levels = levels;
+            int rc2 = alloc_tile_buffers(c);
+            if (rc2 != YCGE_OK) return rc2;
+        }
+    }
     std::vector<GNode> scene_nodes;
     const uint32_t scene_root = to_gpu_nodes(c->scene_tree, REF_SCENE_NODE, REF_SCENE_LEAF, 0, 0, 3, scene_nodes);
     std::vector<uint32_t> leaf_prims(c->scene_tree.leaf_index.begin(), c->scene_tree.leaf_index.end());
@@ -649,17 +707,34 @@ int begin_and_trace(ycge_ctx *c, float *d_slab, hipStream_t stream, FrameState &
     TraceOut O;
     std::memset(&O, 0, sizeof O);
     O.current_hdr = c->current_hdr.p; O.g_albedo = c->g_albedo.p; O.g_normal = c->g_normal.p; O.g_depth = c->g_depth.p; O.sky = c->sky.p;
-    O.slab = d_slab;
     const bool slab = d_slab != nullptr;
     const bool debug = c->cfg.capture_debug && !slab;
     if (debug) { O.rays = c->dbg_rays.p; O.prim_id = c->dbg_prim.p; O.sub_id = c->dbg_sub.p; O.hit_t = c->dbg_hit_t.p; O.rng_state = c->dbg_rng.p; }
+    if (getenv("YCGE_WAVE_PROF")) { if (!c->wave_prof.p) HIP_TRY(c, c->wave_prof.alloc((size_t)c->n_tiles * 16)); O.wave_prof = c->wave_prof.p; }
     if (c->cfg.count_work) {
         O.counters = c->counters.p;
         HIP_TRY(c, hipMemsetAsync(c->counters.p, 0, 8 * sizeof(unsigned long long), stream));
     }
     if (timed) HIP_TRY(c, hipEventRecord(c->ev[0], stream));
-    int e = ycge_launch_trace(&c->sd, &P, &O, c->cfg.count_work, debug ? 1 : 0, slab ? 1 : 0, stream);
-    if (e != 0) return c->fail(YCGE_ERR_DEVICE, "k_trace launch failed: %s", hipGetErrorString((hipError_t)e));
+    int e;
+    O.stack_spill = c->stack_spill.p;
+    O.stack_lanes = (uint32_t)(c->n_owned > 0 ? c->n_owned : 1) * 256u;
+    O.path_stack = c->path_stack.p;
+    const int flat = YCGE_REF_KIND(c->sd.scene_root_ref) == REF_SCENE_LEAF ? 1 : 0;
+    if (c->sd.any_transparent || c->force_megakernel) {
+        // refraction splits need TraceFull's per-pixel LIFO: single-launch path
+        if (!c->path_stack.p) HIP_TRY(c, c->path_stack.alloc((size_t)3 * 11 * O.stack_lanes));
+        O.path_stack = c->path_stack.p;
+        e = ycge_launch_trace(&c->sd, &P, &O, c->cfg.count_work, flat, stream);
+    } else {
+        void *bufs[6] = {c->wf_q0.p, c->wf_q1.p, c->wf_hit.p, c->wf_lq.p, c->wf_counts.p, c->wf_counts.p + (size_t)7 * (c->n_owned > 0 ? c->n_owned : 1)};
+        e = ycge_launch_wavefront(&c->sd, &P, &O, bufs, c->wf_rounds, c->has_grid ? 1 : 0, flat, c->cfg.count_work, stream);
+    }
+    if (e != 0) return c->fail(YCGE_ERR_DEVICE, "trace launch failed: %s", hipGetErrorString((hipError_t)e));
+    if (slab) {
+        e = ycge_launch_pack_slab(&P, c->current_hdr.p, c->g_albedo.p, c->g_normal.p, c->g_depth.p, c->sky.p, d_slab, stream);
+        if (e != 0) return c->fail(YCGE_ERR_DEVICE, "k_pack_slab launch failed: %s", hipGetErrorString((hipError_t)e));
+    }
     if (timed) HIP_TRY(c, hipEventRecord(c->ev[1], stream));
     return YCGE_OK;
 }
@@ -876,6 +951,14 @@ int ycge_host_build_mesh(const float *tris9, int32_t n, void *nodes_out, int32_t
     if (!t.leaf_index.empty()) std::memcpy(leaf_out, t.leaf_index.data(), t.leaf_index.size() * 4);
     if (stats_out) { stats_out[0] = t.root; stats_out[1] = t.max_depth; stats_out[2] = t.sort_fallbacks; }
     return (int)t.nodes.size();
+}
+// profiling aid: per-wavefront {start, end, node iterations, leaf phases} of the last counted k_wf_primary launch
+int ycge_debug_read_wave_prof(ycge_ctx *c, unsigned long long *dst, size_t n_u64)
+{
+    if (!c || !dst || !c->wave_prof.p || n_u64 > c->wave_prof.n) return YCGE_ERR_INVALID_ARG;
+    HIP_TRY(c, hipDeviceSynchronize());
+    HIP_TRY(c, hipMemcpy(dst, c->wave_prof.p, n_u64 * 8, hipMemcpyDeviceToHost));
+    return YCGE_OK;
 }
 // sizeof of each ABI struct, for the ctypes mirror check
 size_t ycge_abi_sizeof(int32_t which)

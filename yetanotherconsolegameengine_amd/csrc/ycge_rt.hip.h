@@ -1,0 +1,884 @@
+// ycge_rt.hip.h — device-side building blocks of the ray-trace core (gfx950, wave64):
+// vectors, sampler, shading helpers, material evaluation, slab tests, analytic primitives,
+// voxel DDA, the closest-hit traversal and hit-attribute reconstruction.  Shared by the
+// wavefront stage kernels and the single-launch megakernel in ycge_kernels.hip.
+//
+// Arithmetic contract: see ycge_math.h (compiled with -ffp-contract=off; every expression is
+// the reference's, operation for operation — citations are to /root/reference/ConsoleGame/).
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include "ycge_device.h"
+#include "ycge_math.h"
+
+namespace ycge {
+
+// ------------------------------------------------------------------ vectors
+struct F3 { float x, y, z; };
+__device__ __forceinline__ F3 f3(float x, float y, float z) { F3 r; r.x = x; r.y = y; r.z = z; return r; }
+__device__ __forceinline__ F3 f3(const float *p) { return f3(p[0], p[1], p[2]); }
+__device__ __forceinline__ F3 operator+(F3 a, F3 b) { return f3(a.x + b.x, a.y + b.y, a.z + b.z); }
+__device__ __forceinline__ F3 operator-(F3 a, F3 b) { return f3(a.x - b.x, a.y - b.y, a.z - b.z); }
+__device__ __forceinline__ F3 operator-(F3 a) { return f3(-a.x, -a.y, -a.z); }
+__device__ __forceinline__ F3 operator*(F3 a, F3 b) { return f3(a.x * b.x, a.y * b.y, a.z * b.z); }
+__device__ __forceinline__ F3 operator*(F3 a, float s) { return f3(a.x * s, a.y * s, a.z * s); }
+__device__ __forceinline__ F3 vdiv(F3 a, float s) { float inv = 1.0f / s; return f3(a.x * inv, a.y * inv, a.z * inv); }   // Vec3.cs:67-71
+__device__ __forceinline__ float dot(F3 a, F3 b) { return a.x * b.x + a.y * b.y + a.z * b.z; }
+__device__ __forceinline__ F3 cross(F3 a, F3 b) { return f3(a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x * b.y - a.y * b.x); }
+__device__ __forceinline__ F3 normalized(F3 a)      // Vec3.cs:98-107
+{
+    float len_sq = a.x * a.x + a.y * a.y + a.z * a.z;
+    if (len_sq <= 0.0f) return a;
+    float inv_len = 1.0f / cs_sqrt(len_sq);
+    return f3(a.x * inv_len, a.y * inv_len, a.z * inv_len);
+}
+__device__ __forceinline__ F3 saturate(F3 a) { return f3(clamp01(a.x), clamp01(a.y), clamp01(a.z)); }
+
+struct RayQ {              // one closest-hit query: Scene.Hit(r, tMin, tMax)
+    F3 o, d;
+    float tmin, tmax;
+};
+
+struct Work {              // SURVEY 8(d) counters
+    unsigned rays, box, tri, prim, vox;
+};
+
+// ------------------------------------------------------------------ sampler (RaytraceSampler.cs)
+__device__ __constant__ uint8_t c_bayer8x8[64] = {
+    0, 32, 8, 40, 2, 34, 10, 42, 48, 16, 56, 24, 50, 18, 58, 26, 12, 44, 4, 36, 14, 46, 6, 38, 60, 28, 52, 20, 62, 30, 54, 22,
+    3, 35, 11, 43, 1, 33, 9, 41, 51, 19, 59, 27, 49, 17, 57, 25, 15, 47, 7, 39, 13, 45, 5, 37, 63, 31, 55, 23, 61, 29, 53, 21};
+
+__device__ __forceinline__ float frac(float v) { return v - cs_floor(v); }
+__device__ __forceinline__ float blue_noise_sample(int x, int y, int frame_idx, int channel)   // :27-34
+{
+    float base = ((float)c_bayer8x8[(y & 7) * 8 + (x & 7)] + 0.5f) * (1.0f / 64.0f);
+    float rot = frac((float)(frame_idx + 1) * (channel == 0 ? 0.7548776662466927f : 0.5698402909980532f));
+    return frac(base + rot);
+}
+__device__ __forceinline__ uint64_t splitmix64(uint64_t z)                                     // :71-80
+{
+    z += 0x9E3779B97F4A7C15ULL;
+    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ULL;
+    z = (z ^ (z >> 27)) * 0x94D049BB133111EBULL;
+    return z ^ (z >> 31);
+}
+__device__ __forceinline__ uint64_t per_frame_seed(int x, int y, int64_t frame, uint64_t salt)  // :56-68, jx = jy = 0
+{
+    uint64_t h = 1469598103934665603ULL;
+    h ^= (uint64_t)(int64_t)x * 0x9E3779B97F4A7C15ULL; h = splitmix64(h);
+    h ^= (uint64_t)(int64_t)y * 0xC2B2AE3D27D4EB4FULL; h = splitmix64(h);
+    h ^= (uint64_t)frame * 0x165667B19E3779F9ULL; h = splitmix64(h);
+    h ^= 0ULL; h = splitmix64(h);
+    h ^= salt; h = splitmix64(h);
+    return h;
+}
+__device__ __forceinline__ float rng_next_unit(uint64_t &state)                                 // :43-52
+{
+    state = splitmix64(state);
+    uint32_t m24 = (uint32_t)(state >> 40);
+    return ((float)m24 + 0.5f) * (1.0f / 16777216.0f);
+}
+__device__ __forceinline__ F3 cosine_sample_hemisphere(F3 n, uint64_t &rng)                     // :83-111
+{
+    float u1 = rng_next_unit(rng);
+    float u2 = rng_next_unit(rng);
+    float r = cs_sqrt(u1);
+    float phi = 6.2831853071795864769f * u2;
+    float sn, cs;
+    m_sincos(phi, &sn, &cs);
+    float x = r * cs;
+    float y = r * sn;
+    float z = cs_sqrt(1.0f - u1);
+    float wz = n.z;
+    if (wz < -0.999999f) {
+        F3 u = f3(0.0f, -1.0f, 0.0f);
+        F3 v = f3(-1.0f, 0.0f, 0.0f);
+        return u * x + v * y + n * z;
+    }
+    float a = 1.0f / (1.0f + wz);
+    float b = (-n.x * n.y) * a;
+    // new Vec3(double, double, double): `1.0 - (w.X*w.X)*a` is binary64, then narrowed
+    F3 u_axis = f3((float)(1.0 - (double)((n.x * n.x) * a)), b, -n.x);
+    F3 v_axis = f3(b, (float)(1.0 - (double)((n.y * n.y) * a)), -n.y);
+    return u_axis * x + v_axis * y + n * z;
+}
+
+// ------------------------------------------------------------------ shading helpers (RaytraceRenderer.cs:737-831)
+#define YCGE_PI 3.14159265358979323846f
+__device__ __forceinline__ F3 reflect(F3 v, F3 n) { return v - n * (2.0f * dot(v, n)); }
+__device__ __forceinline__ F3 lerp3(F3 a, F3 b, float t) { return a * (1.0f - t) + b * t; }
+__device__ __forceinline__ bool refract(F3 v, F3 n, float eta, F3 &out)
+{
+    float cosi = -cs_max(-1.0f, cs_min(1.0f, dot(v, n)));
+    float k = 1.0f - eta * eta * (1.0f - cosi * cosi);
+    if (k < 0.0f) { out = f3(0, 0, 0); return false; }
+    out = (v * eta) + (n * (eta * cosi - cs_sqrt(k)));
+    return true;
+}
+__device__ __forceinline__ float fresnel_schlick(float cos_theta, float eta_i, float eta_t)
+{
+    float r0 = (eta_i - eta_t) / (eta_i + eta_t);
+    r0 = r0 * r0;
+    return r0 + (1.0f - r0) * m_pow5(1.0f - cos_theta);
+}
+// OrenNayarBRDF, RaytraceRenderer.cs:810-831.  A and B depend on sigma only; the host evaluates the
+// same fp32 expressions once per context (FrameParams.on_a / on_b), which yields the same bits.
+__device__ __forceinline__ F3 oren_nayar(F3 albedo, F3 n, F3 wo, F3 wi, float A, float B)
+{
+    const float inv_pi = 1.0f / YCGE_PI;
+    float cos_i = cs_max(0.0f, dot(n, wi));
+    float cos_o = cs_max(0.0f, dot(n, wo));
+    if (cos_i <= 0.0f || cos_o <= 0.0f) return f3(0, 0, 0);
+    float sin_i = cs_sqrt(cs_max(0.0f, 1.0f - cos_i * cos_i));
+    float sin_o = cs_sqrt(cs_max(0.0f, 1.0f - cos_o * cos_o));
+    F3 proj_i = normalized(wi - n * cos_i);
+    F3 proj_o = normalized(wo - n * cos_o);
+    float cos_phi = cs_max(0.0f, dot(proj_i, proj_o));
+    float sin_alpha = cs_max(sin_i, sin_o);
+    float tan_beta = cs_min(sin_i / cs_max(1e-6f, cos_i), sin_o / cs_max(1e-6f, cos_o));
+    float on = (A + B * cos_phi * sin_alpha * tan_beta);
+    F3 f = albedo * (on * inv_pi);
+    return saturate(f);
+}
+
+// ------------------------------------------------------------------ materials
+struct MatEval {
+    F3 albedo, emission, trans_color;
+    float reflectivity, transparency, ior;
+};
+__device__ __forceinline__ MatEval eval_material(const SceneDev &S, int mi, F3 pos)   // Scenes.cs:408-428
+{
+    const GMaterial *m = S.materials + mi;
+    const float4 a = ((const float4 *)m)[0];   // kind, albedo
+    const float4 b = ((const float4 *)m)[1];   // albedo_b, scale
+    const float4 c = ((const float4 *)m)[2];   // refl, emission
+    const float4 d = ((const float4 *)m)[3];   // transp, ior, trans_color.xy
+    const float4 e = ((const float4 *)m)[4];   // trans_color.z
+    MatEval o;
+    if (__float_as_int(a.x) == 1) {
+        int32_t cx = cs_f2i(cs_floor(pos.x / b.w));
+        int32_t cz = cs_f2i(cs_floor(pos.z / b.w));
+        bool check = (((uint32_t)cx + (uint32_t)cz) & 1u) == 0u;
+        o.albedo = check ? f3(a.y, a.z, a.w) : f3(b.x, b.y, b.z);
+    } else {
+        o.albedo = f3(a.y, a.z, a.w);
+    }
+    o.reflectivity = c.x;
+    o.emission = f3(c.y, c.z, c.w);
+    o.transparency = d.x;
+    o.ior = d.y;
+    o.trans_color = f3(d.z, d.w, e.x);
+    return o;
+}
+
+// ------------------------------------------------------------------ box tests
+// BVH.BoxHitFast, BVH.cs:201-236: NaN-propagating Max/Min, clamp to [tMin, tMax]
+__device__ __forceinline__ bool box_scene(float mnx, float mny, float mnz, float mxx, float mxy, float mxz, F3 o, F3 inv,
+                                          float tmin, float tmax, float &tnear)
+{
+    float en_x = (mnx - o.x) * inv.x, ex_x = (mxx - o.x) * inv.x;
+    if (en_x > ex_x) { float t = en_x; en_x = ex_x; ex_x = t; }
+    float en_y = (mny - o.y) * inv.y, ex_y = (mxy - o.y) * inv.y;
+    if (en_y > ex_y) { float t = en_y; en_y = ex_y; ex_y = t; }
+    float en_z = (mnz - o.z) * inv.z, ex_z = (mxz - o.z) * inv.z;
+    if (en_z > ex_z) { float t = en_z; en_z = ex_z; ex_z = t; }
+    float t_enter = cs_max(en_x, cs_max(en_y, en_z));
+    float t_exit = cs_min(ex_x, cs_min(ex_y, ex_z));
+    if (t_enter < tmin) t_enter = tmin;
+    if (t_exit > tmax) t_exit = tmax;
+    tnear = t_enter;
+    return t_exit >= t_enter;
+}
+// MeshBVH.BoxHitFast, MeshBVH.cs:308-332: sign-indexed slabs.  The C# updates the interval with
+// `if (tEnter > tMin) tMin = tEnter; if (tExit < tMax) tMax = tExit;` — a NaN candidate never wins and the
+// running bound is never NaN, which is exactly IEEE maxNum / minNum (v_max_f32 / v_min_f32); the two
+// returned values can differ from the C# only in the sign of a zero, which no later comparison sees.
+// Its two early-outs are pure shortcuts: the final test fails whenever one of them would.
+__device__ __forceinline__ bool box_mesh(float mnx, float mny, float mnz, float mxx, float mxy, float mxz, F3 o, F3 inv,
+                                         bool sx, bool sy, bool sz, float tmin, float tmax, float &tnear)
+{
+    float tx_en = ((sx ? mxx : mnx) - o.x) * inv.x;
+    float tx_ex = ((sx ? mnx : mxx) - o.x) * inv.x;
+    float ty_en = ((sy ? mxy : mny) - o.y) * inv.y;
+    float ty_ex = ((sy ? mny : mxy) - o.y) * inv.y;
+    float tz_en = ((sz ? mxz : mnz) - o.z) * inv.z;
+    float tz_ex = ((sz ? mnz : mxz) - o.z) * inv.z;
+    tmin = __builtin_fmaxf(__builtin_fmaxf(__builtin_fmaxf(tmin, tx_en), ty_en), tz_en);
+    tmax = __builtin_fminf(__builtin_fminf(__builtin_fminf(tmax, tx_ex), ty_ex), tz_ex);
+    tnear = tmin;
+    return tmax >= tmin;
+}
+
+// ------------------------------------------------------------------ analytic primitives (t only; attributes are rebuilt in resolve_hit)
+// XYRect/XZRect/YZRect.Hit, Surfaces.cs:184-214 / 256-286 / 328-358
+__device__ __forceinline__ bool rect_t(int axis, float a0, float a1, float b0, float b1, float k, F3 o, F3 d, float tmin, float tmax, float &t)
+{
+    float dir_k = axis == 2 ? d.z : axis == 1 ? d.y : d.x;
+    float org_k = axis == 2 ? o.z : axis == 1 ? o.y : o.x;
+    float adir = cs_abs(dir_k);
+    float safe = cs_copysign(cs_max(adir, 1e-8f), dir_k);
+    t = (k - org_k) / safe;
+    float pa, pb;
+    if (axis == 2) { pa = o.x + t * d.x; pb = o.y + t * d.y; }
+    else if (axis == 1) { pa = o.x + t * d.x; pb = o.z + t * d.z; }
+    else { pa = o.y + t * d.y; pb = o.z + t * d.z; }
+    bool ok = adir >= 1e-8f;
+    ok &= (t >= tmin) & (t <= tmax);
+    ok &= (pa >= a0) & (pa <= a1) & (pb >= b0) & (pb <= b1);
+    return ok;
+}
+__device__ __forceinline__ void box_face(const float *p, int i, int &axis, float &a0, float &a1, float &b0, float &b1, float &k)
+{   // Box ctor, BoundedObjects.cs:82-89: +Z, -Z, +Y, -Y, +X, -X
+    const float mnx = p[0], mny = p[1], mnz = p[2], mxx = p[3], mxy = p[4], mxz = p[5];
+    if (i < 2) { axis = 2; a0 = mnx; a1 = mxx; b0 = mny; b1 = mxy; k = i == 0 ? mxz : mnz; }
+    else if (i < 4) { axis = 1; a0 = mnx; a1 = mxx; b0 = mnz; b1 = mxz; k = i == 2 ? mxy : mny; }
+    else { axis = 0; a0 = mny; a1 = mxy; b0 = mnz; b1 = mxz; k = i == 4 ? mxx : mnx; }
+}
+
+template <bool COUNT>
+__device__ __forceinline__ void analytic_prim(const float4 q0, const float4 q1, const float4 q2, const float4 q3, int type, int prim_index,
+                                           F3 o, F3 d, float tmin, float &closest, int &hit_prim, int &hit_sub, Work &w)
+{
+    const float p[12] = {q1.x, q1.y, q1.z, q1.w, q2.x, q2.y, q2.z, q2.w, q3.x, q3.y, q3.z, q3.w};
+    (void)q0;
+    switch (type) {
+    case 0: {   // Sphere.Hit, BoundedObjects.cs:31-69
+        if (COUNT) w.prim++;
+        float ox = o.x - p[0], oy = o.y - p[1], oz = o.z - p[2];
+        float a = d.x * d.x + d.y * d.y + d.z * d.z;
+        float half_b = ox * d.x + oy * d.y + oz * d.z;
+        float c = ox * ox + oy * oy + oz * oz - p[3] * p[3];
+        float disc = half_b * half_b - a * c;
+        if (disc < 0.0f) return;
+        float s = cs_sqrt(disc);
+        float inv_a = 1.0f / a;
+        float t = (-half_b - s) * inv_a;
+        if (t < tmin || t > closest) {
+            t = (-half_b + s) * inv_a;
+            if (t < tmin || t > closest) return;
+        }
+        closest = t; hit_prim = prim_index; hit_sub = 0;
+        return;
+    }
+    case 1: {   // Plane.Hit, Surfaces.cs:39-71
+        if (COUNT) w.prim++;
+        float denom = p[0] * d.x + p[1] * d.y + p[2] * d.z;
+        if (denom > -1e-6f && denom < 1e-6f) return;
+        float t = (p[3] - (p[0] * o.x + p[1] * o.y + p[2] * o.z)) / denom;
+        if (t < tmin || t > closest) return;
+        closest = t; hit_prim = prim_index; hit_sub = 0;
+        return;
+    }
+    case 2: {   // Disk.Hit, Surfaces.cs:108-142
+        if (COUNT) w.prim++;
+        F3 n = f3(p[3], p[4], p[5]);
+        float denom = dot(n, d);
+        float adenom = cs_abs(denom);
+        float safe = cs_copysign(cs_max(adenom, 1e-8f), denom);
+        float t = (p[7] - dot(n, o)) / safe;
+        float px = o.x + t * d.x, pz = o.z + t * d.z;
+        float dx = px - p[0], dz = pz - p[2];
+        float rr = dx * dx + dz * dz;
+        bool ok = adenom >= 1e-6f;
+        ok &= (t >= tmin) & (t <= closest);
+        ok &= rr <= p[6];
+        if (!ok) return;
+        closest = t; hit_prim = prim_index; hit_sub = 0;
+        return;
+    }
+    case 3: case 4: case 5: {
+        if (COUNT) w.prim++;
+        int axis = type == 3 ? 2 : type == 4 ? 1 : 0;
+        float t;
+        if (!rect_t(axis, p[0], p[1], p[2], p[3], p[4], o, d, tmin, closest, t)) return;
+        closest = t; hit_prim = prim_index; hit_sub = 0;
+        return;
+    }
+    case 6: {   // Box.Hit, BoundedObjects.cs:100-115
+        for (int i = 0; i < 6; i++) {
+            if (COUNT) w.prim++;
+            int axis; float a0, a1, b0, b1, k, t;
+            box_face(p, i, axis, a0, a1, b0, b1, k);
+            if (rect_t(axis, a0, a1, b0, b1, k, o, d, tmin, closest, t)) { closest = t; hit_prim = prim_index; hit_sub = i; }
+        }
+        return;
+    }
+    case 7: {   // CylinderY.Hit, BoundedObjects.cs:148-247; p = cx cz radius radius2 yMin yMax capped
+        if (COUNT) w.prim++;
+        float ox = o.x - p[0], oy = o.y, oz = o.z - p[1];
+        float a = d.x * d.x + d.z * d.z;
+        float hit_t = YCGE_FLT_MAX;
+        int code = -1;      // 0 side, 1 top cap, 2 bottom cap
+        if (a > 1e-12f) {
+            float half_b = ox * d.x + oz * d.z;
+            float c = ox * ox + oz * oz - p[3];
+            float disc = half_b * half_b - a * c;
+            if (disc >= 0.0f) {
+                float s = cs_sqrt(disc);
+                float inv_a = 1.0f / a;
+                float t1 = (-half_b - s) * inv_a;
+                if (t1 > tmin && t1 < closest) {
+                    float y1 = oy + t1 * d.y;
+                    if (y1 >= p[4] && y1 <= p[5]) { hit_t = t1; code = 0; }
+                }
+                if (code < 0) {
+                    float t2 = (-half_b + s) * inv_a;
+                    if (t2 > tmin && t2 < closest) {
+                        float y2 = oy + t2 * d.y;
+                        if (y2 >= p[4] && y2 <= p[5]) { hit_t = t2; code = 0; }
+                    }
+                }
+            }
+        }
+        if (p[6] != 0.0f && cs_abs(d.y) > 1e-8f) {
+            float t_top = (p[5] - oy) / d.y;
+            if (t_top > tmin && t_top < closest) {
+                float rx = ox + t_top * d.x, rz = oz + t_top * d.z;
+                if (rx * rx + rz * rz <= p[3]) { if (t_top < hit_t) { hit_t = t_top; code = 1; } }
+            }
+            float t_bot = (p[4] - oy) / d.y;
+            if (t_bot > tmin && t_bot < closest) {
+                float rx = ox + t_bot * d.x, rz = oz + t_bot * d.z;
+                if (rx * rx + rz * rz <= p[3]) { if (t_bot < hit_t) { hit_t = t_bot; code = 2; } }
+            }
+        }
+        if (code < 0) return;
+        closest = hit_t; hit_prim = prim_index; hit_sub = code;
+        return;
+    }
+    case 8: {   // Triangle.Hit scalar path, Triangle.cs:131-175; p = A e1 e2 n
+        if (COUNT) w.prim++;
+        float e1x = p[3], e1y = p[4], e1z = p[5], e2x = p[6], e2y = p[7], e2z = p[8];
+        float px = d.y * e2z - d.z * e2y;
+        float py = d.z * e2x - d.x * e2z;
+        float pz = d.x * e2y - d.y * e2x;
+        float det = e1x * px + e1y * py + e1z * pz;
+        if (cs_abs(det) < 1e-8f) return;
+        float inv_det = 1.0f / det;
+        float sx = o.x - p[0], sy = o.y - p[1], sz = o.z - p[2];
+        float u = (sx * px + sy * py + sz * pz) * inv_det;
+        if (u < 0.0f || u > 1.0f) return;
+        float qx = sy * e1z - sz * e1y;
+        float qy = sz * e1x - sx * e1z;
+        float qz = sx * e1y - sy * e1x;
+        float v = (d.x * qx + d.y * qy + d.z * qz) * inv_det;
+        if (v < 0.0f || (u + v) > 1.0f) return;
+        float t = (e2x * qx + e2y * qy + e2z * qz) * inv_det;
+        if (t < tmin || t > closest) return;
+        closest = t; hit_prim = prim_index; hit_sub = 0;
+        return;
+    }
+    default: return;
+    }
+}
+
+// ------------------------------------------------------------------ voxel grid
+__device__ __forceinline__ int morton3_3bits(int x, int y, int z)   // VolumeGrid.cs:246-252
+{
+    return ((x & 1) << 0) | ((y & 1) << 1) | ((z & 1) << 2) | ((x & 2) << 2) | ((y & 2) << 3) | ((z & 2) << 4) | ((x & 4) << 4) | ((y & 4) << 5) | ((z & 4) << 6);
+}
+__device__ __forceinline__ uint32_t grid_index(const GGrid &g, int ix, int iy, int iz)   // VolumeGrid.cs:235-242
+{
+    int brick = (((iz >> 3) * g.nby) + (iy >> 3)) * g.nbx + (ix >> 3);
+    return (uint32_t)(brick * 512 + morton3_3bits(ix & 7, iy & 7, iz & 7));
+}
+__device__ __forceinline__ bool grid_slab(float ro, float rd, float mn, float mx, float &t_enter, float &t_exit, int axis, int &enter_axis)
+{   // VolumeGrid.Slab, VolumeGrid.cs:331-355
+    if (cs_abs(rd) < 1e-12f) {
+        if (ro < mn || ro > mx) return false;
+        return true;
+    }
+    float inv = 1.0f / rd;
+    float t0 = (mn - ro) * inv;
+    float t1 = (mx - ro) * inv;
+    if (t0 > t1) { float t = t0; t0 = t1; t1 = t; }
+    if (t0 > t_enter) { t_enter = t0; enter_axis = axis; }
+    if (t1 < t_exit) t_exit = t1;
+    return t_exit >= t_enter;
+}
+
+// VolumeGrid.Hit, VolumeGrid.cs:99-231 (Amanatides-Woo DDA; first cell with matId > 0 hits)
+template <bool COUNT>
+__device__ __forceinline__ void grid_dda(const SceneDev &S, int grid_index_, int prim_index, F3 o, F3 d, float tmin, float &closest,
+                                      int &hit_prim, int &hit_sub, Work &w)
+{
+    if (COUNT) w.prim++;
+    const GGrid g = S.grids[grid_index_];
+    const float min_x = g.min_corner[0], min_y = g.min_corner[1], min_z = g.min_corner[2];
+    const float size_x = g.voxel_size[0], size_y = g.voxel_size[1], size_z = g.voxel_size[2];
+    const float max_x = min_x + (float)g.nx * size_x, max_y = min_y + (float)g.ny * size_y, max_z = min_z + (float)g.nz * size_z;
+    const float tmax = closest;
+    int enter_axis = -1;
+    float t_enter = -YCGE_INF, t_exit = YCGE_INF;
+    if (!grid_slab(o.x, d.x, min_x, max_x, t_enter, t_exit, 0, enter_axis)) return;
+    if (!grid_slab(o.y, d.y, min_y, max_y, t_enter, t_exit, 1, enter_axis)) return;
+    if (!grid_slab(o.z, d.z, min_z, max_z, t_enter, t_exit, 2, enter_axis)) return;
+    if (!(t_exit >= cs_max(0.0f, t_enter))) return;
+    float t = t_enter; if (t < tmin) t = tmin; if (t > tmax || t > t_exit) return;
+    t += 1e-6f;
+    float px = o.x + d.x * t, py = o.y + d.y * t, pz = o.z + d.z * t;
+    int ix = cs_f2i(cs_floor((px - min_x) / size_x)); if (ix < 0) ix = 0; else if (ix >= g.nx) ix = g.nx - 1;
+    int iy = cs_f2i(cs_floor((py - min_y) / size_y)); if (iy < 0) iy = 0; else if (iy >= g.ny) iy = g.ny - 1;
+    int iz = cs_f2i(cs_floor((pz - min_z) / size_z)); if (iz < 0) iz = 0; else if (iz >= g.nz) iz = g.nz - 1;
+    const int step_x = d.x > 0.0f ? 1 : d.x < 0.0f ? -1 : 0;
+    const int step_y = d.y > 0.0f ? 1 : d.y < 0.0f ? -1 : 0;
+    const int step_z = d.z > 0.0f ? 1 : d.z < 0.0f ? -1 : 0;
+    const float inv_dx = step_x == 0 ? 0.0f : 1.0f / d.x;
+    const float inv_dy = step_y == 0 ? 0.0f : 1.0f / d.y;
+    const float inv_dz = step_z == 0 ? 0.0f : 1.0f / d.z;
+    const float next_vx = min_x + (step_x > 0 ? (float)(ix + 1) * size_x : (float)ix * size_x);
+    const float next_vy = min_y + (step_y > 0 ? (float)(iy + 1) * size_y : (float)iy * size_y);
+    const float next_vz = min_z + (step_z > 0 ? (float)(iz + 1) * size_z : (float)iz * size_z);
+    float t_max_x = step_x == 0 ? YCGE_INF : (next_vx - o.x) * inv_dx;
+    float t_max_y = step_y == 0 ? YCGE_INF : (next_vy - o.y) * inv_dy;
+    float t_max_z = step_z == 0 ? YCGE_INF : (next_vz - o.z) * inv_dz;
+    const float t_delta_x = step_x == 0 ? YCGE_INF : cs_abs(size_x * inv_dx);
+    const float t_delta_y = step_y == 0 ? YCGE_INF : cs_abs(size_y * inv_dy);
+    const float t_delta_z = step_z == 0 ? YCGE_INF : cs_abs(size_z * inv_dz);
+    int last_axis = enter_axis < 0 ? (t_max_x <= t_max_y && t_max_x <= t_max_z ? 0 : t_max_y <= t_max_z ? 1 : 2) : enter_axis;
+    const uint8_t *cells = S.grid_cells + g.cell_offset;
+    while (t <= t_exit && t <= tmax) {
+        if ((uint32_t)ix < (uint32_t)g.nx && (uint32_t)iy < (uint32_t)g.ny && (uint32_t)iz < (uint32_t)g.nz) {
+            if (COUNT) w.vox++;
+            if (cells[grid_index(g, ix, iy, iz)] != 0) {
+                closest = cs_max(t, tmin);
+                hit_prim = prim_index;
+                hit_sub = (ix + g.nx * (iy + g.ny * iz)) | (last_axis << 30);
+                return;
+            }
+        }
+        if (t_max_x <= t_max_y && t_max_x <= t_max_z) { ix += step_x; t = t_max_x; t_max_x += t_delta_x; last_axis = 0; }
+        else if (t_max_y <= t_max_z) { iy += step_y; t = t_max_y; t_max_y += t_delta_y; last_axis = 1; }
+        else { iz += step_z; t = t_max_z; t_max_z += t_delta_z; last_axis = 2; }
+        if ((uint32_t)ix >= (uint32_t)g.nx || (uint32_t)iy >= (uint32_t)g.ny || (uint32_t)iz >= (uint32_t)g.nz) break;
+    }
+}
+__device__ __forceinline__ double edge_distance(double v, double v0, double v1)   // VolumeGrid.cs:291-296
+{
+    double a = v - v0, b = v1 - v;
+    if (a < 0.0) a = 0.0;
+    if (b < 0.0) b = 0.0;
+    return cs_min_d(a, b);
+}
+__device__ __forceinline__ bool is_wire_on_face(const GGrid &g, F3 p, int ix, int iy, int iz, int axis)   // VolumeGrid.cs:256-283 (fp64)
+{
+    double x0 = (double)(g.min_corner[0] + (float)ix * g.voxel_size[0]); double x1 = x0 + (double)g.voxel_size[0];
+    double y0 = (double)(g.min_corner[1] + (float)iy * g.voxel_size[1]); double y1 = y0 + (double)g.voxel_size[1];
+    double z0 = (double)(g.min_corner[2] + (float)iz * g.voxel_size[2]); double z1 = z0 + (double)g.voxel_size[2];
+    if (axis == 0) {
+        double dy = edge_distance((double)p.y, y0, y1), dz = edge_distance((double)p.z, z0, z1);
+        double wv = (double)(g.wire_width_frac * cs_min(g.voxel_size[1], g.voxel_size[2]));
+        return dy <= wv || dz <= wv;
+    } else if (axis == 1) {
+        double dx = edge_distance((double)p.x, x0, x1), dz = edge_distance((double)p.z, z0, z1);
+        double wv = (double)(g.wire_width_frac * cs_min(g.voxel_size[0], g.voxel_size[2]));
+        return dx <= wv || dz <= wv;
+    }
+    double dx = edge_distance((double)p.x, x0, x1), dy = edge_distance((double)p.y, y0, y1);
+    double wv = (double)(g.wire_width_frac * cs_min(g.voxel_size[0], g.voxel_size[1]));
+    return dx <= wv || dy <= wv;
+}
+
+
+// ------------------------------------------------------------------ per-lane traversal stacks
+// Entries are {reference, tNear}.  The first YCGE_LDS_STACK levels of every lane live in LDS (entry e of
+// thread t at g_lds_stack[e * 256 + t]: consecutive lanes hit consecutive 8-byte slots, so ds_read_b64 /
+// ds_write_b64 are conflict-free whatever the per-lane depth); deeper levels — rare, a near-first DFS
+// stacks one entry per level where both children are hit — go to a preallocated HBM spill area laid out
+// [level][global lane] so that a wavefront's accesses coalesce.  No private arrays: scratch-backed
+// kernels are admitted at about one wavefront per SIMD on this part (measured), which costs far more
+// than the spill traffic.
+#define YCGE_LDS_STACK 12
+#define YCGE_BLOCK 256
+static __shared__ uint2 g_lds_stack[YCGE_LDS_STACK * YCGE_BLOCK];
+static __shared__ unsigned int g_wave_iters[8];   // [wave][node iterations, leaf phases] (profiling aid, COUNT variants)
+__device__ __forceinline__ void prof_tick(int which)
+{
+    const unsigned long long m = __ballot(1);
+    const int lane = threadIdx.x & 63;
+    if ((m & ((1ull << lane) - 1ull)) == 0ull) atomicAdd(&g_wave_iters[(threadIdx.x >> 6) * 2 + which], 1u);
+}
+
+struct Stack {
+    uint2 *spill;          // this lane's column of the spill area
+    uint32_t spill_stride; // lanes in the grid
+    int sp;
+    __device__ __forceinline__ void init(void *spill_base, uint32_t n_lanes)
+    {
+        spill = (uint2 *)spill_base + (blockIdx.x * YCGE_BLOCK + threadIdx.x);
+        spill_stride = n_lanes;
+        sp = 0;
+    }
+    __device__ __forceinline__ void reset() { sp = 0; }
+    __device__ __forceinline__ void push(uint32_t ref, float tnear)
+    {
+        const uint2 v = make_uint2(ref, __float_as_uint(tnear));
+        if (sp < YCGE_LDS_STACK) g_lds_stack[sp * YCGE_BLOCK + threadIdx.x] = v;
+        else spill[(size_t)(sp - YCGE_LDS_STACK) * spill_stride] = v;
+        sp++;
+    }
+    __device__ __forceinline__ bool pop(uint32_t &ref, float &tnear)
+    {
+        if (sp == 0) return false;
+        sp--;
+        uint2 v;
+        if (sp < YCGE_LDS_STACK) v = g_lds_stack[sp * YCGE_BLOCK + threadIdx.x];
+        else v = spill[(size_t)(sp - YCGE_LDS_STACK) * spill_stride];
+        ref = v.x; tnear = __uint_as_float(v.y);
+        return true;
+    }
+};
+
+// MeshBVH.TriHit, MeshBVH.cs:239-304: scaled-numerator Moller-Trumbore, one divide on accept.
+struct TriData { float4 t0, t1; float e2z; };
+__device__ __forceinline__ TriData load_tri(const GTri *tp)
+{
+    TriData r;
+    r.t0 = ((const float4 *)tp)[0];
+    r.t1 = ((const float4 *)tp)[1];
+    r.e2z = ((const float *)tp)[8];
+    return r;
+}
+__device__ __forceinline__ bool tri_hit(const TriData &T, F3 o, F3 d, float tmin, float tmax, float &t)
+{
+    const float ax = T.t0.x, ay = T.t0.y, az = T.t0.z, e1x = T.t0.w, e1y = T.t1.x, e1z = T.t1.y, e2x = T.t1.z, e2y = T.t1.w, e2z = T.e2z;
+    float px = d.y * e2z - d.z * e2y;
+    float py = d.z * e2x - d.x * e2z;
+    float pz = d.x * e2y - d.y * e2x;
+    float det = e1x * px + e1y * py + e1z * pz;
+    if (det > -1e-8f && det < 1e-8f) return false;
+    float sxx = o.x - ax, syy = o.y - ay, szz = o.z - az;
+    float u_num = sxx * px + syy * py + szz * pz;
+    float sgn = det > 0.0f ? 1.0f : -1.0f;
+    float det_abs = det * sgn;
+    float u_num_s = u_num * sgn;
+    if (u_num_s < 0.0f || u_num_s > det_abs) return false;
+    float qx = syy * e1z - szz * e1y;
+    float qy = szz * e1x - sxx * e1z;
+    float qz = sxx * e1y - syy * e1x;
+    float v_num = d.x * qx + d.y * qy + d.z * qz;
+    float v_num_s = v_num * sgn;
+    float uv_sum_s = u_num_s + v_num_s;
+    if (v_num_s < 0.0f || uv_sum_s > det_abs) return false;
+    float t_num = e2x * qx + e2y * qy + e2z * qz;
+    float t_num_s = t_num * sgn;
+    float t_min_scaled = tmin * det_abs;
+    float t_max_scaled = tmax * det_abs;
+    if (t_num_s < t_min_scaled || t_num_s > t_max_scaled) return false;
+    float inv_det = 1.0f / det;
+    t = t_num * inv_det;
+    return true;
+}
+// One leaf (<= 8 triangles, tested in leaf order against the shrinking `closest`).  The records are
+// fetched one triangle AHEAD of the test so that a leaf costs about one memory latency, not one per
+// triangle: traversal time on this workload is the serial latency of its longest wavefronts.
+template <bool COUNT>
+__device__ __forceinline__ void leaf_triangles(const SceneDev &S, uint32_t pay, int mesh_prim, F3 o, F3 d, float tmin, float &closest,
+                                               int &hit_prim, int &hit_sub, Work &w)
+{
+    const uint32_t start = pay >> 4, count = pay & 15u;
+    const GTri *tp = S.tris + start;
+    TriData nxt = load_tri(tp);
+    for (uint32_t i = 0; i < count; i++) {
+        const TriData cur = nxt;
+        if (i + 1 < count) nxt = load_tri(tp + i + 1);
+        if (COUNT) w.tri++;
+        float t;
+        if (tri_hit(cur, o, d, tmin, closest, t)) {
+            closest = t;
+            hit_prim = mesh_prim;
+            hit_sub = (int)(start + i);
+        }
+    }
+}
+
+// ------------------------------------------------------------------ closest-hit traversal
+// Scene.Hit -> BVH.Hit (BVH.cs:99-198) with Mesh -> MeshBVH.Hit (MeshBVH.cs:132-236) run on ONE stack.
+//
+// Visit order and pruning are exactly the reference's:
+//  * children are tested against [tMin, closest]; both hit -> the nearer is visited first and the
+//    other is stacked (ties: `lNear < rNear` false -> right first);
+//  * the reference re-tests a node's own box when it pops it; with the entry distance tNear kept
+//    next to the reference on the stack that re-test is `closest >= tNear` (same predicate, no
+//    re-fetch: the raw slab values cannot change, only `closest` shrank);
+//  * a scene leaf's objects are queued in order; a Mesh object opens its own tree on the same
+//    stack and runs to completion before the next object of the leaf is tried.
+// hit_sub of a mesh hit is the LEAF-ORDER triangle index (resolve_hit maps it back).
+template <bool COUNT, bool HAS_GRID>
+__device__ __forceinline__ void walk(const SceneDev &S, uint32_t cur, int mesh_prim, Stack &st, F3 o, F3 d, F3 inv, bool sx, bool sy, bool sz,
+                                     float tmin, float &closest, int &hit_prim, int &hit_sub, Work &w)
+{
+    for (;;) {
+        if (cur == YCGE_REF_NONE_VALUE) {
+            float tn;
+            if (!st.pop(cur, tn)) break;
+            if (!(closest >= tn)) { cur = YCGE_REF_NONE_VALUE; continue; }
+        }
+        const uint32_t kind = YCGE_REF_KIND(cur), pay = YCGE_REF_PAYLOAD(cur);
+        if (kind == REF_MESH_NODE || kind == REF_SCENE_NODE) {
+            const float4 *np = (const float4 *)((kind == REF_MESH_NODE ? S.mesh_nodes : S.scene_nodes) + pay);
+            const float4 a = np[0], b = np[1], c = np[2], e = np[3];
+            float ln, rn;
+            bool hl, hr;
+            if (COUNT) w.box += 2;
+            if (kind == REF_MESH_NODE) {
+                hl = box_mesh(a.x, a.y, a.z, a.w, b.x, b.y, o, inv, sx, sy, sz, tmin, closest, ln);
+                hr = box_mesh(b.z, b.w, c.x, c.y, c.z, c.w, o, inv, sx, sy, sz, tmin, closest, rn);
+            } else {
+                hl = box_scene(a.x, a.y, a.z, a.w, b.x, b.y, o, inv, tmin, closest, ln);
+                hr = box_scene(b.z, b.w, c.x, c.y, c.z, c.w, o, inv, tmin, closest, rn);
+            }
+            const uint32_t lref = __float_as_uint(e.x), rref = __float_as_uint(e.y);
+            if (hl & hr) {
+                if (ln < rn) { st.push(rref, rn); cur = lref; }
+                else { st.push(lref, ln); cur = rref; }
+            } else if (hl) cur = lref;
+            else if (hr) cur = rref;
+            else cur = YCGE_REF_NONE_VALUE;
+        } else if (kind == REF_MESH_LEAF) {
+            leaf_triangles<COUNT>(S, pay, mesh_prim, o, d, tmin, closest, hit_prim, hit_sub, w);
+            cur = YCGE_REF_NONE_VALUE;
+        } else if (kind == REF_SCENE_LEAF) {
+            const uint32_t start = pay >> 3, count = pay & 7u;
+            for (uint32_t i = count - 1; i >= 1; i--) st.push(YCGE_REF(REF_PRIM, S.scene_leaf_prims[start + i]), -YCGE_INF);
+            cur = YCGE_REF(REF_PRIM, S.scene_leaf_prims[start]);
+        } else {    // REF_PRIM: objectHit[objId](r, tMin, closest, ...), BVH.cs:139-149
+            const float4 *pp = (const float4 *)(S.prims + pay);
+            const float4 q0 = pp[0], q1 = pp[1], q2 = pp[2], q3 = pp[3];
+            const int type = __float_as_int(q0.x);
+            cur = YCGE_REF_NONE_VALUE;
+            if (type == 9) {            // Mesh.Hit -> MeshBVH.Hit: root pushed, popped, own box tested (p = root box, ref)
+                const uint32_t root_ref = __float_as_uint(q2.z);
+                if (root_ref != YCGE_REF_NONE_VALUE) {
+                    float tn;
+                    if (COUNT) w.box++;
+                    if (box_mesh(q1.x, q1.y, q1.z, q1.w, q2.x, q2.y, o, inv, sx, sy, sz, tmin, closest, tn)) {
+                        cur = root_ref;
+                        mesh_prim = (int)pay;
+                    }
+                }
+            } else if (type == 10) {
+                if (HAS_GRID) grid_dda<COUNT>(S, __float_as_int(q0.z), (int)pay, o, d, tmin, closest, hit_prim, hit_sub, w);
+            } else {
+                analytic_prim<COUNT>(q0, q1, q2, q3, type, (int)pay, o, d, tmin, closest, hit_prim, hit_sub, w);
+            }
+        }
+    }
+}
+
+// MeshBVH.Hit (MeshBVH.cs:132-236) for one mesh as a UNIFIED-STEP loop: in every iteration each live lane
+// either visits one internal node (one 64-byte fetch, two slab tests, order, stack the far child) or tests
+// one triangle of its current leaf (36-byte fetch), whichever it is at.  Both fetches are issued as the
+// same load sequence from a per-lane address, so an iteration has ONE memory wait.  The kernel's duration
+// is the serial latency chain of its slowest wavefront (measured: tens of x the mean), and this form makes
+// a wavefront's iteration count ~ max over lanes of (nodes + triangles) instead of the sum over "rounds"
+// of the slowest lane per round that a while-while loop pays.  Visit order is unchanged.
+template <bool COUNT>
+__device__ __forceinline__ void mesh_walk(const SceneDev &S, uint32_t cur, int mesh_prim, Stack &st, F3 o, F3 inv, F3 d, bool sx, bool sy,
+                                          bool sz, float tmin, float &closest, int &hit_prim, int &hit_sub, Work &w)
+{
+    while (cur != YCGE_REF_NONE_VALUE) {
+        const bool is_node = YCGE_REF_KIND(cur) == REF_MESH_NODE;
+        const uint32_t pay = YCGE_REF_PAYLOAD(cur);
+        const uint32_t tri_index = pay >> 4;
+        const float4 *addr = is_node ? (const float4 *)(S.mesh_nodes + pay) : (const float4 *)(S.tris + tri_index);
+        const float4 a = addr[0], b = addr[1], c = addr[2];
+        if (COUNT) prof_tick(0);
+        if (is_node) {
+            const uint2 e = *(const uint2 *)(addr + 3);
+            float ln, rn;
+            if (COUNT) w.box += 2;
+            const bool hl = box_mesh(a.x, a.y, a.z, a.w, b.x, b.y, o, inv, sx, sy, sz, tmin, closest, ln);
+            const bool hr = box_mesh(b.z, b.w, c.x, c.y, c.z, c.w, o, inv, sx, sy, sz, tmin, closest, rn);
+            if (hl & hr) {
+                if (ln < rn) { st.push(e.y, rn); cur = e.x; }
+                else { st.push(e.x, ln); cur = e.y; }
+            } else if (hl) cur = e.x;
+            else if (hr) cur = e.y;
+            else cur = YCGE_REF_NONE_VALUE;
+        } else {
+            TriData T; T.t0 = a; T.t1 = b; T.e2z = c.x;
+            if (COUNT) w.tri++;
+            float t;
+            if (tri_hit(T, o, d, tmin, closest, t)) { closest = t; hit_prim = mesh_prim; hit_sub = (int)tri_index; }
+            const uint32_t left = (pay & 15u) - 1u;
+            cur = left ? YCGE_REF(REF_MESH_LEAF, ((tri_index + 1u) << 4) | left) : YCGE_REF_NONE_VALUE;
+        }
+        if (cur == YCGE_REF_NONE_VALUE) {
+            float tn; uint32_t r;
+            while (st.pop(r, tn)) { if (closest >= tn) { cur = r; break; } }
+        }
+    }
+}
+
+// One closest-hit query.  FLAT (the whole scene is one BVH leaf, <= 4 objects: every mesh-viewer scene of
+// the reference): the object list is walked in leaf order with WAVE-UNIFORM control flow, so object records
+// come through the scalar cache and only the per-lane mesh walk diverges.  Otherwise the generic walk
+// starts at the scene root.  Both give the reference's visit order.
+template <bool COUNT, bool HAS_GRID, bool FLAT>
+__device__ __forceinline__ void traverse(const SceneDev &S, const RayQ &q, Stack &st, float &closest, int &hit_prim, int &hit_sub, Work &w)
+{
+    const F3 o = q.o, d = q.d;
+    const float tmin = q.tmin;
+    closest = q.tmax;
+    hit_prim = -1;
+    hit_sub = 0;
+    st.reset();
+    if (COUNT) w.rays++;
+    if (S.scene_root_ref == YCGE_REF_NONE_VALUE) return;
+    const F3 inv = f3(1.0f / d.x, 1.0f / d.y, 1.0f / d.z);
+    const bool sx = inv.x < 0.0f, sy = inv.y < 0.0f, sz = inv.z < 0.0f;
+    float tn;
+    if (COUNT) w.box++;
+    const bool root_hit = box_scene(S.scene_root_min[0], S.scene_root_min[1], S.scene_root_min[2], S.scene_root_max[0], S.scene_root_max[1],
+                                    S.scene_root_max[2], o, inv, tmin, closest, tn);
+    if (!FLAT) {
+        walk<COUNT, HAS_GRID>(S, root_hit ? S.scene_root_ref : YCGE_REF_NONE_VALUE, -1, st, o, d, inv, sx, sy, sz, tmin, closest, hit_prim, hit_sub, w);
+        return;
+    }
+    const uint32_t leaf_start = YCGE_REF_PAYLOAD(S.scene_root_ref) >> 3;
+    const int n_top = (int)(YCGE_REF_PAYLOAD(S.scene_root_ref) & 7u);
+    for (int i = 0; i < n_top; i++) {
+        const int pi = (int)S.scene_leaf_prims[leaf_start + i];               // uniform address -> scalar loads
+        const float4 *pp = (const float4 *)(S.prims + pi);
+        const float4 q0 = pp[0], q1 = pp[1], q2 = pp[2], q3 = pp[3];
+        const int type = __float_as_int(q0.x);
+        if (type == 9) {
+            uint32_t start = YCGE_REF_NONE_VALUE;
+            const uint32_t root_ref = __float_as_uint(q2.z);
+            if (root_hit && root_ref != YCGE_REF_NONE_VALUE) {
+                float tm;
+                if (COUNT) w.box++;
+                if (box_mesh(q1.x, q1.y, q1.z, q1.w, q2.x, q2.y, o, inv, sx, sy, sz, tmin, closest, tm)) start = root_ref;
+            }
+            mesh_walk<COUNT>(S, start, pi, st, o, inv, d, sx, sy, sz, tmin, closest, hit_prim, hit_sub, w);
+        } else if (type == 10) {
+            if (HAS_GRID) { if (root_hit) grid_dda<COUNT>(S, __float_as_int(q0.z), pi, o, d, tmin, closest, hit_prim, hit_sub, w); }
+        } else {
+            if (root_hit) analytic_prim<COUNT>(q0, q1, q2, q3, type, pi, o, d, tmin, closest, hit_prim, hit_sub, w);
+        }
+    }
+}
+
+// ------------------------------------------------------------------ hit attributes
+// Rebuild HitRecord {P, N, Mat} of the winning primitive from (prim, sub, t) with the same
+// expressions its C# Hit() uses, so the values are the bits the reference would have stored.
+struct HitAttr {
+    F3 p, n;
+    MatEval m;
+    int sub_public;     // triangle index in input order / box face / voxel cell
+};
+template <bool HAS_GRID>
+__device__ __forceinline__ void resolve_hit(const SceneDev &S, int prim_index, int sub, float t, F3 o, F3 d, HitAttr &h)
+{
+    const GPrim *P = S.prims + prim_index;
+    const float4 q0 = ((const float4 *)P)[0];
+    const int type = __float_as_int(q0.x);
+    int material = __float_as_int(q0.y);
+    const float refl_override = q0.w;
+    bool override_refl = false;
+    bool wire_black = false;
+    h.sub_public = sub;
+    if (type == 9) {    // MeshBVH.cs:177-185
+        const float4 *tp = (const float4 *)(S.tris + sub);
+        const float4 t0 = tp[0], t1 = tp[1], t2 = tp[2];
+        const float e1x = t0.w, e1y = t1.x, e1z = t1.y, e2x = t1.z, e2y = t1.w, e2z = t2.x;
+        // unit normal exactly as the MeshBVH ctor computes it, MeshBVH.cs:93-97
+        float nnx = e1y * e2z - e1z * e2y;
+        float nny = e1z * e2x - e1x * e2z;
+        float nnz = e1x * e2y - e1y * e2x;
+        float inv_len = 1.0f / cs_max(1e-20f, cs_sqrt(nnx * nnx + nny * nny + nnz * nnz));
+        float nx = nnx * inv_len, ny = nny * inv_len, nz = nnz * inv_len;
+        h.p = f3(o.x + t * d.x, o.y + t * d.y, o.z + t * d.z);
+        float ndotd = nx * d.x + ny * d.y + nz * d.z;
+        h.n = ndotd < 0.0f ? f3(nx, ny, nz) : f3(-nx, -ny, -nz);
+        material = __float_as_int(t2.z);
+        h.sub_public = __float_as_int(t2.y);
+    } else if (type == 10) {   // VolumeGrid.cs:160-198
+        if (HAS_GRID) {
+            const GGrid g = S.grids[__float_as_int(q0.z)];
+            const int axis = (int)((uint32_t)sub >> 30);
+            const int cell = sub & 0x3fffffff;
+            const int ix = cell % g.nx, iy = (cell / g.nx) % g.ny, iz = cell / (g.nx * g.ny);
+            h.sub_public = cell;
+            if (axis == 0) h.n = f3(d.x > 0.0f ? -1.0f : 1.0f, 0.0f, 0.0f);
+            else if (axis == 1) h.n = f3(0.0f, d.y > 0.0f ? -1.0f : 1.0f, 0.0f);
+            else h.n = f3(0.0f, 0.0f, d.z > 0.0f ? -1.0f : 1.0f);
+            h.p = f3(o.x + d.x * t, o.y + d.y * t, o.z + d.z * t);     // Ray.At
+            const uint8_t code = S.grid_cells[g.cell_offset + grid_index(g, ix, iy, iz)];
+            material = S.grid_lut[g.lut_offset + code];
+            if (g.wireframe) {
+                const float wire_max2 = g.wire_max_distance <= 0.0f ? -1.0f : g.wire_max_distance * g.wire_max_distance;
+                bool within = false;
+                if (wire_max2 >= 0.0f) {
+                    float dir_len2 = d.x * d.x + d.y * d.y + d.z * d.z;
+                    float dist2 = t * t * dir_len2;
+                    within = dist2 <= wire_max2;
+                }
+                // centre-block highlight (VolumeGrid.cs:176-187): shared mutable state raced by all pixel
+                // threads in the reference; unreachable when hiW or hiH is even.  Not modelled.
+                if (within && is_wire_on_face(g, h.p, ix, iy, iz, axis)) wire_black = true;
+            }
+        }
+    } else {
+        const float4 q1 = ((const float4 *)P)[1], q2 = ((const float4 *)P)[2], q3 = ((const float4 *)P)[3];
+        const float p[12] = {q1.x, q1.y, q1.z, q1.w, q2.x, q2.y, q2.z, q2.w, q3.x, q3.y, q3.z, q3.w};
+        switch (type) {
+        case 0: {
+            float px = o.x + t * d.x, py = o.y + t * d.y, pz = o.z + t * d.z;
+            float inv_r = 1.0f / p[3];
+            h.p = f3(px, py, pz);
+            h.n = f3((px - p[0]) * inv_r, (py - p[1]) * inv_r, (pz - p[2]) * inv_r);
+            break;
+        }
+        case 1: {
+            float denom = p[0] * d.x + p[1] * d.y + p[2] * d.z;
+            h.p = f3(o.x + t * d.x, o.y + t * d.y, o.z + t * d.z);
+            h.n = denom < 0.0f ? f3(p[0], p[1], p[2]) : f3(-p[0], -p[1], -p[2]);
+            override_refl = true;
+            break;
+        }
+        case 2: {
+            F3 n = f3(p[3], p[4], p[5]);
+            float denom = dot(n, d);
+            h.p = f3(o.x + t * d.x, o.y + t * d.y, o.z + t * d.z);
+            h.n = denom < 0.0f ? n : -n;
+            override_refl = true;
+            break;
+        }
+        case 3: case 4: case 5: case 6: {
+            int axis; float a0, a1, b0, b1, k;
+            if (type == 6) box_face(p, sub, axis, a0, a1, b0, b1, k);
+            else { axis = type == 3 ? 2 : type == 4 ? 1 : 0; a0 = p[0]; a1 = p[1]; b0 = p[2]; b1 = p[3]; k = p[4]; }
+            float dir_k = axis == 2 ? d.z : axis == 1 ? d.y : d.x;
+            float nk = cs_copysign(1.0f, -dir_k);
+            if (axis == 2) { h.p = f3(o.x + t * d.x, o.y + t * d.y, k); h.n = f3(0.0f, 0.0f, nk); }
+            else if (axis == 1) { h.p = f3(o.x + t * d.x, k, o.z + t * d.z); h.n = f3(0.0f, nk, 0.0f); }
+            else { h.p = f3(k, o.y + t * d.y, o.z + t * d.z); h.n = f3(nk, 0.0f, 0.0f); }
+            override_refl = true;
+            break;
+        }
+        case 7: {
+            float ox = o.x - p[0], oz = o.z - p[1];
+            F3 hn;
+            if (sub == 0) hn = f3((ox + t * d.x) / p[2], 0.0f, (oz + t * d.z) / p[2]);
+            else if (sub == 1) hn = f3(0.0f, 1.0f, 0.0f);
+            else hn = f3(0.0f, -1.0f, 0.0f);
+            h.p = f3(o.x + t * d.x, o.y + t * d.y, o.z + t * d.z);
+            h.n = dot(hn, d) < 0.0f ? hn : -hn;
+            break;
+        }
+        default: {  // 8 Triangle
+            h.p = f3(o.x + t * d.x, o.y + t * d.y, o.z + t * d.z);
+            float nd = p[9] * d.x + p[10] * d.y + p[11] * d.z;
+            h.n = nd < 0.0f ? f3(p[9], p[10], p[11]) : f3(-p[9], -p[10], -p[11]);
+            break;
+        }
+        }
+    }
+    h.m = eval_material(S, material, h.p);
+    if (override_refl) h.m.reflectivity = refl_override;
+    if (wire_black) h.m.albedo = f3(0.0f, 0.0f, 0.0f);
+}
+
+} // namespace ycge
