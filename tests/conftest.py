@@ -14,7 +14,19 @@ def pytest_configure(config):
 
 
 @pytest.fixture(scope="session")
-def product_lib():
+def torch_hip_first():
+    """When torch is going to share the process (device buffers for the all-gather), let it bring up the HIP
+    runtime BEFORE libycge_hip.so is loaded, so that both resolve to one libamdhip64 (bench.py does the same)."""
+    try:
+        import torch
+        if torch.cuda.is_available():
+            torch.zeros(1, device="cuda")
+    except Exception:
+        pass
+
+
+@pytest.fixture(scope="session")
+def product_lib(torch_hip_first):
     """libycge_hip.so — must exist (built by __graft_entry__.build()); never substituted."""
     from yetanotherconsolegameengine_amd import abi, build
     build.build_library()

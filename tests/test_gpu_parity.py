@@ -1,29 +1,44 @@
 """-m gpu: the HIP path against the oracle through the C-ABI, on the same seeded inputs.
 
 Bars (north_star / SURVEY 8d): primary hit index and t bit-exact, integer RNG state bit-exact,
-traversal counters equal, radiance RMS <= 1e-4 (we additionally report exact-bit mismatch counts).
+traversal counters equal, radiance RMS <= 1e-4 — the implementation is in fact bit-exact on every
+buffer, which the tests report and the strict ones require.  Every test runs on both device paths
+(wavefront stage pipeline and single-launch kernel; YCGE_PATH selects).
 """
+import ctypes as C
+
 import numpy as np
 import pytest
 
 import parity_util as pu
-from yetanotherconsolegameengine_amd import abi, scenes
+from yetanotherconsolegameengine_amd import abi, scenes, tiles
+from yetanotherconsolegameengine_amd.renderer import RaytraceRenderer
+from yetanotherconsolegameengine_amd.scene import (AmbientLight, Box, Checker, CylinderY, Disk, Material, Mesh, Plane, PointLight,
+                                                   Scene, Solid, Sphere, Triangle, XZRect, flatten, vec3, ZERO)
 
 pytestmark = pytest.mark.gpu
 
 
-def _assert_parity(stats, label):
+@pytest.fixture(params=["wavefront", "megakernel"])
+def path(request, monkeypatch):
+    monkeypatch.setenv("YCGE_PATH", request.param)
+    return request.param
+
+
+def _assert_parity(stats, label, exact=True):
     print(label, stats)
     for k in ("rays", "prim_id", "sub_id", "hit_t", "rng_state", "sky", "g_depth"):
         assert stats[k + "_mismatch"] == 0, f"{label}: {k} differs in {stats[k + '_mismatch']} elements"
     for k in ("current_hdr", "taa_history", "g_albedo", "g_normal"):
-        assert stats[k + "_rms"] <= pu.RMS_TOL, f"{label}: {k} RMS {stats[k + '_rms']}"
+        assert stats[k + "_rms"] <= pu.RMS_TOL, f"{label}: {k} RMS {stats[k + '_rms']}"      # north_star tolerance: 1e-4 RMS
+        if exact:
+            assert stats[k + "_mismatch"] == 0, f"{label}: {k} not bit-exact ({stats[k + '_mismatch']} elements)"
     for k in ("n_rays", "n_box", "n_tri", "n_prim", "n_vox"):
         assert stats[k][0] == stats[k][1], f"{label}: counter {k} oracle {stats[k][0]} != hip {stats[k][1]}"
 
 
 @pytest.mark.parametrize("cfg_n", [1, 2])
-def test_analytic_scenes_three_frames(product_lib, oracle, cfg_n):
+def test_analytic_scenes_three_frames(product_lib, oracle, path, cfg_n):
     sc, w, h, ss, pose = scenes.config_scene(cfg_n)
     o, g = pu.run_pair(oracle, sc, w, h, ss, pose, frames=1)
     _assert_parity(pu.compare_frame(o, g), f"cfg{cfg_n} frame1")
@@ -33,24 +48,172 @@ def test_analytic_scenes_three_frames(product_lib, oracle, cfg_n):
     o.close(); g.close()
 
 
-def test_bunny_reduced_resolution(product_lib, oracle):
+def test_committed_goldens_on_gpu(product_lib, path):
+    """The HIP path against the committed oracle fixture (no oracle run involved)."""
+    z = np.load(scenes.GOLDEN_DIR / "cornell_80x45_frames123.npz")
+    sc, w, h, ss, pose = scenes.config_scene(1)
+    with RaytraceRenderer(sc, w, h, pose["fov"], ss, capture_debug=True) as g:
+        g.SetCamera(pose["pos"], pose["yaw"], pose["pitch"])
+        for frame in (1, 2, 3):
+            g.TryFlipAndBlit()
+            if frame == 1:
+                for name, which in (("rays", abi.BUF_RAYS), ("prim_id", abi.BUF_PRIM_ID), ("sub_id", abi.BUF_SUB_ID), ("hit_t", abi.BUF_HIT_T),
+                                    ("current_hdr", abi.BUF_CURRENT_HDR), ("rng_state", abi.BUF_RNG_STATE)):
+                    assert pu.bits_equal(g.read(which), z[f"f1_{name}"]), name
+            assert pu.bits_equal(g.read(abi.BUF_TAA_HISTORY), z[f"f{frame}_taa_history"]), frame
+
+
+def _zoo_scene(transparent: bool):
+    """Every primitive class + checker + emissive + a true mirror (>= 0.9) and, optionally, glass."""
+    s = Scene()
+    s.Ambient = AmbientLight(vec3(1, 1, 1), 0.05)
+    s.Add(Plane(vec3(0, 0, 0), vec3(0, 1, 0), Checker(vec3(0.75, 0.75, 0.75), vec3(0.2, 0.2, 0.2), 0.8), 0.05, 0.0))
+    s.Add(CylinderY(vec3(-1.2, 0.0, -3.0), 0.6, 0.0, 1.6, True, Material(vec3(0.2, 0.35, 0.9), 0.1, 0.0, ZERO)))
+    s.Add(Disk(vec3(1.6, 0.01, -2.2), vec3(0, 1, 0), 0.9, Solid(vec3(0.8, 0.8, 0.1)), 0.0, 0.0))
+    s.Add(Triangle(vec3(0.2, 0.0, -3.6), vec3(1.3, 1.4, -3.0), vec3(-0.7, 0.7, -2.8), Material(vec3(0.9, 0.25, 0.25), 0.1, 0.0, ZERO)))
+    s.Add(Sphere(vec3(2.4, 0.8, -4.0), 0.8, Material(vec3(0.98, 0.98, 0.98), 0.0, 0.95, ZERO)))             # mirror branch
+    s.Add(Box(vec3(-2.8, 0.0, -5.5), vec3(-1.6, 1.2, -4.3), Solid(vec3(0.86, 0.86, 0.86)), 0.1, 0.92))       # mirror via ctor override
+    s.Add(XZRect(-0.5, 0.5, -2.6, -2.0, 1.9, Material(vec3(0, 0, 0), 0.0, 0.0, vec3(2.0, 1.8, 1.5)), 0.0, 0.0))  # emissive panel
+    if transparent:
+        s.Add(Sphere(vec3(0.3, 0.6, -1.9), 0.6, Material(vec3(1, 1, 1), 0.0, 0.05, ZERO, 0.9, 1.5, vec3(0.9, 1.0, 0.9))))
+        s.Add(Sphere(vec3(-0.6, 0.4, -1.6), 0.4, Material(vec3(1, 1, 1), 0.0, 0.0, ZERO, 0.6, 1.33, vec3(1.0, 0.8, 0.8))))
+    pos, faces = scenes.make_torus_knot(60, 16)
+    s.Add(Mesh((pos[faces] * np.float32(0.25) + np.float32([-0.2, 1.9, -3.2])).astype(np.float32), Material(vec3(0.3, 0.8, 0.4))))
+    s.Lights.append(PointLight(vec3(-2.2, 3.2, -2.0), vec3(1.0, 0.95, 0.9), 70.0))
+    s.Lights.append(PointLight(vec3(2.4, 2.2, -1.4), vec3(0.9, 0.95, 1.0), 60.0))
+    s.Lights.append(PointLight(vec3(0.0, 0.5, 3.0), vec3(1, 1, 1), 0.0))       # zero intensity still costs a shadow ray (quirk 8)
+    s.BackgroundTop, s.BackgroundBottom = vec3(0.58, 0.78, 1.0), vec3(0.95, 0.98, 1.0)
+    return s
+
+
+@pytest.mark.parametrize("transparent", [False, True])
+def test_every_primitive_mirror_and_glass(product_lib, oracle, path, transparent):
+    pose = dict(pos=(0.1, 1.2, 1.0), yaw=0.05, pitch=-0.12, fov=50.0)
+    o, g = pu.run_pair(oracle, _zoo_scene(transparent), 192, 54, 1, pose, frames=2)
+    st = pu.compare_frame(o, g)
+    _assert_parity(st, f"zoo transparent={transparent}")
+    pid = g.read(abi.BUF_PRIM_ID)
+    assert set(np.unique(pid)) >= set(range(0, 7))        # every analytic primitive is seen by some primary ray
+    o.close(); g.close()
+
+
+def test_bunny_full_resolution(product_lib, oracle, path):
     sc, w, h, ss, pose = scenes.config_scene(3)
-    o, g = pu.run_pair(oracle, sc, 320, 90, 1, pose, frames=2)
-    _assert_parity(pu.compare_frame(o, g), "cfg3 320x180")
+    o, g = pu.run_pair(oracle, sc, w, h, ss, pose, frames=2, oracle_threads=32)
+    _assert_parity(pu.compare_frame(o, g), "cfg3 1280x720")
     assert pu.bits_equal(o.accel(abi.ACCEL_MESH_NODES), g.accel(abi.ACCEL_MESH_NODES))
     assert pu.bits_equal(o.accel(abi.ACCEL_MESH_LEAF_INDEX), g.accel(abi.ACCEL_MESH_LEAF_INDEX))
     o.close(); g.close()
 
 
-def test_dragon_standin_small(product_lib, oracle):
-    sc, w, h, ss, pose = scenes.config_scene(4, small=True)
-    o, g = pu.run_pair(oracle, sc, 256, 72, 1, pose, frames=2)
-    _assert_parity(pu.compare_frame(o, g), "cfg4-small")
+def test_dragon_standin_full_size(product_lib, oracle, path):
+    """BASELINE config 4 at its full size: 871,200 triangles, 1920x1080 trace grid."""
+    sc, w, h, ss, pose = scenes.config_scene(4)
+    o, g = pu.run_pair(oracle, sc, w, h, ss, pose, frames=1, oracle_threads=64)
+    _assert_parity(pu.compare_frame(o, g), "cfg4 1920x1080")
+    hdr = g.read(abi.BUF_CURRENT_HDR)
+    assert np.isfinite(hdr).all() and (hdr >= 0).all()
     o.close(); g.close()
 
 
-def test_voxel_world_small(product_lib, oracle):
+def test_voxel_world_small_and_ss2(product_lib, oracle, path):
     sc, w, h, ss, pose = scenes.config_scene(5, small=True)
     o, g = pu.run_pair(oracle, sc, 160, 45, 2, pose, frames=2)
     _assert_parity(pu.compare_frame(o, g), "cfg5-small ss2")
+    o.close(); g.close()
+
+
+def test_voxel_world_wireframe_close_up(product_lib, oracle, path):
+    """Camera a few voxels from a wall so that the fp64 wire test (VolumeGrid.cs:256-283) decides pixels."""
+    sc, w, h, ss, pose = scenes.config_scene(5, small=True)
+    pose = dict(pose, pitch=-0.9)
+    o, g = pu.run_pair(oracle, sc, 128, 36, 1, pose, frames=1)
+    st = pu.compare_frame(o, g)
+    _assert_parity(st, "cfg5-small close-up")
+    alb = g.read(abi.BUF_G_ALBEDO); sky = g.read(abi.BUF_SKY_MASK)
+    assert ((alb.sum(-1) == 0) & (sky == 0)).any()        # black wire pixels exist
+    o.close(); g.close()
+
+
+def test_taa_reset_rules_and_resize(product_lib, oracle, path):
+    sc, w, h, ss, pose = scenes.config_scene(2)
+    o, g = pu.run_pair(oracle, sc, 160, 45, 1, pose, frames=2)
+    assert g.stats.history_reset == 0 and o.stats.history_reset == 0
+    # move below the threshold (0.0025): no reset; above: reset (TemporalAA.cs:58-67)
+    for dx, expect in ((0.001, 0), (0.01, 1)):
+        p = (pose["pos"][0] + dx, pose["pos"][1], pose["pos"][2])
+        o.set_camera(p, pose["yaw"], pose["pitch"]); g.SetCamera(p, pose["yaw"], pose["pitch"])
+        o.render(stages=1, threads=8); g.TryFlipAndBlit()
+        assert g.stats.history_reset == expect == o.stats.history_reset
+        _assert_parity(pu.compare_frame(o, g), f"taa move {dx}")
+        pose = dict(pose, pos=p)
+    g.Resize(96, 27, 2)
+    assert g.hiW == 192 and g.hiH == 108
+    g.TryFlipAndBlit()
+    assert g.stats.history_reset == 1 and g.read(abi.BUF_TAA_HISTORY).shape == (108, 192, 3)
+    o.close(); g.close()
+
+
+def test_error_codes(product_lib, path):
+    c = abi.default_config()
+    ctx = C.c_void_p()
+    assert product_lib.ycge_create(C.byref(c), C.byref(ctx)) == 0
+    assert product_lib.ycge_render_frame(ctx, None, None) == abi.YCGE_ERR_NO_SCENE          # Scene.cs:73
+    assert b"BVH" in product_lib.ycge_last_error(ctx)
+    assert product_lib.ycge_scene_upload(ctx, None) == abi.YCGE_ERR_INVALID_ARG
+    assert product_lib.ycge_resize(ctx, 0, 10, 1) == abi.YCGE_ERR_INVALID_ARG
+    assert product_lib.ycge_read_buffer(ctx, abi.BUF_RAYS, C.c_void_p(1), 4) == abi.YCGE_ERR_INVALID_ARG   # needs capture_debug
+    empty = flatten(Scene())
+    assert product_lib.ycge_scene_upload(ctx, empty.byref()) == 0                            # empty Objects: every ray is sky
+    assert product_lib.ycge_render_frame(ctx, None, None) == 0
+    product_lib.ycge_destroy(ctx)
+
+
+def test_two_rank_tile_split_matches_single_gpu(product_lib, path):
+    """world_size 2 emulated on one GPU: two contexts trace their tiles, slabs are concatenated as an
+    all-gather would, both resolve; results equal the single-context frame bit for bit."""
+    sc, w, h, ss, pose = scenes.config_scene(1)
+    flat = flatten(sc)
+    import torch
+    def mk(rank, world):
+        r = RaytraceRenderer(flat, w, h, pose["fov"], ss, rank=rank, world_size=world)
+        r.SetCamera(pose["pos"], pose["yaw"], pose["pitch"])
+        return r
+    single = mk(0, 1)
+    ranks = [mk(0, 2), mk(1, 2)]
+    nb = ranks[0].tile_slab_bytes()
+    assert nb == ranks[1].tile_slab_bytes() == tiles.slab_floats(2, tiles.tile_grid(single.hiW, single.hiH)[2]) * 4
+    for frame in range(3):
+        single.TryFlipAndBlit()
+        gathered = torch.zeros(2 * nb // 4, dtype=torch.float32, device="cuda")
+        for i, r in enumerate(ranks):
+            r.trace_tiles(gathered[i * nb // 4:].data_ptr(), 0, want_stats=True)
+        torch.cuda.synchronize()
+        for r in ranks:
+            r.resolve_gathered(gathered.data_ptr(), 0, want_stats=True)
+        for which in (abi.BUF_CURRENT_HDR, abi.BUF_G_ALBEDO, abi.BUF_G_NORMAL, abi.BUF_G_DEPTH, abi.BUF_SKY_MASK, abi.BUF_TAA_HISTORY):
+            ref = single.read(which)
+            for r in ranks:
+                assert pu.bits_equal(ref, r.read(which)), (frame, which)
+        # the device slab layout is the documented one (tiles.py)
+        hdr, alb, nrm = single.read(abi.BUF_CURRENT_HDR), single.read(abi.BUF_G_ALBEDO), single.read(abi.BUF_G_NORMAL)
+        full = np.concatenate([hdr, alb, nrm, single.read(abi.BUF_G_DEPTH)[..., None], single.read(abi.BUF_SKY_MASK)[..., None].astype(np.float32)], -1)
+        assert np.array_equal(tiles.unpermute(gathered.cpu().numpy(), single.hiW, single.hiH, 2), full)
+    for r in ranks + [single]:
+        r.close()
+
+
+def test_update_lights_per_frame(product_lib, oracle, path):
+    """DayNightEntity-style per-frame light / sky animation through ycge_scene_update_lights."""
+    sc, w, h, ss, pose = scenes.config_scene(5, small=True)
+    o, g = pu.run_pair(oracle, sc, 96, 27, 1, pose, frames=1)
+    lights, top, bottom = scenes.sun_moon_lights(0.31)
+    g.UpdateLights(lights, sc.Ambient, top, bottom)
+    arr = (abi.Light * len(lights))()
+    for i, l in enumerate(lights):
+        arr[i].position, arr[i].color, arr[i].intensity = abi.Vec3(*l.Position), abi.Vec3(*l.Color), float(l.Intensity)
+    amb, t_, b_ = abi.Vec3(*sc.Ambient.Color), abi.Vec3(*top), abi.Vec3(*bottom)
+    assert o.L.orc_scene_update_lights(o.ctx, arr, len(lights), C.byref(amb), float(sc.Ambient.Intensity), C.byref(t_), C.byref(b_)) == 0
+    o.render(stages=1, threads=8); g.TryFlipAndBlit()
+    _assert_parity(pu.compare_frame(o, g), "lights updated")
     o.close(); g.close()

@@ -1,0 +1,256 @@
+"""Known-answer tests pinning the ORACLE (CPU only).
+
+The reference has no tests or golden vectors for this path ("parity unpinned"), so the oracle is pinned by
+(1) KATs derived independently here from the cited formulas with plain Python integer / numpy-float32
+arithmetic, (2) analytic cases, (3) structural invariants, (4) committed golden buffers (regression).
+"""
+import ctypes as C
+import math
+
+import numpy as np
+import pytest
+
+import oracle_binding as ob
+from yetanotherconsolegameengine_amd import abi, scenes
+from yetanotherconsolegameengine_amd.scene import (Box, CylinderY, Disk, Material, Plane, PointLight, Scene, Solid, Sphere,
+                                                   Triangle, XYRect, XZRect, YZRect, vec3, ZERO)
+
+M64 = (1 << 64) - 1
+SALT = 0x9E3779B97F4A7C15
+f32 = np.float32
+
+
+# ---- independent restatement of RaytraceSampler.cs:43-80 in Python integers ------------------------
+def py_splitmix64(z):
+    z = (z + 0x9E3779B97F4A7C15) & M64
+    z = ((z ^ (z >> 30)) * 0xBF58476D1CE4E5B9) & M64
+    z = ((z ^ (z >> 27)) * 0x94D049BB133111EB) & M64
+    return z ^ (z >> 31)
+
+
+def py_seed(x, y, frame, jx=0, jy=0, salt=SALT):
+    h = 1469598103934665603
+    h ^= (x * 0x9E3779B97F4A7C15) & M64; h = py_splitmix64(h)
+    h ^= (y * 0xC2B2AE3D27D4EB4F) & M64; h = py_splitmix64(h)
+    h ^= (frame * 0x165667B19E3779F9) & M64; h = py_splitmix64(h)
+    h ^= ((jx & 0xff) << 8) ^ (jy & 0xff); h = py_splitmix64(h)
+    h ^= salt; h = py_splitmix64(h)
+    return h
+
+
+def py_next_unit(state):
+    state = py_splitmix64(state)
+    m24 = state >> 40
+    return state, f32(f32(m24) + f32(0.5)) * f32(1.0 / 16777216.0)
+
+
+def bits(x):
+    return int(np.float32(x).view(np.uint32))
+
+
+def test_splitmix_and_seed_kats():
+    L = ob.lib()
+    assert L.orc_splitmix64(0) == 0xE220A8397B1DCDAF == py_splitmix64(0)
+    for (x, y, fr), want in {(0, 0, 1): 0x17EF7D0094EB2C76, (1, 0, 1): 0xE30B62FE1AC2EDC5, (0, 1, 1): 0x7EDFB4004F82140E,
+                             (79, 89, 1): 0x011D69A47BC4BB30, (1919, 1079, 7): 0x34D62C289D4318E2}.items():
+        assert py_seed(x, y, fr) == want
+        assert L.orc_per_frame_seed(x, y, fr, 0, 0, SALT) == want
+    rng = np.random.RandomState(1)
+    for _ in range(200):
+        x, y, fr = int(rng.randint(0, 4000)), int(rng.randint(0, 2200)), int(rng.randint(1, 1 << 40))
+        assert L.orc_per_frame_seed(x, y, fr, 0, 0, SALT) == py_seed(x, y, fr)
+
+
+def test_next_unit_kats():
+    L = ob.lib()
+    st = C.c_uint64(L.orc_rng_init(0x17EF7D0094EB2C76))
+    a = L.orc_rng_next_unit(C.byref(st)); b = L.orc_rng_next_unit(C.byref(st))
+    assert bits(a) == 0x3EE1315F and bits(b) == 0x3DEF486C
+    s = 0x17EF7D0094EB2C76
+    s, pa = py_next_unit(s); s, pb = py_next_unit(s)
+    assert bits(pa) == 0x3EE1315F and bits(pb) == 0x3DEF486C and s == st.value
+    assert L.orc_rng_init(0) == SALT                       # Rng ctor: seed 0 -> golden-ratio constant
+
+
+def test_blue_noise_and_jitter_kats():
+    L = ob.lib()
+    assert bits(L.orc_blue_noise_sample(0, 0, 1, 0)) == 0x3F047F54
+    assert bits(L.orc_blue_noise_sample(0, 0, 1, 1)) == 0x3E170870
+    frac = lambda v: f32(v) - f32(math.floor(float(v)))
+    assert bits(frac(f32(2) * f32(0.61803398875))) == bits(L.orc_frac(f32(2) * f32(0.61803398875)))
+    assert abs(float(frac(f32(2) * f32(0.61803398875))) - 0.2360680103) < 1e-9
+    assert abs(float(frac(f32(2) * f32(0.38196601125))) - 0.7639320493) < 1e-9
+    tile = np.array([[0, 32, 8, 40, 2, 34, 10, 42], [48, 16, 56, 24, 50, 18, 58, 26], [12, 44, 4, 36, 14, 46, 6, 38], [60, 28, 52, 20, 62, 30, 54, 22],
+                     [3, 35, 11, 43, 1, 33, 9, 41], [51, 19, 59, 27, 49, 17, 57, 25], [15, 47, 7, 39, 13, 45, 5, 37], [63, 31, 55, 23, 61, 29, 53, 21]])
+    assert sorted(tile.reshape(-1)) == list(range(64))      # a permutation of 0..63 (RaytraceSampler.cs:9-19)
+    for y in range(8):
+        for x in range(8):
+            want = frac(f32(f32(tile[y, x]) + f32(0.5)) * f32(1 / 64) + frac(f32(1) * f32(0.7548776662466927)))
+            assert bits(L.orc_blue_noise_sample(x + 8, y + 16, 0, 0)) == bits(want)
+
+
+def test_csharp_numeric_semantics():
+    L = ob.lib()
+    nan, inf = float("nan"), float("inf")
+    assert math.isnan(L.orc_max(nan, 1.0)) and math.isnan(L.orc_max(1.0, nan))       # MathF.Max propagates NaN
+    assert math.isnan(L.orc_min(nan, 1.0)) and math.isnan(L.orc_min(1.0, nan))
+    assert math.copysign(1, L.orc_max(-0.0, 0.0)) == 1 and math.copysign(1, L.orc_min(0.0, -0.0)) == -1
+    assert L.orc_f2i(3.9) == 3 and L.orc_f2i(-3.9) == -3
+    for v in (nan, inf, -inf, 3e9, -3e9, 2147483648.0):
+        assert L.orc_f2i(v) == -2147483648                                            # cvttss2si "integer indefinite"
+    assert L.orc_f2i(-2147483648.0) == -2147483648 and L.orc_f2i(2147483520.0) == 2147483520
+
+
+def test_transcendental_kernels_against_libm():
+    L = ob.lib()
+    s, c = C.c_float(), C.c_float()
+    xs = np.concatenate([np.linspace(0, 6.2831855, 4001, dtype=np.float32), np.float32([0.0, 1e-8, 1.5707964, 3.1415927, 6.2831855])])
+    worst = 0
+    for x in xs:
+        L.orc_sincos(x, C.byref(s), C.byref(c))
+        rs, rc = np.float32(math.sin(float(x))), np.float32(math.cos(float(x)))
+        worst = max(worst, abs(int(np.float32(s.value).view(np.int32)) - int(rs.view(np.int32))) if abs(rs) > 1e-6 else 0,
+                    abs(int(np.float32(c.value).view(np.int32)) - int(rc.view(np.int32))) if abs(rc) > 1e-6 else 0)
+        assert abs(s.value - float(rs)) <= 1.2e-7 and abs(c.value - float(rc)) <= 1.2e-7
+    assert worst <= 1                                                                  # within 1 ulp of correctly rounded
+    for x in np.linspace(0, 1, 1001, dtype=np.float32):
+        assert bits(L.orc_pow5(x)) == bits(np.float32(float(x) ** 5))                  # exact product, rounded once
+    for x in np.linspace(-20, 5, 501, dtype=np.float32):
+        assert abs(L.orc_exp(x) / math.exp(float(x)) - 1) < 1.3e-7
+    for x in np.geomspace(1e-6, 50, 501).astype(np.float32):
+        assert abs(L.orc_log(x) - math.log(float(x))) <= 1.3e-7 * max(1.0, abs(math.log(float(x))))
+    for x in np.linspace(0.001, 1, 300, dtype=np.float32):
+        assert abs(L.orc_pow(x, np.float32(1 / 2.2)) / (float(x) ** float(np.float32(1 / 2.2))) - 1) < 2e-7
+
+
+def test_morton_index_table():
+    L = ob.lib()
+    seen = set()
+    for z in range(8):
+        for y in range(8):
+            for x in range(8):
+                m = L.orc_morton3(x, y, z)
+                want = sum((((x >> b) & 1) << (3 * b)) | (((y >> b) & 1) << (3 * b + 1)) | (((z >> b) & 1) << (3 * b + 2)) for b in range(3))
+                assert m == want
+                seen.add(m)
+    assert seen == set(range(512))
+
+
+# ---- analytic intersection KATs -----------------------------------------------------------------------
+def _scene(objs, lights=()):
+    s = Scene()
+    for o in objs:
+        s.Add(o)
+    s.Lights.extend(lights)
+    return s
+
+
+def test_axis_ray_vs_sphere_and_rect_edges():
+    white = Solid(vec3(0.8, 0.8, 0.8))
+    sc = _scene([Sphere(vec3(0, 0, -5), 1.0, Material(vec3(1, 0, 0))), XZRect(-1.0, 1.0, -1.0, 1.0, -2.0, white, 0.0, 0.0)])
+    with ob.OracleRenderer(sc, 8, 4) as r:
+        h = r.scene_hit((0, 0, 0), (0, 0, -1))
+        assert h[0] == 1 and h[1] == 0 and h[3] == 4.0                              # t = d - r
+        assert tuple(h[7:10]) == (0.0, 0.0, 1.0)                                    # outward normal
+        h = r.scene_hit((0, 0, -5), (0, 0, -1))                                     # from the centre: far root, outward N
+        assert h[0] == 1 and h[3] == 1.0 and tuple(h[7:10]) == (0.0, 0.0, -1.0)
+        # rect edge inclusivity (px >= X0 & px <= X1), Surfaces.cs:269
+        assert r.scene_hit((1.0, 0, 0), (0, -1, 0), brute=True)[0] == 1 and r.scene_hit((-1.0, 0, 1.0), (0, -1, 0), brute=True)[0] == 1
+        assert r.scene_hit((np.nextafter(f32(1.0), f32(2.0)), 0, 0), (0, -1, 0), brute=True)[0] == 0
+        # ... but through the BVH the same edge ray is LOST: dir.x == 0 gives invD = inf and the slab that the
+        # origin sits on evaluates (1 - 1) * inf = NaN, which MathF.Max/Min propagate (BVH.cs:228-235) -> miss
+        assert r.scene_hit((1.0, 0, 0), (0, -1, 0))[0] == 0
+        assert r.scene_hit((0.5, 0, 0), (0, -1, 0))[0] == 1
+        # tMin / tMax are inclusive for rects and spheres
+        assert r.scene_hit((0, 0, 0), (0, -1, 0), t_min=2.0, t_max=2.0)[0] == 1
+
+
+def test_disk_ignores_y_in_radius_test_and_cylinder_ignores_center_y():
+    sc = _scene([Disk(vec3(0, 1, -3), vec3(0, 0, 1), 0.5, Solid(vec3(1, 1, 1)), 0.0, 0.0),           # vertical disk: quirk 4
+                 CylinderY(vec3(5, 100.0, 0), 0.5, 0.0, 1.0, True, Material(vec3(1, 1, 1)))])          # quirk 6
+    with ob.OracleRenderer(sc, 8, 4) as r:
+        h = r.scene_hit((0.2, 3.0, 0), (0, 0, -1), brute=True)   # 2 units above the disk centre in y: the x,z-only test accepts
+        assert h[0] == 1 and h[1] == 0 and h[3] == 3.0
+        assert r.scene_hit((0.2, 3.0, 0), (0, 0, -1))[0] == 0     # (its BVH box, centre +- radius, still culls that ray)
+        h = r.scene_hit((5, 0.5, 5), (0, 0, -1))         # cylinder sits at absolute y in [0,1] although Center.Y = 100
+        assert h[0] == 1 and h[1] == 1 and abs(h[3] - 4.5) < 1e-6
+
+
+def test_box_face_order_and_tie_rule():
+    sc = _scene([Box(vec3(-1, -1, -1), vec3(1, 1, 1), Solid(vec3(1, 1, 1)), 0.0, 0.0)])
+    with ob.OracleRenderer(sc, 8, 4) as r:
+        assert r.scene_hit((0, 0, 5), (0, 0, -1))[2] == 0        # +Z face first (BoundedObjects.cs:84)
+        assert r.scene_hit((0, 0, -5), (0, 0, 1))[2] == 1
+        assert r.scene_hit((0, 5, 0), (0, -1, 0))[2] == 2 and r.scene_hit((0, -5, 0), (0, 1, 0))[2] == 3
+        assert r.scene_hit((5, 0, 0), (-1, 0, 0))[2] == 4 and r.scene_hit((-5, 0, 0), (1, 0, 0))[2] == 5
+        # a ray through the +Z/+X edge hits both faces at the same t: the LATER face (index 4) wins the tie
+        h = r.scene_hit((2, 0, 2), (-1, 0, -1))
+        assert h[0] == 1 and h[2] == 4
+
+
+# ---- structural invariants of the builders ---------------------------------------------------------------
+def _check_tree(nodes, leaf, n_items):
+    assert sorted(leaf.tolist()) == list(range(n_items))                               # every item in exactly one leaf
+    for i, nd in enumerate(nodes):
+        if nd["count"] > 0:
+            assert nd["left"] == -1 and nd["right"] == -1
+            continue
+        l, r = nodes[nd["left"]], nodes[nd["right"]]
+        assert nd["left"] == i + 1                                                     # pre-order: left child follows its parent
+        for c in (l, r):
+            assert (c["min"] >= nd["min"]).all() and (c["max"] <= nd["max"]).all()    # child boxes inside the parent
+
+
+def test_builder_invariants_and_bvh_equals_bruteforce():
+    rng = np.random.RandomState(7)
+    objs = [Sphere(vec3(*rng.uniform(-4, 4, 3)), float(rng.uniform(0.2, 0.8)), Material(vec3(1, 1, 1))) for _ in range(40)]
+    objs += [Box(vec3(-6, -1, -6), vec3(-5, 1, -5), Solid(vec3(1, 1, 1)), 0.0, 0.0), XZRect(-8.0, 8.0, -8.0, 8.0, -5.0, Solid(vec3(1, 1, 1)), 0.0, 0.0)]
+    pos, faces = scenes.make_torus_knot(40, 12)
+    from yetanotherconsolegameengine_amd.scene import Mesh
+    objs.append(Mesh(pos[faces], Material(vec3(0.5, 0.5, 0.5))))
+    sc = _scene(objs)
+    with ob.OracleRenderer(sc, 8, 4) as r:
+        _check_tree(r.accel(abi.ACCEL_SCENE_NODES), r.accel(abi.ACCEL_SCENE_LEAF_INDEX), len(objs))
+        _check_tree(r.accel(abi.ACCEL_MESH_NODES), r.accel(abi.ACCEL_MESH_LEAF_INDEX), faces.shape[0])
+        for _ in range(400):
+            o = rng.uniform(-9, 9, 3); d = rng.normal(size=3)
+            a, b = r.scene_hit(o, d), r.scene_hit(o, d, brute=True)
+            assert a[0] == b[0]
+            if a[0]:
+                assert a[3] == b[3]                                                   # same closest t, bit for bit
+
+
+def test_dotnet_introsort_properties():
+    L = ob.lib()
+    rng = np.random.RandomState(3)
+    for n in (2, 3, 5, 16, 17, 33, 200, 1000):
+        for dup in (False, True):
+            keys = (rng.randint(0, 7, n) if dup else rng.uniform(-1, 1, n)).astype(np.float32)
+            idx = np.arange(n, dtype=np.int32)
+            k2, i2 = keys.copy(), idx.copy()
+            L.orc_introsort(k2.ctypes.data_as(C.POINTER(C.c_float)), i2.ctypes.data_as(C.POINTER(C.c_int32)), n)
+            assert (np.diff(k2) >= 0).all() and sorted(i2.tolist()) == list(range(n)) and (keys[i2] == k2).all()
+    # regression vector for the unstable order of equal keys (heapsort is not reached; insertion + partition order)
+    keys = np.float32([1, 0, 1, 0, 1, 0, 1, 0, 1, 0, 1, 0, 1, 0, 1, 0, 1, 0, 1, 0])
+    idx = np.arange(20, dtype=np.int32)
+    L.orc_introsort(keys.ctypes.data_as(C.POINTER(C.c_float)), idx.ctypes.data_as(C.POINTER(C.c_int32)), 20)
+    assert idx.tolist() == GOLDEN_EQUAL_KEY_ORDER, idx.tolist()
+
+
+GOLDEN_EQUAL_KEY_ORDER = [9, 17, 15, 13, 11, 7, 19, 5, 3, 1, 8, 18, 10, 4, 12, 14, 2, 16, 6, 0]   # frozen regression vector
+
+
+def test_committed_golden_buffers_cornell():
+    z = np.load(scenes.GOLDEN_DIR / "cornell_80x45_frames123.npz")
+    sc, w, h, ss, pose = scenes.config_scene(1)
+    with ob.OracleRenderer(sc, w, h, ss, pose) as r:
+        for frame in (1, 2, 3):
+            r.render(stages=1)
+            if frame == 1:
+                for name, which in (("rays", abi.BUF_RAYS), ("prim_id", abi.BUF_PRIM_ID), ("sub_id", abi.BUF_SUB_ID), ("hit_t", abi.BUF_HIT_T),
+                                    ("current_hdr", abi.BUF_CURRENT_HDR), ("rng_state", abi.BUF_RNG_STATE)):
+                    assert np.array_equal(r.read(which).view(np.uint8), z[f"f1_{name}"].view(np.uint8)), name
+            assert np.array_equal(r.read(abi.BUF_TAA_HISTORY).view(np.uint8), z[f"f{frame}_taa_history"].view(np.uint8))
+        # a Cornell primary ray through the image centre hits the back wall (object 4) at z = -5 from (0,1,0)
+        pid = r.read(abi.BUF_PRIM_ID)
+        assert pid[45, 40] in (4, 6, 7) and (pid >= 0).all()        # closed box: no primary ray escapes

@@ -100,7 +100,7 @@ struct ycge_ctx {
     DevBuf<uint64_t> stack_spill;                 // [YCGE_TRAVERSAL_STACK - 12][persistent lanes]
     DevBuf<float> path_stack;                  // [3][11][persistent lanes], only for scenes with transparent materials
     int spill_levels = 0;                      // traversal depth beyond the 12 LDS levels, from the uploaded trees
-    bool force_megakernel = false;
+    int path_policy = 0;                       // 0 auto, 1 wavefront, 2 single launch (env YCGE_PATH)
     int wf_rounds = 2;                         // 2 = primary + diffuse bounce; 4 when a surface can mirror (<= 2 mirror bounces)
     bool has_grid = false;
 
@@ -346,7 +346,10 @@ int ycge_create(const ycge_config *cfg, ycge_ctx **out)
     c->cfg = *cfg;
     c->device = cfg->device;
     c->fov_deg = cfg->fov_deg;
-    { const char *e = getenv("YCGE_FORCE_MEGAKERNEL"); c->force_megakernel = e && e[0] == '1'; }
+    {   // YCGE_PATH=auto|wavefront|megakernel — test/benchmark knob; results are bit-identical on both paths
+        const char *e = getenv("YCGE_PATH");
+        c->path_policy = !e ? 0 : (e[0] == 'w' ? 1 : (e[0] == 'm' ? 2 : 0));
+    }
     auto bail = [&](int code) { g_create_error = c->err; ycge_destroy(c); return code; };
     if (hipSetDevice(c->device) != hipSuccess) { c->err = "hipSetDevice failed"; return bail(YCGE_ERR_DEVICE); }
     hipDeviceProp_t prop;
@@ -721,8 +724,12 @@ int begin_and_trace(ycge_ctx *c, float *d_slab, hipStream_t stream, FrameState &
     O.stack_lanes = (uint32_t)(c->n_owned > 0 ? c->n_owned : 1) * 256u;
     O.path_stack = c->path_stack.p;
     const int flat = YCGE_REF_KIND(c->sd.scene_root_ref) == REF_SCENE_LEAF ? 1 : 0;
-    if (c->sd.any_transparent || c->force_megakernel) {
-        // refraction splits need TraceFull's per-pixel LIFO: single-launch path
+    // Path choice.  Refraction splits need TraceFull's per-pixel LIFO -> single launch.  Otherwise: scenes
+    // that are one BVH leaf (mesh viewers) are bounded by the latency chain of their few heaviest tiles, and
+    // one launch lets the chains of all stages overlap (measured 0.85 vs 1.24 ms on config 4); scenes with a
+    // real top-level tree (voxel worlds) are throughput-bound and run 1.7x faster as occupancy-friendly stages.
+    const bool single_launch = c->sd.any_transparent || c->path_policy == 2 || (c->path_policy == 0 && flat);
+    if (single_launch) {
         if (!c->path_stack.p) HIP_TRY(c, c->path_stack.alloc((size_t)3 * 11 * O.stack_lanes));
         O.path_stack = c->path_stack.p;
         e = ycge_launch_trace(&c->sd, &P, &O, c->cfg.count_work, flat, stream);

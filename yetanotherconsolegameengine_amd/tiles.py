@@ -1,0 +1,71 @@
+"""Framebuffer tiling across GPUs — the host-side statement of the layout the kernels use.
+
+The trace grid is cut into 32x8-pixel tiles, numbered row-major; rank r of `world` traces the tiles with
+tile_id % world == r (round-robin, so the expensive tiles of a mesh in the image centre spread over all
+GPUs).  Each rank packs its tiles into a slab — for its k-th owned tile (ascending tile_id), 256 pixel
+records in row-major order inside the tile (j = y*32 + x), 11 float32 each {hdr rgb, albedo rgb, normal
+xyz, depth, sky} — and
+one all-gather of equal-sized slabs (RCCL over xGMI, torch.distributed backend "nccl") reassembles the
+frame; k_unpermute scatters the gathered slabs back to row-major full-frame buffers on every rank.
+
+(Inside the kernels a tile is one 256-thread workgroup: thread t -> wavefront w = t // 64, lane l = t % 64
+traces pixel x = 8*w + l % 8, y = l // 8, i.e. one 8x8 pixel block per wavefront.)
+
+This module is pure layout arithmetic (numpy); it is what the multi-process CPU tests exercise and what
+the GPU tests compare k_pack_slab / k_unpermute against.
+"""
+from __future__ import annotations
+
+import numpy as np
+
+TILE_W, TILE_H, SLAB_FLOATS = 32, 8, 11
+
+
+def tile_grid(hiW: int, hiH: int):
+    tx, ty = (hiW + TILE_W - 1) // TILE_W, (hiH + TILE_H - 1) // TILE_H
+    return tx, ty, tx * ty
+
+
+def owned_tiles(rank: int, world: int, n_tiles: int) -> np.ndarray:
+    return np.arange(rank, n_tiles, world, dtype=np.int64)
+
+
+def tiles_per_rank_padded(world: int, n_tiles: int) -> int:
+    return (n_tiles + world - 1) // world
+
+
+def slab_floats(world: int, n_tiles: int) -> int:
+    return tiles_per_rank_padded(world, n_tiles) * 256 * SLAB_FLOATS
+
+
+def _local_xy():
+    j = np.arange(256)
+    return j % TILE_W, j // TILE_W
+
+
+def pack_slab(frame: np.ndarray, rank: int, world: int) -> np.ndarray:
+    """frame: [hiH, hiW, 11] float32 -> this rank's slab [padded_tiles*256*11] (k_pack_slab)."""
+    hiH, hiW, _ = frame.shape
+    tx, ty, n = tile_grid(hiW, hiH)
+    out = np.zeros((tiles_per_rank_padded(world, n), 256, SLAB_FLOATS), dtype=np.float32)
+    lx, ly = _local_xy()
+    for k, tid in enumerate(owned_tiles(rank, world, n)):
+        px, py = (tid % tx) * TILE_W + lx, (tid // tx) * TILE_H + ly
+        ok = (px < hiW) & (py < hiH)
+        out[k, ok] = frame[py[ok], px[ok]]
+    return out.reshape(-1)
+
+
+def unpermute(all_slabs: np.ndarray, hiW: int, hiH: int, world: int) -> np.ndarray:
+    """all_slabs: [world * slab_floats] rank-major (as all_gather leaves it) -> frame [hiH, hiW, 11] (k_unpermute)."""
+    tx, ty, n = tile_grid(hiW, hiH)
+    per = tiles_per_rank_padded(world, n)
+    s = all_slabs.reshape(world, per, 256, SLAB_FLOATS)
+    frame = np.zeros((hiH, hiW, SLAB_FLOATS), dtype=np.float32)
+    lx, ly = _local_xy()
+    for tid in range(n):
+        r, k = tid % world, tid // world
+        px, py = (tid % tx) * TILE_W + lx, (tid // tx) * TILE_H + ly
+        ok = (px < hiW) & (py < hiH)
+        frame[py[ok], px[ok]] = s[r, k, ok]
+    return frame
