@@ -44,6 +44,7 @@ __device__ __forceinline__ void make_primary_ray(const FrameParams &P, int px, i
 }
 
 // block -> tile -> pixel: 32x8 tile per 256-thread block, 8x8 sub-tile per wavefront
+__device__ __forceinline__ int block_tile(const FrameParams &P) { return P.tile_order ? (int)P.tile_order[blockIdx.x] : (int)blockIdx.x; }
 __device__ __forceinline__ bool tile_pixel(const FrameParams &P, int k, int &px, int &py, int &lx, int &ly)
 {
     const int tile_id = P.rank + k * P.world_size;
@@ -99,6 +100,7 @@ struct WfBuffers {
     uint32_t *n_q;              // [round][owned tile] live entries of that tile's queue segment (round 0: implicit 256)
     uint32_t *n_lq;             // [owned tile] light records of the current round
     uint32_t tiles;             // owned tiles (= gridDim.x of every stage)
+    const uint32_t *tile_order; // = FrameParams.tile_order
 };
 
 // Compaction without global atomics: every tile (= workgroup) owns a 256-entry segment of each queue.
@@ -125,7 +127,7 @@ template <bool COUNT, bool HAS_GRID, bool FLAT>
 __global__ __launch_bounds__(256) void k_wf_primary(const SceneDev S, const FrameParams P, const TraceOut O, const WfBuffers B)
 {
     Work w = {0, 0, 0, 0, 0};
-    const int k = blockIdx.x;
+    const int k = block_tile(P);
     int px, py, lx, ly;
     unsigned long long t_start = 0;
     if (O.wave_prof) {
@@ -159,7 +161,7 @@ __global__ __launch_bounds__(256) void k_wf_primary(const SceneDev S, const Fram
 template <bool COUNT, bool HAS_GRID, bool FLAT>
 __global__ __launch_bounds__(256) void k_wf_extend(const SceneDev S, const TraceOut O, const WfBuffers B, int round)
 {
-    const int k = blockIdx.x;
+    const int k = B.tile_order ? (int)B.tile_order[blockIdx.x] : (int)blockIdx.x;
     const uint32_t n = B.n_q[(size_t)round * B.tiles + k];
     Work w = {0, 0, 0, 0, 0};
     if (threadIdx.x < n) {
@@ -186,7 +188,7 @@ __global__ __launch_bounds__(256) void k_wf_shade(const SceneDev S, const FrameP
 {
     __shared__ uint32_t s_cnt[4];
     const bool DEBUG = O.prim_id != nullptr;       // capture_debug (wave-uniform)
-    const int k = blockIdx.x;
+    const int k = block_tile(P);
     const size_t i = (size_t)k * 256 + threadIdx.x;
     const QEntry *Q = B.q[round & 1];
     QEntry *Qn = B.q[(round + 1) & 1];
@@ -318,7 +320,7 @@ __global__ __launch_bounds__(256) void k_wf_shade(const SceneDev S, const FrameP
 template <bool COUNT, bool HAS_GRID, bool FLAT>
 __global__ __launch_bounds__(256) void k_wf_lights(const SceneDev S, const FrameParams P, const TraceOut O, const WfBuffers B, int round)
 {
-    const int k = blockIdx.x;
+    const int k = block_tile(P);
     const uint32_t n = B.n_lq[k];
     Work w = {0, 0, 0, 0, 0};
     if (threadIdx.x < n) {
@@ -437,7 +439,7 @@ __global__ __launch_bounds__(256) void k_trace(const SceneDev S, const FramePara
     Stack st;
     st.init(O.stack_spill, O.stack_lanes);
     const PathStack pstack = {O.path_stack, O.stack_lanes};
-    const int k = blockIdx.x;
+    const int k = block_tile(P);
     int px, py, lx, ly;
     const bool in_image = tile_pixel(P, k, px, py, lx, ly);
 
@@ -827,6 +829,7 @@ int ycge_launch_wavefront(const ycge::SceneDev *S, const ycge::FrameParams *P, c
     B.q[0] = (QEntry *)bufs[0]; B.q[1] = (QEntry *)bufs[1]; B.hit = (HitRec *)bufs[2]; B.lq = (LEntry *)bufs[3];
     B.n_q = (uint32_t *)bufs[4]; B.n_lq = (uint32_t *)bufs[5];
     B.tiles = (uint32_t)P->n_owned_tiles;
+    B.tile_order = P->tile_order;
     const dim3 block(256), tiles((unsigned)P->n_owned_tiles);
     sel3(count != 0, has_grid != 0, flat != 0, [&](auto C, auto G, auto F) {
         hipLaunchKernelGGL((k_wf_primary<decltype(C)::value, decltype(G)::value, decltype(F)::value>), tiles, block, 0, stream, *S, *P, *O, B);
