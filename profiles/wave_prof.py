@@ -3,7 +3,8 @@ import ctypes as C, os, sys
 from pathlib import Path
 ROOT = Path(__file__).resolve().parents[1]
 sys.path.insert(0, str(ROOT))
-os.environ["YCGE_WAVE_PROF"] = "1"
+os.environ["YCGE_WAVE_PROF"] = os.environ.get("PROF_STAGE", "primary")
+os.environ.setdefault("YCGE_PATH", "wavefront")
 import numpy as np
 from yetanotherconsolegameengine_amd import abi, scenes
 from yetanotherconsolegameengine_amd.renderer import RaytraceRenderer
@@ -24,8 +25,10 @@ dur = p[:, 1] - p[:, 0]
 t0 = p[:, 0].min()
 print("waves", len(p), "kernel span (cycles)", p[:, 1].max() - t0)
 print("duration cycles pcts 50/90/99/99.9/max", np.percentile(dur, [50, 90, 99, 99.9]), dur.max())
-print("node iters pcts", np.percentile(p[:, 2], [50, 90, 99, 99.9]), p[:, 2].max(), "sum", p[:, 2].sum())
-print("leaf phases pcts", np.percentile(p[:, 3], [50, 90, 99, 99.9]), p[:, 3].max(), "sum", p[:, 3].sum())
+c0, c1, c2, c3 = p[:, 2] & 0xffffffff, p[:, 2] >> 32, p[:, 3] & 0xffffffff, p[:, 3] >> 32
+for name, c in (("node/unified iterations", c0), ("leaf phases", c1), ("grid setups", c2), ("dda steps", c3)):
+    print(f"wave-level {name}: pcts 50/90/99/max", np.percentile(c, [50, 90, 99]), c.max(), "mean", c.mean())
+p[:, 2], p[:, 3] = c0 + c2, c1 + c3
 heavy = np.argsort(-dur)[:10]
 for i in heavy:
     print("wave", i, "start", p[i, 0] - t0, "dur", dur[i], "node_iters", p[i, 2], "leaf_phases", p[i, 3], "cycles/iter", dur[i] / max(1, p[i, 2] + p[i, 3]))

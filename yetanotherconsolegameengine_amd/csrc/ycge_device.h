@@ -100,7 +100,9 @@ struct alignas(16) GGrid {
     float wire_width_frac;
     float wire_max_distance;
     uint32_t lut_offset;        // index of this grid's first entry in grid_lut (cell code -> material)
-    uint32_t pad[7];
+    uint32_t brick_mask_lo, brick_mask_hi;   // bit b set = brick b holds a solid voxel (grids of <= 64 bricks, e.g. 32^3 chunks)
+    int32_t has_brick_mask;
+    uint32_t pad[4];
 };
 static_assert(sizeof(GGrid) == 96, "GGrid must be 96 B");
 
@@ -182,6 +184,7 @@ struct TraceOut {
     float *path_stack;
     // per-wavefront profile of k_wf_primary (COUNT variant; may be null): 4 x u64 {start, end, node iters, leaf phases}
     unsigned long long *wave_prof;
+    int32_t wave_prof_stage;            // 0 = k_wf_primary, 1 = k_wf_extend of round 1
     // traversal counters (may be null): rays, box, tri, prim, vox
     unsigned long long *counters;
 };

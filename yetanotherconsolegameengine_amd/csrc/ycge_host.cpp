@@ -530,6 +530,8 @@ int ycge_scene_upload(ycge_ctx *c, const ycge_scene *s)
         // code 0 = empty; codes 1.. = distinct (matId, metaId) pairs in first-seen order
         std::vector<std::pair<int32_t, int32_t>> seen;
         lut.push_back(-1);
+        const bool maskable = (size_t)G.nbx * G.nby * G.nbz <= 64;
+        uint64_t brick_mask = 0;
         for (int iz = 0; iz < g.nz; iz++)
             for (int iy = 0; iy < g.ny; iy++)
                 for (int ix = 0; ix < g.nx; ix++) {
@@ -549,7 +551,10 @@ int ycge_scene_upload(ycge_ctx *c, const ycge_scene *s)
                     }
                     const int brick = (((iz >> 3) * G.nby) + (iy >> 3)) * G.nbx + (ix >> 3);
                     cells[off + (size_t)brick * 512 + morton3(ix & 7, iy & 7, iz & 7)] = (uint8_t)code;
+                    if (maskable) brick_mask |= (uint64_t)1 << brick;
                 }
+        G.has_brick_mask = maskable ? 1 : 0;
+        G.brick_mask_lo = (uint32_t)brick_mask; G.brick_mask_hi = (uint32_t)(brick_mask >> 32);
     }
 
     // ---- Scene.Objects -> device prim records + scene BVH (BVH ctor, BVH.cs:29-97)
@@ -740,7 +745,7 @@ int begin_and_trace(ycge_ctx *c, float *d_slab, hipStream_t stream, FrameState &
     const bool slab = d_slab != nullptr;
     const bool debug = c->cfg.capture_debug && !slab;
     if (debug) { O.rays = c->dbg_rays.p; O.prim_id = c->dbg_prim.p; O.sub_id = c->dbg_sub.p; O.hit_t = c->dbg_hit_t.p; O.rng_state = c->dbg_rng.p; }
-    if (getenv("YCGE_WAVE_PROF")) { if (!c->wave_prof.p) HIP_TRY(c, c->wave_prof.alloc((size_t)c->n_tiles * 16)); O.wave_prof = c->wave_prof.p; }
+    if (getenv("YCGE_WAVE_PROF")) { if (!c->wave_prof.p) HIP_TRY(c, c->wave_prof.alloc((size_t)c->n_tiles * 16)); O.wave_prof = c->wave_prof.p; O.wave_prof_stage = getenv("YCGE_WAVE_PROF")[0] == 'e' ? 1 : 0; }
     if (c->cfg.count_work) {
         O.counters = c->counters.p;
         HIP_TRY(c, hipMemsetAsync(c->counters.p, 0, 8 * sizeof(unsigned long long), stream));

@@ -130,8 +130,8 @@ __global__ __launch_bounds__(256) void k_wf_primary(const SceneDev S, const Fram
     const int k = block_tile(P);
     int px, py, lx, ly;
     unsigned long long t_start = 0;
-    if (O.wave_prof) {
-        if (COUNT) { if (threadIdx.x < 8) g_wave_iters[threadIdx.x] = 0; __syncthreads(); }
+    if (O.wave_prof && O.wave_prof_stage == 0) {
+        if (COUNT) { if (threadIdx.x < 16) g_wave_iters[threadIdx.x] = 0; __syncthreads(); }
         t_start = __builtin_readcyclecounter();
     }
     if (tile_pixel(P, k, px, py, lx, ly)) {
@@ -148,11 +148,12 @@ __global__ __launch_bounds__(256) void k_wf_primary(const SceneDev S, const Fram
         traverse<COUNT, HAS_GRID, FLAT>(S, q, st, t, prim, sub, w);
         *(float4 *)(B.hit + ((size_t)k * 256 + threadIdx.x)) = make_float4(t, __int_as_float(prim), __int_as_float(sub), 0.0f);
     }
-    if (O.wave_prof && (threadIdx.x & 63) == 0) {
+    if (O.wave_prof && O.wave_prof_stage == 0 && (threadIdx.x & 63) == 0) {
         const int wv = threadIdx.x >> 6;
         unsigned long long *dst = O.wave_prof + ((size_t)k * 4 + wv) * 4;
         dst[0] = t_start; dst[1] = __builtin_readcyclecounter();
-        dst[2] = COUNT ? g_wave_iters[wv * 2] : 0; dst[3] = COUNT ? g_wave_iters[wv * 2 + 1] : 0;
+        dst[2] = COUNT ? (((unsigned long long)g_wave_iters[wv * 4 + 1] << 32) | g_wave_iters[wv * 4]) : 0;
+        dst[3] = COUNT ? (((unsigned long long)g_wave_iters[wv * 4 + 3] << 32) | g_wave_iters[wv * 4 + 2]) : 0;
     }
     flush_work<COUNT>(w, O.counters);
 }
@@ -164,6 +165,12 @@ __global__ __launch_bounds__(256) void k_wf_extend(const SceneDev S, const Trace
     const int k = B.tile_order ? (int)B.tile_order[blockIdx.x] : (int)blockIdx.x;
     const uint32_t n = B.n_q[(size_t)round * B.tiles + k];
     Work w = {0, 0, 0, 0, 0};
+    const bool prof = O.wave_prof && O.wave_prof_stage == 1 && round == 1;
+    unsigned long long t_start = 0;
+    if (prof) {
+        if (COUNT) { if (threadIdx.x < 16) g_wave_iters[threadIdx.x] = 0; __syncthreads(); }
+        t_start = __builtin_readcyclecounter();
+    }
     if (threadIdx.x < n) {
         const size_t i = (size_t)k * 256 + threadIdx.x;
         const QEntry *Q = B.q[round & 1];
@@ -176,6 +183,13 @@ __global__ __launch_bounds__(256) void k_wf_extend(const SceneDev S, const Trace
         float t; int prim, sub;
         traverse<COUNT, HAS_GRID, FLAT>(S, q, st, t, prim, sub, w);
         *(float4 *)(B.hit + i) = make_float4(t, __int_as_float(prim), __int_as_float(sub), 0.0f);
+    }
+    if (prof && (threadIdx.x & 63) == 0) {
+        const int wv = threadIdx.x >> 6;
+        unsigned long long *dst = O.wave_prof + ((size_t)k * 4 + wv) * 4;
+        dst[0] = t_start; dst[1] = __builtin_readcyclecounter();
+        dst[2] = COUNT ? (((unsigned long long)g_wave_iters[wv * 4 + 1] << 32) | g_wave_iters[wv * 4]) : 0;
+        dst[3] = COUNT ? (((unsigned long long)g_wave_iters[wv * 4 + 3] << 32) | g_wave_iters[wv * 4 + 2]) : 0;
     }
     flush_work<COUNT>(w, O.counters);
 }

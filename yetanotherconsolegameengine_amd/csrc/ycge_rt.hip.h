@@ -43,6 +43,16 @@ struct Work {              // SURVEY 8(d) counters
     unsigned rays, box, tri, prim, vox;
 };
 
+// wave-level iteration counters (profiling aid, only touched by COUNT variants)
+static __shared__ unsigned int g_wave_iters[16];  // [wave][4 wave-level iteration counters] (profiling aid, COUNT variants)
+__device__ __forceinline__ void prof_tick(int which)
+{
+    const unsigned long long m = __ballot(1);
+    const int lane = threadIdx.x & 63;
+    if ((m & ((1ull << lane) - 1ull)) == 0ull) atomicAdd(&g_wave_iters[(threadIdx.x >> 6) * 4 + which], 1u);
+}
+
+
 // ------------------------------------------------------------------ sampler (RaytraceSampler.cs)
 __device__ __constant__ uint8_t c_bayer8x8[64] = {
     0, 32, 8, 40, 2, 34, 10, 42, 48, 16, 56, 24, 50, 18, 58, 26, 12, 44, 4, 36, 14, 46, 6, 38, 60, 28, 52, 20, 62, 30, 54, 22,
@@ -382,13 +392,12 @@ __device__ __forceinline__ uint32_t grid_index(const GGrid &g, int ix, int iy, i
     int brick = (((iz >> 3) * g.nby) + (iy >> 3)) * g.nbx + (ix >> 3);
     return (uint32_t)(brick * 512 + morton3_3bits(ix & 7, iy & 7, iz & 7));
 }
-__device__ __forceinline__ bool grid_slab(float ro, float rd, float mn, float mx, float &t_enter, float &t_exit, int axis, int &enter_axis)
-{   // VolumeGrid.Slab, VolumeGrid.cs:331-355
+__device__ __forceinline__ bool grid_slab(float ro, float rd, float inv, float mn, float mx, float &t_enter, float &t_exit, int axis, int &enter_axis)
+{   // VolumeGrid.Slab, VolumeGrid.cs:331-355.  `inv` = 1.0f / rd, the C#'s own expression, evaluated once per ray
     if (cs_abs(rd) < 1e-12f) {
         if (ro < mn || ro > mx) return false;
         return true;
     }
-    float inv = 1.0f / rd;
     float t0 = (mn - ro) * inv;
     float t1 = (mx - ro) * inv;
     if (t0 > t1) { float t = t0; t0 = t1; t1 = t; }
@@ -396,13 +405,18 @@ __device__ __forceinline__ bool grid_slab(float ro, float rd, float mn, float mx
     if (t1 < t_exit) t_exit = t1;
     return t_exit >= t_enter;
 }
+// x / s with the exact shortcut x / 1.0f == x (every voxel world of the reference has unit voxels)
+__device__ __forceinline__ float div_by_size(float x, float s) { return s == 1.0f ? x : x / s; }
 
-// VolumeGrid.Hit, VolumeGrid.cs:99-231 (Amanatides-Woo DDA; first cell with matId > 0 hits)
+// VolumeGrid.Hit, VolumeGrid.cs:99-231 (Amanatides-Woo DDA; first cell with matId > 0 hits).
+// Every floating-point step of the C# is performed (the t of a hit is the running sum of its tDelta
+// additions), but cell bytes are only FETCHED inside bricks the grid's 64-bit occupancy mask marks
+// non-empty: in open air the walk is pure ALU instead of one dependent load per voxel.
 template <bool COUNT>
-__device__ __forceinline__ void grid_dda(const SceneDev &S, int grid_index_, int prim_index, F3 o, F3 d, float tmin, float &closest,
+__device__ __forceinline__ void grid_dda(const SceneDev &S, int grid_index_, int prim_index, F3 o, F3 d, F3 inv, float tmin, float &closest,
                                       int &hit_prim, int &hit_sub, Work &w)
 {
-    if (COUNT) w.prim++;
+    if (COUNT) { w.prim++; prof_tick(2); }
     const GGrid g = S.grids[grid_index_];
     const float min_x = g.min_corner[0], min_y = g.min_corner[1], min_z = g.min_corner[2];
     const float size_x = g.voxel_size[0], size_y = g.voxel_size[1], size_z = g.voxel_size[2];
@@ -410,22 +424,22 @@ __device__ __forceinline__ void grid_dda(const SceneDev &S, int grid_index_, int
     const float tmax = closest;
     int enter_axis = -1;
     float t_enter = -YCGE_INF, t_exit = YCGE_INF;
-    if (!grid_slab(o.x, d.x, min_x, max_x, t_enter, t_exit, 0, enter_axis)) return;
-    if (!grid_slab(o.y, d.y, min_y, max_y, t_enter, t_exit, 1, enter_axis)) return;
-    if (!grid_slab(o.z, d.z, min_z, max_z, t_enter, t_exit, 2, enter_axis)) return;
+    if (!grid_slab(o.x, d.x, inv.x, min_x, max_x, t_enter, t_exit, 0, enter_axis)) return;
+    if (!grid_slab(o.y, d.y, inv.y, min_y, max_y, t_enter, t_exit, 1, enter_axis)) return;
+    if (!grid_slab(o.z, d.z, inv.z, min_z, max_z, t_enter, t_exit, 2, enter_axis)) return;
     if (!(t_exit >= cs_max(0.0f, t_enter))) return;
     float t = t_enter; if (t < tmin) t = tmin; if (t > tmax || t > t_exit) return;
     t += 1e-6f;
     float px = o.x + d.x * t, py = o.y + d.y * t, pz = o.z + d.z * t;
-    int ix = cs_f2i(cs_floor((px - min_x) / size_x)); if (ix < 0) ix = 0; else if (ix >= g.nx) ix = g.nx - 1;
-    int iy = cs_f2i(cs_floor((py - min_y) / size_y)); if (iy < 0) iy = 0; else if (iy >= g.ny) iy = g.ny - 1;
-    int iz = cs_f2i(cs_floor((pz - min_z) / size_z)); if (iz < 0) iz = 0; else if (iz >= g.nz) iz = g.nz - 1;
+    int ix = cs_f2i(cs_floor(div_by_size(px - min_x, size_x))); if (ix < 0) ix = 0; else if (ix >= g.nx) ix = g.nx - 1;
+    int iy = cs_f2i(cs_floor(div_by_size(py - min_y, size_y))); if (iy < 0) iy = 0; else if (iy >= g.ny) iy = g.ny - 1;
+    int iz = cs_f2i(cs_floor(div_by_size(pz - min_z, size_z))); if (iz < 0) iz = 0; else if (iz >= g.nz) iz = g.nz - 1;
     const int step_x = d.x > 0.0f ? 1 : d.x < 0.0f ? -1 : 0;
     const int step_y = d.y > 0.0f ? 1 : d.y < 0.0f ? -1 : 0;
     const int step_z = d.z > 0.0f ? 1 : d.z < 0.0f ? -1 : 0;
-    const float inv_dx = step_x == 0 ? 0.0f : 1.0f / d.x;
-    const float inv_dy = step_y == 0 ? 0.0f : 1.0f / d.y;
-    const float inv_dz = step_z == 0 ? 0.0f : 1.0f / d.z;
+    const float inv_dx = step_x == 0 ? 0.0f : inv.x;
+    const float inv_dy = step_y == 0 ? 0.0f : inv.y;
+    const float inv_dz = step_z == 0 ? 0.0f : inv.z;
     const float next_vx = min_x + (step_x > 0 ? (float)(ix + 1) * size_x : (float)ix * size_x);
     const float next_vy = min_y + (step_y > 0 ? (float)(iy + 1) * size_y : (float)iy * size_y);
     const float next_vz = min_z + (step_z > 0 ? (float)(iz + 1) * size_z : (float)iz * size_z);
@@ -437,19 +451,31 @@ __device__ __forceinline__ void grid_dda(const SceneDev &S, int grid_index_, int
     const float t_delta_z = step_z == 0 ? YCGE_INF : cs_abs(size_z * inv_dz);
     int last_axis = enter_axis < 0 ? (t_max_x <= t_max_y && t_max_x <= t_max_z ? 0 : t_max_y <= t_max_z ? 1 : 2) : enter_axis;
     const uint8_t *cells = S.grid_cells + g.cell_offset;
+    const unsigned long long mask = ((unsigned long long)g.brick_mask_hi << 32) | g.brick_mask_lo;
+    const bool use_mask = g.has_brick_mask != 0;
     while (t <= t_exit && t <= tmax) {
+        if (COUNT) prof_tick(3);
         if ((uint32_t)ix < (uint32_t)g.nx && (uint32_t)iy < (uint32_t)g.ny && (uint32_t)iz < (uint32_t)g.nz) {
             if (COUNT) w.vox++;
-            if (cells[grid_index(g, ix, iy, iz)] != 0) {
-                closest = cs_max(t, tmin);
-                hit_prim = prim_index;
-                hit_sub = (ix + g.nx * (iy + g.ny * iz)) | (last_axis << 30);
-                return;
+            const int brick = (((iz >> 3) * g.nby) + (iy >> 3)) * g.nbx + (ix >> 3);
+            if (!use_mask || ((mask >> brick) & 1ull)) {
+                if (cells[(uint32_t)(brick * 512 + morton3_3bits(ix & 7, iy & 7, iz & 7))] != 0) {
+                    closest = cs_max(t, tmin);
+                    hit_prim = prim_index;
+                    hit_sub = (ix + g.nx * (iy + g.ny * iz)) | (last_axis << 30);
+                    return;
+                }
             }
         }
-        if (t_max_x <= t_max_y && t_max_x <= t_max_z) { ix += step_x; t = t_max_x; t_max_x += t_delta_x; last_axis = 0; }
-        else if (t_max_y <= t_max_z) { iy += step_y; t = t_max_y; t_max_y += t_delta_y; last_axis = 1; }
-        else { iz += step_z; t = t_max_z; t_max_z += t_delta_z; last_axis = 2; }
+        // the three-way `if` of VolumeGrid.cs:203-223 as selects (one axis advances; the others keep their bits)
+        const bool ax = t_max_x <= t_max_y && t_max_x <= t_max_z;
+        const bool ay = !ax && t_max_y <= t_max_z;
+        const bool az = !ax && !ay;
+        t = ax ? t_max_x : ay ? t_max_y : t_max_z;
+        ix += ax ? step_x : 0; iy += ay ? step_y : 0; iz += az ? step_z : 0;
+        const float nx_ = t_max_x + t_delta_x, ny_ = t_max_y + t_delta_y, nz_ = t_max_z + t_delta_z;
+        t_max_x = ax ? nx_ : t_max_x; t_max_y = ay ? ny_ : t_max_y; t_max_z = az ? nz_ : t_max_z;
+        last_axis = ax ? 0 : ay ? 1 : 2;
         if ((uint32_t)ix >= (uint32_t)g.nx || (uint32_t)iy >= (uint32_t)g.ny || (uint32_t)iz >= (uint32_t)g.nz) break;
     }
 }
@@ -491,14 +517,6 @@ __device__ __forceinline__ bool is_wire_on_face(const GGrid &g, F3 p, int ix, in
 #define YCGE_LDS_STACK 12
 #define YCGE_BLOCK 256
 static __shared__ uint2 g_lds_stack[YCGE_LDS_STACK * YCGE_BLOCK];
-static __shared__ unsigned int g_wave_iters[8];   // [wave][node iterations, leaf phases] (profiling aid, COUNT variants)
-__device__ __forceinline__ void prof_tick(int which)
-{
-    const unsigned long long m = __ballot(1);
-    const int lane = threadIdx.x & 63;
-    if ((m & ((1ull << lane) - 1ull)) == 0ull) atomicAdd(&g_wave_iters[(threadIdx.x >> 6) * 2 + which], 1u);
-}
-
 struct Stack {
     uint2 *spill;          // this lane's column of the spill area
     uint32_t spill_stride; // lanes in the grid
@@ -604,65 +622,79 @@ __device__ __forceinline__ void leaf_triangles(const SceneDev &S, uint32_t pay, 
 //  * a scene leaf's objects are queued in order; a Mesh object opens its own tree on the same
 //    stack and runs to completion before the next object of the leaf is tried.
 // hit_sub of a mesh hit is the LEAF-ORDER triangle index (resolve_hit maps it back).
+// Voxel grids are handled in PHASES: a lane that reaches a VolumeGrid object parks, the node loop keeps
+// running until every lane of the wavefront is parked or finished, then all parked lanes run their DDA
+// together.  Incoherent rays otherwise serialise: measured on config 5's bounce rays, running each DDA where
+// it is met left 4.4 of 64 lanes active per VALU instruction.  Per-lane order of events is unchanged.
 template <bool COUNT, bool HAS_GRID>
 __device__ __forceinline__ void walk(const SceneDev &S, uint32_t cur, int mesh_prim, Stack &st, F3 o, F3 d, F3 inv, bool sx, bool sy, bool sz,
                                      float tmin, float &closest, int &hit_prim, int &hit_sub, Work &w)
 {
     for (;;) {
-        if (cur == YCGE_REF_NONE_VALUE) {
-            float tn;
-            if (!st.pop(cur, tn)) break;
-            if (!(closest >= tn)) { cur = YCGE_REF_NONE_VALUE; continue; }
-        }
-        const uint32_t kind = YCGE_REF_KIND(cur), pay = YCGE_REF_PAYLOAD(cur);
-        if (kind == REF_MESH_NODE || kind == REF_SCENE_NODE) {
-            const float4 *np = (const float4 *)((kind == REF_MESH_NODE ? S.mesh_nodes : S.scene_nodes) + pay);
-            const float4 a = np[0], b = np[1], c = np[2], e = np[3];
-            float ln, rn;
-            bool hl, hr;
-            if (COUNT) w.box += 2;
-            if (kind == REF_MESH_NODE) {
-                hl = box_mesh(a.x, a.y, a.z, a.w, b.x, b.y, o, inv, sx, sy, sz, tmin, closest, ln);
-                hr = box_mesh(b.z, b.w, c.x, c.y, c.z, c.w, o, inv, sx, sy, sz, tmin, closest, rn);
-            } else {
-                hl = box_scene(a.x, a.y, a.z, a.w, b.x, b.y, o, inv, tmin, closest, ln);
-                hr = box_scene(b.z, b.w, c.x, c.y, c.z, c.w, o, inv, tmin, closest, rn);
+        int parked_grid = -1, parked_prim = -1;
+        for (;;) {
+            if (cur == YCGE_REF_NONE_VALUE) {
+                float tn;
+                if (!st.pop(cur, tn)) break;
+                if (!(closest >= tn)) { cur = YCGE_REF_NONE_VALUE; continue; }
             }
-            const uint32_t lref = __float_as_uint(e.x), rref = __float_as_uint(e.y);
-            if (hl & hr) {
-                if (ln < rn) { st.push(rref, rn); cur = lref; }
-                else { st.push(lref, ln); cur = rref; }
-            } else if (hl) cur = lref;
-            else if (hr) cur = rref;
-            else cur = YCGE_REF_NONE_VALUE;
-        } else if (kind == REF_MESH_LEAF) {
-            leaf_triangles<COUNT>(S, pay, mesh_prim, o, d, tmin, closest, hit_prim, hit_sub, w);
-            cur = YCGE_REF_NONE_VALUE;
-        } else if (kind == REF_SCENE_LEAF) {
-            const uint32_t start = pay >> 3, count = pay & 7u;
-            for (uint32_t i = count - 1; i >= 1; i--) st.push(YCGE_REF(REF_PRIM, S.scene_leaf_prims[start + i]), -YCGE_INF);
-            cur = YCGE_REF(REF_PRIM, S.scene_leaf_prims[start]);
-        } else {    // REF_PRIM: objectHit[objId](r, tMin, closest, ...), BVH.cs:139-149
-            const float4 *pp = (const float4 *)(S.prims + pay);
-            const float4 q0 = pp[0], q1 = pp[1], q2 = pp[2], q3 = pp[3];
-            const int type = __float_as_int(q0.x);
-            cur = YCGE_REF_NONE_VALUE;
-            if (type == 9) {            // Mesh.Hit -> MeshBVH.Hit: root pushed, popped, own box tested (p = root box, ref)
-                const uint32_t root_ref = __float_as_uint(q2.z);
-                if (root_ref != YCGE_REF_NONE_VALUE) {
-                    float tn;
-                    if (COUNT) w.box++;
-                    if (box_mesh(q1.x, q1.y, q1.z, q1.w, q2.x, q2.y, o, inv, sx, sy, sz, tmin, closest, tn)) {
-                        cur = root_ref;
-                        mesh_prim = (int)pay;
+            const uint32_t kind = YCGE_REF_KIND(cur), pay = YCGE_REF_PAYLOAD(cur);
+            if (COUNT) prof_tick(0);
+            if (kind == REF_MESH_NODE || kind == REF_SCENE_NODE) {
+                const float4 *np = (const float4 *)((kind == REF_MESH_NODE ? S.mesh_nodes : S.scene_nodes) + pay);
+                const float4 a = np[0], b = np[1], c = np[2], e = np[3];
+                float ln, rn;
+                bool hl, hr;
+                if (COUNT) w.box += 2;
+                if (kind == REF_MESH_NODE) {
+                    hl = box_mesh(a.x, a.y, a.z, a.w, b.x, b.y, o, inv, sx, sy, sz, tmin, closest, ln);
+                    hr = box_mesh(b.z, b.w, c.x, c.y, c.z, c.w, o, inv, sx, sy, sz, tmin, closest, rn);
+                } else {
+                    hl = box_scene(a.x, a.y, a.z, a.w, b.x, b.y, o, inv, tmin, closest, ln);
+                    hr = box_scene(b.z, b.w, c.x, c.y, c.z, c.w, o, inv, tmin, closest, rn);
+                }
+                const uint32_t lref = __float_as_uint(e.x), rref = __float_as_uint(e.y);
+                if (hl & hr) {
+                    if (ln < rn) { st.push(rref, rn); cur = lref; }
+                    else { st.push(lref, ln); cur = rref; }
+                } else if (hl) cur = lref;
+                else if (hr) cur = rref;
+                else cur = YCGE_REF_NONE_VALUE;
+            } else if (kind == REF_MESH_LEAF) {
+                leaf_triangles<COUNT>(S, pay, mesh_prim, o, d, tmin, closest, hit_prim, hit_sub, w);
+                cur = YCGE_REF_NONE_VALUE;
+            } else if (kind == REF_SCENE_LEAF) {
+                const uint32_t start = pay >> 3, count = pay & 7u;
+                for (uint32_t i = count - 1; i >= 1; i--) st.push(YCGE_REF(REF_PRIM, S.scene_leaf_prims[start + i]), -YCGE_INF);
+                cur = YCGE_REF(REF_PRIM, S.scene_leaf_prims[start]);
+            } else {    // REF_PRIM: objectHit[objId](r, tMin, closest, ...), BVH.cs:139-149
+                const float4 *pp = (const float4 *)(S.prims + pay);
+                const float4 q0 = pp[0];
+                const int type = __float_as_int(q0.x);
+                cur = YCGE_REF_NONE_VALUE;
+                if (type == 10) {
+                    if (HAS_GRID) { parked_grid = __float_as_int(q0.z); parked_prim = (int)pay; break; }
+                } else {
+                    const float4 q1 = pp[1], q2 = pp[2], q3 = pp[3];
+                    if (type == 9) {    // Mesh.Hit -> MeshBVH.Hit: root pushed, popped, own box tested (p = root box, ref)
+                        const uint32_t root_ref = __float_as_uint(q2.z);
+                        if (root_ref != YCGE_REF_NONE_VALUE) {
+                            float tn;
+                            if (COUNT) w.box++;
+                            if (box_mesh(q1.x, q1.y, q1.z, q1.w, q2.x, q2.y, o, inv, sx, sy, sz, tmin, closest, tn)) {
+                                cur = root_ref;
+                                mesh_prim = (int)pay;
+                            }
+                        }
+                    } else {
+                        analytic_prim<COUNT>(q0, q1, q2, q3, type, (int)pay, o, d, tmin, closest, hit_prim, hit_sub, w);
                     }
                 }
-            } else if (type == 10) {
-                if (HAS_GRID) grid_dda<COUNT>(S, __float_as_int(q0.z), (int)pay, o, d, tmin, closest, hit_prim, hit_sub, w);
-            } else {
-                analytic_prim<COUNT>(q0, q1, q2, q3, type, (int)pay, o, d, tmin, closest, hit_prim, hit_sub, w);
             }
         }
+        if (!HAS_GRID) break;
+        if (!__any(parked_grid >= 0)) break;
+        if (parked_grid >= 0) grid_dda<COUNT>(S, parked_grid, parked_prim, o, d, inv, tmin, closest, hit_prim, hit_sub, w);
     }
 }
 
@@ -753,7 +785,7 @@ __device__ __forceinline__ void traverse(const SceneDev &S, const RayQ &q, Stack
             }
             mesh_walk<COUNT>(S, start, pi, st, o, inv, d, sx, sy, sz, tmin, closest, hit_prim, hit_sub, w);
         } else if (type == 10) {
-            if (HAS_GRID) { if (root_hit) grid_dda<COUNT>(S, __float_as_int(q0.z), pi, o, d, tmin, closest, hit_prim, hit_sub, w); }
+            if (HAS_GRID) { if (root_hit) grid_dda<COUNT>(S, __float_as_int(q0.z), pi, o, d, inv, tmin, closest, hit_prim, hit_sub, w); }
         } else {
             if (root_hit) analytic_prim<COUNT>(q0, q1, q2, q3, type, pi, o, d, tmin, closest, hit_prim, hit_sub, w);
         }
