@@ -185,6 +185,10 @@ struct TraceOut {
     // per-wavefront profile of k_wf_primary (COUNT variant; may be null): 4 x u64 {start, end, node iters, leaf phases}
     unsigned long long *wave_prof;
     int32_t wave_prof_stage;            // 0 = k_wf_primary, 1 = k_wf_extend of round 1
+    // k_trace scheduling feedback: block_cost[b] = duration of 8x8 block b this frame (10 ns ticks), written every
+    // frame; block_order = permutation for THIS frame (longest blocks of the previous frame first), or null
+    uint32_t *block_cost;
+    const uint32_t *block_order;
     // traversal counters (may be null): rays, box, tri, prim, vox
     unsigned long long *counters;
 };

@@ -24,6 +24,7 @@ size_t ycge_wf_sizes(int which);
 int ycge_launch_trace(const ycge::SceneDev *S, const ycge::FrameParams *P, const ycge::TraceOut *O, int count, int flat, hipStream_t stream);
 int ycge_launch_wavefront(const ycge::SceneDev *S, const ycge::FrameParams *P, const ycge::TraceOut *O, void *const bufs[6], int rounds,
                           int has_grid, int flat, int count, hipStream_t stream);
+int ycge_launch_order_blocks(const uint32_t *cost, uint32_t n, uint32_t *order_ws, uint32_t *order, hipStream_t stream);
 int ycge_launch_taa(const ycge::TaaParams *T, const float *current, const float *normal, const float *depth, const uint8_t *sky,
                     float *hist, float *prev_normal, float *prev_depth, uint8_t *prev_sky, hipStream_t stream);
 int ycge_launch_pack_slab(const ycge::FrameParams *P, const float *hdr, const float *albedo, const float *normal, const float *depth,
@@ -97,6 +98,8 @@ struct ycge_ctx {
     // wavefront pipeline storage (ycge_kernels.hip: QEntry / HitRec / LEntry), sized for one ray per pixel
     DevBuf<uint8_t> wf_q0, wf_q1, wf_hit, wf_lq;
     DevBuf<uint32_t> wf_counts, tile_order;
+    DevBuf<uint32_t> block_cost, block_order, order_ws;   // k_trace scheduling feedback (4 blocks of 8x8 px per tile)
+    bool block_order_valid = false;
     DevBuf<uint64_t> stack_spill;                 // [YCGE_TRAVERSAL_STACK - 12][persistent lanes]
     DevBuf<float> path_stack;                  // [3][11][persistent lanes], only for scenes with transparent materials
     int spill_levels = 0;                      // traversal depth beyond the 12 LDS levels, from the uploaded trees
@@ -166,6 +169,11 @@ int alloc_tile_buffers(ycge_ctx *c)
     HIP_TRY(c, c->wf_counts.alloc((size_t)(c->n_owned > 0 ? c->n_owned : 1) * 8));
     HIP_TRY(c, c->stack_spill.alloc((size_t)(c->spill_levels > 0 ? c->spill_levels : 1) * lanes));
     c->path_stack.release();
+    {
+        const size_t nb = (size_t)(c->n_owned > 0 ? c->n_owned : 1) * 4;
+        HIP_TRY(c, c->block_cost.alloc(nb)); HIP_TRY(c, c->block_order.alloc(nb)); HIP_TRY(c, c->order_ws.alloc(16));
+        c->block_order_valid = false;
+    }
     {   // XCD-aware block -> tile table: bucket the owned tiles by image strip (4 tiles = 128 px wide, strip s -> XCD s % 8),
         // then deal the buckets out round-robin so that block b (which lands on XCD b % 8) draws from bucket b % 8
         const int n = c->n_owned, world = c->cfg.world_size, rank = c->cfg.rank;
@@ -404,7 +412,7 @@ void ycge_destroy(ycge_ctx *c)
     c->prev_normal.release(); c->prev_depth.release(); c->sky.release(); c->prev_sky.release();
     c->dbg_rays.release(); c->dbg_hit_t.release(); c->dbg_prim.release(); c->dbg_sub.release(); c->dbg_rng.release();
     c->counters.release(); c->wave_prof.release(); c->own_slab.release();
-    c->wf_q0.release(); c->wf_q1.release(); c->wf_hit.release(); c->wf_lq.release(); c->wf_counts.release(); c->tile_order.release(); c->stack_spill.release(); c->path_stack.release();
+    c->wf_q0.release(); c->wf_q1.release(); c->wf_hit.release(); c->wf_lq.release(); c->wf_counts.release(); c->tile_order.release(); c->block_cost.release(); c->block_order.release(); c->order_ws.release(); c->stack_spill.release(); c->path_stack.release();
     c->d_scene_nodes.release(); c->d_mesh_nodes.release(); c->d_scene_leaf.release(); c->d_tris.release(); c->d_prims.release();
     c->d_materials.release(); c->d_meshes.release(); c->d_grids.release(); c->d_cells.release(); c->d_lut.release(); c->d_lights.release();
     for (auto &ev : c->ev) if (ev) (void)hipEventDestroy(ev);
@@ -665,6 +673,7 @@ int ycge_scene_upload(ycge_ctx *c, const ycge_scene *s)
     int rc = upload_lights(c, s->lights, s->n_lights);
     if (rc != YCGE_OK) return rc;
     c->have_scene = true;
+    c->block_order_valid = false;
     return YCGE_OK;
 }
 
@@ -745,7 +754,7 @@ int begin_and_trace(ycge_ctx *c, float *d_slab, hipStream_t stream, FrameState &
     const bool slab = d_slab != nullptr;
     const bool debug = c->cfg.capture_debug && !slab;
     if (debug) { O.rays = c->dbg_rays.p; O.prim_id = c->dbg_prim.p; O.sub_id = c->dbg_sub.p; O.hit_t = c->dbg_hit_t.p; O.rng_state = c->dbg_rng.p; }
-    if (getenv("YCGE_WAVE_PROF")) { if (!c->wave_prof.p) HIP_TRY(c, c->wave_prof.alloc((size_t)c->n_tiles * 16)); O.wave_prof = c->wave_prof.p; O.wave_prof_stage = getenv("YCGE_WAVE_PROF")[0] == 'e' ? 1 : 0; }
+    if (getenv("YCGE_WAVE_PROF")) { if (!c->wave_prof.p) HIP_TRY(c, c->wave_prof.alloc((size_t)c->n_tiles * 16)); O.wave_prof = c->wave_prof.p; { const char ch = getenv("YCGE_WAVE_PROF")[0]; O.wave_prof_stage = ch == 'e' ? 1 : ch == 'm' ? 2 : 0; } }
     if (c->cfg.count_work) {
         O.counters = c->counters.p;
         HIP_TRY(c, hipMemsetAsync(c->counters.p, 0, 8 * sizeof(unsigned long long), stream));
@@ -764,7 +773,14 @@ int begin_and_trace(ycge_ctx *c, float *d_slab, hipStream_t stream, FrameState &
     if (single_launch) {
         if (!c->path_stack.p) HIP_TRY(c, c->path_stack.alloc((size_t)3 * 11 * O.stack_lanes));
         O.path_stack = c->path_stack.p;
+        const bool lpt = !getenv("YCGE_NO_LPT");
+        O.block_cost = lpt ? c->block_cost.p : nullptr;
+        O.block_order = (lpt && c->block_order_valid) ? c->block_order.p : nullptr;
         e = ycge_launch_trace(&c->sd, &P, &O, c->cfg.count_work, flat, stream);
+        if (e == 0 && lpt) {
+            e = ycge_launch_order_blocks(c->block_cost.p, (uint32_t)c->n_owned * 4u, c->order_ws.p, c->block_order.p, stream);
+            c->block_order_valid = true;
+        }
     } else {
         void *bufs[6] = {c->wf_q0.p, c->wf_q1.p, c->wf_hit.p, c->wf_lq.p, c->wf_counts.p, c->wf_counts.p + (size_t)7 * (c->n_owned > 0 ? c->n_owned : 1)};
         e = ycge_launch_wavefront(&c->sd, &P, &O, bufs, c->wf_rounds, c->has_grid ? 1 : 0, flat, c->cfg.count_work, stream);

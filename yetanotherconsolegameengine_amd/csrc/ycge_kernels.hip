@@ -45,14 +45,17 @@ __device__ __forceinline__ void make_primary_ray(const FrameParams &P, int px, i
 
 // block -> tile -> pixel: 32x8 tile per 256-thread block, 8x8 sub-tile per wavefront
 __device__ __forceinline__ int block_tile(const FrameParams &P) { return P.tile_order ? (int)P.tile_order[blockIdx.x] : (int)blockIdx.x; }
-__device__ __forceinline__ bool tile_pixel(const FrameParams &P, int k, int &px, int &py, int &lx, int &ly)
+__device__ __forceinline__ bool tile_pixel_wl(const FrameParams &P, int k, int wave, int lane, int &px, int &py, int &lx, int &ly)
 {
     const int tile_id = P.rank + k * P.world_size;
     const int tx = tile_id % P.tiles_x, ty = tile_id / P.tiles_x;
-    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     lx = wave * 8 + (lane & 7); ly = lane >> 3;
     px = tx * YCGE_TILE_W + lx; py = ty * YCGE_TILE_H + ly;
     return px < P.hiW && py < P.hiH;
+}
+__device__ __forceinline__ bool tile_pixel(const FrameParams &P, int k, int &px, int &py, int &lx, int &ly)
+{
+    return tile_pixel_wl(P, k, (int)(threadIdx.x >> 6), (int)(threadIdx.x & 63), px, py, lx, ly);
 }
 
 template <bool COUNT>
@@ -428,7 +431,7 @@ struct PathItem {       // PathWorkItem, RaytraceRenderer.cs:439-446 (IsPrimary 
 // it is touched only on refraction splits, and a private array would make the whole kernel scratch-backed.
 struct PathStack {
     float *base; uint32_t lanes;
-    __device__ __forceinline__ float *at(int slot, int field) const { return base + ((size_t)(slot * 11 + field) * lanes + (blockIdx.x * YCGE_BLOCK + threadIdx.x)); }
+    __device__ __forceinline__ float *at(int slot, int field) const { return base + ((size_t)(slot * 11 + field) * lanes + (blockIdx.x * blockDim.x + threadIdx.x)); }
     __device__ __forceinline__ void store(int slot, const PathItem &it) const
     {
         *at(slot, 0) = it.o.x; *at(slot, 1) = it.o.y; *at(slot, 2) = it.o.z; *at(slot, 3) = it.d.x; *at(slot, 4) = it.d.y; *at(slot, 5) = it.d.z;
@@ -445,17 +448,29 @@ struct PathStack {
     }
 };
 
+// One 64-thread workgroup per 8x8 pixel block (4 per tile): a finished wavefront frees its slot at once
+// instead of waiting for the slowest of a 256-thread workgroup (measured: 1.76 -> ~3 resident wavefronts/SIMD).
 template <bool COUNT, bool FLAT>
-__global__ __launch_bounds__(256) void k_trace(const SceneDev S, const FrameParams P, const TraceOut O)
+__global__ __launch_bounds__(64) void k_trace(const SceneDev S, const FrameParams P, const TraceOut O)
 {
     const bool DEBUG = O.prim_id != nullptr;
     Work w = {0, 0, 0, 0, 0};
-    Stack st;
+    StackT<64> st;
     st.init(O.stack_spill, O.stack_lanes);
     const PathStack pstack = {O.path_stack, O.stack_lanes};
-    const int k = block_tile(P);
+    // longest-processing-time-first: the frame ends when its slowest 8x8 block ends, so blocks are started in
+    // descending order of what they cost in the previous frame (k_order_blocks); any order gives the same pixels
+    const uint32_t bid = O.block_order ? O.block_order[blockIdx.x] : blockIdx.x;
+    const int k = (int)(bid >> 2), wave_in_tile = (int)(bid & 3);
     int px, py, lx, ly;
-    const bool in_image = tile_pixel(P, k, px, py, lx, ly);
+    const bool in_image = tile_pixel_wl(P, k, wave_in_tile, (int)threadIdx.x, px, py, lx, ly);
+    const bool prof = O.wave_prof && O.wave_prof_stage == 2;
+    const unsigned long long t_start = __builtin_amdgcn_s_memrealtime();     // 100 MHz, chip-wide
+    // the blocks that bounded the previous frame get issue priority over the light blocks sharing their SIMD
+    if (O.block_order && O.block_cost) {
+        const uint32_t prev = O.block_cost[bid];
+        if (prev > 16384u) __builtin_amdgcn_s_setprio(3); else if (prev > 4096u) __builtin_amdgcn_s_setprio(1);
+    }
 
     RayQ q;
     make_primary_ray(P, px, py, q.o, q.d);
@@ -682,7 +697,52 @@ __global__ __launch_bounds__(256) void k_trace(const SceneDev S, const FramePara
             if (O.rng_state) O.rng_state[i] = rng;
         }
     }
+    if (O.block_cost && threadIdx.x == 0) O.block_cost[bid] = (uint32_t)(__builtin_amdgcn_s_memrealtime() - t_start);
+    if (prof && (threadIdx.x & 63) == 0) {
+        unsigned long long *dst = O.wave_prof + ((size_t)k * 4 + wave_in_tile) * 4;
+        dst[0] = t_start; dst[1] = __builtin_amdgcn_s_memrealtime(); dst[2] = blockIdx.x; dst[3] = __builtin_amdgcn_s_getreg(((32 - 1) << 11) | (0 << 6) | 20);   // XCC_ID
+    }
     flush_work<COUNT>(w, O.counters);
+}
+
+// ---------------------------------------------------------------------------------- block ordering (LPT feedback)
+// Classes by floor(log2(cost)): class 7 = longest.  k_cost_hist counts the classes, k_cost_scatter writes the
+// permutation class by class (descending); both compact with wave ballots + LDS so that the global atomics are
+// 8 per 1024-thread workgroup, not one per element.
+__device__ __forceinline__ int cost_class(uint32_t c)
+{
+    const int lg = c ? 31 - __builtin_clz(c) : 0;       // 10 ns ticks: 2^9 = 5 us ... 2^16 = 655 us
+    const int k = lg - 9;
+    return k < 0 ? 0 : k > 7 ? 7 : k;
+}
+__global__ __launch_bounds__(1024) void k_cost_hist(const uint32_t *__restrict__ cost, uint32_t n, uint32_t *__restrict__ totals /* [8], zeroed */)
+{
+    __shared__ uint32_t h[8];
+    if (threadIdx.x < 8) h[threadIdx.x] = 0;
+    __syncthreads();
+    const uint32_t i = blockIdx.x * 1024u + threadIdx.x;
+    if (i < n) atomicAdd(&h[cost_class(cost[i])], 1u);
+    __syncthreads();
+    if (threadIdx.x < 8 && h[threadIdx.x]) atomicAdd(&totals[threadIdx.x], h[threadIdx.x]);
+}
+__global__ __launch_bounds__(1024) void k_cost_scatter(const uint32_t *__restrict__ cost, uint32_t n, const uint32_t *__restrict__ totals,
+                                                       uint32_t *__restrict__ cursors /* [8], zeroed */, uint32_t *__restrict__ order)
+{
+    __shared__ uint32_t h[8], base[8];
+    if (threadIdx.x < 8) h[threadIdx.x] = 0;
+    __syncthreads();
+    const uint32_t i = blockIdx.x * 1024u + threadIdx.x;
+    int cls = -1;
+    uint32_t local = 0;
+    if (i < n) { cls = cost_class(cost[i]); local = atomicAdd(&h[cls], 1u); }
+    __syncthreads();
+    if (threadIdx.x < 8) {
+        uint32_t off = 0;                                   // classes 7, 6, ..., 0 laid out in that order
+        for (int c = 7; c > (int)threadIdx.x; c--) off += totals[c];
+        base[threadIdx.x] = off + (h[threadIdx.x] ? atomicAdd(&cursors[threadIdx.x], h[threadIdx.x]) : 0u);
+    }
+    __syncthreads();
+    if (cls >= 0) order[base[cls] + local] = i;
 }
 
 // ---------------------------------------------------------------------------------- K_taa
@@ -825,7 +885,7 @@ int ycge_launch_trace(const ycge::SceneDev *S, const ycge::FrameParams *P, const
 {
     using namespace ycge;
     if (P->n_owned_tiles <= 0) return 0;
-    const dim3 grid((unsigned)P->n_owned_tiles), block(256);
+    const dim3 grid((unsigned)P->n_owned_tiles * 4u), block(64);
     sel3(count != 0, flat != 0, false, [&](auto C, auto F, auto) {
         hipLaunchKernelGGL((k_trace<decltype(C)::value, decltype(F)::value>), grid, block, 0, stream, *S, *P, *O);
     });
@@ -860,6 +920,18 @@ int ycge_launch_wavefront(const ycge::SceneDev *S, const ycge::FrameParams *P, c
             hipLaunchKernelGGL((k_wf_lights<decltype(C)::value, decltype(G)::value, decltype(F)::value>), tiles, block, 0, stream, *S, *P, *O, B, r);
         });
     }
+    return (int)hipGetLastError();
+}
+
+// order_ws: 16 uint32 (totals[8], cursors[8])
+int ycge_launch_order_blocks(const uint32_t *cost, uint32_t n, uint32_t *order_ws, uint32_t *order, hipStream_t stream)
+{
+    if (n == 0) return 0;
+    hipError_t e = hipMemsetAsync(order_ws, 0, 16 * sizeof(uint32_t), stream);
+    if (e != hipSuccess) return (int)e;
+    const dim3 grid((n + 1023u) / 1024u), block(1024);
+    hipLaunchKernelGGL(ycge::k_cost_hist, grid, block, 0, stream, cost, n, order_ws);
+    hipLaunchKernelGGL(ycge::k_cost_scatter, grid, block, 0, stream, cost, n, order_ws, order_ws + 8, order);
     return (int)hipGetLastError();
 }
 

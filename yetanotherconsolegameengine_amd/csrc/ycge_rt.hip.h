@@ -516,14 +516,16 @@ __device__ __forceinline__ bool is_wire_on_face(const GGrid &g, F3 p, int ix, in
 // than the spill traffic.
 #define YCGE_LDS_STACK 12
 #define YCGE_BLOCK 256
-static __shared__ uint2 g_lds_stack[YCGE_LDS_STACK * YCGE_BLOCK];
-struct Stack {
+static __shared__ uint2 g_lds_stack[YCGE_LDS_STACK * YCGE_BLOCK];     // 256-thread workgroups (tile = workgroup)
+static __shared__ uint2 g_lds_stack64[YCGE_LDS_STACK * 64];           // 64-thread workgroups (8x8 block = workgroup)
+template <int BS>
+struct StackT {
     uint2 *spill;          // this lane's column of the spill area
     uint32_t spill_stride; // lanes in the grid
     int sp;
     __device__ __forceinline__ void init(void *spill_base, uint32_t n_lanes)
     {
-        spill = (uint2 *)spill_base + (blockIdx.x * YCGE_BLOCK + threadIdx.x);
+        spill = (uint2 *)spill_base + (blockIdx.x * BS + threadIdx.x);
         spill_stride = n_lanes;
         sp = 0;
     }
@@ -531,7 +533,7 @@ struct Stack {
     __device__ __forceinline__ void push(uint32_t ref, float tnear)
     {
         const uint2 v = make_uint2(ref, __float_as_uint(tnear));
-        if (sp < YCGE_LDS_STACK) g_lds_stack[sp * YCGE_BLOCK + threadIdx.x] = v;
+        if (sp < YCGE_LDS_STACK) { if (BS == 64) g_lds_stack64[sp * 64 + threadIdx.x] = v; else g_lds_stack[sp * YCGE_BLOCK + threadIdx.x] = v; }
         else spill[(size_t)(sp - YCGE_LDS_STACK) * spill_stride] = v;
         sp++;
     }
@@ -540,12 +542,13 @@ struct Stack {
         if (sp == 0) return false;
         sp--;
         uint2 v;
-        if (sp < YCGE_LDS_STACK) v = g_lds_stack[sp * YCGE_BLOCK + threadIdx.x];
+        if (sp < YCGE_LDS_STACK) v = BS == 64 ? g_lds_stack64[sp * 64 + threadIdx.x] : g_lds_stack[sp * YCGE_BLOCK + threadIdx.x];
         else v = spill[(size_t)(sp - YCGE_LDS_STACK) * spill_stride];
         ref = v.x; tnear = __uint_as_float(v.y);
         return true;
     }
 };
+using Stack = StackT<256>;
 
 // MeshBVH.TriHit, MeshBVH.cs:239-304: scaled-numerator Moller-Trumbore, one divide on accept.
 struct TriData { float4 t0, t1; float e2z; };
@@ -626,8 +629,8 @@ __device__ __forceinline__ void leaf_triangles(const SceneDev &S, uint32_t pay, 
 // running until every lane of the wavefront is parked or finished, then all parked lanes run their DDA
 // together.  Incoherent rays otherwise serialise: measured on config 5's bounce rays, running each DDA where
 // it is met left 4.4 of 64 lanes active per VALU instruction.  Per-lane order of events is unchanged.
-template <bool COUNT, bool HAS_GRID>
-__device__ __forceinline__ void walk(const SceneDev &S, uint32_t cur, int mesh_prim, Stack &st, F3 o, F3 d, F3 inv, bool sx, bool sy, bool sz,
+template <bool COUNT, bool HAS_GRID, class STK>
+__device__ __forceinline__ void walk(const SceneDev &S, uint32_t cur, int mesh_prim, STK &st, F3 o, F3 d, F3 inv, bool sx, bool sy, bool sz,
                                      float tmin, float &closest, int &hit_prim, int &hit_sub, Work &w)
 {
     for (;;) {
@@ -705,8 +708,8 @@ __device__ __forceinline__ void walk(const SceneDev &S, uint32_t cur, int mesh_p
 // is the serial latency chain of its slowest wavefront (measured: tens of x the mean), and this form makes
 // a wavefront's iteration count ~ max over lanes of (nodes + triangles) instead of the sum over "rounds"
 // of the slowest lane per round that a while-while loop pays.  Visit order is unchanged.
-template <bool COUNT>
-__device__ __forceinline__ void mesh_walk(const SceneDev &S, uint32_t cur, int mesh_prim, Stack &st, F3 o, F3 inv, F3 d, bool sx, bool sy,
+template <bool COUNT, class STK>
+__device__ __forceinline__ void mesh_walk(const SceneDev &S, uint32_t cur, int mesh_prim, STK &st, F3 o, F3 inv, F3 d, bool sx, bool sy,
                                           bool sz, float tmin, float &closest, int &hit_prim, int &hit_sub, Work &w)
 {
     while (cur != YCGE_REF_NONE_VALUE) {
@@ -747,8 +750,8 @@ __device__ __forceinline__ void mesh_walk(const SceneDev &S, uint32_t cur, int m
 // the reference): the object list is walked in leaf order with WAVE-UNIFORM control flow, so object records
 // come through the scalar cache and only the per-lane mesh walk diverges.  Otherwise the generic walk
 // starts at the scene root.  Both give the reference's visit order.
-template <bool COUNT, bool HAS_GRID, bool FLAT>
-__device__ __forceinline__ void traverse(const SceneDev &S, const RayQ &q, Stack &st, float &closest, int &hit_prim, int &hit_sub, Work &w)
+template <bool COUNT, bool HAS_GRID, bool FLAT, class STK>
+__device__ __forceinline__ void traverse(const SceneDev &S, const RayQ &q, STK &st, float &closest, int &hit_prim, int &hit_sub, Work &w)
 {
     const F3 o = q.o, d = q.d;
     const float tmin = q.tmin;
