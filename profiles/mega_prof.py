@@ -22,12 +22,16 @@ assert r.L.ycge_debug_read_wave_prof(r.ctx, buf.ctypes.data, buf.size) == 0
 p = buf.reshape(-1, 4).astype(np.int64)
 dur = p[:, 1] - p[:, 0]
 xcc = p[:, 3] & 0xf
+lg = (p[:, 3] >> 32) & 0xf          # log2(parts) of the block's schedule entry (part 0 reports)
+steps = p[:, 2] >> 32               # lane 0's traversal steps
+p[:, 2] &= 0xffffffff
 print("xcc ids seen", np.unique(xcc))
 t0 = p[:, 0].min()
 start = p[:, 0] - t0
 end = start + dur
 print("timestamps are 100 MHz ticks (10 ns). kernel span us:", end.max() / 100.0)
 print("wave duration us pcts 50/90/99/max", np.percentile(dur, [50, 90, 99]) / 100.0, dur.max() / 100.0)
+print("blocks split into 1/4/16/64 parts:", [int((lg == v).sum()) for v in (0, 2, 4, 6)])
 print("last waves to finish:")
 for i in np.argsort(-end)[:8]:
     print(f"  wave {i} tile {i//4} block {p[i,2]} xcc {xcc[i]} start_us {start[i]/100:.1f} dur_us {dur[i]/100:.1f} end_us {end[i]/100:.1f}")

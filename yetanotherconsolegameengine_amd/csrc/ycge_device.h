@@ -114,6 +114,7 @@ struct GLight {
 };
 
 #define YCGE_TRAVERSAL_STACK 96    // >= scene depth + 4 leaf prims + mesh depth, checked at upload
+#define YCGE_SCHEDULE_SLACK 2u      // k_trace grid = blocks x this: room for the parts of split blocks
 #define YCGE_TILE_W 32
 #define YCGE_TILE_H 8
 #define YCGE_SLAB_FLOATS 11        // hdr rgb, albedo rgb, normal xyz, depth, sky
@@ -185,10 +186,12 @@ struct TraceOut {
     // per-wavefront profile of k_wf_primary (COUNT variant; may be null): 4 x u64 {start, end, node iters, leaf phases}
     unsigned long long *wave_prof;
     int32_t wave_prof_stage;            // 0 = k_wf_primary, 1 = k_wf_extend of round 1
-    // k_trace scheduling feedback: block_cost[b] = duration of 8x8 block b this frame (10 ns ticks), written every
-    // frame; block_order = permutation for THIS frame (longest blocks of the previous frame first), or null
+    // k_trace scheduling feedback: block_cost[b] = traversal steps of 8x8 block b's longest lane this frame
+    // (atomicMax; cleared by k_cost_scatter); block_order / n_order = THIS frame's schedule built from the previous
+    // frame's costs (entries: see k_trace), or null = one wavefront per block in index order
     uint32_t *block_cost;
     const uint32_t *block_order;
+    const uint32_t *n_order;
     // traversal counters (may be null): rays, box, tri, prim, vox
     unsigned long long *counters;
 };

@@ -24,7 +24,7 @@ size_t ycge_wf_sizes(int which);
 int ycge_launch_trace(const ycge::SceneDev *S, const ycge::FrameParams *P, const ycge::TraceOut *O, int count, int flat, hipStream_t stream);
 int ycge_launch_wavefront(const ycge::SceneDev *S, const ycge::FrameParams *P, const ycge::TraceOut *O, void *const bufs[6], int rounds,
                           int has_grid, int flat, int count, hipStream_t stream);
-int ycge_launch_order_blocks(const uint32_t *cost, uint32_t n, uint32_t *order_ws, uint32_t *order, hipStream_t stream);
+int ycge_launch_order_blocks(uint32_t *cost, uint32_t n, uint32_t policy, uint32_t *order_ws, uint32_t *order, hipStream_t stream);
 int ycge_launch_taa(const ycge::TaaParams *T, const float *current, const float *normal, const float *depth, const uint8_t *sky,
                     float *hist, float *prev_normal, float *prev_depth, uint8_t *prev_sky, hipStream_t stream);
 int ycge_launch_pack_slab(const ycge::FrameParams *P, const float *hdr, const float *albedo, const float *normal, const float *depth,
@@ -48,7 +48,7 @@ template <class T> struct DevBuf {
         release();
         n = count;
         if (count == 0) return hipSuccess;
-        return hipMalloc((void **)&p, count * sizeof(T));
+        return hipMalloc((void **)&p, count * sizeof(T) + 64);     // records are read with whole 64-byte fetches (GTri is 48 B)
     }
     hipError_t upload(const std::vector<T> &v)
     {
@@ -164,14 +164,16 @@ int alloc_frame_buffers(ycge_ctx *c)
 int alloc_tile_buffers(ycge_ctx *c)
 {
     const size_t lanes = (size_t)(c->n_owned > 0 ? c->n_owned : 1) * 256;
+    const size_t stack_lanes = lanes * YCGE_SCHEDULE_SLACK;      // k_trace's grid includes the schedule's slack entries
     HIP_TRY(c, c->wf_q0.alloc(lanes * ycge_wf_sizes(0))); HIP_TRY(c, c->wf_q1.alloc(lanes * ycge_wf_sizes(0)));
     HIP_TRY(c, c->wf_hit.alloc(lanes * ycge_wf_sizes(1))); HIP_TRY(c, c->wf_lq.alloc(lanes * ycge_wf_sizes(2)));
     HIP_TRY(c, c->wf_counts.alloc((size_t)(c->n_owned > 0 ? c->n_owned : 1) * 8));
-    HIP_TRY(c, c->stack_spill.alloc((size_t)(c->spill_levels > 0 ? c->spill_levels : 1) * lanes));
+    HIP_TRY(c, c->stack_spill.alloc((size_t)(c->spill_levels > 0 ? c->spill_levels : 1) * stack_lanes));
     c->path_stack.release();
     {
         const size_t nb = (size_t)(c->n_owned > 0 ? c->n_owned : 1) * 4;
-        HIP_TRY(c, c->block_cost.alloc(nb)); HIP_TRY(c, c->block_order.alloc(nb)); HIP_TRY(c, c->order_ws.alloc(16));
+        HIP_TRY(c, c->block_cost.alloc(nb)); HIP_TRY(c, c->block_order.alloc(nb * YCGE_SCHEDULE_SLACK)); HIP_TRY(c, c->order_ws.alloc(18));
+        HIP_TRY(c, hipMemset(c->block_cost.p, 0, nb * sizeof(uint32_t)));
         c->block_order_valid = false;
     }
     {   // XCD-aware block -> tile table: bucket the owned tiles by image strip (4 tiles = 128 px wide, strip s -> XCD s % 8),
@@ -762,7 +764,7 @@ int begin_and_trace(ycge_ctx *c, float *d_slab, hipStream_t stream, FrameState &
     if (timed) HIP_TRY(c, hipEventRecord(c->ev[0], stream));
     int e;
     O.stack_spill = c->stack_spill.p;
-    O.stack_lanes = (uint32_t)(c->n_owned > 0 ? c->n_owned : 1) * 256u;
+    O.stack_lanes = (uint32_t)(c->n_owned > 0 ? c->n_owned : 1) * 256u * YCGE_SCHEDULE_SLACK;
     O.path_stack = c->path_stack.p;
     const int flat = YCGE_REF_KIND(c->sd.scene_root_ref) == REF_SCENE_LEAF ? 1 : 0;
     // Path choice.  Refraction splits need TraceFull's per-pixel LIFO -> single launch.  Otherwise: scenes
@@ -776,9 +778,11 @@ int begin_and_trace(ycge_ctx *c, float *d_slab, hipStream_t stream, FrameState &
         const bool lpt = !getenv("YCGE_NO_LPT");
         O.block_cost = lpt ? c->block_cost.p : nullptr;
         O.block_order = (lpt && c->block_order_valid) ? c->block_order.p : nullptr;
+        O.n_order = c->order_ws.p + 16;
         e = ycge_launch_trace(&c->sd, &P, &O, c->cfg.count_work, flat, stream);
         if (e == 0 && lpt) {
-            e = ycge_launch_order_blocks(c->block_cost.p, (uint32_t)c->n_owned * 4u, c->order_ws.p, c->block_order.p, stream);
+            static const uint32_t policy = getenv("YCGE_SPLIT") ? (uint32_t)strtoul(getenv("YCGE_SPLIT"), nullptr, 8) : 0u;   // octal: digit c = log2(parts) of class c
+            e = ycge_launch_order_blocks(c->block_cost.p, (uint32_t)c->n_owned * 4u, policy, c->order_ws.p, c->block_order.p, stream);
             c->block_order_valid = true;
         }
     } else {

@@ -129,7 +129,7 @@ __device__ __forceinline__ uint32_t block_compact(bool want, uint32_t *s_cnt /* 
 template <bool COUNT, bool HAS_GRID, bool FLAT>
 __global__ __launch_bounds__(256) void k_wf_primary(const SceneDev S, const FrameParams P, const TraceOut O, const WfBuffers B)
 {
-    Work w = {0, 0, 0, 0, 0};
+    Work w = {0, 0, 0, 0, 0, 0};
     const int k = block_tile(P);
     int px, py, lx, ly;
     unsigned long long t_start = 0;
@@ -167,7 +167,7 @@ __global__ __launch_bounds__(256) void k_wf_extend(const SceneDev S, const Trace
 {
     const int k = B.tile_order ? (int)B.tile_order[blockIdx.x] : (int)blockIdx.x;
     const uint32_t n = B.n_q[(size_t)round * B.tiles + k];
-    Work w = {0, 0, 0, 0, 0};
+    Work w = {0, 0, 0, 0, 0, 0};
     const bool prof = O.wave_prof && O.wave_prof_stage == 1 && round == 1;
     unsigned long long t_start = 0;
     if (prof) {
@@ -339,7 +339,7 @@ __global__ __launch_bounds__(256) void k_wf_lights(const SceneDev S, const Frame
 {
     const int k = block_tile(P);
     const uint32_t n = B.n_lq[k];
-    Work w = {0, 0, 0, 0, 0};
+    Work w = {0, 0, 0, 0, 0, 0};
     if (threadIdx.x < n) {
         const float4 *src = (const float4 *)(B.lq + (size_t)k * 256 + threadIdx.x);
         const float4 a = src[0], b = src[1], c = src[2], e = src[3];
@@ -448,29 +448,38 @@ struct PathStack {
     }
 };
 
-// One 64-thread workgroup per 8x8 pixel block (4 per tile): a finished wavefront frees its slot at once
-// instead of waiting for the slowest of a 256-thread workgroup (measured: 1.76 -> ~3 resident wavefronts/SIMD).
+// One 64-thread workgroup per schedule entry.  An entry is an 8x8 pixel block (4 per tile) or, for the blocks that
+// bounded the previous frame, one PART of a block: the frame ends when its slowest wavefront ends, that wavefront's
+// time is (steps of its longest lane) x (time per step), and a wavefront with few live lanes steps about twice as
+// fast as a full one (one lane's path through the node / triangle / pop code instead of all of them, fewer
+// divergent fetches per step).  So k_order_blocks splits a heavy block over 4, 16 or 64 wavefronts of 16, 4 or 1
+// pixels, and lists the entries longest first.  Which lane computes a pixel never changes the pixel.
+//   entry = block (22 bits) | part << 22 (6 bits) | log2(parts) << 28
+#define YCGE_ENT_BLOCK(e) ((e) & 0x3fffffu)
+#define YCGE_ENT_PART(e) (((e) >> 22) & 63u)
+#define YCGE_ENT_LG(e) ((e) >> 28)
 template <bool COUNT, bool FLAT>
-__global__ __launch_bounds__(64) void k_trace(const SceneDev S, const FrameParams P, const TraceOut O)
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu((FLAT && !COUNT) ? 3 : 2, 8))) void k_trace(const SceneDev S, const FrameParams P, const TraceOut O)
 {
     const bool DEBUG = O.prim_id != nullptr;
-    Work w = {0, 0, 0, 0, 0};
+    uint32_t ent = blockIdx.x;
+    if (O.block_order) {
+        if (blockIdx.x >= *O.n_order) return;
+        ent = O.block_order[blockIdx.x];
+    } else if (blockIdx.x >= (uint32_t)P.n_owned_tiles * 4u) return;
+    Work w = {0, 0, 0, 0, 0, 0};
     StackT<64> st;
     st.init(O.stack_spill, O.stack_lanes);
     const PathStack pstack = {O.path_stack, O.stack_lanes};
-    // longest-processing-time-first: the frame ends when its slowest 8x8 block ends, so blocks are started in
-    // descending order of what they cost in the previous frame (k_order_blocks); any order gives the same pixels
-    const uint32_t bid = O.block_order ? O.block_order[blockIdx.x] : blockIdx.x;
+    const uint32_t bid = YCGE_ENT_BLOCK(ent), lg = YCGE_ENT_LG(ent);
     const int k = (int)(bid >> 2), wave_in_tile = (int)(bid & 3);
+    const int live_lanes = 64 >> lg;
+    const int pix_in_block = (int)YCGE_ENT_PART(ent) * live_lanes + (int)threadIdx.x;
     int px, py, lx, ly;
-    const bool in_image = tile_pixel_wl(P, k, wave_in_tile, (int)threadIdx.x, px, py, lx, ly);
+    const bool in_image = tile_pixel_wl(P, k, wave_in_tile, pix_in_block & 63, px, py, lx, ly) && (int)threadIdx.x < live_lanes;
     const bool prof = O.wave_prof && O.wave_prof_stage == 2;
     const unsigned long long t_start = __builtin_amdgcn_s_memrealtime();     // 100 MHz, chip-wide
-    // the blocks that bounded the previous frame get issue priority over the light blocks sharing their SIMD
-    if (O.block_order && O.block_cost) {
-        const uint32_t prev = O.block_cost[bid];
-        if (prev > 16384u) __builtin_amdgcn_s_setprio(3); else if (prev > 4096u) __builtin_amdgcn_s_setprio(1);
-    }
+    if (lg) __builtin_amdgcn_s_setprio(3);      // the frame's critical path: issue priority over the light blocks sharing the SIMD
 
     RayQ q;
     make_primary_ray(P, px, py, q.o, q.d);
@@ -697,52 +706,76 @@ __global__ __launch_bounds__(64) void k_trace(const SceneDev S, const FrameParam
             if (O.rng_state) O.rng_state[i] = rng;
         }
     }
-    if (O.block_cost && threadIdx.x == 0) O.block_cost[bid] = (uint32_t)(__builtin_amdgcn_s_memrealtime() - t_start);
-    if (prof && (threadIdx.x & 63) == 0) {
+    if (O.block_cost) {     // feedback for the next frame's schedule: the block's longest lane, in traversal steps (mode-independent)
+        uint32_t m = w.steps;
+        for (int off = 32; off >= 1; off >>= 1) { const uint32_t o2 = (uint32_t)__shfl_xor((int)m, off, 64); m = o2 > m ? o2 : m; }
+        if (threadIdx.x == 0) atomicMax(O.block_cost + bid, m);
+    }
+    if (prof && threadIdx.x == 0 && YCGE_ENT_PART(ent) == 0) {
         unsigned long long *dst = O.wave_prof + ((size_t)k * 4 + wave_in_tile) * 4;
-        dst[0] = t_start; dst[1] = __builtin_amdgcn_s_memrealtime(); dst[2] = blockIdx.x; dst[3] = __builtin_amdgcn_s_getreg(((32 - 1) << 11) | (0 << 6) | 20);   // XCC_ID
+        dst[0] = t_start; dst[1] = __builtin_amdgcn_s_memrealtime(); dst[2] = blockIdx.x | ((unsigned long long)w.steps << 32);
+        dst[3] = __builtin_amdgcn_s_getreg(((32 - 1) << 11) | (0 << 6) | 20) | ((unsigned long long)lg << 32);   // XCC_ID
     }
     flush_work<COUNT>(w, O.counters);
 }
 
-// ---------------------------------------------------------------------------------- block ordering (LPT feedback)
-// Classes by floor(log2(cost)): class 7 = longest.  k_cost_hist counts the classes, k_cost_scatter writes the
-// permutation class by class (descending); both compact with wave ballots + LDS so that the global atomics are
-// 8 per 1024-thread workgroup, not one per element.
+// ---------------------------------------------------------------------------------- block schedule (feedback from the previous frame)
+// cost[b] = steps of block b's longest lane.  Classes by floor(log2(steps)); class 7 = longest.  The three top
+// classes are split (see k_trace).  k_cost_hist counts entries per class, k_cost_scatter writes the schedule class
+// by class (descending) and clears cost[] for the next frame's atomicMax; both batch their global atomics through LDS.
+// ws: [0..7] entries per class, [8..15] cursors, [16] total entries (read by k_trace), [17] = 1 when splitting fits the grid
 __device__ __forceinline__ int cost_class(uint32_t c)
 {
-    const int lg = c ? 31 - __builtin_clz(c) : 0;       // 10 ns ticks: 2^9 = 5 us ... 2^16 = 655 us
-    const int k = lg - 9;
+    const int lg = c ? 31 - __builtin_clz(c) : 0;       // steps: 2^4 = 16 ... 2^10 = 1024
+    const int k = lg - 3;
     return k < 0 ? 0 : k > 7 ? 7 : k;
 }
-__global__ __launch_bounds__(1024) void k_cost_hist(const uint32_t *__restrict__ cost, uint32_t n, uint32_t *__restrict__ totals /* [8], zeroed */)
+// split policy: log2(parts) of class c in bits [3c, 3c+3) of `policy`
+__device__ __forceinline__ uint32_t class_lg_parts(uint32_t policy, int cls) { return (policy >> (3 * cls)) & 7u; }
+__global__ __launch_bounds__(1024) void k_cost_hist(const uint32_t *__restrict__ cost, uint32_t n, uint32_t *__restrict__ ws)
 {
     __shared__ uint32_t h[8];
     if (threadIdx.x < 8) h[threadIdx.x] = 0;
     __syncthreads();
     const uint32_t i = blockIdx.x * 1024u + threadIdx.x;
-    if (i < n) atomicAdd(&h[cost_class(cost[i])], 1u);
+    if (i < n) { const int cls = cost_class(cost[i]); atomicAdd(&h[cls], 1u); }
     __syncthreads();
-    if (threadIdx.x < 8 && h[threadIdx.x]) atomicAdd(&totals[threadIdx.x], h[threadIdx.x]);
+    if (threadIdx.x < 8 && h[threadIdx.x]) atomicAdd(&ws[threadIdx.x], h[threadIdx.x]);
 }
-__global__ __launch_bounds__(1024) void k_cost_scatter(const uint32_t *__restrict__ cost, uint32_t n, const uint32_t *__restrict__ totals,
-                                                       uint32_t *__restrict__ cursors /* [8], zeroed */, uint32_t *__restrict__ order)
+__global__ __launch_bounds__(1024) void k_cost_scatter(uint32_t *__restrict__ cost, uint32_t n, uint32_t capacity, uint32_t policy,
+                                                       uint32_t *__restrict__ ws, uint32_t *__restrict__ order)
 {
     __shared__ uint32_t h[8], base[8];
+    __shared__ uint32_t s_split;
     if (threadIdx.x < 8) h[threadIdx.x] = 0;
+    if (threadIdx.x == 0) {     // every workgroup derives the same decision from the finished histogram
+        uint32_t total = 0;
+        for (int c = 0; c < 8; c++) total += ws[c] << class_lg_parts(policy, c);
+        s_split = total <= capacity ? 1u : 0u;
+        if (blockIdx.x == 0) ws[16] = s_split ? total : n;
+    }
     __syncthreads();
+    const bool split = s_split != 0;
     const uint32_t i = blockIdx.x * 1024u + threadIdx.x;
     int cls = -1;
-    uint32_t local = 0;
-    if (i < n) { cls = cost_class(cost[i]); local = atomicAdd(&h[cls], 1u); }
+    uint32_t local = 0, lgp = 0;
+    if (i < n) {
+        cls = cost_class(cost[i]);
+        cost[i] = 0;
+        lgp = split ? class_lg_parts(policy, cls) : 0u;
+        local = atomicAdd(&h[cls], 1u << lgp);
+    }
     __syncthreads();
     if (threadIdx.x < 8) {
         uint32_t off = 0;                                   // classes 7, 6, ..., 0 laid out in that order
-        for (int c = 7; c > (int)threadIdx.x; c--) off += totals[c];
-        base[threadIdx.x] = off + (h[threadIdx.x] ? atomicAdd(&cursors[threadIdx.x], h[threadIdx.x]) : 0u);
+        for (int c = 7; c > (int)threadIdx.x; c--) off += ws[c] << (split ? class_lg_parts(policy, c) : 0u);
+        base[threadIdx.x] = off + (h[threadIdx.x] ? atomicAdd(&ws[8 + threadIdx.x], h[threadIdx.x]) : 0u);
     }
     __syncthreads();
-    if (cls >= 0) order[base[cls] + local] = i;
+    if (cls >= 0) {
+        uint32_t *dst = order + base[cls] + local;
+        for (uint32_t p = 0; p < (1u << lgp); p++) dst[p] = i | (p << 22) | (lgp << 28);
+    }
 }
 
 // ---------------------------------------------------------------------------------- K_taa
@@ -885,7 +918,7 @@ int ycge_launch_trace(const ycge::SceneDev *S, const ycge::FrameParams *P, const
 {
     using namespace ycge;
     if (P->n_owned_tiles <= 0) return 0;
-    const dim3 grid((unsigned)P->n_owned_tiles * 4u), block(64);
+    const dim3 grid((unsigned)P->n_owned_tiles * 4u * YCGE_SCHEDULE_SLACK), block(64);   // schedule capacity; idle entries exit at once
     sel3(count != 0, flat != 0, false, [&](auto C, auto F, auto) {
         hipLaunchKernelGGL((k_trace<decltype(C)::value, decltype(F)::value>), grid, block, 0, stream, *S, *P, *O);
     });
@@ -923,15 +956,15 @@ int ycge_launch_wavefront(const ycge::SceneDev *S, const ycge::FrameParams *P, c
     return (int)hipGetLastError();
 }
 
-// order_ws: 16 uint32 (totals[8], cursors[8])
-int ycge_launch_order_blocks(const uint32_t *cost, uint32_t n, uint32_t *order_ws, uint32_t *order, hipStream_t stream)
+// builds next frame's k_trace schedule from this frame's per-block step counts.  ws: 18 uint32 (see k_cost_hist)
+int ycge_launch_order_blocks(uint32_t *cost, uint32_t n, uint32_t policy, uint32_t *ws, uint32_t *order, hipStream_t stream)
 {
     if (n == 0) return 0;
-    hipError_t e = hipMemsetAsync(order_ws, 0, 16 * sizeof(uint32_t), stream);
+    hipError_t e = hipMemsetAsync(ws, 0, 18 * sizeof(uint32_t), stream);
     if (e != hipSuccess) return (int)e;
     const dim3 grid((n + 1023u) / 1024u), block(1024);
-    hipLaunchKernelGGL(ycge::k_cost_hist, grid, block, 0, stream, cost, n, order_ws);
-    hipLaunchKernelGGL(ycge::k_cost_scatter, grid, block, 0, stream, cost, n, order_ws, order_ws + 8, order);
+    hipLaunchKernelGGL(ycge::k_cost_hist, grid, block, 0, stream, cost, n, ws);
+    hipLaunchKernelGGL(ycge::k_cost_scatter, grid, block, 0, stream, cost, n, n * YCGE_SCHEDULE_SLACK, policy, ws, order);
     return (int)hipGetLastError();
 }
 

@@ -39,8 +39,9 @@ struct RayQ {              // one closest-hit query: Scene.Hit(r, tMin, tMax)
     float tmin, tmax;
 };
 
-struct Work {              // SURVEY 8(d) counters
+struct Work {              // SURVEY 8(d) counters (COUNT variants) + this lane's traversal steps (always; scheduling feedback)
     unsigned rays, box, tri, prim, vox;
+    unsigned steps;
 };
 
 // wave-level iteration counters (profiling aid, only touched by COUNT variants)
@@ -455,6 +456,7 @@ __device__ __forceinline__ void grid_dda(const SceneDev &S, int grid_index_, int
     const bool use_mask = g.has_brick_mask != 0;
     while (t <= t_exit && t <= tmax) {
         if (COUNT) prof_tick(3);
+        w.steps++;
         if ((uint32_t)ix < (uint32_t)g.nx && (uint32_t)iy < (uint32_t)g.ny && (uint32_t)iz < (uint32_t)g.nz) {
             if (COUNT) w.vox++;
             const int brick = (((iz >> 3) * g.nby) + (iy >> 3)) * g.nbx + (ix >> 3);
@@ -518,33 +520,53 @@ __device__ __forceinline__ bool is_wire_on_face(const GGrid &g, F3 p, int ix, in
 #define YCGE_BLOCK 256
 static __shared__ uint2 g_lds_stack[YCGE_LDS_STACK * YCGE_BLOCK];     // 256-thread workgroups (tile = workgroup)
 static __shared__ uint2 g_lds_stack64[YCGE_LDS_STACK * 64];           // 64-thread workgroups (8x8 block = workgroup)
+
+// The LDS part is accessed with explicit ds_read_b64 / ds_write_b64: written as plain C++ the compiler merges the
+// "LDS or spill" choice into ONE flat_load through a selected generic pointer (seen in the ISA), which puts the
+// LDS pop on the slow flat path in the middle of the traversal's dependency chain.
+typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ void lds_write_b64(uint32_t byte_addr, uint32_t x, uint32_t y)
+{
+    u32x2 v; v.x = x; v.y = y;
+    asm volatile("ds_write_b64 %0, %1" : : "v"(byte_addr), "v"(v) : "memory");
+}
+__device__ __forceinline__ u32x2 lds_read_b64(uint32_t byte_addr)
+{
+    u32x2 v;
+    asm volatile("ds_read_b64 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=v"(v) : "v"(byte_addr) : "memory");
+    return v;
+}
 template <int BS>
 struct StackT {
     uint2 *spill;          // this lane's column of the spill area
     uint32_t spill_stride; // lanes in the grid
+    uint32_t lds_base;     // LDS byte address of this lane's level-0 slot (levels are BS * 8 bytes apart)
     int sp;
     __device__ __forceinline__ void init(void *spill_base, uint32_t n_lanes)
     {
         spill = (uint2 *)spill_base + (blockIdx.x * BS + threadIdx.x);
         spill_stride = n_lanes;
+        lds_base = (uint32_t)(uintptr_t)(BS == 64 ? (void *)g_lds_stack64 : (void *)g_lds_stack) + threadIdx.x * 8u;
         sp = 0;
     }
     __device__ __forceinline__ void reset() { sp = 0; }
     __device__ __forceinline__ void push(uint32_t ref, float tnear)
     {
-        const uint2 v = make_uint2(ref, __float_as_uint(tnear));
-        if (sp < YCGE_LDS_STACK) { if (BS == 64) g_lds_stack64[sp * 64 + threadIdx.x] = v; else g_lds_stack[sp * YCGE_BLOCK + threadIdx.x] = v; }
-        else spill[(size_t)(sp - YCGE_LDS_STACK) * spill_stride] = v;
+        if (sp < YCGE_LDS_STACK) lds_write_b64(lds_base + (uint32_t)sp * (BS * 8u), ref, __float_as_uint(tnear));
+        else spill[(size_t)(sp - YCGE_LDS_STACK) * spill_stride] = make_uint2(ref, __float_as_uint(tnear));
         sp++;
     }
     __device__ __forceinline__ bool pop(uint32_t &ref, float &tnear)
     {
         if (sp == 0) return false;
         sp--;
-        uint2 v;
-        if (sp < YCGE_LDS_STACK) v = BS == 64 ? g_lds_stack64[sp * 64 + threadIdx.x] : g_lds_stack[sp * YCGE_BLOCK + threadIdx.x];
-        else v = spill[(size_t)(sp - YCGE_LDS_STACK) * spill_stride];
-        ref = v.x; tnear = __uint_as_float(v.y);
+        if (sp < YCGE_LDS_STACK) {
+            const u32x2 v = lds_read_b64(lds_base + (uint32_t)sp * (BS * 8u));
+            ref = v.x; tnear = __uint_as_float(v.y);
+        } else {
+            const uint2 v = spill[(size_t)(sp - YCGE_LDS_STACK) * spill_stride];
+            ref = v.x; tnear = __uint_as_float(v.y);
+        }
         return true;
     }
 };
@@ -643,6 +665,7 @@ __device__ __forceinline__ void walk(const SceneDev &S, uint32_t cur, int mesh_p
             }
             const uint32_t kind = YCGE_REF_KIND(cur), pay = YCGE_REF_PAYLOAD(cur);
             if (COUNT) prof_tick(0);
+            w.steps++;
             if (kind == REF_MESH_NODE || kind == REF_SCENE_NODE) {
                 const float4 *np = (const float4 *)((kind == REF_MESH_NODE ? S.mesh_nodes : S.scene_nodes) + pay);
                 const float4 a = np[0], b = np[1], c = np[2], e = np[3];
@@ -702,12 +725,57 @@ __device__ __forceinline__ void walk(const SceneDev &S, uint32_t cur, int mesh_p
 }
 
 // MeshBVH.Hit (MeshBVH.cs:132-236) for one mesh as a UNIFIED-STEP loop: in every iteration each live lane
-// either visits one internal node (one 64-byte fetch, two slab tests, order, stack the far child) or tests
-// one triangle of its current leaf (36-byte fetch), whichever it is at.  Both fetches are issued as the
-// same load sequence from a per-lane address, so an iteration has ONE memory wait.  The kernel's duration
-// is the serial latency chain of its slowest wavefront (measured: tens of x the mean), and this form makes
-// a wavefront's iteration count ~ max over lanes of (nodes + triangles) instead of the sum over "rounds"
-// of the slowest lane per round that a while-while loop pays.  Visit order is unchanged.
+// either visits one internal node (two slab tests, order, stack the far child) or tests one triangle of its
+// current leaf, whichever it is at.  Both record kinds are fetched by the SAME four 16-byte loads from a
+// per-lane address (a 48-byte triangle record is over-read by 16 bytes; the arrays are padded), issued
+// back to back and waited for once: an iteration has ONE memory round trip.  (Left to the compiler the
+// node's last 28 bytes were fetched after the node/triangle branch - a second dependent round trip per
+// visit.)  The kernel's duration is the serial latency chain of its slowest wavefront, and this form makes a
+// wavefront's iteration count ~ max over lanes of (nodes + triangles).  Visit order is unchanged.
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ void load_record64(const void *p, f32x4 &a, f32x4 &b, f32x4 &c, f32x4 &e)
+{
+    asm volatile("global_load_dwordx4 %0, %4, off\n\t"
+                 "global_load_dwordx4 %1, %4, off offset:16\n\t"
+                 "global_load_dwordx4 %2, %4, off offset:32\n\t"
+                 "global_load_dwordx4 %3, %4, off offset:48\n\t"
+                 "s_waitcnt vmcnt(0)"
+                 : "=&v"(a), "=&v"(b), "=&v"(c), "=&v"(e)
+                 : "v"(p)
+                 : "memory");
+}
+// tri_hit without early exits: the same operations in the same order, one accept mask at the end (a mixed
+// wavefront executes every early-out branch anyway; the nest of exec-mask branches only adds issue slots)
+__device__ __forceinline__ bool tri_hit_flat(f32x4 t0, f32x4 t1, float e2z, F3 o, F3 d, float tmin, float tmax, float &t)
+{
+    const float ax = t0.x, ay = t0.y, az = t0.z, e1x = t0.w, e1y = t1.x, e1z = t1.y, e2x = t1.z, e2y = t1.w;
+    float px = d.y * e2z - d.z * e2y;
+    float py = d.z * e2x - d.x * e2z;
+    float pz = d.x * e2y - d.y * e2x;
+    float det = e1x * px + e1y * py + e1z * pz;
+    bool ok = !(det > -1e-8f && det < 1e-8f);
+    float sxx = o.x - ax, syy = o.y - ay, szz = o.z - az;
+    float u_num = sxx * px + syy * py + szz * pz;
+    float sgn = det > 0.0f ? 1.0f : -1.0f;
+    float det_abs = det * sgn;
+    float u_num_s = u_num * sgn;
+    ok &= !(u_num_s < 0.0f || u_num_s > det_abs);
+    float qx = syy * e1z - szz * e1y;
+    float qy = szz * e1x - sxx * e1z;
+    float qz = sxx * e1y - syy * e1x;
+    float v_num = d.x * qx + d.y * qy + d.z * qz;
+    float v_num_s = v_num * sgn;
+    float uv_sum_s = u_num_s + v_num_s;
+    ok &= !(v_num_s < 0.0f || uv_sum_s > det_abs);
+    float t_num = e2x * qx + e2y * qy + e2z * qz;
+    float t_num_s = t_num * sgn;
+    float t_min_scaled = tmin * det_abs;
+    float t_max_scaled = tmax * det_abs;
+    ok &= !(t_num_s < t_min_scaled || t_num_s > t_max_scaled);
+    float inv_det = 1.0f / det;
+    t = t_num * inv_det;
+    return ok;
+}
 template <bool COUNT, class STK>
 __device__ __forceinline__ void mesh_walk(const SceneDev &S, uint32_t cur, int mesh_prim, STK &st, F3 o, F3 inv, F3 d, bool sx, bool sy,
                                           bool sz, float tmin, float &closest, int &hit_prim, int &hit_sub, Work &w)
@@ -716,29 +784,29 @@ __device__ __forceinline__ void mesh_walk(const SceneDev &S, uint32_t cur, int m
         const bool is_node = YCGE_REF_KIND(cur) == REF_MESH_NODE;
         const uint32_t pay = YCGE_REF_PAYLOAD(cur);
         const uint32_t tri_index = pay >> 4;
-        const float4 *addr = is_node ? (const float4 *)(S.mesh_nodes + pay) : (const float4 *)(S.tris + tri_index);
-        const float4 a = addr[0], b = addr[1], c = addr[2];
+        const void *addr = is_node ? (const void *)(S.mesh_nodes + pay) : (const void *)(S.tris + tri_index);
+        f32x4 a, b, c, e;
+        load_record64(addr, a, b, c, e);
         if (COUNT) prof_tick(0);
+        w.steps++;
+        uint32_t next;
         if (is_node) {
-            const uint2 e = *(const uint2 *)(addr + 3);
             float ln, rn;
             if (COUNT) w.box += 2;
             const bool hl = box_mesh(a.x, a.y, a.z, a.w, b.x, b.y, o, inv, sx, sy, sz, tmin, closest, ln);
             const bool hr = box_mesh(b.z, b.w, c.x, c.y, c.z, c.w, o, inv, sx, sy, sz, tmin, closest, rn);
-            if (hl & hr) {
-                if (ln < rn) { st.push(e.y, rn); cur = e.x; }
-                else { st.push(e.x, ln); cur = e.y; }
-            } else if (hl) cur = e.x;
-            else if (hr) cur = e.y;
-            else cur = YCGE_REF_NONE_VALUE;
+            const uint32_t lref = __float_as_uint(e.x), rref = __float_as_uint(e.y);
+            const bool left_first = ln < rn;
+            if (hl & hr) st.push(left_first ? rref : lref, left_first ? rn : ln);
+            next = (hl & hr) ? (left_first ? lref : rref) : hl ? lref : hr ? rref : YCGE_REF_NONE_VALUE;
         } else {
-            TriData T; T.t0 = a; T.t1 = b; T.e2z = c.x;
             if (COUNT) w.tri++;
             float t;
-            if (tri_hit(T, o, d, tmin, closest, t)) { closest = t; hit_prim = mesh_prim; hit_sub = (int)tri_index; }
+            if (tri_hit_flat(a, b, c.x, o, d, tmin, closest, t)) { closest = t; hit_prim = mesh_prim; hit_sub = (int)tri_index; }
             const uint32_t left = (pay & 15u) - 1u;
-            cur = left ? YCGE_REF(REF_MESH_LEAF, ((tri_index + 1u) << 4) | left) : YCGE_REF_NONE_VALUE;
+            next = left ? YCGE_REF(REF_MESH_LEAF, ((tri_index + 1u) << 4) | left) : YCGE_REF_NONE_VALUE;
         }
+        cur = next;
         if (cur == YCGE_REF_NONE_VALUE) {
             float tn; uint32_t r;
             while (st.pop(r, tn)) { if (closest >= tn) { cur = r; break; } }
