@@ -25,7 +25,7 @@ ARCH = "gfx950"
 FLAGS = [
     f"--offload-arch={ARCH}", "-O3", "-std=c++17", "-fPIC", "-shared",
     "-ffp-contract=off", "-fno-fast-math", "-fhip-fp32-correctly-rounded-divide-sqrt",
-    "-fno-gpu-rdc", "-Wall", "-Wno-unused-function", "-Wno-unused-variable",
+    "-fno-gpu-rdc", "-fno-slp-vectorize", "-Wall", "-Wno-unused-function", "-Wno-unused-variable",
 ]
 
 

@@ -331,7 +331,8 @@ uint32_t to_gpu_nodes(const BuiltTree &t, uint32_t node_kind, uint32_t leaf_kind
         GNode &g = gnodes[base + inner_index[i]];
         const RefNode &L = t.nodes[nd.left];
         const RefNode &R = t.nodes[nd.right];
-        for (int a = 0; a < 3; a++) { g.lmin[a] = L.mn[a]; g.lmax[a] = L.mx[a]; g.rmin[a] = R.mn[a]; g.rmax[a] = R.mx[a]; }
+        g.lmin_x = L.mn[0]; g.lmin_y = L.mn[1]; g.lmin_z = L.mn[2]; g.lmax_x = L.mx[0]; g.lmax_y = L.mx[1]; g.lmax_z = L.mx[2];
+        g.rmin_x = R.mn[0]; g.rmin_y = R.mn[1]; g.rmin_z = R.mn[2]; g.rmax_x = R.mx[0]; g.rmax_y = R.mx[1]; g.rmax_z = R.mx[2];
         g.lref = ref_of(nd.left);
         g.rref = ref_of(nd.right);
         g.pad[0] = g.pad[1] = 0;

@@ -33,9 +33,13 @@ enum : uint32_t {
 #define YCGE_REF_PAYLOAD(r) ((r) & 0x1fffffffu)
 #define YCGE_REF_NONE_VALUE 0xffffffffu
 
+// Plane order: (x y)(z Z)(X Y) per child, lower case = min, upper case = max.  Every 8-byte pair is then an
+// (x, y) or a (z, z) pair, so the twelve slab products of a visit are six packed operations against just two
+// pairings of the ray's origin / reciprocal direction (mesh_walk).
 struct alignas(16) GNode {
-    float lmin[3], lmax[3];     // left child box
-    float rmin[3], rmax[3];     // right child box
+    float lmin_x, lmin_y, lmin_z, lmax_z;
+    float lmax_x, lmax_y, rmin_x, rmin_y;
+    float rmin_z, rmax_z, rmax_x, rmax_y;
     uint32_t lref, rref;        // child references
     uint32_t pad[2];
 };

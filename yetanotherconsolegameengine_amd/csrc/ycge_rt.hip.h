@@ -673,11 +673,11 @@ __device__ __forceinline__ void walk(const SceneDev &S, uint32_t cur, int mesh_p
                 bool hl, hr;
                 if (COUNT) w.box += 2;
                 if (kind == REF_MESH_NODE) {
-                    hl = box_mesh(a.x, a.y, a.z, a.w, b.x, b.y, o, inv, sx, sy, sz, tmin, closest, ln);
-                    hr = box_mesh(b.z, b.w, c.x, c.y, c.z, c.w, o, inv, sx, sy, sz, tmin, closest, rn);
+                    hl = box_mesh(a.x, a.y, a.z, b.x, b.y, a.w, o, inv, sx, sy, sz, tmin, closest, ln);      // GNode plane order
+                    hr = box_mesh(b.z, b.w, c.x, c.z, c.w, c.y, o, inv, sx, sy, sz, tmin, closest, rn);
                 } else {
-                    hl = box_scene(a.x, a.y, a.z, a.w, b.x, b.y, o, inv, tmin, closest, ln);
-                    hr = box_scene(b.z, b.w, c.x, c.y, c.z, c.w, o, inv, tmin, closest, rn);
+                    hl = box_scene(a.x, a.y, a.z, b.x, b.y, a.w, o, inv, tmin, closest, ln);
+                    hr = box_scene(b.z, b.w, c.x, c.z, c.w, c.y, o, inv, tmin, closest, rn);
                 }
                 const uint32_t lref = __float_as_uint(e.x), rref = __float_as_uint(e.y);
                 if (hl & hr) {
@@ -776,10 +776,17 @@ __device__ __forceinline__ bool tri_hit_flat(f32x4 t0, f32x4 t1, float e2z, F3 o
     t = t_num * inv_det;
     return ok;
 }
+typedef float f32x2 __attribute__((ext_vector_type(2)));
 template <bool COUNT, class STK>
 __device__ __forceinline__ void mesh_walk(const SceneDev &S, uint32_t cur, int mesh_prim, STK &st, F3 o, F3 inv, F3 d, bool sx, bool sy,
                                           bool sz, float tmin, float &closest, int &hit_prim, int &hit_sub, Work &w)
 {
+    // the twelve slab products of a node as six packed operations (v_pk_add_f32 / v_pk_mul_f32): GNode keeps its
+    // planes as (x y)(z Z)(X Y) pairs per child, so two pairings of the ray's origin and reciprocal direction serve
+    // all of them.  Each product is the same single subtract and multiply box_mesh performs; selecting by the
+    // direction sign afterwards picks the same values.
+    const f32x2 oxy = {o.x, o.y}, ozz = {o.z, o.z};
+    const f32x2 ixy = {inv.x, inv.y}, izz = {inv.z, inv.z};
     while (cur != YCGE_REF_NONE_VALUE) {
         const bool is_node = YCGE_REF_KIND(cur) == REF_MESH_NODE;
         const uint32_t pay = YCGE_REF_PAYLOAD(cur);
@@ -791,10 +798,14 @@ __device__ __forceinline__ void mesh_walk(const SceneDev &S, uint32_t cur, int m
         w.steps++;
         uint32_t next;
         if (is_node) {
-            float ln, rn;
             if (COUNT) w.box += 2;
-            const bool hl = box_mesh(a.x, a.y, a.z, a.w, b.x, b.y, o, inv, sx, sy, sz, tmin, closest, ln);
-            const bool hr = box_mesh(b.z, b.w, c.x, c.y, c.z, c.w, o, inv, sx, sy, sz, tmin, closest, rn);
+            const f32x2 t0 = (a.xy - oxy) * ixy, t1 = (a.zw - ozz) * izz, t2 = (b.xy - oxy) * ixy;      // left:  (x y)(z Z)(X Y)
+            const f32x2 t3 = (b.zw - oxy) * ixy, t4 = (c.xy - ozz) * izz, t5 = (c.zw - oxy) * ixy;      // right: (x y)(z Z)(X Y)
+            float ln = __builtin_fmaxf(__builtin_fmaxf(__builtin_fmaxf(tmin, sx ? t2.x : t0.x), sy ? t2.y : t0.y), sz ? t1.y : t1.x);
+            float lx = __builtin_fminf(__builtin_fminf(__builtin_fminf(closest, sx ? t0.x : t2.x), sy ? t0.y : t2.y), sz ? t1.x : t1.y);
+            float rn = __builtin_fmaxf(__builtin_fmaxf(__builtin_fmaxf(tmin, sx ? t5.x : t3.x), sy ? t5.y : t3.y), sz ? t4.y : t4.x);
+            float rx = __builtin_fminf(__builtin_fminf(__builtin_fminf(closest, sx ? t3.x : t5.x), sy ? t3.y : t5.y), sz ? t4.x : t4.y);
+            const bool hl = lx >= ln, hr = rx >= rn;
             const uint32_t lref = __float_as_uint(e.x), rref = __float_as_uint(e.y);
             const bool left_first = ln < rn;
             if (hl & hr) st.push(left_first ? rref : lref, left_first ? rn : ln);
