@@ -217,3 +217,42 @@ def test_update_lights_per_frame(product_lib, oracle, path):
     o.render(stages=1, threads=8); g.TryFlipAndBlit()
     _assert_parity(pu.compare_frame(o, g), "lights updated")
     o.close(); g.close()
+
+
+def _post_pair(oracle, sc, w, h, ss, pose, frames=3):
+    """oracle (stages=2) and product (SDR requested) over `frames` frames; yields per-frame comparison tuples"""
+    flat = flatten(sc)
+    o = oracle.OracleRenderer(sc, w, h, ss, pose, flat=flat)
+    g = RaytraceRenderer(flat, w, h, pose.get("fov", 45.0), ss)
+    g.SetCamera(pose["pos"], pose["yaw"], pose["pitch"])
+    out = []
+    for f in range(frames):
+        so = o.render(stages=2, threads=8, want_sdr=True)
+        sg = g.TryFlipAndBlit(want_sdr=True)
+        out.append((pu.mismatch_count(o.read(abi.BUF_TAA_HISTORY), g.read(abi.BUF_TAA_HISTORY)),
+                    pu.mismatch_count(o.read(abi.BUF_DENOISED), g.read(abi.BUF_DENOISED)),
+                    np.float32(o.stats.exposure).view(np.uint32) != np.float32(g.stats.exposure).view(np.uint32),
+                    pu.mismatch_count(so, sg), pu.rms(so, sg), float(g.stats.post_ms)))
+    o.close(); g.close()
+    return out
+
+
+@pytest.mark.parametrize("cfg_n", [1, 2])
+def test_denoise_exposure_tonemap_bit_exact(product_lib, oracle, path, cfg_n):
+    """A-trous (incl. the in-place iteration 1), serial auto-exposure sum, box downsample + MapPixel."""
+    sc, w, h, ss, pose = scenes.config_scene(cfg_n)
+    for f, (taa, den, expo, sdr, sdr_rms, post_ms) in enumerate(_post_pair(oracle, sc, w, h, ss, pose)):
+        print(f"cfg{cfg_n} frame {f + 1}: taa {taa} denoised {den} exposure {expo} sdr {sdr} rms {sdr_rms} post_ms {post_ms:.3f}")
+        assert taa == 0 and den == 0 and not expo and sdr == 0 and sdr_rms <= pu.RMS_TOL
+
+
+def test_post_stage_odd_size_and_supersampling(product_lib, oracle, path):
+    """odd trace-grid sizes (border clamps of the in-place schedule) and ss = 2 (box average, exposure step 4)"""
+    sc, _, _, _, pose = scenes.config_scene(1)
+    for (w, h, ss) in ((37, 19, 1), (21, 13, 2)):
+        for f, (taa, den, expo, sdr, sdr_rms, post_ms) in enumerate(_post_pair(oracle, sc, w, h, ss, pose, frames=2)):
+            print(f"{w}x{h} ss{ss} frame {f + 1}: taa {taa} denoised {den} exposure {expo} sdr {sdr}")
+            assert taa == 0 and den == 0 and not expo and sdr == 0
+    sc5, w5, h5, ss5, pose5 = scenes.config_scene(5, small=True)
+    for f, (taa, den, expo, sdr, sdr_rms, post_ms) in enumerate(_post_pair(oracle, sc5, 96, 27, 2, pose5, frames=2)):
+        assert taa == 0 and den == 0 and not expo and sdr == 0

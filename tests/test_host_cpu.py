@@ -235,3 +235,33 @@ def test_two_process_all_gather_reassembles_the_frame(tmp_path):
                         "--master-port", "29533", str(script), str(ROOT)], capture_output=True, text=True, timeout=300, env=env)
     assert r.returncode == 0, r.stdout + r.stderr
     assert r.stdout.count("ok") == 2
+
+
+@pytest.mark.parametrize("w,h,step", [(37, 23, 2), (64, 48, 2), (80, 90, 2), (9, 7, 2), (33, 40, 8), (5, 5, 2), (1, 13, 2)])
+def test_inplace_atrous_schedule_respects_scan_order(product_lib, w, h, step):
+    """Levels of the in-place A-trous iteration (RaytraceRenderer.cs:648-650,718): for every stencil pair the
+    pixel that comes first in scan order must sit on a strictly earlier level, whichever of the two reads the
+    other - then a level-by-level evaluation sees NEW values of earlier pixels and OLD values of later ones,
+    exactly like the reference's serial scan."""
+    L = product_lib
+    L.ycge_host_inplace_schedule.restype = C.c_int
+    L.ycge_host_inplace_schedule.argtypes = [C.c_int32, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p, C.c_int32]
+    px = np.zeros(w * h, np.uint32); off = np.zeros(w * h + 2, np.uint32)
+    n = L.ycge_host_inplace_schedule(w, h, step, px.ctypes.data, off.ctypes.data, off.size)
+    assert n > 0
+    off = off[:n + 1]
+    assert off[0] == 0 and off[-1] == w * h and np.all(np.diff(off.astype(np.int64)) >= 0)
+    assert np.array_equal(np.sort(px), np.arange(w * h, dtype=np.uint32))          # every pixel exactly once
+    level = np.zeros(w * h, np.int64)
+    for l in range(n):
+        level[px[off[l]:off[l + 1]]] = l
+    ys, xs = np.mgrid[0:h, 0:w]
+    p = (xs + ys * w).ravel()
+    for ky in range(-2, 3):
+        for kx in range(-2, 3):
+            sx = np.clip(xs + kx * step, 0, w - 1); sy = np.clip(ys + ky * step, 0, h - 1)
+            q = (sx + sy * w).ravel()
+            earlier = q < p
+            later = q > p
+            assert np.all(level[q[earlier]] < level[p[earlier]])
+            assert np.all(level[q[later]] > level[p[later]])

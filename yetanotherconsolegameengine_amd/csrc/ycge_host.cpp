@@ -27,6 +27,17 @@ int ycge_launch_wavefront(const ycge::SceneDev *S, const ycge::FrameParams *P, c
 int ycge_launch_order_blocks(uint32_t *cost, uint32_t n, uint32_t policy, uint32_t *order_ws, uint32_t *order, hipStream_t stream);
 int ycge_launch_taa(const ycge::TaaParams *T, const float *current, const float *normal, const float *depth, const uint8_t *sky,
                     float *hist, float *prev_normal, float *prev_depth, uint8_t *prev_sky, hipStream_t stream);
+size_t ycge_post_state_bytes(void);
+int ycge_launch_unit_normals(const float *normal, float *unit, size_t n, hipStream_t stream);
+int ycge_launch_atrous(int w, int h, int step, const float phi[4], const float *cur, float *dst, const float *albedo, const float *unit_n,
+                       const float *depth, const uint8_t *sky, hipStream_t stream);
+int ycge_launch_atrous_inplace(int w, int h, int step, const float phi[4], float *buf, const float *albedo, const float *unit_n,
+                               const float *depth, const uint8_t *sky, const uint32_t *d_pixels, const uint32_t *h_offsets, int n_levels,
+                               hipStream_t stream);
+int ycge_launch_exposure(const float *hdr, const uint8_t *sky, int w, int h, int step, float *terms, void *state, const float consts[5],
+                         hipStream_t stream);
+int ycge_launch_tonemap(const float *hdr, int hiW, int fbW, int fbH, int ss, float gamma, float saturation, float vibrance, const void *state,
+                        float *out, hipStream_t stream);
 int ycge_launch_pack_slab(const ycge::FrameParams *P, const float *hdr, const float *albedo, const float *normal, const float *depth,
                           const uint8_t *sky, float *slab, hipStream_t stream);
 int ycge_launch_unpermute(const float *all_slabs, size_t slab_floats_per_rank, int hiW, int hiH, int tiles_x, int n_tiles, int world_size,
@@ -98,6 +109,12 @@ struct ycge_ctx {
     // wavefront pipeline storage (ycge_kernels.hip: QEntry / HitRec / LEntry), sized for one ray per pixel
     DevBuf<uint8_t> wf_q0, wf_q1, wf_hit, wf_lq;
     DevBuf<uint32_t> wf_counts, tile_order;
+    // denoise / exposure / tonemap stage (ycge_post.hip), allocated on the first frame that asks for SDR output
+    DevBuf<float> den_a, den_b, unit_n, exp_terms, d_sdr;
+    DevBuf<uint8_t> tone_state;                   // ToneMapper state; lives as long as the context (not reset by Resize)
+    struct InplaceSchedule { int w = 0, h = 0, step = 0; DevBuf<uint32_t> pixels; std::vector<uint32_t> offsets; };
+    std::vector<InplaceSchedule *> schedules;     // level schedules of the in-place A-trous iterations, by (w, h, step)
+    const float *denoised = nullptr;              // result of the last post stage (one of den_a / den_b / taa_hist)
     DevBuf<uint32_t> block_cost, block_order, order_ws;   // k_trace scheduling feedback (4 blocks of 8x8 px per tile)
     bool block_order_valid = false;
     DevBuf<uint64_t> stack_spill;                 // [YCGE_TRAVERSAL_STACK - 12][persistent lanes]
@@ -215,6 +232,8 @@ int set_geometry(ycge_ctx *c, int fbw, int fbh, int ss)
     c->tiles_per_rank_padded = (c->n_tiles + world - 1) / world;
     c->taa_valid = false;                                       // Resize: taaHistoryValid = false (:137), taa.Resize (TemporalAA.cs:34-46)
     c->last_cam[0] = c->last_cam[1] = c->last_cam[2] = NAN; c->last_yaw = c->last_pitch = NAN;
+    c->den_a.release(); c->den_b.release(); c->unit_n.release(); c->exp_terms.release(); c->d_sdr.release();     // spatialA / spatialB, :129-130
+    c->denoised = nullptr;
     int rc = alloc_frame_buffers(c);
     if (rc != YCGE_OK) return rc;
     rc = alloc_tile_buffers(c);
@@ -414,6 +433,9 @@ void ycge_destroy(ycge_ctx *c)
     c->prev_normal.release(); c->prev_depth.release(); c->sky.release(); c->prev_sky.release();
     c->dbg_rays.release(); c->dbg_hit_t.release(); c->dbg_prim.release(); c->dbg_sub.release(); c->dbg_rng.release();
     c->counters.release(); c->wave_prof.release(); c->own_slab.release();
+    c->den_a.release(); c->den_b.release(); c->unit_n.release(); c->exp_terms.release(); c->d_sdr.release(); c->tone_state.release();
+    for (auto *sc : c->schedules) { sc->pixels.release(); delete sc; }
+    c->schedules.clear();
     c->wf_q0.release(); c->wf_q1.release(); c->wf_hit.release(); c->wf_lq.release(); c->wf_counts.release(); c->tile_order.release(); c->block_cost.release(); c->block_order.release(); c->order_ws.release(); c->stack_spill.release(); c->path_stack.release();
     c->d_scene_nodes.release(); c->d_mesh_nodes.release(); c->d_scene_leaf.release(); c->d_tris.release(); c->d_prims.release();
     c->d_materials.release(); c->d_meshes.release(); c->d_grids.release(); c->d_cells.release(); c->d_lut.release(); c->d_lights.release();
@@ -817,6 +839,103 @@ int taa_and_commit(ycge_ctx *c, hipStream_t stream, const FrameState &fs, bool &
     return YCGE_OK;
 }
 
+// ---- steps 6-8 of TryFlipAndBlit (RaytraceRenderer.cs:221-264): A-trous denoise, auto-exposure, tonemap + downsample
+// Level schedule of an in-place A-trous iteration (see ycge_post.hip): T(p) = 1 + max T(q) over every pixel q that
+// precedes p in scan order and is stencil-related to it (p reads q -> p needs q's NEW value; q reads p -> q needed
+// p's OLD value).  Pixels of one level are mutually unrelated.  Derived from the clamped stencil itself, so it is
+// exact for every size, step and border case.
+void build_inplace_schedule(int w, int h, int step, std::vector<uint32_t> &pixels, std::vector<uint32_t> &offsets)
+{
+    const size_t n = (size_t)w * h;
+    std::vector<uint32_t> T(n, 0), R(n, 0);      // R[p] = max T over earlier pixels that read p
+    uint32_t max_t = 0;
+    for (int y = 0; y < h; y++) {
+        int sys[5];
+        for (int k = -2; k <= 2; k++) { int v = y + k * step; sys[k + 2] = v < 0 ? 0 : v >= h ? h - 1 : v; }
+        for (int x = 0; x < w; x++) {
+            int sxs[5];
+            for (int k = -2; k <= 2; k++) { int v = x + k * step; sxs[k + 2] = v < 0 ? 0 : v >= w ? w - 1 : v; }
+            const size_t p = (size_t)x + (size_t)y * w;
+            uint32_t m = R[p];
+            for (int ky = 0; ky < 5; ky++)
+                for (int kx = 0; kx < 5; kx++) {
+                    const size_t q = (size_t)sxs[kx] + (size_t)sys[ky] * w;
+                    if (q < p && T[q] > m) m = T[q];
+                }
+            const uint32_t t = m + 1;
+            T[p] = t;
+            if (t > max_t) max_t = t;
+            for (int ky = 0; ky < 5; ky++)
+                for (int kx = 0; kx < 5; kx++) {
+                    const size_t q = (size_t)sxs[kx] + (size_t)sys[ky] * w;
+                    if (q > p && R[q] < t) R[q] = t;
+                }
+        }
+    }
+    offsets.assign((size_t)max_t + 1, 0);
+    for (size_t p = 0; p < n; p++) offsets[T[p]]++;          // offsets[t] = count of level t (levels are 1-based)
+    uint32_t run = 0;
+    for (uint32_t t = 1; t <= max_t; t++) { const uint32_t c2 = offsets[t]; offsets[t - 1] = run; run += c2; }
+    offsets[max_t] = run;                                    // offsets[l] .. offsets[l + 1] = level l + 1
+    pixels.resize(n);
+    std::vector<uint32_t> cursor(offsets.begin(), offsets.end() - 1);
+    for (size_t p = 0; p < n; p++) pixels[cursor[T[p] - 1]++] = (uint32_t)p;
+}
+
+int run_post(ycge_ctx *c, hipStream_t stream, float *out_sdr_host, bool timed)
+{
+    const int w = c->hiW, h = c->hiH;
+    const size_t n = (size_t)w * h;
+    if (!c->den_a.p) {
+        HIP_TRY(c, c->den_a.alloc(3 * n)); HIP_TRY(c, c->den_b.alloc(3 * n)); HIP_TRY(c, c->unit_n.alloc(3 * n));
+        HIP_TRY(c, c->exp_terms.alloc(n)); HIP_TRY(c, c->d_sdr.alloc((size_t)c->fbW * c->fbH * 6));
+    }
+    if (!c->tone_state.p) {
+        HIP_TRY(c, c->tone_state.alloc(ycge_post_state_bytes()));
+        const float init[4] = {1.0f, 1.0f, 0.0f, 0.0f};     // aeExposure = 1, effectiveExposure = 1 (ToneMapper.cs:13,17), count = 0
+        HIP_TRY(c, hipMemcpy(c->tone_state.p, init, sizeof init, hipMemcpyHostToDevice));
+    }
+    int e = ycge_launch_unit_normals(c->g_normal.p, c->unit_n.p, n, stream);
+    if (e != 0) return c->fail(YCGE_ERR_DEVICE, "k_unit_normals launch failed: %s", hipGetErrorString((hipError_t)e));
+    const float phi[4] = {cs_max(1e-6f, c->cfg.atrous_c_phi), cs_max(1e-6f, c->cfg.atrous_n_phi), cs_max(1e-6f, c->cfg.atrous_z_phi),
+                          cs_max(1e-6f, c->cfg.atrous_a_phi)};
+    // ApplyAtrousDenoise's buffer walk, :648-650 and :718 (odd iterations end up in place)
+    const float *cur = c->taa_hist.p;
+    float *A = c->den_a.p, *B = c->den_b.p, *dst = A;
+    const int iters = c->cfg.atrous_iterations > 1 ? c->cfg.atrous_iterations : 1;
+    for (int it = 0; it < iters; it++) {
+        const int step = 1 << it;
+        if (cur == dst) {
+            ycge_ctx::InplaceSchedule *sc = nullptr;
+            for (auto *k : c->schedules) if (k->w == w && k->h == h && k->step == step) sc = k;
+            if (!sc) {
+                sc = new ycge_ctx::InplaceSchedule();
+                sc->w = w; sc->h = h; sc->step = step;
+                std::vector<uint32_t> px;
+                build_inplace_schedule(w, h, step, px, sc->offsets);
+                c->schedules.push_back(sc);
+                HIP_TRY(c, sc->pixels.upload(px));
+            }
+            e = ycge_launch_atrous_inplace(w, h, step, phi, dst, c->g_albedo.p, c->unit_n.p, c->g_depth.p, c->sky.p, sc->pixels.p,
+                                           sc->offsets.data(), (int)sc->offsets.size() - 1, stream);
+        } else {
+            e = ycge_launch_atrous(w, h, step, phi, cur, dst, c->g_albedo.p, c->unit_n.p, c->g_depth.p, c->sky.p, stream);
+        }
+        if (e != 0) return c->fail(YCGE_ERR_DEVICE, "A-trous launch failed: %s", hipGetErrorString((hipError_t)e));
+        const float *tmp = cur; cur = dst; dst = (tmp == A) ? B : A;
+    }
+    c->denoised = cur;
+    const int step = c->ss * 2 > 2 ? c->ss * 2 : 2;            // :226
+    const float tone_consts[5] = {1.0f, 0.18f, 0.2f, 0.10f, 1.50f};     // toneExposure, aeKey, aeSpeed, aeMin, aeMax (ToneMapper.cs:8-16)
+    e = ycge_launch_exposure(cur, c->sky.p, w, h, step, c->exp_terms.p, c->tone_state.p, tone_consts, stream);
+    if (e != 0) return c->fail(YCGE_ERR_DEVICE, "exposure launch failed: %s", hipGetErrorString((hipError_t)e));
+    e = ycge_launch_tonemap(cur, w, c->fbW, c->fbH, c->ss, 2.2f, 2.0f, 0.0f, c->tone_state.p, c->d_sdr.p, stream);   // toneGamma, toneSaturation, toneVibrance
+    if (e != 0) return c->fail(YCGE_ERR_DEVICE, "tonemap launch failed: %s", hipGetErrorString((hipError_t)e));
+    if (timed) HIP_TRY(c, hipEventRecord(c->ev[3], stream));
+    if (out_sdr_host) HIP_TRY(c, hipMemcpyAsync(out_sdr_host, c->d_sdr.p, (size_t)c->fbW * c->fbH * 6 * sizeof(float), hipMemcpyDeviceToHost, stream));
+    return YCGE_OK;
+}
+
 int fill_stats(ycge_ctx *c, ycge_frame_stats *st, const FrameState &fs, bool did_reset, bool have_taa, double wall_ms)
 {
     if (!st) return YCGE_OK;
@@ -845,7 +964,6 @@ int ycge_render_frame(ycge_ctx *c, float *out_sdr, ycge_frame_stats *st)
 {
     if (!c) return YCGE_ERR_INVALID_ARG;
     if (c->cfg.world_size != 1) return c->fail(YCGE_ERR_INVALID_ARG, "ycge_render_frame is the single-GPU entry; with world_size > 1 use ycge_trace_tiles + ycge_resolve_gathered");
-    if (out_sdr) return c->fail(YCGE_ERR_UNSUPPORTED, "denoise/tonemap stage (SURVEY 8-f1) is not built yet: pass NULL and read YCGE_BUF_TAA_HISTORY");
     HIP_TRY(c, hipSetDevice(c->device));
     auto t0 = std::chrono::steady_clock::now();
     FrameState fs;
@@ -854,9 +972,22 @@ int ycge_render_frame(ycge_ctx *c, float *out_sdr, ycge_frame_stats *st)
     bool did_reset = false;
     rc = taa_and_commit(c, c->stream, fs, did_reset, true);
     if (rc != YCGE_OK) return rc;
+    if (out_sdr) {      // steps 6-8; with NULL the frame stops after TAA (trace-only callers, benchmarks of the hot path)
+        rc = run_post(c, c->stream, out_sdr, true);
+        if (rc != YCGE_OK) return rc;
+    }
     HIP_TRY(c, hipStreamSynchronize(c->stream));
     double wall = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
-    return fill_stats(c, st, fs, did_reset, true, wall);
+    rc = fill_stats(c, st, fs, did_reset, true, wall);
+    if (rc == YCGE_OK && st && out_sdr) {
+        float ms = 0.0f;
+        HIP_TRY(c, hipEventElapsedTime(&ms, c->ev[2], c->ev[3]));
+        st->post_ms = ms;
+        float tone[2];
+        HIP_TRY(c, hipMemcpy(tone, c->tone_state.p, sizeof tone, hipMemcpyDeviceToHost));
+        st->exposure = tone[1];
+    }
+    return rc;
 }
 
 int ycge_trace_tiles(ycge_ctx *c, void *d_slab, void *hip_stream, ycge_frame_stats *st)
@@ -882,7 +1013,6 @@ int ycge_resolve_gathered(ycge_ctx *c, const void *d_all_slabs, void *hip_stream
 {
     if (!c) return YCGE_ERR_INVALID_ARG;
     if (!d_all_slabs) return c->fail(YCGE_ERR_INVALID_ARG, "null gathered slabs");
-    if (out_sdr) return c->fail(YCGE_ERR_UNSUPPORTED, "denoise/tonemap stage (SURVEY 8-f1) is not built yet");
     HIP_TRY(c, hipSetDevice(c->device));
     hipStream_t stream = hip_stream ? (hipStream_t)hip_stream : c->stream;
     auto t0 = std::chrono::steady_clock::now();
@@ -901,6 +1031,11 @@ int ycge_resolve_gathered(ycge_ctx *c, const void *d_all_slabs, void *hip_stream
     bool did_reset = false;
     int rc = taa_and_commit(c, stream, fs, did_reset, st != nullptr);
     if (rc != YCGE_OK) return rc;
+    if (out_sdr) {
+        rc = run_post(c, stream, out_sdr, st != nullptr);
+        if (rc != YCGE_OK) return rc;
+        if (!st) HIP_TRY(c, hipStreamSynchronize(stream));      // the caller's host buffer is filled when the call returns
+    }
     if (st) {
         HIP_TRY(c, hipStreamSynchronize(stream));
         std::memset(st, 0, sizeof *st);
@@ -908,8 +1043,15 @@ int ycge_resolve_gathered(ycge_ctx *c, const void *d_all_slabs, void *hip_stream
         float ms = 0.0f;
         HIP_TRY(c, hipEventElapsedTime(&ms, c->ev[1], c->ev[2]));
         st->taa_ms = ms;
-        st->total_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
         st->exposure = 1.0f;
+        if (out_sdr) {
+            HIP_TRY(c, hipEventElapsedTime(&ms, c->ev[2], c->ev[3]));
+            st->post_ms = ms;
+            float tone[2];
+            HIP_TRY(c, hipMemcpy(tone, c->tone_state.p, sizeof tone, hipMemcpyDeviceToHost));
+            st->exposure = tone[1];
+        }
+        st->total_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
     }
     return YCGE_OK;
 }
@@ -936,7 +1078,9 @@ int ycge_read_buffer(ycge_ctx *c, int32_t which, void *dst, size_t bytes)
     case YCGE_BUF_PREV_NORMAL: src = c->prev_normal.p; want = n * 12; break;
     case YCGE_BUF_PREV_DEPTH: src = c->prev_depth.p; want = n * 4; break;
     case YCGE_BUF_PREV_SKY: src = c->prev_sky.p; want = n; break;
-    case YCGE_BUF_DENOISED: return c->fail(YCGE_ERR_UNSUPPORTED, "denoise stage not built yet");
+    case YCGE_BUF_DENOISED:
+        if (!c->denoised) return c->fail(YCGE_ERR_INVALID_ARG, "no denoised frame yet: render with an SDR output buffer first");
+        src = c->denoised; want = n * 12; break;
     default: return c->fail(YCGE_ERR_INVALID_ARG, "unknown buffer %d", which);
     }
     if (!src) return c->fail(YCGE_ERR_INVALID_ARG, "buffer %d needs config.capture_debug", which);
@@ -1010,6 +1154,18 @@ int ycge_host_build_mesh(const float *tris9, int32_t n, void *nodes_out, int32_t
     if (!t.leaf_index.empty()) std::memcpy(leaf_out, t.leaf_index.data(), t.leaf_index.size() * 4);
     if (stats_out) { stats_out[0] = t.root; stats_out[1] = t.max_depth; stats_out[2] = t.sort_fallbacks; }
     return (int)t.nodes.size();
+}
+// Level schedule of an in-place A-trous iteration (host only).  pixels_out: w*h uint32, offsets_out: capacity
+// uint32.  Returns the number of levels (offsets_out holds levels + 1 entries) or <0.
+int ycge_host_inplace_schedule(int32_t w, int32_t h, int32_t step, uint32_t *pixels_out, uint32_t *offsets_out, int32_t capacity)
+{
+    if (w <= 0 || h <= 0 || step <= 0 || !pixels_out || !offsets_out) return YCGE_ERR_INVALID_ARG;
+    std::vector<uint32_t> px, off;
+    build_inplace_schedule(w, h, step, px, off);
+    if ((int64_t)off.size() > capacity) return YCGE_ERR_INVALID_ARG;
+    std::memcpy(pixels_out, px.data(), px.size() * 4);
+    std::memcpy(offsets_out, off.data(), off.size() * 4);
+    return (int)off.size() - 1;
 }
 // profiling aid: per-wavefront {start, end, node iterations, leaf phases} of the last counted k_wf_primary launch
 int ycge_debug_read_wave_prof(ycge_ctx *c, unsigned long long *dst, size_t n_u64)

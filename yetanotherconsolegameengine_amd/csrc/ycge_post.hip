@@ -1,0 +1,324 @@
+// ycge_post.hip — the steps of TryFlipAndBlit after TAA (reference RayTracing/RaytraceRenderer.cs:221-264):
+//   ApplyAtrousDenoise (:622-722), ToneMapper.UpdateExposure (ToneMapper.cs:49-91), the ss x ss box average of the
+//   top / bottom half-cells and ToneMapper.MapPixel (:229-264, ToneMapper.cs:204-260).  SURVEY.md section 8, row f1.
+//
+// Everything here reproduces the reference's floating-point ORDER, not just its formulas:
+//   * a pixel's 25 taps are accumulated in (ky, kx) order;
+//   * odd A-trous iterations run IN PLACE in the reference (buffer swap at :718: iter 0 src->A, iter 1 A->A,
+//     iter 2 A->B), so a pixel sees the NEW values of the neighbours that precede it in scan order and the OLD
+//     values of those that follow.  That recurrence is evaluated exactly by levels: the host derives, from the
+//     stencil itself, the earliest level T(p) = 1 + max T(q) over every stencil-related pixel q that precedes p in
+//     scan order (ycge_post_build_schedule); pixels of one level never read or write each other, levels run as
+//     consecutive launches;
+//   * the auto-exposure is a serial fp32 sum over the sampled pixels in scan order: the log terms are produced
+//     in parallel, the sum is one lane adding them one by one.
+#include <hip/hip_runtime.h>
+
+#include "ycge_rt.hip.h"
+
+namespace ycge {
+
+struct AtrousParams {
+    int32_t w, h, step;
+    float c_phi, n_phi, z_phi, a_phi;      // already max(1e-6f, phi), :693-696
+};
+
+struct ToneState {                          // ToneMapper fields that change (ToneMapper.cs:13,17)
+    float ae_exposure;
+    float effective;
+    uint32_t count;                         // scratch: sampled pixels with lum > 0 this frame
+    uint32_t pad;
+};
+
+__device__ __forceinline__ F3 ld3(const float *p, size_t i) { return f3(p[3 * i], p[3 * i + 1], p[3 * i + 2]); }
+__device__ __forceinline__ void st3(float *p, size_t i, F3 v) { p[3 * i] = v.x; p[3 * i + 1] = v.y; p[3 * i + 2] = v.z; }
+__device__ __forceinline__ float luma3(F3 c) { return 0.2126f * c.x + 0.7152f * c.y + 0.0722f * c.z; }
+__device__ __forceinline__ float kernel_tap(int k) { return k == 0 ? 3.0f / 8.0f : (k == 1 || k == -1) ? 1.0f / 4.0f : 1.0f / 16.0f; }   // :646
+
+// normal[x, y].Normalized() is evaluated once per pixel per frame instead of once per tap (same function, same bits)
+__global__ __launch_bounds__(256) void k_unit_normals(const float *__restrict__ normal, float *__restrict__ unit, size_t n)
+{
+    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (i < n) st3(unit, i, normalized(ld3(normal, i)));
+}
+
+struct Center { F3 c0, a0, n0; float z0; uint8_t sky0; };
+
+// one tap of the 5x5 stencil, :664-700.  Returns false for a tap the reference skips (`continue`).
+__device__ __forceinline__ bool atrous_tap(const AtrousParams &A, const float *cur, const float *albedo, const float *unit_n, const float *depth,
+                                           const uint8_t *sky, int x, int y, int kx, int ky, const Center &C, float &wght, F3 &c)
+{
+    int sy = y + ky * A.step;
+    if (sy < 0) sy = 0; else if (sy >= A.h) sy = A.h - 1;
+    const float wy = kernel_tap(ky);
+    int sx = x + kx * A.step;
+    if (sx < 0) sx = 0; else if (sx >= A.w) sx = A.w - 1;
+    const size_t j = (size_t)sx + (size_t)sy * A.w;
+    if (sky[j] != C.sky0) return false;
+    const float wx = kernel_tap(kx);
+    const float w_base = wx * wy;
+    c = ld3(cur, j);
+    const F3 a = ld3(albedo, j);
+    const F3 n = ld3(unit_n, j);
+    const float z = depth[j];
+    const float lum0 = luma3(C.c0);
+    const float lum = luma3(c);
+    const float dl = cs_abs(lum - lum0);
+    const float dn = cs_max(0.0f, 1.0f - dot(C.n0, n));
+    const float dz = cs_abs(z - C.z0);
+    const float da = cs_abs(a.x - C.a0.x) + cs_abs(a.y - C.a0.y) + cs_abs(a.z - C.a0.z);
+    const float wc = m_exp(-dl / A.c_phi);
+    const float wn = m_exp(-dn / A.n_phi);
+    const float wz = m_exp(-dz / A.z_phi);
+    const float wa = m_exp(-(da) / A.a_phi);
+    wght = w_base * wc * wn * wz * wa;
+    return true;
+}
+
+// an iteration whose source and destination differ: one thread per pixel, taps in order
+__global__ __launch_bounds__(256) void k_atrous(const AtrousParams A, const float *__restrict__ cur, float *__restrict__ dst,
+                                                const float *__restrict__ albedo, const float *__restrict__ unit_n,
+                                                const float *__restrict__ depth, const uint8_t *__restrict__ sky)
+{
+    const int x = blockIdx.x * 32 + (threadIdx.x & 31);
+    const int y = blockIdx.y * 8 + (threadIdx.x >> 5);
+    if (x >= A.w || y >= A.h) return;
+    const size_t i = (size_t)x + (size_t)y * A.w;
+    Center C;
+    C.c0 = ld3(cur, i);
+    C.sky0 = sky[i];
+    if (C.sky0) { st3(dst, i, C.c0); return; }
+    C.a0 = ld3(albedo, i); C.n0 = ld3(unit_n, i); C.z0 = depth[i];
+    float wsum = 0.0f;
+    F3 accum = f3(0, 0, 0);
+    for (int ky = -2; ky <= 2; ky++)
+        for (int kx = -2; kx <= 2; kx++) {
+            float wght; F3 c;
+            if (!atrous_tap(A, cur, albedo, unit_n, depth, sky, x, y, kx, ky, C, wght, c)) continue;
+            accum = f3(accum.x + c.x * wght, accum.y + c.y * wght, accum.z + c.z * wght);
+            wsum += wght;
+        }
+    if (wsum > 1e-8f) {
+        const float inv = 1.0f / wsum;
+        st3(dst, i, f3(accum.x * inv, accum.y * inv, accum.z * inv));
+    } else {
+        st3(dst, i, C.c0);
+    }
+}
+
+// one LEVEL of an in-place iteration: `count` pixels that neither read nor write each other.  32 lanes per pixel:
+// lanes 0..24 evaluate one tap each; lanes 0..3 then add the 25 products of one component (x, y, z, weight) in tap order.
+__global__ __launch_bounds__(256) void k_atrous_level(const AtrousParams A, float *__restrict__ buf, const float *__restrict__ albedo,
+                                                      const float *__restrict__ unit_n, const float *__restrict__ depth,
+                                                      const uint8_t *__restrict__ sky, const uint32_t *__restrict__ pixels, uint32_t count)
+{
+    __shared__ float s_val[8][25][4];
+    __shared__ uint32_t s_mask[8];
+    __shared__ float s_sum[8][4];
+    const int g = threadIdx.x >> 5, t = threadIdx.x & 31;
+    const uint32_t slot = blockIdx.x * 8u + (uint32_t)g;
+    const bool live = slot < count;
+    uint32_t p = 0;
+    Center C;
+    C.c0 = f3(0, 0, 0); C.a0 = f3(0, 0, 0); C.n0 = f3(0, 0, 0); C.z0 = 0.0f; C.sky0 = 1;
+    int x = 0, y = 0;
+    if (live) {
+        p = pixels[slot];
+        x = (int)(p % (uint32_t)A.w); y = (int)(p / (uint32_t)A.w);
+        C.sky0 = sky[p];
+        C.c0 = ld3(buf, p);
+        if (!C.sky0) { C.a0 = ld3(albedo, p); C.n0 = ld3(unit_n, p); C.z0 = depth[p]; }
+    }
+    const bool work = live && !C.sky0;          // sky pixel: dst[x, y] = cur[x, y] on the same buffer, nothing to do
+    bool valid = false;
+    if (work && t < 25) {
+        float wght; F3 c;
+        valid = atrous_tap(A, buf, albedo, unit_n, depth, sky, x, y, t % 5 - 2, t / 5 - 2, C, wght, c);
+        if (valid) { s_val[g][t][0] = c.x * wght; s_val[g][t][1] = c.y * wght; s_val[g][t][2] = c.z * wght; s_val[g][t][3] = wght; }
+    }
+    const unsigned long long m = __ballot(valid);
+    if (t == 0) s_mask[g] = (uint32_t)(m >> ((threadIdx.x & 32) ? 32 : 0));
+    __syncthreads();            // every tap of the level has been read before any pixel of the level is written
+    if (work && t < 4) {
+        const uint32_t mask = s_mask[g];
+        float acc = 0.0f;
+        for (int k = 0; k < 25; k++)
+            if ((mask >> k) & 1u) acc = acc + s_val[g][k][t];
+        s_sum[g][t] = acc;
+    }
+    __syncthreads();
+    if (work && t == 0) {
+        const float wsum = s_sum[g][3];
+        if (wsum > 1e-8f) {
+            const float inv = 1.0f / wsum;
+            st3(buf, p, f3(s_sum[g][0] * inv, s_sum[g][1] * inv, s_sum[g][2] * inv));
+        }                                       // else dst = c0: unchanged
+    }
+}
+
+// ToneMapper.UpdateExposure, serial overload (ToneMapper.cs:49-91), part 1: the log term of every sampled pixel
+// (0 for the ones the reference skips: s + 0.0f == s for every value the running sum can take) + how many count
+__global__ __launch_bounds__(256) void k_exposure_terms(const float *__restrict__ hdr, const uint8_t *__restrict__ sky, int w, int h, int step,
+                                                        int nsx, int nsy, float *__restrict__ terms, ToneState *__restrict__ state)
+{
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    bool counted = false;
+    if (i < nsx * nsy) {
+        const int px = (i % nsx) * step, py = (i / nsx) * step;
+        const size_t j = (size_t)px + (size_t)py * w;
+        float term = 0.0f;
+        if (!sky[j]) {
+            const F3 c = ld3(hdr, j);
+            const float lum = 0.2126f * c.x + 0.7152f * c.y + 0.0722f * c.z;
+            if (lum > 0.0f) { term = m_log(1e-6f + lum); counted = true; }
+        }
+        terms[i] = term;
+    }
+    const unsigned long long m = __ballot(counted);
+    if ((threadIdx.x & 63) == 0 && m) atomicAdd(&state->count, (uint32_t)__popcll(m));
+}
+
+// part 2: logSum += term in scan order by ONE lane, then the exposure update
+struct ToneConsts { float tone_exposure, ae_key, ae_speed, ae_min, ae_max; };
+__global__ __launch_bounds__(64) void k_exposure_sum(const float *__restrict__ terms, int n, ToneConsts K, ToneState *__restrict__ state)
+{
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    float log_sum = 0.0f;
+    int i = 0;
+    const float4 *t4 = (const float4 *)terms;
+    for (; i + 16 <= n; i += 16) {
+        const float4 a = t4[i / 4], b = t4[i / 4 + 1], c = t4[i / 4 + 2], d = t4[i / 4 + 3];
+        log_sum += a.x; log_sum += a.y; log_sum += a.z; log_sum += a.w;
+        log_sum += b.x; log_sum += b.y; log_sum += b.z; log_sum += b.w;
+        log_sum += c.x; log_sum += c.y; log_sum += c.z; log_sum += c.w;
+        log_sum += d.x; log_sum += d.y; log_sum += d.z; log_sum += d.w;
+    }
+    for (; i < n; i++) log_sum += terms[i];
+    const int cnt = (int)state->count;
+    float ae = state->ae_exposure;
+    const float avg_log = cnt > 0 ? log_sum / (float)(cnt > 1 ? cnt : 1) : 0.0f;
+    const float avg_lum = m_exp(avg_log);
+    float target = cnt > 0 ? K.ae_key / cs_max(1e-6f, avg_lum) : ae;
+    if (target < K.ae_min) target = K.ae_min;
+    if (target > K.ae_max) target = K.ae_max;
+    const float s = 1.0f - m_exp(-K.ae_speed);
+    ae = ae + (target - ae) * s;
+    state->ae_exposure = ae;
+    state->effective = K.tone_exposure * ae;
+    state->count = 0;
+}
+
+// ToneMapper.ToneMapAndEncode + ApplySaturation, ToneMapper.cs:204-260
+__device__ __forceinline__ float aces_film(float x)
+{
+    const float a = 2.51f, b = 0.03f, c = 2.43f, d = 0.59f, e = 0.14f;
+    const float num = x * (a * x + b);
+    const float den = x * (c * x + d) + e;
+    float y = den > 0.0f ? num / den : 0.0f;
+    if (y < 0.0f) y = 0.0f;
+    if (y > 1.0f) y = 1.0f;
+    return y;
+}
+__device__ __forceinline__ F3 map_pixel(F3 hdr, float exposure, float gamma, float saturation, float vibrance)
+{
+    float r = cs_max(0.0f, hdr.x) * exposure;
+    float g = cs_max(0.0f, hdr.y) * exposure;
+    float b = cs_max(0.0f, hdr.z) * exposure;
+    r = aces_film(r); g = aces_film(g); b = aces_film(b);
+    const float inv_gamma = 1.0f / cs_max(0.1f, gamma);
+    const float sr = m_pow(clamp01(r), inv_gamma);
+    const float sg = m_pow(clamp01(g), inv_gamma);
+    const float sb = m_pow(clamp01(b), inv_gamma);
+    r = clamp01(sr); g = clamp01(sg); b = clamp01(sb);
+    const float y = 0.2126f * r + 0.7152f * g + 0.0722f * b;
+    const float maxc = cs_max(r, cs_max(g, b));
+    const float minc = cs_min(r, cs_min(g, b));
+    const float chroma = maxc - minc;
+    const float vib = 1.0f + vibrance * (1.0f - chroma);
+    const float f = saturation * vib;
+    const float rr = y + (r - y) * f, gg = y + (g - y) * f, bb = y + (b - y) * f;
+    return f3(clamp01(rr), clamp01(gg), clamp01(bb));
+}
+
+// step 8, :229-264: per chexel the ss x ss box average of its top and bottom half-cell, then MapPixel
+__global__ __launch_bounds__(256) void k_tonemap_downsample(const float *__restrict__ hdr, int hiW, int fbW, int fbH, int ss, float gamma,
+                                                            float saturation, float vibrance, const ToneState *__restrict__ state,
+                                                            float *__restrict__ out /* fbW*fbH*6 */)
+{
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= fbW * fbH) return;
+    const int cx = i % fbW, cy = i / fbW;
+    const int y_top0 = cy * 2 * ss, y_bot0 = (cy * 2 + 1) * ss, x0 = cx * ss;
+    F3 top = f3(0, 0, 0), bot = f3(0, 0, 0);
+    for (int sy = 0; sy < ss; sy++)
+        for (int sx = 0; sx < ss; sx++) {
+            top = top + ld3(hdr, (size_t)(x0 + sx) + (size_t)(y_top0 + sy) * hiW);
+            bot = bot + ld3(hdr, (size_t)(x0 + sx) + (size_t)(y_bot0 + sy) * hiW);
+        }
+    const float inv = 1.0f / (float)(ss * ss);
+    const float exposure = state->effective;
+    const F3 t = map_pixel(f3(top.x * inv, top.y * inv, top.z * inv), exposure, gamma, saturation, vibrance);
+    const F3 b = map_pixel(f3(bot.x * inv, bot.y * inv, bot.z * inv), exposure, gamma, saturation, vibrance);
+    float *o = out + (size_t)i * 6;
+    o[0] = t.x; o[1] = t.y; o[2] = t.z; o[3] = b.x; o[4] = b.y; o[5] = b.z;
+}
+
+} // namespace ycge
+
+extern "C" {
+
+size_t ycge_post_state_bytes(void) { return sizeof(ycge::ToneState); }
+
+int ycge_launch_unit_normals(const float *normal, float *unit, size_t n, hipStream_t stream)
+{
+    if (n == 0) return 0;
+    hipLaunchKernelGGL(ycge::k_unit_normals, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, normal, unit, n);
+    return (int)hipGetLastError();
+}
+
+int ycge_launch_atrous(int w, int h, int step, const float phi[4], const float *cur, float *dst, const float *albedo, const float *unit_n,
+                       const float *depth, const uint8_t *sky, hipStream_t stream)
+{
+    ycge::AtrousParams A = {w, h, step, phi[0], phi[1], phi[2], phi[3]};
+    hipLaunchKernelGGL(ycge::k_atrous, dim3((unsigned)((w + 31) / 32), (unsigned)((h + 7) / 8)), dim3(256), 0, stream, A, cur, dst, albedo, unit_n,
+                       depth, sky);
+    return (int)hipGetLastError();
+}
+
+// in-place iteration: level l holds pixels[offsets[l] .. offsets[l + 1]) (host copy of offsets; pixels on the device)
+int ycge_launch_atrous_inplace(int w, int h, int step, const float phi[4], float *buf, const float *albedo, const float *unit_n,
+                               const float *depth, const uint8_t *sky, const uint32_t *d_pixels, const uint32_t *h_offsets, int n_levels,
+                               hipStream_t stream)
+{
+    ycge::AtrousParams A = {w, h, step, phi[0], phi[1], phi[2], phi[3]};
+    for (int l = 0; l < n_levels; l++) {
+        const uint32_t count = h_offsets[l + 1] - h_offsets[l];
+        if (count == 0) continue;
+        hipLaunchKernelGGL(ycge::k_atrous_level, dim3((count + 7u) / 8u), dim3(256), 0, stream, A, buf, albedo, unit_n, depth, sky,
+                           d_pixels + h_offsets[l], count);
+    }
+    return (int)hipGetLastError();
+}
+
+int ycge_launch_exposure(const float *hdr, const uint8_t *sky, int w, int h, int step, float *terms, void *state, const float consts[5],
+                         hipStream_t stream)
+{
+    const int nsx = (w + step - 1) / step, nsy = (h + step - 1) / step;
+    const int n = nsx * nsy;
+    ycge::ToneConsts K = {consts[0], consts[1], consts[2], consts[3], consts[4]};
+    hipLaunchKernelGGL(ycge::k_exposure_terms, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, hdr, sky, w, h, step, nsx, nsy, terms,
+                       (ycge::ToneState *)state);
+    hipLaunchKernelGGL(ycge::k_exposure_sum, dim3(1), dim3(64), 0, stream, terms, n, K, (ycge::ToneState *)state);
+    return (int)hipGetLastError();
+}
+
+int ycge_launch_tonemap(const float *hdr, int hiW, int fbW, int fbH, int ss, float gamma, float saturation, float vibrance, const void *state,
+                        float *out, hipStream_t stream)
+{
+    const int n = fbW * fbH;
+    hipLaunchKernelGGL(ycge::k_tonemap_downsample, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, hdr, hiW, fbW, fbH, ss, gamma,
+                       saturation, vibrance, (const ycge::ToneState *)state, out);
+    return (int)hipGetLastError();
+}
+
+} // extern "C"
