@@ -182,18 +182,34 @@ __global__ __launch_bounds__(256) void k_exposure_terms(const float *__restrict_
 struct ToneConsts { float tone_exposure, ae_key, ae_speed, ae_min, ae_max; };
 __global__ __launch_bounds__(64) void k_exposure_sum(const float *__restrict__ terms, int n, ToneConsts K, ToneState *__restrict__ state)
 {
-    if (threadIdx.x != 0 || blockIdx.x != 0) return;
-    float log_sum = 0.0f;
-    int i = 0;
+    // The adds are one dependent chain (4 cycles each at best); everything else is kept off it: the wavefront
+    // fetches the next 1024 terms with coalesced 16-byte loads while lane 0 adds the current 1024 out of LDS.
+    __shared__ float4 s_buf[2][256];
+    const int lane = threadIdx.x;
     const float4 *t4 = (const float4 *)terms;
-    for (; i + 16 <= n; i += 16) {
-        const float4 a = t4[i / 4], b = t4[i / 4 + 1], c = t4[i / 4 + 2], d = t4[i / 4 + 3];
-        log_sum += a.x; log_sum += a.y; log_sum += a.z; log_sum += a.w;
-        log_sum += b.x; log_sum += b.y; log_sum += b.z; log_sum += b.w;
-        log_sum += c.x; log_sum += c.y; log_sum += c.z; log_sum += c.w;
-        log_sum += d.x; log_sum += d.y; log_sum += d.z; log_sum += d.w;
+    const int n_chunks = n / 1024;
+    float log_sum = 0.0f;
+    float4 r0, r1, r2, r3;
+    if (n_chunks > 0) { r0 = t4[lane]; r1 = t4[64 + lane]; r2 = t4[128 + lane]; r3 = t4[192 + lane]; }
+    for (int c = 0; c < n_chunks; c++) {
+        float4 *buf = s_buf[c & 1];
+        buf[lane] = r0; buf[64 + lane] = r1; buf[128 + lane] = r2; buf[192 + lane] = r3;
+        if (c + 1 < n_chunks) {
+            const float4 *nx = t4 + (size_t)(c + 1) * 256;
+            r0 = nx[lane]; r1 = nx[64 + lane]; r2 = nx[128 + lane]; r3 = nx[192 + lane];
+        }
+        __syncthreads();
+        if (lane == 0) {
+#pragma unroll 8
+            for (int i = 0; i < 256; i++) {
+                const float4 v = buf[i];
+                log_sum += v.x; log_sum += v.y; log_sum += v.z; log_sum += v.w;
+            }
+        }
+        // the other buffer is written next; it was last read two iterations ago, before the barrier above
     }
-    for (; i < n; i++) log_sum += terms[i];
+    if (lane != 0) return;
+    for (int i = n_chunks * 1024; i < n; i++) log_sum += terms[i];
     const int cnt = (int)state->count;
     float ae = state->ae_exposure;
     const float avg_log = cnt > 0 ? log_sum / (float)(cnt > 1 ? cnt : 1) : 0.0f;
