@@ -875,6 +875,23 @@ int orc_scene_hit_many(void *ctx, const float *od /* n x 6 */, int n, float t_mi
     }
     return YCGE_OK;
 }
+/* analysis aid: re-trace the last rendered frame and report, per pixel, the traversal steps of each of its first
+ * `per_pixel` Scene.Hit calls in call order (primary, shadow rays of vertex 1, bounce, shadow rays of vertex 2, ...) */
+int orc_query_profile(void *ctx, uint32_t *out, int per_pixel)
+{
+    Renderer *r = (Renderer *)ctx;
+    if (!r || !r->have_scene || !out || per_pixel <= 0) return YCGE_ERR_INVALID_ARG;
+    size_t npx = (size_t)r->hiW * r->hiH;
+    std::memset(out, 0, npx * per_pixel * sizeof(uint32_t));
+    for (size_t i = 0; i < npx; i++) {
+        int px = (int)(i % r->hiW), py = (int)(i / r->hiW);
+        orc::Rng rng(orc::per_frame_seed(px, py, r->frame_counter, 0, 0, r->cfg.seed_salt));
+        orc::Counters c; c.qlog = out + i * per_pixel; c.qcap = per_pixel;
+        bool is_sky; orc::GBuf g;
+        (void)orc::trace_full(r->scene, r->K, r->rays[i], rng, is_sky, g, c);
+    }
+    return YCGE_OK;
+}
 /* brute-force closest hit over Scene.Objects in order (no BVH), same tie rule */
 int orc_scene_hit_bruteforce(void *ctx, const float o[3], const float d[3], float t_min, float t_max, float out[4])
 {

@@ -865,6 +865,11 @@ static inline bool scene_box_hit(const Node &n, const Ray &r, float t_min, float
 /* ---- BVH.Hit, BVH.cs:99-198 ------------------------------------------- */
 bool SceneData::hit(const Ray &r, float t_min, float t_max, Hit &rec, Counters &cnt) const
 {
+    struct QueryLog {       /* analysis aid only */
+        Counters &c; uint64_t b0, t0;
+        explicit QueryLog(Counters &cc) : c(cc), b0(cc.box), t0(cc.tri) {}
+        ~QueryLog() { if (c.qlog && c.qn < c.qcap) c.qlog[c.qn++] = (uint32_t)((c.box - b0) / 2 + (c.tri - t0)); }
+    } query_log(cnt);
     cnt.rays++;
     if (root < 0) return false;
     float inv_dx = 1.0f / r.d.x, inv_dy = 1.0f / r.d.y, inv_dz = 1.0f / r.d.z;

@@ -73,6 +73,8 @@ struct Hit {
 
 struct Counters {
     uint64_t rays = 0, box = 0, tri = 0, prim = 0, vox = 0;
+    /* analysis aid (orc_query_profile): traversal steps (node visits + triangle tests) of each Scene.Hit call, in call order */
+    uint32_t *qlog = nullptr; int qn = 0, qcap = 0;
     void add(const Counters &o) { rays += o.rays; box += o.box; tri += o.tri; prim += o.prim; vox += o.vox; }
 };
 

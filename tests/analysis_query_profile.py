@@ -1,0 +1,29 @@
+"""Analysis aid (CPU, oracle): traversal steps of every Scene.Hit call of every pixel of config 4, frame 1.
+Shows what bounds the frame on the GPU: the serial chain of the heaviest pixel / 8x8 block."""
+import sys, time, ctypes as C
+from pathlib import Path; ROOT = Path(__file__).resolve().parents[1]; sys.path.insert(0, str(ROOT)); sys.path.insert(0, str(ROOT / 'tests'))
+import numpy as np
+import oracle_binding as ob
+from yetanotherconsolegameengine_amd import abi, scenes
+from yetanotherconsolegameengine_amd.scene import flatten
+sc,w,h,ss,pose=scenes.config_scene(4)
+o=ob.OracleRenderer(sc,w,h,ss,pose,flat=flatten(sc))
+o.render(stages=0,threads=8)
+n=o.hiW*o.hiH
+q=np.zeros((n,8),np.uint32)
+o.L.orc_query_profile.restype=C.c_int; o.L.orc_query_profile.argtypes=[C.c_void_p,C.c_void_p,C.c_int]
+t=time.time(); print(o.L.orc_query_profile(o.ctx,q.ctypes.data,8), time.time()-t)
+np.save('/tmp/ycge_query_profile.npy',q)
+tot=q.sum(1).astype(np.int64)
+print('per-pixel total steps: max',tot.max(),'p99.9',np.percentile(tot,99.9))
+idx=np.argsort(-tot)[:12]
+for i in idx: print(i%o.hiW,i//o.hiW,tot[i],q[i])
+# ray-parallel chain: P + max(S1,S2, B + max(S1',S2'))
+P=q[:,0]; S1=q[:,1]; S2=q[:,2]; B=q[:,3]; S1b=q[:,4]; S2b=q[:,5]
+par=P+np.maximum(np.maximum(S1,S2),B+np.maximum(S1b,S2b))
+print('ray-parallel chain max',par.max(),'vs serial',tot.max())
+W,H=o.hiW,o.hiH
+def blockmax(a): return a.reshape(H//8,8,W//8,8).max(axis=(1,3))
+# megakernel wave model: sum over query slots of per-block max
+mk=sum(blockmax(q[:,k].astype(np.int64)) for k in range(8))
+print('wave model (sum over queries of block max): max',mk.max(), ' per-pixel-sum block max',blockmax(tot).max())
