@@ -44,12 +44,13 @@ def stats_dict(s):
     return {k: int(getattr(s, k)) for k in ("n_rays", "n_box", "n_tri", "n_prim", "n_vox")}
 
 
-def load_traffic_hint():
-    """HBM bytes per k_trace launch from the committed PMC pass (profiles/), or None."""
+def load_traffic_hint(config):
+    """HBM bytes per k_trace launch from the committed PMC pass (profiles/) of THIS config, or None."""
     p = ROOT / "profiles" / "trace_hbm_traffic.json"
     if p.exists():
         try:
-            return json.loads(p.read_text()).get("hbm_bytes_per_launch")
+            d = json.loads(p.read_text())
+            return d.get("hbm_bytes_per_launch") if d.get("config", 4) == config else None
         except Exception:
             return None
     return None
@@ -164,7 +165,7 @@ def main():
     if mean_trace_ms:
         ach = my_alg / (mean_trace_ms * 1e-3) / 1e9
         roof = {"bound": "hbm", "kernel": "k_trace", "achieved": round(ach, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                "frac": round(ach / HBM_PEAK_GBS, 5), "traffic": load_traffic_hint() if world == 1 else None,
+                "frac": round(ach / HBM_PEAK_GBS, 5), "traffic": load_traffic_hint(args.config) if world == 1 else None,
                 "algorithmic_bytes_per_launch": int(my_alg), "mean_launch_ms": round(mean_trace_ms, 4)}
 
     cpu = None

@@ -265,3 +265,49 @@ def test_inplace_atrous_schedule_respects_scan_order(product_lib, w, h, step):
             later = q > p
             assert np.all(level[q[earlier]] < level[p[earlier]])
             assert np.all(level[q[later]] > level[p[later]])
+
+
+def test_vg01_world_file_roundtrip_and_errors(tmp_path):
+    """the VG01 world file (WorldManager.cs:612-629 writer, :399-441 reader) and its error behaviour."""
+    import struct
+    from yetanotherconsolegameengine_amd import world_file as wf
+    rng = np.random.default_rng(7)
+    cells = rng.integers(0, 9, size=(5, 7, 3, 2), dtype=np.int32)
+    p = tmp_path / "w.vg"
+    wf.write_vg01(p, cells)
+    raw = p.read_bytes()
+    assert raw[:4] == b"VG01" and struct.unpack("<iii", raw[4:16]) == (5, 7, 3) and len(raw) == 16 + 5 * 7 * 3 * 8
+    # z fastest, then y, then x; matId before metaId
+    assert struct.unpack("<ii", raw[16:24]) == (int(cells[0, 0, 0, 0]), int(cells[0, 0, 0, 1]))
+    assert struct.unpack("<ii", raw[24:32]) == (int(cells[0, 0, 1, 0]), int(cells[0, 0, 1, 1]))
+    assert np.array_equal(wf.read_vg01(p), cells)
+    (tmp_path / "bad.vg").write_bytes(b"VG02" + raw[4:])
+    with pytest.raises(ValueError, match="VG01"):
+        wf.read_vg01(tmp_path / "bad.vg")
+    (tmp_path / "dims.vg").write_bytes(b"VG01" + struct.pack("<iii", 0, 1, 1))
+    with pytest.raises(ValueError, match="dimensions"):
+        wf.read_vg01(tmp_path / "dims.vg")
+    (tmp_path / "short.vg").write_bytes(raw[:-4])
+    with pytest.raises(EOFError):
+        wf.read_vg01(tmp_path / "short.vg")
+    with pytest.raises(FileNotFoundError):
+        wf.read_vg01(tmp_path / "nope.vg")
+
+
+def test_chunk_streaming_set_and_attach_order():
+    """BuildDesiredSet (:372-397) + AttachChunkFromPreloaded (:696-731): key order, clipping, air skipping."""
+    from yetanotherconsolegameengine_amd import world_file as wf
+    from yetanotherconsolegameengine_amd.scene import Scene
+    keys = wf.build_desired_set((5.0, 0.0, -40.0), (-64.0, 0.0, -64.0), (1.0, 1.0, 1.0), 32, 1, 2)
+    # centre column: floor((5+64)/32) = 2, floor((-40+64)/32) = 0 -> cx 1..3, cz -1..1, every cy; cx outermost, cy innermost
+    assert keys[0] == (1, 0, -1) and keys[1] == (1, 1, -1) and keys[2] == (1, 0, 0) and keys[-1] == (3, 1, 1) and len(keys) == 18
+    world = np.zeros((70, 40, 64, 2), np.int32)
+    world[:, :20, :, 0] = 1                       # ground slab: chunks with cy = 1 are air
+    world[69, 39, 63, 0] = 2                      # one voxel in the clipped far corner chunk (2, 1, 1)
+    sc = Scene()
+    loaded = {}
+    added = wf.attach_view(sc, world, (5.0, 0.0, -40.0), (-64.0, 0.0, -64.0), (1.0, 1.0, 1.0), 32, 1, lambda m, t: None, loaded=loaded)
+    assert added == [(1, 0, 0), (1, 0, 1), (2, 0, 0), (2, 0, 1), (2, 1, 1)]      # negative cz and cx = 3 lie outside the 70-wide world
+    assert sc.Objects[4].Cells.shape == (6, 8, 32, 2)                            # clipped: 70 - 64, 40 - 32
+    assert sc.Objects[2].MinCorner == (0.0, 0.0, -64.0)
+    assert wf.attach_view(sc, world, (5.0, 0.0, -40.0), (-64.0, 0.0, -64.0), (1.0, 1.0, 1.0), 32, 1, lambda m, t: None, loaded=loaded) == []
