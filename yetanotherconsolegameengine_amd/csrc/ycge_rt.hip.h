@@ -481,6 +481,94 @@ __device__ __forceinline__ void grid_dda(const SceneDev &S, int grid_index_, int
         if ((uint32_t)ix >= (uint32_t)g.nx || (uint32_t)iy >= (uint32_t)g.ny || (uint32_t)iz >= (uint32_t)g.nz) break;
     }
 }
+// The same walk as grid_dda, split into "enter the grid" and "one cell step", so that a lane can pause inside a
+// grid while the wavefront hands finished lanes new rays (k_wf_extend_p).  Operation for operation the code of grid_dda.
+struct DdaState {
+    int ix, iy, iz;
+    float t, t_max_x, t_max_y, t_max_z, t_delta_x, t_delta_y, t_delta_z, t_exit, tmax;
+    uint32_t packed;            // (step_x + 1) | (step_y + 1) << 2 | (step_z + 1) << 4 | last_axis << 6 | use_mask << 8
+    int nx, ny, nz;
+    uint32_t cell_offset, mask_lo, mask_hi;
+    int prim;
+};
+template <bool COUNT>
+__device__ __forceinline__ bool dda_begin(const SceneDev &S, int grid_index_, int prim_index, F3 o, F3 d, F3 inv, float tmin, float closest,
+                                          DdaState &D, Work &w)
+{
+    if (COUNT) { w.prim++; prof_tick(2); }
+    const GGrid g = S.grids[grid_index_];
+    const float min_x = g.min_corner[0], min_y = g.min_corner[1], min_z = g.min_corner[2];
+    const float size_x = g.voxel_size[0], size_y = g.voxel_size[1], size_z = g.voxel_size[2];
+    const float max_x = min_x + (float)g.nx * size_x, max_y = min_y + (float)g.ny * size_y, max_z = min_z + (float)g.nz * size_z;
+    const float tmax = closest;
+    int enter_axis = -1;
+    float t_enter = -YCGE_INF, t_exit = YCGE_INF;
+    if (!grid_slab(o.x, d.x, inv.x, min_x, max_x, t_enter, t_exit, 0, enter_axis)) return false;
+    if (!grid_slab(o.y, d.y, inv.y, min_y, max_y, t_enter, t_exit, 1, enter_axis)) return false;
+    if (!grid_slab(o.z, d.z, inv.z, min_z, max_z, t_enter, t_exit, 2, enter_axis)) return false;
+    if (!(t_exit >= cs_max(0.0f, t_enter))) return false;
+    float t = t_enter; if (t < tmin) t = tmin; if (t > tmax || t > t_exit) return false;
+    t += 1e-6f;
+    float px = o.x + d.x * t, py = o.y + d.y * t, pz = o.z + d.z * t;
+    int ix = cs_f2i(cs_floor(div_by_size(px - min_x, size_x))); if (ix < 0) ix = 0; else if (ix >= g.nx) ix = g.nx - 1;
+    int iy = cs_f2i(cs_floor(div_by_size(py - min_y, size_y))); if (iy < 0) iy = 0; else if (iy >= g.ny) iy = g.ny - 1;
+    int iz = cs_f2i(cs_floor(div_by_size(pz - min_z, size_z))); if (iz < 0) iz = 0; else if (iz >= g.nz) iz = g.nz - 1;
+    const int step_x = d.x > 0.0f ? 1 : d.x < 0.0f ? -1 : 0;
+    const int step_y = d.y > 0.0f ? 1 : d.y < 0.0f ? -1 : 0;
+    const int step_z = d.z > 0.0f ? 1 : d.z < 0.0f ? -1 : 0;
+    const float inv_dx = step_x == 0 ? 0.0f : inv.x;
+    const float inv_dy = step_y == 0 ? 0.0f : inv.y;
+    const float inv_dz = step_z == 0 ? 0.0f : inv.z;
+    const float next_vx = min_x + (step_x > 0 ? (float)(ix + 1) * size_x : (float)ix * size_x);
+    const float next_vy = min_y + (step_y > 0 ? (float)(iy + 1) * size_y : (float)iy * size_y);
+    const float next_vz = min_z + (step_z > 0 ? (float)(iz + 1) * size_z : (float)iz * size_z);
+    D.t_max_x = step_x == 0 ? YCGE_INF : (next_vx - o.x) * inv_dx;
+    D.t_max_y = step_y == 0 ? YCGE_INF : (next_vy - o.y) * inv_dy;
+    D.t_max_z = step_z == 0 ? YCGE_INF : (next_vz - o.z) * inv_dz;
+    D.t_delta_x = step_x == 0 ? YCGE_INF : cs_abs(size_x * inv_dx);
+    D.t_delta_y = step_y == 0 ? YCGE_INF : cs_abs(size_y * inv_dy);
+    D.t_delta_z = step_z == 0 ? YCGE_INF : cs_abs(size_z * inv_dz);
+    const int last_axis = enter_axis < 0 ? (D.t_max_x <= D.t_max_y && D.t_max_x <= D.t_max_z ? 0 : D.t_max_y <= D.t_max_z ? 1 : 2) : enter_axis;
+    D.ix = ix; D.iy = iy; D.iz = iz; D.t = t; D.t_exit = t_exit; D.tmax = tmax;
+    D.packed = (uint32_t)(step_x + 1) | ((uint32_t)(step_y + 1) << 2) | ((uint32_t)(step_z + 1) << 4) | ((uint32_t)last_axis << 6) |
+               (g.has_brick_mask ? 256u : 0u);
+    D.nx = g.nx; D.ny = g.ny; D.nz = g.nz;
+    D.cell_offset = g.cell_offset; D.mask_lo = g.brick_mask_lo; D.mask_hi = g.brick_mask_hi;
+    D.prim = prim_index;
+    return t <= t_exit && t <= tmax;            // the while condition of VolumeGrid.cs:151 before the first cell
+}
+// one pass of the while loop of VolumeGrid.Hit (:151-228).  Returns false when the lane has left the grid (hit or exit).
+template <bool COUNT>
+__device__ __forceinline__ bool dda_step(const SceneDev &S, DdaState &D, float tmin, float &closest, int &hit_prim, int &hit_sub, Work &w)
+{
+    if (COUNT) prof_tick(3);
+    w.steps++;
+    const int nby = (D.ny + 7) >> 3, nbx = (D.nx + 7) >> 3;
+    if ((uint32_t)D.ix < (uint32_t)D.nx && (uint32_t)D.iy < (uint32_t)D.ny && (uint32_t)D.iz < (uint32_t)D.nz) {
+        if (COUNT) w.vox++;
+        const int brick = (((D.iz >> 3) * nby) + (D.iy >> 3)) * nbx + (D.ix >> 3);
+        const unsigned long long mask = ((unsigned long long)D.mask_hi << 32) | D.mask_lo;
+        if (!(D.packed & 256u) || ((mask >> brick) & 1ull)) {
+            if (S.grid_cells[D.cell_offset + (uint32_t)(brick * 512 + morton3_3bits(D.ix & 7, D.iy & 7, D.iz & 7))] != 0) {
+                closest = cs_max(D.t, tmin);
+                hit_prim = D.prim;
+                hit_sub = (D.ix + D.nx * (D.iy + D.ny * D.iz)) | (int)(((D.packed >> 6) & 3u) << 30);
+                return false;
+            }
+        }
+    }
+    const int step_x = (int)(D.packed & 3u) - 1, step_y = (int)((D.packed >> 2) & 3u) - 1, step_z = (int)((D.packed >> 4) & 3u) - 1;
+    const bool ax = D.t_max_x <= D.t_max_y && D.t_max_x <= D.t_max_z;
+    const bool ay = !ax && D.t_max_y <= D.t_max_z;
+    const bool az = !ax && !ay;
+    D.t = ax ? D.t_max_x : ay ? D.t_max_y : D.t_max_z;
+    D.ix += ax ? step_x : 0; D.iy += ay ? step_y : 0; D.iz += az ? step_z : 0;
+    const float nx_ = D.t_max_x + D.t_delta_x, ny_ = D.t_max_y + D.t_delta_y, nz_ = D.t_max_z + D.t_delta_z;
+    D.t_max_x = ax ? nx_ : D.t_max_x; D.t_max_y = ay ? ny_ : D.t_max_y; D.t_max_z = az ? nz_ : D.t_max_z;
+    D.packed = (D.packed & ~(3u << 6)) | ((ax ? 0u : ay ? 1u : 2u) << 6);
+    if ((uint32_t)D.ix >= (uint32_t)D.nx || (uint32_t)D.iy >= (uint32_t)D.ny || (uint32_t)D.iz >= (uint32_t)D.nz) return false;
+    return D.t <= D.t_exit && D.t <= D.tmax;
+}
 __device__ __forceinline__ double edge_distance(double v, double v0, double v1)   // VolumeGrid.cs:291-296
 {
     double a = v - v0, b = v1 - v;
@@ -651,76 +739,91 @@ __device__ __forceinline__ void leaf_triangles(const SceneDev &S, uint32_t pay, 
 // running until every lane of the wavefront is parked or finished, then all parked lanes run their DDA
 // together.  Incoherent rays otherwise serialise: measured on config 5's bounce rays, running each DDA where
 // it is met left 4.4 of 64 lanes active per VALU instruction.  Per-lane order of events is unchanged.
+// The tree part of a query: runs until the lane reaches a VolumeGrid object (returns TREE_AT_GRID, the grid /
+// object in parked_grid / parked_prim), has nothing left to visit (TREE_DONE) or has used its step budget (TREE_YIELD).
+enum : int { TREE_DONE = 0, TREE_AT_GRID = 1, TREE_YIELD = 2 };
+template <bool COUNT, bool HAS_GRID, class STK>
+__device__ __forceinline__ int tree_phase(const SceneDev &S, uint32_t &cur, int &mesh_prim, STK &st, F3 o, F3 d, F3 inv, bool sx, bool sy, bool sz,
+                                          float tmin, float &closest, int &hit_prim, int &hit_sub, int &parked_grid, int &parked_prim, Work &w,
+                                          int budget = 0x7fffffff)
+{
+    for (;;) {
+        if (budget-- <= 0) return TREE_YIELD;
+        if (cur == YCGE_REF_NONE_VALUE) {
+            float tn;
+            if (!st.pop(cur, tn)) { cur = YCGE_REF_NONE_VALUE; return TREE_DONE; }
+            if (!(closest >= tn)) { cur = YCGE_REF_NONE_VALUE; continue; }
+        }
+        const uint32_t kind = YCGE_REF_KIND(cur), pay = YCGE_REF_PAYLOAD(cur);
+        if (COUNT) prof_tick(0);
+        w.steps++;
+        if (kind == REF_MESH_NODE || kind == REF_SCENE_NODE) {
+            const float4 *np = (const float4 *)((kind == REF_MESH_NODE ? S.mesh_nodes : S.scene_nodes) + pay);
+            const float4 a = np[0], b = np[1], c = np[2], e = np[3];
+            float ln, rn;
+            bool hl, hr;
+            if (COUNT) w.box += 2;
+            if (kind == REF_MESH_NODE) {
+                hl = box_mesh(a.x, a.y, a.z, b.x, b.y, a.w, o, inv, sx, sy, sz, tmin, closest, ln);      // GNode plane order
+                hr = box_mesh(b.z, b.w, c.x, c.z, c.w, c.y, o, inv, sx, sy, sz, tmin, closest, rn);
+            } else {
+                hl = box_scene(a.x, a.y, a.z, b.x, b.y, a.w, o, inv, tmin, closest, ln);
+                hr = box_scene(b.z, b.w, c.x, c.z, c.w, c.y, o, inv, tmin, closest, rn);
+            }
+            const uint32_t lref = __float_as_uint(e.x), rref = __float_as_uint(e.y);
+            if (hl & hr) {
+                if (ln < rn) { st.push(rref, rn); cur = lref; }
+                else { st.push(lref, ln); cur = rref; }
+            } else if (hl) cur = lref;
+            else if (hr) cur = rref;
+            else cur = YCGE_REF_NONE_VALUE;
+        } else if (kind == REF_MESH_LEAF) {
+            leaf_triangles<COUNT>(S, pay, mesh_prim, o, d, tmin, closest, hit_prim, hit_sub, w);
+            cur = YCGE_REF_NONE_VALUE;
+        } else if (kind == REF_SCENE_LEAF) {
+            const uint32_t start = pay >> 3, count = pay & 7u;
+            for (uint32_t i = count - 1; i >= 1; i--) st.push(YCGE_REF(REF_PRIM, S.scene_leaf_prims[start + i]), -YCGE_INF);
+            cur = YCGE_REF(REF_PRIM, S.scene_leaf_prims[start]);
+        } else {    // REF_PRIM: objectHit[objId](r, tMin, closest, ...), BVH.cs:139-149
+            const float4 *pp = (const float4 *)(S.prims + pay);
+            const float4 q0 = pp[0];
+            const int type = __float_as_int(q0.x);
+            cur = YCGE_REF_NONE_VALUE;
+            if (type == 10) {
+                if (HAS_GRID) { parked_grid = __float_as_int(q0.z); parked_prim = (int)pay; return TREE_AT_GRID; }
+            } else {
+                const float4 q1 = pp[1], q2 = pp[2], q3 = pp[3];
+                if (type == 9) {    // Mesh.Hit -> MeshBVH.Hit: root pushed, popped, own box tested (p = root box, ref)
+                    const uint32_t root_ref = __float_as_uint(q2.z);
+                    if (root_ref != YCGE_REF_NONE_VALUE) {
+                        float tn;
+                        if (COUNT) w.box++;
+                        if (box_mesh(q1.x, q1.y, q1.z, q1.w, q2.x, q2.y, o, inv, sx, sy, sz, tmin, closest, tn)) {
+                            cur = root_ref;
+                            mesh_prim = (int)pay;
+                        }
+                    }
+                } else {
+                    analytic_prim<COUNT>(q0, q1, q2, q3, type, (int)pay, o, d, tmin, closest, hit_prim, hit_sub, w);
+                }
+            }
+        }
+    }
+}
+
 template <bool COUNT, bool HAS_GRID, class STK>
 __device__ __forceinline__ void walk(const SceneDev &S, uint32_t cur, int mesh_prim, STK &st, F3 o, F3 d, F3 inv, bool sx, bool sy, bool sz,
                                      float tmin, float &closest, int &hit_prim, int &hit_sub, Work &w)
 {
+    bool more = cur != YCGE_REF_NONE_VALUE;      // the stack is empty at entry
     for (;;) {
         int parked_grid = -1, parked_prim = -1;
-        for (;;) {
-            if (cur == YCGE_REF_NONE_VALUE) {
-                float tn;
-                if (!st.pop(cur, tn)) break;
-                if (!(closest >= tn)) { cur = YCGE_REF_NONE_VALUE; continue; }
-            }
-            const uint32_t kind = YCGE_REF_KIND(cur), pay = YCGE_REF_PAYLOAD(cur);
-            if (COUNT) prof_tick(0);
-            w.steps++;
-            if (kind == REF_MESH_NODE || kind == REF_SCENE_NODE) {
-                const float4 *np = (const float4 *)((kind == REF_MESH_NODE ? S.mesh_nodes : S.scene_nodes) + pay);
-                const float4 a = np[0], b = np[1], c = np[2], e = np[3];
-                float ln, rn;
-                bool hl, hr;
-                if (COUNT) w.box += 2;
-                if (kind == REF_MESH_NODE) {
-                    hl = box_mesh(a.x, a.y, a.z, b.x, b.y, a.w, o, inv, sx, sy, sz, tmin, closest, ln);      // GNode plane order
-                    hr = box_mesh(b.z, b.w, c.x, c.z, c.w, c.y, o, inv, sx, sy, sz, tmin, closest, rn);
-                } else {
-                    hl = box_scene(a.x, a.y, a.z, b.x, b.y, a.w, o, inv, tmin, closest, ln);
-                    hr = box_scene(b.z, b.w, c.x, c.z, c.w, c.y, o, inv, tmin, closest, rn);
-                }
-                const uint32_t lref = __float_as_uint(e.x), rref = __float_as_uint(e.y);
-                if (hl & hr) {
-                    if (ln < rn) { st.push(rref, rn); cur = lref; }
-                    else { st.push(lref, ln); cur = rref; }
-                } else if (hl) cur = lref;
-                else if (hr) cur = rref;
-                else cur = YCGE_REF_NONE_VALUE;
-            } else if (kind == REF_MESH_LEAF) {
-                leaf_triangles<COUNT>(S, pay, mesh_prim, o, d, tmin, closest, hit_prim, hit_sub, w);
-                cur = YCGE_REF_NONE_VALUE;
-            } else if (kind == REF_SCENE_LEAF) {
-                const uint32_t start = pay >> 3, count = pay & 7u;
-                for (uint32_t i = count - 1; i >= 1; i--) st.push(YCGE_REF(REF_PRIM, S.scene_leaf_prims[start + i]), -YCGE_INF);
-                cur = YCGE_REF(REF_PRIM, S.scene_leaf_prims[start]);
-            } else {    // REF_PRIM: objectHit[objId](r, tMin, closest, ...), BVH.cs:139-149
-                const float4 *pp = (const float4 *)(S.prims + pay);
-                const float4 q0 = pp[0];
-                const int type = __float_as_int(q0.x);
-                cur = YCGE_REF_NONE_VALUE;
-                if (type == 10) {
-                    if (HAS_GRID) { parked_grid = __float_as_int(q0.z); parked_prim = (int)pay; break; }
-                } else {
-                    const float4 q1 = pp[1], q2 = pp[2], q3 = pp[3];
-                    if (type == 9) {    // Mesh.Hit -> MeshBVH.Hit: root pushed, popped, own box tested (p = root box, ref)
-                        const uint32_t root_ref = __float_as_uint(q2.z);
-                        if (root_ref != YCGE_REF_NONE_VALUE) {
-                            float tn;
-                            if (COUNT) w.box++;
-                            if (box_mesh(q1.x, q1.y, q1.z, q1.w, q2.x, q2.y, o, inv, sx, sy, sz, tmin, closest, tn)) {
-                                cur = root_ref;
-                                mesh_prim = (int)pay;
-                            }
-                        }
-                    } else {
-                        analytic_prim<COUNT>(q0, q1, q2, q3, type, (int)pay, o, d, tmin, closest, hit_prim, hit_sub, w);
-                    }
-                }
-            }
-        }
+        bool parked = false;
+        if (more) parked = tree_phase<COUNT, HAS_GRID>(S, cur, mesh_prim, st, o, d, inv, sx, sy, sz, tmin, closest, hit_prim, hit_sub, parked_grid, parked_prim, w) == TREE_AT_GRID;
+        more = parked;
         if (!HAS_GRID) break;
-        if (!__any(parked_grid >= 0)) break;
-        if (parked_grid >= 0) grid_dda<COUNT>(S, parked_grid, parked_prim, o, d, inv, tmin, closest, hit_prim, hit_sub, w);
+        if (!__any(parked)) break;
+        if (parked) grid_dda<COUNT>(S, parked_grid, parked_prim, o, d, inv, tmin, closest, hit_prim, hit_sub, w);
     }
 }
 
