@@ -22,7 +22,7 @@
 extern "C" {
 size_t ycge_wf_sizes(int which);
 int ycge_launch_trace(const ycge::SceneDev *S, const ycge::FrameParams *P, const ycge::TraceOut *O, int count, int flat, hipStream_t stream);
-int ycge_launch_wavefront(const ycge::SceneDev *S, const ycge::FrameParams *P, const ycge::TraceOut *O, void *const bufs[9], int rounds,
+int ycge_launch_wavefront(const ycge::SceneDev *S, const ycge::FrameParams *P, const ycge::TraceOut *O, void *const bufs[7], int rounds,
                           int has_grid, int flat, int count, int persistent_waves, hipStream_t stream);
 int ycge_launch_order_blocks(uint32_t *cost, uint32_t n, uint32_t policy, uint32_t *order_ws, uint32_t *order, hipStream_t stream);
 int ycge_launch_taa(const ycge::TaaParams *T, const float *current, const float *normal, const float *depth, const uint8_t *sky,
@@ -107,8 +107,8 @@ struct ycge_ctx {
     DevBuf<unsigned long long> counters, wave_prof;
     DevBuf<float> own_slab;                    // used when world_size > 1 and the caller passes no slab
     // wavefront pipeline storage (ycge_kernels.hip: QEntry / HitRec / LEntry), sized for one ray per pixel
-    DevBuf<uint8_t> wf_q0, wf_q1, wf_hit, wf_lq, wf_dense;
-    DevBuf<uint32_t> wf_seg;                      // [tiles + 1] scan of a round's per-tile ray counts, then the chunk counter
+    DevBuf<uint8_t> wf_q0, wf_q1, wf_hit, wf_lq;
+    DevBuf<uint32_t> wf_seg;                      // segment counter of the persistent extend stage
     DevBuf<uint32_t> wf_counts, tile_order;
     // denoise / exposure / tonemap stage (ycge_post.hip), allocated on the first frame that asks for SDR output
     DevBuf<float> den_a, den_b, unit_n, exp_terms, d_sdr;
@@ -185,7 +185,7 @@ int alloc_tile_buffers(ycge_ctx *c)
     const size_t stack_lanes = lanes * YCGE_SCHEDULE_SLACK;      // k_trace's grid includes the schedule's slack entries
     HIP_TRY(c, c->wf_q0.alloc(lanes * ycge_wf_sizes(0))); HIP_TRY(c, c->wf_q1.alloc(lanes * ycge_wf_sizes(0)));
     HIP_TRY(c, c->wf_hit.alloc(lanes * ycge_wf_sizes(1))); HIP_TRY(c, c->wf_lq.alloc(lanes * ycge_wf_sizes(2)));
-    HIP_TRY(c, c->wf_dense.alloc(lanes * ycge_wf_sizes(0))); HIP_TRY(c, c->wf_seg.alloc((size_t)(c->n_owned > 0 ? c->n_owned : 1) + 2));
+    HIP_TRY(c, c->wf_seg.alloc(4));
     HIP_TRY(c, c->wf_counts.alloc((size_t)(c->n_owned > 0 ? c->n_owned : 1) * 8));
     HIP_TRY(c, c->stack_spill.alloc((size_t)(c->spill_levels > 0 ? c->spill_levels : 1) * stack_lanes));
     c->path_stack.release();
@@ -438,7 +438,7 @@ void ycge_destroy(ycge_ctx *c)
     c->den_a.release(); c->den_b.release(); c->unit_n.release(); c->exp_terms.release(); c->d_sdr.release(); c->tone_state.release();
     for (auto *sc : c->schedules) { sc->pixels.release(); delete sc; }
     c->schedules.clear();
-    c->wf_q0.release(); c->wf_q1.release(); c->wf_hit.release(); c->wf_lq.release(); c->wf_dense.release(); c->wf_seg.release(); c->wf_counts.release(); c->tile_order.release(); c->block_cost.release(); c->block_order.release(); c->order_ws.release(); c->stack_spill.release(); c->path_stack.release();
+    c->wf_q0.release(); c->wf_q1.release(); c->wf_hit.release(); c->wf_lq.release(); c->wf_seg.release(); c->wf_counts.release(); c->tile_order.release(); c->block_cost.release(); c->block_order.release(); c->order_ws.release(); c->stack_spill.release(); c->path_stack.release();
     c->d_scene_nodes.release(); c->d_mesh_nodes.release(); c->d_scene_leaf.release(); c->d_tris.release(); c->d_prims.release();
     c->d_materials.release(); c->d_meshes.release(); c->d_grids.release(); c->d_cells.release(); c->d_lut.release(); c->d_lights.release();
     for (auto &ev : c->ev) if (ev) (void)hipEventDestroy(ev);
@@ -811,10 +811,11 @@ int begin_and_trace(ycge_ctx *c, float *d_slab, hipStream_t stream, FrameState &
         }
     } else {
         const size_t nt = (size_t)(c->n_owned > 0 ? c->n_owned : 1);
-        void *bufs[9] = {c->wf_q0.p, c->wf_q1.p, c->wf_hit.p, c->wf_lq.p, c->wf_counts.p, c->wf_counts.p + 7 * nt, c->wf_dense.p, c->wf_seg.p, c->wf_seg.p + nt + 1};
+        void *bufs[7] = {c->wf_q0.p, c->wf_q1.p, c->wf_hit.p, c->wf_lq.p, c->wf_counts.p, c->wf_counts.p + 7 * nt, c->wf_seg.p};
         // persistent extend: as many wavefronts as the chip holds (16 per CU), within the stack-spill columns
         int pw = getenv("YCGE_NO_REFILL") ? 0 : c->compute_units * 16;
         if ((size_t)pw * 64 > O.stack_lanes) pw = (int)(O.stack_lanes / 64);
+        if ((size_t)pw > nt * 4) pw = (int)(nt * 4);            // never more wavefronts than the round can have rays for
         e = ycge_launch_wavefront(&c->sd, &P, &O, bufs, c->wf_rounds, c->has_grid ? 1 : 0, flat, c->cfg.count_work, pw, stream);
     }
     if (e != 0) return c->fail(YCGE_ERR_DEVICE, "trace launch failed: %s", hipGetErrorString((hipError_t)e));

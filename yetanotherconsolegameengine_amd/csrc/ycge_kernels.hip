@@ -102,9 +102,7 @@ struct WfBuffers {
     LEntry *lq;                 // light records of the current round, same segmentation
     uint32_t *n_q;              // [round][owned tile] live entries of that tile's queue segment (round 0: implicit 256)
     uint32_t *n_lq;             // [owned tile] light records of the current round
-    QEntry *dense;              // continuation rays of the current round gathered into one list (persistent extend)
-    uint32_t *seg_start;        // [tiles + 1] exclusive scan of the round's per-tile counts; [tiles] = total
-    uint32_t *chunk_ctr;        // next 256-ray chunk of the dense list
+    uint32_t *chunk_ctr;        // next tile segment of the persistent extend stage
     uint32_t tiles;             // owned tiles (= gridDim.x of every stage)
     const uint32_t *tile_order; // = FrameParams.tile_order
 };
@@ -200,91 +198,63 @@ __global__ __launch_bounds__(256) void k_wf_extend(const SceneDev S, const Trace
     flush_work<COUNT>(w, O.counters);
 }
 
-// ---------------------------------------------------------------------------------- persistent extend (ray refill)
-// Bounce rays of a voxel world differ in length by two orders of magnitude (a ray into the ground: a few
+// ---------------------------------------------------------------------------------- persistent trace stages (ray refill)
+// Secondary rays of a voxel world differ in length by two orders of magnitude (a ray into the ground: a few
 // steps; a ray along the horizon: hundreds of cells through a dozen chunks), so a wavefront that keeps its 64
 // rays until the longest one ends runs almost empty: measured 8 % of VALU lanes active in k_wf_extend on
-// config 5.  Here a lane that finishes its ray takes the next one: the per-tile queue segments are first
-// gathered into one dense list (k_wf_scan + k_wf_gather; no atomics), persistent wavefronts then draw
-// 256-ray chunks from one counter (one atomic per 256 rays) and hand the chunk's rays to their idle lanes.
-// Which lane traces a ray never changes the ray's result.
-__global__ __launch_bounds__(1024) void k_wf_scan(const uint32_t *__restrict__ counts, uint32_t n, uint32_t *__restrict__ start /* n + 1 */,
-                                                  uint32_t *__restrict__ chunk_ctr)
-{
-    __shared__ uint32_t s_part[1024];
-    const uint32_t per = (n + 1023u) / 1024u;
-    const uint32_t lo = threadIdx.x * per, hi = lo + per < n ? lo + per : n;
-    uint32_t sum = 0;
-    for (uint32_t i = lo; i < hi; i++) sum += counts[i];
-    s_part[threadIdx.x] = sum;
-    __syncthreads();
-    for (uint32_t off = 1; off < 1024u; off <<= 1) {        // Hillis-Steele inclusive scan
-        const uint32_t v = threadIdx.x >= off ? s_part[threadIdx.x - off] : 0u;
-        __syncthreads();
-        s_part[threadIdx.x] += v;
-        __syncthreads();
-    }
-    uint32_t run = s_part[threadIdx.x] - sum;
-    for (uint32_t i = lo; i < hi; i++) { start[i] = run; run += counts[i]; }
-    if (threadIdx.x == 1023) start[n] = s_part[1023];
-    if (threadIdx.x == 0) *chunk_ctr = 0;
-}
-__global__ __launch_bounds__(256) void k_wf_gather(const QEntry *__restrict__ seg, const uint32_t *__restrict__ counts,
-                                                   const uint32_t *__restrict__ start, QEntry *__restrict__ dense)
-{
-    const uint32_t k = blockIdx.x;
-    if (threadIdx.x >= counts[k]) return;
-    const size_t i = (size_t)k * 256 + threadIdx.x;
-    const float4 *src = (const float4 *)(seg + i);
-    float4 *dst = (float4 *)(dense + start[k] + threadIdx.x);
-    float4 c = src[2];
-    c.w = __uint_as_float((uint32_t)i);                     // where the hit record goes
-    dst[0] = src[0]; dst[1] = src[1]; dst[2] = c;
-}
+// config 5.  Here a lane that finishes its ray takes the next one: persistent wavefronts draw whole tile
+// segments from one counter (one atomic per tile, no other atomics) and hand the segment's rays to their idle
+// lanes; every round a lane does a bounded number of tree steps or of voxel steps (the voxel walk is resumable),
+// so a short ray never waits for a long one.  Which lane traces a ray never changes the ray's result.
+// Used for the continuation (bounce / mirror) rays.  The shadow rays of the light loop were tried the same way
+// (one ray per (light record, light), contributions applied in light order afterwards): no gain - they all aim
+// at the same light, their lengths are alike, and k_wf_lights already keeps 53 % of its lanes busy.
 #define YCGE_ROUND_TREE_STEPS 3
 #define YCGE_ROUND_CELL_STEPS 8
 template <bool COUNT, bool HAS_GRID>
-__global__ __launch_bounds__(64) void k_wf_extend_p(const SceneDev S, const TraceOut O, const QEntry *__restrict__ dense,
-                                                    const uint32_t *__restrict__ n_total, uint32_t *__restrict__ chunk_ctr, HitRec *__restrict__ hit,
-                                                    int round_tree_steps, int round_cell_steps)
+__global__ __launch_bounds__(64) void k_wf_trace_p(const SceneDev S, const FrameParams P, const TraceOut O, const WfBuffers B, int round,
+                                                   uint32_t *__restrict__ chunk_ctr, int round_tree_steps, int round_cell_steps)
 {
     Work w = {0, 0, 0, 0, 0, 0};
     StackT<64> st;
     st.init(O.stack_spill, O.stack_lanes);
-    const uint32_t N = *n_total;
     const int lane = (int)threadIdx.x;
-    bool have = false, more = false;
+    const uint32_t *counts = B.n_q + (size_t)round * B.tiles;
+    const QEntry *Q = B.q[round & 1];
+    const float tmin = 0.001f;
+    bool have = false, more = false, in_dda = false;
     uint32_t src = 0, cur = YCGE_REF_NONE_VALUE;
     F3 o = f3(0, 0, 0), d = f3(0, 0, 1), inv = f3(0, 0, 0);
     bool sx = false, sy = false, sz = false;
     float closest = YCGE_FLT_MAX;
     int hit_prim = -1, hit_sub = 0, mesh_prim = -1;
-    uint32_t chunk_next = 0, chunk_end = 0;                 // wave-uniform
-    bool exhausted = false;
-    bool in_dda = false;
     DdaState D;
     D.ix = D.iy = D.iz = 0; D.t = D.t_max_x = D.t_max_y = D.t_max_z = D.t_delta_x = D.t_delta_y = D.t_delta_z = D.t_exit = D.tmax = 0.0f;
     D.packed = 0; D.nx = D.ny = D.nz = 1; D.cell_offset = D.mask_lo = D.mask_hi = 0; D.prim = -1;
+    uint32_t tile = 0, next_ray = 0, end_ray = 0;          // wave-uniform: the segment being handed out
+    bool exhausted = false;
     for (;;) {
         // ---- hand new rays to the idle lanes
         unsigned long long idle = __ballot(!have);
         while (idle && !exhausted) {
-            if (chunk_next == chunk_end) {
+            if (next_ray == end_ray) {
                 uint32_t c = 0;
                 if (lane == 0) c = atomicAdd(chunk_ctr, 1u);
                 c = (uint32_t)__builtin_amdgcn_readfirstlane((int)c);
-                if ((unsigned long long)c * 256ull >= N) { exhausted = true; break; }
-                chunk_next = c * 256u;
-                chunk_end = chunk_next + 256u < N ? chunk_next + 256u : N;
+                if (c >= B.tiles) { exhausted = true; break; }
+                tile = B.tile_order ? B.tile_order[c] : c;
+                next_ray = 0;
+                end_ray = counts[tile];
+                continue;
             }
-            const uint32_t avail = chunk_end - chunk_next, n_idle = (uint32_t)__popcll(idle);
+            const uint32_t avail = end_ray - next_ray, n_idle = (uint32_t)__popcll(idle);
             const uint32_t take = avail < n_idle ? avail : n_idle;
             const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(idle >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)idle, 0u));
             if (!have && rank < take) {
-                const float4 *q = (const float4 *)(dense + chunk_next + rank);
-                const float4 a = q[0], b = q[1], c = q[2];
+                src = tile * 256u + next_ray + rank;
+                const float4 *q = (const float4 *)(Q + src);
+                const float4 a = q[0], b = q[1];
                 o = f3(a.x, a.y, a.z); d = f3(a.w, b.x, b.y);
-                src = __float_as_uint(c.w);
                 // traverse(): Scene.Hit(r, 0.001f, float.MaxValue)
                 closest = YCGE_FLT_MAX; hit_prim = -1; hit_sub = 0; mesh_prim = -1;
                 st.reset();
@@ -296,33 +266,34 @@ __global__ __launch_bounds__(64) void k_wf_extend_p(const SceneDev S, const Trac
                     float tn;
                     if (COUNT) w.box++;
                     if (box_scene(S.scene_root_min[0], S.scene_root_min[1], S.scene_root_min[2], S.scene_root_max[0], S.scene_root_max[1],
-                                  S.scene_root_max[2], o, inv, 0.001f, closest, tn))
+                                  S.scene_root_max[2], o, inv, tmin, closest, tn))
                         cur = S.scene_root_ref;
                 }
                 more = cur != YCGE_REF_NONE_VALUE;
+                in_dda = false;
                 have = true;
             }
-            chunk_next += take;
+            next_ray += take;
             idle = __ballot(!have);
         }
         if (!__any(have)) break;
-        // ---- one round: a bounded number of tree steps for the lanes in the tree, then a bounded number of cell steps
-        // for the lanes inside a grid (their state persists in D); lanes that finish are refilled at the top
+        // ---- one round: a bounded number of tree steps for the lanes in the tree, then a bounded number of cell
+        // steps for the lanes inside a grid (their state persists in D); lanes that finish are refilled at the top
         if (have && more && !in_dda) {
             int parked_grid = -1, parked_prim = -1;
-            const int r = tree_phase<COUNT, HAS_GRID>(S, cur, mesh_prim, st, o, d, inv, sx, sy, sz, 0.001f, closest, hit_prim, hit_sub, parked_grid,
+            const int r = tree_phase<COUNT, HAS_GRID>(S, cur, mesh_prim, st, o, d, inv, sx, sy, sz, tmin, closest, hit_prim, hit_sub, parked_grid,
                                                       parked_prim, w, round_tree_steps);
             if (r == TREE_DONE) more = false;
-            if (HAS_GRID && r == TREE_AT_GRID) in_dda = dda_begin<COUNT>(S, parked_grid, parked_prim, o, d, inv, 0.001f, closest, D, w);
+            if (HAS_GRID && r == TREE_AT_GRID) in_dda = dda_begin<COUNT>(S, parked_grid, parked_prim, o, d, inv, tmin, closest, D, w);
         }
         if (HAS_GRID && in_dda) {
             bool in = true;
 #pragma unroll 1
-            for (int k2 = 0; k2 < round_cell_steps && in; k2++) in = dda_step<COUNT>(S, D, 0.001f, closest, hit_prim, hit_sub, w);
+            for (int k2 = 0; k2 < round_cell_steps && in; k2++) in = dda_step<COUNT>(S, D, tmin, closest, hit_prim, hit_sub, w);
             in_dda = in;
         }
         if (have && !more && !in_dda) {
-            *(float4 *)(hit + src) = make_float4(closest, __int_as_float(hit_prim), __int_as_float(hit_sub), 0.0f);
+            *(float4 *)(B.hit + src) = make_float4(closest, __int_as_float(hit_prim), __int_as_float(hit_sub), 0.0f);
             have = false;
         }
     }
@@ -1061,7 +1032,7 @@ int ycge_launch_trace(const ycge::SceneDev *S, const ycge::FrameParams *P, const
 
 // wavefront path.  bufs = {q0, q1, hit, lq, n_q, n_lq}: queues segmented per owned tile (256 entries each),
 // n_q = (rounds + 1) x tiles counts, n_lq = tiles counts.  Every stage is one workgroup per tile.
-int ycge_launch_wavefront(const ycge::SceneDev *S, const ycge::FrameParams *P, const ycge::TraceOut *O, void *const bufs[9], int rounds,
+int ycge_launch_wavefront(const ycge::SceneDev *S, const ycge::FrameParams *P, const ycge::TraceOut *O, void *const bufs[7], int rounds,
                           int has_grid, int flat, int count, int persistent_waves, hipStream_t stream)
 {
     using namespace ycge;
@@ -1069,7 +1040,7 @@ int ycge_launch_wavefront(const ycge::SceneDev *S, const ycge::FrameParams *P, c
     WfBuffers B;
     B.q[0] = (QEntry *)bufs[0]; B.q[1] = (QEntry *)bufs[1]; B.hit = (HitRec *)bufs[2]; B.lq = (LEntry *)bufs[3];
     B.n_q = (uint32_t *)bufs[4]; B.n_lq = (uint32_t *)bufs[5];
-    B.dense = (QEntry *)bufs[6]; B.seg_start = (uint32_t *)bufs[7]; B.chunk_ctr = (uint32_t *)bufs[8];
+    B.chunk_ctr = (uint32_t *)bufs[6];
     B.tiles = (uint32_t)P->n_owned_tiles;
     B.tile_order = P->tile_order;
     const dim3 block(256), tiles((unsigned)P->n_owned_tiles);
@@ -1082,13 +1053,12 @@ int ycge_launch_wavefront(const ycge::SceneDev *S, const ycge::FrameParams *P, c
         hipLaunchKernelGGL((k_wf_primary<decltype(C)::value, decltype(G)::value, decltype(F)::value>), tiles, block, 0, stream, *S, *P, *O, B);
     });
     for (int r = 0; r < rounds; r++) {
-        if (r > 0 && !flat && persistent_waves > 0) {
-            // gather the round's rays into one list, then trace them with ray refill (see k_wf_extend_p)
-            hipLaunchKernelGGL(k_wf_scan, dim3(1), dim3(1024), 0, stream, B.n_q + (size_t)r * B.tiles, B.tiles, B.seg_start, B.chunk_ctr);
-            hipLaunchKernelGGL(k_wf_gather, tiles, block, 0, stream, B.q[r & 1], B.n_q + (size_t)r * B.tiles, B.seg_start, B.dense);
+        const bool persistent = !flat && persistent_waves > 0;
+        if (r > 0 && persistent) {
+            (void)hipMemsetAsync(B.chunk_ctr, 0, sizeof(uint32_t), stream);
             sel3(count != 0, has_grid != 0, false, [&](auto C, auto G, auto) {
-                hipLaunchKernelGGL((k_wf_extend_p<decltype(C)::value, decltype(G)::value>), dim3((unsigned)persistent_waves), dim3(64), 0, stream, *S, *O,
-                                   B.dense, B.seg_start + B.tiles, B.chunk_ctr, B.hit, round_steps[0], round_steps[1]);
+                hipLaunchKernelGGL((k_wf_trace_p<decltype(C)::value, decltype(G)::value>), dim3((unsigned)persistent_waves), dim3(64), 0, stream,
+                                   *S, *P, *O, B, r, B.chunk_ctr, round_steps[0], round_steps[1]);
             });
         } else if (r > 0)
             sel3(count != 0, has_grid != 0, flat != 0, [&](auto C, auto G, auto F) {
