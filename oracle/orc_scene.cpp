@@ -868,7 +868,7 @@ bool SceneData::hit(const Ray &r, float t_min, float t_max, Hit &rec, Counters &
     struct QueryLog {       /* analysis aid only */
         Counters &c; uint64_t b0, t0;
         explicit QueryLog(Counters &cc) : c(cc), b0(cc.box), t0(cc.tri) {}
-        ~QueryLog() { if (c.qlog && c.qn < c.qcap) c.qlog[c.qn++] = (uint32_t)((c.box - b0) / 2 + (c.tri - t0)); }
+        ~QueryLog() { if (c.qlog && c.qn < c.qcap) c.qlog[c.qn++] = (uint32_t)((c.box - b0) / 2 + (c.tri - t0)) | ((uint32_t)(c.tri - t0) << 16);   /* steps | triangle tests << 16 */ }
     } query_log(cnt);
     cnt.rays++;
     if (root < 0) return false;

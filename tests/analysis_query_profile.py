@@ -13,11 +13,12 @@ n=o.hiW*o.hiH
 q=np.zeros((n,8),np.uint32)
 o.L.orc_query_profile.restype=C.c_int; o.L.orc_query_profile.argtypes=[C.c_void_p,C.c_void_p,C.c_int]
 t=time.time(); print(o.L.orc_query_profile(o.ctx,q.ctypes.data,8), time.time()-t)
+tri=q>>16; q=q&0xffff
 np.save('/tmp/ycge_query_profile.npy',q)
 tot=q.sum(1).astype(np.int64)
 print('per-pixel total steps: max',tot.max(),'p99.9',np.percentile(tot,99.9))
 idx=np.argsort(-tot)[:12]
-for i in idx: print(i%o.hiW,i//o.hiW,tot[i],q[i])
+for i in idx: print(i%o.hiW,i//o.hiW,tot[i],q[i],'triangle tests',tri[i])
 # ray-parallel chain: P + max(S1,S2, B + max(S1',S2'))
 P=q[:,0]; S1=q[:,1]; S2=q[:,2]; B=q[:,3]; S1b=q[:,4]; S2b=q[:,5]
 par=P+np.maximum(np.maximum(S1,S2),B+np.maximum(S1b,S2b))
@@ -27,3 +28,8 @@ def blockmax(a): return a.reshape(H//8,8,W//8,8).max(axis=(1,3))
 # megakernel wave model: sum over query slots of per-block max
 mk=sum(blockmax(q[:,k].astype(np.int64)) for k in range(8))
 print('wave model (sum over queries of block max): max',mk.max(), ' per-pixel-sum block max',blockmax(tot).max())
+
+# what two triangles per step would give: a leaf of n triangles costs ceil(n/2) steps; bound by halving the triangle steps
+q2=(q-tri)+(tri+1)//2
+mk2=sum(blockmax(q2[:,k].astype(np.int64)) for k in range(8))
+print('wave model with 2 triangles per step: max',mk2.max(),'(now',mk.max(),')')
