@@ -256,3 +256,28 @@ def test_post_stage_odd_size_and_supersampling(product_lib, oracle, path):
     sc5, w5, h5, ss5, pose5 = scenes.config_scene(5, small=True)
     for f, (taa, den, expo, sdr, sdr_rms, post_ms) in enumerate(_post_pair(oracle, sc5, 96, 27, 2, pose5, frames=2)):
         assert taa == 0 and den == 0 and not expo and sdr == 0
+
+
+def test_voxel_world_full_size(product_lib, oracle, path):
+    """BASELINE config 5 at its full size: 544x256x544 voxels in 32^3 chunk grids, 3840x2160 trace grid (1080p, ss 2).
+    Exercises the persistent extend stage (ray refill) and the HBM part of the traversal stacks at scale."""
+    sc, w, h, ss, pose = scenes.config_scene(5)
+    o, g = pu.run_pair(oracle, sc, w, h, ss, pose, frames=1, oracle_threads=64)
+    _assert_parity(pu.compare_frame(o, g), "cfg5 3840x2160")
+    o.close(); g.close()
+
+
+def test_no_lights_and_single_object(product_lib, oracle, path):
+    """degenerate inputs: a scene without lights (no light records are queued) and a one-object scene (BVH = one leaf)"""
+    s = _zoo_scene(False)
+    s.Lights.clear()
+    pose = dict(pos=(0.0, 1.2, 1.5), yaw=0.0, pitch=-0.1, fov=60.0)
+    o, g = pu.run_pair(oracle, s, 96, 27, 1, pose, frames=2)
+    _assert_parity(pu.compare_frame(o, g), "no lights")
+    o.close(); g.close()
+    one = Scene()
+    one.Add(Sphere(vec3(0.0, 1.0, -3.0), 1.0, Solid(vec3(0.7, 0.3, 0.3))))
+    one.Lights.append(PointLight(vec3(2.0, 4.0, 0.0), vec3(1, 1, 1), 40.0))
+    o, g = pu.run_pair(oracle, one, 33, 17, 1, dict(pos=(0.0, 1.0, 0.0), yaw=0.0, pitch=0.0, fov=45.0), frames=2)
+    _assert_parity(pu.compare_frame(o, g), "one sphere, odd size")
+    o.close(); g.close()
