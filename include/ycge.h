@@ -256,6 +256,12 @@ int ycge_scene_update_lights(ycge_ctx *ctx, const ycge_light *lights, int32_t n_
                              const ycge_vec3 *ambient_color, float ambient_intensity,
                              const ycge_vec3 *background_top, const ycge_vec3 *background_bottom);
 
+/* Scene.Update() -> RebuildBVH() after an entity moved its geometry (Scenes/Scene.cs:122-127; e.g.
+ * BobbingSphereEntity.Update, Scenes/TestScenesRandom.cs:708-714): replaces the Scene.Objects records and
+ * rebuilds the scene-level BVH only.  `prims` index the materials, meshes and grids of the last
+ * ycge_scene_upload (a Mesh keeps its own BVH in the reference too, Mesh.cs:14). */
+int ycge_scene_update_objects(ycge_ctx *ctx, const ycge_prim *prims, int32_t n_prims);
+
 /* Resize(fb, ss)   RaytraceEntity.cs:289; drops TAA history (RaytraceRenderer.cs:137) */
 int ycge_resize(ycge_ctx *ctx, int32_t fb_width, int32_t fb_height, int32_t super_sample);
 /* SetCamera(pos,yaw,pitch) + SetFov(deg)   RaytraceEntity.cs:229,99 */

@@ -281,3 +281,25 @@ def test_no_lights_and_single_object(product_lib, oracle, path):
     o, g = pu.run_pair(oracle, one, 33, 17, 1, dict(pos=(0.0, 1.0, 0.0), yaw=0.0, pitch=0.0, fov=45.0), frames=2)
     _assert_parity(pu.compare_frame(o, g), "one sphere, odd size")
     o.close(); g.close()
+
+
+def test_update_objects_rebuilds_scene_bvh_only(product_lib, oracle, path):
+    """Entity animation (BobbingSphereEntity, TestScenesRandom.cs:708-714 -> Scene.RebuildBVH): the product takes new object
+    records through ycge_scene_update_objects, the oracle a full re-upload; frames (and TAA history) must stay identical."""
+    def build(dy):
+        s = _zoo_scene(False)
+        sph = [o for o in s.Objects if isinstance(o, Sphere)][0]
+        sph.Center = vec3(sph.Center[0], sph.Center[1] + dy, sph.Center[2])
+        return s
+    pose = dict(pos=(0.1, 1.2, 1.0), yaw=0.05, pitch=-0.12, fov=50.0)
+    o, g = pu.run_pair(oracle, build(0.0), 160, 45, 1, pose, frames=2)
+    keep = []
+    for step in (1, 2, 3):
+        moved = flatten(build(0.15 * step))
+        keep.append(moved)
+        assert o.L.orc_scene_upload(o.ctx, moved.byref()) == 0
+        g.UpdateObjects(moved)
+        o.render(stages=1, threads=8); g.TryFlipAndBlit()
+        _assert_parity(pu.compare_frame(o, g), f"objects moved, step {step}")
+    assert pu.bits_equal(o.accel(abi.ACCEL_SCENE_NODES), g.accel(abi.ACCEL_SCENE_NODES))
+    o.close(); g.close()

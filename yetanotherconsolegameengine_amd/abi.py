@@ -161,6 +161,7 @@ _PROTOTYPES = {
     "ycge_scene_upload": (C.c_int, [C.c_void_p, C.POINTER(Scene)]),
     "ycge_scene_update_lights": (C.c_int, [C.c_void_p, C.POINTER(Light), C.c_int32, C.POINTER(Vec3), C.c_float,
                                            C.POINTER(Vec3), C.POINTER(Vec3)]),
+    "ycge_scene_update_objects": (C.c_int, [C.c_void_p, C.POINTER(Prim), C.c_int32]),
     "ycge_resize": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.c_int32]),
     "ycge_set_camera": (C.c_int, [C.c_void_p, C.POINTER(C.c_float), C.c_float, C.c_float, C.c_float]),
     "ycge_render_frame": (C.c_int, [C.c_void_p, C.POINTER(C.c_float), C.POINTER(FrameStats)]),

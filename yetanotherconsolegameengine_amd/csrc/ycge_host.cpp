@@ -4,6 +4,7 @@
 // implementation of any per-pixel stage here.
 #include <hip/hip_runtime.h>
 
+#include <array>
 #include <chrono>
 #include <cmath>
 #include <cstdarg>
@@ -115,6 +116,11 @@ struct ycge_ctx {
     DevBuf<uint8_t> tone_state;                   // ToneMapper state; lives as long as the context (not reset by Resize)
     struct InplaceSchedule { int w = 0, h = 0, step = 0; DevBuf<uint32_t> pixels; std::vector<uint32_t> offsets; };
     std::vector<InplaceSchedule *> schedules;     // level schedules of the in-place A-trous iterations, by (w, h, step)
+    // what ycge_scene_update_objects needs from the last full upload
+    std::vector<GMesh> gmeshes_host;
+    std::vector<std::array<float, 6>> grid_bounds;   // VolumeGrid.TryGetBounds per grid; max < min marks an empty grid
+    int n_materials = 0, max_mesh_depth = 0;
+    bool materials_can_mirror = false;
     const float *denoised = nullptr;              // result of the last post stage (one of den_a / den_b / taa_hist)
     DevBuf<uint32_t> block_cost, block_order, order_ws;   // k_trace scheduling feedback (4 blocks of 8x8 px per tile)
     bool block_order_valid = false;
@@ -309,7 +315,7 @@ void fill_frame_params(ycge_ctx *c, FrameParams &P, int64_t frame, const float p
 }
 
 // Hittable.TryGetBounds of each primitive class (see the citations in include/ycge.h)
-bool prim_bounds(const ycge_prim &q, const std::vector<MeshHost> &meshes, const ycge_scene *s, float b[6], float cen[3])
+bool prim_bounds(const ycge_prim &q, const std::vector<MeshHost> &meshes, const std::vector<std::array<float, 6>> &grid_bounds, float b[6], float cen[3])
 {
     const float *p = q.p;
     const float eps = 1e-4f;
@@ -341,11 +347,9 @@ bool prim_bounds(const ycge_prim &q, const std::vector<MeshHost> &meshes, const 
         break;
     }
     case YCGE_PRIM_VOLUME_GRID: {
-        const ycge_grid &g = s->grids[q.ref];
-        if (g.nx <= 0 || g.ny <= 0 || g.nz <= 0) return false;
-        const float vs[3] = {cs_max(1e-6f, g.voxel_size.x), cs_max(1e-6f, g.voxel_size.y), cs_max(1e-6f, g.voxel_size.z)};
-        b[0] = g.min_corner.x; b[1] = g.min_corner.y; b[2] = g.min_corner.z;
-        b[3] = g.min_corner.x + (float)g.nx * vs[0]; b[4] = g.min_corner.y + (float)g.ny * vs[1]; b[5] = g.min_corner.z + (float)g.nz * vs[2];
+        const std::array<float, 6> &gb = grid_bounds[q.ref];
+        if (!(gb[3] >= gb[0])) return false;                 // empty grid (marked at upload)
+        for (int k = 0; k < 6; k++) b[k] = gb[k];
         break;
     }
     default: return false;
@@ -470,6 +474,108 @@ static int upload_lights(ycge_ctx *c, const ycge_light *lights, int n)
     return YCGE_OK;
 }
 
+}
+namespace {
+// Scene.Objects -> device object records + scene BVH (BVH ctor, BVH.cs:29-97), uploaded; meshes, grids and
+// materials are the ones of the last full upload.  Shared by ycge_scene_upload and ycge_scene_update_objects.
+int build_and_upload_objects(ycge_ctx *c, const ycge_prim *prims, int n_prims)
+{
+    std::vector<GPrim> gprims(n_prims);
+    BoundsSoA items;
+    items.resize(n_prims);
+    for (int i = 0; i < n_prims; i++) {
+        const ycge_prim &q = prims[i];
+        GPrim &g = gprims[i];
+        std::memset(&g, 0, sizeof g);
+        g.type = q.type; g.material = q.material; g.ref = q.ref; g.reflectivity = q.reflectivity;
+        const float *p = q.p;
+        switch (q.type) {
+        case YCGE_PRIM_SPHERE: for (int k = 0; k < 4; k++) g.p[k] = p[k]; break;
+        case YCGE_PRIM_PLANE: {      // Plane ctor, Surfaces.cs:19-28
+            H3 n = h_norm(H3{p[3], p[4], p[5]});
+            g.p[0] = n.x; g.p[1] = n.y; g.p[2] = n.z;
+            g.p[3] = n.x * p[0] + n.y * p[1] + n.z * p[2];
+            break;
+        }
+        case YCGE_PRIM_DISK: {       // Disk ctor, Surfaces.cs:84-94
+            H3 n = h_norm(H3{p[3], p[4], p[5]});
+            g.p[0] = p[0]; g.p[1] = p[1]; g.p[2] = p[2]; g.p[3] = n.x; g.p[4] = n.y; g.p[5] = n.z;
+            g.p[6] = p[6] * p[6];
+            g.p[7] = n.x * p[0] + n.y * p[1] + n.z * p[2];
+            break;
+        }
+        case YCGE_PRIM_XYRECT: case YCGE_PRIM_XZRECT: case YCGE_PRIM_YZRECT: for (int k = 0; k < 5; k++) g.p[k] = p[k]; break;
+        case YCGE_PRIM_BOX: for (int k = 0; k < 6; k++) g.p[k] = p[k]; break;
+        case YCGE_PRIM_CYLINDER_Y:   // CylinderY ctor, BoundedObjects.cs:128-137
+            g.p[0] = p[0]; g.p[1] = p[2]; g.p[2] = p[3]; g.p[3] = p[3] * p[3];
+            g.p[4] = cs_min(p[4], p[5]); g.p[5] = cs_max(p[4], p[5]); g.p[6] = p[6];
+            break;
+        case YCGE_PRIM_TRIANGLE: {   // Triangle ctor, Triangle.cs:36-45
+            float e1x = p[3] - p[0], e1y = p[4] - p[1], e1z = p[5] - p[2];
+            float e2x = p[6] - p[0], e2y = p[7] - p[1], e2z = p[8] - p[2];
+            float nnx = e1y * e2z - e1z * e2y, nny = e1z * e2x - e1x * e2z, nnz = e1x * e2y - e1y * e2x;
+            float inv_len = 1.0f / cs_max(1e-20f, cs_sqrt(nnx * nnx + nny * nny + nnz * nnz));
+            g.p[0] = p[0]; g.p[1] = p[1]; g.p[2] = p[2];
+            g.p[3] = e1x; g.p[4] = e1y; g.p[5] = e1z; g.p[6] = e2x; g.p[7] = e2y; g.p[8] = e2z;
+            g.p[9] = nnx * inv_len; g.p[10] = nny * inv_len; g.p[11] = nnz * inv_len;
+            break;
+        }
+        case YCGE_PRIM_MESH: {      // root box + root reference ride in the object record (one fetch less per query)
+            if (q.ref < 0 || q.ref >= (int)c->gmeshes_host.size()) return c->fail(YCGE_ERR_INVALID_ARG, "prim %d: mesh ref out of range", i);
+            const GMesh &gm = c->gmeshes_host[q.ref];
+            for (int a = 0; a < 3; a++) { g.p[a] = gm.root_min[a]; g.p[3 + a] = gm.root_max[a]; }
+            g.p[6] = u2f(gm.root_ref);
+            break;
+        }
+        case YCGE_PRIM_VOLUME_GRID:
+            if (q.ref < 0 || q.ref >= (int)c->grid_bounds.size()) return c->fail(YCGE_ERR_INVALID_ARG, "prim %d: grid ref out of range", i);
+            break;
+        default: return c->fail(YCGE_ERR_INVALID_ARG, "prim %d: unknown type %d", i, q.type);
+        }
+        if (q.type != YCGE_PRIM_MESH && q.type != YCGE_PRIM_VOLUME_GRID && !(q.material >= 0 && q.material < c->n_materials))
+            return c->fail(YCGE_ERR_INVALID_ARG, "prim %d: material out of range", i);
+        float b[6], cen[3];
+        if (!prim_bounds(q, c->meshes, c->grid_bounds, b, cen)) return c->fail(YCGE_ERR_INVALID_ARG, "Unbounded Hittable (prim %d)", i);   // BVH.cs:37-40
+        for (int a = 0; a < 3; a++) { items.mn[a][i] = b[a]; items.mx[a][i] = b[3 + a]; items.c[a][i] = cen[a]; }
+    }
+    // can any surface take the mirror branch (Reflectivity >= MirrorThreshold, RaytraceRenderer.cs:559)?
+    bool can_mirror = c->materials_can_mirror;
+    for (int i = 0; i < n_prims; i++) {
+        const int ty = prims[i].type;
+        const bool overrides = ty == YCGE_PRIM_PLANE || ty == YCGE_PRIM_DISK || ty == YCGE_PRIM_XYRECT || ty == YCGE_PRIM_XZRECT || ty == YCGE_PRIM_YZRECT || ty == YCGE_PRIM_BOX;
+        if (overrides && prims[i].reflectivity >= c->cfg.mirror_threshold) can_mirror = true;
+    }
+    c->wf_rounds = can_mirror ? 2 + c->cfg.max_mirror_bounces : 2;
+    build_tree(items, TreeFlavour::Scene, c->scene_tree);
+    if (c->scene_tree.max_depth > 128) return c->fail(YCGE_ERR_STACK_DEPTH, "scene BVH depth %d exceeds the reference's 128-entry stack (BVH.cs:118)", c->scene_tree.max_depth);
+    if (c->scene_tree.max_depth + 4 + c->max_mesh_depth + 2 > YCGE_TRAVERSAL_STACK)
+        return c->fail(YCGE_ERR_STACK_DEPTH, "combined traversal depth %d + %d exceeds the device stack", c->scene_tree.max_depth, c->max_mesh_depth);
+    {   // levels the per-lane stack can need beyond its LDS part: scene depth + 4 leaf objects + deepest mesh
+        const int need = c->scene_tree.max_depth + 4 + c->max_mesh_depth + 2 - 12;
+        const int levels = need > 0 ? need : 0;
+        if (levels != c->spill_levels) {
+            c->spill_levels = levels;
+            int rc2 = alloc_tile_buffers(c);
+            if (rc2 != YCGE_OK) return rc2;
+        }
+    }
+    std::vector<GNode> scene_nodes;
+    const uint32_t scene_root = to_gpu_nodes(c->scene_tree, REF_SCENE_NODE, REF_SCENE_LEAF, 0, 0, 3, scene_nodes);
+    std::vector<uint32_t> leaf_prims(c->scene_tree.leaf_index.begin(), c->scene_tree.leaf_index.end());
+
+    HIP_TRY(c, c->d_prims.upload(gprims)); HIP_TRY(c, c->d_scene_nodes.upload(scene_nodes)); HIP_TRY(c, c->d_scene_leaf.upload(leaf_prims));
+    SceneDev &sd = c->sd;
+    sd.scene_nodes = c->d_scene_nodes.p; sd.scene_leaf_prims = c->d_scene_leaf.p; sd.prims = c->d_prims.p;
+    sd.scene_root_ref = scene_root;
+    for (int a = 0; a < 3; a++) { sd.scene_root_min[a] = sd.scene_root_max[a] = 0.0f; }
+    if (c->scene_tree.root >= 0)
+        for (int a = 0; a < 3; a++) { sd.scene_root_min[a] = c->scene_tree.nodes[c->scene_tree.root].mn[a]; sd.scene_root_max[a] = c->scene_tree.nodes[c->scene_tree.root].mx[a]; }
+    c->block_order_valid = false;
+    return YCGE_OK;
+}
+
+} // namespace
+extern "C" {
 int ycge_scene_upload(ycge_ctx *c, const ycge_scene *s)
 {
     if (!c) return YCGE_ERR_INVALID_ARG;
@@ -591,105 +697,35 @@ int ycge_scene_upload(ycge_ctx *c, const ycge_scene *s)
         G.brick_mask_lo = (uint32_t)brick_mask; G.brick_mask_hi = (uint32_t)(brick_mask >> 32);
     }
 
-    // ---- Scene.Objects -> device prim records + scene BVH (BVH ctor, BVH.cs:29-97)
-    std::vector<GPrim> gprims(s->n_prims);
-    BoundsSoA items;
-    items.resize(s->n_prims);
-    for (int i = 0; i < s->n_prims; i++) {
-        const ycge_prim &q = s->prims[i];
-        GPrim &g = gprims[i];
-        std::memset(&g, 0, sizeof g);
-        g.type = q.type; g.material = q.material; g.ref = q.ref; g.reflectivity = q.reflectivity;
-        const float *p = q.p;
-        switch (q.type) {
-        case YCGE_PRIM_SPHERE: for (int k = 0; k < 4; k++) g.p[k] = p[k]; break;
-        case YCGE_PRIM_PLANE: {      // Plane ctor, Surfaces.cs:19-28
-            H3 n = h_norm(H3{p[3], p[4], p[5]});
-            g.p[0] = n.x; g.p[1] = n.y; g.p[2] = n.z;
-            g.p[3] = n.x * p[0] + n.y * p[1] + n.z * p[2];
-            break;
-        }
-        case YCGE_PRIM_DISK: {       // Disk ctor, Surfaces.cs:84-94
-            H3 n = h_norm(H3{p[3], p[4], p[5]});
-            g.p[0] = p[0]; g.p[1] = p[1]; g.p[2] = p[2]; g.p[3] = n.x; g.p[4] = n.y; g.p[5] = n.z;
-            g.p[6] = p[6] * p[6];
-            g.p[7] = n.x * p[0] + n.y * p[1] + n.z * p[2];
-            break;
-        }
-        case YCGE_PRIM_XYRECT: case YCGE_PRIM_XZRECT: case YCGE_PRIM_YZRECT: for (int k = 0; k < 5; k++) g.p[k] = p[k]; break;
-        case YCGE_PRIM_BOX: for (int k = 0; k < 6; k++) g.p[k] = p[k]; break;
-        case YCGE_PRIM_CYLINDER_Y:   // CylinderY ctor, BoundedObjects.cs:128-137
-            g.p[0] = p[0]; g.p[1] = p[2]; g.p[2] = p[3]; g.p[3] = p[3] * p[3];
-            g.p[4] = cs_min(p[4], p[5]); g.p[5] = cs_max(p[4], p[5]); g.p[6] = p[6];
-            break;
-        case YCGE_PRIM_TRIANGLE: {   // Triangle ctor, Triangle.cs:36-45
-            float e1x = p[3] - p[0], e1y = p[4] - p[1], e1z = p[5] - p[2];
-            float e2x = p[6] - p[0], e2y = p[7] - p[1], e2z = p[8] - p[2];
-            float nnx = e1y * e2z - e1z * e2y, nny = e1z * e2x - e1x * e2z, nnz = e1x * e2y - e1y * e2x;
-            float inv_len = 1.0f / cs_max(1e-20f, cs_sqrt(nnx * nnx + nny * nny + nnz * nnz));
-            g.p[0] = p[0]; g.p[1] = p[1]; g.p[2] = p[2];
-            g.p[3] = e1x; g.p[4] = e1y; g.p[5] = e1z; g.p[6] = e2x; g.p[7] = e2y; g.p[8] = e2z;
-            g.p[9] = nnx * inv_len; g.p[10] = nny * inv_len; g.p[11] = nnz * inv_len;
-            break;
-        }
-        case YCGE_PRIM_MESH: {      // root box + root reference ride in the object record (one fetch less per query)
-            if (q.ref < 0 || q.ref >= s->n_meshes) return c->fail(YCGE_ERR_INVALID_ARG, "prim %d: mesh ref out of range", i);
-            const GMesh &gm = gmeshes[q.ref];
-            for (int a = 0; a < 3; a++) { g.p[a] = gm.root_min[a]; g.p[3 + a] = gm.root_max[a]; }
-            g.p[6] = u2f(gm.root_ref);
-            break;
-        }
-        case YCGE_PRIM_VOLUME_GRID:
-            if (q.ref < 0 || q.ref >= s->n_grids) return c->fail(YCGE_ERR_INVALID_ARG, "prim %d: grid ref out of range", i);
-            break;
-        default: return c->fail(YCGE_ERR_INVALID_ARG, "prim %d: unknown type %d", i, q.type);
-        }
-        if (q.type != YCGE_PRIM_MESH && q.type != YCGE_PRIM_VOLUME_GRID && !mat_ok(q.material))
-            return c->fail(YCGE_ERR_INVALID_ARG, "prim %d: material out of range", i);
-        float b[6], cen[3];
-        if (!prim_bounds(q, c->meshes, s, b, cen)) return c->fail(YCGE_ERR_INVALID_ARG, "Unbounded Hittable (prim %d)", i);   // BVH.cs:37-40
-        for (int a = 0; a < 3; a++) { items.mn[a][i] = b[a]; items.mx[a][i] = b[3 + a]; items.c[a][i] = cen[a]; }
+    // ---- what the object / scene-BVH step needs (kept for ycge_scene_update_objects)
+    c->gmeshes_host = gmeshes;
+    c->n_materials = s->n_materials;
+    c->max_mesh_depth = max_mesh_depth;
+    c->materials_can_mirror = false;
+    for (int i = 0; i < s->n_materials; i++) if (s->materials[i].reflectivity >= c->cfg.mirror_threshold) c->materials_can_mirror = true;
+    c->grid_bounds.assign(s->n_grids, std::array<float, 6>{{0, 0, 0, -1, -1, -1}});
+    for (int gi = 0; gi < s->n_grids; gi++) {                // VolumeGrid.TryGetBounds, VolumeGrid.cs:95-97
+        const ycge_grid &g = s->grids[gi];
+        if (g.nx <= 0 || g.ny <= 0 || g.nz <= 0) continue;
+        const float vs[3] = {cs_max(1e-6f, g.voxel_size.x), cs_max(1e-6f, g.voxel_size.y), cs_max(1e-6f, g.voxel_size.z)};
+        c->grid_bounds[gi] = {{g.min_corner.x, g.min_corner.y, g.min_corner.z, g.min_corner.x + (float)g.nx * vs[0],
+                               g.min_corner.y + (float)g.ny * vs[1], g.min_corner.z + (float)g.nz * vs[2]}};
     }
-    // can any surface take the mirror branch (Reflectivity >= MirrorThreshold, RaytraceRenderer.cs:559)?
-    bool can_mirror = false;
-    for (int i = 0; i < s->n_materials; i++) if (s->materials[i].reflectivity >= c->cfg.mirror_threshold) can_mirror = true;
-    for (int i = 0; i < s->n_prims; i++) {
-        const int ty = s->prims[i].type;
-        const bool overrides = ty == YCGE_PRIM_PLANE || ty == YCGE_PRIM_DISK || ty == YCGE_PRIM_XYRECT || ty == YCGE_PRIM_XZRECT || ty == YCGE_PRIM_YZRECT || ty == YCGE_PRIM_BOX;
-        if (overrides && s->prims[i].reflectivity >= c->cfg.mirror_threshold) can_mirror = true;
-    }
-    c->wf_rounds = can_mirror ? 2 + c->cfg.max_mirror_bounces : 2;
     c->has_grid = s->n_grids > 0;
-    build_tree(items, TreeFlavour::Scene, c->scene_tree);
-    if (c->scene_tree.max_depth > 128) return c->fail(YCGE_ERR_STACK_DEPTH, "scene BVH depth %d exceeds the reference's 128-entry stack (BVH.cs:118)", c->scene_tree.max_depth);
-    if (c->scene_tree.max_depth + 4 + max_mesh_depth + 2 > YCGE_TRAVERSAL_STACK)
-        return c->fail(YCGE_ERR_STACK_DEPTH, "combined traversal depth %d + %d exceeds the device stack", c->scene_tree.max_depth, max_mesh_depth);
-    {   // levels the per-lane stack can need beyond its LDS part: scene depth + 4 leaf objects + deepest mesh
-        const int need = c->scene_tree.max_depth + 4 + max_mesh_depth + 2 - 12;
-        const int levels = need > 0 ? need : 0;
-        if (levels != c->spill_levels) {
-            c->spill_levels = levels;
-            int rc2 = alloc_tile_buffers(c);
-            if (rc2 != YCGE_OK) return rc2;
-        }
-    }
-    std::vector<GNode> scene_nodes;
-    const uint32_t scene_root = to_gpu_nodes(c->scene_tree, REF_SCENE_NODE, REF_SCENE_LEAF, 0, 0, 3, scene_nodes);
-    std::vector<uint32_t> leaf_prims(c->scene_tree.leaf_index.begin(), c->scene_tree.leaf_index.end());
 
     // ---- upload
     HIP_TRY(c, c->d_materials.upload(mats)); HIP_TRY(c, c->d_mesh_nodes.upload(mesh_nodes)); HIP_TRY(c, c->d_tris.upload(tris));
     HIP_TRY(c, c->d_meshes.upload(gmeshes)); HIP_TRY(c, c->d_grids.upload(ggrids)); HIP_TRY(c, c->d_cells.upload(cells));
-    HIP_TRY(c, c->d_lut.upload(lut)); HIP_TRY(c, c->d_prims.upload(gprims)); HIP_TRY(c, c->d_scene_nodes.upload(scene_nodes));
-    HIP_TRY(c, c->d_scene_leaf.upload(leaf_prims));
+    HIP_TRY(c, c->d_lut.upload(lut));
     SceneDev &sd = c->sd;
     std::memset(&sd, 0, sizeof sd);
-    sd.scene_nodes = c->d_scene_nodes.p; sd.scene_leaf_prims = c->d_scene_leaf.p; sd.mesh_nodes = c->d_mesh_nodes.p; sd.tris = c->d_tris.p;
-    sd.prims = c->d_prims.p; sd.materials = c->d_materials.p; sd.meshes = c->d_meshes.p; sd.grids = c->d_grids.p;
+    sd.mesh_nodes = c->d_mesh_nodes.p; sd.tris = c->d_tris.p;
+    sd.materials = c->d_materials.p; sd.meshes = c->d_meshes.p; sd.grids = c->d_grids.p;
     sd.grid_cells = c->d_cells.p; sd.grid_lut = c->d_lut.p;
-    sd.scene_root_ref = scene_root;
-    if (c->scene_tree.root >= 0)
-        for (int a = 0; a < 3; a++) { sd.scene_root_min[a] = c->scene_tree.nodes[c->scene_tree.root].mn[a]; sd.scene_root_max[a] = c->scene_tree.nodes[c->scene_tree.root].mx[a]; }
+    {
+        const int rc_obj = build_and_upload_objects(c, s->prims, s->n_prims);
+        if (rc_obj != YCGE_OK) return rc_obj;
+    }
     sd.ambient[0] = s->ambient_color.x; sd.ambient[1] = s->ambient_color.y; sd.ambient[2] = s->ambient_color.z;
     sd.ambient_intensity = s->ambient_intensity;
     sd.bg_top[0] = s->background_top.x; sd.bg_top[1] = s->background_top.y; sd.bg_top[2] = s->background_top.z;
@@ -716,6 +752,23 @@ int ycge_scene_update_lights(ycge_ctx *c, const ycge_light *lights, int32_t n_li
     if (ambient_color) { c->sd.ambient[0] = ambient_color->x; c->sd.ambient[1] = ambient_color->y; c->sd.ambient[2] = ambient_color->z; c->sd.ambient_intensity = ambient_intensity; }
     if (top) { c->sd.bg_top[0] = top->x; c->sd.bg_top[1] = top->y; c->sd.bg_top[2] = top->z; }
     if (bottom) { c->sd.bg_bottom[0] = bottom->x; c->sd.bg_bottom[1] = bottom->y; c->sd.bg_bottom[2] = bottom->z; }
+    return YCGE_OK;
+}
+
+// Scene.Update -> RebuildBVH when an entity moved (Scenes/Scene.cs:122-127, e.g. BobbingSphereEntity,
+// TestScenesRandom.cs:708-714): new Scene.Objects records against the meshes, grids and materials of the last
+// ycge_scene_upload.  Only the scene-level BVH is rebuilt (as in the reference: a Mesh keeps its own BVH).
+int ycge_scene_update_objects(ycge_ctx *c, const ycge_prim *prims, int32_t n_prims)
+{
+    if (!c) return YCGE_ERR_INVALID_ARG;
+    if (!c->have_scene) return c->fail(YCGE_ERR_NO_SCENE, "no scene uploaded");
+    if (n_prims < 0 || (n_prims > 0 && !prims)) return c->fail(YCGE_ERR_INVALID_ARG, "bad object array");
+    HIP_TRY(c, hipSetDevice(c->device));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    c->have_scene = false;
+    const int rc = build_and_upload_objects(c, prims, n_prims);
+    if (rc != YCGE_OK) return rc;
+    c->have_scene = true;
     return YCGE_OK;
 }
 

@@ -85,6 +85,13 @@ class RaytraceRenderer:
             float(ambient.Intensity) if ambient is not None else 0.0,
             C.byref(top) if top is not None else None, C.byref(bot) if bot is not None else None))
 
+    def UpdateObjects(self, scene: Scene | FlatScene):
+        """Scene.Update() -> RebuildBVH() after entities moved (Scene.cs:122-127): same materials, meshes and grids
+        as the uploaded scene (in the same first-use order), new object records; only the scene BVH is rebuilt."""
+        f = scene if isinstance(scene, FlatScene) else flatten(scene)
+        self._check(self.L.ycge_scene_update_objects(self.ctx, C.cast(f.prims, C.POINTER(abi.Prim)), f.struct.n_prims))
+        self.flat = f
+
     def Resize(self, fb_width: int, fb_height: int, superSample: int):
         self._check(self.L.ycge_resize(self.ctx, fb_width, fb_height, superSample))
         self._set_dims(fb_width, fb_height, max(1, superSample))
