@@ -64,6 +64,7 @@ def main():
     ap.add_argument("--config", type=int, default=4)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
+    ap.add_argument("--post", action="store_true", help="also time a few frames WITH the denoise/exposure/tonemap stage (reported apart)")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -168,6 +169,16 @@ def main():
                 "frac": round(ach / HBM_PEAK_GBS, 5), "traffic": load_traffic_hint(args.config) if world == 1 else None,
                 "algorithmic_bytes_per_launch": int(my_alg), "mean_launch_ms": round(mean_trace_ms, 4)}
 
+    post = None
+    if args.post and world == 1:        # SURVEY 8-f1, outside the headline metric (SURVEY 8d times the frame through TAA)
+        ms = []
+        for _ in range(4):
+            r.TryFlipAndBlit(want_sdr=True)
+            ms.append((float(r.stats.trace_ms), float(r.stats.taa_ms), float(r.stats.post_ms), float(r.stats.total_ms)))
+        ms = np.array(ms[1:])            # the first frame builds the in-place level schedule
+        post = {"trace_ms": round(float(ms[:, 0].mean()), 4), "taa_ms": round(float(ms[:, 1].mean()), 4),
+                "post_ms": round(float(ms[:, 2].mean()), 4), "frame_ms_with_sdr_readback": round(float(ms[:, 3].mean()), 4)}
+
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         import oracle_binding as ob
@@ -204,6 +215,8 @@ def main():
         }
         if cpu:
             out["gpu_over_cpu"] = round(mrays / cpu["value"], 2)
+        if post:
+            out["post_stage"] = post
         print(json.dumps(out))
     r.close()
     if multi:
