@@ -265,6 +265,15 @@ def test_inplace_atrous_schedule_respects_scan_order(product_lib, w, h, step):
             later = q > p
             assert np.all(level[q[earlier]] < level[p[earlier]])
             assert np.all(level[q[later]] > level[p[later]])
+            # the banded pipeline of k_atrous_band: launch = band + level // K; a band runs its levels in order inside one
+            # workgroup, different bands only meet across kernel boundaries
+            for rows_per_band, K in ((16, 8), (4, 3)):
+                band = (np.arange(w * h) // w) // rows_per_band
+                launch = band + level // K
+                same = band[q] == band[p]
+                e_same, e_diff = earlier & same, earlier & ~same
+                assert np.all((launch[q[e_same]] < launch[p[e_same]]) | ((launch[q[e_same]] == launch[p[e_same]]) & (level[q[e_same]] < level[p[e_same]])))
+                assert np.all(launch[q[e_diff]] < launch[p[e_diff]])
 
 
 def test_vg01_world_file_roundtrip_and_errors(tmp_path):

@@ -33,8 +33,8 @@ int ycge_launch_unit_normals(const float *normal, float *unit, size_t n, hipStre
 int ycge_launch_atrous(int w, int h, int step, const float phi[4], const float *cur, float *dst, const float *albedo, const float *unit_n,
                        const float *depth, const uint8_t *sky, hipStream_t stream);
 int ycge_launch_atrous_inplace(int w, int h, int step, const float phi[4], float *buf, const float *albedo, const float *unit_n,
-                               const float *depth, const uint8_t *sky, const uint32_t *d_pixels, const uint32_t *h_offsets, int n_levels,
-                               hipStream_t stream);
+                               const float *depth, const uint8_t *sky, const uint32_t *d_pixels, const uint32_t *d_offsets, int n_levels,
+                               int n_bands, int K, hipStream_t stream);
 int ycge_launch_exposure(const float *hdr, const uint8_t *sky, int w, int h, int step, float *terms, void *state, const float consts[5],
                          hipStream_t stream);
 int ycge_launch_tonemap(const float *hdr, int hiW, int fbW, int fbH, int ss, float gamma, float saturation, float vibrance, const void *state,
@@ -114,7 +114,7 @@ struct ycge_ctx {
     // denoise / exposure / tonemap stage (ycge_post.hip), allocated on the first frame that asks for SDR output
     DevBuf<float> den_a, den_b, unit_n, exp_terms, d_sdr;
     DevBuf<uint8_t> tone_state;                   // ToneMapper state; lives as long as the context (not reset by Resize)
-    struct InplaceSchedule { int w = 0, h = 0, step = 0; DevBuf<uint32_t> pixels; std::vector<uint32_t> offsets; };
+    struct InplaceSchedule { int w = 0, h = 0, step = 0, levels = 0, bands = 0; DevBuf<uint32_t> pixels, offsets; };
     std::vector<InplaceSchedule *> schedules;     // level schedules of the in-place A-trous iterations, by (w, h, step)
     // what ycge_scene_update_objects needs from the last full upload
     std::vector<GMesh> gmeshes_host;
@@ -440,7 +440,7 @@ void ycge_destroy(ycge_ctx *c)
     c->dbg_rays.release(); c->dbg_hit_t.release(); c->dbg_prim.release(); c->dbg_sub.release(); c->dbg_rng.release();
     c->counters.release(); c->wave_prof.release(); c->own_slab.release();
     c->den_a.release(); c->den_b.release(); c->unit_n.release(); c->exp_terms.release(); c->d_sdr.release(); c->tone_state.release();
-    for (auto *sc : c->schedules) { sc->pixels.release(); delete sc; }
+    for (auto *sc : c->schedules) { sc->pixels.release(); sc->offsets.release(); delete sc; }
     c->schedules.clear();
     c->wf_q0.release(); c->wf_q1.release(); c->wf_hit.release(); c->wf_lq.release(); c->wf_seg.release(); c->wf_counts.release(); c->tile_order.release(); c->block_cost.release(); c->block_order.release(); c->order_ws.release(); c->stack_spill.release(); c->path_stack.release();
     c->d_scene_nodes.release(); c->d_mesh_nodes.release(); c->d_scene_leaf.release(); c->d_tris.release(); c->d_prims.release();
@@ -942,6 +942,32 @@ void build_inplace_schedule(int w, int h, int step, std::vector<uint32_t> &pixel
     for (size_t p = 0; p < n; p++) pixels[cursor[T[p] - 1]++] = (uint32_t)p;
 }
 
+// The level lists regrouped per band of `rows_per_band` image rows: band_pixels sorted by (band, level),
+// band_offsets[b * (levels + 1) + t] = start of level t (0-based) of band b.
+void band_inplace_schedule(int w, int h, int rows_per_band, const std::vector<uint32_t> &pixels, const std::vector<uint32_t> &offsets,
+                           std::vector<uint32_t> &band_pixels, std::vector<uint32_t> &band_offsets, int &n_bands)
+{
+    const int levels = (int)offsets.size() - 1;
+    n_bands = (h + rows_per_band - 1) / rows_per_band;
+    band_offsets.assign((size_t)n_bands * (levels + 1), 0);
+    std::vector<uint32_t> count((size_t)n_bands * levels, 0);
+    for (int t = 0; t < levels; t++)
+        for (uint32_t i = offsets[t]; i < offsets[t + 1]; i++) count[(size_t)((pixels[i] / (uint32_t)w) / rows_per_band) * levels + t]++;
+    uint32_t run = 0;
+    for (int b = 0; b < n_bands; b++) {
+        for (int t = 0; t < levels; t++) { band_offsets[(size_t)b * (levels + 1) + t] = run; run += count[(size_t)b * levels + t]; }
+        band_offsets[(size_t)b * (levels + 1) + levels] = run;
+    }
+    band_pixels.resize(pixels.size());
+    std::vector<uint32_t> cursor((size_t)n_bands * levels);
+    for (int b = 0; b < n_bands; b++) for (int t = 0; t < levels; t++) cursor[(size_t)b * levels + t] = band_offsets[(size_t)b * (levels + 1) + t];
+    for (int t = 0; t < levels; t++)
+        for (uint32_t i = offsets[t]; i < offsets[t + 1]; i++) {
+            const uint32_t p = pixels[i];
+            band_pixels[cursor[(size_t)((p / (uint32_t)w) / rows_per_band) * levels + t]++] = p;
+        }
+}
+
 int run_post(ycge_ctx *c, hipStream_t stream, float *out_sdr_host, bool timed)
 {
     const int w = c->hiW, h = c->hiH;
@@ -971,13 +997,18 @@ int run_post(ycge_ctx *c, hipStream_t stream, float *out_sdr_host, bool timed)
             if (!sc) {
                 sc = new ycge_ctx::InplaceSchedule();
                 sc->w = w; sc->h = h; sc->step = step;
-                std::vector<uint32_t> px;
-                build_inplace_schedule(w, h, step, px, sc->offsets);
+                std::vector<uint32_t> px, off, bpx, boff;
+                build_inplace_schedule(w, h, step, px, off);
+                // bands of whole rows; related pixels are at most 2 * step rows apart, so they share a band or sit in adjacent ones
+                const int rows_per_band = 2 * step > 16 ? 2 * step : 16;
+                band_inplace_schedule(w, h, rows_per_band, px, off, bpx, boff, sc->bands);
+                sc->levels = (int)off.size() - 1;
                 c->schedules.push_back(sc);
-                HIP_TRY(c, sc->pixels.upload(px));
+                HIP_TRY(c, sc->pixels.upload(bpx)); HIP_TRY(c, sc->offsets.upload(boff));
             }
+            static const int levels_per_launch = getenv("YCGE_POST_K") ? atoi(getenv("YCGE_POST_K")) : 8;
             e = ycge_launch_atrous_inplace(w, h, step, phi, dst, c->g_albedo.p, c->unit_n.p, c->g_depth.p, c->sky.p, sc->pixels.p,
-                                           sc->offsets.data(), (int)sc->offsets.size() - 1, stream);
+                                           sc->offsets.p, sc->levels, sc->bands, levels_per_launch > 0 ? levels_per_launch : 8, stream);
         } else {
             e = ycge_launch_atrous(w, h, step, phi, cur, dst, c->g_albedo.p, c->unit_n.p, c->g_depth.p, c->sky.p, stream);
         }

@@ -8,8 +8,8 @@
 //     iter 2 A->B), so a pixel sees the NEW values of the neighbours that precede it in scan order and the OLD
 //     values of those that follow.  That recurrence is evaluated exactly by levels: the host derives, from the
 //     stencil itself, the earliest level T(p) = 1 + max T(q) over every stencil-related pixel q that precedes p in
-//     scan order (ycge_post_build_schedule); pixels of one level never read or write each other, levels run as
-//     consecutive launches;
+//     scan order (build_inplace_schedule); pixels of one level never read or write each other.  Levels run in order
+//     inside a workgroup per band of rows, bands pipelined over consecutive launches (k_atrous_band);
 //   * the auto-exposure is a serial fp32 sum over the sampled pixels in scan order: the log terms are produced
 //     in parallel, the sum is one lane adding them one by one.
 #include <hip/hip_runtime.h>
@@ -44,23 +44,20 @@ __global__ __launch_bounds__(256) void k_unit_normals(const float *__restrict__ 
 
 struct Center { F3 c0, a0, n0; float z0; uint8_t sky0; };
 
-// one tap of the 5x5 stencil, :664-700.  Returns false for a tap the reference skips (`continue`).
-__device__ __forceinline__ bool atrous_tap(const AtrousParams &A, const float *cur, const float *albedo, const float *unit_n, const float *depth,
-                                           const uint8_t *sky, int x, int y, int kx, int ky, const Center &C, float &wght, F3 &c)
+// one tap of the 5x5 stencil, :664-700, in two halves so that callers can issue every load before any arithmetic
+__device__ __forceinline__ size_t atrous_tap_index(const AtrousParams &A, int x, int y, int kx, int ky)
 {
     int sy = y + ky * A.step;
     if (sy < 0) sy = 0; else if (sy >= A.h) sy = A.h - 1;
-    const float wy = kernel_tap(ky);
     int sx = x + kx * A.step;
     if (sx < 0) sx = 0; else if (sx >= A.w) sx = A.w - 1;
-    const size_t j = (size_t)sx + (size_t)sy * A.w;
-    if (sky[j] != C.sky0) return false;
+    return (size_t)sx + (size_t)sy * A.w;
+}
+__device__ __forceinline__ float atrous_tap_weight(const AtrousParams &A, int kx, int ky, const Center &C, F3 c, F3 a, F3 n, float z)
+{
+    const float wy = kernel_tap(ky);
     const float wx = kernel_tap(kx);
     const float w_base = wx * wy;
-    c = ld3(cur, j);
-    const F3 a = ld3(albedo, j);
-    const F3 n = ld3(unit_n, j);
-    const float z = depth[j];
     const float lum0 = luma3(C.c0);
     const float lum = luma3(c);
     const float dl = cs_abs(lum - lum0);
@@ -71,7 +68,16 @@ __device__ __forceinline__ bool atrous_tap(const AtrousParams &A, const float *c
     const float wn = m_exp(-dn / A.n_phi);
     const float wz = m_exp(-dz / A.z_phi);
     const float wa = m_exp(-(da) / A.a_phi);
-    wght = w_base * wc * wn * wz * wa;
+    return w_base * wc * wn * wz * wa;
+}
+// Returns false for a tap the reference skips (`continue`).
+__device__ __forceinline__ bool atrous_tap(const AtrousParams &A, const float *cur, const float *albedo, const float *unit_n, const float *depth,
+                                           const uint8_t *sky, int x, int y, int kx, int ky, const Center &C, float &wght, F3 &c)
+{
+    const size_t j = atrous_tap_index(A, x, y, kx, ky);
+    if (sky[j] != C.sky0) return false;
+    c = ld3(cur, j);
+    wght = atrous_tap_weight(A, kx, ky, C, c, ld3(albedo, j), ld3(unit_n, j), depth[j]);
     return true;
 }
 
@@ -106,53 +112,91 @@ __global__ __launch_bounds__(256) void k_atrous(const AtrousParams A, const floa
     }
 }
 
-// one LEVEL of an in-place iteration: `count` pixels that neither read nor write each other.  32 lanes per pixel:
-// lanes 0..24 evaluate one tap each; lanes 0..3 then add the 25 products of one component (x, y, z, weight) in tap order.
-__global__ __launch_bounds__(256) void k_atrous_level(const AtrousParams A, float *__restrict__ buf, const float *__restrict__ albedo,
-                                                      const float *__restrict__ unit_n, const float *__restrict__ depth,
-                                                      const uint8_t *__restrict__ sky, const uint32_t *__restrict__ pixels, uint32_t count)
+// One pixel of an in-place iteration by a 32-lane group: lanes 0..24 evaluate one tap each; lanes 0..3 then add the
+// 25 products of one component (x, y, z, weight) in tap order.  Called by every thread of the workgroup (barriers).
+#define YCGE_POST_GROUPS 32         // pixel groups per workgroup (1024 threads)
+struct PostShared {
+    float val[YCGE_POST_GROUPS][25][4];
+    uint32_t mask[YCGE_POST_GROUPS];
+    float sum[YCGE_POST_GROUPS][4];
+};
+__device__ __forceinline__ void atrous_pixel_group(const AtrousParams &A, float *buf, const float *albedo, const float *unit_n, const float *depth,
+                                                   const uint8_t *sky, bool live, uint32_t p, PostShared &sh)
 {
-    __shared__ float s_val[8][25][4];
-    __shared__ uint32_t s_mask[8];
-    __shared__ float s_sum[8][4];
     const int g = threadIdx.x >> 5, t = threadIdx.x & 31;
-    const uint32_t slot = blockIdx.x * 8u + (uint32_t)g;
-    const bool live = slot < count;
-    uint32_t p = 0;
+    // every load of the pixel - its own values and this lane's tap - is issued before anything is computed: inside a
+    // band the levels run back to back, and a level's time is its chain of dependent fetches
+    const int x = (int)(p % (uint32_t)A.w), y = (int)(p / (uint32_t)A.w);
+    const int kx = t % 5 - 2, ky = t / 5 - 2;
+    const size_t j = (live && t < 25) ? atrous_tap_index(A, x, y, kx, ky) : (size_t)p;
     Center C;
-    C.c0 = f3(0, 0, 0); C.a0 = f3(0, 0, 0); C.n0 = f3(0, 0, 0); C.z0 = 0.0f; C.sky0 = 1;
-    int x = 0, y = 0;
-    if (live) {
-        p = pixels[slot];
-        x = (int)(p % (uint32_t)A.w); y = (int)(p / (uint32_t)A.w);
-        C.sky0 = sky[p];
-        C.c0 = ld3(buf, p);
-        if (!C.sky0) { C.a0 = ld3(albedo, p); C.n0 = ld3(unit_n, p); C.z0 = depth[p]; }
-    }
+    C.sky0 = sky[p];
+    C.c0 = ld3(buf, p); C.a0 = ld3(albedo, p); C.n0 = ld3(unit_n, p); C.z0 = depth[p];
+    const uint8_t sky_j = sky[j];
+    const F3 cj = ld3(buf, j), aj = ld3(albedo, j), nj = ld3(unit_n, j);
+    const float zj = depth[j];
     const bool work = live && !C.sky0;          // sky pixel: dst[x, y] = cur[x, y] on the same buffer, nothing to do
-    bool valid = false;
-    if (work && t < 25) {
-        float wght; F3 c;
-        valid = atrous_tap(A, buf, albedo, unit_n, depth, sky, x, y, t % 5 - 2, t / 5 - 2, C, wght, c);
-        if (valid) { s_val[g][t][0] = c.x * wght; s_val[g][t][1] = c.y * wght; s_val[g][t][2] = c.z * wght; s_val[g][t][3] = wght; }
+    const bool valid = work && t < 25 && sky_j == C.sky0;
+    if (valid) {
+        const float wght = atrous_tap_weight(A, kx, ky, C, cj, aj, nj, zj);
+        sh.val[g][t][0] = cj.x * wght; sh.val[g][t][1] = cj.y * wght; sh.val[g][t][2] = cj.z * wght; sh.val[g][t][3] = wght;
     }
     const unsigned long long m = __ballot(valid);
-    if (t == 0) s_mask[g] = (uint32_t)(m >> ((threadIdx.x & 32) ? 32 : 0));
-    __syncthreads();            // every tap of the level has been read before any pixel of the level is written
-    if (work && t < 4) {
-        const uint32_t mask = s_mask[g];
+    if (t == 0) sh.mask[g] = (uint32_t)(m >> ((threadIdx.x & 32) ? 32 : 0));
+    __syncthreads();            // every tap of this batch has been read before any of its pixels is written
+    if (work && t < 4) {        // 25 LDS reads issued together, then the adds in tap order; a skipped tap leaves the sum untouched
+        const uint32_t mask = sh.mask[g];
+        float v[25];
+#pragma unroll
+        for (int k = 0; k < 25; k++) v[k] = sh.val[g][k][t];
         float acc = 0.0f;
-        for (int k = 0; k < 25; k++)
-            if ((mask >> k) & 1u) acc = acc + s_val[g][k][t];
-        s_sum[g][t] = acc;
+#pragma unroll
+        for (int k = 0; k < 25; k++) { const float nx = acc + v[k]; acc = ((mask >> k) & 1u) ? nx : acc; }
+        sh.sum[g][t] = acc;
     }
     __syncthreads();
     if (work && t == 0) {
-        const float wsum = s_sum[g][3];
+        const float wsum = sh.sum[g][3];
         if (wsum > 1e-8f) {
             const float inv = 1.0f / wsum;
-            st3(buf, p, f3(s_sum[g][0] * inv, s_sum[g][1] * inv, s_sum[g][2] * inv));
+            st3(buf, p, f3(sh.sum[g][0] * inv, sh.sum[g][1] * inv, sh.sum[g][2] * inv));
         }                                       // else dst = c0: unchanged
+    }
+}
+
+// In-place iteration, launch `launch`: the image is cut into bands of whole rows, one workgroup per band; band b runs
+// its levels [K * (launch - b), K * (launch - b) + K) one after the other (barrier + workgroup fence between levels).
+// Two stencil-related pixels are either in the same band (same workgroup: ordered by level) or in adjacent bands, and
+// then the one that comes first in scan order is in the upper band and has the smaller level, hence a strictly
+// smaller launch index band + level / K: kernel boundaries order them.  pixels / off: the level lists per band
+// (off[b * (levels + 1) + t] .. off[b * (levels + 1) + t + 1] = level t of band b).
+__global__ __launch_bounds__(1024) void k_atrous_band(const AtrousParams A, float *__restrict__ buf, const float *__restrict__ albedo,
+                                                      const float *__restrict__ unit_n, const float *__restrict__ depth,
+                                                      const uint8_t *__restrict__ sky, const uint32_t *__restrict__ pixels,
+                                                      const uint32_t *__restrict__ off, int levels, int K, int launch, int first_band)
+{
+    __shared__ PostShared sh;
+    const int b = first_band + (int)blockIdx.x;
+    const int g0 = launch - b;
+    if (g0 < 0) return;
+    const int t0 = g0 * K, t1 = t0 + K < levels ? t0 + K : levels;
+    const uint32_t *o = off + (size_t)b * (levels + 1);
+    const int grp = threadIdx.x >> 5;
+    // the pixel index of the next level's first batch is fetched while this level computes
+    uint32_t lo = o[t0], hi = t0 < t1 ? o[t0 + 1] : o[t0];
+    uint32_t p_first = lo + (uint32_t)grp < hi ? pixels[lo + (uint32_t)grp] : 0u;
+    for (int t = t0; t < t1; t++) {
+        const uint32_t nlo = hi, nhi = t + 1 < t1 ? o[t + 2] : hi;
+        const uint32_t p_next = (t + 1 < t1 && nlo + (uint32_t)grp < nhi) ? pixels[nlo + (uint32_t)grp] : 0u;
+        for (uint32_t base = lo; base < hi; base += YCGE_POST_GROUPS) {
+            const uint32_t slot = base + (uint32_t)grp;
+            const bool live = slot < hi;
+            const uint32_t p = !live ? 0u : base == lo ? p_first : pixels[slot];
+            atrous_pixel_group(A, buf, albedo, unit_n, depth, sky, live, p, sh);
+        }
+        __threadfence_block();
+        __syncthreads();        // this level's pixels are written before the next level reads them
+        lo = nlo; hi = nhi; p_first = p_next;
     }
 }
 
@@ -301,17 +345,18 @@ int ycge_launch_atrous(int w, int h, int step, const float phi[4], const float *
     return (int)hipGetLastError();
 }
 
-// in-place iteration: level l holds pixels[offsets[l] .. offsets[l + 1]) (host copy of offsets; pixels on the device)
+// in-place iteration as a pipeline of bands (see k_atrous_band): n_bands + ceil(levels / K) - 1 launches
 int ycge_launch_atrous_inplace(int w, int h, int step, const float phi[4], float *buf, const float *albedo, const float *unit_n,
-                               const float *depth, const uint8_t *sky, const uint32_t *d_pixels, const uint32_t *h_offsets, int n_levels,
-                               hipStream_t stream)
+                               const float *depth, const uint8_t *sky, const uint32_t *d_pixels, const uint32_t *d_offsets, int n_levels,
+                               int n_bands, int K, hipStream_t stream)
 {
     ycge::AtrousParams A = {w, h, step, phi[0], phi[1], phi[2], phi[3]};
-    for (int l = 0; l < n_levels; l++) {
-        const uint32_t count = h_offsets[l + 1] - h_offsets[l];
-        if (count == 0) continue;
-        hipLaunchKernelGGL(ycge::k_atrous_level, dim3((count + 7u) / 8u), dim3(256), 0, stream, A, buf, albedo, unit_n, depth, sky,
-                           d_pixels + h_offsets[l], count);
+    const int groups = (n_levels + K - 1) / K;
+    for (int launch = 0; launch < n_bands + groups - 1; launch++) {
+        const int first = launch - (groups - 1) > 0 ? launch - (groups - 1) : 0;      // bands with a level group left to run
+        const int last = launch < n_bands - 1 ? launch : n_bands - 1;
+        hipLaunchKernelGGL(ycge::k_atrous_band, dim3((unsigned)(last - first + 1)), dim3(1024), 0, stream, A, buf, albedo, unit_n, depth, sky,
+                           d_pixels, d_offsets, n_levels, K, launch, first);
     }
     return (int)hipGetLastError();
 }
