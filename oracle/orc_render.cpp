@@ -875,6 +875,45 @@ int orc_scene_hit_many(void *ctx, const float *od /* n x 6 */, int n, float t_mi
     }
     return YCGE_OK;
 }
+/* probe for known-answer tests of steps 6-8 (denoise, exposure, downsample + tonemap) on caller-supplied buffers:
+ * hdr / albedo / normal = hiW*hiH*3 f32, depth = hiW*hiH f32, sky = hiW*hiH u8; denoised_out = hiW*hiH*3,
+ * sdr_out = fbW*fbH*6; exposure_io = {aeExposure before -> after, effective exposure after} */
+int orc_post_probe(int fb_w, int fb_h, int ss, const float *hdr, const float *albedo, const float *normal, const float *depth,
+                   const uint8_t *sky, int iterations, const float phi[4], float *denoised_out, float *exposure_io, float *sdr_out)
+{
+    if (fb_w <= 0 || fb_h <= 0 || !hdr || !albedo || !normal || !depth || !sky || !phi || !denoised_out || !exposure_io || !sdr_out) return YCGE_ERR_INVALID_ARG;
+    Renderer r;
+    ycge_config cfg{};
+    cfg.atrous_iterations = iterations; cfg.atrous_c_phi = phi[0]; cfg.atrous_n_phi = phi[1]; cfg.atrous_z_phi = phi[2]; cfg.atrous_a_phi = phi[3];
+    r.cfg = cfg;
+    r.resize(fb_w, fb_h, ss);
+    size_t n = (size_t)r.hiW * r.hiH;
+    std::memcpy(r.taa_hist.data(), hdr, n * 12); std::memcpy(r.g_albedo.data(), albedo, n * 12); std::memcpy(r.g_normal.data(), normal, n * 12);
+    std::memcpy(r.g_depth.data(), depth, n * 4); std::memcpy(r.sky.data(), sky, n);
+    const orc::V3 *den = r.atrous(r.taa_hist.data());
+    std::memcpy(denoised_out, den, n * 12);
+    r.tone.ae_exposure = exposure_io[0];
+    r.tone.update_exposure(den, r.sky.data(), r.hiW, r.hiH, (r.ss * 2 > 2) ? r.ss * 2 : 2);
+    exposure_io[0] = r.tone.ae_exposure; exposure_io[1] = r.tone.effective;
+    for (int cy = 0; cy < r.fbH; cy++) {
+        int y_top0 = cy * 2 * r.ss, y_bot0 = (cy * 2 + 1) * r.ss;
+        for (int cx = 0; cx < r.fbW; cx++) {
+            int x0 = cx * r.ss;
+            orc::V3 top = orc::v3(0, 0, 0), bot = orc::v3(0, 0, 0);
+            for (int sy = 0; sy < r.ss; sy++)
+                for (int sx = 0; sx < r.ss; sx++) {
+                    top = top + den[(size_t)(x0 + sx) + (size_t)(y_top0 + sy) * r.hiW];
+                    bot = bot + den[(size_t)(x0 + sx) + (size_t)(y_bot0 + sy) * r.hiW];
+                }
+            float inv = 1.0f / (float)(r.ss * r.ss);
+            orc::V3 t_sdr = r.tone.map_pixel(orc::v3(top.x * inv, top.y * inv, top.z * inv));
+            orc::V3 b_sdr = r.tone.map_pixel(orc::v3(bot.x * inv, bot.y * inv, bot.z * inv));
+            float *o = sdr_out + ((size_t)cx + (size_t)cy * r.fbW) * 6;
+            o[0] = t_sdr.x; o[1] = t_sdr.y; o[2] = t_sdr.z; o[3] = b_sdr.x; o[4] = b_sdr.y; o[5] = b_sdr.z;
+        }
+    }
+    return YCGE_OK;
+}
 /* analysis aid: re-trace the last rendered frame and report, per pixel, the traversal steps of each of its first
  * `per_pixel` Scene.Hit calls in call order (primary, shadow rays of vertex 1, bounce, shadow rays of vertex 2, ...) */
 int orc_query_profile(void *ctx, uint32_t *out, int per_pixel)

@@ -3,6 +3,7 @@
 Run in the authoring container only (needs /root/reference for the bunny asset):
     python tests/golden/make_fixtures.py bunny      # parse the reference's OBJ asset -> npz (data, not source)
     python tests/golden/make_fixtures.py goldens    # oracle-rendered golden buffers for config 1 (needs oracle/liborc_oracle.so)
+    python tests/golden/make_fixtures.py post       # same scene through denoise / exposure / tonemap (frames 1-3)
 
 The bunny fixture is the reference's own data file (ConsoleGame/assets/stanford-bunny.obj, the
 Stanford bunny as exported by MeshLab) stored as parsed float32 positions + int32 fan-triangulated
@@ -45,6 +46,23 @@ def goldens():
         print("goldens:", {k: v.shape for k, v in out.items()})
 
 
+def post():
+    """frames 1-3 of config 1 through the WHOLE of TryFlipAndBlit (stages = 2): exposure of every frame, SDR of every frame,
+    denoised HDR of frame 3"""
+    sys.path.insert(0, str(ROOT / "tests"))
+    import oracle_binding as ob
+    from yetanotherconsolegameengine_amd import abi, scenes
+    sc, fbw, fbh, ss, pose = scenes.config_scene(1)
+    with ob.OracleRenderer(sc, fbw, fbh, ss, pose) as r:
+        out = {}
+        for frame in (1, 2, 3):
+            out[f"f{frame}_sdr"] = r.render(stages=2, want_sdr=True)
+            out[f"f{frame}_exposure"] = np.float32(r.stats.exposure)
+        out["f3_denoised"] = r.read(abi.BUF_DENOISED)
+        np.savez_compressed(HERE / "cornell_80x45_post.npz", **out)
+        print("post:", {k: np.shape(v) for k, v in out.items()})
+
+
 if __name__ == "__main__":
-    for what in sys.argv[1:] or ["bunny", "goldens"]:
-        {"bunny": bunny, "goldens": goldens}[what]()
+    for what in sys.argv[1:] or ["bunny", "goldens", "post"]:
+        {"bunny": bunny, "goldens": goldens, "post": post}[what]()

@@ -63,6 +63,19 @@ def test_committed_goldens_on_gpu(product_lib, path):
             assert pu.bits_equal(g.read(abi.BUF_TAA_HISTORY), z[f"f{frame}_taa_history"]), frame
 
 
+def test_committed_post_goldens_on_gpu(product_lib, path):
+    """The HIP post stage against the committed fixture (no oracle run involved)."""
+    z = np.load(scenes.GOLDEN_DIR / "cornell_80x45_post.npz")
+    sc, w, h, ss, pose = scenes.config_scene(1)
+    with RaytraceRenderer(sc, w, h, pose["fov"], ss) as g:
+        g.SetCamera(pose["pos"], pose["yaw"], pose["pitch"])
+        for frame in (1, 2, 3):
+            sdr = g.TryFlipAndBlit(want_sdr=True)
+            assert pu.bits_equal(sdr, z[f"f{frame}_sdr"]), frame
+            assert np.float32(g.stats.exposure).view(np.uint32) == np.float32(z[f"f{frame}_exposure"]).view(np.uint32)
+        assert pu.bits_equal(g.read(abi.BUF_DENOISED), z["f3_denoised"])
+
+
 def _zoo_scene(transparent: bool):
     """Every primitive class + checker + emissive + a true mirror (>= 0.9) and, optionally, glass."""
     s = Scene()

@@ -254,3 +254,146 @@ def test_committed_golden_buffers_cornell():
         # a Cornell primary ray through the image centre hits the back wall (object 4) at z = -5 from (0,1,0)
         pid = r.read(abi.BUF_PRIM_ID)
         assert pid[45, 40] in (4, 6, 7) and (pid >= 0).all()        # closed box: no primary ray escapes
+
+
+# ---- independent restatement of steps 6-8 of TryFlipAndBlit in numpy float32 scalars ------------------------------
+# ApplyAtrousDenoise (RaytraceRenderer.cs:622-722) incl. the buffer walk of :648-650 / :718 (iteration 1 in place),
+# ToneMapper.UpdateExposure (ToneMapper.cs:49-91), the box average of :229-264 and ToneMapAndEncode (:204-260).
+# exp / log / pow are the oracle's own scalar kernels (pinned against libm above): everything ELSE - loop order,
+# clamping, buffer aliasing, the serial sum, the tone curve - is written again here from the C# text.
+def _py_post(L, fbw, fbh, ss, hdr, alb, nrm, dep, sky, iters, phi, ae0):
+    ex = lambda v: f32(L.orc_exp(float(v)))
+    W, H = fbw * ss, fbh * 2 * ss
+    k = [f32(1) / f32(16), f32(1) / f32(4), f32(3) / f32(8), f32(1) / f32(4), f32(1) / f32(16)]
+
+    def normalized(v):
+        ls = f32(f32(f32(v[0] * v[0]) + f32(v[1] * v[1])) + f32(v[2] * v[2]))
+        if ls <= 0:
+            return v.copy()
+        inv = f32(1) / f32(np.sqrt(ls))
+        return np.array([v[0] * inv, v[1] * inv, v[2] * inv], f32)
+
+    def luma(c):
+        return f32(f32(f32(f32(0.2126) * c[0]) + f32(f32(0.7152) * c[1])) + f32(f32(0.0722) * c[2]))
+
+    src = hdr.copy(); A = np.zeros_like(hdr); B = np.zeros_like(hdr)
+    cur, dst = src, A
+    phis = [max(f32(1e-6), f32(p)) for p in phi]
+    for it in range(max(1, iters)):
+        step = 1 << it
+        for y in range(H):
+            for x in range(W):
+                if sky[y, x]:
+                    dst[y, x] = cur[y, x]; continue
+                c0 = cur[y, x].copy(); a0 = alb[y, x]; n0 = normalized(nrm[y, x]); z0 = dep[y, x]
+                wsum = f32(0); acc = np.zeros(3, f32)
+                for ky in range(-2, 3):
+                    sy = min(max(y + ky * step, 0), H - 1)
+                    for kx in range(-2, 3):
+                        sx = min(max(x + kx * step, 0), W - 1)
+                        if sky[sy, sx] != sky[y, x]:
+                            continue
+                        wb = f32(k[kx + 2] * k[ky + 2])
+                        c = cur[sy, sx]; a = alb[sy, sx]; n = normalized(nrm[sy, sx]); z = dep[sy, sx]
+                        dl = abs(f32(luma(c) - luma(c0)))
+                        dot = f32(f32(f32(n0[0] * n[0]) + f32(n0[1] * n[1])) + f32(n0[2] * n[2]))
+                        dn = max(f32(0), f32(f32(1) - dot))
+                        dz = abs(f32(z - z0))
+                        da = f32(f32(abs(f32(a[0] - a0[0])) + abs(f32(a[1] - a0[1]))) + abs(f32(a[2] - a0[2])))
+                        w = f32(f32(f32(f32(wb * ex(f32(-dl / phis[0]))) * ex(f32(-dn / phis[1]))) * ex(f32(-dz / phis[2]))) * ex(f32(-da / phis[3])))
+                        acc = np.array([f32(acc[0] + f32(c[0] * w)), f32(acc[1] + f32(c[1] * w)), f32(acc[2] + f32(c[2] * w))], f32)
+                        wsum = f32(wsum + w)
+                if wsum > f32(1e-8):
+                    inv = f32(1) / wsum
+                    dst[y, x] = [acc[0] * inv, acc[1] * inv, acc[2] * inv]
+                else:
+                    dst[y, x] = c0
+        tmp = cur; cur = dst; dst = B if tmp is A else A            # `var tmp = cur; cur = dst; dst = (tmp == scratchA) ? scratchB : scratchA`
+    den = cur
+    # UpdateExposure (serial overload)
+    st = max(2, ss * 2)
+    log_sum = f32(0); cnt = 0
+    for py in range(0, H, st):
+        for px in range(0, W, st):
+            if sky[py, px]:
+                continue
+            lum = luma(den[py, px])
+            if lum > 0:
+                log_sum = f32(log_sum + f32(L.orc_log(float(f32(f32(1e-6) + lum))))); cnt += 1
+    avg_log = f32(log_sum / f32(max(1, cnt))) if cnt > 0 else f32(0)
+    avg_lum = ex(avg_log)
+    target = f32(f32(0.18) / max(f32(1e-6), avg_lum)) if cnt > 0 else f32(ae0)
+    target = min(max(target, f32(0.10)), f32(1.50))
+    s = f32(f32(1) - ex(f32(-0.2)))
+    ae = f32(f32(ae0) + f32(f32(target - f32(ae0)) * s))
+    eff = f32(f32(1.0) * ae)
+
+    def aces(xv):
+        num = f32(xv * f32(f32(f32(2.51) * xv) + f32(0.03)))
+        dn_ = f32(f32(xv * f32(f32(f32(2.43) * xv) + f32(0.59))) + f32(0.14))
+        yv = f32(num / dn_) if dn_ > 0 else f32(0)
+        return min(max(yv, f32(0)), f32(1))
+
+    def map_pixel(c):
+        inv_g = f32(f32(1) / max(f32(0.1), f32(2.2)))
+        v = []
+        for ch in range(3):
+            t = aces(f32(max(f32(0), c[ch]) * eff))
+            t = min(max(t, f32(0)), f32(1))
+            v.append(min(max(f32(L.orc_pow(float(t), float(inv_g))), f32(0)), f32(1)))
+        r, g, b = v
+        yv = luma(np.array([r, g, b], f32))
+        chroma = f32(max(r, max(g, b)) - min(r, min(g, b)))
+        fsat = f32(f32(2.0) * f32(f32(1) + f32(f32(0.0) * f32(f32(1) - chroma))))
+        return [min(max(f32(yv + f32(f32(ch_ - yv) * fsat)), f32(0)), f32(1)) for ch_ in (r, g, b)]
+
+    sdr = np.zeros((fbh, fbw, 2, 3), f32)
+    inv = f32(f32(1) / f32(ss * ss))
+    for cy in range(fbh):
+        for cx in range(fbw):
+            for half, y0 in ((0, cy * 2 * ss), (1, (cy * 2 + 1) * ss)):
+                sm = np.zeros(3, f32)
+                for sy in range(ss):
+                    for sx in range(ss):
+                        sm = (sm + den[y0 + sy, cx * ss + sx]).astype(f32)
+                sdr[cy, cx, half] = map_pixel((sm * inv).astype(f32))
+    return den, ae, eff, sdr
+
+
+@pytest.mark.parametrize("fbw,fbh,ss,iters", [(7, 4, 1, 3), (5, 3, 2, 3), (6, 3, 1, 2)])
+def test_post_stage_against_python_restatement(fbw, fbh, ss, iters):
+    L = ob.lib()
+    L.orc_post_probe.restype = C.c_int
+    L.orc_post_probe.argtypes = [C.c_int] * 3 + [C.c_void_p] * 5 + [C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+    W, H = fbw * ss, fbh * 2 * ss
+    rng = np.random.default_rng(fbw * 100 + fbh * 10 + ss)
+    hdr = rng.uniform(0, 2.5, (H, W, 3)).astype(f32)
+    alb = rng.uniform(0, 1, (H, W, 3)).astype(f32)
+    nrm = rng.normal(size=(H, W, 3)).astype(f32); nrm[0, 0] = 0           # one zero normal: Normalized() returns it unchanged
+    dep = rng.uniform(1, 9, (H, W)).astype(f32)
+    sky = (rng.uniform(size=(H, W)) < 0.2).astype(np.uint8)
+    hdr[sky == 1] = f32(0.7)
+    phi = np.array([3.0, 0.35, 2.0, 0.20], f32)
+    den_o = np.zeros_like(hdr); sdr_o = np.zeros((fbh, fbw, 2, 3), f32); expo = np.array([1.0, 0.0], f32)
+    assert L.orc_post_probe(fbw, fbh, ss, hdr.ctypes.data, alb.ctypes.data, nrm.ctypes.data, dep.ctypes.data, sky.ctypes.data, iters,
+                            phi.ctypes.data, den_o.ctypes.data, expo.ctypes.data, sdr_o.ctypes.data) == 0
+    den_p, ae, eff, sdr_p = _py_post(L, fbw, fbh, ss, hdr, alb, nrm, dep, sky, iters, phi, 1.0)
+    assert np.array_equal(den_o.view(np.uint32), np.ascontiguousarray(den_p, f32).view(np.uint32))
+    assert bits(expo[0]) == bits(ae) and bits(expo[1]) == bits(eff)
+    assert np.array_equal(sdr_o.view(np.uint32), sdr_p.view(np.uint32))
+    # the in-place iteration is not a ping-pong: redoing iteration 1 out of place must give a different image
+    if iters >= 2:
+        assert not np.array_equal(den_p, hdr)
+
+
+def test_committed_golden_post_stage_cornell():
+    """regression fixture of steps 6-8 (tests/golden/make_fixtures.py post)"""
+    z = np.load(scenes.GOLDEN_DIR / "cornell_80x45_post.npz")
+    sc, w, h, ss, pose = scenes.config_scene(1)
+    with ob.OracleRenderer(sc, w, h, ss, pose) as r:
+        for frame in (1, 2, 3):
+            sdr = r.render(stages=2, want_sdr=True)
+            assert np.array_equal(sdr.view(np.uint32), z[f"f{frame}_sdr"].view(np.uint32)), frame
+            assert bits(r.stats.exposure) == bits(z[f"f{frame}_exposure"])
+        assert np.array_equal(r.read(abi.BUF_DENOISED).view(np.uint32), z["f3_denoised"].view(np.uint32))
+        assert 0.1 <= float(r.stats.exposure) <= 1.5 and (sdr >= 0).all() and (sdr <= 1).all()
