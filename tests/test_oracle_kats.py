@@ -397,3 +397,33 @@ def test_committed_golden_post_stage_cornell():
             assert bits(r.stats.exposure) == bits(z[f"f{frame}_exposure"])
         assert np.array_equal(r.read(abi.BUF_DENOISED).view(np.uint32), z["f3_denoised"].view(np.uint32))
         assert 0.1 <= float(r.stats.exposure) <= 1.5 and (sdr >= 0).all() and (sdr <= 1).all()
+
+
+def test_whole_pixel_path_against_python_restatement():
+    """The oracle against tests/py_restatement.py (a second, independent restatement written from the C# text): camera
+    rays, primary hits, radiance incl. checker floor, true mirror, glass (reflect + refract split, transmittance of the
+    shadow rays), emissive panel, two lights, diffuse bounce; RNG state; two frame numbers.  Bit for bit."""
+    import py_restatement as pr
+    s = Scene()
+    s.Ambient.Color, s.Ambient.Intensity = vec3(1, 1, 1), 0.05
+    from yetanotherconsolegameengine_amd.scene import Checker
+    s.Add(Plane(vec3(0, 0, 0), vec3(0, 1, 0), Checker(vec3(0.75, 0.75, 0.75), vec3(0.2, 0.2, 0.2), 0.8), 0.05, 0.0))
+    s.Add(Sphere(vec3(-1.1, 0.7, -3.2), 0.7, Material(vec3(0.8, 0.3, 0.2), 0.1, 0.0, ZERO)))
+    s.Add(Sphere(vec3(0.6, 0.55, -2.6), 0.55, Material(vec3(0.97, 0.97, 0.97), 0.0, 0.95, ZERO)))                       # mirror branch
+    s.Add(Sphere(vec3(-0.2, 0.4, -1.7), 0.4, Material(vec3(1, 1, 1), 0.0, 0.05, ZERO, 0.9, 1.5, vec3(0.9, 1.0, 0.9))))   # glass
+    s.Add(XZRect(-0.6, 0.6, -2.9, -2.2, 2.2, Material(vec3(0, 0, 0), 0.0, 0.0, vec3(2.0, 1.8, 1.5)), 0.0, 0.0))          # emissive panel
+    s.Lights.append(PointLight(vec3(-2.0, 3.5, -1.0), vec3(1.0, 0.95, 0.9), 60.0))
+    s.Lights.append(PointLight(vec3(2.5, 2.0, -4.0), vec3(0.9, 0.95, 1.0), 35.0))
+    pose = dict(pos=(0.05, 1.0, 0.4), yaw=0.04, pitch=-0.15, fov=55.0)
+    fbw, fbh = 14, 6
+    with ob.OracleRenderer(s, fbw, fbh, 1, pose) as o:
+        for frame in (1, 2):
+            o.render(stages=0)
+            p = pr.render_frame(o.L, s, o.hiW, o.hiH, pose, frame)
+            for name, which, key in (("rays", abi.BUF_RAYS, "rays"), ("radiance", abi.BUF_CURRENT_HDR, "hdr"), ("albedo", abi.BUF_G_ALBEDO, "albedo"),
+                                     ("normal", abi.BUF_G_NORMAL, "normal"), ("depth", abi.BUF_G_DEPTH, "depth")):
+                a, b = o.read(which), p[key]
+                assert np.array_equal(a.view(np.uint32), np.ascontiguousarray(b, f32).view(np.uint32)), (frame, name, int((a.view(np.uint32) != b.view(np.uint32)).sum()))
+            assert np.array_equal(o.read(abi.BUF_SKY_MASK), p["sky"]) and np.array_equal(o.read(abi.BUF_PRIM_ID), p["prim"])
+            assert np.array_equal(o.read(abi.BUF_RNG_STATE), p["rng"])
+            assert set(np.unique(p["prim"])) >= {0, 1, 2, 3}                         # floor, diffuse, mirror and glass spheres are all seen
