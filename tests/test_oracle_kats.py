@@ -427,3 +427,80 @@ def test_whole_pixel_path_against_python_restatement():
             assert np.array_equal(o.read(abi.BUF_SKY_MASK), p["sky"]) and np.array_equal(o.read(abi.BUF_PRIM_ID), p["prim"])
             assert np.array_equal(o.read(abi.BUF_RNG_STATE), p["rng"])
             assert set(np.unique(p["prim"])) >= {0, 1, 2, 3}                         # floor, diffuse, mirror and glass spheres are all seen
+
+
+def _check_frames_against_restatement(scene, fbw, fbh, pose, frames, need_objects):
+    import py_restatement as pr
+    taa = {}
+    with ob.OracleRenderer(scene, fbw, fbh, 1, pose) as o:
+        seen = set()
+        for frame in range(1, frames + 1):
+            o.render(stages=1)
+            p = pr.render_frame(o.L, scene, o.hiW, o.hiH, pose, frame)
+            for name, which, key in (("rays", abi.BUF_RAYS, "rays"), ("radiance", abi.BUF_CURRENT_HDR, "hdr"), ("albedo", abi.BUF_G_ALBEDO, "albedo"),
+                                     ("normal", abi.BUF_G_NORMAL, "normal"), ("depth", abi.BUF_G_DEPTH, "depth")):
+                a, b = o.read(which), np.ascontiguousarray(p[key], f32)
+                assert np.array_equal(a.view(np.uint32), b.view(np.uint32)), (frame, name, int((a.view(np.uint32) != b.view(np.uint32)).sum()))
+            assert np.array_equal(o.read(abi.BUF_SKY_MASK), p["sky"]) and np.array_equal(o.read(abi.BUF_PRIM_ID), p["prim"])
+            assert np.array_equal(o.read(abi.BUF_RNG_STATE), p["rng"])
+            hist = pr.temporal_blend(taa, p["hdr"], p["normal"], p["depth"], p["sky"], force_reset=False)
+            assert np.array_equal(o.read(abi.BUF_TAA_HISTORY).view(np.uint32), np.ascontiguousarray(hist, f32).view(np.uint32)), (frame, "taa")
+            seen |= set(np.unique(p["prim"]).tolist())
+        assert seen >= need_objects, seen
+
+
+def test_every_analytic_primitive_and_taa_against_python_restatement():
+    """Disk, the three rects, Box (six faces), CylinderY with caps, Triangle (scalar path) and three frames of
+    TemporalBlendWithClamp, oracle vs tests/py_restatement.py, bit for bit."""
+    from yetanotherconsolegameengine_amd.scene import Checker
+    s = Scene()
+    s.Ambient.Color, s.Ambient.Intensity = vec3(1, 1, 1), 0.03
+    s.Add(Plane(vec3(0, 0, 0), vec3(0, 1, 0), Checker(vec3(0.7, 0.7, 0.7), vec3(0.25, 0.25, 0.25), 0.6), 0.0, 0.0))
+    s.Add(CylinderY(vec3(-1.3, 0.0, -3.0), 0.5, 0.0, 1.4, True, Material(vec3(0.2, 0.35, 0.9), 0.1, 0.0, ZERO)))
+    s.Add(Disk(vec3(1.5, 0.02, -2.0), vec3(0, 1, 0), 0.7, Solid(vec3(0.8, 0.8, 0.1)), 0.0, 0.0))
+    s.Add(Triangle(vec3(0.1, 0.0, -3.4), vec3(1.2, 1.3, -3.0), vec3(-0.7, 0.8, -2.7), Material(vec3(0.9, 0.25, 0.25), 0.1, 0.0, ZERO)))
+    s.Add(Box(vec3(-2.6, 0.0, -5.0), vec3(-1.7, 1.1, -4.1), Solid(vec3(0.8, 0.8, 0.8)), 0.1, 0.92))                      # mirror via the ctor override
+    s.Add(XYRect(0.8, 2.2, 0.0, 1.2, -4.6, Solid(vec3(0.3, 0.8, 0.4)), 0.0, 0.0))
+    s.Add(YZRect(0.0, 1.0, -3.6, -2.8, 2.4, Solid(vec3(0.6, 0.3, 0.8)), 0.0, 0.0))
+    s.Add(XZRect(-0.5, 0.5, -2.6, -2.0, 2.0, Material(vec3(0, 0, 0), 0.0, 0.0, vec3(1.8, 1.7, 1.5)), 0.0, 0.0))
+    s.Lights.append(PointLight(vec3(-1.5, 3.0, -0.5), vec3(1.0, 0.95, 0.9), 50.0))
+    pose = dict(pos=(0.0, 1.1, 0.8), yaw=-0.03, pitch=-0.12, fov=60.0)
+    _check_frames_against_restatement(s, 16, 6, pose, 3, {0, 1, 2, 3, 4, 5, 6})
+
+
+def test_voxel_grid_walk_against_python_restatement():
+    """VolumeGrid.Hit (Amanatides-Woo walk, accumulated t, entry nudge, face normals, binary64 wire test) and the
+    VolumeScene shadow rule, oracle vs tests/py_restatement.py, bit for bit."""
+    from yetanotherconsolegameengine_amd.scene import VolumeGrid
+    rng = np.random.default_rng(5)
+    cells = np.zeros((12, 9, 10, 2), np.int32)
+    cells[:, :3, :, 0] = 1                                   # ground
+    cells[..., 0] = np.where(rng.uniform(size=cells.shape[:3]) < 0.06, 2, cells[..., 0])          # floating blocks
+    cells[2:5, 3:7, 4:6, 0] = 3                              # a wall
+    palette = {1: Material(vec3(0.35, 0.6, 0.25), 0.0, 0.0, ZERO), 2: Material(vec3(0.7, 0.5, 0.3), 0.0, 0.0, ZERO),
+               3: Material(vec3(0.6, 0.6, 0.65), 0.0, 0.0, ZERO)}
+    s = Scene()
+    s.IsVolumeScene = True
+    s.Ambient.Color, s.Ambient.Intensity = vec3(1, 1, 1), 0.0
+    s.Objects.append(VolumeGrid(cells, vec3(-6.0, 0.0, -12.0), vec3(1, 1, 1), lambda m, t: palette[m], True, 0.06, 9.0))
+    s.Objects.append(VolumeGrid(cells[::-1].copy(), vec3(6.0, 0.0, -12.0), vec3(0.5, 0.5, 0.5), lambda m, t: palette[m], False))
+    s.Lights.append(PointLight(vec3(40.0, 90.0, 30.0), vec3(1.0, 0.96, 0.88), 9000.0))
+    pose = dict(pos=(0.3, 4.6, 1.5), yaw=0.1, pitch=-0.2, fov=60.0)
+    _check_frames_against_restatement(s, 16, 6, pose, 2, {0, 1})
+
+
+def test_mesh_triangle_test_against_python_restatement():
+    """MeshBVH.TriHit (sign-normalised, |det|-scaled ranges, division on accept) and the mesh hit attributes through the
+    oracle's BVH vs a brute-force loop over the triangles in tests/py_restatement.py, bit for bit, incl. the bounce and
+    shadow rays that start ON the mesh."""
+    from yetanotherconsolegameengine_amd.scene import Mesh
+    pos, faces = scenes.make_torus_knot(22, 9)
+    pos = (pos * f32(0.35) + np.array([0.0, 1.2, -3.0], f32)).astype(f32)
+    tri = pos[faces].astype(f32)                              # [n, 3, 3]
+    s = Scene()
+    s.Ambient.Color, s.Ambient.Intensity = vec3(1, 1, 1), 0.1
+    s.Add(Plane(vec3(0, 0, 0), vec3(0, 1, 0), Solid(vec3(0.6, 0.6, 0.6)), 0.0, 0.0))
+    s.Objects.append(Mesh(tri, Material(vec3(0.1, 0.2, 0.85), 0.0, 0.7, ZERO)))
+    s.Lights.append(PointLight(vec3(0.5, 6.0, -1.0), vec3(1, 1, 1), 80.0))
+    pose = dict(pos=(0.0, 1.3, 0.0), yaw=0.0, pitch=-0.05, fov=50.0)
+    _check_frames_against_restatement(s, 16, 6, pose, 1, {0, 1})
