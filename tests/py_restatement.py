@@ -646,3 +646,214 @@ def temporal_blend(state, cur, normal, depth, sky, force_reset, alpha=0.01, radi
             hist[y, x] = [f32(f32(prev[0] * ia) + f32(c[0] * la)), f32(f32(prev[1] * ia) + f32(c[1] * la)), f32(f32(prev[2] * ia) + f32(c[2] * la))]
     state.update(prev_normal=normal.copy(), prev_depth=depth.copy(), prev_sky=sky.copy())
     return hist
+
+
+# ---- the two BVH builders (Objects/BVH.cs:258-459, Objects/MeshBVH.cs:371-576), restated from the C# text ----------------
+def _f2i(v):
+    """(int)float on x64: cvttss2si - truncation, 0x80000000 for NaN / out of range"""
+    v = float(v)
+    if v != v or v >= 2147483648.0 or v < -2147483648.0:
+        return -2147483648
+    return int(v)
+
+
+def _surface_area(b):
+    dx, dy, dz = f32(b[3] - b[0]), f32(b[4] - b[1]), f32(b[5] - b[2])
+    return f32(f32(2.0) * f32(f32(f32(dx * dy) + f32(dx * dz)) + f32(dy * dz)))
+
+
+def _surround(acc, b):
+    for k in range(3):
+        if b[k] < acc[k]: acc[k] = b[k]
+    for k in range(3, 6):
+        if b[k] > acc[k]: acc[k] = b[k]
+
+
+def build_bvh(bounds, cents, mesh_flavour, sort_fn):
+    """bounds [n,6] (min xyz, max xyz), cents [n,3], both float32.  mesh_flavour: leaf size 8 and the partition binned
+    with the node's own centroid range (MeshBVH.cs); else leaf size 4 and the partition binned with the FIRST / LAST
+    item's centroid (BVH.cs:394-396).  sort_fn(keys, idx) -> (keys, idx): Array.Sort of the items on one axis (.NET
+    introsort; pinned separately).  Returns (nodes as rows [min3, max3, left, right, start, count], leaf index list)."""
+    leaf_size, bins = (8 if mesh_flavour else 4), 16
+    arr = [[i, [f32(v) for v in bounds[i]], [f32(v) for v in cents[i]]] for i in range(len(bounds))]
+    nodes, leaves = [], []
+    inf = f32(np.inf)
+
+    def sort_range(start, count, ax):
+        keys = np.array([arr[i][2][ax] for i in range(start, start + count)], f32)
+        idx = np.arange(count, dtype=np.int32)
+        keys, idx = sort_fn(keys, idx)
+        seg = [arr[start + int(j)] for j in idx]
+        arr[start:start + count] = seg
+
+    def rec(start, count):
+        if count <= 0:
+            return -1
+        if count <= leaf_size:
+            b = list(arr[start][1])
+            for i in range(1, count):
+                _surround(b, arr[start + i][1])
+            base = len(leaves)
+            leaves.extend(arr[start + i][0] for i in range(count))
+            nodes.append([*b, -1, -1, base, count])
+            return len(nodes) - 1
+        cmin, cmax = list(arr[start][2]), list(arr[start][2])
+        for i in range(start + 1, start + count):
+            for k in range(3):
+                c = arr[i][2][k]
+                if c < cmin[k]: cmin[k] = c
+                if c > cmax[k]: cmax[k] = c
+        ext = [f32(cmax[k] - cmin[k]) for k in range(3)]
+        axis = 0
+        if ext[1] > ext[0] and ext[1] >= ext[2]: axis = 1
+        elif ext[2] > ext[0] and ext[2] >= ext[1]: axis = 2
+        split_bin, best_axis, best_cost = -1, axis, inf
+        for ax in range(3):
+            if not (ext[ax] > 0):
+                continue
+            origin, inv_e = cmin[ax], f32(f32(1.0) / ext[ax])
+            counts = [0] * bins
+            bb = [[inf, inf, inf, -inf, -inf, -inf] for _ in range(bins)]
+            for i in range(start, start + count):
+                b = _f2i(f32(f32(f32(arr[i][2][ax] - origin) * inv_e) * f32(bins - 1)))
+                b = 0 if b < 0 else bins - 1 if b >= bins else b
+                counts[b] += 1
+                _surround(bb[b], arr[i][1])
+            lc, la, rc, ra = [0] * bins, [f32(0)] * bins, [0] * bins, [f32(0)] * bins
+            cur, acc = [inf, inf, inf, -inf, -inf, -inf], 0
+            for b in range(bins):
+                if counts[b] > 0: _surround(cur, bb[b])
+                acc += counts[b]; lc[b] = acc; la[b] = _surface_area(cur)
+            cur, acc = [inf, inf, inf, -inf, -inf, -inf], 0
+            for b in range(bins - 1, -1, -1):
+                if counts[b] > 0: _surround(cur, bb[b])
+                acc += counts[b]; rc[b] = acc; ra[b] = _surface_area(cur)
+            for b in range(bins - 1):
+                if lc[b] == 0 or rc[b + 1] == 0:
+                    continue
+                cost = f32(f32(la[b] * f32(lc[b])) + f32(ra[b + 1] * f32(rc[b + 1])))
+                if cost < best_cost:
+                    best_cost, best_axis, split_bin = cost, ax, b
+        if split_bin < 0:
+            sort_range(start, count, best_axis)
+            mid = start + (count >> 1)
+        else:
+            if mesh_flavour:
+                origin, inv_e, use = cmin[best_axis], f32(f32(1.0) / ext[best_axis]), True
+            else:
+                origin = arr[start][2][best_axis]
+                e = f32(arr[start + count - 1][2][best_axis] - origin)
+                inv_e = f32(f32(1.0) / e) if e != 0 else f32(0)
+                use = inv_e != 0
+            i0, i1 = start, start + count - 1
+            while i0 <= i1:
+                b0 = _f2i(f32(f32(f32(arr[i0][2][best_axis] - origin) * inv_e) * f32(bins - 1))) if use else 0
+                if b0 <= split_bin:
+                    i0 += 1
+                else:
+                    arr[i0], arr[i1] = arr[i1], arr[i0]; i1 -= 1
+            mid = i0
+            if mid == start or mid == start + count:
+                sort_range(start, count, best_axis)
+                mid = start + (count >> 1)
+        me = len(nodes)
+        nodes.append(None)
+        li = rec(start, mid - start)
+        ri = rec(mid, start + count - mid)
+        if li >= 0 and ri >= 0:
+            L, R = nodes[li], nodes[ri]
+            b = [fmin(L[0], R[0]), fmin(L[1], R[1]), fmin(L[2], R[2]), fmax(L[3], R[3]), fmax(L[4], R[4]), fmax(L[5], R[5])]
+        else:
+            b = list(nodes[li if li >= 0 else ri][:6])
+        nodes[me] = [*b, li, ri, 0, 0]
+        return me
+
+    root = rec(0, len(arr))
+    return root, nodes, leaves
+
+
+def triangle_items(tris):
+    """MeshBVH ctor: TryComputeBounds (:351-365, pad 1e-4) and the box-centre centroid (:55-57)."""
+    t = np.asarray(tris, f32).reshape(-1, 3, 3)
+    mn = (np.minimum(t[:, 0], np.minimum(t[:, 1], t[:, 2])) - f32(1e-4)).astype(f32)
+    mx = (np.maximum(t[:, 0], np.maximum(t[:, 1], t[:, 2])) + f32(1e-4)).astype(f32)
+    return np.concatenate([mn, mx], 1), (f32(0.5) * (mn + mx)).astype(f32)
+
+
+# ---- Array.Sort(T[], int, int, IComparer<T>) of .NET (System.Private.CoreLib ArraySortHelper<T>: introspective sort) -------
+def dotnet_introsort(keys, idx):
+    """Sorts (key, payload) pairs by key the way ArraySortHelper<T>.IntrospectiveSort does with a Comparison<T>:
+    depth limit 2 * (floor(log2 n) + 1); partitions of <= 16 by insertion sort (2 and 3 by compare-swaps); median of
+    three with the pivot parked at hi - 1; heapsort when the depth limit is hit.  Unstable: equal keys end up in the
+    order these steps leave them, which is what the BVH builders inherit."""
+    a = [(f32(k), int(i)) for k, i in zip(keys, idx)]
+    cmp = lambda x, y: -1 if x[0] < y[0] else 1 if x[0] > y[0] else 0           # float.CompareTo on non-NaN keys
+
+    def swap_if_greater(i, j):
+        if cmp(a[i], a[j]) > 0:
+            a[i], a[j] = a[j], a[i]
+
+    def insertion(lo, n):
+        for i in range(lo, lo + n - 1):
+            t = a[i + 1]; j = i
+            while j >= lo and cmp(t, a[j]) < 0:
+                a[j + 1] = a[j]; j -= 1
+            a[j + 1] = t
+
+    def down_heap(i, n, lo):
+        d = a[lo + i - 1]
+        while i <= n >> 1:
+            child = 2 * i
+            if child < n and cmp(a[lo + child - 1], a[lo + child]) < 0:
+                child += 1
+            if not (cmp(d, a[lo + child - 1]) < 0):
+                break
+            a[lo + i - 1] = a[lo + child - 1]; i = child
+        a[lo + i - 1] = d
+
+    def heapsort(lo, n):
+        for i in range(n >> 1, 0, -1):
+            down_heap(i, n, lo)
+        for i in range(n, 1, -1):
+            a[lo], a[lo + i - 1] = a[lo + i - 1], a[lo]
+            down_heap(1, i - 1, lo)
+
+    def partition(lo, n):
+        hi = lo + n - 1; mid = lo + ((n - 1) >> 1)
+        swap_if_greater(lo, mid); swap_if_greater(lo, hi); swap_if_greater(mid, hi)
+        pivot = a[mid]
+        a[mid], a[hi - 1] = a[hi - 1], a[mid]
+        left, right = lo, hi - 1
+        while left < right:
+            left += 1
+            while cmp(a[left], pivot) < 0: left += 1
+            right -= 1
+            while cmp(pivot, a[right]) < 0: right -= 1
+            if left >= right:
+                break
+            a[left], a[right] = a[right], a[left]
+        if left != hi - 1:
+            a[left], a[hi - 1] = a[hi - 1], a[left]
+        return left
+
+    def intro(lo, n, depth):
+        while n > 1:
+            if n <= 16:
+                if n == 2:
+                    swap_if_greater(lo, lo + 1)
+                elif n == 3:
+                    swap_if_greater(lo, lo + 1); swap_if_greater(lo, lo + 2); swap_if_greater(lo + 1, lo + 2)
+                else:
+                    insertion(lo, n)
+                return
+            if depth == 0:
+                heapsort(lo, n); return
+            depth -= 1
+            p = partition(lo, n)
+            intro(p + 1, lo + n - (p + 1), depth)
+            n = p - lo
+
+    n = len(a)
+    if n >= 2:
+        intro(0, n, 2 * (n.bit_length() - 1 + 1))
+    return np.array([k for k, _ in a], f32), np.array([i for _, i in a], np.int32)

@@ -504,3 +504,77 @@ def test_mesh_triangle_test_against_python_restatement():
     s.Lights.append(PointLight(vec3(0.5, 6.0, -1.0), vec3(1, 1, 1), 80.0))
     pose = dict(pos=(0.0, 1.3, 0.0), yaw=0.0, pitch=-0.05, fov=50.0)
     _check_frames_against_restatement(s, 16, 6, pose, 1, {0, 1})
+
+
+def _oracle_sort(keys, idx):
+    L = ob.lib()
+    k = np.ascontiguousarray(keys, f32).copy(); i = np.ascontiguousarray(idx, np.int32).copy()
+    L.orc_introsort(k.ctypes.data_as(C.POINTER(C.c_float)), i.ctypes.data_as(C.POINTER(C.c_int32)), len(k))
+    return k, i
+
+
+def test_introsort_against_python_restatement():
+    """The oracle's Array.Sort (.NET introspective sort) vs the restatement in tests/py_restatement.py: same permutation,
+    ties included, on random, heavily tied, descending and median-of-three-killer inputs (the last reach the heapsort)."""
+    import py_restatement as pr
+    rng = np.random.RandomState(1)
+    cases = []
+    for trial in range(120):
+        n = int(rng.choice([2, 3, 5, 16, 17, 18, 33, 64, 100, 257, 1000]))
+        mode = trial % 4
+        k = (rng.uniform(-1, 1, n) if mode == 0 else rng.randint(0, 4, n).astype(float) if mode == 1 else
+             np.sort(rng.uniform(-1, 1, n))[::-1] if mode == 2 else np.where(rng.uniform(size=n) < 0.5, 0.0, rng.randint(0, 3, n)))
+        cases.append(np.asarray(k, f32))
+    for n in (64, 200, 1000):                  # Musser's median-of-3 killer
+        h = n // 2; a = [0] * n
+        for i in range(1, h + 1):
+            a[i - 1] = i if i % 2 == 1 else h + i - 1
+            a[h + i - 1] = 2 * i
+        cases.append(np.asarray(a, f32))
+    for k in cases:
+        i = np.arange(len(k), dtype=np.int32)
+        ko, io = _oracle_sort(k, i)
+        kp, ip = pr.dotnet_introsort(k, i)
+        assert np.array_equal(ko, kp) and np.array_equal(io, ip), len(k)
+
+
+def _rows(nodes):
+    return np.array([(tuple(n[:3]), tuple(n[3:6]), n[6], n[7], n[8], n[9]) for n in nodes], dtype=ob.NODE_DTYPE)
+
+
+@pytest.mark.parametrize("case", ["random", "lattice", "equal", "clustered"])
+def test_both_bvh_builders_against_python_restatement(case):
+    """Binned-SAH builders of BVH.cs (leaf 4, partition binned with the first / last item) and MeshBVH.cs (leaf 8),
+    restated in tests/py_restatement.py: node boxes, child links, leaf ranges and the leaf index order must equal the
+    oracle's.  Array.Sort on the fallback path is the restatement's own introsort (test_introsort_against_python_restatement)."""
+    import py_restatement as pr
+    from yetanotherconsolegameengine_amd.scene import Mesh
+    rng = np.random.RandomState(3)
+    if case == "random":
+        c = rng.uniform(-4, 4, (300, 1, 3)); tris = (c + rng.normal(scale=0.15, size=(300, 3, 3))).astype(f32)
+    elif case == "lattice":         # equal centroids per axis: degenerate bins, Array.Sort fallbacks
+        g = np.stack(np.meshgrid(np.arange(7), np.arange(6), np.arange(3), indexing="ij"), -1).reshape(-1, 1, 3).astype(f32)
+        tris = (g + f32([[0, 0, 0], [0.5, 0, 0], [0, 0.5, 0]])).astype(f32)
+    elif case == "equal":
+        tris = np.tile(f32([[0, 0, 0], [1, 0, 0], [0, 1, 0]]), (37, 1, 1))
+    else:
+        c = np.concatenate([rng.normal(scale=0.05, size=(120, 1, 3)), rng.normal(loc=5.0, scale=2.0, size=(60, 1, 3))])
+        tris = (c + rng.normal(scale=0.02, size=(180, 3, 3))).astype(f32)
+    # mesh flavour
+    s = Scene(); s.Objects.append(Mesh(tris, Material(vec3(1, 1, 1))))
+    with ob.OracleRenderer(s, 8, 4) as r:
+        on, ol = r.accel(abi.ACCEL_MESH_NODES), r.accel(abi.ACCEL_MESH_LEAF_INDEX)
+    b, c = pr.triangle_items(tris)
+    root, nodes, leaves = pr.build_bvh(b, c, True, pr.dotnet_introsort)
+    assert np.array_equal(_rows(nodes).view(np.uint8), on.view(np.uint8)) and np.array_equal(np.int32(leaves), ol)
+    # scene flavour over spheres with the same centres
+    s = Scene()
+    cen = tris.mean(axis=1).astype(f32)
+    for k in range(len(cen)):
+        s.Add(Sphere(vec3(*cen[k]), 0.1 + 0.01 * (k % 7), Material(vec3(1, 1, 1))))
+    with ob.OracleRenderer(s, 8, 4) as r:
+        on, ol = r.accel(abi.ACCEL_SCENE_NODES), r.accel(abi.ACCEL_SCENE_LEAF_INDEX)
+    cc = np.float32([o.Center for o in s.Objects]); rr = np.float32([[o.Radius] for o in s.Objects])
+    mn, mx = (cc - rr).astype(f32), (cc + rr).astype(f32)
+    root, nodes, leaves = pr.build_bvh(np.concatenate([mn, mx], 1), (f32(0.5) * (mn + mx)).astype(f32), False, pr.dotnet_introsort)
+    assert np.array_equal(_rows(nodes).view(np.uint8), on.view(np.uint8)) and np.array_equal(np.int32(leaves), ol)
