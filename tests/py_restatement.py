@@ -418,6 +418,8 @@ def wire_on_face(g, mn, sz, p, ix, iy, iz, axis):           # VolumeGrid.cs:256-
 
 
 def scene_hit(scene, r, tmin, tmax):
+    if isinstance(scene, BvhScene):
+        return scene.hit(r, tmin, tmax)
     best, closest = None, tmax
     for i, o in enumerate(scene.Objects):
         h = hit_object(i, o, r, tmin, closest)
@@ -857,3 +859,130 @@ def dotnet_introsort(keys, idx):
     if n >= 2:
         intro(0, n, 2 * (n.bit_length() - 1 + 1))
     return np.array([k for k, _ in a], f32), np.array([i for _, i in a], np.int32)
+
+
+# ---- BVH.Hit (Objects/BVH.cs:99-198) and MeshBVH.Hit (Objects/MeshBVH.cs:132-236) over the trees of build_bvh ---------------
+class Counters:
+    """the work counters of SURVEY 8(d): Scene.Hit calls, AABB evaluations as root or as child (the re-test of a node's
+    own box when it is popped is not counted), MeshBVH.TriHit calls, analytic primitive tests (a Box = 6 rects)"""
+    def __init__(self): self.rays = self.box = self.tri = self.prim = 0
+
+
+def box_scene(b, r, inv, tmin, tmax):                       # BVH.BoxHitFast, BVH.cs:201-236 (MathF.Max / Min propagate NaN)
+    o3 = r.o.tup()
+    en, ex = [], []
+    for a in range(3):
+        t0, t1 = f32(f32(b[a] - o3[a]) * inv[a]), f32(f32(b[3 + a] - o3[a]) * inv[a])
+        if t0 > t1: t0, t1 = t1, t0
+        en.append(t0); ex.append(t1)
+    t_en = fmax(en[0], fmax(en[1], en[2])); t_ex = fmin(ex[0], fmin(ex[1], ex[2]))
+    if t_en < tmin: t_en = tmin
+    if t_ex > tmax: t_ex = tmax
+    return bool(t_ex >= t_en), t_en
+
+
+def box_mesh(b, r, inv, sign, tmin, tmax):                  # MeshBVH.BoxHitFast, MeshBVH.cs:308-332 (compare chains, early outs)
+    o3 = r.o.tup()
+    for a in range(3):
+        en = f32(f32((b[a] if sign[a] == 0 else b[3 + a]) - o3[a]) * inv[a])
+        ex = f32(f32((b[3 + a] if sign[a] == 0 else b[a]) - o3[a]) * inv[a])
+        if en > tmin: tmin = en
+        if ex < tmax: tmax = ex
+        if a < 2 and tmax < tmin:
+            return False, tmin
+    return bool(tmax >= tmin), tmin
+
+
+def _walk(nodes, root, r, tmin, tmax, mesh, leaf_fn, cnt):
+    """the common loop of both Hit methods; leaf_fn(start, count, closest) -> (hit record or None, closest)"""
+    if root < 0:
+        return None
+    with np.errstate(divide="ignore"):
+        inv = [f32(f32(1.0) / c) for c in r.d.tup()]
+    sign = [1 if v < 0 else 0 for v in inv]
+    test = (lambda b, lo, hi: box_mesh(b, r, inv, sign, lo, hi)) if mesh else (lambda b, lo, hi: box_scene(b, r, inv, lo, hi))
+    best, closest = None, tmax
+    stack = [root]
+    cnt.box += 1                                            # the root's evaluation
+    while stack:
+        ni = stack.pop()
+        n = nodes[ni]
+        ok, _ = test(n[:6], tmin, closest)                  # re-test on pop (not counted)
+        if not ok:
+            continue
+        if n[9] > 0:
+            h, closest = leaf_fn(n[8], n[9], closest)
+            if h is not None:
+                best = h
+        else:
+            l, rr = n[6], n[7]
+            hl = hr = False; ln = rn = f32(0)
+            if l >= 0:
+                cnt.box += 1; hl, ln = test(nodes[l][:6], tmin, closest)
+            if rr >= 0:
+                cnt.box += 1; hr, rn = test(nodes[rr][:6], tmin, closest)
+            if hl and hr:
+                if ln < rn: stack.append(rr); stack.append(l)
+                else: stack.append(l); stack.append(rr)
+            elif hl: stack.append(l)
+            elif hr: stack.append(rr)
+    return best
+
+
+class BvhScene:
+    """Scene.Hit through the restated builders and traversals instead of the brute-force loop"""
+    def __init__(self, scene):
+        self.scene = scene
+        self.cnt = Counters()
+        self.mesh = {}
+        bounds, cents = [], []
+        for i, o in enumerate(scene.Objects):
+            if isinstance(o, Mesh):
+                b, c = triangle_items(o.Triangles)
+                root, nodes, leaves = build_bvh(b, c, True, dotnet_introsort)
+                self.mesh[i] = (root, nodes, leaves)
+                bb = list(nodes[root][:6])
+            elif isinstance(o, Sphere):
+                c3, rr = [f32(v) for v in o.Center], f32(o.Radius)
+                bb = [f32(c3[0] - rr), f32(c3[1] - rr), f32(c3[2] - rr), f32(c3[0] + rr), f32(c3[1] + rr), f32(c3[2] + rr)]
+            elif isinstance(o, Plane):
+                bounds.append([f32(-1e6)] * 3 + [f32(1e6)] * 3); cents.append([f32(0)] * 3); continue
+            elif isinstance(o, XZRect):
+                bb = [f32(o.X0), f32(f32(o.Y) - f32(1e-4)), f32(o.Z0), f32(o.X1), f32(f32(o.Y) + f32(1e-4)), f32(o.Z1)]
+            elif isinstance(o, Box):
+                bb = [f32(v) for v in (*o.Min, *o.Max)]
+            else:
+                raise TypeError(type(o).__name__)
+            bounds.append(bb); cents.append([f32(f32(0.5) * f32(bb[k] + bb[3 + k])) for k in range(3)])
+        self.root, self.nodes, self.leaves = build_bvh(np.array(bounds, f32), np.array(cents, f32), False, dotnet_introsort)
+
+    def __getattr__(self, name):                          # Ambient, Lights, BackgroundTop, ... of the wrapped scene
+        return getattr(self.scene, name)
+
+    def _object_hit(self, i, r, tmin, tmax):
+        o = self.scene.Objects[i]
+        if isinstance(o, Mesh):
+            root, nodes, leaves = self.mesh[i]
+            tris = np.asarray(o.Triangles, f32).reshape(-1, 3, 3)
+            def leaf(start, count, closest):
+                best = None
+                for k in range(count):
+                    self.cnt.tri += 1
+                    h = mesh_hit(i, type("M", (), {"Triangles": tris[leaves[start + k]:leaves[start + k] + 1], "Mat": o.Mat})(), r, tmin, closest)
+                    if h is not None:
+                        best, closest = h, h.t
+                return best, closest
+            return _walk(nodes, root, r, tmin, tmax, True, leaf, self.cnt)
+        self.cnt.prim += 6 if isinstance(o, Box) else 1
+        return hit_object(i, o, r, tmin, tmax)
+
+    def hit(self, r, tmin, tmax):
+        self.cnt.rays += 1
+        def leaf(start, count, closest):
+            best = None
+            for k in range(count):
+                h = self._object_hit(self.leaves[start + k], r, tmin, closest)
+                if h is not None:
+                    best, closest = h, h.t
+            return best, closest
+        return _walk(self.nodes, self.root, r, tmin, tmax, False, leaf, self.cnt)

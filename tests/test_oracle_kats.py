@@ -578,3 +578,40 @@ def test_both_bvh_builders_against_python_restatement(case):
     mn, mx = (cc - rr).astype(f32), (cc + rr).astype(f32)
     root, nodes, leaves = pr.build_bvh(np.concatenate([mn, mx], 1), (f32(0.5) * (mn + mx)).astype(f32), False, pr.dotnet_introsort)
     assert np.array_equal(_rows(nodes).view(np.uint8), on.view(np.uint8)) and np.array_equal(np.int32(leaves), ol)
+
+
+def test_bvh_traversal_order_and_work_counters_against_python_restatement():
+    """BVH.Hit / MeshBVH.Hit (near child first, far child stacked, re-test on pop, leaf objects in order) over trees built
+    by the restated builders: same pixels AND the same work counters (Scene.Hit calls, AABB evaluations, triangle tests,
+    primitive tests) as the oracle for a whole frame - the counters are what SURVEY 8(d)'s algorithmic bytes are made of."""
+    import py_restatement as pr
+    from yetanotherconsolegameengine_amd.scene import Mesh
+    rng = np.random.RandomState(9)
+    pos, faces = scenes.make_torus_knot(18, 7)
+    tri = (pos * f32(0.3) + np.array([0.4, 1.0, -2.8], f32)).astype(f32)[faces].astype(f32)
+    s = Scene()
+    s.Ambient.Color, s.Ambient.Intensity = vec3(1, 1, 1), 0.05
+    s.Add(Plane(vec3(0, 0, 0), vec3(0, 1, 0), Solid(vec3(0.6, 0.6, 0.6)), 0.0, 0.0))
+    for k in range(11):                                      # enough objects for a real scene-level tree (leaf size 4)
+        s.Add(Sphere(vec3(*(rng.uniform(-2.5, 2.5), rng.uniform(0.2, 1.6), rng.uniform(-6.0, -2.0))), float(rng.uniform(0.15, 0.4)),
+                     Material(vec3(*rng.uniform(0.2, 0.9, 3)), 0.0, 0.95 if k == 3 else 0.0, ZERO)))
+    s.Add(Box(vec3(-2.4, 0.0, -3.4), vec3(-1.8, 0.7, -2.8), Solid(vec3(0.8, 0.5, 0.3)), 0.0, 0.0))
+    s.Objects.append(Mesh(tri, Material(vec3(0.1, 0.2, 0.85), 0.0, 0.7, ZERO)))
+    s.Add(XZRect(-0.5, 0.5, -3.0, -2.4, 2.4, Material(vec3(0, 0, 0), 0.0, 0.0, vec3(1.5, 1.5, 1.4)), 0.0, 0.0))
+    s.Lights.append(PointLight(vec3(1.0, 5.0, 0.0), vec3(1, 1, 1), 70.0))
+    pose = dict(pos=(0.0, 1.2, 0.5), yaw=0.0, pitch=-0.08, fov=55.0)
+    with ob.OracleRenderer(s, 14, 5, 1, pose) as o:
+        o.render(stages=0)
+        bs = pr.BvhScene(s)
+        assert np.array_equal(pr_rows(bs.nodes).view(np.uint8), o.accel(abi.ACCEL_SCENE_NODES).view(np.uint8))
+        p = pr.render_frame(o.L, bs, o.hiW, o.hiH, pose, 1)
+        for which, key in ((abi.BUF_CURRENT_HDR, "hdr"), (abi.BUF_G_NORMAL, "normal"), (abi.BUF_G_DEPTH, "depth")):
+            assert np.array_equal(o.read(which).view(np.uint32), np.ascontiguousarray(p[key], f32).view(np.uint32)), key
+        assert np.array_equal(o.read(abi.BUF_PRIM_ID), p["prim"])
+        st = o.stats
+        assert (int(st.n_rays), int(st.n_box), int(st.n_tri), int(st.n_prim)) == (bs.cnt.rays, bs.cnt.box, bs.cnt.tri, bs.cnt.prim)
+        assert bs.cnt.tri > 0 and len(bs.nodes) > 3
+
+
+def pr_rows(nodes):
+    return _rows(nodes)
