@@ -843,7 +843,7 @@ int begin_and_trace(ycge_ctx *c, float *d_slab, hipStream_t stream, FrameState &
     O.stack_spill = c->stack_spill.p;
     O.stack_lanes = (uint32_t)(c->n_owned > 0 ? c->n_owned : 1) * 256u * YCGE_SCHEDULE_SLACK;
     O.path_stack = c->path_stack.p;
-    const int flat = YCGE_REF_KIND(c->sd.scene_root_ref) == REF_SCENE_LEAF ? 1 : 0;
+    const int flat = (YCGE_REF_KIND(c->sd.scene_root_ref) == REF_SCENE_LEAF && !getenv("YCGE_GENERIC_WALK")) ? 1 : 0;      // YCGE_GENERIC_WALK: experiment knob, same pixels
     // Path choice.  Refraction splits need TraceFull's per-pixel LIFO -> single launch.  Otherwise: scenes
     // that are one BVH leaf (mesh viewers) are bounded by the latency chain of their few heaviest tiles, and
     // one launch lets the chains of all stages overlap (measured 0.85 vs 1.24 ms on config 4); scenes with a
