@@ -809,14 +809,14 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu((FLAT && !CO
             if (O.rng_state) O.rng_state[i] = rng;
         }
     }
-    if (O.block_cost) {     // feedback for the next frame's schedule: the block's longest lane, in traversal steps (mode-independent)
-        uint32_t m = w.steps;
-        for (int off = 32; off >= 1; off >>= 1) { const uint32_t o2 = (uint32_t)__shfl_xor((int)m, off, 64); m = o2 > m ? o2 : m; }
-        if (threadIdx.x == 0) atomicMax(O.block_cost + bid, m);
+    uint32_t wave_max_steps = w.steps;      // the block's longest lane, in traversal steps (mode-independent)
+    if (O.block_cost || prof) {
+        for (int off = 32; off >= 1; off >>= 1) { const uint32_t o2 = (uint32_t)__shfl_xor((int)wave_max_steps, off, 64); wave_max_steps = o2 > wave_max_steps ? o2 : wave_max_steps; }
+        if (O.block_cost && threadIdx.x == 0) atomicMax(O.block_cost + bid, wave_max_steps);      // feedback for the next frame's schedule
     }
     if (prof && threadIdx.x == 0 && YCGE_ENT_PART(ent) == 0) {
         unsigned long long *dst = O.wave_prof + ((size_t)k * 4 + wave_in_tile) * 4;
-        dst[0] = t_start; dst[1] = __builtin_amdgcn_s_memrealtime(); dst[2] = blockIdx.x | ((unsigned long long)w.steps << 32);
+        dst[0] = t_start; dst[1] = __builtin_amdgcn_s_memrealtime(); dst[2] = blockIdx.x | ((unsigned long long)wave_max_steps << 32);
         dst[3] = __builtin_amdgcn_s_getreg(((32 - 1) << 11) | (0 << 6) | 20) | ((unsigned long long)lg << 32);   // XCC_ID
     }
     flush_work<COUNT>(w, O.counters);
@@ -1024,8 +1024,9 @@ int ycge_launch_trace(const ycge::SceneDev *S, const ycge::FrameParams *P, const
     using namespace ycge;
     if (P->n_owned_tiles <= 0) return 0;
     const dim3 grid((unsigned)P->n_owned_tiles * 4u * YCGE_SCHEDULE_SLACK), block(64);   // schedule capacity; idle entries exit at once
+    static const unsigned lds_pad = getenv("YCGE_LDS_PAD") ? (unsigned)atoi(getenv("YCGE_LDS_PAD")) : 0u;   // experiment knob: fewer resident wavefronts
     sel3(count != 0, flat != 0, false, [&](auto C, auto F, auto) {
-        hipLaunchKernelGGL((k_trace<decltype(C)::value, decltype(F)::value>), grid, block, 0, stream, *S, *P, *O);
+        hipLaunchKernelGGL((k_trace<decltype(C)::value, decltype(F)::value>), grid, block, lds_pad, stream, *S, *P, *O);
     });
     return (int)hipGetLastError();
 }
