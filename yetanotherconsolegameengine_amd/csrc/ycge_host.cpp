@@ -242,6 +242,8 @@ int set_geometry(ycge_ctx *c, int fbw, int fbh, int ss)
     c->last_cam[0] = c->last_cam[1] = c->last_cam[2] = NAN; c->last_yaw = c->last_pitch = NAN;
     c->den_a.release(); c->den_b.release(); c->unit_n.release(); c->exp_terms.release(); c->d_sdr.release();     // spatialA / spatialB, :129-130
     c->denoised = nullptr;
+    for (auto *sc : c->schedules) { sc->pixels.release(); sc->offsets.release(); delete sc; }      // level schedules are per size: rebuilt on demand
+    c->schedules.clear();
     int rc = alloc_frame_buffers(c);
     if (rc != YCGE_OK) return rc;
     rc = alloc_tile_buffers(c);
