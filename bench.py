@@ -13,7 +13,8 @@ value   = Mrays/s over ALL rays: calls to Scene.Hit + Scene.Occluded (primary, s
           re-run with the counting kernel variant afterwards (same frame numbers, untimed).
 roofline= algorithmic bytes of k_trace per launch (32*N_box + 48*N_tri + 64*N_prim +
           1*N_vox + 118*pixels, counters from the counting replay) / its mean launch duration from
-          HIP events recorded around the kernel on its own stream inside the timed region.
+          HIP events recorded around the kernel on its own stream inside the timed region (N > 1: in a few
+          extra frames right after it, so that the timed region has no per-step host synchronisation).
 cpu_baseline = the oracle (scalar C++ restatement of the reference, all host threads) on a bounded
           sample of the same workload, rank 0, N = 1 only.  A reported baseline, not the target.
 """
@@ -72,7 +73,7 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if world != args.gpus and world > 1:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
-    multi = world > 1
+    multi = world > 1 or bool(os.environ.get("YCGE_BENCH_FORCE_TILED"))     # the env knob runs the tiled path (slab + all-gather + resolve) with one rank
 
     import torch
     if not torch.cuda.is_available():
@@ -131,9 +132,14 @@ def main():
     trace_ms = []
     t0 = time.perf_counter()
     for _ in range(args.steps):
-        trace_ms.append(step(r, want_stats=True))
+        # one GPU: ycge_render_frame times k_trace with HIP events on its own stream as part of the call.  Several GPUs:
+        # no per-step host synchronisation inside the timed region (trace -> all-gather -> resolve are queued on one stream)
+        trace_ms.append(step(r, want_stats=not multi))
     fence()
     elapsed = time.perf_counter() - t0
+    if multi:       # kernel duration for the roofline line: a few extra, untimed frames with event timing
+        trace_ms = [step(r, want_stats=True) for _ in range(4)][1:]
+        fence()
     if multi:
         te = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
         dist.all_reduce(te, op=dist.ReduceOp.MAX)
