@@ -310,7 +310,7 @@ void triangle_items(const float *t9, int32_t n, BoundsSoA &out)
 }
 
 uint32_t to_gpu_nodes(const BuiltTree &t, uint32_t node_kind, uint32_t leaf_kind, uint32_t node_base, uint32_t leaf_base,
-                      int leaf_count_bits, std::vector<GNode> &gnodes)
+                      int leaf_count_bits, std::vector<GNode> &gnodes, const std::vector<uint32_t> *leaf_slot)
 {
     if (t.root < 0) return YCGE_REF_NONE_VALUE;
     // internal nodes keep their relative (pre-)order so a subtree stays contiguous in memory
@@ -320,7 +320,10 @@ uint32_t to_gpu_nodes(const BuiltTree &t, uint32_t node_kind, uint32_t leaf_kind
         if (t.nodes[i].count == 0) inner_index[i] = (int32_t)n_inner++;
     auto ref_of = [&](int32_t ni) -> uint32_t {
         const RefNode &nd = t.nodes[ni];
-        if (nd.count > 0) return YCGE_REF(leaf_kind, ((uint32_t)(nd.start + (int32_t)leaf_base) << leaf_count_bits) | (uint32_t)nd.count);
+        if (nd.count > 0) {
+            const uint32_t start = leaf_slot ? (*leaf_slot)[(size_t)nd.start] : (uint32_t)nd.start;
+            return YCGE_REF(leaf_kind, ((start + leaf_base) << leaf_count_bits) | (uint32_t)nd.count);
+        }
         return YCGE_REF(node_kind, node_base + (uint32_t)inner_index[ni]);
     };
     const size_t base = gnodes.size();

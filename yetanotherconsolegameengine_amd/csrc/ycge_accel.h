@@ -48,8 +48,10 @@ void triangle_items(const float *tris9, int32_t n, BoundsSoA &out);
 // Convert a reference-format tree to the paired-children GPU layout.
 //   node_kind / leaf_kind : REF_SCENE_NODE/REF_SCENE_LEAF or REF_MESH_NODE/REF_MESH_LEAF
 //   node_base / leaf_base : global offsets added to internal-node indices and leaf starts
+//   leaf_slot             : optional map from a leaf's start in leaf_index to its start in the device array
+//                           (mesh leaves start on triangle-pair records); identity when null
 // Appends to gnodes; returns the reference for the root.
 uint32_t to_gpu_nodes(const BuiltTree &t, uint32_t node_kind, uint32_t leaf_kind, uint32_t node_base, uint32_t leaf_base,
-                      int leaf_count_bits, std::vector<GNode> &gnodes);
+                      int leaf_count_bits, std::vector<GNode> &gnodes, const std::vector<uint32_t> *leaf_slot = nullptr);
 
 } // namespace ycge

@@ -45,15 +45,22 @@ struct alignas(16) GNode {
 };
 static_assert(sizeof(GNode) == 64, "GNode must be 64 B");
 
-struct alignas(16) GTri {
-    float ax, ay, az, e1x;
-    float e1y, e1z, e2x, e2y;
-    float e2z;
-    int32_t orig;               // index in the mesh's input triangle order
-    int32_t material;           // material index (per-triangle or the mesh's)
-    int32_t pad;
+// Leaf triangles, TWO to a record with the components interleaved (slot 0, slot 1): a 16-byte fetch then lands
+// each component pair in an aligned register pair, and the Moller-Trumbore test of both triangles runs as packed
+// operations (v_pk_mul_f32 / v_pk_add_f32) - one traversal step per two triangles.  A leaf starts on a record
+// boundary; the second slot of a leaf's last record is all zeros when its count is odd (det = 0, and the walk
+// masks it by the count anyway).  A triangle is addressed as record * 2 + slot.
+struct alignas(16) GTriPair {
+    float ax[2], ay[2];
+    float az[2], e1x[2];
+    float e1y[2], e1z[2];
+    float e2x[2], e2y[2];
+    float e2z[2];
+    int32_t orig[2];            // index in the mesh's input triangle order
+    int32_t material[2];        // material index (per-triangle or the mesh's)
+    int32_t pad[2];
 };
-static_assert(sizeof(GTri) == 48, "GTri must be 48 B");
+static_assert(sizeof(GTriPair) == 96, "GTriPair must be 96 B");
 
 // prim types: identical numbering to ycge_prim_type in include/ycge.h
 struct alignas(16) GPrim {
@@ -128,7 +135,7 @@ struct SceneDev {
     const GNode *scene_nodes;
     const uint32_t *scene_leaf_prims;   // leafObjIndex
     const GNode *mesh_nodes;
-    const GTri *tris;
+    const GTriPair *tris;          // leaf-ordered triangle pair records
     const GPrim *prims;
     const GMaterial *materials;
     const GMesh *meshes;

@@ -136,7 +136,7 @@ struct ycge_ctx {
     SceneDev sd{};
     DevBuf<GNode> d_scene_nodes, d_mesh_nodes;
     DevBuf<uint32_t> d_scene_leaf;
-    DevBuf<GTri> d_tris;
+    DevBuf<GTriPair> d_tris;
     DevBuf<GPrim> d_prims;
     DevBuf<GMaterial> d_materials;
     DevBuf<GMesh> d_meshes;
@@ -610,7 +610,7 @@ int ycge_scene_upload(ycge_ctx *c, const ycge_scene *s)
     // ---- meshes: MeshBVH ctor (MeshBVH.cs:41-130) -> paired nodes + leaf-ordered triangles
     c->meshes.assign(s->n_meshes, MeshHost{});
     std::vector<GNode> mesh_nodes;
-    std::vector<GTri> tris;
+    std::vector<GTriPair> tris;
     std::vector<GMesh> gmeshes(s->n_meshes);
     int max_mesh_depth = 0;
     for (int mi = 0; mi < s->n_meshes; mi++) {
@@ -623,24 +623,36 @@ int ycge_scene_upload(ycge_ctx *c, const ycge_scene *s)
         build_tree(items, TreeFlavour::Mesh, t);
         if (t.max_depth > 64) return c->fail(YCGE_ERR_STACK_DEPTH, "mesh %d: BVH depth %d exceeds the reference's 64-entry stack (MeshBVH.cs:150)", mi, t.max_depth);
         if (t.max_depth > max_mesh_depth) max_mesh_depth = t.max_depth;
-        const uint32_t tri_base = (uint32_t)tris.size();
-        if ((uint64_t)tri_base + (uint64_t)m.n_triangles >= (1u << 25)) return c->fail(YCGE_ERR_UNSUPPORTED, "more than 2^25 triangles");
+        // leaves in leaf_index order, each padded to whole pair records
+        std::vector<uint32_t> leaf_slot(t.leaf_index.size() + 1, 0);
+        uint32_t n_pairs = 0;
+        for (const RefNode &nd : t.nodes) {
+            if (nd.count <= 0) continue;
+            if (nd.count > 15) return c->fail(YCGE_ERR_UNSUPPORTED, "mesh %d: leaf of %d triangles", mi, nd.count);
+            leaf_slot[(size_t)nd.start] = n_pairs;
+            n_pairs += ((uint32_t)nd.count + 1u) / 2u;
+        }
+        const uint32_t pair_base = (uint32_t)tris.size();
+        if ((uint64_t)pair_base + (uint64_t)n_pairs >= (1u << 24)) return c->fail(YCGE_ERR_UNSUPPORTED, "more than 2^24 triangle pair records");
         GMesh &gm = gmeshes[mi];
         std::memset(&gm, 0, sizeof gm);
-        gm.root_ref = to_gpu_nodes(t, REF_MESH_NODE, REF_MESH_LEAF, (uint32_t)mesh_nodes.size(), tri_base, 4, mesh_nodes);
+        gm.root_ref = to_gpu_nodes(t, REF_MESH_NODE, REF_MESH_LEAF, (uint32_t)mesh_nodes.size(), pair_base, 4, mesh_nodes, &leaf_slot);
         if (t.root >= 0) for (int a = 0; a < 3; a++) { gm.root_min[a] = t.nodes[t.root].mn[a]; gm.root_max[a] = t.nodes[t.root].mx[a]; }
-        tris.resize(tri_base + t.leaf_index.size());
-        for (size_t k = 0; k < t.leaf_index.size(); k++) {
-            const int32_t ti = t.leaf_index[k];
-            const float *v = m.triangles + 9 * (size_t)ti;
-            GTri &g = tris[tri_base + k];
-            g.ax = v[0]; g.ay = v[1]; g.az = v[2];
-            g.e1x = v[3] - v[0]; g.e1y = v[4] - v[1]; g.e1z = v[5] - v[2];        // MeshBVH.cs:87-91
-            g.e2x = v[6] - v[0]; g.e2y = v[7] - v[1]; g.e2z = v[8] - v[2];
-            g.orig = ti;
-            g.material = m.tri_material ? m.tri_material[ti] : m.material;
-            if (!mat_ok(g.material)) return c->fail(YCGE_ERR_INVALID_ARG, "mesh %d triangle %d: material out of range", mi, ti);
-            g.pad = 0;
+        tris.resize(pair_base + n_pairs);
+        std::memset((void *)(tris.data() + pair_base), 0, sizeof(GTriPair) * (size_t)n_pairs);
+        for (const RefNode &nd : t.nodes) {
+            for (int32_t k = 0; k < nd.count; k++) {
+                const int32_t ti = t.leaf_index[(size_t)(nd.start + k)];
+                const float *v = m.triangles + 9 * (size_t)ti;
+                GTriPair &g = tris[pair_base + leaf_slot[(size_t)nd.start] + (uint32_t)k / 2u];
+                const int sl = k & 1;
+                g.ax[sl] = v[0]; g.ay[sl] = v[1]; g.az[sl] = v[2];
+                g.e1x[sl] = v[3] - v[0]; g.e1y[sl] = v[4] - v[1]; g.e1z[sl] = v[5] - v[2];        // MeshBVH.cs:87-91
+                g.e2x[sl] = v[6] - v[0]; g.e2y[sl] = v[7] - v[1]; g.e2z[sl] = v[8] - v[2];
+                g.orig[sl] = ti;
+                g.material[sl] = m.tri_material ? m.tri_material[ti] : m.material;
+                if (!mat_ok(g.material[sl])) return c->fail(YCGE_ERR_INVALID_ARG, "mesh %d triangle %d: material out of range", mi, ti);
+            }
         }
     }
 

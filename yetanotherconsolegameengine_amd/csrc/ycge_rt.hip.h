@@ -660,66 +660,80 @@ struct StackT {
 };
 using Stack = StackT<256>;
 
-// MeshBVH.TriHit, MeshBVH.cs:239-304: scaled-numerator Moller-Trumbore, one divide on accept.
-struct TriData { float4 t0, t1; float e2z; };
-__device__ __forceinline__ TriData load_tri(const GTri *tp)
+// MeshBVH.TriHit, MeshBVH.cs:239-304: scaled-numerator Moller-Trumbore, one divide on accept - for the TWO
+// triangles of a GTriPair record at once.  Every product, sum and comparison is the one TriHit performs for that
+// triangle, in its order (contraction is off), evaluated for both slots by packed operations; the accepts are
+// then taken in leaf order, slot 1 against the `closest` slot 0 may just have lowered, which is what the
+// reference's loop over the leaf does (MeshBVH.cs:171-186).  No early exits: a mixed wavefront runs every branch
+// of them anyway (measured: skipping the two IEEE divisions when no lane accepts is slower than executing them).
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+struct TriPairRec { f32x4 r0, r1, r2, r3; f32x2 e2z; };
+__device__ __forceinline__ TriPairRec load_tri_pair(const GTriPair *tp)
 {
-    TriData r;
-    r.t0 = ((const float4 *)tp)[0];
-    r.t1 = ((const float4 *)tp)[1];
-    r.e2z = ((const float *)tp)[8];
+    TriPairRec r;
+    const f32x4 *q = (const f32x4 *)tp;
+    r.r0 = q[0]; r.r1 = q[1]; r.r2 = q[2]; r.r3 = q[3];
+    r.e2z = *(const f32x2 *)(q + 4);
     return r;
 }
-__device__ __forceinline__ bool tri_hit(const TriData &T, F3 o, F3 d, float tmin, float tmax, float &t)
+// `left` = triangles of the leaf still to test (>= 1; slot 1 exists when >= 2), `first` = index of slot 0
+__device__ __forceinline__ void tri_pair_hit(const TriPairRec &T, uint32_t left, uint32_t first, int mesh_prim, F3 o, F3 d, float tmin,
+                                             float &closest, int &hit_prim, int &hit_sub)
 {
-    const float ax = T.t0.x, ay = T.t0.y, az = T.t0.z, e1x = T.t0.w, e1y = T.t1.x, e1z = T.t1.y, e2x = T.t1.z, e2y = T.t1.w, e2z = T.e2z;
-    float px = d.y * e2z - d.z * e2y;
-    float py = d.z * e2x - d.x * e2z;
-    float pz = d.x * e2y - d.y * e2x;
-    float det = e1x * px + e1y * py + e1z * pz;
-    if (det > -1e-8f && det < 1e-8f) return false;
-    float sxx = o.x - ax, syy = o.y - ay, szz = o.z - az;
-    float u_num = sxx * px + syy * py + szz * pz;
-    float sgn = det > 0.0f ? 1.0f : -1.0f;
-    float det_abs = det * sgn;
-    float u_num_s = u_num * sgn;
-    if (u_num_s < 0.0f || u_num_s > det_abs) return false;
-    float qx = syy * e1z - szz * e1y;
-    float qy = szz * e1x - sxx * e1z;
-    float qz = sxx * e1y - syy * e1x;
-    float v_num = d.x * qx + d.y * qy + d.z * qz;
-    float v_num_s = v_num * sgn;
-    float uv_sum_s = u_num_s + v_num_s;
-    if (v_num_s < 0.0f || uv_sum_s > det_abs) return false;
-    float t_num = e2x * qx + e2y * qy + e2z * qz;
-    float t_num_s = t_num * sgn;
-    float t_min_scaled = tmin * det_abs;
-    float t_max_scaled = tmax * det_abs;
-    if (t_num_s < t_min_scaled || t_num_s > t_max_scaled) return false;
-    float inv_det = 1.0f / det;
-    t = t_num * inv_det;
-    return true;
+    const f32x2 ax = T.r0.xy, ay = T.r0.zw, az = T.r1.xy, e1x = T.r1.zw, e1y = T.r2.xy, e1z = T.r2.zw, e2x = T.r3.xy, e2y = T.r3.zw, e2z = T.e2z;
+    const f32x2 dx = {d.x, d.x}, dy = {d.y, d.y}, dz = {d.z, d.z};
+    const f32x2 ox = {o.x, o.x}, oy = {o.y, o.y}, oz = {o.z, o.z};
+    const f32x2 px = dy * e2z - dz * e2y;
+    const f32x2 py = dz * e2x - dx * e2z;
+    const f32x2 pz = dx * e2y - dy * e2x;
+    const f32x2 det = e1x * px + e1y * py + e1z * pz;
+    const f32x2 sxx = ox - ax, syy = oy - ay, szz = oz - az;
+    const f32x2 u_num = sxx * px + syy * py + szz * pz;
+    const f32x2 sgn = {det.x > 0.0f ? 1.0f : -1.0f, det.y > 0.0f ? 1.0f : -1.0f};
+    const f32x2 det_abs = det * sgn;
+    const f32x2 u_num_s = u_num * sgn;
+    const f32x2 qx = syy * e1z - szz * e1y;
+    const f32x2 qy = szz * e1x - sxx * e1z;
+    const f32x2 qz = sxx * e1y - syy * e1x;
+    const f32x2 v_num = dx * qx + dy * qy + dz * qz;
+    const f32x2 v_num_s = v_num * sgn;
+    const f32x2 uv_sum_s = u_num_s + v_num_s;
+    const f32x2 t_num = e2x * qx + e2y * qy + e2z * qz;
+    const f32x2 t_num_s = t_num * sgn;
+    const f32x2 tmin2 = {tmin, tmin};
+    const f32x2 t_min_scaled = tmin2 * det_abs;
+    bool ok0 = !(det.x > -1e-8f && det.x < 1e-8f);
+    ok0 &= !(u_num_s.x < 0.0f || u_num_s.x > det_abs.x);
+    ok0 &= !(v_num_s.x < 0.0f || uv_sum_s.x > det_abs.x);
+    ok0 &= !(t_num_s.x < t_min_scaled.x || t_num_s.x > closest * det_abs.x);
+    const float t_0 = t_num.x * (1.0f / det.x);
+    if (ok0) { closest = t_0; hit_prim = mesh_prim; hit_sub = (int)first; }
+    bool ok1 = left >= 2u;
+    ok1 &= !(det.y > -1e-8f && det.y < 1e-8f);
+    ok1 &= !(u_num_s.y < 0.0f || u_num_s.y > det_abs.y);
+    ok1 &= !(v_num_s.y < 0.0f || uv_sum_s.y > det_abs.y);
+    ok1 &= !(t_num_s.y < t_min_scaled.y || t_num_s.y > closest * det_abs.y);
+    const float t_1 = t_num.y * (1.0f / det.y);
+    if (ok1) { closest = t_1; hit_prim = mesh_prim; hit_sub = (int)(first + 1u); }
 }
-// One leaf (<= 8 triangles, tested in leaf order against the shrinking `closest`).  The records are
-// fetched one triangle AHEAD of the test so that a leaf costs about one memory latency, not one per
-// triangle: traversal time on this workload is the serial latency of its longest wavefronts.
+// One leaf (<= 15 triangles, tested in leaf order against the shrinking `closest`), two triangles per record.
+// The records are fetched one AHEAD of the test so that a leaf costs about one memory latency, not one per
+// record: traversal time on this workload is the serial latency of its longest wavefronts.
 template <bool COUNT>
 __device__ __forceinline__ void leaf_triangles(const SceneDev &S, uint32_t pay, int mesh_prim, F3 o, F3 d, float tmin, float &closest,
                                                int &hit_prim, int &hit_sub, Work &w)
 {
-    const uint32_t start = pay >> 4, count = pay & 15u;
-    const GTri *tp = S.tris + start;
-    TriData nxt = load_tri(tp);
-    for (uint32_t i = 0; i < count; i++) {
-        const TriData cur = nxt;
-        if (i + 1 < count) nxt = load_tri(tp + i + 1);
-        if (COUNT) w.tri++;
-        float t;
-        if (tri_hit(cur, o, d, tmin, closest, t)) {
-            closest = t;
-            hit_prim = mesh_prim;
-            hit_sub = (int)(start + i);
-        }
+    uint32_t rec = pay >> 4, left = pay & 15u;
+    if (COUNT) w.tri += (int)left;
+    TriPairRec nxt = load_tri_pair(S.tris + rec);
+    while (true) {
+        const TriPairRec cur = nxt;
+        if (left > 2u) nxt = load_tri_pair(S.tris + rec + 1u);
+        tri_pair_hit(cur, left, rec * 2u, mesh_prim, o, d, tmin, closest, hit_prim, hit_sub);
+        if (left <= 2u) break;
+        left -= 2u;
+        rec++;
     }
 }
 
@@ -835,51 +849,21 @@ __device__ __forceinline__ void walk(const SceneDev &S, uint32_t cur, int mesh_p
 // node's last 28 bytes were fetched after the node/triangle branch - a second dependent round trip per
 // visit.)  The kernel's duration is the serial latency chain of its slowest wavefront, and this form makes a
 // wavefront's iteration count ~ max over lanes of (nodes + triangles).  Visit order is unchanged.
-typedef float f32x4 __attribute__((ext_vector_type(4)));
-__device__ __forceinline__ void load_record64(const void *p, f32x4 &a, f32x4 &b, f32x4 &c, f32x4 &e)
+// a node (64 B) or a triangle pair record (its first 72 B) in one round trip: every fetch is issued before the
+// single wait.  The fifth fetch only has a use for leaf lanes; for node lanes it reads the start of the next
+// node (the arrays are padded at upload).
+__device__ __forceinline__ void load_record72(const void *p, f32x4 &a, f32x4 &b, f32x4 &c, f32x4 &e, f32x2 &f)
 {
-    asm volatile("global_load_dwordx4 %0, %4, off\n\t"
-                 "global_load_dwordx4 %1, %4, off offset:16\n\t"
-                 "global_load_dwordx4 %2, %4, off offset:32\n\t"
-                 "global_load_dwordx4 %3, %4, off offset:48\n\t"
+    asm volatile("global_load_dwordx4 %0, %5, off\n\t"
+                 "global_load_dwordx4 %1, %5, off offset:16\n\t"
+                 "global_load_dwordx4 %2, %5, off offset:32\n\t"
+                 "global_load_dwordx4 %3, %5, off offset:48\n\t"
+                 "global_load_dwordx2 %4, %5, off offset:64\n\t"
                  "s_waitcnt vmcnt(0)"
-                 : "=&v"(a), "=&v"(b), "=&v"(c), "=&v"(e)
+                 : "=&v"(a), "=&v"(b), "=&v"(c), "=&v"(e), "=&v"(f)
                  : "v"(p)
                  : "memory");
 }
-// tri_hit without early exits: the same operations in the same order, one accept mask at the end (a mixed
-// wavefront executes every early-out branch anyway; the nest of exec-mask branches only adds issue slots)
-__device__ __forceinline__ bool tri_hit_flat(f32x4 t0, f32x4 t1, float e2z, F3 o, F3 d, float tmin, float tmax, float &t)
-{
-    const float ax = t0.x, ay = t0.y, az = t0.z, e1x = t0.w, e1y = t1.x, e1z = t1.y, e2x = t1.z, e2y = t1.w;
-    float px = d.y * e2z - d.z * e2y;
-    float py = d.z * e2x - d.x * e2z;
-    float pz = d.x * e2y - d.y * e2x;
-    float det = e1x * px + e1y * py + e1z * pz;
-    bool ok = !(det > -1e-8f && det < 1e-8f);
-    float sxx = o.x - ax, syy = o.y - ay, szz = o.z - az;
-    float u_num = sxx * px + syy * py + szz * pz;
-    float sgn = det > 0.0f ? 1.0f : -1.0f;
-    float det_abs = det * sgn;
-    float u_num_s = u_num * sgn;
-    ok &= !(u_num_s < 0.0f || u_num_s > det_abs);
-    float qx = syy * e1z - szz * e1y;
-    float qy = szz * e1x - sxx * e1z;
-    float qz = sxx * e1y - syy * e1x;
-    float v_num = d.x * qx + d.y * qy + d.z * qz;
-    float v_num_s = v_num * sgn;
-    float uv_sum_s = u_num_s + v_num_s;
-    ok &= !(v_num_s < 0.0f || uv_sum_s > det_abs);
-    float t_num = e2x * qx + e2y * qy + e2z * qz;
-    float t_num_s = t_num * sgn;
-    float t_min_scaled = tmin * det_abs;
-    float t_max_scaled = tmax * det_abs;
-    ok &= !(t_num_s < t_min_scaled || t_num_s > t_max_scaled);
-    float inv_det = 1.0f / det;
-    t = t_num * inv_det;
-    return ok;
-}
-typedef float f32x2 __attribute__((ext_vector_type(2)));
 template <bool COUNT, class STK>
 __device__ __forceinline__ void mesh_walk(const SceneDev &S, uint32_t cur, int mesh_prim, STK &st, F3 o, F3 inv, F3 d, bool sx, bool sy,
                                           bool sz, float tmin, float &closest, int &hit_prim, int &hit_sub, Work &w)
@@ -893,10 +877,11 @@ __device__ __forceinline__ void mesh_walk(const SceneDev &S, uint32_t cur, int m
     while (cur != YCGE_REF_NONE_VALUE) {
         const bool is_node = YCGE_REF_KIND(cur) == REF_MESH_NODE;
         const uint32_t pay = YCGE_REF_PAYLOAD(cur);
-        const uint32_t tri_index = pay >> 4;
-        const void *addr = is_node ? (const void *)(S.mesh_nodes + pay) : (const void *)(S.tris + tri_index);
+        const uint32_t rec = pay >> 4;
+        const void *addr = is_node ? (const void *)(S.mesh_nodes + pay) : (const void *)(S.tris + rec);
         f32x4 a, b, c, e;
-        load_record64(addr, a, b, c, e);
+        f32x2 f;
+        load_record72(addr, a, b, c, e, f);
         if (COUNT) prof_tick(0);
         w.steps++;
         uint32_t next;
@@ -914,11 +899,12 @@ __device__ __forceinline__ void mesh_walk(const SceneDev &S, uint32_t cur, int m
             if (hl & hr) st.push(left_first ? rref : lref, left_first ? rn : ln);
             next = (hl & hr) ? (left_first ? lref : rref) : hl ? lref : hr ? rref : YCGE_REF_NONE_VALUE;
         } else {
-            if (COUNT) w.tri++;
-            float t;
-            if (tri_hit_flat(a, b, c.x, o, d, tmin, closest, t)) { closest = t; hit_prim = mesh_prim; hit_sub = (int)tri_index; }
-            const uint32_t left = (pay & 15u) - 1u;
-            next = left ? YCGE_REF(REF_MESH_LEAF, ((tri_index + 1u) << 4) | left) : YCGE_REF_NONE_VALUE;
+            const uint32_t left = pay & 15u;
+            if (COUNT) w.tri += left >= 2u ? 2 : 1;
+            TriPairRec T;
+            T.r0 = a; T.r1 = b; T.r2 = c; T.r3 = e; T.e2z = f;
+            tri_pair_hit(T, left, rec * 2u, mesh_prim, o, d, tmin, closest, hit_prim, hit_sub);
+            next = left > 2u ? YCGE_REF(REF_MESH_LEAF, ((rec + 1u) << 4) | (left - 2u)) : YCGE_REF_NONE_VALUE;
         }
         cur = next;
         if (cur == YCGE_REF_NONE_VALUE) {
@@ -997,9 +983,9 @@ __device__ __forceinline__ void resolve_hit(const SceneDev &S, int prim_index, i
     bool wire_black = false;
     h.sub_public = sub;
     if (type == 9) {    // MeshBVH.cs:177-185
-        const float4 *tp = (const float4 *)(S.tris + sub);
-        const float4 t0 = tp[0], t1 = tp[1], t2 = tp[2];
-        const float e1x = t0.w, e1y = t1.x, e1z = t1.y, e2x = t1.z, e2y = t1.w, e2z = t2.x;
+        const GTriPair *tp = S.tris + ((uint32_t)sub >> 1);
+        const int sl = sub & 1;
+        const float e1x = tp->e1x[sl], e1y = tp->e1y[sl], e1z = tp->e1z[sl], e2x = tp->e2x[sl], e2y = tp->e2y[sl], e2z = tp->e2z[sl];
         // unit normal exactly as the MeshBVH ctor computes it, MeshBVH.cs:93-97
         float nnx = e1y * e2z - e1z * e2y;
         float nny = e1z * e2x - e1x * e2z;
@@ -1009,8 +995,8 @@ __device__ __forceinline__ void resolve_hit(const SceneDev &S, int prim_index, i
         h.p = f3(o.x + t * d.x, o.y + t * d.y, o.z + t * d.z);
         float ndotd = nx * d.x + ny * d.y + nz * d.z;
         h.n = ndotd < 0.0f ? f3(nx, ny, nz) : f3(-nx, -ny, -nz);
-        material = __float_as_int(t2.z);
-        h.sub_public = __float_as_int(t2.y);
+        material = tp->material[sl];
+        h.sub_public = tp->orig[sl];
     } else if (type == 10) {   // VolumeGrid.cs:160-198
         if (HAS_GRID) {
             const GGrid g = S.grids[__float_as_int(q0.z)];
