@@ -33,3 +33,13 @@ print('wave model (sum over queries of block max): max',mk.max(), ' per-pixel-su
 q2=(q-tri)+(tri+1)//2
 mk2=sum(blockmax(q2[:,k].astype(np.int64)) for k in range(8))
 print('wave model with 2 triangles per step: max',mk2.max(),'(now',mk.max(),')')
+
+# query fan-out: the queries of one hit (shadow rays + bounce) traced side by side, per 8x8 block
+bm = lambda k: blockmax(q2[:, k].astype(np.int64))
+fan = bm(0) + np.maximum(np.maximum(bm(1), bm(2)), bm(3)) + np.maximum(bm(4), bm(5)) + bm(6) + bm(7)
+print('fan-out wave model (2 tris/step): max', fan.max(), 'vs', mk2.max())
+for thr in (128, 192, 256, 384):
+    sel = mk2 >= thr
+    print(f'  blocks with wave model >= {thr}: {int(sel.sum())}; after fan-out their max {fan[sel].max()}, median ratio {np.median(fan[sel] / mk2[sel]):.2f}')
+order = np.argsort(-mk2.ravel())[:10]
+print('  heaviest blocks now -> fanned:', [(int(mk2.ravel()[i]), int(fan.ravel()[i])) for i in order])

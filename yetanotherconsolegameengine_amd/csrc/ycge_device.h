@@ -126,6 +126,8 @@ struct GLight {
 
 #define YCGE_TRAVERSAL_STACK 96    // >= scene depth + 4 leaf prims + mesh depth, checked at upload
 #define YCGE_SCHEDULE_SLACK 2u      // k_trace grid = blocks x this: room for the parts of split blocks
+#define YCGE_FAN_CLASS_DEFAULT 0u     // k_trace_fan off by default (measured: no gain, see DESIGN); YCGE_FAN=<class> turns it on for classes >= that
+#define YCGE_FAN_CAP_DEFAULT 2048u   // ... at most this many
 #define YCGE_TILE_W 32
 #define YCGE_TILE_H 8
 #define YCGE_SLAB_FLOATS 11        // hdr rgb, albedo rgb, normal xyz, depth, sky
@@ -193,6 +195,7 @@ struct TraceOut {
     // traversal-stack overflow area [level][global lane] and refraction path stack [slot][field][global lane]
     void *stack_spill;                  // uint2 entries {ref, tNear}
     uint32_t stack_lanes;
+    uint32_t lane_base;                 // first column of this launch (k_trace_fan runs beside k_trace)
     float *path_stack;
     // per-wavefront profile of k_wf_primary (COUNT variant; may be null): 4 x u64 {start, end, node iters, leaf phases}
     unsigned long long *wave_prof;
@@ -203,6 +206,7 @@ struct TraceOut {
     uint32_t *block_cost;
     const uint32_t *block_order;
     const uint32_t *n_order;
+    const uint32_t *n_fan;              // the first *n_fan schedule entries are traced by k_trace_fan (null or 0: none)
     // traversal counters (may be null): rays, box, tri, prim, vox
     unsigned long long *counters;
 };

@@ -25,7 +25,10 @@ size_t ycge_wf_sizes(int which);
 int ycge_launch_trace(const ycge::SceneDev *S, const ycge::FrameParams *P, const ycge::TraceOut *O, int count, int flat, hipStream_t stream);
 int ycge_launch_wavefront(const ycge::SceneDev *S, const ycge::FrameParams *P, const ycge::TraceOut *O, void *const bufs[7], int rounds,
                           int has_grid, int flat, int count, int persistent_waves, hipStream_t stream);
-int ycge_launch_order_blocks(uint32_t *cost, uint32_t n, uint32_t policy, uint32_t *order_ws, uint32_t *order, hipStream_t stream);
+int ycge_launch_order_blocks(uint32_t *cost, uint32_t n, uint32_t policy, uint32_t fan_class, uint32_t fan_cap, uint32_t *order_ws, uint32_t *order,
+                             hipStream_t stream);
+int ycge_launch_trace_fan(const ycge::SceneDev *S, const ycge::FrameParams *P, const ycge::TraceOut *O, int count, int flat, uint32_t fan_cap,
+                          hipStream_t stream);
 int ycge_launch_taa(const ycge::TaaParams *T, const float *current, const float *normal, const float *depth, const uint8_t *sky,
                     float *hist, float *prev_normal, float *prev_depth, uint8_t *prev_sky, hipStream_t stream);
 size_t ycge_post_state_bytes(void);
@@ -82,6 +85,10 @@ struct ycge_ctx {
     int device = 0;
     hipStream_t stream = nullptr;
     hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
+    // k_trace runs beside k_trace_fan on a side stream, forked from and joined to the frame's stream
+    hipStream_t fan_stream = nullptr;
+    hipEvent_t fan_ev[2] = {nullptr, nullptr};
+    uint32_t fan_class = 0, fan_cap = 0;       // schedule classes >= fan_class are fanned, at most fan_cap blocks (0 = off)
     char device_name[256] = {0};
     int compute_units = 0;
 
@@ -188,7 +195,7 @@ int alloc_frame_buffers(ycge_ctx *c)
 int alloc_tile_buffers(ycge_ctx *c)
 {
     const size_t lanes = (size_t)(c->n_owned > 0 ? c->n_owned : 1) * 256;
-    const size_t stack_lanes = lanes * YCGE_SCHEDULE_SLACK;      // k_trace's grid includes the schedule's slack entries
+    const size_t stack_lanes = lanes * YCGE_SCHEDULE_SLACK + (size_t)c->fan_cap * 192;      // k_trace's grid includes the schedule's slack entries; k_trace_fan's columns follow
     HIP_TRY(c, c->wf_q0.alloc(lanes * ycge_wf_sizes(0))); HIP_TRY(c, c->wf_q1.alloc(lanes * ycge_wf_sizes(0)));
     HIP_TRY(c, c->wf_hit.alloc(lanes * ycge_wf_sizes(1))); HIP_TRY(c, c->wf_lq.alloc(lanes * ycge_wf_sizes(2)));
     HIP_TRY(c, c->wf_seg.alloc(4));
@@ -197,7 +204,8 @@ int alloc_tile_buffers(ycge_ctx *c)
     c->path_stack.release();
     {
         const size_t nb = (size_t)(c->n_owned > 0 ? c->n_owned : 1) * 4;
-        HIP_TRY(c, c->block_cost.alloc(nb)); HIP_TRY(c, c->block_order.alloc(nb * YCGE_SCHEDULE_SLACK)); HIP_TRY(c, c->order_ws.alloc(18));
+        HIP_TRY(c, c->block_cost.alloc(nb)); HIP_TRY(c, c->block_order.alloc(nb * YCGE_SCHEDULE_SLACK)); HIP_TRY(c, c->order_ws.alloc(20));
+        HIP_TRY(c, hipMemset(c->order_ws.p, 0, 20 * sizeof(uint32_t)));
         HIP_TRY(c, hipMemset(c->block_cost.p, 0, nb * sizeof(uint32_t)));
         c->block_order_valid = false;
     }
@@ -427,6 +435,13 @@ int ycge_create(const ycge_config *cfg, ycge_ctx **out)
     if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess) { c->err = "hipStreamCreate failed"; return bail(YCGE_ERR_DEVICE); }
     for (auto &ev : c->ev)
         if (hipEventCreate(&ev) != hipSuccess) { c->err = "hipEventCreate failed"; return bail(YCGE_ERR_DEVICE); }
+    {
+        if (hipStreamCreateWithFlags(&c->fan_stream, hipStreamNonBlocking) != hipSuccess) { c->err = "hipStreamCreate failed"; return bail(YCGE_ERR_DEVICE); }
+        for (auto &ev : c->fan_ev)
+            if (hipEventCreateWithFlags(&ev, hipEventDisableTiming) != hipSuccess) { c->err = "hipEventCreate failed"; return bail(YCGE_ERR_DEVICE); }
+        c->fan_class = getenv("YCGE_FAN") ? (uint32_t)atoi(getenv("YCGE_FAN")) : YCGE_FAN_CLASS_DEFAULT;
+        c->fan_cap = c->fan_class ? (getenv("YCGE_FAN_CAP") ? (uint32_t)atoi(getenv("YCGE_FAN_CAP")) : YCGE_FAN_CAP_DEFAULT) : 0u;
+    }
     int rc = set_geometry(c, cfg->fb_width, cfg->fb_height, cfg->super_sample);
     if (rc != YCGE_OK) return bail(rc);
     *out = c;
@@ -448,6 +463,8 @@ void ycge_destroy(ycge_ctx *c)
     c->d_scene_nodes.release(); c->d_mesh_nodes.release(); c->d_scene_leaf.release(); c->d_tris.release(); c->d_prims.release();
     c->d_materials.release(); c->d_meshes.release(); c->d_grids.release(); c->d_cells.release(); c->d_lut.release(); c->d_lights.release();
     for (auto &ev : c->ev) if (ev) (void)hipEventDestroy(ev);
+    for (auto &ev : c->fan_ev) if (ev) (void)hipEventDestroy(ev);
+    if (c->fan_stream) (void)hipStreamDestroy(c->fan_stream);
     if (c->stream) (void)hipStreamDestroy(c->stream);
     delete c;
 }
@@ -855,7 +872,8 @@ int begin_and_trace(ycge_ctx *c, float *d_slab, hipStream_t stream, FrameState &
     if (timed) HIP_TRY(c, hipEventRecord(c->ev[0], stream));
     int e;
     O.stack_spill = c->stack_spill.p;
-    O.stack_lanes = (uint32_t)(c->n_owned > 0 ? c->n_owned : 1) * 256u * YCGE_SCHEDULE_SLACK;
+    const uint32_t trace_lanes = (uint32_t)(c->n_owned > 0 ? c->n_owned : 1) * 256u * YCGE_SCHEDULE_SLACK;
+    O.stack_lanes = trace_lanes + c->fan_cap * 192u;
     O.path_stack = c->path_stack.p;
     const int flat = (YCGE_REF_KIND(c->sd.scene_root_ref) == REF_SCENE_LEAF && !getenv("YCGE_GENERIC_WALK")) ? 1 : 0;      // YCGE_GENERIC_WALK: experiment knob, same pixels
     // Path choice.  Refraction splits need TraceFull's per-pixel LIFO -> single launch.  Otherwise: scenes
@@ -870,10 +888,26 @@ int begin_and_trace(ycge_ctx *c, float *d_slab, hipStream_t stream, FrameState &
         O.block_cost = lpt ? c->block_cost.p : nullptr;
         O.block_order = (lpt && c->block_order_valid) ? c->block_order.p : nullptr;
         O.n_order = c->order_ws.p + 16;
-        e = ycge_launch_trace(&c->sd, &P, &O, c->cfg.count_work, flat, stream);
+        // the schedule's head (the heaviest blocks of the previous frame) goes to k_trace_fan, launched first and beside k_trace
+        const bool fan = O.block_order != nullptr && c->fan_cap > 0;
+        if (fan) {
+            // k_trace_fan goes FIRST and on the frame's stream, so that its blocks - the frame's longest chains - are resident from
+            // t = 0; the rest of the schedule follows on the side stream (forked before, joined after) and fills in around them
+            O.n_fan = c->order_ws.p + 18;
+            TraceOut OF = O;
+            OF.lane_base = trace_lanes;
+            HIP_TRY(c, hipEventRecord(c->fan_ev[0], stream));
+            e = ycge_launch_trace_fan(&c->sd, &P, &OF, c->cfg.count_work, flat, c->fan_cap, stream);
+            if (e != 0) return c->fail(YCGE_ERR_DEVICE, "k_trace_fan launch failed: %s", hipGetErrorString((hipError_t)e));
+            HIP_TRY(c, hipStreamWaitEvent(c->fan_stream, c->fan_ev[0], 0));
+            e = ycge_launch_trace(&c->sd, &P, &O, c->cfg.count_work, flat, c->fan_stream);
+            HIP_TRY(c, hipEventRecord(c->fan_ev[1], c->fan_stream));
+            HIP_TRY(c, hipStreamWaitEvent(stream, c->fan_ev[1], 0));
+        } else
+            e = ycge_launch_trace(&c->sd, &P, &O, c->cfg.count_work, flat, stream);
         if (e == 0 && lpt) {
             static const uint32_t policy = getenv("YCGE_SPLIT") ? (uint32_t)strtoul(getenv("YCGE_SPLIT"), nullptr, 8) : 0u;   // octal: digit c = log2(parts) of class c
-            e = ycge_launch_order_blocks(c->block_cost.p, (uint32_t)c->n_owned * 4u, policy, c->order_ws.p, c->block_order.p, stream);
+            e = ycge_launch_order_blocks(c->block_cost.p, (uint32_t)c->n_owned * 4u, policy, c->fan_class, c->fan_cap, c->order_ws.p, c->block_order.p, stream);
             c->block_order_valid = true;
         }
     } else {

@@ -533,8 +533,8 @@ struct PathItem {       // PathWorkItem, RaytraceRenderer.cs:439-446 (IsPrimary 
 // TraceFull's PathWorkItem stack (RaytraceRenderer.cs:450-453) lives in HBM, [slot][field][global lane]:
 // it is touched only on refraction splits, and a private array would make the whole kernel scratch-backed.
 struct PathStack {
-    float *base; uint32_t lanes;
-    __device__ __forceinline__ float *at(int slot, int field) const { return base + ((size_t)(slot * 11 + field) * lanes + (blockIdx.x * blockDim.x + threadIdx.x)); }
+    float *base; uint32_t lanes, lane_base;
+    __device__ __forceinline__ float *at(int slot, int field) const { return base + ((size_t)(slot * 11 + field) * lanes + (lane_base + blockIdx.x * blockDim.x + threadIdx.x)); }
     __device__ __forceinline__ void store(int slot, const PathItem &it) const
     {
         *at(slot, 0) = it.o.x; *at(slot, 1) = it.o.y; *at(slot, 2) = it.o.z; *at(slot, 3) = it.d.x; *at(slot, 4) = it.d.y; *at(slot, 5) = it.d.z;
@@ -561,25 +561,50 @@ struct PathStack {
 #define YCGE_ENT_BLOCK(e) ((e) & 0x3fffffu)
 #define YCGE_ENT_PART(e) (((e) >> 22) & 63u)
 #define YCGE_ENT_LG(e) ((e) >> 28)
-template <bool COUNT, bool FLAT>
-__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu((FLAT && !COUNT) ? 3 : 2, 8))) void k_trace(const SceneDev S, const FrameParams P, const TraceOut O)
+// Query fan-out (k_trace_fan): the heaviest blocks of the previous frame get THREE wavefronts.  The queries a
+// diffuse hit gives rise to - the first shadow segment towards each of the first two lit lights, and the bounce
+// ray - depend on the hit but not on each other (TraceFull only consumes them one after the other,
+// RaytraceRenderer.cs:578-616; the bounce direction is the next draw of the pixel's generator whatever the shadow
+// rays return), so the three wavefronts trace them side by side and wavefront 0 then runs TraceFull's loop over
+// the stored answers in the reference's order: same queries, same answers, same additions in the same order.  A
+// block's chain becomes  primary + max(shadow, shadow, bounce) + max(shadow, shadow)  instead of the sum of the six.
+// Every other query (path items of refractive hits, later transmittance segments, a third light) goes through
+// slot 0 one at a time.  Slots live in LDS; a stage boundary is one workgroup barrier.
+struct FanShared {
+    float q[3][8][64];          // slot, {o xyz, d xyz, tmin (< 0: empty), tmax}, lane
+    float r[3][3][64];          // slot, {t, prim, sub}, lane
+    uint32_t iters[3];          // traversal loop iterations per wavefront (summed into the block's cost)
+    int alive;
+};
+__device__ __forceinline__ void fan_post(FanShared *F, int slot, int lane, F3 o, F3 d, float tmin, float tmax)
+{
+    F->q[slot][0][lane] = o.x; F->q[slot][1][lane] = o.y; F->q[slot][2][lane] = o.z;
+    F->q[slot][3][lane] = d.x; F->q[slot][4][lane] = d.y; F->q[slot][5][lane] = d.z;
+    F->q[slot][6][lane] = tmin; F->q[slot][7][lane] = tmax;
+}
+
+__device__ __forceinline__ uint32_t wave_umax(uint32_t v)
+{
+    for (int off = 32; off >= 1; off >>= 1) { const uint32_t o2 = (uint32_t)__shfl_xor((int)v, off, 64); v = o2 > v ? o2 : v; }
+    return v;
+}
+
+template <bool COUNT, bool FLAT, bool FAN>
+__device__ __forceinline__ void trace_block(const SceneDev &S, const FrameParams &P, const TraceOut &O, const uint32_t ent, const uint32_t sched_index,
+                                            FanShared *F)
 {
     const bool DEBUG = O.prim_id != nullptr;
-    uint32_t ent = blockIdx.x;
-    if (O.block_order) {
-        if (blockIdx.x >= *O.n_order) return;
-        ent = O.block_order[blockIdx.x];
-    } else if (blockIdx.x >= (uint32_t)P.n_owned_tiles * 4u) return;
     Work w = {0, 0, 0, 0, 0, 0};
-    StackT<64> st;
-    st.init(O.stack_spill, O.stack_lanes);
-    const PathStack pstack = {O.path_stack, O.stack_lanes};
-    const uint32_t bid = YCGE_ENT_BLOCK(ent), lg = YCGE_ENT_LG(ent);
+    StackT<FAN ? 192 : 64> st;
+    st.init(O.stack_spill, O.stack_lanes, O.lane_base);
+    const PathStack pstack = {O.path_stack, O.stack_lanes, O.lane_base};
+    const int lane = (int)(threadIdx.x & 63u), wave = FAN ? (int)(threadIdx.x >> 6) : 0;
+    const uint32_t bid = YCGE_ENT_BLOCK(ent), lg = FAN ? 0u : YCGE_ENT_LG(ent);
     const int k = (int)(bid >> 2), wave_in_tile = (int)(bid & 3);
     const int live_lanes = 64 >> lg;
-    const int pix_in_block = (int)YCGE_ENT_PART(ent) * live_lanes + (int)threadIdx.x;
+    const int pix_in_block = (int)(FAN ? 0u : YCGE_ENT_PART(ent)) * live_lanes + lane;
     int px, py, lx, ly;
-    const bool in_image = tile_pixel_wl(P, k, wave_in_tile, pix_in_block & 63, px, py, lx, ly) && (int)threadIdx.x < live_lanes;
+    const bool in_image = tile_pixel_wl(P, k, wave_in_tile, pix_in_block & 63, px, py, lx, ly) && lane < live_lanes;
     const bool prof = O.wave_prof && O.wave_prof_stage == 2;
     const unsigned long long t_start = __builtin_amdgcn_s_memrealtime();     // 100 MHz, chip-wide
     if (lg) __builtin_amdgcn_s_setprio(3);      // the frame's critical path: issue priority over the light blocks sharing the SIMD
@@ -587,7 +612,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu((FLAT && !CO
     RayQ q;
     make_primary_ray(P, px, py, q.o, q.d);
     q.tmin = 0.001f; q.tmax = YCGE_FLT_MAX;
-    if (in_image && O.rays) {
+    if (in_image && O.rays && wave == 0) {
         float *r = O.rays + ((size_t)px + (size_t)py * P.hiW) * 6;
         r[0] = q.o.x; r[1] = q.o.y; r[2] = q.o.z; r[3] = q.d.x; r[4] = q.d.y; r[5] = q.d.z;
     }
@@ -607,15 +632,37 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu((FLAT && !CO
     int light = 0;
     float tr_r = 1.0f, tr_g = 1.0f, tr_b = 1.0f, sh_maxdist = 0.0f;
     int tr_counter = 0;
-    int phase = in_image ? PH_PATH : PH_DONE;
+    int phase = (in_image && wave == 0) ? PH_PATH : PH_DONE;
+    // fan-out state (FAN only): `want` = where the answer to the pending query q is (slot 0-2, 3 = the bounce answer
+    // held in registers), parked = that answer is still to be traced by the next stage B
+    int want = 0, pre_l1 = -1, pre_l2 = -1, pre_b_prim = -1, pre_b_sub = 0;
+    float pre_b_t = 0.0f;
+    bool parked = FAN, pre_b = false, bounce_in_flight = false;
+    // the block's cost for the next frame's schedule: loop iterations its wavefront(s) spend in traversal = sum over the
+    // query batches of the longest lane's steps.  The same scale whether the block is fanned or not.
+    uint32_t wave_iters = 0;
+    if (FAN) {
+        F->q[wave][6][lane] = -1.0f;
+        if (phase != PH_DONE) fan_post(F, 0, lane, q.o, q.d, q.tmin, q.tmax);      // the primary query
+    }
 
+  for (;;) {          // FAN: one round = stage A (wavefront 0 consumes answers, posts queries) + stage B (all trace)
+   if (!FAN || wave == 0) {
     for (;;) {
-        if (!__any(phase != PH_DONE)) break;
+        if (!__any(phase != PH_DONE && !parked)) break;
         float t_hit = 0.0f;
         int hit_prim = -1, hit_sub = 0;
-        if (phase != PH_DONE) traverse<COUNT, true, FLAT>(S, q, st, t_hit, hit_prim, hit_sub, w);
-        if (phase == PH_DONE) continue;
+        const uint32_t steps_before = w.steps;
+        if (phase != PH_DONE && !parked) {
+            if (!FAN) traverse<COUNT, true, FLAT>(S, q, st, t_hit, hit_prim, hit_sub, w);
+            else if (want == 3) { t_hit = pre_b_t; hit_prim = pre_b_prim; hit_sub = pre_b_sub; }
+            else { t_hit = F->r[want][0][lane]; hit_prim = __float_as_int(F->r[want][1][lane]); hit_sub = __float_as_int(F->r[want][2][lane]); }
+        }
+        if (!FAN) wave_iters += wave_umax(w.steps - steps_before);
+        if (phase == PH_DONE || parked) continue;
         const bool hit = hit_prim >= 0;
+        int new_kind = 0;       // the next query: 1 = first shadow segment towards `light`, 2 = bounce, 0 = anything else
+        bool fanned = false;
 
         bool go_lights = false, go_next_light = false, go_contrib = false, go_next_item = false;
         if (phase == PH_PATH) {
@@ -699,6 +746,30 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu((FLAT && !CO
                     sh_wo = normalized(q.d * -1.0f);
                     light = 0;
                     go_lights = true;
+                    if (FAN) {          // post this hit's independent queries: the expressions of the light loop head and the bounce below
+                        int ns = 0;
+                        pre_l1 = pre_l2 = -1;
+                        pre_b = false;
+                        for (int li = 0; li < S.n_lights && ns < 2; li++) {
+                            const GLight &L = S.lights[li];
+                            F3 to_l = f3(L.pos) - sh_p;
+                            float dist2 = dot(to_l, to_l);
+                            float dist = cs_sqrt(dist2);
+                            F3 ldir = vdiv(to_l, dist);
+                            float n_dot_l = cs_max(0.0f, dot(sh_n, ldir));
+                            if (n_dot_l <= 0.0f) continue;
+                            fan_post(F, 1 + ns, lane, sh_p + sh_n * P.eps, normalized(ldir), S.is_volume_scene ? 0.001f : 0.0f + P.eps, dist - P.eps);
+                            if (ns == 0) pre_l1 = li; else pre_l2 = li;
+                            ns++;
+                        }
+                        if (diffuse_depth < P.diffuse_bounces) {
+                            uint64_t rng_peek = rng;        // the draw itself happens at the bounce, below
+                            F3 bounce = cosine_sample_hemisphere(sh_n, rng_peek);
+                            fan_post(F, 0, lane, sh_p + sh_n * P.eps, normalized(bounce), 0.001f, YCGE_FLT_MAX);
+                            bounce_in_flight = true;
+                        }
+                        fanned = ns > 0 || bounce_in_flight;
+                    }
                 }
             }
         } else if (phase == PH_SHADOW_OCC) {            // VolumeScene: binary occlusion, :761-765
@@ -762,6 +833,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu((FLAT && !CO
                 if (S.is_volume_scene) { q.tmin = 0.001f; phase = PH_SHADOW_OCC; }
                 else { q.tmin = 0.0f + P.eps; tr_r = tr_g = tr_b = 1.0f; tr_counter = 0; phase = PH_SHADOW_TR; }
                 queued = true;
+                new_kind = 1;
                 break;
             }
             if (!queued) {                              // bounce, :604-616
@@ -776,6 +848,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu((FLAT && !CO
                     beta = f3(beta.x * mult.x, beta.y * mult.y, beta.z * mult.z);
                     diffuse_depth++;
                     phase = PH_PATH;
+                    new_kind = 2;
                 } else {
                     go_next_item = true;
                 }
@@ -793,8 +866,48 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu((FLAT && !CO
                 phase = PH_PATH;
             }
         }
-    }
 
+        if (FAN && phase != PH_DONE) {                  // where is the answer to the query just set up?
+            if (new_kind == 1 && light == pre_l1) { want = 1; pre_l1 = -1; }
+            else if (new_kind == 1 && light == pre_l2) { want = 2; pre_l2 = -1; }
+            else if (new_kind == 2 && (pre_b || bounce_in_flight)) { want = 3; pre_b = false; }
+            else { fan_post(F, 0, lane, q.o, q.d, q.tmin, q.tmax); want = 0; parked = true; }
+            if (fanned) parked = true;
+        }
+    }
+    if (FAN) { const bool alive = __any(phase != PH_DONE); if (lane == 0) F->alive = alive ? 1 : 0; }
+   }
+   if (!FAN) break;
+   __syncthreads();
+   if (!F->alive) break;
+   {    // ---- stage B: wavefront w answers slot w
+        const float f_tmin = F->q[wave][6][lane];
+        const uint32_t steps_before = w.steps;
+        if (f_tmin >= 0.0f) {
+            RayQ fq;
+            fq.o = f3(F->q[wave][0][lane], F->q[wave][1][lane], F->q[wave][2][lane]);
+            fq.d = f3(F->q[wave][3][lane], F->q[wave][4][lane], F->q[wave][5][lane]);
+            fq.tmin = f_tmin; fq.tmax = F->q[wave][7][lane];
+            float f_t; int f_prim, f_sub;
+            traverse<COUNT, true, FLAT>(S, fq, st, f_t, f_prim, f_sub, w);
+            F->r[wave][0][lane] = f_t; F->r[wave][1][lane] = __int_as_float(f_prim); F->r[wave][2][lane] = __int_as_float(f_sub);
+            F->q[wave][6][lane] = -1.0f;
+        }
+        wave_iters += wave_umax(w.steps - steps_before);
+   }
+   __syncthreads();
+   parked = false;
+   if (bounce_in_flight) {      // slot 0 is needed for the queries that go one at a time: keep the bounce answer in registers
+        pre_b_t = F->r[0][0][lane]; pre_b_prim = __float_as_int(F->r[0][1][lane]); pre_b_sub = __float_as_int(F->r[0][2][lane]);
+        bounce_in_flight = false; pre_b = true;
+   }
+  }
+
+    if (FAN) {
+        if (lane == 0) F->iters[wave] = wave_iters;
+        __syncthreads();
+        if (wave != 0) { flush_work<COUNT>(w, O.counters); return; }
+    }
     if (in_image) {                                     // :210-215
         const size_t i = (size_t)px + (size_t)py * P.hiW;
         O.current_hdr[3 * i + 0] = radiance.x; O.current_hdr[3 * i + 1] = radiance.y; O.current_hdr[3 * i + 2] = radiance.z;
@@ -809,29 +922,48 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu((FLAT && !CO
             if (O.rng_state) O.rng_state[i] = rng;
         }
     }
-    uint32_t wave_max_steps = w.steps;      // the block's longest lane, in traversal steps (mode-independent)
-    if (O.block_cost || prof) {
-        for (int off = 32; off >= 1; off >>= 1) { const uint32_t o2 = (uint32_t)__shfl_xor((int)wave_max_steps, off, 64); wave_max_steps = o2 > wave_max_steps ? o2 : wave_max_steps; }
-        if (O.block_cost && threadIdx.x == 0) atomicMax(O.block_cost + bid, wave_max_steps);      // feedback for the next frame's schedule
-    }
-    if (prof && threadIdx.x == 0 && YCGE_ENT_PART(ent) == 0) {
+    const uint32_t wave_max_steps = FAN ? F->iters[0] + F->iters[1] + F->iters[2] : wave_iters;
+    if (O.block_cost && lane == 0) atomicMax(O.block_cost + bid, wave_max_steps);      // feedback for the next frame's schedule
+    if (prof && lane == 0 && (FAN || YCGE_ENT_PART(ent) == 0)) {
         unsigned long long *dst = O.wave_prof + ((size_t)k * 4 + wave_in_tile) * 4;
-        dst[0] = t_start; dst[1] = __builtin_amdgcn_s_memrealtime(); dst[2] = blockIdx.x | ((unsigned long long)wave_max_steps << 32);
-        dst[3] = __builtin_amdgcn_s_getreg(((32 - 1) << 11) | (0 << 6) | 20) | ((unsigned long long)lg << 32);   // XCC_ID
+        dst[0] = t_start; dst[1] = __builtin_amdgcn_s_memrealtime(); dst[2] = sched_index | ((unsigned long long)wave_max_steps << 32);
+        dst[3] = __builtin_amdgcn_s_getreg(((32 - 1) << 11) | (0 << 6) | 20) | ((unsigned long long)(FAN ? 7u : lg) << 32);   // XCC_ID; 7 = fanned block
     }
     flush_work<COUNT>(w, O.counters);
 }
 
+#ifndef YCGE_TRACE_WAVES
+#define YCGE_TRACE_WAVES 3
+#endif
+template <bool COUNT, bool FLAT>
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu((FLAT && !COUNT) ? YCGE_TRACE_WAVES : 2, 8))) void k_trace(const SceneDev S, const FrameParams P, const TraceOut O)
+{
+    uint32_t idx = blockIdx.x, ent = blockIdx.x;
+    if (O.block_order) {
+        if (O.n_fan) idx += *O.n_fan;           // the first n_fan entries belong to k_trace_fan
+        if (idx >= *O.n_order) return;
+        ent = O.block_order[idx];
+    } else if (blockIdx.x >= (uint32_t)P.n_owned_tiles * 4u) return;
+    trace_block<COUNT, FLAT, false>(S, P, O, ent, idx, nullptr);
+}
+template <bool COUNT, bool FLAT>
+__global__ __launch_bounds__(192) __attribute__((amdgpu_waves_per_eu((FLAT && !COUNT) ? YCGE_TRACE_WAVES : 2, 8))) void k_trace_fan(const SceneDev S, const FrameParams P, const TraceOut O)
+{
+    __shared__ FanShared F;
+    if (blockIdx.x >= *O.n_fan) return;
+    trace_block<COUNT, FLAT, true>(S, P, O, O.block_order[blockIdx.x], blockIdx.x, &F);
+}
+
 // ---------------------------------------------------------------------------------- block schedule (feedback from the previous frame)
-// cost[b] = steps of block b's longest lane.  Classes by floor(log2(steps)); class 7 = longest.  The three top
-// classes are split (see k_trace).  k_cost_hist counts entries per class, k_cost_scatter writes the schedule class
-// by class (descending) and clears cost[] for the next frame's atomicMax; both batch their global atomics through LDS.
-// ws: [0..7] entries per class, [8..15] cursors, [16] total entries (read by k_trace), [17] = 1 when splitting fits the grid
+// cost[b] = traversal loop iterations of block b's wavefront(s) (trace_block).  Eight classes, finer towards the top
+// (class 7 = longest): < 64, < 128, < 192, < 256, < 384, < 512, < 768, more.  k_cost_hist counts entries per class,
+// k_cost_scatter writes the schedule class by class (descending) and clears cost[] for the next frame's atomicMax; both
+// batch their global atomics through LDS.
+// ws: [0..7] entries per class, [8..15] cursors, [16] total entries (read by k_trace), [18] = entries at the head of
+// the schedule that go to k_trace_fan
 __device__ __forceinline__ int cost_class(uint32_t c)
 {
-    const int lg = c ? 31 - __builtin_clz(c) : 0;       // steps: 2^4 = 16 ... 2^10 = 1024
-    const int k = lg - 3;
-    return k < 0 ? 0 : k > 7 ? 7 : k;
+    return c < 64u ? 0 : c < 128u ? 1 : c < 192u ? 2 : c < 256u ? 3 : c < 384u ? 4 : c < 512u ? 5 : c < 768u ? 6 : 7;
 }
 // split policy: log2(parts) of class c in bits [3c, 3c+3) of `policy`
 __device__ __forceinline__ uint32_t class_lg_parts(uint32_t policy, int cls) { return (policy >> (3 * cls)) & 7u; }
@@ -846,7 +978,7 @@ __global__ __launch_bounds__(1024) void k_cost_hist(const uint32_t *__restrict__
     if (threadIdx.x < 8 && h[threadIdx.x]) atomicAdd(&ws[threadIdx.x], h[threadIdx.x]);
 }
 __global__ __launch_bounds__(1024) void k_cost_scatter(uint32_t *__restrict__ cost, uint32_t n, uint32_t capacity, uint32_t policy,
-                                                       uint32_t *__restrict__ ws, uint32_t *__restrict__ order)
+                                                       uint32_t fan_class, uint32_t fan_cap, uint32_t *__restrict__ ws, uint32_t *__restrict__ order)
 {
     __shared__ uint32_t h[8], base[8];
     __shared__ uint32_t s_split;
@@ -855,7 +987,12 @@ __global__ __launch_bounds__(1024) void k_cost_scatter(uint32_t *__restrict__ co
         uint32_t total = 0;
         for (int c = 0; c < 8; c++) total += ws[c] << class_lg_parts(policy, c);
         s_split = total <= capacity ? 1u : 0u;
-        if (blockIdx.x == 0) ws[16] = s_split ? total : n;
+        if (blockIdx.x == 0) {
+            ws[16] = s_split ? total : n;
+            uint32_t n_fan = 0;                 // blocks of the classes >= fan_class, at the head of the schedule
+            if (fan_class > 0 && policy == 0) for (int c = 7; c >= (int)fan_class; c--) n_fan += ws[c];
+            ws[18] = n_fan < fan_cap ? n_fan : fan_cap;
+        }
     }
     __syncthreads();
     const bool split = s_split != 0;
@@ -1076,14 +1213,27 @@ int ycge_launch_wavefront(const ycge::SceneDev *S, const ycge::FrameParams *P, c
 }
 
 // builds next frame's k_trace schedule from this frame's per-block step counts.  ws: 18 uint32 (see k_cost_hist)
-int ycge_launch_order_blocks(uint32_t *cost, uint32_t n, uint32_t policy, uint32_t *ws, uint32_t *order, hipStream_t stream)
+int ycge_launch_order_blocks(uint32_t *cost, uint32_t n, uint32_t policy, uint32_t fan_class, uint32_t fan_cap, uint32_t *ws, uint32_t *order,
+                             hipStream_t stream)
 {
     if (n == 0) return 0;
-    hipError_t e = hipMemsetAsync(ws, 0, 18 * sizeof(uint32_t), stream);
+    hipError_t e = hipMemsetAsync(ws, 0, 18 * sizeof(uint32_t), stream);     // ws[18] (n_fan) is rewritten by k_cost_scatter
     if (e != hipSuccess) return (int)e;
     const dim3 grid((n + 1023u) / 1024u), block(1024);
     hipLaunchKernelGGL(ycge::k_cost_hist, grid, block, 0, stream, cost, n, ws);
-    hipLaunchKernelGGL(ycge::k_cost_scatter, grid, block, 0, stream, cost, n, n * YCGE_SCHEDULE_SLACK, policy, ws, order);
+    hipLaunchKernelGGL(ycge::k_cost_scatter, grid, block, 0, stream, cost, n, n * YCGE_SCHEDULE_SLACK, policy, fan_class, fan_cap, ws, order);
+    return (int)hipGetLastError();
+}
+
+// the fanned blocks of the schedule (see k_trace_fan); grid = the cap the schedule was built with
+int ycge_launch_trace_fan(const ycge::SceneDev *S, const ycge::FrameParams *P, const ycge::TraceOut *O, int count, int flat, uint32_t fan_cap,
+                          hipStream_t stream)
+{
+    using namespace ycge;
+    if (P->n_owned_tiles <= 0 || fan_cap == 0) return 0;
+    sel3(count != 0, flat != 0, false, [&](auto C, auto F, auto) {
+        hipLaunchKernelGGL((k_trace_fan<decltype(C)::value, decltype(F)::value>), dim3(fan_cap), dim3(192), 0, stream, *S, *P, *O);
+    });
     return (int)hipGetLastError();
 }
 

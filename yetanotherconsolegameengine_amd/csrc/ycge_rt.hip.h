@@ -630,9 +630,9 @@ struct StackT {
     uint32_t spill_stride; // lanes in the grid
     uint32_t lds_base;     // LDS byte address of this lane's level-0 slot (levels are BS * 8 bytes apart)
     int sp;
-    __device__ __forceinline__ void init(void *spill_base, uint32_t n_lanes)
+    __device__ __forceinline__ void init(void *spill_base, uint32_t n_lanes, uint32_t first_lane = 0)
     {
-        spill = (uint2 *)spill_base + (blockIdx.x * BS + threadIdx.x);
+        spill = (uint2 *)spill_base + (first_lane + blockIdx.x * BS + threadIdx.x);
         spill_stride = n_lanes;
         lds_base = (uint32_t)(uintptr_t)(BS == 64 ? (void *)g_lds_stack64 : (void *)g_lds_stack) + threadIdx.x * 8u;
         sp = 0;
