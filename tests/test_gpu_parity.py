@@ -182,10 +182,17 @@ def test_error_codes(product_lib, path):
     product_lib.ycge_destroy(ctx)
 
 
-def test_two_rank_tile_split_matches_single_gpu(product_lib, path):
-    """world_size 2 emulated on one GPU: two contexts trace their tiles, slabs are concatenated as an
-    all-gather would, both resolve; results equal the single-context frame bit for bit."""
-    sc, w, h, ss, pose = scenes.config_scene(1)
+@pytest.mark.parametrize("case", ["cornell-2", "bunny-4-fan"])
+def test_two_rank_tile_split_matches_single_gpu(product_lib, path, case, monkeypatch):
+    """world_size 2 (4) emulated on one GPU: the contexts trace their tiles, slabs are concatenated as an
+    all-gather would, all resolve; results equal the single-context frame bit for bit.  The bunny case runs the
+    ranks' heavy blocks through k_trace_fan (the tiled default from 2 ranks up; YCGE_FAN=1 lowers its threshold so that
+    this small frame has such blocks) against a single context that does not."""
+    if case == "cornell-2":
+        (sc, w, h, ss, pose), world = scenes.config_scene(1), 2
+    else:
+        (sc, _, _, ss, pose), world = scenes.config_scene(3), 4
+        w, h = 320, 90
     flat = flatten(sc)
     import torch
     def mk(rank, world):
@@ -193,12 +200,13 @@ def test_two_rank_tile_split_matches_single_gpu(product_lib, path):
         r.SetCamera(pose["pos"], pose["yaw"], pose["pitch"])
         return r
     single = mk(0, 1)
-    ranks = [mk(0, 2), mk(1, 2)]
+    if case != "cornell-2": monkeypatch.setenv("YCGE_FAN", "1")
+    ranks = [mk(i, world) for i in range(world)]
     nb = ranks[0].tile_slab_bytes()
-    assert nb == ranks[1].tile_slab_bytes() == tiles.slab_floats(2, tiles.tile_grid(single.hiW, single.hiH)[2]) * 4
+    assert nb == ranks[1].tile_slab_bytes() == tiles.slab_floats(world, tiles.tile_grid(single.hiW, single.hiH)[2]) * 4
     for frame in range(3):
         single.TryFlipAndBlit()
-        gathered = torch.zeros(2 * nb // 4, dtype=torch.float32, device="cuda")
+        gathered = torch.zeros(world * nb // 4, dtype=torch.float32, device="cuda")
         for i, r in enumerate(ranks):
             r.trace_tiles(gathered[i * nb // 4:].data_ptr(), 0, want_stats=True)
         torch.cuda.synchronize()
@@ -211,7 +219,7 @@ def test_two_rank_tile_split_matches_single_gpu(product_lib, path):
         # the device slab layout is the documented one (tiles.py)
         hdr, alb, nrm = single.read(abi.BUF_CURRENT_HDR), single.read(abi.BUF_G_ALBEDO), single.read(abi.BUF_G_NORMAL)
         full = np.concatenate([hdr, alb, nrm, single.read(abi.BUF_G_DEPTH)[..., None], single.read(abi.BUF_SKY_MASK)[..., None].astype(np.float32)], -1)
-        assert np.array_equal(tiles.unpermute(gathered.cpu().numpy(), single.hiW, single.hiH, 2), full)
+        assert np.array_equal(tiles.unpermute(gathered.cpu().numpy(), single.hiW, single.hiH, world), full)
     for r in ranks + [single]:
         r.close()
 
@@ -316,3 +324,26 @@ def test_update_objects_rebuilds_scene_bvh_only(product_lib, oracle, path):
         _assert_parity(pu.compare_frame(o, g), f"objects moved, step {step}")
     assert pu.bits_equal(o.accel(abi.ACCEL_SCENE_NODES), g.accel(abi.ACCEL_SCENE_NODES))
     o.close(); g.close()
+
+
+@pytest.mark.parametrize("knob", ["YCGE_FAN=1", "YCGE_REFILL=8"])
+def test_query_fan_out_and_refill_kernels_bit_exact(product_lib, oracle, monkeypatch, knob):
+    """k_trace_fan (three wavefronts per heavy block, the default when a frame is tiled over >= 2 GPUs) and k_trace_refill
+    (experiment) trace the same queries as k_trace in another arrangement: every buffer and every counter must still
+    equal the oracle's.  Fan-out needs a schedule, i.e. starts with the second frame; three frames are compared.
+    Scenes: the bunny (heavy blocks, diffuse bounces), the primitive zoo with glass (path items and transmittance
+    segments go through slot 0 one at a time), Cornell (not a flat scene: generic walk under the fan-out)."""
+    name, value = knob.split("=")
+    monkeypatch.setenv("YCGE_PATH", "megakernel")
+    monkeypatch.setenv(name, value)
+    sc3, w3, h3, ss3, pose3 = scenes.config_scene(3)
+    sc1, w1, h1, ss1, pose1 = scenes.config_scene(1)
+    cases = [("bunny", sc3, 320, 90, 1, pose3), ("zoo+glass", _zoo_scene(True), 192, 54, 1, dict(pos=(0.1, 1.2, 1.0), yaw=0.05, pitch=-0.12, fov=50.0)),
+             ("cornell", sc1, w1, h1, ss1, pose1)]
+    for label, sc, w, h, ss, pose in cases:
+        o, g = pu.run_pair(oracle, sc, w, h, ss, pose, frames=1)
+        _assert_parity(pu.compare_frame(o, g), f"{knob} {label} frame1")
+        for f in (2, 3):
+            o.render(stages=1, threads=8); g.TryFlipAndBlit()
+            _assert_parity(pu.compare_frame(o, g), f"{knob} {label} frame{f}")
+        o.close(); g.close()

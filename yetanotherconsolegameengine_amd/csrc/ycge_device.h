@@ -126,8 +126,8 @@ struct GLight {
 
 #define YCGE_TRAVERSAL_STACK 96    // >= scene depth + 4 leaf prims + mesh depth, checked at upload
 #define YCGE_SCHEDULE_SLACK 2u      // k_trace grid = blocks x this: room for the parts of split blocks
-#define YCGE_FAN_CLASS_DEFAULT 0u     // k_trace_fan off by default (measured: no gain, see DESIGN); YCGE_FAN=<class> turns it on for classes >= that
-#define YCGE_FAN_CAP_DEFAULT 2048u   // ... at most this many
+#define YCGE_FAN_CAP_DEFAULT 2048u   // k_trace_fan: at most this many blocks of the schedule's head
+#define YCGE_REFILL_STEPS_DEFAULT 0
 #define YCGE_TILE_W 32
 #define YCGE_TILE_H 8
 #define YCGE_SLAB_FLOATS 11        // hdr rgb, albedo rgb, normal xyz, depth, sky

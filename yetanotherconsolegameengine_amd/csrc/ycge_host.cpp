@@ -22,7 +22,8 @@
 
 extern "C" {
 size_t ycge_wf_sizes(int which);
-int ycge_launch_trace(const ycge::SceneDev *S, const ycge::FrameParams *P, const ycge::TraceOut *O, int count, int flat, hipStream_t stream);
+int ycge_launch_trace(const ycge::SceneDev *S, const ycge::FrameParams *P, const ycge::TraceOut *O, int count, int flat, int refill_steps,
+                      hipStream_t stream);
 int ycge_launch_wavefront(const ycge::SceneDev *S, const ycge::FrameParams *P, const ycge::TraceOut *O, void *const bufs[7], int rounds,
                           int has_grid, int flat, int count, int persistent_waves, hipStream_t stream);
 int ycge_launch_order_blocks(uint32_t *cost, uint32_t n, uint32_t policy, uint32_t fan_class, uint32_t fan_cap, uint32_t *order_ws, uint32_t *order,
@@ -439,7 +440,11 @@ int ycge_create(const ycge_config *cfg, ycge_ctx **out)
         if (hipStreamCreateWithFlags(&c->fan_stream, hipStreamNonBlocking) != hipSuccess) { c->err = "hipStreamCreate failed"; return bail(YCGE_ERR_DEVICE); }
         for (auto &ev : c->fan_ev)
             if (hipEventCreateWithFlags(&ev, hipEventDisableTiming) != hipSuccess) { c->err = "hipEventCreate failed"; return bail(YCGE_ERR_DEVICE); }
-        c->fan_class = getenv("YCGE_FAN") ? (uint32_t)atoi(getenv("YCGE_FAN")) : YCGE_FAN_CLASS_DEFAULT;
+        // query fan-out pays when wavefront slots are plentiful, i.e. when the frame is tiled over several GPUs and a rank's
+        // time is the chain of its heaviest blocks (measured per rank on config 4: 0.565 -> 0.418 ms at 8 ranks, 0.562 -> 0.433
+        // at 4); on a whole frame the idle helper wavefronts cost more than the shorter chains save (0.60 -> 0.66 ms)
+        const uint32_t fan_default = c->cfg.world_size >= 4 ? 4u : c->cfg.world_size >= 2 ? 5u : 0u;
+        c->fan_class = getenv("YCGE_FAN") ? (uint32_t)atoi(getenv("YCGE_FAN")) : fan_default;
         c->fan_cap = c->fan_class ? (getenv("YCGE_FAN_CAP") ? (uint32_t)atoi(getenv("YCGE_FAN_CAP")) : YCGE_FAN_CAP_DEFAULT) : 0u;
     }
     int rc = set_geometry(c, cfg->fb_width, cfg->fb_height, cfg->super_sample);
@@ -889,7 +894,8 @@ int begin_and_trace(ycge_ctx *c, float *d_slab, hipStream_t stream, FrameState &
         O.block_order = (lpt && c->block_order_valid) ? c->block_order.p : nullptr;
         O.n_order = c->order_ws.p + 16;
         // the schedule's head (the heaviest blocks of the previous frame) goes to k_trace_fan, launched first and beside k_trace
-        const bool fan = O.block_order != nullptr && c->fan_cap > 0;
+        const int refill_steps = getenv("YCGE_REFILL") ? atoi(getenv("YCGE_REFILL")) : YCGE_REFILL_STEPS_DEFAULT;   // k_trace_refill: steps between refills (0 = k_trace)
+        const bool fan = O.block_order != nullptr && c->fan_cap > 0 && !(flat && refill_steps > 0);
         if (fan) {
             // k_trace_fan goes FIRST and on the frame's stream, so that its blocks - the frame's longest chains - are resident from
             // t = 0; the rest of the schedule follows on the side stream (forked before, joined after) and fills in around them
@@ -900,11 +906,11 @@ int begin_and_trace(ycge_ctx *c, float *d_slab, hipStream_t stream, FrameState &
             e = ycge_launch_trace_fan(&c->sd, &P, &OF, c->cfg.count_work, flat, c->fan_cap, stream);
             if (e != 0) return c->fail(YCGE_ERR_DEVICE, "k_trace_fan launch failed: %s", hipGetErrorString((hipError_t)e));
             HIP_TRY(c, hipStreamWaitEvent(c->fan_stream, c->fan_ev[0], 0));
-            e = ycge_launch_trace(&c->sd, &P, &O, c->cfg.count_work, flat, c->fan_stream);
+            e = ycge_launch_trace(&c->sd, &P, &O, c->cfg.count_work, flat, 0, c->fan_stream);
             HIP_TRY(c, hipEventRecord(c->fan_ev[1], c->fan_stream));
             HIP_TRY(c, hipStreamWaitEvent(stream, c->fan_ev[1], 0));
         } else
-            e = ycge_launch_trace(&c->sd, &P, &O, c->cfg.count_work, flat, stream);
+            e = ycge_launch_trace(&c->sd, &P, &O, c->cfg.count_work, flat, refill_steps, stream);
         if (e == 0 && lpt) {
             static const uint32_t policy = getenv("YCGE_SPLIT") ? (uint32_t)strtoul(getenv("YCGE_SPLIT"), nullptr, 8) : 0u;   // octal: digit c = log2(parts) of class c
             e = ycge_launch_order_blocks(c->block_cost.p, (uint32_t)c->n_owned * 4u, policy, c->fan_class, c->fan_cap, c->order_ws.p, c->block_order.p, stream);

@@ -571,38 +571,55 @@ struct PathStack {
 // Every other query (path items of refractive hits, later transmittance segments, a third light) goes through
 // slot 0 one at a time.  Slots live in LDS; a stage boundary is one workgroup barrier.
 struct FanShared {
-    float q[3][8][64];          // slot, {o xyz, d xyz, tmin (< 0: empty), tmax}, lane
+    float o[3][64];             // origin of the lane's posted queries (the queries of one hit share it), xyz, lane
+    float q[3][5][64];          // slot, {d xyz, tmin (< 0: empty), tmax}, lane
     float r[3][3][64];          // slot, {t, prim, sub}, lane
     uint32_t iters[3];          // traversal loop iterations per wavefront (summed into the block's cost)
     int alive;
+    uint8_t list[192];          // refill mode: the posted queries, compacted (slot * 64 + lane)
 };
 __device__ __forceinline__ void fan_post(FanShared *F, int slot, int lane, F3 o, F3 d, float tmin, float tmax)
 {
-    F->q[slot][0][lane] = o.x; F->q[slot][1][lane] = o.y; F->q[slot][2][lane] = o.z;
-    F->q[slot][3][lane] = d.x; F->q[slot][4][lane] = d.y; F->q[slot][5][lane] = d.z;
-    F->q[slot][6][lane] = tmin; F->q[slot][7][lane] = tmax;
+    F->o[0][lane] = o.x; F->o[1][lane] = o.y; F->o[2][lane] = o.z;
+    F->q[slot][0][lane] = d.x; F->q[slot][1][lane] = d.y; F->q[slot][2][lane] = d.z;
+    F->q[slot][3][lane] = tmin; F->q[slot][4][lane] = tmax;
 }
-
+__device__ __forceinline__ RayQ fan_query(const FanShared *F, int slot, int lane)
+{
+    RayQ q;
+    q.o = f3(F->o[0][lane], F->o[1][lane], F->o[2][lane]);
+    q.d = f3(F->q[slot][0][lane], F->q[slot][1][lane], F->q[slot][2][lane]);
+    q.tmin = F->q[slot][3][lane]; q.tmax = F->q[slot][4][lane];
+    return q;
+}
 __device__ __forceinline__ uint32_t wave_umax(uint32_t v)
 {
     for (int off = 32; off >= 1; off >>= 1) { const uint32_t o2 = (uint32_t)__shfl_xor((int)v, off, 64); v = o2 > v ? o2 : v; }
     return v;
 }
 
-template <bool COUNT, bool FLAT, bool FAN>
+// MODE 0: one wavefront per block, queries traced where TraceFull asks for them.
+// MODE 1: k_trace_fan, three wavefronts per block (see above).
+// MODE 2: k_trace_refill, ONE wavefront per block and the same posting of a hit's queries, but stage B is a refill loop:
+//         the block's posted queries (up to 192) form a list, a lane that finishes its query takes the next one whichever
+//         pixel it belongs to, and the walk yields every `refill_steps` steps so that idle lanes can do so.  A block then
+//         costs about max(its longest query, its steps / 64) per stage instead of the sum of the stage's longest lanes.
+template <bool COUNT, bool FLAT, int MODE>
 __device__ __forceinline__ void trace_block(const SceneDev &S, const FrameParams &P, const TraceOut &O, const uint32_t ent, const uint32_t sched_index,
-                                            FanShared *F)
+                                            FanShared *F, const int refill_steps)
 {
+    constexpr bool FAN = MODE != 0;          // queries are posted to LDS slots and answered in stage B
+    constexpr bool WAVES3 = MODE == 1;
     const bool DEBUG = O.prim_id != nullptr;
     Work w = {0, 0, 0, 0, 0, 0};
-    StackT<FAN ? 192 : 64> st;
+    StackT<WAVES3 ? 192 : 64> st;
     st.init(O.stack_spill, O.stack_lanes, O.lane_base);
     const PathStack pstack = {O.path_stack, O.stack_lanes, O.lane_base};
-    const int lane = (int)(threadIdx.x & 63u), wave = FAN ? (int)(threadIdx.x >> 6) : 0;
-    const uint32_t bid = YCGE_ENT_BLOCK(ent), lg = FAN ? 0u : YCGE_ENT_LG(ent);
+    const int lane = (int)(threadIdx.x & 63u), wave = WAVES3 ? (int)(threadIdx.x >> 6) : 0;
+    const uint32_t bid = YCGE_ENT_BLOCK(ent), lg = WAVES3 ? 0u : YCGE_ENT_LG(ent);
     const int k = (int)(bid >> 2), wave_in_tile = (int)(bid & 3);
     const int live_lanes = 64 >> lg;
-    const int pix_in_block = (int)(FAN ? 0u : YCGE_ENT_PART(ent)) * live_lanes + lane;
+    const int pix_in_block = (int)(WAVES3 ? 0u : YCGE_ENT_PART(ent)) * live_lanes + lane;
     int px, py, lx, ly;
     const bool in_image = tile_pixel_wl(P, k, wave_in_tile, pix_in_block & 63, px, py, lx, ly) && lane < live_lanes;
     const bool prof = O.wave_prof && O.wave_prof_stage == 2;
@@ -642,7 +659,8 @@ __device__ __forceinline__ void trace_block(const SceneDev &S, const FrameParams
     // query batches of the longest lane's steps.  The same scale whether the block is fanned or not.
     uint32_t wave_iters = 0;
     if (FAN) {
-        F->q[wave][6][lane] = -1.0f;
+        if (WAVES3) F->q[wave][3][lane] = -1.0f;
+        else { F->q[0][3][lane] = -1.0f; F->q[1][3][lane] = -1.0f; F->q[2][3][lane] = -1.0f; }
         if (phase != PH_DONE) fan_post(F, 0, lane, q.o, q.d, q.tmin, q.tmax);      // the primary query
     }
 
@@ -875,27 +893,60 @@ __device__ __forceinline__ void trace_block(const SceneDev &S, const FrameParams
             if (fanned) parked = true;
         }
     }
-    if (FAN) { const bool alive = __any(phase != PH_DONE); if (lane == 0) F->alive = alive ? 1 : 0; }
+    if (WAVES3) { const bool alive = __any(phase != PH_DONE); if (lane == 0) F->alive = alive ? 1 : 0; }
    }
    if (!FAN) break;
-   __syncthreads();
-   if (!F->alive) break;
-   {    // ---- stage B: wavefront w answers slot w
-        const float f_tmin = F->q[wave][6][lane];
-        const uint32_t steps_before = w.steps;
-        if (f_tmin >= 0.0f) {
-            RayQ fq;
-            fq.o = f3(F->q[wave][0][lane], F->q[wave][1][lane], F->q[wave][2][lane]);
-            fq.d = f3(F->q[wave][3][lane], F->q[wave][4][lane], F->q[wave][5][lane]);
-            fq.tmin = f_tmin; fq.tmax = F->q[wave][7][lane];
-            float f_t; int f_prim, f_sub;
-            traverse<COUNT, true, FLAT>(S, fq, st, f_t, f_prim, f_sub, w);
-            F->r[wave][0][lane] = f_t; F->r[wave][1][lane] = __int_as_float(f_prim); F->r[wave][2][lane] = __int_as_float(f_sub);
-            F->q[wave][6][lane] = -1.0f;
-        }
-        wave_iters += wave_umax(w.steps - steps_before);
+   if (WAVES3) {
+       __syncthreads();
+       if (!F->alive) break;
+       // ---- stage B: wavefront w answers slot w
+       const float f_tmin = F->q[wave][3][lane];
+       const uint32_t steps_before = w.steps;
+       if (f_tmin >= 0.0f) {
+           const RayQ fq = fan_query(F, wave, lane);
+           float f_t; int f_prim, f_sub;
+           traverse<COUNT, true, FLAT>(S, fq, st, f_t, f_prim, f_sub, w);
+           F->r[wave][0][lane] = f_t; F->r[wave][1][lane] = __int_as_float(f_prim); F->r[wave][2][lane] = __int_as_float(f_sub);
+           F->q[wave][3][lane] = -1.0f;
+       }
+       wave_iters += wave_umax(w.steps - steps_before);
+       __syncthreads();
+   } else {
+       if (!__any(phase != PH_DONE)) break;
+       // ---- stage B: the posted queries as one list, lanes refill from it
+       uint32_t n = 0;
+       for (int sl = 0; sl < 3; sl++) {
+           const bool v = F->q[sl][3][lane] >= 0.0f;
+           const unsigned long long m = __ballot(v);
+           if (v) F->list[n + __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u))] = (uint8_t)(sl * 64 + lane);
+           n += (uint32_t)__popcll(m);
+       }
+       uint32_t next = 0;
+       bool has = false;
+       int id = 0;
+       FlatQuery fq;
+       fq.cur = YCGE_REF_NONE_VALUE;
+       for (;;) {
+           const unsigned long long idle = __ballot(!has);
+           if (next < n && idle != 0ull) {
+               const uint32_t my = next + __builtin_amdgcn_mbcnt_hi((uint32_t)(idle >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)idle, 0u));
+               if (!has && my < n) {
+                   id = (int)F->list[my];
+                   flat_begin<COUNT>(S, fan_query(F, id >> 6, id & 63), st, fq, w);
+                   has = true;
+               }
+               next += (uint32_t)__popcll(idle);
+           }
+           if (!__any(has)) break;
+           wave_iters += (uint32_t)refill_steps;
+           if (has && flat_advance<COUNT, true>(S, st, fq, w, refill_steps)) {
+               const int sl = id >> 6, ln = id & 63;
+               F->r[sl][0][ln] = fq.closest; F->r[sl][1][ln] = __int_as_float(fq.hit_prim); F->r[sl][2][ln] = __int_as_float(fq.hit_sub);
+               F->q[sl][3][ln] = -1.0f;
+               has = false;
+           }
+       }
    }
-   __syncthreads();
    parked = false;
    if (bounce_in_flight) {      // slot 0 is needed for the queries that go one at a time: keep the bounce answer in registers
         pre_b_t = F->r[0][0][lane]; pre_b_prim = __float_as_int(F->r[0][1][lane]); pre_b_sub = __float_as_int(F->r[0][2][lane]);
@@ -903,7 +954,7 @@ __device__ __forceinline__ void trace_block(const SceneDev &S, const FrameParams
    }
   }
 
-    if (FAN) {
+    if (WAVES3) {
         if (lane == 0) F->iters[wave] = wave_iters;
         __syncthreads();
         if (wave != 0) { flush_work<COUNT>(w, O.counters); return; }
@@ -922,12 +973,12 @@ __device__ __forceinline__ void trace_block(const SceneDev &S, const FrameParams
             if (O.rng_state) O.rng_state[i] = rng;
         }
     }
-    const uint32_t wave_max_steps = FAN ? F->iters[0] + F->iters[1] + F->iters[2] : wave_iters;
+    const uint32_t wave_max_steps = WAVES3 ? F->iters[0] + F->iters[1] + F->iters[2] : wave_iters;
     if (O.block_cost && lane == 0) atomicMax(O.block_cost + bid, wave_max_steps);      // feedback for the next frame's schedule
-    if (prof && lane == 0 && (FAN || YCGE_ENT_PART(ent) == 0)) {
+    if (prof && lane == 0 && (WAVES3 || YCGE_ENT_PART(ent) == 0)) {
         unsigned long long *dst = O.wave_prof + ((size_t)k * 4 + wave_in_tile) * 4;
         dst[0] = t_start; dst[1] = __builtin_amdgcn_s_memrealtime(); dst[2] = sched_index | ((unsigned long long)wave_max_steps << 32);
-        dst[3] = __builtin_amdgcn_s_getreg(((32 - 1) << 11) | (0 << 6) | 20) | ((unsigned long long)(FAN ? 7u : lg) << 32);   // XCC_ID; 7 = fanned block
+        dst[3] = __builtin_amdgcn_s_getreg(((32 - 1) << 11) | (0 << 6) | 20) | ((unsigned long long)(WAVES3 ? 7u : lg) << 32);   // XCC_ID; 7 = fanned block
     }
     flush_work<COUNT>(w, O.counters);
 }
@@ -944,14 +995,25 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu((FLAT && !CO
         if (idx >= *O.n_order) return;
         ent = O.block_order[idx];
     } else if (blockIdx.x >= (uint32_t)P.n_owned_tiles * 4u) return;
-    trace_block<COUNT, FLAT, false>(S, P, O, ent, idx, nullptr);
+    trace_block<COUNT, FLAT, 0>(S, P, O, ent, idx, nullptr, 0);
+}
+template <bool COUNT>
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(COUNT ? 2 : YCGE_TRACE_WAVES, 8))) void k_trace_refill(const SceneDev S, const FrameParams P, const TraceOut O, const int refill_steps)
+{
+    __shared__ FanShared F;
+    uint32_t idx = blockIdx.x, ent = blockIdx.x;
+    if (O.block_order) {
+        if (idx >= *O.n_order) return;
+        ent = O.block_order[idx];
+    } else if (blockIdx.x >= (uint32_t)P.n_owned_tiles * 4u) return;
+    trace_block<COUNT, true, 2>(S, P, O, ent, idx, &F, refill_steps);
 }
 template <bool COUNT, bool FLAT>
 __global__ __launch_bounds__(192) __attribute__((amdgpu_waves_per_eu((FLAT && !COUNT) ? YCGE_TRACE_WAVES : 2, 8))) void k_trace_fan(const SceneDev S, const FrameParams P, const TraceOut O)
 {
     __shared__ FanShared F;
     if (blockIdx.x >= *O.n_fan) return;
-    trace_block<COUNT, FLAT, true>(S, P, O, O.block_order[blockIdx.x], blockIdx.x, &F);
+    trace_block<COUNT, FLAT, 1>(S, P, O, O.block_order[blockIdx.x], blockIdx.x, &F, 0);
 }
 
 // ---------------------------------------------------------------------------------- block schedule (feedback from the previous frame)
@@ -1156,11 +1218,17 @@ size_t ycge_wf_sizes(int which)
 }
 
 // single-launch path
-int ycge_launch_trace(const ycge::SceneDev *S, const ycge::FrameParams *P, const ycge::TraceOut *O, int count, int flat, hipStream_t stream)
+int ycge_launch_trace(const ycge::SceneDev *S, const ycge::FrameParams *P, const ycge::TraceOut *O, int count, int flat, int refill_steps,
+                      hipStream_t stream)
 {
     using namespace ycge;
     if (P->n_owned_tiles <= 0) return 0;
     const dim3 grid((unsigned)P->n_owned_tiles * 4u * YCGE_SCHEDULE_SLACK), block(64);   // schedule capacity; idle entries exit at once
+    if (flat && refill_steps > 0) {
+        if (count) hipLaunchKernelGGL((k_trace_refill<true>), grid, block, 0, stream, *S, *P, *O, refill_steps);
+        else hipLaunchKernelGGL((k_trace_refill<false>), grid, block, 0, stream, *S, *P, *O, refill_steps);
+        return (int)hipGetLastError();
+    }
     static const unsigned lds_pad = getenv("YCGE_LDS_PAD") ? (unsigned)atoi(getenv("YCGE_LDS_PAD")) : 0u;   // experiment knob: fewer resident wavefronts
     sel3(count != 0, flat != 0, false, [&](auto C, auto F, auto) {
         hipLaunchKernelGGL((k_trace<decltype(C)::value, decltype(F)::value>), grid, block, lds_pad, stream, *S, *P, *O);

@@ -864,9 +864,9 @@ __device__ __forceinline__ void load_record72(const void *p, f32x4 &a, f32x4 &b,
                  : "v"(p)
                  : "memory");
 }
-template <bool COUNT, class STK>
-__device__ __forceinline__ void mesh_walk(const SceneDev &S, uint32_t cur, int mesh_prim, STK &st, F3 o, F3 inv, F3 d, bool sx, bool sy,
-                                          bool sz, float tmin, float &closest, int &hit_prim, int &hit_sub, Work &w)
+template <bool COUNT, bool BOUNDED = false, class STK>
+__device__ __forceinline__ void mesh_walk(const SceneDev &S, uint32_t &cur, int mesh_prim, STK &st, F3 o, F3 inv, F3 d, bool sx, bool sy,
+                                          bool sz, float tmin, float &closest, int &hit_prim, int &hit_sub, Work &w, int budget = 0x7fffffff)
 {
     // the twelve slab products of a node as six packed operations (v_pk_add_f32 / v_pk_mul_f32): GNode keeps its
     // planes as (x y)(z Z)(X Y) pairs per child, so two pairings of the ray's origin and reciprocal direction serve
@@ -874,7 +874,7 @@ __device__ __forceinline__ void mesh_walk(const SceneDev &S, uint32_t cur, int m
     // direction sign afterwards picks the same values.
     const f32x2 oxy = {o.x, o.y}, ozz = {o.z, o.z};
     const f32x2 ixy = {inv.x, inv.y}, izz = {inv.z, inv.z};
-    while (cur != YCGE_REF_NONE_VALUE) {
+    while (cur != YCGE_REF_NONE_VALUE && (!BOUNDED || budget-- > 0)) {      // budget: refill mode yields with the walk's state in (cur, stack)
         const bool is_node = YCGE_REF_KIND(cur) == REF_MESH_NODE;
         const uint32_t pay = YCGE_REF_PAYLOAD(cur);
         const uint32_t rec = pay >> 4;
@@ -954,12 +954,72 @@ __device__ __forceinline__ void traverse(const SceneDev &S, const RayQ &q, STK &
                 if (COUNT) w.box++;
                 if (box_mesh(q1.x, q1.y, q1.z, q1.w, q2.x, q2.y, o, inv, sx, sy, sz, tmin, closest, tm)) start = root_ref;
             }
-            mesh_walk<COUNT>(S, start, pi, st, o, inv, d, sx, sy, sz, tmin, closest, hit_prim, hit_sub, w);
+            mesh_walk<COUNT>(S, start, pi, st, o, inv, d, sx, sy, sz, tmin, closest, hit_prim, hit_sub, w);     // start is consumed
         } else if (type == 10) {
             if (HAS_GRID) { if (root_hit) grid_dda<COUNT>(S, __float_as_int(q0.z), pi, o, d, inv, tmin, closest, hit_prim, hit_sub, w); }
         } else {
             if (root_hit) analytic_prim<COUNT>(q0, q1, q2, q3, type, pi, o, d, tmin, closest, hit_prim, hit_sub, w);
         }
+    }
+}
+
+// The FLAT query of traverse() as a resumable state machine (k_trace's refill mode): flat_begin is traverse's
+// prologue, flat_advance runs at most `budget` mesh steps and returns true when the query is finished.  Object
+// order, box tests, counters and every visit are traverse's; only WHEN a lane performs them differs.
+struct FlatQuery {
+    F3 o, d, inv;
+    float tmin, closest;
+    int hit_prim, hit_sub, obj_i, n_top, mesh_prim;
+    uint32_t cur;
+};
+template <bool COUNT, class STK>
+__device__ __forceinline__ void flat_begin(const SceneDev &S, const RayQ &q, STK &st, FlatQuery &fq, Work &w)
+{
+    fq.o = q.o; fq.d = q.d; fq.tmin = q.tmin;
+    fq.closest = q.tmax;
+    fq.hit_prim = -1; fq.hit_sub = 0;
+    fq.cur = YCGE_REF_NONE_VALUE; fq.mesh_prim = -1;
+    fq.obj_i = 0; fq.n_top = 0;
+    fq.inv = f3(0.0f, 0.0f, 0.0f);
+    st.reset();
+    if (COUNT) w.rays++;
+    if (S.scene_root_ref == YCGE_REF_NONE_VALUE) return;
+    fq.inv = f3(1.0f / q.d.x, 1.0f / q.d.y, 1.0f / q.d.z);
+    float tn;
+    if (COUNT) w.box++;
+    const bool root_hit = box_scene(S.scene_root_min[0], S.scene_root_min[1], S.scene_root_min[2], S.scene_root_max[0], S.scene_root_max[1],
+                                    S.scene_root_max[2], q.o, fq.inv, q.tmin, fq.closest, tn);
+    fq.n_top = root_hit ? (int)(YCGE_REF_PAYLOAD(S.scene_root_ref) & 7u) : 0;     // a missed root: no object is looked at (traverse)
+}
+template <bool COUNT, bool HAS_GRID, class STK>
+__device__ __forceinline__ bool flat_advance(const SceneDev &S, STK &st, FlatQuery &fq, Work &w, int budget)
+{
+    const bool sx = fq.inv.x < 0.0f, sy = fq.inv.y < 0.0f, sz = fq.inv.z < 0.0f;
+    const uint32_t leaf_start = YCGE_REF_PAYLOAD(S.scene_root_ref) >> 3;
+    for (;;) {
+        if (fq.cur == YCGE_REF_NONE_VALUE) {
+            if (fq.obj_i >= fq.n_top) return true;
+            const int pi = (int)S.scene_leaf_prims[leaf_start + fq.obj_i];
+            fq.obj_i++;
+            const float4 *pp = (const float4 *)(S.prims + pi);
+            const float4 q0 = pp[0], q1 = pp[1], q2 = pp[2], q3 = pp[3];
+            const int type = __float_as_int(q0.x);
+            if (type == 9) {
+                const uint32_t root_ref = __float_as_uint(q2.z);
+                if (root_ref != YCGE_REF_NONE_VALUE) {
+                    float tm;
+                    if (COUNT) w.box++;
+                    if (box_mesh(q1.x, q1.y, q1.z, q1.w, q2.x, q2.y, fq.o, fq.inv, sx, sy, sz, fq.tmin, fq.closest, tm)) { fq.cur = root_ref; fq.mesh_prim = pi; }
+                }
+            } else if (type == 10) {
+                if (HAS_GRID) grid_dda<COUNT>(S, __float_as_int(q0.z), pi, fq.o, fq.d, fq.inv, fq.tmin, fq.closest, fq.hit_prim, fq.hit_sub, w);
+            } else {
+                analytic_prim<COUNT>(q0, q1, q2, q3, type, pi, fq.o, fq.d, fq.tmin, fq.closest, fq.hit_prim, fq.hit_sub, w);
+            }
+            continue;
+        }
+        mesh_walk<COUNT, true>(S, fq.cur, fq.mesh_prim, st, fq.o, fq.inv, fq.d, sx, sy, sz, fq.tmin, fq.closest, fq.hit_prim, fq.hit_sub, w, budget);
+        if (fq.cur != YCGE_REF_NONE_VALUE) return false;
     }
 }
 
