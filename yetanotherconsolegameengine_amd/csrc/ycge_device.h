@@ -23,8 +23,8 @@ namespace ycge {
 enum : uint32_t {
     REF_SCENE_NODE = 0u,   // payload = index into scene_nodes
     REF_SCENE_LEAF = 1u,   // payload = (start << 3) | count        (count 1..4, BVH.cs:7)
-    REF_MESH_NODE = 2u,    // payload = global index into mesh_nodes
-    REF_MESH_LEAF = 3u,    // payload = (global tri start << 4) | count (count 1..8, MeshBVH.cs:14)
+    REF_MESH_NODE = 2u,    // payload = (32-byte unit of the GNode in the mesh arena) << 4
+    REF_MESH_LEAF = 3u,    // payload = (unit of the leaf's first GTriPair << 4) | triangles left in the leaf (1..15; MeshBVH.cs:14 caps a leaf at 8)
     REF_PRIM = 4u,         // payload = index into prims
     REF_NONE = 7u
 };
@@ -136,8 +136,7 @@ struct GLight {
 struct SceneDev {
     const GNode *scene_nodes;
     const uint32_t *scene_leaf_prims;   // leafObjIndex
-    const GNode *mesh_nodes;
-    const GTriPair *tris;          // leaf-ordered triangle pair records
+    const uint8_t *mesh_arena;          // GNode / GTriPair records of all meshes in depth-first order; byte offset = (ref & 0x1ffffff0) << 1
     const GPrim *prims;
     const GMaterial *materials;
     const GMesh *meshes;

@@ -14,6 +14,7 @@
 #include <mutex>
 #include <string>
 #include <vector>
+#include <functional>
 
 #include "../../include/ycge.h"
 #include "ycge_accel.h"
@@ -142,9 +143,9 @@ struct ycge_ctx {
     // scene
     bool have_scene = false;
     SceneDev sd{};
-    DevBuf<GNode> d_scene_nodes, d_mesh_nodes;
+    DevBuf<GNode> d_scene_nodes;
+    DevBuf<uint8_t> d_mesh_arena;
     DevBuf<uint32_t> d_scene_leaf;
-    DevBuf<GTriPair> d_tris;
     DevBuf<GPrim> d_prims;
     DevBuf<GMaterial> d_materials;
     DevBuf<GMesh> d_meshes;
@@ -465,7 +466,7 @@ void ycge_destroy(ycge_ctx *c)
     for (auto *sc : c->schedules) { sc->pixels.release(); sc->offsets.release(); delete sc; }
     c->schedules.clear();
     c->wf_q0.release(); c->wf_q1.release(); c->wf_hit.release(); c->wf_lq.release(); c->wf_seg.release(); c->wf_counts.release(); c->tile_order.release(); c->block_cost.release(); c->block_order.release(); c->order_ws.release(); c->stack_spill.release(); c->path_stack.release();
-    c->d_scene_nodes.release(); c->d_mesh_nodes.release(); c->d_scene_leaf.release(); c->d_tris.release(); c->d_prims.release();
+    c->d_scene_nodes.release(); c->d_mesh_arena.release(); c->d_scene_leaf.release(); c->d_prims.release();
     c->d_materials.release(); c->d_meshes.release(); c->d_grids.release(); c->d_cells.release(); c->d_lut.release(); c->d_lights.release();
     for (auto &ev : c->ev) if (ev) (void)hipEventDestroy(ev);
     for (auto &ev : c->fan_ev) if (ev) (void)hipEventDestroy(ev);
@@ -631,8 +632,7 @@ int ycge_scene_upload(ycge_ctx *c, const ycge_scene *s)
 
     // ---- meshes: MeshBVH ctor (MeshBVH.cs:41-130) -> paired nodes + leaf-ordered triangles
     c->meshes.assign(s->n_meshes, MeshHost{});
-    std::vector<GNode> mesh_nodes;
-    std::vector<GTriPair> tris;
+    std::vector<uint8_t> arena;         // GNode (64 B) and GTriPair (96 B) records of every mesh, addressed in 32-byte units
     std::vector<GMesh> gmeshes(s->n_meshes);
     int max_mesh_depth = 0;
     for (int mi = 0; mi < s->n_meshes; mi++) {
@@ -645,37 +645,54 @@ int ycge_scene_upload(ycge_ctx *c, const ycge_scene *s)
         build_tree(items, TreeFlavour::Mesh, t);
         if (t.max_depth > 64) return c->fail(YCGE_ERR_STACK_DEPTH, "mesh %d: BVH depth %d exceeds the reference's 64-entry stack (MeshBVH.cs:150)", mi, t.max_depth);
         if (t.max_depth > max_mesh_depth) max_mesh_depth = t.max_depth;
-        // leaves in leaf_index order, each padded to whole pair records
-        std::vector<uint32_t> leaf_slot(t.leaf_index.size() + 1, 0);
-        uint32_t n_pairs = 0;
-        for (const RefNode &nd : t.nodes) {
-            if (nd.count <= 0) continue;
-            if (nd.count > 15) return c->fail(YCGE_ERR_UNSUPPORTED, "mesh %d: leaf of %d triangles", mi, nd.count);
-            leaf_slot[(size_t)nd.start] = n_pairs;
-            n_pairs += ((uint32_t)nd.count + 1u) / 2u;
-        }
-        const uint32_t pair_base = (uint32_t)tris.size();
-        if ((uint64_t)pair_base + (uint64_t)n_pairs >= (1u << 24)) return c->fail(YCGE_ERR_UNSUPPORTED, "more than 2^24 triangle pair records");
+        // records in depth-first order: an internal node, then its left child's records (a leaf's triangle pair records or the
+        // whole left subtree), then the right child's - a walk's next fetch is usually the next cache line
         GMesh &gm = gmeshes[mi];
         std::memset(&gm, 0, sizeof gm);
-        gm.root_ref = to_gpu_nodes(t, REF_MESH_NODE, REF_MESH_LEAF, (uint32_t)mesh_nodes.size(), pair_base, 4, mesh_nodes, &leaf_slot);
-        if (t.root >= 0) for (int a = 0; a < 3; a++) { gm.root_min[a] = t.nodes[t.root].mn[a]; gm.root_max[a] = t.nodes[t.root].mx[a]; }
-        tris.resize(pair_base + n_pairs);
-        std::memset((void *)(tris.data() + pair_base), 0, sizeof(GTriPair) * (size_t)n_pairs);
-        for (const RefNode &nd : t.nodes) {
-            for (int32_t k = 0; k < nd.count; k++) {
-                const int32_t ti = t.leaf_index[(size_t)(nd.start + k)];
-                const float *v = m.triangles + 9 * (size_t)ti;
-                GTriPair &g = tris[pair_base + leaf_slot[(size_t)nd.start] + (uint32_t)k / 2u];
-                const int sl = k & 1;
-                g.ax[sl] = v[0]; g.ay[sl] = v[1]; g.az[sl] = v[2];
-                g.e1x[sl] = v[3] - v[0]; g.e1y[sl] = v[4] - v[1]; g.e1z[sl] = v[5] - v[2];        // MeshBVH.cs:87-91
-                g.e2x[sl] = v[6] - v[0]; g.e2y[sl] = v[7] - v[1]; g.e2z[sl] = v[8] - v[2];
-                g.orig[sl] = ti;
-                g.material[sl] = m.tri_material ? m.tri_material[ti] : m.material;
-                if (!mat_ok(g.material[sl])) return c->fail(YCGE_ERR_INVALID_ARG, "mesh %d triangle %d: material out of range", mi, ti);
+        gm.root_ref = YCGE_REF_NONE_VALUE;
+        bool bad_material = false, bad_leaf = false;
+        std::function<uint32_t(int32_t)> emit = [&](int32_t ni) -> uint32_t {
+            const RefNode &nd = t.nodes[(size_t)ni];
+            const uint32_t unit = (uint32_t)(arena.size() / 32);
+            if (nd.count > 0) {
+                if (nd.count > 15) { bad_leaf = true; return YCGE_REF_NONE_VALUE; }
+                const uint32_t n_rec = ((uint32_t)nd.count + 1u) / 2u;
+                arena.resize(arena.size() + (size_t)n_rec * sizeof(GTriPair), 0);
+                for (int32_t k = 0; k < nd.count; k++) {
+                    const int32_t ti = t.leaf_index[(size_t)(nd.start + k)];
+                    const float *v = m.triangles + 9 * (size_t)ti;
+                    GTriPair g;
+                    std::memcpy(&g, arena.data() + (size_t)unit * 32 + (size_t)(k / 2) * sizeof(GTriPair), sizeof g);
+                    const int sl = k & 1;
+                    g.ax[sl] = v[0]; g.ay[sl] = v[1]; g.az[sl] = v[2];
+                    g.e1x[sl] = v[3] - v[0]; g.e1y[sl] = v[4] - v[1]; g.e1z[sl] = v[5] - v[2];        // MeshBVH.cs:87-91
+                    g.e2x[sl] = v[6] - v[0]; g.e2y[sl] = v[7] - v[1]; g.e2z[sl] = v[8] - v[2];
+                    g.orig[sl] = ti;
+                    g.material[sl] = m.tri_material ? m.tri_material[ti] : m.material;
+                    if (!mat_ok(g.material[sl])) bad_material = true;
+                    std::memcpy(arena.data() + (size_t)unit * 32 + (size_t)(k / 2) * sizeof(GTriPair), &g, sizeof g);
+                }
+                return YCGE_REF(REF_MESH_LEAF, (unit << 4) | (uint32_t)nd.count);
             }
+            arena.resize(arena.size() + sizeof(GNode), 0);
+            GNode g;
+            std::memset(&g, 0, sizeof g);
+            const RefNode &L = t.nodes[(size_t)nd.left];
+            const RefNode &R = t.nodes[(size_t)nd.right];
+            g.lmin_x = L.mn[0]; g.lmin_y = L.mn[1]; g.lmin_z = L.mn[2]; g.lmax_x = L.mx[0]; g.lmax_y = L.mx[1]; g.lmax_z = L.mx[2];
+            g.rmin_x = R.mn[0]; g.rmin_y = R.mn[1]; g.rmin_z = R.mn[2]; g.rmax_x = R.mx[0]; g.rmax_y = R.mx[1]; g.rmax_z = R.mx[2];
+            g.lref = emit(nd.left);
+            g.rref = emit(nd.right);
+            std::memcpy(arena.data() + (size_t)unit * 32, &g, sizeof g);
+            return YCGE_REF(REF_MESH_NODE, unit << 4);
+        };
+        if (t.root >= 0) {
+            gm.root_ref = emit(t.root);
+            for (int a = 0; a < 3; a++) { gm.root_min[a] = t.nodes[t.root].mn[a]; gm.root_max[a] = t.nodes[t.root].mx[a]; }
         }
+        if (bad_leaf) return c->fail(YCGE_ERR_UNSUPPORTED, "mesh %d: a leaf of more than 15 triangles", mi);
+        if (bad_material) return c->fail(YCGE_ERR_INVALID_ARG, "mesh %d: triangle material out of range", mi);
+        if (arena.size() / 32 >= (1u << 25)) return c->fail(YCGE_ERR_UNSUPPORTED, "mesh records exceed the 1 GB arena");
     }
 
     // ---- voxel grids: VolumeGrid ctor (VolumeGrid.cs:55-93), one byte per voxel = index into a per-grid material table
@@ -750,12 +767,12 @@ int ycge_scene_upload(ycge_ctx *c, const ycge_scene *s)
     c->has_grid = s->n_grids > 0;
 
     // ---- upload
-    HIP_TRY(c, c->d_materials.upload(mats)); HIP_TRY(c, c->d_mesh_nodes.upload(mesh_nodes)); HIP_TRY(c, c->d_tris.upload(tris));
+    HIP_TRY(c, c->d_materials.upload(mats)); HIP_TRY(c, c->d_mesh_arena.upload(arena));
     HIP_TRY(c, c->d_meshes.upload(gmeshes)); HIP_TRY(c, c->d_grids.upload(ggrids)); HIP_TRY(c, c->d_cells.upload(cells));
     HIP_TRY(c, c->d_lut.upload(lut));
     SceneDev &sd = c->sd;
     std::memset(&sd, 0, sizeof sd);
-    sd.mesh_nodes = c->d_mesh_nodes.p; sd.tris = c->d_tris.p;
+    sd.mesh_arena = c->d_mesh_arena.p;
     sd.materials = c->d_materials.p; sd.meshes = c->d_meshes.p; sd.grids = c->d_grids.p;
     sd.grid_cells = c->d_cells.p; sd.grid_lut = c->d_lut.p;
     {

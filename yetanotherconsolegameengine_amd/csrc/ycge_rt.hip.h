@@ -756,12 +756,12 @@ template <bool COUNT>
 __device__ __forceinline__ void leaf_triangles(const SceneDev &S, uint32_t pay, int mesh_prim, F3 o, F3 d, float tmin, float &closest,
                                                int &hit_prim, int &hit_sub, Work &w)
 {
-    const uint32_t first = (pay >> 4) * 2u, count = pay & 15u;
+    const uint32_t unit = pay >> 4, count = pay & 15u;
     if (COUNT) w.tri += (int)count;
 #pragma unroll 1
     for (uint32_t i = 0; i < count; i++) {
-        const uint32_t tri = first + i;
-        const float *tp = (const float *)(S.tris + (tri >> 1)) + (tri & 1u);       // component c of a slot is at tp[2 c]
+        const uint32_t tri = ((unit + 3u * (i >> 1)) << 1) | (i & 1u);             // (record unit << 1) | slot
+        const float *tp = (const float *)(S.mesh_arena + (size_t)(tri >> 1) * 32u) + (tri & 1u);       // component c of a slot is at tp[2 c]
         float t;
         if (tri_hit(tp[0], tp[2], tp[4], tp[6], tp[8], tp[10], tp[12], tp[14], tp[16], o, d, tmin, closest, t)) {
             closest = t;
@@ -806,7 +806,7 @@ __device__ __forceinline__ int tree_phase(const SceneDev &S, uint32_t &cur, int 
         if (COUNT) prof_tick(0);
         w.steps++;
         if (kind == REF_MESH_NODE || kind == REF_SCENE_NODE) {
-            const float4 *np = (const float4 *)((kind == REF_MESH_NODE ? S.mesh_nodes : S.scene_nodes) + pay);
+            const float4 *np = kind == REF_MESH_NODE ? (const float4 *)(S.mesh_arena + (size_t)(pay >> 4) * 32u) : (const float4 *)(S.scene_nodes + pay);
             const float4 a = np[0], b = np[1], c = np[2], e = np[3];
             float ln, rn;
             bool hl, hr;
@@ -886,16 +886,16 @@ __device__ __forceinline__ void walk(const SceneDev &S, uint32_t cur, int mesh_p
 // a node (64 B) or a triangle pair record (its first 72 B) in one round trip: every fetch is issued before the
 // single wait.  The fifth fetch only has a use for leaf lanes; for node lanes it reads the start of the next
 // node (the arrays are padded at upload).
-__device__ __forceinline__ void load_record72(const void *p, f32x4 &a, f32x4 &b, f32x4 &c, f32x4 &e, f32x2 &f)
+__device__ __forceinline__ void load_record72(const uint8_t *base, uint32_t byte_offset, f32x4 &a, f32x4 &b, f32x4 &c, f32x4 &e, f32x2 &f)
 {
-    asm volatile("global_load_dwordx4 %0, %5, off\n\t"
-                 "global_load_dwordx4 %1, %5, off offset:16\n\t"
-                 "global_load_dwordx4 %2, %5, off offset:32\n\t"
-                 "global_load_dwordx4 %3, %5, off offset:48\n\t"
-                 "global_load_dwordx2 %4, %5, off offset:64\n\t"
+    asm volatile("global_load_dwordx4 %0, %5, %6\n\t"
+                 "global_load_dwordx4 %1, %5, %6 offset:16\n\t"
+                 "global_load_dwordx4 %2, %5, %6 offset:32\n\t"
+                 "global_load_dwordx4 %3, %5, %6 offset:48\n\t"
+                 "global_load_dwordx2 %4, %5, %6 offset:64\n\t"
                  "s_waitcnt vmcnt(0)"
                  : "=&v"(a), "=&v"(b), "=&v"(c), "=&v"(e), "=&v"(f)
-                 : "v"(p)
+                 : "v"(byte_offset), "s"(base)
                  : "memory");
 }
 template <bool COUNT, bool BOUNDED = false, class STK>
@@ -910,12 +910,10 @@ __device__ __forceinline__ void mesh_walk(const SceneDev &S, uint32_t &cur, int 
     const f32x2 ixy = {inv.x, inv.y}, izz = {inv.z, inv.z};
     while (cur != YCGE_REF_NONE_VALUE && (!BOUNDED || budget-- > 0)) {      // budget: refill mode yields with the walk's state in (cur, stack)
         const bool is_node = YCGE_REF_KIND(cur) == REF_MESH_NODE;
-        const uint32_t pay = YCGE_REF_PAYLOAD(cur);
-        const uint32_t rec = pay >> 4;
-        const void *addr = is_node ? (const void *)(S.mesh_nodes + pay) : (const void *)(S.tris + rec);
+        const uint32_t unit2 = (cur & 0x1ffffff0u) >> 3;       // record's 32-byte unit, times two
         f32x4 a, b, c, e;
         f32x2 f;
-        load_record72(addr, a, b, c, e, f);
+        load_record72(S.mesh_arena, unit2 << 4, a, b, c, e, f);
         if (COUNT) prof_tick(0);
         w.steps++;
         uint32_t next;
@@ -933,12 +931,12 @@ __device__ __forceinline__ void mesh_walk(const SceneDev &S, uint32_t &cur, int 
             if (hl & hr) st.push(left_first ? rref : lref, left_first ? rn : ln);
             next = (hl & hr) ? (left_first ? lref : rref) : hl ? lref : hr ? rref : YCGE_REF_NONE_VALUE;
         } else {
-            const uint32_t left = pay & 15u;
+            const uint32_t left = cur & 15u;
             if (COUNT) w.tri += left >= 2u ? 2 : 1;
             TriPairRec T;
             T.r0 = a; T.r1 = b; T.r2 = c; T.r3 = e; T.e2z = f;
-            tri_pair_hit(T, left, rec * 2u, mesh_prim, o, d, tmin, closest, hit_prim, hit_sub);
-            next = left > 2u ? YCGE_REF(REF_MESH_LEAF, ((rec + 1u) << 4) | (left - 2u)) : YCGE_REF_NONE_VALUE;
+            tri_pair_hit(T, left, unit2, mesh_prim, o, d, tmin, closest, hit_prim, hit_sub);
+            next = left > 2u ? cur + ((3u << 4) - 2u) : YCGE_REF_NONE_VALUE;       // next record: 3 units on, two triangles fewer
         }
         cur = next;
         if (cur == YCGE_REF_NONE_VALUE) {
@@ -1077,7 +1075,7 @@ __device__ __forceinline__ void resolve_hit(const SceneDev &S, int prim_index, i
     bool wire_black = false;
     h.sub_public = sub;
     if (type == 9) {    // MeshBVH.cs:177-185
-        const GTriPair *tp = S.tris + ((uint32_t)sub >> 1);
+        const GTriPair *tp = (const GTriPair *)(S.mesh_arena + (size_t)((uint32_t)sub >> 1) * 32u);      // sub = (record unit << 1) | slot
         const int sl = sub & 1;
         const float e1x = tp->e1x[sl], e1y = tp->e1y[sl], e1z = tp->e1z[sl], e2x = tp->e2x[sl], e2y = tp->e2y[sl], e2z = tp->e2z[sl];
         // unit normal exactly as the MeshBVH ctor computes it, MeshBVH.cs:93-97
