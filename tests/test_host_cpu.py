@@ -85,6 +85,65 @@ def _same(a, b):
     return a.shape == b.shape and np.array_equal(a.view(np.uint8), b.view(np.uint8))
 
 
+@pytest.mark.parametrize("n_tris", [1, 2, 9, 700])
+def test_mesh_arena_is_the_reference_tree_record_for_record(product_lib, n_tris):
+    """The device layout of a mesh (emit_mesh_records: GNode / GTriPair records in depth-first order, references in
+    32-byte units) against the reference-format tree it is made from: same shape, a node's two boxes are its
+    children's boxes, a leaf's records hold its triangles in leaf order (A, e1 = B - A, e2 = C - A, original index),
+    an odd leaf ends with an all-zero slot, no byte of the arena is unused."""
+    rng = np.random.RandomState(5)
+    c = rng.uniform(-1, 1, (n_tris, 1, 3)); tris = (c + rng.normal(scale=0.05, size=(n_tris, 3, 3))).astype(np.float32)
+    nodes, leaf, st = _product_mesh(product_lib, tris)
+    L = product_lib
+    L.ycge_host_mesh_arena.restype = C.c_int
+    L.ycge_host_mesh_arena.argtypes = [C.c_void_p, C.c_int32, C.c_void_p, C.c_int64, C.c_void_p]
+    root = np.zeros(1, dtype=np.uint32)
+    t9 = np.ascontiguousarray(tris.reshape(-1, 9))
+    nbytes = L.ycge_host_mesh_arena(t9.ctypes.data, n_tris, None, 0, root.ctypes.data)
+    assert nbytes > 0 and nbytes % 32 == 0
+    arena = np.zeros(nbytes, dtype=np.uint8)
+    assert L.ycge_host_mesh_arena(t9.ctypes.data, n_tris, arena.ctypes.data, nbytes, root.ctypes.data) == nbytes
+    f32, u32, i32 = arena.view(np.float32), arena.view(np.uint32), arena.view(np.int32)
+    used = np.zeros(nbytes // 32, dtype=bool)
+    seen = []
+    KIND_NODE, KIND_LEAF = 2, 3
+
+    def walk(ref, ni):
+        kind, pay = int(ref) >> 29, int(ref) & 0x1fffffff
+        nd = nodes[ni]
+        unit = pay >> 4
+        if nd["count"] > 0:
+            assert kind == KIND_LEAF and (pay & 15) == nd["count"]
+            n_rec = (int(nd["count"]) + 1) // 2
+            assert not used[unit:unit + 3 * n_rec].any(); used[unit:unit + 3 * n_rec] = True
+            for k in range(int(nd["count"])):
+                base = (unit + 3 * (k // 2)) * 8          # float index of the record
+                sl = k & 1
+                comp = f32[base + sl: base + 18: 2]       # ax ay az e1x e1y e1z e2x e2y e2z
+                ti = int(leaf[nd["start"] + k])
+                A, B, Cc = tris[ti]
+                assert np.array_equal(comp, np.concatenate([A, B - A, Cc - A]).astype(np.float32))
+                assert i32[base + 18 + sl] == ti and i32[base + 20 + sl] == 0
+                seen.append(ti)
+            if nd["count"] & 1:                           # the spare slot: zeros (det = 0 rejects it, the walk masks it anyway)
+                base = (unit + 3 * (n_rec - 1)) * 8
+                assert not f32[base + 1: base + 18: 2].any() and i32[base + 19] == 0
+            return
+        assert kind == KIND_NODE and (pay & 15) == 0
+        assert not used[unit:unit + 2].any(); used[unit:unit + 2] = True
+        g = f32[unit * 8: unit * 8 + 16]
+        lch, rch = nodes[nd["left"]], nodes[nd["right"]]
+        # plane order (x y)(z Z)(X Y) per child, lower case = min
+        assert np.array_equal(g[:12], np.float32([lch["min"][0], lch["min"][1], lch["min"][2], lch["max"][2], lch["max"][0], lch["max"][1],
+                                                 rch["min"][0], rch["min"][1], rch["min"][2], rch["max"][2], rch["max"][0], rch["max"][1]]))
+        lref, rref = u32[unit * 8 + 12], u32[unit * 8 + 13]
+        assert (int(lref) & 0x1fffffff) >> 4 == unit + 2  # depth-first: the left child's records follow the node
+        walk(lref, nd["left"]); walk(rref, nd["right"])
+
+    walk(root[0], int(st[0]))
+    assert used.all() and sorted(seen) == list(range(n_tris))
+
+
 @pytest.mark.parametrize("case", ["random", "grid_ties", "all_equal", "collinear", "tiny"])
 def test_mesh_builder_matches_oracle(product_lib, case):
     rng = np.random.RandomState(11)

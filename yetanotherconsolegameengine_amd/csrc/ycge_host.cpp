@@ -601,6 +601,52 @@ int build_and_upload_objects(ycge_ctx *c, const ycge_prim *prims, int n_prims)
 
 } // namespace
 extern "C" {
+// A mesh's device records appended to the arena (32-byte units): depth-first - an internal node (GNode, both child boxes),
+// then its left child's records (a leaf's triangle pair records or the whole left subtree), then the right child's - so a
+// walk's next fetch is usually the next cache line.  Returns the root reference (ycge_device.h).
+static uint32_t emit_mesh_records(const BuiltTree &t, const float *tris9, const int32_t *tri_material, int32_t material, int n_materials,
+                                  std::vector<uint8_t> &arena, bool &bad_leaf, bool &bad_material)
+{
+    if (t.root < 0) return YCGE_REF_NONE_VALUE;
+    std::function<uint32_t(int32_t)> emit = [&](int32_t ni) -> uint32_t {
+        const RefNode &nd = t.nodes[(size_t)ni];
+        const uint32_t unit = (uint32_t)(arena.size() / 32);
+        if (nd.count > 0) {
+            if (nd.count > 15) { bad_leaf = true; return YCGE_REF_NONE_VALUE; }
+            const uint32_t n_rec = ((uint32_t)nd.count + 1u) / 2u;
+            arena.resize(arena.size() + (size_t)n_rec * sizeof(GTriPair), 0);        // an odd leaf's last slot stays all zeros
+            for (int32_t k = 0; k < nd.count; k++) {
+                const int32_t ti = t.leaf_index[(size_t)(nd.start + k)];
+                const float *v = tris9 + 9 * (size_t)ti;
+                uint8_t *rec = arena.data() + (size_t)unit * 32 + (size_t)(k / 2) * sizeof(GTriPair);
+                GTriPair g;
+                std::memcpy(&g, rec, sizeof g);
+                const int sl = k & 1;
+                g.ax[sl] = v[0]; g.ay[sl] = v[1]; g.az[sl] = v[2];
+                g.e1x[sl] = v[3] - v[0]; g.e1y[sl] = v[4] - v[1]; g.e1z[sl] = v[5] - v[2];        // MeshBVH.cs:87-91
+                g.e2x[sl] = v[6] - v[0]; g.e2y[sl] = v[7] - v[1]; g.e2z[sl] = v[8] - v[2];
+                g.orig[sl] = ti;
+                g.material[sl] = tri_material ? tri_material[ti] : material;
+                if (g.material[sl] < 0 || g.material[sl] >= n_materials) bad_material = true;
+                std::memcpy(rec, &g, sizeof g);
+            }
+            return YCGE_REF(REF_MESH_LEAF, (unit << 4) | (uint32_t)nd.count);
+        }
+        arena.resize(arena.size() + sizeof(GNode), 0);
+        GNode g;
+        std::memset(&g, 0, sizeof g);
+        const RefNode &L = t.nodes[(size_t)nd.left];
+        const RefNode &R = t.nodes[(size_t)nd.right];
+        g.lmin_x = L.mn[0]; g.lmin_y = L.mn[1]; g.lmin_z = L.mn[2]; g.lmax_x = L.mx[0]; g.lmax_y = L.mx[1]; g.lmax_z = L.mx[2];
+        g.rmin_x = R.mn[0]; g.rmin_y = R.mn[1]; g.rmin_z = R.mn[2]; g.rmax_x = R.mx[0]; g.rmax_y = R.mx[1]; g.rmax_z = R.mx[2];
+        g.lref = emit(nd.left);
+        g.rref = emit(nd.right);
+        std::memcpy(arena.data() + (size_t)unit * 32, &g, sizeof g);
+        return YCGE_REF(REF_MESH_NODE, unit << 4);
+    };
+    return emit(t.root);
+}
+
 int ycge_scene_upload(ycge_ctx *c, const ycge_scene *s)
 {
     if (!c) return YCGE_ERR_INVALID_ARG;
@@ -645,51 +691,11 @@ int ycge_scene_upload(ycge_ctx *c, const ycge_scene *s)
         build_tree(items, TreeFlavour::Mesh, t);
         if (t.max_depth > 64) return c->fail(YCGE_ERR_STACK_DEPTH, "mesh %d: BVH depth %d exceeds the reference's 64-entry stack (MeshBVH.cs:150)", mi, t.max_depth);
         if (t.max_depth > max_mesh_depth) max_mesh_depth = t.max_depth;
-        // records in depth-first order: an internal node, then its left child's records (a leaf's triangle pair records or the
-        // whole left subtree), then the right child's - a walk's next fetch is usually the next cache line
         GMesh &gm = gmeshes[mi];
         std::memset(&gm, 0, sizeof gm);
-        gm.root_ref = YCGE_REF_NONE_VALUE;
         bool bad_material = false, bad_leaf = false;
-        std::function<uint32_t(int32_t)> emit = [&](int32_t ni) -> uint32_t {
-            const RefNode &nd = t.nodes[(size_t)ni];
-            const uint32_t unit = (uint32_t)(arena.size() / 32);
-            if (nd.count > 0) {
-                if (nd.count > 15) { bad_leaf = true; return YCGE_REF_NONE_VALUE; }
-                const uint32_t n_rec = ((uint32_t)nd.count + 1u) / 2u;
-                arena.resize(arena.size() + (size_t)n_rec * sizeof(GTriPair), 0);
-                for (int32_t k = 0; k < nd.count; k++) {
-                    const int32_t ti = t.leaf_index[(size_t)(nd.start + k)];
-                    const float *v = m.triangles + 9 * (size_t)ti;
-                    GTriPair g;
-                    std::memcpy(&g, arena.data() + (size_t)unit * 32 + (size_t)(k / 2) * sizeof(GTriPair), sizeof g);
-                    const int sl = k & 1;
-                    g.ax[sl] = v[0]; g.ay[sl] = v[1]; g.az[sl] = v[2];
-                    g.e1x[sl] = v[3] - v[0]; g.e1y[sl] = v[4] - v[1]; g.e1z[sl] = v[5] - v[2];        // MeshBVH.cs:87-91
-                    g.e2x[sl] = v[6] - v[0]; g.e2y[sl] = v[7] - v[1]; g.e2z[sl] = v[8] - v[2];
-                    g.orig[sl] = ti;
-                    g.material[sl] = m.tri_material ? m.tri_material[ti] : m.material;
-                    if (!mat_ok(g.material[sl])) bad_material = true;
-                    std::memcpy(arena.data() + (size_t)unit * 32 + (size_t)(k / 2) * sizeof(GTriPair), &g, sizeof g);
-                }
-                return YCGE_REF(REF_MESH_LEAF, (unit << 4) | (uint32_t)nd.count);
-            }
-            arena.resize(arena.size() + sizeof(GNode), 0);
-            GNode g;
-            std::memset(&g, 0, sizeof g);
-            const RefNode &L = t.nodes[(size_t)nd.left];
-            const RefNode &R = t.nodes[(size_t)nd.right];
-            g.lmin_x = L.mn[0]; g.lmin_y = L.mn[1]; g.lmin_z = L.mn[2]; g.lmax_x = L.mx[0]; g.lmax_y = L.mx[1]; g.lmax_z = L.mx[2];
-            g.rmin_x = R.mn[0]; g.rmin_y = R.mn[1]; g.rmin_z = R.mn[2]; g.rmax_x = R.mx[0]; g.rmax_y = R.mx[1]; g.rmax_z = R.mx[2];
-            g.lref = emit(nd.left);
-            g.rref = emit(nd.right);
-            std::memcpy(arena.data() + (size_t)unit * 32, &g, sizeof g);
-            return YCGE_REF(REF_MESH_NODE, unit << 4);
-        };
-        if (t.root >= 0) {
-            gm.root_ref = emit(t.root);
-            for (int a = 0; a < 3; a++) { gm.root_min[a] = t.nodes[t.root].mn[a]; gm.root_max[a] = t.nodes[t.root].mx[a]; }
-        }
+        gm.root_ref = emit_mesh_records(t, m.triangles, m.tri_material, m.material, s->n_materials, arena, bad_leaf, bad_material);
+        if (t.root >= 0) for (int a = 0; a < 3; a++) { gm.root_min[a] = t.nodes[t.root].mn[a]; gm.root_max[a] = t.nodes[t.root].mx[a]; }
         if (bad_leaf) return c->fail(YCGE_ERR_UNSUPPORTED, "mesh %d: a leaf of more than 15 triangles", mi);
         if (bad_material) return c->fail(YCGE_ERR_INVALID_ARG, "mesh %d: triangle material out of range", mi);
         if (arena.size() / 32 >= (1u << 25)) return c->fail(YCGE_ERR_UNSUPPORTED, "mesh records exceed the 1 GB arena");
@@ -1305,6 +1311,22 @@ int ycge_host_build_tree(const float *bounds, const float *centroids, int32_t n,
     return (int)t.nodes.size();
 }
 // Same for a triangle soup (MeshBVH ctor path incl. TryComputeBounds).
+// test hook: the device records of one mesh (single material 0) as emit_mesh_records lays them out
+int ycge_host_mesh_arena(const float *tris9, int32_t n, void *out, int64_t capacity_bytes, uint32_t *root_ref_out)
+{
+    if (n < 0 || (n > 0 && !tris9) || !root_ref_out) return YCGE_ERR_INVALID_ARG;
+    BoundsSoA it;
+    triangle_items(tris9, n, it);
+    BuiltTree t;
+    build_tree(it, TreeFlavour::Mesh, t);
+    std::vector<uint8_t> arena;
+    bool bad_leaf = false, bad_material = false;
+    *root_ref_out = emit_mesh_records(t, tris9, nullptr, 0, 1, arena, bad_leaf, bad_material);
+    if (bad_leaf || bad_material) return YCGE_ERR_UNSUPPORTED;
+    if (out && (int64_t)arena.size() <= capacity_bytes && !arena.empty()) std::memcpy(out, arena.data(), arena.size());
+    return (int)arena.size();
+}
+
 int ycge_host_build_mesh(const float *tris9, int32_t n, void *nodes_out, int32_t *leaf_out, int32_t *stats_out)
 {
     if (n < 0 || (n > 0 && (!tris9 || !nodes_out || !leaf_out))) return YCGE_ERR_INVALID_ARG;
