@@ -38,8 +38,8 @@ int ycge_launch_unit_normals(const float *normal, float *unit, size_t n, hipStre
 int ycge_launch_atrous(int w, int h, int step, const float phi[4], const float *cur, float *dst, const float *albedo, const float *unit_n,
                        const float *depth, const uint8_t *sky, hipStream_t stream);
 int ycge_launch_atrous_inplace(int w, int h, int step, const float phi[4], float *buf, const float *albedo, const float *unit_n,
-                               const float *depth, const uint8_t *sky, const uint32_t *d_pixels, const uint32_t *d_offsets, int n_levels,
-                               int n_bands, int K, hipStream_t stream);
+                               const float *depth, const uint8_t *sky, float *statw, const uint32_t *d_pixels, const uint32_t *d_offsets,
+                               int n_levels, int n_bands, int K, hipStream_t stream);
 int ycge_launch_exposure(const float *hdr, const uint8_t *sky, int w, int h, int step, float *terms, void *state, const float consts[5],
                          hipStream_t stream);
 int ycge_launch_tonemap(const float *hdr, int hiW, int fbW, int fbH, int ss, float gamma, float saturation, float vibrance, const void *state,
@@ -122,8 +122,9 @@ struct ycge_ctx {
     DevBuf<uint32_t> wf_counts, tile_order;
     // denoise / exposure / tonemap stage (ycge_post.hip), allocated on the first frame that asks for SDR output
     DevBuf<float> den_a, den_b, unit_n, exp_terms, d_sdr;
+    DevBuf<float> atrous_statw;                // [pixel][25 taps][3]: colour-independent weight factors of an in-place A-trous iteration
     DevBuf<uint8_t> tone_state;                   // ToneMapper state; lives as long as the context (not reset by Resize)
-    struct InplaceSchedule { int w = 0, h = 0, step = 0, levels = 0, bands = 0; DevBuf<uint32_t> pixels, offsets; };
+    struct InplaceSchedule { int w = 0, h = 0, step = 0, levels = 0, bands = 0; uint32_t max_level_pixels = 0; DevBuf<uint32_t> pixels, offsets; };
     std::vector<InplaceSchedule *> schedules;     // level schedules of the in-place A-trous iterations, by (w, h, step)
     // what ycge_scene_update_objects needs from the last full upload
     std::vector<GMesh> gmeshes_host;
@@ -250,7 +251,7 @@ int set_geometry(ycge_ctx *c, int fbw, int fbh, int ss)
     c->tiles_per_rank_padded = (c->n_tiles + world - 1) / world;
     c->taa_valid = false;                                       // Resize: taaHistoryValid = false (:137), taa.Resize (TemporalAA.cs:34-46)
     c->last_cam[0] = c->last_cam[1] = c->last_cam[2] = NAN; c->last_yaw = c->last_pitch = NAN;
-    c->den_a.release(); c->den_b.release(); c->unit_n.release(); c->exp_terms.release(); c->d_sdr.release();     // spatialA / spatialB, :129-130
+    c->den_a.release(); c->den_b.release(); c->unit_n.release(); c->exp_terms.release(); c->d_sdr.release(); c->atrous_statw.release();     // spatialA / spatialB, :129-130
     c->denoised = nullptr;
     for (auto *sc : c->schedules) { sc->pixels.release(); sc->offsets.release(); delete sc; }      // level schedules are per size: rebuilt on demand
     c->schedules.clear();
@@ -462,7 +463,7 @@ void ycge_destroy(ycge_ctx *c)
     c->prev_normal.release(); c->prev_depth.release(); c->sky.release(); c->prev_sky.release();
     c->dbg_rays.release(); c->dbg_hit_t.release(); c->dbg_prim.release(); c->dbg_sub.release(); c->dbg_rng.release();
     c->counters.release(); c->wave_prof.release(); c->own_slab.release();
-    c->den_a.release(); c->den_b.release(); c->unit_n.release(); c->exp_terms.release(); c->d_sdr.release(); c->tone_state.release();
+    c->den_a.release(); c->den_b.release(); c->unit_n.release(); c->exp_terms.release(); c->d_sdr.release(); c->atrous_statw.release(); c->tone_state.release();
     for (auto *sc : c->schedules) { sc->pixels.release(); sc->offsets.release(); delete sc; }
     c->schedules.clear();
     c->wf_q0.release(); c->wf_q1.release(); c->wf_hit.release(); c->wf_lq.release(); c->wf_seg.release(); c->wf_counts.release(); c->tile_order.release(); c->block_cost.release(); c->block_order.release(); c->order_ws.release(); c->stack_spill.release(); c->path_stack.release();
@@ -1021,8 +1022,11 @@ void build_inplace_schedule(int w, int h, int step, std::vector<uint32_t> &pixel
 
 // The level lists regrouped per band of `rows_per_band` image rows: band_pixels sorted by (band, level),
 // band_offsets[b * (levels + 1) + t] = start of level t (0-based) of band b.
+// The level lists per band, every level padded to whole passes of 32 pixels (0xffffffff = no pixel): band_offsets[b * (levels + 1) + t]
+// = first pass of level t of band b (passes are numbered through all bands; pass i covers band_pixels[32 i .. 32 i + 32)).
+// max_level_pixels = the most pixels (padding included) one level of one band holds: bounds what a launch of K levels writes.
 void band_inplace_schedule(int w, int h, int rows_per_band, const std::vector<uint32_t> &pixels, const std::vector<uint32_t> &offsets,
-                           std::vector<uint32_t> &band_pixels, std::vector<uint32_t> &band_offsets, int &n_bands)
+                           std::vector<uint32_t> &band_pixels, std::vector<uint32_t> &band_offsets, int &n_bands, uint32_t &max_level_pixels)
 {
     const int levels = (int)offsets.size() - 1;
     n_bands = (h + rows_per_band - 1) / rows_per_band;
@@ -1030,18 +1034,24 @@ void band_inplace_schedule(int w, int h, int rows_per_band, const std::vector<ui
     std::vector<uint32_t> count((size_t)n_bands * levels, 0);
     for (int t = 0; t < levels; t++)
         for (uint32_t i = offsets[t]; i < offsets[t + 1]; i++) count[(size_t)((pixels[i] / (uint32_t)w) / rows_per_band) * levels + t]++;
-    uint32_t run = 0;
+    uint32_t run = 0;       // in passes
+    max_level_pixels = 0;
     for (int b = 0; b < n_bands; b++) {
-        for (int t = 0; t < levels; t++) { band_offsets[(size_t)b * (levels + 1) + t] = run; run += count[(size_t)b * levels + t]; }
+        for (int t = 0; t < levels; t++) {
+            band_offsets[(size_t)b * (levels + 1) + t] = run;
+            const uint32_t passes = (count[(size_t)b * levels + t] + 31u) / 32u;
+            run += passes;
+            if (passes * 32u > max_level_pixels) max_level_pixels = passes * 32u;
+        }
         band_offsets[(size_t)b * (levels + 1) + levels] = run;
     }
-    band_pixels.resize(pixels.size());
+    band_pixels.assign((size_t)run * 32, 0xffffffffu);
     std::vector<uint32_t> cursor((size_t)n_bands * levels);
-    for (int b = 0; b < n_bands; b++) for (int t = 0; t < levels; t++) cursor[(size_t)b * levels + t] = band_offsets[(size_t)b * (levels + 1) + t];
+    for (int b = 0; b < n_bands; b++) for (int t = 0; t < levels; t++) cursor[(size_t)b * levels + t] = band_offsets[(size_t)b * (levels + 1) + t] * 32u;
     for (int t = 0; t < levels; t++)
         for (uint32_t i = offsets[t]; i < offsets[t + 1]; i++) {
             const uint32_t p = pixels[i];
-            band_pixels[cursor[(size_t)((p / (uint32_t)w) / rows_per_band) * levels + t]++] = p;
+            band_pixels[cursor[(size_t)((p / (uint32_t)w) / rows_per_band) * levels + t]++] = (p % (uint32_t)w) | ((p / (uint32_t)w) << 16);      // x | y << 16
         }
 }
 
@@ -1069,6 +1079,7 @@ int run_post(ycge_ctx *c, hipStream_t stream, float *out_sdr_host, bool timed)
     for (int it = 0; it < iters; it++) {
         const int step = 1 << it;
         if (cur == dst) {
+            if (w > 65535 || h > 65535) return c->fail(YCGE_ERR_UNSUPPORTED, "in-place A-trous: trace grid above 65535 pixels a side");
             ycge_ctx::InplaceSchedule *sc = nullptr;
             for (auto *k : c->schedules) if (k->w == w && k->h == h && k->step == step) sc = k;
             if (!sc) {
@@ -1078,14 +1089,19 @@ int run_post(ycge_ctx *c, hipStream_t stream, float *out_sdr_host, bool timed)
                 build_inplace_schedule(w, h, step, px, off);
                 // bands of whole rows; related pixels are at most 2 * step rows apart, so they share a band or sit in adjacent ones
                 const int rows_per_band = 2 * step > 16 ? 2 * step : 16;
-                band_inplace_schedule(w, h, rows_per_band, px, off, bpx, boff, sc->bands);
+                band_inplace_schedule(w, h, rows_per_band, px, off, bpx, boff, sc->bands, sc->max_level_pixels);
                 sc->levels = (int)off.size() - 1;
                 c->schedules.push_back(sc);
                 HIP_TRY(c, sc->pixels.upload(bpx)); HIP_TRY(c, sc->offsets.upload(boff));
             }
-            static const int levels_per_launch = getenv("YCGE_POST_K") ? atoi(getenv("YCGE_POST_K")) : 8;
-            e = ycge_launch_atrous_inplace(w, h, step, phi, dst, c->g_albedo.p, c->unit_n.p, c->g_depth.p, c->sky.p, sc->pixels.p,
-                                           sc->offsets.p, sc->levels, sc->bands, levels_per_launch > 0 ? levels_per_launch : 8, stream);
+            // levels per launch: a launch keeps what it writes in a 2048-entry LDS table (k_atrous_band), at most 3/4 full
+            int levels_per_launch = getenv("YCGE_POST_K") ? atoi(getenv("YCGE_POST_K")) : YCGE_POST_K_DEFAULT;
+            const int k_cap = (int)(1536u / (sc->max_level_pixels > 0 ? sc->max_level_pixels : 32u));
+            if (levels_per_launch > k_cap) levels_per_launch = k_cap;
+            if (levels_per_launch < 1) return c->fail(YCGE_ERR_UNSUPPORTED, "in-place A-trous: a level of %u pixels in one band", sc->max_level_pixels);
+            if (!c->atrous_statw.p) HIP_TRY(c, c->atrous_statw.alloc(n * 75));
+            e = ycge_launch_atrous_inplace(w, h, step, phi, dst, c->g_albedo.p, c->unit_n.p, c->g_depth.p, c->sky.p, c->atrous_statw.p,
+                                           sc->pixels.p, sc->offsets.p, sc->levels, sc->bands, levels_per_launch, stream);
         } else {
             e = ycge_launch_atrous(w, h, step, phi, cur, dst, c->g_albedo.p, c->unit_n.p, c->g_depth.p, c->sky.p, stream);
         }

@@ -112,66 +112,135 @@ __global__ __launch_bounds__(256) void k_atrous(const AtrousParams A, const floa
     }
 }
 
-// One pixel of an in-place iteration by a 32-lane group: lanes 0..24 evaluate one tap each; lanes 0..3 then add the
-// 25 products of one component (x, y, z, weight) in tap order.  Called by every thread of the workgroup (barriers).
-#define YCGE_POST_GROUPS 32         // pixel groups per workgroup (1024 threads)
+// The three factors of a tap's weight that do not depend on the colour buffer (normal, depth, albedo terms of
+// atrous_tap_weight, the same expressions): an in-place iteration changes colours only, so these are computed for every
+// (pixel, tap) by the whole chip before the iteration starts instead of inside its serial chain of levels - there a band
+// is ONE workgroup, and four binary64 exponentials per tap made a level's time the fp64 issue rate of one CU.
+// statw[(p * 25 + tap) * 3 + {0, 1, 2}] = wn, wz, wa.  32 lanes per pixel, 25 of them with a tap.
+__global__ __launch_bounds__(256) void k_atrous_static(const AtrousParams A, const float *__restrict__ albedo, const float *__restrict__ unit_n,
+                                                       const float *__restrict__ depth, const uint8_t *__restrict__ sky, float *__restrict__ statw,
+                                                       size_t n)
+{
+    const size_t gid = (size_t)blockIdx.x * 256 + threadIdx.x;
+    const size_t p = gid >> 5;
+    const int t = (int)(gid & 31);
+    if (p >= n || t >= 25 || sky[p]) return;
+    const int x = (int)(p % (size_t)A.w), y = (int)(p / (size_t)A.w);
+    const int kx = t % 5 - 2, ky = t / 5 - 2;
+    const size_t j = atrous_tap_index(A, x, y, kx, ky);
+    if (sky[j]) return;                         // a tap the reference skips: its weight is never read
+    const F3 n0 = ld3(unit_n, p), nj = ld3(unit_n, j), a0 = ld3(albedo, p), aj = ld3(albedo, j);
+    const float dn = cs_max(0.0f, 1.0f - dot(n0, nj));
+    const float dz = cs_abs(depth[j] - depth[p]);
+    const float da = cs_abs(aj.x - a0.x) + cs_abs(aj.y - a0.y) + cs_abs(aj.z - a0.z);
+    float *o = statw + (p * 25 + (size_t)t) * 3;
+    o[0] = m_exp(-dn / A.n_phi);
+    o[1] = m_exp(-dz / A.z_phi);
+    o[2] = m_exp(-(da) / A.a_phi);
+}
+
+// ---- in-place iteration.  The image is cut into bands of whole rows, one 1024-thread workgroup per band; a band's pixels
+// are listed level by level, every level padded to whole PASSES of 32 pixels (0xffffffff = no pixel).  A pass gives each
+// pixel a 32-lane group: lanes 0..24 evaluate one tap each, lanes 0..3 then add the 25 products of one component
+// (x, y, z, weight) in tap order.  Launch `launch` runs, for band b, the passes of its levels [K (launch - b),
+// K (launch - b) + K) one after the other.  Two stencil-related pixels are either in the same band (same workgroup:
+// ordered by pass) or in adjacent bands, and then the one that comes first in scan order is in the upper band and has
+// the smaller level, hence a strictly smaller launch index band + level / K: kernel boundaries order them.
+//
+// What a pass costs is its chain of dependent operations, 2 600 times per 1080p frame, so the chain is kept short:
+//  * everything a pass reads from memory - pixel index, colours of the pixel and of its taps, sky flags, the static
+//    weights - is fetched ONE PASS AHEAD (two for the index), while the previous pass computes;
+//  * the values a launch writes stay in an LDS hash table (pixel -> new colour) until the launch ends: a tap whose
+//    source was rewritten earlier in this launch takes it from there, so a pass never waits for a store to reach L2,
+//    and the prefetch may read a stale colour for exactly those pixels (the table wins);
+//  * the 25 products of a pixel are written and read by ONE wavefront (a group is half of it): no workgroup barrier
+//    between the taps and the sum, one barrier per pass (table visible to the next pass), and it is a bare
+//    s_barrier - the fenced __syncthreads would wait for the prefetches in flight.
+#define YCGE_POST_GROUPS 32         // pixels per pass
+#define YCGE_POST_HASH 2048         // entries; the host keeps a launch's pixels below 3/4 of it
+#define YCGE_POST_NONE 0xffffffffu
 struct PostShared {
     float val[YCGE_POST_GROUPS][25][4];
-    uint32_t mask[YCGE_POST_GROUPS];
-    float sum[YCGE_POST_GROUPS][4];
+    uint32_t tag[YCGE_POST_HASH];
+    float hv[YCGE_POST_HASH][3];
 };
-__device__ __forceinline__ void atrous_pixel_group(const AtrousParams &A, float *buf, const float *albedo, const float *unit_n, const float *depth,
-                                                   const uint8_t *sky, bool live, uint32_t p, PostShared &sh)
+__device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+__device__ __forceinline__ uint32_t post_hash(uint32_t p) { return (p * 2654435761u) >> (32 - 11); }
+struct PassData {           // what one lane needs for one pass, fetched ahead
+    F3 c0, cj;
+    float wn, wz, wa;
+    uint32_t p, j;          // pixel index and this lane's tap source
+    uint8_t sky0, sky_j;
+};
+__device__ __forceinline__ PassData pass_fetch(const AtrousParams &A, const float *buf, const float *statw, const uint8_t *sky, uint32_t p, int t)
+{
+    PassData D;
+    const uint32_t e = p == YCGE_POST_NONE ? 0u : p;        // list entries are x | y << 16: no division in the chain
+    const int x = (int)(e & 0xffffu), y = (int)(e >> 16);
+    const uint32_t pp = (uint32_t)x + (uint32_t)y * (uint32_t)A.w;
+    D.p = pp;
+    D.j = (p != YCGE_POST_NONE && t < 25) ? (uint32_t)atrous_tap_index(A, x, y, t % 5 - 2, t / 5 - 2) : pp;
+    D.sky0 = sky[pp];
+    D.c0 = ld3(buf, pp);
+    D.sky_j = sky[D.j];
+    D.cj = ld3(buf, D.j);
+    const float *sw = statw + ((size_t)pp * 25 + (size_t)(t < 25 ? t : 0)) * 3;
+    D.wn = sw[0]; D.wz = sw[1]; D.wa = sw[2];
+    return D;
+}
+__device__ __forceinline__ void pass_compute(const AtrousParams &A, uint32_t p, PassData D, PostShared &sh)
 {
     const int g = threadIdx.x >> 5, t = threadIdx.x & 31;
-    // every load of the pixel - its own values and this lane's tap - is issued before anything is computed: inside a
-    // band the levels run back to back, and a level's time is its chain of dependent fetches
-    const int x = (int)(p % (uint32_t)A.w), y = (int)(p / (uint32_t)A.w);
     const int kx = t % 5 - 2, ky = t / 5 - 2;
-    const size_t j = (live && t < 25) ? atrous_tap_index(A, x, y, kx, ky) : (size_t)p;
-    Center C;
-    C.sky0 = sky[p];
-    C.c0 = ld3(buf, p); C.a0 = ld3(albedo, p); C.n0 = ld3(unit_n, p); C.z0 = depth[p];
-    const uint8_t sky_j = sky[j];
-    const F3 cj = ld3(buf, j), aj = ld3(albedo, j), nj = ld3(unit_n, j);
-    const float zj = depth[j];
-    const bool work = live && !C.sky0;          // sky pixel: dst[x, y] = cur[x, y] on the same buffer, nothing to do
-    const bool valid = work && t < 25 && sky_j == C.sky0;
+    const bool work = p != YCGE_POST_NONE && !D.sky0;        // sky pixel: dst[x, y] = cur[x, y] on the same buffer, nothing to do
+    const bool valid = work && t < 25 && D.sky_j == D.sky0;
     if (valid) {
-        const float wght = atrous_tap_weight(A, kx, ky, C, cj, aj, nj, zj);
+        F3 cj = D.cj;
+        for (uint32_t h = post_hash(D.j);; h = (h + 1u) & (YCGE_POST_HASH - 1u)) {      // rewritten earlier in this launch?
+            const uint32_t tg = sh.tag[h];
+            if (tg == D.j) { cj = f3(sh.hv[h][0], sh.hv[h][1], sh.hv[h][2]); break; }
+            if (tg == YCGE_POST_NONE) break;
+        }
+        // atrous_tap_weight with its three colour-independent exponentials read back: w_base * wc * wn * wz * wa, left to right
+        const float w_base = kernel_tap(kx) * kernel_tap(ky);
+        const float dl = cs_abs(luma3(cj) - luma3(D.c0));
+        const float wc = m_exp(-dl / A.c_phi);
+        const float wght = w_base * wc * D.wn * D.wz * D.wa;
         sh.val[g][t][0] = cj.x * wght; sh.val[g][t][1] = cj.y * wght; sh.val[g][t][2] = cj.z * wght; sh.val[g][t][3] = wght;
+    } else if (work && t < 25) {
+        // a tap the reference skips contributes +0: the running sums start at +0.0f and can therefore never be -0.0f, so
+        // s + 0.0f == s for every value they take - no per-tap select in the chain of adds below
+        sh.val[g][t][0] = 0.0f; sh.val[g][t][1] = 0.0f; sh.val[g][t][2] = 0.0f; sh.val[g][t][3] = 0.0f;
     }
-    const unsigned long long m = __ballot(valid);
-    if (t == 0) sh.mask[g] = (uint32_t)(m >> ((threadIdx.x & 32) ? 32 : 0));
-    __syncthreads();            // every tap of this batch has been read before any of its pixels is written
-    if (work && t < 4) {        // 25 LDS reads issued together, then the adds in tap order; a skipped tap leaves the sum untouched
-        const uint32_t mask = sh.mask[g];
+    // the group's 25 products were written by this wavefront: in-order LDS, no barrier.  25 reads issued together, then the
+    // adds in tap order
+    float acc = 0.0f;
+    if (work && t < 4) {
         float v[25];
 #pragma unroll
         for (int k = 0; k < 25; k++) v[k] = sh.val[g][k][t];
-        float acc = 0.0f;
 #pragma unroll
-        for (int k = 0; k < 25; k++) { const float nx = acc + v[k]; acc = ((mask >> k) & 1u) ? nx : acc; }
-        sh.sum[g][t] = acc;
+        for (int k = 0; k < 25; k++) acc = acc + v[k];
     }
-    __syncthreads();
-    if (work && t == 0) {
-        const float wsum = sh.sum[g][3];
-        if (wsum > 1e-8f) {
-            const float inv = 1.0f / wsum;
-            st3(buf, p, f3(sh.sum[g][0] * inv, sh.sum[g][1] * inv, sh.sum[g][2] * inv));
-        }                                       // else dst = c0: unchanged
+    const float wsum = __shfl(acc, (threadIdx.x & 32) + 3, 64);
+    uint32_t h = 0;
+    const bool changed = work && wsum > 1e-8f;          // else dst = c0: unchanged, nothing to record
+    if (changed && t == 0) {
+        for (h = post_hash(D.p);; h = (h + 1u) & (YCGE_POST_HASH - 1u)) {
+            const uint32_t prev = atomicCAS(&sh.tag[h], YCGE_POST_NONE, D.p);
+            if (prev == YCGE_POST_NONE || prev == D.p) break;
+        }
     }
+    h = (uint32_t)__shfl((int)h, threadIdx.x & 32, 64);
+    if (changed && t < 3) {
+        const float inv = 1.0f / wsum;
+        sh.hv[h][t] = acc * inv;
+    }
+    lds_barrier();              // the table holds this pass's pixels before the next pass looks its taps up
 }
 
-// In-place iteration, launch `launch`: the image is cut into bands of whole rows, one workgroup per band; band b runs
-// its levels [K * (launch - b), K * (launch - b) + K) one after the other (barrier + workgroup fence between levels).
-// Two stencil-related pixels are either in the same band (same workgroup: ordered by level) or in adjacent bands, and
-// then the one that comes first in scan order is in the upper band and has the smaller level, hence a strictly
-// smaller launch index band + level / K: kernel boundaries order them.  pixels / off: the level lists per band
-// (off[b * (levels + 1) + t] .. off[b * (levels + 1) + t + 1] = level t of band b).
-__global__ __launch_bounds__(1024) void k_atrous_band(const AtrousParams A, float *__restrict__ buf, const float *__restrict__ albedo,
-                                                      const float *__restrict__ unit_n, const float *__restrict__ depth,
+// pixels: the padded pass list; off[b * (levels + 1) + t] = first pass of level t of band b (.. + 1: one past its last)
+__global__ __launch_bounds__(1024) void k_atrous_band(const AtrousParams A, float *__restrict__ buf, const float *__restrict__ statw,
                                                       const uint8_t *__restrict__ sky, const uint32_t *__restrict__ pixels,
                                                       const uint32_t *__restrict__ off, int levels, int K, int launch, int first_band)
 {
@@ -181,22 +250,24 @@ __global__ __launch_bounds__(1024) void k_atrous_band(const AtrousParams A, floa
     if (g0 < 0) return;
     const int t0 = g0 * K, t1 = t0 + K < levels ? t0 + K : levels;
     const uint32_t *o = off + (size_t)b * (levels + 1);
-    const int grp = threadIdx.x >> 5;
-    // the pixel index of the next level's first batch is fetched while this level computes
-    uint32_t lo = o[t0], hi = t0 < t1 ? o[t0 + 1] : o[t0];
-    uint32_t p_first = lo + (uint32_t)grp < hi ? pixels[lo + (uint32_t)grp] : 0u;
-    for (int t = t0; t < t1; t++) {
-        const uint32_t nlo = hi, nhi = t + 1 < t1 ? o[t + 2] : hi;
-        const uint32_t p_next = (t + 1 < t1 && nlo + (uint32_t)grp < nhi) ? pixels[nlo + (uint32_t)grp] : 0u;
-        for (uint32_t base = lo; base < hi; base += YCGE_POST_GROUPS) {
-            const uint32_t slot = base + (uint32_t)grp;
-            const bool live = slot < hi;
-            const uint32_t p = !live ? 0u : base == lo ? p_first : pixels[slot];
-            atrous_pixel_group(A, buf, albedo, unit_n, depth, sky, live, p, sh);
-        }
-        __threadfence_block();
-        __syncthreads();        // this level's pixels are written before the next level reads them
-        lo = nlo; hi = nhi; p_first = p_next;
+    const uint32_t pass_lo = o[t0], pass_hi = o[t1];
+    if (pass_lo >= pass_hi) return;
+    const int grp = threadIdx.x >> 5, t = threadIdx.x & 31;
+    for (uint32_t e = threadIdx.x; e < YCGE_POST_HASH; e += 1024) sh.tag[e] = YCGE_POST_NONE;
+    uint32_t p1 = pixels[(size_t)pass_lo * YCGE_POST_GROUPS + grp];
+    uint32_t p2 = pass_lo + 1 < pass_hi ? pixels[(size_t)(pass_lo + 1) * YCGE_POST_GROUPS + grp] : YCGE_POST_NONE;
+    PassData D1 = pass_fetch(A, buf, statw, sky, p1, t);
+    lds_barrier();              // table cleared
+    for (uint32_t i = pass_lo; i < pass_hi; i++) {
+        const uint32_t p3 = i + 2 < pass_hi ? pixels[(size_t)(i + 2) * YCGE_POST_GROUPS + grp] : YCGE_POST_NONE;
+        const PassData D2 = pass_fetch(A, buf, statw, sky, p2, t);      // in flight while this pass computes
+        pass_compute(A, p1, D1, sh);
+        p1 = p2; D1 = D2; p2 = p3;
+    }
+    // the launch's new colours go to memory together; the kernel boundary publishes them
+    for (uint32_t e = threadIdx.x; e < YCGE_POST_HASH; e += 1024) {
+        const uint32_t tg = sh.tag[e];
+        if (tg != YCGE_POST_NONE) st3(buf, tg, f3(sh.hv[e][0], sh.hv[e][1], sh.hv[e][2]));
     }
 }
 
@@ -347,16 +418,18 @@ int ycge_launch_atrous(int w, int h, int step, const float phi[4], const float *
 
 // in-place iteration as a pipeline of bands (see k_atrous_band): n_bands + ceil(levels / K) - 1 launches
 int ycge_launch_atrous_inplace(int w, int h, int step, const float phi[4], float *buf, const float *albedo, const float *unit_n,
-                               const float *depth, const uint8_t *sky, const uint32_t *d_pixels, const uint32_t *d_offsets, int n_levels,
-                               int n_bands, int K, hipStream_t stream)
+                               const float *depth, const uint8_t *sky, float *statw, const uint32_t *d_pixels, const uint32_t *d_offsets,
+                               int n_levels, int n_bands, int K, hipStream_t stream)
 {
     ycge::AtrousParams A = {w, h, step, phi[0], phi[1], phi[2], phi[3]};
+    const size_t n = (size_t)w * h;
+    hipLaunchKernelGGL(ycge::k_atrous_static, dim3((unsigned)((n * 32 + 255) / 256)), dim3(256), 0, stream, A, albedo, unit_n, depth, sky, statw, n);
     const int groups = (n_levels + K - 1) / K;
     for (int launch = 0; launch < n_bands + groups - 1; launch++) {
         const int first = launch - (groups - 1) > 0 ? launch - (groups - 1) : 0;      // bands with a level group left to run
         const int last = launch < n_bands - 1 ? launch : n_bands - 1;
-        hipLaunchKernelGGL(ycge::k_atrous_band, dim3((unsigned)(last - first + 1)), dim3(1024), 0, stream, A, buf, albedo, unit_n, depth, sky,
-                           d_pixels, d_offsets, n_levels, K, launch, first);
+        hipLaunchKernelGGL(ycge::k_atrous_band, dim3((unsigned)(last - first + 1)), dim3(1024), 0, stream, A, buf, statw, sky, d_pixels, d_offsets,
+                           n_levels, K, launch, first);
     }
     return (int)hipGetLastError();
 }
