@@ -315,10 +315,19 @@ __global__ __launch_bounds__(64) void k_exposure_sum(const float *__restrict__ t
         }
         __syncthreads();
         if (lane == 0) {
-#pragma unroll 8
-            for (int i = 0; i < 256; i++) {
-                const float4 v = buf[i];
-                log_sum += v.x; log_sum += v.y; log_sum += v.z; log_sum += v.w;
+            // 64 terms in registers while the next 64 come out of LDS: the chain never waits for a read
+            float4 cur[16], nxt[16];
+#pragma unroll
+            for (int k = 0; k < 16; k++) cur[k] = buf[k];
+#pragma unroll 1
+            for (int blk = 0; blk < 16; blk++) {
+                const int nb = blk + 1 < 16 ? blk + 1 : blk;
+#pragma unroll
+                for (int k = 0; k < 16; k++) nxt[k] = buf[nb * 16 + k];
+#pragma unroll
+                for (int k = 0; k < 16; k++) { log_sum += cur[k].x; log_sum += cur[k].y; log_sum += cur[k].z; log_sum += cur[k].w; }
+#pragma unroll
+                for (int k = 0; k < 16; k++) cur[k] = nxt[k];
             }
         }
         // the other buffer is written next; it was last read two iterations ago, before the barrier above
