@@ -105,23 +105,47 @@ def main():
     r = make(False)
     stream = torch.cuda.current_stream()
     slab = all_slabs = None
+    # Several GPUs: the trace of frame N+1 does not depend on the all-gather / resolve (TAA) of frame N - the library keeps the
+    # trace's outputs apart from the resolved frame - so the two run on two streams with double-buffered slabs: a frame
+    # costs max(trace, gather + resolve) instead of their sum.  Every frame is still traced, gathered and resolved inside
+    # the timed region (both streams are drained before the clock stops).  YCGE_BENCH_PIPELINE=0: one stream, in sequence.
+    pipelined = multi and os.environ.get("YCGE_BENCH_PIPELINE", "1") != "0"
     if multi:
         nb = r.tile_slab_bytes()
-        slab = torch.empty(nb // 4, dtype=torch.float32, device="cuda")
-        all_slabs = torch.empty(world * (nb // 4), dtype=torch.float32, device="cuda")
+        slabs = [torch.empty(nb // 4, dtype=torch.float32, device="cuda") for _ in range(2)]
+        gathered = [torch.empty(world * (nb // 4), dtype=torch.float32, device="cuda") for _ in range(2)]
+        slab, all_slabs = slabs[0], gathered[0]
+        s_trace, s_comm = torch.cuda.Stream(), torch.cuda.Stream()
+        ev_traced = [torch.cuda.Event() for _ in range(2)]
+        ev_resolved = [torch.cuda.Event() for _ in range(2)]
+        n_issued = [0]
 
     def step(rr, want_stats=False):
         if not multi:
             rr.TryFlipAndBlit()
             return rr.stats.trace_ms
-        rr.trace_tiles(slab.data_ptr(), stream.cuda_stream, want_stats=want_stats)
-        t = rr.stats.trace_ms if want_stats else 0.0
-        dist.all_gather_into_tensor(all_slabs, slab)
-        rr.resolve_gathered(all_slabs.data_ptr(), stream.cuda_stream)
-        return t
+        if not pipelined or want_stats:
+            rr.trace_tiles(slab.data_ptr(), stream.cuda_stream, want_stats=want_stats)
+            t = rr.stats.trace_ms if want_stats else 0.0
+            dist.all_gather_into_tensor(all_slabs, slab)
+            rr.resolve_gathered(all_slabs.data_ptr(), stream.cuda_stream)
+            return t
+        k = n_issued[0] & 1
+        n_issued[0] += 1
+        with torch.cuda.stream(s_trace):
+            s_trace.wait_event(ev_resolved[k])           # slab k was last read by the gather of two frames ago
+            rr.trace_tiles(slabs[k].data_ptr(), s_trace.cuda_stream)
+            ev_traced[k].record(s_trace)
+        with torch.cuda.stream(s_comm):
+            s_comm.wait_event(ev_traced[k])
+            dist.all_gather_into_tensor(gathered[k], slabs[k])
+            rr.resolve_gathered(gathered[k].data_ptr(), s_comm.cuda_stream)
+            ev_resolved[k].record(s_comm)
+        return 0.0
 
     def fence():
         if multi:
+            s_trace.synchronize(); s_comm.synchronize()
             dist.barrier()
         torch.cuda.synchronize()
 
@@ -133,7 +157,7 @@ def main():
     t0 = time.perf_counter()
     for _ in range(args.steps):
         # one GPU: ycge_render_frame times k_trace with HIP events on its own stream as part of the call.  Several GPUs:
-        # no per-step host synchronisation inside the timed region (trace -> all-gather -> resolve are queued on one stream)
+        # no per-step host synchronisation inside the timed region (trace on one stream, all-gather -> resolve on another, see above)
         trace_ms.append(step(r, want_stats=not multi))
     fence()
     elapsed = time.perf_counter() - t0
@@ -216,7 +240,7 @@ def main():
                                                                5: "voxel world 544x256x544"}[args.config],
                        "trace_grid": f"{hiW}x{hiH}", "spp": ss * ss, "triangles": flat.n_triangles,
                        "frame": "ray-gen + trace + TAA" + (" + RCCL all-gather of tile slabs + un-permute" if multi else ""),
-                       "parallelism": f"framebuffer tiles 32x8 round-robin over {world} GPU(s)", "device": name, "compute_units": cus},
+                       "parallelism": f"framebuffer tiles 32x8 round-robin over {world} GPU(s)" + (", one all-gather per frame; trace of frame N+1 beside gather + resolve of frame N (two streams)" if pipelined else ", one all-gather per frame" if multi else ""), "device": name, "compute_units": cus},
             "primary_mrays_per_s": round(pixels * args.steps / elapsed / 1e6, 2),
             "rays_per_frame": round(per_frame["n_rays"], 1),
             "work_per_frame": {k: round(v, 1) for k, v in per_frame.items()},

@@ -347,3 +347,44 @@ def test_query_fan_out_and_refill_kernels_bit_exact(product_lib, oracle, monkeyp
             o.render(stages=1, threads=8); g.TryFlipAndBlit()
             _assert_parity(pu.compare_frame(o, g), f"{knob} {label} frame{f}")
         o.close(); g.close()
+
+
+def test_tiled_frame_pipelined_over_two_streams(product_lib, path):
+    """bench.py's multi-GPU loop runs the trace of frame N+1 on one stream beside the all-gather + resolve (TAA) of frame N on
+    another, with double-buffered slabs: the library keeps the trace's outputs apart from the resolved frame.  One rank in slab
+    mode (the gather is a copy): five frames pipelined must equal five frames issued in sequence, bit for bit."""
+    import torch
+    sc, _, _, ss, pose = scenes.config_scene(3)
+    flat = flatten(sc)
+    w, h = 320, 90
+
+    def mk():
+        r = RaytraceRenderer(flat, w, h, pose["fov"], ss)
+        r.SetCamera(pose["pos"], pose["yaw"], pose["pitch"])
+        return r
+    seq, pip = mk(), mk()
+    n = seq.tile_slab_bytes() // 4
+    slab = torch.empty(n, dtype=torch.float32, device="cuda")
+    for _ in range(5):
+        seq.trace_tiles(slab.data_ptr(), 0, want_stats=True)
+        seq.resolve_gathered(slab.data_ptr(), 0, want_stats=True)
+    slabs = [torch.empty(n, dtype=torch.float32, device="cuda") for _ in range(2)]
+    gathered = [torch.empty(n, dtype=torch.float32, device="cuda") for _ in range(2)]
+    s_trace, s_comm = torch.cuda.Stream(), torch.cuda.Stream()
+    ev_traced = [torch.cuda.Event() for _ in range(2)]
+    ev_resolved = [torch.cuda.Event() for _ in range(2)]
+    for i in range(5):
+        k = i & 1
+        with torch.cuda.stream(s_trace):
+            s_trace.wait_event(ev_resolved[k])
+            pip.trace_tiles(slabs[k].data_ptr(), s_trace.cuda_stream)
+            ev_traced[k].record(s_trace)
+        with torch.cuda.stream(s_comm):
+            s_comm.wait_event(ev_traced[k])
+            gathered[k].copy_(slabs[k], non_blocking=True)          # stands in for the all-gather
+            pip.resolve_gathered(gathered[k].data_ptr(), s_comm.cuda_stream)
+            ev_resolved[k].record(s_comm)
+    torch.cuda.synchronize()
+    for which in (abi.BUF_CURRENT_HDR, abi.BUF_G_ALBEDO, abi.BUF_G_NORMAL, abi.BUF_G_DEPTH, abi.BUF_SKY_MASK, abi.BUF_TAA_HISTORY):
+        assert pu.bits_equal(seq.read(which), pip.read(which)), which
+    seq.close(); pip.close()

@@ -111,6 +111,10 @@ struct ycge_ctx {
     // per-pixel buffers in HBM (row-major, x + y*hiW)
     DevBuf<float> current_hdr, g_albedo, g_normal, g_depth, taa_hist, prev_normal, prev_depth;
     DevBuf<uint8_t> sky, prev_sky;
+    // tiled frame: the trace writes its tiles here (same full-frame indexing), ycge_resolve_gathered writes the buffers above -
+    // so the trace of frame N+1 may run beside the all-gather and resolve of frame N (two streams, caller-ordered)
+    DevBuf<float> t_hdr, t_albedo, t_normal, t_depth;
+    DevBuf<uint8_t> t_sky;
     DevBuf<float> dbg_rays, dbg_hit_t;
     DevBuf<int32_t> dbg_prim, dbg_sub;
     DevBuf<uint64_t> dbg_rng;
@@ -253,6 +257,7 @@ int set_geometry(ycge_ctx *c, int fbw, int fbh, int ss)
     c->last_cam[0] = c->last_cam[1] = c->last_cam[2] = NAN; c->last_yaw = c->last_pitch = NAN;
     c->den_a.release(); c->den_b.release(); c->unit_n.release(); c->exp_terms.release(); c->d_sdr.release(); c->atrous_statw.release();     // spatialA / spatialB, :129-130
     c->denoised = nullptr;
+    c->t_hdr.release(); c->t_albedo.release(); c->t_normal.release(); c->t_depth.release(); c->t_sky.release();
     for (auto *sc : c->schedules) { sc->pixels.release(); sc->offsets.release(); delete sc; }      // level schedules are per size: rebuilt on demand
     c->schedules.clear();
     int rc = alloc_frame_buffers(c);
@@ -463,6 +468,7 @@ void ycge_destroy(ycge_ctx *c)
     c->prev_normal.release(); c->prev_depth.release(); c->sky.release(); c->prev_sky.release();
     c->dbg_rays.release(); c->dbg_hit_t.release(); c->dbg_prim.release(); c->dbg_sub.release(); c->dbg_rng.release();
     c->counters.release(); c->wave_prof.release(); c->own_slab.release();
+    c->t_hdr.release(); c->t_albedo.release(); c->t_normal.release(); c->t_depth.release(); c->t_sky.release();
     c->den_a.release(); c->den_b.release(); c->unit_n.release(); c->exp_terms.release(); c->d_sdr.release(); c->atrous_statw.release(); c->tone_state.release();
     for (auto *sc : c->schedules) { sc->pixels.release(); sc->offsets.release(); delete sc; }
     c->schedules.clear();
@@ -891,6 +897,14 @@ int begin_and_trace(ycge_ctx *c, float *d_slab, hipStream_t stream, FrameState &
     std::memset(&O, 0, sizeof O);
     O.current_hdr = c->current_hdr.p; O.g_albedo = c->g_albedo.p; O.g_normal = c->g_normal.p; O.g_depth = c->g_depth.p; O.sky = c->sky.p;
     const bool slab = d_slab != nullptr;
+    if (slab) {
+        const size_t npx = (size_t)c->hiW * c->hiH;
+        if (!c->t_hdr.p) {
+            HIP_TRY(c, c->t_hdr.alloc(3 * npx)); HIP_TRY(c, c->t_albedo.alloc(3 * npx)); HIP_TRY(c, c->t_normal.alloc(3 * npx));
+            HIP_TRY(c, c->t_depth.alloc(npx)); HIP_TRY(c, c->t_sky.alloc(npx));
+        }
+        O.current_hdr = c->t_hdr.p; O.g_albedo = c->t_albedo.p; O.g_normal = c->t_normal.p; O.g_depth = c->t_depth.p; O.sky = c->t_sky.p;
+    }
     const bool debug = c->cfg.capture_debug && !slab;
     if (debug) { O.rays = c->dbg_rays.p; O.prim_id = c->dbg_prim.p; O.sub_id = c->dbg_sub.p; O.hit_t = c->dbg_hit_t.p; O.rng_state = c->dbg_rng.p; }
     if (getenv("YCGE_WAVE_PROF")) { if (!c->wave_prof.p) HIP_TRY(c, c->wave_prof.alloc((size_t)c->n_tiles * 16)); O.wave_prof = c->wave_prof.p; { const char ch = getenv("YCGE_WAVE_PROF")[0]; O.wave_prof_stage = ch == 'e' ? 1 : ch == 'm' ? 2 : 0; } }
@@ -951,7 +965,7 @@ int begin_and_trace(ycge_ctx *c, float *d_slab, hipStream_t stream, FrameState &
     }
     if (e != 0) return c->fail(YCGE_ERR_DEVICE, "trace launch failed: %s", hipGetErrorString((hipError_t)e));
     if (slab) {
-        e = ycge_launch_pack_slab(&P, c->current_hdr.p, c->g_albedo.p, c->g_normal.p, c->g_depth.p, c->sky.p, d_slab, stream);
+        e = ycge_launch_pack_slab(&P, O.current_hdr, O.g_albedo, O.g_normal, O.g_depth, O.sky, d_slab, stream);
         if (e != 0) return c->fail(YCGE_ERR_DEVICE, "k_pack_slab launch failed: %s", hipGetErrorString((hipError_t)e));
     }
     if (timed) HIP_TRY(c, hipEventRecord(c->ev[1], stream));
