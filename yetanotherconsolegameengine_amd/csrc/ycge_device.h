@@ -8,9 +8,11 @@
 //   GNode   64 B  an INTERNAL node of either BVH with BOTH child boxes inline:
 //                 one fetch per visit replaces the reference's three
 //                 (own box on pop + two child boxes; BVH.cs:126-166).
-//   GTri    48 B  triangle in LEAF ORDER (leafTriIndex applied at upload):
-//                 A, e1, e2 + original index; the unit normal is recomputed
-//                 from e1 x e2 on the final hit only (MeshBVH.cs:93-97 ops).
+//   GTriPair 96 B TWO leaf triangles, components interleaved, in LEAF ORDER
+//                 (leafTriIndex applied at upload): A, e1, e2 + original indices;
+//                 the unit normal is recomputed from e1 x e2 on the final hit
+//                 only (MeshBVH.cs:93-97 ops).  Mesh GNodes and GTriPairs share
+//                 one arena in depth-first order, addressed in 32-byte units.
 //   GPrim   64 B  one Scene.Objects entry with its ctor-derived constants.
 //   GMaterial 80 B, GGrid 96 B + 1 byte per voxel (bricked 8^3, Morton inside).
 #pragma once
@@ -200,7 +202,7 @@ struct TraceOut {
     // per-wavefront profile of k_wf_primary (COUNT variant; may be null): 4 x u64 {start, end, node iters, leaf phases}
     unsigned long long *wave_prof;
     int32_t wave_prof_stage;            // 0 = k_wf_primary, 1 = k_wf_extend of round 1
-    // k_trace scheduling feedback: block_cost[b] = traversal steps of 8x8 block b's longest lane this frame
+    // k_trace scheduling feedback: block_cost[b] = traversal loop iterations of 8x8 block b's wavefront(s) this frame
     // (atomicMax; cleared by k_cost_scatter); block_order / n_order = THIS frame's schedule built from the previous
     // frame's costs (entries: see k_trace), or null = one wavefront per block in index order
     uint32_t *block_cost;

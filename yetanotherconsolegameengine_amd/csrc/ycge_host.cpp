@@ -65,7 +65,7 @@ template <class T> struct DevBuf {
         release();
         n = count;
         if (count == 0) return hipSuccess;
-        return hipMalloc((void **)&p, count * sizeof(T) + 64);     // records are read with whole 64-byte fetches (GTri is 48 B)
+        return hipMalloc((void **)&p, count * sizeof(T) + 64);     // records are read with whole 64- / 72-byte fetches: room for the over-read past the last record
     }
     hipError_t upload(const std::vector<T> &v)
     {

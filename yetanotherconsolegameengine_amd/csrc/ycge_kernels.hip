@@ -551,12 +551,11 @@ struct PathStack {
     }
 };
 
-// One 64-thread workgroup per schedule entry.  An entry is an 8x8 pixel block (4 per tile) or, for the blocks that
-// bounded the previous frame, one PART of a block: the frame ends when its slowest wavefront ends, that wavefront's
-// time is (steps of its longest lane) x (time per step), and a wavefront with few live lanes steps about twice as
-// fast as a full one (one lane's path through the node / triangle / pop code instead of all of them, fewer
-// divergent fetches per step).  So k_order_blocks splits a heavy block over 4, 16 or 64 wavefronts of 16, 4 or 1
-// pixels, and lists the entries longest first.  Which lane computes a pixel never changes the pixel.
+// One 64-thread workgroup per schedule entry, listed longest first (k_cost_scatter).  An entry is an 8x8 pixel block
+// (4 per tile) or - experiment knob YCGE_SPLIT, off by default - one PART of a block: a wavefront with few live lanes
+// steps faster than a full one (one lane's path through the node / triangle / pop code instead of all of them,
+// fewer divergent fetches per step), so a heavy block can be split over 4, 16 or 64 wavefronts of 16, 4 or 1 pixels.
+// Which lane computes a pixel never changes the pixel.
 //   entry = block (22 bits) | part << 22 (6 bits) | log2(parts) << 28
 #define YCGE_ENT_BLOCK(e) ((e) & 0x3fffffu)
 #define YCGE_ENT_PART(e) (((e) >> 22) & 63u)
