@@ -326,16 +326,17 @@ def test_update_objects_rebuilds_scene_bvh_only(product_lib, oracle, path):
     o.close(); g.close()
 
 
-@pytest.mark.parametrize("knob", ["YCGE_FAN=1", "YCGE_REFILL=8"])
+@pytest.mark.parametrize("knob", ["YCGE_FAN=1", "YCGE_FAN=1,YCGE_SPLIT=22222220", "YCGE_REFILL=8"])
 def test_query_fan_out_and_refill_kernels_bit_exact(product_lib, oracle, monkeypatch, knob):
     """k_trace_fan (three wavefronts per heavy block, the default when a frame is tiled over >= 2 GPUs) and k_trace_refill
     (experiment) trace the same queries as k_trace in another arrangement: every buffer and every counter must still
     equal the oracle's.  Fan-out needs a schedule, i.e. starts with the second frame; three frames are compared.
     Scenes: the bunny (heavy blocks, diffuse bounces), the primitive zoo with glass (path items and transmittance
     segments go through slot 0 one at a time), Cornell (not a flat scene: generic walk under the fan-out)."""
-    name, value = knob.split("=")
     monkeypatch.setenv("YCGE_PATH", "megakernel")
-    monkeypatch.setenv(name, value)
+    for kv in knob.split(","):                  # the split variant runs fanned blocks in 4 parts of 16 pixels (the 8-rank default)
+        name, value = kv.split("=")
+        monkeypatch.setenv(name, value)
     sc3, w3, h3, ss3, pose3 = scenes.config_scene(3)
     sc1, w1, h1, ss1, pose1 = scenes.config_scene(1)
     cases = [("bunny", sc3, 320, 90, 1, pose3), ("zoo+glass", _zoo_scene(True), 192, 54, 1, dict(pos=(0.1, 1.2, 1.0), yaw=0.05, pitch=-0.12, fov=50.0)),

@@ -950,7 +950,11 @@ int begin_and_trace(ycge_ctx *c, float *d_slab, hipStream_t stream, FrameState &
         } else
             e = ycge_launch_trace(&c->sd, &P, &O, c->cfg.count_work, flat, refill_steps, stream);
         if (e == 0 && lpt) {
-            static const uint32_t policy = getenv("YCGE_SPLIT") ? (uint32_t)strtoul(getenv("YCGE_SPLIT"), nullptr, 8) : 0u;   // octal: digit c = log2(parts) of class c
+            // octal: digit c = log2(parts) a block of class c is split into.  Default: none (a split costs more slots than it saves,
+            // DESIGN section 5) except from 8 ranks up, where the classes >= 384 iterations go in 4 parts of 16 pixels: slots are plentiful
+            // on an eighth of a frame, thin wavefronts step faster and see a smaller maximum over their lanes (per-rank trace on config 4:
+            // 0.393 -> 0.366 ms at 8 ranks; at 4 ranks the same split loses, 0.407 -> 0.461 ms)
+            const uint32_t policy = getenv("YCGE_SPLIT") ? (uint32_t)strtoul(getenv("YCGE_SPLIT"), nullptr, 8) : c->cfg.world_size >= 8 ? 022200000u : 0u;
             e = ycge_launch_order_blocks(c->block_cost.p, (uint32_t)c->n_owned * 4u, policy, c->fan_class, c->fan_cap, c->order_ws.p, c->block_order.p, stream);
             c->block_order_valid = true;
         }

@@ -615,10 +615,10 @@ __device__ __forceinline__ void trace_block(const SceneDev &S, const FrameParams
     st.init(O.stack_spill, O.stack_lanes, O.lane_base);
     const PathStack pstack = {O.path_stack, O.stack_lanes, O.lane_base};
     const int lane = (int)(threadIdx.x & 63u), wave = WAVES3 ? (int)(threadIdx.x >> 6) : 0;
-    const uint32_t bid = YCGE_ENT_BLOCK(ent), lg = WAVES3 ? 0u : YCGE_ENT_LG(ent);
+    const uint32_t bid = YCGE_ENT_BLOCK(ent), lg = YCGE_ENT_LG(ent);
     const int k = (int)(bid >> 2), wave_in_tile = (int)(bid & 3);
     const int live_lanes = 64 >> lg;
-    const int pix_in_block = (int)(WAVES3 ? 0u : YCGE_ENT_PART(ent)) * live_lanes + lane;
+    const int pix_in_block = (int)YCGE_ENT_PART(ent) * live_lanes + lane;
     int px, py, lx, ly;
     const bool in_image = tile_pixel_wl(P, k, wave_in_tile, pix_in_block & 63, px, py, lx, ly) && lane < live_lanes;
     const bool prof = O.wave_prof && O.wave_prof_stage == 2;
@@ -972,12 +972,15 @@ __device__ __forceinline__ void trace_block(const SceneDev &S, const FrameParams
             if (O.rng_state) O.rng_state[i] = rng;
         }
     }
-    const uint32_t wave_max_steps = WAVES3 ? F->iters[0] + F->iters[1] + F->iters[2] : wave_iters;
+    // a part of a split block sees fewer lanes, hence fewer iterations than the whole block would: scaled so that the block
+    // stays in its schedule class from frame to frame (x 1.5 for 4 parts, x 2 for 16, x 2.5 for 64: measured ratios are 1.3-2)
+    const uint32_t part_iters = WAVES3 ? F->iters[0] + F->iters[1] + F->iters[2] : wave_iters;
+    const uint32_t wave_max_steps = part_iters + ((part_iters * lg) >> 2);
     if (O.block_cost && lane == 0) atomicMax(O.block_cost + bid, wave_max_steps);      // feedback for the next frame's schedule
-    if (prof && lane == 0 && (WAVES3 || YCGE_ENT_PART(ent) == 0)) {
+    if (prof && lane == 0 && YCGE_ENT_PART(ent) == 0) {
         unsigned long long *dst = O.wave_prof + ((size_t)k * 4 + wave_in_tile) * 4;
         dst[0] = t_start; dst[1] = __builtin_amdgcn_s_memrealtime(); dst[2] = sched_index | ((unsigned long long)wave_max_steps << 32);
-        dst[3] = __builtin_amdgcn_s_getreg(((32 - 1) << 11) | (0 << 6) | 20) | ((unsigned long long)(WAVES3 ? 7u : lg) << 32);   // XCC_ID; 7 = fanned block
+        dst[3] = __builtin_amdgcn_s_getreg(((32 - 1) << 11) | (0 << 6) | 20) | ((unsigned long long)(lg | (WAVES3 ? 8u : 0u)) << 32);   // XCC_ID; bit 3 = fanned block
     }
     flush_work<COUNT>(w, O.counters);
 }
@@ -1051,7 +1054,7 @@ __global__ __launch_bounds__(1024) void k_cost_scatter(uint32_t *__restrict__ co
         if (blockIdx.x == 0) {
             ws[16] = s_split ? total : n;
             uint32_t n_fan = 0;                 // blocks of the classes >= fan_class, at the head of the schedule
-            if (fan_class > 0 && policy == 0) for (int c = 7; c >= (int)fan_class; c--) n_fan += ws[c];
+            if (fan_class > 0) for (int c = 7; c >= (int)fan_class; c--) n_fan += ws[c] << (s_split ? class_lg_parts(policy, c) : 0u);
             ws[18] = n_fan < fan_cap ? n_fan : fan_cap;
         }
     }
