@@ -35,7 +35,7 @@
 extern "C" {
 #endif
 
-#define YCGE_ABI_VERSION 1
+#define YCGE_ABI_VERSION 2
 
 typedef enum ycge_status {
     YCGE_OK = 0,
@@ -189,6 +189,12 @@ typedef struct ycge_config {
     float atrous_c_phi, atrous_n_phi, atrous_z_phi, atrous_a_phi; /* 3, 0.35, 2, 0.20 */
     int32_t capture_debug;       /* also keep rays / primId / hitT buffers      */
     int32_t count_work;          /* keep per-frame traversal counters           */
+    /* tiled frame (world_size > 1): 1 = slabs carry the albedo plane (11 floats
+     * per pixel; the denoise stage needs it), 0 = lean slabs of 8 floats per
+     * pixel (hdr, normal, depth, sky: what TAA needs) - 27 % less all-gather
+     * traffic; ycge_resolve_gathered then refuses an SDR buffer. Default 1.  */
+    int32_t slab_albedo;
+    int32_t reserved0;
 } ycge_config;
 
 typedef struct ycge_frame_stats {

@@ -182,13 +182,15 @@ def test_error_codes(product_lib, path):
     product_lib.ycge_destroy(ctx)
 
 
-@pytest.mark.parametrize("case", ["cornell-2", "bunny-4-fan"])
+@pytest.mark.parametrize("case", ["cornell-2", "cornell-2-lean", "bunny-4-fan"])
 def test_two_rank_tile_split_matches_single_gpu(product_lib, path, case, monkeypatch):
     """world_size 2 (4) emulated on one GPU: the contexts trace their tiles, slabs are concatenated as an
     all-gather would, all resolve; results equal the single-context frame bit for bit.  The bunny case runs the
     ranks' heavy blocks through k_trace_fan (the tiled default from 2 ranks up; YCGE_FAN=1 lowers its threshold so that
     this small frame has such blocks) against a single context that does not."""
-    if case == "cornell-2":
+    lean = case.endswith("lean")             # config.slab_albedo = 0: 8-float slab records, no albedo plane
+    floats = tiles.LEAN_SLAB_FLOATS if lean else tiles.SLAB_FLOATS
+    if case.startswith("cornell-2"):
         (sc, w, h, ss, pose), world = scenes.config_scene(1), 2
     else:
         (sc, _, _, ss, pose), world = scenes.config_scene(3), 4
@@ -196,14 +198,14 @@ def test_two_rank_tile_split_matches_single_gpu(product_lib, path, case, monkeyp
     flat = flatten(sc)
     import torch
     def mk(rank, world):
-        r = RaytraceRenderer(flat, w, h, pose["fov"], ss, rank=rank, world_size=world)
+        r = RaytraceRenderer(flat, w, h, pose["fov"], ss, rank=rank, world_size=world, slab_albedo=not lean)
         r.SetCamera(pose["pos"], pose["yaw"], pose["pitch"])
         return r
     single = mk(0, 1)
-    if case != "cornell-2": monkeypatch.setenv("YCGE_FAN", "1")
+    if case == "bunny-4-fan": monkeypatch.setenv("YCGE_FAN", "1")
     ranks = [mk(i, world) for i in range(world)]
     nb = ranks[0].tile_slab_bytes()
-    assert nb == ranks[1].tile_slab_bytes() == tiles.slab_floats(world, tiles.tile_grid(single.hiW, single.hiH)[2]) * 4
+    assert nb == ranks[1].tile_slab_bytes() == tiles.slab_floats(world, tiles.tile_grid(single.hiW, single.hiH)[2], floats) * 4
     for frame in range(3):
         single.TryFlipAndBlit()
         gathered = torch.zeros(world * nb // 4, dtype=torch.float32, device="cuda")
@@ -213,13 +215,18 @@ def test_two_rank_tile_split_matches_single_gpu(product_lib, path, case, monkeyp
         for r in ranks:
             r.resolve_gathered(gathered.data_ptr(), 0, want_stats=True)
         for which in (abi.BUF_CURRENT_HDR, abi.BUF_G_ALBEDO, abi.BUF_G_NORMAL, abi.BUF_G_DEPTH, abi.BUF_SKY_MASK, abi.BUF_TAA_HISTORY):
+            if lean and which == abi.BUF_G_ALBEDO: continue          # not gathered
             ref = single.read(which)
             for r in ranks:
                 assert pu.bits_equal(ref, r.read(which)), (frame, which)
         # the device slab layout is the documented one (tiles.py)
         hdr, alb, nrm = single.read(abi.BUF_CURRENT_HDR), single.read(abi.BUF_G_ALBEDO), single.read(abi.BUF_G_NORMAL)
         full = np.concatenate([hdr, alb, nrm, single.read(abi.BUF_G_DEPTH)[..., None], single.read(abi.BUF_SKY_MASK)[..., None].astype(np.float32)], -1)
-        assert np.array_equal(tiles.unpermute(gathered.cpu().numpy(), single.hiW, single.hiH, world), full)
+        if lean: full = full[..., tiles.LEAN_COLUMNS]
+        assert np.array_equal(tiles.unpermute(gathered.cpu().numpy(), single.hiW, single.hiH, world, floats), full)
+    if lean:        # the denoise stage needs the albedo plane: refused, not computed from garbage
+        with pytest.raises(abi.YcgeError):
+            ranks[0].resolve_gathered(gathered.data_ptr(), 0, want_sdr=True)
     for r in ranks + [single]:
         r.close()
 

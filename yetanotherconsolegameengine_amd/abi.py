@@ -12,7 +12,7 @@ import ctypes as C
 import os
 from pathlib import Path
 
-YCGE_ABI_VERSION = 1
+YCGE_ABI_VERSION = 2
 
 # ycge_status
 YCGE_OK = 0
@@ -118,6 +118,8 @@ class Config(C.Structure):
         ("atrous_iterations", C.c_int32), ("atrous_c_phi", C.c_float), ("atrous_n_phi", C.c_float),
         ("atrous_z_phi", C.c_float), ("atrous_a_phi", C.c_float), ("capture_debug", C.c_int32),
         ("count_work", C.c_int32),
+        ("slab_albedo", C.c_int32),
+        ("reserved0", C.c_int32),
     ]
 
 
@@ -146,6 +148,7 @@ def default_config() -> Config:
     c.atrous_iterations = 3
     c.atrous_c_phi, c.atrous_n_phi, c.atrous_z_phi, c.atrous_a_phi = 3.0, 0.35, 2.0, 0.20
     c.capture_debug, c.count_work = 0, 0
+    c.slab_albedo, c.reserved0 = 1, 0
     return c
 
 

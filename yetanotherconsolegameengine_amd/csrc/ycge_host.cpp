@@ -45,9 +45,9 @@ int ycge_launch_exposure(const float *hdr, const uint8_t *sky, int w, int h, int
 int ycge_launch_tonemap(const float *hdr, int hiW, int fbW, int fbH, int ss, float gamma, float saturation, float vibrance, const void *state,
                         float *out, hipStream_t stream);
 int ycge_launch_pack_slab(const ycge::FrameParams *P, const float *hdr, const float *albedo, const float *normal, const float *depth,
-                          const uint8_t *sky, float *slab, hipStream_t stream);
+                          const uint8_t *sky, float *slab, int slab_floats, hipStream_t stream);
 int ycge_launch_unpermute(const float *all_slabs, size_t slab_floats_per_rank, int hiW, int hiH, int tiles_x, int n_tiles, int world_size,
-                          float *hdr, float *albedo, float *normal, float *depth, uint8_t *sky, hipStream_t stream);
+                          int slab_floats, float *hdr, float *albedo, float *normal, float *depth, uint8_t *sky, hipStream_t stream);
 }
 
 using namespace ycge;
@@ -242,6 +242,9 @@ int alloc_tile_buffers(ycge_ctx *c)
     return YCGE_OK;
 }
 
+// floats per slab pixel: hdr, [albedo,] normal, depth, sky
+static size_t slab_floats(const ycge_ctx *c) { return c->cfg.slab_albedo ? (size_t)YCGE_SLAB_FLOATS : (size_t)YCGE_SLAB_FLOATS - 3; }
+
 int set_geometry(ycge_ctx *c, int fbw, int fbh, int ss)
 {
     if (fbw <= 0 || fbh <= 0) return c->fail(YCGE_ERR_INVALID_ARG, "framebuffer size must be positive");
@@ -264,7 +267,7 @@ int set_geometry(ycge_ctx *c, int fbw, int fbh, int ss)
     if (rc != YCGE_OK) return rc;
     rc = alloc_tile_buffers(c);
     if (rc != YCGE_OK) return rc;
-    if (world > 1) HIP_TRY(c, c->own_slab.alloc((size_t)c->tiles_per_rank_padded * 256 * YCGE_SLAB_FLOATS));
+    if (world > 1) HIP_TRY(c, c->own_slab.alloc((size_t)c->tiles_per_rank_padded * 256 * slab_floats(c)));
     return YCGE_OK;
 }
 
@@ -391,6 +394,7 @@ int ycge_config_default(ycge_config *cfg)
     if (!cfg) return YCGE_ERR_INVALID_ARG;
     std::memset(cfg, 0, sizeof *cfg);
     cfg->abi_version = YCGE_ABI_VERSION;
+    cfg->slab_albedo = 1; cfg->reserved0 = 0;
     cfg->fb_width = 80; cfg->fb_height = 45; cfg->super_sample = 1;
     cfg->fov_deg = 45.0f;
     cfg->device = 0; cfg->rank = 0; cfg->world_size = 1;
@@ -866,7 +870,7 @@ int ycge_set_frame_counter(ycge_ctx *c, int64_t fc)
 int ycge_tile_slab_bytes(const ycge_ctx *c, size_t *bytes)
 {
     if (!c || !bytes) return YCGE_ERR_INVALID_ARG;
-    *bytes = (size_t)c->tiles_per_rank_padded * 256 * YCGE_SLAB_FLOATS * sizeof(float);
+    *bytes = (size_t)c->tiles_per_rank_padded * 256 * slab_floats(c) * sizeof(float);
     return YCGE_OK;
 }
 
@@ -969,7 +973,7 @@ int begin_and_trace(ycge_ctx *c, float *d_slab, hipStream_t stream, FrameState &
     }
     if (e != 0) return c->fail(YCGE_ERR_DEVICE, "trace launch failed: %s", hipGetErrorString((hipError_t)e));
     if (slab) {
-        e = ycge_launch_pack_slab(&P, O.current_hdr, O.g_albedo, O.g_normal, O.g_depth, O.sky, d_slab, stream);
+        e = ycge_launch_pack_slab(&P, O.current_hdr, O.g_albedo, O.g_normal, O.g_depth, O.sky, d_slab, (int)slab_floats(c), stream);
         if (e != 0) return c->fail(YCGE_ERR_DEVICE, "k_pack_slab launch failed: %s", hipGetErrorString((hipError_t)e));
     }
     if (timed) HIP_TRY(c, hipEventRecord(c->ev[1], stream));
@@ -1218,10 +1222,11 @@ int ycge_resolve_gathered(ycge_ctx *c, const void *d_all_slabs, void *hip_stream
     HIP_TRY(c, hipSetDevice(c->device));
     hipStream_t stream = hip_stream ? (hipStream_t)hip_stream : c->stream;
     auto t0 = std::chrono::steady_clock::now();
-    const size_t per_rank = (size_t)c->tiles_per_rank_padded * 256 * YCGE_SLAB_FLOATS;
+    if (out_sdr && !c->cfg.slab_albedo) return c->fail(YCGE_ERR_INVALID_ARG, "lean slabs (config.slab_albedo = 0) carry no albedo: the denoise stage cannot run");
+    const size_t per_rank = (size_t)c->tiles_per_rank_padded * 256 * slab_floats(c);
     if (st) HIP_TRY(c, hipEventRecord(c->ev[1], stream));
     int e = ycge_launch_unpermute((const float *)d_all_slabs, per_rank, c->hiW, c->hiH, c->tiles_x, c->n_tiles, c->cfg.world_size,
-                                  c->current_hdr.p, c->g_albedo.p, c->g_normal.p, c->g_depth.p, c->sky.p, stream);
+                                  (int)slab_floats(c), c->current_hdr.p, c->g_albedo.p, c->g_normal.p, c->g_depth.p, c->sky.p, stream);
     if (e != 0) return c->fail(YCGE_ERR_DEVICE, "k_unpermute launch failed: %s", hipGetErrorString((hipError_t)e));
     FrameState fs;
     {

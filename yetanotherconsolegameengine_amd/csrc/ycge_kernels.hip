@@ -1157,24 +1157,25 @@ __global__ __launch_bounds__(256) void k_taa(const TaaParams T, const float *__r
 
 // ---------------------------------------------------------------------------------- tile slabs (multi-GPU)
 // pack this rank's tiles (tile_id % world == rank) from the full-frame buffers into its slab
+// slab pixel = {hdr rgb, [albedo rgb,] normal xyz, depth, sky}: sf = 11 floats with the albedo plane, 8 without (lean)
 __global__ __launch_bounds__(256) void k_pack_slab(const FrameParams P, const float *__restrict__ hdr, const float *__restrict__ albedo,
                                                    const float *__restrict__ normal, const float *__restrict__ depth,
-                                                   const uint8_t *__restrict__ sky, float *__restrict__ slab)
+                                                   const uint8_t *__restrict__ sky, float *__restrict__ slab, int sf)
 {
     int px, py, lx, ly;
     const int k = blockIdx.x;
     if (!tile_pixel(P, k, px, py, lx, ly)) return;
     const size_t i = (size_t)px + (size_t)py * P.hiW;
-    float *s = slab + ((size_t)k * 256 + (size_t)(ly * YCGE_TILE_W + lx)) * YCGE_SLAB_FLOATS;
+    float *s = slab + ((size_t)k * 256 + (size_t)(ly * YCGE_TILE_W + lx)) * (size_t)sf;
     s[0] = hdr[3 * i]; s[1] = hdr[3 * i + 1]; s[2] = hdr[3 * i + 2];
-    s[3] = albedo[3 * i]; s[4] = albedo[3 * i + 1]; s[5] = albedo[3 * i + 2];
-    s[6] = normal[3 * i]; s[7] = normal[3 * i + 1]; s[8] = normal[3 * i + 2];
-    s[9] = depth[i]; s[10] = sky[i] ? 1.0f : 0.0f;
+    if (sf == YCGE_SLAB_FLOATS) { s[3] = albedo[3 * i]; s[4] = albedo[3 * i + 1]; s[5] = albedo[3 * i + 2]; s += 3; }
+    s[3] = normal[3 * i]; s[4] = normal[3 * i + 1]; s[5] = normal[3 * i + 2];
+    s[6] = depth[i]; s[7] = sky[i] ? 1.0f : 0.0f;
 }
 
 // all_slabs: world_size equal-sized slabs, rank-major, as an all-gather leaves them.
 __global__ __launch_bounds__(256) void k_unpermute(const float *__restrict__ all_slabs, size_t slab_floats_per_rank, int hiW, int hiH,
-                                                   int tiles_x, int n_tiles, int world_size, float *__restrict__ hdr,
+                                                   int tiles_x, int n_tiles, int world_size, int sf, float *__restrict__ hdr,
                                                    float *__restrict__ albedo, float *__restrict__ normal, float *__restrict__ depth,
                                                    uint8_t *__restrict__ sky)
 {
@@ -1185,13 +1186,13 @@ __global__ __launch_bounds__(256) void k_unpermute(const float *__restrict__ all
     const int lx = wave * 8 + (lane & 7), ly = lane >> 3;
     const int px = (tile_id % tiles_x) * YCGE_TILE_W + lx, py = (tile_id / tiles_x) * YCGE_TILE_H + ly;
     if (px >= hiW || py >= hiH) return;
-    const float *s = all_slabs + (size_t)rank * slab_floats_per_rank + ((size_t)k * 256 + (size_t)(ly * YCGE_TILE_W + lx)) * YCGE_SLAB_FLOATS;
+    const float *s = all_slabs + (size_t)rank * slab_floats_per_rank + ((size_t)k * 256 + (size_t)(ly * YCGE_TILE_W + lx)) * (size_t)sf;
     const size_t i = (size_t)px + (size_t)py * hiW;
     hdr[3 * i] = s[0]; hdr[3 * i + 1] = s[1]; hdr[3 * i + 2] = s[2];
-    albedo[3 * i] = s[3]; albedo[3 * i + 1] = s[4]; albedo[3 * i + 2] = s[5];
-    normal[3 * i] = s[6]; normal[3 * i + 1] = s[7]; normal[3 * i + 2] = s[8];
-    depth[i] = s[9];
-    sky[i] = s[10] != 0.0f ? 1 : 0;
+    if (sf == YCGE_SLAB_FLOATS) { albedo[3 * i] = s[3]; albedo[3 * i + 1] = s[4]; albedo[3 * i + 2] = s[5]; s += 3; }
+    normal[3 * i] = s[3]; normal[3 * i + 1] = s[4]; normal[3 * i + 2] = s[5];
+    depth[i] = s[6];
+    sky[i] = s[7] != 0.0f ? 1 : 0;
 }
 
 } // namespace ycge
@@ -1316,20 +1317,20 @@ int ycge_launch_taa(const ycge::TaaParams *T, const float *current, const float 
 }
 
 int ycge_launch_pack_slab(const ycge::FrameParams *P, const float *hdr, const float *albedo, const float *normal, const float *depth,
-                          const uint8_t *sky, float *slab, hipStream_t stream)
+                          const uint8_t *sky, float *slab, int slab_floats, hipStream_t stream)
 {
     if (P->n_owned_tiles <= 0) return 0;
     dim3 grid((unsigned)P->n_owned_tiles), block(256);
-    hipLaunchKernelGGL(ycge::k_pack_slab, grid, block, 0, stream, *P, hdr, albedo, normal, depth, sky, slab);
+    hipLaunchKernelGGL(ycge::k_pack_slab, grid, block, 0, stream, *P, hdr, albedo, normal, depth, sky, slab, slab_floats);
     return (int)hipGetLastError();
 }
 
 int ycge_launch_unpermute(const float *all_slabs, size_t slab_floats_per_rank, int hiW, int hiH, int tiles_x, int n_tiles, int world_size,
-                          float *hdr, float *albedo, float *normal, float *depth, uint8_t *sky, hipStream_t stream)
+                          int slab_floats, float *hdr, float *albedo, float *normal, float *depth, uint8_t *sky, hipStream_t stream)
 {
     dim3 grid((unsigned)n_tiles), block(256);
     hipLaunchKernelGGL(ycge::k_unpermute, grid, block, 0, stream, all_slabs, slab_floats_per_rank, hiW, hiH, tiles_x, n_tiles, world_size,
-                       hdr, albedo, normal, depth, sky);
+                       slab_floats, hdr, albedo, normal, depth, sky);
     return (int)hipGetLastError();
 }
 

@@ -22,13 +22,14 @@ NODE_DTYPE = np.dtype([("min", "<f4", 3), ("max", "<f4", 3), ("left", "<i4"), ("
 class RaytraceRenderer:
     def __init__(self, scene: Scene | FlatScene, fb_width: int, fb_height: int, fovDeg: float = 45.0, superSample: int = 1, *,
                  cfg: Optional[abi.Config] = None, capture_debug: bool = False, count_work: bool = False, device: int = 0,
-                 rank: int = 0, world_size: int = 1, lib=None):
+                 rank: int = 0, world_size: int = 1, slab_albedo: bool = True, lib=None):
         self.L = lib if lib is not None else abi.load_library()
         c = cfg if cfg is not None else abi.default_config()
         c.fb_width, c.fb_height, c.super_sample = fb_width, fb_height, max(1, superSample)
         c.fov_deg = fovDeg
         c.capture_debug, c.count_work = int(capture_debug), int(count_work)
         c.device, c.rank, c.world_size = device, rank, world_size
+        c.slab_albedo = int(slab_albedo)          # tiled frame: lean 8-float slabs when the denoise stage will not run
         self.cfg = c
         self.ctx = C.c_void_p()
         rc = self.L.ycge_create(C.byref(c), C.byref(self.ctx))
@@ -126,9 +127,13 @@ class RaytraceRenderer:
         st = C.byref(self.stats) if want_stats else None
         self._check(self.L.ycge_trace_tiles(self.ctx, C.c_void_p(d_slab_ptr), C.c_void_p(stream_ptr), st))
 
-    def resolve_gathered(self, d_all_slabs_ptr: int, stream_ptr: int = 0, want_stats: bool = False):
+    def resolve_gathered(self, d_all_slabs_ptr: int, stream_ptr: int = 0, want_stats: bool = False, want_sdr: bool = False):
+        """TAA on the gathered frame; with want_sdr also the denoise / exposure / tonemap stage (needs slab_albedo), returns the SDR array."""
         st = C.byref(self.stats) if want_stats else None
-        self._check(self.L.ycge_resolve_gathered(self.ctx, C.c_void_p(d_all_slabs_ptr), C.c_void_p(stream_ptr), None, st))
+        sdr = np.zeros((self.fbH, self.fbW, 2, 3), dtype=np.float32) if want_sdr else None
+        ptr = sdr.ctypes.data_as(C.POINTER(C.c_float)) if want_sdr else None
+        self._check(self.L.ycge_resolve_gathered(self.ctx, C.c_void_p(d_all_slabs_ptr), C.c_void_p(stream_ptr), ptr, st))
+        return sdr
 
     # ---------------------------------------------------------------- tests only
     def set_frame_counter(self, n: int):

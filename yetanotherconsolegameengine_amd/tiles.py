@@ -4,7 +4,8 @@ The trace grid is cut into 32x8-pixel tiles, numbered row-major; rank r of `worl
 tile_id % world == r (round-robin, so the expensive tiles of a mesh in the image centre spread over all
 GPUs).  Each rank packs its tiles into a slab — for its k-th owned tile (ascending tile_id), 256 pixel
 records in row-major order inside the tile (j = y*32 + x), 11 float32 each {hdr rgb, albedo rgb, normal
-xyz, depth, sky} — and
+xyz, depth, sky} or, with config.slab_albedo = 0 (no denoise stage to feed), 8 {hdr rgb, normal xyz, depth,
+sky} — and
 one all-gather of equal-sized slabs (RCCL over xGMI, torch.distributed backend "nccl") reassembles the
 frame; k_unpermute scatters the gathered slabs back to row-major full-frame buffers on every rank.
 
@@ -18,7 +19,8 @@ from __future__ import annotations
 
 import numpy as np
 
-TILE_W, TILE_H, SLAB_FLOATS = 32, 8, 11
+TILE_W, TILE_H, SLAB_FLOATS, LEAN_SLAB_FLOATS = 32, 8, 11, 8
+LEAN_COLUMNS = [0, 1, 2, 6, 7, 8, 9, 10]        # the 11-float record's columns a lean record keeps, in order
 
 
 def tile_grid(hiW: int, hiH: int):
@@ -34,8 +36,8 @@ def tiles_per_rank_padded(world: int, n_tiles: int) -> int:
     return (n_tiles + world - 1) // world
 
 
-def slab_floats(world: int, n_tiles: int) -> int:
-    return tiles_per_rank_padded(world, n_tiles) * 256 * SLAB_FLOATS
+def slab_floats(world: int, n_tiles: int, floats: int = SLAB_FLOATS) -> int:
+    return tiles_per_rank_padded(world, n_tiles) * 256 * floats
 
 
 def _local_xy():
@@ -44,10 +46,10 @@ def _local_xy():
 
 
 def pack_slab(frame: np.ndarray, rank: int, world: int) -> np.ndarray:
-    """frame: [hiH, hiW, 11] float32 -> this rank's slab [padded_tiles*256*11] (k_pack_slab)."""
-    hiH, hiW, _ = frame.shape
+    """frame: [hiH, hiW, F] float32 (F = 11, or 8 for lean slabs) -> this rank's slab [padded_tiles*256*F] (k_pack_slab)."""
+    hiH, hiW, floats = frame.shape
     tx, ty, n = tile_grid(hiW, hiH)
-    out = np.zeros((tiles_per_rank_padded(world, n), 256, SLAB_FLOATS), dtype=np.float32)
+    out = np.zeros((tiles_per_rank_padded(world, n), 256, floats), dtype=np.float32)
     lx, ly = _local_xy()
     for k, tid in enumerate(owned_tiles(rank, world, n)):
         px, py = (tid % tx) * TILE_W + lx, (tid // tx) * TILE_H + ly
@@ -56,12 +58,12 @@ def pack_slab(frame: np.ndarray, rank: int, world: int) -> np.ndarray:
     return out.reshape(-1)
 
 
-def unpermute(all_slabs: np.ndarray, hiW: int, hiH: int, world: int) -> np.ndarray:
-    """all_slabs: [world * slab_floats] rank-major (as all_gather leaves it) -> frame [hiH, hiW, 11] (k_unpermute)."""
+def unpermute(all_slabs: np.ndarray, hiW: int, hiH: int, world: int, floats: int = SLAB_FLOATS) -> np.ndarray:
+    """all_slabs: [world * slab_floats] rank-major (as all_gather leaves it) -> frame [hiH, hiW, floats] (k_unpermute)."""
     tx, ty, n = tile_grid(hiW, hiH)
     per = tiles_per_rank_padded(world, n)
-    s = all_slabs.reshape(world, per, 256, SLAB_FLOATS)
-    frame = np.zeros((hiH, hiW, SLAB_FLOATS), dtype=np.float32)
+    s = all_slabs.reshape(world, per, 256, floats)
+    frame = np.zeros((hiH, hiW, floats), dtype=np.float32)
     lx, ly = _local_xy()
     for tid in range(n):
         r, k = tid % world, tid // world
