@@ -130,6 +130,7 @@ struct GLight {
 #define YCGE_SCHEDULE_SLACK 2u      // k_trace grid = blocks x this: room for the parts of split blocks
 #define YCGE_FAN_CAP_DEFAULT 2048u   // k_trace_fan: at most this many blocks of the schedule's head
 #define YCGE_REFILL_STEPS_DEFAULT 0
+#define YCGE_POST_BAND_ROWS_DEFAULT 16 // rows per band of the in-place A-trous iteration (at least 2 x step)
 #define YCGE_POST_K_DEFAULT 8         // levels per launch of the banded in-place A-trous iteration
 #define YCGE_TILE_W 32
 #define YCGE_TILE_H 8

@@ -1110,7 +1110,8 @@ int run_post(ycge_ctx *c, hipStream_t stream, float *out_sdr_host, bool timed)
                 std::vector<uint32_t> px, off, bpx, boff;
                 build_inplace_schedule(w, h, step, px, off);
                 // bands of whole rows; related pixels are at most 2 * step rows apart, so they share a band or sit in adjacent ones
-                const int rows_per_band = 2 * step > 16 ? 2 * step : 16;
+                static const int band_rows = getenv("YCGE_POST_BAND_ROWS") ? atoi(getenv("YCGE_POST_BAND_ROWS")) : YCGE_POST_BAND_ROWS_DEFAULT;
+                const int rows_per_band = 2 * step > band_rows ? 2 * step : band_rows;
                 band_inplace_schedule(w, h, rows_per_band, px, off, bpx, boff, sc->bands, sc->max_level_pixels);
                 sc->levels = (int)off.size() - 1;
                 c->schedules.push_back(sc);
