@@ -5,6 +5,6 @@ for v in "$@"; do
   echo "== $v"
   ( if [ "$v" != "-" ]; then for kv in ${v//,/ }; do export "$kv"; done; fi
     for i in 1 2; do
-    YCGE_PATH=megakernel python bench.py --steps 30 --warmup 5 --no-cpu-baseline 2>> gpurun_out/bench.err | python -c "import sys,json; d=json.loads(sys.stdin.read()); print('MEGA', d['value'],'Mrays/s', d['ms_per_step'],'ms', d['roofline']['mean_launch_ms'])"
+    YCGE_PATH=megakernel python bench.py --steps 30 --warmup 8 --no-cpu-baseline 2>> gpurun_out/bench.err | python -c "import sys,json; d=json.loads(sys.stdin.read()); print('MEGA', d['value'],'Mrays/s', d['ms_per_step'],'ms', d['roofline']['mean_launch_ms'])"
     done )
 done

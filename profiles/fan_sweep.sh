@@ -1,6 +1,8 @@
 #!/bin/bash
+# builds of the library with other occupancy targets (var_<name>.so) under the fan-out knobs
 REPO=${GRAFT_REPO_ROOT:-/root/repo}; cd $REPO
-bash profiles/env_sweep.sh YCGE_FAN=0 YCGE_FAN=6 YCGE_FAN=5 YCGE_FAN=4 YCGE_FAN=3
-export YCGE_LIB=$REPO/yetanotherconsolegameengine_amd/lib/var_w4.so
-echo "#### 4 wavefronts per SIMD"
-bash profiles/env_sweep.sh YCGE_FAN=0 YCGE_FAN=6 YCGE_FAN=5 YCGE_FAN=4 YCGE_FAN=3
+for v in w34 w44; do
+export YCGE_LIB=$REPO/yetanotherconsolegameengine_amd/lib/var_$v.so
+echo "#### $v (wavefronts per SIMD: k_trace, k_trace_fan)"
+bash profiles/env_sweep.sh "$@"
+done

@@ -27,8 +27,8 @@ int ycge_launch_trace(const ycge::SceneDev *S, const ycge::FrameParams *P, const
                       hipStream_t stream);
 int ycge_launch_wavefront(const ycge::SceneDev *S, const ycge::FrameParams *P, const ycge::TraceOut *O, void *const bufs[7], int rounds,
                           int has_grid, int flat, int count, int persistent_waves, hipStream_t stream);
-int ycge_launch_order_blocks(uint32_t *cost, uint32_t n, uint32_t policy, uint32_t fan_class, uint32_t fan_cap, uint32_t *order_ws, uint32_t *order,
-                             hipStream_t stream);
+int ycge_launch_order_blocks(uint32_t *cost, uint32_t n, uint32_t policy, uint32_t fan_class, uint32_t fan_cap, uint32_t next_slot, uint32_t *order_ws,
+                             uint32_t *order, hipStream_t stream);
 int ycge_launch_trace_fan(const ycge::SceneDev *S, const ycge::FrameParams *P, const ycge::TraceOut *O, int count, int flat, uint32_t fan_cap,
                           hipStream_t stream);
 int ycge_launch_taa(const ycge::TaaParams *T, const float *current, const float *normal, const float *depth, const uint8_t *sky,
@@ -91,6 +91,7 @@ struct ycge_ctx {
     hipStream_t fan_stream = nullptr;
     hipEvent_t fan_ev[2] = {nullptr, nullptr};
     uint32_t fan_class = 0, fan_cap = 0;       // schedule classes >= fan_class are fanned, at most fan_cap blocks (0 = off)
+    uint32_t *h_n_fan = nullptr;               // pinned: how many entries the last finished schedule gave k_trace_fan (read without waiting)
     char device_name[256] = {0};
     int compute_units = 0;
 
@@ -211,9 +212,9 @@ int alloc_tile_buffers(ycge_ctx *c)
     c->path_stack.release();
     {
         const size_t nb = (size_t)(c->n_owned > 0 ? c->n_owned : 1) * 4;
-        HIP_TRY(c, c->block_cost.alloc(nb)); HIP_TRY(c, c->block_order.alloc(nb * YCGE_SCHEDULE_SLACK)); HIP_TRY(c, c->order_ws.alloc(20));
+        HIP_TRY(c, c->block_cost.alloc(nb * YCGE_COST_FRAMES)); HIP_TRY(c, c->block_order.alloc(nb * YCGE_SCHEDULE_SLACK)); HIP_TRY(c, c->order_ws.alloc(20));
         HIP_TRY(c, hipMemset(c->order_ws.p, 0, 20 * sizeof(uint32_t)));
-        HIP_TRY(c, hipMemset(c->block_cost.p, 0, nb * sizeof(uint32_t)));
+        HIP_TRY(c, hipMemset(c->block_cost.p, 0, nb * YCGE_COST_FRAMES * sizeof(uint32_t)));
         c->block_order_valid = false;
     }
     {   // XCD-aware block -> tile table: bucket the owned tiles by image strip (4 tiles = 128 px wide, strip s -> XCD s % 8),
@@ -451,12 +452,16 @@ int ycge_create(const ycge_config *cfg, ycge_ctx **out)
         if (hipStreamCreateWithFlags(&c->fan_stream, hipStreamNonBlocking) != hipSuccess) { c->err = "hipStreamCreate failed"; return bail(YCGE_ERR_DEVICE); }
         for (auto &ev : c->fan_ev)
             if (hipEventCreateWithFlags(&ev, hipEventDisableTiming) != hipSuccess) { c->err = "hipEventCreate failed"; return bail(YCGE_ERR_DEVICE); }
-        // query fan-out pays when wavefront slots are plentiful, i.e. when the frame is tiled over several GPUs and a rank's
-        // time is the chain of its heaviest blocks (measured per rank on config 4: 0.565 -> 0.418 ms at 8 ranks, 0.562 -> 0.433
-        // at 4); on a whole frame the idle helper wavefronts cost more than the shorter chains save (0.60 -> 0.66 ms)
-        const uint32_t fan_default = c->cfg.world_size >= 4 ? 4u : c->cfg.world_size >= 2 ? 5u : 0u;
+        // Query fan-out (k_trace_fan).  On a rank's share of a tiled frame wavefront slots are plentiful and the rank's time is the
+        // chain of its heaviest blocks: fan the classes >= 384 iterations (>= 256 from 4 ranks up), up to 2048 blocks (per rank on
+        // config 4: 0.565 -> 0.418 ms at 8 ranks, 0.562 -> 0.433 at 4, 0.595 -> 0.493 at 2).  On a whole frame slots are what the
+        // bulk is short of: only the 200 blocks at the head of the schedule (cost = max over four frames), with both kernels at 4
+        // wavefronts per SIMD (0.590 -> 0.569 ms; 400+ blocks or 3 wavefronts per SIMD lose what the shorter chains gain).
+        const uint32_t fan_default = c->cfg.world_size >= 4 ? 4u : 5u;
         c->fan_class = getenv("YCGE_FAN") ? (uint32_t)atoi(getenv("YCGE_FAN")) : fan_default;
-        c->fan_cap = c->fan_class ? (getenv("YCGE_FAN_CAP") ? (uint32_t)atoi(getenv("YCGE_FAN_CAP")) : YCGE_FAN_CAP_DEFAULT) : 0u;
+        if (hipHostMalloc((void **)&c->h_n_fan, sizeof(uint32_t), hipHostMallocDefault) != hipSuccess) { c->err = "hipHostMalloc failed"; return bail(YCGE_ERR_DEVICE); }
+        *c->h_n_fan = 0;
+        c->fan_cap = c->fan_class ? (getenv("YCGE_FAN_CAP") ? (uint32_t)atoi(getenv("YCGE_FAN_CAP")) : c->cfg.world_size >= 2 ? YCGE_FAN_CAP_DEFAULT : 200u) : 0u;
     }
     int rc = set_geometry(c, cfg->fb_width, cfg->fb_height, cfg->super_sample);
     if (rc != YCGE_OK) return bail(rc);
@@ -482,6 +487,7 @@ void ycge_destroy(ycge_ctx *c)
     for (auto &ev : c->ev) if (ev) (void)hipEventDestroy(ev);
     for (auto &ev : c->fan_ev) if (ev) (void)hipEventDestroy(ev);
     if (c->fan_stream) (void)hipStreamDestroy(c->fan_stream);
+    if (c->h_n_fan) (void)hipHostFree(c->h_n_fan);
     if (c->stream) (void)hipStreamDestroy(c->stream);
     delete c;
 }
@@ -932,12 +938,17 @@ int begin_and_trace(ycge_ctx *c, float *d_slab, hipStream_t stream, FrameState &
         if (!c->path_stack.p) HIP_TRY(c, c->path_stack.alloc((size_t)3 * 11 * O.stack_lanes));
         O.path_stack = c->path_stack.p;
         const bool lpt = !getenv("YCGE_NO_LPT");
-        O.block_cost = lpt ? c->block_cost.p : nullptr;
+        const uint32_t n_blocks = (uint32_t)c->n_owned * 4u;
+        const uint32_t cost_slot = (uint32_t)(c->frame_counter % YCGE_COST_FRAMES);       // this frame's array of the cost ring
+        O.block_cost = lpt ? c->block_cost.p + (size_t)cost_slot * n_blocks : nullptr;
         O.block_order = (lpt && c->block_order_valid) ? c->block_order.p : nullptr;
         O.n_order = c->order_ws.p + 16;
         // the schedule's head (the heaviest blocks of the previous frame) goes to k_trace_fan, launched first and beside k_trace
         const int refill_steps = getenv("YCGE_REFILL") ? atoi(getenv("YCGE_REFILL")) : YCGE_REFILL_STEPS_DEFAULT;   // k_trace_refill: steps between refills (0 = k_trace)
-        const bool fan = O.block_order != nullptr && c->fan_cap > 0 && !(flat && refill_steps > 0);
+        // a schedule without fanned blocks (analytic scenes, small frames) skips k_trace_fan and the side stream altogether: the count
+        // comes back through pinned memory and is a frame or two old when read here - either answer traces every block exactly once,
+        // because k_trace is told (n_fan pointer or null) which convention this frame uses
+        const bool fan = O.block_order != nullptr && c->fan_cap > 0 && !(flat && refill_steps > 0) && c->h_n_fan && *(volatile uint32_t *)c->h_n_fan > 0;
         if (fan) {
             // k_trace_fan goes FIRST and on the frame's stream, so that its blocks - the frame's longest chains - are resident from
             // t = 0; the rest of the schedule follows on the side stream (forked before, joined after) and fills in around them
@@ -959,8 +970,9 @@ int begin_and_trace(ycge_ctx *c, float *d_slab, hipStream_t stream, FrameState &
             // on an eighth of a frame, thin wavefronts step faster and see a smaller maximum over their lanes (per-rank trace on config 4:
             // 0.393 -> 0.366 ms at 8 ranks; at 4 ranks the same split loses, 0.407 -> 0.461 ms)
             const uint32_t policy = getenv("YCGE_SPLIT") ? (uint32_t)strtoul(getenv("YCGE_SPLIT"), nullptr, 8) : c->cfg.world_size >= 8 ? 022200000u : 0u;
-            e = ycge_launch_order_blocks(c->block_cost.p, (uint32_t)c->n_owned * 4u, policy, c->fan_class, c->fan_cap, c->order_ws.p, c->block_order.p, stream);
+            e = ycge_launch_order_blocks(c->block_cost.p, n_blocks, policy, c->fan_class, c->fan_cap, (cost_slot + 1u) % YCGE_COST_FRAMES, c->order_ws.p, c->block_order.p, stream);
             c->block_order_valid = true;
+            if (e == 0 && c->h_n_fan && c->fan_cap > 0) HIP_TRY(c, hipMemcpyAsync(c->h_n_fan, c->order_ws.p + 18, sizeof(uint32_t), hipMemcpyDeviceToHost, stream));
         }
     } else {
         const size_t nt = (size_t)(c->n_owned > 0 ? c->n_owned : 1);

@@ -985,8 +985,15 @@ __device__ __forceinline__ void trace_block(const SceneDev &S, const FrameParams
     flush_work<COUNT>(w, O.counters);
 }
 
+// Occupancy targets of the flat, non-counting variants.  4 wavefronts per SIMD means a 128-VGPR budget: k_trace then carries 44 bytes
+// of scratch (19 spilled registers, all outside the traversal loops).  On its own that buys nothing - the frame ends with its longest
+// chains (0.601 vs 0.604 ms) - but together with fanning the ~200 blocks most likely to be those chains it does: the bulk of the
+// frame gets a third more slots and absorbs the helper wavefronts (0.590 -> 0.569 ms; 3 + 4 or 4 + 3 wavefronts: 0.60 / 0.59).
 #ifndef YCGE_TRACE_WAVES
-#define YCGE_TRACE_WAVES 3
+#define YCGE_TRACE_WAVES 4
+#endif
+#ifndef YCGE_FAN_WAVES
+#define YCGE_FAN_WAVES 4
 #endif
 template <bool COUNT, bool FLAT>
 __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu((FLAT && !COUNT) ? YCGE_TRACE_WAVES : 2, 8))) void k_trace(const SceneDev S, const FrameParams P, const TraceOut O)
@@ -1000,7 +1007,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu((FLAT && !CO
     trace_block<COUNT, FLAT, 0>(S, P, O, ent, idx, nullptr, 0);
 }
 template <bool COUNT>
-__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(COUNT ? 2 : YCGE_TRACE_WAVES, 8))) void k_trace_refill(const SceneDev S, const FrameParams P, const TraceOut O, const int refill_steps)
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(COUNT ? 2 : 3, 8))) void k_trace_refill(const SceneDev S, const FrameParams P, const TraceOut O, const int refill_steps)
 {
     __shared__ FanShared F;
     uint32_t idx = blockIdx.x, ent = blockIdx.x;
@@ -1011,7 +1018,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(COUNT ? 2 : 
     trace_block<COUNT, true, 2>(S, P, O, ent, idx, &F, refill_steps);
 }
 template <bool COUNT, bool FLAT>
-__global__ __launch_bounds__(192) __attribute__((amdgpu_waves_per_eu((FLAT && !COUNT) ? YCGE_TRACE_WAVES : 2, 8))) void k_trace_fan(const SceneDev S, const FrameParams P, const TraceOut O)
+__global__ __launch_bounds__(192) __attribute__((amdgpu_waves_per_eu((FLAT && !COUNT) ? YCGE_FAN_WAVES : 2, 8))) void k_trace_fan(const SceneDev S, const FrameParams P, const TraceOut O)
 {
     __shared__ FanShared F;
     if (blockIdx.x >= *O.n_fan) return;
@@ -1031,18 +1038,29 @@ __device__ __forceinline__ int cost_class(uint32_t c)
 }
 // split policy: log2(parts) of class c in bits [3c, 3c+3) of `policy`
 __device__ __forceinline__ uint32_t class_lg_parts(uint32_t policy, int cls) { return (policy >> (3 * cls)) & 7u; }
+// A block's schedule cost = the largest of its costs over the last YCGE_COST_FRAMES frames (ring of per-frame arrays, cost[f][b]):
+// which blocks run long is a property of the image region (silhouettes seen at grazing angles), how long a given one runs in a
+// given frame depends on that frame's random bounce directions - the 40 longest-running blocks of a frame are found among the
+// top 200 of the previous frame's costs 58 % of the time, among the top 200 of max-over-four-frames 90 % (profiles/cost_persistence.py).
+__device__ __forceinline__ uint32_t smoothed_cost(const uint32_t *cost, uint32_t n, uint32_t i)
+{
+    uint32_t m = 0;
+#pragma unroll
+    for (int f = 0; f < YCGE_COST_FRAMES; f++) { const uint32_t v = cost[(size_t)f * n + i]; m = v > m ? v : m; }
+    return m;
+}
 __global__ __launch_bounds__(1024) void k_cost_hist(const uint32_t *__restrict__ cost, uint32_t n, uint32_t *__restrict__ ws)
 {
     __shared__ uint32_t h[8];
     if (threadIdx.x < 8) h[threadIdx.x] = 0;
     __syncthreads();
     const uint32_t i = blockIdx.x * 1024u + threadIdx.x;
-    if (i < n) { const int cls = cost_class(cost[i]); atomicAdd(&h[cls], 1u); }
+    if (i < n) { const int cls = cost_class(smoothed_cost(cost, n, i)); atomicAdd(&h[cls], 1u); }
     __syncthreads();
     if (threadIdx.x < 8 && h[threadIdx.x]) atomicAdd(&ws[threadIdx.x], h[threadIdx.x]);
 }
 __global__ __launch_bounds__(1024) void k_cost_scatter(uint32_t *__restrict__ cost, uint32_t n, uint32_t capacity, uint32_t policy,
-                                                       uint32_t fan_class, uint32_t fan_cap, uint32_t *__restrict__ ws, uint32_t *__restrict__ order)
+                                                       uint32_t fan_class, uint32_t fan_cap, uint32_t next_slot, uint32_t *__restrict__ ws, uint32_t *__restrict__ order)
 {
     __shared__ uint32_t h[8], base[8];
     __shared__ uint32_t s_split;
@@ -1064,8 +1082,8 @@ __global__ __launch_bounds__(1024) void k_cost_scatter(uint32_t *__restrict__ co
     int cls = -1;
     uint32_t local = 0, lgp = 0;
     if (i < n) {
-        cls = cost_class(cost[i]);
-        cost[i] = 0;
+        cls = cost_class(smoothed_cost(cost, n, i));
+        cost[(size_t)next_slot * n + i] = 0;         // the ring slot the next frame's atomicMax goes to
         lgp = split ? class_lg_parts(policy, cls) : 0u;
         local = atomicAdd(&h[cls], 1u << lgp);
     }
@@ -1284,15 +1302,15 @@ int ycge_launch_wavefront(const ycge::SceneDev *S, const ycge::FrameParams *P, c
 }
 
 // builds next frame's k_trace schedule from this frame's per-block step counts.  ws: 18 uint32 (see k_cost_hist)
-int ycge_launch_order_blocks(uint32_t *cost, uint32_t n, uint32_t policy, uint32_t fan_class, uint32_t fan_cap, uint32_t *ws, uint32_t *order,
-                             hipStream_t stream)
+int ycge_launch_order_blocks(uint32_t *cost, uint32_t n, uint32_t policy, uint32_t fan_class, uint32_t fan_cap, uint32_t next_slot, uint32_t *ws,
+                             uint32_t *order, hipStream_t stream)
 {
     if (n == 0) return 0;
     hipError_t e = hipMemsetAsync(ws, 0, 18 * sizeof(uint32_t), stream);     // ws[18] (n_fan) is rewritten by k_cost_scatter
     if (e != hipSuccess) return (int)e;
     const dim3 grid((n + 1023u) / 1024u), block(1024);
     hipLaunchKernelGGL(ycge::k_cost_hist, grid, block, 0, stream, cost, n, ws);
-    hipLaunchKernelGGL(ycge::k_cost_scatter, grid, block, 0, stream, cost, n, n * YCGE_SCHEDULE_SLACK, policy, fan_class, fan_cap, ws, order);
+    hipLaunchKernelGGL(ycge::k_cost_scatter, grid, block, 0, stream, cost, n, n * YCGE_SCHEDULE_SLACK, policy, fan_class, fan_cap, next_slot, ws, order);
     return (int)hipGetLastError();
 }
 
