@@ -196,9 +196,10 @@ def main():
     roof = None
     if mean_trace_ms:
         ach = my_alg / (mean_trace_ms * 1e-3) / 1e9
-        # which launches trace_ms brackets: the single-launch kernel (mesh viewers), beside k_trace_fan when the frame is tiled
-        # (two streams, the duration is their makespan), or the stage pipeline of scenes with a real top-level tree (config 5)
-        kernel = "k_wf_* stages" if args.config == 5 else "k_trace" if world == 1 else "k_trace_fan + k_trace (concurrent)"
+        # which launches trace_ms brackets: the single-launch kernel k_trace with k_trace_fan beside it for the head of the schedule
+        # (two streams forked from and joined to the frame's stream: the duration is their makespan; scenes without heavy blocks
+        # run k_trace alone), or the stage pipeline of scenes with a real top-level tree (config 5)
+        kernel = "k_wf_* stages" if args.config == 5 else "k_trace" if args.config in (1, 2) else "k_trace + k_trace_fan (concurrent)"
         roof = {"bound": "hbm", "kernel": kernel, "achieved": round(ach, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": round(ach / HBM_PEAK_GBS, 5), "traffic": load_traffic_hint(args.config) if world == 1 else None,
                 "algorithmic_bytes_per_launch": int(my_alg), "mean_launch_ms": round(mean_trace_ms, 4)}
