@@ -90,6 +90,8 @@ struct ycge_ctx {
     // k_trace runs beside k_trace_fan on a side stream, forked from and joined to the frame's stream
     hipStream_t fan_stream = nullptr;
     hipEvent_t fan_ev[2] = {nullptr, nullptr};
+    hipEvent_t traced_ev = nullptr, order_ev = nullptr;   // the next frame's schedule is built on the side stream, beside TAA
+    bool order_pending = false;
     uint32_t fan_class = 0, fan_cap = 0;       // schedule classes >= fan_class are fanned, at most fan_cap blocks (0 = off)
     uint32_t *h_n_fan = nullptr;               // pinned: how many entries the last finished schedule gave k_trace_fan (read without waiting)
     char device_name[256] = {0};
@@ -202,6 +204,7 @@ int alloc_frame_buffers(ycge_ctx *c)
 // queue segments, hit records and stack-spill columns: one 256-entry segment per owned tile
 int alloc_tile_buffers(ycge_ctx *c)
 {
+    if (c->fan_stream) { HIP_TRY(c, hipStreamSynchronize(c->fan_stream)); c->order_pending = false; }      // schedule kernels of the old size
     const size_t lanes = (size_t)(c->n_owned > 0 ? c->n_owned : 1) * 256;
     const size_t stack_lanes = lanes * YCGE_SCHEDULE_SLACK + (size_t)c->fan_cap * 192;      // k_trace's grid includes the schedule's slack entries; k_trace_fan's columns follow
     HIP_TRY(c, c->wf_q0.alloc(lanes * ycge_wf_sizes(0))); HIP_TRY(c, c->wf_q1.alloc(lanes * ycge_wf_sizes(0)));
@@ -450,8 +453,8 @@ int ycge_create(const ycge_config *cfg, ycge_ctx **out)
         if (hipEventCreate(&ev) != hipSuccess) { c->err = "hipEventCreate failed"; return bail(YCGE_ERR_DEVICE); }
     {
         if (hipStreamCreateWithFlags(&c->fan_stream, hipStreamNonBlocking) != hipSuccess) { c->err = "hipStreamCreate failed"; return bail(YCGE_ERR_DEVICE); }
-        for (auto &ev : c->fan_ev)
-            if (hipEventCreateWithFlags(&ev, hipEventDisableTiming) != hipSuccess) { c->err = "hipEventCreate failed"; return bail(YCGE_ERR_DEVICE); }
+        for (hipEvent_t *ev : {&c->fan_ev[0], &c->fan_ev[1], &c->traced_ev, &c->order_ev})
+            if (hipEventCreateWithFlags(ev, hipEventDisableTiming) != hipSuccess) { c->err = "hipEventCreate failed"; return bail(YCGE_ERR_DEVICE); }
         // Query fan-out (k_trace_fan).  On a rank's share of a tiled frame wavefront slots are plentiful and the rank's time is the
         // chain of its heaviest blocks: fan the classes >= 384 iterations (>= 256 from 4 ranks up), up to 2048 blocks (per rank on
         // config 4: 0.565 -> 0.418 ms at 8 ranks, 0.562 -> 0.433 at 4, 0.595 -> 0.493 at 2).  On a whole frame slots are what the
@@ -473,6 +476,8 @@ void ycge_destroy(ycge_ctx *c)
 {
     if (!c) return;
     (void)hipSetDevice(c->device);
+    if (c->fan_stream) (void)hipStreamSynchronize(c->fan_stream);
+    if (c->stream) (void)hipStreamSynchronize(c->stream);
     c->current_hdr.release(); c->g_albedo.release(); c->g_normal.release(); c->g_depth.release(); c->taa_hist.release();
     c->prev_normal.release(); c->prev_depth.release(); c->sky.release(); c->prev_sky.release();
     c->dbg_rays.release(); c->dbg_hit_t.release(); c->dbg_prim.release(); c->dbg_sub.release(); c->dbg_rng.release();
@@ -485,7 +490,7 @@ void ycge_destroy(ycge_ctx *c)
     c->d_scene_nodes.release(); c->d_mesh_arena.release(); c->d_scene_leaf.release(); c->d_prims.release();
     c->d_materials.release(); c->d_meshes.release(); c->d_grids.release(); c->d_cells.release(); c->d_lut.release(); c->d_lights.release();
     for (auto &ev : c->ev) if (ev) (void)hipEventDestroy(ev);
-    for (auto &ev : c->fan_ev) if (ev) (void)hipEventDestroy(ev);
+    for (hipEvent_t ev : {c->fan_ev[0], c->fan_ev[1], c->traced_ev, c->order_ev}) if (ev) (void)hipEventDestroy(ev);
     if (c->fan_stream) (void)hipStreamDestroy(c->fan_stream);
     if (c->h_n_fan) (void)hipHostFree(c->h_n_fan);
     if (c->stream) (void)hipStreamDestroy(c->stream);
@@ -941,6 +946,7 @@ int begin_and_trace(ycge_ctx *c, float *d_slab, hipStream_t stream, FrameState &
         const uint32_t n_blocks = (uint32_t)c->n_owned * 4u;
         const uint32_t cost_slot = (uint32_t)(c->frame_counter % YCGE_COST_FRAMES);       // this frame's array of the cost ring
         O.block_cost = lpt ? c->block_cost.p + (size_t)cost_slot * n_blocks : nullptr;
+        if (c->order_pending) { HIP_TRY(c, hipStreamWaitEvent(stream, c->order_ev, 0)); c->order_pending = false; }     // the schedule built beside the last frame's TAA
         O.block_order = (lpt && c->block_order_valid) ? c->block_order.p : nullptr;
         O.n_order = c->order_ws.p + 16;
         // the schedule's head (the heaviest blocks of the previous frame) goes to k_trace_fan, launched first and beside k_trace
@@ -970,9 +976,15 @@ int begin_and_trace(ycge_ctx *c, float *d_slab, hipStream_t stream, FrameState &
             // on an eighth of a frame, thin wavefronts step faster and see a smaller maximum over their lanes (per-rank trace on config 4:
             // 0.393 -> 0.366 ms at 8 ranks; at 4 ranks the same split loses, 0.407 -> 0.461 ms)
             const uint32_t policy = getenv("YCGE_SPLIT") ? (uint32_t)strtoul(getenv("YCGE_SPLIT"), nullptr, 8) : c->cfg.world_size >= 8 ? 022200000u : 0u;
-            e = ycge_launch_order_blocks(c->block_cost.p, n_blocks, policy, c->fan_class, c->fan_cap, (cost_slot + 1u) % YCGE_COST_FRAMES, c->order_ws.p, c->block_order.p, stream);
+            // the next frame's schedule needs this frame's trace and nothing else: built on the side stream, beside TAA (or the slab
+            // pack and all-gather), instead of 25 us in front of it; the next trace waits for it (order_ev)
+            HIP_TRY(c, hipEventRecord(c->traced_ev, stream));
+            HIP_TRY(c, hipStreamWaitEvent(c->fan_stream, c->traced_ev, 0));
+            e = ycge_launch_order_blocks(c->block_cost.p, n_blocks, policy, c->fan_class, c->fan_cap, (cost_slot + 1u) % YCGE_COST_FRAMES, c->order_ws.p, c->block_order.p, c->fan_stream);
             c->block_order_valid = true;
-            if (e == 0 && c->h_n_fan && c->fan_cap > 0) HIP_TRY(c, hipMemcpyAsync(c->h_n_fan, c->order_ws.p + 18, sizeof(uint32_t), hipMemcpyDeviceToHost, stream));
+            if (e == 0 && c->h_n_fan && c->fan_cap > 0) HIP_TRY(c, hipMemcpyAsync(c->h_n_fan, c->order_ws.p + 18, sizeof(uint32_t), hipMemcpyDeviceToHost, c->fan_stream));
+            HIP_TRY(c, hipEventRecord(c->order_ev, c->fan_stream));
+            c->order_pending = true;
         }
     } else {
         const size_t nt = (size_t)(c->n_owned > 0 ? c->n_owned : 1);
