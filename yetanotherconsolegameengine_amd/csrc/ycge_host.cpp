@@ -940,7 +940,8 @@ int begin_and_trace(ycge_ctx *c, float *d_slab, hipStream_t stream, FrameState &
     // real top-level tree (voxel worlds) are throughput-bound and run 1.7x faster as occupancy-friendly stages.
     const bool single_launch = c->sd.any_transparent || c->path_policy == 2 || (c->path_policy == 0 && flat);
     if (single_launch) {
-        if (!c->path_stack.p) HIP_TRY(c, c->path_stack.alloc((size_t)3 * 11 * O.stack_lanes));
+        // TraceFull's per-pixel LIFO is only ever touched at a refractive hit: scenes without transparent materials get none (0.5 GB at 1080p)
+        if (!c->path_stack.p && c->sd.any_transparent) HIP_TRY(c, c->path_stack.alloc((size_t)3 * 11 * O.stack_lanes));
         O.path_stack = c->path_stack.p;
         const bool lpt = !getenv("YCGE_NO_LPT");
         const uint32_t n_blocks = (uint32_t)c->n_owned * 4u;
