@@ -315,20 +315,41 @@ __global__ __launch_bounds__(64) void k_exposure_sum(const float *__restrict__ t
         }
         __syncthreads();
         if (lane == 0) {
-            // 64 terms in registers while the next 64 come out of LDS: the chain never waits for a read
-            float4 cur[16], nxt[16];
-#pragma unroll
-            for (int k = 0; k < 16; k++) cur[k] = buf[k];
+            // The adds are ONE dependent chain; nothing else may sit on it.  32 terms in registers (set A) are added while the next 32
+            // (set B) are already on their way out of LDS, and vice versa: reads issued by hand (ds_read_b128, no wait), consumed
+            // behind an explicit s_waitcnt that leaves the OTHER set's eight reads outstanding.
+            typedef float f4 __attribute__((ext_vector_type(4)));
+            f4 a0, a1, a2, a3, a4, a5, a6, a7, b0, b1, b2, b3, b4, b5, b6, b7;
+            const uint32_t base = (uint32_t)(uintptr_t)buf;
+#define YCGE_RD8(r0, r1, r2, r3, r4, r5, r6, r7, addr)                                                                                         \
+            asm volatile("ds_read_b128 %0, %8\n\tds_read_b128 %1, %8 offset:16\n\tds_read_b128 %2, %8 offset:32\n\tds_read_b128 %3, %8 offset:48\n\t" \
+                         "ds_read_b128 %4, %8 offset:64\n\tds_read_b128 %5, %8 offset:80\n\tds_read_b128 %6, %8 offset:96\n\tds_read_b128 %7, %8 offset:112" \
+                         : "=&v"(r0), "=&v"(r1), "=&v"(r2), "=&v"(r3), "=&v"(r4), "=&v"(r5), "=&v"(r6), "=&v"(r7) : "v"(addr) : "memory")
+#define YCGE_WAIT8(n, r0, r1, r2, r3, r4, r5, r6, r7)                                                                                          \
+            asm volatile("s_waitcnt lgkmcnt(" #n ")" : "+v"(r0), "+v"(r1), "+v"(r2), "+v"(r3), "+v"(r4), "+v"(r5), "+v"(r6), "+v"(r7))
+#define YCGE_ADD8(r0, r1, r2, r3, r4, r5, r6, r7)                                                                                              \
+            log_sum += r0.x; log_sum += r0.y; log_sum += r0.z; log_sum += r0.w; log_sum += r1.x; log_sum += r1.y; log_sum += r1.z; log_sum += r1.w; \
+            log_sum += r2.x; log_sum += r2.y; log_sum += r2.z; log_sum += r2.w; log_sum += r3.x; log_sum += r3.y; log_sum += r3.z; log_sum += r3.w; \
+            log_sum += r4.x; log_sum += r4.y; log_sum += r4.z; log_sum += r4.w; log_sum += r5.x; log_sum += r5.y; log_sum += r5.z; log_sum += r5.w; \
+            log_sum += r6.x; log_sum += r6.y; log_sum += r6.z; log_sum += r6.w; log_sum += r7.x; log_sum += r7.y; log_sum += r7.z; log_sum += r7.w
+            YCGE_RD8(a0, a1, a2, a3, a4, a5, a6, a7, base);
 #pragma unroll 1
-            for (int blk = 0; blk < 16; blk++) {
-                const int nb = blk + 1 < 16 ? blk + 1 : blk;
-#pragma unroll
-                for (int k = 0; k < 16; k++) nxt[k] = buf[nb * 16 + k];
-#pragma unroll
-                for (int k = 0; k < 16; k++) { log_sum += cur[k].x; log_sum += cur[k].y; log_sum += cur[k].z; log_sum += cur[k].w; }
-#pragma unroll
-                for (int k = 0; k < 16; k++) cur[k] = nxt[k];
+            for (uint32_t blk = 0; blk < 30; blk += 2) {        // 32 blocks of 8 float4 = the chunk's 1024 terms; no branch inside:
+                YCGE_RD8(b0, b1, b2, b3, b4, b5, b6, b7, base + (blk + 1u) * 128u);     // the two sets must stay in their registers
+                YCGE_WAIT8(8, a0, a1, a2, a3, a4, a5, a6, a7);
+                YCGE_ADD8(a0, a1, a2, a3, a4, a5, a6, a7);
+                YCGE_RD8(a0, a1, a2, a3, a4, a5, a6, a7, base + (blk + 2u) * 128u);
+                YCGE_WAIT8(8, b0, b1, b2, b3, b4, b5, b6, b7);
+                YCGE_ADD8(b0, b1, b2, b3, b4, b5, b6, b7);
             }
+            YCGE_RD8(b0, b1, b2, b3, b4, b5, b6, b7, base + 31u * 128u);
+            YCGE_WAIT8(8, a0, a1, a2, a3, a4, a5, a6, a7);
+            YCGE_ADD8(a0, a1, a2, a3, a4, a5, a6, a7);
+            YCGE_WAIT8(0, b0, b1, b2, b3, b4, b5, b6, b7);
+            YCGE_ADD8(b0, b1, b2, b3, b4, b5, b6, b7);
+#undef YCGE_RD8
+#undef YCGE_WAIT8
+#undef YCGE_ADD8
         }
         // the other buffer is written next; it was last read two iterations ago, before the barrier above
     }
