@@ -127,7 +127,9 @@ struct GLight {
 };
 
 #define YCGE_TRAVERSAL_STACK 96    // >= scene depth + 4 leaf prims + mesh depth, checked at upload
+#ifndef YCGE_COST_FRAMES
 #define YCGE_COST_FRAMES 4          // a block's schedule cost is its largest cost over this many frames
+#endif
 #define YCGE_SCHEDULE_SLACK 2u      // k_trace grid = blocks x this: room for the parts of split blocks
 #define YCGE_FAN_CAP_DEFAULT 2048u   // k_trace_fan: at most this many blocks of the schedule's head
 #define YCGE_REFILL_STEPS_DEFAULT 0
