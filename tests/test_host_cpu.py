@@ -335,6 +335,45 @@ def test_inplace_atrous_schedule_respects_scan_order(product_lib, w, h, step):
                 assert np.all(launch[q[e_diff]] < launch[p[e_diff]])
 
 
+@pytest.mark.parametrize("w,h,step,rows", [(37, 23, 2, 16), (80, 90, 2, 16), (64, 48, 2, 8), (33, 40, 8, 16), (5, 5, 2, 4)])
+def test_inplace_atrous_band_pass_lists(product_lib, w, h, step, rows):
+    """What k_atrous_band reads: per band, the level schedule restricted to the band's rows, every level padded to whole
+    passes of 32 entries (x | y << 16, 0xffffffff = no pixel), pass offsets per (band, level)."""
+    L = product_lib
+    L.ycge_host_inplace_schedule.restype = C.c_int
+    L.ycge_host_inplace_schedule.argtypes = [C.c_int32, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p, C.c_int32]
+    px = np.zeros(w * h, np.uint32); off = np.zeros(w * h + 2, np.uint32)
+    n_levels = L.ycge_host_inplace_schedule(w, h, step, px.ctypes.data, off.ctypes.data, off.size)
+    level = np.zeros(w * h, np.int64)
+    for l in range(n_levels):
+        level[px[off[l]:off[l + 1]]] = l
+    L.ycge_host_inplace_bands.restype = C.c_int
+    L.ycge_host_inplace_bands.argtypes = [C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_void_p, C.c_int64, C.c_void_p, C.c_int64, C.c_void_p]
+    info = np.zeros(3, np.int32)
+    n_pass = L.ycge_host_inplace_bands(w, h, step, rows, None, 0, None, 0, info.ctypes.data)
+    levels, n_bands, max_level_pixels = (int(v) for v in info)
+    assert levels == n_levels and n_bands == (h + rows - 1) // rows and n_pass > 0
+    ent = np.zeros(n_pass * 32, np.uint32); boff = np.zeros(n_bands * (levels + 1), np.uint32)
+    assert L.ycge_host_inplace_bands(w, h, step, rows, ent.ctypes.data, ent.size, boff.ctypes.data, boff.size, info.ctypes.data) == n_pass
+    boff = boff.reshape(n_bands, levels + 1).astype(np.int64)
+    assert boff[0, 0] == 0 and boff[-1, -1] == n_pass and np.all(np.diff(boff.ravel()) >= 0)        # bands follow one another, levels in order
+    seen = np.zeros(w * h, bool)
+    widest = 0
+    for b in range(n_bands):
+        for t in range(levels):
+            e = ent[boff[b, t] * 32: boff[b, t + 1] * 32]
+            real = e[e != 0xffffffff]
+            x, y = (real & 0xffff).astype(np.int64), (real >> 16).astype(np.int64)
+            assert np.all(y // rows == b) and np.all(x < w) and np.all(y < h)
+            p = x + y * w
+            assert np.all(level[p] == t) and not seen[p].any()
+            seen[p] = True
+            assert len(e) - len(real) < 32 and (len(real) > 0) == (len(e) > 0)      # padding only completes the last pass of a level
+            assert np.all(e[:len(real)] != 0xffffffff)                               # ... and sits at its end
+            widest = max(widest, len(e))
+    assert seen.all() and widest == max_level_pixels
+
+
 def test_vg01_world_file_roundtrip_and_errors(tmp_path):
     """the VG01 world file (WorldManager.cs:612-629 writer, :399-441 reader) and its error behaviour."""
     import struct

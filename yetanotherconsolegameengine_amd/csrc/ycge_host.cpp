@@ -1416,6 +1416,22 @@ int ycge_host_inplace_schedule(int32_t w, int32_t h, int32_t step, uint32_t *pix
     std::memcpy(offsets_out, off.data(), off.size() * 4);
     return (int)off.size() - 1;
 }
+// test hook: the banded pass lists of an in-place iteration as k_atrous_band reads them.  Returns the number of passes (entries = 32 x
+// passes, x | y << 16 or 0xffffffff); offsets_out gets n_bands x (levels + 1) pass offsets; info_out = {levels, n_bands, max_level_pixels}
+int ycge_host_inplace_bands(int32_t w, int32_t h, int32_t step, int32_t rows_per_band, uint32_t *entries_out, int64_t entries_capacity,
+                            uint32_t *offsets_out, int64_t offsets_capacity, int32_t *info_out)
+{
+    if (w <= 0 || h <= 0 || step <= 0 || rows_per_band <= 0 || !info_out) return YCGE_ERR_INVALID_ARG;
+    std::vector<uint32_t> px, off, bpx, boff;
+    build_inplace_schedule(w, h, step, px, off);
+    int n_bands = 0;
+    uint32_t max_level_pixels = 0;
+    band_inplace_schedule(w, h, rows_per_band, px, off, bpx, boff, n_bands, max_level_pixels);
+    info_out[0] = (int32_t)off.size() - 1; info_out[1] = n_bands; info_out[2] = (int32_t)max_level_pixels;
+    if (entries_out && (int64_t)bpx.size() <= entries_capacity) std::memcpy(entries_out, bpx.data(), bpx.size() * 4);
+    if (offsets_out && (int64_t)boff.size() <= offsets_capacity) std::memcpy(offsets_out, boff.data(), boff.size() * 4);
+    return (int)(bpx.size() / 32);
+}
 // profiling aid: per-wavefront {start, end, node iterations, leaf phases} of the last counted k_wf_primary launch
 int ycge_debug_read_wave_prof(ycge_ctx *c, unsigned long long *dst, size_t n_u64)
 {
