@@ -269,7 +269,8 @@ dist.init_process_group("gloo")
 rank, world = dist.get_rank(), dist.get_world_size()
 W, H = 200, 90
 yy, xx = np.mgrid[0:H, 0:W]
-frame = np.stack([(xx * 1000 + yy + c * 0.125).astype(np.float32) for c in range(11)], -1)      # what the full frame must be
+FLOATS = int(sys.argv[2])                       # 11, or 8 for lean slabs (config.slab_albedo = 0)
+frame = np.stack([(xx * 1000 + yy + c * 0.125).astype(np.float32) for c in range(FLOATS)], -1)  # what the full frame must be
 mine = np.full_like(frame, np.nan)                                                              # this rank only "traces" its tiles
 tx, ty, n = tiles.tile_grid(W, H)
 for tid in tiles.owned_tiles(rank, world, n):
@@ -278,7 +279,7 @@ for tid in tiles.owned_tiles(rank, world, n):
 slab = torch.from_numpy(tiles.pack_slab(mine, rank, world))
 gathered = torch.empty(world * slab.numel(), dtype=torch.float32)
 dist.all_gather_into_tensor(gathered, slab)              # the one collective of the path
-full = tiles.unpermute(gathered.numpy(), W, H, world)
+full = tiles.unpermute(gathered.numpy(), W, H, world, FLOATS)
 assert np.array_equal(full, frame), "rank %d: reassembled frame differs" % rank
 dist.barrier()
 dist.destroy_process_group()
@@ -286,12 +287,13 @@ print("rank", rank, "ok")
 '''
 
 
-def test_two_process_all_gather_reassembles_the_frame(tmp_path):
+@pytest.mark.parametrize("floats", [11, 8])
+def test_two_process_all_gather_reassembles_the_frame(tmp_path, floats):
     script = tmp_path / "worker.py"
     script.write_text(_WORKER)
     env = dict(os.environ, MASTER_ADDR="127.0.0.1")
     r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr", "127.0.0.1",
-                        "--master-port", "29533", str(script), str(ROOT)], capture_output=True, text=True, timeout=300, env=env)
+                        "--master-port", str(29533 + floats), str(script), str(ROOT), str(floats)], capture_output=True, text=True, timeout=300, env=env)
     assert r.returncode == 0, r.stdout + r.stderr
     assert r.stdout.count("ok") == 2
 
