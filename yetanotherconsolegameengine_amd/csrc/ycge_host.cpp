@@ -990,8 +990,8 @@ int begin_and_trace(ycge_ctx *c, float *d_slab, hipStream_t stream, FrameState &
     } else {
         const size_t nt = (size_t)(c->n_owned > 0 ? c->n_owned : 1);
         void *bufs[7] = {c->wf_q0.p, c->wf_q1.p, c->wf_hit.p, c->wf_lq.p, c->wf_counts.p, c->wf_counts.p + 7 * nt, c->wf_seg.p};
-        // persistent extend: 20 wavefronts per CU (88 VGPRs: five per SIMD; measured 16 -> 20: 13.1 -> 12.5 ms on the voxel world, 24: 12.5), within the stack-spill columns
-        int pw = getenv("YCGE_NO_REFILL") ? 0 : c->compute_units * (getenv("YCGE_PW_PER_CU") ? atoi(getenv("YCGE_PW_PER_CU")) : 20);
+        // persistent extend: 32 wavefronts per CU (6 per SIMD resident, the rest queue behind them; measured on the voxel world: 16 per CU 13.1 ms, 20 12.5, 24 12.2, 32 12.0, 40 12.1), within the stack-spill columns
+        int pw = getenv("YCGE_NO_REFILL") ? 0 : c->compute_units * (getenv("YCGE_PW_PER_CU") ? atoi(getenv("YCGE_PW_PER_CU")) : 32);
         if ((size_t)pw * 64 > O.stack_lanes) pw = (int)(O.stack_lanes / 64);
         if ((size_t)pw > nt * 4) pw = (int)(nt * 4);            // never more wavefronts than the round can have rays for
         e = ycge_launch_wavefront(&c->sd, &P, &O, bufs, c->wf_rounds, c->has_grid ? 1 : 0, flat, c->cfg.count_work, pw, stream);

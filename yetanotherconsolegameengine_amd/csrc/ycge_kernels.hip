@@ -211,8 +211,11 @@ __global__ __launch_bounds__(256) void k_wf_extend(const SceneDev S, const Trace
 // at the same light, their lengths are alike, and k_wf_lights already keeps 53 % of its lanes busy.
 #define YCGE_ROUND_TREE_STEPS 3
 #define YCGE_ROUND_CELL_STEPS 8
+#ifndef YCGE_TRACEP_WAVES
+#define YCGE_TRACEP_WAVES 6          // persistent extend stage: 6 wavefronts per SIMD (85-VGPR budget) and 32 persistent wavefronts per CU: 12.35 -> 12.0 ms on the voxel world
+#endif
 template <bool COUNT, bool HAS_GRID>
-__global__ __launch_bounds__(64) void k_wf_trace_p(const SceneDev S, const FrameParams P, const TraceOut O, const WfBuffers B, int round,
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu((HAS_GRID && !COUNT) ? YCGE_TRACEP_WAVES : 1, 8))) void k_wf_trace_p(const SceneDev S, const FrameParams P, const TraceOut O, const WfBuffers B, int round,
                                                    uint32_t *__restrict__ chunk_ctr, int round_tree_steps, int round_cell_steps)
 {
     Work w = {0, 0, 0, 0, 0, 0};
@@ -437,8 +440,11 @@ __global__ __launch_bounds__(256) void k_wf_shade(const SceneDev S, const FrameP
 // ---------------------------------------------------------------------------------- k_wf_lights
 // The light loop of TraceFull (RaytraceRenderer.cs:578-603) with ComputeTransmittanceToLight
 // (:757-798) for one diffuse vertex per thread; contributions are added in light order.
+#ifndef YCGE_LIGHTS_WAVES
+#define YCGE_LIGHTS_WAVES 5         // voxel worlds: 5 wavefronts per SIMD (a 102-VGPR budget, 16 spilled registers outside the walk): 12.63 -> 12.35 ms; 6: 13.0
+#endif
 template <bool COUNT, bool HAS_GRID, bool FLAT>
-__global__ __launch_bounds__(256) void k_wf_lights(const SceneDev S, const FrameParams P, const TraceOut O, const WfBuffers B, int round)
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu((HAS_GRID && !FLAT && !COUNT) ? YCGE_LIGHTS_WAVES : 1, 8))) void k_wf_lights(const SceneDev S, const FrameParams P, const TraceOut O, const WfBuffers B, int round)
 {
     const int k = block_tile(P);
     const uint32_t n = B.n_lq[k];
