@@ -1149,6 +1149,27 @@ __global__ __launch_bounds__(256) void k_taa(const TaaParams T, const float *__r
     }
     float min_l = YCGE_INF, max_l = -YCGE_INF;
     const int r = T.radius;
+    if (r == 1) {       // the default window: all nine taps fetched before any is looked at (the loop below waits for a tap's sky flag
+                        // before it asks for the colour, nine times in a row); same comparisons in the same order
+        size_t js[9];
+#pragma unroll
+        for (int k = 0; k < 9; k++) {
+            int sy = y + k / 3 - 1; if (sy < 0) sy = 0; else if (sy >= T.h) sy = T.h - 1;
+            int sx = x + k % 3 - 1; if (sx < 0) sx = 0; else if (sx >= T.w) sx = T.w - 1;
+            js[k] = (size_t)sx + (size_t)sy * T.w;
+        }
+        uint8_t sk[9];
+        float lr[9], lg[9], lb[9];
+#pragma unroll
+        for (int k = 0; k < 9; k++) { sk[k] = sky[js[k]]; lr[k] = current[3 * js[k]]; lg[k] = current[3 * js[k] + 1]; lb[k] = current[3 * js[k] + 2]; }
+#pragma unroll
+        for (int k = 0; k < 9; k++) {
+            const float l = luma(lr[k], lg[k], lb[k]);
+            const bool use = sk[k] == sky_now;
+            if (use && l < min_l) min_l = l;
+            if (use && l > max_l) max_l = l;
+        }
+    } else
     for (int oy = -r; oy <= r; oy++) {
         int sy = y + oy; if (sy < 0) sy = 0; else if (sy >= T.h) sy = T.h - 1;
         for (int ox = -r; ox <= r; ox++) {
