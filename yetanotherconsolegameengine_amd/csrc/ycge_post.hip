@@ -97,13 +97,25 @@ __global__ __launch_bounds__(256) void k_atrous(const AtrousParams A, const floa
     C.a0 = ld3(albedo, i); C.n0 = ld3(unit_n, i); C.z0 = depth[i];
     float wsum = 0.0f;
     F3 accum = f3(0, 0, 0);
-    for (int ky = -2; ky <= 2; ky++)
-        for (int kx = -2; kx <= 2; kx++) {
-            float wght; F3 c;
-            if (!atrous_tap(A, cur, albedo, unit_n, depth, sky, x, y, kx, ky, C, wght, c)) continue;
-            accum = f3(accum.x + c.x * wght, accum.y + c.y * wght, accum.z + c.z * wght);
+    for (int ky = -2; ky <= 2; ky++) {
+        // a stencil row's five taps are fetched before any of them is looked at (atrous_tap asks for a tap's sky flag, waits, and only
+        // then for its data: 25 dependent round trips per pixel); weights and sums as before, in (ky, kx) order
+        size_t j[5];
+        uint8_t sj[5];
+        F3 cj[5], aj[5], nj[5];
+        float zj[5];
+#pragma unroll
+        for (int k = 0; k < 5; k++) j[k] = atrous_tap_index(A, x, y, k - 2, ky);
+#pragma unroll
+        for (int k = 0; k < 5; k++) { sj[k] = sky[j[k]]; cj[k] = ld3(cur, j[k]); aj[k] = ld3(albedo, j[k]); nj[k] = ld3(unit_n, j[k]); zj[k] = depth[j[k]]; }
+#pragma unroll
+        for (int k = 0; k < 5; k++) {
+            if (sj[k] != C.sky0) continue;
+            const float wght = atrous_tap_weight(A, k - 2, ky, C, cj[k], aj[k], nj[k], zj[k]);
+            accum = f3(accum.x + cj[k].x * wght, accum.y + cj[k].y * wght, accum.z + cj[k].z * wght);
             wsum += wght;
         }
+    }
     if (wsum > 1e-8f) {
         const float inv = 1.0f / wsum;
         st3(dst, i, f3(accum.x * inv, accum.y * inv, accum.z * inv));
