@@ -288,21 +288,29 @@ __global__ __launch_bounds__(1024) void k_atrous_band(const AtrousParams A, floa
 __global__ __launch_bounds__(256) void k_exposure_terms(const float *__restrict__ hdr, const uint8_t *__restrict__ sky, int w, int h, int step,
                                                         int nsx, int nsy, float *__restrict__ terms, ToneState *__restrict__ state)
 {
+    // how many samples count is an integer sum (order-free): per workgroup through LDS into counts[block] = the words behind the
+    // nsx * nsy terms, added up by k_exposure_sum - one global atomic per wavefront on a single word serialised the whole kernel
+    __shared__ uint32_t s_cnt;
+    if (threadIdx.x == 0) s_cnt = 0;
+    __syncthreads();
     const int i = blockIdx.x * 256 + threadIdx.x;
     bool counted = false;
     if (i < nsx * nsy) {
         const int px = (i % nsx) * step, py = (i / nsx) * step;
         const size_t j = (size_t)px + (size_t)py * w;
         float term = 0.0f;
-        if (!sky[j]) {
-            const F3 c = ld3(hdr, j);
+        const uint8_t is_sky = sky[j];
+        const F3 c = ld3(hdr, j);
+        if (!is_sky) {
             const float lum = 0.2126f * c.x + 0.7152f * c.y + 0.0722f * c.z;
             if (lum > 0.0f) { term = m_log(1e-6f + lum); counted = true; }
         }
         terms[i] = term;
     }
     const unsigned long long m = __ballot(counted);
-    if ((threadIdx.x & 63) == 0 && m) atomicAdd(&state->count, (uint32_t)__popcll(m));
+    if ((threadIdx.x & 63) == 0 && m) atomicAdd(&s_cnt, (uint32_t)__popcll(m));
+    __syncthreads();
+    if (threadIdx.x == 0) ((uint32_t *)(terms + (size_t)nsx * nsy))[blockIdx.x] = s_cnt;
 }
 
 // part 2: logSum += term in scan order by ONE lane, then the exposure update
@@ -313,6 +321,13 @@ __global__ __launch_bounds__(64) void k_exposure_sum(const float *__restrict__ t
     // fetches the next 1024 terms with coalesced 16-byte loads while lane 0 adds the current 1024 out of LDS.
     __shared__ float4 s_buf[2][256];
     const int lane = threadIdx.x;
+    uint32_t total_cnt = 0;     // samples that count: k_exposure_terms left one word per workgroup behind the terms
+    {
+        const uint32_t *counts = (const uint32_t *)(terms + n);
+        const int n_blocks = (n + 255) / 256;
+        for (int b = lane; b < n_blocks; b += 64) total_cnt += counts[b];
+        for (int off = 32; off >= 1; off >>= 1) total_cnt += (uint32_t)__shfl_xor((int)total_cnt, off, 64);
+    }
     const float4 *t4 = (const float4 *)terms;
     const int n_chunks = n / 1024;
     float log_sum = 0.0f;
@@ -367,7 +382,7 @@ __global__ __launch_bounds__(64) void k_exposure_sum(const float *__restrict__ t
     }
     if (lane != 0) return;
     for (int i = n_chunks * 1024; i < n; i++) log_sum += terms[i];
-    const int cnt = (int)state->count;
+    const int cnt = (int)total_cnt;
     float ae = state->ae_exposure;
     const float avg_log = cnt > 0 ? log_sum / (float)(cnt > 1 ? cnt : 1) : 0.0f;
     const float avg_lum = m_exp(avg_log);
