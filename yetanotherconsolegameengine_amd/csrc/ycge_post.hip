@@ -173,8 +173,7 @@ __global__ __launch_bounds__(256) void k_atrous_static(const AtrousParams A, con
 #define YCGE_POST_NONE 0xffffffffu
 struct PostShared {
     float val[YCGE_POST_GROUPS][25][4];
-    uint32_t tag[YCGE_POST_HASH];
-    float hv[YCGE_POST_HASH][3];
+    uint4 ent[YCGE_POST_HASH];  // {pixel (tag), r, g, b as bits}: a lookup is ONE 16-byte LDS read
 };
 __device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
 __device__ __forceinline__ uint32_t post_hash(uint32_t p) { return (p * 2654435761u) >> (32 - 11); }
@@ -209,9 +208,9 @@ __device__ __forceinline__ void pass_compute(const AtrousParams &A, uint32_t p, 
     if (valid) {
         F3 cj = D.cj;
         for (uint32_t h = post_hash(D.j);; h = (h + 1u) & (YCGE_POST_HASH - 1u)) {      // rewritten earlier in this launch?
-            const uint32_t tg = sh.tag[h];
-            if (tg == D.j) { cj = f3(sh.hv[h][0], sh.hv[h][1], sh.hv[h][2]); break; }
-            if (tg == YCGE_POST_NONE) break;
+            const uint4 en = sh.ent[h];
+            if (en.x == D.j) { cj = f3(__uint_as_float(en.y), __uint_as_float(en.z), __uint_as_float(en.w)); break; }
+            if (en.x == YCGE_POST_NONE) break;
         }
         // atrous_tap_weight with its three colour-independent exponentials read back: w_base * wc * wn * wz * wa, left to right
         const float w_base = kernel_tap(kx) * kernel_tap(ky);
@@ -239,14 +238,14 @@ __device__ __forceinline__ void pass_compute(const AtrousParams &A, uint32_t p, 
     const bool changed = work && wsum > 1e-8f;          // else dst = c0: unchanged, nothing to record
     if (changed && t == 0) {
         for (h = post_hash(D.p);; h = (h + 1u) & (YCGE_POST_HASH - 1u)) {
-            const uint32_t prev = atomicCAS(&sh.tag[h], YCGE_POST_NONE, D.p);
+            const uint32_t prev = atomicCAS(&sh.ent[h].x, YCGE_POST_NONE, D.p);
             if (prev == YCGE_POST_NONE || prev == D.p) break;
         }
     }
     h = (uint32_t)__shfl((int)h, threadIdx.x & 32, 64);
     if (changed && t < 3) {
         const float inv = 1.0f / wsum;
-        sh.hv[h][t] = acc * inv;
+        (&sh.ent[h].y)[t] = __float_as_uint(acc * inv);
     }
     lds_barrier();              // the table holds this pass's pixels before the next pass looks its taps up
 }
@@ -265,7 +264,7 @@ __global__ __launch_bounds__(1024) void k_atrous_band(const AtrousParams A, floa
     const uint32_t pass_lo = o[t0], pass_hi = o[t1];
     if (pass_lo >= pass_hi) return;
     const int grp = threadIdx.x >> 5, t = threadIdx.x & 31;
-    for (uint32_t e = threadIdx.x; e < YCGE_POST_HASH; e += 1024) sh.tag[e] = YCGE_POST_NONE;
+    for (uint32_t e = threadIdx.x; e < YCGE_POST_HASH; e += 1024) sh.ent[e].x = YCGE_POST_NONE;
     uint32_t p1 = pixels[(size_t)pass_lo * YCGE_POST_GROUPS + grp];
     uint32_t p2 = pass_lo + 1 < pass_hi ? pixels[(size_t)(pass_lo + 1) * YCGE_POST_GROUPS + grp] : YCGE_POST_NONE;
     PassData D1 = pass_fetch(A, buf, statw, sky, p1, t);
@@ -278,8 +277,8 @@ __global__ __launch_bounds__(1024) void k_atrous_band(const AtrousParams A, floa
     }
     // the launch's new colours go to memory together; the kernel boundary publishes them
     for (uint32_t e = threadIdx.x; e < YCGE_POST_HASH; e += 1024) {
-        const uint32_t tg = sh.tag[e];
-        if (tg != YCGE_POST_NONE) st3(buf, tg, f3(sh.hv[e][0], sh.hv[e][1], sh.hv[e][2]));
+        const uint4 en = sh.ent[e];
+        if (en.x != YCGE_POST_NONE) st3(buf, en.x, f3(__uint_as_float(en.y), __uint_as_float(en.z), __uint_as_float(en.w)));
     }
 }
 
