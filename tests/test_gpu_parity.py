@@ -396,3 +396,24 @@ def test_tiled_frame_pipelined_over_two_streams(product_lib, path):
     for which in (abi.BUF_CURRENT_HDR, abi.BUF_G_ALBEDO, abi.BUF_G_NORMAL, abi.BUF_G_DEPTH, abi.BUF_SKY_MASK, abi.BUF_TAA_HISTORY):
         assert pu.bits_equal(seq.read(which), pip.read(which)), which
     seq.close(); pip.close()
+
+
+def test_empty_scene_and_empty_mesh(product_lib, oracle, path):
+    """Edge inputs: Scene.Objects empty (every ray is sky; TAA still runs) matches the oracle frame for frame; a mesh with no
+    triangles has no bounds, and the reference's BVH builder refuses such an object ("Unbounded Hittable", BVH.cs) - so do the
+    oracle and the product, with the same error."""
+    import oracle_binding as ob
+    pose = dict(pos=(0.0, 1.0, 0.0), yaw=0.3, pitch=0.1, fov=45.0)
+    o, g = pu.run_pair(oracle, Scene(), 64, 20, 1, pose, frames=1)
+    _assert_parity(pu.compare_frame(o, g), "empty frame1")
+    for f in (2, 3):
+        o.render(stages=1, threads=4); g.TryFlipAndBlit()
+        _assert_parity(pu.compare_frame(o, g), f"empty frame{f}")
+    o.close(); g.close()
+    sc = Scene()
+    sc.Objects.append(Mesh(np.zeros((0, 3, 3), np.float32), Material(vec3(1, 1, 1))))
+    sc.Objects.append(Sphere(vec3(0.0, 1.0, -3.0), 0.7, Material(vec3(0.8, 0.3, 0.2))))
+    with pytest.raises(abi.YcgeError, match="Unbounded"):
+        ob.OracleRenderer(sc, 64, 20, 1, pose)
+    with pytest.raises(abi.YcgeError, match="Unbounded"):
+        RaytraceRenderer(sc, 64, 20, pose["fov"], 1)
