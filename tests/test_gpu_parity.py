@@ -417,3 +417,16 @@ def test_empty_scene_and_empty_mesh(product_lib, oracle, path):
         ob.OracleRenderer(sc, 64, 20, 1, pose)
     with pytest.raises(abi.YcgeError, match="Unbounded"):
         RaytraceRenderer(sc, 64, 20, pose["fov"], 1)
+
+
+@pytest.mark.parametrize("fbw,fbh,ss", [(1, 1, 1), (3, 2, 1), (33, 5, 1), (2, 1, 3)])
+def test_tiny_and_ragged_framebuffers(product_lib, oracle, path, fbw, fbh, ss):
+    """Trace grids smaller than one 32x8 tile / one 8x8 block and ragged at both edges: lanes outside the image must neither
+    trace nor write, the schedule has a handful of blocks, TAA's clamp window is all border."""
+    sc, _, _, _, pose = scenes.config_scene(2)
+    o, g = pu.run_pair(oracle, sc, fbw, fbh, ss, pose, frames=1)
+    _assert_parity(pu.compare_frame(o, g), f"{fbw}x{fbh} ss{ss} frame1")
+    for f in (2, 3):
+        o.render(stages=1, threads=2); g.TryFlipAndBlit()
+        _assert_parity(pu.compare_frame(o, g), f"{fbw}x{fbh} ss{ss} frame{f}")
+    o.close(); g.close()
