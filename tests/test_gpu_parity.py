@@ -430,3 +430,35 @@ def test_tiny_and_ragged_framebuffers(product_lib, oracle, path, fbw, fbh, ss):
         o.render(stages=1, threads=2); g.TryFlipAndBlit()
         _assert_parity(pu.compare_frame(o, g), f"{fbw}x{fbh} ss{ss} frame{f}")
     o.close(); g.close()
+
+
+def test_more_ranks_than_tiles(product_lib, path):
+    """A 33x5 framebuffer is four 32x8 tiles: at world_size 8 half the ranks own nothing.  Their trace and pack are no-ops, their
+    slabs are padding, and every rank still resolves the same frame as a single context."""
+    import torch
+    sc, _, _, _, pose = scenes.config_scene(2)
+    flat = flatten(sc)
+    w, h, world = 33, 5, 8
+
+    def mk(rank, ws):
+        r = RaytraceRenderer(flat, w, h, pose["fov"], 1, rank=rank, world_size=ws)
+        r.SetCamera(pose["pos"], pose["yaw"], pose["pitch"])
+        return r
+    single = mk(0, 1)
+    ranks = [mk(i, world) for i in range(world)]
+    nb = ranks[0].tile_slab_bytes()
+    for frame in range(3):
+        single.TryFlipAndBlit()
+        gathered = torch.zeros(world * nb // 4, dtype=torch.float32, device="cuda")
+        for i, r in enumerate(ranks):
+            assert r.tile_slab_bytes() == nb
+            r.trace_tiles(gathered[i * nb // 4:].data_ptr(), 0, want_stats=True)
+        torch.cuda.synchronize()
+        for r in ranks:
+            r.resolve_gathered(gathered.data_ptr(), 0, want_stats=True)
+        for which in (abi.BUF_CURRENT_HDR, abi.BUF_G_NORMAL, abi.BUF_G_DEPTH, abi.BUF_SKY_MASK, abi.BUF_TAA_HISTORY):
+            ref = single.read(which)
+            for r in ranks:
+                assert pu.bits_equal(ref, r.read(which)), (frame, which)
+    for r in ranks + [single]:
+        r.close()
