@@ -11,12 +11,21 @@ are resident in HBM before the timed region.  Prints ONE JSON line (rank 0).
 value   = Mrays/s over ALL rays: calls to Scene.Hit + Scene.Occluded (primary, shadow, bounce) per
           frame / frame time, whole job (all ranks).  Ray counts are exact: the timed frames are
           re-run with the counting kernel variant afterwards (same frame numbers, untimed).
-roofline= algorithmic bytes of k_trace per launch (32*N_box + 48*N_tri + 64*N_prim +
+roofline= ALGORITHMIC bytes of the trace per launch (32*N_box + 48*N_tri + 64*N_prim +
           1*N_vox + 118*pixels, counters from the counting replay) / its mean launch duration from
           HIP events recorded around the kernel on its own stream inside the timed region (N > 1: in a few
-          extra frames right after it, so that the timed region has no per-step host synchronisation).
+          extra frames right after it, so that the timed region has no per-step host synchronisation):
+          `achieved` / `frac`.  That figure prices work, not memory traffic - most of those bytes are cache
+          hits.  What the hardware counters of the same build say is reported beside it, from the committed
+          rocprofv3 PMC passes (profiles/r02/pmc_config<N>.json, written by profiles/run_profiles.sh +
+          summarize.py): `traffic` = fabric bytes per launch (FETCH_SIZE doubled per the gfx950 note of
+          MI355X_MICROARCH.md, WRITE_SIZE scaled by the copy calibration), `hbm_counter_gbs`,
+          `frac_hbm_counter`, `lanes_active`, `valu_busy`, `wait_frac`; `bound` says what those show.
 cpu_baseline = the oracle (scalar C++ restatement of the reference, all host threads) on a bounded
-          sample of the same workload, rank 0, N = 1 only.  A reported baseline, not the target.
+          sample of the same workload, rank 0, N = 1 only: `value` = trace only (what `value` of the GPU line
+          counts rays over is the whole frame, so `whole_frame_serial_taa` is the like-for-like figure); the
+          reference's TAA is one serial loop (`taa_serial_ms`), `taa_parallel_ms` is the same loop in row bands
+          (SURVEY 8d asks for both).  A reported baseline, not the target.
 """
 from __future__ import annotations
 
@@ -45,16 +54,21 @@ def stats_dict(s):
     return {k: int(getattr(s, k)) for k in ("n_rays", "n_box", "n_tri", "n_prim", "n_vox")}
 
 
-def load_traffic_hint(config):
-    """HBM bytes per k_trace launch from the committed PMC pass (profiles/) of THIS config, or None."""
-    p = ROOT / "profiles" / "trace_hbm_traffic.json"
-    if p.exists():
-        try:
-            d = json.loads(p.read_text())
-            return d.get("hbm_bytes_per_launch") if d.get("config", 4) == config else None
-        except Exception:
-            return None
-    return None
+WORKLOADS = {1: "Cornell box", 2: "mirror spheres on checker", 3: "Stanford bunny 69,451 tris",
+             4: "Dragon-class stand-in mesh 871,200 tris (seeded torus-knot, dragon OBJ is a missing blob)",
+             5: "voxel world 544x256x544"}
+METRIC_SHAPES = {1: "Cornell box 80x90 1spp", 2: "mirror spheres 640x360 1spp", 3: "Bunny BVH 1280x720 1spp",
+                 4: "Dragon-class BVH 1920x1080 1spp", 5: "voxel volume grid 1920x1080 4spp + TAA"}
+
+
+def load_pmc(config):
+    """Counter summary of the trace kernels of THIS config from the committed rocprofv3 PMC passes (profiles/r02/), or None.
+    Produced on the GPU box by profiles/run_profiles.sh -> summarize.py --json; bench.py itself never runs a profiler."""
+    p = ROOT / "profiles" / "r02" / f"pmc_config{config}.json"
+    try:
+        return json.loads(p.read_text()) if p.exists() else None
+    except Exception:
+        return None
 
 
 def main():
@@ -65,7 +79,7 @@ def main():
     ap.add_argument("--config", type=int, default=4)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
-    ap.add_argument("--post", action="store_true", help="also time a few frames WITH the denoise/exposure/tonemap stage (reported apart)")
+    ap.add_argument("--no-post", action="store_true", help="skip the frames WITH the denoise/exposure/tonemap stage (reported apart as post_stage)")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -201,18 +215,34 @@ def main():
         # run k_trace alone), or the stage pipeline of scenes with a real top-level tree (config 5)
         kernel = "k_wf_* stages" if args.config == 5 else "k_trace" if args.config in (1, 2) else "k_trace + k_trace_fan (concurrent)"
         roof = {"bound": "hbm", "kernel": kernel, "achieved": round(ach, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                "frac": round(ach / HBM_PEAK_GBS, 5), "traffic": load_traffic_hint(args.config) if world == 1 else None,
+                "frac": round(ach / HBM_PEAK_GBS, 5), "traffic": None,
+                "achieved_is": "algorithmic bytes (SURVEY 8d) / launch time - mostly cache hits, NOT memory traffic",
                 "algorithmic_bytes_per_launch": int(my_alg), "mean_launch_ms": round(mean_trace_ms, 4)}
+        pmc = load_pmc(args.config) if world == 1 else None
+        if pmc:
+            # counters of the same kernels from the committed PMC passes; the rate uses THIS run's launch time
+            t = pmc.get("traffic_bytes_per_launch")
+            roof["traffic"] = int(t) if t else None
+            if t:
+                roof["hbm_counter_gbs"] = round(t / (mean_trace_ms * 1e-3) / 1e9, 1)
+                roof["frac_hbm_counter"] = round(t / (mean_trace_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)
+            for k in ("fetch_bytes_x2", "write_bytes_calibrated", "scratch_bytes_per_lane", "lanes_active", "valu_busy", "wait_frac", "l2_hit_rate"):
+                if pmc.get(k) is not None:
+                    roof[k] = pmc[k]
+            roof["bound"] = pmc.get("bound", "latency")
+            roof["bound_evidence"] = pmc.get("bound_evidence")
+            roof["pmc_source"] = pmc.get("source")
 
     post = None
-    if args.post and world == 1:        # SURVEY 8-f1, outside the headline metric (SURVEY 8d times the frame through TAA)
+    if not args.no_post and world == 1:        # the frame the C# wrapper asks for (SDR out); outside the headline metric, which SURVEY 8d times through TAA
         ms = []
-        for _ in range(4):
+        for _ in range(5):
             r.TryFlipAndBlit(want_sdr=True)
             ms.append((float(r.stats.trace_ms), float(r.stats.taa_ms), float(r.stats.post_ms), float(r.stats.total_ms)))
         ms = np.array(ms[1:])            # the first frame builds the in-place level schedule
         post = {"trace_ms": round(float(ms[:, 0].mean()), 4), "taa_ms": round(float(ms[:, 1].mean()), 4),
-                "post_ms": round(float(ms[:, 2].mean()), 4), "frame_ms_with_sdr_readback": round(float(ms[:, 3].mean()), 4)}
+                "post_ms": round(float(ms[:, 2].mean()), 4), "frame_ms_with_sdr_readback": round(float(ms[:, 3].mean()), 4),
+                "what": "ycge_render_frame with an SDR buffer: + A-trous denoise, auto-exposure, tonemap/downsample, read-back (4 frames)"}
 
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
@@ -220,26 +250,33 @@ def main():
         threads = os.cpu_count() or 1
         o = ob.OracleRenderer(scene, fbw, fbh, ss, pose, flat=flat)
         o.set_frame_counter(first_frame - 1)
-        rays = 0; secs = 0.0; frames = 0
-        while secs < args.cpu_seconds and frames < args.steps:
+        rays = 0; t_trace = 0.0; t_taa = 0.0; frames = 0
+        while t_trace + t_taa < args.cpu_seconds and frames < args.steps:
             o.render(stages=1, threads=threads)
-            rays += int(o.stats.n_rays); secs += (o.stats.trace_ms + o.stats.taa_ms) * 1e-3; frames += 1
+            rays += int(o.stats.n_rays); t_trace += o.stats.trace_ms * 1e-3; t_taa += o.stats.taa_ms * 1e-3; frames += 1
+        o.set_taa_threads(threads)           # the same TAA loop in row bands: identical result, "also reported parallel" 
+        t_taa_par = 0.0; n_par = min(frames, 3)
+        for _ in range(n_par):
+            o.render(stages=1, threads=threads)
+            t_taa_par += o.stats.taa_ms * 1e-3
         o.close()
-        cpu = {"value": round(rays / secs / 1e6, 3), "unit": "Mrays/s", "cores": threads, "kind": "port",
-               "sample": f"{frames} frame(s) of the same workload (frame numbers {first_frame}..{first_frame + frames - 1}), "
-                         f"ray-gen + trace + serial TAA, {secs:.1f} s of host time",
-               "ms_per_frame": round(secs / frames * 1e3, 2)}
+        cpu = {"value": round(rays / t_trace / 1e6, 3), "unit": "Mrays/s", "cores": threads, "kind": "port",
+               "sample": f"{frames} frame(s) of the same workload (frame numbers {first_frame}..{first_frame + frames - 1}): ray-gen + trace on {threads} threads "
+                         f"({t_trace:.1f} s of host time), then the reference's serial TAA ({t_taa:.1f} s); {n_par} more frame(s) with the TAA in {threads} row bands",
+               "value_is": "trace only (ray-gen + TraceFull)",
+               "trace_ms_per_frame": round(t_trace / frames * 1e3, 2),
+               "taa_serial_ms": round(t_taa / frames * 1e3, 2),
+               "taa_parallel_ms": round(t_taa_par / max(1, n_par) * 1e3, 2),
+               "whole_frame_serial_taa": {"value": round(rays / (t_trace + t_taa) / 1e6, 3), "unit": "Mrays/s", "ms_per_frame": round((t_trace + t_taa) / frames * 1e3, 2)}}
 
     if rank == 0:
         name, cus = r.device_info()
         out = {
-            "metric": "Mrays/s (all rays: Scene.Hit + Scene.Occluded calls) and ms/frame, Dragon-class BVH 1920x1080 1spp",
+            "metric": f"Mrays/s (all rays: Scene.Hit + Scene.Occluded calls) and ms/frame, {METRIC_SHAPES[args.config]}",
             "value": round(mrays, 2), "unit": "Mrays/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(ms_per_step, 4), "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
             "dtype": "f32", "data": "synthetic",
-            "config": {"workload": f"config {args.config}: " + {1: "Cornell box", 2: "mirror spheres on checker", 3: "Stanford bunny 69,451 tris",
-                                                               4: "Dragon-class stand-in mesh 871,200 tris (seeded torus-knot, dragon OBJ is a missing blob)",
-                                                               5: "voxel world 544x256x544"}[args.config],
+            "config": {"workload": f"config {args.config}: " + WORKLOADS[args.config],
                        "trace_grid": f"{hiW}x{hiH}", "spp": ss * ss, "triangles": flat.n_triangles,
                        "frame": "ray-gen + trace + TAA" + (" + RCCL all-gather of tile slabs + un-permute" if multi else ""),
                        "parallelism": f"framebuffer tiles 32x8 round-robin over {world} GPU(s)" + (", one all-gather per frame; trace of frame N+1 beside gather + resolve of frame N (two streams)" if pipelined else ", one all-gather per frame" if multi else ""), "device": name, "compute_units": cus},
@@ -248,8 +285,8 @@ def main():
             "work_per_frame": {k: round(v, 1) for k, v in per_frame.items()},
             "roofline": roof, "cpu_baseline": cpu,
         }
-        if cpu:
-            out["gpu_over_cpu"] = round(mrays / cpu["value"], 2)
+        if cpu:       # like for like: whole frames (trace + TAA) on both sides
+            out["gpu_over_cpu"] = round(mrays / cpu["whole_frame_serial_taa"]["value"], 2)
         if post:
             out["post_stage"] = post
         print(json.dumps(out))

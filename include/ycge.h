@@ -35,7 +35,8 @@
 extern "C" {
 #endif
 
-#define YCGE_ABI_VERSION 2
+#define YCGE_ABI_VERSION 3
+#define YCGE_MAX_DEVICES 8
 
 typedef enum ycge_status {
     YCGE_OK = 0,
@@ -61,7 +62,9 @@ typedef struct ycge_vec3 { float x, y, z; } ycge_vec3;
  */
 typedef enum ycge_material_kind {
     YCGE_MAT_CONSTANT = 0,       /* Solid / Emissive / plain Material struct    */
-    YCGE_MAT_CHECKER = 1         /* Scenes.cs:418-428: parity of floor(x/s)+floor(z/s) */
+    YCGE_MAT_CHECKER = 1,        /* Scenes.cs:418-428: parity of floor(x/s)+floor(z/s) */
+    YCGE_MAT_TEXTURED = 2        /* Material.DiffuseTexture != null (RaytraceRenderer.cs:724-735 -> Texture.cs:108-163):
+                                    outside the path; ycge_scene_upload refuses it with YCGE_ERR_UNSUPPORTED */
 } ycge_material_kind;
 
 typedef struct ycge_material {
@@ -194,13 +197,19 @@ typedef struct ycge_config {
      * pixel (hdr, normal, depth, sky: what TAA needs) - 27 % less all-gather
      * traffic; ycge_resolve_gathered then refuses an SDR buffer. Default 1.  */
     int32_t slab_albedo;
-    int32_t reserved0;
+    /* One process, several GPUs (the reference makes ONE TryFlipAndBlit call from one process,
+     * RaytraceEntity.cs:230): n_devices >= 2 makes ycge_render_frame drive devices[0 .. n_devices) itself -
+     * tiles dealt round-robin over them, every device traces its share, the peers write their tiles straight
+     * into devices[0]'s frame buffers over xGMI (no staging slabs), TAA and the post stage run on devices[0].
+     * rank / world_size must then be 0 / 1.  n_devices 0 or 1 = the single GPU `device`. */
+    int32_t n_devices;
+    int32_t devices[YCGE_MAX_DEVICES];
 } ycge_config;
 
 typedef struct ycge_frame_stats {
     int64_t frame;               /* frameCounter after the increment            */
     int32_t history_reset;       /* TAA history was (re)initialised this frame  */
-    int32_t reserved;
+    int32_t fan_blocks;          /* 8x8 blocks of this frame's schedule that went to k_trace_fan (0 = kernel not launched) */
     double trace_ms;             /* device time of ray-gen + trace              */
     double taa_ms;
     double post_ms;              /* denoise + exposure + tonemap/downsample     */
@@ -267,6 +276,11 @@ int ycge_scene_update_lights(ycge_ctx *ctx, const ycge_light *lights, int32_t n_
  * rebuilds the scene-level BVH only.  `prims` index the materials, meshes and grids of the last
  * ycge_scene_upload (a Mesh keeps its own BVH in the reference too, Mesh.cs:14). */
 int ycge_scene_update_objects(ycge_ctx *ctx, const ycge_prim *prims, int32_t n_prims);
+
+/* The argument checks of ycge_scene_upload on their own: pure host code, no device and no context needed
+ * (every index in range, counts non-negative, pointers present, material kinds known).  Returns YCGE_OK or the
+ * status ycge_scene_upload would return; `msg` (may be NULL) receives the reason. */
+int ycge_validate_scene(const ycge_scene *scene, char *msg, size_t msg_bytes);
 
 /* Resize(fb, ss)   RaytraceEntity.cs:289; drops TAA history (RaytraceRenderer.cs:137) */
 int ycge_resize(ycge_ctx *ctx, int32_t fb_width, int32_t fb_height, int32_t super_sample);

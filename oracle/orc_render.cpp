@@ -438,6 +438,10 @@ struct Renderer {
         return trans > cfg.motion_trans_reset || dyaw > cfg.motion_rot_reset || dpitch > cfg.motion_rot_reset;
     }
 
+    /* taa_threads: 1 = the reference's serial loops; n > 1 = the same per-pixel work in n row bands (every pixel reads its
+     * own history and the CURRENT frame of its neighbours only, so bands are independent and the result is identical) - the
+     * "also reported parallel" CPU figure of SURVEY 8(d), not something the reference does. */
+    int taa_threads = 1;
     bool temporal_blend(bool force_reset)                               /* RaytraceRenderer.cs:274-398 */
     {
         int w = hiW, h = hiH;
@@ -450,7 +454,8 @@ struct Renderer {
         }
         float alpha = cs_max(0.0f, cs_min(1.0f, cfg.taa_alpha));
         int r = cfg.taa_clamp_radius > 0 ? cfg.taa_clamp_radius : 0;
-        for (int y = 0; y < h; y++)
+        auto rows = [&](int y_begin, int y_end) {
+        for (int y = y_begin; y < y_end; y++)
             for (int x = 0; x < w; x++) {
                 size_t i = (size_t)x + (size_t)y * w;
                 V3 cur = current[i];
@@ -500,6 +505,13 @@ struct Renderer {
                                  prev.y * (1.0f - local_alpha) + cur.y * local_alpha,
                                  prev.z * (1.0f - local_alpha) + cur.z * local_alpha);
             }
+        };
+        if (taa_threads <= 1) rows(0, h);
+        else {
+            std::vector<std::thread> th;
+            for (int k = 0; k < taa_threads; k++) th.emplace_back(rows, (int)((long long)k * h / taa_threads), (int)((long long)(k + 1) * h / taa_threads));
+            for (auto &t : th) t.join();
+        }
         for (size_t i = 0; i < (size_t)w * h; i++) { prev_normal[i] = g_normal[i]; prev_depth[i] = g_depth[i]; prev_sky[i] = sky[i]; }
         return false;
     }
@@ -739,6 +751,13 @@ int orc_render_frame(void *ctx, float *out_sdr, ycge_frame_stats *st, int thread
     Renderer *r = (Renderer *)ctx;
     if (!r) return YCGE_ERR_INVALID_ARG;
     return r->render(out_sdr, st, threads, stages);
+}
+int orc_set_taa_threads(void *ctx, int n)
+{
+    Renderer *r = (Renderer *)ctx;
+    if (!r) return YCGE_ERR_INVALID_ARG;
+    r->taa_threads = n < 1 ? 1 : n;
+    return YCGE_OK;
 }
 int orc_set_frame_counter(void *ctx, int64_t fc)
 {

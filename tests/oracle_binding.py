@@ -43,6 +43,8 @@ def lib() -> C.CDLL:
         abi.bind(L, prefix="orc_", names=names)
         L.orc_render_frame.restype = C.c_int
         L.orc_render_frame.argtypes = [C.c_void_p, C.POINTER(C.c_float), C.POINTER(abi.FrameStats), C.c_int, C.c_int]
+        L.orc_set_taa_threads.restype = C.c_int
+        L.orc_set_taa_threads.argtypes = [C.c_void_p, C.c_int]
         L.orc_build_stats.restype = C.c_int
         L.orc_build_stats.argtypes = [C.c_void_p, C.c_int32, C.POINTER(C.c_int32)]
         L.orc_splitmix64.restype = C.c_uint64; L.orc_splitmix64.argtypes = [C.c_uint64]
@@ -118,6 +120,10 @@ class OracleRenderer:
 
     def set_frame_counter(self, n: int):
         _check(self.L, self.ctx, self.L.orc_set_frame_counter(self.ctx, n))
+
+    def set_taa_threads(self, n: int):
+        """1 = the reference's serial TAA loops; n > 1 = row bands (identical result; the 'also reported parallel' baseline)."""
+        _check(self.L, self.ctx, self.L.orc_set_taa_threads(self.ctx, n))
 
     def render(self, stages: int = 2, threads: int = 1, want_sdr: bool = False):
         st = abi.FrameStats()

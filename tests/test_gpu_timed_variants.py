@@ -1,0 +1,194 @@
+"""-m gpu: the kernel variants bench.py TIMES, held to the oracle.
+
+Every other oracle comparison runs with config.count_work = 1, i.e. the counting template instances (k_trace<true, .>, the
+COUNT stage kernels).  The benchmark runs the non-counting ones - k_trace<false,true> and k_trace_fan<false,true> with their
+4-wavefronts-per-SIMD register budget (spills), the occupancy-budgeted stage kernels of the voxel world - in their steady state:
+longest-first schedule, cost history over four frames, the head of the schedule fanned out.  Here those binaries run the
+BASELINE configs at full size for several frames and every buffer of every frame is compared with the oracle
+(reference order and semantics: Objects/MeshBVH.cs:132-236, RaytraceRenderer.cs:448-620, 274-398).
+"""
+import numpy as np
+import pytest
+
+import parity_util as pu
+from yetanotherconsolegameengine_amd import abi, scenes
+from yetanotherconsolegameengine_amd.renderer import RaytraceRenderer
+from yetanotherconsolegameengine_amd.scene import flatten
+
+pytestmark = pytest.mark.gpu
+
+BUFFERS = ("rays", "prim_id", "sub_id", "hit_t", "rng_state", "current_hdr", "g_albedo", "g_normal", "g_depth", "sky", "taa_history")
+
+
+def _assert_frame(o, g, label):
+    st = pu.compare_frame(o, g, check_counters=False)
+    bad = {k: st[k + "_mismatch"] for k in BUFFERS if st[k + "_mismatch"]}
+    print(label, "fan_blocks", g.stats.fan_blocks, "trace_ms %.3f" % g.stats.trace_ms, bad or "bit-exact")
+    assert not bad, f"{label}: {bad}"
+    for k in ("current_hdr", "taa_history"):
+        assert st[k + "_rms"] <= pu.RMS_TOL
+
+
+@pytest.mark.parametrize("cfg_n,frames", [(3, 5), (4, 6)])
+def test_timed_mesh_kernels_full_size_steady_state(product_lib, oracle, monkeypatch, cfg_n, frames):
+    """Configs 3 and 4 at full size, default path (single launch for mesh viewers), NON-counting kernels, capture on.
+    Frame 1 has no schedule; from frame 2 on k_trace runs longest first; once the pinned fan count has come back (frame 3 or 4)
+    the head of the schedule runs in k_trace_fan<false,true> beside k_trace<false,true> - asserted through stats.fan_blocks."""
+    monkeypatch.delenv("YCGE_PATH", raising=False)
+    sc, w, h, ss, pose = scenes.config_scene(cfg_n)
+    o, g = pu.run_pair(oracle, sc, w, h, ss, pose, frames=1, oracle_threads=64, count=False)
+    _assert_frame(o, g, f"cfg{cfg_n} timed variants frame 1")
+    fanned = []
+    for f in range(2, frames + 1):
+        o.render(stages=1, threads=64); g.TryFlipAndBlit()
+        _assert_frame(o, g, f"cfg{cfg_n} timed variants frame {f}")
+        fanned.append(int(g.stats.fan_blocks))
+    if cfg_n == 4:
+        assert fanned[-1] > 0 and fanned[-2] > 0, f"k_trace_fan never launched: {fanned}"      # the default 200-block fan-out is active
+        assert fanned[-1] <= 200
+    o.close(); g.close()
+
+
+def test_timed_mesh_kernels_sdr_frame(product_lib, oracle, monkeypatch):
+    """The frame the C# wrapper asks for (SDR out): non-counting trace kernels + TAA + post stage on config 3 at full size,
+    three frames, against the oracle's stages=2."""
+    monkeypatch.delenv("YCGE_PATH", raising=False)
+    sc, w, h, ss, pose = scenes.config_scene(3)
+    flat = flatten(sc)
+    o = oracle.OracleRenderer(sc, w, h, ss, pose, flat=flat)
+    g = RaytraceRenderer(flat, w, h, pose["fov"], ss)
+    g.SetCamera(pose["pos"], pose["yaw"], pose["pitch"])
+    for f in range(3):
+        so = o.render(stages=2, threads=64, want_sdr=True)
+        sg = g.TryFlipAndBlit(want_sdr=True)
+        assert pu.mismatch_count(o.read(abi.BUF_TAA_HISTORY), g.read(abi.BUF_TAA_HISTORY)) == 0, f
+        assert pu.mismatch_count(o.read(abi.BUF_DENOISED), g.read(abi.BUF_DENOISED)) == 0, f
+        assert np.float32(o.stats.exposure).view(np.uint32) == np.float32(g.stats.exposure).view(np.uint32), f
+        assert pu.mismatch_count(so, sg) == 0, f
+        print(f"cfg3 sdr frame {f + 1}: post_ms {g.stats.post_ms:.3f}")
+    o.close(); g.close()
+
+
+def test_timed_voxel_stage_kernels_full_size(product_lib, oracle, monkeypatch):
+    """Config 5 at full size (3840x2160 trace grid), default path (stage pipeline), NON-counting stage kernels: k_wf_trace_p at 6
+    wavefronts per SIMD and k_wf_lights at 5 (16 spilled registers) exist only in this form.  Three frames: the 3-frame
+    taaHistory gate of SURVEY 8(d)."""
+    monkeypatch.delenv("YCGE_PATH", raising=False)
+    sc, w, h, ss, pose = scenes.config_scene(5)
+    o, g = pu.run_pair(oracle, sc, w, h, ss, pose, frames=1, oracle_threads=64, count=False)
+    _assert_frame(o, g, "cfg5 timed variants frame 1")
+    for f in (2, 3):
+        o.render(stages=1, threads=64); g.TryFlipAndBlit()
+        _assert_frame(o, g, f"cfg5 timed variants frame {f}")
+    o.close(); g.close()
+
+
+def test_one_call_drives_several_devices(product_lib, oracle, monkeypatch):
+    """config.n_devices = 2: ONE ycge_render_frame call traces the frame on two device contexts (here both on GPU 0 - the
+    driver's box has one), the peer pushes its tiles straight into rank 0's frame buffers, TAA and the post stage run on
+    rank 0.  Every buffer equals the oracle's over three frames (counters are the sum over the devices), and the SDR frame
+    equals the single-device one."""
+    monkeypatch.delenv("YCGE_PATH", raising=False)
+    sc, _, _, ss, pose = scenes.config_scene(3)
+    flat = flatten(sc)
+    w, h = 320, 90
+    o = oracle.OracleRenderer(sc, w, h, ss, pose, flat=flat)
+    g = RaytraceRenderer(flat, w, h, pose["fov"], ss, capture_debug=True, count_work=True, devices=[0, 0])
+    one = RaytraceRenderer(flat, w, h, pose["fov"], ss)
+    for r in (g, one):
+        r.SetCamera(pose["pos"], pose["yaw"], pose["pitch"])
+    for f in range(3):
+        so = o.render(stages=2, threads=8, want_sdr=True)
+        sg = g.TryFlipAndBlit(want_sdr=True)
+        s1 = one.TryFlipAndBlit(want_sdr=True)
+        st = pu.compare_frame(o, g)
+        bad = {k: st[k + "_mismatch"] for k in BUFFERS if st[k + "_mismatch"]}
+        assert not bad, (f, bad)
+        for k in ("n_rays", "n_box", "n_tri", "n_prim", "n_vox"):
+            assert st[k][0] == st[k][1], (f, k, st[k])
+        assert pu.bits_equal(sg, s1) and pu.mismatch_count(so, sg) == 0, f
+    # moving an entity and the lights reaches every device
+    g.Resize(96, 27, 1); one.Resize(96, 27, 1)
+    lights, top, bottom = scenes.sun_moon_lights(0.3)
+    for r in (g, one):
+        r.UpdateLights(lights, sc.Ambient, top, bottom)
+        r.TryFlipAndBlit()
+    for which in (abi.BUF_CURRENT_HDR, abi.BUF_G_NORMAL, abi.BUF_G_DEPTH, abi.BUF_SKY_MASK, abi.BUF_TAA_HISTORY):
+        assert pu.bits_equal(g.read(which), one.read(which)), which
+    # the one-process-per-GPU halves are refused on such a context, and so is a plain world_size > 1 context in render_frame
+    with pytest.raises(abi.YcgeError):
+        g.trace_tiles(0, 0)
+    o.close(); g.close(); one.close()
+    with RaytraceRenderer(flat, 96, 27, pose["fov"], 1, rank=0, world_size=2) as half:
+        with pytest.raises(abi.YcgeError, match="n_devices"):
+            half.TryFlipAndBlit()
+
+
+def test_pipelined_tiled_frames_with_a_moving_camera(product_lib):
+    """The trace of frame N+1 is issued BEFORE frame N is resolved (bench.py's two-stream loop), and the camera moves between
+    them - sometimes below the TAA reset threshold, sometimes above (TemporalAA.cs:58-67).  Every ycge_resolve_gathered must
+    resolve ITS frame: the pose it was traced with decides the history reset and is what CommitCamera stores
+    (RaytraceRenderer.cs:159-176, 266).  Reference behaviour = the same frames issued strictly in sequence."""
+    import torch
+    sc, _, _, ss, pose = scenes.config_scene(2)
+    flat = flatten(sc)
+    w, h = 160, 45
+    moves = [0.0, 0.001, 0.0012, 0.02, 0.0201, 0.0201, 0.05, 0.0505]          # x offsets: small, small, big, small, none, big, small
+    yaws = [0.0, 0.0, 0.001, 0.001, 0.01, 0.01, 0.01, 0.0101]
+
+    def mk():
+        return RaytraceRenderer(flat, w, h, pose["fov"], ss)
+
+    def cam(r, i):
+        r.SetCamera((pose["pos"][0] + moves[i], pose["pos"][1], pose["pos"][2]), pose["yaw"] + yaws[i], pose["pitch"])
+
+    seq, pip = mk(), mk()
+    n = seq.tile_slab_bytes() // 4
+    slab = torch.empty(n, dtype=torch.float32, device="cuda")
+    seq_resets, seq_hist = [], []
+    for i in range(len(moves)):
+        cam(seq, i)
+        seq.trace_tiles(slab.data_ptr(), 0, want_stats=True)
+        seq.resolve_gathered(slab.data_ptr(), 0, want_stats=True)
+        seq_resets.append(int(seq.stats.history_reset)); seq_hist.append(seq.read(abi.BUF_TAA_HISTORY))
+    assert seq_resets == [1, 0, 0, 1, 1, 0, 1, 0], seq_resets
+    slabs = [torch.empty(n, dtype=torch.float32, device="cuda") for _ in range(2)]
+    pip_resets = []
+    # software pipeline of depth 2: trace(i + 1) is issued - with the camera already moved - before resolve(i)
+    cam(pip, 0)
+    pip.trace_tiles(slabs[0].data_ptr(), 0)
+    for i in range(len(moves)):
+        if i + 1 < len(moves):
+            cam(pip, i + 1)
+            pip.trace_tiles(slabs[(i + 1) & 1].data_ptr(), 0)
+        pip.resolve_gathered(slabs[i & 1].data_ptr(), 0, want_stats=True)
+        pip_resets.append(int(pip.stats.history_reset))
+        assert int(pip.stats.frame) == i + 1
+        assert pu.bits_equal(pip.read(abi.BUF_TAA_HISTORY), seq_hist[i]), i
+    assert pip_resets == seq_resets
+    with pytest.raises(abi.YcgeError, match="no traced frame"):
+        pip.resolve_gathered(slabs[0].data_ptr(), 0)
+    seq.close(); pip.close()
+
+
+def test_textured_material_and_bad_indices_are_refused(product_lib):
+    """A textured material (Material.DiffuseTexture, RaytraceRenderer.cs:724-735) is outside the path: refused loudly."""
+    from yetanotherconsolegameengine_amd.scene import Material, Scene, Sphere, vec3
+    s = Scene()
+    s.Add(Sphere(vec3(0, 1, -3), 1.0, Material(vec3(0.7, 0.3, 0.3), Kind=abi.MAT_TEXTURED)))
+    with pytest.raises(abi.YcgeError) as e:
+        RaytraceRenderer(s, 32, 9)
+    assert e.value.status == abi.YCGE_ERR_UNSUPPORTED and "textured" in str(e.value)
+    ok = Scene()
+    ok.Add(Sphere(vec3(0, 1, -3), 1.0, Material(vec3(0.7, 0.3, 0.3))))
+    f = flatten(ok)
+    f.prims[0].material = 5
+    with pytest.raises(abi.YcgeError) as e:
+        RaytraceRenderer(f, 32, 9)
+    assert e.value.status == abi.YCGE_ERR_INVALID_ARG
+    with RaytraceRenderer(ok, 32, 9) as r:
+        with pytest.raises(abi.YcgeError):
+            r.set_frame_counter(-5)
+        r.set_frame_counter(2 ** 40)
+        r.TryFlipAndBlit()
+        assert r.stats.frame == 2 ** 40 + 1

@@ -35,6 +35,7 @@ def test_ctypes_mirror_matches_header_layout(product_lib):
     d = abi.default_config()
     for f, _ in abi.Config._fields_:
         a, b = getattr(c, f), getattr(d, f)
+        if hasattr(a, "__len__"): a, b = list(a), list(b)
         assert (a == b) or (isinstance(a, float) and np.float32(a) == np.float32(b)), f
 
 
@@ -51,6 +52,65 @@ def test_create_fails_loudly_without_a_gpu(product_lib):
     bad = abi.default_config(); bad.diffuse_bounces = 3
     assert product_lib.ycge_create(C.byref(bad), C.byref(ctx)) == abi.YCGE_ERR_UNSUPPORTED
     assert product_lib.ycge_create(None, C.byref(ctx)) == abi.YCGE_ERR_INVALID_ARG
+    # MaxMirrorBounces sizes TraceFull's path stack (RaytraceRenderer.cs:450: at most 3 live items with the reference's 2):
+    # any other value is refused, never silently truncated
+    for v in (0, 1, 3, 7):
+        bad = abi.default_config(); bad.max_mirror_bounces = v
+        assert product_lib.ycge_create(C.byref(bad), C.byref(ctx)) == abi.YCGE_ERR_UNSUPPORTED
+    bad = abi.default_config(); bad.n_devices = 9
+    assert product_lib.ycge_create(C.byref(bad), C.byref(ctx)) == abi.YCGE_ERR_INVALID_ARG
+    bad = abi.default_config(); bad.n_devices = 2; bad.world_size = 2
+    assert product_lib.ycge_create(C.byref(bad), C.byref(ctx)) == abi.YCGE_ERR_INVALID_ARG
+
+
+def test_scene_upload_argument_checks_fuzzed(product_lib):
+    """ycge_validate_scene = the argument checks of ycge_scene_upload (host only): every index a scene carries is poked out of
+    range, one at a time and at random, and must be refused with INVALID_ARG (UNSUPPORTED for textured / unknown materials) - never
+    accepted, never a crash.  The untouched scene passes."""
+    from yetanotherconsolegameengine_amd.scene import Material, Mesh, PointLight, Scene, Sphere, VolumeGrid, vec3
+    rng = np.random.default_rng(11)
+
+    def build():
+        s = Scene()
+        s.Add(Sphere(vec3(0, 1, -3), 1.0, Material(vec3(0.7, 0.3, 0.3))))
+        s.Add(Mesh(rng.random((12, 3, 3), dtype=np.float32), Material(vec3(0.2, 0.8, 0.2))))
+        cells = np.zeros((4, 4, 4, 2), np.int32); cells[1, 1, 1] = (3, 0); cells[2, 1, 1] = (5, 1)
+        s.Add(VolumeGrid(cells, vec3(2, 0, -4), vec3(1, 1, 1), lambda m, meta: Material(vec3(0.5, 0.5, 0.1 * m))))
+        s.Lights.append(PointLight(vec3(0, 4, 0), vec3(1, 1, 1), 30.0))
+        return flatten(s)
+
+    msg = C.create_string_buffer(256)
+    ok = build()
+    assert product_lib.ycge_validate_scene(ok.byref(), msg, 256) == abi.YCGE_OK, msg.value
+    assert product_lib.ycge_validate_scene(None, msg, 256) == abi.YCGE_ERR_INVALID_ARG
+    n_mat = ok.struct.n_materials
+    out_of_range = [-1, -7, n_mat, n_mat + 1, 1 << 20, -(1 << 31)]
+    pokes = 0
+    for trial in range(200):
+        f = build()
+        kind = trial % 10
+        v = int(out_of_range[rng.integers(len(out_of_range))])
+        expect = abi.YCGE_ERR_INVALID_ARG
+        if kind == 0: f.prims[0].material = v
+        elif kind == 1: f.prims[1].ref = int(rng.choice([-1, 1, 99]))
+        elif kind == 2: f.prims[2].ref = int(rng.choice([-1, 1, 99]))
+        elif kind == 3: f.prims[int(rng.integers(3))].type = int(rng.choice([-1, 11, 1000]))
+        elif kind == 4: f.meshes[0].material = v
+        elif kind == 5: f.grids[0].lookup[int(rng.integers(2))].material = v
+        elif kind == 6: f.struct.n_prims = -1
+        elif kind == 7: f.grids[0].nx = int(rng.choice([0, -3]))
+        elif kind == 8: f.materials[int(rng.integers(n_mat))].kind = abi.MAT_TEXTURED; expect = abi.YCGE_ERR_UNSUPPORTED
+        else: f.materials[int(rng.integers(n_mat))].kind = int(rng.choice([3, -1, 77])); expect = abi.YCGE_ERR_UNSUPPORTED
+        rc = product_lib.ycge_validate_scene(f.byref(), msg, 256)
+        assert rc == expect, (trial, kind, v, rc, msg.value)
+        assert msg.value, (trial, kind)
+        pokes += 1
+    # per-triangle materials are checked triangle by triangle
+    f = build()
+    tm = np.zeros(12, np.int32); tm[7] = n_mat
+    f.meshes[0].tri_material = tm.ctypes.data_as(C.POINTER(C.c_int32))
+    assert product_lib.ycge_validate_scene(f.byref(), msg, 256) == abi.YCGE_ERR_INVALID_ARG and b"triangle material" in msg.value
+    assert pokes == 200
 
 
 # ---- builders: product (ycge_accel.cpp) vs oracle (orc_scene.cpp), node for node ----------------------------
@@ -420,3 +480,16 @@ def test_chunk_streaming_set_and_attach_order():
     assert sc.Objects[4].Cells.shape == (6, 8, 32, 2)                            # clipped: 70 - 64, 40 - 32
     assert sc.Objects[2].MinCorner == (0.0, 0.0, -64.0)
     assert wf.attach_view(sc, world, (5.0, 0.0, -40.0), (-64.0, 0.0, -64.0), (1.0, 1.0, 1.0), 32, 1, lambda m, t: None, loaded=loaded) == []
+
+
+def test_oracle_parallel_taa_equals_the_serial_loops():
+    """bench.py's cpu_baseline reports the reference's serial TAA and the same loop in row bands: identical pixels."""
+    sc, w, h, ss, pose = scenes.config_scene(2)
+    a = ob.OracleRenderer(sc, 96, 27, 1, pose)
+    b = ob.OracleRenderer(sc, 96, 27, 1, pose)
+    b.set_taa_threads(5)
+    for f in range(3):
+        a.render(stages=1, threads=2); b.render(stages=1, threads=2)
+        for which in (abi.BUF_TAA_HISTORY, abi.BUF_PREV_NORMAL, abi.BUF_PREV_DEPTH, abi.BUF_PREV_SKY):
+            assert np.array_equal(a.read(which).view(np.uint8), b.read(which).view(np.uint8)), (f, which)
+    a.close(); b.close()

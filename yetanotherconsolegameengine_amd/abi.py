@@ -12,7 +12,8 @@ import ctypes as C
 import os
 from pathlib import Path
 
-YCGE_ABI_VERSION = 2
+YCGE_ABI_VERSION = 3
+YCGE_MAX_DEVICES = 8
 
 # ycge_status
 YCGE_OK = 0
@@ -31,7 +32,7 @@ STATUS_NAMES = {
 }
 
 # ycge_material_kind
-MAT_CONSTANT, MAT_CHECKER = 0, 1
+MAT_CONSTANT, MAT_CHECKER, MAT_TEXTURED = 0, 1, 2
 # ycge_prim_type
 (PRIM_SPHERE, PRIM_PLANE, PRIM_DISK, PRIM_XYRECT, PRIM_XZRECT, PRIM_YZRECT, PRIM_BOX,
  PRIM_CYLINDER_Y, PRIM_TRIANGLE, PRIM_MESH, PRIM_VOLUME_GRID) = range(11)
@@ -119,13 +120,13 @@ class Config(C.Structure):
         ("atrous_z_phi", C.c_float), ("atrous_a_phi", C.c_float), ("capture_debug", C.c_int32),
         ("count_work", C.c_int32),
         ("slab_albedo", C.c_int32),
-        ("reserved0", C.c_int32),
+        ("n_devices", C.c_int32), ("devices", C.c_int32 * YCGE_MAX_DEVICES),
     ]
 
 
 class FrameStats(C.Structure):
     _fields_ = [
-        ("frame", C.c_int64), ("history_reset", C.c_int32), ("reserved", C.c_int32),
+        ("frame", C.c_int64), ("history_reset", C.c_int32), ("fan_blocks", C.c_int32),
         ("trace_ms", C.c_double), ("taa_ms", C.c_double), ("post_ms", C.c_double), ("total_ms", C.c_double),
         ("n_rays", C.c_uint64), ("n_box", C.c_uint64), ("n_tri", C.c_uint64), ("n_prim", C.c_uint64),
         ("n_vox", C.c_uint64), ("exposure", C.c_float), ("reserved2", C.c_float),
@@ -148,7 +149,7 @@ def default_config() -> Config:
     c.atrous_iterations = 3
     c.atrous_c_phi, c.atrous_n_phi, c.atrous_z_phi, c.atrous_a_phi = 3.0, 0.35, 2.0, 0.20
     c.capture_debug, c.count_work = 0, 0
-    c.slab_albedo, c.reserved0 = 1, 0
+    c.slab_albedo, c.n_devices = 1, 0
     return c
 
 
@@ -162,6 +163,7 @@ _PROTOTYPES = {
     "ycge_destroy": (None, [C.c_void_p]),
     "ycge_last_error": (C.c_char_p, [C.c_void_p]),
     "ycge_scene_upload": (C.c_int, [C.c_void_p, C.POINTER(Scene)]),
+    "ycge_validate_scene": (C.c_int, [C.POINTER(Scene), C.c_char_p, C.c_size_t]),
     "ycge_scene_update_lights": (C.c_int, [C.c_void_p, C.POINTER(Light), C.c_int32, C.POINTER(Vec3), C.c_float,
                                            C.POINTER(Vec3), C.POINTER(Vec3)]),
     "ycge_scene_update_objects": (C.c_int, [C.c_void_p, C.POINTER(Prim), C.c_int32]),

@@ -126,6 +126,7 @@ struct GLight {
     float pad;
 };
 
+#define YCGE_LDS_STACK_LEVELS 12    // levels of a lane's traversal stack kept in LDS; deeper ones go to the HBM spill area
 #define YCGE_TRAVERSAL_STACK 96    // >= scene depth + 4 leaf prims + mesh depth, checked at upload
 #ifndef YCGE_COST_FRAMES
 #define YCGE_COST_FRAMES 4          // a block's schedule cost is its largest cost over this many frames
@@ -215,6 +216,14 @@ struct TraceOut {
     const uint32_t *n_fan;              // the first *n_fan schedule entries are traced by k_trace_fan (null or 0: none)
     // traversal counters (may be null): rays, box, tri, prim, vox
     unsigned long long *counters;
+};
+
+// planes a peer device copies from its own frame buffers into rank 0's (one process, several GPUs): its tiles only
+struct PushPlanes {
+    const uint8_t *src[12];
+    uint8_t *dst[12];
+    int32_t bytes_per_pixel[12];
+    int32_t n;
 };
 
 struct TaaParams {

@@ -11,6 +11,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <deque>
 #include <mutex>
 #include <string>
 #include <vector>
@@ -46,6 +47,7 @@ int ycge_launch_tonemap(const float *hdr, int hiW, int fbW, int fbH, int ss, flo
                         float *out, hipStream_t stream);
 int ycge_launch_pack_slab(const ycge::FrameParams *P, const float *hdr, const float *albedo, const float *normal, const float *depth,
                           const uint8_t *sky, float *slab, int slab_floats, hipStream_t stream);
+int ycge_launch_push_tiles(const ycge::FrameParams *P, const ycge::PushPlanes *planes, hipStream_t stream);
 int ycge_launch_unpermute(const float *all_slabs, size_t slab_floats_per_rank, int hiW, int hiH, int tiles_x, int n_tiles, int world_size,
                           int slab_floats, float *hdr, float *albedo, float *normal, float *depth, uint8_t *sky, hipStream_t stream);
 }
@@ -58,21 +60,64 @@ std::string g_create_error;
 
 template <class T> struct DevBuf {
     T *p = nullptr;
-    size_t n = 0;
-    void release() { if (p) { (void)hipFree(p); p = nullptr; } n = 0; }
+    size_t n = 0, cap = 0;          // elements in use / elements allocated
+    void release() { if (p) { (void)hipFree(p); p = nullptr; } n = cap = 0; }
     hipError_t alloc(size_t count)
     {
         release();
-        n = count;
         if (count == 0) return hipSuccess;
-        return hipMalloc((void **)&p, count * sizeof(T) + 64);     // records are read with whole 64- / 72-byte fetches: room for the over-read past the last record
+        const hipError_t e = hipMalloc((void **)&p, count * sizeof(T) + 64);     // records are read with whole 64- / 72-byte fetches: room for the over-read past the last record
+        if (e != hipSuccess) { p = nullptr; return e; }
+        n = cap = count;
+        return hipSuccess;
     }
+    // per-frame callers (lights, moved objects) reuse the allocation when the new contents fit
     hipError_t upload(const std::vector<T> &v)
     {
-        hipError_t e = alloc(v.size());
-        if (e != hipSuccess || v.empty()) return e;
+        if (v.size() > cap || (v.empty() && cap == 0)) {
+            const hipError_t e = alloc(v.size());
+            if (e != hipSuccess) return e;
+        }
+        n = v.size();
+        if (v.empty()) return hipSuccess;
         return hipMemcpy(p, v.data(), v.size() * sizeof(T), hipMemcpyHostToDevice);
     }
+};
+
+// Experiment knobs (none changes a pixel): read ONCE, when the context is created.
+struct Knobs {
+    int path_policy = 0;             // YCGE_PATH: 0 auto, 1 wavefront, 2 single launch
+    bool xcd_strips = false, generic_walk = false, no_lpt = false, no_refill = false;
+    int wave_prof_stage = -1;        // YCGE_WAVE_PROF: -1 off, 0 primary, 1 extend, 2 mega
+    int refill_steps = YCGE_REFILL_STEPS_DEFAULT;
+    bool split_set = false; uint32_t split_policy = 0;
+    int pw_per_cu = 32;
+    int post_band_rows = YCGE_POST_BAND_ROWS_DEFAULT, post_k = YCGE_POST_K_DEFAULT;
+    int fan_class = -1, fan_cap = -1;   // -1 = default by world size
+    int post_mode = 0;               // YCGE_POST_MODE: in-place A-trous implementation (0 = default)
+    void read()
+    {
+        auto geti = [](const char *n, int dflt) { const char *e = getenv(n); return e ? atoi(e) : dflt; };
+        if (const char *e = getenv("YCGE_PATH")) path_policy = e[0] == 'w' ? 1 : e[0] == 'm' ? 2 : 0;
+        xcd_strips = getenv("YCGE_XCD_STRIPS") != nullptr; generic_walk = getenv("YCGE_GENERIC_WALK") != nullptr;
+        no_lpt = getenv("YCGE_NO_LPT") != nullptr; no_refill = getenv("YCGE_NO_REFILL") != nullptr;
+        if (const char *e = getenv("YCGE_WAVE_PROF")) wave_prof_stage = e[0] == 'e' ? 1 : e[0] == 'm' ? 2 : 0;
+        refill_steps = geti("YCGE_REFILL", YCGE_REFILL_STEPS_DEFAULT);
+        if (const char *e = getenv("YCGE_SPLIT")) { split_set = true; split_policy = (uint32_t)strtoul(e, nullptr, 8); }
+        pw_per_cu = geti("YCGE_PW_PER_CU", 32);
+        post_band_rows = geti("YCGE_POST_BAND_ROWS", YCGE_POST_BAND_ROWS_DEFAULT); post_k = geti("YCGE_POST_K", YCGE_POST_K_DEFAULT);
+        fan_class = geti("YCGE_FAN", -1); fan_cap = geti("YCGE_FAN_CAP", -1);
+        post_mode = geti("YCGE_POST_MODE", 0);
+    }
+};
+
+// One frame's identity from snapshot to commit (TryFlipAndBlit steps 1-3, RaytraceRenderer.cs:159-176): the pose the
+// frame is traced with is the pose its reset decision and CommitCamera use.
+struct FrameState {
+    float pos[3], yaw, pitch, fov;
+    bool reset;
+    int64_t frame;
+    uint32_t fan_blocks;
 };
 
 struct MeshHost {
@@ -83,8 +128,15 @@ struct MeshHost {
 
 struct ycge_ctx {
     ycge_config cfg;
+    Knobs knobs;
     std::string err;
     int device = 0;
+    // one process, several GPUs (config.n_devices >= 2): this context is rank 0 and owns one context per further device
+    std::vector<ycge_ctx *> peers;
+    ycge_ctx *parent = nullptr;
+    hipEvent_t pushed_ev = nullptr;            // a peer's tiles have arrived in the parent's frame buffers
+    std::deque<FrameState> pending;            // frames traced by ycge_trace_tiles and not yet resolved (pipelined callers)
+    hipStream_t last_stream = nullptr;         // the stream the last tiled call ran on (scene updates wait for it too)
     hipStream_t stream = nullptr;
     hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
     // k_trace runs beside k_trace_fan on a side stream, forked from and joined to the frame's stream
@@ -144,7 +196,6 @@ struct ycge_ctx {
     DevBuf<uint64_t> stack_spill;                 // [YCGE_TRAVERSAL_STACK - 12][persistent lanes]
     DevBuf<float> path_stack;                  // [3][11][persistent lanes], only for scenes with transparent materials
     int spill_levels = 0;                      // traversal depth beyond the 12 LDS levels, from the uploaded trees
-    int path_policy = 0;                       // 0 auto, 1 wavefront, 2 single launch (env YCGE_PATH)
     int wf_rounds = 2;                         // 2 = primary + diffuse bounce; 4 when a surface can mirror (<= 2 mirror bounces)
     bool has_grid = false;
 
@@ -264,6 +315,8 @@ int set_geometry(ycge_ctx *c, int fbw, int fbh, int ss)
     c->last_cam[0] = c->last_cam[1] = c->last_cam[2] = NAN; c->last_yaw = c->last_pitch = NAN;
     c->den_a.release(); c->den_b.release(); c->unit_n.release(); c->exp_terms.release(); c->d_sdr.release(); c->atrous_statw.release();     // spatialA / spatialB, :129-130
     c->denoised = nullptr;
+    c->wave_prof.release();                                     // sized for the tile grid
+    c->pending.clear();
     c->t_hdr.release(); c->t_albedo.release(); c->t_normal.release(); c->t_depth.release(); c->t_sky.release();
     for (auto *sc : c->schedules) { sc->pixels.release(); sc->offsets.release(); delete sc; }      // level schedules are per size: rebuilt on demand
     c->schedules.clear();
@@ -336,7 +389,7 @@ void fill_frame_params(ycge_ctx *c, FrameParams &P, int64_t frame, const float p
     // measured on config 4: strip-per-XCD ordering is 2.1x SLOWER than plain round-robin (1.79 vs 0.84 ms): the
     // heavy tiles cluster in a few strips and the frame is bounded by its heaviest tiles, so spreading them over
     // all 8 XCDs beats L2 affinity.  Kept as an opt-in experiment knob only.
-    P.tile_order = getenv("YCGE_XCD_STRIPS") ? c->tile_order.p : nullptr;
+    P.tile_order = c->knobs.xcd_strips ? c->tile_order.p : nullptr;
 }
 
 // Hittable.TryGetBounds of each primitive class (see the citations in include/ycge.h)
@@ -398,7 +451,7 @@ int ycge_config_default(ycge_config *cfg)
     if (!cfg) return YCGE_ERR_INVALID_ARG;
     std::memset(cfg, 0, sizeof *cfg);
     cfg->abi_version = YCGE_ABI_VERSION;
-    cfg->slab_albedo = 1; cfg->reserved0 = 0;
+    cfg->slab_albedo = 1; cfg->n_devices = 0;
     cfg->fb_width = 80; cfg->fb_height = 45; cfg->super_sample = 1;
     cfg->fov_deg = 45.0f;
     cfg->device = 0; cfg->rank = 0; cfg->world_size = 1;
@@ -412,17 +465,8 @@ int ycge_config_default(ycge_config *cfg)
     return YCGE_OK;
 }
 
-int ycge_create(const ycge_config *cfg, ycge_ctx **out)
+static int create_one(const ycge_config *cfg, ycge_ctx *parent, ycge_ctx **out)
 {
-    if (!cfg || !out) { g_create_error = "null argument"; return YCGE_ERR_INVALID_ARG; }
-    *out = nullptr;
-    if (cfg->abi_version != YCGE_ABI_VERSION) { g_create_error = "abi_version mismatch"; return YCGE_ERR_INVALID_ARG; }
-    if (cfg->world_size < 1 || cfg->rank < 0 || cfg->rank >= cfg->world_size) { g_create_error = "bad rank/world_size"; return YCGE_ERR_INVALID_ARG; }
-    // the kernels implement the reference's compile-time constants (RaytraceRenderer.cs:31-36)
-    if (cfg->diffuse_bounces != 1 || cfg->max_mirror_bounces != 2 || cfg->max_refractions != 2 || cfg->taa_clamp_radius < 0) {
-        g_create_error = "DiffuseBounces/MaxMirrorBounces/MaxRefractions are compile-time constants in the reference (1/2/2)";
-        return YCGE_ERR_UNSUPPORTED;
-    }
     int n_dev = 0;
     hipError_t e = hipGetDeviceCount(&n_dev);
     if (e != hipSuccess || n_dev <= 0) {
@@ -434,10 +478,8 @@ int ycge_create(const ycge_config *cfg, ycge_ctx **out)
     c->cfg = *cfg;
     c->device = cfg->device;
     c->fov_deg = cfg->fov_deg;
-    {   // YCGE_PATH=auto|wavefront|megakernel — test/benchmark knob; results are bit-identical on both paths
-        const char *e = getenv("YCGE_PATH");
-        c->path_policy = !e ? 0 : (e[0] == 'w' ? 1 : (e[0] == 'm' ? 2 : 0));
-    }
+    c->parent = parent;
+    c->knobs.read();                // every YCGE_* knob is read here, once
     auto bail = [&](int code) { g_create_error = c->err; ycge_destroy(c); return code; };
     if (hipSetDevice(c->device) != hipSuccess) { c->err = "hipSetDevice failed"; return bail(YCGE_ERR_DEVICE); }
     hipDeviceProp_t prop;
@@ -453,7 +495,7 @@ int ycge_create(const ycge_config *cfg, ycge_ctx **out)
         if (hipEventCreate(&ev) != hipSuccess) { c->err = "hipEventCreate failed"; return bail(YCGE_ERR_DEVICE); }
     {
         if (hipStreamCreateWithFlags(&c->fan_stream, hipStreamNonBlocking) != hipSuccess) { c->err = "hipStreamCreate failed"; return bail(YCGE_ERR_DEVICE); }
-        for (hipEvent_t *ev : {&c->fan_ev[0], &c->fan_ev[1], &c->traced_ev, &c->order_ev})
+        for (hipEvent_t *ev : {&c->fan_ev[0], &c->fan_ev[1], &c->traced_ev, &c->order_ev, &c->pushed_ev})
             if (hipEventCreateWithFlags(ev, hipEventDisableTiming) != hipSuccess) { c->err = "hipEventCreate failed"; return bail(YCGE_ERR_DEVICE); }
         // Query fan-out (k_trace_fan).  On a rank's share of a tiled frame wavefront slots are plentiful and the rank's time is the
         // chain of its heaviest blocks: fan the classes >= 384 iterations (>= 256 from 4 ranks up), up to 2048 blocks (per rank on
@@ -461,10 +503,10 @@ int ycge_create(const ycge_config *cfg, ycge_ctx **out)
         // bulk is short of: only the 200 blocks at the head of the schedule (cost = max over four frames), with both kernels at 4
         // wavefronts per SIMD (0.590 -> 0.569 ms; 400+ blocks or 3 wavefronts per SIMD lose what the shorter chains gain).
         const uint32_t fan_default = c->cfg.world_size >= 4 ? 4u : 5u;
-        c->fan_class = getenv("YCGE_FAN") ? (uint32_t)atoi(getenv("YCGE_FAN")) : fan_default;
+        c->fan_class = c->knobs.fan_class >= 0 ? (uint32_t)c->knobs.fan_class : fan_default;
         if (hipHostMalloc((void **)&c->h_n_fan, sizeof(uint32_t), hipHostMallocDefault) != hipSuccess) { c->err = "hipHostMalloc failed"; return bail(YCGE_ERR_DEVICE); }
         *c->h_n_fan = 0;
-        c->fan_cap = c->fan_class ? (getenv("YCGE_FAN_CAP") ? (uint32_t)atoi(getenv("YCGE_FAN_CAP")) : c->cfg.world_size >= 2 ? YCGE_FAN_CAP_DEFAULT : 200u) : 0u;
+        c->fan_cap = c->fan_class ? (c->knobs.fan_cap >= 0 ? (uint32_t)c->knobs.fan_cap : c->cfg.world_size >= 2 ? YCGE_FAN_CAP_DEFAULT : 200u) : 0u;
     }
     int rc = set_geometry(c, cfg->fb_width, cfg->fb_height, cfg->super_sample);
     if (rc != YCGE_OK) return bail(rc);
@@ -472,9 +514,64 @@ int ycge_create(const ycge_config *cfg, ycge_ctx **out)
     return YCGE_OK;
 }
 
+int ycge_create(const ycge_config *cfg, ycge_ctx **out)
+{
+    if (!cfg || !out) { g_create_error = "null argument"; return YCGE_ERR_INVALID_ARG; }
+    *out = nullptr;
+    if (cfg->abi_version != YCGE_ABI_VERSION) { g_create_error = "abi_version mismatch"; return YCGE_ERR_INVALID_ARG; }
+    if (cfg->world_size < 1 || cfg->rank < 0 || cfg->rank >= cfg->world_size) { g_create_error = "bad rank/world_size"; return YCGE_ERR_INVALID_ARG; }
+    // the kernels implement the reference's compile-time constants (RaytraceRenderer.cs:31-36): in particular the path stack is
+    // sized for MaxMirrorBounces = 2 (at most 3 live items), so any other value is refused here instead of dropping items
+    if (cfg->diffuse_bounces != 1 || cfg->max_mirror_bounces != 2 || cfg->max_refractions != 2 || cfg->taa_clamp_radius < 0) {
+        g_create_error = "DiffuseBounces/MaxMirrorBounces/MaxRefractions are compile-time constants in the reference (1/2/2)";
+        return YCGE_ERR_UNSUPPORTED;
+    }
+    if (cfg->n_devices < 0 || cfg->n_devices > YCGE_MAX_DEVICES) { g_create_error = "n_devices out of range"; return YCGE_ERR_INVALID_ARG; }
+    if (cfg->n_devices <= 1) {
+        ycge_config one = *cfg;
+        if (cfg->n_devices == 1) one.device = cfg->devices[0];
+        one.n_devices = 0;
+        return create_one(&one, nullptr, out);
+    }
+    // ---- one process, n_devices GPUs: this context is rank 0 on devices[0]; ranks 1.. live in peer contexts it owns
+    if (cfg->world_size != 1 || cfg->rank != 0) { g_create_error = "n_devices > 1 excludes rank/world_size (that is the one-process-per-GPU form)"; return YCGE_ERR_INVALID_ARG; }
+    ycge_config base = *cfg;
+    base.world_size = cfg->n_devices; base.n_devices = 0;
+    base.rank = 0; base.device = cfg->devices[0];
+    ycge_ctx *root = nullptr;
+    int rc = create_one(&base, nullptr, &root);
+    if (rc != YCGE_OK) return rc;
+    root->cfg.n_devices = cfg->n_devices;
+    for (int r = 1; r < cfg->n_devices; r++) {
+        ycge_config pc = base;
+        pc.rank = r; pc.device = cfg->devices[r];
+        ycge_ctx *peer = nullptr;
+        rc = create_one(&pc, root, &peer);
+        if (rc != YCGE_OK) { ycge_destroy(root); return rc; }
+        root->peers.push_back(peer);
+        if (peer->device != root->device) {        // the peer's kernels write into the root's frame buffers over xGMI
+            int can = 0;
+            if (hipDeviceCanAccessPeer(&can, peer->device, root->device) != hipSuccess || !can) {
+                g_create_error = "devices cannot access each other's memory (no xGMI / PCIe peer path)";
+                ycge_destroy(root);
+                return YCGE_ERR_DEVICE;
+            }
+            (void)hipSetDevice(peer->device);
+            const hipError_t pe = hipDeviceEnablePeerAccess(root->device, 0);
+            if (pe != hipSuccess && pe != hipErrorPeerAccessAlreadyEnabled) { g_create_error = "hipDeviceEnablePeerAccess failed"; ycge_destroy(root); return YCGE_ERR_DEVICE; }
+            (void)hipGetLastError();
+        }
+    }
+    (void)hipSetDevice(root->device);
+    *out = root;
+    return YCGE_OK;
+}
+
 void ycge_destroy(ycge_ctx *c)
 {
     if (!c) return;
+    for (ycge_ctx *p : c->peers) ycge_destroy(p);
+    c->peers.clear();
     (void)hipSetDevice(c->device);
     if (c->fan_stream) (void)hipStreamSynchronize(c->fan_stream);
     if (c->stream) (void)hipStreamSynchronize(c->stream);
@@ -490,7 +587,7 @@ void ycge_destroy(ycge_ctx *c)
     c->d_scene_nodes.release(); c->d_mesh_arena.release(); c->d_scene_leaf.release(); c->d_prims.release();
     c->d_materials.release(); c->d_meshes.release(); c->d_grids.release(); c->d_cells.release(); c->d_lut.release(); c->d_lights.release();
     for (auto &ev : c->ev) if (ev) (void)hipEventDestroy(ev);
-    for (hipEvent_t ev : {c->fan_ev[0], c->fan_ev[1], c->traced_ev, c->order_ev}) if (ev) (void)hipEventDestroy(ev);
+    for (hipEvent_t ev : {c->fan_ev[0], c->fan_ev[1], c->traced_ev, c->order_ev, c->pushed_ev}) if (ev) (void)hipEventDestroy(ev);
     if (c->fan_stream) (void)hipStreamDestroy(c->fan_stream);
     if (c->h_n_fan) (void)hipHostFree(c->h_n_fan);
     if (c->stream) (void)hipStreamDestroy(c->stream);
@@ -523,11 +620,74 @@ static int upload_lights(ycge_ctx *c, const ycge_light *lights, int n)
 
 }
 namespace {
-// Scene.Objects -> device object records + scene BVH (BVH ctor, BVH.cs:29-97), uploaded; meshes, grids and
-// materials are the ones of the last full upload.  Shared by ycge_scene_upload and ycge_scene_update_objects.
-int build_and_upload_objects(ycge_ctx *c, const ycge_prim *prims, int n_prims)
+
+// every stream a frame of this context may still be running on
+int quiesce(ycge_ctx *c)
 {
-    std::vector<GPrim> gprims(n_prims);
+    HIP_TRY(c, hipSetDevice(c->device));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    if (c->fan_stream) HIP_TRY(c, hipStreamSynchronize(c->fan_stream));
+    if (c->last_stream && c->last_stream != c->stream) HIP_TRY(c, hipStreamSynchronize(c->last_stream));
+    return YCGE_OK;
+}
+
+// ---- argument checks of ycge_scene_upload (pure host code; also exported as ycge_validate_scene)
+int validate_scene(const ycge_scene *s, std::string &msg)
+{
+    char buf[256];
+    auto bad = [&](int code, const char *fmt, int a = 0, int b = 0, int c2 = 0) { std::snprintf(buf, sizeof buf, fmt, a, b, c2); msg = buf; return code; };
+    if (!s) return bad(YCGE_ERR_INVALID_ARG, "null scene");
+    if (s->n_prims < 0 || s->n_materials < 0 || s->n_lights < 0 || s->n_meshes < 0 || s->n_grids < 0) return bad(YCGE_ERR_INVALID_ARG, "negative count");
+    if ((s->n_prims > 0 && !s->prims) || (s->n_materials > 0 && !s->materials) || (s->n_lights > 0 && !s->lights) || (s->n_meshes > 0 && !s->meshes) ||
+        (s->n_grids > 0 && !s->grids))
+        return bad(YCGE_ERR_INVALID_ARG, "null array with a non-zero count");
+    auto mat_ok = [&](int mi) { return mi >= 0 && mi < s->n_materials; };
+    for (int i = 0; i < s->n_materials; i++) {
+        const int k = s->materials[i].kind;
+        if (k == YCGE_MAT_TEXTURED) return bad(YCGE_ERR_UNSUPPORTED, "material %d: textured materials (Material.DiffuseTexture, RaytraceRenderer.cs:724-735) are outside the path", i);
+        if (k != YCGE_MAT_CONSTANT && k != YCGE_MAT_CHECKER) return bad(YCGE_ERR_UNSUPPORTED, "material %d: unknown kind %d", i, k);
+    }
+    for (int mi = 0; mi < s->n_meshes; mi++) {
+        const ycge_mesh &m = s->meshes[mi];
+        if (m.n_triangles < 0 || (m.n_triangles > 0 && !m.triangles)) return bad(YCGE_ERR_INVALID_ARG, "mesh %d: bad triangle array", mi);
+        if (!m.tri_material && !mat_ok(m.material)) return bad(YCGE_ERR_INVALID_ARG, "mesh %d: material out of range", mi);
+        if (m.tri_material)
+            for (int t = 0; t < m.n_triangles; t++)
+                if (!mat_ok(m.tri_material[t])) return bad(YCGE_ERR_INVALID_ARG, "mesh %d: triangle material out of range", mi);
+    }
+    for (int gi = 0; gi < s->n_grids; gi++) {
+        const ycge_grid &g = s->grids[gi];
+        if (g.nx <= 0 || g.ny <= 0 || g.nz <= 0 || !g.cells) return bad(YCGE_ERR_INVALID_ARG, "grid %d: empty", gi);
+        if ((uint64_t)g.nx * g.ny * g.nz >= (1u << 30)) return bad(YCGE_ERR_UNSUPPORTED, "grid %d: more than 2^30 cells", gi);
+        if (g.n_lookup < 0 || (g.n_lookup > 0 && !g.lookup)) return bad(YCGE_ERR_INVALID_ARG, "grid %d: bad lookup table", gi);
+        for (int k = 0; k < g.n_lookup; k++)
+            if (!mat_ok(g.lookup[k].material)) return bad(YCGE_ERR_INVALID_ARG, "grid %d: lookup entry %d names a material out of range", gi, k);
+    }
+    for (int i = 0; i < s->n_prims; i++) {
+        const ycge_prim &q = s->prims[i];
+        if (q.type < YCGE_PRIM_SPHERE || q.type > YCGE_PRIM_VOLUME_GRID) return bad(YCGE_ERR_INVALID_ARG, "prim %d: unknown type %d", i, q.type);
+        if (q.type == YCGE_PRIM_MESH) { if (q.ref < 0 || q.ref >= s->n_meshes) return bad(YCGE_ERR_INVALID_ARG, "prim %d: mesh ref out of range", i); }
+        else if (q.type == YCGE_PRIM_VOLUME_GRID) { if (q.ref < 0 || q.ref >= s->n_grids) return bad(YCGE_ERR_INVALID_ARG, "prim %d: grid ref out of range", i); }
+        else if (!mat_ok(q.material)) return bad(YCGE_ERR_INVALID_ARG, "prim %d: material out of range", i);
+    }
+    return YCGE_OK;
+}
+
+// Scene.Objects -> object records + scene BVH (BVH ctor, BVH.cs:29-97), built on the host ONCE per update (rank 0's context
+// keeps the metadata of the last full upload: mesh root boxes, grid bounds, material count) and installed on every device.
+struct ObjectsHost {
+    std::vector<GPrim> gprims;
+    std::vector<GNode> scene_nodes;
+    std::vector<uint32_t> leaf_prims;
+    uint32_t scene_root = YCGE_REF_NONE_VALUE;
+    float root_min[3] = {0, 0, 0}, root_max[3] = {0, 0, 0};
+    int wf_rounds = 2, spill_levels = 0;
+};
+
+int build_objects(ycge_ctx *c, const ycge_prim *prims, int n_prims, ObjectsHost &oh)
+{
+    std::vector<GPrim> &gprims = oh.gprims;
+    gprims.assign(n_prims, GPrim{});
     BoundsSoA items;
     items.resize(n_prims);
     for (int i = 0; i < n_prims; i++) {
@@ -592,31 +752,73 @@ int build_and_upload_objects(ycge_ctx *c, const ycge_prim *prims, int n_prims)
         const bool overrides = ty == YCGE_PRIM_PLANE || ty == YCGE_PRIM_DISK || ty == YCGE_PRIM_XYRECT || ty == YCGE_PRIM_XZRECT || ty == YCGE_PRIM_YZRECT || ty == YCGE_PRIM_BOX;
         if (overrides && prims[i].reflectivity >= c->cfg.mirror_threshold) can_mirror = true;
     }
-    c->wf_rounds = can_mirror ? 2 + c->cfg.max_mirror_bounces : 2;
+    oh.wf_rounds = can_mirror ? 2 + c->cfg.max_mirror_bounces : 2;
     build_tree(items, TreeFlavour::Scene, c->scene_tree);
     if (c->scene_tree.max_depth > 128) return c->fail(YCGE_ERR_STACK_DEPTH, "scene BVH depth %d exceeds the reference's 128-entry stack (BVH.cs:118)", c->scene_tree.max_depth);
     if (c->scene_tree.max_depth + 4 + c->max_mesh_depth + 2 > YCGE_TRAVERSAL_STACK)
         return c->fail(YCGE_ERR_STACK_DEPTH, "combined traversal depth %d + %d exceeds the device stack", c->scene_tree.max_depth, c->max_mesh_depth);
-    {   // levels the per-lane stack can need beyond its LDS part: scene depth + 4 leaf objects + deepest mesh
-        const int need = c->scene_tree.max_depth + 4 + c->max_mesh_depth + 2 - 12;
-        const int levels = need > 0 ? need : 0;
-        if (levels != c->spill_levels) {
-            c->spill_levels = levels;
-            int rc2 = alloc_tile_buffers(c);
-            if (rc2 != YCGE_OK) return rc2;
-        }
-    }
-    std::vector<GNode> scene_nodes;
-    const uint32_t scene_root = to_gpu_nodes(c->scene_tree, REF_SCENE_NODE, REF_SCENE_LEAF, 0, 0, 3, scene_nodes);
-    std::vector<uint32_t> leaf_prims(c->scene_tree.leaf_index.begin(), c->scene_tree.leaf_index.end());
+    // levels the per-lane stack can need beyond its LDS part: scene depth + 4 leaf objects + deepest mesh
+    const int need = c->scene_tree.max_depth + 4 + c->max_mesh_depth + 2 - YCGE_LDS_STACK_LEVELS;
+    oh.spill_levels = need > 0 ? need : 0;
+    oh.scene_root = to_gpu_nodes(c->scene_tree, REF_SCENE_NODE, REF_SCENE_LEAF, 0, 0, 3, oh.scene_nodes);
+    oh.leaf_prims.assign(c->scene_tree.leaf_index.begin(), c->scene_tree.leaf_index.end());
+    if (c->scene_tree.root >= 0)
+        for (int a = 0; a < 3; a++) { oh.root_min[a] = c->scene_tree.nodes[c->scene_tree.root].mn[a]; oh.root_max[a] = c->scene_tree.nodes[c->scene_tree.root].mx[a]; }
+    return YCGE_OK;
+}
 
-    HIP_TRY(c, c->d_prims.upload(gprims)); HIP_TRY(c, c->d_scene_nodes.upload(scene_nodes)); HIP_TRY(c, c->d_scene_leaf.upload(leaf_prims));
+int install_objects(ycge_ctx *c, const ObjectsHost &oh)
+{
+    HIP_TRY(c, hipSetDevice(c->device));
+    c->wf_rounds = oh.wf_rounds;
+    if (oh.spill_levels != c->spill_levels) {
+        c->spill_levels = oh.spill_levels;
+        const int rc2 = alloc_tile_buffers(c);
+        if (rc2 != YCGE_OK) return rc2;
+    }
+    HIP_TRY(c, c->d_prims.upload(oh.gprims)); HIP_TRY(c, c->d_scene_nodes.upload(oh.scene_nodes)); HIP_TRY(c, c->d_scene_leaf.upload(oh.leaf_prims));
     SceneDev &sd = c->sd;
     sd.scene_nodes = c->d_scene_nodes.p; sd.scene_leaf_prims = c->d_scene_leaf.p; sd.prims = c->d_prims.p;
-    sd.scene_root_ref = scene_root;
-    for (int a = 0; a < 3; a++) { sd.scene_root_min[a] = sd.scene_root_max[a] = 0.0f; }
-    if (c->scene_tree.root >= 0)
-        for (int a = 0; a < 3; a++) { sd.scene_root_min[a] = c->scene_tree.nodes[c->scene_tree.root].mn[a]; sd.scene_root_max[a] = c->scene_tree.nodes[c->scene_tree.root].mx[a]; }
+    sd.scene_root_ref = oh.scene_root;
+    for (int a = 0; a < 3; a++) { sd.scene_root_min[a] = oh.root_min[a]; sd.scene_root_max[a] = oh.root_max[a]; }
+    c->block_order_valid = false;
+    return YCGE_OK;
+}
+
+// the arrays of a full upload, built once and installed on every device
+struct SceneArrays {
+    std::vector<GMaterial> mats;
+    std::vector<uint8_t> arena, cells;
+    std::vector<GMesh> gmeshes;
+    std::vector<GGrid> ggrids;
+    std::vector<int32_t> lut;
+    bool any_transparent = false, has_grid = false;
+};
+
+int install_scene(ycge_ctx *c, const SceneArrays &A, const ObjectsHost &oh, const ycge_scene *s)
+{
+    HIP_TRY(c, hipSetDevice(c->device));
+    c->have_scene = false;
+    HIP_TRY(c, c->d_materials.upload(A.mats)); HIP_TRY(c, c->d_mesh_arena.upload(A.arena));
+    HIP_TRY(c, c->d_meshes.upload(A.gmeshes)); HIP_TRY(c, c->d_grids.upload(A.ggrids)); HIP_TRY(c, c->d_cells.upload(A.cells));
+    HIP_TRY(c, c->d_lut.upload(A.lut));
+    SceneDev &sd = c->sd;
+    std::memset(&sd, 0, sizeof sd);
+    sd.mesh_arena = c->d_mesh_arena.p;
+    sd.materials = c->d_materials.p; sd.meshes = c->d_meshes.p; sd.grids = c->d_grids.p;
+    sd.grid_cells = c->d_cells.p; sd.grid_lut = c->d_lut.p;
+    c->has_grid = A.has_grid;
+    int rc = install_objects(c, oh);
+    if (rc != YCGE_OK) return rc;
+    sd.ambient[0] = s->ambient_color.x; sd.ambient[1] = s->ambient_color.y; sd.ambient[2] = s->ambient_color.z;
+    sd.ambient_intensity = s->ambient_intensity;
+    sd.bg_top[0] = s->background_top.x; sd.bg_top[1] = s->background_top.y; sd.bg_top[2] = s->background_top.z;
+    sd.bg_bottom[0] = s->background_bottom.x; sd.bg_bottom[1] = s->background_bottom.y; sd.bg_bottom[2] = s->background_bottom.z;
+    sd.is_volume_scene = s->is_volume_scene ? 1 : 0;
+    sd.any_transparent = A.any_transparent ? 1 : 0;
+    rc = upload_lights(c, s->lights, s->n_lights);
+    if (rc != YCGE_OK) return rc;
+    c->have_scene = true;
     c->block_order_valid = false;
     return YCGE_OK;
 }
@@ -669,23 +871,37 @@ static uint32_t emit_mesh_records(const BuiltTree &t, const float *tris9, const 
     return emit(t.root);
 }
 
+
+int ycge_validate_scene(const ycge_scene *scene, char *msg, size_t msg_bytes)
+{
+    std::string m;
+    const int rc = validate_scene(scene, m);
+    if (msg && msg_bytes) { std::strncpy(msg, m.c_str(), msg_bytes - 1); msg[msg_bytes - 1] = 0; }
+    return rc;
+}
+
 int ycge_scene_upload(ycge_ctx *c, const ycge_scene *s)
 {
     if (!c) return YCGE_ERR_INVALID_ARG;
-    if (!s) return c->fail(YCGE_ERR_INVALID_ARG, "null scene");
-    if (s->n_prims < 0 || s->n_materials < 0 || s->n_lights < 0 || s->n_meshes < 0 || s->n_grids < 0)
-        return c->fail(YCGE_ERR_INVALID_ARG, "negative count");
+    if (c->parent) return c->fail(YCGE_ERR_INVALID_ARG, "peer contexts are driven by their root");
+    {
+        std::string m;
+        const int vrc = validate_scene(s, m);
+        if (vrc != YCGE_OK) return c->fail(vrc, "%s", m.c_str());
+    }
+    int qrc = quiesce(c);
+    for (ycge_ctx *p : c->peers) if (qrc == YCGE_OK) qrc = quiesce(p);
+    if (qrc != YCGE_OK) return qrc;
     HIP_TRY(c, hipSetDevice(c->device));
     c->have_scene = false;
+    SceneArrays A;
 
     // ---- materials
-    std::vector<GMaterial> mats(s->n_materials);
-    bool any_transparent = false;
+    A.mats.assign(s->n_materials, GMaterial{});
     for (int i = 0; i < s->n_materials; i++) {
         const ycge_material &m = s->materials[i];
-        GMaterial &g = mats[i];
+        GMaterial &g = A.mats[i];
         std::memset(&g, 0, sizeof g);
-        if (m.kind != YCGE_MAT_CONSTANT && m.kind != YCGE_MAT_CHECKER) return c->fail(YCGE_ERR_UNSUPPORTED, "material %d: unknown kind %d", i, m.kind);
         g.kind = m.kind;
         g.albedo[0] = m.albedo.x; g.albedo[1] = m.albedo.y; g.albedo[2] = m.albedo.z;
         g.albedo_b[0] = m.albedo_b.x; g.albedo_b[1] = m.albedo_b.y; g.albedo_b[2] = m.albedo_b.z;
@@ -694,19 +910,18 @@ int ycge_scene_upload(ycge_ctx *c, const ycge_scene *s)
         g.emission[0] = m.emission.x; g.emission[1] = m.emission.y; g.emission[2] = m.emission.z;
         g.transparency = m.transparency; g.ior = m.index_of_refraction;
         g.trans_color[0] = m.transmission_color.x; g.trans_color[1] = m.transmission_color.y; g.trans_color[2] = m.transmission_color.z;
-        if (m.transparency > 0.0f) any_transparent = true;
+        if (m.transparency > 0.0f) A.any_transparent = true;
     }
     auto mat_ok = [&](int mi) { return mi >= 0 && mi < s->n_materials; };
 
     // ---- meshes: MeshBVH ctor (MeshBVH.cs:41-130) -> paired nodes + leaf-ordered triangles
     c->meshes.assign(s->n_meshes, MeshHost{});
-    std::vector<uint8_t> arena;         // GNode (64 B) and GTriPair (96 B) records of every mesh, addressed in 32-byte units
-    std::vector<GMesh> gmeshes(s->n_meshes);
+    std::vector<uint8_t> &arena = A.arena;         // GNode (64 B) and GTriPair (96 B) records of every mesh, addressed in 32-byte units
+    std::vector<GMesh> &gmeshes = A.gmeshes;
+    gmeshes.assign(s->n_meshes, GMesh{});
     int max_mesh_depth = 0;
     for (int mi = 0; mi < s->n_meshes; mi++) {
         const ycge_mesh &m = s->meshes[mi];
-        if (m.n_triangles < 0 || (m.n_triangles > 0 && !m.triangles)) return c->fail(YCGE_ERR_INVALID_ARG, "mesh %d: bad triangle array", mi);
-        if (!m.tri_material && !mat_ok(m.material)) return c->fail(YCGE_ERR_INVALID_ARG, "mesh %d: material out of range", mi);
         BoundsSoA items;
         triangle_items(m.triangles, m.n_triangles, items);
         BuiltTree &t = c->meshes[mi].tree;
@@ -724,13 +939,12 @@ int ycge_scene_upload(ycge_ctx *c, const ycge_scene *s)
     }
 
     // ---- voxel grids: VolumeGrid ctor (VolumeGrid.cs:55-93), one byte per voxel = index into a per-grid material table
-    std::vector<GGrid> ggrids(s->n_grids);
-    std::vector<uint8_t> cells;
-    std::vector<int32_t> lut;
+    std::vector<GGrid> &ggrids = A.ggrids;
+    ggrids.assign(s->n_grids, GGrid{});
+    std::vector<uint8_t> &cells = A.cells;
+    std::vector<int32_t> &lut = A.lut;
     for (int gi = 0; gi < s->n_grids; gi++) {
         const ycge_grid &g = s->grids[gi];
-        if (g.nx <= 0 || g.ny <= 0 || g.nz <= 0 || !g.cells) return c->fail(YCGE_ERR_INVALID_ARG, "grid %d: empty", gi);
-        if ((uint64_t)g.nx * g.ny * g.nz >= (1u << 30)) return c->fail(YCGE_ERR_UNSUPPORTED, "grid %d: more than 2^30 cells", gi);
         GGrid &G = ggrids[gi];
         std::memset(&G, 0, sizeof G);
         G.nx = g.nx; G.ny = g.ny; G.nz = g.nz;
@@ -792,32 +1006,20 @@ int ycge_scene_upload(ycge_ctx *c, const ycge_scene *s)
         c->grid_bounds[gi] = {{g.min_corner.x, g.min_corner.y, g.min_corner.z, g.min_corner.x + (float)g.nx * vs[0],
                                g.min_corner.y + (float)g.ny * vs[1], g.min_corner.z + (float)g.nz * vs[2]}};
     }
-    c->has_grid = s->n_grids > 0;
+    A.has_grid = s->n_grids > 0;
 
-    // ---- upload
-    HIP_TRY(c, c->d_materials.upload(mats)); HIP_TRY(c, c->d_mesh_arena.upload(arena));
-    HIP_TRY(c, c->d_meshes.upload(gmeshes)); HIP_TRY(c, c->d_grids.upload(ggrids)); HIP_TRY(c, c->d_cells.upload(cells));
-    HIP_TRY(c, c->d_lut.upload(lut));
-    SceneDev &sd = c->sd;
-    std::memset(&sd, 0, sizeof sd);
-    sd.mesh_arena = c->d_mesh_arena.p;
-    sd.materials = c->d_materials.p; sd.meshes = c->d_meshes.p; sd.grids = c->d_grids.p;
-    sd.grid_cells = c->d_cells.p; sd.grid_lut = c->d_lut.p;
-    {
-        const int rc_obj = build_and_upload_objects(c, s->prims, s->n_prims);
-        if (rc_obj != YCGE_OK) return rc_obj;
-    }
-    sd.ambient[0] = s->ambient_color.x; sd.ambient[1] = s->ambient_color.y; sd.ambient[2] = s->ambient_color.z;
-    sd.ambient_intensity = s->ambient_intensity;
-    sd.bg_top[0] = s->background_top.x; sd.bg_top[1] = s->background_top.y; sd.bg_top[2] = s->background_top.z;
-    sd.bg_bottom[0] = s->background_bottom.x; sd.bg_bottom[1] = s->background_bottom.y; sd.bg_bottom[2] = s->background_bottom.z;
-    sd.is_volume_scene = s->is_volume_scene ? 1 : 0;
-    sd.any_transparent = any_transparent ? 1 : 0;
-    int rc = upload_lights(c, s->lights, s->n_lights);
+    // ---- Scene.Objects + scene BVH, then every device gets the same arrays
+    ObjectsHost oh;
+    int rc = build_objects(c, s->prims, s->n_prims, oh);
     if (rc != YCGE_OK) return rc;
-    c->have_scene = true;
-    c->block_order_valid = false;
-    return YCGE_OK;
+    rc = install_scene(c, A, oh, s);
+    for (ycge_ctx *p : c->peers) {
+        if (rc != YCGE_OK) break;
+        rc = install_scene(p, A, oh, s);
+        if (rc != YCGE_OK) c->err = p->err;
+    }
+    (void)hipSetDevice(c->device);
+    return rc;
 }
 
 int ycge_scene_update_lights(ycge_ctx *c, const ycge_light *lights, int32_t n_lights, const ycge_vec3 *ambient_color,
@@ -826,14 +1028,19 @@ int ycge_scene_update_lights(ycge_ctx *c, const ycge_light *lights, int32_t n_li
     if (!c) return YCGE_ERR_INVALID_ARG;
     if (!c->have_scene) return c->fail(YCGE_ERR_NO_SCENE, "no scene uploaded");
     if (n_lights < 0 || (n_lights > 0 && !lights)) return c->fail(YCGE_ERR_INVALID_ARG, "bad light array");
-    HIP_TRY(c, hipSetDevice(c->device));
-    HIP_TRY(c, hipStreamSynchronize(c->stream));
-    int rc = upload_lights(c, lights, n_lights);
+    int rc = quiesce(c);
+    if (rc != YCGE_OK) return rc;
+    rc = upload_lights(c, lights, n_lights);
     if (rc != YCGE_OK) return rc;
     if (ambient_color) { c->sd.ambient[0] = ambient_color->x; c->sd.ambient[1] = ambient_color->y; c->sd.ambient[2] = ambient_color->z; c->sd.ambient_intensity = ambient_intensity; }
     if (top) { c->sd.bg_top[0] = top->x; c->sd.bg_top[1] = top->y; c->sd.bg_top[2] = top->z; }
     if (bottom) { c->sd.bg_bottom[0] = bottom->x; c->sd.bg_bottom[1] = bottom->y; c->sd.bg_bottom[2] = bottom->z; }
-    return YCGE_OK;
+    for (ycge_ctx *p : c->peers) {
+        rc = ycge_scene_update_lights(p, lights, n_lights, ambient_color, ambient_intensity, top, bottom);
+        if (rc != YCGE_OK) { c->err = p->err; break; }
+    }
+    (void)hipSetDevice(c->device);
+    return rc;
 }
 
 // Scene.Update -> RebuildBVH when an entity moved (Scenes/Scene.cs:122-127, e.g. BobbingSphereEntity,
@@ -842,12 +1049,23 @@ int ycge_scene_update_lights(ycge_ctx *c, const ycge_light *lights, int32_t n_li
 int ycge_scene_update_objects(ycge_ctx *c, const ycge_prim *prims, int32_t n_prims)
 {
     if (!c) return YCGE_ERR_INVALID_ARG;
+    if (c->parent) return c->fail(YCGE_ERR_INVALID_ARG, "peer contexts are driven by their root");
     if (!c->have_scene) return c->fail(YCGE_ERR_NO_SCENE, "no scene uploaded");
     if (n_prims < 0 || (n_prims > 0 && !prims)) return c->fail(YCGE_ERR_INVALID_ARG, "bad object array");
-    HIP_TRY(c, hipSetDevice(c->device));
-    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    ObjectsHost oh;
+    int rc = build_objects(c, prims, n_prims, oh);        // host work first: the devices keep rendering the old objects meanwhile
+    if (rc != YCGE_OK) return rc;
+    rc = quiesce(c);
+    for (ycge_ctx *p : c->peers) if (rc == YCGE_OK) rc = quiesce(p);
+    if (rc != YCGE_OK) return rc;
     c->have_scene = false;
-    const int rc = build_and_upload_objects(c, prims, n_prims);
+    rc = install_objects(c, oh);
+    for (ycge_ctx *p : c->peers) {
+        if (rc != YCGE_OK) break;
+        rc = install_objects(p, oh);
+        if (rc != YCGE_OK) c->err = p->err;
+    }
+    (void)hipSetDevice(c->device);
     if (rc != YCGE_OK) return rc;
     c->have_scene = true;
     return YCGE_OK;
@@ -856,9 +1074,16 @@ int ycge_scene_update_objects(ycge_ctx *c, const ycge_prim *prims, int32_t n_pri
 int ycge_resize(ycge_ctx *c, int32_t fbw, int32_t fbh, int32_t ss)
 {
     if (!c) return YCGE_ERR_INVALID_ARG;
-    HIP_TRY(c, hipSetDevice(c->device));
-    HIP_TRY(c, hipStreamSynchronize(c->stream));
-    return set_geometry(c, fbw, fbh, ss);
+    int rc = quiesce(c);
+    if (rc != YCGE_OK) return rc;
+    rc = set_geometry(c, fbw, fbh, ss);
+    for (ycge_ctx *p : c->peers) {
+        if (rc != YCGE_OK) break;
+        rc = ycge_resize(p, fbw, fbh, ss);
+        if (rc != YCGE_OK) c->err = p->err;
+    }
+    (void)hipSetDevice(c->device);
+    return rc;
 }
 
 int ycge_set_camera(ycge_ctx *c, const float pos[3], float yaw, float pitch, float fov_deg)
@@ -874,6 +1099,7 @@ int ycge_set_camera(ycge_ctx *c, const float pos[3], float yaw, float pitch, flo
 int ycge_set_frame_counter(ycge_ctx *c, int64_t fc)
 {
     if (!c) return YCGE_ERR_INVALID_ARG;
+    if (fc < 0 || fc == INT64_MAX) return c->fail(YCGE_ERR_INVALID_ARG, "frame counter must be in [0, 2^63 - 2] (the reference's counter starts at 0 and only grows, RaytraceRenderer.cs:24,175)");
     c->frame_counter = fc;
     return YCGE_OK;
 }
@@ -889,23 +1115,25 @@ int ycge_tile_slab_bytes(const ycge_ctx *c, size_t *bytes)
 
 namespace {
 
-struct FrameState {
-    float pos[3], yaw, pitch, fov;
-    bool reset;
-    int64_t frame;
-};
-
-// steps 1-4 of TryFlipAndBlit (RaytraceRenderer.cs:159-216): snapshot, frame++, ray-gen + trace
-int begin_and_trace(ycge_ctx *c, float *d_slab, hipStream_t stream, FrameState &fs, bool timed)
+// steps 1-3 of TryFlipAndBlit (RaytraceRenderer.cs:159-176): camera snapshot under the lock, frame = ++frameCounter.
+// The reset decision (step 2) compares this pose with the camera the LAST RESOLVED frame committed, so it is taken where
+// the frame is resolved (taa_and_commit) - in a pipelined caller the previous frame may not have been resolved yet.
+void snapshot_frame(ycge_ctx *c, FrameState &fs)
 {
-    if (!c->have_scene) return c->fail(YCGE_ERR_NO_SCENE, "Scene BVH not built; call ycge_scene_upload first (Scene.cs:73)");
     {
         std::lock_guard<std::mutex> g(c->cam_lock);
         fs.pos[0] = c->cam_pos[0]; fs.pos[1] = c->cam_pos[1]; fs.pos[2] = c->cam_pos[2];
         fs.yaw = c->yaw; fs.pitch = c->pitch; fs.fov = c->fov_deg;
     }
-    fs.reset = should_reset_history(c, fs.pos, fs.yaw, fs.pitch);
+    fs.reset = false;
     fs.frame = ++c->frame_counter;
+    fs.fan_blocks = 0;
+}
+
+// step 4 (RaytraceRenderer.cs:183-216): ray-gen + trace of this context's tiles for the frame `fs`
+int trace_frame(ycge_ctx *c, float *d_slab, hipStream_t stream, FrameState &fs, bool timed)
+{
+    if (!c->have_scene) return c->fail(YCGE_ERR_NO_SCENE, "Scene BVH not built; call ycge_scene_upload first (Scene.cs:73)");
     FrameParams P;
     fill_frame_params(c, P, fs.frame, fs.pos, fs.yaw, fs.pitch, fs.fov);
     TraceOut O;
@@ -922,7 +1150,7 @@ int begin_and_trace(ycge_ctx *c, float *d_slab, hipStream_t stream, FrameState &
     }
     const bool debug = c->cfg.capture_debug && !slab;
     if (debug) { O.rays = c->dbg_rays.p; O.prim_id = c->dbg_prim.p; O.sub_id = c->dbg_sub.p; O.hit_t = c->dbg_hit_t.p; O.rng_state = c->dbg_rng.p; }
-    if (getenv("YCGE_WAVE_PROF")) { if (!c->wave_prof.p) HIP_TRY(c, c->wave_prof.alloc((size_t)c->n_tiles * 16)); O.wave_prof = c->wave_prof.p; { const char ch = getenv("YCGE_WAVE_PROF")[0]; O.wave_prof_stage = ch == 'e' ? 1 : ch == 'm' ? 2 : 0; } }
+    if (c->knobs.wave_prof_stage >= 0) { if (!c->wave_prof.p) HIP_TRY(c, c->wave_prof.alloc((size_t)c->n_tiles * 16)); O.wave_prof = c->wave_prof.p; O.wave_prof_stage = c->knobs.wave_prof_stage; }
     if (c->cfg.count_work) {
         O.counters = c->counters.p;
         HIP_TRY(c, hipMemsetAsync(c->counters.p, 0, 8 * sizeof(unsigned long long), stream));
@@ -933,30 +1161,31 @@ int begin_and_trace(ycge_ctx *c, float *d_slab, hipStream_t stream, FrameState &
     const uint32_t trace_lanes = (uint32_t)(c->n_owned > 0 ? c->n_owned : 1) * 256u * YCGE_SCHEDULE_SLACK;
     O.stack_lanes = trace_lanes + c->fan_cap * 192u;
     O.path_stack = c->path_stack.p;
-    const int flat = (YCGE_REF_KIND(c->sd.scene_root_ref) == REF_SCENE_LEAF && !getenv("YCGE_GENERIC_WALK")) ? 1 : 0;      // YCGE_GENERIC_WALK: experiment knob, same pixels
+    const int flat = (YCGE_REF_KIND(c->sd.scene_root_ref) == REF_SCENE_LEAF && !c->knobs.generic_walk) ? 1 : 0;      // YCGE_GENERIC_WALK: experiment knob, same pixels
     // Path choice.  Refraction splits need TraceFull's per-pixel LIFO -> single launch.  Otherwise: scenes
     // that are one BVH leaf (mesh viewers) are bounded by the latency chain of their few heaviest tiles, and
     // one launch lets the chains of all stages overlap (measured 0.85 vs 1.24 ms on config 4); scenes with a
     // real top-level tree (voxel worlds) are throughput-bound and run 1.7x faster as occupancy-friendly stages.
-    const bool single_launch = c->sd.any_transparent || c->path_policy == 2 || (c->path_policy == 0 && flat);
+    const bool single_launch = c->sd.any_transparent || c->knobs.path_policy == 2 || (c->knobs.path_policy == 0 && flat);
     if (single_launch) {
         // TraceFull's per-pixel LIFO is only ever touched at a refractive hit: scenes without transparent materials get none (0.5 GB at 1080p)
         if (!c->path_stack.p && c->sd.any_transparent) HIP_TRY(c, c->path_stack.alloc((size_t)3 * 11 * O.stack_lanes));
         O.path_stack = c->path_stack.p;
-        const bool lpt = !getenv("YCGE_NO_LPT");
+        const bool lpt = !c->knobs.no_lpt;
         const uint32_t n_blocks = (uint32_t)c->n_owned * 4u;
-        const uint32_t cost_slot = (uint32_t)(c->frame_counter % YCGE_COST_FRAMES);       // this frame's array of the cost ring
+        const uint32_t cost_slot = (uint32_t)((uint64_t)fs.frame % YCGE_COST_FRAMES);       // this frame's array of the cost ring
         O.block_cost = lpt ? c->block_cost.p + (size_t)cost_slot * n_blocks : nullptr;
         if (c->order_pending) { HIP_TRY(c, hipStreamWaitEvent(stream, c->order_ev, 0)); c->order_pending = false; }     // the schedule built beside the last frame's TAA
         O.block_order = (lpt && c->block_order_valid) ? c->block_order.p : nullptr;
         O.n_order = c->order_ws.p + 16;
         // the schedule's head (the heaviest blocks of the previous frame) goes to k_trace_fan, launched first and beside k_trace
-        const int refill_steps = getenv("YCGE_REFILL") ? atoi(getenv("YCGE_REFILL")) : YCGE_REFILL_STEPS_DEFAULT;   // k_trace_refill: steps between refills (0 = k_trace)
+        const int refill_steps = c->knobs.refill_steps;   // k_trace_refill: steps between refills (0 = k_trace)
         // a schedule without fanned blocks (analytic scenes, small frames) skips k_trace_fan and the side stream altogether: the count
         // comes back through pinned memory and is a frame or two old when read here - either answer traces every block exactly once,
         // because k_trace is told (n_fan pointer or null) which convention this frame uses
         const bool fan = O.block_order != nullptr && c->fan_cap > 0 && !(flat && refill_steps > 0) && c->h_n_fan && *(volatile uint32_t *)c->h_n_fan > 0;
         if (fan) {
+            fs.fan_blocks = *(volatile uint32_t *)c->h_n_fan;      // what the last finished schedule handed to k_trace_fan (this frame's may differ by a few)
             // k_trace_fan goes FIRST and on the frame's stream, so that its blocks - the frame's longest chains - are resident from
             // t = 0; the rest of the schedule follows on the side stream (forked before, joined after) and fills in around them
             O.n_fan = c->order_ws.p + 18;
@@ -976,7 +1205,7 @@ int begin_and_trace(ycge_ctx *c, float *d_slab, hipStream_t stream, FrameState &
             // DESIGN section 5) except from 8 ranks up, where the classes >= 384 iterations go in 4 parts of 16 pixels: slots are plentiful
             // on an eighth of a frame, thin wavefronts step faster and see a smaller maximum over their lanes (per-rank trace on config 4:
             // 0.393 -> 0.366 ms at 8 ranks; at 4 ranks the same split loses, 0.407 -> 0.461 ms)
-            const uint32_t policy = getenv("YCGE_SPLIT") ? (uint32_t)strtoul(getenv("YCGE_SPLIT"), nullptr, 8) : c->cfg.world_size >= 8 ? 022200000u : 0u;
+            const uint32_t policy = c->knobs.split_set ? c->knobs.split_policy : c->cfg.world_size >= 8 ? 022200000u : 0u;
             // the next frame's schedule needs this frame's trace and nothing else: built on the side stream, beside TAA (or the slab
             // pack and all-gather), instead of 25 us in front of it; the next trace waits for it (order_ev)
             HIP_TRY(c, hipEventRecord(c->traced_ev, stream));
@@ -991,7 +1220,7 @@ int begin_and_trace(ycge_ctx *c, float *d_slab, hipStream_t stream, FrameState &
         const size_t nt = (size_t)(c->n_owned > 0 ? c->n_owned : 1);
         void *bufs[7] = {c->wf_q0.p, c->wf_q1.p, c->wf_hit.p, c->wf_lq.p, c->wf_counts.p, c->wf_counts.p + 7 * nt, c->wf_seg.p};
         // persistent extend: 32 wavefronts per CU (6 per SIMD resident, the rest queue behind them; measured on the voxel world: 16 per CU 13.1 ms, 20 12.5, 24 12.2, 32 12.0, 40 12.1), within the stack-spill columns
-        int pw = getenv("YCGE_NO_REFILL") ? 0 : c->compute_units * (getenv("YCGE_PW_PER_CU") ? atoi(getenv("YCGE_PW_PER_CU")) : 32);
+        int pw = c->knobs.no_refill ? 0 : c->compute_units * c->knobs.pw_per_cu;
         if ((size_t)pw * 64 > O.stack_lanes) pw = (int)(O.stack_lanes / 64);
         if ((size_t)pw > nt * 4) pw = (int)(nt * 4);            // never more wavefronts than the round can have rays for
         e = ycge_launch_wavefront(&c->sd, &P, &O, bufs, c->wf_rounds, c->has_grid ? 1 : 0, flat, c->cfg.count_work, pw, stream);
@@ -1006,8 +1235,9 @@ int begin_and_trace(ycge_ctx *c, float *d_slab, hipStream_t stream, FrameState &
 }
 
 // steps 5 and 9: TemporalBlendWithClamp + CommitCamera
-int taa_and_commit(ycge_ctx *c, hipStream_t stream, const FrameState &fs, bool &did_reset, bool timed)
+int taa_and_commit(ycge_ctx *c, hipStream_t stream, FrameState &fs, bool &did_reset, bool timed)
 {
+    fs.reset = should_reset_history(c, fs.pos, fs.yaw, fs.pitch);      // step 2 (:162): this frame's pose against the last committed one
     TaaParams T;
     T.w = c->hiW; T.h = c->hiH;
     T.alpha = cs_max(0.0f, cs_min(1.0f, c->cfg.taa_alpha));      // :305
@@ -1135,7 +1365,7 @@ int run_post(ycge_ctx *c, hipStream_t stream, float *out_sdr_host, bool timed)
                 std::vector<uint32_t> px, off, bpx, boff;
                 build_inplace_schedule(w, h, step, px, off);
                 // bands of whole rows; related pixels are at most 2 * step rows apart, so they share a band or sit in adjacent ones
-                static const int band_rows = getenv("YCGE_POST_BAND_ROWS") ? atoi(getenv("YCGE_POST_BAND_ROWS")) : YCGE_POST_BAND_ROWS_DEFAULT;
+                const int band_rows = c->knobs.post_band_rows;
                 const int rows_per_band = 2 * step > band_rows ? 2 * step : band_rows;
                 band_inplace_schedule(w, h, rows_per_band, px, off, bpx, boff, sc->bands, sc->max_level_pixels);
                 sc->levels = (int)off.size() - 1;
@@ -1143,7 +1373,7 @@ int run_post(ycge_ctx *c, hipStream_t stream, float *out_sdr_host, bool timed)
                 HIP_TRY(c, sc->pixels.upload(bpx)); HIP_TRY(c, sc->offsets.upload(boff));
             }
             // levels per launch: a launch keeps what it writes in a 2048-entry LDS table (k_atrous_band), at most 3/4 full
-            int levels_per_launch = getenv("YCGE_POST_K") ? atoi(getenv("YCGE_POST_K")) : YCGE_POST_K_DEFAULT;
+            int levels_per_launch = c->knobs.post_k;
             const int k_cap = (int)(1536u / (sc->max_level_pixels > 0 ? sc->max_level_pixels : 32u));
             if (levels_per_launch > k_cap) levels_per_launch = k_cap;
             if (levels_per_launch < 1) return c->fail(YCGE_ERR_UNSUPPORTED, "in-place A-trous: a level of %u pixels in one band", sc->max_level_pixels);
@@ -1174,6 +1404,7 @@ int fill_stats(ycge_ctx *c, ycge_frame_stats *st, const FrameState &fs, bool did
     std::memset(st, 0, sizeof *st);
     st->frame = fs.frame;
     st->history_reset = did_reset ? 1 : 0;
+    st->fan_blocks = (int32_t)fs.fan_blocks;
     float ms = 0.0f;
     HIP_TRY(c, hipEventElapsedTime(&ms, c->ev[0], c->ev[1]));
     st->trace_ms = ms;
@@ -1192,14 +1423,53 @@ int fill_stats(ycge_ctx *c, ycge_frame_stats *st, const FrameState &fs, bool did
 
 extern "C" {
 
+// n_devices >= 2: every device traces its tiles of the frame `fs`; the peers then copy theirs into this (rank 0's) frame buffers
+static int trace_on_all_devices(ycge_ctx *c, FrameState &fs)
+{
+    HIP_TRY(c, hipEventRecord(c->ev[0], c->stream));
+    int rc = trace_frame(c, nullptr, c->stream, fs, false);
+    if (rc != YCGE_OK) return rc;
+    for (ycge_ctx *p : c->peers) {
+        if (hipSetDevice(p->device) != hipSuccess) return c->fail(YCGE_ERR_DEVICE, "hipSetDevice(%d) failed", p->device);
+        FrameState pfs = fs;
+        p->frame_counter = fs.frame;
+        rc = trace_frame(p, nullptr, p->stream, pfs, false);
+        if (rc != YCGE_OK) { c->err = p->err; (void)hipSetDevice(c->device); return rc; }
+        fs.fan_blocks += pfs.fan_blocks;
+        PushPlanes L;
+        std::memset(&L, 0, sizeof L);
+        auto plane = [&](const void *src, void *dst, int bpp) { if (src && dst) { L.src[L.n] = (const uint8_t *)src; L.dst[L.n] = (uint8_t *)dst; L.bytes_per_pixel[L.n] = bpp; L.n++; } };
+        plane(p->current_hdr.p, c->current_hdr.p, 12); plane(p->g_albedo.p, c->g_albedo.p, 12); plane(p->g_normal.p, c->g_normal.p, 12);
+        plane(p->g_depth.p, c->g_depth.p, 4); plane(p->sky.p, c->sky.p, 1);
+        if (c->cfg.capture_debug) {
+            plane(p->dbg_rays.p, c->dbg_rays.p, 24); plane(p->dbg_prim.p, c->dbg_prim.p, 4); plane(p->dbg_sub.p, c->dbg_sub.p, 4);
+            plane(p->dbg_hit_t.p, c->dbg_hit_t.p, 4); plane(p->dbg_rng.p, c->dbg_rng.p, 8);
+        }
+        FrameParams P;
+        fill_frame_params(p, P, fs.frame, fs.pos, fs.yaw, fs.pitch, fs.fov);
+        const int e = ycge_launch_push_tiles(&P, &L, p->stream);
+        if (e != 0) { (void)hipSetDevice(c->device); return c->fail(YCGE_ERR_DEVICE, "k_push_tiles launch failed: %s", hipGetErrorString((hipError_t)e)); }
+        if (hipEventRecord(p->pushed_ev, p->stream) != hipSuccess) { (void)hipSetDevice(c->device); return c->fail(YCGE_ERR_DEVICE, "hipEventRecord failed on device %d", p->device); }
+    }
+    HIP_TRY(c, hipSetDevice(c->device));
+    for (ycge_ctx *p : c->peers) HIP_TRY(c, hipStreamWaitEvent(c->stream, p->pushed_ev, 0));
+    HIP_TRY(c, hipEventRecord(c->ev[1], c->stream));        // trace_ms of a multi-device frame: until the last tile has arrived
+    return YCGE_OK;
+}
+
 int ycge_render_frame(ycge_ctx *c, float *out_sdr, ycge_frame_stats *st)
 {
     if (!c) return YCGE_ERR_INVALID_ARG;
-    if (c->cfg.world_size != 1) return c->fail(YCGE_ERR_INVALID_ARG, "ycge_render_frame is the single-GPU entry; with world_size > 1 use ycge_trace_tiles + ycge_resolve_gathered");
+    if (c->parent) return c->fail(YCGE_ERR_INVALID_ARG, "peer contexts are driven by their root");
+    const bool multi_dev = !c->peers.empty();
+    if (c->cfg.world_size != 1 && !multi_dev)
+        return c->fail(YCGE_ERR_INVALID_ARG, "ycge_render_frame is the one-process entry: set config.n_devices / devices[] to drive several GPUs from it, "
+                                             "or use ycge_trace_tiles + ycge_resolve_gathered with one process per GPU (rank / world_size)");
     HIP_TRY(c, hipSetDevice(c->device));
     auto t0 = std::chrono::steady_clock::now();
     FrameState fs;
-    int rc = begin_and_trace(c, nullptr, c->stream, fs, true);
+    snapshot_frame(c, fs);
+    int rc = multi_dev ? trace_on_all_devices(c, fs) : trace_frame(c, nullptr, c->stream, fs, true);
     if (rc != YCGE_OK) return rc;
     bool did_reset = false;
     rc = taa_and_commit(c, c->stream, fs, did_reset, true);
@@ -1211,6 +1481,13 @@ int ycge_render_frame(ycge_ctx *c, float *out_sdr, ycge_frame_stats *st)
     HIP_TRY(c, hipStreamSynchronize(c->stream));
     double wall = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
     rc = fill_stats(c, st, fs, did_reset, true, wall);
+    if (rc == YCGE_OK && st && c->cfg.count_work)
+        for (ycge_ctx *p : c->peers) {          // the counters of the peers' tiles
+            unsigned long long h[8];
+            if (hipSetDevice(p->device) != hipSuccess || hipMemcpy(h, p->counters.p, sizeof h, hipMemcpyDeviceToHost) != hipSuccess) { (void)hipSetDevice(c->device); return c->fail(YCGE_ERR_DEVICE, "counter read-back failed on device %d", p->device); }
+            st->n_rays += h[0]; st->n_box += h[1]; st->n_tri += h[2]; st->n_prim += h[3]; st->n_vox += h[4];
+        }
+    if (multi_dev) HIP_TRY(c, hipSetDevice(c->device));
     if (rc == YCGE_OK && st && out_sdr) {
         float ms = 0.0f;
         HIP_TRY(c, hipEventElapsedTime(&ms, c->ev[2], c->ev[3]));
@@ -1225,14 +1502,19 @@ int ycge_render_frame(ycge_ctx *c, float *out_sdr, ycge_frame_stats *st)
 int ycge_trace_tiles(ycge_ctx *c, void *d_slab, void *hip_stream, ycge_frame_stats *st)
 {
     if (!c) return YCGE_ERR_INVALID_ARG;
+    if (c->parent || !c->peers.empty()) return c->fail(YCGE_ERR_INVALID_ARG, "ycge_trace_tiles is the one-process-per-GPU form; this context drives its devices through ycge_render_frame");
     HIP_TRY(c, hipSetDevice(c->device));
     hipStream_t stream = hip_stream ? (hipStream_t)hip_stream : c->stream;
+    c->last_stream = stream;
     float *slab = d_slab ? (float *)d_slab : c->own_slab.p;
     if (!slab) return c->fail(YCGE_ERR_INVALID_ARG, "no slab: pass a device pointer of ycge_tile_slab_bytes() bytes");
+    if (c->pending.size() >= 8) c->pending.pop_front();       // a traced frame nobody resolved (trace-only callers) is abandoned once 8 newer ones wait
     auto t0 = std::chrono::steady_clock::now();
     FrameState fs;
-    int rc = begin_and_trace(c, slab, stream, fs, st != nullptr);
+    snapshot_frame(c, fs);
+    int rc = trace_frame(c, slab, stream, fs, st != nullptr);
     if (rc != YCGE_OK) return rc;
+    c->pending.push_back(fs);           // the matching ycge_resolve_gathered resolves THIS frame: its pose, its number
     if (st) {
         HIP_TRY(c, hipStreamSynchronize(stream));
         double wall = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
@@ -1245,8 +1527,10 @@ int ycge_resolve_gathered(ycge_ctx *c, const void *d_all_slabs, void *hip_stream
 {
     if (!c) return YCGE_ERR_INVALID_ARG;
     if (!d_all_slabs) return c->fail(YCGE_ERR_INVALID_ARG, "null gathered slabs");
+    if (c->pending.empty()) return c->fail(YCGE_ERR_INVALID_ARG, "no traced frame to resolve: every ycge_resolve_gathered follows its own ycge_trace_tiles");
     HIP_TRY(c, hipSetDevice(c->device));
     hipStream_t stream = hip_stream ? (hipStream_t)hip_stream : c->stream;
+    c->last_stream = stream;
     auto t0 = std::chrono::steady_clock::now();
     if (out_sdr && !c->cfg.slab_albedo) return c->fail(YCGE_ERR_INVALID_ARG, "lean slabs (config.slab_albedo = 0) carry no albedo: the denoise stage cannot run");
     const size_t per_rank = (size_t)c->tiles_per_rank_padded * 256 * slab_floats(c);
@@ -1254,13 +1538,10 @@ int ycge_resolve_gathered(ycge_ctx *c, const void *d_all_slabs, void *hip_stream
     int e = ycge_launch_unpermute((const float *)d_all_slabs, per_rank, c->hiW, c->hiH, c->tiles_x, c->n_tiles, c->cfg.world_size,
                                   (int)slab_floats(c), c->current_hdr.p, c->g_albedo.p, c->g_normal.p, c->g_depth.p, c->sky.p, stream);
     if (e != 0) return c->fail(YCGE_ERR_DEVICE, "k_unpermute launch failed: %s", hipGetErrorString((hipError_t)e));
-    FrameState fs;
-    {
-        std::lock_guard<std::mutex> g(c->cam_lock);
-        fs.pos[0] = c->cam_pos[0]; fs.pos[1] = c->cam_pos[1]; fs.pos[2] = c->cam_pos[2]; fs.yaw = c->yaw; fs.pitch = c->pitch; fs.fov = c->fov_deg;
-    }
-    fs.reset = should_reset_history(c, fs.pos, fs.yaw, fs.pitch);
-    fs.frame = c->frame_counter;
+    // the frame being resolved is the oldest traced one: its snapshot (pose, frame number) - NOT the live camera, which a
+    // pipelined caller may already have moved on for the next trace (RaytraceRenderer.cs:159-176 snapshots once per frame)
+    FrameState fs = c->pending.front();
+    c->pending.pop_front();
     bool did_reset = false;
     int rc = taa_and_commit(c, stream, fs, did_reset, st != nullptr);
     if (rc != YCGE_OK) return rc;

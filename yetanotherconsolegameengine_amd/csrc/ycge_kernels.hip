@@ -1218,6 +1218,25 @@ __global__ __launch_bounds__(256) void k_pack_slab(const FrameParams P, const fl
     s[6] = depth[i]; s[7] = sky[i] ? 1.0f : 0.0f;
 }
 
+// One process, several GPUs: a peer device copies ITS tiles of every listed plane from its own frame buffers straight into rank 0's
+// (peer memory over xGMI; rows of 32 pixels are contiguous in both).  Replaces pack -> all-gather -> un-permute: no staging slabs.
+__global__ __launch_bounds__(256) void k_push_tiles(const FrameParams P, const PushPlanes L)
+{
+    int px, py, lx, ly;
+    const int k = blockIdx.x;
+    if (!tile_pixel(P, k, px, py, lx, ly)) return;
+    const size_t i = (size_t)px + (size_t)py * P.hiW;
+    for (int a = 0; a < L.n; a++) {
+        const int bpp = L.bytes_per_pixel[a];
+        if (bpp == 1) L.dst[a][i] = L.src[a][i];
+        else {
+            const uint32_t *s = (const uint32_t *)L.src[a] + i * (size_t)(bpp >> 2);
+            uint32_t *d = (uint32_t *)L.dst[a] + i * (size_t)(bpp >> 2);
+            for (int w = 0; w < (bpp >> 2); w++) d[w] = s[w];
+        }
+    }
+}
+
 // all_slabs: world_size equal-sized slabs, rank-major, as an all-gather leaves them.
 __global__ __launch_bounds__(256) void k_unpermute(const float *__restrict__ all_slabs, size_t slab_floats_per_rank, int hiW, int hiH,
                                                    int tiles_x, int n_tiles, int world_size, int sf, float *__restrict__ hdr,
@@ -1367,6 +1386,13 @@ int ycge_launch_pack_slab(const ycge::FrameParams *P, const float *hdr, const fl
     if (P->n_owned_tiles <= 0) return 0;
     dim3 grid((unsigned)P->n_owned_tiles), block(256);
     hipLaunchKernelGGL(ycge::k_pack_slab, grid, block, 0, stream, *P, hdr, albedo, normal, depth, sky, slab, slab_floats);
+    return (int)hipGetLastError();
+}
+
+int ycge_launch_push_tiles(const ycge::FrameParams *P, const ycge::PushPlanes *planes, hipStream_t stream)
+{
+    if (P->n_owned_tiles <= 0 || planes->n <= 0) return 0;
+    hipLaunchKernelGGL(ycge::k_push_tiles, dim3((unsigned)P->n_owned_tiles), dim3(256), 0, stream, *P, *planes);
     return (int)hipGetLastError();
 }
 

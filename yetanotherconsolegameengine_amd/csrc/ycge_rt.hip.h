@@ -604,7 +604,7 @@ __device__ __forceinline__ bool is_wire_on_face(const GGrid &g, F3 p, int ix, in
 // [level][global lane] so that a wavefront's accesses coalesce.  No private arrays: scratch-backed
 // kernels are admitted at about one wavefront per SIMD on this part (measured), which costs far more
 // than the spill traffic.
-#define YCGE_LDS_STACK 12
+#define YCGE_LDS_STACK YCGE_LDS_STACK_LEVELS
 #define YCGE_BLOCK 256
 static __shared__ uint2 g_lds_stack[YCGE_LDS_STACK * YCGE_BLOCK];     // 256-thread workgroups (tile = workgroup)
 static __shared__ uint2 g_lds_stack64[YCGE_LDS_STACK * 64];           // 64-thread workgroups (8x8 block = workgroup)

@@ -22,7 +22,7 @@ NODE_DTYPE = np.dtype([("min", "<f4", 3), ("max", "<f4", 3), ("left", "<i4"), ("
 class RaytraceRenderer:
     def __init__(self, scene: Scene | FlatScene, fb_width: int, fb_height: int, fovDeg: float = 45.0, superSample: int = 1, *,
                  cfg: Optional[abi.Config] = None, capture_debug: bool = False, count_work: bool = False, device: int = 0,
-                 rank: int = 0, world_size: int = 1, slab_albedo: bool = True, lib=None):
+                 rank: int = 0, world_size: int = 1, slab_albedo: bool = True, devices=None, lib=None):
         self.L = lib if lib is not None else abi.load_library()
         c = cfg if cfg is not None else abi.default_config()
         c.fb_width, c.fb_height, c.super_sample = fb_width, fb_height, max(1, superSample)
@@ -30,6 +30,10 @@ class RaytraceRenderer:
         c.capture_debug, c.count_work = int(capture_debug), int(count_work)
         c.device, c.rank, c.world_size = device, rank, world_size
         c.slab_albedo = int(slab_albedo)          # tiled frame: lean 8-float slabs when the denoise stage will not run
+        if devices is not None:                   # one process, several GPUs: TryFlipAndBlit drives them all (config.n_devices)
+            c.n_devices = len(devices)
+            for i, d in enumerate(devices):
+                c.devices[i] = int(d)
         self.cfg = c
         self.ctx = C.c_void_p()
         rc = self.L.ycge_create(C.byref(c), C.byref(self.ctx))
