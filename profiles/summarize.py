@@ -53,8 +53,8 @@ for k in acc:
 if json_path:
     import json
     TRACE = ("k_trace", "k_trace_fan", "k_trace_refill", "k_wf_primary", "k_wf_extend", "k_wf_trace_p", "k_wf_shade", "k_wf_lights")
-    def is_trace(k):
-        return k.split("<")[0] in TRACE
+    def is_trace(k):      # the kernels the benchmark times: the NON-counting instances (bench.py's counting replay launches the <true, ...> ones)
+        return k.split("<")[0] in TRACE and ("<" not in k or k.split("<")[1].split(",")[0].strip() in ("false", "false>") or k.split("<")[0] == "k_wf_shade")
     # calibration: bytes a copy of known size moves / what the counters say (copycal under the same two PMC passes)
     cal = {"fetch": 2.0, "write": 1.0, "measured": False}      # the guide's gfx950 note for reads; writes as reported
     cal_bytes = None
@@ -72,10 +72,10 @@ if json_path:
                 if "WRITE_SIZE" in acc[k]: cal["write_4B_lanes"] = cal_bytes / (sum(acc[k]["WRITE_SIZE"]) / len(acc[k]["WRITE_SIZE"]) * 1024.0)
     n_frames = {}
     tot = defaultdict(float)
-    for k in acc:
-        if k.startswith("k_taa"):
-            for c, vs in acc[k].items():
-                n_frames[c] = len(vs)
+    lead = [k for k in acc if is_trace(k) and k.split("<")[0] in ("k_trace", "k_wf_primary")]      # one launch of these per frame
+    for k in lead:
+        for c, vs in acc[k].items():
+            n_frames[c] = max(n_frames.get(c, 0), len(vs))
     for k in acc:
         if is_trace(k):
             for c, vs in acc[k].items():
@@ -108,8 +108,15 @@ if json_path:
         # SQ_ACTIVE_INST_VALU counts quad-cycles summed over the SIMDs; SQ_BUSY_CYCLES is summed over the shader engines' SQs:
         # busy fraction of the VALU pipes while the kernels are resident = 4 * active / (SIMD count * launch cycles); the launch
         # cycles come from GRBM_GUI_ACTIVE when that pass exists
-        if g("GRBM_GUI_ACTIVE"):
-            d["valu_busy"] = round(4.0 * g("SQ_ACTIVE_INST_VALU") / (g("GRBM_GUI_ACTIVE") * 1024.0), 3)
+        # GRBM_GUI_ACTIVE comes back summed over the 8 XCDs; concurrent kernels (k_trace_fan beside k_trace) overlap, so the launch's
+        # span is the lead kernel's; the stage kernels of the wavefront pipeline run one after the other, so theirs add up
+        span = 0.0
+        for k in acc:
+            if is_trace(k) and "GRBM_GUI_ACTIVE" in acc[k] and (k.split("<")[0] != "k_trace_fan"):
+                span += sum(acc[k]["GRBM_GUI_ACTIVE"]) / n_frames["GRBM_GUI_ACTIVE"] / 8.0
+        if span > 0:
+            d["launch_cycles"] = round(span)
+            d["valu_busy"] = round(4.0 * g("SQ_ACTIVE_INST_VALU") / (span * 1024.0), 3)
     if g("TCC_HIT_sum") is not None and g("TCC_MISS_sum") is not None and g("TCC_HIT_sum") + g("TCC_MISS_sum") > 0:
         d["l2_hit_rate"] = round(g("TCC_HIT_sum") / (g("TCC_HIT_sum") + g("TCC_MISS_sum")), 3)
     ev = []

@@ -482,6 +482,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu((HAS_GRID &
                     maxdist = dist - P.eps;
                     q.tmax = maxdist;
                     q.tmin = S.is_volume_scene ? 0.001f : 0.0f + P.eps;
+                    q.anyhit = S.is_volume_scene || !S.any_transparent;              // every occluder is opaque: the first hit answers the query
                     tr_r = tr_g = tr_b = 1.0f; tr_counter = 0;
                     in_query = true;
                     break;
@@ -494,6 +495,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu((HAS_GRID &
             bool done = true;
             if (S.is_volume_scene) {                            // binary occlusion, :761-765
                 if (hit) { tr_r = tr_g = tr_b = 0.0f; }
+            } else if (hit && !S.any_transparent) {             // no material with Transparency > 0: `tr <= 0` for whatever was hit, :779-781
+                tr_r = tr_g = tr_b = 0.0f;
             } else if (hit) {                                   // loop body, :775-795
                 tr_counter++;
                 HitAttr h;
@@ -577,17 +580,17 @@ struct PathStack {
 // slot 0 one at a time.  Slots live in LDS; a stage boundary is one workgroup barrier.
 struct FanShared {
     float o[3][64];             // origin of the lane's posted queries (the queries of one hit share it), xyz, lane
-    float q[3][5][64];          // slot, {d xyz, tmin (< 0: empty), tmax}, lane
+    float q[3][6][64];          // slot, {d xyz, tmin (< 0: empty), tmax, any-hit flag}, lane
     float r[3][3][64];          // slot, {t, prim, sub}, lane
     uint32_t iters[3];          // traversal loop iterations per wavefront (summed into the block's cost)
     int alive;
     uint8_t list[192];          // refill mode: the posted queries, compacted (slot * 64 + lane)
 };
-__device__ __forceinline__ void fan_post(FanShared *F, int slot, int lane, F3 o, F3 d, float tmin, float tmax)
+__device__ __forceinline__ void fan_post(FanShared *F, int slot, int lane, F3 o, F3 d, float tmin, float tmax, bool anyhit)
 {
     F->o[0][lane] = o.x; F->o[1][lane] = o.y; F->o[2][lane] = o.z;
     F->q[slot][0][lane] = d.x; F->q[slot][1][lane] = d.y; F->q[slot][2][lane] = d.z;
-    F->q[slot][3][lane] = tmin; F->q[slot][4][lane] = tmax;
+    F->q[slot][3][lane] = tmin; F->q[slot][4][lane] = tmax; F->q[slot][5][lane] = anyhit ? 1.0f : 0.0f;
 }
 __device__ __forceinline__ RayQ fan_query(const FanShared *F, int slot, int lane)
 {
@@ -595,6 +598,7 @@ __device__ __forceinline__ RayQ fan_query(const FanShared *F, int slot, int lane
     q.o = f3(F->o[0][lane], F->o[1][lane], F->o[2][lane]);
     q.d = f3(F->q[slot][0][lane], F->q[slot][1][lane], F->q[slot][2][lane]);
     q.tmin = F->q[slot][3][lane]; q.tmax = F->q[slot][4][lane];
+    q.anyhit = F->q[slot][5][lane] != 0.0f;
     return q;
 }
 __device__ __forceinline__ uint32_t wave_umax(uint32_t v)
@@ -633,7 +637,7 @@ __device__ __forceinline__ void trace_block(const SceneDev &S, const FrameParams
 
     RayQ q;
     make_primary_ray(P, px, py, q.o, q.d);
-    q.tmin = 0.001f; q.tmax = YCGE_FLT_MAX;
+    q.tmin = 0.001f; q.tmax = YCGE_FLT_MAX; q.anyhit = false;
     if (in_image && O.rays && wave == 0) {
         float *r = O.rays + ((size_t)px + (size_t)py * P.hiW) * 6;
         r[0] = q.o.x; r[1] = q.o.y; r[2] = q.o.z; r[3] = q.d.x; r[4] = q.d.y; r[5] = q.d.z;
@@ -666,7 +670,7 @@ __device__ __forceinline__ void trace_block(const SceneDev &S, const FrameParams
     if (FAN) {
         if (WAVES3) F->q[wave][3][lane] = -1.0f;
         else { F->q[0][3][lane] = -1.0f; F->q[1][3][lane] = -1.0f; F->q[2][3][lane] = -1.0f; }
-        if (phase != PH_DONE) fan_post(F, 0, lane, q.o, q.d, q.tmin, q.tmax);      // the primary query
+        if (phase != PH_DONE) fan_post(F, 0, lane, q.o, q.d, q.tmin, q.tmax, false);      // the primary query
     }
 
   for (;;) {          // FAN: one round = stage A (wavefront 0 consumes answers, posts queries) + stage B (all trace)
@@ -755,6 +759,7 @@ __device__ __forceinline__ void trace_block(const SceneDev &S, const FrameParams
                         q.o = h.p + h.n * P.eps;
                         q.d = normalized(refl_dir);
                         q.tmin = 0.001f; q.tmax = YCGE_FLT_MAX;
+                        q.anyhit = false;
                         beta = f3(beta.x * base_albedo.x, beta.y * base_albedo.y, beta.z * base_albedo.z);
                         mirror_depth++;
                         phase = PH_PATH;
@@ -781,14 +786,14 @@ __device__ __forceinline__ void trace_block(const SceneDev &S, const FrameParams
                             F3 ldir = vdiv(to_l, dist);
                             float n_dot_l = cs_max(0.0f, dot(sh_n, ldir));
                             if (n_dot_l <= 0.0f) continue;
-                            fan_post(F, 1 + ns, lane, sh_p + sh_n * P.eps, normalized(ldir), S.is_volume_scene ? 0.001f : 0.0f + P.eps, dist - P.eps);
+                            fan_post(F, 1 + ns, lane, sh_p + sh_n * P.eps, normalized(ldir), S.is_volume_scene ? 0.001f : 0.0f + P.eps, dist - P.eps, S.is_volume_scene || !S.any_transparent);
                             if (ns == 0) pre_l1 = li; else pre_l2 = li;
                             ns++;
                         }
                         if (diffuse_depth < P.diffuse_bounces) {
                             uint64_t rng_peek = rng;        // the draw itself happens at the bounce, below
                             F3 bounce = cosine_sample_hemisphere(sh_n, rng_peek);
-                            fan_post(F, 0, lane, sh_p + sh_n * P.eps, normalized(bounce), 0.001f, YCGE_FLT_MAX);
+                            fan_post(F, 0, lane, sh_p + sh_n * P.eps, normalized(bounce), 0.001f, YCGE_FLT_MAX, false);
                             bounce_in_flight = true;
                         }
                         fanned = ns > 0 || bounce_in_flight;
@@ -801,6 +806,8 @@ __device__ __forceinline__ void trace_block(const SceneDev &S, const FrameParams
         } else {                                        // ComputeTransmittanceToLight loop body, :773-796
             if (!hit) {
                 go_contrib = true;
+            } else if (!S.any_transparent) {            // no material with Transparency > 0: `tr <= 0` for whatever was hit, :779-781
+                tr_r = tr_g = tr_b = 0.0f; go_contrib = true;
             } else {
                 tr_counter++;
                 HitAttr h;
@@ -853,6 +860,7 @@ __device__ __forceinline__ void trace_block(const SceneDev &S, const FrameParams
                 q.d = normalized(ldir);
                 sh_maxdist = dist - P.eps;
                 q.tmax = sh_maxdist;
+                q.anyhit = S.is_volume_scene || !S.any_transparent;          // every occluder is opaque: the first hit answers the query
                 if (S.is_volume_scene) { q.tmin = 0.001f; phase = PH_SHADOW_OCC; }
                 else { q.tmin = 0.0f + P.eps; tr_r = tr_g = tr_b = 1.0f; tr_counter = 0; phase = PH_SHADOW_TR; }
                 queued = true;
@@ -868,6 +876,7 @@ __device__ __forceinline__ void trace_block(const SceneDev &S, const FrameParams
                     q.o = sh_p + sh_n * P.eps;
                     q.d = normalized(bounce);
                     q.tmin = 0.001f; q.tmax = YCGE_FLT_MAX;
+                    q.anyhit = false;
                     beta = f3(beta.x * mult.x, beta.y * mult.y, beta.z * mult.z);
                     diffuse_depth++;
                     phase = PH_PATH;
@@ -884,6 +893,7 @@ __device__ __forceinline__ void trace_block(const SceneDev &S, const FrameParams
             } else {
                 PathItem it = pstack.load(--psp);
                 q.o = it.o; q.d = it.d; q.tmin = 0.001f; q.tmax = YCGE_FLT_MAX;
+                q.anyhit = false;
                 beta = it.beta; mirror_depth = it.mirror_depth; diffuse_depth = it.diffuse_depth;
                 item_is_primary = false;
                 phase = PH_PATH;
@@ -894,7 +904,7 @@ __device__ __forceinline__ void trace_block(const SceneDev &S, const FrameParams
             if (new_kind == 1 && light == pre_l1) { want = 1; pre_l1 = -1; }
             else if (new_kind == 1 && light == pre_l2) { want = 2; pre_l2 = -1; }
             else if (new_kind == 2 && (pre_b || bounce_in_flight)) { want = 3; pre_b = false; }
-            else { fan_post(F, 0, lane, q.o, q.d, q.tmin, q.tmax); want = 0; parked = true; }
+            else { fan_post(F, 0, lane, q.o, q.d, q.tmin, q.tmax, q.anyhit); want = 0; parked = true; }
             if (fanned) parked = true;
         }
     }

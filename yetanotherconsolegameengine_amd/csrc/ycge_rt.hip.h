@@ -37,6 +37,11 @@ __device__ __forceinline__ F3 saturate(F3 a) { return f3(clamp01(a.x), clamp01(a
 struct RayQ {              // one closest-hit query: Scene.Hit(r, tMin, tMax)
     F3 o, d;
     float tmin, tmax;
+    // A shadow query of a scene WITHOUT transparent materials only asks "is anything in [tmin, tmax]?": every hit has
+    // Transparency <= 0, so ComputeTransmittanceToLight returns zero whichever occluder is the closest one
+    // (RaytraceRenderer.cs:761-765, 773-781).  Such a query may stop at its first accepted hit: same radiance, fewer
+    // steps.  The counting variants never do (their counters are the reference's full traversal).
+    bool anyhit = false;
 };
 
 struct Work {              // SURVEY 8(d) counters (COUNT variants) + this lane's traversal steps (always; scheduling feedback)
@@ -793,9 +798,10 @@ enum : int { TREE_DONE = 0, TREE_AT_GRID = 1, TREE_YIELD = 2 };
 template <bool COUNT, bool HAS_GRID, class STK>
 __device__ __forceinline__ int tree_phase(const SceneDev &S, uint32_t &cur, int &mesh_prim, STK &st, F3 o, F3 d, F3 inv, bool sx, bool sy, bool sz,
                                           float tmin, float &closest, int &hit_prim, int &hit_sub, int &parked_grid, int &parked_prim, Work &w,
-                                          int budget = 0x7fffffff)
+                                          int budget = 0x7fffffff, bool anyhit = false)
 {
     for (;;) {
+        if (!COUNT && anyhit && hit_prim >= 0) { st.reset(); cur = YCGE_REF_NONE_VALUE; return TREE_DONE; }      // occlusion query answered
         if (budget-- <= 0) return TREE_YIELD;
         if (cur == YCGE_REF_NONE_VALUE) {
             float tn;
@@ -861,13 +867,13 @@ __device__ __forceinline__ int tree_phase(const SceneDev &S, uint32_t &cur, int 
 
 template <bool COUNT, bool HAS_GRID, class STK>
 __device__ __forceinline__ void walk(const SceneDev &S, uint32_t cur, int mesh_prim, STK &st, F3 o, F3 d, F3 inv, bool sx, bool sy, bool sz,
-                                     float tmin, float &closest, int &hit_prim, int &hit_sub, Work &w)
+                                     float tmin, float &closest, int &hit_prim, int &hit_sub, Work &w, bool anyhit = false)
 {
     bool more = cur != YCGE_REF_NONE_VALUE;      // the stack is empty at entry
     for (;;) {
         int parked_grid = -1, parked_prim = -1;
         bool parked = false;
-        if (more) parked = tree_phase<COUNT, HAS_GRID>(S, cur, mesh_prim, st, o, d, inv, sx, sy, sz, tmin, closest, hit_prim, hit_sub, parked_grid, parked_prim, w) == TREE_AT_GRID;
+        if (more) parked = tree_phase<COUNT, HAS_GRID>(S, cur, mesh_prim, st, o, d, inv, sx, sy, sz, tmin, closest, hit_prim, hit_sub, parked_grid, parked_prim, w, 0x7fffffff, anyhit) == TREE_AT_GRID;
         more = parked;
         if (!HAS_GRID) break;
         if (!__any(parked)) break;
@@ -900,7 +906,8 @@ __device__ __forceinline__ void load_record72(const uint8_t *base, uint32_t byte
 }
 template <bool COUNT, bool BOUNDED = false, class STK>
 __device__ __forceinline__ void mesh_walk(const SceneDev &S, uint32_t &cur, int mesh_prim, STK &st, F3 o, F3 inv, F3 d, bool sx, bool sy,
-                                          bool sz, float tmin, float &closest, int &hit_prim, int &hit_sub, Work &w, int budget = 0x7fffffff)
+                                          bool sz, float tmin, float &closest, int &hit_prim, int &hit_sub, Work &w, int budget = 0x7fffffff,
+                                          bool anyhit = false)
 {
     // the twelve slab products of a node as six packed operations (v_pk_add_f32 / v_pk_mul_f32): GNode keeps its
     // planes as (x y)(z Z)(X Y) pairs per child, so two pairings of the ray's origin and reciprocal direction serve
@@ -937,6 +944,7 @@ __device__ __forceinline__ void mesh_walk(const SceneDev &S, uint32_t &cur, int 
             T.r0 = a; T.r1 = b; T.r2 = c; T.r3 = e; T.e2z = f;
             tri_pair_hit(T, left, unit2, mesh_prim, o, d, tmin, closest, hit_prim, hit_sub);
             next = left > 2u ? cur + ((3u << 4) - 2u) : YCGE_REF_NONE_VALUE;       // next record: 3 units on, two triangles fewer
+            if (!COUNT && anyhit && hit_prim >= 0) { next = YCGE_REF_NONE_VALUE; st.reset(); }      // occlusion query answered: drop what is left
         }
         cur = next;
         if (cur == YCGE_REF_NONE_VALUE) {
@@ -967,8 +975,9 @@ __device__ __forceinline__ void traverse(const SceneDev &S, const RayQ &q, STK &
     if (COUNT) w.box++;
     const bool root_hit = box_scene(S.scene_root_min[0], S.scene_root_min[1], S.scene_root_min[2], S.scene_root_max[0], S.scene_root_max[1],
                                     S.scene_root_max[2], o, inv, tmin, closest, tn);
+    const bool anyhit = !COUNT && q.anyhit;
     if (!FLAT) {
-        walk<COUNT, HAS_GRID>(S, root_hit ? S.scene_root_ref : YCGE_REF_NONE_VALUE, -1, st, o, d, inv, sx, sy, sz, tmin, closest, hit_prim, hit_sub, w);
+        walk<COUNT, HAS_GRID>(S, root_hit ? S.scene_root_ref : YCGE_REF_NONE_VALUE, -1, st, o, d, inv, sx, sy, sz, tmin, closest, hit_prim, hit_sub, w, anyhit);
         return;
     }
     const uint32_t leaf_start = YCGE_REF_PAYLOAD(S.scene_root_ref) >> 3;
@@ -981,16 +990,17 @@ __device__ __forceinline__ void traverse(const SceneDev &S, const RayQ &q, STK &
         if (type == 9) {
             uint32_t start = YCGE_REF_NONE_VALUE;
             const uint32_t root_ref = __float_as_uint(q2.z);
-            if (root_hit && root_ref != YCGE_REF_NONE_VALUE) {
+            const bool open = root_hit && !(anyhit && hit_prim >= 0);      // an answered occlusion query looks at no further object
+            if (open && root_ref != YCGE_REF_NONE_VALUE) {
                 float tm;
                 if (COUNT) w.box++;
                 if (box_mesh(q1.x, q1.y, q1.z, q1.w, q2.x, q2.y, o, inv, sx, sy, sz, tmin, closest, tm)) start = root_ref;
             }
-            mesh_walk<COUNT>(S, start, pi, st, o, inv, d, sx, sy, sz, tmin, closest, hit_prim, hit_sub, w);     // start is consumed
+            mesh_walk<COUNT>(S, start, pi, st, o, inv, d, sx, sy, sz, tmin, closest, hit_prim, hit_sub, w, 0x7fffffff, anyhit);     // start is consumed
         } else if (type == 10) {
-            if (HAS_GRID) { if (root_hit) grid_dda<COUNT>(S, __float_as_int(q0.z), pi, o, d, inv, tmin, closest, hit_prim, hit_sub, w); }
+            if (HAS_GRID) { if (root_hit && !(anyhit && hit_prim >= 0)) grid_dda<COUNT>(S, __float_as_int(q0.z), pi, o, d, inv, tmin, closest, hit_prim, hit_sub, w); }
         } else {
-            if (root_hit) analytic_prim<COUNT>(q0, q1, q2, q3, type, pi, o, d, tmin, closest, hit_prim, hit_sub, w);
+            if (root_hit && !(anyhit && hit_prim >= 0)) analytic_prim<COUNT>(q0, q1, q2, q3, type, pi, o, d, tmin, closest, hit_prim, hit_sub, w);
         }
     }
 }
@@ -1003,11 +1013,13 @@ struct FlatQuery {
     float tmin, closest;
     int hit_prim, hit_sub, obj_i, n_top, mesh_prim;
     uint32_t cur;
+    bool anyhit;
 };
 template <bool COUNT, class STK>
 __device__ __forceinline__ void flat_begin(const SceneDev &S, const RayQ &q, STK &st, FlatQuery &fq, Work &w)
 {
     fq.o = q.o; fq.d = q.d; fq.tmin = q.tmin;
+    fq.anyhit = !COUNT && q.anyhit;
     fq.closest = q.tmax;
     fq.hit_prim = -1; fq.hit_sub = 0;
     fq.cur = YCGE_REF_NONE_VALUE; fq.mesh_prim = -1;
@@ -1030,7 +1042,7 @@ __device__ __forceinline__ bool flat_advance(const SceneDev &S, STK &st, FlatQue
     const uint32_t leaf_start = YCGE_REF_PAYLOAD(S.scene_root_ref) >> 3;
     for (;;) {
         if (fq.cur == YCGE_REF_NONE_VALUE) {
-            if (fq.obj_i >= fq.n_top) return true;
+            if (fq.obj_i >= fq.n_top || (fq.anyhit && fq.hit_prim >= 0)) return true;
             const int pi = (int)S.scene_leaf_prims[leaf_start + fq.obj_i];
             fq.obj_i++;
             const float4 *pp = (const float4 *)(S.prims + pi);
@@ -1050,7 +1062,7 @@ __device__ __forceinline__ bool flat_advance(const SceneDev &S, STK &st, FlatQue
             }
             continue;
         }
-        mesh_walk<COUNT, true>(S, fq.cur, fq.mesh_prim, st, fq.o, fq.inv, fq.d, sx, sy, sz, fq.tmin, fq.closest, fq.hit_prim, fq.hit_sub, w, budget);
+        mesh_walk<COUNT, true>(S, fq.cur, fq.mesh_prim, st, fq.o, fq.inv, fq.d, sx, sy, sz, fq.tmin, fq.closest, fq.hit_prim, fq.hit_sub, w, budget, fq.anyhit);
         if (fq.cur != YCGE_REF_NONE_VALUE) return false;
     }
 }
