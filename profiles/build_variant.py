@@ -1,0 +1,14 @@
+"""Builds an experiment variant of the library: lib/var_<name>.so with extra -D flags (loaded through YCGE_LIB).
+    python profiles/build_variant.py <name> [-DFLAG=1 ...]"""
+import subprocess, sys
+from pathlib import Path
+ROOT = Path(__file__).resolve().parents[1]
+sys.path.insert(0, str(ROOT))
+from yetanotherconsolegameengine_amd import build as b
+name, flags = sys.argv[1], sys.argv[2:]
+out = b.LIB_DIR / f"var_{name}.so"
+cmd = [b.hipcc(), *b.FLAGS, *flags, "-x", "hip", *[str(b.CSRC / s) for s in b.SOURCES], "-o", str(out)]
+r = subprocess.run(cmd, capture_output=True, text=True)
+if r.returncode != 0:
+    sys.stderr.write(r.stdout + r.stderr); raise SystemExit(1)
+print("built", out)

@@ -30,6 +30,8 @@ t0 = p[:, 0].min()
 start = p[:, 0] - t0
 end = start + dur
 print("timestamps are 100 MHz ticks (10 ns). kernel span us:", end.max() / 100.0)
+valid = dur > 0
+print("slot time: sum of wavefront durations %.1f us = %.3f ms on 4096 slots (4 per SIMD) / %.3f ms on 3072" % (dur[valid].sum() / 100.0, dur[valid].sum() / 100.0 / 4096 / 1e3, dur[valid].sum() / 100.0 / 3072 / 1e3))
 print("wave duration us pcts 50/90/99/max", np.percentile(dur, [50, 90, 99]) / 100.0, dur.max() / 100.0)
 print("blocks split into 1/4/16/64 parts:", [int((lg == v).sum()) for v in (0, 2, 4, 6)])
 print("last waves to finish:")

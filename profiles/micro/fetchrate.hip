@@ -8,6 +8,8 @@
 //      look-ups); the chunks are then handed to their owners through LDS (ds_write_b128 x 4, ds_read_b128 x 4)
 //   3  as 2 without the LDS hand-over (memory side alone)
 //   4  per lane: 1 x global_load_dwordx4 (a 16-byte record: lower bound of the per-lane form)
+//   5  per QUAD as 2, but the four fetches are LDS-DMA (global_load_lds_dwordx4: the chunk of lane L lands at plane r + 16 L, no VGPR,
+//      no ds_write); lane L then reads its own record back with 4 x ds_read_b128 from plane (L & 3), columns 4 (L / 4) .. + 3
 // Reports ns per step per wavefront and steps per microsecond per CU, for 4 wavefronts per SIMD resident on every CU.
 //   hipcc --offload-arch=gfx950 -O3 fetchrate.hip -o fetchrate
 #include <hip/hip_runtime.h>
@@ -22,6 +24,7 @@ template <int MODE>
 __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 4))) void k_rate(const uint8_t *recs, uint32_t mask, int steps, int valu, uint32_t *out)
 {
     __shared__ f32x4 xch[4 * 64];
+    __shared__ __attribute__((aligned(16))) uint8_t dma[4 * 1040];
     const int lane = threadIdx.x;
     uint32_t i = (blockIdx.x * 64u + lane) * 2654435761u & mask;
     float acc = 0.0f;
@@ -60,6 +63,24 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 4))) void
                 const float nx = j == 0 ? r0.x : j == 1 ? r1.x : j == 2 ? r2.x : r3.x;
                 a.x = __shfl(nx, q0, 64);
             }
+        } else if (MODE == 5) {
+            const int q0 = lane & ~3, j = lane & 3;
+            const uint32_t i0 = (uint32_t)__shfl((int)i, q0 + 0, 64), i1 = (uint32_t)__shfl((int)i, q0 + 1, 64);
+            const uint32_t i2 = (uint32_t)__shfl((int)i, q0 + 2, 64), i3 = (uint32_t)__shfl((int)i, q0 + 3, 64);
+            const uint8_t *p0 = recs + (size_t)i0 * 64 + j * 16, *p1 = recs + (size_t)i1 * 64 + j * 16;
+            const uint8_t *p2 = recs + (size_t)i2 * 64 + j * 16, *p3 = recs + (size_t)i3 * 64 + j * 16;
+            const uint32_t lds0 = (uint32_t)(uintptr_t)dma;      // plane r at lds0 + r * 1040 (16 bytes of padding: the quad's four planes fall on different banks)
+            unsigned keep;
+            asm volatile("s_mov_b32 %0, m0\n\t"
+                         "s_mov_b32 m0, %5\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\t"
+                         "s_add_u32 m0, m0, 1040\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %2, off\n\t"
+                         "s_add_u32 m0, m0, 1040\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %3, off\n\t"
+                         "s_add_u32 m0, m0, 1040\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %4, off\n\t"
+                         "s_mov_b32 m0, %0\n\ts_waitcnt vmcnt(0)"
+                         : "=&s"(keep) : "v"(p0), "v"(p1), "v"(p2), "v"(p3), "s"(lds0) : "memory", "scc");
+            const uint32_t rd = lds0 + (uint32_t)j * 1040u + (uint32_t)q0 * 16u;
+            asm volatile("ds_read_b128 %0, %4\n\tds_read_b128 %1, %4 offset:16\n\tds_read_b128 %2, %4 offset:32\n\tds_read_b128 %3, %4 offset:48\n\t"
+                         "s_waitcnt lgkmcnt(0)" : "=&v"(a), "=&v"(b), "=&v"(c), "=&v"(e) : "v"(rd) : "memory");
         } else {
             const uint8_t *p = recs + (size_t)i * 64;
             asm volatile("global_load_dwordx4 %0, %1, off\n\ts_waitcnt vmcnt(0)" : "=&v"(a) : "v"(p) : "memory");
@@ -94,19 +115,29 @@ int main()
     hipMemcpy(d, h.data(), max_recs * 64, hipMemcpyHostToDevice);
     uint32_t *out; hipMalloc(&out, 8192 * 64 * 4);
     const int steps = 400, cus = 256;
+    {   // the cooperative forms must walk the same chains as the per-lane form
+        std::vector<uint32_t> o1(1024 * 64), o2(1024 * 64), o5(1024 * 64);
+        run<1>(d, (1u << 20) - 1, 100, 0, 1024, out); hipMemcpy(o1.data(), out, o1.size() * 4, hipMemcpyDeviceToHost);
+        run<2>(d, (1u << 20) - 1, 100, 0, 1024, out); hipMemcpy(o2.data(), out, o2.size() * 4, hipMemcpyDeviceToHost);
+        run<5>(d, (1u << 20) - 1, 100, 0, 1024, out); hipMemcpy(o5.data(), out, o5.size() * 4, hipMemcpyDeviceToHost);
+        size_t bad2 = 0, bad5 = 0;
+        for (size_t k = 0; k < o1.size(); k++) { bad2 += o1[k] != o2[k]; bad5 += o1[k] != o5[k]; }
+        printf("self-check: mode 2 vs 1 mismatches %zu, mode 5 (LDS-DMA) vs 1 mismatches %zu of %zu\n", bad2, bad5, o1.size());
+    }
     for (size_t recs : {(size_t)1 << 16, (size_t)1 << 20, (size_t)1 << 22}) {      // 4 MB (L2), 64 MB (the BVH of config 4: Infinity Cache), 256 MB
         for (int waves : {1024, 4096}) {
             for (int valu : {0, 120}) {
-                float ms[5];
+                float ms[6];
                 ms[0] = run<0>(d, (uint32_t)(recs - 1), steps, valu, waves, out);
                 ms[1] = run<1>(d, (uint32_t)(recs - 1), steps, valu, waves, out);
                 ms[2] = run<2>(d, (uint32_t)(recs - 1), steps, valu, waves, out);
                 ms[3] = run<3>(d, (uint32_t)(recs - 1), steps, valu, waves, out);
                 ms[4] = run<4>(d, (uint32_t)(recs - 1), steps, valu, waves, out);
+                ms[5] = run<5>(d, (uint32_t)(recs - 1), steps, valu, waves, out);
                 printf("footprint %6.1f MB waves %5d valu %3d : ns/step/wave", recs * 64 / 1048576.0, waves, valu);
-                for (int m = 0; m < 5; m++) printf("  m%d %7.1f", m, ms[m] * 1e6 / steps);
+                for (int m = 0; m < 6; m++) printf("  m%d %7.1f", m, ms[m] * 1e6 / steps);
                 printf("   | steps/us/CU");
-                for (int m = 0; m < 5; m++) printf(" %6.2f", (double)waves * steps / (ms[m] * 1e3) / cus);
+                for (int m = 0; m < 6; m++) printf(" %6.2f", (double)waves * steps / (ms[m] * 1e3) / cus);
                 printf("\n");
             }
         }

@@ -9,7 +9,7 @@ OUT=$REPO/gpurun_out/prof_$TAG
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
 BENCH="python3 $REPO/bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-post $*"
-rocprofv3 --kernel-trace --stats -f csv -d $OUT/trace -o trace -- $BENCH > $OUT/trace.log 2>&1
+timeout 600 rocprofv3 --kernel-trace --stats -f csv -d $OUT/trace -o trace -- $BENCH > $OUT/trace.log 2>&1
 echo "trace rc=$?"
 i=0
 for set in \
@@ -20,14 +20,14 @@ for set in \
   "TCP_TOTAL_CACHE_ACCESSES_sum TCP_TCC_READ_REQ_sum TCP_TCC_WRITE_REQ_sum TCP_TCC_READ_REQ_LATENCY_sum" \
   "SQ_INSTS_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INSTS_VALU_TRANS_F32 SQ_INSTS_VALU_FMA_F32 SQ_INSTS_VALU_FLOPS_FP64 SQ_INSTS_BRANCH SQ_IFETCH" ; do
   i=$((i+1))
-  rocprofv3 --kernel-trace --pmc $set -f csv -d $OUT/pmc$i -o pmc$i -- $BENCH > $OUT/pmc$i.log 2>&1
+  timeout 600 rocprofv3 --kernel-trace --pmc $set -f csv -d $OUT/pmc$i -o pmc$i -- $BENCH > $OUT/pmc$i.log 2>&1
   echo "pmc$i rc=$? ($set)"
 done
 # calibration of FETCH_SIZE / WRITE_SIZE on a copy of known size (same two passes)
 if [ -x $REPO/profiles/micro/copycal ]; then
-  rocprofv3 --kernel-trace --pmc FETCH_SIZE -f csv -d $OUT/pmc_calf -o calf -- $REPO/profiles/micro/copycal > $OUT/copycal_f.log 2>&1
-  rocprofv3 --kernel-trace --pmc WRITE_SIZE -f csv -d $OUT/pmc_calw -o calw -- $REPO/profiles/micro/copycal > $OUT/copycal_w.log 2>&1
+  timeout 300 rocprofv3 --kernel-trace --pmc FETCH_SIZE -f csv -d $OUT/pmc_calf -o calf -- $REPO/profiles/micro/copycal > $OUT/copycal_f.log 2>&1
+  timeout 300 rocprofv3 --kernel-trace --pmc WRITE_SIZE -f csv -d $OUT/pmc_calw -o calw -- $REPO/profiles/micro/copycal > $OUT/copycal_w.log 2>&1
 fi
 CFG=4; prev=""; for a in "$@"; do if [ "$prev" = "--config" ]; then CFG=$a; fi; prev=$a; done
-python3 $REPO/profiles/summarize.py $OUT --json $OUT/pmc_config$CFG.json --config $CFG --source "rocprofv3 --kernel-trace --stats + separate --pmc passes of: bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-post $* (tag $TAG)" > $OUT/summary.txt 2>&1
+python3 $REPO/profiles/summarize.py $OUT --json $OUT/pmc_config$CFG.json --config $CFG --source "timeout 600 rocprofv3 --kernel-trace --stats + separate --pmc passes of: bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-post $* (tag $TAG)" > $OUT/summary.txt 2>&1
 cat $OUT/summary.txt

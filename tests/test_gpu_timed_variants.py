@@ -192,3 +192,87 @@ def test_textured_material_and_bad_indices_are_refused(product_lib):
         r.set_frame_counter(2 ** 40)
         r.TryFlipAndBlit()
         assert r.stats.frame == 2 ** 40 + 1
+
+
+OBJ_TEXT = """# a small hull with every index form MeshLoader.cs:23-55 accepts
+v -0.6 0.0 -0.4
+v 0.6 0.0 -0.4
+v 0.6 0.0 0.4
+v -0.6 0.0 0.4
+v 0.0 0.9 0.0
+vt 0 0
+vn 0 1 0
+f 1 2 3 4
+f 1/1/1 2/1/1 5/1/1
+f 2//1 3//1 5//1
+f -3 -2 -1
+f 4 1 5
+v 0.0 -0.5 0.0
+f 1 2 3 4 6
+f -1 -3 -5 -6
+"""
+
+
+def test_scene_loaded_from_obj_text_against_oracle(product_lib, oracle, tmp_path):
+    """SURVEY 8-f4 through the path: OBJ TEXT -> parse_obj (quads / pentagons fan out, `v/vt/vn`, `v//vn` and negative indices) ->
+    AddMeshAutoGround placement -> Scene -> both renderers.  Every buffer of three frames is bit-identical."""
+    from yetanotherconsolegameengine_amd import mesh_loader
+    from yetanotherconsolegameengine_amd.scene import AmbientLight, Checker, Material, Mesh, Plane, PointLight, Scene, vec3
+    path = tmp_path / "hull.obj"
+    path.write_text(OBJ_TEXT)
+    pos, faces = mesh_loader.load_obj(path)
+    assert pos.shape == (6, 3) and faces.shape == (2 + 1 + 1 + 1 + 1 + 3 + 2, 3)
+    tris = mesh_loader.add_mesh_auto_ground(pos, faces, 1.4, (0.0, 0.0, -3.0))
+    s = Scene()
+    s.Ambient = AmbientLight(vec3(1, 1, 1), 0.1)
+    s.Objects.append(Plane(vec3(0, 0, 0), vec3(0, 1, 0), Checker(vec3(0.8, 0.8, 0.8), vec3(0.25, 0.25, 0.25), 0.7), 0.0, 0.0))
+    s.Objects.append(Mesh(tris, Material(vec3(0.85, 0.4, 0.2))))
+    s.Lights.append(PointLight(vec3(2.0, 4.0, 0.0), vec3(1, 1, 1), 60.0))
+    s.Lights.append(PointLight(vec3(-3.0, 2.5, -1.0), vec3(0.8, 0.9, 1.0), 30.0))
+    pose = dict(pos=(0.3, 1.1, 0.0), yaw=0.05, pitch=-0.15, fov=50.0)
+    for count in (True, False):
+        o, g = pu.run_pair(oracle, s, 160, 45, 1, pose, frames=1, count=count)
+        _assert_frame(o, g, f"obj text scene count={count} frame 1")
+        assert (g.read(abi.BUF_PRIM_ID) == 1).any()          # the mesh is in view
+        for f in (2, 3):
+            o.render(stages=1, threads=8); g.TryFlipAndBlit()
+            _assert_frame(o, g, f"obj text scene count={count} frame {f}")
+        o.close(); g.close()
+
+
+def test_world_file_to_attached_chunks_against_oracle(product_lib, oracle, tmp_path):
+    """SURVEY 8-f4 through the path: a VG01 world file (WorldManager.cs:612-629) is written, read back, cut into chunk grids by the
+    streaming-set logic (:372-397, :696-731) and rendered as a VolumeScene by both renderers."""
+    from yetanotherconsolegameengine_amd import world_file as wf
+    from yetanotherconsolegameengine_amd.scene import AmbientLight, PointLight, Scene, vec3
+    rng = np.random.default_rng(3)
+    nx, ny, nz = 48, 24, 48
+    world = np.zeros((nx, ny, nz, 2), np.int32)
+    h = (6 + 5 * np.sin(np.arange(nx)[:, None] * 0.3) + 4 * np.cos(np.arange(nz)[None, :] * 0.25)).astype(int)
+    for x in range(nx):
+        for z in range(nz):
+            world[x, :max(1, h[x, z]), z, 0] = (scenes.STONE, scenes.DIRT, scenes.GRASS)[(x + z) % 3]
+    world[20:23, 10:14, 20:23, 0] = scenes.SAND            # a floating block
+    world[..., 1] = rng.integers(0, 3, size=(nx, ny, nz)) * (world[..., 0] == scenes.STONE)
+    p = tmp_path / "world.vg"
+    wf.write_vg01(p, world)
+    back = wf.read_vg01(p)
+    assert np.array_equal(back, world)
+    palette = scenes.VoxelMaterialLookup
+    s = Scene()
+    s.IsVolumeScene = True
+    s.Ambient = AmbientLight(vec3(1, 1, 1), 0.0)
+    lights, top, bottom = scenes.sun_moon_lights(0.25)
+    s.Lights.extend(lights)
+    s.BackgroundTop, s.BackgroundBottom = top, bottom
+    cam = (24.0, 14.0, 24.0)
+    added = wf.attach_view(s, back, cam, (0.0, 0.0, 0.0), (1.0, 1.0, 1.0), 16, 1, palette)
+    assert len(added) >= 9 and len(s.Objects) == len(added)
+    pose = dict(pos=cam, yaw=0.6, pitch=-0.45, fov=60.0)
+    o, g = pu.run_pair(oracle, s, 128, 36, 1, pose, frames=1, count=False)
+    _assert_frame(o, g, "vg01 world frame 1")
+    for f in (2, 3):
+        o.render(stages=1, threads=8); g.TryFlipAndBlit()
+        _assert_frame(o, g, f"vg01 world frame {f}")
+    assert (g.read(abi.BUF_SKY_MASK) == 0).mean() > 0.3
+    o.close(); g.close()

@@ -493,3 +493,36 @@ def test_oracle_parallel_taa_equals_the_serial_loops():
         for which in (abi.BUF_TAA_HISTORY, abi.BUF_PREV_NORMAL, abi.BUF_PREV_DEPTH, abi.BUF_PREV_SKY):
             assert np.array_equal(a.read(which).view(np.uint8), b.read(which).view(np.uint8)), (f, which)
     a.close(); b.close()
+
+
+def test_reference_obj_assets_parse_to_their_triangle_counts():
+    """MeshLoader.cs:23-55 on the reference's own assets (CPU container only: /root/reference does not travel): cow.obj has
+    n-gons that fan out to 5 804 triangles, teapot.obj 6 320, the bunny 69 451 = the committed fixture, vertex for vertex."""
+    assets = Path("/root/reference/ConsoleGame/assets")
+    if not assets.is_dir():
+        pytest.skip("reference assets not present (GPU box)")
+    for name, n_tri in (("cow.obj", 5804), ("teapot.obj", 6320)):
+        pos, faces = mesh_loader.load_obj(assets / name)
+        assert faces.shape == (n_tri, 3), (name, faces.shape)
+        assert faces.min() >= 0 and faces.max() < len(pos)
+        tris = mesh_loader.from_obj_arrays(pos, faces)
+        ext = tris.reshape(-1, 3).max(0) - tris.reshape(-1, 3).min(0)
+        assert abs(float(ext.max()) - 1.0) < 1e-5                       # normalize: max extent = targetSize
+    pos, faces = mesh_loader.load_obj(assets / "stanford-bunny.obj")
+    fpos, ffaces = scenes.load_bunny_arrays()
+    assert np.array_equal(pos, fpos) and np.array_equal(faces, ffaces)
+
+
+def test_desired_chunk_set_known_answer():
+    """BuildDesiredSet (WorldManager.cs:372-397) against a count and membership worked out by hand, not by the function's own
+    logic: view distance 8 around any column is 17 x 17 columns, times 8 vertical chunks = 2 312 keys (BASELINE config 5);
+    the column of a camera at x = -0.5 with WorldMin.x = 0 is floor(-0.5 / 32) = -1, not 0 (floor, not truncation)."""
+    from yetanotherconsolegameengine_amd import world_file as wf
+    keys = wf.build_desired_set((100.0, 50.0, 100.0), (0.0, 0.0, 0.0), (1.0, 1.0, 1.0), 32, 8, 8)
+    assert len(keys) == 17 * 17 * 8 == 2312 and len(set(keys)) == 2312
+    xs = sorted({k[0] for k in keys}); ys = sorted({k[1] for k in keys}); zs = sorted({k[2] for k in keys})
+    assert xs == list(range(3 - 8, 3 + 9)) and zs == xs and ys == list(range(8))          # 100 / 32 = 3.125 -> column 3
+    neg = wf.build_desired_set((-0.5, 0.0, -0.5), (0.0, 0.0, 0.0), (1.0, 1.0, 1.0), 32, 0, 1)
+    assert neg == [(-1, 0, -1)]
+    half = wf.build_desired_set((10.0, 0.0, 10.0), (0.0, 0.0, 0.0), (0.5, 0.5, 0.5), 16, 1, 2)       # 8-unit chunks: column 1
+    assert len(half) == 3 * 3 * 2 and half[0] == (0, 0, 0) and half[-1] == (2, 1, 2)

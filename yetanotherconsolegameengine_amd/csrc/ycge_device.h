@@ -126,7 +126,7 @@ struct GLight {
     float pad;
 };
 
-#define YCGE_LDS_STACK_LEVELS 12    // levels of a lane's traversal stack kept in LDS; deeper ones go to the HBM spill area
+#define YCGE_LDS_STACK_LEVELS 11    // levels of a lane's traversal stack kept in LDS; deeper ones go to the HBM spill area
 #define YCGE_TRAVERSAL_STACK 96    // >= scene depth + 4 leaf prims + mesh depth, checked at upload
 #ifndef YCGE_COST_FRAMES
 #define YCGE_COST_FRAMES 4          // a block's schedule cost is its largest cost over this many frames
@@ -186,6 +186,19 @@ struct FrameParams {
     const uint32_t *tile_order;
 };
 
+// A path handed from the block that traced its primary vertex to whichever wavefront has idle lanes (k_trace):
+// TraceFull's per-pixel state at the moment its next Scene.Hit query is a path query (bounce / mirror continuation) and its work
+// stack is empty (RaytraceRenderer.cs:439-468) - everything the rest of the path needs, 64 bytes.
+struct alignas(16) MigEntry {
+    float o[3], d[3];           // the pending query: new Ray(origin, dir), tMin 0.001, tMax FLT_MAX
+    float beta[3];              // item.Throughput
+    float radiance[3];          // radiance accumulated so far (later terms are added to it in TraceFull's order)
+    uint32_t rng_lo, rng_hi;    // Rng state
+    uint32_t pixel;             // x + y * hiW
+    uint32_t depths;            // mirrorDepth | diffuseDepth << 4
+};
+static_assert(sizeof(MigEntry) == 64, "MigEntry must be 64 B");
+
 struct TraceOut {
     // full-frame buffers (row-major x + y*hiW); with several GPUs only the owned tiles are written
     float *current_hdr;     // 3 f32 / px
@@ -216,6 +229,14 @@ struct TraceOut {
     const uint32_t *n_fan;              // the first *n_fan schedule entries are traced by k_trace_fan (null or 0: none)
     // traversal counters (may be null): rays, box, tri, prim, vox
     unsigned long long *counters;
+    // path migration (null = off): 64 MigEntry slots per 8x8 block; mig_pub = ring of published segments
+    // ((first entry << 8 | count) | 1 << 63, 0 = not yet written), mig_ctl = {tail, head} running counters (never reset)
+    MigEntry *mig_entries;
+    unsigned long long *mig_pub;
+    unsigned long long *mig_ctl;
+    uint32_t mig_ring;                  // entries of mig_pub
+    int32_t mig_round_steps;            // traversal steps a consuming wavefront takes between refills
+    int32_t mig_shade_min;              // ... and how many finished queries it waits for before it runs the shading code
 };
 
 // planes a peer device copies from its own frame buffers into rank 0's (one process, several GPUs): its tiles only

@@ -41,8 +41,9 @@ int ycge_launch_atrous(int w, int h, int step, const float phi[4], const float *
 int ycge_launch_atrous_inplace(int w, int h, int step, const float phi[4], float *buf, const float *albedo, const float *unit_n,
                                const float *depth, const uint8_t *sky, float *statw, const uint32_t *d_pixels, const uint32_t *d_offsets,
                                int n_levels, int n_bands, int K, hipStream_t stream);
+size_t ycge_exposure_scratch_bytes(int w, int h, int step);
 int ycge_launch_exposure(const float *hdr, const uint8_t *sky, int w, int h, int step, float *terms, void *state, const float consts[5],
-                         hipStream_t stream);
+                         void *scratch, int serial, hipStream_t stream);
 int ycge_launch_tonemap(const float *hdr, int hiW, int fbW, int fbH, int ss, float gamma, float saturation, float vibrance, const void *state,
                         float *out, hipStream_t stream);
 int ycge_launch_pack_slab(const ycge::FrameParams *P, const float *hdr, const float *albedo, const float *normal, const float *depth,
@@ -94,7 +95,9 @@ struct Knobs {
     int pw_per_cu = 32;
     int post_band_rows = YCGE_POST_BAND_ROWS_DEFAULT, post_k = YCGE_POST_K_DEFAULT;
     int fan_class = -1, fan_cap = -1;   // -1 = default by world size
+    int mig = 1, mig_round = 12, mig_shade = 16;      // YCGE_MIG (0 = off), YCGE_MIG_ROUND, YCGE_MIG_SHADE: path migration in k_trace
     int post_mode = 0;               // YCGE_POST_MODE: in-place A-trous implementation (0 = default)
+    bool exposure_serial = false;    // YCGE_EXPOSURE_SERIAL: the one-lane chain instead of the chunked exact evaluation
     void read()
     {
         auto geti = [](const char *n, int dflt) { const char *e = getenv(n); return e ? atoi(e) : dflt; };
@@ -108,6 +111,9 @@ struct Knobs {
         post_band_rows = geti("YCGE_POST_BAND_ROWS", YCGE_POST_BAND_ROWS_DEFAULT); post_k = geti("YCGE_POST_K", YCGE_POST_K_DEFAULT);
         fan_class = geti("YCGE_FAN", -1); fan_cap = geti("YCGE_FAN_CAP", -1);
         post_mode = geti("YCGE_POST_MODE", 0);
+        mig = geti("YCGE_MIG", 1); mig_round = geti("YCGE_MIG_ROUND", 12); mig_shade = geti("YCGE_MIG_SHADE", 16);
+        if (mig_round < 1) mig_round = 1;
+        exposure_serial = getenv("YCGE_EXPOSURE_SERIAL") != nullptr;
     }
 };
 
@@ -182,6 +188,7 @@ struct ycge_ctx {
     // denoise / exposure / tonemap stage (ycge_post.hip), allocated on the first frame that asks for SDR output
     DevBuf<float> den_a, den_b, unit_n, exp_terms, d_sdr;
     DevBuf<float> atrous_statw;                // [pixel][25 taps][3]: colour-independent weight factors of an in-place A-trous iteration
+    DevBuf<uint8_t> exp_scratch;                  // chunk records of the exposure sum (k_exposure_sum)
     DevBuf<uint8_t> tone_state;                   // ToneMapper state; lives as long as the context (not reset by Resize)
     struct InplaceSchedule { int w = 0, h = 0, step = 0, levels = 0, bands = 0; uint32_t max_level_pixels = 0; DevBuf<uint32_t> pixels, offsets; };
     std::vector<InplaceSchedule *> schedules;     // level schedules of the in-place A-trous iterations, by (w, h, step)
@@ -194,6 +201,8 @@ struct ycge_ctx {
     DevBuf<uint32_t> block_cost, block_order, order_ws;   // k_trace scheduling feedback (4 blocks of 8x8 px per tile)
     bool block_order_valid = false;
     DevBuf<uint64_t> stack_spill;                 // [YCGE_TRAVERSAL_STACK - 12][persistent lanes]
+    DevBuf<MigEntry> mig_entries;                 // path migration (k_trace): 64 entries per 8x8 block
+    DevBuf<unsigned long long> mig_pub, mig_ctl;  // ring of published segments; {tail, head}
     DevBuf<float> path_stack;                  // [3][11][persistent lanes], only for scenes with transparent materials
     int spill_levels = 0;                      // traversal depth beyond the 12 LDS levels, from the uploaded trees
     int wf_rounds = 2;                         // 2 = primary + diffuse bounce; 4 when a surface can mirror (<= 2 mirror bounces)
@@ -264,6 +273,7 @@ int alloc_tile_buffers(ycge_ctx *c)
     HIP_TRY(c, c->wf_counts.alloc((size_t)(c->n_owned > 0 ? c->n_owned : 1) * 8));
     HIP_TRY(c, c->stack_spill.alloc((size_t)(c->spill_levels > 0 ? c->spill_levels : 1) * stack_lanes));
     c->path_stack.release();
+    c->mig_entries.release(); c->mig_pub.release(); c->mig_ctl.release();
     {
         const size_t nb = (size_t)(c->n_owned > 0 ? c->n_owned : 1) * 4;
         HIP_TRY(c, c->block_cost.alloc(nb * YCGE_COST_FRAMES)); HIP_TRY(c, c->block_order.alloc(nb * YCGE_SCHEDULE_SLACK)); HIP_TRY(c, c->order_ws.alloc(20));
@@ -313,7 +323,7 @@ int set_geometry(ycge_ctx *c, int fbw, int fbh, int ss)
     c->tiles_per_rank_padded = (c->n_tiles + world - 1) / world;
     c->taa_valid = false;                                       // Resize: taaHistoryValid = false (:137), taa.Resize (TemporalAA.cs:34-46)
     c->last_cam[0] = c->last_cam[1] = c->last_cam[2] = NAN; c->last_yaw = c->last_pitch = NAN;
-    c->den_a.release(); c->den_b.release(); c->unit_n.release(); c->exp_terms.release(); c->d_sdr.release(); c->atrous_statw.release();     // spatialA / spatialB, :129-130
+    c->den_a.release(); c->den_b.release(); c->unit_n.release(); c->exp_terms.release(); c->exp_scratch.release(); c->d_sdr.release(); c->atrous_statw.release();     // spatialA / spatialB, :129-130
     c->denoised = nullptr;
     c->wave_prof.release();                                     // sized for the tile grid
     c->pending.clear();
@@ -580,10 +590,10 @@ void ycge_destroy(ycge_ctx *c)
     c->dbg_rays.release(); c->dbg_hit_t.release(); c->dbg_prim.release(); c->dbg_sub.release(); c->dbg_rng.release();
     c->counters.release(); c->wave_prof.release(); c->own_slab.release();
     c->t_hdr.release(); c->t_albedo.release(); c->t_normal.release(); c->t_depth.release(); c->t_sky.release();
-    c->den_a.release(); c->den_b.release(); c->unit_n.release(); c->exp_terms.release(); c->d_sdr.release(); c->atrous_statw.release(); c->tone_state.release();
+    c->den_a.release(); c->den_b.release(); c->unit_n.release(); c->exp_terms.release(); c->exp_scratch.release(); c->d_sdr.release(); c->atrous_statw.release(); c->tone_state.release();
     for (auto *sc : c->schedules) { sc->pixels.release(); sc->offsets.release(); delete sc; }
     c->schedules.clear();
-    c->wf_q0.release(); c->wf_q1.release(); c->wf_hit.release(); c->wf_lq.release(); c->wf_seg.release(); c->wf_counts.release(); c->tile_order.release(); c->block_cost.release(); c->block_order.release(); c->order_ws.release(); c->stack_spill.release(); c->path_stack.release();
+    c->wf_q0.release(); c->wf_q1.release(); c->wf_hit.release(); c->wf_lq.release(); c->wf_seg.release(); c->wf_counts.release(); c->tile_order.release(); c->block_cost.release(); c->block_order.release(); c->order_ws.release(); c->stack_spill.release(); c->path_stack.release(); c->mig_entries.release(); c->mig_pub.release(); c->mig_ctl.release();
     c->d_scene_nodes.release(); c->d_mesh_arena.release(); c->d_scene_leaf.release(); c->d_prims.release();
     c->d_materials.release(); c->d_meshes.release(); c->d_grids.release(); c->d_cells.release(); c->d_lut.release(); c->d_lights.release();
     for (auto &ev : c->ev) if (ev) (void)hipEventDestroy(ev);
@@ -1173,6 +1183,19 @@ int trace_frame(ycge_ctx *c, float *d_slab, hipStream_t stream, FrameState &fs, 
         O.path_stack = c->path_stack.p;
         const bool lpt = !c->knobs.no_lpt;
         const uint32_t n_blocks = (uint32_t)c->n_owned * 4u;
+        // path migration (flat scenes, the non-counting kernel): a block hands its bounce / mirror paths to whichever wavefront has idle lanes
+        const bool mig = flat && c->knobs.mig && !c->cfg.count_work && c->knobs.refill_steps <= 0 && n_blocks > 0;
+        if (mig) {
+            if (!c->mig_entries.p) {
+                HIP_TRY(c, c->mig_entries.alloc((size_t)n_blocks * 64));
+                HIP_TRY(c, c->mig_pub.alloc((size_t)n_blocks * YCGE_SCHEDULE_SLACK)); HIP_TRY(c, c->mig_ctl.alloc(2));
+                HIP_TRY(c, hipMemset(c->mig_pub.p, 0, (size_t)n_blocks * YCGE_SCHEDULE_SLACK * sizeof(unsigned long long)));
+                HIP_TRY(c, hipMemset(c->mig_ctl.p, 0, 2 * sizeof(unsigned long long)));
+            }
+            O.mig_entries = c->mig_entries.p; O.mig_pub = c->mig_pub.p; O.mig_ctl = c->mig_ctl.p;
+            O.mig_ring = n_blocks * YCGE_SCHEDULE_SLACK;
+            O.mig_round_steps = c->knobs.mig_round; O.mig_shade_min = c->knobs.mig_shade;
+        }
         const uint32_t cost_slot = (uint32_t)((uint64_t)fs.frame % YCGE_COST_FRAMES);       // this frame's array of the cost ring
         O.block_cost = lpt ? c->block_cost.p + (size_t)cost_slot * n_blocks : nullptr;
         if (c->order_pending) { HIP_TRY(c, hipStreamWaitEvent(stream, c->order_ev, 0)); c->order_pending = false; }     // the schedule built beside the last frame's TAA
@@ -1183,7 +1206,7 @@ int trace_frame(ycge_ctx *c, float *d_slab, hipStream_t stream, FrameState &fs, 
         // a schedule without fanned blocks (analytic scenes, small frames) skips k_trace_fan and the side stream altogether: the count
         // comes back through pinned memory and is a frame or two old when read here - either answer traces every block exactly once,
         // because k_trace is told (n_fan pointer or null) which convention this frame uses
-        const bool fan = O.block_order != nullptr && c->fan_cap > 0 && !(flat && refill_steps > 0) && c->h_n_fan && *(volatile uint32_t *)c->h_n_fan > 0;
+        const bool fan = !mig && O.block_order != nullptr && c->fan_cap > 0 && !(flat && refill_steps > 0) && c->h_n_fan && *(volatile uint32_t *)c->h_n_fan > 0;
         if (fan) {
             fs.fan_blocks = *(volatile uint32_t *)c->h_n_fan;      // what the last finished schedule handed to k_trace_fan (this frame's may differ by a few)
             // k_trace_fan goes FIRST and on the frame's stream, so that its blocks - the frame's longest chains - are resident from
@@ -1389,7 +1412,8 @@ int run_post(ycge_ctx *c, hipStream_t stream, float *out_sdr_host, bool timed)
     c->denoised = cur;
     const int step = c->ss * 2 > 2 ? c->ss * 2 : 2;            // :226
     const float tone_consts[5] = {1.0f, 0.18f, 0.2f, 0.10f, 1.50f};     // toneExposure, aeKey, aeSpeed, aeMin, aeMax (ToneMapper.cs:8-16)
-    e = ycge_launch_exposure(cur, c->sky.p, w, h, step, c->exp_terms.p, c->tone_state.p, tone_consts, stream);
+    if (!c->exp_scratch.p) HIP_TRY(c, c->exp_scratch.alloc(ycge_exposure_scratch_bytes(w, h, step)));
+    e = ycge_launch_exposure(cur, c->sky.p, w, h, step, c->exp_terms.p, c->tone_state.p, tone_consts, c->exp_scratch.p, c->knobs.exposure_serial ? 1 : 0, stream);
     if (e != 0) return c->fail(YCGE_ERR_DEVICE, "exposure launch failed: %s", hipGetErrorString((hipError_t)e));
     e = ycge_launch_tonemap(cur, w, c->fbW, c->fbH, c->ss, 2.2f, 2.0f, 0.0f, c->tone_state.p, c->d_sdr.p, stream);   // toneGamma, toneSaturation, toneVibrance
     if (e != 0) return c->fail(YCGE_ERR_DEVICE, "tonemap launch failed: %s", hipGetErrorString((hipError_t)e));

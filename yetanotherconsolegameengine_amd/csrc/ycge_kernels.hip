@@ -532,6 +532,12 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu((HAS_GRID &
 }
 
 // ---------------------------------------------------------------------------------- K_trace (single launch)
+#ifndef YCGE_MIGRATE
+#define YCGE_MIGRATE 1              // path migration in the flat, non-counting k_trace (trace_block, MIG)
+#endif
+#ifndef YCGE_COOP_FETCH
+#define YCGE_COOP_FETCH 1           // quad-cooperative LDS-DMA record fetch in the flat, non-counting single-launch kernels (ycge_rt.hip.h)
+#endif
 enum Phase : int { PH_PATH = 0, PH_SHADOW_OCC = 1, PH_SHADOW_TR = 2, PH_DONE = 3 };
 
 struct PathItem {       // PathWorkItem, RaytraceRenderer.cs:439-446 (IsPrimary is false for every pushed item)
@@ -613,9 +619,21 @@ __device__ __forceinline__ uint32_t wave_umax(uint32_t v)
 //         the block's posted queries (up to 192) form a list, a lane that finishes its query takes the next one whichever
 //         pixel it belongs to, and the walk yields every `refill_steps` steps so that idle lanes can do so.  A block then
 //         costs about max(its longest query, its steps / 64) per stage instead of the sum of the stage's longest lanes.
-template <bool COUNT, bool FLAT, int MODE>
+// MIG (MODE 0, flat scenes): PATH MIGRATION.  A block traces what is coherent - its pixels' primary rays and the shadow rays of the
+// primary hits - in place; the moment a pixel's NEXT query is a path query (the diffuse bounce or a mirror continuation) and its
+// work stack is empty, the pixel's whole TraceFull state (64 bytes: ray, throughput, radiance so far, generator, depths) goes into
+// the block's segment of a global queue and the lane is done.  Bounce rays differ in length by two orders of magnitude and only 3 %
+// of them lead to further shadow rays: traced in place, a block pays the longest lane of every batch (config 4: 554 k + 293 k of
+// the frame's 1.55 M wave-steps for work that fits in 102 k).  A wavefront that has finished its block publishes the segment and
+// then turns CONSUMER: it claims published segments (its own or anybody's), hands the paths to its idle lanes, advances all of
+// them a bounded number of steps per round (the query is resumable: flat_begin / flat_advance) and runs TraceFull's code for the
+// lanes whose query has ended - refilling a lane as soon as its path is finished.  When nothing is published and its lanes are done
+// it exits; whoever publishes later consumes later, the last publisher last.  One kernel, no spinning on another kernel's
+// progress (a published index whose word is not yet visible is waited for: its publisher is between two instructions).
+// Which wavefront finishes a path never changes the path: same queries, same additions in the same order.
+template <bool COUNT, bool FLAT, int MODE, bool MIG = false>
 __device__ __forceinline__ void trace_block(const SceneDev &S, const FrameParams &P, const TraceOut &O, const uint32_t ent, const uint32_t sched_index,
-                                            FanShared *F, const int refill_steps)
+                                            FanShared *F, const int refill_steps, uint32_t *s_nmig = nullptr)
 {
     constexpr bool FAN = MODE != 0;          // queries are posted to LDS slots and answered in stage B
     constexpr bool WAVES3 = MODE == 1;
@@ -667,26 +685,162 @@ __device__ __forceinline__ void trace_block(const SceneDev &S, const FrameParams
     // the block's cost for the next frame's schedule: loop iterations its wavefront(s) spend in traversal = sum over the
     // query batches of the longest lane's steps.  The same scale whether the block is fanned or not.
     uint32_t wave_iters = 0;
+    // path migration state (MIG)
+    const bool mig_on = MIG && O.mig_entries != nullptr;
+    bool consuming = false, migrated = false, need_begin = false, mig_dry = false;
+    uint32_t mig_pixel = 0, seg_next = 0, seg_end = 0, mig_wait = 0;
+    FlatQuery mq;
+    mq.cur = YCGE_REF_NONE_VALUE; mq.obj_i = 0; mq.n_top = 0; mq.closest = 0.0f; mq.hit_prim = -1; mq.hit_sub = 0; mq.mesh_prim = -1; mq.tmin = 0.0f; mq.anyhit = false;
+    mq.o = f3(0, 0, 0); mq.d = f3(0, 0, 1); mq.inv = f3(0, 0, 0);
+    if (MIG) { if (lane == 0) *s_nmig = 0; }
     if (FAN) {
         if (WAVES3) F->q[wave][3][lane] = -1.0f;
         else { F->q[0][3][lane] = -1.0f; F->q[1][3][lane] = -1.0f; F->q[2][3][lane] = -1.0f; }
         if (phase != PH_DONE) fan_post(F, 0, lane, q.o, q.d, q.tmin, q.tmax, false);      // the primary query
     }
 
+    // what a block leaves behind when its last pixel is done (or handed over): the pixels, the schedule feedback, the profile record
+    auto finish_block = [&]() {
+    if (in_image) {                                     // :210-215
+        const size_t i = (size_t)px + (size_t)py * P.hiW;
+        if (!migrated) { O.current_hdr[3 * i + 0] = radiance.x; O.current_hdr[3 * i + 1] = radiance.y; O.current_hdr[3 * i + 2] = radiance.z; }      // a migrated path's consumer writes the radiance
+        O.g_albedo[3 * i + 0] = g_albedo.x; O.g_albedo[3 * i + 1] = g_albedo.y; O.g_albedo[3 * i + 2] = g_albedo.z;
+        O.g_normal[3 * i + 0] = g_normal.x; O.g_normal[3 * i + 1] = g_normal.y; O.g_normal[3 * i + 2] = g_normal.z;
+        O.g_depth[i] = g_depth;
+        O.sky[i] = is_sky ? 1 : 0;
+        if (DEBUG) {
+            if (O.prim_id) O.prim_id[i] = g_prim;
+            if (O.sub_id) O.sub_id[i] = g_sub;
+            if (O.hit_t) O.hit_t[i] = g_depth;
+            if (O.rng_state && !migrated) O.rng_state[i] = rng;
+        }
+    }
+    // a part of a split block sees fewer lanes, hence fewer iterations than the whole block would: scaled so that the block
+    // stays in its schedule class from frame to frame (x 1.5 for 4 parts, x 2 for 16, x 2.5 for 64: measured ratios are 1.3-2)
+    const uint32_t part_iters = WAVES3 ? F->iters[0] + F->iters[1] + F->iters[2] : wave_iters;
+    const uint32_t wave_max_steps = part_iters + ((part_iters * lg) >> 2);
+    if (O.block_cost && lane == 0) atomicMax(O.block_cost + bid, wave_max_steps);      // feedback for the next frame's schedule
+    if (prof && lane == 0 && YCGE_ENT_PART(ent) == 0) {
+        unsigned long long *dst = O.wave_prof + ((size_t)k * 4 + wave_in_tile) * 4;
+        dst[0] = t_start; dst[1] = __builtin_amdgcn_s_memrealtime(); dst[2] = sched_index | ((unsigned long long)wave_max_steps << 32);
+        dst[3] = __builtin_amdgcn_s_getreg(((32 - 1) << 11) | (0 << 6) | 20) | ((unsigned long long)(lg | (WAVES3 ? 8u : 0u)) << 32);   // XCC_ID; bit 3 = fanned block
+    }
+    };
+
   for (;;) {          // FAN: one round = stage A (wavefront 0 consumes answers, posts queries) + stage B (all trace)
    if (!FAN || wave == 0) {
     for (;;) {
-        if (!__any(phase != PH_DONE && !parked)) break;
         float t_hit = 0.0f;
         int hit_prim = -1, hit_sub = 0;
+        if (MIG && consuming) {
+            // ---- consumer round: refill idle lanes, advance every live query a bounded number of steps, then TraceFull's code below for
+            // the lanes whose query has ended (batched: the shading code is long, it runs when enough lanes wait for it)
+            unsigned long long idle = __ballot(phase == PH_DONE);
+            while (idle != 0ull && !mig_dry) {
+                if (seg_next == seg_end) {
+                    // claim the oldest published segment nobody has taken (wave-uniform; lane 0 talks to memory)
+                    unsigned long long word = 0;
+                    int got = 0;
+                    if (lane == 0) {
+                        unsigned long long h = __hip_atomic_load(&O.mig_ctl[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        const unsigned long long t = __hip_atomic_load(&O.mig_ctl[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        if (h < t) {
+                            if (__hip_atomic_compare_exchange_strong(&O.mig_ctl[1], &h, h + 1ull, __ATOMIC_RELAXED, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) {
+                                unsigned long long *slot = O.mig_pub + (h % (unsigned long long)O.mig_ring);
+                                // the publisher took index h before it stored the word: it is a few instructions away
+                                for (uint32_t spin = 0; spin < (1u << 26); spin++) {
+                                    word = __hip_atomic_load(slot, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT);
+                                    if (word != 0ull) break;
+                                    __builtin_amdgcn_s_sleep(2);
+                                }
+                                __hip_atomic_store(slot, 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);       // the ring entry is free again
+                                got = word != 0ull ? 1 : 2;        // 2: gave up on a publisher that never came (cannot happen; never hang)
+                            } else got = 3;                         // somebody else took it: look again
+                        }
+                    }
+                    got = __builtin_amdgcn_readfirstlane(got);
+                    if (got == 0 || got == 2) { mig_dry = true; break; }
+                    if (got == 3) continue;
+                    const uint32_t w_lo = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)word);
+                    const uint32_t w_hi = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(word >> 32));
+                    const unsigned long long ww = ((unsigned long long)(w_hi & 0x7fffffffu) << 32) | w_lo;
+                    seg_next = (uint32_t)(ww >> 8);
+                    seg_end = seg_next + (uint32_t)(ww & 0xffu);
+                    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");      // every lane reads the segment's entries after lane 0 has seen the word
+                    continue;
+                }
+                const uint32_t avail = seg_end - seg_next, n_idle = (uint32_t)__popcll(idle);
+                const uint32_t take = avail < n_idle ? avail : n_idle;
+                const uint32_t rk = __builtin_amdgcn_mbcnt_hi((uint32_t)(idle >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)idle, 0u));
+                if (phase == PH_DONE && rk < take) {
+                    const float4 *e4 = (const float4 *)(O.mig_entries + (seg_next + rk));
+                    const float4 ea = e4[0], eb = e4[1], ec = e4[2], ed = e4[3];
+                    q.o = f3(ea.x, ea.y, ea.z); q.d = f3(ea.w, eb.x, eb.y); q.tmin = 0.001f; q.tmax = YCGE_FLT_MAX; q.anyhit = false;
+                    beta = f3(eb.z, eb.w, ec.x);
+                    radiance = f3(ec.y, ec.z, ec.w);
+                    rng = (uint64_t)__float_as_uint(ed.x) | ((uint64_t)__float_as_uint(ed.y) << 32);
+                    mig_pixel = __float_as_uint(ed.z);
+                    mirror_depth = (int)(__float_as_uint(ed.w) & 15u); diffuse_depth = (int)((__float_as_uint(ed.w) >> 4) & 15u);
+                    psp = 0; item_is_primary = false; primary_hit_something = true; gbuf_valid = true; is_sky = false;
+                    phase = PH_PATH; need_begin = true;
+                }
+                seg_next += take;
+                idle = __ballot(phase == PH_DONE);
+            }
+            if (!__any(phase != PH_DONE)) {
+                if (!mig_dry) continue;
+                // nothing in flight and nothing published when we last looked: look once more, then leave
+                int more = 0;
+                if (lane == 0) more = __hip_atomic_load(&O.mig_ctl[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < __hip_atomic_load(&O.mig_ctl[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) ? 1 : 0;
+                if (__builtin_amdgcn_readfirstlane(more)) { mig_dry = false; continue; }
+                break;
+            }
+            if (mig_dry && seg_next == seg_end) {       // while some lanes still work, new segments may have been published
+                int more = 0;
+                if (lane == 0) more = __hip_atomic_load(&O.mig_ctl[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < __hip_atomic_load(&O.mig_ctl[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) ? 1 : 0;
+                if (__builtin_amdgcn_readfirstlane(more)) mig_dry = false;
+            }
+            if (phase != PH_DONE && need_begin) { flat_begin<COUNT>(S, q, st, mq, w); need_begin = false; }
+            bool fin = false;
+            if (phase != PH_DONE) fin = flat_advance<COUNT, true>(S, st, mq, w, O.mig_round_steps);
+            const uint32_t n_fin = (uint32_t)__popcll(__ballot(fin)), n_trav = (uint32_t)__popcll(__ballot(phase != PH_DONE && !fin));
+            const bool shade_now = n_fin > 0u && (n_fin >= (uint32_t)O.mig_shade_min || n_trav == 0u || mig_wait >= 3u);
+            mig_wait = (n_fin > 0u && !shade_now) ? mig_wait + 1u : 0u;
+            if (!shade_now || !fin) continue;
+            t_hit = mq.closest; hit_prim = mq.hit_prim; hit_sub = mq.hit_sub;
+            need_begin = true;              // whatever query TraceFull asks for next starts afresh
+        } else {
+        if (!__any(phase != PH_DONE && !parked)) {
+            if (!mig_on) break;
+            // ---- the block is done: write it out, publish its segment of migrated paths, turn consumer
+            finish_block();
+            const uint32_t n_mig = *s_nmig;
+            if (n_mig > 0u) {
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");      // the entries of every lane are out before the word is
+                if (lane == 0) {
+                    const unsigned long long idx = __hip_atomic_fetch_add(&O.mig_ctl[0], 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    const unsigned long long base_entry = (unsigned long long)bid * 64ull + (unsigned long long)(YCGE_ENT_PART(ent) * (uint32_t)live_lanes);
+                    __hip_atomic_store(O.mig_pub + (idx % (unsigned long long)O.mig_ring), ((base_entry << 8) | (unsigned long long)n_mig) | (1ull << 63), __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+                }
+            }
+            consuming = true;
+            phase = PH_DONE;
+            continue;
+        }
         const uint32_t steps_before = w.steps;
-        if (phase != PH_DONE && !parked) {
+        // cooperative record fetch (flat scenes, the timed kernels): every lane enters the query, lanes without one with live = false
+        constexpr bool COOPQ = YCGE_COOP_FETCH && FLAT && !COUNT;
+        if (!FAN && COOPQ) {
+            q.live = phase != PH_DONE;
+            traverse<COUNT, true, FLAT, true>(S, q, st, t_hit, hit_prim, hit_sub, w);
+        } else if (phase != PH_DONE && !parked) {
             if (!FAN) traverse<COUNT, true, FLAT>(S, q, st, t_hit, hit_prim, hit_sub, w);
             else if (want == 3) { t_hit = pre_b_t; hit_prim = pre_b_prim; hit_sub = pre_b_sub; }
             else { t_hit = F->r[want][0][lane]; hit_prim = __float_as_int(F->r[want][1][lane]); hit_sub = __float_as_int(F->r[want][2][lane]); }
         }
         if (!FAN) wave_iters += wave_umax(w.steps - steps_before);
         if (phase == PH_DONE || parked) continue;
+        }
         const bool hit = hit_prim >= 0;
         int new_kind = 0;       // the next query: 1 = first shadow segment towards `light`, 2 = bounce, 0 = anything else
         bool fanned = false;
@@ -900,6 +1054,28 @@ __device__ __forceinline__ void trace_block(const SceneDev &S, const FrameParams
             }
         }
 
+        if (MIG && mig_on) {
+            if (!consuming) {
+                // hand the path over: its next query is a path query (bounce, mirror continuation, popped item) and nothing is stacked
+                if (phase == PH_PATH && psp == 0) {
+                    const uint32_t slot = atomicAdd(s_nmig, 1u);
+                    float4 *e4 = (float4 *)(O.mig_entries + ((size_t)bid * 64u + (size_t)(YCGE_ENT_PART(ent) * (uint32_t)live_lanes) + slot));
+                    e4[0] = make_float4(q.o.x, q.o.y, q.o.z, q.d.x);
+                    e4[1] = make_float4(q.d.y, q.d.z, beta.x, beta.y);
+                    e4[2] = make_float4(beta.z, radiance.x, radiance.y, radiance.z);
+                    e4[3] = make_float4(__uint_as_float((uint32_t)rng), __uint_as_float((uint32_t)(rng >> 32)), __uint_as_float((uint32_t)px + (uint32_t)py * (uint32_t)P.hiW),
+                                        __uint_as_float((uint32_t)mirror_depth | ((uint32_t)diffuse_depth << 4)));
+                    migrated = true;
+                    phase = PH_DONE;
+                }
+            } else if (phase == PH_DONE) {
+                // a migrated path has ended: its radiance is the pixel's (RaytraceRenderer.cs:210)
+                float *dst = O.current_hdr + 3 * (size_t)mig_pixel;
+                dst[0] = radiance.x; dst[1] = radiance.y; dst[2] = radiance.z;
+                if (DEBUG && O.rng_state) O.rng_state[mig_pixel] = rng;
+            }
+        }
+
         if (FAN && phase != PH_DONE) {                  // where is the answer to the query just set up?
             if (new_kind == 1 && light == pre_l1) { want = 1; pre_l1 = -1; }
             else if (new_kind == 1 && light == pre_l2) { want = 2; pre_l2 = -1; }
@@ -917,7 +1093,17 @@ __device__ __forceinline__ void trace_block(const SceneDev &S, const FrameParams
        // ---- stage B: wavefront w answers slot w
        const float f_tmin = F->q[wave][3][lane];
        const uint32_t steps_before = w.steps;
-       if (f_tmin >= 0.0f) {
+       constexpr bool COOPB = YCGE_COOP_FETCH && FLAT && !COUNT;
+       if (COOPB) {
+           RayQ fq = fan_query(F, wave, lane);
+           fq.live = f_tmin >= 0.0f;
+           float f_t; int f_prim, f_sub;
+           traverse<COUNT, true, FLAT, true>(S, fq, st, f_t, f_prim, f_sub, w);
+           if (fq.live) {
+               F->r[wave][0][lane] = f_t; F->r[wave][1][lane] = __int_as_float(f_prim); F->r[wave][2][lane] = __int_as_float(f_sub);
+               F->q[wave][3][lane] = -1.0f;
+           }
+       } else if (f_tmin >= 0.0f) {
            const RayQ fq = fan_query(F, wave, lane);
            float f_t; int f_prim, f_sub;
            traverse<COUNT, true, FLAT>(S, fq, st, f_t, f_prim, f_sub, w);
@@ -974,30 +1160,7 @@ __device__ __forceinline__ void trace_block(const SceneDev &S, const FrameParams
         __syncthreads();
         if (wave != 0) { flush_work<COUNT>(w, O.counters); return; }
     }
-    if (in_image) {                                     // :210-215
-        const size_t i = (size_t)px + (size_t)py * P.hiW;
-        O.current_hdr[3 * i + 0] = radiance.x; O.current_hdr[3 * i + 1] = radiance.y; O.current_hdr[3 * i + 2] = radiance.z;
-        O.g_albedo[3 * i + 0] = g_albedo.x; O.g_albedo[3 * i + 1] = g_albedo.y; O.g_albedo[3 * i + 2] = g_albedo.z;
-        O.g_normal[3 * i + 0] = g_normal.x; O.g_normal[3 * i + 1] = g_normal.y; O.g_normal[3 * i + 2] = g_normal.z;
-        O.g_depth[i] = g_depth;
-        O.sky[i] = is_sky ? 1 : 0;
-        if (DEBUG) {
-            if (O.prim_id) O.prim_id[i] = g_prim;
-            if (O.sub_id) O.sub_id[i] = g_sub;
-            if (O.hit_t) O.hit_t[i] = g_depth;
-            if (O.rng_state) O.rng_state[i] = rng;
-        }
-    }
-    // a part of a split block sees fewer lanes, hence fewer iterations than the whole block would: scaled so that the block
-    // stays in its schedule class from frame to frame (x 1.5 for 4 parts, x 2 for 16, x 2.5 for 64: measured ratios are 1.3-2)
-    const uint32_t part_iters = WAVES3 ? F->iters[0] + F->iters[1] + F->iters[2] : wave_iters;
-    const uint32_t wave_max_steps = part_iters + ((part_iters * lg) >> 2);
-    if (O.block_cost && lane == 0) atomicMax(O.block_cost + bid, wave_max_steps);      // feedback for the next frame's schedule
-    if (prof && lane == 0 && YCGE_ENT_PART(ent) == 0) {
-        unsigned long long *dst = O.wave_prof + ((size_t)k * 4 + wave_in_tile) * 4;
-        dst[0] = t_start; dst[1] = __builtin_amdgcn_s_memrealtime(); dst[2] = sched_index | ((unsigned long long)wave_max_steps << 32);
-        dst[3] = __builtin_amdgcn_s_getreg(((32 - 1) << 11) | (0 << 6) | 20) | ((unsigned long long)(lg | (WAVES3 ? 8u : 0u)) << 32);   // XCC_ID; bit 3 = fanned block
-    }
+    if (!mig_on) finish_block();
     flush_work<COUNT>(w, O.counters);
 }
 
@@ -1014,13 +1177,14 @@ __device__ __forceinline__ void trace_block(const SceneDev &S, const FrameParams
 template <bool COUNT, bool FLAT>
 __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu((FLAT && !COUNT) ? YCGE_TRACE_WAVES : 2, 8))) void k_trace(const SceneDev S, const FrameParams P, const TraceOut O)
 {
+    __shared__ uint32_t s_nmig;
     uint32_t idx = blockIdx.x, ent = blockIdx.x;
     if (O.block_order) {
         if (O.n_fan) idx += *O.n_fan;           // the first n_fan entries belong to k_trace_fan
         if (idx >= *O.n_order) return;
         ent = O.block_order[idx];
     } else if (blockIdx.x >= (uint32_t)P.n_owned_tiles * 4u) return;
-    trace_block<COUNT, FLAT, 0>(S, P, O, ent, idx, nullptr, 0);
+    trace_block<COUNT, FLAT, 0, YCGE_MIGRATE && FLAT && !COUNT>(S, P, O, ent, idx, nullptr, 0, &s_nmig);
 }
 template <bool COUNT>
 __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(COUNT ? 2 : 3, 8))) void k_trace_refill(const SceneDev S, const FrameParams P, const TraceOut O, const int refill_steps)

@@ -42,6 +42,7 @@ struct RayQ {              // one closest-hit query: Scene.Hit(r, tMin, tMax)
     // (RaytraceRenderer.cs:761-765, 773-781).  Such a query may stop at its first accepted hit: same radiance, fewer
     // steps.  The counting variants never do (their counters are the reference's full traversal).
     bool anyhit = false;
+    bool live = true;          // cooperative-fetch callers enter traverse() with every lane of the wavefront; lanes without a query carry live = false
 };
 
 struct Work {              // SURVEY 8(d) counters (COUNT variants) + this lane's traversal steps (always; scheduling feedback)
@@ -631,6 +632,7 @@ __device__ __forceinline__ u32x2 lds_read_b64(uint32_t byte_addr)
 }
 template <int BS>
 struct StackT {
+    static constexpr int kBS = BS;
     uint2 *spill;          // this lane's column of the spill area
     uint32_t spill_stride; // lanes in the grid
     uint32_t lds_base;     // LDS byte address of this lane's level-0 slot (levels are BS * 8 bytes apart)
@@ -892,6 +894,27 @@ __device__ __forceinline__ void walk(const SceneDev &S, uint32_t cur, int mesh_p
 // a node (64 B) or a triangle pair record (its first 72 B) in one round trip: every fetch is issued before the
 // single wait.  The fifth fetch only has a use for leaf lanes; for node lanes it reads the start of the next
 // node (the arrays are padded at upload).
+// Variant (-DYCGE_LEAF_ONLY_TAIL=1): the last 8 bytes are fetched by the lanes that are at a LEAF only (exec masked for that one
+// instruction).  Every load instruction of a divergent wavefront costs the texture-address unit one look-up per lane
+// (profiles/micro/fetchrate.hip: 4 + 1 loads per lane 2.08 us per wave-step at 4 wavefronts per SIMD, 4 loads 1.44 us), and three
+// steps in four are node visits.
+__device__ __forceinline__ void load_record72_leaf_tail(const uint8_t *base, uint32_t byte_offset, unsigned long long leaf_mask, f32x4 &a, f32x4 &b,
+                                                        f32x4 &c, f32x4 &e, f32x2 &f)
+{
+    unsigned long long saved;
+    f = f32x2{0.0f, 0.0f};
+    asm volatile("global_load_dwordx4 %0, %6, %7\n\t"
+                 "global_load_dwordx4 %1, %6, %7 offset:16\n\t"
+                 "global_load_dwordx4 %2, %6, %7 offset:32\n\t"
+                 "global_load_dwordx4 %3, %6, %7 offset:48\n\t"
+                 "s_and_saveexec_b64 %5, %8\n\t"
+                 "global_load_dwordx2 %4, %6, %7 offset:64\n\t"
+                 "s_mov_b64 exec, %5\n\t"
+                 "s_waitcnt vmcnt(0)"
+                 : "=&v"(a), "=&v"(b), "=&v"(c), "=&v"(e), "+v"(f), "=&s"(saved)
+                 : "v"(byte_offset), "s"(base), "s"(leaf_mask)
+                 : "memory", "scc");
+}
 __device__ __forceinline__ void load_record72(const uint8_t *base, uint32_t byte_offset, f32x4 &a, f32x4 &b, f32x4 &c, f32x4 &e, f32x2 &f)
 {
     asm volatile("global_load_dwordx4 %0, %5, %6\n\t"
@@ -904,7 +927,64 @@ __device__ __forceinline__ void load_record72(const uint8_t *base, uint32_t byte
                  : "v"(byte_offset), "s"(base)
                  : "memory");
 }
-template <bool COUNT, bool BOUNDED = false, class STK>
+// ---- quad-cooperative record fetch (full wavefronts) ----------------------------------------------------------------------------
+// When every lane of a wavefront fetches its own record, each load instruction costs the texture-address unit one look-up PER LANE:
+// 4 x dwordx4 + 1 x dwordx2 = 320 look-ups per wave-step, and at 4 wavefronts per SIMD that unit - not HBM, not the VALU - sets the
+// pace (profiles/micro/fetchrate.hip: 2.08 us per wave-step, memory side alone, against 0.53 us when the four lanes of a QUAD read
+// the four 16-byte chunks of ONE record, which coalesce into a single look-up).  So: instruction r fetches the record of the quad's
+// lane r, lane j of the quad taking chunk j - by LDS-DMA (global_load_lds_dwordx4: no VGPR, no ds_write), plane r, slot = lane -
+// and every lane then reads its own record back with four ds_read_b128 (plane = its quad lane, slots of its quad).  The leaf
+// lanes' last 8 bytes stay a per-lane load.  Same bytes, same values; a sparse wavefront keeps the direct form (shorter chain).
+#define YCGE_COOP_PLANE 1040u           // 64 x 16 bytes + 16 of padding: the four planes a quad reads fall on different banks
+#ifndef YCGE_COOP_MIN_LANES
+#define YCGE_COOP_MIN_LANES 20          // live lanes from which the cooperative form is used
+#endif
+static __shared__ __attribute__((aligned(16))) uint8_t g_coop_planes64[4 * YCGE_COOP_PLANE];          // 64-thread workgroups (k_trace)
+static __shared__ __attribute__((aligned(16))) uint8_t g_coop_planes192[3][4 * YCGE_COOP_PLANE];      // 192-thread workgroups (k_trace_fan): per wavefront
+__device__ __forceinline__ void load_record72_coop(const uint8_t *base, uint32_t byte_offset, unsigned long long act_mask, unsigned long long leaf_mask,
+                                                   uint32_t lds_planes, f32x4 &a, f32x4 &b, f32x4 &c, f32x4 &e, f32x2 &f)
+{
+    const uint32_t lane = threadIdx.x & 63u, j = lane & 3u;
+    // byte offset of chunk j of the record of quad lane r (DPP quad broadcast; a disabled lane's value is never used: its instruction is masked)
+    const uint32_t o0 = (uint32_t)__builtin_amdgcn_mov_dpp((int)byte_offset, 0x00, 0xf, 0xf, true) + j * 16u;
+    const uint32_t o1 = (uint32_t)__builtin_amdgcn_mov_dpp((int)byte_offset, 0x55, 0xf, 0xf, true) + j * 16u;
+    const uint32_t o2 = (uint32_t)__builtin_amdgcn_mov_dpp((int)byte_offset, 0xaa, 0xf, 0xf, true) + j * 16u;
+    const uint32_t o3 = (uint32_t)__builtin_amdgcn_mov_dpp((int)byte_offset, 0xff, 0xf, 0xf, true) + j * 16u;
+    // lanes whose quad lane r is live: bit 4q + r of act_mask spread over quad q
+    const unsigned long long q1 = 0x1111111111111111ull;
+    unsigned long long m0 = act_mask & q1, m1 = (act_mask >> 1) & q1, m2 = (act_mask >> 2) & q1, m3 = (act_mask >> 3) & q1;
+    m0 = (m0 << 4) - m0; m1 = (m1 << 4) - m1; m2 = (m2 << 4) - m2; m3 = (m3 << 4) - m3;
+    unsigned long long saved;
+    unsigned keep;
+    f = f32x2{0.0f, 0.0f};
+    asm volatile("s_mov_b64 %1, exec\n\t"
+                 "s_mov_b32 %2, m0\n\t"
+                 "s_mov_b32 m0, %9\n\t"
+                 "s_mov_b64 exec, %10\n\t"
+                 "global_load_lds_dwordx4 %3, %8\n\t"
+                 "s_add_u32 m0, m0, 1040\n\t"
+                 "s_mov_b64 exec, %11\n\t"
+                 "global_load_lds_dwordx4 %4, %8\n\t"
+                 "s_add_u32 m0, m0, 1040\n\t"
+                 "s_mov_b64 exec, %12\n\t"
+                 "global_load_lds_dwordx4 %5, %8\n\t"
+                 "s_add_u32 m0, m0, 1040\n\t"
+                 "s_mov_b64 exec, %13\n\t"
+                 "global_load_lds_dwordx4 %6, %8\n\t"
+                 "s_mov_b64 exec, %14\n\t"
+                 "global_load_dwordx2 %0, %7, %8 offset:64\n\t"
+                 "s_mov_b64 exec, %1\n\t"
+                 "s_mov_b32 m0, %2\n\t"
+                 "s_waitcnt vmcnt(0)"
+                 : "+v"(f), "=&s"(saved), "=&s"(keep)
+                 : "v"(o0), "v"(o1), "v"(o2), "v"(o3), "v"(byte_offset), "s"(base), "s"(lds_planes), "s"(m0), "s"(m1), "s"(m2), "s"(m3), "s"(leaf_mask)
+                 : "memory", "scc");
+    const uint32_t rd = lds_planes + j * YCGE_COOP_PLANE + (lane & ~3u) * 16u;
+    asm volatile("ds_read_b128 %0, %4\n\tds_read_b128 %1, %4 offset:16\n\tds_read_b128 %2, %4 offset:32\n\tds_read_b128 %3, %4 offset:48\n\t"
+                 "s_waitcnt lgkmcnt(0)" : "=&v"(a), "=&v"(b), "=&v"(c), "=&v"(e) : "v"(rd) : "memory");
+}
+
+template <bool COUNT, bool BOUNDED = false, bool COOP = false, class STK>
 __device__ __forceinline__ void mesh_walk(const SceneDev &S, uint32_t &cur, int mesh_prim, STK &st, F3 o, F3 inv, F3 d, bool sx, bool sy,
                                           bool sz, float tmin, float &closest, int &hit_prim, int &hit_sub, Work &w, int budget = 0x7fffffff,
                                           bool anyhit = false)
@@ -915,12 +995,30 @@ __device__ __forceinline__ void mesh_walk(const SceneDev &S, uint32_t &cur, int 
     // direction sign afterwards picks the same values.
     const f32x2 oxy = {o.x, o.y}, ozz = {o.z, o.z};
     const f32x2 ixy = {inv.x, inv.y}, izz = {inv.z, inv.z};
-    while (cur != YCGE_REF_NONE_VALUE && (!BOUNDED || budget-- > 0)) {      // budget: refill mode yields with the walk's state in (cur, stack)
+    // COOP: the caller enters with EVERY lane of the wavefront (lanes without a query carry cur = none), and the loop is wave-uniform:
+    // lanes that are done keep fetching chunks for their quad mates
+    const uint32_t coop_planes = !COOP ? 0u : (uint32_t)__builtin_amdgcn_readfirstlane((int)(STK::kBS == 64 ? (uint32_t)(uintptr_t)g_coop_planes64 : (uint32_t)(uintptr_t)g_coop_planes192[threadIdx.x >> 6]));
+    for (;;) {
+        const bool act = cur != YCGE_REF_NONE_VALUE && (!BOUNDED || budget > 0);      // budget: refill mode yields with the walk's state in (cur, stack)
+        unsigned long long act_mask = 0;
+        if (COOP) { act_mask = __ballot(act); if (act_mask == 0ull) break; }
+        else if (!act) break;
+        if (BOUNDED) budget--;
         const bool is_node = YCGE_REF_KIND(cur) == REF_MESH_NODE;
         const uint32_t unit2 = (cur & 0x1ffffff0u) >> 3;       // record's 32-byte unit, times two
         f32x4 a, b, c, e;
         f32x2 f;
-        load_record72(S.mesh_arena, unit2 << 4, a, b, c, e, f);
+        if (COOP && __popcll(act_mask) >= YCGE_COOP_MIN_LANES) {
+            load_record72_coop(S.mesh_arena, act ? unit2 << 4 : 0u, act_mask, __ballot(act && !is_node), coop_planes, a, b, c, e, f);
+            if (!act) continue;
+        } else {
+            if (COOP && !act) continue;
+#if defined(YCGE_LEAF_ONLY_TAIL) && YCGE_LEAF_ONLY_TAIL
+            load_record72_leaf_tail(S.mesh_arena, unit2 << 4, __ballot(!is_node), a, b, c, e, f);
+#else
+            load_record72(S.mesh_arena, unit2 << 4, a, b, c, e, f);
+#endif
+        }
         if (COUNT) prof_tick(0);
         w.steps++;
         uint32_t next;
@@ -958,7 +1056,7 @@ __device__ __forceinline__ void mesh_walk(const SceneDev &S, uint32_t &cur, int 
 // the reference): the object list is walked in leaf order with WAVE-UNIFORM control flow, so object records
 // come through the scalar cache and only the per-lane mesh walk diverges.  Otherwise the generic walk
 // starts at the scene root.  Both give the reference's visit order.
-template <bool COUNT, bool HAS_GRID, bool FLAT, class STK>
+template <bool COUNT, bool HAS_GRID, bool FLAT, bool COOP = false, class STK>
 __device__ __forceinline__ void traverse(const SceneDev &S, const RayQ &q, STK &st, float &closest, int &hit_prim, int &hit_sub, Work &w)
 {
     const F3 o = q.o, d = q.d;
@@ -967,14 +1065,15 @@ __device__ __forceinline__ void traverse(const SceneDev &S, const RayQ &q, STK &
     hit_prim = -1;
     hit_sub = 0;
     st.reset();
-    if (COUNT) w.rays++;
+    const bool live = !COOP || q.live;
+    if (COUNT && live) w.rays++;
     if (S.scene_root_ref == YCGE_REF_NONE_VALUE) return;
     const F3 inv = f3(1.0f / d.x, 1.0f / d.y, 1.0f / d.z);
     const bool sx = inv.x < 0.0f, sy = inv.y < 0.0f, sz = inv.z < 0.0f;
     float tn;
-    if (COUNT) w.box++;
+    if (COUNT && live) w.box++;
     const bool root_hit = box_scene(S.scene_root_min[0], S.scene_root_min[1], S.scene_root_min[2], S.scene_root_max[0], S.scene_root_max[1],
-                                    S.scene_root_max[2], o, inv, tmin, closest, tn);
+                                    S.scene_root_max[2], o, inv, tmin, closest, tn) && live;
     const bool anyhit = !COUNT && q.anyhit;
     if (!FLAT) {
         walk<COUNT, HAS_GRID>(S, root_hit ? S.scene_root_ref : YCGE_REF_NONE_VALUE, -1, st, o, d, inv, sx, sy, sz, tmin, closest, hit_prim, hit_sub, w, anyhit);
@@ -996,7 +1095,7 @@ __device__ __forceinline__ void traverse(const SceneDev &S, const RayQ &q, STK &
                 if (COUNT) w.box++;
                 if (box_mesh(q1.x, q1.y, q1.z, q1.w, q2.x, q2.y, o, inv, sx, sy, sz, tmin, closest, tm)) start = root_ref;
             }
-            mesh_walk<COUNT>(S, start, pi, st, o, inv, d, sx, sy, sz, tmin, closest, hit_prim, hit_sub, w, 0x7fffffff, anyhit);     // start is consumed
+            mesh_walk<COUNT, false, COOP && FLAT>(S, start, pi, st, o, inv, d, sx, sy, sz, tmin, closest, hit_prim, hit_sub, w, 0x7fffffff, anyhit);     // start is consumed
         } else if (type == 10) {
             if (HAS_GRID) { if (root_hit && !(anyhit && hit_prim >= 0)) grid_dda<COUNT>(S, __float_as_int(q0.z), pi, o, d, inv, tmin, closest, hit_prim, hit_sub, w); }
         } else {
