@@ -221,7 +221,7 @@ typedef struct ycge_frame_stats {
     uint64_t n_prim;             /* analytic primitive tests (box = 6 rects)    */
     uint64_t n_vox;              /* DDA cells visited                           */
     float exposure;              /* ToneMapper.EffectiveExposure                */
-    float reserved2;
+    float exposure_serial_chunks;/* diagnostics: 512-term chunks of the exposure sum that took the one-by-one path */
 } ycge_frame_stats;
 
 typedef enum ycge_buffer {

@@ -11,4 +11,4 @@ r = RaytraceRenderer(sc, w, h, pose["fov"], ss)
 r.SetCamera(pose["pos"], pose["yaw"], pose["pitch"])
 for i in range(4):
     t = time.time(); r.TryFlipAndBlit(want_sdr=True); dt = time.time() - t
-    print(f"frame {i+1}: trace {r.stats.trace_ms:.3f} taa {r.stats.taa_ms:.3f} post {r.stats.post_ms:.3f} ms, wall {dt*1e3:.1f} ms, exposure {r.stats.exposure:.5f}")
+    print(f"frame {i+1}: trace {r.stats.trace_ms:.3f} taa {r.stats.taa_ms:.3f} post {r.stats.post_ms:.3f} ms, wall {dt*1e3:.1f} ms, exposure {r.stats.exposure:.5f} serial chunks {r.stats.exposure_serial_chunks:.0f}")

@@ -1,6 +1,6 @@
 #!/bin/bash
 REPO=${GRAFT_REPO_ROOT:-/root/repo}; cd /tmp && export TMPDIR=/tmp
-rocprofv3 --kernel-trace --stats -f csv -d $REPO/gpurun_out/prof_post -o t -- python3 $REPO/profiles/post_prof.py 4 2>&1 | grep "^frame"
+timeout 300 rocprofv3 --kernel-trace --stats -f csv -d $REPO/gpurun_out/prof_post -o t -- python3 $REPO/profiles/post_prof.py 4 2>&1 | grep "^frame"
 python3 - <<PY
 import csv
 for row in csv.DictReader(open("$REPO/gpurun_out/prof_post/t_kernel_stats.csv")):

@@ -28,7 +28,9 @@ def chunked_sum(terms, CH=512):
         neg = 1 if s0 < 0 else 0
         e = math.frexp(abs(s0))[1] - 1 if abs(s0) >= 1e-30 else -1000
         C = dict(e=e, neg=neg, d=[0, 0], lo=[0, 0], hi=[0, 0])
-        if -12 <= e < 100:
+        if not np.any(terms[c * CH:(c + 1) * CH]):
+            C["e"] = -2000                      # nothing but + 0.0f: leaves any sum as it is
+        elif -12 <= e < 100:
             inv_u = (2.0 ** (23 - e)) * (-1.0 if neg else 1.0)
             d, lo, hi, p = [0, 0], [0, 0], [0, 0], [0, 1]
             for t in terms[c * CH:(c + 1) * CH]:
@@ -44,10 +46,41 @@ def chunked_sum(terms, CH=512):
                     hi[k] = max(hi[k], d[k])
             C.update(d=d, lo=lo, hi=hi)
         chunks.append(C)
+    # groups of 16 chunks composed into one map (the kernel's two-level walk)
+    groups = []
+    for g0 in range(0, nch - 15, 16):
+        ok = all(chunks[g0 + j]["e"] == -2000 or (chunks[g0 + j]["e"] == chunks[g0]["e"] and chunks[g0 + j]["neg"] == chunks[g0]["neg"] and chunks[g0]["e"] > -1000)
+                 for j in range(16))
+        G = dict(ok=ok, d=[0, 0], lo=[0, 0], hi=[0, 0])
+        for pin in (0, 1):
+            D, L, H, P = 0, 0, 0, pin
+            for j in range(16):
+                Ck = chunks[g0 + j]
+                if Ck["e"] == -2000:
+                    continue
+                L = min(L, D + Ck["lo"][P]); H = max(H, D + Ck["hi"][P])
+                dk = Ck["d"][P]
+                D += dk
+                P = (P + dk) & 1
+            G["d"][pin], G["lo"][pin], G["hi"][pin] = D, L, H
+        groups.append(G)
     s, n_serial = np.float32(0), 0
-    for c in range(nch):                                                                            # phase C
+    c = 0
+    while c < nch:                                                                                  # phase C
         C = chunks[c]
         bits = f2u(float(s))
+        if C["e"] == -2000:
+            c += 1
+            continue
+        if c % 16 == 0 and c // 16 < len(groups) and groups[c // 16]["ok"]:
+            G = groups[c // 16]
+            ex0 = (bits >> 23) & 0xff
+            m0 = (bits & 0x7fffff) | 0x800000
+            p0 = m0 & 1
+            if ex0 != 0 and ex0 - 127 == C["e"] and (bits >> 31) == C["neg"] and m0 + G["lo"][p0] > (1 << 23) and m0 + G["hi"][p0] < (1 << 24):
+                s = np.float32(u2f((bits & 0xff800000) | ((m0 + G["d"][p0]) & 0x7fffff)))
+                c += 16
+                continue
         ex = (bits >> 23) & 0xff
         m = (bits & 0x7fffff) | 0x800000
         p = m & 1
@@ -58,6 +91,7 @@ def chunked_sum(terms, CH=512):
             for t in terms[c * CH:(c + 1) * CH]:
                 s = np.float32(s + t)
             n_serial += 1
+        c += 1
     return s, n_serial, nch
 
 
@@ -69,6 +103,7 @@ def test_chunked_evaluation_equals_the_serial_binary32_sum(trial):
     terms = np.log(np.float32(1e-6) + lum).astype(np.float32)
     if trial % 2:
         terms[rng.random(n) < 0.3] = np.float32(0)                      # skipped samples contribute +0
+        terms[:7000] = np.float32(0); terms[20000:23000] = np.float32(0)  # whole chunks of sky, at the start and inside
     if trial == 4:
         terms = np.abs(terms) * np.float32(0.01)                        # a positive, slowly growing sum
     if trial == 5:

@@ -33,7 +33,11 @@ def _assert_frame(o, g, label):
 def test_timed_mesh_kernels_full_size_steady_state(product_lib, oracle, monkeypatch, cfg_n, frames):
     """Configs 3 and 4 at full size, default path (single launch for mesh viewers), NON-counting kernels, capture on.
     Frame 1 has no schedule; from frame 2 on k_trace runs longest first; once the pinned fan count has come back (frame 3 or 4)
-    the head of the schedule runs in k_trace_fan<false,true> beside k_trace<false,true> - asserted through stats.fan_blocks."""
+    the head of the schedule runs in k_trace_fan<false,true> beside k_trace<false,true> - asserted through stats.fan_blocks.
+    (A library built with -DYCGE_MIGRATE=1 - the path-migration experiment of DESIGN section 5 - runs without the fan-out
+    kernel; it passes this test bit for bit too when YCGE_TEST_MIG=1 is set.)"""
+    import os
+    mig = os.environ.get("YCGE_TEST_MIG") == "1"
     monkeypatch.delenv("YCGE_PATH", raising=False)
     sc, w, h, ss, pose = scenes.config_scene(cfg_n)
     o, g = pu.run_pair(oracle, sc, w, h, ss, pose, frames=1, oracle_threads=64, count=False)
@@ -43,9 +47,11 @@ def test_timed_mesh_kernels_full_size_steady_state(product_lib, oracle, monkeypa
         o.render(stages=1, threads=64); g.TryFlipAndBlit()
         _assert_frame(o, g, f"cfg{cfg_n} timed variants frame {f}")
         fanned.append(int(g.stats.fan_blocks))
-    if cfg_n == 4:
-        assert fanned[-1] > 0 and fanned[-2] > 0, f"k_trace_fan never launched: {fanned}"      # the default 200-block fan-out is active
+    if cfg_n == 4 and not mig:
+        assert fanned[-1] > 0 and fanned[-2] > 0, f"k_trace_fan never launched: {fanned}"      # the 200-block fan-out is active
         assert fanned[-1] <= 200
+    if mig:
+        assert fanned[-1] == 0
     o.close(); g.close()
 
 

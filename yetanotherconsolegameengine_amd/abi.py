@@ -129,7 +129,7 @@ class FrameStats(C.Structure):
         ("frame", C.c_int64), ("history_reset", C.c_int32), ("fan_blocks", C.c_int32),
         ("trace_ms", C.c_double), ("taa_ms", C.c_double), ("post_ms", C.c_double), ("total_ms", C.c_double),
         ("n_rays", C.c_uint64), ("n_box", C.c_uint64), ("n_tri", C.c_uint64), ("n_prim", C.c_uint64),
-        ("n_vox", C.c_uint64), ("exposure", C.c_float), ("reserved2", C.c_float),
+        ("n_vox", C.c_uint64), ("exposure", C.c_float), ("exposure_serial_chunks", C.c_float),
     ]
 
 

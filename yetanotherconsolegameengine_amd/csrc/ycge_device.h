@@ -126,7 +126,7 @@ struct GLight {
     float pad;
 };
 
-#define YCGE_LDS_STACK_LEVELS 11    // levels of a lane's traversal stack kept in LDS; deeper ones go to the HBM spill area
+#define YCGE_LDS_STACK_LEVELS 12    // levels of a lane's traversal stack kept in LDS; deeper ones go to the HBM spill area
 #define YCGE_TRAVERSAL_STACK 96    // >= scene depth + 4 leaf prims + mesh depth, checked at upload
 #ifndef YCGE_COST_FRAMES
 #define YCGE_COST_FRAMES 4          // a block's schedule cost is its largest cost over this many frames
@@ -134,8 +134,12 @@ struct GLight {
 #define YCGE_SCHEDULE_SLACK 2u      // k_trace grid = blocks x this: room for the parts of split blocks
 #define YCGE_FAN_CAP_DEFAULT 2048u   // k_trace_fan: at most this many blocks of the schedule's head
 #define YCGE_REFILL_STEPS_DEFAULT 0
-#define YCGE_POST_BAND_ROWS_DEFAULT 16 // rows per band of the in-place A-trous iteration (at least 2 x step)
+#define YCGE_POST_BAND_ROWS_DEFAULT 8 // rows per band of the in-place A-trous iteration (at least 2 x step)
+#define YCGE_POST_GROUPS_DEFAULT 16    // pixels per pass of the banded in-place A-trous iteration (workgroup = 32 x this many threads)
 #define YCGE_POST_K_DEFAULT 8         // levels per launch of the banded in-place A-trous iteration
+#define YCGE_MIG_QUEUES 64u          // path migration: published segments are spread over this many queues (power of two)
+#define YCGE_MIG_SCAN 4              // ... of which a wavefront looks at this many neighbours (its own block's queue first)
+#define YCGE_MIG_CTL_STRIDE 64u      // ... whose {tail, head} pairs are this many 8-byte words apart (512 bytes)
 #define YCGE_TILE_W 32
 #define YCGE_TILE_H 8
 #define YCGE_SLAB_FLOATS 11        // hdr rgb, albedo rgb, normal xyz, depth, sky
@@ -229,8 +233,8 @@ struct TraceOut {
     const uint32_t *n_fan;              // the first *n_fan schedule entries are traced by k_trace_fan (null or 0: none)
     // traversal counters (may be null): rays, box, tri, prim, vox
     unsigned long long *counters;
-    // path migration (null = off): 64 MigEntry slots per 8x8 block; mig_pub = ring of published segments
-    // ((first entry << 8 | count) | 1 << 63, 0 = not yet written), mig_ctl = {tail, head} running counters (never reset)
+    // path migration (null = off): 64 MigEntry slots per 8x8 block; mig_pub = YCGE_MIG_QUEUES rings of mig_ring published segments
+    // ((first entry << 8 | count) | 1 << 63, 0 = not yet written), mig_ctl = per queue {tail, head} running counters on a 64-byte line (never reset)
     MigEntry *mig_entries;
     unsigned long long *mig_pub;
     unsigned long long *mig_ctl;

@@ -24,6 +24,7 @@
 
 extern "C" {
 size_t ycge_wf_sizes(int which);
+int ycge_kernel_has_migration(void);
 int ycge_launch_trace(const ycge::SceneDev *S, const ycge::FrameParams *P, const ycge::TraceOut *O, int count, int flat, int refill_steps,
                       hipStream_t stream);
 int ycge_launch_wavefront(const ycge::SceneDev *S, const ycge::FrameParams *P, const ycge::TraceOut *O, void *const bufs[7], int rounds,
@@ -38,9 +39,11 @@ size_t ycge_post_state_bytes(void);
 int ycge_launch_unit_normals(const float *normal, float *unit, size_t n, hipStream_t stream);
 int ycge_launch_atrous(int w, int h, int step, const float phi[4], const float *cur, float *dst, const float *albedo, const float *unit_n,
                        const float *depth, const uint8_t *sky, hipStream_t stream);
+int ycge_launch_atrous_static(int w, int h, int step, const float phi[4], const float *albedo, const float *unit_n, const float *depth,
+                              const uint8_t *sky, float *statw, hipStream_t stream);
 int ycge_launch_atrous_inplace(int w, int h, int step, const float phi[4], float *buf, const float *albedo, const float *unit_n,
                                const float *depth, const uint8_t *sky, float *statw, const uint32_t *d_pixels, const uint32_t *d_offsets,
-                               int n_levels, int n_bands, int K, hipStream_t stream);
+                               int n_levels, int n_bands, int K, int groups_per_pass, hipStream_t stream);
 size_t ycge_exposure_scratch_bytes(int w, int h, int step);
 int ycge_launch_exposure(const float *hdr, const uint8_t *sky, int w, int h, int step, float *terms, void *state, const float consts[5],
                          void *scratch, int serial, hipStream_t stream);
@@ -93,7 +96,7 @@ struct Knobs {
     int refill_steps = YCGE_REFILL_STEPS_DEFAULT;
     bool split_set = false; uint32_t split_policy = 0;
     int pw_per_cu = 32;
-    int post_band_rows = YCGE_POST_BAND_ROWS_DEFAULT, post_k = YCGE_POST_K_DEFAULT;
+    int post_band_rows = YCGE_POST_BAND_ROWS_DEFAULT, post_k = YCGE_POST_K_DEFAULT, post_groups = YCGE_POST_GROUPS_DEFAULT;
     int fan_class = -1, fan_cap = -1;   // -1 = default by world size
     int mig = 1, mig_round = 12, mig_shade = 16;      // YCGE_MIG (0 = off), YCGE_MIG_ROUND, YCGE_MIG_SHADE: path migration in k_trace
     int post_mode = 0;               // YCGE_POST_MODE: in-place A-trous implementation (0 = default)
@@ -109,6 +112,8 @@ struct Knobs {
         if (const char *e = getenv("YCGE_SPLIT")) { split_set = true; split_policy = (uint32_t)strtoul(e, nullptr, 8); }
         pw_per_cu = geti("YCGE_PW_PER_CU", 32);
         post_band_rows = geti("YCGE_POST_BAND_ROWS", YCGE_POST_BAND_ROWS_DEFAULT); post_k = geti("YCGE_POST_K", YCGE_POST_K_DEFAULT);
+        post_groups = geti("YCGE_POST_GROUPS", YCGE_POST_GROUPS_DEFAULT);
+        if (post_groups != 8 && post_groups != 16 && post_groups != 32) post_groups = YCGE_POST_GROUPS_DEFAULT;
         fan_class = geti("YCGE_FAN", -1); fan_cap = geti("YCGE_FAN_CAP", -1);
         post_mode = geti("YCGE_POST_MODE", 0);
         mig = geti("YCGE_MIG", 1); mig_round = geti("YCGE_MIG_ROUND", 12); mig_shade = geti("YCGE_MIG_SHADE", 16);
@@ -1184,16 +1189,17 @@ int trace_frame(ycge_ctx *c, float *d_slab, hipStream_t stream, FrameState &fs, 
         const bool lpt = !c->knobs.no_lpt;
         const uint32_t n_blocks = (uint32_t)c->n_owned * 4u;
         // path migration (flat scenes, the non-counting kernel): a block hands its bounce / mirror paths to whichever wavefront has idle lanes
-        const bool mig = flat && c->knobs.mig && !c->cfg.count_work && c->knobs.refill_steps <= 0 && n_blocks > 0;
+        const bool mig = ycge_kernel_has_migration() && flat && c->knobs.mig && !c->cfg.count_work && c->knobs.refill_steps <= 0 && n_blocks > 0;
         if (mig) {
+            const uint32_t ring = (n_blocks * YCGE_SCHEDULE_SLACK + YCGE_MIG_QUEUES - 1u) / YCGE_MIG_QUEUES + 1u;      // a block publishes at most once per part, on queue bid % Q
             if (!c->mig_entries.p) {
                 HIP_TRY(c, c->mig_entries.alloc((size_t)n_blocks * 64));
-                HIP_TRY(c, c->mig_pub.alloc((size_t)n_blocks * YCGE_SCHEDULE_SLACK)); HIP_TRY(c, c->mig_ctl.alloc(2));
-                HIP_TRY(c, hipMemset(c->mig_pub.p, 0, (size_t)n_blocks * YCGE_SCHEDULE_SLACK * sizeof(unsigned long long)));
-                HIP_TRY(c, hipMemset(c->mig_ctl.p, 0, 2 * sizeof(unsigned long long)));
+                HIP_TRY(c, c->mig_pub.alloc((size_t)ring * YCGE_MIG_QUEUES)); HIP_TRY(c, c->mig_ctl.alloc((size_t)YCGE_MIG_QUEUES * YCGE_MIG_CTL_STRIDE));
+                HIP_TRY(c, hipMemset(c->mig_pub.p, 0, (size_t)ring * YCGE_MIG_QUEUES * sizeof(unsigned long long)));
+                HIP_TRY(c, hipMemset(c->mig_ctl.p, 0, (size_t)YCGE_MIG_QUEUES * YCGE_MIG_CTL_STRIDE * sizeof(unsigned long long)));
             }
             O.mig_entries = c->mig_entries.p; O.mig_pub = c->mig_pub.p; O.mig_ctl = c->mig_ctl.p;
-            O.mig_ring = n_blocks * YCGE_SCHEDULE_SLACK;
+            O.mig_ring = ring;
             O.mig_round_steps = c->knobs.mig_round; O.mig_shade_min = c->knobs.mig_shade;
         }
         const uint32_t cost_slot = (uint32_t)((uint64_t)fs.frame % YCGE_COST_FRAMES);       // this frame's array of the cost ring
@@ -1326,7 +1332,8 @@ void build_inplace_schedule(int w, int h, int step, std::vector<uint32_t> &pixel
 // = first pass of level t of band b (passes are numbered through all bands; pass i covers band_pixels[32 i .. 32 i + 32)).
 // max_level_pixels = the most pixels (padding included) one level of one band holds: bounds what a launch of K levels writes.
 void band_inplace_schedule(int w, int h, int rows_per_band, const std::vector<uint32_t> &pixels, const std::vector<uint32_t> &offsets,
-                           std::vector<uint32_t> &band_pixels, std::vector<uint32_t> &band_offsets, int &n_bands, uint32_t &max_level_pixels)
+                           std::vector<uint32_t> &band_pixels, std::vector<uint32_t> &band_offsets, int &n_bands, uint32_t &max_level_pixels,
+                           uint32_t G = 32u /* pixels per pass */)
 {
     const int levels = (int)offsets.size() - 1;
     n_bands = (h + rows_per_band - 1) / rows_per_band;
@@ -1339,15 +1346,15 @@ void band_inplace_schedule(int w, int h, int rows_per_band, const std::vector<ui
     for (int b = 0; b < n_bands; b++) {
         for (int t = 0; t < levels; t++) {
             band_offsets[(size_t)b * (levels + 1) + t] = run;
-            const uint32_t passes = (count[(size_t)b * levels + t] + 31u) / 32u;
+            const uint32_t passes = (count[(size_t)b * levels + t] + G - 1u) / G;
             run += passes;
-            if (passes * 32u > max_level_pixels) max_level_pixels = passes * 32u;
+            if (passes * G > max_level_pixels) max_level_pixels = passes * G;
         }
         band_offsets[(size_t)b * (levels + 1) + levels] = run;
     }
-    band_pixels.assign((size_t)run * 32, 0xffffffffu);
+    band_pixels.assign((size_t)run * G, 0xffffffffu);
     std::vector<uint32_t> cursor((size_t)n_bands * levels);
-    for (int b = 0; b < n_bands; b++) for (int t = 0; t < levels; t++) cursor[(size_t)b * levels + t] = band_offsets[(size_t)b * (levels + 1) + t] * 32u;
+    for (int b = 0; b < n_bands; b++) for (int t = 0; t < levels; t++) cursor[(size_t)b * levels + t] = band_offsets[(size_t)b * (levels + 1) + t] * G;
     for (int t = 0; t < levels; t++)
         for (uint32_t i = offsets[t]; i < offsets[t + 1]; i++) {
             const uint32_t p = pixels[i];
@@ -1376,6 +1383,18 @@ int run_post(ycge_ctx *c, hipStream_t stream, float *out_sdr_host, bool timed)
     const float *cur = c->taa_hist.p;
     float *A = c->den_a.p, *B = c->den_b.p, *dst = A;
     const int iters = c->cfg.atrous_iterations > 1 ? c->cfg.atrous_iterations : 1;
+    // The in-place iteration (iteration 1, when there is one) reads colour-independent weight factors that need the G-buffer and the
+    // unit normals only: they are computed on the side stream beside iteration 0 (fork here, join in front of the band launches)
+    bool static_pending = false;
+    if (iters >= 2 && c->fan_stream) {
+        if (!c->atrous_statw.p) HIP_TRY(c, c->atrous_statw.alloc(n * 75));
+        HIP_TRY(c, hipEventRecord(c->fan_ev[0], stream));
+        HIP_TRY(c, hipStreamWaitEvent(c->fan_stream, c->fan_ev[0], 0));
+        e = ycge_launch_atrous_static(w, h, 2, phi, c->g_albedo.p, c->unit_n.p, c->g_depth.p, c->sky.p, c->atrous_statw.p, c->fan_stream);
+        if (e != 0) return c->fail(YCGE_ERR_DEVICE, "k_atrous_static launch failed: %s", hipGetErrorString((hipError_t)e));
+        HIP_TRY(c, hipEventRecord(c->fan_ev[1], c->fan_stream));
+        static_pending = true;
+    }
     for (int it = 0; it < iters; it++) {
         const int step = 1 << it;
         if (cur == dst) {
@@ -1390,7 +1409,7 @@ int run_post(ycge_ctx *c, hipStream_t stream, float *out_sdr_host, bool timed)
                 // bands of whole rows; related pixels are at most 2 * step rows apart, so they share a band or sit in adjacent ones
                 const int band_rows = c->knobs.post_band_rows;
                 const int rows_per_band = 2 * step > band_rows ? 2 * step : band_rows;
-                band_inplace_schedule(w, h, rows_per_band, px, off, bpx, boff, sc->bands, sc->max_level_pixels);
+                band_inplace_schedule(w, h, rows_per_band, px, off, bpx, boff, sc->bands, sc->max_level_pixels, (uint32_t)c->knobs.post_groups);
                 sc->levels = (int)off.size() - 1;
                 c->schedules.push_back(sc);
                 HIP_TRY(c, sc->pixels.upload(bpx)); HIP_TRY(c, sc->offsets.upload(boff));
@@ -1401,14 +1420,20 @@ int run_post(ycge_ctx *c, hipStream_t stream, float *out_sdr_host, bool timed)
             if (levels_per_launch > k_cap) levels_per_launch = k_cap;
             if (levels_per_launch < 1) return c->fail(YCGE_ERR_UNSUPPORTED, "in-place A-trous: a level of %u pixels in one band", sc->max_level_pixels);
             if (!c->atrous_statw.p) HIP_TRY(c, c->atrous_statw.alloc(n * 75));
+            if (static_pending && step == 2) { HIP_TRY(c, hipStreamWaitEvent(stream, c->fan_ev[1], 0)); static_pending = false; }
+            else {
+                e = ycge_launch_atrous_static(w, h, step, phi, c->g_albedo.p, c->unit_n.p, c->g_depth.p, c->sky.p, c->atrous_statw.p, stream);
+                if (e != 0) return c->fail(YCGE_ERR_DEVICE, "k_atrous_static launch failed: %s", hipGetErrorString((hipError_t)e));
+            }
             e = ycge_launch_atrous_inplace(w, h, step, phi, dst, c->g_albedo.p, c->unit_n.p, c->g_depth.p, c->sky.p, c->atrous_statw.p,
-                                           sc->pixels.p, sc->offsets.p, sc->levels, sc->bands, levels_per_launch, stream);
+                                           sc->pixels.p, sc->offsets.p, sc->levels, sc->bands, levels_per_launch, c->knobs.post_groups, stream);
         } else {
             e = ycge_launch_atrous(w, h, step, phi, cur, dst, c->g_albedo.p, c->unit_n.p, c->g_depth.p, c->sky.p, stream);
         }
         if (e != 0) return c->fail(YCGE_ERR_DEVICE, "A-trous launch failed: %s", hipGetErrorString((hipError_t)e));
         const float *tmp = cur; cur = dst; dst = (tmp == A) ? B : A;
     }
+    if (static_pending) HIP_TRY(c, hipStreamWaitEvent(stream, c->fan_ev[1], 0));
     c->denoised = cur;
     const int step = c->ss * 2 > 2 ? c->ss * 2 : 2;            // :226
     const float tone_consts[5] = {1.0f, 0.18f, 0.2f, 0.10f, 1.50f};     // toneExposure, aeKey, aeSpeed, aeMin, aeMax (ToneMapper.cs:8-16)
@@ -1516,9 +1541,11 @@ int ycge_render_frame(ycge_ctx *c, float *out_sdr, ycge_frame_stats *st)
         float ms = 0.0f;
         HIP_TRY(c, hipEventElapsedTime(&ms, c->ev[2], c->ev[3]));
         st->post_ms = ms;
-        float tone[2];
+        float tone[3];
         HIP_TRY(c, hipMemcpy(tone, c->tone_state.p, sizeof tone, hipMemcpyDeviceToHost));
         st->exposure = tone[1];
+        uint32_t n_serial; std::memcpy(&n_serial, &tone[2], 4);
+        st->exposure_serial_chunks = (float)n_serial;
     }
     return rc;
 }

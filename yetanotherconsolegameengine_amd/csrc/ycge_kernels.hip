@@ -533,10 +533,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu((HAS_GRID &
 
 // ---------------------------------------------------------------------------------- K_trace (single launch)
 #ifndef YCGE_MIGRATE
-#define YCGE_MIGRATE 1              // path migration in the flat, non-counting k_trace (trace_block, MIG)
+#define YCGE_MIGRATE 0              // experiment (-DYCGE_MIGRATE=1; measured a loss): path migration in the flat, non-counting k_trace (trace_block, MIG)
 #endif
 #ifndef YCGE_COOP_FETCH
-#define YCGE_COOP_FETCH 1           // quad-cooperative LDS-DMA record fetch in the flat, non-counting single-launch kernels (ycge_rt.hip.h)
+#define YCGE_COOP_FETCH 0           // experiment (measured: a loss): quad-cooperative LDS-DMA record fetch in the flat, non-counting single-launch kernels
 #endif
 enum Phase : int { PH_PATH = 0, PH_SHADOW_OCC = 1, PH_SHADOW_TR = 2, PH_DONE = 3 };
 
@@ -688,10 +688,10 @@ __device__ __forceinline__ void trace_block(const SceneDev &S, const FrameParams
     // path migration state (MIG)
     const bool mig_on = MIG && O.mig_entries != nullptr;
     bool consuming = false, migrated = false, need_begin = false, mig_dry = false;
-    uint32_t mig_pixel = 0, seg_next = 0, seg_end = 0, mig_wait = 0;
+    uint32_t mig_pixel = 0, seg_next = 0, seg_end = 0, mig_wait = 0, mig_poll = 0;
     FlatQuery mq;
-    mq.cur = YCGE_REF_NONE_VALUE; mq.obj_i = 0; mq.n_top = 0; mq.closest = 0.0f; mq.hit_prim = -1; mq.hit_sub = 0; mq.mesh_prim = -1; mq.tmin = 0.0f; mq.anyhit = false;
-    mq.o = f3(0, 0, 0); mq.d = f3(0, 0, 1); mq.inv = f3(0, 0, 0);
+    mq.cur = YCGE_REF_NONE_VALUE; mq.obj_i = 0; mq.n_top = 0; mq.closest = 0.0f; mq.hit_prim = -1; mq.hit_sub = 0; mq.mesh_prim = -1; mq.anyhit = false;
+    mq.inv = f3(0, 0, 0);
     if (MIG) { if (lane == 0) *s_nmig = 0; }
     if (FAN) {
         if (WAVES3) F->q[wave][3][lane] = -1.0f;
@@ -738,43 +738,56 @@ __device__ __forceinline__ void trace_block(const SceneDev &S, const FrameParams
             unsigned long long idle = __ballot(phase == PH_DONE);
             while (idle != 0ull && !mig_dry) {
                 if (seg_next == seg_end) {
-                    // claim the oldest published segment nobody has taken (wave-uniform; lane 0 talks to memory)
+                    // Claim a published segment.  YCGE_MIG_QUEUES queues (a block publishes on queue bid % Q), each with its own {tail, head}
+                    // pair on its own cache line: ONE global pair made every claim a compare-and-swap fight of thousands of wavefronts
+                    // (measured: 10 us per claim, 330 ms per frame).  Lane l looks at queue (bid + l) % Q - the whole scan is one round trip -
+                    // and the first lane that sees work tries to take it.
+                    // (only YCGE_MIG_SCAN neighbouring queues per look: every wavefront polling every queue made the 64 control lines a
+                    // memory hot spot - uncached loads of the same lines from thousands of wavefronts slowed the whole launch 40x)
+                    const uint32_t my_q = (bid + (uint32_t)lane) & (YCGE_MIG_QUEUES - 1u);
+                    unsigned long long *ctl = O.mig_ctl + (size_t)my_q * YCGE_MIG_CTL_STRIDE;
+                    unsigned long long h = 0, t = 0;
+                    if (lane < YCGE_MIG_SCAN) {
+                        h = __hip_atomic_load(ctl + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        t = __hip_atomic_load(ctl + 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    }
+                    const unsigned long long have = __ballot(h < t);
+                    if (have == 0ull) { mig_dry = true; break; }
+                    const int pick = (int)__builtin_ctzll(have);
                     unsigned long long word = 0;
                     int got = 0;
-                    if (lane == 0) {
-                        unsigned long long h = __hip_atomic_load(&O.mig_ctl[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                        const unsigned long long t = __hip_atomic_load(&O.mig_ctl[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                        if (h < t) {
-                            if (__hip_atomic_compare_exchange_strong(&O.mig_ctl[1], &h, h + 1ull, __ATOMIC_RELAXED, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) {
-                                unsigned long long *slot = O.mig_pub + (h % (unsigned long long)O.mig_ring);
-                                // the publisher took index h before it stored the word: it is a few instructions away
-                                for (uint32_t spin = 0; spin < (1u << 26); spin++) {
-                                    word = __hip_atomic_load(slot, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT);
-                                    if (word != 0ull) break;
-                                    __builtin_amdgcn_s_sleep(2);
-                                }
-                                __hip_atomic_store(slot, 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);       // the ring entry is free again
-                                got = word != 0ull ? 1 : 2;        // 2: gave up on a publisher that never came (cannot happen; never hang)
-                            } else got = 3;                         // somebody else took it: look again
-                        }
+                    if (lane == pick) {
+                        if (__hip_atomic_compare_exchange_strong(ctl + 1, &h, h + 1ull, __ATOMIC_RELAXED, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) {
+                            unsigned long long *slot = O.mig_pub + ((size_t)my_q * O.mig_ring + (size_t)(h % (unsigned long long)O.mig_ring));
+                            // the publisher took index h before it stored the word: it is a few instructions away
+                            for (uint32_t spin = 0; spin < (1u << 24); spin++) {
+                                word = __hip_atomic_load(slot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                                if (word != 0ull) break;
+                                __builtin_amdgcn_s_sleep(1);
+                            }
+                            __hip_atomic_store(slot, 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);       // the ring entry is free again
+                            got = word != 0ull ? 1 : 2;        // 2: a publisher that never came (cannot happen; never hang)
+                        } else got = 3;                         // somebody else took it: look again
                     }
-                    got = __builtin_amdgcn_readfirstlane(got);
-                    if (got == 0 || got == 2) { mig_dry = true; break; }
-                    if (got == 3) continue;
-                    const uint32_t w_lo = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)word);
-                    const uint32_t w_hi = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(word >> 32));
+                    got = __builtin_amdgcn_readlane(got, pick);
+                    if (got == 2) { mig_dry = true; break; }
+                    if (got == 3) { __builtin_amdgcn_s_sleep(1); continue; }
+                    const uint32_t w_lo = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)word, pick);
+                    const uint32_t w_hi = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(word >> 32), pick);
                     const unsigned long long ww = ((unsigned long long)(w_hi & 0x7fffffffu) << 32) | w_lo;
                     seg_next = (uint32_t)(ww >> 8);
                     seg_end = seg_next + (uint32_t)(ww & 0xffu);
-                    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");      // every lane reads the segment's entries after lane 0 has seen the word
                     continue;
                 }
                 const uint32_t avail = seg_end - seg_next, n_idle = (uint32_t)__popcll(idle);
                 const uint32_t take = avail < n_idle ? avail : n_idle;
                 const uint32_t rk = __builtin_amdgcn_mbcnt_hi((uint32_t)(idle >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)idle, 0u));
                 if (phase == PH_DONE && rk < take) {
-                    const float4 *e4 = (const float4 *)(O.mig_entries + (seg_next + rk));
-                    const float4 ea = e4[0], eb = e4[1], ec = e4[2], ed = e4[3];
+                    const MigEntry *ep = O.mig_entries + (seg_next + rk);
+                    f32x4 ea, eb, ec, ed;
+                    asm volatile("global_load_dwordx4 %0, %4, off sc1\n\tglobal_load_dwordx4 %1, %4, off offset:16 sc1\n\t"
+                                 "global_load_dwordx4 %2, %4, off offset:32 sc1\n\tglobal_load_dwordx4 %3, %4, off offset:48 sc1\n\ts_waitcnt vmcnt(0)"
+                                 : "=&v"(ea), "=&v"(eb), "=&v"(ec), "=&v"(ed) : "v"(ep) : "memory");
                     q.o = f3(ea.x, ea.y, ea.z); q.d = f3(ea.w, eb.x, eb.y); q.tmin = 0.001f; q.tmax = YCGE_FLT_MAX; q.anyhit = false;
                     beta = f3(eb.z, eb.w, ec.x);
                     radiance = f3(ec.y, ec.z, ec.w);
@@ -790,19 +803,23 @@ __device__ __forceinline__ void trace_block(const SceneDev &S, const FrameParams
             if (!__any(phase != PH_DONE)) {
                 if (!mig_dry) continue;
                 // nothing in flight and nothing published when we last looked: look once more, then leave
-                int more = 0;
-                if (lane == 0) more = __hip_atomic_load(&O.mig_ctl[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < __hip_atomic_load(&O.mig_ctl[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) ? 1 : 0;
-                if (__builtin_amdgcn_readfirstlane(more)) { mig_dry = false; continue; }
+                const unsigned long long *ctl = O.mig_ctl + (size_t)((bid + (uint32_t)lane) & (YCGE_MIG_QUEUES - 1u)) * YCGE_MIG_CTL_STRIDE;
+                bool more = false;
+                if (lane < YCGE_MIG_SCAN) more = __hip_atomic_load(ctl + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < __hip_atomic_load(ctl + 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if (__any(more)) { mig_dry = false; continue; }
                 break;
             }
-            if (mig_dry && seg_next == seg_end) {       // while some lanes still work, new segments may have been published
-                int more = 0;
-                if (lane == 0) more = __hip_atomic_load(&O.mig_ctl[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < __hip_atomic_load(&O.mig_ctl[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) ? 1 : 0;
-                if (__builtin_amdgcn_readfirstlane(more)) mig_dry = false;
+            mig_poll++;
+            if (mig_dry && seg_next == seg_end && (mig_poll & 3u) == 0u && __popcll(__ballot(phase == PH_DONE)) >= 32) {
+                // while some lanes still work, new segments may have been published: look again now and then, when half the lanes idle
+                const unsigned long long *ctl = O.mig_ctl + (size_t)((bid + (uint32_t)lane) & (YCGE_MIG_QUEUES - 1u)) * YCGE_MIG_CTL_STRIDE;
+                bool more = false;
+                if (lane < YCGE_MIG_SCAN) more = __hip_atomic_load(ctl + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < __hip_atomic_load(ctl + 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if (__any(more)) mig_dry = false;
             }
             if (phase != PH_DONE && need_begin) { flat_begin<COUNT>(S, q, st, mq, w); need_begin = false; }
             bool fin = false;
-            if (phase != PH_DONE) fin = flat_advance<COUNT, true>(S, st, mq, w, O.mig_round_steps);
+            if (phase != PH_DONE) fin = flat_advance<COUNT, true>(S, q, st, mq, w, O.mig_round_steps);
             const uint32_t n_fin = (uint32_t)__popcll(__ballot(fin)), n_trav = (uint32_t)__popcll(__ballot(phase != PH_DONE && !fin));
             const bool shade_now = n_fin > 0u && (n_fin >= (uint32_t)O.mig_shade_min || n_trav == 0u || mig_wait >= 3u);
             mig_wait = (n_fin > 0u && !shade_now) ? mig_wait + 1u : 0u;
@@ -816,11 +833,13 @@ __device__ __forceinline__ void trace_block(const SceneDev &S, const FrameParams
             finish_block();
             const uint32_t n_mig = *s_nmig;
             if (n_mig > 0u) {
-                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");      // the entries of every lane are out before the word is
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");         // the (write-through) entry stores of every lane have been acknowledged before the word goes out
                 if (lane == 0) {
-                    const unsigned long long idx = __hip_atomic_fetch_add(&O.mig_ctl[0], 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    const uint32_t pq = bid & (YCGE_MIG_QUEUES - 1u);
+                    const unsigned long long idx = __hip_atomic_fetch_add(O.mig_ctl + (size_t)pq * YCGE_MIG_CTL_STRIDE, 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                     const unsigned long long base_entry = (unsigned long long)bid * 64ull + (unsigned long long)(YCGE_ENT_PART(ent) * (uint32_t)live_lanes);
-                    __hip_atomic_store(O.mig_pub + (idx % (unsigned long long)O.mig_ring), ((base_entry << 8) | (unsigned long long)n_mig) | (1ull << 63), __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+                    __hip_atomic_store(O.mig_pub + ((size_t)pq * O.mig_ring + (size_t)(idx % (unsigned long long)O.mig_ring)),
+                                       ((base_entry << 8) | (unsigned long long)n_mig) | (1ull << 63), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 }
             }
             consuming = true;
@@ -1059,12 +1078,15 @@ __device__ __forceinline__ void trace_block(const SceneDev &S, const FrameParams
                 // hand the path over: its next query is a path query (bounce, mirror continuation, popped item) and nothing is stacked
                 if (phase == PH_PATH && psp == 0) {
                     const uint32_t slot = atomicAdd(s_nmig, 1u);
-                    float4 *e4 = (float4 *)(O.mig_entries + ((size_t)bid * 64u + (size_t)(YCGE_ENT_PART(ent) * (uint32_t)live_lanes) + slot));
-                    e4[0] = make_float4(q.o.x, q.o.y, q.o.z, q.d.x);
-                    e4[1] = make_float4(q.d.y, q.d.z, beta.x, beta.y);
-                    e4[2] = make_float4(beta.z, radiance.x, radiance.y, radiance.z);
-                    e4[3] = make_float4(__uint_as_float((uint32_t)rng), __uint_as_float((uint32_t)(rng >> 32)), __uint_as_float((uint32_t)px + (uint32_t)py * (uint32_t)P.hiW),
-                                        __uint_as_float((uint32_t)mirror_depth | ((uint32_t)diffuse_depth << 4)));
+                    // the entry goes out WRITE-THROUGH (sc1) and is read back with sc1 loads: no cache write-back / invalidate fences
+                    // (a buffer_wbl2 per published segment - 32 k per frame - cost 340 ms: it flushes the XCD's whole L2 every time)
+                    MigEntry *ep = O.mig_entries + ((size_t)bid * 64u + (size_t)(YCGE_ENT_PART(ent) * (uint32_t)live_lanes) + slot);
+                    const f32x4 e0 = {q.o.x, q.o.y, q.o.z, q.d.x}, e1 = {q.d.y, q.d.z, beta.x, beta.y}, e2 = {beta.z, radiance.x, radiance.y, radiance.z};
+                    const f32x4 e3 = {__uint_as_float((uint32_t)rng), __uint_as_float((uint32_t)(rng >> 32)), __uint_as_float((uint32_t)px + (uint32_t)py * (uint32_t)P.hiW),
+                                      __uint_as_float((uint32_t)mirror_depth | ((uint32_t)diffuse_depth << 4))};
+                    asm volatile("global_store_dwordx4 %0, %1, off sc1\n\tglobal_store_dwordx4 %0, %2, off offset:16 sc1\n\t"
+                                 "global_store_dwordx4 %0, %3, off offset:32 sc1\n\tglobal_store_dwordx4 %0, %4, off offset:48 sc1"
+                                 : : "v"(ep), "v"(e0), "v"(e1), "v"(e2), "v"(e3) : "memory");
                     migrated = true;
                     phase = PH_DONE;
                 }
@@ -1126,6 +1148,8 @@ __device__ __forceinline__ void trace_block(const SceneDev &S, const FrameParams
        bool has = false;
        int id = 0;
        FlatQuery fq;
+       RayQ rq;
+       rq.o = f3(0, 0, 0); rq.d = f3(0, 0, 1); rq.tmin = 0.0f; rq.tmax = 0.0f;
        fq.cur = YCGE_REF_NONE_VALUE;
        for (;;) {
            const unsigned long long idle = __ballot(!has);
@@ -1133,14 +1157,15 @@ __device__ __forceinline__ void trace_block(const SceneDev &S, const FrameParams
                const uint32_t my = next + __builtin_amdgcn_mbcnt_hi((uint32_t)(idle >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)idle, 0u));
                if (!has && my < n) {
                    id = (int)F->list[my];
-                   flat_begin<COUNT>(S, fan_query(F, id >> 6, id & 63), st, fq, w);
+                   rq = fan_query(F, id >> 6, id & 63);
+                   flat_begin<COUNT>(S, rq, st, fq, w);
                    has = true;
                }
                next += (uint32_t)__popcll(idle);
            }
            if (!__any(has)) break;
            wave_iters += (uint32_t)refill_steps;
-           if (has && flat_advance<COUNT, true>(S, st, fq, w, refill_steps)) {
+           if (has && flat_advance<COUNT, true>(S, rq, st, fq, w, refill_steps)) {
                const int sl = id >> 6, ln = id & 63;
                F->r[sl][0][ln] = fq.closest; F->r[sl][1][ln] = __int_as_float(fq.hit_prim); F->r[sl][2][ln] = __int_as_float(fq.hit_sub);
                F->q[sl][3][ln] = -1.0f;
@@ -1450,6 +1475,8 @@ template <class F> void sel3(bool a, bool b, bool c, F f)
 } // namespace
 
 extern "C" {
+
+int ycge_kernel_has_migration(void) { return YCGE_MIGRATE ? 1 : 0; }
 
 size_t ycge_wf_sizes(int which)
 {

@@ -168,11 +168,13 @@ __global__ __launch_bounds__(256) void k_atrous_static(const AtrousParams A, con
 //  * the 25 products of a pixel are written and read by ONE wavefront (a group is half of it): no workgroup barrier
 //    between the taps and the sum, one barrier per pass (table visible to the next pass), and it is a bare
 //    s_barrier - the fenced __syncthreads would wait for the prefetches in flight.
-#define YCGE_POST_GROUPS 32         // pixels per pass
+// Pixels per pass = the workgroup's size / 32.  A level of a 16-row band holds 12 pixels on average and never more than 32; a pass is
+// bound by the instruction issue of its wavefronts on ONE CU (4 per SIMD at 32 pixels: 1.45 us), so a narrower workgroup - two passes
+// for the rare wide level - is faster: template parameter G (8, 16 or 32 pixels; knob YCGE_POST_GROUPS).
 #define YCGE_POST_HASH 2048         // entries; the host keeps a launch's pixels below 3/4 of it
 #define YCGE_POST_NONE 0xffffffffu
-struct PostShared {
-    float val[YCGE_POST_GROUPS][25][4];
+template <int G> struct PostSharedT {
+    float val[G][25][4];
     uint4 ent[YCGE_POST_HASH];  // {pixel (tag), r, g, b as bits}: a lookup is ONE 16-byte LDS read
 };
 __device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
@@ -199,7 +201,8 @@ __device__ __forceinline__ PassData pass_fetch(const AtrousParams &A, const floa
     D.wn = sw[0]; D.wz = sw[1]; D.wa = sw[2];
     return D;
 }
-__device__ __forceinline__ void pass_compute(const AtrousParams &A, uint32_t p, PassData D, PostShared &sh)
+template <class SH>
+__device__ __forceinline__ void pass_compute(const AtrousParams &A, uint32_t p, PassData D, SH &sh)
 {
     const int g = threadIdx.x >> 5, t = threadIdx.x & 31;
     const int kx = t % 5 - 2, ky = t / 5 - 2;
@@ -251,11 +254,12 @@ __device__ __forceinline__ void pass_compute(const AtrousParams &A, uint32_t p, 
 }
 
 // pixels: the padded pass list; off[b * (levels + 1) + t] = first pass of level t of band b (.. + 1: one past its last)
-__global__ __launch_bounds__(1024) void k_atrous_band(const AtrousParams A, float *__restrict__ buf, const float *__restrict__ statw,
-                                                      const uint8_t *__restrict__ sky, const uint32_t *__restrict__ pixels,
-                                                      const uint32_t *__restrict__ off, int levels, int K, int launch, int first_band)
+template <int G>
+__global__ __launch_bounds__(32 * G) void k_atrous_band(const AtrousParams A, float *__restrict__ buf, const float *__restrict__ statw,
+                                                        const uint8_t *__restrict__ sky, const uint32_t *__restrict__ pixels,
+                                                        const uint32_t *__restrict__ off, int levels, int K, int launch, int first_band)
 {
-    __shared__ PostShared sh;
+    __shared__ PostSharedT<G> sh;
     const int b = first_band + (int)blockIdx.x;
     const int g0 = launch - b;
     if (g0 < 0) return;
@@ -264,19 +268,19 @@ __global__ __launch_bounds__(1024) void k_atrous_band(const AtrousParams A, floa
     const uint32_t pass_lo = o[t0], pass_hi = o[t1];
     if (pass_lo >= pass_hi) return;
     const int grp = threadIdx.x >> 5, t = threadIdx.x & 31;
-    for (uint32_t e = threadIdx.x; e < YCGE_POST_HASH; e += 1024) sh.ent[e].x = YCGE_POST_NONE;
-    uint32_t p1 = pixels[(size_t)pass_lo * YCGE_POST_GROUPS + grp];
-    uint32_t p2 = pass_lo + 1 < pass_hi ? pixels[(size_t)(pass_lo + 1) * YCGE_POST_GROUPS + grp] : YCGE_POST_NONE;
+    for (uint32_t e = threadIdx.x; e < YCGE_POST_HASH; e += 32 * G) sh.ent[e].x = YCGE_POST_NONE;
+    uint32_t p1 = pixels[(size_t)pass_lo * G + grp];
+    uint32_t p2 = pass_lo + 1 < pass_hi ? pixels[(size_t)(pass_lo + 1) * G + grp] : YCGE_POST_NONE;
     PassData D1 = pass_fetch(A, buf, statw, sky, p1, t);
     lds_barrier();              // table cleared
     for (uint32_t i = pass_lo; i < pass_hi; i++) {
-        const uint32_t p3 = i + 2 < pass_hi ? pixels[(size_t)(i + 2) * YCGE_POST_GROUPS + grp] : YCGE_POST_NONE;
+        const uint32_t p3 = i + 2 < pass_hi ? pixels[(size_t)(i + 2) * G + grp] : YCGE_POST_NONE;
         const PassData D2 = pass_fetch(A, buf, statw, sky, p2, t);      // in flight while this pass computes
         pass_compute(A, p1, D1, sh);
         p1 = p2; D1 = D2; p2 = p3;
     }
     // the launch's new colours go to memory together; the kernel boundary publishes them
-    for (uint32_t e = threadIdx.x; e < YCGE_POST_HASH; e += 1024) {
+    for (uint32_t e = threadIdx.x; e < YCGE_POST_HASH; e += 32 * G) {
         const uint4 en = sh.ent[e];
         if (en.x != YCGE_POST_NONE) st3(buf, en.x, f3(__uint_as_float(en.y), __uint_as_float(en.z), __uint_as_float(en.w)));
     }
@@ -413,24 +417,124 @@ __global__ __launch_bounds__(64) void k_exposure_sum_serial(const float *__restr
 // Same bits as the serial loop for every input (the fallback IS the serial loop); tested against the oracle's exposure on every
 // post-stage parity test.  1.44 ms -> ~0.1 ms at 1080p.
 #define YCGE_EXPO_CHUNK 512
-struct ExpoChunk { long long d[2], lo[2], hi[2]; int32_t par[2]; int32_t e; int32_t neg; };
+#define YCGE_EXPO_BATCH 1024            // chunks whose records sit in LDS at a time during the walk
+struct ExpoRec { long long d[2], lo[2], hi[2]; int32_t e, neg; };       // one chunk's map (parity in -> increment, bounds), 56 bytes
+
+// phase A: binary64 sum of each chunk (one lane per chunk, spread over the chip; order inside a chunk is irrelevant for a prediction)
+__global__ __launch_bounds__(64) void k_exposure_chunk_sums(const float *__restrict__ terms, int n, double *__restrict__ chunk_sum)
+{
+    const int c = blockIdx.x * 64 + threadIdx.x;
+    const int n_chunks = (n + YCGE_EXPO_CHUNK - 1) / YCGE_EXPO_CHUNK;
+    if (c >= n_chunks) return;
+    const int lo = c * YCGE_EXPO_CHUNK, hi = lo + YCGE_EXPO_CHUNK < n ? lo + YCGE_EXPO_CHUNK : n;
+    double a0 = 0.0, a1 = 0.0;
+    const float4 *t4 = (const float4 *)(terms + lo);
+    const int nq = (hi - lo) >> 2;
+    int q4 = 0;
+    for (; q4 + 2 <= nq; q4 += 2) {
+        const float4 v = t4[q4], u = t4[q4 + 1];
+        a0 += ((double)v.x + (double)v.y) + ((double)v.z + (double)v.w);
+        a1 += ((double)u.x + (double)u.y) + ((double)u.z + (double)u.w);
+    }
+    for (int i = lo + 4 * q4; i < hi; i++) a0 += (double)terms[i];
+    chunk_sum[c] = a0 + a1;
+}
+// exclusive prefix of the chunk sums (one workgroup; n_chunks is ~1000), in place: chunk_sum[c] <- what the sum is predicted to be
+// when chunk c starts
+__global__ __launch_bounds__(1024) void k_exposure_prefix(double *__restrict__ chunk_sum, int n_chunks)
+{
+    __shared__ double s[1024];
+    __shared__ double s_carry;
+    const int tid = threadIdx.x;
+    if (tid == 0) s_carry = 0.0;
+    for (int base = 0; base < n_chunks; base += 1024) {
+        __syncthreads();
+        const double own = base + tid < n_chunks ? chunk_sum[base + tid] : 0.0;
+        s[tid] = own;
+        __syncthreads();
+        for (int off = 1; off < 1024; off <<= 1) {
+            const double add = tid >= off ? s[tid - off] : 0.0;
+            __syncthreads();
+            s[tid] += add;
+            __syncthreads();
+        }
+        const double carry = s_carry;
+        if (base + tid < n_chunks) chunk_sum[base + tid] = carry + s[tid] - own;
+        __syncthreads();
+        if (tid == 1023) s_carry = carry + s[1023];
+    }
+}
+// phase B: every chunk simulates its terms for both input parities in units of its predicted ulp (one lane per chunk, spread over the chip)
+__global__ __launch_bounds__(64) void k_exposure_chunk_maps(const float *__restrict__ terms, int n, const double *__restrict__ chunk_start,
+                                                            ExpoRec *__restrict__ recs)
+{
+    const int c = blockIdx.x * 64 + threadIdx.x;
+    const int n_chunks = (n + YCGE_EXPO_CHUNK - 1) / YCGE_EXPO_CHUNK;
+    if (c >= n_chunks) return;
+    const double s0 = chunk_start[c];
+    const int neg = s0 < 0.0 ? 1 : 0;
+    const double mag = s0 < 0.0 ? -s0 : s0;
+    int e = -1000;
+    if (mag >= 1.0e-30) e = (int)((double_to_bits(mag) >> 52) & 0x7ff) - 1023;      // 2^e <= |s0| < 2^(e+1)
+    long long d0 = 0, d1 = 0, lo0 = 0, lo1 = 0, hi0 = 0, hi1 = 0;
+    bool all_zero = true;           // a chunk of skipped samples (sky) leaves any sum as it is: s + 0.0f == s
+    {
+        const int lo = c * YCGE_EXPO_CHUNK, hi = lo + YCGE_EXPO_CHUNK < n ? lo + YCGE_EXPO_CHUNK : n;
+        const float4 *t4 = (const float4 *)(terms + lo);
+        const int nq = (hi - lo) >> 2;
+        for (int q4 = 0; q4 < nq && all_zero; q4++) { const float4 v = t4[q4]; all_zero = v.x == 0.0f && v.y == 0.0f && v.z == 0.0f && v.w == 0.0f; }
+        for (int i = lo + 4 * nq; i < hi && all_zero; i++) all_zero = terms[i] == 0.0f;
+    }
+    if (all_zero) e = -2000;
+    else if (e >= -12 && e < 100) {      // below 2^-12 the sum is still tiny (first terms): serial
+        const double inv_u = bits_to_double((uint64_t)(1023 + 23 - e) << 52) * (neg ? -1.0 : 1.0);      // sign(s) / u, a power of two
+        const int lo = c * YCGE_EXPO_CHUNK, hi = lo + YCGE_EXPO_CHUNK < n ? lo + YCGE_EXPO_CHUNK : n;
+        int p0 = 0, p1 = 1;
+        auto one = [&](float term) {
+            const double x = (double)term * inv_u;
+            if (!(x > -1.0e12 && x < 1.0e12)) { lo0 = lo1 = -(1ll << 62); return; }      // absurd term (inf / nan): never take the fast path
+            const double fx = floor(x);
+            const double fr = x - fx;
+            const long long ifx = (long long)fx;
+            const int up = fr > 0.5 ? 1 : 0, tie = fr == 0.5 ? 1 : 0;
+            const int inc0 = tie ? (int)((p0 + ifx) & 1) : up;
+            const int inc1 = tie ? (int)((p1 + ifx) & 1) : up;
+            d0 += ifx + inc0; d1 += ifx + inc1;
+            p0 = (int)((p0 + ifx + inc0) & 1); p1 = (int)((p1 + ifx + inc1) & 1);
+            lo0 = d0 < lo0 ? d0 : lo0; hi0 = d0 > hi0 ? d0 : hi0;
+            lo1 = d1 < lo1 ? d1 : lo1; hi1 = d1 > hi1 ? d1 : hi1;
+        };
+        const float4 *t4 = (const float4 *)(terms + lo);
+        const int nq = (hi - lo) >> 2;
+        float4 nxt = nq > 0 ? t4[0] : make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+        for (int q4 = 0; q4 < nq; q4++) {           // the next four terms are on their way while these four are worked on
+            const float4 v = nxt;
+            if (q4 + 1 < nq) nxt = t4[q4 + 1];
+            one(v.x); one(v.y); one(v.z); one(v.w);
+        }
+        for (int i = lo + 4 * nq; i < hi; i++) one(terms[i]);
+    } else e = -1000;
+    ExpoRec r;
+    r.d[0] = d0; r.d[1] = d1; r.lo[0] = lo0; r.lo[1] = lo1; r.hi[0] = hi0; r.hi[1] = hi1; r.e = e; r.neg = neg;
+    recs[c] = r;
+}
+// phase C: the walk (one workgroup) + the exposure update
 __global__ __launch_bounds__(1024) void k_exposure_sum(const float *__restrict__ terms, int n, ToneConsts K, ToneState *__restrict__ state,
-                                                       double *__restrict__ chunk_sum, ExpoChunk *__restrict__ chunks)
+                                                       const ExpoRec *__restrict__ recs)
 {
     const int n_chunks = (n + YCGE_EXPO_CHUNK - 1) / YCGE_EXPO_CHUNK;
     const int tid = threadIdx.x;
+    // chunk records of the current batch, structure of arrays: the walking lane reads them at LDS latency, not memory latency
+    __shared__ long long s_d[2][YCGE_EXPO_BATCH], s_lo[2][YCGE_EXPO_BATCH], s_hi[2][YCGE_EXPO_BATCH];
+    __shared__ short s_e[YCGE_EXPO_BATCH];
+    __shared__ unsigned char s_neg[YCGE_EXPO_BATCH];
+    __shared__ long long s_gd[2][YCGE_EXPO_BATCH / 16], s_glo[2][YCGE_EXPO_BATCH / 16], s_ghi[2][YCGE_EXPO_BATCH / 16];
+    __shared__ unsigned char s_gok[YCGE_EXPO_BATCH / 16];
+    __shared__ float4 s_terms[YCGE_EXPO_CHUNK / 4];
     __shared__ uint32_t s_total_cnt;
-    if (tid == 0) s_total_cnt = 0;
-    // ---- phase A: binary64 chunk sums (order inside a chunk is irrelevant for a prediction)
-    for (int c = tid; c < n_chunks; c += 1024) {
-        const int lo = c * YCGE_EXPO_CHUNK, hi = lo + YCGE_EXPO_CHUNK < n ? lo + YCGE_EXPO_CHUNK : n;
-        double a = 0.0;
-        const float4 *t4 = (const float4 *)(terms + lo);
-        int i = lo;
-        for (; i + 4 <= hi; i += 4) { const float4 v = t4[(i - lo) >> 2]; a += (double)v.x + (double)v.y + (double)v.z + (double)v.w; }
-        for (; i < hi; i++) a += (double)terms[i];
-        chunk_sum[c] = a;
-    }
+    __shared__ int s_c, s_serial;
+    __shared__ float s_sum;
+    if (tid == 0) { s_total_cnt = 0; s_sum = 0.0f; s_serial = 0; }
     __syncthreads();
     {   // samples that count: k_exposure_terms left one word per workgroup behind the terms
         const uint32_t *counts = (const uint32_t *)(terms + n);
@@ -440,63 +544,99 @@ __global__ __launch_bounds__(1024) void k_exposure_sum(const float *__restrict__
         for (int off = 32; off >= 1; off >>= 1) part += (uint32_t)__shfl_xor((int)part, off, 64);
         if ((tid & 63) == 0 && part) atomicAdd(&s_total_cnt, part);
     }
-    // ---- phase B: per chunk, the predicted start (exclusive prefix of the chunk sums: n_chunks is ~1000, each lane sums its own prefix
-    // in binary64 - 0.5 M additions spread over the block) and the integer simulation for both parities
-    for (int c = tid; c < n_chunks; c += 1024) {
-        double s0 = 0.0;
-        for (int k = 0; k < c; k++) s0 += chunk_sum[k];
-        ExpoChunk C;
-        C.neg = s0 < 0.0 ? 1 : 0;
-        const double mag = s0 < 0.0 ? -s0 : s0;
-        int e = -1000;
-        if (mag >= 1.0e-30) e = (int)((double_to_bits(mag) >> 52) & 0x7ff) - 1023;      // 2^e <= |s0| < 2^(e+1)
-        C.e = e;
-        C.d[0] = C.d[1] = 0; C.lo[0] = C.lo[1] = 0; C.hi[0] = C.hi[1] = 0; C.par[0] = 0; C.par[1] = 1;
-        if (e >= -12 && e < 100) {      // below 2^-12 the sum is still tiny (first terms): serial
-            const double inv_u = bits_to_double((uint64_t)(1023 + 23 - e) << 52) * (C.neg ? -1.0 : 1.0);      // sign(s) / u, a power of two
-            const int lo = c * YCGE_EXPO_CHUNK, hi = lo + YCGE_EXPO_CHUNK < n ? lo + YCGE_EXPO_CHUNK : n;
-            long long d0 = 0, d1 = 0, lo0 = 0, lo1 = 0, hi0 = 0, hi1 = 0;
-            int p0 = 0, p1 = 1;
-            for (int i = lo; i < hi; i++) {
-                const double x = (double)terms[i] * inv_u;
-                if (!(x > -1.0e12 && x < 1.0e12)) { lo0 = lo1 = -(1ll << 62); continue; }      // absurd term (inf / nan): never take the fast path
-                const double fx = floor(x);
-                const double fr = x - fx;
-                const long long ifx = (long long)fx;
-                const int up = fr > 0.5 ? 1 : 0, tie = fr == 0.5 ? 1 : 0;
-                const int inc0 = tie ? (int)((p0 + ifx) & 1) : up;
-                const int inc1 = tie ? (int)((p1 + ifx) & 1) : up;
-                d0 += ifx + inc0; d1 += ifx + inc1;
-                p0 = (int)((p0 + ifx + inc0) & 1); p1 = (int)((p1 + ifx + inc1) & 1);
-                lo0 = d0 < lo0 ? d0 : lo0; hi0 = d0 > hi0 ? d0 : hi0;
-                lo1 = d1 < lo1 ? d1 : lo1; hi1 = d1 > hi1 ? d1 : hi1;
-            }
-            C.d[0] = d0; C.d[1] = d1; C.lo[0] = lo0; C.lo[1] = lo1; C.hi[0] = hi0; C.hi[1] = hi1; C.par[0] = p0; C.par[1] = p1;
+    for (int batch = 0; batch < n_chunks; batch += YCGE_EXPO_BATCH) {
+        const int batch_end = batch + YCGE_EXPO_BATCH < n_chunks ? batch + YCGE_EXPO_BATCH : n_chunks;
+        __syncthreads();
+        if (batch + tid < batch_end) {
+            const ExpoRec r = recs[batch + tid];
+            s_d[0][tid] = r.d[0]; s_d[1][tid] = r.d[1]; s_lo[0][tid] = r.lo[0]; s_lo[1][tid] = r.lo[1]; s_hi[0][tid] = r.hi[0]; s_hi[1][tid] = r.hi[1];
+            s_e[tid] = (short)r.e; s_neg[tid] = (unsigned char)r.neg;
         }
-        chunks[c] = C;
+        if (tid == 0) s_c = batch;
+        __syncthreads();
+        // groups of 16 chunks composed into one map each (valid when the 16 were simulated in the same binade with the same sign):
+        // the walking lane then takes 64 steps per batch instead of 1024, and opens a group only when the group does not fit
+        if (tid < YCGE_EXPO_BATCH / 16) {
+            const int k0 = tid * 16;
+            bool ok = batch + k0 + 16 <= batch_end;
+            const int e0 = s_e[k0], n0 = s_neg[k0];
+            long long gd[2] = {0, 0}, glo[2] = {0, 0}, ghi[2] = {0, 0};
+            if (ok) {
+                for (int pin = 0; pin < 2; pin++) {
+                    long long D = 0, L = 0, H = 0;
+                    int P = pin;
+                    for (int j = 0; j < 16; j++) {
+                        const int k = k0 + j;
+                        if ((int)s_e[k] == -2000) continue;                 // an all-zero chunk changes nothing
+                        if ((int)s_e[k] != e0 || (int)s_neg[k] != n0 || e0 <= -1000) ok = false;
+                        const long long l = D + s_lo[P][k], h = D + s_hi[P][k];
+                        L = l < L ? l : L; H = h > H ? h : H;
+                        const long long dk = s_d[P][k];
+                        D += dk;
+                        P = (int)((P + dk) & 1);            // parity of m + d
+                    }
+                    gd[pin] = D; glo[pin] = L; ghi[pin] = H;
+                }
+            }
+            s_gd[0][tid] = gd[0]; s_gd[1][tid] = gd[1]; s_glo[0][tid] = glo[0]; s_glo[1][tid] = glo[1]; s_ghi[0][tid] = ghi[0]; s_ghi[1][tid] = ghi[1];
+            s_gok[tid] = ok ? 1 : 0;
+        }
+        __syncthreads();
+        // s_sum is the reference's logSum after each chunk, bit for bit.  One lane walks the chunks that take the fast path; at a chunk
+        // that does not, the whole workgroup stages its terms in LDS and the lane adds them one by one (the reference's loop)
+        for (;;) {
+            if (tid == 0) {
+                float log_sum = s_sum;
+                int cc = s_c;
+                while (cc < batch_end) {
+                    const int k = cc - batch;
+                    const uint32_t bits = __float_as_uint(log_sum);
+                    const int e_now = (int)((bits >> 23) & 0xff) - 127;
+                    const int neg_now = (int)(bits >> 31);
+                    const long long m = (long long)((bits & 0x7fffffu) | 0x800000u);       // |s| = m * 2^(e_now - 23) for a normal s
+                    const int p = (int)(m & 1);
+                    const bool normal = ((bits >> 23) & 0xff) != 0;
+                    if ((int)s_e[k] == -2000) { cc++; continue; }           // nothing but + 0.0f
+                    if ((k & 15) == 0 && s_gok[k >> 4] && normal && e_now == (int)s_e[k] && neg_now == (int)s_neg[k] &&
+                        m + s_glo[p][k >> 4] > (1ll << 23) && m + s_ghi[p][k >> 4] < (1ll << 24)) {
+                        const long long m2 = m + s_gd[p][k >> 4];         // sixteen chunks at once
+                        log_sum = __uint_as_float((bits & 0xff800000u) | (uint32_t)(m2 & 0x7fffff));
+                        cc += 16;
+                        continue;
+                    }
+                    // strictly inside the binade: a sum that touches 2^e from above may have come from the finer grid below it
+                    const bool fast = normal && e_now == (int)s_e[k] && neg_now == (int)s_neg[k] && m + s_lo[p][k] > (1ll << 23) && m + s_hi[p][k] < (1ll << 24);
+                    if (!fast) break;
+                    const long long m2 = m + s_d[p][k];
+                    log_sum = __uint_as_float((bits & 0xff800000u) | (uint32_t)(m2 & 0x7fffff));
+                    cc++;
+                }
+                s_sum = log_sum; s_c = cc;
+            }
+            __syncthreads();
+            const int cc = s_c;
+            if (cc >= batch_end) break;
+            const int lo = cc * YCGE_EXPO_CHUNK, hi = lo + YCGE_EXPO_CHUNK < n ? lo + YCGE_EXPO_CHUNK : n;
+            if (tid < YCGE_EXPO_CHUNK / 4) {
+                float4 v = make_float4(0.0f, 0.0f, 0.0f, 0.0f);     // past the end: + 0.0f leaves the sum as it is
+                const int i = lo + 4 * tid;
+                if (i + 4 <= hi) v = ((const float4 *)(terms + lo))[tid];
+                else { if (i < hi) v.x = terms[i]; if (i + 1 < hi) v.y = terms[i + 1]; if (i + 2 < hi) v.z = terms[i + 2]; }
+                s_terms[tid] = v;
+            }
+            __syncthreads();
+            if (tid == 0) {
+                float log_sum = s_sum;
+#pragma unroll 8
+                for (int i = 0; i < YCGE_EXPO_CHUNK / 4; i++) { const float4 v = s_terms[i]; log_sum += v.x; log_sum += v.y; log_sum += v.z; log_sum += v.w; }
+                s_sum = log_sum; s_c = cc + 1; s_serial = s_serial + 1;
+            }
+            __syncthreads();
+        }
     }
     __syncthreads();
     if (tid != 0) return;
-    // ---- phase C: the walk.  s is the reference's logSum after each chunk, bit for bit
-    float log_sum = 0.0f;
-    int n_serial = 0;
-    for (int c = 0; c < n_chunks; c++) {
-        const ExpoChunk C = chunks[c];
-        const uint32_t bits = __float_as_uint(log_sum);
-        const int e_now = (int)((bits >> 23) & 0xff) - 127;
-        const int neg_now = (int)(bits >> 31);
-        const long long m = (long long)((bits & 0x7fffffu) | 0x800000u);       // |s| = m * 2^(e_now - 23) for a normal s
-        const int p = (int)(m & 1);
-        const bool fast = ((bits >> 23) & 0xff) != 0 && e_now == C.e && neg_now == C.neg && m + C.lo[p] > (1ll << 23) && m + C.hi[p] < (1ll << 24);      // strictly inside: a sum that touches 2^e from above may have come from the finer grid below it
-        if (fast) {
-            const long long m2 = m + C.d[p];
-            log_sum = __uint_as_float((bits & 0xff800000u) | (uint32_t)(m2 & 0x7fffff));
-        } else {
-            const int lo = c * YCGE_EXPO_CHUNK, hi = lo + YCGE_EXPO_CHUNK < n ? lo + YCGE_EXPO_CHUNK : n;
-            for (int i = lo; i < hi; i++) log_sum += terms[i];
-            n_serial++;
-        }
-    }
+    const float log_sum = s_sum;
     const int cnt = (int)s_total_cnt;
     float ae = state->ae_exposure;
     const float avg_log = cnt > 0 ? log_sum / (float)(cnt > 1 ? cnt : 1) : 0.0f;
@@ -508,7 +648,7 @@ __global__ __launch_bounds__(1024) void k_exposure_sum(const float *__restrict__
     ae = ae + (target - ae) * sp;
     state->ae_exposure = ae;
     state->effective = K.tone_exposure * ae;
-    state->count = (uint32_t)n_serial;          // diagnostics: chunks that took the serial path this frame
+    state->count = (uint32_t)s_serial;          // diagnostics: chunks that took the serial path this frame
 }
 
 // ToneMapper.ToneMapAndEncode + ApplySaturation, ToneMapper.cs:204-260
@@ -588,20 +728,34 @@ int ycge_launch_atrous(int w, int h, int step, const float phi[4], const float *
     return (int)hipGetLastError();
 }
 
-// in-place iteration as a pipeline of bands (see k_atrous_band): n_bands + ceil(levels / K) - 1 launches
-int ycge_launch_atrous_inplace(int w, int h, int step, const float phi[4], float *buf, const float *albedo, const float *unit_n,
-                               const float *depth, const uint8_t *sky, float *statw, const uint32_t *d_pixels, const uint32_t *d_offsets,
-                               int n_levels, int n_bands, int K, hipStream_t stream)
+// the colour-independent weight factors of an in-place iteration (k_atrous_static): needs the G-buffer only, so the host runs it on a
+// side stream beside the iteration before it
+int ycge_launch_atrous_static(int w, int h, int step, const float phi[4], const float *albedo, const float *unit_n, const float *depth,
+                              const uint8_t *sky, float *statw, hipStream_t stream)
 {
     ycge::AtrousParams A = {w, h, step, phi[0], phi[1], phi[2], phi[3]};
     const size_t n = (size_t)w * h;
     hipLaunchKernelGGL(ycge::k_atrous_static, dim3((unsigned)((n * 32 + 255) / 256)), dim3(256), 0, stream, A, albedo, unit_n, depth, sky, statw, n);
+    return (int)hipGetLastError();
+}
+
+// in-place iteration as a pipeline of bands (see k_atrous_band): n_bands + ceil(levels / K) - 1 launches
+int ycge_launch_atrous_inplace(int w, int h, int step, const float phi[4], float *buf, const float *albedo, const float *unit_n,
+                               const float *depth, const uint8_t *sky, float *statw, const uint32_t *d_pixels, const uint32_t *d_offsets,
+                               int n_levels, int n_bands, int K, int groups_per_pass, hipStream_t stream)
+{
+    ycge::AtrousParams A = {w, h, step, phi[0], phi[1], phi[2], phi[3]};
     const int groups = (n_levels + K - 1) / K;
     for (int launch = 0; launch < n_bands + groups - 1; launch++) {
         const int first = launch - (groups - 1) > 0 ? launch - (groups - 1) : 0;      // bands with a level group left to run
         const int last = launch < n_bands - 1 ? launch : n_bands - 1;
-        hipLaunchKernelGGL(ycge::k_atrous_band, dim3((unsigned)(last - first + 1)), dim3(1024), 0, stream, A, buf, statw, sky, d_pixels, d_offsets,
-                           n_levels, K, launch, first);
+        const dim3 grid((unsigned)(last - first + 1));
+        if (groups_per_pass == 8)
+            hipLaunchKernelGGL(ycge::k_atrous_band<8>, grid, dim3(256), 0, stream, A, buf, statw, sky, d_pixels, d_offsets, n_levels, K, launch, first);
+        else if (groups_per_pass == 16)
+            hipLaunchKernelGGL(ycge::k_atrous_band<16>, grid, dim3(512), 0, stream, A, buf, statw, sky, d_pixels, d_offsets, n_levels, K, launch, first);
+        else
+            hipLaunchKernelGGL(ycge::k_atrous_band<32>, grid, dim3(1024), 0, stream, A, buf, statw, sky, d_pixels, d_offsets, n_levels, K, launch, first);
     }
     return (int)hipGetLastError();
 }
@@ -610,7 +764,7 @@ size_t ycge_exposure_scratch_bytes(int w, int h, int step)
 {
     const int nsx = (w + step - 1) / step, nsy = (h + step - 1) / step;
     const size_t n_chunks = ((size_t)nsx * nsy + YCGE_EXPO_CHUNK - 1) / YCGE_EXPO_CHUNK;
-    return n_chunks * (sizeof(double) + sizeof(ycge::ExpoChunk)) + 64;
+    return ((n_chunks * sizeof(double) + 63) & ~(size_t)63) + n_chunks * sizeof(ycge::ExpoRec) + 64;
 }
 
 int ycge_launch_exposure(const float *hdr, const uint8_t *sky, int w, int h, int step, float *terms, void *state, const float consts[5],
@@ -627,8 +781,12 @@ int ycge_launch_exposure(const float *hdr, const uint8_t *sky, int w, int h, int
     }
     const size_t n_chunks = ((size_t)n + YCGE_EXPO_CHUNK - 1) / YCGE_EXPO_CHUNK;
     double *chunk_sum = (double *)scratch;
-    ycge::ExpoChunk *chunks = (ycge::ExpoChunk *)((char *)scratch + ((n_chunks * sizeof(double) + 63) & ~(size_t)63));
-    hipLaunchKernelGGL(ycge::k_exposure_sum, dim3(1), dim3(1024), 0, stream, terms, n, K, (ycge::ToneState *)state, chunk_sum, chunks);
+    ycge::ExpoRec *recs = (ycge::ExpoRec *)((char *)scratch + ((n_chunks * sizeof(double) + 63) & ~(size_t)63));
+    const unsigned cb = (unsigned)((n_chunks + 63) / 64);
+    hipLaunchKernelGGL(ycge::k_exposure_chunk_sums, dim3(cb), dim3(64), 0, stream, terms, n, chunk_sum);
+    hipLaunchKernelGGL(ycge::k_exposure_prefix, dim3(1), dim3(1024), 0, stream, chunk_sum, (int)n_chunks);
+    hipLaunchKernelGGL(ycge::k_exposure_chunk_maps, dim3(cb), dim3(64), 0, stream, terms, n, chunk_sum, recs);
+    hipLaunchKernelGGL(ycge::k_exposure_sum, dim3(1), dim3(1024), 0, stream, terms, n, K, (ycge::ToneState *)state, recs);
     return (int)hipGetLastError();
 }
 

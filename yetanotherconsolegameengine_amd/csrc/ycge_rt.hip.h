@@ -1107,9 +1107,9 @@ __device__ __forceinline__ void traverse(const SceneDev &S, const RayQ &q, STK &
 // The FLAT query of traverse() as a resumable state machine (k_trace's refill mode): flat_begin is traverse's
 // prologue, flat_advance runs at most `budget` mesh steps and returns true when the query is finished.  Object
 // order, box tests, counters and every visit are traverse's; only WHEN a lane performs them differs.
-struct FlatQuery {
-    F3 o, d, inv;
-    float tmin, closest;
+struct FlatQuery {       // the walk's state; the ray itself (o, d, tmin) stays in the caller's RayQ
+    F3 inv;
+    float closest;
     int hit_prim, hit_sub, obj_i, n_top, mesh_prim;
     uint32_t cur;
     bool anyhit;
@@ -1117,7 +1117,6 @@ struct FlatQuery {
 template <bool COUNT, class STK>
 __device__ __forceinline__ void flat_begin(const SceneDev &S, const RayQ &q, STK &st, FlatQuery &fq, Work &w)
 {
-    fq.o = q.o; fq.d = q.d; fq.tmin = q.tmin;
     fq.anyhit = !COUNT && q.anyhit;
     fq.closest = q.tmax;
     fq.hit_prim = -1; fq.hit_sub = 0;
@@ -1135,7 +1134,7 @@ __device__ __forceinline__ void flat_begin(const SceneDev &S, const RayQ &q, STK
     fq.n_top = root_hit ? (int)(YCGE_REF_PAYLOAD(S.scene_root_ref) & 7u) : 0;     // a missed root: no object is looked at (traverse)
 }
 template <bool COUNT, bool HAS_GRID, class STK>
-__device__ __forceinline__ bool flat_advance(const SceneDev &S, STK &st, FlatQuery &fq, Work &w, int budget)
+__device__ __forceinline__ bool flat_advance(const SceneDev &S, const RayQ &q, STK &st, FlatQuery &fq, Work &w, int budget)
 {
     const bool sx = fq.inv.x < 0.0f, sy = fq.inv.y < 0.0f, sz = fq.inv.z < 0.0f;
     const uint32_t leaf_start = YCGE_REF_PAYLOAD(S.scene_root_ref) >> 3;
@@ -1152,16 +1151,16 @@ __device__ __forceinline__ bool flat_advance(const SceneDev &S, STK &st, FlatQue
                 if (root_ref != YCGE_REF_NONE_VALUE) {
                     float tm;
                     if (COUNT) w.box++;
-                    if (box_mesh(q1.x, q1.y, q1.z, q1.w, q2.x, q2.y, fq.o, fq.inv, sx, sy, sz, fq.tmin, fq.closest, tm)) { fq.cur = root_ref; fq.mesh_prim = pi; }
+                    if (box_mesh(q1.x, q1.y, q1.z, q1.w, q2.x, q2.y, q.o, fq.inv, sx, sy, sz, q.tmin, fq.closest, tm)) { fq.cur = root_ref; fq.mesh_prim = pi; }
                 }
             } else if (type == 10) {
-                if (HAS_GRID) grid_dda<COUNT>(S, __float_as_int(q0.z), pi, fq.o, fq.d, fq.inv, fq.tmin, fq.closest, fq.hit_prim, fq.hit_sub, w);
+                if (HAS_GRID) grid_dda<COUNT>(S, __float_as_int(q0.z), pi, q.o, q.d, fq.inv, q.tmin, fq.closest, fq.hit_prim, fq.hit_sub, w);
             } else {
-                analytic_prim<COUNT>(q0, q1, q2, q3, type, pi, fq.o, fq.d, fq.tmin, fq.closest, fq.hit_prim, fq.hit_sub, w);
+                analytic_prim<COUNT>(q0, q1, q2, q3, type, pi, q.o, q.d, q.tmin, fq.closest, fq.hit_prim, fq.hit_sub, w);
             }
             continue;
         }
-        mesh_walk<COUNT, true>(S, fq.cur, fq.mesh_prim, st, fq.o, fq.inv, fq.d, sx, sy, sz, fq.tmin, fq.closest, fq.hit_prim, fq.hit_sub, w, budget, fq.anyhit);
+        mesh_walk<COUNT, true>(S, fq.cur, fq.mesh_prim, st, q.o, fq.inv, q.d, sx, sy, sz, q.tmin, fq.closest, fq.hit_prim, fq.hit_sub, w, budget, fq.anyhit);
         if (fq.cur != YCGE_REF_NONE_VALUE) return false;
     }
 }
