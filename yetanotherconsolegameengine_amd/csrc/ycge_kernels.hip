@@ -535,6 +535,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu((HAS_GRID &
 #ifndef YCGE_MIGRATE
 #define YCGE_MIGRATE 0              // experiment (-DYCGE_MIGRATE=1; measured a loss): path migration in the flat, non-counting k_trace (trace_block, MIG)
 #endif
+#ifndef YCGE_SPLIT_QUERIES
+#define YCGE_SPLIT_QUERIES 0         // experiment (-DYCGE_SPLIT_QUERIES=1; bit-exact, measured slower): long queries of nearly finished wavefronts split over the idle lanes (mesh_walk_split)
+#endif
 #ifndef YCGE_COOP_FETCH
 #define YCGE_COOP_FETCH 0           // experiment (measured: a loss): quad-cooperative LDS-DMA record fetch in the flat, non-counting single-launch kernels
 #endif
@@ -848,7 +851,7 @@ __device__ __forceinline__ void trace_block(const SceneDev &S, const FrameParams
         }
         const uint32_t steps_before = w.steps;
         // cooperative record fetch (flat scenes, the timed kernels): every lane enters the query, lanes without one with live = false
-        constexpr bool COOPQ = YCGE_COOP_FETCH && FLAT && !COUNT;
+        constexpr bool COOPQ = YCGE_SPLIT_QUERIES && FLAT && !COUNT;
         if (!FAN && COOPQ) {
             q.live = phase != PH_DONE;
             traverse<COUNT, true, FLAT, true>(S, q, st, t_hit, hit_prim, hit_sub, w);
