@@ -436,6 +436,35 @@ def test_inplace_atrous_band_pass_lists(product_lib, w, h, step, rows):
     assert seen.all() and widest == max_level_pixels
 
 
+@pytest.mark.parametrize("w,h,step,rows,K", [(1920, 1080, 2, 8, 8), (640, 360, 2, 8, 8), (257, 131, 2, 8, 8), (320, 200, 4, 8, 8), (97, 61, 2, 16, 4), (33, 40, 8, 16, 8)])
+def test_inplace_atrous_window_is_collision_free(product_lib, w, h, step, rows, K):
+    """k_atrous_band's window form keeps what one launch writes at (row in band) * WX + (x mod WX): the width the host picks
+    must separate every two pixels of one launch (levels [K g, K g + K) of one band), re-checked here from the pass lists."""
+    L = product_lib
+    L.ycge_host_band_window_width.restype = C.c_int
+    L.ycge_host_band_window_width.argtypes = [C.c_int32] * 6
+    rows_eff = max(rows, 2 * step)
+    wx = L.ycge_host_band_window_width(w, h, step, rows_eff, K, 32)
+    assert wx >= 64 and wx & (wx - 1) == 0 and wx * rows_eff <= 2048, wx
+    if (w, h) == (1920, 1080):
+        assert wx == 64 and L.ycge_host_band_window_width(w, h, step, rows_eff, K, 16) == 64       # the shipped defaults
+    L.ycge_host_inplace_bands.restype = C.c_int
+    L.ycge_host_inplace_bands.argtypes = [C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_void_p, C.c_int64, C.c_void_p, C.c_int64, C.c_void_p]
+    info = np.zeros(3, np.int32)
+    n_pass = L.ycge_host_inplace_bands(w, h, step, rows_eff, None, 0, None, 0, info.ctypes.data)
+    levels, n_bands, _ = (int(v) for v in info)
+    ent = np.zeros(n_pass * 32, np.uint32); boff = np.zeros(n_bands * (levels + 1), np.uint32)
+    L.ycge_host_inplace_bands(w, h, step, rows_eff, ent.ctypes.data, ent.size, boff.ctypes.data, boff.size, info.ctypes.data)
+    boff = boff.reshape(n_bands, levels + 1).astype(np.int64)
+    for b in range(n_bands):
+        for t0 in range(0, levels, K):
+            e = ent[boff[b, t0] * 32: boff[b, min(t0 + K, levels)] * 32]
+            e = e[e != 0xffffffff].astype(np.int64)
+            slot = ((e >> 16) - b * rows_eff) * wx + ((e & 0xffff) & (wx - 1))
+            assert len(np.unique(slot)) == len(slot) and (slot >= 0).all() and (slot < 2048).all()
+    assert L.ycge_host_band_window_width(0, h, step, rows_eff, K, 32) < 0 and L.ycge_host_band_window_width(w, h, step, rows_eff, K, 7) < 0
+
+
 def test_vg01_world_file_roundtrip_and_errors(tmp_path):
     """the VG01 world file (WorldManager.cs:612-629 writer, :399-441 reader) and its error behaviour."""
     import struct

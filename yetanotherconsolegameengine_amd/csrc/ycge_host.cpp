@@ -43,7 +43,7 @@ int ycge_launch_atrous_static(int w, int h, int step, const float phi[4], const 
                               const uint8_t *sky, float *statw, hipStream_t stream);
 int ycge_launch_atrous_inplace(int w, int h, int step, const float phi[4], float *buf, const float *albedo, const float *unit_n,
                                const float *depth, const uint8_t *sky, float *statw, const uint32_t *d_pixels, const uint32_t *d_offsets,
-                               int n_levels, int n_bands, int K, int groups_per_pass, hipStream_t stream);
+                               int n_levels, int n_bands, int K, int groups_per_pass, int rows_per_band, unsigned window_width, hipStream_t stream);
 size_t ycge_exposure_scratch_bytes(int w, int h, int step);
 int ycge_launch_exposure(const float *hdr, const uint8_t *sky, int w, int h, int step, float *terms, void *state, const float consts[5],
                          void *scratch, int serial, hipStream_t stream);
@@ -100,6 +100,7 @@ struct Knobs {
     int fan_class = -1, fan_cap = -1;   // -1 = default by world size
     int mig = 1, mig_round = 12, mig_shade = 16;      // YCGE_MIG (0 = off), YCGE_MIG_ROUND, YCGE_MIG_SHADE: path migration in k_trace
     int post_mode = 0;               // YCGE_POST_MODE: in-place A-trous implementation (0 = default)
+    bool post_hash = false;          // YCGE_POST_HASH_FORM=1: the hash form of k_atrous_band even where the window fits
     bool exposure_serial = false;    // YCGE_EXPOSURE_SERIAL: the one-lane chain instead of the chunked exact evaluation
     void read()
     {
@@ -116,6 +117,7 @@ struct Knobs {
         if (post_groups != 8 && post_groups != 16 && post_groups != 32) post_groups = YCGE_POST_GROUPS_DEFAULT;
         fan_class = geti("YCGE_FAN", -1); fan_cap = geti("YCGE_FAN_CAP", -1);
         post_mode = geti("YCGE_POST_MODE", 0);
+        post_hash = geti("YCGE_POST_HASH_FORM", 0) != 0;
         mig = geti("YCGE_MIG", 1); mig_round = geti("YCGE_MIG_ROUND", 12); mig_shade = geti("YCGE_MIG_SHADE", 16);
         if (mig_round < 1) mig_round = 1;
         exposure_serial = getenv("YCGE_EXPOSURE_SERIAL") != nullptr;
@@ -195,7 +197,7 @@ struct ycge_ctx {
     DevBuf<float> atrous_statw;                // [pixel][25 taps][3]: colour-independent weight factors of an in-place A-trous iteration
     DevBuf<uint8_t> exp_scratch;                  // chunk records of the exposure sum (k_exposure_sum)
     DevBuf<uint8_t> tone_state;                   // ToneMapper state; lives as long as the context (not reset by Resize)
-    struct InplaceSchedule { int w = 0, h = 0, step = 0, levels = 0, bands = 0; uint32_t max_level_pixels = 0; DevBuf<uint32_t> pixels, offsets; };
+    struct InplaceSchedule { int w = 0, h = 0, step = 0, levels = 0, bands = 0, rows_per_band = 0, levels_per_launch = 0; uint32_t max_level_pixels = 0, window_width = 0; DevBuf<uint32_t> pixels, offsets; };
     std::vector<InplaceSchedule *> schedules;     // level schedules of the in-place A-trous iterations, by (w, h, step)
     // what ycge_scene_update_objects needs from the last full upload
     std::vector<GMesh> gmeshes_host;
@@ -1362,6 +1364,35 @@ void band_inplace_schedule(int w, int h, int rows_per_band, const std::vector<ui
         }
 }
 
+// The narrowest power-of-two window width WX (64 ..) for which no two pixels that ONE launch of k_atrous_band writes - the levels
+// [K g, K g + K) of one band - share the entry (row in the band) * WX + (x mod WX), with rows * WX <= capacity; 0 if there is none.
+uint32_t band_window_width(const std::vector<uint32_t> &band_pixels, const std::vector<uint32_t> &band_offsets, int n_bands, int levels, int K,
+                           int rows_per_band, uint32_t G, uint32_t capacity)
+{
+    std::vector<uint32_t> seen;
+    for (uint32_t wx = 64; (size_t)wx * rows_per_band <= capacity; wx *= 2) {
+        seen.assign((size_t)wx * rows_per_band, 0u);
+        uint32_t stamp = 0;
+        bool ok = true;
+        for (int b = 0; b < n_bands && ok; b++)
+            for (int t0 = 0; t0 < levels && ok; t0 += K) {
+                stamp++;
+                const int t1 = t0 + K < levels ? t0 + K : levels;
+                const size_t lo = (size_t)band_offsets[(size_t)b * (levels + 1) + t0] * G, hi = (size_t)band_offsets[(size_t)b * (levels + 1) + t1] * G;
+                for (size_t i = lo; i < hi; i++) {
+                    const uint32_t e = band_pixels[i];
+                    if (e == 0xffffffffu) continue;
+                    const uint32_t x = e & 0xffffu, y = e >> 16;
+                    const size_t slot = (size_t)(y - (uint32_t)b * rows_per_band) * wx + (x & (wx - 1u));
+                    if (seen[slot] == stamp) { ok = false; break; }
+                    seen[slot] = stamp;
+                }
+            }
+        if (ok) return wx;
+    }
+    return 0u;
+}
+
 int run_post(ycge_ctx *c, hipStream_t stream, float *out_sdr_host, bool timed)
 {
     const int w = c->hiW, h = c->hiH;
@@ -1411,13 +1442,17 @@ int run_post(ycge_ctx *c, hipStream_t stream, float *out_sdr_host, bool timed)
                 const int rows_per_band = 2 * step > band_rows ? 2 * step : band_rows;
                 band_inplace_schedule(w, h, rows_per_band, px, off, bpx, boff, sc->bands, sc->max_level_pixels, (uint32_t)c->knobs.post_groups);
                 sc->levels = (int)off.size() - 1;
+                sc->rows_per_band = rows_per_band;
+                // levels per launch: a launch keeps what it writes in a 2048-entry LDS table (k_atrous_band), at most 3/4 full
+                sc->levels_per_launch = c->knobs.post_k;
+                const int k_cap = (int)(1536u / (sc->max_level_pixels > 0 ? sc->max_level_pixels : 32u));
+                if (sc->levels_per_launch > k_cap) sc->levels_per_launch = k_cap;
+                sc->window_width = sc->levels_per_launch >= 1 && !c->knobs.post_hash
+                                       ? band_window_width(bpx, boff, sc->bands, sc->levels, sc->levels_per_launch, rows_per_band, (uint32_t)c->knobs.post_groups, 2048u) : 0u;
                 c->schedules.push_back(sc);
                 HIP_TRY(c, sc->pixels.upload(bpx)); HIP_TRY(c, sc->offsets.upload(boff));
             }
-            // levels per launch: a launch keeps what it writes in a 2048-entry LDS table (k_atrous_band), at most 3/4 full
-            int levels_per_launch = c->knobs.post_k;
-            const int k_cap = (int)(1536u / (sc->max_level_pixels > 0 ? sc->max_level_pixels : 32u));
-            if (levels_per_launch > k_cap) levels_per_launch = k_cap;
+            const int levels_per_launch = sc->levels_per_launch;
             if (levels_per_launch < 1) return c->fail(YCGE_ERR_UNSUPPORTED, "in-place A-trous: a level of %u pixels in one band", sc->max_level_pixels);
             if (!c->atrous_statw.p) HIP_TRY(c, c->atrous_statw.alloc(n * 75));
             if (static_pending && step == 2) { HIP_TRY(c, hipStreamWaitEvent(stream, c->fan_ev[1], 0)); static_pending = false; }
@@ -1426,7 +1461,7 @@ int run_post(ycge_ctx *c, hipStream_t stream, float *out_sdr_host, bool timed)
                 if (e != 0) return c->fail(YCGE_ERR_DEVICE, "k_atrous_static launch failed: %s", hipGetErrorString((hipError_t)e));
             }
             e = ycge_launch_atrous_inplace(w, h, step, phi, dst, c->g_albedo.p, c->unit_n.p, c->g_depth.p, c->sky.p, c->atrous_statw.p,
-                                           sc->pixels.p, sc->offsets.p, sc->levels, sc->bands, levels_per_launch, c->knobs.post_groups, stream);
+                                           sc->pixels.p, sc->offsets.p, sc->levels, sc->bands, levels_per_launch, c->knobs.post_groups, sc->rows_per_band, sc->window_width, stream);
         } else {
             e = ycge_launch_atrous(w, h, step, phi, cur, dst, c->g_albedo.p, c->unit_n.p, c->g_depth.p, c->sky.p, stream);
         }
@@ -1763,6 +1798,17 @@ int ycge_host_inplace_bands(int32_t w, int32_t h, int32_t step, int32_t rows_per
     if (entries_out && (int64_t)bpx.size() <= entries_capacity) std::memcpy(entries_out, bpx.data(), bpx.size() * 4);
     if (offsets_out && (int64_t)boff.size() <= offsets_capacity) std::memcpy(offsets_out, boff.data(), boff.size() * 4);
     return (int)(bpx.size() / 32);
+}
+// test hook: the window width run_post would hand k_atrous_band for this schedule (0 = hash form)
+int ycge_host_band_window_width(int32_t w, int32_t h, int32_t step, int32_t rows_per_band, int32_t K, int32_t G)
+{
+    if (w <= 0 || h <= 0 || step <= 0 || rows_per_band <= 0 || K <= 0 || (G != 8 && G != 16 && G != 32)) return YCGE_ERR_INVALID_ARG;
+    std::vector<uint32_t> px, off, bpx, boff;
+    build_inplace_schedule(w, h, step, px, off);
+    int n_bands = 0;
+    uint32_t max_level_pixels = 0;
+    band_inplace_schedule(w, h, rows_per_band, px, off, bpx, boff, n_bands, max_level_pixels, (uint32_t)G);
+    return (int)band_window_width(bpx, boff, n_bands, (int)off.size() - 1, K, rows_per_band, (uint32_t)G, 2048u);
 }
 // profiling aid: per-wavefront {start, end, node iterations, leaf phases} of the last counted k_wf_primary launch
 int ycge_debug_read_wave_prof(ycge_ctx *c, unsigned long long *dst, size_t n_u64)

@@ -171,28 +171,46 @@ __global__ __launch_bounds__(256) void k_atrous_static(const AtrousParams A, con
 // Pixels per pass = the workgroup's size / 32.  A level of a 16-row band holds 12 pixels on average and never more than 32; a pass is
 // bound by the instruction issue of its wavefronts on ONE CU (4 per SIMD at 32 pixels: 1.45 us), so a narrower workgroup - two passes
 // for the rare wide level - is faster: template parameter G (8, 16 or 32 pixels; knob YCGE_POST_GROUPS).
-#define YCGE_POST_HASH 2048         // entries; the host keeps a launch's pixels below 3/4 of it
+#define YCGE_POST_HASH 2048         // entries of the hash form; the host keeps a launch's pixels below 3/4 of it
+#define YCGE_POST_WIN 2048          // entries of the window form: rows of the band x window width
 #define YCGE_POST_NONE 0xffffffffu
+// Where a launch keeps its new colours.  WINDOW form (the default): entry (row in the band) * WX + (x mod WX) - the host has checked,
+// list by list, that no two pixels one launch writes share an entry (a launch's levels cover a short diagonal stripe of the band: 16
+// columns per row at step 2), so a lookup is one LDS read at an address known a pass ahead and an insert is a plain store: no probe
+// loop, no LDS atomic and no cross-lane broadcast of the slot in the chain.  HASH form: open addressing by pixel index, for a schedule
+// the window does not fit (never seen; kept as the general case).
 template <int G> struct PostSharedT {
-    float val[G][25][4];
+    float val[G][4][28];        // [component x, y, z, weight][tap], a row padded to 16-byte multiples: the sum reads its 25 terms as 6 x b128 + 1
     uint4 ent[YCGE_POST_HASH];  // {pixel (tag), r, g, b as bits}: a lookup is ONE 16-byte LDS read
 };
+static_assert(YCGE_POST_WIN == YCGE_POST_HASH, "one LDS array serves both forms");
+struct BandWindow { int y0, rows; uint32_t wx, use; };     // use == 0: hash form
 __device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
 __device__ __forceinline__ uint32_t post_hash(uint32_t p) { return (p * 2654435761u) >> (32 - 11); }
 struct PassData {           // what one lane needs for one pass, fetched ahead
     F3 c0, cj;
     float wn, wz, wa;
     uint32_t p, j;          // pixel index and this lane's tap source
+    uint32_t pslot, jslot;  // window form: their entries (YCGE_POST_NONE: the tap's row is outside the band)
     uint8_t sky0, sky_j;
 };
-__device__ __forceinline__ PassData pass_fetch(const AtrousParams &A, const float *buf, const float *statw, const uint8_t *sky, uint32_t p, int t)
+__device__ __forceinline__ PassData pass_fetch(const AtrousParams &A, const BandWindow &W, const float *buf, const float *statw, const uint8_t *sky,
+                                               uint32_t p, int t)
 {
     PassData D;
     const uint32_t e = p == YCGE_POST_NONE ? 0u : p;        // list entries are x | y << 16: no division in the chain
     const int x = (int)(e & 0xffffu), y = (int)(e >> 16);
     const uint32_t pp = (uint32_t)x + (uint32_t)y * (uint32_t)A.w;
     D.p = pp;
-    D.j = (p != YCGE_POST_NONE && t < 25) ? (uint32_t)atrous_tap_index(A, x, y, t % 5 - 2, t / 5 - 2) : pp;
+    int sx = x, sy = y;
+    if (p != YCGE_POST_NONE && t < 25) {                    // atrous_tap_index, coordinates kept
+        sy = y + (t / 5 - 2) * A.step; if (sy < 0) sy = 0; else if (sy >= A.h) sy = A.h - 1;
+        sx = x + (t % 5 - 2) * A.step; if (sx < 0) sx = 0; else if (sx >= A.w) sx = A.w - 1;
+    }
+    D.j = (uint32_t)sx + (uint32_t)sy * (uint32_t)A.w;
+    const int rj = sy - W.y0, rp = y - W.y0;
+    D.jslot = (rj >= 0 && rj < W.rows) ? (uint32_t)rj * W.wx + ((uint32_t)sx & (W.wx - 1u)) : YCGE_POST_NONE;
+    D.pslot = ((uint32_t)rp * W.wx + ((uint32_t)x & (W.wx - 1u))) & (YCGE_POST_WIN - 1u);
     D.sky0 = sky[pp];
     D.c0 = ld3(buf, pp);
     D.sky_j = sky[D.j];
@@ -201,7 +219,7 @@ __device__ __forceinline__ PassData pass_fetch(const AtrousParams &A, const floa
     D.wn = sw[0]; D.wz = sw[1]; D.wa = sw[2];
     return D;
 }
-template <class SH>
+template <bool WIN, class SH>
 __device__ __forceinline__ void pass_compute(const AtrousParams &A, uint32_t p, PassData D, SH &sh)
 {
     const int g = threadIdx.x >> 5, t = threadIdx.x & 31;
@@ -210,56 +228,75 @@ __device__ __forceinline__ void pass_compute(const AtrousParams &A, uint32_t p, 
     const bool valid = work && t < 25 && D.sky_j == D.sky0;
     if (valid) {
         F3 cj = D.cj;
-        for (uint32_t h = post_hash(D.j);; h = (h + 1u) & (YCGE_POST_HASH - 1u)) {      // rewritten earlier in this launch?
-            const uint4 en = sh.ent[h];
-            if (en.x == D.j) { cj = f3(__uint_as_float(en.y), __uint_as_float(en.z), __uint_as_float(en.w)); break; }
-            if (en.x == YCGE_POST_NONE) break;
+        if (WIN) {                                           // rewritten earlier in this launch?
+            if (D.jslot != YCGE_POST_NONE) {
+                const uint4 en = sh.ent[D.jslot];
+                if (en.x == D.j) cj = f3(__uint_as_float(en.y), __uint_as_float(en.z), __uint_as_float(en.w));
+            }
+        } else {
+            for (uint32_t h = post_hash(D.j);; h = (h + 1u) & (YCGE_POST_HASH - 1u)) {
+                const uint4 en = sh.ent[h];
+                if (en.x == D.j) { cj = f3(__uint_as_float(en.y), __uint_as_float(en.z), __uint_as_float(en.w)); break; }
+                if (en.x == YCGE_POST_NONE) break;
+            }
         }
         // atrous_tap_weight with its three colour-independent exponentials read back: w_base * wc * wn * wz * wa, left to right
         const float w_base = kernel_tap(kx) * kernel_tap(ky);
         const float dl = cs_abs(luma3(cj) - luma3(D.c0));
         const float wc = m_exp(-dl / A.c_phi);
         const float wght = w_base * wc * D.wn * D.wz * D.wa;
-        sh.val[g][t][0] = cj.x * wght; sh.val[g][t][1] = cj.y * wght; sh.val[g][t][2] = cj.z * wght; sh.val[g][t][3] = wght;
+        sh.val[g][0][t] = cj.x * wght; sh.val[g][1][t] = cj.y * wght; sh.val[g][2][t] = cj.z * wght; sh.val[g][3][t] = wght;
     } else if (work && t < 25) {
         // a tap the reference skips contributes +0: the running sums start at +0.0f and can therefore never be -0.0f, so
         // s + 0.0f == s for every value they take - no per-tap select in the chain of adds below
-        sh.val[g][t][0] = 0.0f; sh.val[g][t][1] = 0.0f; sh.val[g][t][2] = 0.0f; sh.val[g][t][3] = 0.0f;
+        sh.val[g][0][t] = 0.0f; sh.val[g][1][t] = 0.0f; sh.val[g][2][t] = 0.0f; sh.val[g][3][t] = 0.0f;
     }
-    // the group's 25 products were written by this wavefront: in-order LDS, no barrier.  25 reads issued together, then the
-    // adds in tap order
+    // the group's 25 products were written by this wavefront: in-order LDS, no barrier.  Lane c < 4 reads the 25 terms of component c
+    // (seven reads issued together), then adds them in tap order
     float acc = 0.0f;
     if (work && t < 4) {
-        float v[25];
+        float v[28];
+        const float4 *row = (const float4 *)&sh.val[g][t][0];
 #pragma unroll
-        for (int k = 0; k < 25; k++) v[k] = sh.val[g][k][t];
+        for (int k = 0; k < 6; k++) { const float4 q = row[k]; v[4 * k] = q.x; v[4 * k + 1] = q.y; v[4 * k + 2] = q.z; v[4 * k + 3] = q.w; }
+        v[24] = sh.val[g][t][24];
 #pragma unroll
         for (int k = 0; k < 25; k++) acc = acc + v[k];
     }
-    const float wsum = __shfl(acc, (threadIdx.x & 32) + 3, 64);
-    uint32_t h = 0;
-    const bool changed = work && wsum > 1e-8f;          // else dst = c0: unchanged, nothing to record
-    if (changed && t == 0) {
-        for (h = post_hash(D.p);; h = (h + 1u) & (YCGE_POST_HASH - 1u)) {
-            const uint32_t prev = atomicCAS(&sh.ent[h].x, YCGE_POST_NONE, D.p);
-            if (prev == YCGE_POST_NONE || prev == D.p) break;
+    if (WIN) {
+        // lanes 0..2 hold the colour sums, lane 3 the weight sum: one DPP move hands it to its quad, every lane of the quad stores one word
+        const float wsum = __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(acc), 0xFF /* quad_perm 3,3,3,3 */, 0xF, 0xF, true));
+        if (work && t < 4 && wsum > 1e-8f) {                // else dst = c0: unchanged, nothing to record
+            const float inv = 1.0f / wsum;
+            (&sh.ent[D.pslot].x)[(t + 1) & 3] = t < 3 ? __float_as_uint(acc * inv) : D.p;
         }
-    }
-    h = (uint32_t)__shfl((int)h, threadIdx.x & 32, 64);
-    if (changed && t < 3) {
-        const float inv = 1.0f / wsum;
-        (&sh.ent[h].y)[t] = __float_as_uint(acc * inv);
+    } else {
+        const float wsum = __shfl(acc, (threadIdx.x & 32) + 3, 64);
+        uint32_t h = 0;
+        const bool changed = work && wsum > 1e-8f;
+        if (changed && t == 0) {
+            for (h = post_hash(D.p);; h = (h + 1u) & (YCGE_POST_HASH - 1u)) {
+                const uint32_t prev = atomicCAS(&sh.ent[h].x, YCGE_POST_NONE, D.p);
+                if (prev == YCGE_POST_NONE || prev == D.p) break;
+            }
+        }
+        h = (uint32_t)__shfl((int)h, threadIdx.x & 32, 64);
+        if (changed && t < 3) {
+            const float inv = 1.0f / wsum;
+            (&sh.ent[h].y)[t] = __float_as_uint(acc * inv);
+        }
     }
     lds_barrier();              // the table holds this pass's pixels before the next pass looks its taps up
 }
 
 // pixels: the padded pass list; off[b * (levels + 1) + t] = first pass of level t of band b (.. + 1: one past its last)
-template <int G>
+template <int G, bool WIN>
 __global__ __launch_bounds__(32 * G) void k_atrous_band(const AtrousParams A, float *__restrict__ buf, const float *__restrict__ statw,
                                                         const uint8_t *__restrict__ sky, const uint32_t *__restrict__ pixels,
-                                                        const uint32_t *__restrict__ off, int levels, int K, int launch, int first_band)
+                                                        const uint32_t *__restrict__ off, int levels, int K, int launch, int first_band,
+                                                        int rows_per_band, uint32_t wx)
 {
-    __shared__ PostSharedT<G> sh;
+    __shared__ __attribute__((aligned(16))) PostSharedT<G> sh;
     const int b = first_band + (int)blockIdx.x;
     const int g0 = launch - b;
     if (g0 < 0) return;
@@ -268,19 +305,21 @@ __global__ __launch_bounds__(32 * G) void k_atrous_band(const AtrousParams A, fl
     const uint32_t pass_lo = o[t0], pass_hi = o[t1];
     if (pass_lo >= pass_hi) return;
     const int grp = threadIdx.x >> 5, t = threadIdx.x & 31;
-    for (uint32_t e = threadIdx.x; e < YCGE_POST_HASH; e += 32 * G) sh.ent[e].x = YCGE_POST_NONE;
+    const BandWindow W = {b * rows_per_band, rows_per_band, WIN ? wx : 1u, WIN ? 1u : 0u};
+    const uint32_t n_ent = WIN ? (uint32_t)rows_per_band * wx : (uint32_t)YCGE_POST_HASH;
+    for (uint32_t e = threadIdx.x; e < n_ent; e += 32 * G) sh.ent[e].x = YCGE_POST_NONE;
     uint32_t p1 = pixels[(size_t)pass_lo * G + grp];
     uint32_t p2 = pass_lo + 1 < pass_hi ? pixels[(size_t)(pass_lo + 1) * G + grp] : YCGE_POST_NONE;
-    PassData D1 = pass_fetch(A, buf, statw, sky, p1, t);
+    PassData D1 = pass_fetch(A, W, buf, statw, sky, p1, t);
     lds_barrier();              // table cleared
     for (uint32_t i = pass_lo; i < pass_hi; i++) {
         const uint32_t p3 = i + 2 < pass_hi ? pixels[(size_t)(i + 2) * G + grp] : YCGE_POST_NONE;
-        const PassData D2 = pass_fetch(A, buf, statw, sky, p2, t);      // in flight while this pass computes
-        pass_compute(A, p1, D1, sh);
+        const PassData D2 = pass_fetch(A, W, buf, statw, sky, p2, t);      // in flight while this pass computes
+        pass_compute<WIN>(A, p1, D1, sh);
         p1 = p2; D1 = D2; p2 = p3;
     }
     // the launch's new colours go to memory together; the kernel boundary publishes them
-    for (uint32_t e = threadIdx.x; e < YCGE_POST_HASH; e += 32 * G) {
+    for (uint32_t e = threadIdx.x; e < n_ent; e += 32 * G) {
         const uint4 en = sh.ent[e];
         if (en.x != YCGE_POST_NONE) st3(buf, en.x, f3(__uint_as_float(en.y), __uint_as_float(en.z), __uint_as_float(en.w)));
     }
@@ -708,6 +747,14 @@ __global__ __launch_bounds__(256) void k_tonemap_downsample(const float *__restr
 
 } // namespace ycge
 
+template <int G>
+static void launch_band(bool win, dim3 grid, hipStream_t stream, const ycge::AtrousParams &A, float *buf, const float *statw, const uint8_t *sky,
+                        const uint32_t *d_pixels, const uint32_t *d_offsets, int n_levels, int K, int launch, int first, int rows_per_band, uint32_t wx)
+{
+    if (win) hipLaunchKernelGGL((ycge::k_atrous_band<G, true>), grid, dim3(32 * G), 0, stream, A, buf, statw, sky, d_pixels, d_offsets, n_levels, K, launch, first, rows_per_band, wx);
+    else hipLaunchKernelGGL((ycge::k_atrous_band<G, false>), grid, dim3(32 * G), 0, stream, A, buf, statw, sky, d_pixels, d_offsets, n_levels, K, launch, first, rows_per_band, wx);
+}
+
 extern "C" {
 
 size_t ycge_post_state_bytes(void) { return sizeof(ycge::ToneState); }
@@ -739,23 +786,22 @@ int ycge_launch_atrous_static(int w, int h, int step, const float phi[4], const 
     return (int)hipGetLastError();
 }
 
-// in-place iteration as a pipeline of bands (see k_atrous_band): n_bands + ceil(levels / K) - 1 launches
+// in-place iteration as a pipeline of bands (see k_atrous_band): n_bands + ceil(levels / K) - 1 launches.  window_width: the
+// collision-free window the host found for this schedule and K (0: hash form)
 int ycge_launch_atrous_inplace(int w, int h, int step, const float phi[4], float *buf, const float *albedo, const float *unit_n,
                                const float *depth, const uint8_t *sky, float *statw, const uint32_t *d_pixels, const uint32_t *d_offsets,
-                               int n_levels, int n_bands, int K, int groups_per_pass, hipStream_t stream)
+                               int n_levels, int n_bands, int K, int groups_per_pass, int rows_per_band, unsigned window_width, hipStream_t stream)
 {
     ycge::AtrousParams A = {w, h, step, phi[0], phi[1], phi[2], phi[3]};
     const int groups = (n_levels + K - 1) / K;
+    const bool win = window_width != 0 && (size_t)rows_per_band * window_width <= YCGE_POST_WIN && (window_width & (window_width - 1)) == 0;
     for (int launch = 0; launch < n_bands + groups - 1; launch++) {
         const int first = launch - (groups - 1) > 0 ? launch - (groups - 1) : 0;      // bands with a level group left to run
         const int last = launch < n_bands - 1 ? launch : n_bands - 1;
         const dim3 grid((unsigned)(last - first + 1));
-        if (groups_per_pass == 8)
-            hipLaunchKernelGGL(ycge::k_atrous_band<8>, grid, dim3(256), 0, stream, A, buf, statw, sky, d_pixels, d_offsets, n_levels, K, launch, first);
-        else if (groups_per_pass == 16)
-            hipLaunchKernelGGL(ycge::k_atrous_band<16>, grid, dim3(512), 0, stream, A, buf, statw, sky, d_pixels, d_offsets, n_levels, K, launch, first);
-        else
-            hipLaunchKernelGGL(ycge::k_atrous_band<32>, grid, dim3(1024), 0, stream, A, buf, statw, sky, d_pixels, d_offsets, n_levels, K, launch, first);
+        if (groups_per_pass == 8) launch_band<8>(win, grid, stream, A, buf, statw, sky, d_pixels, d_offsets, n_levels, K, launch, first, rows_per_band, window_width);
+        else if (groups_per_pass == 16) launch_band<16>(win, grid, stream, A, buf, statw, sky, d_pixels, d_offsets, n_levels, K, launch, first, rows_per_band, window_width);
+        else launch_band<32>(win, grid, stream, A, buf, statw, sky, d_pixels, d_offsets, n_levels, K, launch, first, rows_per_band, window_width);
     }
     return (int)hipGetLastError();
 }
