@@ -2,6 +2,7 @@
 // See ycge_accel.h for the contract (same topology / node order / leaf order as
 // reference Objects/BVH.cs:258-459 and Objects/MeshBVH.cs:371-576).
 #include "ycge_accel.h"
+#include "ycge_keysort.h"
 
 #include <cstring>
 
@@ -12,99 +13,6 @@ namespace ycge {
 namespace {
 
 constexpr int kBins = 16;           // SAH_Bins (BVH.cs:8, MeshBVH.cs:15)
-
-// ---- .NET 8 Array.Sort over a sub-range, as an index sort -----------------
-// The reference falls back to Array.Sort(arr, start, count, comparer) on the
-// centroid of one axis (BVH.cs:389,419; MeshBVH.cs:506,536).  Array.Sort is
-// System.Private.CoreLib's introspective sort (ArraySortHelper<T>): depth limit
-// 2*(log2(n)+1); partitions of <= 16 are finished by insertion sort (2 and 3
-// by compare-exchange), pivot = median of first/middle/last parked at hi-1,
-// heapsort when the depth budget is spent.  It is not stable, so the order it
-// leaves equal keys in is reproduced by running the same procedure.
-struct KeySorter {
-    int32_t *ord;           // permutation slice being sorted
-    const float *key;       // centroid of the chosen axis, indexed by item id
-
-    int cmp(int32_t a, int32_t b) const     // float.CompareTo
-    {
-        float x = key[a], y = key[b];
-        if (x < y) return -1;
-        if (x > y) return 1;
-        if (x == y) return 0;
-        if (is_nan(x)) return is_nan(y) ? 0 : -1;
-        return 1;
-    }
-    void exch(int i, int j) { int32_t t = ord[i]; ord[i] = ord[j]; ord[j] = t; }
-    void order2(int lo, int i, int j) { if (cmp(ord[lo + i], ord[lo + j]) > 0) exch(lo + i, lo + j); }
-
-    void insertion(int lo, int n)
-    {
-        for (int i = 0; i + 1 < n; i++) {
-            int32_t t = ord[lo + i + 1];
-            int j = i;
-            for (; j >= 0 && cmp(t, ord[lo + j]) < 0; j--) ord[lo + j + 1] = ord[lo + j];
-            ord[lo + j + 1] = t;
-        }
-    }
-    void sift(int lo, int i, int n)         // 1-based heap positions
-    {
-        int32_t d = ord[lo + i - 1];
-        while (i <= n / 2) {
-            int child = 2 * i;
-            if (child < n && cmp(ord[lo + child - 1], ord[lo + child]) < 0) child++;
-            if (!(cmp(d, ord[lo + child - 1]) < 0)) break;
-            ord[lo + i - 1] = ord[lo + child - 1];
-            i = child;
-        }
-        ord[lo + i - 1] = d;
-    }
-    void heap(int lo, int n)
-    {
-        for (int i = n / 2; i >= 1; i--) sift(lo, i, n);
-        for (int i = n; i > 1; i--) { exch(lo, lo + i - 1); sift(lo, 1, i - 1); }
-    }
-    int partition(int lo, int n)
-    {
-        int hi = n - 1, mid = hi >> 1;
-        order2(lo, 0, mid);
-        order2(lo, 0, hi);
-        order2(lo, mid, hi);
-        int32_t pivot = ord[lo + mid];
-        exch(lo + mid, lo + hi - 1);
-        int left = 0, right = hi - 1;
-        while (left < right) {
-            while (cmp(ord[lo + (++left)], pivot) < 0) {}
-            while (cmp(pivot, ord[lo + (--right)]) < 0) {}
-            if (left >= right) break;
-            exch(lo + left, lo + right);
-        }
-        if (left != hi - 1) exch(lo + left, lo + hi - 1);
-        return left;
-    }
-    void intro(int lo, int n, int depth)
-    {
-        while (n > 1) {
-            if (n <= 16) {
-                if (n == 2) { order2(lo, 0, 1); return; }
-                if (n == 3) { order2(lo, 0, 1); order2(lo, 0, 2); order2(lo, 1, 2); return; }
-                insertion(lo, n);
-                return;
-            }
-            if (depth == 0) { heap(lo, n); return; }
-            depth--;
-            int p = partition(lo, n);
-            intro(lo + p + 1, n - (p + 1), depth);
-            n = p;
-        }
-    }
-    void sort(int lo, int n)
-    {
-        if (n < 2) return;
-        int lg = 0;
-        for (uint32_t v = (uint32_t)n; v >>= 1;) lg++;
-        intro(lo, n, 2 * (lg + 1));
-    }
-};
 
 struct Box3 {
     float mn[3], mx[3];
@@ -233,7 +141,7 @@ void build_tree(const BoundsSoA &it, TreeFlavour flavour, BuiltTree &out)
         }
 
         int mid;
-        KeySorter sorter{ord.data(), it.c[best_axis].data()};
+        KeySorter<int32_t> sorter{ord.data(), it.c[best_axis].data()};
         if (split_bin < 0) {
             sorter.sort(s, cnt);
             out.sort_fallbacks++;

@@ -35,6 +35,17 @@ enum : uint32_t {
 #define YCGE_REF_PAYLOAD(r) ((r) & 0x1fffffffu)
 #define YCGE_REF_NONE_VALUE 0xffffffffu
 
+// device-side build of the scene-level BVH (ycge_bvh_build.hip): what the kernel hands back to the host
+#define YCGE_BVH_DEV_MAX_ITEMS 2560     // one workgroup keeps the item order and its node queue in LDS
+struct BvhBuildResult {
+    uint32_t root_ref;
+    float root_min[3], root_max[3];
+    int32_t n_nodes, n_inner, max_depth, fallback;      // fallback: deeper than the reference's stack - the host builder redoes the tree and reports it
+    uint32_t sorts;                                      // how often the reference's Array.Sort case ran (BVH.cs:389,419)
+    uint32_t pad[4];
+};
+static_assert(sizeof(BvhBuildResult) == 64, "BvhBuildResult");
+
 // Plane order: (x y)(z Z)(X Y) per child, lower case = min, upper case = max.  Every 8-byte pair is then an
 // (x, y) or a (z, z) pair, so the twelve slab products of a visit are six packed operations against just two
 // pairings of the ray's origin / reciprocal direction (mesh_walk).

@@ -45,6 +45,9 @@ int ycge_launch_atrous_inplace(int w, int h, int step, const float phi[4], float
                                const float *depth, const uint8_t *sky, float *statw, const uint32_t *d_pixels, const uint32_t *d_offsets,
                                int n_levels, int n_bands, int K, int groups_per_pass, int rows_per_band, unsigned window_width, hipStream_t stream);
 size_t ycge_exposure_scratch_bytes(int w, int h, int step);
+size_t ycge_bvh_build_scratch_bytes(int n);
+int ycge_launch_scene_bvh_build(const float *items, int n, void *scratch, void *ref_out, void *gnodes_out, uint32_t *leaf_out, void *result,
+                                hipStream_t stream);
 int ycge_launch_exposure(const float *hdr, const uint8_t *sky, int w, int h, int step, float *terms, void *state, const float consts[5],
                          void *scratch, int serial, hipStream_t stream);
 int ycge_launch_tonemap(const float *hdr, int hiW, int fbW, int fbH, int ss, float gamma, float saturation, float vibrance, const void *state,
@@ -75,6 +78,13 @@ template <class T> struct DevBuf {
         n = cap = count;
         return hipSuccess;
     }
+    // room for `count` elements, contents undefined; the allocation is kept when it is large enough
+    hipError_t reserve(size_t count)
+    {
+        if (count > cap || cap == 0) { const hipError_t e = alloc(count > 0 ? count : 1); if (e != hipSuccess) return e; }
+        n = count;
+        return hipSuccess;
+    }
     // per-frame callers (lights, moved objects) reuse the allocation when the new contents fit
     hipError_t upload(const std::vector<T> &v)
     {
@@ -101,6 +111,7 @@ struct Knobs {
     int mig = 1, mig_round = 12, mig_shade = 16;      // YCGE_MIG (0 = off), YCGE_MIG_ROUND, YCGE_MIG_SHADE: path migration in k_trace
     int post_mode = 0;               // YCGE_POST_MODE: in-place A-trous implementation (0 = default)
     bool post_hash = false;          // YCGE_POST_HASH_FORM=1: the hash form of k_atrous_band even where the window fits
+    bool scene_bvh_host = false;     // YCGE_SCENE_BVH_HOST: ycge_scene_update_objects builds the scene BVH on the host, not on the device
     bool exposure_serial = false;    // YCGE_EXPOSURE_SERIAL: the one-lane chain instead of the chunked exact evaluation
     void read()
     {
@@ -121,6 +132,7 @@ struct Knobs {
         mig = geti("YCGE_MIG", 1); mig_round = geti("YCGE_MIG_ROUND", 12); mig_shade = geti("YCGE_MIG_SHADE", 16);
         if (mig_round < 1) mig_round = 1;
         exposure_serial = getenv("YCGE_EXPOSURE_SERIAL") != nullptr;
+        scene_bvh_host = getenv("YCGE_SCENE_BVH_HOST") != nullptr;
     }
 };
 
@@ -228,7 +240,13 @@ struct ycge_ctx {
     DevBuf<uint8_t> d_cells;
     DevBuf<int32_t> d_lut;
     DevBuf<GLight> d_lights;
-    BuiltTree scene_tree;
+    BuiltTree scene_tree;                      // host copy of the scene BVH in the reference's format (ycge_read_accel)
+    bool scene_tree_on_device = false;         // ... not fetched yet from the last device-side build (accel_view does it on demand)
+    int32_t dev_tree_nodes = 0, dev_tree_items = 0;
+    DevBuf<float> d_bvh_items;                 // device-side scene BVH build (ycge_bvh_build.hip): item boxes + centroids, nine planes
+    DevBuf<uint8_t> d_bvh_scratch, d_bvh_ref, d_bvh_res;
+    int64_t bvh_device_builds = 0, bvh_host_fallbacks = 0, bvh_host_builds = 0;
+    double bvh_last_build_us = 0.0;
     std::vector<MeshHost> meshes;
 
     int fail(int code, const char *fmt, ...)
@@ -602,6 +620,7 @@ void ycge_destroy(ycge_ctx *c)
     c->schedules.clear();
     c->wf_q0.release(); c->wf_q1.release(); c->wf_hit.release(); c->wf_lq.release(); c->wf_seg.release(); c->wf_counts.release(); c->tile_order.release(); c->block_cost.release(); c->block_order.release(); c->order_ws.release(); c->stack_spill.release(); c->path_stack.release(); c->mig_entries.release(); c->mig_pub.release(); c->mig_ctl.release();
     c->d_scene_nodes.release(); c->d_mesh_arena.release(); c->d_scene_leaf.release(); c->d_prims.release();
+    c->d_bvh_items.release(); c->d_bvh_scratch.release(); c->d_bvh_ref.release(); c->d_bvh_res.release();
     c->d_materials.release(); c->d_meshes.release(); c->d_grids.release(); c->d_cells.release(); c->d_lut.release(); c->d_lights.release();
     for (auto &ev : c->ev) if (ev) (void)hipEventDestroy(ev);
     for (hipEvent_t ev : {c->fan_ev[0], c->fan_ev[1], c->traced_ev, c->order_ev, c->pushed_ev}) if (ev) (void)hipEventDestroy(ev);
@@ -701,11 +720,11 @@ struct ObjectsHost {
     int wf_rounds = 2, spill_levels = 0;
 };
 
-int build_objects(ycge_ctx *c, const ycge_prim *prims, int n_prims, ObjectsHost &oh)
+// Scene.Objects as device records + what Scene.RebuildBVH gets from every object's TryGetBounds (BVH.cs:32-53); no tree yet
+int flatten_objects(ycge_ctx *c, const ycge_prim *prims, int n_prims, ObjectsHost &oh, BoundsSoA &items)
 {
     std::vector<GPrim> &gprims = oh.gprims;
     gprims.assign(n_prims, GPrim{});
-    BoundsSoA items;
     items.resize(n_prims);
     for (int i = 0; i < n_prims; i++) {
         const ycge_prim &q = prims[i];
@@ -770,13 +789,28 @@ int build_objects(ycge_ctx *c, const ycge_prim *prims, int n_prims, ObjectsHost 
         if (overrides && prims[i].reflectivity >= c->cfg.mirror_threshold) can_mirror = true;
     }
     oh.wf_rounds = can_mirror ? 2 + c->cfg.max_mirror_bounces : 2;
-    build_tree(items, TreeFlavour::Scene, c->scene_tree);
-    if (c->scene_tree.max_depth > 128) return c->fail(YCGE_ERR_STACK_DEPTH, "scene BVH depth %d exceeds the reference's 128-entry stack (BVH.cs:118)", c->scene_tree.max_depth);
-    if (c->scene_tree.max_depth + 4 + c->max_mesh_depth + 2 > YCGE_TRAVERSAL_STACK)
-        return c->fail(YCGE_ERR_STACK_DEPTH, "combined traversal depth %d + %d exceeds the device stack", c->scene_tree.max_depth, c->max_mesh_depth);
+    return YCGE_OK;
+}
+
+int check_scene_depth(ycge_ctx *c, int max_depth, int &spill_levels)
+{
+    if (max_depth > 128) return c->fail(YCGE_ERR_STACK_DEPTH, "scene BVH depth %d exceeds the reference's 128-entry stack (BVH.cs:118)", max_depth);
+    if (max_depth + 4 + c->max_mesh_depth + 2 > YCGE_TRAVERSAL_STACK)
+        return c->fail(YCGE_ERR_STACK_DEPTH, "combined traversal depth %d + %d exceeds the device stack", max_depth, c->max_mesh_depth);
     // levels the per-lane stack can need beyond its LDS part: scene depth + 4 leaf objects + deepest mesh
-    const int need = c->scene_tree.max_depth + 4 + c->max_mesh_depth + 2 - YCGE_LDS_STACK_LEVELS;
-    oh.spill_levels = need > 0 ? need : 0;
+    const int need = max_depth + 4 + c->max_mesh_depth + 2 - YCGE_LDS_STACK_LEVELS;
+    spill_levels = need > 0 ? need : 0;
+    return YCGE_OK;
+}
+
+// the scene-level BVH by the host builder (ycge_accel.cpp)
+int build_scene_tree_host(ycge_ctx *c, const BoundsSoA &items, ObjectsHost &oh)
+{
+    build_tree(items, TreeFlavour::Scene, c->scene_tree);
+    c->scene_tree_on_device = false;
+    c->bvh_host_builds++;
+    const int rc = check_scene_depth(c, c->scene_tree.max_depth, oh.spill_levels);
+    if (rc != YCGE_OK) return rc;
     oh.scene_root = to_gpu_nodes(c->scene_tree, REF_SCENE_NODE, REF_SCENE_LEAF, 0, 0, 3, oh.scene_nodes);
     oh.leaf_prims.assign(c->scene_tree.leaf_index.begin(), c->scene_tree.leaf_index.end());
     if (c->scene_tree.root >= 0)
@@ -799,6 +833,55 @@ int install_objects(ycge_ctx *c, const ObjectsHost &oh)
     sd.scene_root_ref = oh.scene_root;
     for (int a = 0; a < 3; a++) { sd.scene_root_min[a] = oh.root_min[a]; sd.scene_root_max[a] = oh.root_max[a]; }
     c->block_order_valid = false;
+    return YCGE_OK;
+}
+
+int build_objects(ycge_ctx *c, const ycge_prim *prims, int n_prims, ObjectsHost &oh)
+{
+    BoundsSoA items;
+    const int rc = flatten_objects(c, prims, n_prims, oh, items);
+    return rc != YCGE_OK ? rc : build_scene_tree_host(c, items, oh);
+}
+
+// ycge_scene_update_objects, device form: the object records and their boxes go up, ycge_bvh_build.hip builds the tree where the
+// trace reads it.  Returns 1 when the kernel declines (a tree deeper than the reference's stack; the caller then builds on the host).
+int install_objects_device_built(ycge_ctx *c, ycge_ctx *root, const ObjectsHost &oh, const BoundsSoA &items)
+{
+    HIP_TRY(c, hipSetDevice(c->device));
+    const int n = (int)items.size();
+    std::vector<float> planes((size_t)9 * n);
+    for (int a = 0; a < 3; a++)
+        for (int i = 0; i < n; i++) {
+            planes[(size_t)a * n + i] = items.mn[a][i]; planes[(size_t)(3 + a) * n + i] = items.mx[a][i]; planes[(size_t)(6 + a) * n + i] = items.c[a][i];
+        }
+    HIP_TRY(c, c->d_prims.upload(oh.gprims)); HIP_TRY(c, c->d_bvh_items.upload(planes));
+    HIP_TRY(c, c->d_scene_nodes.reserve((size_t)n)); HIP_TRY(c, c->d_scene_leaf.reserve((size_t)n));
+    HIP_TRY(c, c->d_bvh_scratch.reserve(ycge_bvh_build_scratch_bytes(n))); HIP_TRY(c, c->d_bvh_ref.reserve((size_t)2 * n * sizeof(RefNode)));
+    HIP_TRY(c, c->d_bvh_res.reserve(sizeof(BvhBuildResult)));
+    const int e = ycge_launch_scene_bvh_build(c->d_bvh_items.p, n, c->d_bvh_scratch.p, c->d_bvh_ref.p, c->d_scene_nodes.p, c->d_scene_leaf.p, c->d_bvh_res.p, c->stream);
+    if (e != 0) return c->fail(YCGE_ERR_DEVICE, "k_scene_bvh_build launch failed: %s", hipGetErrorString((hipError_t)e));
+    BvhBuildResult res;
+    HIP_TRY(c, hipMemcpyAsync(&res, c->d_bvh_res.p, sizeof res, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    if (res.fallback) {
+        if (getenv("YCGE_DEBUG_BVH")) fprintf(stderr, "[ycge] device BVH build fell back: reason %u node %u count %u split bin %d (n = %d)\n", res.pad[0], res.pad[1], res.pad[2], (int)res.pad[3], n);
+        return 1;
+    }
+    int spill = 0;
+    const int rc = check_scene_depth(c, res.max_depth, spill);
+    if (rc != YCGE_OK) return rc;
+    c->wf_rounds = oh.wf_rounds;
+    if (spill != c->spill_levels) {
+        c->spill_levels = spill;
+        const int rc2 = alloc_tile_buffers(c);
+        if (rc2 != YCGE_OK) return rc2;
+    }
+    SceneDev &sd = c->sd;
+    sd.scene_nodes = c->d_scene_nodes.p; sd.scene_leaf_prims = c->d_scene_leaf.p; sd.prims = c->d_prims.p;
+    sd.scene_root_ref = res.root_ref;
+    for (int a = 0; a < 3; a++) { sd.scene_root_min[a] = res.root_min[a]; sd.scene_root_max[a] = res.root_max[a]; }
+    c->block_order_valid = false;
+    if (c == root) { c->scene_tree_on_device = true; c->dev_tree_nodes = res.n_nodes; c->dev_tree_items = n; c->scene_tree.max_depth = res.max_depth; c->scene_tree.sort_fallbacks = (int32_t)res.sorts; }
     return YCGE_OK;
 }
 
@@ -1070,21 +1153,53 @@ int ycge_scene_update_objects(ycge_ctx *c, const ycge_prim *prims, int32_t n_pri
     if (!c->have_scene) return c->fail(YCGE_ERR_NO_SCENE, "no scene uploaded");
     if (n_prims < 0 || (n_prims > 0 && !prims)) return c->fail(YCGE_ERR_INVALID_ARG, "bad object array");
     ObjectsHost oh;
-    int rc = build_objects(c, prims, n_prims, oh);        // host work first: the devices keep rendering the old objects meanwhile
+    BoundsSoA items;
+    int rc = flatten_objects(c, prims, n_prims, oh, items);       // host work first: the devices keep rendering the old objects meanwhile
     if (rc != YCGE_OK) return rc;
+    // the tree itself is built on the device (ycge_bvh_build.hip) - on the host only for what that kernel does not take: no objects,
+    // more than YCGE_BVH_DEV_MAX_ITEMS, or (reported by the kernel) a tree deeper than the reference's stack allows
+    bool on_device = !c->knobs.scene_bvh_host && n_prims >= 1 && n_prims <= YCGE_BVH_DEV_MAX_ITEMS;
+    if (!on_device) { rc = build_scene_tree_host(c, items, oh); if (rc != YCGE_OK) return rc; }
     rc = quiesce(c);
     for (ycge_ctx *p : c->peers) if (rc == YCGE_OK) rc = quiesce(p);
     if (rc != YCGE_OK) return rc;
     c->have_scene = false;
-    rc = install_objects(c, oh);
-    for (ycge_ctx *p : c->peers) {
-        if (rc != YCGE_OK) break;
-        rc = install_objects(p, oh);
-        if (rc != YCGE_OK) c->err = p->err;
+    const auto t0 = std::chrono::steady_clock::now();
+    if (on_device) {
+        rc = install_objects_device_built(c, c, oh, items);
+        for (ycge_ctx *p : c->peers) {
+            if (rc != YCGE_OK) break;
+            rc = install_objects_device_built(p, c, oh, items);       // the same kernel on the same items: the same tree
+            if (rc < 0) c->err = p->err;
+        }
+        if (rc == 1) {
+            c->bvh_host_fallbacks++;
+            on_device = false;
+            rc = build_scene_tree_host(c, items, oh);
+        } else if (rc == YCGE_OK) c->bvh_device_builds++;
     }
+    if (!on_device && rc == YCGE_OK) {
+        rc = install_objects(c, oh);
+        for (ycge_ctx *p : c->peers) {
+            if (rc != YCGE_OK) break;
+            rc = install_objects(p, oh);
+            if (rc != YCGE_OK) c->err = p->err;
+        }
+    }
+    c->bvh_last_build_us = std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t0).count();
     (void)hipSetDevice(c->device);
     if (rc != YCGE_OK) return rc;
     c->have_scene = true;
+    return YCGE_OK;
+}
+
+// test / profiling hook: {device builds, host rebuilds after the kernel declined (a tree deeper than the reference's stack), host builds,
+// microseconds of the last update's build + install, Array.Sort cases in the current tree (BVH.cs:389,419), depth of the current tree}
+int ycge_debug_scene_bvh_stats(ycge_ctx *c, int64_t *out6)
+{
+    if (!c || !out6) return YCGE_ERR_INVALID_ARG;
+    out6[0] = c->bvh_device_builds; out6[1] = c->bvh_host_fallbacks; out6[2] = c->bvh_host_builds; out6[3] = (int64_t)c->bvh_last_build_us;
+    out6[4] = c->scene_tree.sort_fallbacks; out6[5] = c->scene_tree.max_depth;
     return YCGE_OK;
 }
 
@@ -1692,6 +1807,17 @@ int ycge_read_buffer(ycge_ctx *c, int32_t which, void *dst, size_t bytes)
 
 static int accel_view(ycge_ctx *c, int32_t which, int32_t index, const void **p, size_t *n)
 {
+    if (c->scene_tree_on_device && (which == YCGE_ACCEL_SCENE_NODES || which == YCGE_ACCEL_SCENE_LEAF_INDEX)) {
+        // the tree was built on the device: fetch the reference-format copy the first time somebody asks for it
+        c->scene_tree.nodes.resize((size_t)c->dev_tree_nodes);
+        c->scene_tree.leaf_index.resize((size_t)c->dev_tree_items);
+        if (hipSetDevice(c->device) != hipSuccess || hipStreamSynchronize(c->stream) != hipSuccess ||
+            hipMemcpy(c->scene_tree.nodes.data(), c->d_bvh_ref.p, (size_t)c->dev_tree_nodes * sizeof(RefNode), hipMemcpyDeviceToHost) != hipSuccess ||
+            hipMemcpy(c->scene_tree.leaf_index.data(), c->d_scene_leaf.p, (size_t)c->dev_tree_items * 4, hipMemcpyDeviceToHost) != hipSuccess)
+            return -1;
+        c->scene_tree.root = 0;
+        c->scene_tree_on_device = false;
+    }
     switch (which) {
     case YCGE_ACCEL_SCENE_NODES: *p = c->scene_tree.nodes.data(); *n = c->scene_tree.nodes.size() * sizeof(RefNode); return 0;
     case YCGE_ACCEL_SCENE_LEAF_INDEX: *p = c->scene_tree.leaf_index.data(); *n = c->scene_tree.leaf_index.size() * 4; return 0;

@@ -97,6 +97,17 @@ class RaytraceRenderer:
         self._check(self.L.ycge_scene_update_objects(self.ctx, C.cast(f.prims, C.POINTER(abi.Prim)), f.struct.n_prims))
         self.flat = f
 
+    def scene_bvh_stats(self) -> dict:
+        """How ycge_scene_update_objects built the scene BVH so far: on the device (csrc/ycge_bvh_build.hip), on the host after the
+        kernel declined, on the host outright; microseconds of the last build + install; how often the current tree took the
+        reference's Array.Sort path (BVH.cs:389,419) and its depth."""
+        out = (C.c_int64 * 6)()
+        self.L.ycge_debug_scene_bvh_stats.restype = C.c_int
+        self.L.ycge_debug_scene_bvh_stats.argtypes = [C.c_void_p, C.c_void_p]
+        self._check(self.L.ycge_debug_scene_bvh_stats(self.ctx, out))
+        return dict(device_builds=int(out[0]), host_fallbacks=int(out[1]), host_builds=int(out[2]), last_build_us=int(out[3]),
+                    sort_fallbacks=int(out[4]), max_depth=int(out[5]))
+
     def Resize(self, fb_width: int, fb_height: int, superSample: int):
         self._check(self.L.ycge_resize(self.ctx, fb_width, fb_height, superSample))
         self._set_dims(fb_width, fb_height, max(1, superSample))
