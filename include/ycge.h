@@ -274,7 +274,9 @@ int ycge_scene_update_lights(ycge_ctx *ctx, const ycge_light *lights, int32_t n_
 /* Scene.Update() -> RebuildBVH() after an entity moved its geometry (Scenes/Scene.cs:122-127; e.g.
  * BobbingSphereEntity.Update, Scenes/TestScenesRandom.cs:708-714): replaces the Scene.Objects records and
  * rebuilds the scene-level BVH only.  `prims` index the materials, meshes and grids of the last
- * ycge_scene_upload (a Mesh keeps its own BVH in the reference too, Mesh.cs:14). */
+ * ycge_scene_upload (a Mesh keeps its own BVH in the reference too, Mesh.cs:14).  The tree (Objects/BVH.cs:258-459,
+ * same nodes, numbering and leaf order) is built on the device for up to 2 560 objects - the host only flattens the
+ * records and their boxes - and by the host builder above that. */
 int ycge_scene_update_objects(ycge_ctx *ctx, const ycge_prim *prims, int32_t n_prims);
 
 /* The argument checks of ycge_scene_upload on their own: pure host code, no device and no context needed
