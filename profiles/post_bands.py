@@ -1,0 +1,42 @@
+"""Per-band begin / end of the persistent in-place A-trous launch (k_atrous_stream): chain per pass, lag between neighbouring bands."""
+import sys, ctypes as C
+from pathlib import Path
+ROOT = Path(__file__).resolve().parents[1]
+sys.path.insert(0, str(ROOT))
+import numpy as np
+from yetanotherconsolegameengine_amd import scenes
+from yetanotherconsolegameengine_amd.renderer import RaytraceRenderer
+sc, w, h, ss, pose = scenes.config_scene(4)
+r = RaytraceRenderer(sc, w, h, pose["fov"], ss)
+r.SetCamera(pose["pos"], pose["yaw"], pose["pitch"])
+for i in range(4):
+    r.TryFlipAndBlit(want_sdr=True)
+print(f"post {r.stats.post_ms:.3f} ms")
+nb = 135
+buf = np.zeros(nb * 32, np.uint32)
+r.L.ycge_debug_read_post_progress.restype = C.c_int
+r.L.ycge_debug_read_post_progress.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t]
+assert r.L.ycge_debug_read_post_progress(r.ctx, buf.ctypes.data, buf.size) == 0
+rec = buf.reshape(nb, 32)
+t = rec[:, 4:8].copy().view(np.uint64).reshape(nb, 2).astype(np.float64) * 0.01     # us
+passes = rec[:, 8].astype(np.float64)
+t0 = t[:, 0].min()
+dur = t[:, 1] - t[:, 0]
+print(f"launch span {t[:, 1].max() - t0:.1f} us; band 0: {dur[0]:.1f} us for {passes[0]:.0f} passes = {dur[0] / passes[0]:.3f} us per pass")
+print("per pass (own duration / passes), bands 0, 1, 2, 10, 60, 134:", [round(dur[b] / passes[b], 3) for b in (0, 1, 2, 10, 60, 134)])
+end_lag = np.diff(t[:, 1])
+print(f"end(b) - end(b-1): mean {end_lag.mean():.2f} us, median {np.median(end_lag):.2f}, max {end_lag.max():.2f}")
+beg_lag = np.diff(t[:, 0])
+print(f"begin(b) - begin(b-1): mean {beg_lag.mean():.2f} us (dispatch)")
+
+# hand-over of level 1400 (bands that have it: 12 b <= 1400 < 12 b + 970)
+pub = rec[:, 10:12].copy().view(np.uint64).ravel().astype(np.float64) * 0.01       # this band published "1400 complete"
+fet = rec[:, 12:14].copy().view(np.uint64).ravel().astype(np.float64) * 0.01       # this band was allowed to fetch level 1400
+cmp_ = rec[:, 14:16].copy().view(np.uint64).ravel().astype(np.float64) * 0.01      # this band began computing level 1400
+act = [b for b in range(1, nb) if pub[b] > 0 and pub[b - 1] > 0 and fet[b] > 0 and cmp_[b] > 0]
+if act:
+    a = np.array(act)
+    print(f"level 1400 over {len(a)} band pairs (us): published(b) - published(b-1) median {np.median(pub[a] - pub[a-1]):.2f}")
+    print(f"  upstream computes 1399 -> ... this band may fetch 1400: fetch(b) - compute(b-1, 1400) median {np.median(fet[a] - cmp_[a-1]):.2f}")
+    print(f"  fetch -> begin computing: {np.median(cmp_[a] - fet[a]):.2f};  begin computing -> published complete: {np.median(pub[a] - cmp_[a]):.2f}")
+    print(f"  compute(b,1400) - compute(b-1,1400): {np.median(cmp_[a] - cmp_[a-1]):.2f}")

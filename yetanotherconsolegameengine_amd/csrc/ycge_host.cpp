@@ -44,6 +44,9 @@ int ycge_launch_atrous_static(int w, int h, int step, const float phi[4], const 
 int ycge_launch_atrous_inplace(int w, int h, int step, const float phi[4], float *buf, const float *albedo, const float *unit_n,
                                const float *depth, const uint8_t *sky, float *statw, const uint32_t *d_pixels, const uint32_t *d_offsets,
                                int n_levels, int n_bands, int K, int groups_per_pass, int rows_per_band, unsigned window_width, hipStream_t stream);
+int ycge_launch_atrous_persist(int w, int h, int step, const float phi[4], float *buf, const uint8_t *sky, float *statw, const uint32_t *d_pixels,
+                               const uint32_t *d_offsets, const uint32_t *d_pass_level, int n_levels, int n_bands, int K, int groups_per_pass, int rows_per_band, unsigned window_width,
+                               uint32_t *progress, uint32_t epoch, int xcd_local, int level_handover, hipStream_t stream);
 size_t ycge_exposure_scratch_bytes(int w, int h, int step);
 size_t ycge_bvh_build_scratch_bytes(int n);
 int ycge_launch_scene_bvh_build(const float *items, int n, void *scratch, void *ref_out, void *gnodes_out, uint32_t *leaf_out, void *result,
@@ -109,7 +112,7 @@ struct Knobs {
     int post_band_rows = YCGE_POST_BAND_ROWS_DEFAULT, post_k = YCGE_POST_K_DEFAULT, post_groups = YCGE_POST_GROUPS_DEFAULT;
     int fan_class = -1, fan_cap = -1;   // -1 = default by world size
     int mig = 1, mig_round = 12, mig_shade = 16;      // YCGE_MIG (0 = off), YCGE_MIG_ROUND, YCGE_MIG_SHADE: path migration in k_trace
-    int post_mode = 0;               // YCGE_POST_MODE: in-place A-trous implementation (0 = default)
+    int post_mode = 0;               // YCGE_POST_MODE: in-place A-trous: 0 = one persistent launch, level-granular hand-over (k_atrous_stream), 2 = a launch per level group, 3 = as 0 with bands in block order, 4 = persistent with group hand-over (k_atrous_persist)
     bool post_hash = false;          // YCGE_POST_HASH_FORM=1: the hash form of k_atrous_band even where the window fits
     bool scene_bvh_host = false;     // YCGE_SCENE_BVH_HOST: ycge_scene_update_objects builds the scene BVH on the host, not on the device
     bool exposure_serial = false;    // YCGE_EXPOSURE_SERIAL: the one-lane chain instead of the chunked exact evaluation
@@ -208,8 +211,10 @@ struct ycge_ctx {
     DevBuf<float> den_a, den_b, unit_n, exp_terms, d_sdr;
     DevBuf<float> atrous_statw;                // [pixel][25 taps][3]: colour-independent weight factors of an in-place A-trous iteration
     DevBuf<uint8_t> exp_scratch;                  // chunk records of the exposure sum (k_exposure_sum)
+    DevBuf<uint32_t> post_progress;               // k_atrous_persist: groups finished per band, one 128-byte line each
+    uint32_t post_epoch = 0;                      // ... counted from here in the next launch
     DevBuf<uint8_t> tone_state;                   // ToneMapper state; lives as long as the context (not reset by Resize)
-    struct InplaceSchedule { int w = 0, h = 0, step = 0, levels = 0, bands = 0, rows_per_band = 0, levels_per_launch = 0; uint32_t max_level_pixels = 0, window_width = 0; DevBuf<uint32_t> pixels, offsets; };
+    struct InplaceSchedule { int w = 0, h = 0, step = 0, levels = 0, bands = 0, rows_per_band = 0, levels_per_launch = 0; uint32_t max_level_pixels = 0, window_width = 0; DevBuf<uint32_t> pixels, offsets, pass_level; };
     std::vector<InplaceSchedule *> schedules;     // level schedules of the in-place A-trous iterations, by (w, h, step)
     // what ycge_scene_update_objects needs from the last full upload
     std::vector<GMesh> gmeshes_host;
@@ -1193,6 +1198,15 @@ int ycge_scene_update_objects(ycge_ctx *c, const ycge_prim *prims, int32_t n_pri
     return YCGE_OK;
 }
 
+// profiling aid: the progress lines of the persistent in-place A-trous launch (32 words per band: [0] progress, [4..7] begin / end
+// timestamps at 100 MHz, [8] passes) of the last frame with a post stage
+int ycge_debug_read_post_progress(ycge_ctx *c, uint32_t *dst, size_t n_words)
+{
+    if (!c || !dst || !c->post_progress.p || n_words > c->post_progress.n) return YCGE_ERR_INVALID_ARG;
+    HIP_TRY(c, hipDeviceSynchronize());
+    HIP_TRY(c, hipMemcpy(dst, c->post_progress.p, n_words * 4, hipMemcpyDeviceToHost));
+    return YCGE_OK;
+}
 // test / profiling hook: {device builds, host rebuilds after the kernel declined (a tree deeper than the reference's stack), host builds,
 // microseconds of the last update's build + install, Array.Sort cases in the current tree (BVH.cs:389,419), depth of the current tree}
 int ycge_debug_scene_bvh_stats(ycge_ctx *c, int64_t *out6)
@@ -1566,6 +1580,11 @@ int run_post(ycge_ctx *c, hipStream_t stream, float *out_sdr_host, bool timed)
                                        ? band_window_width(bpx, boff, sc->bands, sc->levels, sc->levels_per_launch, rows_per_band, (uint32_t)c->knobs.post_groups, 2048u) : 0u;
                 c->schedules.push_back(sc);
                 HIP_TRY(c, sc->pixels.upload(bpx)); HIP_TRY(c, sc->offsets.upload(boff));
+                std::vector<uint32_t> plevel(bpx.size() / (size_t)c->knobs.post_groups + 1, 0u);       // level of every pass (k_atrous_stream)
+                for (int b = 0; b < sc->bands; b++)
+                    for (int t = 0; t < sc->levels; t++)
+                        for (uint32_t ps = boff[(size_t)b * (sc->levels + 1) + t]; ps < boff[(size_t)b * (sc->levels + 1) + t + 1]; ps++) plevel[ps] = (uint32_t)t;
+                HIP_TRY(c, sc->pass_level.upload(plevel));
             }
             const int levels_per_launch = sc->levels_per_launch;
             if (levels_per_launch < 1) return c->fail(YCGE_ERR_UNSUPPORTED, "in-place A-trous: a level of %u pixels in one band", sc->max_level_pixels);
@@ -1575,6 +1594,22 @@ int run_post(ycge_ctx *c, hipStream_t stream, float *out_sdr_host, bool timed)
                 e = ycge_launch_atrous_static(w, h, step, phi, c->g_albedo.p, c->unit_n.p, c->g_depth.p, c->sky.p, c->atrous_statw.p, stream);
                 if (e != 0) return c->fail(YCGE_ERR_DEVICE, "k_atrous_static launch failed: %s", hipGetErrorString((hipError_t)e));
             }
+            // one persistent launch when the window form applies and every band's workgroup is resident at once (it waits for its
+            // neighbour inside the kernel); else a launch per level group
+            const bool persist = c->knobs.post_mode != 2 && sc->window_width != 0 && (size_t)sc->rows_per_band * sc->window_width <= 2048 &&
+                                 c->compute_units > 0 && ((sc->bands + 7) / 8) * 8 <= c->compute_units;
+            if (persist) {
+                const uint32_t groups = (uint32_t)((sc->levels + levels_per_launch - 1) / levels_per_launch);
+                if (c->post_progress.n < (size_t)sc->bands * 32 || c->post_epoch > 0x60000000u) {
+                    HIP_TRY(c, c->post_progress.reserve((size_t)sc->bands * 32));
+                    HIP_TRY(c, hipMemsetAsync(c->post_progress.p, 0, (size_t)sc->bands * 32 * sizeof(uint32_t), stream));
+                    c->post_epoch = 0;
+                }
+                e = ycge_launch_atrous_persist(w, h, step, phi, dst, c->sky.p, c->atrous_statw.p, sc->pixels.p, sc->offsets.p, sc->pass_level.p, sc->levels, sc->bands,
+                                               levels_per_launch, c->knobs.post_groups, sc->rows_per_band, sc->window_width, c->post_progress.p, c->post_epoch,
+                                               c->knobs.post_mode == 3 ? 0 : 1, c->knobs.post_mode == 4 ? 0 : 1, stream);
+                c->post_epoch += (groups > (uint32_t)sc->levels ? groups : (uint32_t)sc->levels) + 1u;
+            } else
             e = ycge_launch_atrous_inplace(w, h, step, phi, dst, c->g_albedo.p, c->unit_n.p, c->g_depth.p, c->sky.p, c->atrous_statw.p,
                                            sc->pixels.p, sc->offsets.p, sc->levels, sc->bands, levels_per_launch, c->knobs.post_groups, sc->rows_per_band, sc->window_width, stream);
         } else {

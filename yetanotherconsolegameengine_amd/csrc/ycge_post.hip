@@ -32,6 +32,16 @@ struct ToneState {                          // ToneMapper fields that change (To
 
 __device__ __forceinline__ F3 ld3(const float *p, size_t i) { return f3(p[3 * i], p[3 * i + 1], p[3 * i + 2]); }
 __device__ __forceinline__ void st3(float *p, size_t i, F3 v) { p[3 * i] = v.x; p[3 * i + 1] = v.y; p[3 * i + 2] = v.z; }
+// device-coherent forms (sc1): a store written through to memory, a load that never returns another XCD's stale copy - measured
+// in profiles/micro/xcdvis.hip (store sc1 + load sc1: 0 stale reads of 2 000 across XCDs; every other pairing: 2 000 of 2 000)
+__device__ __forceinline__ float ld_dev(const float *p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ F3 ld3_dev(const float *p, size_t i) { return f3(ld_dev(p + 3 * i), ld_dev(p + 3 * i + 1), ld_dev(p + 3 * i + 2)); }
+__device__ __forceinline__ void st3_dev(float *p, size_t i, F3 v)
+{
+    __hip_atomic_store(p + 3 * i, v.x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __hip_atomic_store(p + 3 * i + 1, v.y, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __hip_atomic_store(p + 3 * i + 2, v.z, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
 __device__ __forceinline__ float luma3(F3 c) { return 0.2126f * c.x + 0.7152f * c.y + 0.0722f * c.z; }
 __device__ __forceinline__ float kernel_tap(int k) { return k == 0 ? 3.0f / 8.0f : (k == 1 || k == -1) ? 1.0f / 4.0f : 1.0f / 16.0f; }   // :646
 
@@ -174,6 +184,7 @@ __global__ __launch_bounds__(256) void k_atrous_static(const AtrousParams A, con
 #define YCGE_POST_HASH 2048         // entries of the hash form; the host keeps a launch's pixels below 3/4 of it
 #define YCGE_POST_WIN 2048          // entries of the window form: rows of the band x window width
 #define YCGE_POST_NONE 0xffffffffu
+#define YCGE_POST_PROBE_LEVEL 1400    // profiling aid of k_atrous_stream: times of this level's hand-over (profiles/post_bands.py)
 // Where a launch keeps its new colours.  WINDOW form (the default): entry (row in the band) * WX + (x mod WX) - the host has checked,
 // list by list, that no two pixels one launch writes share an entry (a launch's levels cover a short diagonal stripe of the band: 16
 // columns per row at step 2), so a lookup is one LDS read at an address known a pass ahead and an insert is a plain store: no probe
@@ -182,6 +193,7 @@ __global__ __launch_bounds__(256) void k_atrous_static(const AtrousParams A, con
 template <int G> struct PostSharedT {
     float val[G][4][28];        // [component x, y, z, weight][tap], a row padded to 16-byte multiples: the sum reads its 25 terms as 6 x b128 + 1
     uint4 ent[YCGE_POST_HASH];  // {pixel (tag), r, g, b as bits}: a lookup is ONE 16-byte LDS read
+    uint32_t out_slot[2][G];    // k_atrous_stream: the entry each group wrote in the last two passes (YCGE_POST_NONE: none), for the publishing wavefront
 };
 static_assert(YCGE_POST_WIN == YCGE_POST_HASH, "one LDS array serves both forms");
 struct BandWindow { int y0, rows; uint32_t wx, use; };     // use == 0: hash form
@@ -194,6 +206,7 @@ struct PassData {           // what one lane needs for one pass, fetched ahead
     uint32_t pslot, jslot;  // window form: their entries (YCGE_POST_NONE: the tap's row is outside the band)
     uint8_t sky0, sky_j;
 };
+template <bool COH = false, bool COH_ALL = false>
 __device__ __forceinline__ PassData pass_fetch(const AtrousParams &A, const BandWindow &W, const float *buf, const float *statw, const uint8_t *sky,
                                                uint32_t p, int t)
 {
@@ -212,15 +225,15 @@ __device__ __forceinline__ PassData pass_fetch(const AtrousParams &A, const Band
     D.jslot = (rj >= 0 && rj < W.rows) ? (uint32_t)rj * W.wx + ((uint32_t)sx & (W.wx - 1u)) : YCGE_POST_NONE;
     D.pslot = ((uint32_t)rp * W.wx + ((uint32_t)x & (W.wx - 1u))) & (YCGE_POST_WIN - 1u);
     D.sky0 = sky[pp];
-    D.c0 = ld3(buf, pp);
+    D.c0 = COH_ALL ? ld3_dev(buf, pp) : ld3(buf, pp);   // (own rows in k_atrous_stream: what this launch has rewritten comes from the LDS table, the rest is old in every cache)
     D.sky_j = sky[D.j];
-    D.cj = ld3(buf, D.j);
+    D.cj = (COH_ALL || (COH && rj < 0)) ? ld3_dev(buf, D.j) : ld3(buf, D.j);     // ... a tap above the band is the only colour this launch reads that another workgroup writes
     const float *sw = statw + ((size_t)pp * 25 + (size_t)(t < 25 ? t : 0)) * 3;
     D.wn = sw[0]; D.wz = sw[1]; D.wa = sw[2];
     return D;
 }
 template <bool WIN, class SH>
-__device__ __forceinline__ void pass_compute(const AtrousParams &A, uint32_t p, PassData D, SH &sh)
+__device__ __forceinline__ void pass_compute(const AtrousParams &A, uint32_t p, PassData D, SH &sh, uint32_t *out_slot = nullptr)
 {
     const int g = threadIdx.x >> 5, t = threadIdx.x & 31;
     const int kx = t % 5 - 2, ky = t / 5 - 2;
@@ -266,10 +279,12 @@ __device__ __forceinline__ void pass_compute(const AtrousParams &A, uint32_t p, 
     if (WIN) {
         // lanes 0..2 hold the colour sums, lane 3 the weight sum: one DPP move hands it to its quad, every lane of the quad stores one word
         const float wsum = __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(acc), 0xFF /* quad_perm 3,3,3,3 */, 0xF, 0xF, true));
-        if (work && t < 4 && wsum > 1e-8f) {                // else dst = c0: unchanged, nothing to record
+        const bool changed = work && wsum > 1e-8f;          // else dst = c0: unchanged, nothing to record
+        if (changed && t < 4) {
             const float inv = 1.0f / wsum;
             (&sh.ent[D.pslot].x)[(t + 1) & 3] = t < 3 ? __float_as_uint(acc * inv) : D.p;
         }
+        if (out_slot && t == 3) out_slot[threadIdx.x >> 5] = changed ? D.pslot : YCGE_POST_NONE;      // k_atrous_stream: for the publishing wavefront
     } else {
         const float wsum = __shfl(acc, (threadIdx.x & 32) + 3, 64);
         uint32_t h = 0;
@@ -322,6 +337,175 @@ __global__ __launch_bounds__(32 * G) void k_atrous_band(const AtrousParams A, fl
     for (uint32_t e = threadIdx.x; e < n_ent; e += 32 * G) {
         const uint4 en = sh.ent[e];
         if (en.x != YCGE_POST_NONE) st3(buf, en.x, f3(__uint_as_float(en.y), __uint_as_float(en.z), __uint_as_float(en.w)));
+    }
+}
+
+// The whole in-place iteration in ONE launch: a workgroup per band walks all of its level groups; before a group it waits for the
+// band above to have finished the same group (progress[band] = epoch + groups finished, one 128-byte line per band), after it the
+// new colours go out and the count goes up.  The launch form pays a kernel boundary per group AND lets a band start a group only a
+// whole launch after its neighbour (8 levels of skew per band where the stencil needs 12 levels of offset anyway: 135 x 8 + 2 581
+// level times); here a band trails its neighbour by what the data needs.  What makes it possible without cache-wide fences
+// (a buffer_wbl2 / buffer_inv pair per group cost more than the launches, round 1): colours are stored write-through and loaded
+// with device-coherent loads (sc1), which cost 25 ns more than plain ones when the line is in L2 (profiles/micro/ldflavour.hip)
+// and are never stale (profiles/micro/xcdvis.hip).  Why the order is right: as in k_atrous_band - a tap in the band above is
+// earlier in scan order and has a smaller level, hence a group <= this one, finished and published before this group starts; a
+// tap in the band below must be read OLD, and that band does not start the group that rewrites it before this band has published
+// the same group.  All bands must be resident at once (one workgroup each; the host checks the count against the chip).
+// xcd_local: band = (block % 8) * per_xcd + block / 8 keeps neighbouring bands on one XCD under round-robin dispatch (their
+// colours then meet in one L2); correctness does not depend on where a workgroup lands.
+template <int G>
+__global__ __launch_bounds__(32 * G) void k_atrous_persist(const AtrousParams A, float *__restrict__ buf, const float *__restrict__ statw,
+                                                           const uint8_t *__restrict__ sky, const uint32_t *__restrict__ pixels,
+                                                           const uint32_t *__restrict__ off, int levels, int K, int n_bands, int rows_per_band,
+                                                           uint32_t wx, uint32_t *__restrict__ progress, uint32_t epoch, int xcd_local)
+{
+    __shared__ __attribute__((aligned(16))) PostSharedT<G> sh;
+    int b = (int)blockIdx.x;
+    if (xcd_local) { const int per_xcd = (n_bands + 7) / 8; b = ((int)blockIdx.x % 8) * per_xcd + (int)blockIdx.x / 8; }
+    if (b >= n_bands) return;
+    const int groups = (levels + K - 1) / K;
+    const uint32_t *o = off + (size_t)b * (levels + 1);
+    const int grp = threadIdx.x >> 5, t = threadIdx.x & 31;
+    const BandWindow W = {b * rows_per_band, rows_per_band, wx, 1u};
+    const uint32_t n_ent = (uint32_t)rows_per_band * wx;
+    for (int g = 0; g < groups; g++) {
+        const int t0 = g * K, t1 = t0 + K < levels ? t0 + K : levels;
+        const uint32_t pass_lo = o[t0], pass_hi = o[t1];
+        if (pass_lo < pass_hi) {
+            if (b > 0)      // every lane polls the one word: no one-lane loop in front of the barriers below
+                while ((int32_t)(__hip_atomic_load(&progress[(size_t)(b - 1) * 32], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - epoch) < g + 1)
+                    __builtin_amdgcn_s_sleep(1);
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+            for (uint32_t e = threadIdx.x; e < n_ent; e += 32 * G) sh.ent[e].x = YCGE_POST_NONE;
+            uint32_t p1 = pixels[(size_t)pass_lo * G + grp];
+            uint32_t p2 = pass_lo + 1 < pass_hi ? pixels[(size_t)(pass_lo + 1) * G + grp] : YCGE_POST_NONE;
+            PassData D1 = pass_fetch<true, true>(A, W, buf, statw, sky, p1, t);
+            lds_barrier();              // table cleared
+            for (uint32_t i = pass_lo; i < pass_hi; i++) {
+                const uint32_t p3 = i + 2 < pass_hi ? pixels[(size_t)(i + 2) * G + grp] : YCGE_POST_NONE;
+                const PassData D2 = pass_fetch<true, true>(A, W, buf, statw, sky, p2, t);
+                pass_compute<true>(A, p1, D1, sh);
+                p1 = p2; D1 = D2; p2 = p3;
+            }
+            for (uint32_t e = threadIdx.x; e < n_ent; e += 32 * G) {
+                const uint4 en = sh.ent[e];
+                if (en.x != YCGE_POST_NONE) st3_dev(buf, en.x, f3(__uint_as_float(en.y), __uint_as_float(en.z), __uint_as_float(en.w)));
+            }
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // this wavefront's colours are in memory
+            __syncthreads();                                      // ... and everybody's; the table is free again
+        }
+        if (threadIdx.x == 0) __hip_atomic_store(&progress[(size_t)b * 32], epoch + (uint32_t)g + 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+}
+
+// The persistent form with LEVEL-granular hand-over.  In k_atrous_persist a band starts a group when the band above has FINISHED
+// the same group: it trails by a group plus the hand-over, like the launch form.  The data needs far less - a pixel of level T
+// reads the band above up to level T - 1.  Here the LDS window is never cleared (an entry is reused 64 columns = 32 levels
+// later, a tap reaches 8 levels back) and one extra wavefront per workgroup PUBLISHES: after the barrier of pass i it copies the
+// colours that pass wrote from the window to memory (written through), waits for its own stores - off the computing wavefronts'
+// chain, which a write-through acknowledgement (0.4 us) or a device-coherent load of a cold line (1.3 us) would lengthen by a
+// third each (measured with YCGE_POST_DBG) - and raises progress[band] = epoch + (the first level this band has NOT completed).
+// A band fetches the taps of level T (one pass ahead of computing them) once the band above has published >= T; it reads that
+// word one pass ahead as well, so in the steady state nothing waits.  Only the taps ABOVE the band are read device-coherently:
+// what the band rewrote itself comes from the window, everything else it reads is old and right in any cache.
+template <int G>
+__global__ __launch_bounds__(32 * G + 64) void k_atrous_stream(const AtrousParams A, float *__restrict__ buf, const float *__restrict__ statw,
+                                                               const uint8_t *__restrict__ sky, const uint32_t *__restrict__ pixels,
+                                                               const uint32_t *__restrict__ off, const uint32_t *__restrict__ pass_level, int levels,
+                                                               int n_bands, int rows_per_band, uint32_t wx, uint32_t *__restrict__ progress, uint32_t epoch,
+                                                               int xcd_local)
+{
+    __shared__ __attribute__((aligned(16))) PostSharedT<G> sh;
+    int b = (int)blockIdx.x;
+    if (xcd_local) { const int per_xcd = (n_bands + 7) / 8; b = ((int)blockIdx.x % 8) * per_xcd + (int)blockIdx.x / 8; }
+    if (b >= n_bands) return;
+    const uint32_t *o = off + (size_t)b * (levels + 1);
+    const bool publisher = threadIdx.x >= 32 * G;               // the last wavefront
+    const int grp = threadIdx.x >> 5, t = threadIdx.x & 31;
+    const BandWindow W = {b * rows_per_band, rows_per_band, wx, 1u};
+    const uint32_t n_ent = (uint32_t)rows_per_band * wx;
+    uint32_t *mine = progress + (size_t)b * 32;
+    const uint32_t *above = progress + (size_t)(b > 0 ? b - 1 : 0) * 32;
+    const uint32_t first = o[0], end = o[levels];
+    if (first >= end) {         // a band without pixels: everything "done" (and an XCC id nobody shares: its neighbour writes through)
+        if (threadIdx.x == 0) {
+            __hip_atomic_store(mine, epoch + (uint32_t)levels, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store(mine + 1, epoch + 16u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        return;
+    }
+    const unsigned long long t_begin = __builtin_amdgcn_s_memrealtime();
+    uint32_t my_xcc;
+    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(my_xcc));
+    my_xcc &= 0xfu;
+    if (threadIdx.x == 0) __hip_atomic_store(mine + 1, epoch + 1u + my_xcc, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    for (uint32_t e = threadIdx.x; e < n_ent; e += 32 * G + 64) sh.ent[e].x = YCGE_POST_NONE;
+    if (publisher) {
+        const int lane = (int)threadIdx.x - 32 * G;
+        if (lane == 0) __hip_atomic_store(mine, epoch + pass_level[first], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        // Does the band below run on this XCD?  Then its device-coherent loads find these colours in the L2 both share, and a plain
+        // store (acknowledged by that L2 in 0.18 us, the line stays there) is enough; across XCDs the store must be written through
+        // (0.38 us, and the reader's load goes to memory: ~1.5 us).  Measured, not assumed: every band announces its XCC id.
+        bool same_xcd = false;
+        if (b + 1 < n_bands) {
+            uint32_t v;
+            do v = __hip_atomic_load(progress + (size_t)(b + 1) * 32 + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - epoch; while (v == 0u || v > 16u);
+            same_xcd = v - 1u == my_xcc;
+        }
+        lds_barrier();          // table cleared
+        uint32_t lv = pass_level[first];
+        for (uint32_t i = first; i < end; i++) {
+            const uint32_t lv_next = i + 1 < end ? pass_level[i + 1] : (uint32_t)levels;
+            lds_barrier();      // end of pass i: its colours are in the window, its entries in out_slot[i & 1]
+            for (int l = lane; l < 4 * G; l += 64) {
+                const uint32_t slot = sh.out_slot[(i - first) & 1u][l >> 2];
+                if (slot != YCGE_POST_NONE && (l & 3) < 3) {
+                    float *dst = buf + 3 * (size_t)sh.ent[slot].x + (l & 3);
+                    const float v = __uint_as_float((&sh.ent[slot].y)[l & 3]);
+                    if (same_xcd) __hip_atomic_store(dst, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                    else __hip_atomic_store(dst, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                }
+            }
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                                       // ... and now in memory
+            if (lane == 0 && lv_next != lv) __hip_atomic_store(mine, epoch + lv_next, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (lane == 0 && lv == YCGE_POST_PROBE_LEVEL && lv_next != lv) ((unsigned long long *)(mine + 10))[0] = __builtin_amdgcn_s_memrealtime();
+            lv = lv_next;
+        }
+        if (lane == 0) {        // profiling aid (profiles/post_bands.py): when this band began and ended (100 MHz), how many passes it ran
+            ((unsigned long long *)(mine + 4))[0] = t_begin; ((unsigned long long *)(mine + 4))[1] = __builtin_amdgcn_s_memrealtime(); mine[8] = end - first;
+        }
+        return;
+    }
+    // pixel list entry and level of the passes i, i + 1, i + 2 travel in registers (fetched two passes ahead)
+    int lvl1 = (int)pass_level[first];
+    int lvl2 = first + 1 < end ? (int)pass_level[first + 1] : levels;
+    int up_seen = b > 0 ? 0 : 0x7fffffff;                           // levels the band above has completed, as far as this wavefront knows
+    while (up_seen < lvl1) { up_seen = (int32_t)(__hip_atomic_load(above, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - epoch); if (up_seen < lvl1) __builtin_amdgcn_s_sleep(1); }
+    asm volatile("" ::: "memory");
+    uint32_t p1 = pixels[(size_t)first * G + grp];
+    uint32_t p2 = first + 1 < end ? pixels[(size_t)(first + 1) * G + grp] : YCGE_POST_NONE;
+    PassData D1 = pass_fetch<true>(A, W, buf, statw, sky, p1, t);
+    uint32_t up_word_old = epoch;   // the word read in the pass before: a device-coherent load of a line its owner keeps rewriting takes longer than a pass
+    lds_barrier();              // table cleared
+    for (uint32_t i = first; i < end; i++) {
+        const uint32_t p3 = i + 2 < end ? pixels[(size_t)(i + 2) * G + grp] : YCGE_POST_NONE;
+        const int lvl3 = i + 2 < end ? (int)pass_level[i + 2] : levels;
+        // the word of the band above, for the NEXT pass's decision (in flight while this pass computes)
+        const uint32_t up_word = b > 0 ? __hip_atomic_load(above, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0u;
+        PassData D2 = D1;
+        if (i + 1 < end) {
+            while (up_seen < lvl2) {            // rare in the steady state: the band above is not far enough yet
+                up_seen = (int32_t)(__hip_atomic_load(above, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - epoch);
+                if (up_seen < lvl2) __builtin_amdgcn_s_sleep(1);
+            }
+            if (threadIdx.x == 0 && lvl2 == YCGE_POST_PROBE_LEVEL) ((unsigned long long *)(mine + 12))[0] = __builtin_amdgcn_s_memrealtime();
+            asm volatile("" ::: "memory");      // (the loads below are issued after the word was seen: program order; a fence would wait for everything in flight)
+            D2 = pass_fetch<true>(A, W, buf, statw, sky, p2, t);
+        }
+        if (threadIdx.x == 0 && lvl1 == YCGE_POST_PROBE_LEVEL) ((unsigned long long *)(mine + 14))[0] = __builtin_amdgcn_s_memrealtime();
+        pass_compute<true>(A, p1, D1, sh, sh.out_slot[(i - first) & 1u]);     // ends with the workgroup's barrier
+        if (b > 0) { const int s = (int32_t)(up_word_old - epoch); if (s > up_seen) up_seen = s; up_word_old = up_word; }
+        p1 = p2; D1 = D2; p2 = p3; lvl1 = lvl2; lvl2 = lvl3;
     }
 }
 
@@ -803,6 +987,30 @@ int ycge_launch_atrous_inplace(int w, int h, int step, const float phi[4], float
         else if (groups_per_pass == 16) launch_band<16>(win, grid, stream, A, buf, statw, sky, d_pixels, d_offsets, n_levels, K, launch, first, rows_per_band, window_width);
         else launch_band<32>(win, grid, stream, A, buf, statw, sky, d_pixels, d_offsets, n_levels, K, launch, first, rows_per_band, window_width);
     }
+    return (int)hipGetLastError();
+}
+
+// the same iteration as ONE persistent launch (k_atrous_persist).  progress: n_bands x 32 words, zero before the first use; epoch: a
+// value that grows by more than the group count from call to call (the host's running sum)
+int ycge_launch_atrous_persist(int w, int h, int step, const float phi[4], float *buf, const uint8_t *sky, float *statw, const uint32_t *d_pixels,
+                               const uint32_t *d_offsets, const uint32_t *d_pass_level, int n_levels, int n_bands, int K, int groups_per_pass, int rows_per_band, unsigned window_width,
+                               uint32_t *progress, uint32_t epoch, int xcd_local, int level_handover, hipStream_t stream)
+{
+    ycge::AtrousParams A = {w, h, step, phi[0], phi[1], phi[2], phi[3]};
+    const int per_xcd = (n_bands + 7) / 8;
+    const dim3 grid((unsigned)(xcd_local ? 8 * per_xcd : n_bands));
+    if (level_handover) {
+        if (groups_per_pass == 8) hipLaunchKernelGGL((ycge::k_atrous_stream<8>), grid, dim3(256 + 64), 0, stream, A, buf, statw, sky, d_pixels, d_offsets, d_pass_level, n_levels, n_bands, rows_per_band, window_width, progress, epoch, xcd_local);
+        else if (groups_per_pass == 16) hipLaunchKernelGGL((ycge::k_atrous_stream<16>), grid, dim3(512 + 64), 0, stream, A, buf, statw, sky, d_pixels, d_offsets, d_pass_level, n_levels, n_bands, rows_per_band, window_width, progress, epoch, xcd_local);
+        else hipLaunchKernelGGL((ycge::k_atrous_stream<32>), grid, dim3(1024 + 64), 0, stream, A, buf, statw, sky, d_pixels, d_offsets, d_pass_level, n_levels, n_bands, rows_per_band, window_width, progress, epoch, xcd_local);
+        return (int)hipGetLastError();
+    }
+    if (groups_per_pass == 8)
+        hipLaunchKernelGGL((ycge::k_atrous_persist<8>), grid, dim3(256), 0, stream, A, buf, statw, sky, d_pixels, d_offsets, n_levels, K, n_bands, rows_per_band, window_width, progress, epoch, xcd_local);
+    else if (groups_per_pass == 16)
+        hipLaunchKernelGGL((ycge::k_atrous_persist<16>), grid, dim3(512), 0, stream, A, buf, statw, sky, d_pixels, d_offsets, n_levels, K, n_bands, rows_per_band, window_width, progress, epoch, xcd_local);
+    else
+        hipLaunchKernelGGL((ycge::k_atrous_persist<32>), grid, dim3(1024), 0, stream, A, buf, statw, sky, d_pixels, d_offsets, n_levels, K, n_bands, rows_per_band, window_width, progress, epoch, xcd_local);
     return (int)hipGetLastError();
 }
 
