@@ -13,11 +13,12 @@ for i in range(4):
     r.TryFlipAndBlit(want_sdr=True)
 print(f"post {r.stats.post_ms:.3f} ms")
 nb = 135
-buf = np.zeros(nb * 32, np.uint32)
+buf = np.zeros(nb * 32 + 8000, np.uint32)
 r.L.ycge_debug_read_post_progress.restype = C.c_int
 r.L.ycge_debug_read_post_progress.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t]
 assert r.L.ycge_debug_read_post_progress(r.ctx, buf.ctypes.data, buf.size) == 0
-rec = buf.reshape(nb, 32)
+rec = buf[:nb * 32].reshape(nb, 32)
+tl = buf[nb * 32:].reshape(2, 1000, 4)
 t = rec[:, 4:8].copy().view(np.uint64).reshape(nb, 2).astype(np.float64) * 0.01     # us
 passes = rec[:, 8].astype(np.float64)
 t0 = t[:, 0].min()
@@ -40,3 +41,25 @@ if act:
     print(f"  upstream computes 1399 -> ... this band may fetch 1400: fetch(b) - compute(b-1, 1400) median {np.median(fet[a] - cmp_[a-1]):.2f}")
     print(f"  fetch -> begin computing: {np.median(cmp_[a] - fet[a]):.2f};  begin computing -> published complete: {np.median(pub[a] - cmp_[a]):.2f}")
     print(f"  compute(b,1400) - compute(b-1,1400): {np.median(cmp_[a] - cmp_[a-1]):.2f}")
+
+import os
+PB = int(os.environ.get('YCGE_POST_PROBE_BAND', '0'))
+for k in (0, 1):
+    tt = (tl[k, :, 0].astype(np.uint64) | (tl[k, :, 1].astype(np.uint64) << np.uint64(32))).astype(np.float64) * 0.01
+    n = int((tt > 0).sum())
+    dt = np.diff(tt[:n])
+    sp = tl[k, :n, 2]
+    gaps = [(round(float(tt[j] - t0), 0), round(float(dt[j]), 1)) for j in range(n - 1) if dt[j] > 5]
+    print(f"band {PB + k}: gaps above 5 us (time since launch, gap):", gaps[:12])
+    print(f"band {PB + k}: {n} passes; pass-to-pass median {np.median(dt):.2f} us, mean {dt.mean():.2f}, p90 {np.percentile(dt, 90):.2f}; passes that waited {int((sp > 0).sum())}, mean spins when waiting {sp[sp > 0].mean() if (sp > 0).any() else 0:.1f}")
+    print("   first 12 pass gaps:", np.round(dt[:12], 2).tolist(), " middle:", np.round(dt[400:412], 2).tolist())
+t60 = (tl[0, :, 0].astype(np.uint64) | (tl[0, :, 1].astype(np.uint64) << np.uint64(32))).astype(np.float64) * 0.01
+t61 = (tl[1, :, 0].astype(np.uint64) | (tl[1, :, 1].astype(np.uint64) << np.uint64(32))).astype(np.float64) * 0.01
+l60, l61 = tl[0, :, 3].astype(int), tl[1, :, 3].astype(int)
+# same-level offset: when band 61 starts level L vs band 60
+m60 = {int(l): t for l, t in zip(l60, t60) if t > 0}
+offs = [t - m60[int(l)] for l, t in zip(l61, t61) if t > 0 and int(l) in m60]
+print(f"band {PB+1} starts a level {np.median(offs):.2f} us (median) after band {PB} starts the same level; min {np.min(offs):.2f} max {np.max(offs):.2f}")
+big = [(int(bb + 1), round(float(x), 1)) for bb, x in enumerate(end_lag) if x > 40]
+print("end lags above 40 us (band, us):", big)
+print("end lag by band, every 8th:", [round(float(x), 1) for x in end_lag[::8]])

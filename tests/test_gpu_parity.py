@@ -274,6 +274,20 @@ def test_denoise_exposure_tonemap_bit_exact(product_lib, oracle, path, cfg_n):
         assert taa == 0 and den == 0 and not expo and sdr == 0 and sdr_rms <= pu.RMS_TOL
 
 
+@pytest.mark.parametrize("mode", ["0", "2", "3", "4"])
+def test_inplace_atrous_in_every_form_against_the_oracle(product_lib, oracle, monkeypatch, mode):
+    """The in-place A-trous iteration as ONE persistent launch with level-granular hand-over between the bands' workgroups (0, the
+    default; 3: bands in block order), as a launch per level group (2) and as a persistent launch with group hand-over (4): the
+    denoised frame, the exposure and the SDR frame must equal the oracle's on every frame.  Sizes: several bands (the hand-over is
+    exercised), an odd size (border clamps), a width that is not a multiple of a cache line's pixels (two bands share lines)."""
+    monkeypatch.setenv("YCGE_POST_MODE", mode)
+    sc, _, _, _, pose = scenes.config_scene(2)
+    for (w, h, ss) in ((192, 54, 1), (131, 37, 1), (64, 20, 2)):
+        for f, (taa, den, expo, sdr, sdr_rms, post_ms) in enumerate(_post_pair(oracle, sc, w, h, ss, pose, frames=3)):
+            print(f"mode {mode} {w}x{h} ss{ss} frame {f + 1}: taa {taa} denoised {den} exposure {expo} sdr {sdr}")
+            assert taa == 0 and den == 0 and not expo and sdr == 0
+
+
 def test_post_stage_odd_size_and_supersampling(product_lib, oracle, path):
     """odd trace-grid sizes (border clamps of the in-place schedule) and ss = 2 (box average, exposure step 4)"""
     sc, _, _, _, pose = scenes.config_scene(1)

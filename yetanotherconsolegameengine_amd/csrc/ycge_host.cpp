@@ -113,6 +113,7 @@ struct Knobs {
     int fan_class = -1, fan_cap = -1;   // -1 = default by world size
     int mig = 1, mig_round = 12, mig_shade = 16;      // YCGE_MIG (0 = off), YCGE_MIG_ROUND, YCGE_MIG_SHADE: path migration in k_trace
     int post_mode = 0;               // YCGE_POST_MODE: in-place A-trous: 0 = one persistent launch, level-granular hand-over (k_atrous_stream), 2 = a launch per level group, 3 = as 0 with bands in block order, 4 = persistent with group hand-over (k_atrous_persist)
+    int post_resident_per_cu = 2;    // YCGE_POST_RESIDENT: band workgroups of the persistent in-place A-trous a CU may hold (576 threads, 46 KB LDS each: 3 fit)
     bool post_hash = false;          // YCGE_POST_HASH_FORM=1: the hash form of k_atrous_band even where the window fits
     bool scene_bvh_host = false;     // YCGE_SCENE_BVH_HOST: ycge_scene_update_objects builds the scene BVH on the host, not on the device
     bool exposure_serial = false;    // YCGE_EXPOSURE_SERIAL: the one-lane chain instead of the chunked exact evaluation
@@ -132,6 +133,8 @@ struct Knobs {
         fan_class = geti("YCGE_FAN", -1); fan_cap = geti("YCGE_FAN_CAP", -1);
         post_mode = geti("YCGE_POST_MODE", 0);
         post_hash = geti("YCGE_POST_HASH_FORM", 0) != 0;
+        post_resident_per_cu = geti("YCGE_POST_RESIDENT", 2);
+        if (post_resident_per_cu < 1 || post_resident_per_cu > 3) post_resident_per_cu = 2;
         mig = geti("YCGE_MIG", 1); mig_round = geti("YCGE_MIG_ROUND", 12); mig_shade = geti("YCGE_MIG_SHADE", 16);
         if (mig_round < 1) mig_round = 1;
         exposure_serial = getenv("YCGE_EXPOSURE_SERIAL") != nullptr;
@@ -1596,13 +1599,14 @@ int run_post(ycge_ctx *c, hipStream_t stream, float *out_sdr_host, bool timed)
             }
             // one persistent launch when the window form applies and every band's workgroup is resident at once (it waits for its
             // neighbour inside the kernel); else a launch per level group
-            const bool persist = c->knobs.post_mode != 2 && sc->window_width != 0 && (size_t)sc->rows_per_band * sc->window_width <= 2048 &&
-                                 c->compute_units > 0 && ((sc->bands + 7) / 8) * 8 <= c->compute_units;
+            const bool persist = c->knobs.post_mode != 2 && (c->knobs.post_groups <= 16 || c->knobs.post_mode == 4) && sc->window_width != 0 && (size_t)sc->rows_per_band * sc->window_width <= 2048 &&
+                                 c->compute_units > 0 && ((sc->bands + 7) / 8) * 8 <= c->knobs.post_resident_per_cu * c->compute_units;
             if (persist) {
                 const uint32_t groups = (uint32_t)((sc->levels + levels_per_launch - 1) / levels_per_launch);
-                if (c->post_progress.n < (size_t)sc->bands * 32 || c->post_epoch > 0x60000000u) {
-                    HIP_TRY(c, c->post_progress.reserve((size_t)sc->bands * 32));
-                    HIP_TRY(c, hipMemsetAsync(c->post_progress.p, 0, (size_t)sc->bands * 32 * sizeof(uint32_t), stream));
+                if (c->post_progress.n < (size_t)sc->bands * 32 + 8000 || c->post_epoch > 0x60000000u) {
+                    HIP_TRY(c, c->post_progress.reserve((size_t)sc->bands * 32 + 8000));       // + room for the profiling timeline of two bands
+                    HIP_TRY(c, hipMemsetAsync(c->post_progress.p, 0, ((size_t)sc->bands * 32 + 8000) * sizeof(uint32_t), stream));
+                    if (const char *pb = getenv("YCGE_POST_PROBE_BAND")) { const uint32_t v = (uint32_t)atoi(pb) + 1u; HIP_TRY(c, hipMemcpyAsync(c->post_progress.p + (size_t)sc->bands * 32 + 7999, &v, 4, hipMemcpyHostToDevice, stream)); HIP_TRY(c, hipStreamSynchronize(stream)); }
                     c->post_epoch = 0;
                 }
                 e = ycge_launch_atrous_persist(w, h, step, phi, dst, c->sky.p, c->atrous_statw.p, sc->pixels.p, sc->offsets.p, sc->pass_level.p, sc->levels, sc->bands,

@@ -434,6 +434,7 @@ __global__ __launch_bounds__(32 * G + 64) void k_atrous_stream(const AtrousParam
         }
         return;
     }
+    const int probe0 = (int)(progress[(size_t)n_bands * 32 + 7999] & 0xffffu) - 1;   // profiling aid: which two bands record a timeline (-1: none)
     const unsigned long long t_begin = __builtin_amdgcn_s_memrealtime();
     uint32_t my_xcc;
     asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(my_xcc));
@@ -453,10 +454,16 @@ __global__ __launch_bounds__(32 * G + 64) void k_atrous_stream(const AtrousParam
             same_xcd = v - 1u == my_xcc;
         }
         lds_barrier();          // table cleared
-        uint32_t lv = pass_level[first];
+        // One pass of slack for the acknowledgement: the colours of pass i are sent after barrier i, and "pass i - 1 complete" is
+        // published once all but that newest store instruction have been acknowledged (this wavefront issues nothing but stores,
+        // and stores complete in order among themselves) - waiting for the newest one would make every pass as long as a
+        // write-through round trip, because this wavefront stands at the workgroup's barrier like the others.
+        uint32_t lv = pass_level[first], lv_done = lv;          // lv_done: what to publish once pass i - 1 is in memory
+        bool have_prev = false;
         for (uint32_t i = first; i < end; i++) {
             const uint32_t lv_next = i + 1 < end ? pass_level[i + 1] : (uint32_t)levels;
             lds_barrier();      // end of pass i: its colours are in the window, its entries in out_slot[i & 1]
+            bool any = false;
             for (int l = lane; l < 4 * G; l += 64) {
                 const uint32_t slot = sh.out_slot[(i - first) & 1u][l >> 2];
                 if (slot != YCGE_POST_NONE && (l & 3) < 3) {
@@ -464,13 +471,20 @@ __global__ __launch_bounds__(32 * G + 64) void k_atrous_stream(const AtrousParam
                     const float v = __uint_as_float((&sh.ent[slot].y)[l & 3]);
                     if (same_xcd) __hip_atomic_store(dst, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
                     else __hip_atomic_store(dst, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    any = true;
                 }
             }
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                                       // ... and now in memory
-            if (lane == 0 && lv_next != lv) __hip_atomic_store(mine, epoch + lv_next, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            if (lane == 0 && lv == YCGE_POST_PROBE_LEVEL && lv_next != lv) ((unsigned long long *)(mine + 10))[0] = __builtin_amdgcn_s_memrealtime();
+            // (G <= 16: the loop above is one iteration, at most one store instruction of each flavour - wait for all but the
+            // newest; wider passes wait for everything)
+            if (4 * G <= 64 && __any(any)) asm volatile("s_waitcnt vmcnt(1)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            if (lane == 0 && have_prev) __hip_atomic_store(mine, epoch + lv_done, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            have_prev = true;
+            lv_done = lv_next;      // once pass i is in memory, the first level not completed is that of pass i + 1 (the same level if it has two passes)
+            if (lv_next == lv) lv_done = lv;
             lv = lv_next;
         }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        if (lane == 0) __hip_atomic_store(mine, epoch + (uint32_t)levels, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         if (lane == 0) {        // profiling aid (profiles/post_bands.py): when this band began and ended (100 MHz), how many passes it ran
             ((unsigned long long *)(mine + 4))[0] = t_begin; ((unsigned long long *)(mine + 4))[1] = __builtin_amdgcn_s_memrealtime(); mine[8] = end - first;
         }
@@ -493,8 +507,10 @@ __global__ __launch_bounds__(32 * G + 64) void k_atrous_stream(const AtrousParam
         // the word of the band above, for the NEXT pass's decision (in flight while this pass computes)
         const uint32_t up_word = b > 0 ? __hip_atomic_load(above, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0u;
         PassData D2 = D1;
+        uint32_t spins = 0;
         if (i + 1 < end) {
-            while (up_seen < lvl2) {            // rare in the steady state: the band above is not far enough yet
+            while (up_seen < lvl2) {
+                spins++;            // rare in the steady state: the band above is not far enough yet
                 up_seen = (int32_t)(__hip_atomic_load(above, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - epoch);
                 if (up_seen < lvl2) __builtin_amdgcn_s_sleep(1);
             }
@@ -503,6 +519,11 @@ __global__ __launch_bounds__(32 * G + 64) void k_atrous_stream(const AtrousParam
             D2 = pass_fetch<true>(A, W, buf, statw, sky, p2, t);
         }
         if (threadIdx.x == 0 && lvl1 == YCGE_POST_PROBE_LEVEL) ((unsigned long long *)(mine + 14))[0] = __builtin_amdgcn_s_memrealtime();
+        if (threadIdx.x == 0 && (b == probe0 || b == probe0 + 1) && i - first < 1000u) {      // profiling aid: timeline of two neighbouring bands
+            uint32_t *tl = progress + (size_t)n_bands * 32 + (size_t)(b - probe0) * 4000 + (size_t)(i - first) * 4;
+            const unsigned long long now = __builtin_amdgcn_s_memrealtime();
+            tl[0] = (uint32_t)now; tl[1] = (uint32_t)(now >> 32); tl[2] = spins; tl[3] = (uint32_t)lvl1;
+        }
         pass_compute<true>(A, p1, D1, sh, sh.out_slot[(i - first) & 1u]);     // ends with the workgroup's barrier
         if (b > 0) { const int s = (int32_t)(up_word_old - epoch); if (s > up_seen) up_seen = s; up_word_old = up_word; }
         p1 = p2; D1 = D2; p2 = p3; lvl1 = lvl2; lvl2 = lvl3;
