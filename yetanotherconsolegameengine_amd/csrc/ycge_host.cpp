@@ -113,7 +113,7 @@ struct Knobs {
     int fan_class = -1, fan_cap = -1;   // -1 = default by world size
     int mig = 1, mig_round = 12, mig_shade = 16;      // YCGE_MIG (0 = off), YCGE_MIG_ROUND, YCGE_MIG_SHADE: path migration in k_trace
     int post_mode = 0;               // YCGE_POST_MODE: in-place A-trous: 0 = one persistent launch, level-granular hand-over (k_atrous_stream), 2 = a launch per level group, 3 = as 0 with bands in block order, 4 = persistent with group hand-over (k_atrous_persist)
-    int post_resident_per_cu = 2;    // YCGE_POST_RESIDENT: band workgroups of the persistent in-place A-trous a CU may hold (576 threads, 46 KB LDS each: 3 fit)
+    int post_resident_per_cu = 1;    // YCGE_POST_RESIDENT: band workgroups of the persistent in-place A-trous a CU may hold (3 fit; two to a CU measured slower than the launch form at 4K)
     bool post_hash = false;          // YCGE_POST_HASH_FORM=1: the hash form of k_atrous_band even where the window fits
     bool scene_bvh_host = false;     // YCGE_SCENE_BVH_HOST: ycge_scene_update_objects builds the scene BVH on the host, not on the device
     bool exposure_serial = false;    // YCGE_EXPOSURE_SERIAL: the one-lane chain instead of the chunked exact evaluation
@@ -133,8 +133,8 @@ struct Knobs {
         fan_class = geti("YCGE_FAN", -1); fan_cap = geti("YCGE_FAN_CAP", -1);
         post_mode = geti("YCGE_POST_MODE", 0);
         post_hash = geti("YCGE_POST_HASH_FORM", 0) != 0;
-        post_resident_per_cu = geti("YCGE_POST_RESIDENT", 2);
-        if (post_resident_per_cu < 1 || post_resident_per_cu > 3) post_resident_per_cu = 2;
+        post_resident_per_cu = geti("YCGE_POST_RESIDENT", 1);
+        if (post_resident_per_cu < 1 || post_resident_per_cu > 3) post_resident_per_cu = 1;
         mig = geti("YCGE_MIG", 1); mig_round = geti("YCGE_MIG_ROUND", 12); mig_shade = geti("YCGE_MIG_SHADE", 16);
         if (mig_round < 1) mig_round = 1;
         exposure_serial = getenv("YCGE_EXPOSURE_SERIAL") != nullptr;
