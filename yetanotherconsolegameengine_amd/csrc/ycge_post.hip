@@ -208,9 +208,14 @@ struct PassData {           // what one lane needs for one pass, fetched ahead
 };
 template <bool COH = false, bool COH_ALL = false>
 __device__ __forceinline__ PassData pass_fetch(const AtrousParams &A, const BandWindow &W, const float *buf, const float *statw, const uint8_t *sky,
-                                               uint32_t p, int t)
+                                               uint32_t p, int t, int sky_known = -1)
 {
     PassData D;
+    if (sky_known > 0 || (sky_known >= 0 && p == YCGE_POST_NONE)) {      // k_atrous_stream knows the flag a pass early: a sky pixel (or no pixel) fetches nothing
+        D.p = 0; D.j = 0; D.pslot = 0; D.jslot = YCGE_POST_NONE; D.sky0 = 1; D.sky_j = 1;
+        D.c0 = f3(0.0f, 0.0f, 0.0f); D.cj = D.c0; D.wn = D.wz = D.wa = 0.0f;
+        return D;
+    }
     const uint32_t e = p == YCGE_POST_NONE ? 0u : p;        // list entries are x | y << 16: no division in the chain
     const int x = (int)(e & 0xffffu), y = (int)(e >> 16);
     const uint32_t pp = (uint32_t)x + (uint32_t)y * (uint32_t)A.w;
@@ -224,7 +229,7 @@ __device__ __forceinline__ PassData pass_fetch(const AtrousParams &A, const Band
     const int rj = sy - W.y0, rp = y - W.y0;
     D.jslot = (rj >= 0 && rj < W.rows) ? (uint32_t)rj * W.wx + ((uint32_t)sx & (W.wx - 1u)) : YCGE_POST_NONE;
     D.pslot = ((uint32_t)rp * W.wx + ((uint32_t)x & (W.wx - 1u))) & (YCGE_POST_WIN - 1u);
-    D.sky0 = sky[pp];
+    D.sky0 = sky_known >= 0 ? (uint8_t)sky_known : sky[pp];
     D.c0 = COH_ALL ? ld3_dev(buf, pp) : ld3(buf, pp);   // (own rows in k_atrous_stream: what this launch has rewritten comes from the LDS table, the rest is old in every cache)
     D.sky_j = sky[D.j];
     D.cj = (COH_ALL || (COH && rj < 0)) ? ld3_dev(buf, D.j) : ld3(buf, D.j);     // ... a tap above the band is the only colour this launch reads that another workgroup writes
@@ -496,13 +501,18 @@ __global__ __launch_bounds__(32 * G + 64) void k_atrous_stream(const AtrousParam
     int up_seen = b > 0 ? 0 : 0x7fffffff;                           // levels the band above has completed, as far as this wavefront knows
     while (up_seen < lvl1) { up_seen = (int32_t)(__hip_atomic_load(above, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - epoch); if (up_seen < lvl1) __builtin_amdgcn_s_sleep(1); }
     asm volatile("" ::: "memory");
-    uint32_t p1 = pixels[(size_t)first * G + grp];
-    uint32_t p2 = first + 1 < end ? pixels[(size_t)(first + 1) * G + grp] : YCGE_POST_NONE;
+    // list entries run three passes ahead, the sky flag of an entry two: a pass of sky pixels (the upper half of an outdoor frame)
+    // then fetches nothing and computes nothing - list entry, flag, barrier
+    auto entry = [&](uint32_t i) -> uint32_t { return i < end ? pixels[(size_t)i * G + grp] : YCGE_POST_NONE; };
+    auto sky_of = [&](uint32_t e) -> int { return e == YCGE_POST_NONE ? 1 : (int)sky[(size_t)(e & 0xffffu) + (size_t)(e >> 16) * (size_t)A.w]; };
+    uint32_t p1 = entry(first), p2 = entry(first + 1), p3 = entry(first + 2);
+    int s2 = sky_of(p2);
     PassData D1 = pass_fetch<true>(A, W, buf, statw, sky, p1, t);
     uint32_t up_word_old = epoch;   // the word read in the pass before: a device-coherent load of a line its owner keeps rewriting takes longer than a pass
     lds_barrier();              // table cleared
     for (uint32_t i = first; i < end; i++) {
-        const uint32_t p3 = i + 2 < end ? pixels[(size_t)(i + 2) * G + grp] : YCGE_POST_NONE;
+        const uint32_t p4 = entry(i + 3);
+        const int s3 = sky_of(p3);
         const int lvl3 = i + 2 < end ? (int)pass_level[i + 2] : levels;
         // the word of the band above, for the NEXT pass's decision (in flight while this pass computes)
         const uint32_t up_word = b > 0 ? __hip_atomic_load(above, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0u;
@@ -516,7 +526,7 @@ __global__ __launch_bounds__(32 * G + 64) void k_atrous_stream(const AtrousParam
             }
             if (threadIdx.x == 0 && lvl2 == YCGE_POST_PROBE_LEVEL) ((unsigned long long *)(mine + 12))[0] = __builtin_amdgcn_s_memrealtime();
             asm volatile("" ::: "memory");      // (the loads below are issued after the word was seen: program order; a fence would wait for everything in flight)
-            D2 = pass_fetch<true>(A, W, buf, statw, sky, p2, t);
+            D2 = pass_fetch<true>(A, W, buf, statw, sky, p2, t, s2);
         }
         if (threadIdx.x == 0 && lvl1 == YCGE_POST_PROBE_LEVEL) ((unsigned long long *)(mine + 14))[0] = __builtin_amdgcn_s_memrealtime();
         if (threadIdx.x == 0 && (b == probe0 || b == probe0 + 1) && i - first < 1000u) {      // profiling aid: timeline of two neighbouring bands
@@ -526,7 +536,7 @@ __global__ __launch_bounds__(32 * G + 64) void k_atrous_stream(const AtrousParam
         }
         pass_compute<true>(A, p1, D1, sh, sh.out_slot[(i - first) & 1u]);     // ends with the workgroup's barrier
         if (b > 0) { const int s = (int32_t)(up_word_old - epoch); if (s > up_seen) up_seen = s; up_word_old = up_word; }
-        p1 = p2; D1 = D2; p2 = p3; lvl1 = lvl2; lvl2 = lvl3;
+        p1 = p2; D1 = D2; p2 = p3; p3 = p4; s2 = s3; lvl1 = lvl2; lvl2 = lvl3;
     }
 }
 
