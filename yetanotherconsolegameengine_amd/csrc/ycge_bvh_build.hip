@@ -386,11 +386,10 @@ size_t ycge_bvh_build_scratch_bytes(int n) { return (size_t)(2 * n + 2) * sizeof
 
 // n items (1 .. YCGE_BVH_DEV_MAX_ITEMS); ref_out holds 2 n - 1 records of 40 bytes, gnodes_out n, leaf_out n
 int ycge_launch_scene_bvh_build(const float *items, int n, void *scratch, void *ref_out, void *gnodes_out, uint32_t *leaf_out, void *result,
-                                hipStream_t stream)
+                                int active_waves, hipStream_t stream)
 {
     if (n < 1 || n > YCGE_BVH_DEV_MAX_ITEMS) return (int)hipErrorInvalidValue;
-    const char *ew = getenv("YCGE_BVH_WAVES");
-    const int active_waves = ew ? atoi(ew) : 16;
+    if (active_waves < 1 || active_waves > 16) active_waves = 16;
     static bool lds_set = false;
     if (!lds_set) {
         const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(ycge::k_scene_bvh_build), hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(ycge::BvhShared));
@@ -418,7 +417,7 @@ int ycge_debug_device_bvh(const float *bounds, const float *centroids, int32_t n
         hipMalloc(&d_ref, (size_t)2 * n * 40) == hipSuccess && hipMalloc(&d_g, (size_t)n * 64 + 64) == hipSuccess && hipMalloc(&d_res, 64) == hipSuccess &&
         hipMalloc((void **)&d_leaf, (size_t)n * 4) == hipSuccess && hipMemcpy(d_items, planes, (size_t)9 * n * 4, hipMemcpyHostToDevice) == hipSuccess &&
         hipMemset(d_scratch, 0, ycge_bvh_build_scratch_bytes(n)) == hipSuccess &&
-        ycge_launch_scene_bvh_build(d_items, n, d_scratch, d_ref, d_g, d_leaf, d_res, nullptr) == 0 && hipDeviceSynchronize() == hipSuccess &&
+        ycge_launch_scene_bvh_build(d_items, n, d_scratch, d_ref, d_g, d_leaf, d_res, getenv("YCGE_BVH_WAVES") ? atoi(getenv("YCGE_BVH_WAVES")) : 16, nullptr) == 0 && hipDeviceSynchronize() == hipSuccess &&
         hipMemcpy(result_out, d_res, 64, hipMemcpyDeviceToHost) == hipSuccess) {
         const ycge::BvhBuildResult *r = (const ycge::BvhBuildResult *)result_out;
         if (build_out) (void)hipMemcpy(build_out, d_scratch, (size_t)2 * n * 64, hipMemcpyDeviceToHost);

@@ -50,7 +50,7 @@ int ycge_launch_atrous_persist(int w, int h, int step, const float phi[4], float
 size_t ycge_exposure_scratch_bytes(int w, int h, int step);
 size_t ycge_bvh_build_scratch_bytes(int n);
 int ycge_launch_scene_bvh_build(const float *items, int n, void *scratch, void *ref_out, void *gnodes_out, uint32_t *leaf_out, void *result,
-                                hipStream_t stream);
+                                int active_waves, hipStream_t stream);
 int ycge_launch_exposure(const float *hdr, const uint8_t *sky, int w, int h, int step, float *terms, void *state, const float consts[5],
                          void *scratch, int serial, hipStream_t stream);
 int ycge_launch_tonemap(const float *hdr, int hiW, int fbW, int fbH, int ss, float gamma, float saturation, float vibrance, const void *state,
@@ -113,8 +113,11 @@ struct Knobs {
     int fan_class = -1, fan_cap = -1;   // -1 = default by world size
     int mig = 1, mig_round = 12, mig_shade = 16;      // YCGE_MIG (0 = off), YCGE_MIG_ROUND, YCGE_MIG_SHADE: path migration in k_trace
     int post_mode = 0;               // YCGE_POST_MODE: in-place A-trous: 0 = one persistent launch, level-granular hand-over (k_atrous_stream), 2 = a launch per level group, 3 = as 0 with bands in block order, 4 = persistent with group hand-over (k_atrous_persist)
+    int post_probe_band = -1;        // YCGE_POST_PROBE_BAND: this band and the next record a per-pass timeline (profiles/post_bands.py)
     int post_resident_per_cu = 1;    // YCGE_POST_RESIDENT: band workgroups of the persistent in-place A-trous a CU may hold (3 fit; two to a CU measured slower than the launch form at 4K)
     bool post_hash = false;          // YCGE_POST_HASH_FORM=1: the hash form of k_atrous_band even where the window fits
+    bool debug_bvh = false;          // YCGE_DEBUG_BVH: say why the device builder declined
+    int bvh_waves = 16;              // YCGE_BVH_WAVES: wavefronts of k_scene_bvh_build that take nodes (tests: the order nodes are split in must not matter)
     bool scene_bvh_host = false;     // YCGE_SCENE_BVH_HOST: ycge_scene_update_objects builds the scene BVH on the host, not on the device
     bool exposure_serial = false;    // YCGE_EXPOSURE_SERIAL: the one-lane chain instead of the chunked exact evaluation
     void read()
@@ -133,12 +136,15 @@ struct Knobs {
         fan_class = geti("YCGE_FAN", -1); fan_cap = geti("YCGE_FAN_CAP", -1);
         post_mode = geti("YCGE_POST_MODE", 0);
         post_hash = geti("YCGE_POST_HASH_FORM", 0) != 0;
+        post_probe_band = geti("YCGE_POST_PROBE_BAND", -1);
         post_resident_per_cu = geti("YCGE_POST_RESIDENT", 1);
         if (post_resident_per_cu < 1 || post_resident_per_cu > 3) post_resident_per_cu = 1;
         mig = geti("YCGE_MIG", 1); mig_round = geti("YCGE_MIG_ROUND", 12); mig_shade = geti("YCGE_MIG_SHADE", 16);
         if (mig_round < 1) mig_round = 1;
         exposure_serial = getenv("YCGE_EXPOSURE_SERIAL") != nullptr;
         scene_bvh_host = getenv("YCGE_SCENE_BVH_HOST") != nullptr;
+        bvh_waves = geti("YCGE_BVH_WAVES", 16);
+        debug_bvh = getenv("YCGE_DEBUG_BVH") != nullptr;
     }
 };
 
@@ -866,13 +872,13 @@ int install_objects_device_built(ycge_ctx *c, ycge_ctx *root, const ObjectsHost 
     HIP_TRY(c, c->d_scene_nodes.reserve((size_t)n)); HIP_TRY(c, c->d_scene_leaf.reserve((size_t)n));
     HIP_TRY(c, c->d_bvh_scratch.reserve(ycge_bvh_build_scratch_bytes(n))); HIP_TRY(c, c->d_bvh_ref.reserve((size_t)2 * n * sizeof(RefNode)));
     HIP_TRY(c, c->d_bvh_res.reserve(sizeof(BvhBuildResult)));
-    const int e = ycge_launch_scene_bvh_build(c->d_bvh_items.p, n, c->d_bvh_scratch.p, c->d_bvh_ref.p, c->d_scene_nodes.p, c->d_scene_leaf.p, c->d_bvh_res.p, c->stream);
+    const int e = ycge_launch_scene_bvh_build(c->d_bvh_items.p, n, c->d_bvh_scratch.p, c->d_bvh_ref.p, c->d_scene_nodes.p, c->d_scene_leaf.p, c->d_bvh_res.p, c->knobs.bvh_waves, c->stream);
     if (e != 0) return c->fail(YCGE_ERR_DEVICE, "k_scene_bvh_build launch failed: %s", hipGetErrorString((hipError_t)e));
     BvhBuildResult res;
     HIP_TRY(c, hipMemcpyAsync(&res, c->d_bvh_res.p, sizeof res, hipMemcpyDeviceToHost, c->stream));
     HIP_TRY(c, hipStreamSynchronize(c->stream));
     if (res.fallback) {
-        if (getenv("YCGE_DEBUG_BVH")) fprintf(stderr, "[ycge] device BVH build fell back: reason %u node %u count %u split bin %d (n = %d)\n", res.pad[0], res.pad[1], res.pad[2], (int)res.pad[3], n);
+        if (c->knobs.debug_bvh) fprintf(stderr, "[ycge] device BVH build fell back: reason %u node %u count %u split bin %d (n = %d)\n", res.pad[0], res.pad[1], res.pad[2], (int)res.pad[3], n);
         return 1;
     }
     int spill = 0;
@@ -1606,7 +1612,7 @@ int run_post(ycge_ctx *c, hipStream_t stream, float *out_sdr_host, bool timed)
                 if (c->post_progress.n < (size_t)sc->bands * 32 + 8000 || c->post_epoch > 0x60000000u) {
                     HIP_TRY(c, c->post_progress.reserve((size_t)sc->bands * 32 + 8000));       // + room for the profiling timeline of two bands
                     HIP_TRY(c, hipMemsetAsync(c->post_progress.p, 0, ((size_t)sc->bands * 32 + 8000) * sizeof(uint32_t), stream));
-                    if (const char *pb = getenv("YCGE_POST_PROBE_BAND")) { const uint32_t v = (uint32_t)atoi(pb) + 1u; HIP_TRY(c, hipMemcpyAsync(c->post_progress.p + (size_t)sc->bands * 32 + 7999, &v, 4, hipMemcpyHostToDevice, stream)); HIP_TRY(c, hipStreamSynchronize(stream)); }
+                    if (c->knobs.post_probe_band >= 0) { const uint32_t v = (uint32_t)c->knobs.post_probe_band + 1u; HIP_TRY(c, hipMemcpyAsync(c->post_progress.p + (size_t)sc->bands * 32 + 7999, &v, 4, hipMemcpyHostToDevice, stream)); HIP_TRY(c, hipStreamSynchronize(stream)); }
                     c->post_epoch = 0;
                 }
                 e = ycge_launch_atrous_persist(w, h, step, phi, dst, c->sky.p, c->atrous_statw.p, sc->pixels.p, sc->offsets.p, sc->pass_level.p, sc->levels, sc->bands,
