@@ -46,7 +46,7 @@ int ycge_launch_atrous_inplace(int w, int h, int step, const float phi[4], float
                                int n_levels, int n_bands, int K, int groups_per_pass, int rows_per_band, unsigned window_width, hipStream_t stream);
 int ycge_launch_atrous_persist(int w, int h, int step, const float phi[4], float *buf, const uint8_t *sky, float *statw, const uint32_t *d_pixels,
                                const uint32_t *d_offsets, const uint32_t *d_pass_level, int n_levels, int n_bands, int K, int groups_per_pass, int rows_per_band, unsigned window_width,
-                               uint32_t *progress, uint32_t epoch, int xcd_local, int level_handover, hipStream_t stream);
+                               uint32_t *progress, uint32_t epoch, int xcd_local, int level_handover, int profile, hipStream_t stream);
 size_t ycge_exposure_scratch_bytes(int w, int h, int step);
 size_t ycge_bvh_build_scratch_bytes(int n);
 int ycge_launch_scene_bvh_build(const float *items, int n, void *scratch, void *ref_out, void *gnodes_out, uint32_t *leaf_out, void *result,
@@ -1617,7 +1617,7 @@ int run_post(ycge_ctx *c, hipStream_t stream, float *out_sdr_host, bool timed)
                 }
                 e = ycge_launch_atrous_persist(w, h, step, phi, dst, c->sky.p, c->atrous_statw.p, sc->pixels.p, sc->offsets.p, sc->pass_level.p, sc->levels, sc->bands,
                                                levels_per_launch, c->knobs.post_groups, sc->rows_per_band, sc->window_width, c->post_progress.p, c->post_epoch,
-                                               c->knobs.post_mode == 3 ? 0 : 1, c->knobs.post_mode == 4 ? 0 : 1, stream);
+                                               c->knobs.post_mode == 3 ? 0 : 1, c->knobs.post_mode == 4 ? 0 : 1, c->knobs.post_probe_band >= 0 ? 1 : 0, stream);
                 c->post_epoch += (groups > (uint32_t)sc->levels ? groups : (uint32_t)sc->levels) + 1u;
             } else
             e = ycge_launch_atrous_inplace(w, h, step, phi, dst, c->g_albedo.p, c->unit_n.p, c->g_depth.p, c->sky.p, c->atrous_statw.p,

@@ -238,7 +238,7 @@ __device__ __forceinline__ PassData pass_fetch(const AtrousParams &A, const Band
     return D;
 }
 template <bool WIN, class SH>
-__device__ __forceinline__ void pass_compute(const AtrousParams &A, uint32_t p, PassData D, SH &sh, uint32_t *out_slot = nullptr)
+__device__ __forceinline__ void pass_compute(const AtrousParams &A, uint32_t p, const PassData &D, SH &sh, uint32_t *out_slot = nullptr)
 {
     const int g = threadIdx.x >> 5, t = threadIdx.x & 31;
     const int kx = t % 5 - 2, ky = t / 5 - 2;
@@ -413,7 +413,7 @@ __global__ __launch_bounds__(32 * G) void k_atrous_persist(const AtrousParams A,
 // A band fetches the taps of level T (one pass ahead of computing them) once the band above has published >= T; it reads that
 // word one pass ahead as well, so in the steady state nothing waits.  Only the taps ABOVE the band are read device-coherently:
 // what the band rewrote itself comes from the window, everything else it reads is old and right in any cache.
-template <int G>
+template <int G, bool PROF>
 __global__ __launch_bounds__(32 * G + 64) void k_atrous_stream(const AtrousParams A, float *__restrict__ buf, const float *__restrict__ statw,
                                                                const uint8_t *__restrict__ sky, const uint32_t *__restrict__ pixels,
                                                                const uint32_t *__restrict__ off, const uint32_t *__restrict__ pass_level, int levels,
@@ -439,7 +439,7 @@ __global__ __launch_bounds__(32 * G + 64) void k_atrous_stream(const AtrousParam
         }
         return;
     }
-    const int probe0 = (int)(progress[(size_t)n_bands * 32 + 7999] & 0xffffu) - 1;   // profiling aid: which two bands record a timeline (-1: none)
+    const int probe0 = PROF ? (int)(progress[(size_t)n_bands * 32 + 7999] & 0xffffu) - 1 : -1;     // profiling build: which two bands record a timeline
     const unsigned long long t_begin = __builtin_amdgcn_s_memrealtime();
     uint32_t my_xcc;
     asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(my_xcc));
@@ -510,33 +510,42 @@ __global__ __launch_bounds__(32 * G + 64) void k_atrous_stream(const AtrousParam
     PassData D1 = pass_fetch<true>(A, W, buf, statw, sky, p1, t);
     uint32_t up_word_old = epoch;   // the word read in the pass before: a device-coherent load of a line its owner keeps rewriting takes longer than a pass
     lds_barrier();              // table cleared
-    for (uint32_t i = first; i < end; i++) {
+    uint32_t i = first;
+    // one pass: compute Dc (pass i) while Dn (pass i + 1) is fetched.  The loop below runs it twice per iteration with the two
+    // register sets swapped - handing Dn over to Dc by assignment cost 50 register moves a pass
+    auto one_pass = [&](const PassData &Dc, PassData &Dn) {
         const uint32_t p4 = entry(i + 3);
         const int s3 = sky_of(p3);
         const int lvl3 = i + 2 < end ? (int)pass_level[i + 2] : levels;
         // the word of the band above, for the NEXT pass's decision (in flight while this pass computes)
         const uint32_t up_word = b > 0 ? __hip_atomic_load(above, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0u;
-        PassData D2 = D1;
         uint32_t spins = 0;
         if (i + 1 < end) {
-            while (up_seen < lvl2) {
-                spins++;            // rare in the steady state: the band above is not far enough yet
+            while (up_seen < lvl2) {            // rare in the steady state: the band above is not far enough yet
+                if (PROF) spins++;
                 up_seen = (int32_t)(__hip_atomic_load(above, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - epoch);
                 if (up_seen < lvl2) __builtin_amdgcn_s_sleep(1);
             }
-            if (threadIdx.x == 0 && lvl2 == YCGE_POST_PROBE_LEVEL) ((unsigned long long *)(mine + 12))[0] = __builtin_amdgcn_s_memrealtime();
+            if (PROF && threadIdx.x == 0 && lvl2 == YCGE_POST_PROBE_LEVEL) ((unsigned long long *)(mine + 12))[0] = __builtin_amdgcn_s_memrealtime();
             asm volatile("" ::: "memory");      // (the loads below are issued after the word was seen: program order; a fence would wait for everything in flight)
-            D2 = pass_fetch<true>(A, W, buf, statw, sky, p2, t, s2);
+            Dn = pass_fetch<true>(A, W, buf, statw, sky, p2, t, s2);
         }
-        if (threadIdx.x == 0 && lvl1 == YCGE_POST_PROBE_LEVEL) ((unsigned long long *)(mine + 14))[0] = __builtin_amdgcn_s_memrealtime();
-        if (threadIdx.x == 0 && (b == probe0 || b == probe0 + 1) && i - first < 1000u) {      // profiling aid: timeline of two neighbouring bands
+        if (PROF && threadIdx.x == 0 && lvl1 == YCGE_POST_PROBE_LEVEL) ((unsigned long long *)(mine + 14))[0] = __builtin_amdgcn_s_memrealtime();
+        if (PROF && threadIdx.x == 0 && (b == probe0 || b == probe0 + 1) && i - first < 1000u) {      // timeline of two neighbouring bands
             uint32_t *tl = progress + (size_t)n_bands * 32 + (size_t)(b - probe0) * 4000 + (size_t)(i - first) * 4;
             const unsigned long long now = __builtin_amdgcn_s_memrealtime();
             tl[0] = (uint32_t)now; tl[1] = (uint32_t)(now >> 32); tl[2] = spins; tl[3] = (uint32_t)lvl1;
         }
-        pass_compute<true>(A, p1, D1, sh, sh.out_slot[(i - first) & 1u]);     // ends with the workgroup's barrier
+        pass_compute<true>(A, p1, Dc, sh, sh.out_slot[(i - first) & 1u]);     // ends with the workgroup's barrier
         if (b > 0) { const int s = (int32_t)(up_word_old - epoch); if (s > up_seen) up_seen = s; up_word_old = up_word; }
-        p1 = p2; D1 = D2; p2 = p3; p3 = p4; s2 = s3; lvl1 = lvl2; lvl2 = lvl3;
+        p1 = p2; p2 = p3; p3 = p4; s2 = s3; lvl1 = lvl2; lvl2 = lvl3;
+        i++;
+    };
+    PassData D2 = D1;
+    while (i < end) {
+        one_pass(D1, D2);
+        if (i >= end) break;
+        one_pass(D2, D1);
     }
 }
 
@@ -1025,15 +1034,16 @@ int ycge_launch_atrous_inplace(int w, int h, int step, const float phi[4], float
 // value that grows by more than the group count from call to call (the host's running sum)
 int ycge_launch_atrous_persist(int w, int h, int step, const float phi[4], float *buf, const uint8_t *sky, float *statw, const uint32_t *d_pixels,
                                const uint32_t *d_offsets, const uint32_t *d_pass_level, int n_levels, int n_bands, int K, int groups_per_pass, int rows_per_band, unsigned window_width,
-                               uint32_t *progress, uint32_t epoch, int xcd_local, int level_handover, hipStream_t stream)
+                               uint32_t *progress, uint32_t epoch, int xcd_local, int level_handover, int profile, hipStream_t stream)
 {
     ycge::AtrousParams A = {w, h, step, phi[0], phi[1], phi[2], phi[3]};
     const int per_xcd = (n_bands + 7) / 8;
     const dim3 grid((unsigned)(xcd_local ? 8 * per_xcd : n_bands));
-    if (level_handover) {
-        if (groups_per_pass == 8) hipLaunchKernelGGL((ycge::k_atrous_stream<8>), grid, dim3(256 + 64), 0, stream, A, buf, statw, sky, d_pixels, d_offsets, d_pass_level, n_levels, n_bands, rows_per_band, window_width, progress, epoch, xcd_local);
-        else if (groups_per_pass == 16) hipLaunchKernelGGL((ycge::k_atrous_stream<16>), grid, dim3(512 + 64), 0, stream, A, buf, statw, sky, d_pixels, d_offsets, d_pass_level, n_levels, n_bands, rows_per_band, window_width, progress, epoch, xcd_local);
-        else hipLaunchKernelGGL((ycge::k_atrous_stream<32>), grid, dim3(1024 + 64), 0, stream, A, buf, statw, sky, d_pixels, d_offsets, d_pass_level, n_levels, n_bands, rows_per_band, window_width, progress, epoch, xcd_local);
+    if (level_handover) {       // 8 or 16 pixels a pass: the publishing wavefront is the workgroup's 5th or 9th
+        if (groups_per_pass == 8) hipLaunchKernelGGL((ycge::k_atrous_stream<8, false>), grid, dim3(256 + 64), 0, stream, A, buf, statw, sky, d_pixels, d_offsets, d_pass_level, n_levels, n_bands, rows_per_band, window_width, progress, epoch, xcd_local);
+        else if (groups_per_pass == 16 && !profile) hipLaunchKernelGGL((ycge::k_atrous_stream<16, false>), grid, dim3(512 + 64), 0, stream, A, buf, statw, sky, d_pixels, d_offsets, d_pass_level, n_levels, n_bands, rows_per_band, window_width, progress, epoch, xcd_local);
+        else if (groups_per_pass == 16) hipLaunchKernelGGL((ycge::k_atrous_stream<16, true>), grid, dim3(512 + 64), 0, stream, A, buf, statw, sky, d_pixels, d_offsets, d_pass_level, n_levels, n_bands, rows_per_band, window_width, progress, epoch, xcd_local);
+        else return (int)hipErrorInvalidValue;
         return (int)hipGetLastError();
     }
     if (groups_per_pass == 8)
