@@ -1567,7 +1567,8 @@ int run_post(ycge_ctx *c, hipStream_t stream, float *out_sdr_host, bool timed)
     for (int it = 0; it < iters; it++) {
         const int step = 1 << it;
         if (cur == dst) {
-            if (w > 65535 || h > 65535) return c->fail(YCGE_ERR_UNSUPPORTED, "in-place A-trous: trace grid above 65535 pixels a side");
+            if (w > 65535 || h > 65535 || n * 300 >= ((size_t)1 << 32))
+                return c->fail(YCGE_ERR_UNSUPPORTED, "in-place A-trous: trace grid above 65535 pixels a side or 14.3 M pixels (32-bit offsets into the weight table)");
             ycge_ctx::InplaceSchedule *sc = nullptr;
             for (auto *k : c->schedules) if (k->w == w && k->h == h && k->step == step) sc = k;
             if (!sc) {

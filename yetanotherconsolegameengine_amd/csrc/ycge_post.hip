@@ -212,8 +212,7 @@ __device__ __forceinline__ PassData pass_fetch(const AtrousParams &A, const Band
 {
     PassData D;
     if (sky_known > 0 || (sky_known >= 0 && p == YCGE_POST_NONE)) {      // k_atrous_stream knows the flag a pass early: a sky pixel (or no pixel) fetches nothing
-        D.p = 0; D.j = 0; D.pslot = 0; D.jslot = YCGE_POST_NONE; D.sky0 = 1; D.sky_j = 1;
-        D.c0 = f3(0.0f, 0.0f, 0.0f); D.cj = D.c0; D.wn = D.wz = D.wa = 0.0f;
+        D.sky0 = 1;             // nothing else of D is read for a sky pixel (pass_compute: work = false), so nothing else is set
         return D;
     }
     const uint32_t e = p == YCGE_POST_NONE ? 0u : p;        // list entries are x | y << 16: no division in the chain
@@ -229,11 +228,14 @@ __device__ __forceinline__ PassData pass_fetch(const AtrousParams &A, const Band
     const int rj = sy - W.y0, rp = y - W.y0;
     D.jslot = (rj >= 0 && rj < W.rows) ? (uint32_t)rj * W.wx + ((uint32_t)sx & (W.wx - 1u)) : YCGE_POST_NONE;
     D.pslot = ((uint32_t)rp * W.wx + ((uint32_t)x & (W.wx - 1u))) & (YCGE_POST_WIN - 1u);
-    D.sky0 = sky_known >= 0 ? (uint8_t)sky_known : sky[pp];
-    D.c0 = COH_ALL ? ld3_dev(buf, pp) : ld3(buf, pp);   // (own rows in k_atrous_stream: what this launch has rewritten comes from the LDS table, the rest is old in every cache)
-    D.sky_j = sky[D.j];
-    D.cj = (COH_ALL || (COH && rj < 0)) ? ld3_dev(buf, D.j) : ld3(buf, D.j);     // ... a tap above the band is the only colour this launch reads that another workgroup writes
-    const float *sw = statw + ((size_t)pp * 25 + (size_t)(t < 25 ? t : 0)) * 3;
+    // 32-bit byte offsets against the (scalar) array bases: one address register per load instead of 64-bit arithmetic per lane
+    // (the host keeps the in-place form to grids whose weight table stays below 4 GB: 14.3 M pixels)
+    const float *c0p = (const float *)((const char *)buf + 12u * pp), *cjp = (const float *)((const char *)buf + 12u * D.j);
+    D.sky0 = sky_known >= 0 ? (uint8_t)sky_known : *(const uint8_t *)((const char *)sky + pp);
+    D.c0 = COH_ALL ? ld3_dev(c0p, 0) : ld3(c0p, 0);     // (own rows in k_atrous_stream: what this launch has rewritten comes from the LDS table, the rest is old in every cache)
+    D.sky_j = *(const uint8_t *)((const char *)sky + D.j);
+    D.cj = (COH_ALL || (COH && rj < 0)) ? ld3_dev(cjp, 0) : ld3(cjp, 0);       // ... a tap above the band is the only colour this launch reads that another workgroup writes
+    const float *sw = (const float *)((const char *)statw + (pp * 25u + (uint32_t)(t < 25 ? t : 0)) * 12u);
     D.wn = sw[0]; D.wz = sw[1]; D.wa = sw[2];
     return D;
 }
