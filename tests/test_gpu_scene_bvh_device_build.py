@@ -218,3 +218,24 @@ def test_device_builder_against_the_host_builder_on_hard_inputs(product_lib, mon
         sorted_sets += sorts > 0
     print(f"{len(cases)} item sets, {sorted_sets} of them with the reference's Array.Sort case")
     assert sorted_sets >= 2
+
+
+def test_moved_objects_reach_every_device_of_a_multi_device_context(product_lib, oracle):
+    """ycge_scene_update_objects on a context that drives two devices (both GPU 0 here): the tree is built on each of them by the
+    same kernel, and the frames stay the oracle's."""
+    scene = _crowd(700, 21)
+    flat = flatten(scene)
+    o = oracle.OracleRenderer(scene, 160, 90, 1, POSE, flat=flat)
+    g = RaytraceRenderer(flat, 160, 90, POSE["fov"], 1, capture_debug=True, count_work=True, devices=[0, 0])
+    g.SetCamera(POSE["pos"], POSE["yaw"], POSE["pitch"])
+    o.render(stages=1, threads=16); g.TryFlipAndBlit()
+    rng = np.random.default_rng(2)
+    for step in range(3):
+        _move(scene, rng, 0.5)
+        moved = flatten(scene)
+        assert o.L.orc_scene_upload(o.ctx, moved.byref()) == 0
+        g.UpdateObjects(moved)
+        _same_tree(o, g, f"two devices, move {step}")
+        _frame_parity(o, g, f"two devices, frame after move {step}")
+    assert g.scene_bvh_stats()["device_builds"] == 3
+    o.close(); g.close()
