@@ -35,7 +35,7 @@
 extern "C" {
 #endif
 
-#define YCGE_ABI_VERSION 3
+#define YCGE_ABI_VERSION 4
 #define YCGE_MAX_DEVICES 8
 
 typedef enum ycge_status {
@@ -63,9 +63,18 @@ typedef struct ycge_vec3 { float x, y, z; } ycge_vec3;
 typedef enum ycge_material_kind {
     YCGE_MAT_CONSTANT = 0,       /* Solid / Emissive / plain Material struct    */
     YCGE_MAT_CHECKER = 1,        /* Scenes.cs:418-428: parity of floor(x/s)+floor(z/s) */
-    YCGE_MAT_TEXTURED = 2        /* Material.DiffuseTexture != null (RaytraceRenderer.cs:724-735 -> Texture.cs:108-163):
-                                    outside the path; ycge_scene_upload refuses it with YCGE_ERR_UNSUPPORTED */
+    YCGE_MAT_TEXTURED = 2        /* a constant Material with DiffuseTexture != null: SampleAlbedo blends the albedo with a
+                                    bilinear sample of the texture at the hit's (U, V) (RaytraceRenderer.cs:724-735 ->
+                                    Renderer/Texture.cs:142-163, static textures; a live video texture - Texture.cs:113-140 -
+                                    is refused with YCGE_ERR_UNSUPPORTED by the host wrapper, it has no pixels to pass) */
 } ycge_material_kind;
+
+/* Renderer/Texture.cs:15,22-23: `pixels[y * width + x]` as RGBA32.ToInt() packs them (RGBA32.cs:14-31: byte 0 = r,
+ * 1 = g, 2 = b, 3 = a of the little-endian int). */
+typedef struct ycge_texture {
+    int32_t width, height;       /* both >= 1                                   */
+    const uint32_t *pixels;      /* width * height                              */
+} ycge_texture;
 
 typedef struct ycge_material {
     int32_t kind;                /* ycge_material_kind                          */
@@ -78,6 +87,12 @@ typedef struct ycge_material {
     float transparency;
     float index_of_refraction;
     ycge_vec3 transmission_color;
+    /* YCGE_MAT_TEXTURED only (Material.cs:16-18; doubles as in the reference: SampleAlbedo compares and clamps them as
+     * doubles before it narrows) */
+    int32_t texture;             /* index into ycge_scene.textures              */
+    int32_t reserved;
+    double texture_weight;       /* Material.TextureWeight; <= 0 means no texture */
+    double uv_scale;             /* Material.UVScale                            */
 } ycge_material;
 
 /* --------------------------------------------------------------- primitives
@@ -159,7 +174,8 @@ typedef struct ycge_scene {      /* Scenes/Scene.cs:12-24 */
     ycge_vec3 background_top;
     ycge_vec3 background_bottom;
     int32_t is_volume_scene;     /* `scene is VolumeScene` (RaytraceRenderer.cs:761) */
-    int32_t reserved;
+    int32_t n_textures;
+    const ycge_texture *textures;   /* what YCGE_MAT_TEXTURED materials index */
 } ycge_scene;
 
 /* ------------------------------------------------------------------- config */

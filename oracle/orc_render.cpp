@@ -201,7 +201,7 @@ static V3 trace_full(const SceneData &S, const Consts &K, Ray r, Rng &rng, bool 
                 primary_hit_something = true;
                 is_sky = false;
                 if (!gbuf_valid) {
-                    primary = GBuf{rec.m.albedo, rec.n, rec.t, rec.prim, rec.sub, rec.t};
+                    primary = GBuf{S.sample_albedo(rec.m, rec.u, rec.v), rec.n, rec.t, rec.prim, rec.sub, rec.t};     /* :494-495 */
                     gbuf_valid = true;
                 }
                 item.is_primary = false;
@@ -210,7 +210,7 @@ static V3 trace_full(const SceneData &S, const Consts &K, Ray r, Rng &rng, bool 
                 V3 e = rec.m.emission;
                 radiance = radiance + v3(beta.x * e.x, beta.y * e.y, beta.z * e.z);
             }
-            V3 base_albedo = rec.m.albedo;     /* SampleAlbedo with no texture, :724-729 */
+            V3 base_albedo = S.sample_albedo(rec.m, rec.u, rec.v);     /* :505, SampleAlbedo :724-735 */
             if (rec.m.transparency > 0.0f) {
                 if (mirror_depth >= K.max_mirror_bounces) break;
                 V3 n = rec.n;
@@ -877,6 +877,31 @@ int orc_scene_hit(void *ctx, const float o[3], const float d[3], float t_min, fl
     out[0] = hit ? 1.0f : 0.0f; out[1] = (float)h.prim; out[2] = (float)h.sub; out[3] = h.t;
     out[4] = h.p.x; out[5] = h.p.y; out[6] = h.p.z; out[7] = h.n.x; out[8] = h.n.y; out[9] = h.n.z;
     out[10] = h.m.albedo.x; out[11] = h.m.albedo.y; out[12] = h.m.albedo.z;
+    return YCGE_OK;
+}
+/* SampleAlbedo of material `mi` of the uploaded scene at n (u, v) pairs (known-answer tests of the texture branch): out = n x 3;
+ * and the (u, v) the closest hit of a ray carries: hit_uv out = {hit, u, v, sampled albedo rgb} */
+int orc_sample_albedo(void *ctx, int32_t mi, const float *uv, int n, float *out)
+{
+    Renderer *r = (Renderer *)ctx;
+    if (!r || !r->have_scene || mi < 0 || mi >= (int)r->scene.materials.size()) return YCGE_ERR_INVALID_ARG;
+    const orc::Mat m = r->scene.eval_material(mi, orc::v3(0, 0, 0));
+    for (int i = 0; i < n; i++) {
+        const orc::V3 a = r->scene.sample_albedo(m, uv[2 * i], uv[2 * i + 1]);
+        out[3 * i] = a.x; out[3 * i + 1] = a.y; out[3 * i + 2] = a.z;
+    }
+    return YCGE_OK;
+}
+int orc_scene_hit_uv(void *ctx, const float o[3], const float d[3], float out[6])
+{
+    Renderer *r = (Renderer *)ctx;
+    if (!r || !r->have_scene) return YCGE_ERR_NO_SCENE;
+    orc::Counters c; orc::Hit h{};
+    orc::Ray ray = orc::make_ray(orc::v3(o[0], o[1], o[2]), orc::v3(d[0], d[1], d[2]));
+    const bool hit = r->scene.hit(ray, 0.001f, 3.402823466e+38f, h, c);
+    out[0] = hit ? 1.0f : 0.0f; out[1] = h.u; out[2] = h.v;
+    const orc::V3 a = hit ? r->scene.sample_albedo(h.m, h.u, h.v) : orc::v3(0, 0, 0);
+    out[3] = a.x; out[4] = a.y; out[5] = a.z;
     return YCGE_OK;
 }
 /* closest hits of n rays with per-ray work counters: counts = n x {box, tri, prim, vox} (analysis aid) */

@@ -376,6 +376,17 @@ std::string SceneData::load(const ycge_scene *s)
 {
     if (!s) return "null scene";
     materials.assign(s->materials, s->materials + s->n_materials);
+    textures.clear();
+    for (int i = 0; i < s->n_textures; i++) {
+        const ycge_texture &t = s->textures[i];
+        if (t.width < 1 || t.height < 1 || !t.pixels) return "texture without pixels";
+        Texture T;
+        T.width = t.width; T.height = t.height;
+        T.pixels.assign(t.pixels, t.pixels + (size_t)t.width * t.height);
+        textures.push_back(std::move(T));
+    }
+    for (int i = 0; i < s->n_materials; i++)
+        if (s->materials[i].kind == YCGE_MAT_TEXTURED && (s->materials[i].texture < 0 || s->materials[i].texture >= s->n_textures)) return "material texture index out of range";
     lights.clear();
     for (int i = 0; i < s->n_lights; i++)
         lights.push_back(Light{v3(s->lights[i].position), v3(s->lights[i].color), s->lights[i].intensity});
@@ -576,7 +587,54 @@ Mat SceneData::eval_material(int32_t mi, V3 pos) const
     out.transparency = m.transparency;
     out.ior = m.index_of_refraction;
     out.trans_color = v3(m.transmission_color);
+    if (m.kind == YCGE_MAT_TEXTURED) { out.tex = m.texture; out.tex_weight = m.texture_weight; out.uv_scale = m.uv_scale; }
     return out;
+}
+
+/* Texture.SampleBilinear, Texture.cs:142-163: wrap by u - floor(u), texel coordinates over (size - 1), right / lower neighbour
+ * wraps with %, RGBA32.toVec3 = byte / 255f (RGBA32.cs:82-85), Lerp(a, b, t) = a * (1 - t) + b * t per component
+ * (Texture.cs:165-168), Saturate.  A u or v that is not finite would index out of range in the reference (an exception);
+ * here such an index yields white - not reachable from finite barycentrics and rectangle coordinates. */
+V3 Texture::sample_bilinear(float u, float v) const
+{
+    if (width <= 0 || height <= 0 || pixels.empty()) return v3(1.0f, 1.0f, 1.0f);
+    u = u - cs_floor(u);
+    v = v - cs_floor(v);
+    float fx = u * (float)(width - 1);
+    float fy = v * (float)(height - 1);
+    int x0 = cs_f2i(cs_floor(fx));
+    int y0 = cs_f2i(cs_floor(fy));
+    if (x0 < 0 || x0 >= width || y0 < 0 || y0 >= height) return v3(1.0f, 1.0f, 1.0f);
+    int x1 = (x0 + 1) % width;
+    int y1 = (y0 + 1) % height;
+    float tx = fx - (float)x0;
+    float ty = fy - (float)y0;
+    auto texel = [&](int x, int y) {
+        uint32_t c = pixels[(size_t)y * width + x];
+        return v3((float)(c & 255u) / 255.0f, (float)((c >> 8) & 255u) / 255.0f, (float)((c >> 16) & 255u) / 255.0f);
+    };
+    auto lerp3 = [](V3 a, V3 b, float t) {
+        float s = 1.0f - t;
+        return v3(a.x * s + b.x * t, a.y * s + b.y * t, a.z * s + b.z * t);
+    };
+    V3 a = lerp3(texel(x0, y0), texel(x1, y0), tx);
+    V3 b = lerp3(texel(x0, y1), texel(x1, y1), tx);
+    V3 c = lerp3(a, b, ty);
+    return v3(clamp01(c.x), clamp01(c.y), clamp01(c.z));
+}
+
+/* RaytraceRenderer.SampleAlbedo, RaytraceRenderer.cs:724-735 */
+V3 SceneData::sample_albedo(const Mat &m, float u, float v) const
+{
+    if (m.tex < 0 || m.tex_weight <= 0.0) return m.albedo;
+    double sc = m.uv_scale > 1e-6 ? m.uv_scale : 1e-6;                    /* Math.Max(1e-6, mat.UVScale); a NaN scale gives NaN in .NET: not modelled */
+    float tiles = (float)sc;
+    V3 tex = textures[m.tex].sample_bilinear(u * tiles, v * tiles);
+    double w = m.tex_weight < 0.0 ? 0.0 : m.tex_weight > 1.0 ? 1.0 : m.tex_weight;      /* Math.Clamp */
+    float t = (float)w;
+    float s = 1.0f - t;
+    V3 o = v3(m.albedo.x * s + tex.x * t, m.albedo.y * s + tex.y * t, m.albedo.z * s + tex.z * t);
+    return v3(clamp01(o.x), clamp01(o.y), clamp01(o.z));
 }
 
 /* ======================================================================

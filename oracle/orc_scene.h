@@ -59,6 +59,8 @@ struct Mat {
     float transparency;     /* (float)Material.Transparency */
     float ior;
     V3 trans_color;
+    int32_t tex = -1;       /* Material.DiffuseTexture (index into SceneData::textures), -1 = none */
+    double tex_weight = 1.0, uv_scale = 1.0;    /* Material.TextureWeight / UVScale, doubles as in Material.cs:17-18 */
 };
 
 /* ---- RayTracing/HitRecord.cs + ids for the parity buffers ---------------- */
@@ -136,12 +138,20 @@ struct Prim {
 
 struct Light { V3 pos, color; float intensity; };
 
+/* Renderer/Texture.cs, static texture: pixels[y * width + x] = RGBA32.ToInt() */
+struct Texture {
+    int32_t width = 0, height = 0;
+    std::vector<uint32_t> pixels;
+    V3 sample_bilinear(float u, float v) const;     /* Texture.cs:108-163 (the branch without a live frame reader) */
+};
+
 struct SceneData {
     std::vector<ycge_material> materials;
     std::vector<Prim> prims;
     std::vector<MeshAccel> meshes;
     std::vector<Grid> grids;
     std::vector<Light> lights;
+    std::vector<Texture> textures;
     V3 ambient_color; float ambient_intensity;
     V3 bg_top, bg_bottom;
     bool is_volume_scene;
@@ -158,6 +168,7 @@ struct SceneData {
     bool prim_hit(int32_t prim_index, const Ray &r, float t_min, float t_max, Hit &rec, Counters &c) const;
     bool prim_bounds(int32_t prim_index, float b[6], float c[3]) const;
     Mat eval_material(int32_t material, V3 pos) const;
+    V3 sample_albedo(const Mat &m, float u, float v) const;      /* RaytraceRenderer.SampleAlbedo, RaytraceRenderer.cs:724-735 */
 };
 
 /* .NET 8 Array.Sort(T[], int, int, IComparer<T>) = ArraySortHelper<T>.IntrospectiveSort */

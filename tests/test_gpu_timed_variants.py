@@ -178,13 +178,14 @@ def test_pipelined_tiled_frames_with_a_moving_camera(product_lib):
 
 
 def test_textured_material_and_bad_indices_are_refused(product_lib):
-    """A textured material (Material.DiffuseTexture, RaytraceRenderer.cs:724-735) is outside the path: refused loudly."""
+    """A textured material whose texture index points nowhere, a texture without pixels, an object with a material index out of
+    range: refused loudly, with the reason."""
     from yetanotherconsolegameengine_amd.scene import Material, Scene, Sphere, vec3
     s = Scene()
     s.Add(Sphere(vec3(0, 1, -3), 1.0, Material(vec3(0.7, 0.3, 0.3), Kind=abi.MAT_TEXTURED)))
     with pytest.raises(abi.YcgeError) as e:
         RaytraceRenderer(s, 32, 9)
-    assert e.value.status == abi.YCGE_ERR_UNSUPPORTED and "textured" in str(e.value)
+    assert e.value.status == abi.YCGE_ERR_INVALID_ARG and "texture index" in str(e.value)
     ok = Scene()
     ok.Add(Sphere(vec3(0, 1, -3), 1.0, Material(vec3(0.7, 0.3, 0.3))))
     f = flatten(ok)

@@ -99,7 +99,7 @@ def test_scene_upload_argument_checks_fuzzed(product_lib):
         elif kind == 5: f.grids[0].lookup[int(rng.integers(2))].material = v
         elif kind == 6: f.struct.n_prims = -1
         elif kind == 7: f.grids[0].nx = int(rng.choice([0, -3]))
-        elif kind == 8: f.materials[int(rng.integers(n_mat))].kind = abi.MAT_TEXTURED; expect = abi.YCGE_ERR_UNSUPPORTED
+        elif kind == 8: f.materials[int(rng.integers(n_mat))].kind = abi.MAT_TEXTURED      # a textured material without a texture to index
         else: f.materials[int(rng.integers(n_mat))].kind = int(rng.choice([3, -1, 77])); expect = abi.YCGE_ERR_UNSUPPORTED
         rc = product_lib.ycge_validate_scene(f.byref(), msg, 256)
         assert rc == expect, (trial, kind, v, rc, msg.value)

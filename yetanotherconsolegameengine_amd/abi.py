@@ -12,7 +12,7 @@ import ctypes as C
 import os
 from pathlib import Path
 
-YCGE_ABI_VERSION = 3
+YCGE_ABI_VERSION = 4
 YCGE_MAX_DEVICES = 8
 
 # ycge_status
@@ -61,7 +61,12 @@ class Material(C.Structure):
         ("kind", C.c_int32), ("albedo", Vec3), ("albedo_b", Vec3), ("checker_scale", C.c_float),
         ("specular", C.c_float), ("reflectivity", C.c_float), ("emission", Vec3),
         ("transparency", C.c_float), ("index_of_refraction", C.c_float), ("transmission_color", Vec3),
+        ("texture", C.c_int32), ("reserved", C.c_int32), ("texture_weight", C.c_double), ("uv_scale", C.c_double),
     ]
+
+
+class Texture(C.Structure):
+    _fields_ = [("width", C.c_int32), ("height", C.c_int32), ("pixels", C.POINTER(C.c_uint32))]
 
 
 class Prim(C.Structure):
@@ -104,7 +109,7 @@ class Scene(C.Structure):
         ("lights", C.POINTER(Light)), ("n_lights", C.c_int32),
         ("ambient_color", Vec3), ("ambient_intensity", C.c_float),
         ("background_top", Vec3), ("background_bottom", Vec3),
-        ("is_volume_scene", C.c_int32), ("reserved", C.c_int32),
+        ("is_volume_scene", C.c_int32), ("n_textures", C.c_int32), ("textures", C.POINTER(Texture)),
     ]
 
 

@@ -103,7 +103,10 @@ struct alignas(16) GMaterial {
     float transparency;
     float ior;
     float trans_color[3];
-    float pad[3];
+    // kind == YCGE_MAT_TEXTURED (SampleAlbedo, RaytraceRenderer.cs:724-735): texture index (-1: weight <= 0, no texture), and the two
+    // doubles as SampleAlbedo narrows them: tiles = (float)Math.Max(1e-6, UVScale), t = (float)Math.Clamp(TextureWeight, 0, 1)
+    int32_t tex;
+    float tex_tiles, tex_t;
 };
 static_assert(sizeof(GMaterial) == 80, "GMaterial must be 80 B");
 
@@ -175,6 +178,10 @@ struct SceneDev {
     float bg_top[3], bg_bottom[3];
     int32_t is_volume_scene;
     int32_t any_transparent;            // some material has Transparency > 0
+    const uint32_t *tex_pixels;         // every texture's RGBA32 pixels (Renderer/Texture.cs:15), back to back
+    const int32_t *tex_info;            // per texture: {first pixel, width, height, 0}
+    int32_t any_textured;               // some material samples a texture (SampleAlbedo, RaytraceRenderer.cs:724-735)
+    int32_t pad_tex;
 };
 
 struct FrameParams {

@@ -253,6 +253,8 @@ struct ycge_ctx {
     DevBuf<GGrid> d_grids;
     DevBuf<uint8_t> d_cells;
     DevBuf<int32_t> d_lut;
+    DevBuf<uint32_t> d_tex_pixels;             // textures of YCGE_MAT_TEXTURED materials
+    DevBuf<int32_t> d_tex_info;
     DevBuf<GLight> d_lights;
     BuiltTree scene_tree;                      // host copy of the scene BVH in the reference's format (ycge_read_accel)
     bool scene_tree_on_device = false;         // ... not fetched yet from the last device-side build (accel_view does it on demand)
@@ -635,7 +637,7 @@ void ycge_destroy(ycge_ctx *c)
     c->wf_q0.release(); c->wf_q1.release(); c->wf_hit.release(); c->wf_lq.release(); c->wf_seg.release(); c->wf_counts.release(); c->tile_order.release(); c->block_cost.release(); c->block_order.release(); c->order_ws.release(); c->stack_spill.release(); c->path_stack.release(); c->mig_entries.release(); c->mig_pub.release(); c->mig_ctl.release();
     c->d_scene_nodes.release(); c->d_mesh_arena.release(); c->d_scene_leaf.release(); c->d_prims.release();
     c->d_bvh_items.release(); c->d_bvh_scratch.release(); c->d_bvh_ref.release(); c->d_bvh_res.release();
-    c->d_materials.release(); c->d_meshes.release(); c->d_grids.release(); c->d_cells.release(); c->d_lut.release(); c->d_lights.release();
+    c->d_materials.release(); c->d_meshes.release(); c->d_grids.release(); c->d_cells.release(); c->d_lut.release(); c->d_lights.release(); c->d_tex_pixels.release(); c->d_tex_info.release();
     for (auto &ev : c->ev) if (ev) (void)hipEventDestroy(ev);
     for (hipEvent_t ev : {c->fan_ev[0], c->fan_ev[1], c->traced_ev, c->order_ev, c->pushed_ev}) if (ev) (void)hipEventDestroy(ev);
     if (c->fan_stream) (void)hipStreamDestroy(c->fan_stream);
@@ -694,8 +696,16 @@ int validate_scene(const ycge_scene *s, std::string &msg)
     auto mat_ok = [&](int mi) { return mi >= 0 && mi < s->n_materials; };
     for (int i = 0; i < s->n_materials; i++) {
         const int k = s->materials[i].kind;
-        if (k == YCGE_MAT_TEXTURED) return bad(YCGE_ERR_UNSUPPORTED, "material %d: textured materials (Material.DiffuseTexture, RaytraceRenderer.cs:724-735) are outside the path", i);
-        if (k != YCGE_MAT_CONSTANT && k != YCGE_MAT_CHECKER) return bad(YCGE_ERR_UNSUPPORTED, "material %d: unknown kind %d", i, k);
+        if (k == YCGE_MAT_TEXTURED) {
+            if (s->materials[i].texture < 0 || s->materials[i].texture >= s->n_textures)
+                return bad(YCGE_ERR_INVALID_ARG, "material %d: texture index %d out of range (%d textures)", i, s->materials[i].texture, s->n_textures);
+        } else if (k != YCGE_MAT_CONSTANT && k != YCGE_MAT_CHECKER) return bad(YCGE_ERR_UNSUPPORTED, "material %d: unknown kind %d", i, k);
+    }
+    if (s->n_textures < 0 || (s->n_textures > 0 && !s->textures)) return bad(YCGE_ERR_INVALID_ARG, "bad texture array");
+    for (int i = 0; i < s->n_textures; i++) {
+        const ycge_texture &t = s->textures[i];
+        if (t.width < 1 || t.height < 1 || !t.pixels) return bad(YCGE_ERR_INVALID_ARG, "texture %d: needs width, height >= 1 and pixels (%d x %d)", i, t.width, t.height);
+        if ((long long)t.width * t.height > (1ll << 28)) return bad(YCGE_ERR_UNSUPPORTED, "texture %d: above 2^28 pixels", i);
     }
     for (int mi = 0; mi < s->n_meshes; mi++) {
         const ycge_mesh &m = s->meshes[mi];
@@ -906,7 +916,9 @@ struct SceneArrays {
     std::vector<GMesh> gmeshes;
     std::vector<GGrid> ggrids;
     std::vector<int32_t> lut;
-    bool any_transparent = false, has_grid = false;
+    bool any_transparent = false, has_grid = false, any_textured = false;
+    std::vector<uint32_t> tex_pixels;
+    std::vector<int32_t> tex_info;
 };
 
 int install_scene(ycge_ctx *c, const SceneArrays &A, const ObjectsHost &oh, const ycge_scene *s)
@@ -916,11 +928,13 @@ int install_scene(ycge_ctx *c, const SceneArrays &A, const ObjectsHost &oh, cons
     HIP_TRY(c, c->d_materials.upload(A.mats)); HIP_TRY(c, c->d_mesh_arena.upload(A.arena));
     HIP_TRY(c, c->d_meshes.upload(A.gmeshes)); HIP_TRY(c, c->d_grids.upload(A.ggrids)); HIP_TRY(c, c->d_cells.upload(A.cells));
     HIP_TRY(c, c->d_lut.upload(A.lut));
+    HIP_TRY(c, c->d_tex_pixels.upload(A.tex_pixels)); HIP_TRY(c, c->d_tex_info.upload(A.tex_info));
     SceneDev &sd = c->sd;
     std::memset(&sd, 0, sizeof sd);
     sd.mesh_arena = c->d_mesh_arena.p;
     sd.materials = c->d_materials.p; sd.meshes = c->d_meshes.p; sd.grids = c->d_grids.p;
     sd.grid_cells = c->d_cells.p; sd.grid_lut = c->d_lut.p;
+    sd.tex_pixels = c->d_tex_pixels.p; sd.tex_info = c->d_tex_info.p;
     c->has_grid = A.has_grid;
     int rc = install_objects(c, oh);
     if (rc != YCGE_OK) return rc;
@@ -930,6 +944,7 @@ int install_scene(ycge_ctx *c, const SceneArrays &A, const ObjectsHost &oh, cons
     sd.bg_bottom[0] = s->background_bottom.x; sd.bg_bottom[1] = s->background_bottom.y; sd.bg_bottom[2] = s->background_bottom.z;
     sd.is_volume_scene = s->is_volume_scene ? 1 : 0;
     sd.any_transparent = A.any_transparent ? 1 : 0;
+    sd.any_textured = A.any_textured ? 1 : 0;
     rc = upload_lights(c, s->lights, s->n_lights);
     if (rc != YCGE_OK) return rc;
     c->have_scene = true;
@@ -1025,6 +1040,19 @@ int ycge_scene_upload(ycge_ctx *c, const ycge_scene *s)
         g.transparency = m.transparency; g.ior = m.index_of_refraction;
         g.trans_color[0] = m.transmission_color.x; g.trans_color[1] = m.transmission_color.y; g.trans_color[2] = m.transmission_color.z;
         if (m.transparency > 0.0f) A.any_transparent = true;
+        g.tex = -1;
+        if (m.kind == YCGE_MAT_TEXTURED && m.texture_weight > 0.0) {     // SampleAlbedo, RaytraceRenderer.cs:726-733 (a weight <= 0: the plain albedo)
+            g.tex = m.texture;
+            A.any_textured = true;
+            g.tex_tiles = (float)(m.uv_scale > 1e-6 ? m.uv_scale : 1e-6);                                            // (float)Math.Max(1e-6, mat.UVScale)
+            g.tex_t = (float)(m.texture_weight < 0.0 ? 0.0 : m.texture_weight > 1.0 ? 1.0 : m.texture_weight);       // (float)Math.Clamp(mat.TextureWeight, 0.0, 1.0)
+        }
+    }
+    for (int i = 0; i < s->n_textures; i++) {
+        const ycge_texture &t = s->textures[i];
+        const int32_t info[4] = {(int32_t)A.tex_pixels.size(), t.width, t.height, 0};
+        A.tex_info.insert(A.tex_info.end(), info, info + 4);
+        A.tex_pixels.insert(A.tex_pixels.end(), t.pixels, t.pixels + (size_t)t.width * t.height);
     }
     auto mat_ok = [&](int mi) { return mi >= 0 && mi < s->n_materials; };
 
@@ -1316,7 +1344,9 @@ int trace_frame(ycge_ctx *c, float *d_slab, hipStream_t stream, FrameState &fs, 
     const uint32_t trace_lanes = (uint32_t)(c->n_owned > 0 ? c->n_owned : 1) * 256u * YCGE_SCHEDULE_SLACK;
     O.stack_lanes = trace_lanes + c->fan_cap * 192u;
     O.path_stack = c->path_stack.p;
-    const int flat = (YCGE_REF_KIND(c->sd.scene_root_ref) == REF_SCENE_LEAF && !c->knobs.generic_walk) ? 1 : 0;      // YCGE_GENERIC_WALK: experiment knob, same pixels
+    // (a scene with a textured material takes the generic kernels: the flat ones - configs 3 and 4 - are compiled without the texture
+    // branch, which cost them 1.6 % when it was merely present, profiles/tex_ab.sh)
+    const int flat = (YCGE_REF_KIND(c->sd.scene_root_ref) == REF_SCENE_LEAF && !c->knobs.generic_walk && !c->sd.any_textured) ? 1 : 0;      // YCGE_GENERIC_WALK: experiment knob, same pixels
     // Path choice.  Refraction splits need TraceFull's per-pixel LIFO -> single launch.  Otherwise: scenes
     // that are one BVH leaf (mesh viewers) are bounded by the latency chain of their few heaviest tiles, and
     // one launch lets the chains of all stages overlap (measured 0.85 vs 1.24 ms on config 4); scenes with a

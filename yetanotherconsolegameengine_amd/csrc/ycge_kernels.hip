@@ -361,6 +361,7 @@ __global__ __launch_bounds__(256) void k_wf_shade(const SceneDev S, const FrameP
         } else {
             HitAttr h;
             resolve_hit<HAS_GRID>(S, hit_prim, hit_sub, t_hit, o, d, h);
+            if (YCGE_TEXTURES && S.any_textured) apply_texture(S, hit_prim, hit_sub, o, d, h);
             if (ROUND0) {           // primary G-buffer, :488-499
                 O.g_albedo[3 * (size_t)pixel] = h.m.albedo.x; O.g_albedo[3 * (size_t)pixel + 1] = h.m.albedo.y; O.g_albedo[3 * (size_t)pixel + 2] = h.m.albedo.z;
                 O.g_normal[3 * (size_t)pixel] = h.n.x; O.g_normal[3 * (size_t)pixel + 1] = h.n.y; O.g_normal[3 * (size_t)pixel + 2] = h.n.z;
@@ -881,6 +882,7 @@ __device__ __forceinline__ void trace_block(const SceneDev &S, const FrameParams
             } else {
                 HitAttr h;
                 resolve_hit<true>(S, hit_prim, hit_sub, t_hit, q.o, q.d, h);
+                if (YCGE_TEXTURES && !FLAT && S.any_textured) apply_texture(S, hit_prim, hit_sub, q.o, q.d, h);      // (the host sends textured scenes to the generic kernels)
                 if (item_is_primary) {
                     primary_hit_something = true;
                     is_sky = false;

@@ -187,6 +187,32 @@ __device__ __forceinline__ MatEval eval_material(const SceneDev &S, int mi, F3 p
     o.trans_color = f3(d.z, d.w, e.x);
     return o;
 }
+// Texture.SampleBilinear (Renderer/Texture.cs:142-163, static texture) + the blend of SampleAlbedo (RaytraceRenderer.cs:730-734):
+// wrap by u - floor(u), texel coordinates over (size - 1), the right / lower neighbour wraps with %, RGBA32.toVec3 = byte / 255f,
+// Lerp(a, b, t) = a * (1 - t) + b * t, Saturate; then albedo * (1 - t) + tex * t, Saturate.
+__device__ __forceinline__ F3 sample_albedo(const SceneDev &S, F3 albedo, int tex_index, float tiles, float weight, float u, float v)
+{
+    const int4 info = ((const int4 *)S.tex_info)[tex_index];
+    const int w = info.y, hgt = info.z;
+    u = u * tiles; v = v * tiles;
+    u = u - cs_floor(u);
+    v = v - cs_floor(v);
+    const float fx = u * (float)(w - 1), fy = v * (float)(hgt - 1);
+    const int x0 = cs_f2i(cs_floor(fx)), y0 = cs_f2i(cs_floor(fy));
+    F3 tex = f3(1.0f, 1.0f, 1.0f);
+    if (x0 >= 0 && x0 < w && y0 >= 0 && y0 < hgt) {        // (not finite: an exception in the reference; white here, as in the oracle)
+        const int x1 = (x0 + 1) % w, y1 = (y0 + 1) % hgt;
+        const float tx = fx - (float)x0, ty = fy - (float)y0;
+        const uint32_t *px = S.tex_pixels + info.x;
+        const uint32_t c00 = px[(size_t)y0 * w + x0], c10 = px[(size_t)y0 * w + x1], c01 = px[(size_t)y1 * w + x0], c11 = px[(size_t)y1 * w + x1];
+        auto texel = [](uint32_t c) { return f3((float)(c & 255u) / 255.0f, (float)((c >> 8) & 255u) / 255.0f, (float)((c >> 16) & 255u) / 255.0f); };
+        auto lerp3 = [](F3 a, F3 b, float t) { const float s = 1.0f - t; return f3(a.x * s + b.x * t, a.y * s + b.y * t, a.z * s + b.z * t); };
+        const F3 a = lerp3(texel(c00), texel(c10), tx), b = lerp3(texel(c01), texel(c11), tx);
+        tex = saturate(lerp3(a, b, ty));
+    }
+    const float t = weight, s1 = 1.0f - t;
+    return saturate(f3(albedo.x * s1 + tex.x * t, albedo.y * s1 + tex.y * t, albedo.z * s1 + tex.z * t));
+}
 
 // ------------------------------------------------------------------ box tests
 // BVH.BoxHitFast, BVH.cs:201-236: NaN-propagating Max/Min, clamp to [tMin, tMax]
@@ -1508,6 +1534,63 @@ __device__ __forceinline__ void resolve_hit(const SceneDev &S, int prim_index, i
     h.m = eval_material(S, material, h.p);
     if (override_refl) h.m.reflectivity = refl_override;
     if (wire_black) h.m.albedo = f3(0.0f, 0.0f, 0.0f);
+}
+
+#ifndef YCGE_TEXTURES
+#define YCGE_TEXTURES 1         // 0: an A/B build without the texture branch at the shade sites (profiles/tex_ab.sh)
+#endif
+// SampleAlbedo's texture branch (RaytraceRenderer.cs:724-735) for the hit resolve_hit has just described - called where a hit is SHADED,
+// and only in scenes that have a textured material (S.any_textured is uniform: untextured scenes skip it with one scalar branch).
+__device__ __forceinline__ void apply_texture(const SceneDev &S, int prim_index, int sub, F3 o, F3 d, HitAttr &h)
+{
+    const GPrim *P = S.prims + prim_index;
+    const float4 q0 = ((const float4 *)P)[0];
+    const int type = __float_as_int(q0.x);
+    int material = __float_as_int(q0.y);
+    if (type == 9) material = ((const GTriPair *)(S.mesh_arena + (size_t)((uint32_t)sub >> 1) * 32u))->material[sub & 1];
+    if (type == 10) return;                                  // VolumeGrid.Hit leaves (U, V) = (0, 0) and its palette materials carry no texture
+    const float4 mk = ((const float4 *)(S.materials + material))[0], me = ((const float4 *)(S.materials + material))[4];
+    const int tex = __float_as_int(me.y);
+    if (__float_as_int(mk.x) != 2 || tex < 0) return;
+    {
+        // HitRecord.U / V as the hit routines leave them, recomputed from the ray: barycentrics of a mesh triangle (MeshBVH.cs:296-303) or
+        // a Triangle (Triangle.cs:136-174), the plane coordinates of a rectangle / box face over its span (Surfaces.cs:209-212, 281-284,
+        // 353-356), 0 for everything else
+        float u = 0.0f, v = 0.0f;
+        if (type == 9) {
+            const GTriPair *tp = (const GTriPair *)(S.mesh_arena + (size_t)((uint32_t)sub >> 1) * 32u);
+            const int sl = sub & 1;
+            const float e1x = tp->e1x[sl], e1y = tp->e1y[sl], e1z = tp->e1z[sl], e2x = tp->e2x[sl], e2y = tp->e2y[sl], e2z = tp->e2z[sl];
+            const float px = d.y * e2z - d.z * e2y, py = d.z * e2x - d.x * e2z, pz = d.x * e2y - d.y * e2x;
+            const float det = e1x * px + e1y * py + e1z * pz;
+            const float sx = o.x - tp->ax[sl], sy = o.y - tp->ay[sl], sz = o.z - tp->az[sl];
+            const float u_num = sx * px + sy * py + sz * pz;
+            const float qx = sy * e1z - sz * e1y, qy = sz * e1x - sx * e1z, qz = sx * e1y - sy * e1x;
+            const float v_num = d.x * qx + d.y * qy + d.z * qz;
+            const float inv_det = 1.0f / det;
+            u = u_num * inv_det; v = v_num * inv_det;
+        } else if (type == 8) {
+            const float4 q1 = ((const float4 *)P)[1], q2 = ((const float4 *)P)[2], q3 = ((const float4 *)P)[3];
+            const float e1x = q1.w, e1y = q2.x, e1z = q2.y, e2x = q2.z, e2y = q2.w, e2z = q3.x;
+            const float px = d.y * e2z - d.z * e2y, py = d.z * e2x - d.x * e2z, pz = d.x * e2y - d.y * e2x;
+            const float det = e1x * px + e1y * py + e1z * pz;
+            const float inv_det = 1.0f / det;
+            const float sx = o.x - q1.x, sy = o.y - q1.y, sz = o.z - q1.z;
+            u = (sx * px + sy * py + sz * pz) * inv_det;
+            const float qx = sy * e1z - sz * e1y, qy = sz * e1x - sx * e1z, qz = sx * e1y - sy * e1x;
+            v = (d.x * qx + d.y * qy + d.z * qz) * inv_det;
+        } else if (type >= 3 && type <= 6) {
+            const float4 q1 = ((const float4 *)P)[1], q2 = ((const float4 *)P)[2], q3 = ((const float4 *)P)[3];
+            const float p[12] = {q1.x, q1.y, q1.z, q1.w, q2.x, q2.y, q2.z, q2.w, q3.x, q3.y, q3.z, q3.w};
+            int axis; float a0, a1, b0, b1, k;
+            if (type == 6) box_face(p, sub, axis, a0, a1, b0, b1, k);
+            else { axis = type == 3 ? 2 : type == 4 ? 1 : 0; a0 = p[0]; a1 = p[1]; b0 = p[2]; b1 = p[3]; k = p[4]; }
+            const float pa = axis == 0 ? h.p.y : h.p.x, pb = axis == 2 ? h.p.y : h.p.z;     // the two in-plane coordinates in the class's field order
+            u = (pa - a0) * (1.0f / (a1 - a0));
+            v = (pb - b0) * (1.0f / (b1 - b0));
+        }
+        h.m.albedo = sample_albedo(S, h.m.albedo, tex, me.z, me.w, u, v);
+    }
 }
 
 } // namespace ycge

@@ -32,9 +32,26 @@ ZERO = vec3(0, 0, 0)
 ONE = vec3(1, 1, 1)
 
 
+class Texture:
+    """Renderer/Texture.cs:13-23, a static texture: `pixels[y * width + x]` = RGBA32.ToInt() (byte 0 = r, 1 = g, 2 = b, 3 = a,
+    RGBA32.cs:14-31).  Built from an (h, w, 3 or 4) uint8 RGB(A) array; live video textures (Texture.cs:113-140) have no pixels
+    to pass and are not mirrored."""
+
+    def __init__(self, rgba):
+        a = np.asarray(rgba, dtype=np.uint8)
+        if a.ndim != 3 or a.shape[2] not in (3, 4) or a.shape[0] < 1 or a.shape[1] < 1:
+            raise ValueError("texture must be (height, width, 3 or 4) uint8")
+        if a.shape[2] == 3:
+            a = np.concatenate([a, np.full(a.shape[:2] + (1,), 255, np.uint8)], axis=2)
+        self.height, self.width = int(a.shape[0]), int(a.shape[1])
+        a = a.astype(np.uint32)
+        self.pixels = np.ascontiguousarray((a[..., 0] | (a[..., 1] << 8) | (a[..., 2] << 16) | (a[..., 3] << 24)).reshape(-1), dtype=np.uint32)
+
+
 @dataclass
 class Material:
-    """RayTracing/Material.cs:20-46 (texture fields are outside the path)."""
+    """RayTracing/Material.cs:7-46.  DiffuseTexture / TextureWeight / UVScale (Material.cs:16-18, doubles) feed SampleAlbedo
+    (RaytraceRenderer.cs:724-735); a material with a texture is passed as YCGE_MAT_TEXTURED."""
     Albedo: tuple
     Specular: float = 0.0
     Reflectivity: float = 0.0
@@ -46,6 +63,9 @@ class Material:
     Kind: int = abi.MAT_CONSTANT
     AlbedoB: tuple = ZERO
     CheckerScale: float = 1.0
+    DiffuseTexture: Optional[Texture] = None
+    TextureWeight: float = 1.0
+    UVScale: float = 1.0
 
 
 # material delegates Func<Vec3,Vec3,float,Material>, Scenes/Scenes.cs:408-428
@@ -297,9 +317,19 @@ class FlatScene:
             return a
 
         mat_structs = []
+        textures: List[Texture] = []
+        tex_index = {}
         for m in mats:
             s = abi.Material()
             s.kind = m.Kind
+            s.texture, s.texture_weight, s.uv_scale = -1, float(m.TextureWeight), float(m.UVScale)
+            if m.DiffuseTexture is not None:
+                if m.Kind != abi.MAT_CONSTANT:
+                    raise ValueError("a texture belongs to a plain Material (the checker delegate builds untextured ones)")
+                if id(m.DiffuseTexture) not in tex_index:
+                    tex_index[id(m.DiffuseTexture)] = len(textures)
+                    textures.append(m.DiffuseTexture)
+                s.kind, s.texture = abi.MAT_TEXTURED, tex_index[id(m.DiffuseTexture)]
             s.albedo = abi.Vec3(*m.Albedo)
             s.albedo_b = abi.Vec3(*m.AlbedoB)
             s.checker_scale = m.CheckerScale
@@ -321,6 +351,13 @@ class FlatScene:
         self.meshes = arr(abi.Mesh, meshes)
         self.grids = arr(abi.Grid, grids)
         self.lights = arr(abi.Light, lights)
+        tex_structs = []
+        for t in textures:
+            ts = abi.Texture()
+            ts.width, ts.height, ts.pixels = t.width, t.height, t.pixels.ctypes.data_as(C.POINTER(C.c_uint32))
+            self._keep.append(t)
+            tex_structs.append(ts)
+        self.textures = arr(abi.Texture, tex_structs)
 
         sc = abi.Scene()
         sc.materials, sc.n_materials = C.cast(self.materials, C.POINTER(abi.Material)), len(mat_structs)
@@ -333,6 +370,7 @@ class FlatScene:
         sc.background_top = abi.Vec3(*scene.BackgroundTop)
         sc.background_bottom = abi.Vec3(*scene.BackgroundBottom)
         sc.is_volume_scene = 1 if scene.IsVolumeScene else 0
+        sc.textures, sc.n_textures = C.cast(self.textures, C.POINTER(abi.Texture)), len(tex_structs)
         self.struct = sc
         self.n_triangles = int(sum(m.n_triangles for m in meshes))
 
