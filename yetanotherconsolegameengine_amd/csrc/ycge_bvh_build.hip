@@ -9,8 +9,8 @@
 //   * binning (BVH.cs:322-352): counts are integer sums, bin boxes and centroid bounds are min / max - order-free (LDS
 //     atomics on order-preserving integer keys).  The one thing an order could change is the sign of a zero bound, which
 //     reaches only the SAH cost's sign of zero and no comparison;
-//   * the SAH sweep (16 bins, strict '<' over axes then bins) is evaluated by one lane per axis with the reference's
-//     operation order, first minimum wins;
+//   * the SAH sweep (16 bins, strict '<' over axes then bins): running boxes and counts by scans over the bins (min / max / integer
+//     sums), the cost of every split by one lane with the reference's operation order, first minimum in (axis, bin) order wins;
 //   * the partition (BVH.cs:394-410) is the reference's two-pointer in-place loop, whose RESULT depends on the order the
 //     items are visited in.  It has a closed form (tests/test_partition_closed_form.py checks it exhaustively): with
 //     mid = #L, the front region = positions < mid plus position mid if it holds an R, the back region = the rest;
@@ -107,54 +107,47 @@ __device__ __forceinline__ bool bvh_split_node(BvhShared &sh, const float *__res
     }
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
     __builtin_amdgcn_wave_barrier();
-    // SAH sweep (BVH.cs:354-383): lane a evaluates axis a
-    float my_cost = YCGE_INF;
-    int my_bin = -1;
-    if (lane < 3 && ext[lane] > 0.0f) {
-        const int a = lane;
-        int lcount[YCGE_BVH_DEV_BINS];
-        float larea[YCGE_BVH_DEV_BINS];
-        float amn[3] = {YCGE_INF, YCGE_INF, YCGE_INF}, amx[3] = {-YCGE_INF, -YCGE_INF, -YCGE_INF};
-        int acc = 0;
-        for (int b = 0; b < YCGE_BVH_DEV_BINS; b++) {
-            const int cb = (int)B.cnt[a][b];
-            if (cb > 0)
-                for (int k = 0; k < 3; k++) {
-                    const float lo = fkey_inv(B.mn[a][b][k]), hi = fkey_inv(B.mx[a][b][k]);
-                    if (lo < amn[k]) amn[k] = lo;
-                    if (hi > amx[k]) amx[k] = hi;
-                }
-            acc += cb;
-            lcount[b] = acc;
-            larea[b] = box_area(amn, amx);
-        }
-        for (int k = 0; k < 3; k++) { amn[k] = YCGE_INF; amx[k] = -YCGE_INF; }
-        acc = 0;
-        // the suffix runs downwards, so candidates arrive with falling b: '<=' keeps the SMALLEST b of equal costs, which is the
-        // bin the reference's ascending strict '<' keeps; a cost of +inf never beats the initial +inf there
-        for (int b = YCGE_BVH_DEV_BINS - 1; b >= 1; b--) {
-            const int cb = (int)B.cnt[a][b];
-            if (cb > 0)
-                for (int k = 0; k < 3; k++) {
-                    const float lo = fkey_inv(B.mn[a][b][k]), hi = fkey_inv(B.mx[a][b][k]);
-                    if (lo < amn[k]) amn[k] = lo;
-                    if (hi > amx[k]) amx[k] = hi;
-                }
-            acc += cb;
-            const int lc = lcount[b - 1], rc = acc;
-            if (lc == 0 || rc == 0) continue;
-            const float cost = larea[b - 1] * (float)lc + box_area(amn, amx) * (float)rc;
-            if (cost <= my_cost && cost < YCGE_INF) { my_cost = cost; my_bin = b - 1; }
-        }
+    // SAH sweep (BVH.cs:354-383), one lane per (axis, bin): lanes 16 a + b.  The running boxes and counts of the reference's two
+    // loops are inclusive scans over the 16 bins of an axis - min / max and integer sums, so their grouping is free - and every lane
+    // then evaluates the ONE cost expression of its split, larea[b] * lc + rarea[b + 1] * rc, in the reference's operation order.
+    // The reference keeps the first strict minimum in (axis, bin) order = the smallest lane among the lanes with the least cost.
+    const int sa = lane >> 4, sb = lane & 15;
+    const bool slot = lane < 48 && ext[sa < 3 ? sa : 0] > 0.0f;
+    int c_pre = 0, c_suf = 0;
+    float pmn[3] = {YCGE_INF, YCGE_INF, YCGE_INF}, pmx[3] = {-YCGE_INF, -YCGE_INF, -YCGE_INF};
+    if (slot) {
+        c_pre = (int)B.cnt[sa][sb];
+        if (c_pre > 0)      // an empty bin joins no box (BVH.cs:358, 367)
+            for (int k = 0; k < 3; k++) { pmn[k] = fkey_inv(B.mn[sa][sb][k]); pmx[k] = fkey_inv(B.mx[sa][sb][k]); }
     }
-    float best_cost = YCGE_INF;
+    c_suf = c_pre;
+    float qmn[3] = {pmn[0], pmn[1], pmn[2]}, qmx[3] = {pmx[0], pmx[1], pmx[2]};
+    for (int o = 1; o < 16; o <<= 1) {          // inclusive scans inside the 16-lane segment: prefix from the left, suffix from the right
+        const int cu = __shfl_up(c_pre, o, 16), cd = __shfl_down(c_suf, o, 16);
+        float umn[3], umx[3], dmn[3], dmx[3];
+        for (int k = 0; k < 3; k++) { umn[k] = __shfl_up(pmn[k], o, 16); umx[k] = __shfl_up(pmx[k], o, 16); dmn[k] = __shfl_down(qmn[k], o, 16); dmx[k] = __shfl_down(qmx[k], o, 16); }
+        if (sb >= o) { c_pre += cu; for (int k = 0; k < 3; k++) { if (umn[k] < pmn[k]) pmn[k] = umn[k]; if (umx[k] > pmx[k]) pmx[k] = umx[k]; } }
+        if (sb + o < 16) { c_suf += cd; for (int k = 0; k < 3; k++) { if (dmn[k] < qmn[k]) qmn[k] = dmn[k]; if (dmx[k] > qmx[k]) qmx[k] = dmx[k]; } }
+    }
+    // split b: left = bins 0..b (this lane's prefix), right = bins b + 1..15 (the next lane's suffix)
+    const int rc = __shfl_down(c_suf, 1, 16);
+    float rmn[3], rmx[3];
+    for (int k = 0; k < 3; k++) { rmn[k] = __shfl_down(qmn[k], 1, 16); rmx[k] = __shfl_down(qmx[k], 1, 16); }
+    float my_cost = YCGE_INF;
+    if (slot && sb < 15 && c_pre > 0 && rc > 0) {
+        const float cost = box_area(pmn, pmx) * (float)c_pre + box_area(rmn, rmx) * (float)rc;
+        if (cost < YCGE_INF) my_cost = cost;            // (+inf and NaN never beat the reference's initial +inf)
+    }
+    int my_lane = lane;
+    for (int o = 32; o > 0; o >>= 1) {
+        const float oc = __shfl_xor(my_cost, o, 64);
+        const int ol = __shfl_xor(my_lane, o, 64);
+        if (oc < my_cost || (oc == my_cost && ol < my_lane)) { my_cost = oc; my_lane = ol; }
+    }
+    const float best_cost = my_cost;
     int split_bin = -1, best_axis = 0;
     if (ext[1] > ext[0] && ext[1] >= ext[2]) best_axis = 1; else if (ext[2] > ext[0] && ext[2] >= ext[1]) best_axis = 2;      // BVH.cs:314-316
-    for (int a = 0; a < 3; a++) {
-        const float ca = __shfl(my_cost, a, 64);
-        const int ba = __shfl(my_bin, a, 64);
-        if (ba >= 0 && ca < best_cost) { best_cost = ca; split_bin = ba; best_axis = a; }
-    }
+    if (best_cost < YCGE_INF) { split_bin = my_lane & 15; best_axis = my_lane >> 4; }
     const float *key = cpl[best_axis];
     int mid = 0;
     bool sort_it = split_bin < 0;
