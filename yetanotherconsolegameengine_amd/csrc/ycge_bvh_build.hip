@@ -63,7 +63,6 @@ struct BvhShared {
     BvhWaveBins bins[16];
     float ikey[YCGE_BVH_DEV_MAX_ITEMS];                                             // Array.Sort case: the sort key of every item of the range, by item
     uint32_t q_head, q_tail, pending, n_nodes, fallback, max_depth, sorts;
-    uint32_t why[4];       // diagnostics of the first fallback: reason (1 no split, 2 one-sided partition, 3 depth), node, count, split bin
 };
 
 // one wavefront splits node `id` = items ord[s .. s + cnt)
@@ -264,7 +263,6 @@ __global__ __launch_bounds__(1024) void k_scene_bvh_build(const float *__restric
     for (int i = tid; i < YCGE_BVH_DEV_MAX_ITEMS; i += 1024) sh.queue[i] = 0ull;
     if (tid == 0) {
         sh.q_head = 0; sh.q_tail = 0; sh.pending = 0; sh.n_nodes = 1; sh.fallback = 0; sh.max_depth = 1; sh.sorts = 0;
-        sh.why[0] = sh.why[1] = sh.why[2] = sh.why[3] = 0;
         BvhBuildNode &r = nodes[0];
         r.start = 0; r.count = n; r.depth = 1; r.left = -1; r.inner = 0; r.pre = 0; r.ipre = 0;
         if (n > YCGE_BVH_DEV_LEAF) {
@@ -304,7 +302,7 @@ __global__ __launch_bounds__(1024) void k_scene_bvh_build(const float *__restric
     __syncthreads();
     const int n_nodes = (int)sh.n_nodes, max_depth = (int)sh.max_depth;
     if (sh.fallback) {
-        if (tid == 0) { res->fallback = 1; res->n_nodes = 0; res->n_inner = 0; res->max_depth = 0; res->root_ref = YCGE_REF_NONE_VALUE; for (int k = 0; k < 4; k++) res->pad[k] = sh.why[k]; }
+        if (tid == 0) { res->fallback = 1; res->n_nodes = 0; res->n_inner = 0; res->max_depth = 0; res->root_ref = YCGE_REF_NONE_VALUE; }
         return;
     }
     // ---- leaf boxes (compare-assign in leaf order, BVH.cs:281-296), then inner boxes and subtree sizes bottom-up

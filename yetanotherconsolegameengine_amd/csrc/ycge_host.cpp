@@ -116,7 +116,6 @@ struct Knobs {
     int post_probe_band = -1;        // YCGE_POST_PROBE_BAND: this band and the next record a per-pass timeline (profiles/post_bands.py)
     int post_resident_per_cu = 1;    // YCGE_POST_RESIDENT: band workgroups of the persistent in-place A-trous a CU may hold (3 fit; two to a CU measured slower than the launch form at 4K)
     bool post_hash = false;          // YCGE_POST_HASH_FORM=1: the hash form of k_atrous_band even where the window fits
-    bool debug_bvh = false;          // YCGE_DEBUG_BVH: say why the device builder declined
     int bvh_waves = 16;              // YCGE_BVH_WAVES: wavefronts of k_scene_bvh_build that take nodes (tests: the order nodes are split in must not matter)
     bool scene_bvh_host = false;     // YCGE_SCENE_BVH_HOST: ycge_scene_update_objects builds the scene BVH on the host, not on the device
     bool exposure_serial = false;    // YCGE_EXPOSURE_SERIAL: the one-lane chain instead of the chunked exact evaluation
@@ -144,7 +143,6 @@ struct Knobs {
         exposure_serial = getenv("YCGE_EXPOSURE_SERIAL") != nullptr;
         scene_bvh_host = getenv("YCGE_SCENE_BVH_HOST") != nullptr;
         bvh_waves = geti("YCGE_BVH_WAVES", 16);
-        debug_bvh = getenv("YCGE_DEBUG_BVH") != nullptr;
     }
 };
 
@@ -887,10 +885,7 @@ int install_objects_device_built(ycge_ctx *c, ycge_ctx *root, const ObjectsHost 
     BvhBuildResult res;
     HIP_TRY(c, hipMemcpyAsync(&res, c->d_bvh_res.p, sizeof res, hipMemcpyDeviceToHost, c->stream));
     HIP_TRY(c, hipStreamSynchronize(c->stream));
-    if (res.fallback) {
-        if (c->knobs.debug_bvh) fprintf(stderr, "[ycge] device BVH build fell back: reason %u node %u count %u split bin %d (n = %d)\n", res.pad[0], res.pad[1], res.pad[2], (int)res.pad[3], n);
-        return 1;
-    }
+    if (res.fallback) return 1;
     int spill = 0;
     const int rc = check_scene_depth(c, res.max_depth, spill);
     if (rc != YCGE_OK) return rc;
