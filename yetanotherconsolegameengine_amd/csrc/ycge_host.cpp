@@ -114,7 +114,7 @@ struct Knobs {
     int mig = 1, mig_round = 12, mig_shade = 16;      // YCGE_MIG (0 = off), YCGE_MIG_ROUND, YCGE_MIG_SHADE: path migration in k_trace
     int post_mode = 0;               // YCGE_POST_MODE: in-place A-trous: 0 = one persistent launch, level-granular hand-over (k_atrous_stream), 2 = a launch per level group, 3 = as 0 with bands in block order, 4 = persistent with group hand-over (k_atrous_persist)
     int post_probe_band = -1;        // YCGE_POST_PROBE_BAND: this band and the next record a per-pass timeline (profiles/post_bands.py)
-    int post_resident_per_cu = 1;    // YCGE_POST_RESIDENT: band workgroups of the persistent in-place A-trous a CU may hold (3 fit; two to a CU measured slower than the launch form at 4K)
+    int post_resident_per_cu = 2;    // YCGE_POST_RESIDENT: band workgroups of the persistent in-place A-trous a CU may hold (3 fit)
     bool post_hash = false;          // YCGE_POST_HASH_FORM=1: the hash form of k_atrous_band even where the window fits
     int bvh_waves = 16;              // YCGE_BVH_WAVES: wavefronts of k_scene_bvh_build that take nodes (tests: the order nodes are split in must not matter)
     bool scene_bvh_host = false;     // YCGE_SCENE_BVH_HOST: ycge_scene_update_objects builds the scene BVH on the host, not on the device
@@ -136,8 +136,8 @@ struct Knobs {
         post_mode = geti("YCGE_POST_MODE", 0);
         post_hash = geti("YCGE_POST_HASH_FORM", 0) != 0;
         post_probe_band = geti("YCGE_POST_PROBE_BAND", -1);
-        post_resident_per_cu = geti("YCGE_POST_RESIDENT", 1);
-        if (post_resident_per_cu < 1 || post_resident_per_cu > 3) post_resident_per_cu = 1;
+        post_resident_per_cu = geti("YCGE_POST_RESIDENT", 2);
+        if (post_resident_per_cu < 1 || post_resident_per_cu > 3) post_resident_per_cu = 2;
         mig = geti("YCGE_MIG", 1); mig_round = geti("YCGE_MIG_ROUND", 12); mig_shade = geti("YCGE_MIG_SHADE", 16);
         if (mig_round < 1) mig_round = 1;
         exposure_serial = getenv("YCGE_EXPOSURE_SERIAL") != nullptr;
@@ -1634,6 +1634,10 @@ int run_post(ycge_ctx *c, hipStream_t stream, float *out_sdr_host, bool timed)
             const bool persist = c->knobs.post_mode != 2 && (c->knobs.post_groups <= 16 || c->knobs.post_mode == 4) && sc->window_width != 0 && (size_t)sc->rows_per_band * sc->window_width <= 2048 &&
                                  c->compute_units > 0 && ((sc->bands + 7) / 8) * 8 <= c->knobs.post_resident_per_cu * c->compute_units;
             if (persist) {
+                // Bands of one XCD adjacent (their colours meet in one L2) while every band has a CU of its own: 1080p 3.90 against 4.03 ms.
+                // Where two bands must share a CU (a 4K grid: 270 bands) block order is the better one - 14.7 against 15.9 ms, launch
+                // form 16.3: the pairs a CU gets are then far apart in the image and busy at different times.
+                const int xcd_local = c->knobs.post_mode == 3 ? 0 : c->knobs.post_mode == 0 ? (((sc->bands + 7) / 8) * 8 <= c->compute_units ? 1 : 0) : 1;
                 const uint32_t groups = (uint32_t)((sc->levels + levels_per_launch - 1) / levels_per_launch);
                 if (c->post_progress.n < (size_t)sc->bands * 32 + 8000 || c->post_epoch > 0x60000000u) {
                     HIP_TRY(c, c->post_progress.reserve((size_t)sc->bands * 32 + 8000));       // + room for the profiling timeline of two bands
@@ -1643,7 +1647,7 @@ int run_post(ycge_ctx *c, hipStream_t stream, float *out_sdr_host, bool timed)
                 }
                 e = ycge_launch_atrous_persist(w, h, step, phi, dst, c->sky.p, c->atrous_statw.p, sc->pixels.p, sc->offsets.p, sc->pass_level.p, sc->levels, sc->bands,
                                                levels_per_launch, c->knobs.post_groups, sc->rows_per_band, sc->window_width, c->post_progress.p, c->post_epoch,
-                                               c->knobs.post_mode == 3 ? 0 : 1, c->knobs.post_mode == 4 ? 0 : 1, c->knobs.post_probe_band >= 0 ? 1 : 0, stream);
+                                               xcd_local, c->knobs.post_mode == 4 ? 0 : 1, c->knobs.post_probe_band >= 0 ? 1 : 0, stream);
                 c->post_epoch += (groups > (uint32_t)sc->levels ? groups : (uint32_t)sc->levels) + 1u;
             } else
             e = ycge_launch_atrous_inplace(w, h, step, phi, dst, c->g_albedo.p, c->unit_n.p, c->g_depth.p, c->sky.p, c->atrous_statw.p,
