@@ -12,7 +12,8 @@ r.SetCamera(pose["pos"], pose["yaw"], pose["pitch"])
 for i in range(4):
     r.TryFlipAndBlit(want_sdr=True)
 print(f"post {r.stats.post_ms:.3f} ms")
-nb = 135
+import os
+nb = int(os.environ.get('NB', '135'))
 buf = np.zeros(nb * 32 + 8000, np.uint32)
 r.L.ycge_debug_read_post_progress.restype = C.c_int
 r.L.ycge_debug_read_post_progress.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t]

@@ -45,7 +45,7 @@ int ycge_launch_atrous_inplace(int w, int h, int step, const float phi[4], float
                                const float *depth, const uint8_t *sky, float *statw, const uint32_t *d_pixels, const uint32_t *d_offsets,
                                int n_levels, int n_bands, int K, int groups_per_pass, int rows_per_band, unsigned window_width, hipStream_t stream);
 int ycge_launch_atrous_persist(int w, int h, int step, const float phi[4], float *buf, const uint8_t *sky, float *statw, const uint32_t *d_pixels,
-                               const uint32_t *d_offsets, const uint32_t *d_pass_level, int n_levels, int n_bands, int K, int groups_per_pass, int rows_per_band, unsigned window_width,
+                               const uint32_t *d_offsets, const uint32_t *d_pass_level, const int32_t *d_band_desc, int n_levels, int n_bands, int K, int groups_per_pass, int rows_per_band, unsigned window_width,
                                uint32_t *progress, uint32_t epoch, int xcd_local, int level_handover, int profile, hipStream_t stream);
 size_t ycge_exposure_scratch_bytes(int w, int h, int step);
 size_t ycge_bvh_build_scratch_bytes(int n);
@@ -113,8 +113,9 @@ struct Knobs {
     int fan_class = -1, fan_cap = -1;   // -1 = default by world size
     int mig = 1, mig_round = 12, mig_shade = 16;      // YCGE_MIG (0 = off), YCGE_MIG_ROUND, YCGE_MIG_SHADE: path migration in k_trace
     int post_mode = 0;               // YCGE_POST_MODE: in-place A-trous: 0 = one persistent launch, level-granular hand-over (k_atrous_stream), 2 = a launch per level group, 3 = as 0 with bands in block order, 4 = persistent with group hand-over (k_atrous_persist)
+    bool post_no_split = false;      // YCGE_POST_NO_SPLIT: whole bands in the persistent in-place A-trous (no row-parity half-bands)
     int post_probe_band = -1;        // YCGE_POST_PROBE_BAND: this band and the next record a per-pass timeline (profiles/post_bands.py)
-    int post_resident_per_cu = 2;    // YCGE_POST_RESIDENT: band workgroups of the persistent in-place A-trous a CU may hold (3 fit)
+    int post_resident_per_cu = 3;    // YCGE_POST_RESIDENT: band workgroups of the persistent in-place A-trous a CU may hold (3 fit: 576 threads, 46 KB of LDS each)
     bool post_hash = false;          // YCGE_POST_HASH_FORM=1: the hash form of k_atrous_band even where the window fits
     int bvh_waves = 16;              // YCGE_BVH_WAVES: wavefronts of k_scene_bvh_build that take nodes (tests: the order nodes are split in must not matter)
     bool scene_bvh_host = false;     // YCGE_SCENE_BVH_HOST: ycge_scene_update_objects builds the scene BVH on the host, not on the device
@@ -135,9 +136,10 @@ struct Knobs {
         fan_class = geti("YCGE_FAN", -1); fan_cap = geti("YCGE_FAN_CAP", -1);
         post_mode = geti("YCGE_POST_MODE", 0);
         post_hash = geti("YCGE_POST_HASH_FORM", 0) != 0;
+        post_no_split = getenv("YCGE_POST_NO_SPLIT") != nullptr;
         post_probe_band = geti("YCGE_POST_PROBE_BAND", -1);
-        post_resident_per_cu = geti("YCGE_POST_RESIDENT", 2);
-        if (post_resident_per_cu < 1 || post_resident_per_cu > 3) post_resident_per_cu = 2;
+        post_resident_per_cu = geti("YCGE_POST_RESIDENT", 3);
+        if (post_resident_per_cu < 1 || post_resident_per_cu > 3) post_resident_per_cu = 3;
         mig = geti("YCGE_MIG", 1); mig_round = geti("YCGE_MIG_ROUND", 12); mig_shade = geti("YCGE_MIG_SHADE", 16);
         if (mig_round < 1) mig_round = 1;
         exposure_serial = getenv("YCGE_EXPOSURE_SERIAL") != nullptr;
@@ -221,7 +223,7 @@ struct ycge_ctx {
     DevBuf<uint32_t> post_progress;               // k_atrous_persist: groups finished per band, one 128-byte line each
     uint32_t post_epoch = 0;                      // ... counted from here in the next launch
     DevBuf<uint8_t> tone_state;                   // ToneMapper state; lives as long as the context (not reset by Resize)
-    struct InplaceSchedule { int w = 0, h = 0, step = 0, levels = 0, bands = 0, rows_per_band = 0, levels_per_launch = 0; uint32_t max_level_pixels = 0, window_width = 0; DevBuf<uint32_t> pixels, offsets, pass_level; };
+    struct InplaceSchedule { int w = 0, h = 0, step = 0, levels = 0, bands = 0, rows_per_band = 0, levels_per_launch = 0; uint32_t max_level_pixels = 0, window_width = 0; bool split = false; DevBuf<uint32_t> pixels, offsets, pass_level; DevBuf<int32_t> band_desc; };
     std::vector<InplaceSchedule *> schedules;     // level schedules of the in-place A-trous iterations, by (w, h, step)
     // what ycge_scene_update_objects needs from the last full upload
     std::vector<GMesh> gmeshes_host;
@@ -1498,14 +1500,15 @@ void build_inplace_schedule(int w, int h, int step, std::vector<uint32_t> &pixel
 // max_level_pixels = the most pixels (padding included) one level of one band holds: bounds what a launch of K levels writes.
 void band_inplace_schedule(int w, int h, int rows_per_band, const std::vector<uint32_t> &pixels, const std::vector<uint32_t> &offsets,
                            std::vector<uint32_t> &band_pixels, std::vector<uint32_t> &band_offsets, int &n_bands, uint32_t &max_level_pixels,
-                           uint32_t G = 32u /* pixels per pass */)
+                           uint32_t G = 32u /* pixels per pass */, const std::vector<int32_t> *row_band = nullptr /* band of every row; n_bands given */)
 {
     const int levels = (int)offsets.size() - 1;
-    n_bands = (h + rows_per_band - 1) / rows_per_band;
+    if (!row_band) n_bands = (h + rows_per_band - 1) / rows_per_band;
+    auto band_of = [&](uint32_t p) -> size_t { const uint32_t y = p / (uint32_t)w; return row_band ? (size_t)(*row_band)[y] : (size_t)(y / (uint32_t)rows_per_band); };
     band_offsets.assign((size_t)n_bands * (levels + 1), 0);
     std::vector<uint32_t> count((size_t)n_bands * levels, 0);
     for (int t = 0; t < levels; t++)
-        for (uint32_t i = offsets[t]; i < offsets[t + 1]; i++) count[(size_t)((pixels[i] / (uint32_t)w) / rows_per_band) * levels + t]++;
+        for (uint32_t i = offsets[t]; i < offsets[t + 1]; i++) count[band_of(pixels[i]) * levels + t]++;
     uint32_t run = 0;       // in passes
     max_level_pixels = 0;
     for (int b = 0; b < n_bands; b++) {
@@ -1523,21 +1526,74 @@ void band_inplace_schedule(int w, int h, int rows_per_band, const std::vector<ui
     for (int t = 0; t < levels; t++)
         for (uint32_t i = offsets[t]; i < offsets[t + 1]; i++) {
             const uint32_t p = pixels[i];
-            band_pixels[cursor[(size_t)((p / (uint32_t)w) / rows_per_band) * levels + t]++] = (p % (uint32_t)w) | ((p / (uint32_t)w) << 16);      // x | y << 16
+            band_pixels[cursor[band_of(p) * levels + t]++] = (p % (uint32_t)w) | ((p / (uint32_t)w) << 16);      // x | y << 16
         }
+}
+
+// Bands for the persistent form at step 2, split by ROW PARITY.  A tap is 0, +-2 or +-4 rows away: rows of one parity only ever
+// read rows of the same parity - except where the clamp at the image's top and bottom folds a tap onto row 0 or row h - 1.  So the
+// first and the last four rows stay together (a band of 4 rows each), and the rows between them fall apart into two INDEPENDENT
+// chains of half-bands (4 even rows, 4 odd rows of an 8-row stretch).  Every band then has 8 pixels a level, half a workgroup's
+// wavefronts: the other half fetches the next pass meanwhile (k_atrous_stream's two sets).  desc = 8 ints a band: first row, rows, row stride, pixel groups a pass uses, the (at most two)
+// bands it waits for and the (at most two) bands that wait for it (-1: none), derived from the clamped stencil itself.
+// Band order: the first four rows, the even chain, the odd chain, the last four rows - neighbours in a chain are neighbours in
+// the order.  Returns false where the layout does not apply (a grid below 24 rows).
+bool split_band_layout(int h, int step, std::vector<int32_t> &row_band, std::vector<int32_t> &desc, int &n_bands)
+{
+    const int R = 8, edge = 2 * step;          // rows 0 .. 3 and h - 4 .. h - 1: where the clamp folds taps onto another parity
+    if (step != 2 || h < 3 * R) return false;
+    const int chunks = (h - 2 * edge + R - 1) / R;
+    n_bands = 2 + 2 * chunks;
+    row_band.assign(h, 0);
+    desc.assign((size_t)n_bands * 8, -1);
+    auto set = [&](int b, int y0, int rows, int stride, int groups) { desc[8 * b] = y0; desc[8 * b + 1] = rows; desc[8 * b + 2] = stride; desc[8 * b + 3] = groups; };
+    set(0, 0, edge, 1, 8);
+    for (int y = 0; y < edge; y++) row_band[y] = 0;
+    for (int k = 0; k < chunks; k++)
+        for (int par = 0; par < 2; par++) {
+            const int b = 1 + par * chunks + k, y_first = edge + R * k + par;
+            int rows = 0;
+            for (int y = y_first; y < h - edge && y < edge + R * (k + 1); y += 2) { row_band[y] = b; rows++; }
+            set(b, y_first, rows, 2, 8);
+        }
+    const int last = n_bands - 1;
+    set(last, h - edge, edge, 1, 8);
+    for (int y = h - edge; y < h; y++) row_band[y] = last;
+    // who waits for whom: band A needs band B's progress iff a pixel of A reads a row of B that lies above it (same row: same band)
+    for (int y = 0; y < h; y++)
+        for (int k = 1; k <= 2; k++) {
+            int sy = y - k * step; if (sy < 0) sy = 0;
+            const int a = row_band[y], b = row_band[sy];
+            if (a == b) continue;
+            int *up = &desc[8 * a + 4], *dn = &desc[8 * b + 6];
+            if (up[0] != b && up[1] != b) { if (up[0] < 0) up[0] = b; else if (up[1] < 0) up[1] = b; else return false; }
+            if (dn[0] != a && dn[1] != a) { if (dn[0] < 0) dn[0] = a; else if (dn[1] < 0) dn[1] = a; else return false; }
+        }
+    // ... and nothing may read DOWN into a row of another chain either (it would be an unordered read of a value in flux)
+    for (int y = 0; y < h; y++)
+        for (int k = 1; k <= 2; k++) {
+            int sy = y + k * step; if (sy >= h) sy = h - 1;
+            const int a = row_band[y], b = row_band[sy];
+            if (a == b) continue;
+            const int *dn = &desc[8 * a + 6];
+            if (dn[0] != b && dn[1] != b) return false;         // a lower row read as OLD must belong to a band that waits for this one
+        }
+    return true;
 }
 
 // The narrowest power-of-two window width WX (64 ..) for which no two pixels that ONE launch of k_atrous_band writes - the levels
 // [K g, K g + K) of one band - share the entry (row in the band) * WX + (x mod WX), with rows * WX <= capacity; 0 if there is none.
 uint32_t band_window_width(const std::vector<uint32_t> &band_pixels, const std::vector<uint32_t> &band_offsets, int n_bands, int levels, int K,
-                           int rows_per_band, uint32_t G, uint32_t capacity)
+                           int rows_per_band, uint32_t G, uint32_t capacity, const std::vector<int32_t> *desc = nullptr /* split layout: 8 ints a band */)
 {
     std::vector<uint32_t> seen;
-    for (uint32_t wx = 64; (size_t)wx * rows_per_band <= capacity; wx *= 2) {
-        seen.assign((size_t)wx * rows_per_band, 0u);
+    const int max_rows = desc ? 8 : rows_per_band;
+    for (uint32_t wx = 64; (size_t)wx * max_rows <= capacity; wx *= 2) {
+        seen.assign((size_t)wx * max_rows, 0u);
         uint32_t stamp = 0;
         bool ok = true;
-        for (int b = 0; b < n_bands && ok; b++)
+        for (int b = 0; b < n_bands && ok; b++) {
+            const uint32_t y0 = desc ? (uint32_t)(*desc)[8 * b] : (uint32_t)b * rows_per_band, stride = desc ? (uint32_t)(*desc)[8 * b + 2] : 1u;
             for (int t0 = 0; t0 < levels && ok; t0 += K) {
                 stamp++;
                 const int t1 = t0 + K < levels ? t0 + K : levels;
@@ -1546,11 +1602,12 @@ uint32_t band_window_width(const std::vector<uint32_t> &band_pixels, const std::
                     const uint32_t e = band_pixels[i];
                     if (e == 0xffffffffu) continue;
                     const uint32_t x = e & 0xffffu, y = e >> 16;
-                    const size_t slot = (size_t)(y - (uint32_t)b * rows_per_band) * wx + (x & (wx - 1u));
+                    const size_t slot = (size_t)((y - y0) / stride) * wx + (x & (wx - 1u));
                     if (seen[slot] == stamp) { ok = false; break; }
                     seen[slot] = stamp;
                 }
             }
+        }
         if (ok) return wx;
     }
     return 0u;
@@ -1604,6 +1661,29 @@ int run_post(ycge_ctx *c, hipStream_t stream, float *out_sdr_host, bool timed)
                 // bands of whole rows; related pixels are at most 2 * step rows apart, so they share a band or sit in adjacent ones
                 const int band_rows = c->knobs.post_band_rows;
                 const int rows_per_band = 2 * step > band_rows ? 2 * step : band_rows;
+                // the persistent form at step 2: bands split by row parity (split_band_layout) where every band then still finds a place
+                std::vector<int32_t> row_band, desc;
+                int split_bands = 0;
+                if ((c->knobs.post_mode == 0 || c->knobs.post_mode == 3) && !c->knobs.post_no_split && !c->knobs.post_hash && c->knobs.post_groups == 16 && rows_per_band == 8 &&
+                    split_band_layout(h, step, row_band, desc, split_bands) && c->compute_units > 0 &&
+                    ((split_bands + 7) / 8) * 8 <= c->knobs.post_resident_per_cu * c->compute_units) {
+                    sc->split = true;
+                    sc->bands = split_bands;
+                    band_inplace_schedule(w, h, rows_per_band, px, off, bpx, boff, sc->bands, sc->max_level_pixels, (uint32_t)c->knobs.post_groups, &row_band);
+                    // a half-band's level must fit the 8 pixel groups its workgroup keeps (one pass, the upper 8 entries padding)
+                    const int levels_n = (int)off.size() - 1;
+                    for (int b2 = 0; b2 < sc->bands && sc->split; b2++) {
+                        const uint32_t gmax = (uint32_t)desc[8 * b2 + 3];
+                        for (int t = 0; t < levels_n && sc->split; t++) {
+                            const uint32_t p0 = boff[(size_t)b2 * (levels_n + 1) + t], p1 = boff[(size_t)b2 * (levels_n + 1) + t + 1];
+                            if (p1 - p0 > 1 && gmax < 16u) sc->split = false;
+                            for (uint32_t ps = p0; ps < p1 && sc->split; ps++)
+                                for (uint32_t g2 = gmax; g2 < 16u; g2++) if (bpx[(size_t)ps * 16 + g2] != 0xffffffffu) sc->split = false;
+                        }
+                    }
+                    if (sc->split) HIP_TRY(c, sc->band_desc.upload(desc));
+                }
+                if (!sc->split)
                 band_inplace_schedule(w, h, rows_per_band, px, off, bpx, boff, sc->bands, sc->max_level_pixels, (uint32_t)c->knobs.post_groups);
                 sc->levels = (int)off.size() - 1;
                 sc->rows_per_band = rows_per_band;
@@ -1612,7 +1692,7 @@ int run_post(ycge_ctx *c, hipStream_t stream, float *out_sdr_host, bool timed)
                 const int k_cap = (int)(1536u / (sc->max_level_pixels > 0 ? sc->max_level_pixels : 32u));
                 if (sc->levels_per_launch > k_cap) sc->levels_per_launch = k_cap;
                 sc->window_width = sc->levels_per_launch >= 1 && !c->knobs.post_hash
-                                       ? band_window_width(bpx, boff, sc->bands, sc->levels, sc->levels_per_launch, rows_per_band, (uint32_t)c->knobs.post_groups, 2048u) : 0u;
+                                       ? band_window_width(bpx, boff, sc->bands, sc->levels, sc->levels_per_launch, rows_per_band, (uint32_t)c->knobs.post_groups, 2048u, sc->split ? &desc : nullptr) : 0u;
                 c->schedules.push_back(sc);
                 HIP_TRY(c, sc->pixels.upload(bpx)); HIP_TRY(c, sc->offsets.upload(boff));
                 std::vector<uint32_t> plevel(bpx.size() / (size_t)c->knobs.post_groups + 1, 0u);       // level of every pass (k_atrous_stream)
@@ -1621,6 +1701,7 @@ int run_post(ycge_ctx *c, hipStream_t stream, float *out_sdr_host, bool timed)
                         for (uint32_t ps = boff[(size_t)b * (sc->levels + 1) + t]; ps < boff[(size_t)b * (sc->levels + 1) + t + 1]; ps++) plevel[ps] = (uint32_t)t;
                 HIP_TRY(c, sc->pass_level.upload(plevel));
             }
+            if (sc->split && sc->window_width == 0) return c->fail(YCGE_ERR_DEVICE, "in-place A-trous: the split band layout found no collision-free window (set YCGE_POST_NO_SPLIT=1)");
             const int levels_per_launch = sc->levels_per_launch;
             if (levels_per_launch < 1) return c->fail(YCGE_ERR_UNSUPPORTED, "in-place A-trous: a level of %u pixels in one band", sc->max_level_pixels);
             if (!c->atrous_statw.p) HIP_TRY(c, c->atrous_statw.alloc(n * 75));
@@ -1631,8 +1712,8 @@ int run_post(ycge_ctx *c, hipStream_t stream, float *out_sdr_host, bool timed)
             }
             // one persistent launch when the window form applies and every band's workgroup is resident at once (it waits for its
             // neighbour inside the kernel); else a launch per level group
-            const bool persist = c->knobs.post_mode != 2 && (c->knobs.post_groups <= 16 || c->knobs.post_mode == 4) && sc->window_width != 0 && (size_t)sc->rows_per_band * sc->window_width <= 2048 &&
-                                 c->compute_units > 0 && ((sc->bands + 7) / 8) * 8 <= c->knobs.post_resident_per_cu * c->compute_units;
+            const bool persist = sc->split || (c->knobs.post_mode != 2 && (c->knobs.post_groups <= 16 || c->knobs.post_mode == 4) && sc->window_width != 0 && (size_t)sc->rows_per_band * sc->window_width <= 2048 &&
+                                 c->compute_units > 0 && ((sc->bands + 7) / 8) * 8 <= c->knobs.post_resident_per_cu * c->compute_units);
             if (persist) {
                 // Bands of one XCD adjacent (their colours meet in one L2) while every band has a CU of its own: 1080p 3.90 against 4.03 ms.
                 // Where two bands must share a CU (a 4K grid: 270 bands) block order is the better one - 14.7 against 15.9 ms, launch
@@ -1645,7 +1726,7 @@ int run_post(ycge_ctx *c, hipStream_t stream, float *out_sdr_host, bool timed)
                     if (c->knobs.post_probe_band >= 0) { const uint32_t v = (uint32_t)c->knobs.post_probe_band + 1u; HIP_TRY(c, hipMemcpyAsync(c->post_progress.p + (size_t)sc->bands * 32 + 7999, &v, 4, hipMemcpyHostToDevice, stream)); HIP_TRY(c, hipStreamSynchronize(stream)); }
                     c->post_epoch = 0;
                 }
-                e = ycge_launch_atrous_persist(w, h, step, phi, dst, c->sky.p, c->atrous_statw.p, sc->pixels.p, sc->offsets.p, sc->pass_level.p, sc->levels, sc->bands,
+                e = ycge_launch_atrous_persist(w, h, step, phi, dst, c->sky.p, c->atrous_statw.p, sc->pixels.p, sc->offsets.p, sc->pass_level.p, sc->split ? sc->band_desc.p : nullptr, sc->levels, sc->bands,
                                                levels_per_launch, c->knobs.post_groups, sc->rows_per_band, sc->window_width, c->post_progress.p, c->post_epoch,
                                                xcd_local, c->knobs.post_mode == 4 ? 0 : 1, c->knobs.post_probe_band >= 0 ? 1 : 0, stream);
                 c->post_epoch += (groups > (uint32_t)sc->levels ? groups : (uint32_t)sc->levels) + 1u;

@@ -196,7 +196,7 @@ template <int G> struct PostSharedT {
     uint32_t out_slot[2][G];    // k_atrous_stream: the entry each group wrote in the last two passes (YCGE_POST_NONE: none), for the publishing wavefront
 };
 static_assert(YCGE_POST_WIN == YCGE_POST_HASH, "one LDS array serves both forms");
-struct BandWindow { int y0, rows; uint32_t wx, use; };     // use == 0: hash form
+struct BandWindow { int y0, rows; uint32_t wx, use; int shift; };     // use == 0: hash form; shift 1: the band's rows are y0, y0 + 2, .. (k_atrous_stream's half-bands)
 __device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
 __device__ __forceinline__ uint32_t post_hash(uint32_t p) { return (p * 2654435761u) >> (32 - 11); }
 struct PassData {           // what one lane needs for one pass, fetched ahead
@@ -225,9 +225,9 @@ __device__ __forceinline__ PassData pass_fetch(const AtrousParams &A, const Band
         sx = x + (t % 5 - 2) * A.step; if (sx < 0) sx = 0; else if (sx >= A.w) sx = A.w - 1;
     }
     D.j = (uint32_t)sx + (uint32_t)sy * (uint32_t)A.w;
-    const int rj = sy - W.y0, rp = y - W.y0;
-    D.jslot = (rj >= 0 && rj < W.rows) ? (uint32_t)rj * W.wx + ((uint32_t)sx & (W.wx - 1u)) : YCGE_POST_NONE;
-    D.pslot = ((uint32_t)rp * W.wx + ((uint32_t)x & (W.wx - 1u))) & (YCGE_POST_WIN - 1u);
+    const int rj = sy - W.y0, rp = y - W.y0;             // (a half-band's taps stay on its own row parity, or leave its rows upwards / downwards)
+    D.jslot = (rj >= 0 && (rj >> W.shift) < W.rows) ? (uint32_t)(rj >> W.shift) * W.wx + ((uint32_t)sx & (W.wx - 1u)) : YCGE_POST_NONE;
+    D.pslot = ((uint32_t)(rp >> W.shift) * W.wx + ((uint32_t)x & (W.wx - 1u))) & (YCGE_POST_WIN - 1u);
     // 32-bit byte offsets against the (scalar) array bases: one address register per load instead of 64-bit arithmetic per lane
     // (the host keeps the in-place form to grids whose weight table stays below 4 GB: 14.3 M pixels)
     const float *c0p = (const float *)((const char *)buf + 12u * pp), *cjp = (const float *)((const char *)buf + 12u * D.j);
@@ -240,7 +240,7 @@ __device__ __forceinline__ PassData pass_fetch(const AtrousParams &A, const Band
     return D;
 }
 template <bool WIN, class SH>
-__device__ __forceinline__ void pass_compute(const AtrousParams &A, uint32_t p, const PassData &D, SH &sh, uint32_t *out_slot = nullptr)
+__device__ __forceinline__ void pass_compute(const AtrousParams &A, uint32_t p, const PassData &D, SH &sh, uint32_t *out_entry = nullptr /* this group's */)
 {
     const int g = threadIdx.x >> 5, t = threadIdx.x & 31;
     const int kx = t % 5 - 2, ky = t / 5 - 2;
@@ -291,7 +291,7 @@ __device__ __forceinline__ void pass_compute(const AtrousParams &A, uint32_t p, 
             const float inv = 1.0f / wsum;
             (&sh.ent[D.pslot].x)[(t + 1) & 3] = t < 3 ? __float_as_uint(acc * inv) : D.p;
         }
-        if (out_slot && t == 3) out_slot[threadIdx.x >> 5] = changed ? D.pslot : YCGE_POST_NONE;      // k_atrous_stream: for the publishing wavefront
+        if (out_entry && t == 3) *out_entry = changed ? D.pslot : YCGE_POST_NONE;      // k_atrous_stream: for the publishing wavefront
     } else {
         const float wsum = __shfl(acc, (threadIdx.x & 32) + 3, 64);
         uint32_t h = 0;
@@ -327,7 +327,7 @@ __global__ __launch_bounds__(32 * G) void k_atrous_band(const AtrousParams A, fl
     const uint32_t pass_lo = o[t0], pass_hi = o[t1];
     if (pass_lo >= pass_hi) return;
     const int grp = threadIdx.x >> 5, t = threadIdx.x & 31;
-    const BandWindow W = {b * rows_per_band, rows_per_band, WIN ? wx : 1u, WIN ? 1u : 0u};
+    const BandWindow W = {b * rows_per_band, rows_per_band, WIN ? wx : 1u, WIN ? 1u : 0u, 0};
     const uint32_t n_ent = WIN ? (uint32_t)rows_per_band * wx : (uint32_t)YCGE_POST_HASH;
     for (uint32_t e = threadIdx.x; e < n_ent; e += 32 * G) sh.ent[e].x = YCGE_POST_NONE;
     uint32_t p1 = pixels[(size_t)pass_lo * G + grp];
@@ -373,7 +373,7 @@ __global__ __launch_bounds__(32 * G) void k_atrous_persist(const AtrousParams A,
     const int groups = (levels + K - 1) / K;
     const uint32_t *o = off + (size_t)b * (levels + 1);
     const int grp = threadIdx.x >> 5, t = threadIdx.x & 31;
-    const BandWindow W = {b * rows_per_band, rows_per_band, wx, 1u};
+    const BandWindow W = {b * rows_per_band, rows_per_band, wx, 1u, 0};
     const uint32_t n_ent = (uint32_t)rows_per_band * wx;
     for (int g = 0; g < groups; g++) {
         const int t0 = g * K, t1 = t0 + K < levels ? t0 + K : levels;
@@ -415,11 +415,11 @@ __global__ __launch_bounds__(32 * G) void k_atrous_persist(const AtrousParams A,
 // A band fetches the taps of level T (one pass ahead of computing them) once the band above has published >= T; it reads that
 // word one pass ahead as well, so in the steady state nothing waits.  Only the taps ABOVE the band are read device-coherently:
 // what the band rewrote itself comes from the window, everything else it reads is old and right in any cache.
-template <int G, bool PROF>
+template <int G, bool PROF, bool DUO = false>
 __global__ __launch_bounds__(32 * G + 64) void k_atrous_stream(const AtrousParams A, float *__restrict__ buf, const float *__restrict__ statw,
                                                                const uint8_t *__restrict__ sky, const uint32_t *__restrict__ pixels,
-                                                               const uint32_t *__restrict__ off, const uint32_t *__restrict__ pass_level, int levels,
-                                                               int n_bands, int rows_per_band, uint32_t wx, uint32_t *__restrict__ progress, uint32_t epoch,
+                                                               const uint32_t *__restrict__ off, const uint32_t *__restrict__ pass_level,
+                                                               const int32_t *__restrict__ band_desc, int levels, int n_bands, int rows_per_band, uint32_t wx, uint32_t *__restrict__ progress, uint32_t epoch,
                                                                int xcd_local)
 {
     __shared__ __attribute__((aligned(16))) PostSharedT<G> sh;
@@ -429,10 +429,24 @@ __global__ __launch_bounds__(32 * G + 64) void k_atrous_stream(const AtrousParam
     const uint32_t *o = off + (size_t)b * (levels + 1);
     const bool publisher = threadIdx.x >= 32 * G;               // the last wavefront
     const int grp = threadIdx.x >> 5, t = threadIdx.x & 31;
-    const BandWindow W = {b * rows_per_band, rows_per_band, wx, 1u};
-    const uint32_t n_ent = (uint32_t)rows_per_band * wx;
+    // the band: rows y0, y0 + stride, .. (rows of them), how many 32-lane groups its passes use, whom it waits for, who waits for it
+    // (band_desc: the row-parity split of the host's split_band_layout; without it whole bands of rows_per_band rows in a chain)
+    int y0 = b * rows_per_band, rows = rows_per_band, stride = 1, groups = G, up0 = b > 0 ? b - 1 : -1, up1 = -1, dn0 = b + 1 < n_bands ? b + 1 : -1, dn1 = -1;
+    if (band_desc) {
+        const int4 d0 = ((const int4 *)band_desc)[2 * b], d1 = ((const int4 *)band_desc)[2 * b + 1];
+        y0 = d0.x; rows = d0.y; stride = d0.z; groups = d0.w; up0 = d1.x; up1 = d1.y; dn0 = d1.z; dn1 = d1.w;
+    }
+    const BandWindow W = {y0, rows, wx, 1u, stride == 2 ? 1 : 0};
+    const uint32_t n_ent = (uint32_t)rows * wx;
     uint32_t *mine = progress + (size_t)b * 32;
-    const uint32_t *above = progress + (size_t)(b > 0 ? b - 1 : 0) * 32;
+    const bool has_up = up0 >= 0;
+    const uint32_t *above = progress + (size_t)(has_up ? up0 : 0) * 32, *above2 = progress + (size_t)(up1 >= 0 ? up1 : has_up ? up0 : 0) * 32;
+    // how far the band(s) above are, as seen by one (device-coherent) look: the smaller of the two words
+    auto look_up = [&]() -> int {
+        const int s0 = (int32_t)(__hip_atomic_load(above, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - epoch);
+        const int s1 = (int32_t)(__hip_atomic_load(above2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - epoch);
+        return s0 < s1 ? s0 : s1;
+    };
     const uint32_t first = o[0], end = o[levels];
     if (first >= end) {         // a band without pixels: everything "done" (and an XCC id nobody shares: its neighbour writes through)
         if (threadIdx.x == 0) {
@@ -450,19 +464,22 @@ __global__ __launch_bounds__(32 * G + 64) void k_atrous_stream(const AtrousParam
     // A band of sky pixels only (the upper half of an outdoor frame) changes nothing: it says so at once, and the band below never
     // waits for it - otherwise its 12 levels of head start, 0.5 us each, stand in front of every band under it
     {
-        const int y0 = b * rows_per_band, y1 = y0 + rows_per_band < A.h ? y0 + rows_per_band : A.h;
-        const uint32_t *row32 = (const uint32_t *)(sky + (size_t)y0 * A.w);            // (whole words where the band's bytes allow, bytes for the rest)
-        const size_t n_bytes = (size_t)(y1 - y0) * A.w, head = (4 - ((uintptr_t)row32 & 3)) & 3;
         int shaded = 0;
-        const uint8_t *bytes = sky + (size_t)y0 * A.w;
-        const size_t n_words = n_bytes > head ? (n_bytes - head) / 4 : 0;
-        for (size_t i = threadIdx.x; i < n_words; i += 32 * G + 64) shaded |= ((const uint32_t *)(bytes + head))[i] != 0x01010101u;
-        for (size_t i = threadIdx.x; i < n_bytes; i += 32 * G + 64) if (i < head || i >= head + 4 * n_words) shaded |= bytes[i] != 1;
+        for (int k = 0; k < rows; k++) {
+            const int y = y0 + k * stride;
+            if (y >= A.h) break;
+            const uint8_t *bytes = sky + (size_t)y * A.w;               // (whole words where the row's bytes allow, bytes for the rest)
+            const size_t head = (4 - ((uintptr_t)bytes & 3)) & 3, n_words = (size_t)A.w > head ? ((size_t)A.w - head) / 4 : 0;
+            for (size_t i = threadIdx.x; i < n_words; i += 32 * G + 64) shaded |= ((const uint32_t *)(bytes + head))[i] != 0x01010101u;
+            for (size_t i = threadIdx.x; i < (size_t)A.w; i += 32 * G + 64) if (i < head || i >= head + 4 * n_words) shaded |= bytes[i] != 1;
+        }
         if (!__syncthreads_or(shaded)) {
             if (threadIdx.x == 0) __hip_atomic_store(mine, epoch + (uint32_t)levels, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             return;
         }
     }
+    if (threadIdx.x < 2 * G) (&sh.out_slot[0][0])[threadIdx.x] = YCGE_POST_NONE;
+    if (!DUO && !publisher && grp >= groups) return;        // (a band whose passes use fewer groups than the workgroup has: the others leave before the first barrier)
     for (uint32_t e = threadIdx.x; e < n_ent; e += 32 * G + 64) sh.ent[e].x = YCGE_POST_NONE;
     if (publisher) {
         const int lane = (int)threadIdx.x - 32 * G;
@@ -470,11 +487,13 @@ __global__ __launch_bounds__(32 * G + 64) void k_atrous_stream(const AtrousParam
         // Does the band below run on this XCD?  Then its device-coherent loads find these colours in the L2 both share, and a plain
         // store (acknowledged by that L2 in 0.18 us, the line stays there) is enough; across XCDs the store must be written through
         // (0.38 us, and the reader's load goes to memory: ~1.5 us).  Measured, not assumed: every band announces its XCC id.
-        bool same_xcd = false;
-        if (b + 1 < n_bands) {
+        bool same_xcd = dn0 >= 0;
+        for (int k = 0; k < 2; k++) {
+            const int dn = k == 0 ? dn0 : dn1;
+            if (dn < 0) continue;
             uint32_t v;
-            do v = __hip_atomic_load(progress + (size_t)(b + 1) * 32 + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - epoch; while (v == 0u || v > 16u);
-            same_xcd = v - 1u == my_xcc;
+            do v = __hip_atomic_load(progress + (size_t)dn * 32 + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - epoch; while (v == 0u || v > 16u);
+            same_xcd = same_xcd && v - 1u == my_xcc;
         }
         lds_barrier();          // table cleared
         // One pass of slack for the acknowledgement: the colours of pass i are sent after barrier i, and "pass i - 1 complete" is
@@ -513,11 +532,48 @@ __global__ __launch_bounds__(32 * G + 64) void k_atrous_stream(const AtrousParam
         }
         return;
     }
+    if (DUO) {
+        // Every band of the split layout has 8 pixels a level: the 16 groups are TWO sets of 8 that take turns - while one set computes
+        // pass i the other issues everything pass i + 1 reads (index arithmetic, the loads), and at the pass's barrier the roles swap.
+        // A pass is one wavefront's instruction stream from the first look-up to the barrier (1.6 us with 4 wavefronts as with 8):
+        // the ~100 instructions of the fetch now run on the SIMD's other wavefront instead of in front of the chain.
+        const int set = grp >> 3, gl = grp & 7;
+        auto entry = [&](uint32_t i) -> uint32_t { return i < end ? pixels[(size_t)i * G + gl] : YCGE_POST_NONE; };
+        auto level_of = [&](uint32_t i) -> int { return i < end ? (int)pass_level[i] : levels; };
+        auto sky_of = [&](uint32_t e) -> int { return e == YCGE_POST_NONE ? 1 : (int)sky[(size_t)(e & 0xffffu) + (size_t)(e >> 16) * (size_t)A.w]; };
+        int up_seen = has_up ? 0 : 0x7fffffff;
+        auto wait_above = [&](int need) {
+            while (up_seen < need) { up_seen = look_up(); if (up_seen < need) __builtin_amdgcn_s_sleep(1); }
+            asm volatile("" ::: "memory");
+        };
+        // this set computes the passes first + set, first + set + 2, ..: (pcur, scur, lcur) describe the next of them, (pnxt, lnxt) the one after
+        uint32_t pcur = entry(first + set), pnxt = entry(first + set + 2);
+        int lcur = level_of(first + set), lnxt = level_of(first + set + 2);
+        int scur = set == 0 ? -1 : sky_of(pcur);
+        PassData D;
+        D.sky0 = 1;
+        if (set == 0) { wait_above(lcur); D = pass_fetch<true>(A, W, buf, statw, sky, pcur, t, scur); }
+        lds_barrier();              // table cleared
+        for (uint32_t i = first; i < end; i++) {
+            if (((i - first) & 1u) == (uint32_t)set) {
+                const uint32_t p_new = entry(i + 4);
+                const int l_new = level_of(i + 4), s_new = sky_of(pnxt);
+                const int up_word = has_up ? look_up() : 0;             // in flight while this pass computes; read before the next fetch
+                pass_compute<true>(A, pcur, D, sh, &sh.out_slot[set][gl]);       // ends with the workgroup's barrier
+                if (has_up && up_word > up_seen) up_seen = up_word;
+                pcur = pnxt; scur = s_new; lcur = lnxt; pnxt = p_new; lnxt = l_new;
+            } else {
+                if (i + 1 < end) { wait_above(lcur); D = pass_fetch<true>(A, W, buf, statw, sky, pcur, t, scur); }
+                lds_barrier();
+            }
+        }
+        return;
+    }
     // pixel list entry and level of the passes i, i + 1, i + 2 travel in registers (fetched two passes ahead)
     int lvl1 = (int)pass_level[first];
     int lvl2 = first + 1 < end ? (int)pass_level[first + 1] : levels;
-    int up_seen = b > 0 ? 0 : 0x7fffffff;                           // levels the band above has completed, as far as this wavefront knows
-    while (up_seen < lvl1) { up_seen = (int32_t)(__hip_atomic_load(above, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - epoch); if (up_seen < lvl1) __builtin_amdgcn_s_sleep(1); }
+    int up_seen = has_up ? 0 : 0x7fffffff;                          // levels the band(s) above have completed, as far as this wavefront knows
+    while (up_seen < lvl1) { up_seen = look_up(); if (up_seen < lvl1) __builtin_amdgcn_s_sleep(1); }
     asm volatile("" ::: "memory");
     // list entries run three passes ahead, the sky flag of an entry two: a pass of sky pixels (the upper half of an outdoor frame)
     // then fetches nothing and computes nothing - list entry, flag, barrier
@@ -526,7 +582,7 @@ __global__ __launch_bounds__(32 * G + 64) void k_atrous_stream(const AtrousParam
     uint32_t p1 = entry(first), p2 = entry(first + 1), p3 = entry(first + 2);
     int s2 = sky_of(p2);
     PassData D1 = pass_fetch<true>(A, W, buf, statw, sky, p1, t);
-    uint32_t up_word_old = epoch;   // the word read in the pass before: a device-coherent load of a line its owner keeps rewriting takes longer than a pass
+    int up_word_old = 0;           // the word read in the pass before: a device-coherent load of a line its owner keeps rewriting takes longer than a pass
     lds_barrier();              // table cleared
     uint32_t i = first;
     // one pass: compute Dc (pass i) while Dn (pass i + 1) is fetched.  The loop below runs it twice per iteration with the two
@@ -536,12 +592,12 @@ __global__ __launch_bounds__(32 * G + 64) void k_atrous_stream(const AtrousParam
         const int s3 = sky_of(p3);
         const int lvl3 = i + 2 < end ? (int)pass_level[i + 2] : levels;
         // the word of the band above, for the NEXT pass's decision (in flight while this pass computes)
-        const uint32_t up_word = b > 0 ? __hip_atomic_load(above, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0u;
+        const int up_word = has_up ? look_up() : 0;
         uint32_t spins = 0;
         if (i + 1 < end) {
             while (up_seen < lvl2) {            // rare in the steady state: the band above is not far enough yet
                 if (PROF) spins++;
-                up_seen = (int32_t)(__hip_atomic_load(above, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - epoch);
+                up_seen = look_up();
                 if (up_seen < lvl2) __builtin_amdgcn_s_sleep(1);
             }
             if (PROF && threadIdx.x == 0 && lvl2 == YCGE_POST_PROBE_LEVEL) ((unsigned long long *)(mine + 12))[0] = __builtin_amdgcn_s_memrealtime();
@@ -554,8 +610,8 @@ __global__ __launch_bounds__(32 * G + 64) void k_atrous_stream(const AtrousParam
             const unsigned long long now = __builtin_amdgcn_s_memrealtime();
             tl[0] = (uint32_t)now; tl[1] = (uint32_t)(now >> 32); tl[2] = spins; tl[3] = (uint32_t)lvl1;
         }
-        pass_compute<true>(A, p1, Dc, sh, sh.out_slot[(i - first) & 1u]);     // ends with the workgroup's barrier
-        if (b > 0) { const int s = (int32_t)(up_word_old - epoch); if (s > up_seen) up_seen = s; up_word_old = up_word; }
+        pass_compute<true>(A, p1, Dc, sh, &sh.out_slot[(i - first) & 1u][grp]);     // ends with the workgroup's barrier
+        if (has_up) { if (up_word_old > up_seen) up_seen = up_word_old; up_word_old = up_word; }
         p1 = p2; p2 = p3; p3 = p4; s2 = s3; lvl1 = lvl2; lvl2 = lvl3;
         i++;
     };
@@ -1051,16 +1107,17 @@ int ycge_launch_atrous_inplace(int w, int h, int step, const float phi[4], float
 // the same iteration as ONE persistent launch (k_atrous_persist).  progress: n_bands x 32 words, zero before the first use; epoch: a
 // value that grows by more than the group count from call to call (the host's running sum)
 int ycge_launch_atrous_persist(int w, int h, int step, const float phi[4], float *buf, const uint8_t *sky, float *statw, const uint32_t *d_pixels,
-                               const uint32_t *d_offsets, const uint32_t *d_pass_level, int n_levels, int n_bands, int K, int groups_per_pass, int rows_per_band, unsigned window_width,
+                               const uint32_t *d_offsets, const uint32_t *d_pass_level, const int32_t *d_band_desc, int n_levels, int n_bands, int K, int groups_per_pass, int rows_per_band, unsigned window_width,
                                uint32_t *progress, uint32_t epoch, int xcd_local, int level_handover, int profile, hipStream_t stream)
 {
     ycge::AtrousParams A = {w, h, step, phi[0], phi[1], phi[2], phi[3]};
     const int per_xcd = (n_bands + 7) / 8;
     const dim3 grid((unsigned)(xcd_local ? 8 * per_xcd : n_bands));
     if (level_handover) {       // 8 or 16 pixels a pass: the publishing wavefront is the workgroup's 5th or 9th
-        if (groups_per_pass == 8) hipLaunchKernelGGL((ycge::k_atrous_stream<8, false>), grid, dim3(256 + 64), 0, stream, A, buf, statw, sky, d_pixels, d_offsets, d_pass_level, n_levels, n_bands, rows_per_band, window_width, progress, epoch, xcd_local);
-        else if (groups_per_pass == 16 && !profile) hipLaunchKernelGGL((ycge::k_atrous_stream<16, false>), grid, dim3(512 + 64), 0, stream, A, buf, statw, sky, d_pixels, d_offsets, d_pass_level, n_levels, n_bands, rows_per_band, window_width, progress, epoch, xcd_local);
-        else if (groups_per_pass == 16) hipLaunchKernelGGL((ycge::k_atrous_stream<16, true>), grid, dim3(512 + 64), 0, stream, A, buf, statw, sky, d_pixels, d_offsets, d_pass_level, n_levels, n_bands, rows_per_band, window_width, progress, epoch, xcd_local);
+        if (groups_per_pass == 8) hipLaunchKernelGGL((ycge::k_atrous_stream<8, false>), grid, dim3(256 + 64), 0, stream, A, buf, statw, sky, d_pixels, d_offsets, d_pass_level, d_band_desc, n_levels, n_bands, rows_per_band, window_width, progress, epoch, xcd_local);
+        else if (groups_per_pass == 16 && d_band_desc && !profile) hipLaunchKernelGGL((ycge::k_atrous_stream<16, false, true>), grid, dim3(512 + 64), 0, stream, A, buf, statw, sky, d_pixels, d_offsets, d_pass_level, d_band_desc, n_levels, n_bands, rows_per_band, window_width, progress, epoch, xcd_local);
+        else if (groups_per_pass == 16 && !profile) hipLaunchKernelGGL((ycge::k_atrous_stream<16, false>), grid, dim3(512 + 64), 0, stream, A, buf, statw, sky, d_pixels, d_offsets, d_pass_level, d_band_desc, n_levels, n_bands, rows_per_band, window_width, progress, epoch, xcd_local);
+        else if (groups_per_pass == 16) hipLaunchKernelGGL((ycge::k_atrous_stream<16, true>), grid, dim3(512 + 64), 0, stream, A, buf, statw, sky, d_pixels, d_offsets, d_pass_level, d_band_desc, n_levels, n_bands, rows_per_band, window_width, progress, epoch, xcd_local);
         else return (int)hipErrorInvalidValue;
         return (int)hipGetLastError();
     }
