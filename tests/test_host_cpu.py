@@ -465,6 +465,42 @@ def test_inplace_atrous_window_is_collision_free(product_lib, w, h, step, rows, 
     assert L.ycge_host_band_window_width(0, h, step, rows_eff, K, 32) < 0 and L.ycge_host_band_window_width(w, h, step, rows_eff, K, 7) < 0
 
 
+@pytest.mark.parametrize("w,h", [(1920, 1080), (640, 360), (131, 90), (64, 27), (40, 24)])
+def test_row_parity_band_layout_of_the_persistent_atrous(product_lib, w, h):
+    """The persistent in-place A-trous launch cuts the grid (step 2) into the first four rows, two chains of half-bands (the even / the
+    odd rows of every 8-row stretch) and the last four rows.  Checked here from the stencil itself: every row is in exactly one band;
+    whatever row a pixel's taps land on (clamped) is in its own band, in a band it waits for (above) or in a band that waits for it
+    (below); nobody waits for more than two bands; no band has more than 8 pixels in a level (its workgroup keeps 8 groups a set)."""
+    L = product_lib
+    L.ycge_host_split_bands.restype = C.c_int
+    L.ycge_host_split_bands.argtypes = [C.c_int32, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p]
+    row_band = np.full(h, -1, np.int32); desc = np.full(8 * (h + 4), -7, np.int32); max_px = np.zeros(h + 4, np.int32)
+    nb = L.ycge_host_split_bands(w, h, 2, row_band.ctypes.data, desc.ctypes.data, desc.size, max_px.ctypes.data)
+    assert nb == 2 + 2 * ((h - 8 + 7) // 8)
+    d = desc[:8 * nb].reshape(nb, 8)
+    rows_of = [[int(y0) + k * int(st) for k in range(int(n))] for y0, n, st in d[:, :3]]
+    assert sorted(y for r in rows_of for y in r) == list(range(h))                      # a partition of the rows
+    assert all(row_band[y] == b for b, r in enumerate(rows_of) for y in r)
+    assert rows_of[0] == [0, 1, 2, 3] and rows_of[-1] == list(range(h - 4, h))
+    for b in range(1, nb - 1):
+        assert d[b, 2] == 2 and len({y & 1 for y in rows_of[b]}) <= 1                    # a half-band: one row parity
+    for y in range(h):
+        a = int(row_band[y])
+        ups, dns = {int(v) for v in d[a, 4:6] if v >= 0}, {int(v) for v in d[a, 6:8] if v >= 0}
+        for k in (-2, -1, 0, 1, 2):
+            q = int(row_band[min(max(y + 2 * k, 0), h - 1)])
+            if q != a:
+                assert q in (ups if min(max(y + 2 * k, 0), h - 1) < y else dns), (y, k, a, q)
+    for b in range(nb):                                                                  # the two lists agree
+        for u in d[b, 4:6]:
+            if u >= 0: assert b in d[u, 6:8]
+        for v in d[b, 6:8]:
+            if v >= 0: assert b in d[v, 4:6]
+    assert (d[:, 3] == 8).all() and max_px[:nb].max() <= 8, max_px[:nb].max()
+    assert L.ycge_host_split_bands(w, h, 4, row_band.ctypes.data, desc.ctypes.data, desc.size, None) == 0       # the layout is step 2's
+    assert L.ycge_host_split_bands(w, 16, 2, row_band.ctypes.data, desc.ctypes.data, desc.size, None) == 0      # too few rows
+
+
 def test_vg01_world_file_roundtrip_and_errors(tmp_path):
     """the VG01 world file (WorldManager.cs:612-629 writer, :399-441 reader) and its error behaviour."""
     import struct

@@ -1542,18 +1542,24 @@ bool split_band_layout(int h, int step, std::vector<int32_t> &row_band, std::vec
 {
     const int R = 8, edge = 2 * step;          // rows 0 .. 3 and h - 4 .. h - 1: where the clamp folds taps onto another parity
     if (step != 2 || h < 3 * R) return false;
-    const int chunks = (h - 2 * edge + R - 1) / R;
+    // stretches of 8 rows between the edges; every stretch keeps at least 4 rows (a tap reaches 4 rows up: it must not skip a stretch),
+    // so a remainder of 1 .. 3 rows takes 4 rows from the stretch before it
+    std::vector<int> stretch;
+    for (int left = h - 2 * edge; left > 0; left -= R) stretch.push_back(left < R ? left : R);
+    if (stretch.size() >= 2 && stretch.back() < 4) { stretch[stretch.size() - 2] -= 4; stretch.back() += 4; }
+    if (stretch.empty() || stretch.back() < 4) return false;
+    const int chunks = (int)stretch.size();
     n_bands = 2 + 2 * chunks;
     row_band.assign(h, 0);
     desc.assign((size_t)n_bands * 8, -1);
     auto set = [&](int b, int y0, int rows, int stride, int groups) { desc[8 * b] = y0; desc[8 * b + 1] = rows; desc[8 * b + 2] = stride; desc[8 * b + 3] = groups; };
     set(0, 0, edge, 1, 8);
     for (int y = 0; y < edge; y++) row_band[y] = 0;
-    for (int k = 0; k < chunks; k++)
+    for (int k = 0, y_k = edge; k < chunks; y_k += stretch[k], k++)
         for (int par = 0; par < 2; par++) {
-            const int b = 1 + par * chunks + k, y_first = edge + R * k + par;
+            const int b = 1 + par * chunks + k, y_first = y_k + ((y_k & 1) == par ? 0 : 1);       // the stretch's first row of this parity
             int rows = 0;
-            for (int y = y_first; y < h - edge && y < edge + R * (k + 1); y += 2) { row_band[y] = b; rows++; }
+            for (int y = y_first; y < y_k + stretch[k]; y += 2) { row_band[y] = b; rows++; }
             set(b, y_first, rows, 2, 8);
         }
     const int last = n_bands - 1;
@@ -2080,6 +2086,29 @@ int ycge_host_inplace_bands(int32_t w, int32_t h, int32_t step, int32_t rows_per
     if (entries_out && (int64_t)bpx.size() <= entries_capacity) std::memcpy(entries_out, bpx.data(), bpx.size() * 4);
     if (offsets_out && (int64_t)boff.size() <= offsets_capacity) std::memcpy(offsets_out, boff.data(), boff.size() * 4);
     return (int)(bpx.size() / 32);
+}
+// test hook: the row-parity band layout of the persistent in-place A-trous launch (split_band_layout) and, per band, the most pixels a
+// level holds.  row_band_out: h ints; desc_out: 8 ints a band (first row, rows, stride, groups, up0, up1, dn0, dn1); max_px_out: a band.
+// Returns the number of bands, 0 where the layout does not apply.
+int ycge_host_split_bands(int32_t w, int32_t h, int32_t step, int32_t *row_band_out, int32_t *desc_out, int32_t desc_capacity, int32_t *max_px_out)
+{
+    if (w <= 0 || h <= 0 || step <= 0 || !row_band_out || !desc_out) return YCGE_ERR_INVALID_ARG;
+    std::vector<int32_t> row_band, desc;
+    int n_bands = 0;
+    if (!split_band_layout(h, step, row_band, desc, n_bands)) return 0;
+    if ((int32_t)desc.size() > desc_capacity) return YCGE_ERR_INVALID_ARG;
+    std::memcpy(row_band_out, row_band.data(), row_band.size() * 4);
+    std::memcpy(desc_out, desc.data(), desc.size() * 4);
+    if (max_px_out) {
+        std::vector<uint32_t> px, off;
+        build_inplace_schedule(w, h, step, px, off);
+        const int levels = (int)off.size() - 1;
+        std::vector<int32_t> cnt((size_t)n_bands * levels, 0);
+        for (int t = 0; t < levels; t++)
+            for (uint32_t i = off[t]; i < off[t + 1]; i++) cnt[(size_t)row_band[px[i] / (uint32_t)w] * levels + t]++;
+        for (int b = 0; b < n_bands; b++) { int m = 0; for (int t = 0; t < levels; t++) if (cnt[(size_t)b * levels + t] > m) m = cnt[(size_t)b * levels + t]; max_px_out[b] = m; }
+    }
+    return n_bands;
 }
 // test hook: the window width run_post would hand k_atrous_band for this schedule (0 = hash form)
 int ycge_host_band_window_width(int32_t w, int32_t h, int32_t step, int32_t rows_per_band, int32_t K, int32_t G)
