@@ -1,4 +1,5 @@
 #!/bin/bash
+# (-DYCGE_PRIO_BLOCKS - s_setprio for the first N schedule entries in k_trace - was measured and taken out again: DESIGN section 5, experiment table)
 # wavefront priority for the head of the longest-first schedule (lib/var_prio<N>.so, -DYCGE_PRIO_BLOCKS=N): config 4 / 3 trace, fan on and off
 REPO=${GRAFT_REPO_ROOT:-/root/repo}; cd $REPO
 for round in 1 2; do
