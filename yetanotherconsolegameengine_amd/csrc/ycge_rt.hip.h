@@ -215,10 +215,29 @@ __device__ __forceinline__ F3 sample_albedo(const SceneDev &S, F3 albedo, int te
 }
 
 // ------------------------------------------------------------------ box tests
-// BVH.BoxHitFast, BVH.cs:201-236: NaN-propagating Max/Min, clamp to [tMin, tMax]
+// BVH.BoxHitFast, BVH.cs:201-236: NaN-propagating Max/Min, clamp to [tMin, tMax].
+// MathF.Max / MathF.Min differ from the hardware's maxNum / minNum (v_max_f32 / v_min_f32) in ONE respect that a comparison can see:
+// they propagate a NaN.  A slab product (plane - o) * inv is NaN only as 0 * inf, i.e. when a direction component is exactly zero
+// (inv = +-inf) - boxes and origins are finite.  So a ray whose three reciprocals are finite takes the plain form: per axis min /
+// max of the two products (the reference's swap), max3 / min3, clamp by max / min - results equal to the reference's up to the sign
+// of a zero, which no later comparison sees (the value is only ever compared: entry order, the pop test against closest).  The
+// rare ray with a zero component takes the reference's own sequence.  `inv` is constant over a query: the test is hoisted out of the
+// walk.  (A scene-level node visit is two of these: config 5 makes 676 M of them a frame.)
 __device__ __forceinline__ bool box_scene(float mnx, float mny, float mnz, float mxx, float mxy, float mxz, F3 o, F3 inv,
                                           float tmin, float tmax, float &tnear)
 {
+    const bool plain = cs_abs(inv.x) < YCGE_INF && cs_abs(inv.y) < YCGE_INF && cs_abs(inv.z) < YCGE_INF;      // false for +-inf and NaN
+    if (plain) {
+        const float ax = (mnx - o.x) * inv.x, bx = (mxx - o.x) * inv.x;
+        const float ay = (mny - o.y) * inv.y, by = (mxy - o.y) * inv.y;
+        const float az = (mnz - o.z) * inv.z, bz = (mxz - o.z) * inv.z;
+        float t_enter = __builtin_fmaxf(__builtin_fminf(ax, bx), __builtin_fmaxf(__builtin_fminf(ay, by), __builtin_fminf(az, bz)));
+        float t_exit = __builtin_fminf(__builtin_fmaxf(ax, bx), __builtin_fminf(__builtin_fmaxf(ay, by), __builtin_fmaxf(az, bz)));
+        t_enter = __builtin_fmaxf(t_enter, tmin);
+        t_exit = __builtin_fminf(t_exit, tmax);
+        tnear = t_enter;
+        return t_exit >= t_enter;
+    }
     float en_x = (mnx - o.x) * inv.x, ex_x = (mxx - o.x) * inv.x;
     if (en_x > ex_x) { float t = en_x; en_x = ex_x; ex_x = t; }
     float en_y = (mny - o.y) * inv.y, ex_y = (mxy - o.y) * inv.y;
