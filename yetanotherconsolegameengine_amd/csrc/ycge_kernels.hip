@@ -233,7 +233,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu((HAS_GRID &&
     int hit_prim = -1, hit_sub = 0, mesh_prim = -1;
     DdaState D;
     D.ix = D.iy = D.iz = 0; D.t = D.t_max_x = D.t_max_y = D.t_max_z = D.t_delta_x = D.t_delta_y = D.t_delta_z = D.t_exit = D.tmax = 0.0f;
-    D.packed = 0; D.nx = D.ny = D.nz = 1; D.cell_offset = D.mask_lo = D.mask_hi = 0; D.prim = -1;
+    D.step_x = D.step_y = D.step_z = D.last_axis = D.use_mask = 0; D.nx = D.ny = D.nz = D.nbx = D.nby = 1; D.cell_offset = D.mask_lo = D.mask_hi = 0; D.prim = -1;
     uint32_t tile = 0, next_ray = 0, end_ray = 0;          // wave-uniform: the segment being handed out
     bool exhausted = false;
     for (;;) {

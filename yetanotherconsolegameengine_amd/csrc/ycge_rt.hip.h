@@ -508,7 +508,8 @@ __device__ __forceinline__ void grid_dda(const SceneDev &S, int grid_index_, int
     while (t <= t_exit && t <= tmax) {
         if (COUNT) prof_tick(3);
         w.steps++;
-        if ((uint32_t)ix < (uint32_t)g.nx && (uint32_t)iy < (uint32_t)g.ny && (uint32_t)iz < (uint32_t)g.nz) {
+        {   // (VolumeGrid.cs:153 tests the cell against the grid's bounds here: always true - the entry cell is clamped into the grid
+            // and the walk leaves the loop the moment a step takes it outside, :224-227)
             if (COUNT) w.vox++;
             const int brick = (((iz >> 3) * g.nby) + (iy >> 3)) * g.nbx + (ix >> 3);
             if (!use_mask || ((mask >> brick) & 1ull)) {
@@ -537,8 +538,8 @@ __device__ __forceinline__ void grid_dda(const SceneDev &S, int grid_index_, int
 struct DdaState {
     int ix, iy, iz;
     float t, t_max_x, t_max_y, t_max_z, t_delta_x, t_delta_y, t_delta_z, t_exit, tmax;
-    uint32_t packed;            // (step_x + 1) | (step_y + 1) << 2 | (step_z + 1) << 4 | last_axis << 6 | use_mask << 8
-    int nx, ny, nz;
+    int step_x, step_y, step_z, last_axis, use_mask;        // (kept apart: the extend stage has registers to spare, a cell step no instructions)
+    int nx, ny, nz, nbx, nby;
     uint32_t cell_offset, mask_lo, mask_hi;
     int prim;
 };
@@ -581,9 +582,8 @@ __device__ __forceinline__ bool dda_begin(const SceneDev &S, int grid_index_, in
     D.t_delta_z = step_z == 0 ? YCGE_INF : cs_abs(size_z * inv_dz);
     const int last_axis = enter_axis < 0 ? (D.t_max_x <= D.t_max_y && D.t_max_x <= D.t_max_z ? 0 : D.t_max_y <= D.t_max_z ? 1 : 2) : enter_axis;
     D.ix = ix; D.iy = iy; D.iz = iz; D.t = t; D.t_exit = t_exit; D.tmax = tmax;
-    D.packed = (uint32_t)(step_x + 1) | ((uint32_t)(step_y + 1) << 2) | ((uint32_t)(step_z + 1) << 4) | ((uint32_t)last_axis << 6) |
-               (g.has_brick_mask ? 256u : 0u);
-    D.nx = g.nx; D.ny = g.ny; D.nz = g.nz;
+    D.step_x = step_x; D.step_y = step_y; D.step_z = step_z; D.last_axis = last_axis; D.use_mask = g.has_brick_mask ? 1 : 0;
+    D.nx = g.nx; D.ny = g.ny; D.nz = g.nz; D.nbx = (g.nx + 7) >> 3; D.nby = (g.ny + 7) >> 3;
     D.cell_offset = g.cell_offset; D.mask_lo = g.brick_mask_lo; D.mask_hi = g.brick_mask_hi;
     D.prim = prim_index;
     return t <= t_exit && t <= tmax;            // the while condition of VolumeGrid.cs:151 before the first cell
@@ -594,29 +594,27 @@ __device__ __forceinline__ bool dda_step(const SceneDev &S, DdaState &D, float t
 {
     if (COUNT) prof_tick(3);
     w.steps++;
-    const int nby = (D.ny + 7) >> 3, nbx = (D.nx + 7) >> 3;
-    if ((uint32_t)D.ix < (uint32_t)D.nx && (uint32_t)D.iy < (uint32_t)D.ny && (uint32_t)D.iz < (uint32_t)D.nz) {
+    {   // (the cell is inside the grid: see grid_dda)
         if (COUNT) w.vox++;
-        const int brick = (((D.iz >> 3) * nby) + (D.iy >> 3)) * nbx + (D.ix >> 3);
+        const int brick = (((D.iz >> 3) * D.nby) + (D.iy >> 3)) * D.nbx + (D.ix >> 3);
         const unsigned long long mask = ((unsigned long long)D.mask_hi << 32) | D.mask_lo;
-        if (!(D.packed & 256u) || ((mask >> brick) & 1ull)) {
+        if (!D.use_mask || ((mask >> brick) & 1ull)) {
             if (S.grid_cells[D.cell_offset + (uint32_t)(brick * 512 + morton3_3bits(D.ix & 7, D.iy & 7, D.iz & 7))] != 0) {
                 closest = cs_max(D.t, tmin);
                 hit_prim = D.prim;
-                hit_sub = (D.ix + D.nx * (D.iy + D.ny * D.iz)) | (int)(((D.packed >> 6) & 3u) << 30);
+                hit_sub = (D.ix + D.nx * (D.iy + D.ny * D.iz)) | (D.last_axis << 30);
                 return false;
             }
         }
     }
-    const int step_x = (int)(D.packed & 3u) - 1, step_y = (int)((D.packed >> 2) & 3u) - 1, step_z = (int)((D.packed >> 4) & 3u) - 1;
     const bool ax = D.t_max_x <= D.t_max_y && D.t_max_x <= D.t_max_z;
     const bool ay = !ax && D.t_max_y <= D.t_max_z;
     const bool az = !ax && !ay;
     D.t = ax ? D.t_max_x : ay ? D.t_max_y : D.t_max_z;
-    D.ix += ax ? step_x : 0; D.iy += ay ? step_y : 0; D.iz += az ? step_z : 0;
+    D.ix += ax ? D.step_x : 0; D.iy += ay ? D.step_y : 0; D.iz += az ? D.step_z : 0;
     const float nx_ = D.t_max_x + D.t_delta_x, ny_ = D.t_max_y + D.t_delta_y, nz_ = D.t_max_z + D.t_delta_z;
     D.t_max_x = ax ? nx_ : D.t_max_x; D.t_max_y = ay ? ny_ : D.t_max_y; D.t_max_z = az ? nz_ : D.t_max_z;
-    D.packed = (D.packed & ~(3u << 6)) | ((ax ? 0u : ay ? 1u : 2u) << 6);
+    D.last_axis = ax ? 0 : ay ? 1 : 2;
     if ((uint32_t)D.ix >= (uint32_t)D.nx || (uint32_t)D.iy >= (uint32_t)D.ny || (uint32_t)D.iz >= (uint32_t)D.nz) return false;
     return D.t <= D.t_exit && D.t <= D.tmax;
 }
