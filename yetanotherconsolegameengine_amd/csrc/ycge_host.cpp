@@ -719,6 +719,9 @@ int validate_scene(const ycge_scene *s, std::string &msg)
         const ycge_grid &g = s->grids[gi];
         if (g.nx <= 0 || g.ny <= 0 || g.nz <= 0 || !g.cells) return bad(YCGE_ERR_INVALID_ARG, "grid %d: empty", gi);
         if ((uint64_t)g.nx * g.ny * g.nz >= (1u << 30)) return bad(YCGE_ERR_UNSUPPORTED, "grid %d: more than 2^30 cells", gi);
+        // (the voxel walk forms brick indices with 24-bit multiplies: ((z >> 3) * bricks_y + (y >> 3)) * bricks_x)
+        if ((uint64_t)((g.nz + 7) >> 3) * (uint64_t)((g.ny + 7) >> 3) >= (1u << 23) || ((g.nx + 7) >> 3) >= (1 << 23))
+            return bad(YCGE_ERR_UNSUPPORTED, "grid %d: more than 2^23 bricks across one face", gi);
         if (g.n_lookup < 0 || (g.n_lookup > 0 && !g.lookup)) return bad(YCGE_ERR_INVALID_ARG, "grid %d: bad lookup table", gi);
         for (int k = 0; k < g.n_lookup; k++)
             if (!mat_ok(g.lookup[k].material)) return bad(YCGE_ERR_INVALID_ARG, "grid %d: lookup entry %d names a material out of range", gi, k);

@@ -435,14 +435,23 @@ __device__ __forceinline__ void analytic_prim(const float4 q0, const float4 q1, 
 }
 
 // ------------------------------------------------------------------ voxel grid
+// The low three bits of x, y, z interleaved (x lowest).  All three are spread at once: the fields sit 9 bits apart in one
+// word, one shift-or pair opens the gaps, one mask keeps bits 0, 3, 6 of each field (12 instructions, not 23 bit by bit).
 __device__ __forceinline__ int morton3_3bits(int x, int y, int z)   // VolumeGrid.cs:246-252
 {
-    return ((x & 1) << 0) | ((y & 1) << 1) | ((z & 1) << 2) | ((x & 2) << 2) | ((y & 2) << 3) | ((z & 2) << 4) | ((x & 4) << 4) | ((y & 4) << 5) | ((z & 4) << 6);
+    const uint32_t w = (uint32_t)(x & 7) | ((uint32_t)(y & 7) << 9) | ((uint32_t)(z & 7) << 18);
+    const uint32_t t = (w | (w << 2) | (w << 4)) & 0x01249249u;
+    return (int)((t | (t >> 8) | (t >> 16)) & 0x1ffu);
+}
+// cell coordinates and brick counts are far below 2^23: the one-instruction 24-bit multiply-add, not the 64-bit one
+__device__ __forceinline__ int grid_brick(int ix, int iy, int iz, int nbx, int nby)
+{
+    return __mul24(__mul24(iz >> 3, nby) + (iy >> 3), nbx) + (ix >> 3);
 }
 __device__ __forceinline__ uint32_t grid_index(const GGrid &g, int ix, int iy, int iz)   // VolumeGrid.cs:235-242
 {
-    int brick = (((iz >> 3) * g.nby) + (iy >> 3)) * g.nbx + (ix >> 3);
-    return (uint32_t)(brick * 512 + morton3_3bits(ix & 7, iy & 7, iz & 7));
+    const int brick = grid_brick(ix, iy, iz, g.nbx, g.nby);
+    return (uint32_t)(brick * 512 + morton3_3bits(ix, iy, iz));
 }
 __device__ __forceinline__ bool grid_slab(float ro, float rd, float inv, float mn, float mx, float &t_enter, float &t_exit, int axis, int &enter_axis)
 {   // VolumeGrid.Slab, VolumeGrid.cs:331-355.  `inv` = 1.0f / rd, the C#'s own expression, evaluated once per ray
@@ -511,9 +520,9 @@ __device__ __forceinline__ void grid_dda(const SceneDev &S, int grid_index_, int
         {   // (VolumeGrid.cs:153 tests the cell against the grid's bounds here: always true - the entry cell is clamped into the grid
             // and the walk leaves the loop the moment a step takes it outside, :224-227)
             if (COUNT) w.vox++;
-            const int brick = (((iz >> 3) * g.nby) + (iy >> 3)) * g.nbx + (ix >> 3);
+            const int brick = grid_brick(ix, iy, iz, g.nbx, g.nby);
             if (!use_mask || ((mask >> brick) & 1ull)) {
-                if (cells[(uint32_t)(brick * 512 + morton3_3bits(ix & 7, iy & 7, iz & 7))] != 0) {
+                if (cells[(uint32_t)(brick * 512 + morton3_3bits(ix, iy, iz))] != 0) {
                     closest = cs_max(t, tmin);
                     hit_prim = prim_index;
                     hit_sub = (ix + g.nx * (iy + g.ny * iz)) | (last_axis << 30);
@@ -596,10 +605,10 @@ __device__ __forceinline__ bool dda_step(const SceneDev &S, DdaState &D, float t
     w.steps++;
     {   // (the cell is inside the grid: see grid_dda)
         if (COUNT) w.vox++;
-        const int brick = (((D.iz >> 3) * D.nby) + (D.iy >> 3)) * D.nbx + (D.ix >> 3);
+        const int brick = grid_brick(D.ix, D.iy, D.iz, D.nbx, D.nby);
         const unsigned long long mask = ((unsigned long long)D.mask_hi << 32) | D.mask_lo;
         if (!D.use_mask || ((mask >> brick) & 1ull)) {
-            if (S.grid_cells[D.cell_offset + (uint32_t)(brick * 512 + morton3_3bits(D.ix & 7, D.iy & 7, D.iz & 7))] != 0) {
+            if (S.grid_cells[D.cell_offset + (uint32_t)(brick * 512 + morton3_3bits(D.ix, D.iy, D.iz))] != 0) {
                 closest = cs_max(D.t, tmin);
                 hit_prim = D.prim;
                 hit_sub = (D.ix + D.nx * (D.iy + D.ny * D.iz)) | (D.last_axis << 30);
