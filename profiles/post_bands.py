@@ -6,11 +6,16 @@ sys.path.insert(0, str(ROOT))
 import numpy as np
 from yetanotherconsolegameengine_amd import scenes
 from yetanotherconsolegameengine_amd.renderer import RaytraceRenderer
-sc, w, h, ss, pose = scenes.config_scene(4)
+import os
+sc, w, h, ss, pose = scenes.config_scene(int(os.environ.get('CFG', '4')))
+ss = int(os.environ.get('SS', ss))          # SS=2: the 3840x2160 trace grid of config 5 (NB=540 half-bands)
 r = RaytraceRenderer(sc, w, h, pose["fov"], ss)
 r.SetCamera(pose["pos"], pose["yaw"], pose["pitch"])
+import time
 for i in range(4):
+    t_wall = time.time()
     r.TryFlipAndBlit(want_sdr=True)
+    print(f"frame {i}: post {r.stats.post_ms:.3f} ms, wall {time.time() - t_wall:.3f} s", flush=True)
 print(f"post {r.stats.post_ms:.3f} ms")
 import os
 nb = int(os.environ.get('NB', '135'))
@@ -25,7 +30,7 @@ passes = rec[:, 8].astype(np.float64)
 t0 = t[:, 0].min()
 dur = t[:, 1] - t[:, 0]
 print(f"launch span {t[:, 1].max() - t0:.1f} us; band 0: {dur[0]:.1f} us for {passes[0]:.0f} passes = {dur[0] / passes[0]:.3f} us per pass")
-print("per pass (own duration / passes), bands 0, 1, 2, 10, 60, 134:", [round(dur[b] / passes[b], 3) for b in (0, 1, 2, 10, 60, 134)])
+print("per pass (own duration / passes), bands 0, 1, 2, 10, 60, last:", [round(dur[b] / passes[b], 3) for b in (0, 1, 2, 10, 60, nb - 1)])
 end_lag = np.diff(t[:, 1])
 print(f"end(b) - end(b-1): mean {end_lag.mean():.2f} us, median {np.median(end_lag):.2f}, max {end_lag.max():.2f}")
 beg_lag = np.diff(t[:, 0])

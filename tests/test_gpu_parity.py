@@ -537,3 +537,30 @@ def test_more_ranks_than_tiles(product_lib, path):
                 assert pu.bits_equal(ref, r.read(which)), (frame, which)
     for r in ranks + [single]:
         r.close()
+
+
+def test_persistent_atrous_when_fewer_band_workgroups_fit(product_lib, monkeypatch):
+    """A 3840x2160 trace grid without a sky pixel (config 5's post stage): 540 row-parity half-bands.  The two-set kernel holds
+    three band workgroups per CU (768 places), the profiling instantiation two (512): there the host must not take the split layout
+    - a band that is not resident while its neighbours wait for it stalls the frame for seconds (measured: 1 - 59 s).  The host asks
+    the runtime for the residency of the instantiation it will launch; both builds must produce the same SDR frame, promptly."""
+    s = Scene()
+    s.Add(Plane(vec3(0.0, 0.0, 0.0), vec3(0.0, 1.0, 0.0), Solid(vec3(0.6, 0.6, 0.55)), 0.05, 0.0))
+    s.Add(Sphere(vec3(0.0, 0.5, -2.0), 0.5, Solid(vec3(0.8, 0.2, 0.2))))
+    s.Lights.append(PointLight(vec3(1.0, 3.0, -1.0), vec3(1, 1, 1), 30.0))
+    out = {}
+    for label, probe in (("two-set", None), ("profiling", "7")):
+        if probe is None: monkeypatch.delenv("YCGE_POST_PROBE_BAND", raising=False)
+        else: monkeypatch.setenv("YCGE_POST_PROBE_BAND", probe)
+        r = RaytraceRenderer(s, 1920, 540, 60.0, 2)
+        r.SetCamera((0.0, 1.5, 0.0), 0.0, -1.2)         # looking down: ground in every pixel
+        frames = []
+        for f in range(3):
+            frames.append(r.TryFlipAndBlit(want_sdr=True).copy())
+            print(f"{label} frame {f + 1}: post {r.stats.post_ms:.2f} ms")
+            if f > 0: assert r.stats.post_ms < 200.0, f"{label}: post stage took {r.stats.post_ms:.0f} ms - band workgroups not all resident?"
+        assert int(r.read(abi.BUF_SKY_MASK).sum()) == 0
+        out[label] = frames
+        r.close()
+    for a, b in zip(out["two-set"], out["profiling"]):
+        assert np.array_equal(a.view(np.uint32), b.view(np.uint32))

@@ -36,6 +36,7 @@ int ycge_launch_trace_fan(const ycge::SceneDev *S, const ycge::FrameParams *P, c
 int ycge_launch_taa(const ycge::TaaParams *T, const float *current, const float *normal, const float *depth, const uint8_t *sky,
                     float *hist, float *prev_normal, float *prev_depth, uint8_t *prev_sky, hipStream_t stream);
 size_t ycge_post_state_bytes(void);
+int ycge_atrous_persist_resident(int groups_per_pass, int split, int level_handover, int profile);
 int ycge_launch_unit_normals(const float *normal, float *unit, size_t n, hipStream_t stream);
 int ycge_launch_atrous(int w, int h, int step, const float phi[4], const float *cur, float *dst, const float *albedo, const float *unit_n,
                        const float *depth, const uint8_t *sky, hipStream_t stream);
@@ -222,6 +223,7 @@ struct ycge_ctx {
     DevBuf<uint8_t> exp_scratch;                  // chunk records of the exposure sum (k_exposure_sum)
     DevBuf<uint32_t> post_progress;               // k_atrous_persist: groups finished per band, one 128-byte line each
     uint32_t post_epoch = 0;                      // ... counted from here in the next launch
+    int post_resident_seen[2] = {-1, -1};         // post_resident_per_cu: the runtime's answer for the whole-band / split-band instantiation (-1: not asked yet)
     DevBuf<uint8_t> tone_state;                   // ToneMapper state; lives as long as the context (not reset by Resize)
     struct InplaceSchedule { int w = 0, h = 0, step = 0, levels = 0, bands = 0, rows_per_band = 0, levels_per_launch = 0; uint32_t max_level_pixels = 0, window_width = 0; bool split = false; DevBuf<uint32_t> pixels, offsets, pass_level; DevBuf<int32_t> band_desc; };
     std::vector<InplaceSchedule *> schedules;     // level schedules of the in-place A-trous iterations, by (w, h, step)
@@ -1622,6 +1624,15 @@ uint32_t band_window_width(const std::vector<uint32_t> &band_pixels, const std::
     return 0u;
 }
 
+// band workgroups of the persistent in-place A-trous a CU holds at once: what the runtime says of the instantiation that would be
+// launched, capped by the YCGE_POST_RESIDENT knob.  0 (the question failed) keeps the persistent form off.
+int post_resident_per_cu(ycge_ctx *c, bool split)
+{
+    int &q = c->post_resident_seen[split ? 1 : 0];
+    if (q < 0) q = ycge_atrous_persist_resident(c->knobs.post_groups, split ? 1 : 0, c->knobs.post_mode == 4 ? 0 : 1, c->knobs.post_probe_band >= 0 ? 1 : 0);
+    return q < c->knobs.post_resident_per_cu ? q : c->knobs.post_resident_per_cu;
+}
+
 int run_post(ycge_ctx *c, hipStream_t stream, float *out_sdr_host, bool timed)
 {
     const int w = c->hiW, h = c->hiH;
@@ -1675,7 +1686,7 @@ int run_post(ycge_ctx *c, hipStream_t stream, float *out_sdr_host, bool timed)
                 int split_bands = 0;
                 if ((c->knobs.post_mode == 0 || c->knobs.post_mode == 3) && !c->knobs.post_no_split && !c->knobs.post_hash && c->knobs.post_groups == 16 && rows_per_band == 8 &&
                     split_band_layout(h, step, row_band, desc, split_bands) && c->compute_units > 0 &&
-                    ((split_bands + 7) / 8) * 8 <= c->knobs.post_resident_per_cu * c->compute_units) {
+                    ((split_bands + 7) / 8) * 8 <= post_resident_per_cu(c, true) * c->compute_units) {
                     sc->split = true;
                     sc->bands = split_bands;
                     band_inplace_schedule(w, h, rows_per_band, px, off, bpx, boff, sc->bands, sc->max_level_pixels, (uint32_t)c->knobs.post_groups, &row_band);
@@ -1722,7 +1733,7 @@ int run_post(ycge_ctx *c, hipStream_t stream, float *out_sdr_host, bool timed)
             // one persistent launch when the window form applies and every band's workgroup is resident at once (it waits for its
             // neighbour inside the kernel); else a launch per level group
             const bool persist = sc->split || (c->knobs.post_mode != 2 && (c->knobs.post_groups <= 16 || c->knobs.post_mode == 4) && sc->window_width != 0 && (size_t)sc->rows_per_band * sc->window_width <= 2048 &&
-                                 c->compute_units > 0 && ((sc->bands + 7) / 8) * 8 <= c->knobs.post_resident_per_cu * c->compute_units);
+                                 c->compute_units > 0 && ((sc->bands + 7) / 8) * 8 <= post_resident_per_cu(c, sc->split) * c->compute_units);
             if (persist) {
                 // Bands of one XCD adjacent (their colours meet in one L2) while every band has a CU of its own: 1080p 3.90 against 4.03 ms.
                 // Where two bands must share a CU (a 4K grid: 270 bands) block order is the better one - 14.7 against 15.9 ms, launch

@@ -1130,6 +1130,26 @@ int ycge_launch_atrous_persist(int w, int h, int step, const float phi[4], float
     return (int)hipGetLastError();
 }
 
+// How many band workgroups of the persistent launch one CU holds - asked of the runtime for the very instantiation
+// ycge_launch_atrous_persist would start (they differ: 66 VGPRs and three workgroups for the two-set form, 82 and two for the
+// others).  A band that is not resident while its neighbours spin on its progress word stalls the frame for seconds.
+int ycge_atrous_persist_resident(int groups_per_pass, int split, int level_handover, int profile)
+{
+    int n = 0;
+    hipError_t e = hipErrorInvalidValue;
+    if (level_handover) {
+        if (groups_per_pass == 8) e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, ycge::k_atrous_stream<8, false>, 256 + 64, 0);
+        else if (groups_per_pass == 16 && split && !profile) e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, ycge::k_atrous_stream<16, false, true>, 512 + 64, 0);
+        else if (groups_per_pass == 16 && !profile) e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, ycge::k_atrous_stream<16, false>, 512 + 64, 0);
+        else if (groups_per_pass == 16) e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, ycge::k_atrous_stream<16, true>, 512 + 64, 0);
+    } else {
+        if (groups_per_pass == 8) e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, ycge::k_atrous_persist<8>, 256, 0);
+        else if (groups_per_pass == 16) e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, ycge::k_atrous_persist<16>, 512, 0);
+        else e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, ycge::k_atrous_persist<32>, 1024, 0);
+    }
+    return e == hipSuccess ? n : 0;
+}
+
 size_t ycge_exposure_scratch_bytes(int w, int h, int step)
 {
     const int nsx = (w + step - 1) / step, nsy = (h + step - 1) / step;
