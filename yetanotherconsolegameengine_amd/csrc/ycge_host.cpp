@@ -47,7 +47,7 @@ int ycge_launch_atrous_inplace(int w, int h, int step, const float phi[4], float
                                int n_levels, int n_bands, int K, int groups_per_pass, int rows_per_band, unsigned window_width, hipStream_t stream);
 int ycge_launch_atrous_persist(int w, int h, int step, const float phi[4], float *buf, const uint8_t *sky, float *statw, const uint32_t *d_pixels,
                                const uint32_t *d_offsets, const uint32_t *d_pass_level, const int32_t *d_band_desc, int n_levels, int n_bands, int K, int groups_per_pass, int rows_per_band, unsigned window_width,
-                               uint32_t *progress, uint32_t epoch, int xcd_local, int level_handover, int profile, hipStream_t stream);
+                               uint32_t *progress, uint32_t epoch, int xcd_local, int level_handover, int profile, uint32_t ticket_base, hipStream_t stream);
 size_t ycge_exposure_scratch_bytes(int w, int h, int step);
 size_t ycge_bvh_build_scratch_bytes(int n);
 int ycge_launch_scene_bvh_build(const float *items, int n, void *scratch, void *ref_out, void *gnodes_out, uint32_t *leaf_out, void *result,
@@ -116,6 +116,7 @@ struct Knobs {
     int post_mode = 0;               // YCGE_POST_MODE: in-place A-trous: 0 = one persistent launch, level-granular hand-over (k_atrous_stream), 2 = a launch per level group, 3 = as 0 with bands in block order, 4 = persistent with group hand-over (k_atrous_persist)
     bool post_no_split = false;      // YCGE_POST_NO_SPLIT: whole bands in the persistent in-place A-trous (no row-parity half-bands)
     int post_probe_band = -1;        // YCGE_POST_PROBE_BAND: this band and the next record a per-pass timeline (profiles/post_bands.py)
+    int post_assume_resident = 0;    // YCGE_POST_ASSUME_RESIDENT (tests): take this for the runtime's answer - more bands than fit, to exercise the order-of-arrival numbering
     int post_resident_per_cu = 3;    // YCGE_POST_RESIDENT: band workgroups of the persistent in-place A-trous a CU may hold (3 fit: 576 threads, 46 KB of LDS each)
     bool post_hash = false;          // YCGE_POST_HASH_FORM=1: the hash form of k_atrous_band even where the window fits
     int bvh_waves = 16;              // YCGE_BVH_WAVES: wavefronts of k_scene_bvh_build that take nodes (tests: the order nodes are split in must not matter)
@@ -140,6 +141,7 @@ struct Knobs {
         post_no_split = getenv("YCGE_POST_NO_SPLIT") != nullptr;
         post_probe_band = geti("YCGE_POST_PROBE_BAND", -1);
         post_resident_per_cu = geti("YCGE_POST_RESIDENT", 3);
+        post_assume_resident = geti("YCGE_POST_ASSUME_RESIDENT", 0);
         if (post_resident_per_cu < 1 || post_resident_per_cu > 3) post_resident_per_cu = 3;
         mig = geti("YCGE_MIG", 1); mig_round = geti("YCGE_MIG_ROUND", 12); mig_shade = geti("YCGE_MIG_SHADE", 16);
         if (mig_round < 1) mig_round = 1;
@@ -223,6 +225,7 @@ struct ycge_ctx {
     DevBuf<uint8_t> exp_scratch;                  // chunk records of the exposure sum (k_exposure_sum)
     DevBuf<uint32_t> post_progress;               // k_atrous_persist: groups finished per band, one 128-byte line each
     uint32_t post_epoch = 0;                      // ... counted from here in the next launch
+    uint32_t post_ticket = 0;                     // k_atrous_stream, bands in order of arrival: numbers drawn so far (the counter lives in post_progress)
     int post_resident_seen[2] = {-1, -1};         // post_resident_per_cu: the runtime's answer for the whole-band / split-band instantiation (-1: not asked yet)
     DevBuf<uint8_t> tone_state;                   // ToneMapper state; lives as long as the context (not reset by Resize)
     struct InplaceSchedule { int w = 0, h = 0, step = 0, levels = 0, bands = 0, rows_per_band = 0, levels_per_launch = 0; uint32_t max_level_pixels = 0, window_width = 0; bool split = false; DevBuf<uint32_t> pixels, offsets, pass_level; DevBuf<int32_t> band_desc; };
@@ -1630,6 +1633,7 @@ int post_resident_per_cu(ycge_ctx *c, bool split)
 {
     int &q = c->post_resident_seen[split ? 1 : 0];
     if (q < 0) q = ycge_atrous_persist_resident(c->knobs.post_groups, split ? 1 : 0, c->knobs.post_mode == 4 ? 0 : 1, c->knobs.post_probe_band >= 0 ? 1 : 0);
+    if (c->knobs.post_assume_resident > 0) return c->knobs.post_assume_resident;
     return q < c->knobs.post_resident_per_cu ? q : c->knobs.post_resident_per_cu;
 }
 
@@ -1745,10 +1749,12 @@ int run_post(ycge_ctx *c, hipStream_t stream, float *out_sdr_host, bool timed)
                     HIP_TRY(c, hipMemsetAsync(c->post_progress.p, 0, ((size_t)sc->bands * 32 + 8000) * sizeof(uint32_t), stream));
                     if (c->knobs.post_probe_band >= 0) { const uint32_t v = (uint32_t)c->knobs.post_probe_band + 1u; HIP_TRY(c, hipMemcpyAsync(c->post_progress.p + (size_t)sc->bands * 32 + 7999, &v, 4, hipMemcpyHostToDevice, stream)); HIP_TRY(c, hipStreamSynchronize(stream)); }
                     c->post_epoch = 0;
+                    c->post_ticket = 0;
                 }
                 e = ycge_launch_atrous_persist(w, h, step, phi, dst, c->sky.p, c->atrous_statw.p, sc->pixels.p, sc->offsets.p, sc->pass_level.p, sc->split ? sc->band_desc.p : nullptr, sc->levels, sc->bands,
                                                levels_per_launch, c->knobs.post_groups, sc->rows_per_band, sc->window_width, c->post_progress.p, c->post_epoch,
-                                               xcd_local, c->knobs.post_mode == 4 ? 0 : 1, c->knobs.post_probe_band >= 0 ? 1 : 0, stream);
+                                               xcd_local, c->knobs.post_mode == 4 ? 0 : 1, c->knobs.post_probe_band >= 0 ? 1 : 0, c->post_ticket, stream);
+                if (!xcd_local && c->knobs.post_mode != 4) c->post_ticket += (uint32_t)sc->bands;      // one number per workgroup of the launch
                 c->post_epoch += (groups > (uint32_t)sc->levels ? groups : (uint32_t)sc->levels) + 1u;
             } else
             e = ycge_launch_atrous_inplace(w, h, step, phi, dst, c->g_albedo.p, c->unit_n.p, c->g_depth.p, c->sky.p, c->atrous_statw.p,

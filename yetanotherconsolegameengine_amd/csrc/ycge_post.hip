@@ -184,6 +184,7 @@ __global__ __launch_bounds__(256) void k_atrous_static(const AtrousParams A, con
 #define YCGE_POST_HASH 2048         // entries of the hash form; the host keeps a launch's pixels below 3/4 of it
 #define YCGE_POST_WIN 2048          // entries of the window form: rows of the band x window width
 #define YCGE_POST_NONE 0xffffffffu
+#define YCGE_POST_TICKET_WORD 16       // k_atrous_stream, bands in order of arrival: the counter (a free word of band 0's progress record; only ever incremented)
 #define YCGE_POST_PROBE_LEVEL 1400    // profiling aid of k_atrous_stream: times of this level's hand-over (profiles/post_bands.py)
 // Where a launch keeps its new colours.  WINDOW form (the default): entry (row in the band) * WX + (x mod WX) - the host has checked,
 // list by list, that no two pixels one launch writes share an entry (a launch's levels cover a short diagonal stripe of the band: 16
@@ -194,6 +195,7 @@ template <int G> struct PostSharedT {
     float val[G][4][28];        // [component x, y, z, weight][tap], a row padded to 16-byte multiples: the sum reads its 25 terms as 6 x b128 + 1
     uint4 ent[YCGE_POST_HASH];  // {pixel (tag), r, g, b as bits}: a lookup is ONE 16-byte LDS read
     uint32_t out_slot[2][G];    // k_atrous_stream: the entry each group wrote in the last two passes (YCGE_POST_NONE: none), for the publishing wavefront
+    uint32_t ticket;            // k_atrous_stream, bands in order of arrival: the band this workgroup drew
 };
 static_assert(YCGE_POST_WIN == YCGE_POST_HASH, "one LDS array serves both forms");
 struct BandWindow { int y0, rows; uint32_t wx, use; int shift; };     // use == 0: hash form; shift 1: the band's rows are y0, y0 + 2, .. (k_atrous_stream's half-bands)
@@ -420,11 +422,19 @@ __global__ __launch_bounds__(32 * G + 64) void k_atrous_stream(const AtrousParam
                                                                const uint8_t *__restrict__ sky, const uint32_t *__restrict__ pixels,
                                                                const uint32_t *__restrict__ off, const uint32_t *__restrict__ pass_level,
                                                                const int32_t *__restrict__ band_desc, int levels, int n_bands, int rows_per_band, uint32_t wx, uint32_t *__restrict__ progress, uint32_t epoch,
-                                                               int xcd_local)
+                                                               int xcd_local, uint32_t ticket_base)
 {
     __shared__ __attribute__((aligned(16))) PostSharedT<G> sh;
     int b = (int)blockIdx.x;
     if (xcd_local) { const int per_xcd = (n_bands + 7) / 8; b = ((int)blockIdx.x % 8) * per_xcd + (int)blockIdx.x / 8; }
+    else {
+        // Bands in order of ARRIVAL, not by block index: a band only ever waits for bands of lower numbers, and with a drawn number
+        // all of those have started - whatever order the dispatcher places workgroups in, and however many of them fit the chip at
+        // once.  (By block index a launch with 28 workgroups too many stalled for 1 - 59 s, until the queue was preempted.)
+        if (threadIdx.x == 0) sh.ticket = atomicAdd(progress + YCGE_POST_TICKET_WORD, 1u) - ticket_base;
+        __syncthreads();
+        b = __builtin_amdgcn_readfirstlane((int)sh.ticket);
+    }
     if (b >= n_bands) return;
     const uint32_t *o = off + (size_t)b * (levels + 1);
     const bool publisher = threadIdx.x >= 32 * G;               // the last wavefront
@@ -487,14 +497,21 @@ __global__ __launch_bounds__(32 * G + 64) void k_atrous_stream(const AtrousParam
         // Does the band below run on this XCD?  Then its device-coherent loads find these colours in the L2 both share, and a plain
         // store (acknowledged by that L2 in 0.18 us, the line stays there) is enough; across XCDs the store must be written through
         // (0.38 us, and the reader's load goes to memory: ~1.5 us).  Measured, not assumed: every band announces its XCC id.
-        bool same_xcd = dn0 >= 0;
-        for (int k = 0; k < 2; k++) {
-            const int dn = k == 0 ? dn0 : dn1;
-            if (dn < 0) continue;
-            uint32_t v;
-            do v = __hip_atomic_load(progress + (size_t)dn * 32 + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - epoch; while (v == 0u || v > 16u);
-            same_xcd = same_xcd && v - 1u == my_xcc;
-        }
+        // The answer is LOOKED for at every pass until it is there, never waited for: a band below that has not started yet (more
+        // bands than the chip holds at once) starts only when a band above it has finished and left - until then colours are
+        // written through.  (Waiting here deadlocked such launches until the queue was preempted: frames of 1 - 59 s.)
+        bool same_xcd = false, dn_known = dn0 < 0;
+        auto look_down = [&]() {
+            bool all = true, same = true;
+            for (int k = 0; k < 2; k++) {
+                const int dn = k == 0 ? dn0 : dn1;
+                if (dn < 0) continue;
+                const uint32_t v = __hip_atomic_load(progress + (size_t)dn * 32 + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - epoch;
+                if (v == 0u || v > 16u) all = false; else same = same && v - 1u == my_xcc;
+            }
+            if (all) { dn_known = true; same_xcd = same; }
+        };
+        if (!dn_known) look_down();
         lds_barrier();          // table cleared
         // One pass of slack for the acknowledgement: the colours of pass i are sent after barrier i, and "pass i - 1 complete" is
         // published once all but that newest store instruction have been acknowledged (this wavefront issues nothing but stores,
@@ -504,6 +521,7 @@ __global__ __launch_bounds__(32 * G + 64) void k_atrous_stream(const AtrousParam
         bool have_prev = false;
         for (uint32_t i = first; i < end; i++) {
             const uint32_t lv_next = i + 1 < end ? pass_level[i + 1] : (uint32_t)levels;
+            if (!dn_known) look_down();         // (its loads have returned before this pass's stores are issued: the count below sees stores only)
             lds_barrier();      // end of pass i: its colours are in the window, its entries in out_slot[i & 1]
             bool any = false;
             for (int l = lane; l < 4 * G; l += 64) {
@@ -1108,16 +1126,16 @@ int ycge_launch_atrous_inplace(int w, int h, int step, const float phi[4], float
 // value that grows by more than the group count from call to call (the host's running sum)
 int ycge_launch_atrous_persist(int w, int h, int step, const float phi[4], float *buf, const uint8_t *sky, float *statw, const uint32_t *d_pixels,
                                const uint32_t *d_offsets, const uint32_t *d_pass_level, const int32_t *d_band_desc, int n_levels, int n_bands, int K, int groups_per_pass, int rows_per_band, unsigned window_width,
-                               uint32_t *progress, uint32_t epoch, int xcd_local, int level_handover, int profile, hipStream_t stream)
+                               uint32_t *progress, uint32_t epoch, int xcd_local, int level_handover, int profile, uint32_t ticket_base, hipStream_t stream)
 {
     ycge::AtrousParams A = {w, h, step, phi[0], phi[1], phi[2], phi[3]};
     const int per_xcd = (n_bands + 7) / 8;
     const dim3 grid((unsigned)(xcd_local ? 8 * per_xcd : n_bands));
     if (level_handover) {       // 8 or 16 pixels a pass: the publishing wavefront is the workgroup's 5th or 9th
-        if (groups_per_pass == 8) hipLaunchKernelGGL((ycge::k_atrous_stream<8, false>), grid, dim3(256 + 64), 0, stream, A, buf, statw, sky, d_pixels, d_offsets, d_pass_level, d_band_desc, n_levels, n_bands, rows_per_band, window_width, progress, epoch, xcd_local);
-        else if (groups_per_pass == 16 && d_band_desc && !profile) hipLaunchKernelGGL((ycge::k_atrous_stream<16, false, true>), grid, dim3(512 + 64), 0, stream, A, buf, statw, sky, d_pixels, d_offsets, d_pass_level, d_band_desc, n_levels, n_bands, rows_per_band, window_width, progress, epoch, xcd_local);
-        else if (groups_per_pass == 16 && !profile) hipLaunchKernelGGL((ycge::k_atrous_stream<16, false>), grid, dim3(512 + 64), 0, stream, A, buf, statw, sky, d_pixels, d_offsets, d_pass_level, d_band_desc, n_levels, n_bands, rows_per_band, window_width, progress, epoch, xcd_local);
-        else if (groups_per_pass == 16) hipLaunchKernelGGL((ycge::k_atrous_stream<16, true>), grid, dim3(512 + 64), 0, stream, A, buf, statw, sky, d_pixels, d_offsets, d_pass_level, d_band_desc, n_levels, n_bands, rows_per_band, window_width, progress, epoch, xcd_local);
+        if (groups_per_pass == 8) hipLaunchKernelGGL((ycge::k_atrous_stream<8, false>), grid, dim3(256 + 64), 0, stream, A, buf, statw, sky, d_pixels, d_offsets, d_pass_level, d_band_desc, n_levels, n_bands, rows_per_band, window_width, progress, epoch, xcd_local, ticket_base);
+        else if (groups_per_pass == 16 && d_band_desc && !profile) hipLaunchKernelGGL((ycge::k_atrous_stream<16, false, true>), grid, dim3(512 + 64), 0, stream, A, buf, statw, sky, d_pixels, d_offsets, d_pass_level, d_band_desc, n_levels, n_bands, rows_per_band, window_width, progress, epoch, xcd_local, ticket_base);
+        else if (groups_per_pass == 16 && !profile) hipLaunchKernelGGL((ycge::k_atrous_stream<16, false>), grid, dim3(512 + 64), 0, stream, A, buf, statw, sky, d_pixels, d_offsets, d_pass_level, d_band_desc, n_levels, n_bands, rows_per_band, window_width, progress, epoch, xcd_local, ticket_base);
+        else if (groups_per_pass == 16) hipLaunchKernelGGL((ycge::k_atrous_stream<16, true>), grid, dim3(512 + 64), 0, stream, A, buf, statw, sky, d_pixels, d_offsets, d_pass_level, d_band_desc, n_levels, n_bands, rows_per_band, window_width, progress, epoch, xcd_local, ticket_base);
         else return (int)hipErrorInvalidValue;
         return (int)hipGetLastError();
     }
