@@ -138,27 +138,62 @@ __global__ __launch_bounds__(256) void k_atrous(const AtrousParams A, const floa
 // atrous_tap_weight, the same expressions): an in-place iteration changes colours only, so these are computed for every
 // (pixel, tap) by the whole chip before the iteration starts instead of inside its serial chain of levels - there a band
 // is ONE workgroup, and four binary64 exponentials per tap made a level's time the fp64 issue rate of one CU.
-// statw[(p * 25 + tap) * 3 + {0, 1, 2}] = wn, wz, wa.  32 lanes per pixel, 25 of them with a tap.
+// statw[(p * 25 + tap) * 3 + {0, 1, 2}] = wn, wz, wa.
+// The three factors are symmetric in the two pixels of a tap - the dot product's terms commute, |a - b| = |b - a| bit for bit - so
+// a pair of pixels is evaluated ONCE, by the one that comes first in scan order, and stored in both records: tap t of p and tap
+// 24 - t of its partner.  16 lanes per pixel: lanes 0..12 take the centre tap and the 12 forward ones; a backward tap has no such
+// partner only where the border clamps it (the partner's forward tap would then not lead back here), and there the lane computes
+// it itself.  Half the binary64 exponentials, four pixels to a wavefront instead of two: 0.45 -> 0.32 ms at 1080p (beside iteration 0).
+__device__ __forceinline__ void static_factors(const AtrousParams &A, const float *albedo, const float *unit_n, const float *depth,
+                                               size_t p, size_t j, float &wn, float &wz, float &wa)
+{
+    const F3 n0 = ld3(unit_n, p), nj = ld3(unit_n, j), a0 = ld3(albedo, p), aj = ld3(albedo, j);
+    const float dn = cs_max(0.0f, 1.0f - dot(n0, nj));
+    const float dz = cs_abs(depth[j] - depth[p]);
+    const float da = cs_abs(aj.x - a0.x) + cs_abs(aj.y - a0.y) + cs_abs(aj.z - a0.z);
+    wn = m_exp(-dn / A.n_phi);
+    wz = m_exp(-dz / A.z_phi);
+    wa = m_exp(-(da) / A.a_phi);
+}
 __global__ __launch_bounds__(256) void k_atrous_static(const AtrousParams A, const float *__restrict__ albedo, const float *__restrict__ unit_n,
                                                        const float *__restrict__ depth, const uint8_t *__restrict__ sky, float *__restrict__ statw,
                                                        size_t n)
 {
     const size_t gid = (size_t)blockIdx.x * 256 + threadIdx.x;
-    const size_t p = gid >> 5;
-    const int t = (int)(gid & 31);
-    if (p >= n || t >= 25 || sky[p]) return;
+    const size_t p = gid >> 4;
+    const int l = (int)(gid & 15);
+    if (p >= n || sky[p]) return;
     const int x = (int)(p % (size_t)A.w), y = (int)(p / (size_t)A.w);
-    const int kx = t % 5 - 2, ky = t / 5 - 2;
-    const size_t j = atrous_tap_index(A, x, y, kx, ky);
-    if (sky[j]) return;                         // a tap the reference skips: its weight is never read
-    const F3 n0 = ld3(unit_n, p), nj = ld3(unit_n, j), a0 = ld3(albedo, p), aj = ld3(albedo, j);
-    const float dn = cs_max(0.0f, 1.0f - dot(n0, nj));
-    const float dz = cs_abs(depth[j] - depth[p]);
-    const float da = cs_abs(aj.x - a0.x) + cs_abs(aj.y - a0.y) + cs_abs(aj.z - a0.z);
-    float *o = statw + (p * 25 + (size_t)t) * 3;
-    o[0] = m_exp(-dn / A.n_phi);
-    o[1] = m_exp(-dz / A.z_phi);
-    o[2] = m_exp(-(da) / A.a_phi);
+    if (l < 13) {                               // the centre tap (12) and the forward taps 13..24
+        const int t = 12 + l;
+        const int kx = t % 5 - 2, ky = t / 5 - 2;
+        const size_t j = atrous_tap_index(A, x, y, kx, ky);
+        if (!sky[j]) {                          // (a tap the reference skips: its weight is never read)
+            float wn, wz, wa;
+            static_factors(A, albedo, unit_n, depth, p, j, wn, wz, wa);
+            float *o = statw + (p * 25 + (size_t)t) * 3;
+            o[0] = wn; o[1] = wz; o[2] = wa;
+            const int sx = x + kx * A.step, sy = y + ky * A.step;
+            if (l > 0 && sx >= 0 && sx < A.w && sy >= 0 && sy < A.h) {      // not clamped: this pixel is tap 24 - t of j
+                float *o2 = statw + (j * 25 + (size_t)(24 - t)) * 3;
+                o2[0] = wn; o2[1] = wz; o2[2] = wa;
+            }
+        }
+    }
+    if (l < 12) {                               // a backward tap the border clamps: nobody else writes it
+        const int t = l;
+        const int kx = t % 5 - 2, ky = t / 5 - 2;
+        const int sx = x + kx * A.step, sy = y + ky * A.step;
+        if (sx < 0 || sx >= A.w || sy < 0 || sy >= A.h) {
+            const size_t j = atrous_tap_index(A, x, y, kx, ky);
+            if (!sky[j]) {
+                float wn, wz, wa;
+                static_factors(A, albedo, unit_n, depth, p, j, wn, wz, wa);
+                float *o = statw + (p * 25 + (size_t)t) * 3;
+                o[0] = wn; o[1] = wz; o[2] = wa;
+            }
+        }
+    }
 }
 
 // ---- in-place iteration.  The image is cut into bands of whole rows, one 1024-thread workgroup per band; a band's pixels
@@ -1098,7 +1133,7 @@ int ycge_launch_atrous_static(int w, int h, int step, const float phi[4], const 
 {
     ycge::AtrousParams A = {w, h, step, phi[0], phi[1], phi[2], phi[3]};
     const size_t n = (size_t)w * h;
-    hipLaunchKernelGGL(ycge::k_atrous_static, dim3((unsigned)((n * 32 + 255) / 256)), dim3(256), 0, stream, A, albedo, unit_n, depth, sky, statw, n);
+    hipLaunchKernelGGL(ycge::k_atrous_static, dim3((unsigned)((n * 16 + 255) / 256)), dim3(256), 0, stream, A, albedo, unit_n, depth, sky, statw, n);
     return (int)hipGetLastError();
 }
 
