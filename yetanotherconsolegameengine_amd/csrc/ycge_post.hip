@@ -63,6 +63,14 @@ __device__ __forceinline__ size_t atrous_tap_index(const AtrousParams &A, int x,
     if (sx < 0) sx = 0; else if (sx >= A.w) sx = A.w - 1;
     return (size_t)sx + (size_t)sy * A.w;
 }
+// m_exp(-d / phi).  exp(-0) is exactly 1 (m_exp_d: k = 0, r = -0, every Horner step p * -0 + c = c), and whole wavefronts agree on
+// d == 0 all the time - one material (albedo distance 0), a flat axis-aligned surface (normal distance 0), the centre tap (luminance,
+// depth, albedo): then the ~60 binary64 instructions are skipped.  Per wavefront, never per lane: a lane saves nothing by itself.
+__device__ __forceinline__ float exp_neg_ratio(float d, float phi)
+{
+    if (!__any(d != 0.0f)) return 1.0f;
+    return m_exp(-d / phi);
+}
 __device__ __forceinline__ float atrous_tap_weight(const AtrousParams &A, int kx, int ky, const Center &C, F3 c, F3 a, F3 n, float z)
 {
     const float wy = kernel_tap(ky);
@@ -74,10 +82,10 @@ __device__ __forceinline__ float atrous_tap_weight(const AtrousParams &A, int kx
     const float dn = cs_max(0.0f, 1.0f - dot(C.n0, n));
     const float dz = cs_abs(z - C.z0);
     const float da = cs_abs(a.x - C.a0.x) + cs_abs(a.y - C.a0.y) + cs_abs(a.z - C.a0.z);
-    const float wc = m_exp(-dl / A.c_phi);
-    const float wn = m_exp(-dn / A.n_phi);
-    const float wz = m_exp(-dz / A.z_phi);
-    const float wa = m_exp(-(da) / A.a_phi);
+    const float wc = exp_neg_ratio(dl, A.c_phi);
+    const float wn = exp_neg_ratio(dn, A.n_phi);
+    const float wz = exp_neg_ratio(dz, A.z_phi);
+    const float wa = exp_neg_ratio(da, A.a_phi);
     return w_base * wc * wn * wz * wa;
 }
 // Returns false for a tap the reference skips (`continue`).
@@ -151,9 +159,9 @@ __device__ __forceinline__ void static_factors(const AtrousParams &A, const floa
     const float dn = cs_max(0.0f, 1.0f - dot(n0, nj));
     const float dz = cs_abs(depth[j] - depth[p]);
     const float da = cs_abs(aj.x - a0.x) + cs_abs(aj.y - a0.y) + cs_abs(aj.z - a0.z);
-    wn = m_exp(-dn / A.n_phi);
-    wz = m_exp(-dz / A.z_phi);
-    wa = m_exp(-(da) / A.a_phi);
+    wn = exp_neg_ratio(dn, A.n_phi);
+    wz = exp_neg_ratio(dz, A.z_phi);
+    wa = exp_neg_ratio(da, A.a_phi);
 }
 __global__ __launch_bounds__(256) void k_atrous_static(const AtrousParams A, const float *__restrict__ albedo, const float *__restrict__ unit_n,
                                                        const float *__restrict__ depth, const uint8_t *__restrict__ sky, float *__restrict__ statw,
