@@ -89,6 +89,26 @@ def test_timed_voxel_stage_kernels_full_size(product_lib, oracle, monkeypatch):
     o.close(); g.close()
 
 
+@pytest.mark.parametrize("ypath", ["wavefront", "megakernel"])
+def test_timed_voxel_kernels_skip_grids_the_ray_cannot_hit(product_lib, oracle, monkeypatch, ypath):
+    """The non-counting kernels do not enter a grid whose solid voxels the ray misses (grid_cull: the box of the solid voxels, one
+    voxel of margin); the counting ones walk it as VolumeGrid.Hit does.  Same pixels either way, from poses that put the decision on
+    the spot: above the terrain looking along the chunk tops (rays graze the boxes), straight down and straight along an axis
+    (direction components of exactly 0: 0 x inf in the slab test), inside a chunk's air, far outside the world."""
+    monkeypatch.setenv("YCGE_PATH", ypath)
+    sc, w, h, ss, pose = scenes.config_scene(5, small=True)
+    poses = [pose,
+             dict(pose, pitch=0.0), dict(pose, yaw=0.0, pitch=-1.5707964), dict(pose, yaw=1.5707964, pitch=0.0),
+             dict(pose, pos=(pose["pos"][0], pose["pos"][1] + 40.0, pose["pos"][2]), pitch=-0.05),
+             dict(pose, pos=(pose["pos"][0] - 300.0, pose["pos"][1] + 10.0, pose["pos"][2]), yaw=1.5707964, pitch=-0.02)]
+    for k, ps in enumerate(poses):
+        o, g = pu.run_pair(oracle, sc, 96, 27, 2, ps, frames=1, oracle_threads=16, count=False)
+        _assert_frame(o, g, f"{ypath} pose {k} frame 1")
+        o.render(stages=1, threads=16); g.TryFlipAndBlit()
+        _assert_frame(o, g, f"{ypath} pose {k} frame 2")
+        o.close(); g.close()
+
+
 def test_one_call_drives_several_devices(product_lib, oracle, monkeypatch):
     """config.n_devices = 2: ONE ycge_render_frame call traces the frame on two device contexts (here both on GPU 0 - the
     driver's box has one), the peer pushes its tiles straight into rank 0's frame buffers, TAA and the post stage run on

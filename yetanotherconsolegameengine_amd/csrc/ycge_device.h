@@ -129,9 +129,13 @@ struct alignas(16) GGrid {
     uint32_t lut_offset;        // index of this grid's first entry in grid_lut (cell code -> material)
     uint32_t brick_mask_lo, brick_mask_hi;   // bit b set = brick b holds a solid voxel (grids of <= 64 bricks, e.g. 32^3 chunks)
     int32_t has_brick_mask;
-    uint32_t pad[4];
+    // World-space box of the grid's SOLID voxels, one voxel wider on every side (solid_hi[0] < solid_lo[0]: no solid voxel).  A ray
+    // that misses it between tmin and tmax cannot hit anything here - the voxel walk's rounding errors are ~1e-5 of a voxel - so the
+    // timed kernels do not enter the grid at all (grid_cull); the counting kernels walk it as the reference does.
+    float solid_lo[3], solid_hi[3];
+    uint32_t pad[2];
 };
-static_assert(sizeof(GGrid) == 96, "GGrid must be 96 B");
+static_assert(sizeof(GGrid) == 112, "GGrid must be 112 B");
 
 struct GLight {
     float pos[3];

@@ -1114,6 +1114,7 @@ int ycge_scene_upload(ycge_ctx *c, const ycge_scene *s)
         lut.push_back(-1);
         const bool maskable = (size_t)G.nbx * G.nby * G.nbz <= 64;
         uint64_t brick_mask = 0;
+        int lo[3] = {g.nx, g.ny, g.nz}, hi[3] = {-1, -1, -1};          // index box of the solid voxels
         for (int iz = 0; iz < g.nz; iz++)
             for (int iy = 0; iy < g.ny; iy++)
                 for (int ix = 0; ix < g.nx; ix++) {
@@ -1134,7 +1135,14 @@ int ycge_scene_upload(ycge_ctx *c, const ycge_scene *s)
                     const int brick = (((iz >> 3) * G.nby) + (iy >> 3)) * G.nbx + (ix >> 3);
                     cells[off + (size_t)brick * 512 + morton3(ix & 7, iy & 7, iz & 7)] = (uint8_t)code;
                     if (maskable) brick_mask |= (uint64_t)1 << brick;
+                    if (ix < lo[0]) lo[0] = ix; if (ix > hi[0]) hi[0] = ix;
+                    if (iy < lo[1]) lo[1] = iy; if (iy > hi[1]) hi[1] = iy;
+                    if (iz < lo[2]) lo[2] = iz; if (iz > hi[2]) hi[2] = iz;
                 }
+        for (int a = 0; a < 3; a++) {           // one voxel of margin on every side (GGrid::solid_lo / solid_hi)
+            G.solid_lo[a] = hi[a] < 0 ? 1.0f : G.min_corner[a] + (float)(lo[a] - 1) * G.voxel_size[a];
+            G.solid_hi[a] = hi[a] < 0 ? 0.0f : G.min_corner[a] + (float)(hi[a] + 2) * G.voxel_size[a];
+        }
         G.has_brick_mask = maskable ? 1 : 0;
         G.brick_mask_lo = (uint32_t)brick_mask; G.brick_mask_hi = (uint32_t)(brick_mask >> 32);
     }

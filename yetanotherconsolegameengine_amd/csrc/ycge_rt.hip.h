@@ -469,6 +469,22 @@ __device__ __forceinline__ bool grid_slab(float ro, float rd, float inv, float m
 // x / s with the exact shortcut x / 1.0f == x (every voxel world of the reference has unit voxels)
 __device__ __forceinline__ float div_by_size(float x, float s) { return s == 1.0f ? x : x / s; }
 
+// true: between tmin and tmax the ray stays outside the box of the grid's solid voxels (GGrid::solid_lo / solid_hi, one voxel of
+// margin): VolumeGrid.Hit would walk through air and return false, so the timed kernels skip the walk (a bounce ray that leaves
+// the ground crosses the empty upper part of chunk after chunk).  Not in the counting kernels: their voxel-step and grid-entry
+// counters are the reference's.  A NaN (0 * inf: ray parallel to a face, origin in its plane) is a point one voxel away from
+// every solid voxel: either outcome of the comparison is right.
+__device__ __forceinline__ bool grid_cull(const GGrid &g, F3 o, F3 inv, float tmin, float tmax)
+{
+    if (g.solid_hi[0] < g.solid_lo[0]) return true;
+    const float ax = (g.solid_lo[0] - o.x) * inv.x, bx = (g.solid_hi[0] - o.x) * inv.x;
+    const float ay = (g.solid_lo[1] - o.y) * inv.y, by = (g.solid_hi[1] - o.y) * inv.y;
+    const float az = (g.solid_lo[2] - o.z) * inv.z, bz = (g.solid_hi[2] - o.z) * inv.z;
+    const float t_in = fmaxf(fmaxf(fminf(ax, bx), fminf(ay, by)), fminf(az, bz));
+    const float t_out = fminf(fminf(fmaxf(ax, bx), fmaxf(ay, by)), fmaxf(az, bz));
+    return t_in > t_out || t_out < tmin || t_in > tmax;
+}
+
 // VolumeGrid.Hit, VolumeGrid.cs:99-231 (Amanatides-Woo DDA; first cell with matId > 0 hits).
 // Every floating-point step of the C# is performed (the t of a hit is the running sum of its tDelta
 // additions), but cell bytes are only FETCHED inside bricks the grid's 64-bit occupancy mask marks
@@ -479,6 +495,7 @@ __device__ __forceinline__ void grid_dda(const SceneDev &S, int grid_index_, int
 {
     if (COUNT) { w.prim++; prof_tick(2); }
     const GGrid g = S.grids[grid_index_];
+    if (!COUNT && grid_cull(g, o, inv, tmin, closest)) return;
     const float min_x = g.min_corner[0], min_y = g.min_corner[1], min_z = g.min_corner[2];
     const float size_x = g.voxel_size[0], size_y = g.voxel_size[1], size_z = g.voxel_size[2];
     const float max_x = min_x + (float)g.nx * size_x, max_y = min_y + (float)g.ny * size_y, max_z = min_z + (float)g.nz * size_z;
@@ -558,6 +575,7 @@ __device__ __forceinline__ bool dda_begin(const SceneDev &S, int grid_index_, in
 {
     if (COUNT) { w.prim++; prof_tick(2); }
     const GGrid g = S.grids[grid_index_];
+    if (!COUNT && grid_cull(g, o, inv, tmin, closest)) return false;
     const float min_x = g.min_corner[0], min_y = g.min_corner[1], min_z = g.min_corner[2];
     const float size_x = g.voxel_size[0], size_y = g.voxel_size[1], size_z = g.voxel_size[2];
     const float max_x = min_x + (float)g.nx * size_x, max_y = min_y + (float)g.ny * size_y, max_z = min_z + (float)g.nz * size_z;
