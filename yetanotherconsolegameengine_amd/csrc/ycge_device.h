@@ -89,6 +89,7 @@ struct alignas(16) GPrim {
     //  BOX        min xyz max xyz
     //  CYLINDER_Y cx cz radius radius2 yMin yMax capped
     //  TRIANGLE   A xyz e1 xyz e2 xyz n xyz
+    //  VOLUME_GRID  box of the grid's solid voxels, one voxel of margin: lo xyz, hi xyz (GGrid::solid_lo / solid_hi)
     float p[12];
 };
 static_assert(sizeof(GPrim) == 64, "GPrim must be 64 B");

@@ -233,6 +233,7 @@ struct ycge_ctx {
     // what ycge_scene_update_objects needs from the last full upload
     std::vector<GMesh> gmeshes_host;
     std::vector<std::array<float, 6>> grid_bounds;   // VolumeGrid.TryGetBounds per grid; max < min marks an empty grid
+    std::vector<std::array<float, 6>> grid_solid;    // GGrid::solid_lo / solid_hi per grid (copied into the grid's object record: the walk culls before it enters)
     int n_materials = 0, max_mesh_depth = 0;
     bool materials_can_mirror = false;
     const float *denoised = nullptr;              // result of the last post stage (one of den_a / den_b / taa_hist)
@@ -804,6 +805,7 @@ int flatten_objects(ycge_ctx *c, const ycge_prim *prims, int n_prims, ObjectsHos
         }
         case YCGE_PRIM_VOLUME_GRID:
             if (q.ref < 0 || q.ref >= (int)c->grid_bounds.size()) return c->fail(YCGE_ERR_INVALID_ARG, "prim %d: grid ref out of range", i);
+            for (int k = 0; k < 6; k++) g.p[k] = c->grid_solid[q.ref][k];       // box of the grid's solid voxels (grid_cull in the walk)
             break;
         default: return c->fail(YCGE_ERR_INVALID_ARG, "prim %d: unknown type %d", i, q.type);
         }
@@ -1161,6 +1163,9 @@ int ycge_scene_upload(ycge_ctx *c, const ycge_scene *s)
         c->grid_bounds[gi] = {{g.min_corner.x, g.min_corner.y, g.min_corner.z, g.min_corner.x + (float)g.nx * vs[0],
                                g.min_corner.y + (float)g.ny * vs[1], g.min_corner.z + (float)g.nz * vs[2]}};
     }
+    c->grid_solid.resize(s->n_grids);
+    for (int gi = 0; gi < s->n_grids; gi++)
+        for (int a = 0; a < 3; a++) { c->grid_solid[gi][a] = A.ggrids[gi].solid_lo[a]; c->grid_solid[gi][3 + a] = A.ggrids[gi].solid_hi[a]; }
     A.has_grid = s->n_grids > 0;
 
     // ---- Scene.Objects + scene BVH, then every device gets the same arrays

@@ -474,15 +474,19 @@ __device__ __forceinline__ float div_by_size(float x, float s) { return s == 1.0
 // the ground crosses the empty upper part of chunk after chunk).  Not in the counting kernels: their voxel-step and grid-entry
 // counters are the reference's.  A NaN (0 * inf: ray parallel to a face, origin in its plane) is a point one voxel away from
 // every solid voxel: either outcome of the comparison is right.
-__device__ __forceinline__ bool grid_cull(const GGrid &g, F3 o, F3 inv, float tmin, float tmax)
+__device__ __forceinline__ bool solid_box_missed(float lx, float ly, float lz, float hx, float hy, float hz, F3 o, F3 inv, float tmin, float tmax)
 {
-    if (g.solid_hi[0] < g.solid_lo[0]) return true;
-    const float ax = (g.solid_lo[0] - o.x) * inv.x, bx = (g.solid_hi[0] - o.x) * inv.x;
-    const float ay = (g.solid_lo[1] - o.y) * inv.y, by = (g.solid_hi[1] - o.y) * inv.y;
-    const float az = (g.solid_lo[2] - o.z) * inv.z, bz = (g.solid_hi[2] - o.z) * inv.z;
+    if (hx < lx) return true;                   // no solid voxel at all
+    const float ax = (lx - o.x) * inv.x, bx = (hx - o.x) * inv.x;
+    const float ay = (ly - o.y) * inv.y, by = (hy - o.y) * inv.y;
+    const float az = (lz - o.z) * inv.z, bz = (hz - o.z) * inv.z;
     const float t_in = fmaxf(fmaxf(fminf(ax, bx), fminf(ay, by)), fminf(az, bz));
     const float t_out = fminf(fminf(fmaxf(ax, bx), fmaxf(ay, by)), fmaxf(az, bz));
     return t_in > t_out || t_out < tmin || t_in > tmax;
+}
+__device__ __forceinline__ bool grid_cull(const GGrid &g, F3 o, F3 inv, float tmin, float tmax)
+{
+    return solid_box_missed(g.solid_lo[0], g.solid_lo[1], g.solid_lo[2], g.solid_hi[0], g.solid_hi[1], g.solid_hi[2], o, inv, tmin, tmax);
 }
 
 // VolumeGrid.Hit, VolumeGrid.cs:99-231 (Amanatides-Woo DDA; first cell with matId > 0 hits).
@@ -575,7 +579,6 @@ __device__ __forceinline__ bool dda_begin(const SceneDev &S, int grid_index_, in
 {
     if (COUNT) { w.prim++; prof_tick(2); }
     const GGrid g = S.grids[grid_index_];
-    if (!COUNT && grid_cull(g, o, inv, tmin, closest)) return false;
     const float min_x = g.min_corner[0], min_y = g.min_corner[1], min_z = g.min_corner[2];
     const float size_x = g.voxel_size[0], size_y = g.voxel_size[1], size_z = g.voxel_size[2];
     const float max_x = min_x + (float)g.nx * size_x, max_y = min_y + (float)g.ny * size_y, max_z = min_z + (float)g.nz * size_z;
@@ -916,7 +919,12 @@ __device__ __forceinline__ int tree_phase(const SceneDev &S, uint32_t &cur, int 
             const int type = __float_as_int(q0.x);
             cur = YCGE_REF_NONE_VALUE;
             if (type == 10) {
-                if (HAS_GRID) { parked_grid = __float_as_int(q0.z); parked_prim = (int)pay; return TREE_AT_GRID; }
+                if (HAS_GRID) {
+                    // (the object record carries the box of the grid's solid voxels: a grid the ray cannot hit costs this test, not the
+                    // rest of the lane's tree steps of the round plus a voxel phase spent waiting - see grid_cull)
+                    if (!COUNT) { const float4 q1 = pp[1]; const float2 q2 = *(const float2 *)(pp + 2); if (solid_box_missed(q1.x, q1.y, q1.z, q1.w, q2.x, q2.y, o, inv, tmin, closest)) continue; }
+                    parked_grid = __float_as_int(q0.z); parked_prim = (int)pay; return TREE_AT_GRID;
+                }
             } else {
                 const float4 q1 = pp[1], q2 = pp[2], q3 = pp[3];
                 if (type == 9) {    // Mesh.Hit -> MeshBVH.Hit: root pushed, popped, own box tested (p = root box, ref)
