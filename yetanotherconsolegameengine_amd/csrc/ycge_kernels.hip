@@ -284,10 +284,11 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu((HAS_GRID &&
         // steps for the lanes inside a grid (their state persists in D); lanes that finish are refilled at the top
         if (have && more && !in_dda) {
             int parked_grid = -1, parked_prim = -1;
+            float parked_tend = YCGE_INF;       // where the ray leaves the box of the grid's solid voxels: the walk ends there (timed kernels)
             const int r = tree_phase<COUNT, HAS_GRID>(S, cur, mesh_prim, st, o, d, inv, sx, sy, sz, tmin, closest, hit_prim, hit_sub, parked_grid,
-                                                      parked_prim, w, round_tree_steps);
+                                                      parked_prim, parked_tend, w, round_tree_steps);
             if (r == TREE_DONE) more = false;
-            if (HAS_GRID && r == TREE_AT_GRID) in_dda = dda_begin<COUNT>(S, parked_grid, parked_prim, o, d, inv, tmin, closest, D, w);
+            if (HAS_GRID && r == TREE_AT_GRID) in_dda = dda_begin<COUNT>(S, parked_grid, parked_prim, o, d, inv, tmin, COUNT ? closest : fminf(closest, parked_tend), D, w);
         }
         if (HAS_GRID && in_dda) {
             bool in = true;

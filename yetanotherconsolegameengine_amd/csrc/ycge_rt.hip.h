@@ -474,19 +474,23 @@ __device__ __forceinline__ float div_by_size(float x, float s) { return s == 1.0
 // the ground crosses the empty upper part of chunk after chunk).  Not in the counting kernels: their voxel-step and grid-entry
 // counters are the reference's.  A NaN (0 * inf: ray parallel to a face, origin in its plane) is a point one voxel away from
 // every solid voxel: either outcome of the comparison is right.
-__device__ __forceinline__ bool solid_box_missed(float lx, float ly, float lz, float hx, float hy, float hz, F3 o, F3 inv, float tmin, float tmax)
+// t_out: where the ray leaves the box - beyond it the walk meets air only, so the timed kernels end it there (a ray that rises from
+// the ground stops two voxels above the chunk's highest block instead of at the chunk's top).
+__device__ __forceinline__ bool solid_box_missed(float lx, float ly, float lz, float hx, float hy, float hz, F3 o, F3 inv, float tmin, float tmax,
+                                                 float &t_out)
 {
+    t_out = YCGE_INF;
     if (hx < lx) return true;                   // no solid voxel at all
     const float ax = (lx - o.x) * inv.x, bx = (hx - o.x) * inv.x;
     const float ay = (ly - o.y) * inv.y, by = (hy - o.y) * inv.y;
     const float az = (lz - o.z) * inv.z, bz = (hz - o.z) * inv.z;
     const float t_in = fmaxf(fmaxf(fminf(ax, bx), fminf(ay, by)), fminf(az, bz));
-    const float t_out = fminf(fminf(fmaxf(ax, bx), fmaxf(ay, by)), fmaxf(az, bz));
+    t_out = fminf(fminf(fmaxf(ax, bx), fmaxf(ay, by)), fmaxf(az, bz));
     return t_in > t_out || t_out < tmin || t_in > tmax;
 }
-__device__ __forceinline__ bool grid_cull(const GGrid &g, F3 o, F3 inv, float tmin, float tmax)
+__device__ __forceinline__ bool grid_cull(const GGrid &g, F3 o, F3 inv, float tmin, float tmax, float &t_out)
 {
-    return solid_box_missed(g.solid_lo[0], g.solid_lo[1], g.solid_lo[2], g.solid_hi[0], g.solid_hi[1], g.solid_hi[2], o, inv, tmin, tmax);
+    return solid_box_missed(g.solid_lo[0], g.solid_lo[1], g.solid_lo[2], g.solid_hi[0], g.solid_hi[1], g.solid_hi[2], o, inv, tmin, tmax, t_out);
 }
 
 // VolumeGrid.Hit, VolumeGrid.cs:99-231 (Amanatides-Woo DDA; first cell with matId > 0 hits).
@@ -499,11 +503,12 @@ __device__ __forceinline__ void grid_dda(const SceneDev &S, int grid_index_, int
 {
     if (COUNT) { w.prim++; prof_tick(2); }
     const GGrid g = S.grids[grid_index_];
-    if (!COUNT && grid_cull(g, o, inv, tmin, closest)) return;
+    float t_solid_out = YCGE_INF;
+    if (!COUNT && grid_cull(g, o, inv, tmin, closest, t_solid_out)) return;
     const float min_x = g.min_corner[0], min_y = g.min_corner[1], min_z = g.min_corner[2];
     const float size_x = g.voxel_size[0], size_y = g.voxel_size[1], size_z = g.voxel_size[2];
     const float max_x = min_x + (float)g.nx * size_x, max_y = min_y + (float)g.ny * size_y, max_z = min_z + (float)g.nz * size_z;
-    const float tmax = closest;
+    const float tmax = COUNT ? closest : fminf(closest, t_solid_out);       // (only the loop's end test reads it)
     int enter_axis = -1;
     float t_enter = -YCGE_INF, t_exit = YCGE_INF;
     if (!grid_slab(o.x, d.x, inv.x, min_x, max_x, t_enter, t_exit, 0, enter_axis)) return;
@@ -872,8 +877,8 @@ __device__ __forceinline__ void leaf_triangles(const SceneDev &S, uint32_t pay, 
 enum : int { TREE_DONE = 0, TREE_AT_GRID = 1, TREE_YIELD = 2 };
 template <bool COUNT, bool HAS_GRID, class STK>
 __device__ __forceinline__ int tree_phase(const SceneDev &S, uint32_t &cur, int &mesh_prim, STK &st, F3 o, F3 d, F3 inv, bool sx, bool sy, bool sz,
-                                          float tmin, float &closest, int &hit_prim, int &hit_sub, int &parked_grid, int &parked_prim, Work &w,
-                                          int budget = 0x7fffffff, bool anyhit = false)
+                                          float tmin, float &closest, int &hit_prim, int &hit_sub, int &parked_grid, int &parked_prim, float &parked_tend,
+                                          Work &w, int budget = 0x7fffffff, bool anyhit = false)
 {
     for (;;) {
         if (!COUNT && anyhit && hit_prim >= 0) { st.reset(); cur = YCGE_REF_NONE_VALUE; return TREE_DONE; }      // occlusion query answered
@@ -922,7 +927,7 @@ __device__ __forceinline__ int tree_phase(const SceneDev &S, uint32_t &cur, int 
                 if (HAS_GRID) {
                     // (the object record carries the box of the grid's solid voxels: a grid the ray cannot hit costs this test, not the
                     // rest of the lane's tree steps of the round plus a voxel phase spent waiting - see grid_cull)
-                    if (!COUNT) { const float4 q1 = pp[1]; const float2 q2 = *(const float2 *)(pp + 2); if (solid_box_missed(q1.x, q1.y, q1.z, q1.w, q2.x, q2.y, o, inv, tmin, closest)) continue; }
+                    if (!COUNT) { const float4 q1 = pp[1]; const float2 q2 = *(const float2 *)(pp + 2); if (solid_box_missed(q1.x, q1.y, q1.z, q1.w, q2.x, q2.y, o, inv, tmin, closest, parked_tend)) continue; }
                     parked_grid = __float_as_int(q0.z); parked_prim = (int)pay; return TREE_AT_GRID;
                 }
             } else {
@@ -952,8 +957,9 @@ __device__ __forceinline__ void walk(const SceneDev &S, uint32_t cur, int mesh_p
     bool more = cur != YCGE_REF_NONE_VALUE;      // the stack is empty at entry
     for (;;) {
         int parked_grid = -1, parked_prim = -1;
+        float parked_tend = YCGE_INF;       // (grid_dda finds the end of the solid box itself)
         bool parked = false;
-        if (more) parked = tree_phase<COUNT, HAS_GRID>(S, cur, mesh_prim, st, o, d, inv, sx, sy, sz, tmin, closest, hit_prim, hit_sub, parked_grid, parked_prim, w, 0x7fffffff, anyhit) == TREE_AT_GRID;
+        if (more) parked = tree_phase<COUNT, HAS_GRID>(S, cur, mesh_prim, st, o, d, inv, sx, sy, sz, tmin, closest, hit_prim, hit_sub, parked_grid, parked_prim, parked_tend, w, 0x7fffffff, anyhit) == TREE_AT_GRID;
         more = parked;
         if (!HAS_GRID) break;
         if (!__any(parked)) break;
