@@ -209,8 +209,8 @@ __global__ __launch_bounds__(256) void k_wf_extend(const SceneDev S, const Trace
 // Used for the continuation (bounce / mirror) rays.  The shadow rays of the light loop were tried the same way
 // (one ray per (light record, light), contributions applied in light order afterwards): no gain - they all aim
 // at the same light, their lengths are alike, and k_wf_lights already keeps 53 % of its lanes busy.
-#define YCGE_ROUND_TREE_STEPS 3
-#define YCGE_ROUND_CELL_STEPS 8
+#define YCGE_ROUND_TREE_STEPS 6
+#define YCGE_ROUND_CELL_STEPS 10
 #ifndef YCGE_TRACEP_WAVES
 #define YCGE_TRACEP_WAVES 6          // persistent extend stage: 6 wavefronts per SIMD (85-VGPR budget) and 32 persistent wavefronts per CU: 12.35 -> 12.0 ms on the voxel world
 #endif
