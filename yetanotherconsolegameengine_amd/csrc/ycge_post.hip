@@ -619,9 +619,19 @@ __global__ __launch_bounds__(32 * G + 64) void k_atrous_stream(const AtrousParam
             if (((i - first) & 1u) == (uint32_t)set) {
                 const uint32_t p_new = entry(i + 4);
                 const int l_new = level_of(i + 4), s_new = sky_of(pnxt);
-                const int up_word = has_up ? look_up() : 0;             // in flight while this pass computes; read before the next fetch
+                // The words of the band(s) above, for the next fetch's decision: asked for here, looked at after the pass.  By hand:
+                // written as look_up() the compiler put the subtraction and the minimum - and with them a wait for these two
+                // device-coherent loads AND for the three list loads above - in FRONT of the pass, a round trip to memory in every
+                // level's chain.  (The compiler's own waits stay right: loads return in order, these are the newest.)
+                uint32_t w0 = 0, w1 = 0;
+                if (has_up) asm volatile("global_load_dword %0, %2, %3 sc1\n\tglobal_load_dword %1, %2, %4 sc1" : "=&v"(w0), "=&v"(w1) : "v"(0u), "s"(above), "s"(above2) : "memory");
                 pass_compute<true>(A, pcur, D, sh, &sh.out_slot[set][gl]);       // ends with the workgroup's barrier
-                if (has_up && up_word > up_seen) up_seen = up_word;
+                if (has_up) {
+                    asm volatile("s_waitcnt vmcnt(0)" : "+v"(w0), "+v"(w1) : : "memory");
+                    const int s0 = (int32_t)(w0 - epoch), s1 = (int32_t)(w1 - epoch);
+                    const int up_word = s0 < s1 ? s0 : s1;
+                    if (up_word > up_seen) up_seen = up_word;
+                }
                 pcur = pnxt; scur = s_new; lcur = lnxt; pnxt = p_new; lnxt = l_new;
             } else {
                 if (i + 1 < end) { wait_above(lcur); D = pass_fetch<true>(A, W, buf, statw, sky, pcur, t, scur); }
