@@ -613,12 +613,18 @@ __global__ __launch_bounds__(32 * G + 64) void k_atrous_stream(const AtrousParam
         int scur = set == 0 ? -1 : sky_of(pcur);
         PassData D;
         D.sky0 = 1;
-        if (set == 0) { wait_above(lcur); D = pass_fetch<true>(A, W, buf, statw, sky, pcur, t, scur); }
+        // list entry and level of the pass after next, sky flag of the next: asked for in the fetch phase (here for set 0's first
+        // pass), not at the head of the computing one - a level's chain starts at the barrier
+        uint32_t p_new = YCGE_POST_NONE;
+        int l_new = levels, s_new = 1;
+        if (set == 0) {
+            wait_above(lcur);
+            D = pass_fetch<true>(A, W, buf, statw, sky, pcur, t, scur);
+            p_new = entry(first + 4); l_new = level_of(first + 4); s_new = sky_of(pnxt);
+        }
         lds_barrier();              // table cleared
         for (uint32_t i = first; i < end; i++) {
             if (((i - first) & 1u) == (uint32_t)set) {
-                const uint32_t p_new = entry(i + 4);
-                const int l_new = level_of(i + 4), s_new = sky_of(pnxt);
                 // The words of the band(s) above, for the next fetch's decision: asked for here, looked at after the pass.  By hand:
                 // written as look_up() the compiler put the subtraction and the minimum - and with them a wait for these two
                 // device-coherent loads AND for the three list loads above - in FRONT of the pass, a round trip to memory in every
@@ -634,7 +640,11 @@ __global__ __launch_bounds__(32 * G + 64) void k_atrous_stream(const AtrousParam
                 }
                 pcur = pnxt; scur = s_new; lcur = lnxt; pnxt = p_new; lnxt = l_new;
             } else {
-                if (i + 1 < end) { wait_above(lcur); D = pass_fetch<true>(A, W, buf, statw, sky, pcur, t, scur); }
+                if (i + 1 < end) {
+                    wait_above(lcur);
+                    D = pass_fetch<true>(A, W, buf, statw, sky, pcur, t, scur);
+                    p_new = entry(i + 5); l_new = level_of(i + 5); s_new = sky_of(pnxt);
+                }
                 lds_barrier();
             }
         }
