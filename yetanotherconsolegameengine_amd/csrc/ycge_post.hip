@@ -617,10 +617,12 @@ __global__ __launch_bounds__(32 * G + 64) void k_atrous_stream(const AtrousParam
         // pass), not at the head of the computing one - a level's chain starts at the barrier
         uint32_t p_new = YCGE_POST_NONE;
         int l_new = levels, s_new = 1;
+        uint32_t w0 = epoch, w1 = epoch;
         if (set == 0) {
             wait_above(lcur);
             D = pass_fetch<true>(A, W, buf, statw, sky, pcur, t, scur);
             p_new = entry(first + 4); l_new = level_of(first + 4); s_new = sky_of(pnxt);
+            if (has_up) asm volatile("global_load_dword %0, %2, %3 sc1\n\tglobal_load_dword %1, %2, %4 sc1" : "=&v"(w0), "=&v"(w1) : "v"(0u), "s"(above), "s"(above2) : "memory");
         }
         lds_barrier();              // table cleared
         for (uint32_t i = first; i < end; i++) {
@@ -629,8 +631,6 @@ __global__ __launch_bounds__(32 * G + 64) void k_atrous_stream(const AtrousParam
                 // written as look_up() the compiler put the subtraction and the minimum - and with them a wait for these two
                 // device-coherent loads AND for the three list loads above - in FRONT of the pass, a round trip to memory in every
                 // level's chain.  (The compiler's own waits stay right: loads return in order, these are the newest.)
-                uint32_t w0 = 0, w1 = 0;
-                if (has_up) asm volatile("global_load_dword %0, %2, %3 sc1\n\tglobal_load_dword %1, %2, %4 sc1" : "=&v"(w0), "=&v"(w1) : "v"(0u), "s"(above), "s"(above2) : "memory");
                 pass_compute<true>(A, pcur, D, sh, &sh.out_slot[set][gl]);       // ends with the workgroup's barrier
                 if (has_up) {
                     asm volatile("s_waitcnt vmcnt(0)" : "+v"(w0), "+v"(w1) : : "memory");
@@ -644,6 +644,7 @@ __global__ __launch_bounds__(32 * G + 64) void k_atrous_stream(const AtrousParam
                     wait_above(lcur);
                     D = pass_fetch<true>(A, W, buf, statw, sky, pcur, t, scur);
                     p_new = entry(i + 5); l_new = level_of(i + 5); s_new = sky_of(pnxt);
+                    if (has_up) asm volatile("global_load_dword %0, %2, %3 sc1\n\tglobal_load_dword %1, %2, %4 sc1" : "=&v"(w0), "=&v"(w1) : "v"(0u), "s"(above), "s"(above2) : "memory");
                 }
                 lds_barrier();
             }
