@@ -161,6 +161,8 @@ YCGE_HD double m_exp_d(double x)
     p = p * r + 5.0000000000000000000e-01;
     p = p * r + 1.0;
     p = p * r + 1.0;
+    // p * 2^k.  In two steps (below) where 2^k alone would leave the normal range; everywhere else one exact scaling does the same
+    if (k > -1000) return __builtin_ldexp(p, k);
     int k1 = k / 2, k2 = k - k1;
     double s1 = bits_to_double((uint64_t)(int64_t)(k1 + 1023) << 52);
     double s2 = bits_to_double((uint64_t)(int64_t)(k2 + 1023) << 52);
