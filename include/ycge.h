@@ -144,7 +144,10 @@ typedef struct ycge_voxel_lookup {
 
 /* One VolumeGrid (Objects/VolumeGrid.cs:55-93).  cells = the ctor's
  * (int,int)[nx,ny,nz] in its native memory order: pair index
- * (ix*ny + iy)*nz + iz, Item1 = matId, Item2 = metaId. */
+ * (ix*ny + iy)*nz + iz, Item1 = matId, Item2 = metaId.
+ * Limits (YCGE_ERR_UNSUPPORTED beyond them): fewer than 2^30 cells per grid,
+ * fewer than 2^23 8x8x8 bricks across any face, at most 255 distinct
+ * (matId, metaId) pairs per grid, 4 GiB of voxel bytes per scene. */
 typedef struct ycge_grid {
     int32_t nx, ny, nz;
     ycge_vec3 min_corner;
