@@ -673,8 +673,10 @@ __global__ __launch_bounds__(32 * G + 64) void k_atrous_stream(const AtrousParam
         const uint32_t p4 = entry(i + 3);
         const int s3 = sky_of(p3);
         const int lvl3 = i + 2 < end ? (int)pass_level[i + 2] : levels;
-        // the word of the band above, for the NEXT pass's decision (in flight while this pass computes)
-        const int up_word = has_up ? look_up() : 0;
+        // the word of the band above, for the NEXT pass's decision: asked for here by hand, looked at after the pass (as look_up() the
+        // compiler waited for the two device-coherent loads on the spot - see the two-set form above)
+        uint32_t w0 = epoch, w1 = epoch;
+        if (has_up) asm volatile("global_load_dword %0, %2, %3 sc1\n\tglobal_load_dword %1, %2, %4 sc1" : "=&v"(w0), "=&v"(w1) : "v"(0u), "s"(above), "s"(above2) : "memory");
         uint32_t spins = 0;
         if (i + 1 < end) {
             while (up_seen < lvl2) {            // rare in the steady state: the band above is not far enough yet
@@ -693,7 +695,13 @@ __global__ __launch_bounds__(32 * G + 64) void k_atrous_stream(const AtrousParam
             tl[0] = (uint32_t)now; tl[1] = (uint32_t)(now >> 32); tl[2] = spins; tl[3] = (uint32_t)lvl1;
         }
         pass_compute<true>(A, p1, Dc, sh, &sh.out_slot[(i - first) & 1u][grp]);     // ends with the workgroup's barrier
-        if (has_up) { if (up_word_old > up_seen) up_seen = up_word_old; up_word_old = up_word; }
+        if (has_up) {
+            asm volatile("s_waitcnt vmcnt(0)" : "+v"(w0), "+v"(w1) : : "memory");
+            const int s0 = (int32_t)(w0 - epoch), s1 = (int32_t)(w1 - epoch);
+            const int up_word = s0 < s1 ? s0 : s1;
+            if (up_word_old > up_seen) up_seen = up_word_old;
+            up_word_old = up_word;
+        }
         p1 = p2; p2 = p3; p3 = p4; s2 = s3; lvl1 = lvl2; lvl2 = lvl3;
         i++;
     };
