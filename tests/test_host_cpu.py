@@ -111,6 +111,12 @@ def test_scene_upload_argument_checks_fuzzed(product_lib):
     f.meshes[0].tri_material = tm.ctypes.data_as(C.POINTER(C.c_int32))
     assert product_lib.ycge_validate_scene(f.byref(), msg, 256) == abi.YCGE_ERR_INVALID_ARG and b"triangle material" in msg.value
     assert pokes == 200
+    # the limits of a voxel grid (include/ycge.h): 2^30 cells, 2^23 bricks across a face - checked before a cell is read
+    for dims, what in (((1024, 1024, 1024), b"2^30 cells"), ((1, 8, (1 << 26) + 8), b"2^23 bricks")):
+        f = build()
+        f.grids[0].nx, f.grids[0].ny, f.grids[0].nz = dims
+        rc = product_lib.ycge_validate_scene(f.byref(), msg, 256)
+        assert rc == abi.YCGE_ERR_UNSUPPORTED and what in msg.value, (dims, rc, msg.value)
 
 
 # ---- builders: product (ycge_accel.cpp) vs oracle (orc_scene.cpp), node for node ----------------------------
