@@ -117,21 +117,24 @@ def test_timed_kernels_with_an_all_air_grid_and_a_one_voxel_grid(product_lib, or
     from yetanotherconsolegameengine_amd.scene import Material, Plane, PointLight, Scene, Solid, VolumeGrid, vec3
     monkeypatch.setenv("YCGE_PATH", ypath)
     look = lambda m, meta: Material(vec3(0.2 + 0.1 * m, 0.5, 0.3))
-    s = Scene()
-    s.Add(Plane(vec3(0.0, -0.5, 0.0), vec3(0.0, 1.0, 0.0), Solid(vec3(0.6, 0.6, 0.55)), 0.05, 0.0))
     air = np.zeros((8, 8, 8, 2), np.int32)
     one = np.zeros((8, 8, 8, 2), np.int32); one[7, 0, 7] = (2, 0)
     full = np.zeros((4, 4, 4, 2), np.int32); full[..., 0] = 3
-    s.Add(VolumeGrid(air, vec3(-4.0, 0.0, -10.0), vec3(1.0, 1.0, 1.0), look))          # in front of the others, empty
-    s.Add(VolumeGrid(one, vec3(-4.0, 0.0, -20.0), vec3(1.0, 1.0, 1.0), look))
-    s.Add(VolumeGrid(full, vec3(3.0, 0.0, -14.0), vec3(0.5, 0.5, 0.5), look))
-    s.Lights.append(PointLight(vec3(0.0, 12.0, -6.0), vec3(1, 1, 1), 300.0))
-    for k, pose in enumerate((dict(pos=(0.0, 3.0, 0.0), yaw=0.0, pitch=-0.1, fov=60.0), dict(pos=(0.5, 4.0, -14.0), yaw=0.0, pitch=-0.4, fov=70.0))):
-        o, g = pu.run_pair(oracle, s, 96, 27, 2, pose, frames=1, count=False)
-        _assert_frame(o, g, f"{ypath} extremes pose {k} frame 1")
-        o.render(stages=1, threads=8); g.TryFlipAndBlit()
-        _assert_frame(o, g, f"{ypath} extremes pose {k} frame 2")
-        o.close(); g.close()
+    # ... at the origin and 65 536 units away from it, where a binary32 coordinate resolves 1/128 of a voxel: the walk's cells are
+    # then whatever its own arithmetic says, and the voxel of margin has to cover the difference to the slab test of the cull
+    for far in (0.0, 65536.0):
+        s = Scene()
+        s.Add(Plane(vec3(0.0, -0.5, 0.0), vec3(0.0, 1.0, 0.0), Solid(vec3(0.6, 0.6, 0.55)), 0.05, 0.0))
+        s.Add(VolumeGrid(air, vec3(far - 4.0, 0.0, -far - 10.0), vec3(1.0, 1.0, 1.0), look))          # in front of the others, empty
+        s.Add(VolumeGrid(one, vec3(far - 4.0, 0.0, -far - 20.0), vec3(1.0, 1.0, 1.0), look))
+        s.Add(VolumeGrid(full, vec3(far + 3.0, 0.0, -far - 14.0), vec3(0.5, 0.5, 0.5), look))
+        s.Lights.append(PointLight(vec3(far, 12.0, -far - 6.0), vec3(1, 1, 1), 300.0))
+        for k, pose in enumerate((dict(pos=(far, 3.0, -far), yaw=0.0, pitch=-0.1, fov=60.0), dict(pos=(far + 0.5, 4.0, -far - 14.0), yaw=0.0, pitch=-0.4, fov=70.0))):
+            o, g = pu.run_pair(oracle, s, 96, 27, 2, pose, frames=1, count=False)
+            _assert_frame(o, g, f"{ypath} extremes at {far:g} pose {k} frame 1")
+            o.render(stages=1, threads=8); g.TryFlipAndBlit()
+            _assert_frame(o, g, f"{ypath} extremes at {far:g} pose {k} frame 2")
+            o.close(); g.close()
 
 
 def test_one_call_drives_several_devices(product_lib, oracle, monkeypatch):
