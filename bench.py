@@ -1,36 +1,41 @@
 """bench.py — headline benchmark of the MI355X ray-trace core (BASELINE.json metric).
 
-    python bench.py --gpus N --steps K --warmup W [--config 4]
+    python bench.py --gpus N --steps K --warmup W [--config 4] [--camera static|orbit] [--form auto|onecall|rccl]
 
-A "step" is one frame of the hot path (ray-gen + per-pixel trace + TAA; with N > 1 also the
-RCCL all-gather of the tile slabs and the un-permute) over the configuration BASELINE.json quotes
-the metric on: config 4, the Dragon-class mesh (871,200-triangle procedural stand-in for the
-missing xyzrgb_dragon.obj) at a 1920x1080 trace grid, 1 spp.  Scene, BVH and all per-pixel buffers
-are resident in HBM before the timed region.  Prints ONE JSON line (rank 0).
+A "step" is one frame of the hot path (ray-gen + per-pixel trace + TAA; with N > 1 also the reassembly of the tiles) over the
+configuration BASELINE.json quotes the metric on: config 4, the Dragon-class mesh (871,200-triangle procedural stand-in for the
+missing xyzrgb_dragon.obj) at a 1920x1080 trace grid, 1 spp.  Scene, BVH and all per-pixel buffers are resident in HBM before the
+timed region.  Prints ONE JSON line (rank 0).
 
-value   = Mrays/s over ALL rays: calls to Scene.Hit + Scene.Occluded (primary, shadow, bounce) per
-          frame / frame time, whole job (all ranks).  Ray counts are exact: the timed frames are
-          re-run with the counting kernel variant afterwards (same frame numbers, untimed).
-roofline= ALGORITHMIC bytes of the trace per launch (32*N_box + 48*N_tri + 64*N_prim +
-          1*N_vox + 118*pixels, counters from the counting replay) / its mean launch duration from
-          HIP events recorded around the kernel on its own stream inside the timed region (N > 1: in a few
-          extra frames right after it, so that the timed region has no per-step host synchronisation):
-          `achieved` / `frac`.  That figure prices work, not memory traffic - most of those bytes are cache
-          hits.  What the hardware counters of the same build say is reported beside it, from the committed
-          rocprofv3 PMC passes (profiles/r02/pmc_config<N>.json, written by profiles/run_profiles.sh +
-          summarize.py): `traffic` = fabric bytes per launch (FETCH_SIZE doubled per the gfx950 note of
-          MI355X_MICROARCH.md, WRITE_SIZE scaled by the copy calibration), `hbm_counter_gbs`,
-          `frac_hbm_counter`, `lanes_active`, `valu_busy`, `wait_frac`; `bound` says what those show.
-cpu_baseline = the oracle (scalar C++ restatement of the reference, all host threads) on a bounded
-          sample of the same workload, rank 0, N = 1 only: `value` = trace only (what `value` of the GPU line
-          counts rays over is the whole frame, so `whole_frame_serial_taa` is the like-for-like figure); the
-          reference's TAA is one serial loop (`taa_serial_ms`), `taa_parallel_ms` is the same loop in row bands
-          (SURVEY 8d asks for both).  A reported baseline, not the target.
+How N GPUs are driven (`--form`):
+  onecall  ONE process, ONE ycge_render_frame call per frame - the reference's shape (RaytraceEntity.cs:230): config.devices =
+           0..N-1, the library deals the 32x8 tiles round-robin, every device traces its share, the peers write their tiles into
+           device 0's frame buffers over xGMI, TAA on device 0.  This is what a plain `python bench.py --gpus N` runs (auto, no
+           launcher).  Fails loudly when fewer than N devices are visible.
+  rccl     one process per GPU under torchrun (RANK / WORLD_SIZE in the environment): ycge_trace_tiles -> one RCCL all-gather of
+           the tile slabs -> ycge_resolve_gathered on every rank.  What `auto` picks when WORLD_SIZE > 1.
+`n_gpus` in the line is the number of devices that traced tiles this run (`device_tiles` lists their tile counts), never the flag.
+
+value   = Mrays/s over ALL rays: calls to Scene.Hit + Scene.Occluded (primary, shadow, bounce) per frame / frame time, whole job.
+          Ray counts are exact: the timed frames are re-run with the counting kernel variant afterwards (same frame numbers and
+          poses, untimed).  `frame_ms` / `trace_ms` give median, min and mean over the timed steps (SURVEY 8d asks median + min).
+roofline= ALGORITHMIC bytes of the trace per launch (32*N_box + 48*N_tri + 64*N_prim + 1*N_vox + 118*pixels, counters
+          of the REFERENCE's traversal from the counting replay) / its mean launch duration from HIP events on the kernel's own
+          stream inside the timed region: `achieved` / `frac`.  That prices work, not memory traffic - most of those bytes are
+          cache hits - and it prices the reference's walk: the timed kernels stop shadow queries at the first hit and skip culled
+          voxel grids.  `timed_work` is what the timed kernels themselves walked (lane steps, 72 bytes fetched per step), with
+          its own rate.  The hardware counters (`traffic`, `hbm_counter_gbs`, `lanes_active`, ...) come from the committed
+          rocprofv3 PMC passes and are printed only when that summary was taken from THIS build (source hash), else `pmc_stale`.
+cpu_baseline = the oracle (scalar C++ restatement of the reference, all host threads) on a bounded sample of the same workload,
+          rank 0, N = 1 only; per-frame spread reported.  A reported baseline, not the target.
+moving_camera / post_stage = the frame the host really drives: the pose changes every frame (below and above the TAA reset
+          thresholds, TemporalAA.cs:58-67) and the SDR frame (denoise, exposure, tonemap, read-back), reported beside the headline.
 """
 from __future__ import annotations
 
 import argparse
 import json
+import math
 import os
 import sys
 import time
@@ -44,6 +49,7 @@ for p in (str(ROOT), str(ROOT / "tests")):
 import numpy as np  # noqa: E402
 
 HBM_PEAK_GBS = 8000.0       # MI355X HBM3E spec peak (MI355X_MICROARCH.md: 8.0 TB/s; ~6.3 TB/s achievable)
+STEP_FETCH_BYTES = 72       # what one traversal step of the timed kernels fetches per lane (4 x 16 + 8 bytes: a node or a triangle-pair record)
 
 
 def algorithmic_bytes(st, pixels):
@@ -54,6 +60,11 @@ def stats_dict(s):
     return {k: int(getattr(s, k)) for k in ("n_rays", "n_box", "n_tri", "n_prim", "n_vox")}
 
 
+def dist3(a):
+    a = np.asarray(a, dtype=np.float64)
+    return {"median": round(float(np.median(a)), 4), "min": round(float(a.min()), 4), "mean": round(float(a.mean()), 4)}
+
+
 WORKLOADS = {1: "Cornell box", 2: "mirror spheres on checker", 3: "Stanford bunny 69,451 tris",
              4: "Dragon-class stand-in mesh 871,200 tris (seeded torus-knot, dragon OBJ is a missing blob)",
              5: "voxel world 544x256x544"}
@@ -61,66 +72,107 @@ METRIC_SHAPES = {1: "Cornell box 80x90 1spp", 2: "mirror spheres 640x360 1spp", 
                  4: "Dragon-class BVH 1920x1080 1spp", 5: "voxel volume grid 1920x1080 4spp + TAA"}
 
 
-def load_pmc(config):
-    """Counter summary of the trace kernels of THIS config from the committed rocprofv3 PMC passes (profiles/r02/), or None.
+def load_pmc(config, build_hash):
+    """Counter summary of the trace kernels of THIS config from the committed rocprofv3 PMC passes, newest round first.
+    Returns (summary or None, stale): stale = a summary exists but was taken from another build of the kernels.
     Produced on the GPU box by profiles/run_profiles.sh -> summarize.py --json; bench.py itself never runs a profiler."""
-    p = ROOT / "profiles" / "r02" / f"pmc_config{config}.json"
-    try:
-        return json.loads(p.read_text()) if p.exists() else None
-    except Exception:
-        return None
+    stale = False
+    for rnd in ("r03", "r02"):
+        p = ROOT / "profiles" / rnd / f"pmc_config{config}.json"
+        try:
+            if p.exists():
+                d = json.loads(p.read_text())
+                if d.get("source_hash") == build_hash:
+                    return d, False
+                stale = True
+        except Exception:
+            pass
+    return None, stale
+
+
+def orbit_pose(pose, k):
+    """Frame k of the moving camera: the eye circles the point it looks at (2 units ahead), the yaw follows.  Three steps in four
+    are SMALL (0.0008 rad: 0.0016 units of translation - below MotionTransReset = MotionRotReset = 0.0025, TemporalAA.cs:58-67,
+    the history is kept and the image region under each 8x8 block drifts), every fourth is LARGE (0.004 rad / 0.008 units: reset)."""
+    px, py, pz = pose["pos"]
+    yaw0, pitch = pose["yaw"], pose["pitch"]
+    # forward of RaytraceRenderer.cs:413-417: (sin(yaw) cos(pitch), sin(pitch), -cos(yaw) cos(pitch))
+    r = 2.0
+    cx, cz = px + r * math.sin(yaw0) * math.cos(pitch), pz - r * math.cos(yaw0) * math.cos(pitch)
+    a = sum(0.004 if (i % 4) == 3 else 0.0008 for i in range(k))
+    yaw = yaw0 + a
+    return (cx - r * math.sin(yaw) * math.cos(pitch), py, cz + r * math.cos(yaw) * math.cos(pitch)), yaw, pitch
 
 
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--steps", type=int, default=300)
+    ap.add_argument("--warmup", type=int, default=8)
     ap.add_argument("--config", type=int, default=4)
+    ap.add_argument("--camera", choices=("static", "orbit"), default="static", help="orbit: the pose changes every frame of the timed region (the headline then is the moving-camera frame)")
+    ap.add_argument("--form", choices=("auto", "onecall", "rccl"), default="auto", help="how N > 1 GPUs are driven (see the module docstring)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
     ap.add_argument("--no-post", action="store_true", help="skip the frames WITH the denoise/exposure/tonemap stage (reported apart as post_stage)")
+    ap.add_argument("--no-moving", action="store_true", help="skip the moving-camera leg (reported apart as moving_camera)")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
-    if world != args.gpus and world > 1:
-        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
-    multi = world > 1 or bool(os.environ.get("YCGE_BENCH_FORCE_TILED"))     # the env knob runs the tiled path (slab + all-gather + resolve) with one rank
+    form = args.form
+    if form == "auto":
+        form = "rccl" if world > 1 else "onecall"
+    if form == "rccl" and world != args.gpus and not (world == 1 and os.environ.get("YCGE_BENCH_FORCE_TILED")):
+        raise SystemExit(f"--form rccl --gpus {args.gpus} needs one process per GPU (torchrun --nproc-per-node {args.gpus}); WORLD_SIZE={world}")
+    if form == "onecall" and world > 1:
+        raise SystemExit(f"--form onecall is ONE process driving --gpus {args.gpus} devices; it was started under a launcher with WORLD_SIZE={world}")
+    multi = form == "rccl" and (world > 1 or bool(os.environ.get("YCGE_BENCH_FORCE_TILED")))     # the env knob runs the tiled path (slab + all-gather + resolve) with one rank
+    n_dev = args.gpus if form == "onecall" else 1          # devices THIS process drives
 
-    import torch
+    import torch          # (first: the library below must bind to the HIP runtime torch has loaded, not a second copy)
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: the ray-trace path has no CPU fallback")
+    from yetanotherconsolegameengine_amd import abi, build, scenes
+    if rank == 0:
+        build.build_library()
+    L = abi.load_library()
+    visible = L.ycge_device_count()
+    if visible < (n_dev if form == "onecall" else local_rank + 1):
+        raise SystemExit(f"bench.py --gpus {args.gpus}: {visible} HIP device(s) visible - the ray-trace path has no CPU fallback and will not run on fewer GPUs than asked for")
     torch.cuda.set_device(local_rank)
     if multi:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        dist.barrier()
 
-    from yetanotherconsolegameengine_amd import abi, build, scenes
     from yetanotherconsolegameengine_amd.renderer import RaytraceRenderer
     from yetanotherconsolegameengine_amd.scene import flatten
-    if rank == 0:
-        build.build_library()
-    if multi:
-        dist.barrier()
 
     scene, fbw, fbh, ss, pose = scenes.config_scene(args.config)
     flat = flatten(scene)
     hiW, hiH = fbw * ss, fbh * 2 * ss
     pixels = hiW * hiH
+    build_hash = build.source_hash()
 
     def make(count):
         # the multi-GPU frame ends with TAA (the metric's frame): lean slabs, no albedo plane in the all-gather (32 instead of 44 B per pixel)
-        r = RaytraceRenderer(flat, fbw, fbh, pose["fov"], ss, count_work=count, device=local_rank, rank=rank, world_size=world, slab_albedo=not multi)
+        r = RaytraceRenderer(flat, fbw, fbh, pose["fov"], ss, count_work=count, device=local_rank, rank=rank, world_size=world if multi else 1,
+                             slab_albedo=not multi, devices=list(range(n_dev)) if n_dev > 1 else None)
         r.SetCamera(pose["pos"], pose["yaw"], pose["pitch"])
         return r
+
+    def set_pose(rr, k, moving):
+        if moving:
+            pos, yaw, pitch = orbit_pose(pose, k)
+            rr.SetCamera(pos, yaw, pitch)
 
     r = make(False)
     stream = torch.cuda.current_stream()
     slab = all_slabs = None
-    # Several GPUs: the trace of frame N+1 does not depend on the all-gather / resolve (TAA) of frame N - the library keeps the
+    # Several processes: the trace of frame N+1 does not depend on the all-gather / resolve (TAA) of frame N - the library keeps the
     # trace's outputs apart from the resolved frame - so the two run on two streams with double-buffered slabs: a frame
     # costs max(trace, gather + resolve) instead of their sum.  Every frame is still traced, gathered and resolved inside
     # the timed region (both streams are drained before the clock stops).  YCGE_BENCH_PIPELINE=0: one stream, in sequence.
@@ -136,15 +188,16 @@ def main():
         n_issued = [0]
 
     def step(rr, want_stats=False):
+        """One frame; returns (trace_ms, frame_ms) as the library measured them (0 where the pipelined form takes no per-step timing)."""
         if not multi:
             rr.TryFlipAndBlit()
-            return rr.stats.trace_ms
+            return float(rr.stats.trace_ms), float(rr.stats.total_ms)
         if not pipelined or want_stats:
             rr.trace_tiles(slab.data_ptr(), stream.cuda_stream, want_stats=want_stats)
-            t = rr.stats.trace_ms if want_stats else 0.0
+            t = float(rr.stats.trace_ms) if want_stats else 0.0
             dist.all_gather_into_tensor(all_slabs, slab)
             rr.resolve_gathered(all_slabs.data_ptr(), stream.cuda_stream)
-            return t
+            return t, 0.0
         k = n_issued[0] & 1
         n_issued[0] += 1
         with torch.cuda.stream(s_trace):
@@ -156,57 +209,74 @@ def main():
             dist.all_gather_into_tensor(gathered[k], slabs[k])
             rr.resolve_gathered(gathered[k].data_ptr(), s_comm.cuda_stream)
             ev_resolved[k].record(s_comm)
-        return 0.0
+        return 0.0, 0.0
 
     def fence():
         if multi:
             s_trace.synchronize(); s_comm.synchronize()
             dist.barrier()
+        for d in range(n_dev):
+            torch.cuda.synchronize(d)
         torch.cuda.synchronize()
 
-    for _ in range(args.warmup):
+    moving = args.camera == "orbit"
+    for k in range(args.warmup):
+        set_pose(r, k, moving)
         step(r)
     fence()
     first_frame = args.warmup + 1
-    trace_ms = []
+    steps0 = r.timed_steps() if not multi else 0
+    per_step = []
     t0 = time.perf_counter()
-    for _ in range(args.steps):
-        # one GPU: ycge_render_frame times k_trace with HIP events on its own stream as part of the call.  Several GPUs:
-        # no per-step host synchronisation inside the timed region (trace on one stream, all-gather -> resolve on another, see above)
-        trace_ms.append(step(r, want_stats=not multi))
+    for k in range(args.steps):
+        # one process: ycge_render_frame times the trace with HIP events on its own stream as part of the (synchronous) call.  Several
+        # processes: no per-step host synchronisation inside the timed region (trace on one stream, all-gather -> resolve on another)
+        set_pose(r, args.warmup + k, moving)
+        per_step.append(step(r, want_stats=not multi))
     fence()
     elapsed = time.perf_counter() - t0
+    timed_lane_steps = (r.timed_steps() - steps0) / args.steps if not multi else None
+    device_tiles = [int(r.stats.device_tiles[i]) for i in range(int(r.stats.n_devices_traced))] if not multi else None
+    trace_ms = [p[0] for p in per_step]
+    frame_ms = [p[1] for p in per_step]
     if multi:       # kernel duration for the roofline line: a few extra, untimed frames with event timing
-        trace_ms = [step(r, want_stats=True) for _ in range(4)][1:]
+        trace_ms = [step(r, want_stats=True)[0] for _ in range(4)][1:]
         fence()
-    if multi:
         te = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
         dist.all_reduce(te, op=dist.ReduceOp.MAX)
         elapsed = float(te.item())
+        nt = torch.tensor([r.stats.device_tiles[0] if r.stats.n_devices_traced else 0], dtype=torch.int64, device="cuda")
+        allt = [torch.zeros_like(nt) for _ in range(world)]
+        dist.all_gather(allt, nt)
+        device_tiles = [int(t.item()) for t in allt]
+    n_gpus_used = sum(1 for t in device_tiles if t > 0)
 
-    # ---- exact work of the timed frames: counting replay (untimed)
+    # ---- exact work of the timed frames: counting replay (untimed; same frame numbers, same poses)
     rc = make(True)
     rc.set_frame_counter(first_frame - 1)
     tot = {k: 0 for k in ("n_rays", "n_box", "n_tri", "n_prim", "n_vox")}
-    for _ in range(args.steps):
+    replay = args.steps
+    for k in range(replay):
+        set_pose(rc, args.warmup + k, moving)
         if multi:
             rc.trace_tiles(slab.data_ptr(), stream.cuda_stream, want_stats=True)
         else:
             rc.TryFlipAndBlit()
-        for k, v in stats_dict(rc.stats).items():
-            tot[k] += v
+        for kk, v in stats_dict(rc.stats).items():
+            tot[kk] += v
     if multi:
         tt = torch.tensor([tot[k] for k in sorted(tot)], dtype=torch.int64, device="cuda")
         dist.all_reduce(tt)
         tot = dict(zip(sorted(tot), [int(x) for x in tt.tolist()]))
     rc.close()
 
-    per_frame = {k: v / args.steps for k, v in tot.items()}
-    mrays = tot["n_rays"] / elapsed / 1e6
+    per_frame = {k: v / replay for k, v in tot.items()}
+    mrays = per_frame["n_rays"] * args.steps / elapsed / 1e6
     ms_per_step = elapsed / args.steps * 1e3
     mean_trace_ms = float(np.mean(trace_ms)) if trace_ms and trace_ms[0] > 0 else None
-    # roofline of the dominant kernel (k_trace) on THIS rank's share of the frame
-    my_alg = algorithmic_bytes({k: v / world for k, v in per_frame.items()}, pixels / world)
+    # roofline of the dominant kernel (k_trace) on THIS process's share of the frame
+    share = world if multi else 1
+    my_alg = algorithmic_bytes({k: v / share for k, v in per_frame.items()}, pixels / share)
     roof = None
     if mean_trace_ms:
         ach = my_alg / (mean_trace_ms * 1e-3) / 1e9
@@ -216,11 +286,16 @@ def main():
         kernel = "k_wf_* stages" if args.config == 5 else "k_trace" if args.config in (1, 2) else "k_trace + k_trace_fan (concurrent)"
         roof = {"bound": "hbm", "kernel": kernel, "achieved": round(ach, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": round(ach / HBM_PEAK_GBS, 5), "traffic": None,
-                "achieved_is": "algorithmic bytes (SURVEY 8d) / launch time - mostly cache hits, NOT memory traffic",
+                "achieved_is": "algorithmic bytes of the REFERENCE's traversal (SURVEY 8d counters) / launch time - mostly cache hits, NOT memory traffic",
                 "algorithmic_bytes_per_launch": int(my_alg), "mean_launch_ms": round(mean_trace_ms, 4)}
-        pmc = load_pmc(args.config) if world == 1 else None
+        if timed_lane_steps is not None:
+            tb = STEP_FETCH_BYTES * timed_lane_steps + 118 * pixels
+            roof["timed_work"] = {"lane_steps_per_launch": round(timed_lane_steps, 1), "bytes_per_launch": int(tb),
+                                  "achieved_gbs": round(tb / (mean_trace_ms * 1e-3) / 1e9, 2), "frac": round(tb / (mean_trace_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 5),
+                                  "what": f"what the TIMED kernels walked: {STEP_FETCH_BYTES} B fetched per lane step (node / triangle-pair record; a voxel cell step reads 1 B) + 118 B per pixel"}
+        pmc, stale = load_pmc(args.config, build_hash) if (world == 1 and n_dev == 1) else (None, False)
         if pmc:
-            # counters of the same kernels from the committed PMC passes; the rate uses THIS run's launch time
+            # counters of the same kernels, same build, from the committed PMC passes; the rate uses THIS run's launch time
             t = pmc.get("traffic_bytes_per_launch")
             roof["traffic"] = int(t) if t else None
             if t:
@@ -232,28 +307,62 @@ def main():
             roof["bound"] = pmc.get("bound", "latency")
             roof["bound_evidence"] = pmc.get("bound_evidence")
             roof["pmc_source"] = pmc.get("source")
+        elif stale:
+            roof["pmc_stale"] = True       # a committed counter summary exists but belongs to another build of the kernels: not printed
+            roof["bound"] = "latency"
+        roof["build"] = build_hash
+
+    single = world == 1 and n_dev == 1
+    mov = None
+    if not args.no_moving and not moving and not multi:      # the frame the host really drives: the pose changes every frame (RaytraceEntity.cs:221-232)
+        n = 64
+        rows = []
+        resets = 0
+        for k in range(n):
+            set_pose(r, k, True)
+            r.TryFlipAndBlit()
+            rows.append((float(r.stats.trace_ms), float(r.stats.taa_ms), float(r.stats.total_ms)))
+            resets += int(r.stats.history_reset)
+        a = np.array(rows[8:])
+        mov = {"frames": n - 8, "history_resets": resets, "trace_ms": dist3(a[:, 0]), "taa_ms": dist3(a[:, 1]), "frame_ms": dist3(a[:, 2]),
+               "what": "pose changes every frame: 3 small steps (below the TAA reset thresholds) then 1 large (above), orbiting the look-at point; first 8 frames dropped"}
+        if not args.no_post:
+            rows = []
+            for k in range(n, n + 24):
+                set_pose(r, k, True)
+                r.TryFlipAndBlit(want_sdr=True)
+                rows.append((float(r.stats.trace_ms), float(r.stats.post_ms), float(r.stats.total_ms)))
+            a = np.array(rows[4:])
+            mov["with_sdr"] = {"frames": len(a), "trace_ms": dist3(a[:, 0]), "post_ms": dist3(a[:, 1]), "frame_ms_with_sdr_readback": dist3(a[:, 2])}
+        r.SetCamera(pose["pos"], pose["yaw"], pose["pitch"])
 
     post = None
-    if not args.no_post and world == 1:        # the frame the C# wrapper asks for (SDR out); outside the headline metric, which SURVEY 8d times through TAA
+    if not args.no_post and not multi:        # the frame the C# wrapper asks for (SDR out); outside the headline metric, which SURVEY 8d times through TAA
         ms = []
-        for _ in range(5):
+        for _ in range(12):
             r.TryFlipAndBlit(want_sdr=True)
             ms.append((float(r.stats.trace_ms), float(r.stats.taa_ms), float(r.stats.post_ms), float(r.stats.total_ms)))
-        ms = np.array(ms[1:])            # the first frame builds the in-place level schedule
-        post = {"trace_ms": round(float(ms[:, 0].mean()), 4), "taa_ms": round(float(ms[:, 1].mean()), 4),
-                "post_ms": round(float(ms[:, 2].mean()), 4), "frame_ms_with_sdr_readback": round(float(ms[:, 3].mean()), 4),
-                "what": "ycge_render_frame with an SDR buffer: + A-trous denoise, auto-exposure, tonemap/downsample, read-back (4 frames)"}
+        ms = np.array(ms[2:])            # the first frame builds the in-place level schedule
+        post = {"trace_ms": round(float(np.median(ms[:, 0])), 4), "taa_ms": round(float(np.median(ms[:, 1])), 4),
+                "post_ms": round(float(np.median(ms[:, 2])), 4), "frame_ms_with_sdr_readback": round(float(np.median(ms[:, 3])), 4),
+                "frame_ms_min": round(float(ms[:, 3].min()), 4),
+                "what": "ycge_render_frame with an SDR buffer: + A-trous denoise, auto-exposure, tonemap/downsample, read-back (medians of 10 frames, static camera)"}
 
     cpu = None
-    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+    if rank == 0 and single and not args.no_cpu_baseline:
         import oracle_binding as ob
         threads = os.cpu_count() or 1
         o = ob.OracleRenderer(scene, fbw, fbh, ss, pose, flat=flat)
         o.set_frame_counter(first_frame - 1)
         rays = 0; t_trace = 0.0; t_taa = 0.0; frames = 0
+        per = []
         while t_trace + t_taa < args.cpu_seconds and frames < args.steps:
+            if moving:
+                pos, yaw, pitch = orbit_pose(pose, args.warmup + frames)
+                o.set_camera(pos, yaw, pitch)
             o.render(stages=1, threads=threads)
             rays += int(o.stats.n_rays); t_trace += o.stats.trace_ms * 1e-3; t_taa += o.stats.taa_ms * 1e-3; frames += 1
+            per.append(int(o.stats.n_rays) / (o.stats.trace_ms * 1e-3) / 1e6)
         o.set_taa_threads(threads)           # the same TAA loop in row bands: identical result, "also reported parallel" 
         t_taa_par = 0.0; n_par = min(frames, 3)
         for _ in range(n_par):
@@ -264,6 +373,7 @@ def main():
                "sample": f"{frames} frame(s) of the same workload (frame numbers {first_frame}..{first_frame + frames - 1}): ray-gen + trace on {threads} threads "
                          f"({t_trace:.1f} s of host time), then the reference's serial TAA ({t_taa:.1f} s); {n_par} more frame(s) with the TAA in {threads} row bands",
                "value_is": "trace only (ray-gen + TraceFull)",
+               "per_frame_mrays": {"min": round(min(per), 2), "median": round(float(np.median(per)), 2), "max": round(max(per), 2), "frames": frames},
                "trace_ms_per_frame": round(t_trace / frames * 1e3, 2),
                "taa_serial_ms": round(t_taa / frames * 1e3, 2),
                "taa_parallel_ms": round(t_taa_par / max(1, n_par) * 1e3, 2),
@@ -271,22 +381,33 @@ def main():
 
     if rank == 0:
         name, cus = r.device_info()
+        how = ("one process, one ycge_render_frame call per frame drives all devices; peers push their tiles into device 0 over xGMI" if (form == "onecall" and n_dev > 1)
+               else "one process per GPU; one RCCL all-gather of the tile slabs per frame" + ("; trace of frame N+1 beside gather + resolve of frame N (two streams)" if pipelined else "") if multi else "single GPU")
         out = {
             "metric": f"Mrays/s (all rays: Scene.Hit + Scene.Occluded calls) and ms/frame, {METRIC_SHAPES[args.config]}",
-            "value": round(mrays, 2), "unit": "Mrays/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "value": round(mrays, 2), "unit": "Mrays/s", "n_gpus": n_gpus_used, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(ms_per_step, 4), "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
             "dtype": "f32", "data": "synthetic",
             "config": {"workload": f"config {args.config}: " + WORKLOADS[args.config],
-                       "trace_grid": f"{hiW}x{hiH}", "spp": ss * ss, "triangles": flat.n_triangles,
-                       "frame": "ray-gen + trace + TAA" + (" + RCCL all-gather of tile slabs + un-permute" if multi else ""),
-                       "parallelism": f"framebuffer tiles 32x8 round-robin over {world} GPU(s)" + (", one all-gather per frame; trace of frame N+1 beside gather + resolve of frame N (two streams)" if pipelined else ", one all-gather per frame" if multi else ""), "device": name, "compute_units": cus},
+                       "trace_grid": f"{hiW}x{hiH}", "spp": ss * ss, "triangles": flat.n_triangles, "camera": args.camera,
+                       "frame": "ray-gen + trace + TAA" + (" + RCCL all-gather of tile slabs + un-permute" if multi else " + peer tile push" if n_dev > 1 else ""),
+                       "parallelism": f"framebuffer tiles 32x8 round-robin over {n_gpus_used} GPU(s): " + how, "form": form,
+                       "gpus_requested": args.gpus, "device_tiles": device_tiles, "device": name, "compute_units": cus},
             "primary_mrays_per_s": round(pixels * args.steps / elapsed / 1e6, 2),
             "rays_per_frame": round(per_frame["n_rays"], 1),
             "work_per_frame": {k: round(v, 1) for k, v in per_frame.items()},
             "roofline": roof, "cpu_baseline": cpu,
         }
+        if frame_ms and frame_ms[0] > 0:
+            out["frame_ms"] = dist3(frame_ms)
+        if trace_ms and trace_ms[0] > 0:
+            out["trace_ms"] = dist3(trace_ms)
+        if n_gpus_used != args.gpus:
+            out["warning"] = f"--gpus {args.gpus} asked for, {n_gpus_used} device(s) traced tiles"
         if cpu:       # like for like: whole frames (trace + TAA) on both sides
             out["gpu_over_cpu"] = round(mrays / cpu["whole_frame_serial_taa"]["value"], 2)
+        if mov:
+            out["moving_camera"] = mov
         if post:
             out["post_stage"] = post
         print(json.dumps(out))

@@ -35,7 +35,7 @@
 extern "C" {
 #endif
 
-#define YCGE_ABI_VERSION 4
+#define YCGE_ABI_VERSION 5
 #define YCGE_MAX_DEVICES 8
 
 typedef enum ycge_status {
@@ -179,6 +179,9 @@ typedef struct ycge_scene {      /* Scenes/Scene.cs:12-24 */
     int32_t is_volume_scene;     /* `scene is VolumeScene` (RaytraceRenderer.cs:761) */
     int32_t n_textures;
     const ycge_texture *textures;   /* what YCGE_MAT_TEXTURED materials index */
+    /* Scene.HasDynamicTextures (Scenes/Scene.cs:30): the host rewrites texture pixels between frames (video, camera), so
+     * every frame (re)initialises the TAA history - `resetHistory = ... || scene.HasDynamicTextures`, RaytraceRenderer.cs:171. */
+    int32_t has_dynamic_textures;
 } ycge_scene;
 
 /* ------------------------------------------------------------------- config */
@@ -241,6 +244,9 @@ typedef struct ycge_frame_stats {
     uint64_t n_vox;              /* DDA cells visited                           */
     float exposure;              /* ToneMapper.EffectiveExposure                */
     float exposure_serial_chunks;/* diagnostics: 512-term chunks of the exposure sum that took the one-by-one path */
+    /* tiles traced by each device of this frame (one entry for a single-GPU context; devices[] order) */
+    int32_t n_devices_traced;
+    int32_t device_tiles[YCGE_MAX_DEVICES];
 } ycge_frame_stats;
 
 typedef enum ycge_buffer {
@@ -332,6 +338,15 @@ int ycge_resolve_gathered(ycge_ctx *ctx, const void *d_all_slabs, void *hip_stre
 /* tests only */
 int ycge_read_buffer(ycge_ctx *ctx, int32_t which /* ycge_buffer */, void *dst, size_t bytes);
 int ycge_set_frame_counter(ycge_ctx *ctx, int64_t frame_counter);
+/* measurement: what the TIMED kernel instances (config.count_work == 0) have done since the context was created, all devices:
+ * traversal-loop steps summed over lanes - one step = one node visit (a 64-byte record), one leaf record (72 bytes: two triangles)
+ * or one voxel cell.  The counting instances walk the reference's full traversal (SURVEY 8d counters in ycge_frame_stats); the
+ * timed ones stop shadow queries at the first hit and skip culled grids, so their own work is reported apart.  Waits for the
+ * context's stream; never called inside a timed region. */
+int ycge_read_timed_steps(ycge_ctx *ctx, uint64_t *lane_steps);
+/* visible HIP devices (hipGetDeviceCount; does not initialise a device context), < 0 on error: what a host checks before it
+ * fills config.devices[] */
+int ycge_device_count(void);
 int ycge_accel_size(ycge_ctx *ctx, int32_t which /* ycge_accel */, int32_t index, size_t *bytes);
 int ycge_read_accel(ycge_ctx *ctx, int32_t which, int32_t index, void *dst, size_t bytes);
 /* name of the device the context runs on + whether the gfx950 code object loaded */

@@ -587,7 +587,7 @@ struct Renderer {
         if (!have_scene) { err = "Scene BVH not built; call RebuildBVH() after populating Objects."; return YCGE_ERR_NO_SCENE; }
         auto t0 = std::chrono::steady_clock::now();
         float aspect = (float)hiW / (float)hiH;
-        bool reset = should_reset_history();
+        bool reset = should_reset_history() || scene.has_dynamic_textures;      /* RaytraceRenderer.cs:171 */
         int64_t frame = ++frame_counter;
         int frame_idx = (int)(frame & 0x7fffffff);
         float rot_x = frac((float)(frame_idx + 1) * 0.61803398875f);

@@ -393,6 +393,7 @@ std::string SceneData::load(const ycge_scene *s)
     ambient_color = v3(s->ambient_color); ambient_intensity = s->ambient_intensity;
     bg_top = v3(s->background_top); bg_bottom = v3(s->background_bottom);
     is_volume_scene = s->is_volume_scene != 0;
+    has_dynamic_textures = s->has_dynamic_textures != 0;
 
     meshes.clear(); meshes.resize(s->n_meshes);
     for (int i = 0; i < s->n_meshes; i++) {

@@ -155,6 +155,7 @@ struct SceneData {
     V3 ambient_color; float ambient_intensity;
     V3 bg_top, bg_bottom;
     bool is_volume_scene;
+    bool has_dynamic_textures = false;      /* Scene.HasDynamicTextures, Scenes/Scene.cs:30 */
     /* scene-level BVH (Objects/BVH.cs) */
     std::vector<Node> nodes;
     std::vector<int32_t> leaf_obj;

@@ -6,10 +6,15 @@ import tempfile
 from pathlib import Path
 
 ROOT = Path(__file__).resolve().parents[1]
-src = ROOT / "yetanotherconsolegameengine_amd" / "csrc" / "ycge_kernels.hip"
+sys.path.insert(0, str(ROOT))
+from yetanotherconsolegameengine_amd.build import FLAGS  # noqa: E402  (the product's own flags: the numbers are the shipped binary's)
+
+args = [a for a in sys.argv[1:] if not a.endswith(".hip")]
+names = [a for a in sys.argv[1:] if a.endswith(".hip")] or ["ycge_kernels.hip"]
+src = ROOT / "yetanotherconsolegameengine_amd" / "csrc" / names[0]
 with tempfile.TemporaryDirectory() as td:
-    r = subprocess.run(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fno-fast-math",
-                        "-c", "-x", "hip", str(src), "-o", f"{td}/k.o", "-Rpass-analysis=kernel-resource-usage"] + sys.argv[1:],
+    r = subprocess.run(["/opt/rocm/bin/hipcc"] + [f for f in FLAGS if f not in ("-shared", "-fPIC")] +
+                       ["--cuda-device-only", "-c", "-x", "hip", str(src), "-o", f"{td}/k.o", "-Rpass-analysis=kernel-resource-usage"] + args,
                        capture_output=True, text=True)
 cur = {}
 rows = []

@@ -93,7 +93,9 @@ if json_path:
             if is_trace(k) and "Scratch_Size" in row:
                 scratch[k] = int(row["Scratch_Size"])
     g = lambda c: per_frame.get(c)
-    d = {"config": cfg_n, "source": source, "kernels": dur, "calibration": cal, "counters_per_frame": {c: round(v, 1) for c, v in sorted(per_frame.items())}}
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
+    from yetanotherconsolegameengine_amd.build import source_hash
+    d = {"config": cfg_n, "source": source, "source_hash": source_hash(), "kernels": dur, "calibration": cal, "counters_per_frame": {c: round(v, 1) for c, v in sorted(per_frame.items())}}
     if g("FETCH_SIZE") is not None and g("WRITE_SIZE") is not None:
         d["fetch_bytes_x2"] = int(g("FETCH_SIZE") * 1024.0 * cal["fetch"])
         d["write_bytes_calibrated"] = int(g("WRITE_SIZE") * 1024.0 * cal["write"])

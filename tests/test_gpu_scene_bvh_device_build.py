@@ -11,6 +11,15 @@ from yetanotherconsolegameengine_amd.renderer import RaytraceRenderer
 from yetanotherconsolegameengine_amd.scene import (AmbientLight, Box, Material, PointLight, Scene, Solid, Sphere, flatten, vec3, ZERO)
 
 pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(autouse=True)
+def _device_builder_at_every_size(monkeypatch):
+    """The library picks the builder by object count (host below YCGE_SCENE_BVH_DEVICE_MIN, default 1 400: the measured crossover);
+    these tests are about the DEVICE builder, so they ask for it at every size.  test_builder_is_picked_by_object_count checks the default."""
+    monkeypatch.setenv("YCGE_SCENE_BVH_DEVICE_MIN", "1")
+
+
 POSE = dict(pos=(0.0, 6.0, 14.0), yaw=0.0, pitch=-0.35, fov=55.0)
 
 
@@ -238,4 +247,48 @@ def test_moved_objects_reach_every_device_of_a_multi_device_context(product_lib,
         _same_tree(o, g, f"two devices, move {step}")
         _frame_parity(o, g, f"two devices, frame after move {step}")
     assert g.scene_bvh_stats()["device_builds"] == 3
+    o.close(); g.close()
+
+
+def test_builder_is_picked_by_object_count(product_lib, oracle, monkeypatch):
+    """Default policy: fewer objects than the measured crossover are rebuilt by the host builder, more by the kernel; same trees either way."""
+    monkeypatch.delenv("YCGE_SCENE_BVH_DEVICE_MIN")
+    for n, dev in ((300, 0), (976, 0), (1400, 1), (2300, 1)):
+        scene = _crowd(n, 40 + n)
+        o, g = pu.run_pair(oracle, scene, 96, 54, 1, POSE, frames=1)
+        _move(scene, np.random.default_rng(n), 1.0)
+        moved = flatten(scene)
+        assert o.L.orc_scene_upload(o.ctx, moved.byref()) == 0
+        g.UpdateObjects(moved)
+        _same_tree(o, g, f"{n} objects")
+        st = g.scene_bvh_stats()
+        assert st["device_builds"] == dev and st["host_builds"] == 2 - dev, (n, st)
+        o.close(); g.close()
+
+
+def test_moved_objects_of_a_deep_mesh_scene_on_two_devices(product_lib, oracle):
+    """A context driving two devices whose scene holds a DEEP mesh (config 3's bunny: its tree needs stack levels beyond the 12 kept in LDS)
+    plus entities that move: the peer's spill area must be sized from the ROOT's mesh depth after ycge_scene_update_objects (it was
+    sized from the peer's own, never-set value: out-of-bounds stack writes on the peer)."""
+    sc, w, h, ss, pose = scenes.config_scene(3)
+    rng = np.random.default_rng(8)
+    m = Material(vec3(0.7, 0.4, 0.2), 0.1, 0.0, ZERO)
+    for i in range(40):
+        c = rng.uniform((-1.5, 0.2, -0.5), (1.5, 2.0, 2.5)).astype(np.float32)
+        sc.Add(Sphere(vec3(*c), 0.06, m))
+    flat = flatten(sc)
+    o = oracle.OracleRenderer(sc, 160, 90, 1, pose, flat=flat)
+    g = RaytraceRenderer(flat, 160, 90, pose["fov"], 1, capture_debug=True, count_work=True, devices=[0, 0])
+    g.SetCamera(pose["pos"], pose["yaw"], pose["pitch"])
+    o.render(stages=1, threads=16); g.TryFlipAndBlit()
+    for step in range(2):
+        for ob in sc.Objects:
+            if isinstance(ob, Sphere):
+                ob.Center = vec3(*(np.asarray(ob.Center, np.float32) + rng.uniform(-0.2, 0.2, 3).astype(np.float32)))
+        moved = flatten(sc)
+        assert o.L.orc_scene_upload(o.ctx, moved.byref()) == 0
+        g.UpdateObjects(moved)
+        _same_tree(o, g, f"deep mesh, two devices, move {step}")
+        _frame_parity(o, g, f"deep mesh, two devices, frame after move {step}")
+    assert g.scene_bvh_stats()["device_builds"] == 2
     o.close(); g.close()

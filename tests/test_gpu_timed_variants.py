@@ -178,6 +178,66 @@ def test_one_call_drives_several_devices(product_lib, oracle, monkeypatch):
             half.TryFlipAndBlit()
 
 
+def test_one_call_drives_two_real_devices(product_lib, oracle, monkeypatch):
+    """The same one-call frame on TWO DIFFERENT GPUs (hipDeviceEnablePeerAccess + k_push_tiles across xGMI): skipped on a box with one
+    device, so that the peer path runs the first time a multi-GPU node exists.  Timed (non-counting) instances at full config-3 size:
+    what the benchmark launches."""
+    n = product_lib.ycge_device_count()
+    if n < 2:
+        pytest.skip(f"needs >= 2 HIP devices for real peer access; this box has {n}")
+    monkeypatch.delenv("YCGE_PATH", raising=False)
+    sc, w, h, ss, pose = scenes.config_scene(3)
+    flat = flatten(sc)
+    o = oracle.OracleRenderer(sc, w, h, ss, pose, flat=flat)
+    g = RaytraceRenderer(flat, w, h, pose["fov"], ss, capture_debug=True, devices=list(range(min(n, 8))))
+    g.SetCamera(pose["pos"], pose["yaw"], pose["pitch"])
+    for f in range(4):
+        so = o.render(stages=2, threads=16, want_sdr=True)
+        sg = g.TryFlipAndBlit(want_sdr=True)
+        st = pu.compare_frame(o, g)
+        bad = {k: st[k + "_mismatch"] for k in BUFFERS if st[k + "_mismatch"]}
+        assert not bad, (f, bad)
+        assert pu.mismatch_count(so, sg) == 0, f
+        tiles = [g.stats.device_tiles[i] for i in range(g.stats.n_devices_traced)]
+        assert g.stats.n_devices_traced == min(n, 8) and all(t > 0 for t in tiles) and sum(tiles) == ((w * ss + 31) // 32) * ((h * 2 * ss + 7) // 8), tiles
+    o.close(); g.close()
+
+
+def test_dynamic_texture_scenes_restart_the_history_every_frame(product_lib, oracle):
+    """Scene.HasDynamicTextures (Scenes/Scene.cs:30): `resetHistory = taa.ShouldResetHistory(...) || scene.HasDynamicTextures`
+    (RaytraceRenderer.cs:171) - with a static camera every frame still copies current -> history."""
+    sc, _, _, ss, pose = scenes.config_scene(2)
+    sc.HasDynamicTextures = True
+    o, g = pu.run_pair(oracle, sc, 160, 45, ss, pose, frames=0)
+    for f in range(3):
+        o.render(stages=1, threads=8); g.TryFlipAndBlit()
+        st = pu.compare_frame(o, g)
+        assert st["taa_history_mismatch"] == 0 and st["current_hdr_mismatch"] == 0, f
+        assert g.stats.history_reset == 1 and pu.bits_equal(g.read(abi.BUF_TAA_HISTORY), g.read(abi.BUF_CURRENT_HDR)), f
+    o.close(); g.close()
+
+
+def test_timed_step_counter_reports_the_timed_kernels_own_work(product_lib):
+    """ycge_read_timed_steps: lane steps of the NON-counting instances, cumulative.  A frame of config 3 walks a positive number of
+    steps, the same number when the same frame is traced again (frame counter rewound), and fewer than the reference's box + triangle
+    tests would need one by one (two boxes per node step, two triangles per leaf step, shadow queries stop at the first hit)."""
+    sc, w, h, ss, pose = scenes.config_scene(3)
+    flat = flatten(sc)
+    g = RaytraceRenderer(flat, w // 4, h // 4, pose["fov"], ss)
+    c = RaytraceRenderer(flat, w // 4, h // 4, pose["fov"], ss, count_work=True)
+    for r in (g, c):
+        r.SetCamera(pose["pos"], pose["yaw"], pose["pitch"])
+    assert g.timed_steps() == 0
+    g.TryFlipAndBlit(); c.TryFlipAndBlit()
+    s1 = g.timed_steps()
+    g.set_frame_counter(0); g.TryFlipAndBlit()
+    s2 = g.timed_steps() - s1
+    assert s1 > 0 and s2 == s1, (s1, s2)
+    assert s1 <= c.stats.n_box // 2 + c.stats.n_tri + c.stats.n_prim, (s1, c.stats.n_box, c.stats.n_tri)
+    assert c.timed_steps() == 0          # the counting instances report the reference's counters instead
+    g.close(); c.close()
+
+
 def test_pipelined_tiled_frames_with_a_moving_camera(product_lib):
     """The trace of frame N+1 is issued BEFORE frame N is resolved (bench.py's two-stream loop), and the camera moves between
     them - sometimes below the TAA reset threshold, sometimes above (TemporalAA.cs:58-67).  Every ycge_resolve_gathered must

@@ -12,7 +12,7 @@ import ctypes as C
 import os
 from pathlib import Path
 
-YCGE_ABI_VERSION = 4
+YCGE_ABI_VERSION = 5
 YCGE_MAX_DEVICES = 8
 
 # ycge_status
@@ -110,6 +110,7 @@ class Scene(C.Structure):
         ("ambient_color", Vec3), ("ambient_intensity", C.c_float),
         ("background_top", Vec3), ("background_bottom", Vec3),
         ("is_volume_scene", C.c_int32), ("n_textures", C.c_int32), ("textures", C.POINTER(Texture)),
+        ("has_dynamic_textures", C.c_int32),
     ]
 
 
@@ -135,6 +136,7 @@ class FrameStats(C.Structure):
         ("trace_ms", C.c_double), ("taa_ms", C.c_double), ("post_ms", C.c_double), ("total_ms", C.c_double),
         ("n_rays", C.c_uint64), ("n_box", C.c_uint64), ("n_tri", C.c_uint64), ("n_prim", C.c_uint64),
         ("n_vox", C.c_uint64), ("exposure", C.c_float), ("exposure_serial_chunks", C.c_float),
+        ("n_devices_traced", C.c_int32), ("device_tiles", C.c_int32 * 8),
     ]
 
 
@@ -180,6 +182,8 @@ _PROTOTYPES = {
     "ycge_resolve_gathered": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.POINTER(C.c_float), C.POINTER(FrameStats)]),
     "ycge_read_buffer": (C.c_int, [C.c_void_p, C.c_int32, C.c_void_p, C.c_size_t]),
     "ycge_set_frame_counter": (C.c_int, [C.c_void_p, C.c_int64]),
+    "ycge_read_timed_steps": (C.c_int, [C.c_void_p, C.POINTER(C.c_uint64)]),
+    "ycge_device_count": (C.c_int, []),
     "ycge_accel_size": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.POINTER(C.c_size_t)]),
     "ycge_read_accel": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.c_void_p, C.c_size_t]),
     "ycge_device_info": (C.c_int, [C.c_void_p, C.c_char_p, C.c_size_t, C.POINTER(C.c_int32)]),

@@ -36,6 +36,18 @@ def hipcc() -> str:
     raise FileNotFoundError("hipcc not found (ROCm toolchain required; there is no CPU build of the kernels)")
 
 
+def source_hash() -> str:
+    """sha256 (16 hex digits) over the kernel / host sources and the build flags: names the BUILD a measurement belongs to (the
+    rocprofv3 counter summaries under profiles/ carry it; bench.py prints counter-derived figures only for the build it runs)."""
+    import hashlib
+    h = hashlib.sha256()
+    for n in sorted(SOURCES + HEADERS):
+        h.update(n.encode()); h.update((CSRC / n).read_bytes())
+    h.update((PKG.parent / "include" / "ycge.h").read_bytes())
+    h.update(" ".join(FLAGS).encode())
+    return h.hexdigest()[:16]
+
+
 def is_stale() -> bool:
     if not LIB.exists():
         return True
@@ -61,5 +73,7 @@ def build_library(force: bool = False, verbose: bool = False, extra_flags=()) ->
 
 
 if __name__ == "__main__":
+    if "--hash" in sys.argv:
+        print(source_hash()); sys.exit(0)
     p = build_library(force="--force" in sys.argv, verbose=True)
     print("built", p)

@@ -37,6 +37,7 @@ enum : uint32_t {
 
 // device-side build of the scene-level BVH (ycge_bvh_build.hip): what the kernel hands back to the host
 #define YCGE_BVH_DEV_MAX_ITEMS 2560     // one workgroup keeps the item order and its node queue in LDS
+#define YCGE_BVH_DEV_MIN_ITEMS_DEFAULT 1400     // below this ycge_scene_update_objects builds on the host: the measured crossover of the two builders
 struct BvhBuildResult {
     uint32_t root_ref;
     float root_min[3], root_max[3];

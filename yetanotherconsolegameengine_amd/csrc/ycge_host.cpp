@@ -121,6 +121,7 @@ struct Knobs {
     bool post_hash = false;          // YCGE_POST_HASH_FORM=1: the hash form of k_atrous_band even where the window fits
     int bvh_waves = 16;              // YCGE_BVH_WAVES: wavefronts of k_scene_bvh_build that take nodes (tests: the order nodes are split in must not matter)
     bool scene_bvh_host = false;     // YCGE_SCENE_BVH_HOST: ycge_scene_update_objects builds the scene BVH on the host, not on the device
+    int scene_bvh_device_min = YCGE_BVH_DEV_MIN_ITEMS_DEFAULT;   // YCGE_SCENE_BVH_DEVICE_MIN: fewer objects than this are built on the host (measured crossover, profiles/r02/f2_update_objects_timing.txt)
     bool exposure_serial = false;    // YCGE_EXPOSURE_SERIAL: the one-lane chain instead of the chunked exact evaluation
     void read()
     {
@@ -148,6 +149,7 @@ struct Knobs {
         exposure_serial = getenv("YCGE_EXPOSURE_SERIAL") != nullptr;
         scene_bvh_host = getenv("YCGE_SCENE_BVH_HOST") != nullptr;
         bvh_waves = geti("YCGE_BVH_WAVES", 16);
+        scene_bvh_device_min = geti("YCGE_SCENE_BVH_DEVICE_MIN", YCGE_BVH_DEV_MIN_ITEMS_DEFAULT);
     }
 };
 
@@ -228,7 +230,7 @@ struct ycge_ctx {
     uint32_t post_ticket = 0;                     // k_atrous_stream, bands in order of arrival: numbers drawn so far (the counter lives in post_progress)
     int post_resident_seen[2] = {-1, -1};         // post_resident_per_cu: the runtime's answer for the whole-band / split-band instantiation (-1: not asked yet)
     DevBuf<uint8_t> tone_state;                   // ToneMapper state; lives as long as the context (not reset by Resize)
-    struct InplaceSchedule { int w = 0, h = 0, step = 0, levels = 0, bands = 0, rows_per_band = 0, levels_per_launch = 0; uint32_t max_level_pixels = 0, window_width = 0; bool split = false; DevBuf<uint32_t> pixels, offsets, pass_level; DevBuf<int32_t> band_desc; };
+    struct InplaceSchedule { ~InplaceSchedule() { pixels.release(); offsets.release(); pass_level.release(); band_desc.release(); } int w = 0, h = 0, step = 0, levels = 0, bands = 0, rows_per_band = 0, levels_per_launch = 0; uint32_t max_level_pixels = 0, window_width = 0; bool split = false; DevBuf<uint32_t> pixels, offsets, pass_level; DevBuf<int32_t> band_desc; };
     std::vector<InplaceSchedule *> schedules;     // level schedules of the in-place A-trous iterations, by (w, h, step)
     // what ycge_scene_update_objects needs from the last full upload
     std::vector<GMesh> gmeshes_host;
@@ -236,6 +238,7 @@ struct ycge_ctx {
     std::vector<std::array<float, 6>> grid_solid;    // GGrid::solid_lo / solid_hi per grid (copied into the grid's object record: the walk culls before it enters)
     int n_materials = 0, max_mesh_depth = 0;
     bool materials_can_mirror = false;
+    bool has_dynamic_textures = false;           // Scene.HasDynamicTextures: every frame restarts the TAA history (RaytraceRenderer.cs:171)
     const float *denoised = nullptr;              // result of the last post stage (one of den_a / den_b / taa_hist)
     DevBuf<uint32_t> block_cost, block_order, order_ws;   // k_trace scheduling feedback (4 blocks of 8x8 px per tile)
     bool block_order_valid = false;
@@ -304,7 +307,8 @@ int alloc_frame_buffers(ycge_ctx *c)
         HIP_TRY(c, c->dbg_rays.alloc(6 * n)); HIP_TRY(c, c->dbg_prim.alloc(n)); HIP_TRY(c, c->dbg_sub.alloc(n));
         HIP_TRY(c, c->dbg_hit_t.alloc(n)); HIP_TRY(c, c->dbg_rng.alloc(n));
     }
-    if (c->cfg.count_work) HIP_TRY(c, c->counters.alloc(8));
+    HIP_TRY(c, c->counters.alloc(8));            // [0..4] SURVEY 8(d) counters of the counting instances (zeroed per frame), [5] lane steps of the timed instances (cumulative)
+    HIP_TRY(c, hipMemset(c->counters.p, 0, 8 * sizeof(unsigned long long)));
     return YCGE_OK;
 }
 
@@ -375,7 +379,7 @@ int set_geometry(ycge_ctx *c, int fbw, int fbh, int ss)
     c->wave_prof.release();                                     // sized for the tile grid
     c->pending.clear();
     c->t_hdr.release(); c->t_albedo.release(); c->t_normal.release(); c->t_depth.release(); c->t_sky.release();
-    for (auto *sc : c->schedules) { sc->pixels.release(); sc->offsets.release(); delete sc; }      // level schedules are per size: rebuilt on demand
+    for (auto *sc : c->schedules) delete sc;      // level schedules are per size: rebuilt on demand (the destructor frees the device lists)
     c->schedules.clear();
     int rc = alloc_frame_buffers(c);
     if (rc != YCGE_OK) return rc;
@@ -638,8 +642,9 @@ void ycge_destroy(ycge_ctx *c)
     c->counters.release(); c->wave_prof.release(); c->own_slab.release();
     c->t_hdr.release(); c->t_albedo.release(); c->t_normal.release(); c->t_depth.release(); c->t_sky.release();
     c->den_a.release(); c->den_b.release(); c->unit_n.release(); c->exp_terms.release(); c->exp_scratch.release(); c->d_sdr.release(); c->atrous_statw.release(); c->tone_state.release();
-    for (auto *sc : c->schedules) { sc->pixels.release(); sc->offsets.release(); delete sc; }
+    for (auto *sc : c->schedules) delete sc;
     c->schedules.clear();
+    c->post_progress.release();
     c->wf_q0.release(); c->wf_q1.release(); c->wf_hit.release(); c->wf_lq.release(); c->wf_seg.release(); c->wf_counts.release(); c->tile_order.release(); c->block_cost.release(); c->block_order.release(); c->order_ws.release(); c->stack_spill.release(); c->path_stack.release(); c->mig_entries.release(); c->mig_pub.release(); c->mig_ctl.release();
     c->d_scene_nodes.release(); c->d_mesh_arena.release(); c->d_scene_leaf.release(); c->d_prims.release();
     c->d_bvh_items.release(); c->d_bvh_scratch.release(); c->d_bvh_ref.release(); c->d_bvh_res.release();
@@ -683,9 +688,10 @@ namespace {
 int quiesce(ycge_ctx *c)
 {
     HIP_TRY(c, hipSetDevice(c->device));
-    HIP_TRY(c, hipStreamSynchronize(c->stream));
-    if (c->fan_stream) HIP_TRY(c, hipStreamSynchronize(c->fan_stream));
-    if (c->last_stream && c->last_stream != c->stream) HIP_TRY(c, hipStreamSynchronize(c->last_stream));
+    // a pipelined tiled caller may alternate several streams of its own between ycge_trace_tiles and ycge_resolve_gathered; the
+    // scene updates rewrite live allocations in place (DevBuf::upload), so wait for the whole device - this is a per-scene-change
+    // call, never part of a frame
+    HIP_TRY(c, hipDeviceSynchronize());
     return YCGE_OK;
 }
 
@@ -828,11 +834,13 @@ int flatten_objects(ycge_ctx *c, const ycge_prim *prims, int n_prims, ObjectsHos
 
 int check_scene_depth(ycge_ctx *c, int max_depth, int &spill_levels)
 {
+    // (the mesh trees are built once, by the root context: a peer's own max_mesh_depth mirrors it - install_scene - and the root's is what counts)
+    const int mesh_depth = c->parent ? c->parent->max_mesh_depth : c->max_mesh_depth;
     if (max_depth > 128) return c->fail(YCGE_ERR_STACK_DEPTH, "scene BVH depth %d exceeds the reference's 128-entry stack (BVH.cs:118)", max_depth);
-    if (max_depth + 4 + c->max_mesh_depth + 2 > YCGE_TRAVERSAL_STACK)
-        return c->fail(YCGE_ERR_STACK_DEPTH, "combined traversal depth %d + %d exceeds the device stack", max_depth, c->max_mesh_depth);
+    if (max_depth + 4 + mesh_depth + 2 > YCGE_TRAVERSAL_STACK)
+        return c->fail(YCGE_ERR_STACK_DEPTH, "combined traversal depth %d + %d exceeds the device stack", max_depth, mesh_depth);
     // levels the per-lane stack can need beyond its LDS part: scene depth + 4 leaf objects + deepest mesh
-    const int need = max_depth + 4 + c->max_mesh_depth + 2 - YCGE_LDS_STACK_LEVELS;
+    const int need = max_depth + 4 + mesh_depth + 2 - YCGE_LDS_STACK_LEVELS;
     spill_levels = need > 0 ? need : 0;
     return YCGE_OK;
 }
@@ -950,6 +958,7 @@ int install_scene(ycge_ctx *c, const SceneArrays &A, const ObjectsHost &oh, cons
     sd.bg_top[0] = s->background_top.x; sd.bg_top[1] = s->background_top.y; sd.bg_top[2] = s->background_top.z;
     sd.bg_bottom[0] = s->background_bottom.x; sd.bg_bottom[1] = s->background_bottom.y; sd.bg_bottom[2] = s->background_bottom.z;
     sd.is_volume_scene = s->is_volume_scene ? 1 : 0;
+    c->has_dynamic_textures = s->has_dynamic_textures != 0;
     sd.any_transparent = A.any_transparent ? 1 : 0;
     sd.any_textured = A.any_textured ? 1 : 0;
     rc = upload_lights(c, s->lights, s->n_lights);
@@ -1175,6 +1184,7 @@ int ycge_scene_upload(ycge_ctx *c, const ycge_scene *s)
     rc = install_scene(c, A, oh, s);
     for (ycge_ctx *p : c->peers) {
         if (rc != YCGE_OK) break;
+        p->max_mesh_depth = c->max_mesh_depth; p->n_materials = c->n_materials; p->materials_can_mirror = c->materials_can_mirror;
         rc = install_scene(p, A, oh, s);
         if (rc != YCGE_OK) c->err = p->err;
     }
@@ -1218,7 +1228,9 @@ int ycge_scene_update_objects(ycge_ctx *c, const ycge_prim *prims, int32_t n_pri
     if (rc != YCGE_OK) return rc;
     // the tree itself is built on the device (ycge_bvh_build.hip) - on the host only for what that kernel does not take: no objects,
     // more than YCGE_BVH_DEV_MAX_ITEMS, or (reported by the kernel) a tree deeper than the reference's stack allows
-    bool on_device = !c->knobs.scene_bvh_host && n_prims >= 1 && n_prims <= YCGE_BVH_DEV_MAX_ITEMS;
+    // ... and fewer objects than the measured crossover: one CU building a small tree loses to the host builder (300 objects: 168 us
+    // against 105; config 5's 976: 559 against 354; 2 300: 687 against 1 533 - profiles/r02/f2_update_objects_timing.txt)
+    bool on_device = !c->knobs.scene_bvh_host && n_prims >= 1 && n_prims >= c->knobs.scene_bvh_device_min && n_prims <= YCGE_BVH_DEV_MAX_ITEMS;
     if (!on_device) { rc = build_scene_tree_host(c, items, oh); if (rc != YCGE_OK) return rc; }
     rc = quiesce(c);
     for (ycge_ctx *p : c->peers) if (rc == YCGE_OK) rc = quiesce(p);
@@ -1305,6 +1317,29 @@ int ycge_set_frame_counter(ycge_ctx *c, int64_t fc)
     return YCGE_OK;
 }
 
+int ycge_device_count(void)
+{
+    int n = 0;
+    return hipGetDeviceCount(&n) == hipSuccess ? n : -1;
+}
+
+int ycge_read_timed_steps(ycge_ctx *c, uint64_t *lane_steps)
+{
+    if (!c || !lane_steps) return YCGE_ERR_INVALID_ARG;
+    unsigned long long total = 0;
+    std::vector<ycge_ctx *> all{c};
+    all.insert(all.end(), c->peers.begin(), c->peers.end());
+    for (ycge_ctx *d : all) {
+        unsigned long long v = 0;
+        if (hipSetDevice(d->device) != hipSuccess || hipDeviceSynchronize() != hipSuccess ||
+            hipMemcpy(&v, d->counters.p + 5, sizeof v, hipMemcpyDeviceToHost) != hipSuccess) { (void)hipSetDevice(c->device); return c->fail(YCGE_ERR_DEVICE, "timed-step read-back failed on device %d", d->device); }
+        total += v;
+    }
+    (void)hipSetDevice(c->device);
+    *lane_steps = total;
+    return YCGE_OK;
+}
+
 int ycge_tile_slab_bytes(const ycge_ctx *c, size_t *bytes)
 {
     if (!c || !bytes) return YCGE_ERR_INVALID_ARG;
@@ -1352,10 +1387,8 @@ int trace_frame(ycge_ctx *c, float *d_slab, hipStream_t stream, FrameState &fs, 
     const bool debug = c->cfg.capture_debug && !slab;
     if (debug) { O.rays = c->dbg_rays.p; O.prim_id = c->dbg_prim.p; O.sub_id = c->dbg_sub.p; O.hit_t = c->dbg_hit_t.p; O.rng_state = c->dbg_rng.p; }
     if (c->knobs.wave_prof_stage >= 0) { if (!c->wave_prof.p) HIP_TRY(c, c->wave_prof.alloc((size_t)c->n_tiles * 16)); O.wave_prof = c->wave_prof.p; O.wave_prof_stage = c->knobs.wave_prof_stage; }
-    if (c->cfg.count_work) {
-        O.counters = c->counters.p;
-        HIP_TRY(c, hipMemsetAsync(c->counters.p, 0, 8 * sizeof(unsigned long long), stream));
-    }
+    O.counters = c->counters.p;
+    if (c->cfg.count_work) HIP_TRY(c, hipMemsetAsync(c->counters.p, 0, 5 * sizeof(unsigned long long), stream));
     if (timed) HIP_TRY(c, hipEventRecord(c->ev[0], stream));
     int e;
     O.stack_spill = c->stack_spill.p;
@@ -1454,7 +1487,7 @@ int trace_frame(ycge_ctx *c, float *d_slab, hipStream_t stream, FrameState &fs, 
 // steps 5 and 9: TemporalBlendWithClamp + CommitCamera
 int taa_and_commit(ycge_ctx *c, hipStream_t stream, FrameState &fs, bool &did_reset, bool timed)
 {
-    fs.reset = should_reset_history(c, fs.pos, fs.yaw, fs.pitch);      // step 2 (:162): this frame's pose against the last committed one
+    fs.reset = should_reset_history(c, fs.pos, fs.yaw, fs.pitch) || c->has_dynamic_textures;      // step 2 (:171): this frame's pose against the last committed one; a scene with live textures restarts every frame
     TaaParams T;
     T.w = c->hiW; T.h = c->hiH;
     T.alpha = cs_max(0.0f, cs_min(1.0f, c->cfg.taa_alpha));      // :305
@@ -1804,6 +1837,9 @@ int fill_stats(ycge_ctx *c, ycge_frame_stats *st, const FrameState &fs, bool did
     st->trace_ms = ms;
     if (have_taa) { HIP_TRY(c, hipEventElapsedTime(&ms, c->ev[1], c->ev[2])); st->taa_ms = ms; }
     st->total_ms = wall_ms;
+    st->n_devices_traced = 1 + (int32_t)c->peers.size();
+    st->device_tiles[0] = c->n_owned;
+    for (size_t i = 0; i < c->peers.size() && i + 1 < YCGE_MAX_DEVICES; i++) st->device_tiles[i + 1] = c->peers[i]->n_owned;
     if (c->cfg.count_work) {
         unsigned long long h[8];
         HIP_TRY(c, hipMemcpy(h, c->counters.p, sizeof h, hipMemcpyDeviceToHost));

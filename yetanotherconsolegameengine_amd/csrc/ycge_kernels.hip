@@ -61,8 +61,14 @@ __device__ __forceinline__ bool tile_pixel(const FrameParams &P, int k, int &px,
 template <bool COUNT>
 __device__ __forceinline__ void flush_work(const Work &w, unsigned long long *counters)
 {
-    if (!COUNT || !counters) return;
+    if (!counters) return;
     const int lane = threadIdx.x & 63;
+    if (!COUNT) {       // the timed instances report what THEY walked: lane steps, one atomic per wavefront (ycge_read_timed_steps)
+        unsigned long long x = w.steps;
+        for (int off = 32; off >= 1; off >>= 1) x += __shfl_xor(x, off, 64);
+        if (lane == 0 && x) atomicAdd(counters + 5, x);
+        return;
+    }
     const unsigned v[5] = {w.rays, w.box, w.tri, w.prim, w.vox};
     for (int c = 0; c < 5; c++) {
         unsigned long long x = v[c];

@@ -154,6 +154,12 @@ class RaytraceRenderer:
     def set_frame_counter(self, n: int):
         self._check(self.L.ycge_set_frame_counter(self.ctx, n))
 
+    def timed_steps(self) -> int:
+        """Cumulative traversal-loop steps (summed over lanes, all devices) of the timed kernel instances (ycge_read_timed_steps)."""
+        n = C.c_uint64()
+        self._check(self.L.ycge_read_timed_steps(self.ctx, C.byref(n)))
+        return int(n.value)
+
     def read(self, which: int) -> np.ndarray:
         dt, n = abi.BUFFER_LAYOUT[which]
         shape = (self.hiH, self.hiW, n) if n > 1 else (self.hiH, self.hiW)

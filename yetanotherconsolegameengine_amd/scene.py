@@ -220,6 +220,7 @@ class Scene:
     DefaultYaw: float = 0.0
     DefaultPitch: float = 0.0
     IsVolumeScene: bool = False   # `scene is VolumeScene`, RaytraceRenderer.cs:761
+    HasDynamicTextures: bool = False   # Scene.cs:30: a texture is rewritten between frames -> TAA history restarts every frame (RaytraceRenderer.cs:171)
 
     def Add(self, h: Hittable) -> Hittable:   # Scene.cs:505-511 (entity layer collapses to Objects order)
         self.Objects.append(h)
@@ -370,6 +371,7 @@ class FlatScene:
         sc.background_top = abi.Vec3(*scene.BackgroundTop)
         sc.background_bottom = abi.Vec3(*scene.BackgroundBottom)
         sc.is_volume_scene = 1 if scene.IsVolumeScene else 0
+        sc.has_dynamic_textures = 1 if getattr(scene, 'HasDynamicTextures', False) else 0
         sc.textures, sc.n_textures = C.cast(self.textures, C.POINTER(abi.Texture)), len(tex_structs)
         self.struct = sc
         self.n_triangles = int(sum(m.n_triangles for m in meshes))
