@@ -960,16 +960,21 @@ int orc_post_probe(int fb_w, int fb_h, int ss, const float *hdr, const float *al
 }
 /* analysis aid: re-trace the last rendered frame and report, per pixel, the traversal steps of each of its first
  * `per_pixel` Scene.Hit calls in call order (primary, shadow rays of vertex 1, bounce, shadow rays of vertex 2, ...) */
-int orc_query_profile(void *ctx, uint32_t *out, int per_pixel)
+int orc_query_profile2(void *ctx, uint32_t *out, uint32_t *out2, int per_pixel);
+int orc_query_profile(void *ctx, uint32_t *out, int per_pixel) { return orc_query_profile2(ctx, out, nullptr, per_pixel); }
+/* ... out2 (may be null): leaves opened | left descents << 16 of the same calls */
+int orc_query_profile2(void *ctx, uint32_t *out, uint32_t *out2, int per_pixel)
 {
     Renderer *r = (Renderer *)ctx;
     if (!r || !r->have_scene || !out || per_pixel <= 0) return YCGE_ERR_INVALID_ARG;
     size_t npx = (size_t)r->hiW * r->hiH;
     std::memset(out, 0, npx * per_pixel * sizeof(uint32_t));
+    if (out2) std::memset(out2, 0, npx * per_pixel * sizeof(uint32_t));
     for (size_t i = 0; i < npx; i++) {
         int px = (int)(i % r->hiW), py = (int)(i / r->hiW);
         orc::Rng rng(orc::per_frame_seed(px, py, r->frame_counter, 0, 0, r->cfg.seed_salt));
         orc::Counters c; c.qlog = out + i * per_pixel; c.qcap = per_pixel;
+        if (out2) c.qlog2 = out2 + i * per_pixel;
         bool is_sky; orc::GBuf g;
         (void)orc::trace_full(r->scene, r->K, r->rays[i], rng, is_sky, g, c);
     }

@@ -925,9 +925,10 @@ static inline bool scene_box_hit(const Node &n, const Ray &r, float t_min, float
 bool SceneData::hit(const Ray &r, float t_min, float t_max, Hit &rec, Counters &cnt) const
 {
     struct QueryLog {       /* analysis aid only */
-        Counters &c; uint64_t b0, t0;
-        explicit QueryLog(Counters &cc) : c(cc), b0(cc.box), t0(cc.tri) {}
-        ~QueryLog() { if (c.qlog && c.qn < c.qcap) c.qlog[c.qn++] = (uint32_t)((c.box - b0) / 2 + (c.tri - t0)) | ((uint32_t)(c.tri - t0) << 16);   /* steps | triangle tests << 16 */ }
+        Counters &c; uint64_t b0, t0, l0, d0;
+        explicit QueryLog(Counters &cc) : c(cc), b0(cc.box), t0(cc.tri), l0(cc.leaves), d0(cc.left_desc) {}
+        ~QueryLog() { if (c.qlog2 && c.qn < c.qcap) c.qlog2[c.qn] = (uint32_t)(c.leaves - l0) | ((uint32_t)(c.left_desc - d0) << 16);
+                      if (c.qlog && c.qn < c.qcap) c.qlog[c.qn++] = (uint32_t)((c.box - b0) / 2 + (c.tri - t0)) | ((uint32_t)(c.tri - t0) << 16);   /* steps | triangle tests << 16 */ }
     } query_log(cnt);
     cnt.rays++;
     if (root < 0) return false;
@@ -1062,6 +1063,7 @@ static bool mesh_hit(const SceneData &S, const MeshAccel &m, const Ray &r, float
         int cnt_n = m.nodes[ni].count;
         if (cnt_n > 0) {
             int start = m.nodes[ni].start;
+            cnt.leaves++;
             for (int i = 0; i < cnt_n; i++) {
                 int tri = m.leaf_tri[start + i];
                 float t_hit, u, v;
@@ -1079,10 +1081,10 @@ static bool mesh_hit(const SceneData &S, const MeshAccel &m, const Ray &r, float
             if (l >= 0) { cnt.box++; hit_l = mesh_box_hit(m.nodes[l], r, t_min, closest, inv_dx, inv_dy, inv_dz, sx, sy, sz, l_near); }
             if (rr >= 0) { cnt.box++; hit_r = mesh_box_hit(m.nodes[rr], r, t_min, closest, inv_dx, inv_dy, inv_dz, sx, sy, sz, r_near); }
             if (hit_l & hit_r) {
-                if (l_near < r_near) { stack[sp++] = rr; stack[sp++] = l; }
+                if (l_near < r_near) { stack[sp++] = rr; stack[sp++] = l; cnt.left_desc++; }
                 else { stack[sp++] = l; stack[sp++] = rr; }
             } else if (hit_l) {
-                stack[sp++] = l;
+                stack[sp++] = l; cnt.left_desc++;
             } else if (hit_r) {
                 stack[sp++] = rr;
             }

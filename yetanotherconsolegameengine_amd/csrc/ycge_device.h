@@ -59,6 +59,20 @@ struct alignas(16) GNode {
 };
 static_assert(sizeof(GNode) == 64, "GNode must be 64 B");
 
+// A TREELET: the boxes and references of the 2 children, 4 grandchildren and 8 great-grandchildren of one internal mesh node, one
+// 32-byte slot each, heap order (slot 0 = left child, 1 = right; the children of slot b are 2b+2 and 2b+3).  Sixteen lanes fetch
+// it in ONE round trip and test the fourteen boxes side by side: the near-first descent through up to three levels is then bit
+// logic over the hit masks (coop_walk).  A copy of what the GNode records hold - the regular walk never reads it.
+struct alignas(16) GTreeSlot {
+    float mn[3], mx_x;
+    float mx_y, mx_z;
+    uint32_t ref;               // the child's reference as its parent's GNode holds it (REF_MESH_NODE / REF_MESH_LEAF)
+    uint32_t valid;             // 0: no such descendant (its parent position is a leaf)
+};
+static_assert(sizeof(GTreeSlot) == 32, "GTreeSlot must be 32 B");
+#define YCGE_TL_SLOTS 14
+#define YCGE_TL_BYTES_PER_UNIT 256u      // a GNode owns two 32-byte units: 512 bytes of treelet (14 slots = 448)
+
 // Leaf triangles, TWO to a record with the components interleaved (slot 0, slot 1): a 16-byte fetch then lands
 // each component pair in an aligned register pair, and the Moller-Trumbore test of both triangles runs as packed
 // operations (v_pk_mul_f32 / v_pk_add_f32) - one traversal step per two triangles.  A leaf starts on a record
@@ -146,6 +160,8 @@ struct GLight {
     float pad;
 };
 
+#define YCGE_TIMED_STEP_SLOTS_LG 10  // counters[8 + 8 i], i < 1024: lane steps of the timed kernel instances, spread over cache lines (flush_work)
+#define YCGE_COUNTER_WORDS (8 + 8 * (1 << YCGE_TIMED_STEP_SLOTS_LG))
 #define YCGE_LDS_STACK_LEVELS 12    // levels of a lane's traversal stack kept in LDS; deeper ones go to the HBM spill area
 #define YCGE_TRAVERSAL_STACK 96    // >= scene depth + 4 leaf prims + mesh depth, checked at upload
 #ifndef YCGE_COST_FRAMES
@@ -157,9 +173,6 @@ struct GLight {
 #define YCGE_POST_BAND_ROWS_DEFAULT 8 // rows per band of the in-place A-trous iteration (at least 2 x step)
 #define YCGE_POST_GROUPS_DEFAULT 16    // pixels per pass of the banded in-place A-trous iteration (workgroup = 32 x this many threads)
 #define YCGE_POST_K_DEFAULT 8         // levels per launch of the banded in-place A-trous iteration
-#define YCGE_MIG_QUEUES 64u          // path migration: published segments are spread over this many queues (power of two)
-#define YCGE_MIG_SCAN 4              // ... of which a wavefront looks at this many neighbours (its own block's queue first)
-#define YCGE_MIG_CTL_STRIDE 64u      // ... whose {tail, head} pairs are this many 8-byte words apart (512 bytes)
 #define YCGE_TILE_W 32
 #define YCGE_TILE_H 8
 #define YCGE_SLAB_FLOATS 11        // hdr rgb, albedo rgb, normal xyz, depth, sky
@@ -187,7 +200,11 @@ struct SceneDev {
     const uint32_t *tex_pixels;         // every texture's RGBA32 pixels (Renderer/Texture.cs:15), back to back
     const int32_t *tex_info;            // per texture: {first pixel, width, height, 0}
     int32_t any_textured;               // some material samples a texture (SampleAlbedo, RaytraceRenderer.cs:724-735)
-    int32_t pad_tex;
+    // Treelets for the wave-cooperative walk of sparse wavefronts (coop_walk, ycge_rt.hip.h): byte offset, inside the mesh arena's
+    // allocation, of the treelet region - the treelet of the internal node at 32-byte unit u is at tl_offset + u * YCGE_TL_BYTES_PER_UNIT.
+    // 0 = none (no mesh, or the region would not fit 32-bit offsets): the regular walk serves everything.
+    uint32_t tl_offset;
+    unsigned long long *dbg_counters;   // profiling builds (-DYCGE_DBG_COOPSTAT): statistics of the cooperative walk, else unused
 };
 
 struct FrameParams {
@@ -213,19 +230,6 @@ struct FrameParams {
     // measured 2.1x slower than round-robin on config 4 (load balance of the heavy tiles matters more).
     const uint32_t *tile_order;
 };
-
-// A path handed from the block that traced its primary vertex to whichever wavefront has idle lanes (k_trace):
-// TraceFull's per-pixel state at the moment its next Scene.Hit query is a path query (bounce / mirror continuation) and its work
-// stack is empty (RaytraceRenderer.cs:439-468) - everything the rest of the path needs, 64 bytes.
-struct alignas(16) MigEntry {
-    float o[3], d[3];           // the pending query: new Ray(origin, dir), tMin 0.001, tMax FLT_MAX
-    float beta[3];              // item.Throughput
-    float radiance[3];          // radiance accumulated so far (later terms are added to it in TraceFull's order)
-    uint32_t rng_lo, rng_hi;    // Rng state
-    uint32_t pixel;             // x + y * hiW
-    uint32_t depths;            // mirrorDepth | diffuseDepth << 4
-};
-static_assert(sizeof(MigEntry) == 64, "MigEntry must be 64 B");
 
 struct TraceOut {
     // full-frame buffers (row-major x + y*hiW); with several GPUs only the owned tiles are written
@@ -257,14 +261,6 @@ struct TraceOut {
     const uint32_t *n_fan;              // the first *n_fan schedule entries are traced by k_trace_fan (null or 0: none)
     // traversal counters (may be null): rays, box, tri, prim, vox
     unsigned long long *counters;
-    // path migration (null = off): 64 MigEntry slots per 8x8 block; mig_pub = YCGE_MIG_QUEUES rings of mig_ring published segments
-    // ((first entry << 8 | count) | 1 << 63, 0 = not yet written), mig_ctl = per queue {tail, head} running counters on a 64-byte line (never reset)
-    MigEntry *mig_entries;
-    unsigned long long *mig_pub;
-    unsigned long long *mig_ctl;
-    uint32_t mig_ring;                  // entries of mig_pub
-    int32_t mig_round_steps;            // traversal steps a consuming wavefront takes between refills
-    int32_t mig_shade_min;              // ... and how many finished queries it waits for before it runs the shading code
 };
 
 // planes a peer device copies from its own frame buffers into rank 0's (one process, several GPUs): its tiles only

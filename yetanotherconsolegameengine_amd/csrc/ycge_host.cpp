@@ -24,7 +24,6 @@
 
 extern "C" {
 size_t ycge_wf_sizes(int which);
-int ycge_kernel_has_migration(void);
 int ycge_launch_trace(const ycge::SceneDev *S, const ycge::FrameParams *P, const ycge::TraceOut *O, int count, int flat, int refill_steps,
                       hipStream_t stream);
 int ycge_launch_wavefront(const ycge::SceneDev *S, const ycge::FrameParams *P, const ycge::TraceOut *O, void *const bufs[7], int rounds,
@@ -112,7 +111,6 @@ struct Knobs {
     int pw_per_cu = 32;
     int post_band_rows = YCGE_POST_BAND_ROWS_DEFAULT, post_k = YCGE_POST_K_DEFAULT, post_groups = YCGE_POST_GROUPS_DEFAULT;
     int fan_class = -1, fan_cap = -1;   // -1 = default by world size
-    int mig = 1, mig_round = 12, mig_shade = 16;      // YCGE_MIG (0 = off), YCGE_MIG_ROUND, YCGE_MIG_SHADE: path migration in k_trace
     int post_mode = 0;               // YCGE_POST_MODE: in-place A-trous: 0 = one persistent launch, level-granular hand-over (k_atrous_stream), 2 = a launch per level group, 3 = as 0 with bands in block order, 4 = persistent with group hand-over (k_atrous_persist)
     bool post_no_split = false;      // YCGE_POST_NO_SPLIT: whole bands in the persistent in-place A-trous (no row-parity half-bands)
     int post_probe_band = -1;        // YCGE_POST_PROBE_BAND: this band and the next record a per-pass timeline (profiles/post_bands.py)
@@ -122,6 +120,7 @@ struct Knobs {
     int bvh_waves = 16;              // YCGE_BVH_WAVES: wavefronts of k_scene_bvh_build that take nodes (tests: the order nodes are split in must not matter)
     bool scene_bvh_host = false;     // YCGE_SCENE_BVH_HOST: ycge_scene_update_objects builds the scene BVH on the host, not on the device
     int scene_bvh_device_min = YCGE_BVH_DEV_MIN_ITEMS_DEFAULT;   // YCGE_SCENE_BVH_DEVICE_MIN: fewer objects than this are built on the host (measured crossover, profiles/r02/f2_update_objects_timing.txt)
+    bool no_coop = false;            // YCGE_NO_COOP: no treelets are built, sparse wavefronts keep the regular walk (A/B of the cooperative walk)
     bool exposure_serial = false;    // YCGE_EXPOSURE_SERIAL: the one-lane chain instead of the chunked exact evaluation
     void read()
     {
@@ -144,9 +143,8 @@ struct Knobs {
         post_resident_per_cu = geti("YCGE_POST_RESIDENT", 3);
         post_assume_resident = geti("YCGE_POST_ASSUME_RESIDENT", 0);
         if (post_resident_per_cu < 1 || post_resident_per_cu > 3) post_resident_per_cu = 3;
-        mig = geti("YCGE_MIG", 1); mig_round = geti("YCGE_MIG_ROUND", 12); mig_shade = geti("YCGE_MIG_SHADE", 16);
-        if (mig_round < 1) mig_round = 1;
         exposure_serial = getenv("YCGE_EXPOSURE_SERIAL") != nullptr;
+        no_coop = getenv("YCGE_NO_COOP") != nullptr;
         scene_bvh_host = getenv("YCGE_SCENE_BVH_HOST") != nullptr;
         bvh_waves = geti("YCGE_BVH_WAVES", 16);
         scene_bvh_device_min = geti("YCGE_SCENE_BVH_DEVICE_MIN", YCGE_BVH_DEV_MIN_ITEMS_DEFAULT);
@@ -215,7 +213,7 @@ struct ycge_ctx {
     DevBuf<float> dbg_rays, dbg_hit_t;
     DevBuf<int32_t> dbg_prim, dbg_sub;
     DevBuf<uint64_t> dbg_rng;
-    DevBuf<unsigned long long> counters, wave_prof;
+    DevBuf<unsigned long long> counters, wave_prof, dbg_counters;
     DevBuf<float> own_slab;                    // used when world_size > 1 and the caller passes no slab
     // wavefront pipeline storage (ycge_kernels.hip: QEntry / HitRec / LEntry), sized for one ray per pixel
     DevBuf<uint8_t> wf_q0, wf_q1, wf_hit, wf_lq;
@@ -243,8 +241,6 @@ struct ycge_ctx {
     DevBuf<uint32_t> block_cost, block_order, order_ws;   // k_trace scheduling feedback (4 blocks of 8x8 px per tile)
     bool block_order_valid = false;
     DevBuf<uint64_t> stack_spill;                 // [YCGE_TRAVERSAL_STACK - 12][persistent lanes]
-    DevBuf<MigEntry> mig_entries;                 // path migration (k_trace): 64 entries per 8x8 block
-    DevBuf<unsigned long long> mig_pub, mig_ctl;  // ring of published segments; {tail, head}
     DevBuf<float> path_stack;                  // [3][11][persistent lanes], only for scenes with transparent materials
     int spill_levels = 0;                      // traversal depth beyond the 12 LDS levels, from the uploaded trees
     int wf_rounds = 2;                         // 2 = primary + diffuse bounce; 4 when a surface can mirror (<= 2 mirror bounces)
@@ -307,8 +303,8 @@ int alloc_frame_buffers(ycge_ctx *c)
         HIP_TRY(c, c->dbg_rays.alloc(6 * n)); HIP_TRY(c, c->dbg_prim.alloc(n)); HIP_TRY(c, c->dbg_sub.alloc(n));
         HIP_TRY(c, c->dbg_hit_t.alloc(n)); HIP_TRY(c, c->dbg_rng.alloc(n));
     }
-    HIP_TRY(c, c->counters.alloc(8));            // [0..4] SURVEY 8(d) counters of the counting instances (zeroed per frame), [5] lane steps of the timed instances (cumulative)
-    HIP_TRY(c, hipMemset(c->counters.p, 0, 8 * sizeof(unsigned long long)));
+    HIP_TRY(c, c->counters.alloc(YCGE_COUNTER_WORDS));            // [0..4] SURVEY 8(d) counters of the counting instances (zeroed per frame), [8 + 8 i] lane steps of the timed instances (cumulative, spread over cache lines)
+    HIP_TRY(c, hipMemset(c->counters.p, 0, YCGE_COUNTER_WORDS * sizeof(unsigned long long)));
     return YCGE_OK;
 }
 
@@ -324,11 +320,11 @@ int alloc_tile_buffers(ycge_ctx *c)
     HIP_TRY(c, c->wf_counts.alloc((size_t)(c->n_owned > 0 ? c->n_owned : 1) * 8));
     HIP_TRY(c, c->stack_spill.alloc((size_t)(c->spill_levels > 0 ? c->spill_levels : 1) * stack_lanes));
     c->path_stack.release();
-    c->mig_entries.release(); c->mig_pub.release(); c->mig_ctl.release();
+   
     {
         const size_t nb = (size_t)(c->n_owned > 0 ? c->n_owned : 1) * 4;
-        HIP_TRY(c, c->block_cost.alloc(nb * YCGE_COST_FRAMES)); HIP_TRY(c, c->block_order.alloc(nb * YCGE_SCHEDULE_SLACK)); HIP_TRY(c, c->order_ws.alloc(20));
-        HIP_TRY(c, hipMemset(c->order_ws.p, 0, 20 * sizeof(uint32_t)));
+        HIP_TRY(c, c->block_cost.alloc(nb * YCGE_COST_FRAMES)); HIP_TRY(c, c->block_order.alloc(nb * YCGE_SCHEDULE_SLACK)); HIP_TRY(c, c->order_ws.alloc(96));
+        HIP_TRY(c, hipMemset(c->order_ws.p, 0, 96 * sizeof(uint32_t)));
         HIP_TRY(c, hipMemset(c->block_cost.p, 0, nb * YCGE_COST_FRAMES * sizeof(uint32_t)));
         c->block_order_valid = false;
     }
@@ -563,7 +559,9 @@ static int create_one(const ycge_config *cfg, ycge_ctx *parent, ycge_ctx **out)
         // config 4: 0.565 -> 0.418 ms at 8 ranks, 0.562 -> 0.433 at 4, 0.595 -> 0.493 at 2).  On a whole frame slots are what the
         // bulk is short of: only the 200 blocks at the head of the schedule (cost = max over four frames), with both kernels at 4
         // wavefronts per SIMD (0.590 -> 0.569 ms; 400+ blocks or 3 wavefronts per SIMD lose what the shorter chains gain).
-        const uint32_t fan_default = c->cfg.world_size >= 4 ? 4u : 5u;
+        // Round 3: with the cooperative walk (ycge_coop.hip.h) a block's tail is short enough that on a WHOLE frame the helper wavefronts
+        // cost the bulk more than the shorter chains gain (config 4: 0.514 ms without fan-out, 0.547 with the 200 blocks): off there.
+        const uint32_t fan_default = c->cfg.world_size >= 4 ? 4u : c->cfg.world_size >= 2 ? 5u : 0u;
         c->fan_class = c->knobs.fan_class >= 0 ? (uint32_t)c->knobs.fan_class : fan_default;
         if (hipHostMalloc((void **)&c->h_n_fan, sizeof(uint32_t), hipHostMallocDefault) != hipSuccess) { c->err = "hipHostMalloc failed"; return bail(YCGE_ERR_DEVICE); }
         *c->h_n_fan = 0;
@@ -639,13 +637,13 @@ void ycge_destroy(ycge_ctx *c)
     c->current_hdr.release(); c->g_albedo.release(); c->g_normal.release(); c->g_depth.release(); c->taa_hist.release();
     c->prev_normal.release(); c->prev_depth.release(); c->sky.release(); c->prev_sky.release();
     c->dbg_rays.release(); c->dbg_hit_t.release(); c->dbg_prim.release(); c->dbg_sub.release(); c->dbg_rng.release();
-    c->counters.release(); c->wave_prof.release(); c->own_slab.release();
+    c->counters.release(); c->wave_prof.release(); c->own_slab.release(); c->dbg_counters.release();
     c->t_hdr.release(); c->t_albedo.release(); c->t_normal.release(); c->t_depth.release(); c->t_sky.release();
     c->den_a.release(); c->den_b.release(); c->unit_n.release(); c->exp_terms.release(); c->exp_scratch.release(); c->d_sdr.release(); c->atrous_statw.release(); c->tone_state.release();
     for (auto *sc : c->schedules) delete sc;
     c->schedules.clear();
     c->post_progress.release();
-    c->wf_q0.release(); c->wf_q1.release(); c->wf_hit.release(); c->wf_lq.release(); c->wf_seg.release(); c->wf_counts.release(); c->tile_order.release(); c->block_cost.release(); c->block_order.release(); c->order_ws.release(); c->stack_spill.release(); c->path_stack.release(); c->mig_entries.release(); c->mig_pub.release(); c->mig_ctl.release();
+    c->wf_q0.release(); c->wf_q1.release(); c->wf_hit.release(); c->wf_lq.release(); c->wf_seg.release(); c->wf_counts.release(); c->tile_order.release(); c->block_cost.release(); c->block_order.release(); c->order_ws.release(); c->stack_spill.release(); c->path_stack.release();
     c->d_scene_nodes.release(); c->d_mesh_arena.release(); c->d_scene_leaf.release(); c->d_prims.release();
     c->d_bvh_items.release(); c->d_bvh_scratch.release(); c->d_bvh_ref.release(); c->d_bvh_res.release();
     c->d_materials.release(); c->d_meshes.release(); c->d_grids.release(); c->d_cells.release(); c->d_lut.release(); c->d_lights.release(); c->d_tex_pixels.release(); c->d_tex_info.release();
@@ -934,6 +932,7 @@ struct SceneArrays {
     bool any_transparent = false, has_grid = false, any_textured = false;
     std::vector<uint32_t> tex_pixels;
     std::vector<int32_t> tex_info;
+    uint32_t tl_offset = 0;          // treelet region of the arena (append_treelets), 0 = none
 };
 
 int install_scene(ycge_ctx *c, const SceneArrays &A, const ObjectsHost &oh, const ycge_scene *s)
@@ -961,6 +960,9 @@ int install_scene(ycge_ctx *c, const SceneArrays &A, const ObjectsHost &oh, cons
     c->has_dynamic_textures = s->has_dynamic_textures != 0;
     sd.any_transparent = A.any_transparent ? 1 : 0;
     sd.any_textured = A.any_textured ? 1 : 0;
+    sd.tl_offset = A.tl_offset;
+    if (!c->dbg_counters.p) { HIP_TRY(c, c->dbg_counters.alloc(16 + 16 * 256)); HIP_TRY(c, hipMemset(c->dbg_counters.p, 0, (16 + 16 * 256) * sizeof(unsigned long long))); }
+    sd.dbg_counters = c->dbg_counters.p;
     rc = upload_lights(c, s->lights, s->n_lights);
     if (rc != YCGE_OK) return rc;
     c->have_scene = true;
@@ -1016,6 +1018,45 @@ static uint32_t emit_mesh_records(const BuiltTree &t, const float *tris9, const 
     return emit(t.root);
 }
 
+
+// Treelets of every internal mesh node (GTreeSlot, ycge_device.h), appended to the arena: a pure function of the records above.
+// Returns the region's byte offset, 0 when there is nothing to build or 32-bit offsets would not reach its end.
+static uint32_t append_treelets(std::vector<uint8_t> &arena, const std::vector<GMesh> &gmeshes)
+{
+    const size_t n_units = arena.size() / 32;
+    const size_t t0 = (arena.size() + 511) & ~(size_t)511;
+    const size_t total = t0 + n_units * YCGE_TL_BYTES_PER_UNIT;
+    if (n_units == 0 || total + 4096 >= (1ull << 32)) return 0;
+    bool any = false;
+    for (const GMesh &m : gmeshes) any |= YCGE_REF_KIND(m.root_ref) == REF_MESH_NODE && m.root_ref != YCGE_REF_NONE_VALUE;
+    if (!any) return 0;
+    arena.resize(total, 0);
+    auto node_at = [&](uint32_t ref) { GNode g; std::memcpy(&g, arena.data() + (size_t)((ref & 0x1ffffff0u) >> 4) * 32, sizeof g); return g; };
+    std::vector<uint32_t> todo;
+    for (const GMesh &m : gmeshes) if (m.root_ref != YCGE_REF_NONE_VALUE && YCGE_REF_KIND(m.root_ref) == REF_MESH_NODE) todo.push_back(m.root_ref);
+    while (!todo.empty()) {
+        const uint32_t ref = todo.back(); todo.pop_back();
+        const uint32_t unit = (ref & 0x1ffffff0u) >> 4;
+        GTreeSlot slots[YCGE_TL_SLOTS];
+        std::memset(slots, 0, sizeof slots);
+        // fill(b, parent record): slots 2b+2 / 2b+3 from the record of the node in slot b (b = -1: the treelet's own node)
+        std::function<void(int, const GNode &, int)> fill = [&](int b, const GNode &g, int depth) {
+            const int l = 2 * b + 2, r = l + 1;
+            slots[l].mn[0] = g.lmin_x; slots[l].mn[1] = g.lmin_y; slots[l].mn[2] = g.lmin_z; slots[l].mx_x = g.lmax_x; slots[l].mx_y = g.lmax_y; slots[l].mx_z = g.lmax_z;
+            slots[r].mn[0] = g.rmin_x; slots[r].mn[1] = g.rmin_y; slots[r].mn[2] = g.rmin_z; slots[r].mx_x = g.rmax_x; slots[r].mx_y = g.rmax_y; slots[r].mx_z = g.rmax_z;
+            slots[l].ref = g.lref; slots[r].ref = g.rref; slots[l].valid = slots[r].valid = 1;
+            if (depth < 3)
+                for (int c : {l, r})
+                    if (YCGE_REF_KIND(slots[c].ref) == REF_MESH_NODE) fill(c, node_at(slots[c].ref), depth + 1);
+        };
+        const GNode g = node_at(ref);
+        fill(-1, g, 1);
+        std::memcpy(arena.data() + t0 + (size_t)unit * YCGE_TL_BYTES_PER_UNIT, slots, sizeof slots);
+        if (YCGE_REF_KIND(g.lref) == REF_MESH_NODE) todo.push_back(g.lref);
+        if (YCGE_REF_KIND(g.rref) == REF_MESH_NODE) todo.push_back(g.rref);
+    }
+    return (uint32_t)t0;
+}
 
 int ycge_validate_scene(const ycge_scene *scene, char *msg, size_t msg_bytes)
 {
@@ -1095,6 +1136,8 @@ int ycge_scene_upload(ycge_ctx *c, const ycge_scene *s)
         if (bad_material) return c->fail(YCGE_ERR_INVALID_ARG, "mesh %d: triangle material out of range", mi);
         if (arena.size() / 32 >= (1u << 25)) return c->fail(YCGE_ERR_UNSUPPORTED, "mesh records exceed the 1 GB arena");
     }
+
+    A.tl_offset = c->knobs.no_coop ? 0u : append_treelets(arena, gmeshes);
 
     // ---- voxel grids: VolumeGrid ctor (VolumeGrid.cs:55-93), one byte per voxel = index into a per-grid material table
     std::vector<GGrid> &ggrids = A.ggrids;
@@ -1317,6 +1360,17 @@ int ycge_set_frame_counter(ycge_ctx *c, int64_t fc)
     return YCGE_OK;
 }
 
+// profiling builds: the 6 sums of the cooperative walk's statistics (ycge_coop.hip.h, -DYCGE_DBG_COOPSTAT), cumulative
+int ycge_debug_read_coop_stats(ycge_ctx *c, uint64_t out[16])
+{
+    if (!c || !out || !c->dbg_counters.p) return YCGE_ERR_INVALID_ARG;
+    std::vector<unsigned long long> v(16 + 16 * 256);
+    HIP_TRY(c, hipDeviceSynchronize());
+    HIP_TRY(c, hipMemcpy(v.data(), c->dbg_counters.p, v.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost));
+    for (int k = 0; k < 16; k++) { out[k] = 0; for (int i = 0; i < 256; i++) out[k] += v[16 + 8 * 256 * (k >> 3) + 8 * i + (k & 7)]; }
+    return YCGE_OK;
+}
+
 int ycge_device_count(void)
 {
     int n = 0;
@@ -1330,10 +1384,10 @@ int ycge_read_timed_steps(ycge_ctx *c, uint64_t *lane_steps)
     std::vector<ycge_ctx *> all{c};
     all.insert(all.end(), c->peers.begin(), c->peers.end());
     for (ycge_ctx *d : all) {
-        unsigned long long v = 0;
+        std::vector<unsigned long long> v(YCGE_COUNTER_WORDS);
         if (hipSetDevice(d->device) != hipSuccess || hipDeviceSynchronize() != hipSuccess ||
-            hipMemcpy(&v, d->counters.p + 5, sizeof v, hipMemcpyDeviceToHost) != hipSuccess) { (void)hipSetDevice(c->device); return c->fail(YCGE_ERR_DEVICE, "timed-step read-back failed on device %d", d->device); }
-        total += v;
+            hipMemcpy(v.data(), d->counters.p, v.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost) != hipSuccess) { (void)hipSetDevice(c->device); return c->fail(YCGE_ERR_DEVICE, "timed-step read-back failed on device %d", d->device); }
+        for (size_t i = 8; i < v.size(); i += 8) total += v[i];
     }
     (void)hipSetDevice(c->device);
     *lane_steps = total;
@@ -1409,20 +1463,6 @@ int trace_frame(ycge_ctx *c, float *d_slab, hipStream_t stream, FrameState &fs, 
         O.path_stack = c->path_stack.p;
         const bool lpt = !c->knobs.no_lpt;
         const uint32_t n_blocks = (uint32_t)c->n_owned * 4u;
-        // path migration (flat scenes, the non-counting kernel): a block hands its bounce / mirror paths to whichever wavefront has idle lanes
-        const bool mig = ycge_kernel_has_migration() && flat && c->knobs.mig && !c->cfg.count_work && c->knobs.refill_steps <= 0 && n_blocks > 0;
-        if (mig) {
-            const uint32_t ring = (n_blocks * YCGE_SCHEDULE_SLACK + YCGE_MIG_QUEUES - 1u) / YCGE_MIG_QUEUES + 1u;      // a block publishes at most once per part, on queue bid % Q
-            if (!c->mig_entries.p) {
-                HIP_TRY(c, c->mig_entries.alloc((size_t)n_blocks * 64));
-                HIP_TRY(c, c->mig_pub.alloc((size_t)ring * YCGE_MIG_QUEUES)); HIP_TRY(c, c->mig_ctl.alloc((size_t)YCGE_MIG_QUEUES * YCGE_MIG_CTL_STRIDE));
-                HIP_TRY(c, hipMemset(c->mig_pub.p, 0, (size_t)ring * YCGE_MIG_QUEUES * sizeof(unsigned long long)));
-                HIP_TRY(c, hipMemset(c->mig_ctl.p, 0, (size_t)YCGE_MIG_QUEUES * YCGE_MIG_CTL_STRIDE * sizeof(unsigned long long)));
-            }
-            O.mig_entries = c->mig_entries.p; O.mig_pub = c->mig_pub.p; O.mig_ctl = c->mig_ctl.p;
-            O.mig_ring = ring;
-            O.mig_round_steps = c->knobs.mig_round; O.mig_shade_min = c->knobs.mig_shade;
-        }
         const uint32_t cost_slot = (uint32_t)((uint64_t)fs.frame % YCGE_COST_FRAMES);       // this frame's array of the cost ring
         O.block_cost = lpt ? c->block_cost.p + (size_t)cost_slot * n_blocks : nullptr;
         if (c->order_pending) { HIP_TRY(c, hipStreamWaitEvent(stream, c->order_ev, 0)); c->order_pending = false; }     // the schedule built beside the last frame's TAA
@@ -1433,7 +1473,7 @@ int trace_frame(ycge_ctx *c, float *d_slab, hipStream_t stream, FrameState &fs, 
         // a schedule without fanned blocks (analytic scenes, small frames) skips k_trace_fan and the side stream altogether: the count
         // comes back through pinned memory and is a frame or two old when read here - either answer traces every block exactly once,
         // because k_trace is told (n_fan pointer or null) which convention this frame uses
-        const bool fan = !mig && O.block_order != nullptr && c->fan_cap > 0 && !(flat && refill_steps > 0) && c->h_n_fan && *(volatile uint32_t *)c->h_n_fan > 0;
+        const bool fan = O.block_order != nullptr && c->fan_cap > 0 && !(flat && refill_steps > 0) && c->h_n_fan && *(volatile uint32_t *)c->h_n_fan > 0;
         if (fan) {
             fs.fan_blocks = *(volatile uint32_t *)c->h_n_fan;      // what the last finished schedule handed to k_trace_fan (this frame's may differ by a few)
             // k_trace_fan goes FIRST and on the frame's stream, so that its blocks - the frame's longest chains - are resident from
@@ -2112,6 +2152,25 @@ int ycge_host_mesh_arena(const float *tris9, int32_t n, void *out, int64_t capac
     bool bad_leaf = false, bad_material = false;
     *root_ref_out = emit_mesh_records(t, tris9, nullptr, 0, 1, arena, bad_leaf, bad_material);
     if (bad_leaf || bad_material) return YCGE_ERR_UNSUPPORTED;
+    if (out && (int64_t)arena.size() <= capacity_bytes && !arena.empty()) std::memcpy(out, arena.data(), arena.size());
+    return (int)arena.size();
+}
+
+// ... with the treelet region of the cooperative walk appended (append_treelets): returns the total size, *tl_offset_out = where it starts
+int ycge_host_mesh_arena_treelets(const float *tris9, int32_t n, void *out, int64_t capacity_bytes, uint32_t *root_ref_out, uint32_t *tl_offset_out)
+{
+    if (n < 0 || (n > 0 && !tris9) || !root_ref_out || !tl_offset_out) return YCGE_ERR_INVALID_ARG;
+    BoundsSoA it;
+    triangle_items(tris9, n, it);
+    BuiltTree t;
+    build_tree(it, TreeFlavour::Mesh, t);
+    std::vector<uint8_t> arena;
+    bool bad_leaf = false, bad_material = false;
+    GMesh gm;
+    std::memset(&gm, 0, sizeof gm);
+    gm.root_ref = *root_ref_out = emit_mesh_records(t, tris9, nullptr, 0, 1, arena, bad_leaf, bad_material);
+    if (bad_leaf || bad_material) return YCGE_ERR_UNSUPPORTED;
+    *tl_offset_out = append_treelets(arena, std::vector<GMesh>{gm});
     if (out && (int64_t)arena.size() <= capacity_bytes && !arena.empty()) std::memcpy(out, arena.data(), arena.size());
     return (int)arena.size();
 }

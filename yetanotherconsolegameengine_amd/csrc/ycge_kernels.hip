@@ -63,10 +63,12 @@ __device__ __forceinline__ void flush_work(const Work &w, unsigned long long *co
 {
     if (!counters) return;
     const int lane = threadIdx.x & 63;
-    if (!COUNT) {       // the timed instances report what THEY walked: lane steps, one atomic per wavefront (ycge_read_timed_steps)
+    if (!COUNT) {       // the timed instances report what THEY walked: lane steps, one atomic per wavefront (ycge_read_timed_steps) -
+        // spread over YCGE_TIMED_STEP_SLOTS cache lines: one hot address takes ~88 atomics per microsecond on this part, and a 4K frame's
+        // primary stage alone retires 130 000 wavefronts (measured: 0.35 -> 1.58 ms with a single counter)
         unsigned long long x = w.steps;
         for (int off = 32; off >= 1; off >>= 1) x += __shfl_xor(x, off, 64);
-        if (lane == 0 && x) atomicAdd(counters + 5, x);
+        if (lane == 0 && x) atomicAdd(counters + 8 + (size_t)((blockIdx.x * 2654435761u) >> (32 - YCGE_TIMED_STEP_SLOTS_LG)) * 8, x);
         return;
     }
     const unsigned v[5] = {w.rays, w.box, w.tri, w.prim, w.vox};
@@ -540,15 +542,6 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu((HAS_GRID &
 }
 
 // ---------------------------------------------------------------------------------- K_trace (single launch)
-#ifndef YCGE_MIGRATE
-#define YCGE_MIGRATE 0              // experiment (-DYCGE_MIGRATE=1; measured a loss): path migration in the flat, non-counting k_trace (trace_block, MIG)
-#endif
-#ifndef YCGE_SPLIT_QUERIES
-#define YCGE_SPLIT_QUERIES 0         // experiment (-DYCGE_SPLIT_QUERIES=1; bit-exact, measured slower): long queries of nearly finished wavefronts split over the idle lanes (mesh_walk_split)
-#endif
-#ifndef YCGE_COOP_FETCH
-#define YCGE_COOP_FETCH 0           // experiment (measured: a loss): quad-cooperative LDS-DMA record fetch in the flat, non-counting single-launch kernels
-#endif
 enum Phase : int { PH_PATH = 0, PH_SHADOW_OCC = 1, PH_SHADOW_TR = 2, PH_DONE = 3 };
 
 struct PathItem {       // PathWorkItem, RaytraceRenderer.cs:439-446 (IsPrimary is false for every pushed item)
@@ -624,27 +617,34 @@ __device__ __forceinline__ uint32_t wave_umax(uint32_t v)
     return v;
 }
 
+// The shading context of a diffuse hit (position, normal, albedo, direction to the eye) between the hit and the light-loop / bounce
+// code that consumes it, per lane, 48 bytes: written once per hit, read once per shadow answer.  Explicit ds instructions (the
+// compiler cannot forward through them): the twelve values are not live across the shadow queries, where they cost the 4-wavefront
+// build of k_trace 15 spilled registers (135 MB of scratch writes per 1080p frame).  48-byte lane stride: b128 accesses of 16
+// consecutive lanes cover every bank once.
+static __shared__ __attribute__((aligned(16))) float g_shade_ctx[12 * 64];
+__device__ __forceinline__ void shade_ctx_store(uint32_t addr, F3 p, F3 n, F3 alb, F3 wo)
+{
+    const f32x4 v0 = {p.x, p.y, p.z, n.x}, v1 = {n.y, n.z, alb.x, alb.y}, v2 = {alb.z, wo.x, wo.y, wo.z};
+    asm volatile("ds_write_b128 %0, %1\n\tds_write_b128 %0, %2 offset:16\n\tds_write_b128 %0, %3 offset:32" : : "v"(addr), "v"(v0), "v"(v1), "v"(v2) : "memory");
+}
+__device__ __forceinline__ void shade_ctx_load(uint32_t addr, F3 &p, F3 &n, F3 &alb, F3 &wo)
+{
+    f32x4 v0, v1, v2;
+    asm volatile("ds_read_b128 %0, %3\n\tds_read_b128 %1, %3 offset:16\n\tds_read_b128 %2, %3 offset:32\n\ts_waitcnt lgkmcnt(0)"
+                 : "=&v"(v0), "=&v"(v1), "=&v"(v2) : "v"(addr) : "memory");
+    p = f3(v0.x, v0.y, v0.z); n = f3(v0.w, v1.x, v1.y); alb = f3(v1.z, v1.w, v2.x); wo = f3(v2.y, v2.z, v2.w);
+}
+
 // MODE 0: one wavefront per block, queries traced where TraceFull asks for them.
 // MODE 1: k_trace_fan, three wavefronts per block (see above).
 // MODE 2: k_trace_refill, ONE wavefront per block and the same posting of a hit's queries, but stage B is a refill loop:
 //         the block's posted queries (up to 192) form a list, a lane that finishes its query takes the next one whichever
 //         pixel it belongs to, and the walk yields every `refill_steps` steps so that idle lanes can do so.  A block then
 //         costs about max(its longest query, its steps / 64) per stage instead of the sum of the stage's longest lanes.
-// MIG (MODE 0, flat scenes): PATH MIGRATION.  A block traces what is coherent - its pixels' primary rays and the shadow rays of the
-// primary hits - in place; the moment a pixel's NEXT query is a path query (the diffuse bounce or a mirror continuation) and its
-// work stack is empty, the pixel's whole TraceFull state (64 bytes: ray, throughput, radiance so far, generator, depths) goes into
-// the block's segment of a global queue and the lane is done.  Bounce rays differ in length by two orders of magnitude and only 3 %
-// of them lead to further shadow rays: traced in place, a block pays the longest lane of every batch (config 4: 554 k + 293 k of
-// the frame's 1.55 M wave-steps for work that fits in 102 k).  A wavefront that has finished its block publishes the segment and
-// then turns CONSUMER: it claims published segments (its own or anybody's), hands the paths to its idle lanes, advances all of
-// them a bounded number of steps per round (the query is resumable: flat_begin / flat_advance) and runs TraceFull's code for the
-// lanes whose query has ended - refilling a lane as soon as its path is finished.  When nothing is published and its lanes are done
-// it exits; whoever publishes later consumes later, the last publisher last.  One kernel, no spinning on another kernel's
-// progress (a published index whose word is not yet visible is waited for: its publisher is between two instructions).
-// Which wavefront finishes a path never changes the path: same queries, same additions in the same order.
-template <bool COUNT, bool FLAT, int MODE, bool MIG = false>
+template <bool COUNT, bool FLAT, int MODE>
 __device__ __forceinline__ void trace_block(const SceneDev &S, const FrameParams &P, const TraceOut &O, const uint32_t ent, const uint32_t sched_index,
-                                            FanShared *F, const int refill_steps, uint32_t *s_nmig = nullptr)
+                                            FanShared *F, const int refill_steps)
 {
     constexpr bool FAN = MODE != 0;          // queries are posted to LDS slots and answered in stage B
     constexpr bool WAVES3 = MODE == 1;
@@ -677,13 +677,36 @@ __device__ __forceinline__ void trace_block(const SceneDev &S, const FrameParams
     if (rng == 0) rng = 0x9E3779B97F4A7C15ULL;
     F3 radiance = f3(0, 0, 0), beta = f3(1, 1, 1);
     int mirror_depth = 0, diffuse_depth = 0;
-    bool item_is_primary = true, primary_hit_something = false, gbuf_valid = false, is_sky = false;
-    F3 g_albedo = f3(0, 0, 0), g_normal = f3(0, 0, 0);
-    float g_depth = YCGE_FLT_MAX;
-    int g_prim = -1, g_sub = 0;
+    bool item_is_primary = true, primary_hit_something = false, gbuf_valid = false;
+    // The G-buffer (PrimaryGBuffer, :400-405) and the sky flag are decided by the pixel's FIRST query - only that work item is primary
+    // (:452, :462) - and are written out right there (write_gbuffer): nine values less to carry through every later query.
+    // (the pixel index goes through an empty asm at every use: otherwise the compiler computes the six 64-bit store addresses of a
+    // pixel once, in the prologue, keeps them live through the whole kernel - and spills them)
+#if defined(YCGE_DBG_B)
+    auto pixel_index = [&]() { return (size_t)px + (size_t)py * P.hiW; };
+#else
+    auto pixel_index = [&]() { int x = px, y = py; asm volatile("" : "+v"(x), "+v"(y)); return (size_t)x + (size_t)y * P.hiW; };
+#endif
+    auto write_gbuffer = [&](F3 g_albedo, F3 g_normal, float g_depth, int g_prim, int g_sub, bool is_sky) {
+        const size_t i = pixel_index();
+        O.g_albedo[3 * i + 0] = g_albedo.x; O.g_albedo[3 * i + 1] = g_albedo.y; O.g_albedo[3 * i + 2] = g_albedo.z;
+        O.g_normal[3 * i + 0] = g_normal.x; O.g_normal[3 * i + 1] = g_normal.y; O.g_normal[3 * i + 2] = g_normal.z;
+        O.g_depth[i] = g_depth;
+        O.sky[i] = is_sky ? 1 : 0;
+        if (DEBUG) {
+            if (O.prim_id) O.prim_id[i] = g_prim;
+            if (O.sub_id) O.sub_id[i] = g_sub;
+            if (O.hit_t) O.hit_t[i] = g_depth;
+        }
+    };
     int psp = 0;            // a 16-entry stack in the C#; occupancy never exceeds 3 (mirrorDepth < 2 gates pushes)
     // shading context kept across the shadow queries of one hit
+    // (position, normal, albedo, direction to the eye: parked in LDS between the hit and the light / bounce code that reads them,
+    // g_shade_ctx - twelve registers that would otherwise be live across every shadow query)
+    const uint32_t ctx_addr = (uint32_t)(uintptr_t)g_shade_ctx + (uint32_t)lane * 48u;
+#if defined(YCGE_DBG_A)
     F3 sh_p = f3(0, 0, 0), sh_n = f3(0, 0, 0), sh_alb = f3(0, 0, 0), sh_wo = f3(0, 0, 0);
+#endif
     int light = 0;
     float tr_r = 1.0f, tr_g = 1.0f, tr_b = 1.0f, sh_maxdist = 0.0f;
     int tr_counter = 0;
@@ -696,14 +719,6 @@ __device__ __forceinline__ void trace_block(const SceneDev &S, const FrameParams
     // the block's cost for the next frame's schedule: loop iterations its wavefront(s) spend in traversal = sum over the
     // query batches of the longest lane's steps.  The same scale whether the block is fanned or not.
     uint32_t wave_iters = 0;
-    // path migration state (MIG)
-    const bool mig_on = MIG && O.mig_entries != nullptr;
-    bool consuming = false, migrated = false, need_begin = false, mig_dry = false;
-    uint32_t mig_pixel = 0, seg_next = 0, seg_end = 0, mig_wait = 0, mig_poll = 0;
-    FlatQuery mq;
-    mq.cur = YCGE_REF_NONE_VALUE; mq.obj_i = 0; mq.n_top = 0; mq.closest = 0.0f; mq.hit_prim = -1; mq.hit_sub = 0; mq.mesh_prim = -1; mq.anyhit = false;
-    mq.inv = f3(0, 0, 0);
-    if (MIG) { if (lane == 0) *s_nmig = 0; }
     if (FAN) {
         if (WAVES3) F->q[wave][3][lane] = -1.0f;
         else { F->q[0][3][lane] = -1.0f; F->q[1][3][lane] = -1.0f; F->q[2][3][lane] = -1.0f; }
@@ -713,18 +728,9 @@ __device__ __forceinline__ void trace_block(const SceneDev &S, const FrameParams
     // what a block leaves behind when its last pixel is done (or handed over): the pixels, the schedule feedback, the profile record
     auto finish_block = [&]() {
     if (in_image) {                                     // :210-215
-        const size_t i = (size_t)px + (size_t)py * P.hiW;
-        if (!migrated) { O.current_hdr[3 * i + 0] = radiance.x; O.current_hdr[3 * i + 1] = radiance.y; O.current_hdr[3 * i + 2] = radiance.z; }      // a migrated path's consumer writes the radiance
-        O.g_albedo[3 * i + 0] = g_albedo.x; O.g_albedo[3 * i + 1] = g_albedo.y; O.g_albedo[3 * i + 2] = g_albedo.z;
-        O.g_normal[3 * i + 0] = g_normal.x; O.g_normal[3 * i + 1] = g_normal.y; O.g_normal[3 * i + 2] = g_normal.z;
-        O.g_depth[i] = g_depth;
-        O.sky[i] = is_sky ? 1 : 0;
-        if (DEBUG) {
-            if (O.prim_id) O.prim_id[i] = g_prim;
-            if (O.sub_id) O.sub_id[i] = g_sub;
-            if (O.hit_t) O.hit_t[i] = g_depth;
-            if (O.rng_state && !migrated) O.rng_state[i] = rng;
-        }
+        const size_t i = pixel_index();
+        O.current_hdr[3 * i + 0] = radiance.x; O.current_hdr[3 * i + 1] = radiance.y; O.current_hdr[3 * i + 2] = radiance.z;
+        if (DEBUG && O.rng_state) O.rng_state[i] = rng;
     }
     // a part of a split block sees fewer lanes, hence fewer iterations than the whole block would: scaled so that the block
     // stays in its schedule class from frame to frame (x 1.5 for 4 parts, x 2 for 16, x 2.5 for 64: measured ratios are 1.3-2)
@@ -743,135 +749,28 @@ __device__ __forceinline__ void trace_block(const SceneDev &S, const FrameParams
     for (;;) {
         float t_hit = 0.0f;
         int hit_prim = -1, hit_sub = 0;
-        if (MIG && consuming) {
-            // ---- consumer round: refill idle lanes, advance every live query a bounded number of steps, then TraceFull's code below for
-            // the lanes whose query has ended (batched: the shading code is long, it runs when enough lanes wait for it)
-            unsigned long long idle = __ballot(phase == PH_DONE);
-            while (idle != 0ull && !mig_dry) {
-                if (seg_next == seg_end) {
-                    // Claim a published segment.  YCGE_MIG_QUEUES queues (a block publishes on queue bid % Q), each with its own {tail, head}
-                    // pair on its own cache line: ONE global pair made every claim a compare-and-swap fight of thousands of wavefronts
-                    // (measured: 10 us per claim, 330 ms per frame).  Lane l looks at queue (bid + l) % Q - the whole scan is one round trip -
-                    // and the first lane that sees work tries to take it.
-                    // (only YCGE_MIG_SCAN neighbouring queues per look: every wavefront polling every queue made the 64 control lines a
-                    // memory hot spot - uncached loads of the same lines from thousands of wavefronts slowed the whole launch 40x)
-                    const uint32_t my_q = (bid + (uint32_t)lane) & (YCGE_MIG_QUEUES - 1u);
-                    unsigned long long *ctl = O.mig_ctl + (size_t)my_q * YCGE_MIG_CTL_STRIDE;
-                    unsigned long long h = 0, t = 0;
-                    if (lane < YCGE_MIG_SCAN) {
-                        h = __hip_atomic_load(ctl + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                        t = __hip_atomic_load(ctl + 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    }
-                    const unsigned long long have = __ballot(h < t);
-                    if (have == 0ull) { mig_dry = true; break; }
-                    const int pick = (int)__builtin_ctzll(have);
-                    unsigned long long word = 0;
-                    int got = 0;
-                    if (lane == pick) {
-                        if (__hip_atomic_compare_exchange_strong(ctl + 1, &h, h + 1ull, __ATOMIC_RELAXED, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) {
-                            unsigned long long *slot = O.mig_pub + ((size_t)my_q * O.mig_ring + (size_t)(h % (unsigned long long)O.mig_ring));
-                            // the publisher took index h before it stored the word: it is a few instructions away
-                            for (uint32_t spin = 0; spin < (1u << 24); spin++) {
-                                word = __hip_atomic_load(slot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                                if (word != 0ull) break;
-                                __builtin_amdgcn_s_sleep(1);
-                            }
-                            __hip_atomic_store(slot, 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);       // the ring entry is free again
-                            got = word != 0ull ? 1 : 2;        // 2: a publisher that never came (cannot happen; never hang)
-                        } else got = 3;                         // somebody else took it: look again
-                    }
-                    got = __builtin_amdgcn_readlane(got, pick);
-                    if (got == 2) { mig_dry = true; break; }
-                    if (got == 3) { __builtin_amdgcn_s_sleep(1); continue; }
-                    const uint32_t w_lo = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)word, pick);
-                    const uint32_t w_hi = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(word >> 32), pick);
-                    const unsigned long long ww = ((unsigned long long)(w_hi & 0x7fffffffu) << 32) | w_lo;
-                    seg_next = (uint32_t)(ww >> 8);
-                    seg_end = seg_next + (uint32_t)(ww & 0xffu);
-                    continue;
-                }
-                const uint32_t avail = seg_end - seg_next, n_idle = (uint32_t)__popcll(idle);
-                const uint32_t take = avail < n_idle ? avail : n_idle;
-                const uint32_t rk = __builtin_amdgcn_mbcnt_hi((uint32_t)(idle >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)idle, 0u));
-                if (phase == PH_DONE && rk < take) {
-                    const MigEntry *ep = O.mig_entries + (seg_next + rk);
-                    f32x4 ea, eb, ec, ed;
-                    asm volatile("global_load_dwordx4 %0, %4, off sc1\n\tglobal_load_dwordx4 %1, %4, off offset:16 sc1\n\t"
-                                 "global_load_dwordx4 %2, %4, off offset:32 sc1\n\tglobal_load_dwordx4 %3, %4, off offset:48 sc1\n\ts_waitcnt vmcnt(0)"
-                                 : "=&v"(ea), "=&v"(eb), "=&v"(ec), "=&v"(ed) : "v"(ep) : "memory");
-                    q.o = f3(ea.x, ea.y, ea.z); q.d = f3(ea.w, eb.x, eb.y); q.tmin = 0.001f; q.tmax = YCGE_FLT_MAX; q.anyhit = false;
-                    beta = f3(eb.z, eb.w, ec.x);
-                    radiance = f3(ec.y, ec.z, ec.w);
-                    rng = (uint64_t)__float_as_uint(ed.x) | ((uint64_t)__float_as_uint(ed.y) << 32);
-                    mig_pixel = __float_as_uint(ed.z);
-                    mirror_depth = (int)(__float_as_uint(ed.w) & 15u); diffuse_depth = (int)((__float_as_uint(ed.w) >> 4) & 15u);
-                    psp = 0; item_is_primary = false; primary_hit_something = true; gbuf_valid = true; is_sky = false;
-                    phase = PH_PATH; need_begin = true;
-                }
-                seg_next += take;
-                idle = __ballot(phase == PH_DONE);
-            }
-            if (!__any(phase != PH_DONE)) {
-                if (!mig_dry) continue;
-                // nothing in flight and nothing published when we last looked: look once more, then leave
-                const unsigned long long *ctl = O.mig_ctl + (size_t)((bid + (uint32_t)lane) & (YCGE_MIG_QUEUES - 1u)) * YCGE_MIG_CTL_STRIDE;
-                bool more = false;
-                if (lane < YCGE_MIG_SCAN) more = __hip_atomic_load(ctl + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < __hip_atomic_load(ctl + 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                if (__any(more)) { mig_dry = false; continue; }
-                break;
-            }
-            mig_poll++;
-            if (mig_dry && seg_next == seg_end && (mig_poll & 3u) == 0u && __popcll(__ballot(phase == PH_DONE)) >= 32) {
-                // while some lanes still work, new segments may have been published: look again now and then, when half the lanes idle
-                const unsigned long long *ctl = O.mig_ctl + (size_t)((bid + (uint32_t)lane) & (YCGE_MIG_QUEUES - 1u)) * YCGE_MIG_CTL_STRIDE;
-                bool more = false;
-                if (lane < YCGE_MIG_SCAN) more = __hip_atomic_load(ctl + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < __hip_atomic_load(ctl + 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                if (__any(more)) mig_dry = false;
-            }
-            if (phase != PH_DONE && need_begin) { flat_begin<COUNT>(S, q, st, mq, w); need_begin = false; }
-            bool fin = false;
-            if (phase != PH_DONE) fin = flat_advance<COUNT, true>(S, q, st, mq, w, O.mig_round_steps);
-            const uint32_t n_fin = (uint32_t)__popcll(__ballot(fin)), n_trav = (uint32_t)__popcll(__ballot(phase != PH_DONE && !fin));
-            const bool shade_now = n_fin > 0u && (n_fin >= (uint32_t)O.mig_shade_min || n_trav == 0u || mig_wait >= 3u);
-            mig_wait = (n_fin > 0u && !shade_now) ? mig_wait + 1u : 0u;
-            if (!shade_now || !fin) continue;
-            t_hit = mq.closest; hit_prim = mq.hit_prim; hit_sub = mq.hit_sub;
-            need_begin = true;              // whatever query TraceFull asks for next starts afresh
-        } else {
-        if (!__any(phase != PH_DONE && !parked)) {
-            if (!mig_on) break;
-            // ---- the block is done: write it out, publish its segment of migrated paths, turn consumer
-            finish_block();
-            const uint32_t n_mig = *s_nmig;
-            if (n_mig > 0u) {
-                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");         // the (write-through) entry stores of every lane have been acknowledged before the word goes out
-                if (lane == 0) {
-                    const uint32_t pq = bid & (YCGE_MIG_QUEUES - 1u);
-                    const unsigned long long idx = __hip_atomic_fetch_add(O.mig_ctl + (size_t)pq * YCGE_MIG_CTL_STRIDE, 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    const unsigned long long base_entry = (unsigned long long)bid * 64ull + (unsigned long long)(YCGE_ENT_PART(ent) * (uint32_t)live_lanes);
-                    __hip_atomic_store(O.mig_pub + ((size_t)pq * O.mig_ring + (size_t)(idx % (unsigned long long)O.mig_ring)),
-                                       ((base_entry << 8) | (unsigned long long)n_mig) | (1ull << 63), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                }
-            }
-            consuming = true;
-            phase = PH_DONE;
-            continue;
-        }
+        if (!__any(phase != PH_DONE && !parked)) break;
         const uint32_t steps_before = w.steps;
-        // cooperative record fetch (flat scenes, the timed kernels): every lane enters the query, lanes without one with live = false
-        constexpr bool COOPQ = YCGE_SPLIT_QUERIES && FLAT && !COUNT;
-        if (!FAN && COOPQ) {
+#if defined(YCGE_DBG_NOFULL)
+        if (!FAN) { if (phase != PH_DONE) traverse<COUNT, true, FLAT, false>(S, q, st, t_hit, hit_prim, hit_sub, w); }
+        else if (phase != PH_DONE && !parked) {
+#else
+        if (!FAN) {         // every lane of the wavefront enters (the cooperative walk needs them all): finished pixels carry live = false
             q.live = phase != PH_DONE;
             traverse<COUNT, true, FLAT, true>(S, q, st, t_hit, hit_prim, hit_sub, w);
         } else if (phase != PH_DONE && !parked) {
-            if (!FAN) traverse<COUNT, true, FLAT>(S, q, st, t_hit, hit_prim, hit_sub, w);
-            else if (want == 3) { t_hit = pre_b_t; hit_prim = pre_b_prim; hit_sub = pre_b_sub; }
+#endif
+            if (want == 3) { t_hit = pre_b_t; hit_prim = pre_b_prim; hit_sub = pre_b_sub; }
             else { t_hit = F->r[want][0][lane]; hit_prim = __float_as_int(F->r[want][1][lane]); hit_sub = __float_as_int(F->r[want][2][lane]); }
         }
         if (!FAN) wave_iters += wave_umax(w.steps - steps_before);
         if (phase == PH_DONE || parked) continue;
-        }
         const bool hit = hit_prim >= 0;
+#if !defined(YCGE_DBG_A)
+        F3 sh_p, sh_n, sh_alb, sh_wo;
+        if (phase != PH_PATH) shade_ctx_load(ctx_addr, sh_p, sh_n, sh_alb, sh_wo);      // a shadow query's answer: back to the hit it belongs to
+        else { sh_p = sh_n = sh_alb = sh_wo = f3(0, 0, 0); }
+#endif
         int new_kind = 0;       // the next query: 1 = first shadow segment towards `light`, 2 = bounce, 0 = anything else
         bool fanned = false;
 
@@ -881,8 +780,7 @@ __device__ __forceinline__ void trace_block(const SceneDev &S, const FrameParams
                 float tbg = 0.5f * (q.d.y + 1.0f);
                 F3 sky = lerp3(f3(S.bg_bottom), f3(S.bg_top), tbg);
                 if (item_is_primary && !primary_hit_something) {
-                    is_sky = true;
-                    if (!gbuf_valid) { g_albedo = f3(0, 0, 0); g_normal = f3(0, 0, 0); g_depth = YCGE_FLT_MAX; g_prim = -1; g_sub = 0; gbuf_valid = true; }
+                    if (!gbuf_valid) { write_gbuffer(f3(0, 0, 0), f3(0, 0, 0), YCGE_FLT_MAX, -1, 0, true); gbuf_valid = true; }
                 }
                 radiance = radiance + f3(beta.x * sky.x, beta.y * sky.y, beta.z * sky.z);
                 go_next_item = true;
@@ -892,8 +790,7 @@ __device__ __forceinline__ void trace_block(const SceneDev &S, const FrameParams
                 if (YCGE_TEXTURES && !FLAT && S.any_textured) apply_texture(S, hit_prim, hit_sub, q.o, q.d, h);      // (the host sends textured scenes to the generic kernels)
                 if (item_is_primary) {
                     primary_hit_something = true;
-                    is_sky = false;
-                    if (!gbuf_valid) { g_albedo = h.m.albedo; g_normal = h.n; g_depth = t_hit; g_prim = hit_prim; g_sub = h.sub_public; gbuf_valid = true; }
+                    if (!gbuf_valid) { write_gbuffer(h.m.albedo, h.n, t_hit, hit_prim, h.sub_public, false); gbuf_valid = true; }
                     item_is_primary = false;
                 }
                 if (h.m.emission.x != 0.0f || h.m.emission.y != 0.0f || h.m.emission.z != 0.0f) {
@@ -951,12 +848,20 @@ __device__ __forceinline__ void trace_block(const SceneDev &S, const FrameParams
                     }
                 } else {
                     if (S.ambient_intensity > 0.0f) {   // :571-576
-                        F3 a = f3(S.ambient[0] * S.ambient_intensity, S.ambient[1] * S.ambient_intensity, S.ambient[2] * S.ambient_intensity);
+                        float ai = S.ambient_intensity;
+#if !defined(YCGE_DBG_B)
+                        asm volatile("" : "+s"(ai));
+#endif
+                        // (evaluated here, per hit: hoisted out of the loop the three products sit in registers for the whole kernel)
+                        F3 a = f3(S.ambient[0] * ai, S.ambient[1] * ai, S.ambient[2] * ai);
                         F3 amb = f3(a.x * base_albedo.x, a.y * base_albedo.y, a.z * base_albedo.z);
                         radiance = radiance + f3(beta.x * amb.x, beta.y * amb.y, beta.z * amb.z);
                     }
                     sh_p = h.p; sh_n = h.n; sh_alb = base_albedo;
                     sh_wo = normalized(q.d * -1.0f);
+#if !defined(YCGE_DBG_A)
+                    shade_ctx_store(ctx_addr, sh_p, sh_n, sh_alb, sh_wo);
+#endif
                     light = 0;
                     go_lights = true;
                     if (FAN) {          // post this hit's independent queries: the expressions of the light loop head and the bounce below
@@ -1085,31 +990,6 @@ __device__ __forceinline__ void trace_block(const SceneDev &S, const FrameParams
             }
         }
 
-        if (MIG && mig_on) {
-            if (!consuming) {
-                // hand the path over: its next query is a path query (bounce, mirror continuation, popped item) and nothing is stacked
-                if (phase == PH_PATH && psp == 0) {
-                    const uint32_t slot = atomicAdd(s_nmig, 1u);
-                    // the entry goes out WRITE-THROUGH (sc1) and is read back with sc1 loads: no cache write-back / invalidate fences
-                    // (a buffer_wbl2 per published segment - 32 k per frame - cost 340 ms: it flushes the XCD's whole L2 every time)
-                    MigEntry *ep = O.mig_entries + ((size_t)bid * 64u + (size_t)(YCGE_ENT_PART(ent) * (uint32_t)live_lanes) + slot);
-                    const f32x4 e0 = {q.o.x, q.o.y, q.o.z, q.d.x}, e1 = {q.d.y, q.d.z, beta.x, beta.y}, e2 = {beta.z, radiance.x, radiance.y, radiance.z};
-                    const f32x4 e3 = {__uint_as_float((uint32_t)rng), __uint_as_float((uint32_t)(rng >> 32)), __uint_as_float((uint32_t)px + (uint32_t)py * (uint32_t)P.hiW),
-                                      __uint_as_float((uint32_t)mirror_depth | ((uint32_t)diffuse_depth << 4))};
-                    asm volatile("global_store_dwordx4 %0, %1, off sc1\n\tglobal_store_dwordx4 %0, %2, off offset:16 sc1\n\t"
-                                 "global_store_dwordx4 %0, %3, off offset:32 sc1\n\tglobal_store_dwordx4 %0, %4, off offset:48 sc1"
-                                 : : "v"(ep), "v"(e0), "v"(e1), "v"(e2), "v"(e3) : "memory");
-                    migrated = true;
-                    phase = PH_DONE;
-                }
-            } else if (phase == PH_DONE) {
-                // a migrated path has ended: its radiance is the pixel's (RaytraceRenderer.cs:210)
-                float *dst = O.current_hdr + 3 * (size_t)mig_pixel;
-                dst[0] = radiance.x; dst[1] = radiance.y; dst[2] = radiance.z;
-                if (DEBUG && O.rng_state) O.rng_state[mig_pixel] = rng;
-            }
-        }
-
         if (FAN && phase != PH_DONE) {                  // where is the answer to the query just set up?
             if (new_kind == 1 && light == pre_l1) { want = 1; pre_l1 = -1; }
             else if (new_kind == 1 && light == pre_l2) { want = 2; pre_l2 = -1; }
@@ -1127,22 +1007,15 @@ __device__ __forceinline__ void trace_block(const SceneDev &S, const FrameParams
        // ---- stage B: wavefront w answers slot w
        const float f_tmin = F->q[wave][3][lane];
        const uint32_t steps_before = w.steps;
-       constexpr bool COOPB = YCGE_COOP_FETCH && FLAT && !COUNT;
-       if (COOPB) {
+       {
            RayQ fq = fan_query(F, wave, lane);
            fq.live = f_tmin >= 0.0f;
            float f_t; int f_prim, f_sub;
            traverse<COUNT, true, FLAT, true>(S, fq, st, f_t, f_prim, f_sub, w);
            if (fq.live) {
-               F->r[wave][0][lane] = f_t; F->r[wave][1][lane] = __int_as_float(f_prim); F->r[wave][2][lane] = __int_as_float(f_sub);
-               F->q[wave][3][lane] = -1.0f;
-           }
-       } else if (f_tmin >= 0.0f) {
-           const RayQ fq = fan_query(F, wave, lane);
-           float f_t; int f_prim, f_sub;
-           traverse<COUNT, true, FLAT>(S, fq, st, f_t, f_prim, f_sub, w);
            F->r[wave][0][lane] = f_t; F->r[wave][1][lane] = __int_as_float(f_prim); F->r[wave][2][lane] = __int_as_float(f_sub);
            F->q[wave][3][lane] = -1.0f;
+           }
        }
        wave_iters += wave_umax(w.steps - steps_before);
        __syncthreads();
@@ -1197,31 +1070,31 @@ __device__ __forceinline__ void trace_block(const SceneDev &S, const FrameParams
         __syncthreads();
         if (wave != 0) { flush_work<COUNT>(w, O.counters); return; }
     }
-    if (!mig_on) finish_block();
+    finish_block();
     flush_work<COUNT>(w, O.counters);
 }
 
-// Occupancy targets of the flat, non-counting variants.  4 wavefronts per SIMD means a 128-VGPR budget: k_trace then carries 44 bytes
-// of scratch (19 spilled registers, all outside the traversal loops).  On its own that buys nothing - the frame ends with its longest
-// chains (0.601 vs 0.604 ms) - but together with fanning the ~200 blocks most likely to be those chains it does: the bulk of the
-// frame gets a third more slots and absorbs the helper wavefronts (0.590 -> 0.569 ms; 3 + 4 or 4 + 3 wavefronts: 0.60 / 0.59).
+// Occupancy targets of the flat, non-counting variants.  Round 2 ran k_trace at 4 wavefronts per SIMD (a 128-register budget, 19 spilled
+// registers) because the fanned head of the schedule needed the extra slots.  Round 3: with the cooperative walk the tails are short,
+// fan-out is off on whole frames, and 3 wavefronts per SIMD (168 registers: no scratch at all) are faster - each wavefront runs with
+// less contention, and the frame is bound by its longest chains and the late starters, not by slots (config 4, same box: 0.514 ms
+// at 3 wavefronts, 0.544 at 4; config 3: 0.306 / 0.331).
 #ifndef YCGE_TRACE_WAVES
-#define YCGE_TRACE_WAVES 4
+#define YCGE_TRACE_WAVES 3
 #endif
 #ifndef YCGE_FAN_WAVES
-#define YCGE_FAN_WAVES 4
+#define YCGE_FAN_WAVES 3        // k_trace_fan: no register cap below its natural ~150 (a fanned block's three wavefronts are latency chains, not throughput)
 #endif
 template <bool COUNT, bool FLAT>
 __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu((FLAT && !COUNT) ? YCGE_TRACE_WAVES : 2, 8))) void k_trace(const SceneDev S, const FrameParams P, const TraceOut O)
 {
-    __shared__ uint32_t s_nmig;
     uint32_t idx = blockIdx.x, ent = blockIdx.x;
     if (O.block_order) {
         if (O.n_fan) idx += *O.n_fan;           // the first n_fan entries belong to k_trace_fan
         if (idx >= *O.n_order) return;
         ent = O.block_order[idx];
     } else if (blockIdx.x >= (uint32_t)P.n_owned_tiles * 4u) return;
-    trace_block<COUNT, FLAT, 0, YCGE_MIGRATE && FLAT && !COUNT>(S, P, O, ent, idx, nullptr, 0, &s_nmig);
+    trace_block<COUNT, FLAT, 0>(S, P, O, ent, idx, nullptr, 0);
 }
 template <bool COUNT>
 __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(COUNT ? 2 : 3, 8))) void k_trace_refill(const SceneDev S, const FrameParams P, const TraceOut O, const int refill_steps)
@@ -1243,16 +1116,32 @@ __global__ __launch_bounds__(192) __attribute__((amdgpu_waves_per_eu((FLAT && !C
 }
 
 // ---------------------------------------------------------------------------------- block schedule (feedback from the previous frame)
-// cost[b] = traversal loop iterations of block b's wavefront(s) (trace_block).  Eight classes, finer towards the top
-// (class 7 = longest): < 64, < 128, < 192, < 256, < 384, < 512, < 768, more.  k_cost_hist counts entries per class,
-// k_cost_scatter writes the schedule class by class (descending) and clears cost[] for the next frame's atomicMax; both
-// batch their global atomics through LDS.
-// ws: [0..7] entries per class, [8..15] cursors, [16] total entries (read by k_trace), [18] = entries at the head of
-// the schedule that go to k_trace_fan
+// cost[b] = traversal loop iterations of block b's wavefront(s) (trace_block).  Eight POLICY classes, finer towards the top
+// (class 7 = longest): < 64, < 128, < 192, < 256, < 384, < 512, < 768, more - what the fan-out / split knobs speak of - and 32
+// ORDER classes nested inside them (order_class), finer towards the bottom too: the schedule is written order class by order class,
+// longest first.  (With eight classes everything below 64 iterations - nine blocks in ten, up to ~90 us each - came in index order,
+// and the frame drained for 0.1 ms behind 100-us blocks that had started last: round 3.)  k_cost_hist counts entries per order class,
+// k_cost_scatter writes the schedule and clears cost[] for the next frame's atomicMax; both batch their global atomics through LDS.
+// ws: [16] total entries (read by k_trace), [18] = entries at the head of the schedule that go to k_trace_fan,
+//     [32..63] entries per order class, [64..95] cursors
+#define YCGE_ORDER_CLASSES 32
 __device__ __forceinline__ int cost_class(uint32_t c)
 {
     return c < 64u ? 0 : c < 128u ? 1 : c < 192u ? 2 : c < 256u ? 3 : c < 384u ? 4 : c < 512u ? 5 : c < 768u ? 6 : 7;
 }
+// 0..7: eight steps of 8 below 64; then four steps per octave-ish policy class pair: [64,128) by 16, [128,256) by 32, [256,512) by 64,
+// [512,1024) by 128, [1024, ...) by 256 up to class 31.  Every policy-class boundary (64, 128, 192, 256, 384, 512, 768) is a boundary here.
+__device__ __forceinline__ int order_class(uint32_t c)
+{
+    if (c < 64u) return (int)(c >> 3);
+    if (c < 128u) return 8 + (int)((c - 64u) >> 4);
+    if (c < 256u) return 12 + (int)((c - 128u) >> 5);
+    if (c < 512u) return 16 + (int)((c - 256u) >> 6);
+    if (c < 1024u) return 20 + (int)((c - 512u) >> 7);
+    const uint32_t k = 24u + ((c - 1024u) >> 8);
+    return (int)(k < 31u ? k : 31u);
+}
+__device__ __forceinline__ int policy_class_of_order_class(int oc) { return oc < 8 ? 0 : oc < 12 ? 1 : oc < 14 ? 2 : oc < 16 ? 3 : oc < 18 ? 4 : oc < 20 ? 5 : oc < 22 ? 6 : 7; }
 // split policy: log2(parts) of class c in bits [3c, 3c+3) of `policy`
 __device__ __forceinline__ uint32_t class_lg_parts(uint32_t policy, int cls) { return (policy >> (3 * cls)) & 7u; }
 // A block's schedule cost = the largest of its costs over the last YCGE_COST_FRAMES frames (ring of per-frame arrays, cost[f][b]):
@@ -1268,28 +1157,30 @@ __device__ __forceinline__ uint32_t smoothed_cost(const uint32_t *cost, uint32_t
 }
 __global__ __launch_bounds__(1024) void k_cost_hist(const uint32_t *__restrict__ cost, uint32_t n, uint32_t *__restrict__ ws)
 {
-    __shared__ uint32_t h[8];
-    if (threadIdx.x < 8) h[threadIdx.x] = 0;
+    __shared__ uint32_t h[YCGE_ORDER_CLASSES];
+    if (threadIdx.x < YCGE_ORDER_CLASSES) h[threadIdx.x] = 0;
     __syncthreads();
     const uint32_t i = blockIdx.x * 1024u + threadIdx.x;
-    if (i < n) { const int cls = cost_class(smoothed_cost(cost, n, i)); atomicAdd(&h[cls], 1u); }
+    if (i < n) { const int cls = order_class(smoothed_cost(cost, n, i)); atomicAdd(&h[cls], 1u); }
     __syncthreads();
-    if (threadIdx.x < 8 && h[threadIdx.x]) atomicAdd(&ws[threadIdx.x], h[threadIdx.x]);
+    if (threadIdx.x < YCGE_ORDER_CLASSES && h[threadIdx.x]) atomicAdd(&ws[32 + threadIdx.x], h[threadIdx.x]);
 }
 __global__ __launch_bounds__(1024) void k_cost_scatter(uint32_t *__restrict__ cost, uint32_t n, uint32_t capacity, uint32_t policy,
                                                        uint32_t fan_class, uint32_t fan_cap, uint32_t next_slot, uint32_t *__restrict__ ws, uint32_t *__restrict__ order)
 {
-    __shared__ uint32_t h[8], base[8];
+    __shared__ uint32_t h[YCGE_ORDER_CLASSES], base[YCGE_ORDER_CLASSES];
     __shared__ uint32_t s_split;
-    if (threadIdx.x < 8) h[threadIdx.x] = 0;
+    if (threadIdx.x < YCGE_ORDER_CLASSES) h[threadIdx.x] = 0;
     if (threadIdx.x == 0) {     // every workgroup derives the same decision from the finished histogram
         uint32_t total = 0;
-        for (int c = 0; c < 8; c++) total += ws[c] << class_lg_parts(policy, c);
+        for (int c = 0; c < YCGE_ORDER_CLASSES; c++) total += ws[32 + c] << class_lg_parts(policy, policy_class_of_order_class(c));
         s_split = total <= capacity ? 1u : 0u;
         if (blockIdx.x == 0) {
             ws[16] = s_split ? total : n;
-            uint32_t n_fan = 0;                 // blocks of the classes >= fan_class, at the head of the schedule
-            if (fan_class > 0) for (int c = 7; c >= (int)fan_class; c--) n_fan += ws[c] << (s_split ? class_lg_parts(policy, c) : 0u);
+            uint32_t n_fan = 0;                 // blocks of the policy classes >= fan_class, at the head of the schedule
+            if (fan_class > 0)
+                for (int c = YCGE_ORDER_CLASSES - 1; c >= 0 && policy_class_of_order_class(c) >= (int)fan_class; c--)
+                    n_fan += ws[32 + c] << (s_split ? class_lg_parts(policy, policy_class_of_order_class(c)) : 0u);
             ws[18] = n_fan < fan_cap ? n_fan : fan_cap;
         }
     }
@@ -1299,16 +1190,16 @@ __global__ __launch_bounds__(1024) void k_cost_scatter(uint32_t *__restrict__ co
     int cls = -1;
     uint32_t local = 0, lgp = 0;
     if (i < n) {
-        cls = cost_class(smoothed_cost(cost, n, i));
+        cls = order_class(smoothed_cost(cost, n, i));
         cost[(size_t)next_slot * n + i] = 0;         // the ring slot the next frame's atomicMax goes to
-        lgp = split ? class_lg_parts(policy, cls) : 0u;
+        lgp = split ? class_lg_parts(policy, policy_class_of_order_class(cls)) : 0u;
         local = atomicAdd(&h[cls], 1u << lgp);
     }
     __syncthreads();
-    if (threadIdx.x < 8) {
-        uint32_t off = 0;                                   // classes 7, 6, ..., 0 laid out in that order
-        for (int c = 7; c > (int)threadIdx.x; c--) off += ws[c] << (split ? class_lg_parts(policy, c) : 0u);
-        base[threadIdx.x] = off + (h[threadIdx.x] ? atomicAdd(&ws[8 + threadIdx.x], h[threadIdx.x]) : 0u);
+    if (threadIdx.x < YCGE_ORDER_CLASSES) {
+        uint32_t off = 0;                                   // order classes 31, 30, ..., 0 laid out in that order
+        for (int c = YCGE_ORDER_CLASSES - 1; c > (int)threadIdx.x; c--) off += ws[32 + c] << (split ? class_lg_parts(policy, policy_class_of_order_class(c)) : 0u);
+        base[threadIdx.x] = off + (h[threadIdx.x] ? atomicAdd(&ws[64 + threadIdx.x], h[threadIdx.x]) : 0u);
     }
     __syncthreads();
     if (cls >= 0) {
@@ -1488,7 +1379,6 @@ template <class F> void sel3(bool a, bool b, bool c, F f)
 
 extern "C" {
 
-int ycge_kernel_has_migration(void) { return YCGE_MIGRATE ? 1 : 0; }
 
 size_t ycge_wf_sizes(int which)
 {
@@ -1565,7 +1455,7 @@ int ycge_launch_order_blocks(uint32_t *cost, uint32_t n, uint32_t policy, uint32
                              uint32_t *order, hipStream_t stream)
 {
     if (n == 0) return 0;
-    hipError_t e = hipMemsetAsync(ws, 0, 18 * sizeof(uint32_t), stream);     // ws[18] (n_fan) is rewritten by k_cost_scatter
+    hipError_t e = hipMemsetAsync(ws, 0, 96 * sizeof(uint32_t), stream);     // ws[16] / ws[18] (entries, n_fan) are rewritten by k_cost_scatter before anyone reads them
     if (e != hipSuccess) return (int)e;
     const dim3 grid((n + 1023u) / 1024u), block(1024);
     hipLaunchKernelGGL(ycge::k_cost_hist, grid, block, 0, stream, cost, n, ws);

@@ -42,7 +42,9 @@ struct RayQ {              // one closest-hit query: Scene.Hit(r, tMin, tMax)
     // (RaytraceRenderer.cs:761-765, 773-781).  Such a query may stop at its first accepted hit: same radiance, fewer
     // steps.  The counting variants never do (their counters are the reference's full traversal).
     bool anyhit = false;
-    bool live = true;          // cooperative-fetch callers enter traverse() with every lane of the wavefront; lanes without a query carry live = false
+    // FULLWAVE callers (the single-launch kernels) enter traverse() with EVERY lane of the wavefront, so that the cooperative walk
+    // (ycge_coop.hip.h) can use them all; a lane that has no query to trace carries live = false
+    bool live = true;
 };
 
 struct Work {              // SURVEY 8(d) counters (COUNT variants) + this lane's traversal steps (always; scheduling feedback)
@@ -692,6 +694,7 @@ __device__ __forceinline__ bool is_wire_on_face(const GGrid &g, F3 p, int ix, in
 #define YCGE_BLOCK 256
 static __shared__ uint2 g_lds_stack[YCGE_LDS_STACK * YCGE_BLOCK];     // 256-thread workgroups (tile = workgroup)
 static __shared__ uint2 g_lds_stack64[YCGE_LDS_STACK * 64];           // 64-thread workgroups (8x8 block = workgroup)
+static __shared__ uint2 g_lds_stack192[YCGE_LDS_STACK * 192];         // 192-thread workgroups (k_trace_fan: a block's three wavefronts)
 
 // The LDS part is accessed with explicit ds_read_b64 / ds_write_b64: written as plain C++ the compiler merges the
 // "LDS or spill" choice into ONE flat_load through a selected generic pointer (seen in the ISA), which puts the
@@ -719,7 +722,11 @@ struct StackT {
     {
         spill = (uint2 *)spill_base + (first_lane + blockIdx.x * BS + threadIdx.x);
         spill_stride = n_lanes;
+#if defined(YCGE_DBG_D)
         lds_base = (uint32_t)(uintptr_t)(BS == 64 ? (void *)g_lds_stack64 : (void *)g_lds_stack) + threadIdx.x * 8u;
+#else
+        lds_base = (uint32_t)(uintptr_t)(BS == 64 ? (void *)g_lds_stack64 : BS == 192 ? (void *)g_lds_stack192 : (void *)g_lds_stack) + threadIdx.x * 8u;
+#endif
         sp = 0;
     }
     __device__ __forceinline__ void reset() { sp = 0; }
@@ -741,6 +748,31 @@ struct StackT {
             ref = v.x; tnear = __uint_as_float(v.y);
         }
         return true;
+    }
+    // entry `lvl` of the stack of thread `owner` of this workgroup (the cooperative walk: a group of lanes works on the owner's stack)
+    __device__ __forceinline__ void write_at(uint32_t owner, int lvl, uint32_t ref, float tnear) const
+    {
+        if (lvl < YCGE_LDS_STACK) lds_write_b64(lds_base - threadIdx.x * 8u + owner * 8u + (uint32_t)lvl * (BS * 8u), ref, __float_as_uint(tnear));
+        else (spill - threadIdx.x + owner)[(size_t)(lvl - YCGE_LDS_STACK) * spill_stride] = make_uint2(ref, __float_as_uint(tnear));
+    }
+    // The same read asked for EARLY (LDS levels only; any other level asks for level 0 and the caller does not use the answer).  Plain C++
+    // on purpose: the compiler tracks this load itself and puts the wait in front of the first USE, wherever the value has travelled by
+    // then (a hand-issued asm load would be invisible to its wait-count bookkeeping, and a register copy at a loop edge would read stale data).
+    __device__ __forceinline__ uint2 read_early(uint32_t owner, int lvl) const
+    {
+        const uint32_t l = lvl >= 0 && lvl < YCGE_LDS_STACK ? (uint32_t)lvl : 0u;
+        const uint2 *base = BS == 64 ? g_lds_stack64 : BS == 192 ? g_lds_stack192 : g_lds_stack;
+        return base[l * BS + owner];
+    }
+    __device__ __forceinline__ void read_at(uint32_t owner, int lvl, uint32_t &ref, float &tnear) const
+    {
+        if (lvl < YCGE_LDS_STACK) {
+            const u32x2 v = lds_read_b64(lds_base - threadIdx.x * 8u + owner * 8u + (uint32_t)lvl * (BS * 8u));
+            ref = v.x; tnear = __uint_as_float(v.y);
+        } else {
+            const uint2 v = (spill - threadIdx.x + owner)[(size_t)(lvl - YCGE_LDS_STACK) * spill_stride];
+            ref = v.x; tnear = __uint_as_float(v.y);
+        }
     }
 };
 using Stack = StackT<256>;
@@ -978,27 +1010,6 @@ __device__ __forceinline__ void walk(const SceneDev &S, uint32_t cur, int mesh_p
 // a node (64 B) or a triangle pair record (its first 72 B) in one round trip: every fetch is issued before the
 // single wait.  The fifth fetch only has a use for leaf lanes; for node lanes it reads the start of the next
 // node (the arrays are padded at upload).
-// Variant (-DYCGE_LEAF_ONLY_TAIL=1): the last 8 bytes are fetched by the lanes that are at a LEAF only (exec masked for that one
-// instruction).  Every load instruction of a divergent wavefront costs the texture-address unit one look-up per lane
-// (profiles/micro/fetchrate.hip: 4 + 1 loads per lane 2.08 us per wave-step at 4 wavefronts per SIMD, 4 loads 1.44 us), and three
-// steps in four are node visits.
-__device__ __forceinline__ void load_record72_leaf_tail(const uint8_t *base, uint32_t byte_offset, unsigned long long leaf_mask, f32x4 &a, f32x4 &b,
-                                                        f32x4 &c, f32x4 &e, f32x2 &f)
-{
-    unsigned long long saved;
-    f = f32x2{0.0f, 0.0f};
-    asm volatile("global_load_dwordx4 %0, %6, %7\n\t"
-                 "global_load_dwordx4 %1, %6, %7 offset:16\n\t"
-                 "global_load_dwordx4 %2, %6, %7 offset:32\n\t"
-                 "global_load_dwordx4 %3, %6, %7 offset:48\n\t"
-                 "s_and_saveexec_b64 %5, %8\n\t"
-                 "global_load_dwordx2 %4, %6, %7 offset:64\n\t"
-                 "s_mov_b64 exec, %5\n\t"
-                 "s_waitcnt vmcnt(0)"
-                 : "=&v"(a), "=&v"(b), "=&v"(c), "=&v"(e), "+v"(f), "=&s"(saved)
-                 : "v"(byte_offset), "s"(base), "s"(leaf_mask)
-                 : "memory", "scc");
-}
 __device__ __forceinline__ void load_record72(const uint8_t *base, uint32_t byte_offset, f32x4 &a, f32x4 &b, f32x4 &c, f32x4 &e, f32x2 &f)
 {
     asm volatile("global_load_dwordx4 %0, %5, %6\n\t"
@@ -1011,64 +1022,11 @@ __device__ __forceinline__ void load_record72(const uint8_t *base, uint32_t byte
                  : "v"(byte_offset), "s"(base)
                  : "memory");
 }
-// ---- quad-cooperative record fetch (full wavefronts) ----------------------------------------------------------------------------
-// When every lane of a wavefront fetches its own record, each load instruction costs the texture-address unit one look-up PER LANE:
-// 4 x dwordx4 + 1 x dwordx2 = 320 look-ups per wave-step, and at 4 wavefronts per SIMD that unit - not HBM, not the VALU - sets the
-// pace (profiles/micro/fetchrate.hip: 2.08 us per wave-step, memory side alone, against 0.53 us when the four lanes of a QUAD read
-// the four 16-byte chunks of ONE record, which coalesce into a single look-up).  So: instruction r fetches the record of the quad's
-// lane r, lane j of the quad taking chunk j - by LDS-DMA (global_load_lds_dwordx4: no VGPR, no ds_write), plane r, slot = lane -
-// and every lane then reads its own record back with four ds_read_b128 (plane = its quad lane, slots of its quad).  The leaf
-// lanes' last 8 bytes stay a per-lane load.  Same bytes, same values; a sparse wavefront keeps the direct form (shorter chain).
-#define YCGE_COOP_PLANE 1040u           // 64 x 16 bytes + 16 of padding: the four planes a quad reads fall on different banks
-#ifndef YCGE_COOP_MIN_LANES
-#define YCGE_COOP_MIN_LANES 20          // live lanes from which the cooperative form is used
-#endif
-static __shared__ __attribute__((aligned(16))) uint8_t g_coop_planes64[4 * YCGE_COOP_PLANE];          // 64-thread workgroups (k_trace)
-static __shared__ __attribute__((aligned(16))) uint8_t g_coop_planes192[3][4 * YCGE_COOP_PLANE];      // 192-thread workgroups (k_trace_fan): per wavefront
-__device__ __forceinline__ void load_record72_coop(const uint8_t *base, uint32_t byte_offset, unsigned long long act_mask, unsigned long long leaf_mask,
-                                                   uint32_t lds_planes, f32x4 &a, f32x4 &b, f32x4 &c, f32x4 &e, f32x2 &f)
-{
-    const uint32_t lane = threadIdx.x & 63u, j = lane & 3u;
-    // byte offset of chunk j of the record of quad lane r (DPP quad broadcast; a disabled lane's value is never used: its instruction is masked)
-    const uint32_t o0 = (uint32_t)__builtin_amdgcn_mov_dpp((int)byte_offset, 0x00, 0xf, 0xf, true) + j * 16u;
-    const uint32_t o1 = (uint32_t)__builtin_amdgcn_mov_dpp((int)byte_offset, 0x55, 0xf, 0xf, true) + j * 16u;
-    const uint32_t o2 = (uint32_t)__builtin_amdgcn_mov_dpp((int)byte_offset, 0xaa, 0xf, 0xf, true) + j * 16u;
-    const uint32_t o3 = (uint32_t)__builtin_amdgcn_mov_dpp((int)byte_offset, 0xff, 0xf, 0xf, true) + j * 16u;
-    // lanes whose quad lane r is live: bit 4q + r of act_mask spread over quad q
-    const unsigned long long q1 = 0x1111111111111111ull;
-    unsigned long long m0 = act_mask & q1, m1 = (act_mask >> 1) & q1, m2 = (act_mask >> 2) & q1, m3 = (act_mask >> 3) & q1;
-    m0 = (m0 << 4) - m0; m1 = (m1 << 4) - m1; m2 = (m2 << 4) - m2; m3 = (m3 << 4) - m3;
-    unsigned long long saved;
-    unsigned keep;
-    f = f32x2{0.0f, 0.0f};
-    asm volatile("s_mov_b64 %1, exec\n\t"
-                 "s_mov_b32 %2, m0\n\t"
-                 "s_mov_b32 m0, %9\n\t"
-                 "s_mov_b64 exec, %10\n\t"
-                 "global_load_lds_dwordx4 %3, %8\n\t"
-                 "s_add_u32 m0, m0, 1040\n\t"
-                 "s_mov_b64 exec, %11\n\t"
-                 "global_load_lds_dwordx4 %4, %8\n\t"
-                 "s_add_u32 m0, m0, 1040\n\t"
-                 "s_mov_b64 exec, %12\n\t"
-                 "global_load_lds_dwordx4 %5, %8\n\t"
-                 "s_add_u32 m0, m0, 1040\n\t"
-                 "s_mov_b64 exec, %13\n\t"
-                 "global_load_lds_dwordx4 %6, %8\n\t"
-                 "s_mov_b64 exec, %14\n\t"
-                 "global_load_dwordx2 %0, %7, %8 offset:64\n\t"
-                 "s_mov_b64 exec, %1\n\t"
-                 "s_mov_b32 m0, %2\n\t"
-                 "s_waitcnt vmcnt(0)"
-                 : "+v"(f), "=&s"(saved), "=&s"(keep)
-                 : "v"(o0), "v"(o1), "v"(o2), "v"(o3), "v"(byte_offset), "s"(base), "s"(lds_planes), "s"(m0), "s"(m1), "s"(m2), "s"(m3), "s"(leaf_mask)
-                 : "memory", "scc");
-    const uint32_t rd = lds_planes + j * YCGE_COOP_PLANE + (lane & ~3u) * 16u;
-    asm volatile("ds_read_b128 %0, %4\n\tds_read_b128 %1, %4 offset:16\n\tds_read_b128 %2, %4 offset:32\n\tds_read_b128 %3, %4 offset:48\n\t"
-                 "s_waitcnt lgkmcnt(0)" : "=&v"(a), "=&v"(b), "=&v"(c), "=&v"(e) : "v"(rd) : "memory");
-}
+} // namespace ycge
+#include "ycge_coop.hip.h"
+namespace ycge {
 
-template <bool COUNT, bool BOUNDED = false, bool COOP = false, class STK>
+template <bool COUNT, bool BOUNDED = false, bool FULLWAVE = false, class STK>
 __device__ __forceinline__ void mesh_walk(const SceneDev &S, uint32_t &cur, int mesh_prim, STK &st, F3 o, F3 inv, F3 d, bool sx, bool sy,
                                           bool sz, float tmin, float &closest, int &hit_prim, int &hit_sub, Work &w, int budget = 0x7fffffff,
                                           bool anyhit = false)
@@ -1079,30 +1037,20 @@ __device__ __forceinline__ void mesh_walk(const SceneDev &S, uint32_t &cur, int 
     // direction sign afterwards picks the same values.
     const f32x2 oxy = {o.x, o.y}, ozz = {o.z, o.z};
     const f32x2 ixy = {inv.x, inv.y}, izz = {inv.z, inv.z};
-    // COOP: the caller enters with EVERY lane of the wavefront (lanes without a query carry cur = none), and the loop is wave-uniform:
-    // lanes that are done keep fetching chunks for their quad mates
-    const uint32_t coop_planes = !COOP ? 0u : (uint32_t)__builtin_amdgcn_readfirstlane((int)(STK::kBS == 64 ? (uint32_t)(uintptr_t)g_coop_planes64 : (uint32_t)(uintptr_t)g_coop_planes192[threadIdx.x >> 6]));
+    // the timed kernels hand the last few walking lanes of a wavefront to the cooperative walk (ycge_coop.hip.h): same visits, same
+    // answers, a third of the round trips.  The counting instances keep the lane-serial form (their counters are the reference's).
+    // (only where the caller entered with every lane of the wavefront: the groups of the cooperative walk need them all)
+    const bool cwalk = FULLWAVE && !COUNT && !BOUNDED && S.tl_offset != 0u;
     for (;;) {
         const bool act = cur != YCGE_REF_NONE_VALUE && (!BOUNDED || budget > 0);      // budget: refill mode yields with the walk's state in (cur, stack)
-        unsigned long long act_mask = 0;
-        if (COOP) { act_mask = __ballot(act); if (act_mask == 0ull) break; }
-        else if (!act) break;
+        if (!act) break;
+        if (cwalk && __popcll(__ballot(act)) <= YCGE_COOP_RAYS) break;
         if (BOUNDED) budget--;
         const bool is_node = YCGE_REF_KIND(cur) == REF_MESH_NODE;
         const uint32_t unit2 = (cur & 0x1ffffff0u) >> 3;       // record's 32-byte unit, times two
         f32x4 a, b, c, e;
         f32x2 f;
-        if (COOP && __popcll(act_mask) >= YCGE_COOP_MIN_LANES) {
-            load_record72_coop(S.mesh_arena, act ? unit2 << 4 : 0u, act_mask, __ballot(act && !is_node), coop_planes, a, b, c, e, f);
-            if (!act) continue;
-        } else {
-            if (COOP && !act) continue;
-#if defined(YCGE_LEAF_ONLY_TAIL) && YCGE_LEAF_ONLY_TAIL
-            load_record72_leaf_tail(S.mesh_arena, unit2 << 4, __ballot(!is_node), a, b, c, e, f);
-#else
-            load_record72(S.mesh_arena, unit2 << 4, a, b, c, e, f);
-#endif
-        }
+        load_record72(S.mesh_arena, unit2 << 4, a, b, c, e, f);
         if (COUNT) prof_tick(0);
         w.steps++;
         uint32_t next;
@@ -1134,228 +1082,8 @@ __device__ __forceinline__ void mesh_walk(const SceneDev &S, uint32_t &cur, int 
             while (st.pop(r, tn)) { if (closest >= tn) { cur = r; break; } }
         }
     }
-}
-
-// ---- query splitting (SPLIT walks; tests/test_cooperative_traversal_exactness.py is the CPU prototype and the argument) ----------
-// A long query is a serial chain of hundreds of steps on ONE lane while the other lanes of its wavefront have long finished: the
-// frame's tail.  When at most YCGE_SPLIT_MAX_OWNERS lanes of a wavefront are still walking and enough lanes idle, the pending work
-// of each such "owner" - its current reference and every entry of its stack - is handed to idle lanes, one subtree each, and the
-// owner parks.  A helper walks its subtree with the owner's ray in the reference's order, pruned by a bound that is never below the
-// reference's `closest` (the owner's closest at the split, lowered only by the helper's own candidates, with a margin), and RECORDS
-// every triangle that passes TriHit's closest-independent tests instead of accepting it.  When all helpers are done the owner replays
-// the candidates in the reference's visit order - subtree order = stack order (current reference first, then the stack from the top),
-// inside a subtree the order the helper met them - with the reference's own arithmetic: a leaf is opened iff closest >= its entry
-// distance, a triangle accepted iff tNum*sgn <= closest*|det|.  Same (t, triangle) as the serial walk, bit for bit.  If the record
-// area overflows the owners simply resume their untouched serial state.
-#ifndef YCGE_SPLIT_MAX_OWNERS
-#define YCGE_SPLIT_MAX_OWNERS 3
-#endif
-#ifndef YCGE_SPLIT_MIN_ITERS
-#define YCGE_SPLIT_MIN_ITERS 24
-#endif
-#define YCGE_SPLIT_CAP 96
-struct SplitRec { uint32_t key, grp, sub; float entry, t_s, det_abs, t_num, det; };      // key = owner << 26 | major << 20 | seq; 32 bytes
-struct SplitShared { SplitRec rec[YCGE_SPLIT_CAP]; uint8_t order[YCGE_SPLIT_CAP]; uint32_t n; };
-static __shared__ SplitShared g_split64;
-template <bool COUNT, class STK>
-__device__ __forceinline__ void mesh_walk_split(const SceneDev &S, uint32_t &cur, int mesh_prim, STK &st, F3 o, F3 inv, F3 d, bool sx, bool sy,
-                                                bool sz, float tmin, float &closest, int &hit_prim, int &hit_sub, Work &w, bool anyhit)
-{
-    SplitShared &SH = g_split64;
-    const uint32_t lane = threadIdx.x & 63u;
-    f32x2 oxy = {o.x, o.y}, ozz = {o.z, o.z};
-    f32x2 ixy = {inv.x, inv.y}, izz = {inv.z, inv.z};
-    bool parked = false, spec = false, split_done = false;
-    uint32_t spec_key = 0, spec_seq = 0, leaf_ctr = 0, it = 0;
-    float cur_tn = tmin;
-    float save_closest = 0.0f; int save_prim = -1, save_sub = 0;
-    for (;;) {
-      for (;;) {
-        const bool act = cur != YCGE_REF_NONE_VALUE && !parked;
-        const unsigned long long act_mask = __ballot(act);
-        if (act_mask == 0ull) break;
-        it++;
-        if (act) {
-            const bool is_node = YCGE_REF_KIND(cur) == REF_MESH_NODE;
-            const uint32_t unit2 = (cur & 0x1ffffff0u) >> 3;       // record's 32-byte unit, times two
-            f32x4 a, b, c, e;
-            f32x2 f;
-            load_record72(S.mesh_arena, unit2 << 4, a, b, c, e, f);
-            w.steps++;
-            uint32_t next;
-            if (is_node) {
-                if (COUNT) w.box += 2;
-                const f32x2 t0 = (a.xy - oxy) * ixy, t1 = (a.zw - ozz) * izz, t2 = (b.xy - oxy) * ixy;      // left:  (x y)(z Z)(X Y)
-                const f32x2 t3 = (b.zw - oxy) * ixy, t4 = (c.xy - ozz) * izz, t5 = (c.zw - oxy) * ixy;      // right: (x y)(z Z)(X Y)
-                float ln = __builtin_fmaxf(__builtin_fmaxf(__builtin_fmaxf(tmin, sx ? t2.x : t0.x), sy ? t2.y : t0.y), sz ? t1.y : t1.x);
-                float lx = __builtin_fminf(__builtin_fminf(__builtin_fminf(closest, sx ? t0.x : t2.x), sy ? t0.y : t2.y), sz ? t1.x : t1.y);
-                float rn = __builtin_fmaxf(__builtin_fmaxf(__builtin_fmaxf(tmin, sx ? t5.x : t3.x), sy ? t5.y : t3.y), sz ? t4.y : t4.x);
-                float rx = __builtin_fminf(__builtin_fminf(__builtin_fminf(closest, sx ? t3.x : t5.x), sy ? t3.y : t5.y), sz ? t4.x : t4.y);
-                const bool hl = lx >= ln, hr = rx >= rn;
-                const uint32_t lref = __float_as_uint(e.x), rref = __float_as_uint(e.y);
-                const bool left_first = ln < rn;
-                if (hl & hr) st.push(left_first ? rref : lref, left_first ? rn : ln);
-                next = (hl & hr) ? (left_first ? lref : rref) : hl ? lref : hr ? rref : YCGE_REF_NONE_VALUE;
-                cur_tn = (hl & hr) ? (left_first ? ln : rn) : hl ? ln : rn;
-                leaf_ctr++;
-            } else {
-                const uint32_t left = cur & 15u;
-                if (COUNT) w.tri += left >= 2u ? 2 : 1;
-                TriPairRec T;
-                T.r0 = a; T.r1 = b; T.r2 = c; T.r3 = e; T.e2z = f;
-                if (!spec) {
-                    tri_pair_hit(T, left, unit2, mesh_prim, o, d, tmin, closest, hit_prim, hit_sub);
-                    if (!COUNT && anyhit && hit_prim >= 0) { st.reset(); cur = YCGE_REF_NONE_VALUE; }      // occlusion query answered: drop what is left
-                } else {
-                    // TriHit's closest-independent part for both triangles of the record (the expressions of tri_pair_hit), candidates
-                    // recorded in leaf order; the speculative bound only ever comes down to a margin above a candidate
-                    const f32x2 ax = T.r0.xy, ay = T.r0.zw, az = T.r1.xy, e1x = T.r1.zw, e1y = T.r2.xy, e1z = T.r2.zw, e2x = T.r3.xy, e2y = T.r3.zw, e2z = T.e2z;
-                    const f32x2 dx = {d.x, d.x}, dy = {d.y, d.y}, dz = {d.z, d.z};
-                    const f32x2 ox = {o.x, o.x}, oy = {o.y, o.y}, oz = {o.z, o.z};
-                    const f32x2 px = dy * e2z - dz * e2y;
-                    const f32x2 py = dz * e2x - dx * e2z;
-                    const f32x2 pz = dx * e2y - dy * e2x;
-                    const f32x2 det = e1x * px + e1y * py + e1z * pz;
-                    const f32x2 sxx = ox - ax, syy = oy - ay, szz = oz - az;
-                    const f32x2 u_num = sxx * px + syy * py + szz * pz;
-                    const f32x2 sgn = {det.x > 0.0f ? 1.0f : -1.0f, det.y > 0.0f ? 1.0f : -1.0f};
-                    const f32x2 det_abs = det * sgn;
-                    const f32x2 u_num_s = u_num * sgn;
-                    const f32x2 qx = syy * e1z - szz * e1y;
-                    const f32x2 qy = szz * e1x - sxx * e1z;
-                    const f32x2 qz = sxx * e1y - syy * e1x;
-                    const f32x2 v_num = dx * qx + dy * qy + dz * qz;
-                    const f32x2 v_num_s = v_num * sgn;
-                    const f32x2 uv_sum_s = u_num_s + v_num_s;
-                    const f32x2 t_num = e2x * qx + e2y * qy + e2z * qz;
-                    const f32x2 t_num_s = t_num * sgn;
-                    const f32x2 tmin2 = {tmin, tmin};
-                    const f32x2 t_min_scaled = tmin2 * det_abs;
-#pragma unroll
-                    for (int sl = 0; sl < 2; sl++) {
-                        const float det_s = sl ? det.y : det.x, dabs = sl ? det_abs.y : det_abs.x, us = sl ? u_num_s.y : u_num_s.x, vs = sl ? v_num_s.y : v_num_s.x;
-                        const float uvs = sl ? uv_sum_s.y : uv_sum_s.x, tns = sl ? t_num_s.y : t_num_s.x, tn_ = sl ? t_num.y : t_num.x, tms = sl ? t_min_scaled.y : t_min_scaled.x;
-                        bool ok = sl == 0 || left >= 2u;
-                        ok &= !(det_s > -1e-8f && det_s < 1e-8f);
-                        ok &= !(us < 0.0f || us > dabs);
-                        ok &= !(vs < 0.0f || uvs > dabs);
-                        ok &= !(tns < tms || tns > closest * dabs);
-                        if (ok) {
-                            const uint32_t idx = atomicAdd(&SH.n, 1u);
-                            if (idx < YCGE_SPLIT_CAP) {
-                                SplitRec r;
-                                r.key = spec_key | (spec_seq & 0xfffffu); r.grp = leaf_ctr; r.sub = unit2 + (uint32_t)sl; r.entry = cur_tn;
-                                r.t_s = tns; r.det_abs = dabs; r.t_num = tn_; r.det = det_s;
-                                SH.rec[idx] = r;
-                            }
-                            spec_seq++;
-                            const float t = tn_ * (1.0f / det_s);
-                            const float b2 = t * 1.0001f + 1e-4f;
-                            closest = b2 < closest ? b2 : closest;
-                        }
-                    }
-                }
-                next = left > 2u ? cur + ((3u << 4) - 2u) : YCGE_REF_NONE_VALUE;       // next record: 3 units on, two triangles fewer
-                if (cur == YCGE_REF_NONE_VALUE) next = YCGE_REF_NONE_VALUE;
-            }
-            cur = next;
-            if (cur == YCGE_REF_NONE_VALUE) {
-                float tn; uint32_t r;
-                while (st.pop(r, tn)) { if (closest >= tn) { cur = r; cur_tn = tn; leaf_ctr++; break; } }
-            }
-        }
-        // ---- split?  (wave-uniform decision; every lane of the wavefront is here)
-        if (!split_done && it >= YCGE_SPLIT_MIN_ITERS && (it & 7u) == 0u) {
-            const unsigned long long live = __ballot(cur != YCGE_REF_NONE_VALUE);
-            const int n_live = __popcll(live);
-            if (n_live >= 1 && n_live <= YCGE_SPLIT_MAX_OWNERS) {
-                const unsigned long long idle = ~live;
-                const int n_idle = 64 - n_live;
-                int need = 0;
-                bool ok = true;
-                for (unsigned long long m = live; m; m &= m - 1ull) {
-                    const int A = (int)__builtin_ctzll(m);
-                    const int spA = __builtin_amdgcn_readlane(st.sp, A);
-                    if (spA > YCGE_LDS_STACK || spA < 1) ok = false;
-                    need += spA + 1;
-                }
-                if (ok && need <= n_idle) {
-                    split_done = true;
-                    if (lane == 0) SH.n = 0;
-                    const int my_rank = (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(idle >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)idle, 0u));
-                    const bool i_idle = (idle >> lane) & 1ull;
-                    int base = 0;
-                    for (unsigned long long m = live; m; m &= m - 1ull) {
-                        const int A = (int)__builtin_ctzll(m);
-                        const int spA = __builtin_amdgcn_readlane(st.sp, A);
-                        const uint32_t a_cur = (uint32_t)__builtin_amdgcn_readlane((int)cur, A);
-                        const float a_tn = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(cur_tn), A));
-                        const float a_closest = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(closest), A));
-                        const uint32_t a_lds = (uint32_t)__builtin_amdgcn_readlane((int)st.lds_base, A);
-                        const float aox = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(o.x), A)), aoy = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(o.y), A)), aoz = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(o.z), A));
-                        const float adx = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(d.x), A)), ady = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(d.y), A)), adz = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(d.z), A));
-                        const float aix = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(inv.x), A)), aiy = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(inv.y), A)), aiz = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(inv.z), A));
-                        const float atmin = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(tmin), A));
-                        const int k = my_rank - base;
-                        if (i_idle && k >= 0 && k <= spA) {
-                            // this lane becomes helper k of owner A: its own (finished) result is kept aside
-                            save_closest = closest; save_prim = hit_prim; save_sub = hit_sub;
-                            o = f3(aox, aoy, aoz); d = f3(adx, ady, adz); inv = f3(aix, aiy, aiz); tmin = atmin;
-                            sx = inv.x < 0.0f; sy = inv.y < 0.0f; sz = inv.z < 0.0f;
-                            oxy = f32x2{o.x, o.y}; ozz = f32x2{o.z, o.z}; ixy = f32x2{inv.x, inv.y}; izz = f32x2{inv.z, inv.z};
-                            if (k == 0) { cur = a_cur; cur_tn = a_tn; }
-                            else {
-                                const u32x2 v = lds_read_b64(a_lds + (uint32_t)(spA - k) * (STK::kBS * 8u));      // the owner's stack, from the top
-                                cur = v.x; cur_tn = __uint_as_float(v.y);
-                            }
-                            st.reset();
-                            closest = a_closest; hit_prim = -1; hit_sub = 0;
-                            spec = true; spec_seq = 0; leaf_ctr = 0;
-                            spec_key = ((uint32_t)A << 26) | ((uint32_t)k << 20);
-                        }
-                        if ((int)lane == A) parked = true;
-                        base += spA + 1;
-                    }
-                }
-            }
-        }
-      }
-      if (!split_done) break;
-      // ---- every helper is done: replay (or, when the record area overflowed, resume the owners' untouched serial walks)
-      const uint32_t n_rec = SH.n;
-      if (spec) { closest = save_closest; hit_prim = save_prim; hit_sub = save_sub; cur = YCGE_REF_NONE_VALUE; st.reset(); spec = false; }
-      if (n_rec > YCGE_SPLIT_CAP) {
-          const bool any_parked = __any(parked);
-          parked = false;
-          if (!any_parked) break;
-          continue;              // split_done stays set: no second attempt
-      }
-      // rank of every record by key (keys are unique): record i goes to place rank(i)
-      for (uint32_t i = lane; i < n_rec; i += 64u) {
-          const uint32_t ki = SH.rec[i].key;
-          uint32_t rank = 0;
-          for (uint32_t j = 0; j < n_rec; j++) rank += SH.rec[j].key < ki ? 1u : 0u;
-          SH.order[rank] = (uint8_t)i;
-      }
-      __builtin_amdgcn_s_waitcnt(0xc07f);       // lgkmcnt(0): one wavefront, in-order LDS
-      if (parked) {
-          uint32_t grp_key = 0xffffffffu;
-          bool open = false;
-          for (uint32_t i = 0; i < n_rec; i++) {
-              const SplitRec r = SH.rec[SH.order[i]];
-              if ((r.key >> 26) != lane) continue;
-              const uint32_t gk = (r.key & 0xfff00000u) | (r.grp & 0xfffffu);
-              if (gk != grp_key) { grp_key = gk; open = closest >= r.entry; }
-              if (!open || r.t_s > closest * r.det_abs) continue;
-              closest = r.t_num * (1.0f / r.det);
-              hit_prim = mesh_prim; hit_sub = (int)r.sub;
-              if (!COUNT && anyhit) break;
-          }
-          cur = YCGE_REF_NONE_VALUE;
-          st.reset();
-          parked = false;
-      }
-      break;
+    if (FULLWAVE && !COUNT && !BOUNDED) {
+        if (cwalk && __any(cur != YCGE_REF_NONE_VALUE)) coop_walk(S, cur, mesh_prim, st, o, inv, d, tmin, closest, hit_prim, hit_sub, w, anyhit);
     }
 }
 
@@ -1363,7 +1091,7 @@ __device__ __forceinline__ void mesh_walk_split(const SceneDev &S, uint32_t &cur
 // the reference): the object list is walked in leaf order with WAVE-UNIFORM control flow, so object records
 // come through the scalar cache and only the per-lane mesh walk diverges.  Otherwise the generic walk
 // starts at the scene root.  Both give the reference's visit order.
-template <bool COUNT, bool HAS_GRID, bool FLAT, bool COOP = false, class STK>
+template <bool COUNT, bool HAS_GRID, bool FLAT, bool FULLWAVE = false, class STK>
 __device__ __forceinline__ void traverse(const SceneDev &S, const RayQ &q, STK &st, float &closest, int &hit_prim, int &hit_sub, Work &w)
 {
     const F3 o = q.o, d = q.d;
@@ -1372,7 +1100,7 @@ __device__ __forceinline__ void traverse(const SceneDev &S, const RayQ &q, STK &
     hit_prim = -1;
     hit_sub = 0;
     st.reset();
-    const bool live = !COOP || q.live;
+    const bool live = !FULLWAVE || q.live;
     if (COUNT && live) w.rays++;
     if (S.scene_root_ref == YCGE_REF_NONE_VALUE) return;
     const F3 inv = f3(1.0f / d.x, 1.0f / d.y, 1.0f / d.z);
@@ -1402,8 +1130,7 @@ __device__ __forceinline__ void traverse(const SceneDev &S, const RayQ &q, STK &
                 if (COUNT) w.box++;
                 if (box_mesh(q1.x, q1.y, q1.z, q1.w, q2.x, q2.y, o, inv, sx, sy, sz, tmin, closest, tm)) start = root_ref;
             }
-            if (COOP && FLAT && STK::kBS == 64) mesh_walk_split<COUNT>(S, start, pi, st, o, inv, d, sx, sy, sz, tmin, closest, hit_prim, hit_sub, w, anyhit);
-            else mesh_walk<COUNT, false, false>(S, start, pi, st, o, inv, d, sx, sy, sz, tmin, closest, hit_prim, hit_sub, w, 0x7fffffff, anyhit);     // start is consumed
+            mesh_walk<COUNT, false, FULLWAVE>(S, start, pi, st, o, inv, d, sx, sy, sz, tmin, closest, hit_prim, hit_sub, w, 0x7fffffff, anyhit);     // start is consumed
         } else if (type == 10) {
             if (HAS_GRID) { if (root_hit && !(anyhit && hit_prim >= 0)) grid_dda<COUNT>(S, __float_as_int(q0.z), pi, o, d, inv, tmin, closest, hit_prim, hit_sub, w); }
         } else {
