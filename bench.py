@@ -390,6 +390,9 @@ def main():
             "dtype": "f32", "data": "synthetic",
             "config": {"workload": f"config {args.config}: " + WORKLOADS[args.config],
                        "trace_grid": f"{hiW}x{hiH}", "spp": ss * ss, "triangles": flat.n_triangles, "camera": args.camera,
+                       "lights": {"intensity": [float(l.Intensity) for l in scene.Lights],
+                                  "note": "the timed kernels trace no shadow ray towards a light of intensity 0 (its contribution is a zero whatever the ray finds: bit-identical pixels); "
+                                          "`value` counts the reference's Scene.Hit / Scene.Occluded calls, which include those rays" if any(float(l.Intensity) == 0.0 for l in scene.Lights) else None},
                        "frame": "ray-gen + trace + TAA" + (" + RCCL all-gather of tile slabs + un-permute" if multi else " + peer tile push" if n_dev > 1 else ""),
                        "parallelism": f"framebuffer tiles 32x8 round-robin over {n_gpus_used} GPU(s): " + how, "form": form,
                        "gpus_requested": args.gpus, "device_tiles": device_tiles, "device": name, "compute_units": cus},

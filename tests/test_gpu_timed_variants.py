@@ -29,16 +29,16 @@ def _assert_frame(o, g, label):
         assert st[k + "_rms"] <= pu.RMS_TOL
 
 
-@pytest.mark.parametrize("cfg_n,frames", [(3, 5), (4, 6)])
-def test_timed_mesh_kernels_full_size_steady_state(product_lib, oracle, monkeypatch, cfg_n, frames):
-    """Configs 3 and 4 at full size, default path (single launch for mesh viewers), NON-counting kernels, capture on.
-    Frame 1 has no schedule; from frame 2 on k_trace runs longest first; once the pinned fan count has come back (frame 3 or 4)
-    the head of the schedule runs in k_trace_fan<false,true> beside k_trace<false,true> - asserted through stats.fan_blocks.
-    (A library built with -DYCGE_MIGRATE=1 - the path-migration experiment of DESIGN section 5 - runs without the fan-out
-    kernel; it passes this test bit for bit too when YCGE_TEST_MIG=1 is set.)"""
-    import os
-    mig = os.environ.get("YCGE_TEST_MIG") == "1"
+@pytest.mark.parametrize("cfg_n,frames,fan", [(3, 5, None), (4, 6, None), (4, 6, "5")])
+def test_timed_mesh_kernels_full_size_steady_state(product_lib, oracle, monkeypatch, cfg_n, frames, fan):
+    """Configs 3 and 4 at full size, default path (single launch for mesh viewers), NON-counting kernels, capture on: what the
+    benchmark launches - k_trace<false,true> with the cooperative walk of its sparse wavefronts (ycge_coop.hip.h), longest first
+    from frame 2 on.  Round 3: a whole frame runs WITHOUT the query fan-out by default (asserted: stats.fan_blocks == 0); the
+    third case switches it on (YCGE_FAN=5, as a rank's share of a tiled frame has it) so that k_trace_fan<false,true>, its three
+    wavefronts walking cooperatively too, meets the oracle at full size as well - asserted through stats.fan_blocks > 0."""
     monkeypatch.delenv("YCGE_PATH", raising=False)
+    if fan is not None:
+        monkeypatch.setenv("YCGE_FAN", fan)
     sc, w, h, ss, pose = scenes.config_scene(cfg_n)
     o, g = pu.run_pair(oracle, sc, w, h, ss, pose, frames=1, oracle_threads=64, count=False)
     _assert_frame(o, g, f"cfg{cfg_n} timed variants frame 1")
@@ -47,11 +47,12 @@ def test_timed_mesh_kernels_full_size_steady_state(product_lib, oracle, monkeypa
         o.render(stages=1, threads=64); g.TryFlipAndBlit()
         _assert_frame(o, g, f"cfg{cfg_n} timed variants frame {f}")
         fanned.append(int(g.stats.fan_blocks))
-    if cfg_n == 4 and not mig:
-        assert fanned[-1] > 0 and fanned[-2] > 0, f"k_trace_fan never launched: {fanned}"      # the 200-block fan-out is active
+    if fan is None:
+        assert fanned == [0] * len(fanned), f"fan-out on a whole frame: {fanned}"
+    else:
+        assert fanned[-1] > 0 and fanned[-2] > 0, f"k_trace_fan never launched: {fanned}"
         assert fanned[-1] <= 200
-    if mig:
-        assert fanned[-1] == 0
+    assert g.timed_steps() > 0
     o.close(); g.close()
 
 
@@ -201,6 +202,27 @@ def test_one_call_drives_two_real_devices(product_lib, oracle, monkeypatch):
         tiles = [g.stats.device_tiles[i] for i in range(g.stats.n_devices_traced)]
         assert g.stats.n_devices_traced == min(n, 8) and all(t > 0 for t in tiles) and sum(tiles) == ((w * ss + 31) // 32) * ((h * 2 * ss + 7) // 8), tiles
     o.close(); g.close()
+
+
+@pytest.mark.parametrize("path", ["megakernel", "wavefront"])
+def test_zero_intensity_lights_get_no_shadow_query_in_the_timed_kernels(product_lib, oracle, monkeypatch, path):
+    """A light with Intensity == 0 adds `throughput * (f * nDotL * (Color * 0 / dist2) * tr)` = a zero to the radiance whatever its
+    shadow ray finds (RaytraceRenderer.cs:592-602; the reference traces the ray all the same).  The timed
+    kernels skip the query (GLight::dark); the pixels stay the oracle's, bit for bit, on both device paths, with one light dark, with
+    all lights dark (no light record is even written), and the timed instances walk fewer steps than with the light on."""
+    monkeypatch.setenv("YCGE_PATH", path)
+    steps = {}
+    for label, dark in (("lit", ()), ("one dark", (1,)), ("all dark", (0, 1))):
+        sc, _, _, ss, pose = scenes.config_scene(2)
+        for li in dark:
+            sc.Lights[li].Intensity = 0.0
+        o, g = pu.run_pair(oracle, sc, 320, 90, ss, pose, frames=0, count=False)
+        for f in range(3):
+            o.render(stages=1, threads=8); g.TryFlipAndBlit()
+            _assert_frame(o, g, f"{path}, {label}, frame {f + 1}")
+        steps[label] = g.timed_steps()
+        o.close(); g.close()
+    assert steps["all dark"] < steps["one dark"] < steps["lit"], steps
 
 
 def test_dynamic_texture_scenes_restart_the_history_every_frame(product_lib, oracle):

@@ -157,7 +157,10 @@ struct GLight {
     float pos[3];
     float color[3];
     float intensity;
-    float pad;
+    // 1.0f: Intensity == 0 with a finite colour.  Its contribution is `radiance += throughput * (f * nDotL * (Color * (0 / dist2)) * tr)` =
+    // radiance + (+-0) = radiance, whatever the shadow query answers (RaytraceRenderer.cs:592-602; the reference traces the ray all the
+    // same - SURVEY appendix A, quirk 8).  The TIMED kernels skip the query and the addition (light_is_dark); the counting ones trace it.
+    float dark;
 };
 
 #define YCGE_TIMED_STEP_SLOTS_LG 10  // counters[8 + 8 i], i < 1024: lane steps of the timed kernel instances, spread over cache lines (flush_work)

@@ -671,7 +671,8 @@ static int upload_lights(ycge_ctx *c, const ycge_light *lights, int n)
     for (int i = 0; i < n; i++) {
         L[i].pos[0] = lights[i].position.x; L[i].pos[1] = lights[i].position.y; L[i].pos[2] = lights[i].position.z;
         L[i].color[0] = lights[i].color.x; L[i].color[1] = lights[i].color.y; L[i].color[2] = lights[i].color.z;
-        L[i].intensity = lights[i].intensity; L[i].pad = 0.0f;
+        L[i].intensity = lights[i].intensity;
+        L[i].dark = (lights[i].intensity == 0.0f && std::isfinite(lights[i].color.x) && std::isfinite(lights[i].color.y) && std::isfinite(lights[i].color.z)) ? 1.0f : 0.0f;
     }
     HIP_TRY(c, c->d_lights.upload(L));
     c->sd.lights = c->d_lights.p;

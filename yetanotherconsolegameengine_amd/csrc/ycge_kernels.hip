@@ -113,6 +113,7 @@ struct WfBuffers {
     uint32_t *chunk_ctr;        // next tile segment of the persistent extend stage
     uint32_t tiles;             // owned tiles (= gridDim.x of every stage)
     const uint32_t *tile_order; // = FrameParams.tile_order
+    uint32_t elide_dark;        // timed launches: lights of zero intensity get no shadow query (GLight::dark, light_is_dark)
 };
 
 // Compaction without global atomics: every tile (= workgroup) owns a 256-entry segment of each queue.
@@ -400,7 +401,18 @@ __global__ __launch_bounds__(256) void k_wf_shade(const SceneDev S, const FrameP
                 }
                 sh_p = h.p; sh_n = h.n; sh_alb = base_albedo;
                 sh_wo = normalized(d * -1.0f);
-                emit_light = S.n_lights > 0;
+                // a light record only where some light will ask for a shadow query (the light loop head's own test, :578-591): vertices that
+                // face away from every light, and - timed launches - whose lights are all dark, go without
+                emit_light = false;
+                for (int li = 0; li < S.n_lights && !emit_light; li++) {
+                    const GLight &L = S.lights[li];
+                    F3 to_l = f3(L.pos) - sh_p;
+                    const float dist2 = dot(to_l, to_l);
+                    const float dist = cs_sqrt(dist2);
+                    const F3 ldir = vdiv(to_l, dist);
+                    const float n_dot_l = cs_max(0.0f, dot(sh_n, ldir));
+                    emit_light = !(n_dot_l <= 0.0f) && !(B.elide_dark && L.dark != 0.0f && dist2 > 0.0f);
+                }
                 if (diffuse_depth < P.diffuse_bounces) {               // :604-615
                     // the only consumer of the pixel's RNG is this bounce, so its state is the fresh seed
                     if (!(ROUND0 && DEBUG)) {
@@ -460,33 +472,34 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu((HAS_GRID &
     const uint32_t n = B.n_lq[k];
     Work w = {0, 0, 0, 0, 0, 0};
     if (threadIdx.x < n) {
+        // The vertex's shading context stays in its light record (64 bytes, just written by k_wf_shade: L2-resident) and is read again
+        // where it is used - before a shadow query only position and normal, after it the rest - and the pixel's radiance is read and
+        // written around each contribution: nothing but the loop state is live across a query.  (Kept in registers, the context cost the
+        // 5-wavefront build of this kernel 21 spilled registers: 0.64 GB of scratch writes per launch on the 4K voxel frame.)
         const float4 *src = (const float4 *)(B.lq + (size_t)k * 256 + threadIdx.x);
-        const float4 a = src[0], b = src[1], c = src[2], e = src[3];
-        const F3 sh_p = f3(a.x, a.y, a.z), sh_n = f3(a.w, b.x, b.y), sh_alb = f3(b.z, b.w, c.x), sh_wo = f3(c.y, c.z, c.w), beta = f3(e.x, e.y, e.z);
-        const uint32_t pixel = __float_as_uint(e.w);
-        float *rp = O.current_hdr + 3 * (size_t)pixel;
-        F3 rad = f3(rp[0], rp[1], rp[2]);
         Stack st;
         st.init(O.stack_spill, O.stack_lanes);
         // per-lane loop state: one traversal call site serves every light and every transmittance segment
         int light = 0;
         bool in_query = false;
         RayQ q; q.o = f3(0, 0, 0); q.d = f3(0, 0, 1); q.tmin = 0.0f; q.tmax = 0.0f;
-        F3 ldir = f3(0, 0, 0);
-        float dist2 = 0.0f, n_dot_l = 0.0f, maxdist = 0.0f;
+        float maxdist = 0.0f;
         float tr_r = 1.0f, tr_g = 1.0f, tr_b = 1.0f;
         int tr_counter = 0;
         for (;;) {
             if (!in_query) {
                 // light loop head: find the next light that needs a shadow query
+                const float4 a = src[0], b = src[1];
+                const F3 sh_p = f3(a.x, a.y, a.z), sh_n = f3(a.w, b.x, b.y);
                 for (; light < S.n_lights; light++) {
                     const GLight &L = S.lights[light];
                     F3 to_l = f3(L.pos) - sh_p;
-                    dist2 = dot(to_l, to_l);
+                    const float dist2 = dot(to_l, to_l);
                     float dist = cs_sqrt(dist2);
-                    ldir = vdiv(to_l, dist);
-                    n_dot_l = cs_max(0.0f, dot(sh_n, ldir));
+                    const F3 ldir = vdiv(to_l, dist);
+                    const float n_dot_l = cs_max(0.0f, dot(sh_n, ldir));
                     if (n_dot_l <= 0.0f) continue;
+                    if (light_is_dark<COUNT>(L, dist2)) continue;       // nothing to add whatever the query says
                     q.o = sh_p + sh_n * P.eps;
                     q.d = normalized(ldir);                     // new Ray(..., ldir)
                     maxdist = dist - P.eps;
@@ -524,19 +537,27 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu((HAS_GRID &
             }
             if (done) {
                 if (!(tr_r <= 1e-6f && tr_g <= 1e-6f && tr_b <= 1e-6f)) {      // :592-602
+                    // the light-loop head's values for this light again, by its own expressions on the same inputs: the same bits
+                    const float4 a = src[0], b = src[1], c = src[2], e = src[3];
+                    const F3 sh_p = f3(a.x, a.y, a.z), sh_n = f3(a.w, b.x, b.y), sh_alb = f3(b.z, b.w, c.x), sh_wo = f3(c.y, c.z, c.w), beta = f3(e.x, e.y, e.z);
                     const GLight &L = S.lights[light];
+                    F3 to_l = f3(L.pos) - sh_p;
+                    const float dist2 = dot(to_l, to_l);
+                    float dist = cs_sqrt(dist2);
+                    const F3 ldir = vdiv(to_l, dist);
+                    const float n_dot_l = cs_max(0.0f, dot(sh_n, ldir));
                     float atten = L.intensity / dist2;
                     F3 f_diffuse = oren_nayar(sh_alb, sh_n, sh_wo, ldir, P.on_a, P.on_b);
                     F3 Li = f3(L.color) * atten;
                     F3 contrib = (f_diffuse * n_dot_l) * Li;
                     contrib = f3(contrib.x * tr_r, contrib.y * tr_g, contrib.z * tr_b);
-                    rad = rad + f3(beta.x * contrib.x, beta.y * contrib.y, beta.z * contrib.z);
+                    float *rp = O.current_hdr + 3 * (size_t)__float_as_uint(e.w);
+                    rp[0] = rp[0] + beta.x * contrib.x; rp[1] = rp[1] + beta.y * contrib.y; rp[2] = rp[2] + beta.z * contrib.z;      // radiance += throughput * contrib, in light order
                 }
                 light++;
                 in_query = false;
             }
         }
-        rp[0] = rad.x; rp[1] = rad.y; rp[2] = rad.z;
     }
     flush_work<COUNT>(w, O.counters);
 }
@@ -876,6 +897,7 @@ __device__ __forceinline__ void trace_block(const SceneDev &S, const FrameParams
                             F3 ldir = vdiv(to_l, dist);
                             float n_dot_l = cs_max(0.0f, dot(sh_n, ldir));
                             if (n_dot_l <= 0.0f) continue;
+                            if (light_is_dark<COUNT>(L, dist2)) continue;
                             fan_post(F, 1 + ns, lane, sh_p + sh_n * P.eps, normalized(ldir), S.is_volume_scene ? 0.001f : 0.0f + P.eps, dist - P.eps, S.is_volume_scene || !S.any_transparent);
                             if (ns == 0) pre_l1 = li; else pre_l2 = li;
                             ns++;
@@ -946,6 +968,7 @@ __device__ __forceinline__ void trace_block(const SceneDev &S, const FrameParams
                 F3 ldir = vdiv(to_l, dist);
                 float n_dot_l = cs_max(0.0f, dot(sh_n, ldir));
                 if (n_dot_l <= 0.0f) continue;
+                if (light_is_dark<COUNT>(L, dist2)) continue;       // nothing to add whatever the query says (GLight::dark)
                 q.o = sh_p + sh_n * P.eps;
                 q.d = normalized(ldir);
                 sh_maxdist = dist - P.eps;
@@ -1419,6 +1442,7 @@ int ycge_launch_wavefront(const ycge::SceneDev *S, const ycge::FrameParams *P, c
     B.chunk_ctr = (uint32_t *)bufs[6];
     B.tiles = (uint32_t)P->n_owned_tiles;
     B.tile_order = P->tile_order;
+    B.elide_dark = count ? 0u : 1u;
     const dim3 block(256), tiles((unsigned)P->n_owned_tiles);
     static int round_steps[2] = {0, 0};
     if (round_steps[0] == 0) {       // steps per round of k_wf_extend_p: YCGE_ROUND="tree,cell" overrides the tuned defaults

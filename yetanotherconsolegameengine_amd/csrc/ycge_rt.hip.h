@@ -160,6 +160,12 @@ __device__ __forceinline__ F3 oren_nayar(F3 albedo, F3 n, F3 wo, F3 wi, float A,
     return saturate(f);
 }
 
+// A light the timed kernels need no shadow query for (GLight::dark): zero intensity, finite colour, and the shaded point not ON the light
+// (dist2 == 0 would make the attenuation 0 / 0).  The radiance it would add is a zero, and radiance (a sum of non-negative products that
+// starts at +0) + (+-0) is radiance, bit for bit.
+template <bool COUNT>
+__device__ __forceinline__ bool light_is_dark(const GLight &L, float dist2) { return !COUNT && L.dark != 0.0f && dist2 > 0.0f; }
+
 // ------------------------------------------------------------------ materials
 struct MatEval {
     F3 albedo, emission, trans_color;
