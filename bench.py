@@ -57,7 +57,7 @@ def algorithmic_bytes(st, pixels):
 
 
 def stats_dict(s):
-    return {k: int(getattr(s, k)) for k in ("n_rays", "n_box", "n_tri", "n_prim", "n_vox")}
+    return {k: int(getattr(s, k)) for k in ("n_rays", "n_box", "n_tri", "n_prim", "n_vox", "n_rays_dark")}
 
 
 def dist3(a):
@@ -254,7 +254,7 @@ def main():
     # ---- exact work of the timed frames: counting replay (untimed; same frame numbers, same poses)
     rc = make(True)
     rc.set_frame_counter(first_frame - 1)
-    tot = {k: 0 for k in ("n_rays", "n_box", "n_tri", "n_prim", "n_vox")}
+    tot = {k: 0 for k in ("n_rays", "n_box", "n_tri", "n_prim", "n_vox", "n_rays_dark")}
     replay = args.steps
     for k in range(replay):
         set_pose(rc, args.warmup + k, moving)
@@ -330,7 +330,7 @@ def main():
             rows = []
             for k in range(n, n + 24):
                 set_pose(r, k, True)
-                r.TryFlipAndBlit(want_sdr=True)
+                r.TryFlipAndBlit(want_sdr=True, copy=False)
                 rows.append((float(r.stats.trace_ms), float(r.stats.post_ms), float(r.stats.total_ms)))
             a = np.array(rows[4:])
             mov["with_sdr"] = {"frames": len(a), "trace_ms": dist3(a[:, 0]), "post_ms": dist3(a[:, 1]), "frame_ms_with_sdr_readback": dist3(a[:, 2])}
@@ -340,7 +340,7 @@ def main():
     if not args.no_post and not multi:        # the frame the C# wrapper asks for (SDR out); outside the headline metric, which SURVEY 8d times through TAA
         ms = []
         for _ in range(12):
-            r.TryFlipAndBlit(want_sdr=True)
+            r.TryFlipAndBlit(want_sdr=True, copy=False)
             ms.append((float(r.stats.trace_ms), float(r.stats.taa_ms), float(r.stats.post_ms), float(r.stats.total_ms)))
         ms = np.array(ms[2:])            # the first frame builds the in-place level schedule
         post = {"trace_ms": round(float(np.median(ms[:, 0])), 4), "taa_ms": round(float(np.median(ms[:, 1])), 4),
@@ -398,6 +398,9 @@ def main():
                        "gpus_requested": args.gpus, "device_tiles": device_tiles, "device": name, "compute_units": cus},
             "primary_mrays_per_s": round(pixels * args.steps / elapsed / 1e6, 2),
             "rays_per_frame": round(per_frame["n_rays"], 1),
+            # of which the timed kernels never trace: shadow rays towards lights of intensity 0 (bit-identical pixels); the rate over the rest beside `value`
+            "rays_to_dark_lights_per_frame": round(per_frame["n_rays_dark"], 1),
+            "value_traced_rays_only": round((per_frame["n_rays"] - per_frame["n_rays_dark"]) * args.steps / elapsed / 1e6, 2),
             "work_per_frame": {k: round(v, 1) for k, v in per_frame.items()},
             "roofline": roof, "cpu_baseline": cpu,
         }

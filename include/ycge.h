@@ -244,6 +244,9 @@ typedef struct ycge_frame_stats {
     uint64_t n_vox;              /* DDA cells visited                           */
     float exposure;              /* ToneMapper.EffectiveExposure                */
     float exposure_serial_chunks;/* diagnostics: 512-term chunks of the exposure sum that took the one-by-one path */
+    /* of n_rays: shadow queries towards lights of Intensity == 0 (counted with config.count_work).  The reference traces them although
+     * their contribution is a zero whatever they find (RaytraceRenderer.cs:586-602); the timed kernels do not. */
+    uint64_t n_rays_dark;
     /* tiles traced by each device of this frame (one entry for a single-GPU context; devices[] order) */
     int32_t n_devices_traced;
     int32_t device_tiles[YCGE_MAX_DEVICES];
@@ -344,6 +347,12 @@ int ycge_set_frame_counter(ycge_ctx *ctx, int64_t frame_counter);
  * timed ones stop shadow queries at the first hit and skip culled grids, so their own work is reported apart.  Waits for the
  * context's stream; never called inside a timed region. */
 int ycge_read_timed_steps(ycge_ctx *ctx, uint64_t *lane_steps);
+/* The SDR frame leaves the device by one copy into the caller's buffer at the end of ycge_render_frame / ycge_resolve_gathered (24 bytes per
+ * chexel: 25 MB at 1920x540).  A host that keeps ONE buffer for the life of the renderer (the C# wrapper's pinned float[]) registers it
+ * here once: the copy then is a DMA into page-locked memory at the link's full rate instead of a staged copy into pageable pages.
+ * Optional; unpin before the buffer is freed or moved.  (hipHostRegister / hipHostUnregister.) */
+int ycge_pin_host_buffer(void *buffer, size_t bytes);
+int ycge_unpin_host_buffer(void *buffer);
 /* visible HIP devices (hipGetDeviceCount; does not initialise a device context), < 0 on error: what a host checks before it
  * fills config.devices[] */
 int ycge_device_count(void);

@@ -10,6 +10,7 @@
 
 #include <atomic>
 #include <chrono>
+#include <cmath>
 #include <cstdio>
 #include <cstring>
 #include <thread>
@@ -277,6 +278,9 @@ static V3 trace_full(const SceneData &S, const Consts &K, Ray r, Rng &rng, bool 
                 float n_dot_l = cs_max(0.0f, dot(rec.n, ldir));
                 if (n_dot_l <= 0.0f) continue;
                 Ray shadow = make_ray(rec.p + rec.n * K.eps, ldir);
+                /* analysis counter only (the oracle traces every such ray, as the reference does): shadow rays towards lights of zero
+                 * intensity - the product's timed kernels skip them, their contribution being a zero whatever the ray finds */
+                if (light.intensity == 0.0f && std::isfinite(light.color.x) && std::isfinite(light.color.y) && std::isfinite(light.color.z) && dist2 > 0.0f) cnt.dark++;
                 V3 trans = transmittance_to_light(S, K, shadow, dist - K.eps, cnt);
                 if (trans.x <= 1e-6f && trans.y <= 1e-6f && trans.z <= 1e-6f) continue;
                 float atten = light.intensity / dist2;
@@ -673,7 +677,7 @@ struct Renderer {
             st->history_reset = did_reset ? 1 : 0;
             auto ms = [](auto a, auto b) { return std::chrono::duration<double, std::milli>(b - a).count(); };
             st->trace_ms = ms(t0, t1); st->taa_ms = ms(t1, t2); st->post_ms = ms(t2, t3); st->total_ms = ms(t0, t3);
-            st->n_rays = tot.rays; st->n_box = tot.box; st->n_tri = tot.tri; st->n_prim = tot.prim; st->n_vox = tot.vox;
+            st->n_rays = tot.rays; st->n_box = tot.box; st->n_tri = tot.tri; st->n_prim = tot.prim; st->n_vox = tot.vox; st->n_rays_dark = tot.dark;
             st->exposure = tone.effective;
         }
         return YCGE_OK;

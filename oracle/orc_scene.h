@@ -74,13 +74,13 @@ struct Hit {
 };
 
 struct Counters {
-    uint64_t rays = 0, box = 0, tri = 0, prim = 0, vox = 0;
+    uint64_t rays = 0, box = 0, tri = 0, prim = 0, vox = 0, dark = 0;
     /* analysis aid (orc_query_profile): traversal steps (node visits + triangle tests) of each Scene.Hit call, in call order */
     uint32_t *qlog = nullptr; int qn = 0, qcap = 0;
     /* ... and, for the same calls, mesh leaves opened | node visits that go on into the node's LEFT child (the next record in the
      * device arena's depth-first order) << 16: what a wave-cooperative walk would save (tests/analysis_coop_model.py) */
     uint32_t *qlog2 = nullptr; uint64_t leaves = 0, left_desc = 0;
-    void add(const Counters &o) { rays += o.rays; box += o.box; tri += o.tri; prim += o.prim; vox += o.vox; }
+    void add(const Counters &o) { rays += o.rays; box += o.box; tri += o.tri; prim += o.prim; vox += o.vox; dark += o.dark; }
 };
 
 struct SceneData; /* fwd */

@@ -55,6 +55,6 @@ def compare_frame(o, g, check_counters=True):
             out[name + "_rms"] = rms(np.where(fin, a, 0), np.where(fin, b, 0))
     if check_counters:
         so, sg = o.stats, g.stats
-        for k in ("n_rays", "n_box", "n_tri", "n_prim", "n_vox"):
+        for k in ("n_rays", "n_box", "n_tri", "n_prim", "n_vox", "n_rays_dark"):
             out[k] = (int(getattr(so, k)), int(getattr(sg, k)))
     return out

@@ -213,7 +213,7 @@ def test_zero_intensity_lights_get_no_shadow_query_in_the_timed_kernels(product_
     monkeypatch.setenv("YCGE_PATH", path)
     steps = {}
     for label, dark in (("lit", ()), ("one dark", (1,)), ("all dark", (0, 1))):
-        sc, _, _, ss, pose = scenes.config_scene(2)
+        sc, _, _, ss, pose = scenes.config_scene(3)        # the bunny under its two lights (MeshScenes.cs:160-171): shadow rays walk the mesh
         for li in dark:
             sc.Lights[li].Intensity = 0.0
         o, g = pu.run_pair(oracle, sc, 320, 90, ss, pose, frames=0, count=False)
@@ -222,6 +222,12 @@ def test_zero_intensity_lights_get_no_shadow_query_in_the_timed_kernels(product_
             _assert_frame(o, g, f"{path}, {label}, frame {f + 1}")
         steps[label] = g.timed_steps()
         o.close(); g.close()
+        # the counting instances trace those rays like the reference and say how many there are (stats.n_rays_dark = the oracle's count)
+        oc, gc = pu.run_pair(oracle, sc, 320, 90, ss, pose, frames=1, count=True)
+        st = pu.compare_frame(oc, gc)
+        assert st["n_rays"][0] == st["n_rays"][1] and st["n_rays_dark"][0] == st["n_rays_dark"][1], (label, st["n_rays"], st["n_rays_dark"])
+        assert (st["n_rays_dark"][1] > 0) == bool(dark), (label, st["n_rays_dark"])
+        oc.close(); gc.close()
     assert steps["all dark"] < steps["one dark"] < steps["lit"], steps
 
 

@@ -136,7 +136,7 @@ class FrameStats(C.Structure):
         ("trace_ms", C.c_double), ("taa_ms", C.c_double), ("post_ms", C.c_double), ("total_ms", C.c_double),
         ("n_rays", C.c_uint64), ("n_box", C.c_uint64), ("n_tri", C.c_uint64), ("n_prim", C.c_uint64),
         ("n_vox", C.c_uint64), ("exposure", C.c_float), ("exposure_serial_chunks", C.c_float),
-        ("n_devices_traced", C.c_int32), ("device_tiles", C.c_int32 * 8),
+        ("n_rays_dark", C.c_uint64), ("n_devices_traced", C.c_int32), ("device_tiles", C.c_int32 * 8),
     ]
 
 
@@ -184,6 +184,8 @@ _PROTOTYPES = {
     "ycge_set_frame_counter": (C.c_int, [C.c_void_p, C.c_int64]),
     "ycge_read_timed_steps": (C.c_int, [C.c_void_p, C.POINTER(C.c_uint64)]),
     "ycge_device_count": (C.c_int, []),
+    "ycge_pin_host_buffer": (C.c_int, [C.c_void_p, C.c_size_t]),
+    "ycge_unpin_host_buffer": (C.c_int, [C.c_void_p]),
     "ycge_accel_size": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.POINTER(C.c_size_t)]),
     "ycge_read_accel": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.c_void_p, C.c_size_t]),
     "ycge_device_info": (C.c_int, [C.c_void_p, C.c_char_p, C.c_size_t, C.POINTER(C.c_int32)]),

@@ -12,7 +12,9 @@
 #include <cstdlib>
 #include <cstring>
 #include <deque>
+#include <condition_variable>
 #include <mutex>
+#include <thread>
 #include <string>
 #include <vector>
 #include <functional>
@@ -175,6 +177,17 @@ struct ycge_ctx {
     std::vector<ycge_ctx *> peers;
     ycge_ctx *parent = nullptr;
     hipEvent_t pushed_ev = nullptr;            // a peer's tiles have arrived in the parent's frame buffers
+    // A peer's share of a frame is ISSUED by a thread of its own (trace launches, tile push, event): eight devices driven one after the
+    // other from the caller's thread would put 7 x ~0.1 ms of launch calls in front of the last device's first kernel - as long as
+    // the frame itself.  The worker sleeps between frames; the root posts a frame, issues its own share, then collects the peers'.
+    struct PeerWorker {
+        std::thread th;
+        std::mutex m;
+        std::condition_variable cv;
+        int job = 0;                           // 0 idle, 1 frame posted, 2 done, -1 quit
+        FrameState fs{};
+        int rc = 0;
+    } *worker = nullptr;
     std::deque<FrameState> pending;            // frames traced by ycge_trace_tiles and not yet resolved (pipelined callers)
     hipStream_t last_stream = nullptr;         // the stream the last tiled call ran on (scene updates wait for it too)
     hipStream_t stream = nullptr;
@@ -522,6 +535,7 @@ int ycge_config_default(ycge_config *cfg)
     return YCGE_OK;
 }
 
+static void peer_worker_main(ycge_ctx *root, ycge_ctx *peer);
 static int create_one(const ycge_config *cfg, ycge_ctx *parent, ycge_ctx **out)
 {
     int n_dev = 0;
@@ -621,6 +635,10 @@ int ycge_create(const ycge_config *cfg, ycge_ctx **out)
             (void)hipGetLastError();
         }
     }
+    for (ycge_ctx *peer : root->peers) {        // each peer's share of a frame is issued by its own thread (trace_on_all_devices)
+        peer->worker = new ycge_ctx::PeerWorker;
+        peer->worker->th = std::thread(peer_worker_main, root, peer);
+    }
     (void)hipSetDevice(root->device);
     *out = root;
     return YCGE_OK;
@@ -629,6 +647,13 @@ int ycge_create(const ycge_config *cfg, ycge_ctx **out)
 void ycge_destroy(ycge_ctx *c)
 {
     if (!c) return;
+    if (c->worker) {
+        { std::lock_guard<std::mutex> g(c->worker->m); c->worker->job = -1; }
+        c->worker->cv.notify_all();
+        if (c->worker->th.joinable()) c->worker->th.join();
+        delete c->worker;
+        c->worker = nullptr;
+    }
     for (ycge_ctx *p : c->peers) ycge_destroy(p);
     c->peers.clear();
     (void)hipSetDevice(c->device);
@@ -1372,6 +1397,17 @@ int ycge_debug_read_coop_stats(ycge_ctx *c, uint64_t out[16])
     return YCGE_OK;
 }
 
+int ycge_pin_host_buffer(void *buffer, size_t bytes)
+{
+    if (!buffer || bytes == 0) return YCGE_ERR_INVALID_ARG;
+    return hipHostRegister(buffer, bytes, hipHostRegisterDefault) == hipSuccess ? YCGE_OK : YCGE_ERR_DEVICE;
+}
+int ycge_unpin_host_buffer(void *buffer)
+{
+    if (!buffer) return YCGE_ERR_INVALID_ARG;
+    return hipHostUnregister(buffer) == hipSuccess ? YCGE_OK : YCGE_ERR_DEVICE;
+}
+
 int ycge_device_count(void)
 {
     int n = 0;
@@ -1443,7 +1479,7 @@ int trace_frame(ycge_ctx *c, float *d_slab, hipStream_t stream, FrameState &fs, 
     if (debug) { O.rays = c->dbg_rays.p; O.prim_id = c->dbg_prim.p; O.sub_id = c->dbg_sub.p; O.hit_t = c->dbg_hit_t.p; O.rng_state = c->dbg_rng.p; }
     if (c->knobs.wave_prof_stage >= 0) { if (!c->wave_prof.p) HIP_TRY(c, c->wave_prof.alloc((size_t)c->n_tiles * 16)); O.wave_prof = c->wave_prof.p; O.wave_prof_stage = c->knobs.wave_prof_stage; }
     O.counters = c->counters.p;
-    if (c->cfg.count_work) HIP_TRY(c, hipMemsetAsync(c->counters.p, 0, 5 * sizeof(unsigned long long), stream));
+    if (c->cfg.count_work) HIP_TRY(c, hipMemsetAsync(c->counters.p, 0, 6 * sizeof(unsigned long long), stream));
     if (timed) HIP_TRY(c, hipEventRecord(c->ev[0], stream));
     int e;
     O.stack_spill = c->stack_spill.p;
@@ -1884,7 +1920,7 @@ int fill_stats(ycge_ctx *c, ycge_frame_stats *st, const FrameState &fs, bool did
     if (c->cfg.count_work) {
         unsigned long long h[8];
         HIP_TRY(c, hipMemcpy(h, c->counters.p, sizeof h, hipMemcpyDeviceToHost));
-        st->n_rays = h[0]; st->n_box = h[1]; st->n_tri = h[2]; st->n_prim = h[3]; st->n_vox = h[4];
+        st->n_rays = h[0]; st->n_box = h[1]; st->n_tri = h[2]; st->n_prim = h[3]; st->n_vox = h[4]; st->n_rays_dark = h[5];
     }
     st->exposure = 1.0f;
     return YCGE_OK;
@@ -1894,35 +1930,67 @@ int fill_stats(ycge_ctx *c, ycge_frame_stats *st, const FrameState &fs, bool did
 
 extern "C" {
 
-// n_devices >= 2: every device traces its tiles of the frame `fs`; the peers then copy theirs into this (rank 0's) frame buffers
+// one peer's share of the frame `fs`: its tiles traced on its own stream, then written into the root's frame buffers (k_push_tiles)
+static int peer_trace_and_push(ycge_ctx *c, ycge_ctx *p, FrameState &pfs)
+{
+    if (hipSetDevice(p->device) != hipSuccess) return p->fail(YCGE_ERR_DEVICE, "hipSetDevice(%d) failed", p->device);
+    p->frame_counter = pfs.frame;
+    int rc = trace_frame(p, nullptr, p->stream, pfs, false);
+    if (rc != YCGE_OK) return rc;
+    PushPlanes L;
+    std::memset(&L, 0, sizeof L);
+    auto plane = [&](const void *src, void *dst, int bpp) { if (src && dst) { L.src[L.n] = (const uint8_t *)src; L.dst[L.n] = (uint8_t *)dst; L.bytes_per_pixel[L.n] = bpp; L.n++; } };
+    plane(p->current_hdr.p, c->current_hdr.p, 12); plane(p->g_albedo.p, c->g_albedo.p, 12); plane(p->g_normal.p, c->g_normal.p, 12);
+    plane(p->g_depth.p, c->g_depth.p, 4); plane(p->sky.p, c->sky.p, 1);
+    if (c->cfg.capture_debug) {
+        plane(p->dbg_rays.p, c->dbg_rays.p, 24); plane(p->dbg_prim.p, c->dbg_prim.p, 4); plane(p->dbg_sub.p, c->dbg_sub.p, 4);
+        plane(p->dbg_hit_t.p, c->dbg_hit_t.p, 4); plane(p->dbg_rng.p, c->dbg_rng.p, 8);
+    }
+    FrameParams P;
+    fill_frame_params(p, P, pfs.frame, pfs.pos, pfs.yaw, pfs.pitch, pfs.fov);
+    const int e = ycge_launch_push_tiles(&P, &L, p->stream);
+    if (e != 0) return p->fail(YCGE_ERR_DEVICE, "k_push_tiles launch failed: %s", hipGetErrorString((hipError_t)e));
+    if (hipEventRecord(p->pushed_ev, p->stream) != hipSuccess) return p->fail(YCGE_ERR_DEVICE, "hipEventRecord failed on device %d", p->device);
+    return YCGE_OK;
+}
+
+static void peer_worker_main(ycge_ctx *c, ycge_ctx *p)
+{
+    ycge_ctx::PeerWorker &w = *p->worker;
+    for (;;) {
+        std::unique_lock<std::mutex> lk(w.m);
+        w.cv.wait(lk, [&] { return w.job == 1 || w.job == -1; });
+        if (w.job == -1) return;
+        FrameState pfs = w.fs;
+        lk.unlock();
+        const int rc = peer_trace_and_push(c, p, pfs);
+        lk.lock();
+        w.fs = pfs; w.rc = rc; w.job = 2;
+        lk.unlock();
+        w.cv.notify_all();
+    }
+}
+
+// n_devices >= 2: every device traces its tiles of the frame `fs` (each peer's launches issued by its own thread, side by side with
+// the root's); the peers then copy theirs into this (rank 0's) frame buffers
 static int trace_on_all_devices(ycge_ctx *c, FrameState &fs)
 {
     HIP_TRY(c, hipEventRecord(c->ev[0], c->stream));
-    int rc = trace_frame(c, nullptr, c->stream, fs, false);
-    if (rc != YCGE_OK) return rc;
     for (ycge_ctx *p : c->peers) {
-        if (hipSetDevice(p->device) != hipSuccess) return c->fail(YCGE_ERR_DEVICE, "hipSetDevice(%d) failed", p->device);
-        FrameState pfs = fs;
-        p->frame_counter = fs.frame;
-        rc = trace_frame(p, nullptr, p->stream, pfs, false);
-        if (rc != YCGE_OK) { c->err = p->err; (void)hipSetDevice(c->device); return rc; }
-        fs.fan_blocks += pfs.fan_blocks;
-        PushPlanes L;
-        std::memset(&L, 0, sizeof L);
-        auto plane = [&](const void *src, void *dst, int bpp) { if (src && dst) { L.src[L.n] = (const uint8_t *)src; L.dst[L.n] = (uint8_t *)dst; L.bytes_per_pixel[L.n] = bpp; L.n++; } };
-        plane(p->current_hdr.p, c->current_hdr.p, 12); plane(p->g_albedo.p, c->g_albedo.p, 12); plane(p->g_normal.p, c->g_normal.p, 12);
-        plane(p->g_depth.p, c->g_depth.p, 4); plane(p->sky.p, c->sky.p, 1);
-        if (c->cfg.capture_debug) {
-            plane(p->dbg_rays.p, c->dbg_rays.p, 24); plane(p->dbg_prim.p, c->dbg_prim.p, 4); plane(p->dbg_sub.p, c->dbg_sub.p, 4);
-            plane(p->dbg_hit_t.p, c->dbg_hit_t.p, 4); plane(p->dbg_rng.p, c->dbg_rng.p, 8);
-        }
-        FrameParams P;
-        fill_frame_params(p, P, fs.frame, fs.pos, fs.yaw, fs.pitch, fs.fov);
-        const int e = ycge_launch_push_tiles(&P, &L, p->stream);
-        if (e != 0) { (void)hipSetDevice(c->device); return c->fail(YCGE_ERR_DEVICE, "k_push_tiles launch failed: %s", hipGetErrorString((hipError_t)e)); }
-        if (hipEventRecord(p->pushed_ev, p->stream) != hipSuccess) { (void)hipSetDevice(c->device); return c->fail(YCGE_ERR_DEVICE, "hipEventRecord failed on device %d", p->device); }
+        ycge_ctx::PeerWorker &w = *p->worker;
+        { std::lock_guard<std::mutex> g(w.m); w.fs = fs; w.job = 1; }
+        w.cv.notify_all();
     }
-    HIP_TRY(c, hipSetDevice(c->device));
+    int rc = trace_frame(c, nullptr, c->stream, fs, false);
+    for (ycge_ctx *p : c->peers) {          // (every posted frame is collected, whatever the root's own share returned)
+        ycge_ctx::PeerWorker &w = *p->worker;
+        std::unique_lock<std::mutex> lk(w.m);
+        w.cv.wait(lk, [&] { return w.job == 2; });
+        w.job = 0;
+        if (w.rc != YCGE_OK && rc == YCGE_OK) { rc = w.rc; c->err = p->err; }
+        fs.fan_blocks += w.fs.fan_blocks;
+    }
+    if (rc != YCGE_OK) return rc;
     for (ycge_ctx *p : c->peers) HIP_TRY(c, hipStreamWaitEvent(c->stream, p->pushed_ev, 0));
     HIP_TRY(c, hipEventRecord(c->ev[1], c->stream));        // trace_ms of a multi-device frame: until the last tile has arrived
     return YCGE_OK;
@@ -1956,7 +2024,7 @@ int ycge_render_frame(ycge_ctx *c, float *out_sdr, ycge_frame_stats *st)
         for (ycge_ctx *p : c->peers) {          // the counters of the peers' tiles
             unsigned long long h[8];
             if (hipSetDevice(p->device) != hipSuccess || hipMemcpy(h, p->counters.p, sizeof h, hipMemcpyDeviceToHost) != hipSuccess) { (void)hipSetDevice(c->device); return c->fail(YCGE_ERR_DEVICE, "counter read-back failed on device %d", p->device); }
-            st->n_rays += h[0]; st->n_box += h[1]; st->n_tri += h[2]; st->n_prim += h[3]; st->n_vox += h[4];
+            st->n_rays += h[0]; st->n_box += h[1]; st->n_tri += h[2]; st->n_prim += h[3]; st->n_vox += h[4]; st->n_rays_dark += h[5];
         }
     if (multi_dev) HIP_TRY(c, hipSetDevice(c->device));
     if (rc == YCGE_OK && st && out_sdr) {

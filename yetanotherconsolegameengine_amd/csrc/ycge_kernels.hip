@@ -71,8 +71,8 @@ __device__ __forceinline__ void flush_work(const Work &w, unsigned long long *co
         if (lane == 0 && x) atomicAdd(counters + 8 + (size_t)((blockIdx.x * 2654435761u) >> (32 - YCGE_TIMED_STEP_SLOTS_LG)) * 8, x);
         return;
     }
-    const unsigned v[5] = {w.rays, w.box, w.tri, w.prim, w.vox};
-    for (int c = 0; c < 5; c++) {
+    const unsigned v[6] = {w.rays, w.box, w.tri, w.prim, w.vox, w.dark};
+    for (int c = 0; c < 6; c++) {
         unsigned long long x = v[c];
         for (int off = 32; off >= 1; off >>= 1) x += __shfl_xor(x, off, 64);
         if (lane == 0 && x) atomicAdd(counters + c, x);
@@ -139,7 +139,7 @@ __device__ __forceinline__ uint32_t block_compact(bool want, uint32_t *s_cnt /* 
 template <bool COUNT, bool HAS_GRID, bool FLAT>
 __global__ __launch_bounds__(256) void k_wf_primary(const SceneDev S, const FrameParams P, const TraceOut O, const WfBuffers B)
 {
-    Work w = {0, 0, 0, 0, 0, 0};
+    Work w = {0, 0, 0, 0, 0, 0, 0};
     const int k = block_tile(P);
     int px, py, lx, ly;
     unsigned long long t_start = 0;
@@ -177,7 +177,7 @@ __global__ __launch_bounds__(256) void k_wf_extend(const SceneDev S, const Trace
 {
     const int k = B.tile_order ? (int)B.tile_order[blockIdx.x] : (int)blockIdx.x;
     const uint32_t n = B.n_q[(size_t)round * B.tiles + k];
-    Work w = {0, 0, 0, 0, 0, 0};
+    Work w = {0, 0, 0, 0, 0, 0, 0};
     const bool prof = O.wave_prof && O.wave_prof_stage == 1 && round == 1;
     unsigned long long t_start = 0;
     if (prof) {
@@ -227,7 +227,7 @@ template <bool COUNT, bool HAS_GRID>
 __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu((HAS_GRID && !COUNT) ? YCGE_TRACEP_WAVES : 1, 8))) void k_wf_trace_p(const SceneDev S, const FrameParams P, const TraceOut O, const WfBuffers B, int round,
                                                    uint32_t *__restrict__ chunk_ctr, int round_tree_steps, int round_cell_steps)
 {
-    Work w = {0, 0, 0, 0, 0, 0};
+    Work w = {0, 0, 0, 0, 0, 0, 0};
     StackT<64> st;
     st.init(O.stack_spill, O.stack_lanes);
     const int lane = (int)threadIdx.x;
@@ -470,7 +470,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu((HAS_GRID &
 {
     const int k = block_tile(P);
     const uint32_t n = B.n_lq[k];
-    Work w = {0, 0, 0, 0, 0, 0};
+    Work w = {0, 0, 0, 0, 0, 0, 0};
     if (threadIdx.x < n) {
         // The vertex's shading context stays in its light record (64 bytes, just written by k_wf_shade: L2-resident) and is read again
         // where it is used - before a shadow query only position and normal, after it the rest - and the pixel's radiance is read and
@@ -499,7 +499,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu((HAS_GRID &
                     const F3 ldir = vdiv(to_l, dist);
                     const float n_dot_l = cs_max(0.0f, dot(sh_n, ldir));
                     if (n_dot_l <= 0.0f) continue;
-                    if (light_is_dark<COUNT>(L, dist2)) continue;       // nothing to add whatever the query says
+                    if (light_is_dark<COUNT>(L, dist2, w)) continue;       // nothing to add whatever the query says
                     q.o = sh_p + sh_n * P.eps;
                     q.d = normalized(ldir);                     // new Ray(..., ldir)
                     maxdist = dist - P.eps;
@@ -670,7 +670,7 @@ __device__ __forceinline__ void trace_block(const SceneDev &S, const FrameParams
     constexpr bool FAN = MODE != 0;          // queries are posted to LDS slots and answered in stage B
     constexpr bool WAVES3 = MODE == 1;
     const bool DEBUG = O.prim_id != nullptr;
-    Work w = {0, 0, 0, 0, 0, 0};
+    Work w = {0, 0, 0, 0, 0, 0, 0};
     StackT<WAVES3 ? 192 : 64> st;
     st.init(O.stack_spill, O.stack_lanes, O.lane_base);
     const PathStack pstack = {O.path_stack, O.stack_lanes, O.lane_base};
@@ -897,7 +897,7 @@ __device__ __forceinline__ void trace_block(const SceneDev &S, const FrameParams
                             F3 ldir = vdiv(to_l, dist);
                             float n_dot_l = cs_max(0.0f, dot(sh_n, ldir));
                             if (n_dot_l <= 0.0f) continue;
-                            if (light_is_dark<COUNT>(L, dist2)) continue;
+                            if (light_is_dark<COUNT>(L, dist2, w)) continue;
                             fan_post(F, 1 + ns, lane, sh_p + sh_n * P.eps, normalized(ldir), S.is_volume_scene ? 0.001f : 0.0f + P.eps, dist - P.eps, S.is_volume_scene || !S.any_transparent);
                             if (ns == 0) pre_l1 = li; else pre_l2 = li;
                             ns++;
@@ -968,7 +968,7 @@ __device__ __forceinline__ void trace_block(const SceneDev &S, const FrameParams
                 F3 ldir = vdiv(to_l, dist);
                 float n_dot_l = cs_max(0.0f, dot(sh_n, ldir));
                 if (n_dot_l <= 0.0f) continue;
-                if (light_is_dark<COUNT>(L, dist2)) continue;       // nothing to add whatever the query says (GLight::dark)
+                if (light_is_dark<COUNT>(L, dist2, w)) continue;       // nothing to add whatever the query says (GLight::dark)
                 q.o = sh_p + sh_n * P.eps;
                 q.d = normalized(ldir);
                 sh_maxdist = dist - P.eps;

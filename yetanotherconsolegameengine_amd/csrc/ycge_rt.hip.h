@@ -50,6 +50,7 @@ struct RayQ {              // one closest-hit query: Scene.Hit(r, tMin, tMax)
 struct Work {              // SURVEY 8(d) counters (COUNT variants) + this lane's traversal steps (always; scheduling feedback)
     unsigned rays, box, tri, prim, vox;
     unsigned steps;
+    unsigned dark;             // COUNT variants: shadow queries towards lights of zero intensity - traced here as the reference does, skipped by the timed kernels
 };
 
 // wave-level iteration counters (profiling aid, only touched by COUNT variants)
@@ -164,7 +165,12 @@ __device__ __forceinline__ F3 oren_nayar(F3 albedo, F3 n, F3 wo, F3 wi, float A,
 // (dist2 == 0 would make the attenuation 0 / 0).  The radiance it would add is a zero, and radiance (a sum of non-negative products that
 // starts at +0) + (+-0) is radiance, bit for bit.
 template <bool COUNT>
-__device__ __forceinline__ bool light_is_dark(const GLight &L, float dist2) { return !COUNT && L.dark != 0.0f && dist2 > 0.0f; }
+__device__ __forceinline__ bool light_is_dark(const GLight &L, float dist2, Work &w)
+{
+    const bool dark = L.dark != 0.0f && dist2 > 0.0f;
+    if (COUNT && dark) w.dark++;           // the counting kernels trace the query (and say how many such there are)
+    return !COUNT && dark;
+}
 
 // ------------------------------------------------------------------ materials
 struct MatEval {

@@ -56,6 +56,7 @@ class RaytraceRenderer:
             raise abi.YcgeError(rc, (self.L.ycge_last_error(self.ctx) or b"").decode())
 
     def close(self):
+        self._drop_sdr_buffer()
         if getattr(self, "ctx", None):
             self.L.ycge_destroy(self.ctx)
             self.ctx = C.c_void_p()
@@ -124,13 +125,29 @@ class RaytraceRenderer:
         p = (C.c_float * 3)(*self._pos)
         self._check(self.L.ycge_set_camera(self.ctx, p, self._yaw, self._pitch, self._fov))
 
-    def TryFlipAndBlit(self, want_sdr: bool = False):
-        """One frame.  Returns the fbH x fbW x 2 x 3 SDR array (top, bottom per chexel) when
-        want_sdr, else the frame statistics."""
-        sdr = np.zeros((self.fbH, self.fbW, 2, 3), dtype=np.float32) if want_sdr else None
+    def _sdr_buffer(self):
+        """The wrapper's ONE SDR buffer (the C# side keeps a float[] for the life of the renderer), page-locked
+        once through ycge_pin_host_buffer so that the frame's read-back is a plain DMA."""
+        shape = (self.fbH, self.fbW, 2, 3)
+        if getattr(self, "_sdr", None) is None or self._sdr.shape != shape:
+            self._drop_sdr_buffer()
+            self._sdr = np.zeros(shape, dtype=np.float32)
+            self._sdr_pinned = self.L.ycge_pin_host_buffer(self._sdr.ctypes.data_as(C.c_void_p), self._sdr.nbytes) == 0
+        return self._sdr
+
+    def _drop_sdr_buffer(self):
+        if getattr(self, "_sdr", None) is not None and getattr(self, "_sdr_pinned", False):
+            self.L.ycge_unpin_host_buffer(self._sdr.ctypes.data_as(C.c_void_p))
+        self._sdr = None
+        self._sdr_pinned = False
+
+    def TryFlipAndBlit(self, want_sdr: bool = False, copy: bool = True):
+        """One frame.  Returns the fbH x fbW x 2 x 3 SDR array (top, bottom per chexel) when want_sdr (a copy of the wrapper's
+        buffer; copy=False hands out the buffer itself, overwritten by the next frame), else the frame statistics."""
+        sdr = self._sdr_buffer() if want_sdr else None
         ptr = sdr.ctypes.data_as(C.POINTER(C.c_float)) if want_sdr else None
         self._check(self.L.ycge_render_frame(self.ctx, ptr, C.byref(self.stats)))
-        return sdr if want_sdr else self.stats
+        return (sdr.copy() if copy else sdr) if want_sdr else self.stats
 
     # ---------------------------------------------------------------- multi-GPU halves
     def tile_slab_bytes(self) -> int:
