@@ -283,7 +283,8 @@ def main():
         # which launches trace_ms brackets: the single-launch kernel k_trace with k_trace_fan beside it for the head of the schedule
         # (two streams forked from and joined to the frame's stream: the duration is their makespan; scenes without heavy blocks
         # run k_trace alone), or the stage pipeline of scenes with a real top-level tree (config 5)
-        kernel = "k_wf_* stages" if args.config == 5 else "k_trace" if args.config in (1, 2) else "k_trace + k_trace_fan (concurrent)"
+        fanned = int(r.stats.fan_blocks) > 0
+        kernel = "k_wf_* stages" if args.config == 5 else "k_trace + k_trace_fan (concurrent)" if fanned else "k_trace"
         roof = {"bound": "hbm", "kernel": kernel, "achieved": round(ach, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": round(ach / HBM_PEAK_GBS, 5), "traffic": None,
                 "achieved_is": "algorithmic bytes of the REFERENCE's traversal (SURVEY 8d counters) / launch time - mostly cache hits, NOT memory traffic",

@@ -1,11 +1,20 @@
 #!/bin/bash
-# round-end measurement on the GPU box: full GPU test suite, default bench (with CPU baseline and the SDR frame), secondary configs,
-# rocprofv3 kernel trace + PMC passes of configs 4 and 5 (every profiler run under its own timeout).  Everything lands in gpurun_out/.
+# round-end measurement on the GPU box: full GPU test suite, bench of every GPU config WITH the CPU baseline beside it, the moving-camera
+# headline, rocprofv3 kernel trace + PMC passes of configs 4 and 5 (every profiler run under its own timeout).  Everything lands in gpurun_out/.
 REPO=${GRAFT_REPO_ROOT:-/root/repo}; cd $REPO; mkdir -p gpurun_out
-TAG=${1:-r02}
-timeout 1200 python -m pytest tests -m gpu -x -q > gpurun_out/pytest_gpu_$TAG.log 2>&1; echo "pytest rc=$?"; tail -2 gpurun_out/pytest_gpu_$TAG.log
-timeout 600 python bench.py > gpurun_out/bench_$TAG.json 2> gpurun_out/bench_$TAG.err; echo "bench rc=$?"; cat gpurun_out/bench_$TAG.json
-for c in 2 3 5; do timeout 300 python bench.py --config $c --steps 20 --warmup 3 --no-cpu-baseline 2>> gpurun_out/bench_$TAG.err | tee gpurun_out/bench_${TAG}_cfg$c.json | python -c "import sys,json; d=json.loads(sys.stdin.read()); print('config $c', d['value'],'Mrays/s', d['ms_per_step'],'ms/frame', d['roofline']['mean_launch_ms'], d.get('post_stage'))"; done
+TAG=${1:-r03}
+timeout 1800 python -m pytest tests -m gpu -q > gpurun_out/pytest_gpu_$TAG.log 2>&1; echo "pytest rc=$?"; tail -3 gpurun_out/pytest_gpu_$TAG.log
+timeout 600 python bench.py > gpurun_out/bench_$TAG.json 2> gpurun_out/bench_$TAG.err; echo "bench rc=$?"
+for c in 2 3 5; do timeout 400 python bench.py --config $c --cpu-seconds 10 2>> gpurun_out/bench_$TAG.err > gpurun_out/bench_${TAG}_cfg$c.json; done
+timeout 300 python bench.py --camera orbit --no-cpu-baseline > gpurun_out/bench_${TAG}_orbit.json 2>> gpurun_out/bench_$TAG.err
+for f in bench_$TAG bench_${TAG}_cfg2 bench_${TAG}_cfg3 bench_${TAG}_cfg5 bench_${TAG}_orbit; do python - <<PY
+import json
+try:
+    d = json.load(open("gpurun_out/$f.json"))
+    print("$f", d["value"], "Mrays/s", d["ms_per_step"], "ms/frame; trace", d.get("trace_ms"), "cpu", (d.get("cpu_baseline") or {}).get("value"), "x", d.get("gpu_over_cpu"), "moving", (d.get("moving_camera") or {}).get("trace_ms"), "post", (d.get("post_stage") or {}).get("post_ms"), (d.get("post_stage") or {}).get("frame_ms_with_sdr_readback"))
+except Exception as e:
+    print("$f failed", e)
+PY
+done
 bash profiles/run_profiles.sh ${TAG}_c4 > gpurun_out/prof_${TAG}_c4.log 2>&1; echo "profiles c4 rc=$?"; head -12 gpurun_out/prof_${TAG}_c4/summary.txt
-bash profiles/run_profiles.sh ${TAG}_c5 --config 5 > gpurun_out/prof_${TAG}_c5.log 2>&1; echo "profiles c5 rc=$?"
-bash profiles/post_quick.sh 2>&1 | head -24
+bash profiles/run_profiles.sh ${TAG}_c5 --config 5 > gpurun_out/prof_${TAG}_c5.log 2>&1; echo "profiles c5 rc=$?"; head -12 gpurun_out/prof_${TAG}_c5/summary.txt

@@ -163,6 +163,7 @@ struct GLight {
     float dark;
 };
 
+#define YCGE_SPLIT_TOP_DEFAULT 32     // blocks at the head of k_trace's schedule that go in 4 parts of 16 pixels (k_cost_scatter)
 #define YCGE_TIMED_STEP_SLOTS_LG 10  // counters[8 + 8 i], i < 1024: lane steps of the timed kernel instances, spread over cache lines (flush_work)
 #define YCGE_COUNTER_WORDS (8 + 8 * (1 << YCGE_TIMED_STEP_SLOTS_LG))
 #define YCGE_LDS_STACK_LEVELS 12    // levels of a lane's traversal stack kept in LDS; deeper ones go to the HBM spill area

@@ -30,7 +30,7 @@ int ycge_launch_trace(const ycge::SceneDev *S, const ycge::FrameParams *P, const
                       hipStream_t stream);
 int ycge_launch_wavefront(const ycge::SceneDev *S, const ycge::FrameParams *P, const ycge::TraceOut *O, void *const bufs[7], int rounds,
                           int has_grid, int flat, int count, int persistent_waves, hipStream_t stream);
-int ycge_launch_order_blocks(uint32_t *cost, uint32_t n, uint32_t policy, uint32_t fan_class, uint32_t fan_cap, uint32_t next_slot, uint32_t *order_ws,
+int ycge_launch_order_blocks(uint32_t *cost, uint32_t n, uint32_t policy, uint32_t split_top, uint32_t fan_class, uint32_t fan_cap, uint32_t next_slot, uint32_t *order_ws,
                              uint32_t *order, hipStream_t stream);
 int ycge_launch_trace_fan(const ycge::SceneDev *S, const ycge::FrameParams *P, const ycge::TraceOut *O, int count, int flat, uint32_t fan_cap,
                           hipStream_t stream);
@@ -110,6 +110,8 @@ struct Knobs {
     int wave_prof_stage = -1;        // YCGE_WAVE_PROF: -1 off, 0 primary, 1 extend, 2 mega
     int refill_steps = YCGE_REFILL_STEPS_DEFAULT;
     bool split_set = false; uint32_t split_policy = 0;
+    int split_top_lg = 2;                        // YCGE_SPLIT_TOP_LG: log2 of the parts such a block goes in (2 = 4 parts of 16 pixels)
+    int split_top = YCGE_SPLIT_TOP_DEFAULT;     // YCGE_SPLIT_TOP: this many blocks at the head of the schedule go in 4 parts of 16 pixels (0 = none)
     int pw_per_cu = 32;
     int post_band_rows = YCGE_POST_BAND_ROWS_DEFAULT, post_k = YCGE_POST_K_DEFAULT, post_groups = YCGE_POST_GROUPS_DEFAULT;
     int fan_class = -1, fan_cap = -1;   // -1 = default by world size
@@ -133,6 +135,10 @@ struct Knobs {
         if (const char *e = getenv("YCGE_WAVE_PROF")) wave_prof_stage = e[0] == 'e' ? 1 : e[0] == 'm' ? 2 : 0;
         refill_steps = geti("YCGE_REFILL", YCGE_REFILL_STEPS_DEFAULT);
         if (const char *e = getenv("YCGE_SPLIT")) { split_set = true; split_policy = (uint32_t)strtoul(e, nullptr, 8); }
+        split_top = geti("YCGE_SPLIT_TOP", YCGE_SPLIT_TOP_DEFAULT);
+        if (split_top < 0) split_top = 0;
+        split_top_lg = geti("YCGE_SPLIT_TOP_LG", 2);
+        if (split_top_lg < 1 || split_top_lg > 6) split_top_lg = 2;
         pw_per_cu = geti("YCGE_PW_PER_CU", 32);
         post_band_rows = geti("YCGE_POST_BAND_ROWS", YCGE_POST_BAND_ROWS_DEFAULT); post_k = geti("YCGE_POST_K", YCGE_POST_K_DEFAULT);
         post_groups = geti("YCGE_POST_GROUPS", YCGE_POST_GROUPS_DEFAULT);
@@ -1537,7 +1543,9 @@ int trace_frame(ycge_ctx *c, float *d_slab, hipStream_t stream, FrameState &fs, 
             // pack and all-gather), instead of 25 us in front of it; the next trace waits for it (order_ev)
             HIP_TRY(c, hipEventRecord(c->traced_ev, stream));
             HIP_TRY(c, hipStreamWaitEvent(c->fan_stream, c->traced_ev, 0));
-            e = ycge_launch_order_blocks(c->block_cost.p, n_blocks, policy, c->fan_class, c->fan_cap, (cost_slot + 1u) % YCGE_COST_FRAMES, c->order_ws.p, c->block_order.p, c->fan_stream);
+            // ... or, on a whole frame, the split_top blocks at the head of the schedule whatever their class (k_cost_scatter)
+            const uint32_t split_top = (c->knobs.split_set || policy || c->knobs.split_top <= 0) ? 0u : ((uint32_t)c->knobs.split_top & 0xffffu) | ((uint32_t)c->knobs.split_top_lg << 16);
+            e = ycge_launch_order_blocks(c->block_cost.p, n_blocks, policy, split_top, c->fan_class, c->fan_cap, (cost_slot + 1u) % YCGE_COST_FRAMES, c->order_ws.p, c->block_order.p, c->fan_stream);
             c->block_order_valid = true;
             if (e == 0 && c->h_n_fan && c->fan_cap > 0) HIP_TRY(c, hipMemcpyAsync(c->h_n_fan, c->order_ws.p + 18, sizeof(uint32_t), hipMemcpyDeviceToHost, c->fan_stream));
             HIP_TRY(c, hipEventRecord(c->order_ev, c->fan_stream));

@@ -1188,45 +1188,67 @@ __global__ __launch_bounds__(1024) void k_cost_hist(const uint32_t *__restrict__
     __syncthreads();
     if (threadIdx.x < YCGE_ORDER_CLASSES && h[threadIdx.x]) atomicAdd(&ws[32 + threadIdx.x], h[threadIdx.x]);
 }
-__global__ __launch_bounds__(1024) void k_cost_scatter(uint32_t *__restrict__ cost, uint32_t n, uint32_t capacity, uint32_t policy,
+// Which blocks go in parts (a part = 64 >> lg pixels of the block, one wavefront each): either by policy class (`policy`, the YCGE_SPLIT
+// knob and the 8-rank default) or - split_top > 0 - the split_top blocks at the HEAD of the schedule, in 4 parts of 16 pixels: a part's
+// chain is the longest of 16 pixels' queries instead of 64, it reaches the cooperative walk's trigger (<= 4 live lanes) sooner, and a few
+// dozen blocks are what the frame's end waits for (round 3: config 3 0.309 -> 0.275 ms with its ~100 blocks above 256 iterations
+// split; by CLASS the same rule hands config 4 its 780 such blocks and loses).  Within an order class the first-come blocks are the split ones.
+struct ClassLayout { uint32_t entries_before, blocks_before, n_split, lg; };
+__device__ __forceinline__ ClassLayout class_layout(const uint32_t *ws, int cls, uint32_t policy, uint32_t split_top, bool split)
+{
+    ClassLayout L = {0u, 0u, 0u, 0u};
+    for (int c = YCGE_ORDER_CLASSES - 1; c >= cls; c--) {
+        const uint32_t cnt = ws[32 + c];
+        const uint32_t lg = !split ? 0u : split_top ? (split_top >> 16) : class_lg_parts(policy, policy_class_of_order_class(c));
+        const uint32_t top = split_top & 0xffffu;       // split_top = blocks | log2(parts) << 16
+        const uint32_t ns = !split ? 0u : split_top ? (top > L.blocks_before ? (top - L.blocks_before < cnt ? top - L.blocks_before : cnt) : 0u) : (lg ? cnt : 0u);
+        if (c == cls) { L.n_split = ns; L.lg = lg; return L; }
+        L.entries_before += cnt + ns * ((1u << lg) - 1u);
+        L.blocks_before += cnt;
+    }
+    return L;
+}
+__global__ __launch_bounds__(1024) void k_cost_scatter(uint32_t *__restrict__ cost, uint32_t n, uint32_t capacity, uint32_t policy, uint32_t split_top,
                                                        uint32_t fan_class, uint32_t fan_cap, uint32_t next_slot, uint32_t *__restrict__ ws, uint32_t *__restrict__ order)
 {
-    __shared__ uint32_t h[YCGE_ORDER_CLASSES], base[YCGE_ORDER_CLASSES];
+    __shared__ uint32_t h[YCGE_ORDER_CLASSES], rank0[YCGE_ORDER_CLASSES];
+    __shared__ ClassLayout lay[YCGE_ORDER_CLASSES];
     __shared__ uint32_t s_split;
     if (threadIdx.x < YCGE_ORDER_CLASSES) h[threadIdx.x] = 0;
     if (threadIdx.x == 0) {     // every workgroup derives the same decision from the finished histogram
-        uint32_t total = 0;
-        for (int c = 0; c < YCGE_ORDER_CLASSES; c++) total += ws[32 + c] << class_lg_parts(policy, policy_class_of_order_class(c));
-        s_split = total <= capacity ? 1u : 0u;
+        const ClassLayout all = class_layout(ws, -1, policy, split_top, true);         // (cls = -1: the sums over every class)
+        s_split = all.entries_before <= capacity ? 1u : 0u;
         if (blockIdx.x == 0) {
-            ws[16] = s_split ? total : n;
-            uint32_t n_fan = 0;                 // blocks of the policy classes >= fan_class, at the head of the schedule
-            if (fan_class > 0)
-                for (int c = YCGE_ORDER_CLASSES - 1; c >= 0 && policy_class_of_order_class(c) >= (int)fan_class; c--)
-                    n_fan += ws[32 + c] << (s_split ? class_lg_parts(policy, policy_class_of_order_class(c)) : 0u);
+            ws[16] = s_split ? all.entries_before : n;
+            uint32_t n_fan = 0;                 // entries of the policy classes >= fan_class, at the head of the schedule
+            if (fan_class > 0) {
+                int lowest = YCGE_ORDER_CLASSES;
+                while (lowest > 0 && policy_class_of_order_class(lowest - 1) >= (int)fan_class) lowest--;
+                if (lowest < YCGE_ORDER_CLASSES) { const ClassLayout f = class_layout(ws, lowest - 1, policy, split_top, s_split != 0); n_fan = f.entries_before; }
+            }
             ws[18] = n_fan < fan_cap ? n_fan : fan_cap;
         }
     }
     __syncthreads();
     const bool split = s_split != 0;
+    if (threadIdx.x < YCGE_ORDER_CLASSES) lay[threadIdx.x] = class_layout(ws, (int)threadIdx.x, policy, split_top, split);
     const uint32_t i = blockIdx.x * 1024u + threadIdx.x;
     int cls = -1;
-    uint32_t local = 0, lgp = 0;
+    uint32_t local = 0;
     if (i < n) {
         cls = order_class(smoothed_cost(cost, n, i));
         cost[(size_t)next_slot * n + i] = 0;         // the ring slot the next frame's atomicMax goes to
-        lgp = split ? class_lg_parts(policy, policy_class_of_order_class(cls)) : 0u;
-        local = atomicAdd(&h[cls], 1u << lgp);
+        local = atomicAdd(&h[cls], 1u);
     }
     __syncthreads();
-    if (threadIdx.x < YCGE_ORDER_CLASSES) {
-        uint32_t off = 0;                                   // order classes 31, 30, ..., 0 laid out in that order
-        for (int c = YCGE_ORDER_CLASSES - 1; c > (int)threadIdx.x; c--) off += ws[32 + c] << (split ? class_lg_parts(policy, policy_class_of_order_class(c)) : 0u);
-        base[threadIdx.x] = off + (h[threadIdx.x] ? atomicAdd(&ws[64 + threadIdx.x], h[threadIdx.x]) : 0u);
-    }
+    if (threadIdx.x < YCGE_ORDER_CLASSES) rank0[threadIdx.x] = h[threadIdx.x] ? atomicAdd(&ws[64 + threadIdx.x], h[threadIdx.x]) : 0u;     // this workgroup's first rank in the class
     __syncthreads();
     if (cls >= 0) {
-        uint32_t *dst = order + base[cls] + local;
+        const ClassLayout L = lay[cls];
+        const uint32_t rank = rank0[cls] + local, parts = 1u << L.lg;
+        const bool in_parts = rank < L.n_split;
+        uint32_t *dst = order + L.entries_before + (in_parts ? rank * parts : L.n_split * parts + (rank - L.n_split));
+        const uint32_t lgp = in_parts ? L.lg : 0u;
         for (uint32_t p = 0; p < (1u << lgp); p++) dst[p] = i | (p << 22) | (lgp << 28);
     }
 }
@@ -1475,7 +1497,7 @@ int ycge_launch_wavefront(const ycge::SceneDev *S, const ycge::FrameParams *P, c
 }
 
 // builds next frame's k_trace schedule from this frame's per-block step counts.  ws: 18 uint32 (see k_cost_hist)
-int ycge_launch_order_blocks(uint32_t *cost, uint32_t n, uint32_t policy, uint32_t fan_class, uint32_t fan_cap, uint32_t next_slot, uint32_t *ws,
+int ycge_launch_order_blocks(uint32_t *cost, uint32_t n, uint32_t policy, uint32_t split_top, uint32_t fan_class, uint32_t fan_cap, uint32_t next_slot, uint32_t *ws,
                              uint32_t *order, hipStream_t stream)
 {
     if (n == 0) return 0;
@@ -1483,7 +1505,7 @@ int ycge_launch_order_blocks(uint32_t *cost, uint32_t n, uint32_t policy, uint32
     if (e != hipSuccess) return (int)e;
     const dim3 grid((n + 1023u) / 1024u), block(1024);
     hipLaunchKernelGGL(ycge::k_cost_hist, grid, block, 0, stream, cost, n, ws);
-    hipLaunchKernelGGL(ycge::k_cost_scatter, grid, block, 0, stream, cost, n, n * YCGE_SCHEDULE_SLACK, policy, fan_class, fan_cap, next_slot, ws, order);
+    hipLaunchKernelGGL(ycge::k_cost_scatter, grid, block, 0, stream, cost, n, n * YCGE_SCHEDULE_SLACK, policy, split_top, fan_class, fan_cap, next_slot, ws, order);
     return (int)hipGetLastError();
 }
 
