@@ -52,7 +52,7 @@ for k in acc:
 # per-FRAME counter summary of the trace kernels (the launches stats.trace_ms brackets), for bench.py's roofline object
 if json_path:
     import json
-    TRACE = ("k_trace", "k_trace_fan", "k_trace_refill", "k_wf_primary", "k_wf_extend", "k_wf_trace_p", "k_wf_shade", "k_wf_lights")
+    TRACE = ("k_trace", "k_trace_nomesh", "k_trace_fan", "k_trace_refill", "k_wf_primary", "k_wf_extend", "k_wf_trace_p", "k_wf_shade", "k_wf_lights")
     def is_trace(k):      # the kernels the benchmark times: the NON-counting instances (bench.py's counting replay launches the <true, ...> ones)
         return k.split("<")[0] in TRACE and ("<" not in k or k.split("<")[1].split(",")[0].strip() in ("false", "false>") or k.split("<")[0] == "k_wf_shade")
     # calibration: bytes a copy of known size moves / what the counters say (copycal under the same two PMC passes)
@@ -72,7 +72,7 @@ if json_path:
                 if "WRITE_SIZE" in acc[k]: cal["write_4B_lanes"] = cal_bytes / (sum(acc[k]["WRITE_SIZE"]) / len(acc[k]["WRITE_SIZE"]) * 1024.0)
     n_frames = {}
     tot = defaultdict(float)
-    lead = [k for k in acc if is_trace(k) and k.split("<")[0] in ("k_trace", "k_wf_primary")]      # one launch of these per frame
+    lead = [k for k in acc if is_trace(k) and k.split("<")[0] in ("k_trace", "k_trace_nomesh", "k_wf_primary")]      # one launch of these per frame
     for k in lead:
         for c, vs in acc[k].items():
             n_frames[c] = max(n_frames.get(c, 0), len(vs))

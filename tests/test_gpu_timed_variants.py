@@ -247,8 +247,10 @@ def test_dynamic_texture_scenes_restart_the_history_every_frame(product_lib, ora
 
 def test_timed_step_counter_reports_the_timed_kernels_own_work(product_lib):
     """ycge_read_timed_steps: lane steps of the NON-counting instances, cumulative.  A frame of config 3 walks a positive number of
-    steps, the same number when the same frame is traced again (frame counter rewound), and fewer than the reference's box + triangle
-    tests would need one by one (two boxes per node step, two triangles per leaf step, shadow queries stop at the first hit)."""
+    steps, about the same number when the same frame is traced again (frame counter rewound: the second time the blocks run in schedule
+    order and the heaviest in parts, so other lanes share a wavefront and the cooperative walk takes over at other points - a few
+    per cent), and fewer than the reference's box + triangle tests would need one by one (two boxes per node step, two triangles per
+    leaf step, a treelet or a whole leaf per cooperative step, shadow queries stop at the first hit)."""
     sc, w, h, ss, pose = scenes.config_scene(3)
     flat = flatten(sc)
     g = RaytraceRenderer(flat, w // 4, h // 4, pose["fov"], ss)
@@ -260,7 +262,7 @@ def test_timed_step_counter_reports_the_timed_kernels_own_work(product_lib):
     s1 = g.timed_steps()
     g.set_frame_counter(0); g.TryFlipAndBlit()
     s2 = g.timed_steps() - s1
-    assert s1 > 0 and s2 == s1, (s1, s2)
+    assert s1 > 0 and abs(s2 - s1) <= 0.1 * s1, (s1, s2)
     assert s1 <= c.stats.n_box // 2 + c.stats.n_tri + c.stats.n_prim, (s1, c.stats.n_box, c.stats.n_tri)
     assert c.timed_steps() == 0          # the counting instances report the reference's counters instead
     g.close(); c.close()

@@ -149,7 +149,8 @@ struct alignas(16) GGrid {
     // that misses it between tmin and tmax cannot hit anything here - the voxel walk's rounding errors are ~1e-5 of a voxel - so the
     // timed kernels do not enter the grid at all (grid_cull); the counting kernels walk it as the reference does.
     float solid_lo[3], solid_hi[3];
-    uint32_t pad[2];
+    float cull_t_limit;         // ... as long as the ray leaves that box at t <= this (the walk's accumulated rounding stays below half a voxel; host: ycge_scene_upload)
+    uint32_t pad;
 };
 static_assert(sizeof(GGrid) == 112, "GGrid must be 112 B");
 

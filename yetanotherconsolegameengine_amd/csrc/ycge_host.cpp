@@ -252,7 +252,7 @@ struct ycge_ctx {
     // what ycge_scene_update_objects needs from the last full upload
     std::vector<GMesh> gmeshes_host;
     std::vector<std::array<float, 6>> grid_bounds;   // VolumeGrid.TryGetBounds per grid; max < min marks an empty grid
-    std::vector<std::array<float, 6>> grid_solid;    // GGrid::solid_lo / solid_hi per grid (copied into the grid's object record: the walk culls before it enters)
+    std::vector<std::array<float, 7>> grid_solid;    // GGrid::solid_lo / solid_hi per grid (copied into the grid's object record: the walk culls before it enters)
     int n_materials = 0, max_mesh_depth = 0;
     bool materials_can_mirror = false;
     bool has_dynamic_textures = false;           // Scene.HasDynamicTextures: every frame restarts the TAA history (RaytraceRenderer.cs:171)
@@ -841,7 +841,7 @@ int flatten_objects(ycge_ctx *c, const ycge_prim *prims, int n_prims, ObjectsHos
         }
         case YCGE_PRIM_VOLUME_GRID:
             if (q.ref < 0 || q.ref >= (int)c->grid_bounds.size()) return c->fail(YCGE_ERR_INVALID_ARG, "prim %d: grid ref out of range", i);
-            for (int k = 0; k < 6; k++) g.p[k] = c->grid_solid[q.ref][k];       // box of the grid's solid voxels (grid_cull in the walk)
+            for (int k = 0; k < 7; k++) g.p[k] = c->grid_solid[q.ref][k];       // box of the grid's solid voxels + how far along a ray it may be trusted (grid_cull in the walk)
             break;
         default: return c->fail(YCGE_ERR_INVALID_ARG, "prim %d: unknown type %d", i, q.type);
         }
@@ -1229,6 +1229,15 @@ int ycge_scene_upload(ycge_ctx *c, const ycge_scene *s)
             G.solid_lo[a] = hi[a] < 0 ? 1.0f : G.min_corner[a] + (float)(lo[a] - 1) * G.voxel_size[a];
             G.solid_hi[a] = hi[a] < 0 ? 0.0f : G.min_corner[a] + (float)(hi[a] + 2) * G.voxel_size[a];
         }
+        // How far along a ray the one-voxel margin of that box is provably enough.  The reference's walk reaches a cell by repeated
+        // binary32 additions to tMax (VolumeGrid.cs:205-226): after k steps its t is off by at most k * ulp(t) / 2, i.e. the cell path
+        // may drift k * t * 2^-24 world units from the true ray, with k <= nx + ny + nz steps inside one grid.  The cull (and the early
+        // end of a walk at the box's exit) assumes that drift stays below HALF a voxel: t <= voxel * 2^23 / (nx + ny + nz) - 87 000 voxel
+        // lengths for a 32^3 chunk; half of that is what is stored.  Beyond it the timed kernels walk the grid as the reference does.
+        {
+            const float vs = cs_min(G.voxel_size[0], cs_min(G.voxel_size[1], G.voxel_size[2]));
+            G.cull_t_limit = vs * 4194304.0f / (float)(G.nx + G.ny + G.nz);
+        }
         G.has_brick_mask = maskable ? 1 : 0;
         G.brick_mask_lo = (uint32_t)brick_mask; G.brick_mask_hi = (uint32_t)(brick_mask >> 32);
     }
@@ -1249,7 +1258,10 @@ int ycge_scene_upload(ycge_ctx *c, const ycge_scene *s)
     }
     c->grid_solid.resize(s->n_grids);
     for (int gi = 0; gi < s->n_grids; gi++)
+    {
         for (int a = 0; a < 3; a++) { c->grid_solid[gi][a] = A.ggrids[gi].solid_lo[a]; c->grid_solid[gi][3 + a] = A.ggrids[gi].solid_hi[a]; }
+        c->grid_solid[gi][6] = A.ggrids[gi].cull_t_limit;
+    }
     A.has_grid = s->n_grids > 0;
 
     // ---- Scene.Objects + scene BVH, then every device gets the same arrays

@@ -221,7 +221,7 @@ __global__ __launch_bounds__(256) void k_wf_extend(const SceneDev S, const Trace
 #define YCGE_ROUND_TREE_STEPS 6
 #define YCGE_ROUND_CELL_STEPS 10
 #ifndef YCGE_TRACEP_WAVES
-#define YCGE_TRACEP_WAVES 6          // persistent extend stage: 6 wavefronts per SIMD (85-VGPR budget) and 32 persistent wavefronts per CU: 12.35 -> 12.0 ms on the voxel world
+#define YCGE_TRACEP_WAVES 5          // persistent extend stage: 5 wavefronts per SIMD (102 registers, no scratch; round 3: as fast as 6 with its 10 spilled registers - 7.04 against 7.00 ms - and 0.46 GB less written per 4K frame) and 32 persistent wavefronts per CU
 #endif
 template <bool COUNT, bool HAS_GRID>
 __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu((HAS_GRID && !COUNT) ? YCGE_TRACEP_WAVES : 1, 8))) void k_wf_trace_p(const SceneDev S, const FrameParams P, const TraceOut O, const WfBuffers B, int round,
@@ -663,7 +663,7 @@ __device__ __forceinline__ void shade_ctx_load(uint32_t addr, F3 &p, F3 &n, F3 &
 //         the block's posted queries (up to 192) form a list, a lane that finishes its query takes the next one whichever
 //         pixel it belongs to, and the walk yields every `refill_steps` steps so that idle lanes can do so.  A block then
 //         costs about max(its longest query, its steps / 64) per stage instead of the sum of the stage's longest lanes.
-template <bool COUNT, bool FLAT, int MODE>
+template <bool COUNT, bool FLAT, int MODE, bool FULLW = true>
 __device__ __forceinline__ void trace_block(const SceneDev &S, const FrameParams &P, const TraceOut &O, const uint32_t ent, const uint32_t sched_index,
                                             FanShared *F, const int refill_steps)
 {
@@ -772,15 +772,12 @@ __device__ __forceinline__ void trace_block(const SceneDev &S, const FrameParams
         int hit_prim = -1, hit_sub = 0;
         if (!__any(phase != PH_DONE && !parked)) break;
         const uint32_t steps_before = w.steps;
-#if defined(YCGE_DBG_NOFULL)
-        if (!FAN) { if (phase != PH_DONE) traverse<COUNT, true, FLAT, false>(S, q, st, t_hit, hit_prim, hit_sub, w); }
-        else if (phase != PH_DONE && !parked) {
-#else
-        if (!FAN) {         // every lane of the wavefront enters (the cooperative walk needs them all): finished pixels carry live = false
+        if (!FAN && !FULLW) {       // (the instance for scenes without a mesh: nothing to walk cooperatively, lanes without a query stay out)
+            if (phase != PH_DONE) traverse<COUNT, true, FLAT, false>(S, q, st, t_hit, hit_prim, hit_sub, w);
+        } else if (!FAN) {         // every lane of the wavefront enters (the cooperative walk needs them all): finished pixels carry live = false
             q.live = phase != PH_DONE;
             traverse<COUNT, true, FLAT, true>(S, q, st, t_hit, hit_prim, hit_sub, w);
         } else if (phase != PH_DONE && !parked) {
-#endif
             if (want == 3) { t_hit = pre_b_t; hit_prim = pre_b_prim; hit_sub = pre_b_sub; }
             else { t_hit = F->r[want][0][lane]; hit_prim = __float_as_int(F->r[want][1][lane]); hit_sub = __float_as_int(F->r[want][2][lane]); }
         }
@@ -1119,6 +1116,18 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu((FLAT && !CO
     } else if (blockIdx.x >= (uint32_t)P.n_owned_tiles * 4u) return;
     trace_block<COUNT, FLAT, 0>(S, P, O, ent, idx, nullptr, 0);
 }
+// The same kernel for scenes WITHOUT a mesh (nothing to walk cooperatively: the treelet code is compiled out and, with it, the register
+// peak): 125 registers, 4 wavefronts per SIMD - analytic scenes are throughput, not chains (config 2: 0.082 ms at 3 wavefronts, 0.068 at 4).
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 8))) void k_trace_nomesh(const SceneDev S, const FrameParams P, const TraceOut O)
+{
+    uint32_t idx = blockIdx.x, ent = blockIdx.x;
+    if (O.block_order) {
+        if (O.n_fan) idx += *O.n_fan;
+        if (idx >= *O.n_order) return;
+        ent = O.block_order[idx];
+    } else if (blockIdx.x >= (uint32_t)P.n_owned_tiles * 4u) return;
+    trace_block<false, true, 0, false>(S, P, O, ent, idx, nullptr, 0);
+}
 template <bool COUNT>
 __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(COUNT ? 2 : 3, 8))) void k_trace_refill(const SceneDev S, const FrameParams P, const TraceOut O, const int refill_steps)
 {
@@ -1445,6 +1454,10 @@ int ycge_launch_trace(const ycge::SceneDev *S, const ycge::FrameParams *P, const
         return (int)hipGetLastError();
     }
     static const unsigned lds_pad = getenv("YCGE_LDS_PAD") ? (unsigned)atoi(getenv("YCGE_LDS_PAD")) : 0u;   // experiment knob: fewer resident wavefronts
+    if (!count && flat && S->tl_offset == 0u) {         // no mesh (or the cooperative walk switched off): the lean instance
+        hipLaunchKernelGGL(k_trace_nomesh, grid, block, lds_pad, stream, *S, *P, *O);
+        return (int)hipGetLastError();
+    }
     sel3(count != 0, flat != 0, false, [&](auto C, auto F, auto) {
         hipLaunchKernelGGL((k_trace<decltype(C)::value, decltype(F)::value>), grid, block, lds_pad, stream, *S, *P, *O);
     });

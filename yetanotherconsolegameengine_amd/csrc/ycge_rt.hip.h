@@ -490,7 +490,7 @@ __device__ __forceinline__ float div_by_size(float x, float s) { return s == 1.0
 // every solid voxel: either outcome of the comparison is right.
 // t_out: where the ray leaves the box - beyond it the walk meets air only, so the timed kernels end it there (a ray that rises from
 // the ground stops two voxels above the chunk's highest block instead of at the chunk's top).
-__device__ __forceinline__ bool solid_box_missed(float lx, float ly, float lz, float hx, float hy, float hz, F3 o, F3 inv, float tmin, float tmax,
+__device__ __forceinline__ bool solid_box_missed(float lx, float ly, float lz, float hx, float hy, float hz, float t_limit, F3 o, F3 inv, float tmin, float tmax,
                                                  float &t_out)
 {
     t_out = YCGE_INF;
@@ -500,11 +500,14 @@ __device__ __forceinline__ bool solid_box_missed(float lx, float ly, float lz, f
     const float az = (lz - o.z) * inv.z, bz = (hz - o.z) * inv.z;
     const float t_in = fmaxf(fmaxf(fminf(ax, bx), fminf(ay, by)), fminf(az, bz));
     t_out = fminf(fminf(fmaxf(ax, bx), fmaxf(ay, by)), fmaxf(az, bz));
+    // so far from the ray's origin that the reference's cell walk (t by repeated binary32 additions) may stray more than the box's
+    // one-voxel margin from the true ray (GGrid::cull_t_limit): no verdict, and no early end - the grid is walked as the reference walks it
+    if (!(t_out <= t_limit)) { t_out = YCGE_INF; return false; }
     return t_in > t_out || t_out < tmin || t_in > tmax;
 }
 __device__ __forceinline__ bool grid_cull(const GGrid &g, F3 o, F3 inv, float tmin, float tmax, float &t_out)
 {
-    return solid_box_missed(g.solid_lo[0], g.solid_lo[1], g.solid_lo[2], g.solid_hi[0], g.solid_hi[1], g.solid_hi[2], o, inv, tmin, tmax, t_out);
+    return solid_box_missed(g.solid_lo[0], g.solid_lo[1], g.solid_lo[2], g.solid_hi[0], g.solid_hi[1], g.solid_hi[2], g.cull_t_limit, o, inv, tmin, tmax, t_out);
 }
 
 // VolumeGrid.Hit, VolumeGrid.cs:99-231 (Amanatides-Woo DDA; first cell with matId > 0 hits).
@@ -971,7 +974,7 @@ __device__ __forceinline__ int tree_phase(const SceneDev &S, uint32_t &cur, int 
                 if (HAS_GRID) {
                     // (the object record carries the box of the grid's solid voxels: a grid the ray cannot hit costs this test, not the
                     // rest of the lane's tree steps of the round plus a voxel phase spent waiting - see grid_cull)
-                    if (!COUNT) { const float4 q1 = pp[1]; const float2 q2 = *(const float2 *)(pp + 2); if (solid_box_missed(q1.x, q1.y, q1.z, q1.w, q2.x, q2.y, o, inv, tmin, closest, parked_tend)) continue; }
+                    if (!COUNT) { const float4 q1 = pp[1], q2 = pp[2]; if (solid_box_missed(q1.x, q1.y, q1.z, q1.w, q2.x, q2.y, q2.z, o, inv, tmin, closest, parked_tend)) continue; }
                     parked_grid = __float_as_int(q0.z); parked_prim = (int)pay; return TREE_AT_GRID;
                 }
             } else {
