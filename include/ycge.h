@@ -73,7 +73,15 @@ typedef enum ycge_material_kind {
  * 1 = g, 2 = b, 3 = a of the little-endian int). */
 typedef struct ycge_texture {
     int32_t width, height;       /* both >= 1                                   */
-    const uint32_t *pixels;      /* width * height                              */
+    const uint32_t *pixels;      /* width * height (static textures)            */
+    /* A LIVE texture (`new Texture(IFrameReader, useRGBA, flipU, flipV)`, Renderer/Texture.cs:51-66: camera / video frames): bytes per
+     * pixel of the frames, 3 = BGR or 4 = BGRA (dynamicBytesPerPixel); 0 = a static texture.  SampleBilinear then takes its other
+     * branch (Texture.cs:113-140: flips, neighbours CLAMPED at the last row / column, bytes in B, G, R order, no per-lerp Saturate). */
+    int32_t frame_bytes_per_pixel;
+    int32_t flip_u, flip_v;
+    /* the frame GetCurrentFramePtr() shows at upload: width * height * frame_bytes_per_pixel bytes (NULL: black until the first
+     * ycge_scene_update_texture).  `pixels` is not read for a live texture. */
+    const uint8_t *frame;
 } ycge_texture;
 
 typedef struct ycge_material {
@@ -337,6 +345,11 @@ int ycge_trace_tiles(ycge_ctx *ctx, void *d_slab, void *hip_stream, ycge_frame_s
  * full-frame buffers, then steps 5-9 (TAA ... tonemap) on the full frame */
 int ycge_resolve_gathered(ycge_ctx *ctx, const void *d_all_slabs, void *hip_stream,
                           float *out_top_bottom_sdr, ycge_frame_stats *stats);
+
+/* A live texture's next frame (what IFrameReader.GetCurrentFramePtr() will return while the coming frames are traced): bytes =
+ * width * height * frame_bytes_per_pixel of texture `texture_index` of the last ycge_scene_upload.  The host sets
+ * ycge_scene.has_dynamic_textures for such scenes (Scene.cs:30), which restarts the TAA history every frame. */
+int ycge_scene_update_texture(ycge_ctx *ctx, int32_t texture_index, const uint8_t *frame, size_t bytes);
 
 /* tests only */
 int ycge_read_buffer(ycge_ctx *ctx, int32_t which /* ycge_buffer */, void *dst, size_t bytes);

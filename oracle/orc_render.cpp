@@ -723,6 +723,16 @@ int orc_scene_upload(void *ctx, const ycge_scene *s)
     r->have_scene = true;
     return YCGE_OK;
 }
+/* the frame IFrameReader.GetCurrentFramePtr() shows from now on (Texture.cs:116) */
+int orc_scene_update_texture(void *ctx, int32_t texture_index, const uint8_t *frame, size_t bytes)
+{
+    Renderer *r = (Renderer *)ctx;
+    if (!r || !r->have_scene || texture_index < 0 || (size_t)texture_index >= r->scene.textures.size() || !frame) return YCGE_ERR_INVALID_ARG;
+    orc::Texture &t = r->scene.textures[(size_t)texture_index];
+    if (t.frame_bpp == 0 || bytes != t.frame.size()) return YCGE_ERR_INVALID_ARG;
+    std::memcpy(t.frame.data(), frame, bytes);
+    return YCGE_OK;
+}
 int orc_scene_update_lights(void *ctx, const ycge_light *lights, int32_t n, const ycge_vec3 *amb, float amb_i,
                             const ycge_vec3 *top, const ycge_vec3 *bottom)
 {

@@ -379,9 +379,14 @@ std::string SceneData::load(const ycge_scene *s)
     textures.clear();
     for (int i = 0; i < s->n_textures; i++) {
         const ycge_texture &t = s->textures[i];
-        if (t.width < 1 || t.height < 1 || !t.pixels) return "texture without pixels";
+        if (t.width < 1 || t.height < 1 || (!t.pixels && t.frame_bytes_per_pixel == 0)) return "texture without pixels";
         Texture T;
         T.width = t.width; T.height = t.height;
+        T.frame_bpp = t.frame_bytes_per_pixel; T.flip_u = t.flip_u != 0; T.flip_v = t.flip_v != 0;
+        if (T.frame_bpp) {
+            T.frame.assign((size_t)t.width * t.height * T.frame_bpp, 0);
+            if (t.frame) std::memcpy(T.frame.data(), t.frame, T.frame.size());
+        } else
         T.pixels.assign(t.pixels, t.pixels + (size_t)t.width * t.height);
         textures.push_back(std::move(T));
     }
@@ -598,7 +603,31 @@ Mat SceneData::eval_material(int32_t mi, V3 pos) const
  * here such an index yields white - not reachable from finite barycentrics and rectangle coordinates. */
 V3 Texture::sample_bilinear(float u, float v) const
 {
-    if (width <= 0 || height <= 0 || pixels.empty()) return v3(1.0f, 1.0f, 1.0f);
+    if (width <= 0 || height <= 0) return v3(1.0f, 1.0f, 1.0f);
+    if (frame_bpp != 0) {
+        /* Texture.cs:113-140, the live branch: flips, Frac, neighbours CLAMPED at the last column / row, LoadPixel reads B, G, R
+         * (:173-182), r0 = r00 * (1 - dTx) + r10 * dTx per channel and row, one Saturate at the end.  (An index from a NaN coordinate
+         * reads outside the frame in the reference; white here, as in the static branch.) */
+        float uu = flip_u ? (1.0f - u) : u;
+        float vv = flip_v ? (1.0f - v) : v;
+        float dfx = (uu - cs_floor(uu)) * (float)(width - 1);
+        float dfy = (vv - cs_floor(vv)) * (float)(height - 1);
+        int x0 = cs_f2i(cs_floor(dfx)), y0 = cs_f2i(cs_floor(dfy));
+        if (x0 < 0 || x0 >= width || y0 < 0 || y0 >= height) return v3(1.0f, 1.0f, 1.0f);
+        int x1 = (x0 + 1) >= width ? (width - 1) : (x0 + 1);
+        int y1 = (y0 + 1) >= height ? (height - 1) : (y0 + 1);
+        float tx = dfx - (float)x0, ty = dfy - (float)y0;
+        auto load = [&](int x, int y) {
+            const uint8_t *q = frame.data() + ((size_t)y * width + x) * frame_bpp;
+            return v3((float)q[2] / 255.0f, (float)q[1] / 255.0f, (float)q[0] / 255.0f);
+        };
+        V3 c00 = load(x0, y0), c10 = load(x1, y0), c01 = load(x0, y1), c11 = load(x1, y1);
+        float sx = 1.0f - tx, sy = 1.0f - ty;
+        V3 r0 = v3(c00.x * sx + c10.x * tx, c00.y * sx + c10.y * tx, c00.z * sx + c10.z * tx);
+        V3 r1 = v3(c01.x * sx + c11.x * tx, c01.y * sx + c11.y * tx, c01.z * sx + c11.z * tx);
+        return v3(clamp01(r0.x * sy + r1.x * ty), clamp01(r0.y * sy + r1.y * ty), clamp01(r0.z * sy + r1.z * ty));
+    }
+    if (pixels.empty()) return v3(1.0f, 1.0f, 1.0f);
     u = u - cs_floor(u);
     v = v - cs_floor(v);
     float fx = u * (float)(width - 1);

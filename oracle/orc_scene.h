@@ -145,7 +145,10 @@ struct Light { V3 pos, color; float intensity; };
 struct Texture {
     int32_t width = 0, height = 0;
     std::vector<uint32_t> pixels;
-    V3 sample_bilinear(float u, float v) const;     /* Texture.cs:108-163 (the branch without a live frame reader) */
+    /* a live texture (Texture.cs:51-66): bytes per pixel of its frames (3 BGR / 4 BGRA; 0 = static), flips, the current frame */
+    int32_t frame_bpp = 0; bool flip_u = false, flip_v = false;
+    std::vector<uint8_t> frame;
+    V3 sample_bilinear(float u, float v) const;     /* Texture.cs:108-163, both branches */
 };
 
 struct SceneData {

@@ -43,6 +43,8 @@ def lib() -> C.CDLL:
         abi.bind(L, prefix="orc_", names=names)
         L.orc_render_frame.restype = C.c_int
         L.orc_render_frame.argtypes = [C.c_void_p, C.POINTER(C.c_float), C.POINTER(abi.FrameStats), C.c_int, C.c_int]
+        L.orc_scene_update_texture.restype = C.c_int
+        L.orc_scene_update_texture.argtypes = [C.c_void_p, C.c_int32, C.c_void_p, C.c_size_t]
         L.orc_set_taa_threads.restype = C.c_int
         L.orc_set_taa_threads.argtypes = [C.c_void_p, C.c_int]
         L.orc_build_stats.restype = C.c_int
@@ -117,6 +119,12 @@ class OracleRenderer:
     def set_camera(self, pos, yaw, pitch, fov=45.0):
         p = (C.c_float * 3)(*pos)
         _check(self.L, self.ctx, self.L.orc_set_camera(self.ctx, p, yaw, pitch, fov))
+
+    def update_texture(self, texture):
+        """the oracle's twin of RaytraceRenderer.UpdateTexture: the live texture's next frame"""
+        idx = next(i for i, t in enumerate(self.flat.texture_objects) if t is texture)
+        f = texture.frame
+        _check(self.L, self.ctx, self.L.orc_scene_update_texture(self.ctx, idx, f.ctypes.data_as(C.c_void_p), f.nbytes))
 
     def set_frame_counter(self, n: int):
         _check(self.L, self.ctx, self.L.orc_set_frame_counter(self.ctx, n))

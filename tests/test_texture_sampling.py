@@ -8,7 +8,7 @@ import pytest
 
 import oracle_binding as ob
 from yetanotherconsolegameengine_amd import abi
-from yetanotherconsolegameengine_amd.scene import (AmbientLight, Box, Material, Mesh, PointLight, Scene, Sphere, Texture, Triangle,
+from yetanotherconsolegameengine_amd.scene import (AmbientLight, Box, LiveTexture, Material, Mesh, PointLight, Scene, Sphere, Texture, Triangle,
                                                    XZRect, flatten, vec3, ZERO)
 
 f32 = np.float32
@@ -35,11 +35,39 @@ def _bilinear_f32(pix, w, h, u, v):
     return [min(max(x, f32(0)), f32(1)) for x in c]
 
 
-def _sample_albedo_f32(albedo, pix, w, h, weight, uv_scale, u, v):
+def _bilinear_live_f32(frame, flip_u, flip_v, u, v):
+    """Texture.SampleBilinear, the LIVE branch (Texture.cs:113-140), one operation at a time in binary32: flips, Frac, neighbours
+    clamped at the last column / row, LoadPixel's B, G, R byte order (:173-182), one Saturate at the end."""
+    h, w, bpp = frame.shape
+    u, v = f32(u), f32(v)
+    uu = f32(f32(1) - u) if flip_u else u
+    vv = f32(f32(1) - v) if flip_v else v
+    dfx = f32(f32(uu - np.floor(uu)) * f32(w - 1)); dfy = f32(f32(vv - np.floor(vv)) * f32(h - 1))
+    x0, y0 = int(np.floor(dfx)), int(np.floor(dfy))
+    x1 = w - 1 if x0 + 1 >= w else x0 + 1
+    y1 = h - 1 if y0 + 1 >= h else y0 + 1
+    tx, ty = f32(dfx - f32(x0)), f32(dfy - f32(y0))
+
+    def load(x, y):
+        b, g, r = (int(frame[y, x, k]) for k in range(3))
+        return [f32(f32(r) / f32(255)), f32(f32(g) / f32(255)), f32(f32(b) / f32(255))]
+
+    def mix(a, b, t):
+        s = f32(f32(1) - t)
+        return [f32(f32(x * s) + f32(y * t)) for x, y in zip(a, b)]
+
+    c = mix(mix(load(x0, y0), load(x1, y0), tx), mix(load(x0, y1), load(x1, y1), tx), ty)
+    return [min(max(x, f32(0)), f32(1)) for x in c]
+
+
+def _sample_albedo_f32(albedo, pix, w, h, weight, uv_scale, u, v, live=None):
     if weight <= 0.0:
         return [f32(a) for a in albedo]
     tiles = f32(max(1e-6, uv_scale))
-    tex = _bilinear_f32(pix, w, h, f32(f32(u) * tiles), f32(f32(v) * tiles))
+    if live is not None:
+        tex = _bilinear_live_f32(live.frame, live.flipU, live.flipV, f32(f32(u) * tiles), f32(f32(v) * tiles))
+    else:
+        tex = _bilinear_f32(pix, w, h, f32(f32(u) * tiles), f32(f32(v) * tiles))
     t = f32(min(max(weight, 0.0), 1.0))
     s = f32(f32(1) - t)
     o = [f32(f32(f32(a) * s) + f32(x * t)) for a, x in zip(albedo, tex)]
@@ -147,3 +175,39 @@ def test_flatten_shares_a_texture_between_materials_and_refuses_a_textured_check
     assert (f.materials[0].uv_scale, f.materials[1].texture_weight) == (2.0, 0.25)
     with pytest.raises(ValueError):
         bad = Scene(); bad.Add(Sphere(vec3(0, 0, -3), 1.0, Material(vec3(1, 0, 0), Kind=abi.MAT_CHECKER, DiffuseTexture=tex))); flatten(bad)
+
+
+def test_live_texture_known_answers_by_hand():
+    """A 2 x 2 BGR frame: blue / green over red / white (as bytes B, G, R).  The live branch reads r from byte 2, clamps the neighbour at
+    the last column / row instead of wrapping, and flips with 1 - u."""
+    frame = np.array([[[255, 0, 0], [0, 255, 0]], [[0, 0, 255], [255, 255, 255]]], np.uint8)          # (y, x, BGR)
+    tex = LiveTexture(frame)
+    m = Material(vec3(0, 0, 0), DiffuseTexture=tex, TextureWeight=1.0, UVScale=1.0)
+    out = _oracle_samples(m, [(0.0, 0.0), (0.5, 0.0), (0.0, 0.5), (0.5, 0.5), (1.0, 0.0), (-0.25, 0.0)])
+    assert out[0].tolist() == [0.0, 0.0, 1.0]                                  # texel (0, 0): B = 255 -> blue
+    assert out[1].tolist() == [0.0, 0.5, 0.5]                                  # half way to green
+    assert out[2].tolist() == [0.5, 0.0, 0.5]                                  # half way to red (the row below)
+    assert out[3].tolist() == [0.5, 0.5, 0.5]
+    assert out[4].tolist() == [0.0, 0.0, 1.0]                                  # Frac(1.0) = 0
+    assert out[5].tolist() == [0.0, 0.75, 0.25]                                # Frac(-0.25) = 0.75: three quarters of the way to green
+    flipped = LiveTexture(frame, flipU=True, flipV=True)
+    mf = Material(vec3(0, 0, 0), DiffuseTexture=flipped, TextureWeight=1.0, UVScale=1.0)
+    outf = _oracle_samples(mf, [(0.75, 1.0), (0.0, 0.0)])
+    assert outf[0].tolist() == [0.0, 0.25, 0.75]                               # 1 - 0.75 = 0.25 along x, 1 - 1 = 0 along y
+    assert outf[1].tolist() == [0.0, 0.0, 1.0]                                 # 1 - 0 = 1 -> Frac = 0 on both axes
+    f = flatten(_scene_with(m))
+    assert f.struct.n_textures == 1 and f.textures[0].frame_bytes_per_pixel == 3 and not f.textures[0].pixels
+
+
+@pytest.mark.parametrize("w,h,bpp,flips,weight,scale", [(7, 5, 3, (False, False), 1.0, 1.0), (16, 9, 4, (True, False), 0.4, 2.5), (1, 1, 3, (False, True), 1.0, 3.0),
+                                                       (2, 31, 4, (True, True), 0.999, 0.35)])
+def test_live_texture_against_an_independent_float32_restatement(w, h, bpp, flips, weight, scale):
+    rng = np.random.default_rng(w * 1000 + h * 10 + bpp)
+    tex = LiveTexture(rng.integers(0, 256, (h, w, bpp), dtype=np.uint8), flipU=flips[0], flipV=flips[1])
+    albedo = vec3(0.3, 0.6, 0.9)
+    m = Material(albedo, DiffuseTexture=tex, TextureWeight=weight, UVScale=scale)
+    uv = np.concatenate([rng.uniform(-3, 3, (300, 2)), rng.uniform(0, 1, (200, 2)), [[0, 0], [1, 1], [0.999999, 0.5], [1e-8, -1e-8], [4321.7, -765.4]]]).astype(np.float32)
+    got = _oracle_samples(m, uv)
+    for (u, v), g in zip(uv, got):
+        want = np.array(_sample_albedo_f32(albedo, None, w, h, weight, scale, u, v, live=tex), np.float32)
+        assert g.tobytes() == want.tobytes(), (u, v, g, want)

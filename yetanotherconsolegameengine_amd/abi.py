@@ -66,7 +66,8 @@ class Material(C.Structure):
 
 
 class Texture(C.Structure):
-    _fields_ = [("width", C.c_int32), ("height", C.c_int32), ("pixels", C.POINTER(C.c_uint32))]
+    _fields_ = [("width", C.c_int32), ("height", C.c_int32), ("pixels", C.POINTER(C.c_uint32)),
+                ("frame_bytes_per_pixel", C.c_int32), ("flip_u", C.c_int32), ("flip_v", C.c_int32), ("frame", C.POINTER(C.c_uint8))]
 
 
 class Prim(C.Structure):
@@ -174,6 +175,7 @@ _PROTOTYPES = {
     "ycge_scene_update_lights": (C.c_int, [C.c_void_p, C.POINTER(Light), C.c_int32, C.POINTER(Vec3), C.c_float,
                                            C.POINTER(Vec3), C.POINTER(Vec3)]),
     "ycge_scene_update_objects": (C.c_int, [C.c_void_p, C.POINTER(Prim), C.c_int32]),
+    "ycge_scene_update_texture": (C.c_int, [C.c_void_p, C.c_int32, C.c_void_p, C.c_size_t]),
     "ycge_resize": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.c_int32]),
     "ycge_set_camera": (C.c_int, [C.c_void_p, C.POINTER(C.c_float), C.c_float, C.c_float, C.c_float]),
     "ycge_render_frame": (C.c_int, [C.c_void_p, C.POINTER(C.c_float), C.POINTER(FrameStats)]),

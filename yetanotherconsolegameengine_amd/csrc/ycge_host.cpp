@@ -279,6 +279,7 @@ struct ycge_ctx {
     DevBuf<int32_t> d_lut;
     DevBuf<uint32_t> d_tex_pixels;             // textures of YCGE_MAT_TEXTURED materials
     DevBuf<int32_t> d_tex_info;
+    std::vector<int32_t> tex_info_host;        // {first word, width, height, flags} per texture (ycge_scene_update_texture)
     DevBuf<GLight> d_lights;
     BuiltTree scene_tree;                      // host copy of the scene BVH in the reference's format (ycge_read_accel)
     bool scene_tree_on_device = false;         // ... not fetched yet from the last device-side build (accel_view does it on demand)
@@ -746,7 +747,8 @@ int validate_scene(const ycge_scene *s, std::string &msg)
     if (s->n_textures < 0 || (s->n_textures > 0 && !s->textures)) return bad(YCGE_ERR_INVALID_ARG, "bad texture array");
     for (int i = 0; i < s->n_textures; i++) {
         const ycge_texture &t = s->textures[i];
-        if (t.width < 1 || t.height < 1 || !t.pixels) return bad(YCGE_ERR_INVALID_ARG, "texture %d: needs width, height >= 1 and pixels (%d x %d)", i, t.width, t.height);
+        if (t.frame_bytes_per_pixel != 0 && t.frame_bytes_per_pixel != 3 && t.frame_bytes_per_pixel != 4) return bad(YCGE_ERR_INVALID_ARG, "texture %d: frame_bytes_per_pixel %d (0 static, 3 BGR, 4 BGRA)", i, t.frame_bytes_per_pixel);
+        if (t.width < 1 || t.height < 1 || (!t.pixels && t.frame_bytes_per_pixel == 0)) return bad(YCGE_ERR_INVALID_ARG, "texture %d: needs width, height >= 1 and pixels (%d x %d)", i, t.width, t.height);
         if ((long long)t.width * t.height > (1ll << 28)) return bad(YCGE_ERR_UNSUPPORTED, "texture %d: above 2^28 pixels", i);
     }
     for (int mi = 0; mi < s->n_meshes; mi++) {
@@ -963,7 +965,7 @@ struct SceneArrays {
     std::vector<int32_t> lut;
     bool any_transparent = false, has_grid = false, any_textured = false;
     std::vector<uint32_t> tex_pixels;
-    std::vector<int32_t> tex_info;
+    std::vector<int32_t> tex_info;          // per texture {first word, width, height, 0 | live-frame flags}
     uint32_t tl_offset = 0;          // treelet region of the arena (append_treelets), 0 = none
 };
 
@@ -975,6 +977,7 @@ int install_scene(ycge_ctx *c, const SceneArrays &A, const ObjectsHost &oh, cons
     HIP_TRY(c, c->d_meshes.upload(A.gmeshes)); HIP_TRY(c, c->d_grids.upload(A.ggrids)); HIP_TRY(c, c->d_cells.upload(A.cells));
     HIP_TRY(c, c->d_lut.upload(A.lut));
     HIP_TRY(c, c->d_tex_pixels.upload(A.tex_pixels)); HIP_TRY(c, c->d_tex_info.upload(A.tex_info));
+    c->tex_info_host = A.tex_info;
     SceneDev &sd = c->sd;
     std::memset(&sd, 0, sizeof sd);
     sd.mesh_arena = c->d_mesh_arena.p;
@@ -1139,9 +1142,17 @@ int ycge_scene_upload(ycge_ctx *c, const ycge_scene *s)
     }
     for (int i = 0; i < s->n_textures; i++) {
         const ycge_texture &t = s->textures[i];
-        const int32_t info[4] = {(int32_t)A.tex_pixels.size(), t.width, t.height, 0};
+        // info.w: 0 = static (RGBA32 ints); else bytes per pixel of a live texture's frames | flipU << 4 | flipV << 5, the frame's bytes packed into words
+        const int bpp = t.frame_bytes_per_pixel;
+        const int32_t info[4] = {(int32_t)A.tex_pixels.size(), t.width, t.height, bpp ? (bpp | (t.flip_u ? 16 : 0) | (t.flip_v ? 32 : 0)) : 0};
         A.tex_info.insert(A.tex_info.end(), info, info + 4);
-        A.tex_pixels.insert(A.tex_pixels.end(), t.pixels, t.pixels + (size_t)t.width * t.height);
+        if (!bpp) A.tex_pixels.insert(A.tex_pixels.end(), t.pixels, t.pixels + (size_t)t.width * t.height);
+        else {
+            const size_t nbytes = (size_t)t.width * t.height * bpp, nwords = (nbytes + 3) / 4;
+            const size_t at = A.tex_pixels.size();
+            A.tex_pixels.resize(at + nwords, 0u);
+            if (t.frame) std::memcpy(A.tex_pixels.data() + at, t.frame, nbytes);
+        }
     }
     auto mat_ok = [&](int mi) { return mi >= 0 && mi < s->n_materials; };
 
@@ -1294,6 +1305,27 @@ int ycge_scene_update_lights(ycge_ctx *c, const ycge_light *lights, int32_t n_li
     if (bottom) { c->sd.bg_bottom[0] = bottom->x; c->sd.bg_bottom[1] = bottom->y; c->sd.bg_bottom[2] = bottom->z; }
     for (ycge_ctx *p : c->peers) {
         rc = ycge_scene_update_lights(p, lights, n_lights, ambient_color, ambient_intensity, top, bottom);
+        if (rc != YCGE_OK) { c->err = p->err; break; }
+    }
+    (void)hipSetDevice(c->device);
+    return rc;
+}
+
+// The next frame of a live texture (Renderer/Texture.cs:113-116: SampleBilinear reads IFrameReader.GetCurrentFramePtr())
+int ycge_scene_update_texture(ycge_ctx *c, int32_t texture_index, const uint8_t *frame, size_t bytes)
+{
+    if (!c) return YCGE_ERR_INVALID_ARG;
+    if (!c->have_scene) return c->fail(YCGE_ERR_NO_SCENE, "no scene uploaded");
+    if (texture_index < 0 || (size_t)texture_index * 4 + 3 >= c->tex_info_host.size()) return c->fail(YCGE_ERR_INVALID_ARG, "texture index %d out of range", texture_index);
+    const int32_t *info = c->tex_info_host.data() + (size_t)texture_index * 4;
+    const int bpp = info[3] & 15;
+    if (bpp == 0) return c->fail(YCGE_ERR_INVALID_ARG, "texture %d is static: upload the scene again to change it", texture_index);
+    if (!frame || bytes != (size_t)info[1] * info[2] * bpp) return c->fail(YCGE_ERR_INVALID_ARG, "texture %d: a frame is %d x %d x %d bytes", texture_index, info[1], info[2], bpp);
+    int rc = quiesce(c);
+    if (rc != YCGE_OK) return rc;
+    HIP_TRY(c, hipMemcpy(c->d_tex_pixels.p + info[0], frame, bytes, hipMemcpyHostToDevice));
+    for (ycge_ctx *p : c->peers) {
+        rc = ycge_scene_update_texture(p, texture_index, frame, bytes);
         if (rc != YCGE_OK) { c->err = p->err; break; }
     }
     (void)hipSetDevice(c->device);

@@ -209,12 +209,32 @@ __device__ __forceinline__ F3 sample_albedo(const SceneDev &S, F3 albedo, int te
     const int4 info = ((const int4 *)S.tex_info)[tex_index];
     const int w = info.y, hgt = info.z;
     u = u * tiles; v = v * tiles;
+    const float u_in = u, v_in = v;
     u = u - cs_floor(u);
     v = v - cs_floor(v);
     const float fx = u * (float)(w - 1), fy = v * (float)(hgt - 1);
     const int x0 = cs_f2i(cs_floor(fx)), y0 = cs_f2i(cs_floor(fy));
     F3 tex = f3(1.0f, 1.0f, 1.0f);
-    if (x0 >= 0 && x0 < w && y0 >= 0 && y0 < hgt) {        // (not finite: an exception in the reference; white here, as in the oracle)
+    if (info.w != 0) {
+        // a LIVE texture, Texture.cs:113-140: uu = flipU ? 1 - u : u; Frac; neighbours clamped at the last column / row; bytes B, G, R
+        // (LoadPixel, :173-182); two lerps per channel as a * (1 - t) + b * t; ONE Saturate at the end.  (u, v here are the tiled
+        // coordinates SampleAlbedo passes, before this function's own wrap: restored from the arguments.)
+        const int bpp = info.w & 15;
+        const float uu = (info.w & 16) ? 1.0f - u_in : u_in, vv = (info.w & 32) ? 1.0f - v_in : v_in;
+        const float dfx = frac(uu) * (float)(w - 1), dfy = frac(vv) * (float)(hgt - 1);
+        const int dx0 = cs_f2i(cs_floor(dfx)), dy0 = cs_f2i(cs_floor(dfy));
+        if (dx0 >= 0 && dx0 < w && dy0 >= 0 && dy0 < hgt) {
+            const int dx1 = (dx0 + 1) >= w ? (w - 1) : (dx0 + 1), dy1 = (dy0 + 1) >= hgt ? (hgt - 1) : (dy0 + 1);
+            const float dtx = dfx - (float)dx0, dty = dfy - (float)dy0;
+            const uint8_t *bytes = (const uint8_t *)(S.tex_pixels + info.x);
+            auto px3 = [&](int x, int y) { const uint8_t *q = bytes + ((size_t)y * w + x) * bpp; return f3((float)q[2] / 255.0f, (float)q[1] / 255.0f, (float)q[0] / 255.0f); };
+            const F3 c00 = px3(dx0, dy0), c10 = px3(dx1, dy0), c01 = px3(dx0, dy1), c11 = px3(dx1, dy1);
+            const float sx1 = 1.0f - dtx, sy1 = 1.0f - dty;
+            const F3 r0 = f3(c00.x * sx1 + c10.x * dtx, c00.y * sx1 + c10.y * dtx, c00.z * sx1 + c10.z * dtx);
+            const F3 r1 = f3(c01.x * sx1 + c11.x * dtx, c01.y * sx1 + c11.y * dtx, c01.z * sx1 + c11.z * dtx);
+            tex = saturate(f3(r0.x * sy1 + r1.x * dty, r0.y * sy1 + r1.y * dty, r0.z * sy1 + r1.z * dty));
+        }
+    } else if (x0 >= 0 && x0 < w && y0 >= 0 && y0 < hgt) {        // (not finite: an exception in the reference; white here, as in the oracle)
         const int x1 = (x0 + 1) % w, y1 = (y0 + 1) % hgt;
         const float tx = fx - (float)x0, ty = fy - (float)y0;
         const uint32_t *px = S.tex_pixels + info.x;

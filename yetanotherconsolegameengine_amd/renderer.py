@@ -91,6 +91,13 @@ class RaytraceRenderer:
             float(ambient.Intensity) if ambient is not None else 0.0,
             C.byref(top) if top is not None else None, C.byref(bot) if bot is not None else None))
 
+    def UpdateTexture(self, texture) -> None:
+        """The next frame of a live texture (LiveTexture.set_frame before this call): what IFrameReader.GetCurrentFramePtr() returns
+        while the coming frames are traced (Renderer/Texture.cs:116)."""
+        idx = next(i for i, t in enumerate(self.flat.texture_objects) if t is texture)
+        f = texture.frame
+        self._check(self.L.ycge_scene_update_texture(self.ctx, idx, f.ctypes.data_as(C.c_void_p), f.nbytes))
+
     def UpdateObjects(self, scene: Scene | FlatScene):
         """Scene.Update() -> RebuildBVH() after entities moved (Scene.cs:122-127): same materials, meshes and grids
         as the uploaded scene (in the same first-use order), new object records; only the scene BVH is rebuilt."""

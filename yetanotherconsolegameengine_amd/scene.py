@@ -46,6 +46,27 @@ class Texture:
         self.height, self.width = int(a.shape[0]), int(a.shape[1])
         a = a.astype(np.uint32)
         self.pixels = np.ascontiguousarray((a[..., 0] | (a[..., 1] << 8) | (a[..., 2] << 16) | (a[..., 3] << 24)).reshape(-1), dtype=np.uint32)
+        self.frame_bpp = 0
+
+
+class LiveTexture:
+    """`new Texture(IFrameReader reader, useRGBA, flipU, flipV)`, Renderer/Texture.cs:51-66: a texture whose pixels are the reader's
+    CURRENT frame (camera / video), BGR (3 bytes) or BGRA (4) per pixel, sampled by SampleBilinear's live branch (Texture.cs:113-140).
+    `frame` is an (h, w, 3 or 4) uint8 array in the reader's byte order (B, G, R[, A]); set_frame() swaps in the next one - the
+    renderer's UpdateTexture then hands it to the library (the host side of IFrameReader.GetCurrentFramePtr)."""
+
+    def __init__(self, frame, flipU: bool = False, flipV: bool = False):
+        self.flipU, self.flipV = bool(flipU), bool(flipV)
+        self.set_frame(frame)
+
+    def set_frame(self, frame):
+        a = np.ascontiguousarray(frame, dtype=np.uint8)
+        if a.ndim != 3 or a.shape[2] not in (3, 4) or a.shape[0] < 1 or a.shape[1] < 1:
+            raise ValueError("a frame must be (height, width, 3 or 4) uint8, bytes in B, G, R[, A] order")
+        if hasattr(self, "frame") and a.shape != self.frame.shape:
+            raise ValueError("a live texture keeps its size and format")
+        self.frame = a
+        self.height, self.width, self.frame_bpp = int(a.shape[0]), int(a.shape[1]), int(a.shape[2])
 
 
 @dataclass
@@ -355,10 +376,16 @@ class FlatScene:
         tex_structs = []
         for t in textures:
             ts = abi.Texture()
-            ts.width, ts.height, ts.pixels = t.width, t.height, t.pixels.ctypes.data_as(C.POINTER(C.c_uint32))
+            if getattr(t, "frame_bpp", 0):
+                ts.width, ts.height, ts.frame_bytes_per_pixel = t.width, t.height, t.frame_bpp
+                ts.flip_u, ts.flip_v = int(t.flipU), int(t.flipV)
+                ts.frame = t.frame.ctypes.data_as(C.POINTER(C.c_uint8))
+            else:
+                ts.width, ts.height, ts.pixels = t.width, t.height, t.pixels.ctypes.data_as(C.POINTER(C.c_uint32))
             self._keep.append(t)
             tex_structs.append(ts)
         self.textures = arr(abi.Texture, tex_structs)
+        self.texture_objects = textures          # index in ycge_scene.textures -> the Texture / LiveTexture it came from
 
         sc = abi.Scene()
         sc.materials, sc.n_materials = C.cast(self.materials, C.POINTER(abi.Material)), len(mat_structs)
