@@ -96,7 +96,7 @@ __device__ __forceinline__ void coop_walk(const SceneDev &S, uint32_t &cur, int 
 #if defined(YCGE_DBG_COOPSTAT)
     const unsigned long long dbg_t0 = __builtin_amdgcn_s_memrealtime();
     uint32_t dbg_iters = 0, dbg_node = 0, dbg_leaf = 0;
-    unsigned long long dbg_fetch = 0, dbg_c0 = __builtin_amdgcn_s_memtime(), dbg_tn = 0, dbg_tl = 0, dbg_tp = 0, dbg_m = 0; uint32_t dbg_nl = 0;
+    unsigned long long dbg_fetch = 0, dbg_c0 = __builtin_amdgcn_s_memtime();
 #endif
 
     for (;;) {
@@ -123,9 +123,6 @@ __device__ __forceinline__ void coop_walk(const SceneDev &S, uint32_t &cur, int 
         dbg_iters++; dbg_node += (uint32_t)__popcll(__ballot(at_node && gl == 0u)); dbg_leaf += (uint32_t)__popcll(__ballot(at_leaf && gl == 0u));
 #endif
 
-#if defined(YCGE_DBG_COOPSTAT)
-        dbg_m = __builtin_amdgcn_s_memtime();
-#endif
         // ------------------------------------------------------------------ node step
         if (__any(at_node)) {
             // slot: a = (min x, min y, min z, max x), b = (max y, max z, reference, valid) - MeshBVH.BoxHitFast, box_mesh()'s operations
@@ -170,9 +167,6 @@ __device__ __forceinline__ void coop_walk(const SceneDev &S, uint32_t &cur, int 
             if (at_node) c_cur = EX ? next : YCGE_REF_NONE_VALUE;
         }
 
-#if defined(YCGE_DBG_COOPSTAT)
-        { const unsigned long long t = __builtin_amdgcn_s_memtime(); dbg_tn += t - dbg_m; dbg_m = t; if (__any(at_leaf)) dbg_nl++; }
-#endif
         // ------------------------------------------------------------------ leaf step
         if (__any(at_leaf)) {
             // TriHit for the lane's two triangles, every operation as in tri_pair_hit; the closest side of the range test against the
@@ -232,9 +226,6 @@ __device__ __forceinline__ void coop_walk(const SceneDev &S, uint32_t &cur, int 
             }
         }
 
-#if defined(YCGE_DBG_COOPSTAT)
-        { const unsigned long long t = __builtin_amdgcn_s_memtime(); dbg_tl += t - dbg_m; dbg_m = t; }
-#endif
         // ------------------------------------------------------------------ back to the stack (the reference's re-test on pop: closest >= tNear)
         const bool popping = g_act && c_cur == YCGE_REF_NONE_VALUE;
         if (popping) {
@@ -253,17 +244,12 @@ __device__ __forceinline__ void coop_walk(const SceneDev &S, uint32_t &cur, int 
             }
         }
         if (__any(popping)) top = st.read_early(owner, c_sp - 1);       // (a step without push or pop left the top where it was: already asked for)
-#if defined(YCGE_DBG_COOPSTAT)
-        dbg_tp += __builtin_amdgcn_s_memtime() - dbg_m;
-#endif
     }
 #if defined(YCGE_DBG_COOPSTAT)
     if (lane == 0u && S.dbg_counters) {       // [16 + 8 i]: invocations, loop iterations, group node steps, group leaf steps, 100 MHz ticks, rays
         unsigned long long *dc = S.dbg_counters + 16 + (size_t)((blockIdx.x * 2654435761u) >> 24) * 8;
         atomicAdd(dc + 0, 1ull); atomicAdd(dc + 1, (unsigned long long)dbg_iters); atomicAdd(dc + 2, (unsigned long long)dbg_node);
         atomicAdd(dc + 3, (unsigned long long)dbg_leaf); atomicAdd(dc + 4, __builtin_amdgcn_s_memrealtime() - dbg_t0); atomicAdd(dc + 5, (unsigned long long)n_live); atomicAdd(dc + 6, dbg_fetch); atomicAdd(dc + 7, __builtin_amdgcn_s_memtime() - dbg_c0);
-        unsigned long long *de = S.dbg_counters + 16 + 8 * 256 + (size_t)((blockIdx.x * 2654435761u) >> 24) * 8;
-        atomicAdd(de + 0, dbg_tn); atomicAdd(de + 1, dbg_tl); atomicAdd(de + 2, dbg_tp); atomicAdd(de + 3, (unsigned long long)dbg_nl);
     }
 #endif
     __builtin_amdgcn_wave_barrier();

@@ -703,11 +703,7 @@ __device__ __forceinline__ void trace_block(const SceneDev &S, const FrameParams
     // (:452, :462) - and are written out right there (write_gbuffer): nine values less to carry through every later query.
     // (the pixel index goes through an empty asm at every use: otherwise the compiler computes the six 64-bit store addresses of a
     // pixel once, in the prologue, keeps them live through the whole kernel - and spills them)
-#if defined(YCGE_DBG_B)
-    auto pixel_index = [&]() { return (size_t)px + (size_t)py * P.hiW; };
-#else
     auto pixel_index = [&]() { int x = px, y = py; asm volatile("" : "+v"(x), "+v"(y)); return (size_t)x + (size_t)y * P.hiW; };
-#endif
     auto write_gbuffer = [&](F3 g_albedo, F3 g_normal, float g_depth, int g_prim, int g_sub, bool is_sky) {
         const size_t i = pixel_index();
         O.g_albedo[3 * i + 0] = g_albedo.x; O.g_albedo[3 * i + 1] = g_albedo.y; O.g_albedo[3 * i + 2] = g_albedo.z;
@@ -725,9 +721,6 @@ __device__ __forceinline__ void trace_block(const SceneDev &S, const FrameParams
     // (position, normal, albedo, direction to the eye: parked in LDS between the hit and the light / bounce code that reads them,
     // g_shade_ctx - twelve registers that would otherwise be live across every shadow query)
     const uint32_t ctx_addr = (uint32_t)(uintptr_t)g_shade_ctx + (uint32_t)lane * 48u;
-#if defined(YCGE_DBG_A)
-    F3 sh_p = f3(0, 0, 0), sh_n = f3(0, 0, 0), sh_alb = f3(0, 0, 0), sh_wo = f3(0, 0, 0);
-#endif
     int light = 0;
     float tr_r = 1.0f, tr_g = 1.0f, tr_b = 1.0f, sh_maxdist = 0.0f;
     int tr_counter = 0;
@@ -784,11 +777,9 @@ __device__ __forceinline__ void trace_block(const SceneDev &S, const FrameParams
         if (!FAN) wave_iters += wave_umax(w.steps - steps_before);
         if (phase == PH_DONE || parked) continue;
         const bool hit = hit_prim >= 0;
-#if !defined(YCGE_DBG_A)
         F3 sh_p, sh_n, sh_alb, sh_wo;
         if (phase != PH_PATH) shade_ctx_load(ctx_addr, sh_p, sh_n, sh_alb, sh_wo);      // a shadow query's answer: back to the hit it belongs to
         else { sh_p = sh_n = sh_alb = sh_wo = f3(0, 0, 0); }
-#endif
         int new_kind = 0;       // the next query: 1 = first shadow segment towards `light`, 2 = bounce, 0 = anything else
         bool fanned = false;
 
@@ -867,19 +858,14 @@ __device__ __forceinline__ void trace_block(const SceneDev &S, const FrameParams
                 } else {
                     if (S.ambient_intensity > 0.0f) {   // :571-576
                         float ai = S.ambient_intensity;
-#if !defined(YCGE_DBG_B)
-                        asm volatile("" : "+s"(ai));
-#endif
-                        // (evaluated here, per hit: hoisted out of the loop the three products sit in registers for the whole kernel)
+                        asm volatile("" : "+s"(ai));        // (evaluated here, per hit: hoisted out of the loop the three products sit in registers for the whole kernel)
                         F3 a = f3(S.ambient[0] * ai, S.ambient[1] * ai, S.ambient[2] * ai);
                         F3 amb = f3(a.x * base_albedo.x, a.y * base_albedo.y, a.z * base_albedo.z);
                         radiance = radiance + f3(beta.x * amb.x, beta.y * amb.y, beta.z * amb.z);
                     }
                     sh_p = h.p; sh_n = h.n; sh_alb = base_albedo;
                     sh_wo = normalized(q.d * -1.0f);
-#if !defined(YCGE_DBG_A)
                     shade_ctx_store(ctx_addr, sh_p, sh_n, sh_alb, sh_wo);
-#endif
                     light = 0;
                     go_lights = true;
                     if (FAN) {          // post this hit's independent queries: the expressions of the light loop head and the bounce below

@@ -757,11 +757,7 @@ struct StackT {
     {
         spill = (uint2 *)spill_base + (first_lane + blockIdx.x * BS + threadIdx.x);
         spill_stride = n_lanes;
-#if defined(YCGE_DBG_D)
-        lds_base = (uint32_t)(uintptr_t)(BS == 64 ? (void *)g_lds_stack64 : (void *)g_lds_stack) + threadIdx.x * 8u;
-#else
         lds_base = (uint32_t)(uintptr_t)(BS == 64 ? (void *)g_lds_stack64 : BS == 192 ? (void *)g_lds_stack192 : (void *)g_lds_stack) + threadIdx.x * 8u;
-#endif
         sp = 0;
     }
     __device__ __forceinline__ void reset() { sp = 0; }
