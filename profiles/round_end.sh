@@ -5,9 +5,9 @@ REPO=${GRAFT_REPO_ROOT:-/root/repo}; cd $REPO; mkdir -p gpurun_out
 TAG=${1:-r03}
 timeout 1800 python -m pytest tests -m gpu -q > gpurun_out/pytest_gpu_$TAG.log 2>&1; echo "pytest rc=$?"; tail -3 gpurun_out/pytest_gpu_$TAG.log
 timeout 600 python bench.py > gpurun_out/bench_$TAG.json 2> gpurun_out/bench_$TAG.err; echo "bench rc=$?"
-for c in 2 3 5; do timeout 400 python bench.py --config $c --cpu-seconds 10 2>> gpurun_out/bench_$TAG.err > gpurun_out/bench_${TAG}_cfg$c.json; done
+for c in 1 2 3 5; do timeout 400 python bench.py --config $c --cpu-seconds 10 2>> gpurun_out/bench_$TAG.err > gpurun_out/bench_${TAG}_cfg$c.json; done
 timeout 300 python bench.py --camera orbit --no-cpu-baseline > gpurun_out/bench_${TAG}_orbit.json 2>> gpurun_out/bench_$TAG.err
-for f in bench_$TAG bench_${TAG}_cfg2 bench_${TAG}_cfg3 bench_${TAG}_cfg5 bench_${TAG}_orbit; do python - <<PY
+for f in bench_$TAG bench_${TAG}_cfg1 bench_${TAG}_cfg2 bench_${TAG}_cfg3 bench_${TAG}_cfg5 bench_${TAG}_orbit; do python - <<PY
 import json
 try:
     d = json.load(open("gpurun_out/$f.json"))
@@ -18,3 +18,5 @@ PY
 done
 bash profiles/run_profiles.sh ${TAG}_c4 > gpurun_out/prof_${TAG}_c4.log 2>&1; echo "profiles c4 rc=$?"; head -12 gpurun_out/prof_${TAG}_c4/summary.txt
 bash profiles/run_profiles.sh ${TAG}_c5 --config 5 > gpurun_out/prof_${TAG}_c5.log 2>&1; echo "profiles c5 rc=$?"; head -12 gpurun_out/prof_${TAG}_c5/summary.txt
+for fan in "-" "YCGE_FAN=0"; do echo "== rank emulation $fan"; ( if [ "$fan" != "-" ]; then export "$fan"; fi; timeout 600 python profiles/rank_times.py 4 2>&1 | grep -E "world" ); done
+timeout 300 python profiles/mega_prof.py 4 2>&1 | grep -v amdgpu.ids > gpurun_out/mega_prof_$TAG.txt; grep -E "trace_ms|span|slot time|>= 256" gpurun_out/mega_prof_$TAG.txt

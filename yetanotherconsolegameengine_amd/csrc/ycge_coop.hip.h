@@ -26,9 +26,17 @@
 
 namespace ycge {
 
-#ifndef YCGE_COOP_RAYS
-#define YCGE_COOP_RAYS 4            // rays a wavefront walks cooperatively = groups of 16 lanes
+#ifndef YCGE_COOP_GROUP
+#define YCGE_COOP_GROUP 16          // lanes per ray: 16 (the three-level treelet, 14 box lanes) or 8 (its first two levels, 6 box lanes: twice the rays)
 #endif
+#define YCGE_COOP_LEVELS (YCGE_COOP_GROUP == 16 ? 3 : 2)
+#define YCGE_COOP_BOX_LANES (YCGE_COOP_GROUP == 16 ? 14u : 6u)
+#define YCGE_COOP_MASK ((1u << YCGE_COOP_BOX_LANES) - 1u)
+#ifndef YCGE_COOP_RAYS
+#define YCGE_COOP_RAYS (64 / YCGE_COOP_GROUP)      // rays a wavefront walks cooperatively = its groups; handed over when no more lanes than this still walk
+#endif
+static_assert(YCGE_COOP_GROUP == 16 || YCGE_COOP_GROUP == 8, "group size");
+static_assert(YCGE_COOP_RAYS * YCGE_COOP_GROUP <= 64, "every handed-over ray needs a group");
 // hand-over records, 16 words per ray, 4 rays per wavefront, up to 4 wavefronts per workgroup:
 // [0..2] o  [3..5] d  [6..8] 1/d  [9] tmin  [10] closest  [11] cur  [12] sp  [13] hit_sub  [14] hit flag  [15] owner thread / steps back
 static __shared__ __attribute__((aligned(16))) uint32_t g_coop_slots[4 * YCGE_COOP_RAYS * 16];
@@ -59,7 +67,7 @@ template <class STK>
 __device__ __forceinline__ void coop_walk(const SceneDev &S, uint32_t &cur, int mesh_prim, STK &st, F3 o, F3 inv, F3 d, float tmin, float &closest,
                                           int &hit_prim, int &hit_sub, Work &w, bool anyhit)
 {
-    const uint32_t lane = threadIdx.x & 63u, g = lane >> 4, gl = lane & 15u;
+    const uint32_t lane = threadIdx.x & 63u, g = lane / YCGE_COOP_GROUP, gl = lane % YCGE_COOP_GROUP;
     uint32_t *slots = g_coop_slots + (threadIdx.x >> 6) * (YCGE_COOP_RAYS * 16);
     const bool mine = cur != YCGE_REF_NONE_VALUE;
     const unsigned long long live = __ballot(mine);
@@ -88,7 +96,7 @@ __device__ __forceinline__ void coop_walk(const SceneDev &S, uint32_t &cur, int 
     const uint32_t owner = s[15];
     uint32_t c_steps = 0u;
     const bool sx = ix < 0.0f, sy = iy < 0.0f, sz = iz < 0.0f;
-    const uint32_t sh = g * 16u;
+    const uint32_t sh = g * YCGE_COOP_GROUP;
     // The entry a pop will take is asked for as soon as it is known (after the pushes of a node step, after a pop) and looked at
     // when the walk gets there: the LDS round trip is off the chain.  (LDS operations of a wavefront execute in order: a read
     // issued after the far children's writes sees them.)
@@ -106,7 +114,7 @@ __device__ __forceinline__ void coop_walk(const SceneDev &S, uint32_t &cur, int 
         const bool at_leaf = g_act && !at_node;
         const uint32_t unit = (c_cur & 0x1ffffff0u) >> 4;
         const uint32_t left = c_cur & 15u;                                    // triangles of the leaf
-        const bool node_lane = at_node && gl < (uint32_t)YCGE_TL_SLOTS;
+        const bool node_lane = at_node && gl < YCGE_COOP_BOX_LANES;
         const bool leaf_lane = at_leaf && gl < 8u && 2u * gl < left;          // (the record format allows leaves of up to 15 triangles = 8 records)
         const uint32_t off = node_lane ? S.tl_offset + unit * YCGE_TL_BYTES_PER_UNIT + gl * 32u : leaf_lane ? (unit + 3u * gl) * 32u : 0u;
         f32x4 a, b, c, e;
@@ -150,14 +158,15 @@ __device__ __forceinline__ void coop_walk(const SceneDev &S, uint32_t &cur, int 
             const bool reach2 = gl >= 2u && gl < 6u && ((V1 >> parent) & 1u);
             const bool vis2 = reach2 && near_me;
             const uint32_t V2 = (uint32_t)(__ballot(vis2 && internal) >> sh);
-            const bool reach3 = gl >= 6u && gl < (uint32_t)YCGE_TL_SLOTS && ((V2 >> parent) & 1u);
+            const bool reach3 = YCGE_COOP_LEVELS == 3 && gl >= 6u && gl < (uint32_t)YCGE_TL_SLOTS && ((V2 >> parent) & 1u);
             const bool vis3 = reach3 && near_me;
             const bool reached = gl < 2u || reach2 || reach3;
             // the far children, stacked by their own lanes: heap order is level order and a level stacks at most one, so a lane's
             // place is the number of stacking slots below it - the reference's push order
-            const uint32_t PUSH = (uint32_t)(__ballot(at_node && reached && far_me) >> sh) & 0x3fffu;
-            // the walk goes on at the one visited slot that is a leaf or sits on the third level; none: both children missed somewhere -> the stack
-            const uint32_t EX = (uint32_t)(__ballot(at_node && ((vis1 || vis2) && !internal || vis3)) >> sh) & 0x3fffu;
+            const uint32_t PUSH = (uint32_t)(__ballot(at_node && reached && far_me) >> sh) & YCGE_COOP_MASK;
+            // the walk goes on at the one visited slot that is a leaf or sits on the last level; none: both children missed somewhere -> the stack
+            const bool last_level = YCGE_COOP_LEVELS == 3 ? vis3 : vis2;
+            const uint32_t EX = (uint32_t)(__ballot(at_node && ((vis1 || vis2) && !internal || last_level)) >> sh) & YCGE_COOP_MASK;
             if (at_node) {
                 if (reached && far_me) st.write_at(owner, c_sp + (int)__builtin_popcount(PUSH & ((1u << gl) - 1u)), ref, tn);
                 c_sp += (int)__builtin_popcount(PUSH);
