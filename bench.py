@@ -289,11 +289,16 @@ def main():
                 "frac": round(ach / HBM_PEAK_GBS, 5), "traffic": None,
                 "achieved_is": "algorithmic bytes of the REFERENCE's traversal (SURVEY 8d counters) / launch time - mostly cache hits, NOT memory traffic",
                 "algorithmic_bytes_per_launch": int(my_alg), "mean_launch_ms": round(mean_trace_ms, 4)}
-        if timed_lane_steps is not None:
+        if timed_lane_steps is not None and args.config != 5:
             tb = STEP_FETCH_BYTES * timed_lane_steps + 118 * pixels
             roof["timed_work"] = {"lane_steps_per_launch": round(timed_lane_steps, 1), "bytes_per_launch": int(tb),
                                   "achieved_gbs": round(tb / (mean_trace_ms * 1e-3) / 1e9, 2), "frac": round(tb / (mean_trace_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 5),
-                                  "what": f"what the TIMED kernels walked: {STEP_FETCH_BYTES} B fetched per lane step (node / triangle-pair record; a voxel cell step reads 1 B) + 118 B per pixel"}
+                                  "what": f"what the TIMED kernels walked: {STEP_FETCH_BYTES} B fetched per lane step (node / triangle-pair record; a cooperative step - a treelet or a whole leaf - counts as one) + 118 B per pixel"}
+        elif timed_lane_steps is not None:
+            # a voxel world's lane steps mix tree steps (a 64-byte record each) and cell steps (one byte, mostly arithmetic): no byte figure is honest
+            roof["timed_work"] = {"lane_steps_per_launch": round(timed_lane_steps, 1), "bytes_per_launch": None,
+                                  "what": "tree steps and voxel cell steps of the TIMED kernels, summed; the algorithmic figure above prices the REFERENCE's walk - every grid entered, every shadow ray traced - "
+                                          "which the timed kernels do not make (solid-voxel cull, no ray towards a dark light): use the counter figures"}
         pmc, stale = load_pmc(args.config, build_hash) if (world == 1 and n_dev == 1) else (None, False)
         if pmc:
             # counters of the same kernels, same build, from the committed PMC passes; the rate uses THIS run's launch time
