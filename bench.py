@@ -215,8 +215,9 @@ def main():
         if multi:
             s_trace.synchronize(); s_comm.synchronize()
             dist.barrier()
-        for d in range(n_dev):
-            torch.cuda.synchronize(d)
+        if n_dev > 1:           # one process, several devices: drain them all (a rank of the RCCL form only ever touches its own device)
+            for d in range(n_dev):
+                torch.cuda.synchronize(d)
         torch.cuda.synchronize()
 
     moving = args.camera == "orbit"
