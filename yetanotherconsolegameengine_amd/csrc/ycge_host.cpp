@@ -582,7 +582,10 @@ static int create_one(const ycge_config *cfg, ycge_ctx *parent, ycge_ctx **out)
         // wavefronts per SIMD (0.590 -> 0.569 ms; 400+ blocks or 3 wavefronts per SIMD lose what the shorter chains gain).
         // Round 3: with the cooperative walk (ycge_coop.hip.h) a block's tail is short enough that on a WHOLE frame the helper wavefronts
         // cost the bulk more than the shorter chains gain (config 4: 0.514 ms without fan-out, 0.547 with the 200 blocks): off there.
-        const uint32_t fan_default = c->cfg.world_size >= 4 ? 4u : c->cfg.world_size >= 2 ? 5u : 0u;
+        // The same holds on a rank's tiles once the heavy classes are split (trace_frame's default policy): per-rank trace on config 4
+        // at 8 ranks 0.359 ms with fan-out + the round-2 split, 0.289 ms with the round-3 split alone; at 4 ranks 0.381 -> 0.351; at 2
+        // ranks 0.485 -> 0.441 (profiles/r03/f_rank_emulation.txt).  k_trace_fan stays behind YCGE_FAN, parity-tested.
+        const uint32_t fan_default = 0u;
         c->fan_class = c->knobs.fan_class >= 0 ? (uint32_t)c->knobs.fan_class : fan_default;
         if (hipHostMalloc((void **)&c->h_n_fan, sizeof(uint32_t), hipHostMallocDefault) != hipSuccess) { c->err = "hipHostMalloc failed"; return bail(YCGE_ERR_DEVICE); }
         *c->h_n_fan = 0;
@@ -1578,11 +1581,15 @@ int trace_frame(ycge_ctx *c, float *d_slab, hipStream_t stream, FrameState &fs, 
         } else
             e = ycge_launch_trace(&c->sd, &P, &O, c->cfg.count_work, flat, refill_steps, stream);
         if (e == 0 && lpt) {
-            // octal: digit c = log2(parts) a block of class c is split into.  Default: none (a split costs more slots than it saves,
-            // DESIGN section 5) except from 8 ranks up, where the classes >= 384 iterations go in 4 parts of 16 pixels: slots are plentiful
-            // on an eighth of a frame, thin wavefronts step faster and see a smaller maximum over their lanes (per-rank trace on config 4:
-            // 0.393 -> 0.366 ms at 8 ranks; at 4 ranks the same split loses, 0.407 -> 0.461 ms)
-            const uint32_t policy = c->knobs.split_set ? c->knobs.split_policy : c->cfg.world_size >= 8 ? 022200000u : 0u;
+            // octal: digit c = log2(parts) a block of class c (policy_class_of_order_class) is split into, class 7 leftmost.  A whole
+            // frame splits by rank instead (split_top below: a per-class split costs more slots than it saves there).
+            // On a rank's tiles slots are plentiful, thin wavefronts step faster and see a smaller maximum over their lanes, so the
+            // heavier classes are split, deeper the fewer blocks a rank holds.  Per-rank trace on config 4, maximum over ranks
+            // (profiles/rank_times.py): 8 ranks 0.359 -> 0.289 ms, 4 ranks 0.381 -> 0.351, 2 ranks 0.485 -> 0.441; one class deeper
+            // loses at every rank count (8 ranks 55543000: 0.356; 4 ranks 44432000: 0.420; 2 ranks 44320000: 0.471).
+            const uint32_t world_policy = c->cfg.world_size >= 8 ? 044433000u : c->cfg.world_size >= 4 ? 044320000u
+                                        : c->cfg.world_size >= 2 ? 033220000u : 0u;
+            const uint32_t policy = c->knobs.split_set ? c->knobs.split_policy : world_policy;
             // the next frame's schedule needs this frame's trace and nothing else: built on the side stream, beside TAA (or the slab
             // pack and all-gather), instead of 25 us in front of it; the next trace waits for it (order_ev)
             HIP_TRY(c, hipEventRecord(c->traced_ev, stream));
