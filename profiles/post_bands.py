@@ -27,10 +27,46 @@ rec = buf[:nb * 32].reshape(nb, 32)
 tl = buf[nb * 32:].reshape(2, 1000, 4)
 t = rec[:, 4:8].copy().view(np.uint64).reshape(nb, 2).astype(np.float64) * 0.01     # us
 passes = rec[:, 8].astype(np.float64)
-t0 = t[:, 0].min()
+ran_ = rec[:, 8] > 0
+t0 = t[ran_, 0].min()
 dur = t[:, 1] - t[:, 0]
-print(f"launch span {t[:, 1].max() - t0:.1f} us; band 0: {dur[0]:.1f} us for {passes[0]:.0f} passes = {dur[0] / passes[0]:.3f} us per pass")
+print(f"launch span {t[ran_, 1].max() - t0:.1f} us over the {int(ran_.sum())} bands that ran passes; band 0: {dur[0]:.1f} us for {passes[0]:.0f} passes = {dur[0] / passes[0]:.3f} us per pass")
 print("per pass (own duration / passes), bands 0, 1, 2, 10, 60, last:", [round(dur[b] / passes[b], 3) for b in (0, 1, 2, 10, 60, nb - 1)])
+# the two-set form records when a band's first level was allowed: skew between chain neighbours and the pace once running
+tf = rec[:, 18:20].copy().view(np.uint64).ravel().astype(np.float64) * 0.01
+if (tf[ran_] > 0).all() and nb > 8:
+    chunks = (nb - 2) // 2
+    for name, lo in (("even", 1), ("odd", 1 + chunks)):
+        idx = np.arange(lo, lo + chunks)
+        idx = idx[ran_[idx]]
+        sk = np.diff(tf[idx])
+        pace = (t[idx, 1] - tf[idx]) / passes[idx]
+        print(f"{name} chain: {len(idx)} bands; first-level skew between neighbours median {np.median(sk):.2f} us (p10 {np.percentile(sk, 10):.2f}, p90 {np.percentile(sk, 90):.2f}); "
+              f"pace once running: median {np.median(pace):.3f} us per pass (p10 {np.percentile(pace, 10):.3f}, p90 {np.percentile(pace, 90):.3f}); passes per band median {np.median(passes[idx]):.0f}")
+pf = rec[:, 20:30].copy().view(np.uint64).reshape(nb, 5).astype(np.float64)        # profiling instantiation: set 0's shader clocks
+if pf.sum() > 0:
+    per = pf / np.maximum(passes, 1)[:, None] * 2.0      # set 0 computes every second pass and fetches in the others: x2 = per pass of its kind
+    sel = ran_ & (passes > 100)
+    names = ("head wait (vmcnt 0)", "compute incl. barrier", "wait for the band above", "fetch issue", "idle at the barrier after fetching")
+    print("set 0, shader clocks per pass of that kind, median over bands that ran (band 0 in brackets):")
+    for k, nm in enumerate(names):
+        print(f"   {nm:36s} {np.median(per[sel, k]):8.0f}   [{per[0, k]:8.0f}]")
+    tot = per[sel].sum(axis=1)
+    print(f"   compute-kind pass = head + compute: {np.median(per[sel, 0] + per[sel, 1]):.0f}; fetch-kind pass = wait + fetch + idle: {np.median(per[sel, 2] + per[sel, 3] + per[sel, 4]):.0f}")
+hw = rec[:, 9]
+ran = passes > 0
+place = ((hw >> 28) & 15) * 1000 + ((hw >> 13) & 7) * 100 + ((hw >> 12) & 1) * 50 + ((hw >> 8) & 15)      # xcc, se, sh, cu
+cnt = np.bincount(np.unique(place[ran], return_inverse=True)[1])
+print(f"bands that ran passes: {int(ran.sum())} on {len(cnt)} distinct CUs; CUs holding 1/2/3/4+ bands: {[int((cnt == k).sum()) for k in (1, 2, 3)] + [int((cnt >= 4).sum())]}")
+# co-residency proper: for every band, how many other bands on its CU overlap it in time for more than half its own duration
+ov = np.zeros(nb, int)
+for b in np.nonzero(ran)[0]:
+    same = np.nonzero(ran & (place == place[b]))[0]
+    for o_ in same:
+        if o_ != b and min(t[b, 1], t[o_, 1]) - max(t[b, 0], t[o_, 0]) > 0.5 * dur[b]:
+            ov[b] += 1
+print("bands by number of co-resident bands (overlapping > half their life) 0/1/2:", [int((ov[ran] == k).sum()) for k in (0, 1, 2)])
+print("per XCC:", np.bincount(((hw >> 28) & 15)[ran], minlength=8).tolist())
 end_lag = np.diff(t[:, 1])
 print(f"end(b) - end(b-1): mean {end_lag.mean():.2f} us, median {np.median(end_lag):.2f}, max {end_lag.max():.2f}")
 beg_lag = np.diff(t[:, 0])
@@ -53,6 +89,8 @@ PB = int(os.environ.get('YCGE_POST_PROBE_BAND', '0'))
 for k in (0, 1):
     tt = (tl[k, :, 0].astype(np.uint64) | (tl[k, :, 1].astype(np.uint64) << np.uint64(32))).astype(np.float64) * 0.01
     n = int((tt > 0).sum())
+    if n < 3:
+        continue
     dt = np.diff(tt[:n])
     sp = tl[k, :n, 2]
     gaps = [(round(float(tt[j] - t0), 0), round(float(dt[j]), 1)) for j in range(n - 1) if dt[j] > 5]

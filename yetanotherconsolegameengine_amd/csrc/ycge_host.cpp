@@ -38,6 +38,7 @@ int ycge_launch_taa(const ycge::TaaParams *T, const float *current, const float 
                     float *hist, float *prev_normal, float *prev_depth, uint8_t *prev_sky, hipStream_t stream);
 size_t ycge_post_state_bytes(void);
 int ycge_atrous_persist_resident(int groups_per_pass, int split, int level_handover, int profile);
+void ycge_atrous_duo_pad_lds(int bytes);
 int ycge_launch_unit_normals(const float *normal, float *unit, size_t n, hipStream_t stream);
 int ycge_launch_atrous(int w, int h, int step, const float phi[4], const float *cur, float *dst, const float *albedo, const float *unit_n,
                        const float *depth, const uint8_t *sky, hipStream_t stream);
@@ -119,6 +120,8 @@ struct Knobs {
     bool post_no_split = false;      // YCGE_POST_NO_SPLIT: whole bands in the persistent in-place A-trous (no row-parity half-bands)
     int post_probe_band = -1;        // YCGE_POST_PROBE_BAND: this band and the next record a per-pass timeline (profiles/post_bands.py)
     int post_assume_resident = 0;    // YCGE_POST_ASSUME_RESIDENT (tests): take this for the runtime's answer - more bands than fit, to exercise the order-of-arrival numbering
+    bool post_dbg_free = false;      // YCGE_POST_DBG_FREE (timing experiment, WRONG pixels): no band of the persistent in-place A-trous waits for the band above
+    int post_pad_lds = 0;            // YCGE_POST_PAD_LDS (experiment): bytes of unused LDS per band workgroup of the two-set form - fewer of them on a CU
     int post_resident_per_cu = 3;    // YCGE_POST_RESIDENT: band workgroups of the persistent in-place A-trous a CU may hold (3 fit: 576 threads, 46 KB of LDS each)
     bool post_hash = false;          // YCGE_POST_HASH_FORM=1: the hash form of k_atrous_band even where the window fits
     int bvh_waves = 16;              // YCGE_BVH_WAVES: wavefronts of k_scene_bvh_build that take nodes (tests: the order nodes are split in must not matter)
@@ -151,6 +154,8 @@ struct Knobs {
         post_resident_per_cu = geti("YCGE_POST_RESIDENT", 3);
         post_assume_resident = geti("YCGE_POST_ASSUME_RESIDENT", 0);
         if (post_resident_per_cu < 1 || post_resident_per_cu > 3) post_resident_per_cu = 3;
+        post_pad_lds = geti("YCGE_POST_PAD_LDS", 0);
+        post_dbg_free = geti("YCGE_POST_DBG_FREE", 0) != 0;
         exposure_serial = getenv("YCGE_EXPOSURE_SERIAL") != nullptr;
         no_coop = getenv("YCGE_NO_COOP") != nullptr;
         scene_bvh_host = getenv("YCGE_SCENE_BVH_HOST") != nullptr;
@@ -1814,6 +1819,7 @@ uint32_t band_window_width(const std::vector<uint32_t> &band_pixels, const std::
 int post_resident_per_cu(ycge_ctx *c, bool split)
 {
     int &q = c->post_resident_seen[split ? 1 : 0];
+    ycge_atrous_duo_pad_lds(c->knobs.post_pad_lds);
     if (q < 0) q = ycge_atrous_persist_resident(c->knobs.post_groups, split ? 1 : 0, c->knobs.post_mode == 4 ? 0 : 1, c->knobs.post_probe_band >= 0 ? 1 : 0);
     if (c->knobs.post_assume_resident > 0) return c->knobs.post_assume_resident;
     return q < c->knobs.post_resident_per_cu ? q : c->knobs.post_resident_per_cu;
@@ -1872,7 +1878,7 @@ int run_post(ycge_ctx *c, hipStream_t stream, float *out_sdr_host, bool timed)
                 int split_bands = 0;
                 if ((c->knobs.post_mode == 0 || c->knobs.post_mode == 3) && !c->knobs.post_no_split && !c->knobs.post_hash && c->knobs.post_groups == 16 && rows_per_band == 8 &&
                     split_band_layout(h, step, row_band, desc, split_bands) && c->compute_units > 0 &&
-                    ((split_bands + 7) / 8) * 8 <= post_resident_per_cu(c, true) * c->compute_units) {
+                    (c->knobs.post_pad_lds > 0 || ((split_bands + 7) / 8) * 8 <= post_resident_per_cu(c, true) * c->compute_units)) {
                     sc->split = true;
                     sc->bands = split_bands;
                     band_inplace_schedule(w, h, rows_per_band, px, off, bpx, boff, sc->bands, sc->max_level_pixels, (uint32_t)c->knobs.post_groups, &row_band);
@@ -1933,9 +1939,10 @@ int run_post(ycge_ctx *c, hipStream_t stream, float *out_sdr_host, bool timed)
                     c->post_epoch = 0;
                     c->post_ticket = 0;
                 }
+                ycge_atrous_duo_pad_lds(c->knobs.post_pad_lds);
                 e = ycge_launch_atrous_persist(w, h, step, phi, dst, c->sky.p, c->atrous_statw.p, sc->pixels.p, sc->offsets.p, sc->pass_level.p, sc->split ? sc->band_desc.p : nullptr, sc->levels, sc->bands,
                                                levels_per_launch, c->knobs.post_groups, sc->rows_per_band, sc->window_width, c->post_progress.p, c->post_epoch,
-                                               xcd_local, c->knobs.post_mode == 4 ? 0 : 1, c->knobs.post_probe_band >= 0 ? 1 : 0, c->post_ticket, stream);
+                                               xcd_local | (c->knobs.post_dbg_free ? 2 : 0), c->knobs.post_mode == 4 ? 0 : 1, c->knobs.post_probe_band >= 0 ? 1 : 0, c->post_ticket, stream);
                 if (!xcd_local && c->knobs.post_mode != 4) c->post_ticket += (uint32_t)sc->bands;      // one number per workgroup of the launch
                 c->post_epoch += (groups > (uint32_t)sc->levels ? groups : (uint32_t)sc->levels) + 1u;
             } else

@@ -469,7 +469,8 @@ __global__ __launch_bounds__(32 * G + 64) void k_atrous_stream(const AtrousParam
 {
     __shared__ __attribute__((aligned(16))) PostSharedT<G> sh;
     int b = (int)blockIdx.x;
-    if (xcd_local) { const int per_xcd = (n_bands + 7) / 8; b = ((int)blockIdx.x % 8) * per_xcd + (int)blockIdx.x / 8; }
+    const bool dbg_free = (xcd_local & 2) != 0;         // timing experiment (YCGE_POST_DBG_FREE, wrong pixels): no band waits for the band above
+    if (xcd_local & 1) { const int per_xcd = (n_bands + 7) / 8; b = ((int)blockIdx.x % 8) * per_xcd + (int)blockIdx.x / 8; }
     else {
         // Bands in order of ARRIVAL, not by block index: a band only ever waits for bands of lower numbers, and with a drawn number
         // all of those have started - whatever order the dispatcher places workgroups in, and however many of them fit the chip at
@@ -492,7 +493,7 @@ __global__ __launch_bounds__(32 * G + 64) void k_atrous_stream(const AtrousParam
     const BandWindow W = {y0, rows, wx, 1u, stride == 2 ? 1 : 0};
     const uint32_t n_ent = (uint32_t)rows * wx;
     uint32_t *mine = progress + (size_t)b * 32;
-    const bool has_up = up0 >= 0;
+    const bool has_up = up0 >= 0 && !dbg_free;
     const uint32_t *above = progress + (size_t)(has_up ? up0 : 0) * 32, *above2 = progress + (size_t)(up1 >= 0 ? up1 : has_up ? up0 : 0) * 32;
     // how far the band(s) above are, as seen by one (device-coherent) look: the smaller of the two words
     auto look_up = [&]() -> int {
@@ -590,6 +591,9 @@ __global__ __launch_bounds__(32 * G + 64) void k_atrous_stream(const AtrousParam
         if (lane == 0) __hip_atomic_store(mine, epoch + (uint32_t)levels, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         if (lane == 0) {        // profiling aid (profiles/post_bands.py): when this band began and ended (100 MHz), how many passes it ran
             ((unsigned long long *)(mine + 4))[0] = t_begin; ((unsigned long long *)(mine + 4))[1] = __builtin_amdgcn_s_memrealtime(); mine[8] = end - first;
+            uint32_t hw_id;         // where the band ran: cu_id [11:8], sh_id [12], se_id [15:13] (+ the XCC id in [31:28])
+            asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw_id));
+            mine[9] = (hw_id & 0x0fffffffu) | my_xcc << 28;
         }
         return;
     }
@@ -620,18 +624,24 @@ __global__ __launch_bounds__(32 * G + 64) void k_atrous_stream(const AtrousParam
         uint32_t w0 = epoch, w1 = epoch;
         if (set == 0) {
             wait_above(lcur);
+            if (threadIdx.x == 0) ((unsigned long long *)(mine + 18))[0] = __builtin_amdgcn_s_memrealtime();      // (profiles/post_bands.py: the band's first level may be fetched)
             D = pass_fetch<true>(A, W, buf, statw, sky, pcur, t, scur);
             p_new = entry(first + 4); l_new = level_of(first + 4); s_new = sky_of(pnxt);
             if (has_up) asm volatile("global_load_dword %0, %2, %3 sc1\n\tglobal_load_dword %1, %2, %4 sc1" : "=&v"(w0), "=&v"(w1) : "v"(0u), "s"(above), "s"(above2) : "memory");
         }
         lds_barrier();              // table cleared
+        // profiling instantiation (profiles/post_bands.py): where set 0's shader clocks go - the head of a computing pass (its wait for
+        // what it fetched), the pass itself up to its barrier, the fetch phase's wait for the band above, the fetch, its idle time at the barrier
+        unsigned long long pf_head = 0, pf_comp = 0, pf_wait = 0, pf_fetch = 0, pf_bar = 0, pf_t0 = 0, pf_t1 = 0;
         for (uint32_t i = first; i < end; i++) {
             if (((i - first) & 1u) == (uint32_t)set) {
+                if (PROF) { pf_t0 = __builtin_amdgcn_s_memtime(); asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); pf_t1 = __builtin_amdgcn_s_memtime(); pf_head += pf_t1 - pf_t0; }
                 // The words of the band(s) above, for the next fetch's decision: asked for here, looked at after the pass.  By hand:
                 // written as look_up() the compiler put the subtraction and the minimum - and with them a wait for these two
                 // device-coherent loads AND for the three list loads above - in FRONT of the pass, a round trip to memory in every
                 // level's chain.  (The compiler's own waits stay right: loads return in order, these are the newest.)
                 pass_compute<true>(A, pcur, D, sh, &sh.out_slot[set][gl]);       // ends with the workgroup's barrier
+                if (PROF) pf_comp += __builtin_amdgcn_s_memtime() - pf_t1;
                 if (has_up) {
                     asm volatile("s_waitcnt vmcnt(0)" : "+v"(w0), "+v"(w1) : : "memory");
                     const int s0 = (int32_t)(w0 - epoch), s1 = (int32_t)(w1 - epoch);
@@ -640,14 +650,25 @@ __global__ __launch_bounds__(32 * G + 64) void k_atrous_stream(const AtrousParam
                 }
                 pcur = pnxt; scur = s_new; lcur = lnxt; pnxt = p_new; lnxt = l_new;
             } else {
+                if (PROF) pf_t0 = __builtin_amdgcn_s_memtime();
                 if (i + 1 < end) {
                     wait_above(lcur);
+                    if (PROF) { pf_t1 = __builtin_amdgcn_s_memtime(); pf_wait += pf_t1 - pf_t0; }
                     D = pass_fetch<true>(A, W, buf, statw, sky, pcur, t, scur);
                     p_new = entry(i + 5); l_new = level_of(i + 5); s_new = sky_of(pnxt);
+                    // (issued LAST in the phase: ahead of the wait for the band above - a whole phase earlier, so that the computing pass's
+                    // first wait would not include this cross-XCD round trip - the word is a phase staler, the wait spins on fresh looks
+                    // 1 250 instead of 740 shader clocks a pass and every configuration loses 10 %: measured in round 3, profiles/r03)
                     if (has_up) asm volatile("global_load_dword %0, %2, %3 sc1\n\tglobal_load_dword %1, %2, %4 sc1" : "=&v"(w0), "=&v"(w1) : "v"(0u), "s"(above), "s"(above2) : "memory");
+                    if (PROF) { pf_t0 = __builtin_amdgcn_s_memtime(); pf_fetch += pf_t0 - pf_t1; }
                 }
                 lds_barrier();
+                if (PROF) pf_bar += __builtin_amdgcn_s_memtime() - pf_t0;
             }
+        }
+        if (PROF && threadIdx.x == 0) {
+            unsigned long long *rec = (unsigned long long *)(mine + 20);
+            rec[0] = pf_head; rec[1] = pf_comp; rec[2] = pf_wait; rec[3] = pf_fetch; rec[4] = pf_bar;
         }
         return;
     }
@@ -1196,16 +1217,21 @@ int ycge_launch_atrous_inplace(int w, int h, int step, const float phi[4], float
 
 // the same iteration as ONE persistent launch (k_atrous_persist).  progress: n_bands x 32 words, zero before the first use; epoch: a
 // value that grows by more than the group count from call to call (the host's running sum)
+// Unused dynamic LDS of the two-set instantiation: the only way to tell the dispatcher "at most N band workgroups on a CU"
+static int g_duo_pad_lds = 0;
+void ycge_atrous_duo_pad_lds(int bytes) { g_duo_pad_lds = bytes > 0 ? bytes : 0; }
+
 int ycge_launch_atrous_persist(int w, int h, int step, const float phi[4], float *buf, const uint8_t *sky, float *statw, const uint32_t *d_pixels,
                                const uint32_t *d_offsets, const uint32_t *d_pass_level, const int32_t *d_band_desc, int n_levels, int n_bands, int K, int groups_per_pass, int rows_per_band, unsigned window_width,
                                uint32_t *progress, uint32_t epoch, int xcd_local, int level_handover, int profile, uint32_t ticket_base, hipStream_t stream)
 {
     ycge::AtrousParams A = {w, h, step, phi[0], phi[1], phi[2], phi[3]};
     const int per_xcd = (n_bands + 7) / 8;
-    const dim3 grid((unsigned)(xcd_local ? 8 * per_xcd : n_bands));
+    const dim3 grid((unsigned)((xcd_local & 1) ? 8 * per_xcd : n_bands));
     if (level_handover) {       // 8 or 16 pixels a pass: the publishing wavefront is the workgroup's 5th or 9th
         if (groups_per_pass == 8) hipLaunchKernelGGL((ycge::k_atrous_stream<8, false>), grid, dim3(256 + 64), 0, stream, A, buf, statw, sky, d_pixels, d_offsets, d_pass_level, d_band_desc, n_levels, n_bands, rows_per_band, window_width, progress, epoch, xcd_local, ticket_base);
-        else if (groups_per_pass == 16 && d_band_desc && !profile) hipLaunchKernelGGL((ycge::k_atrous_stream<16, false, true>), grid, dim3(512 + 64), 0, stream, A, buf, statw, sky, d_pixels, d_offsets, d_pass_level, d_band_desc, n_levels, n_bands, rows_per_band, window_width, progress, epoch, xcd_local, ticket_base);
+        else if (groups_per_pass == 16 && d_band_desc && !profile) hipLaunchKernelGGL((ycge::k_atrous_stream<16, false, true>), grid, dim3(512 + 64), (size_t)g_duo_pad_lds, stream, A, buf, statw, sky, d_pixels, d_offsets, d_pass_level, d_band_desc, n_levels, n_bands, rows_per_band, window_width, progress, epoch, xcd_local, ticket_base);
+        else if (groups_per_pass == 16 && d_band_desc) hipLaunchKernelGGL((ycge::k_atrous_stream<16, true, true>), grid, dim3(512 + 64), (size_t)g_duo_pad_lds, stream, A, buf, statw, sky, d_pixels, d_offsets, d_pass_level, d_band_desc, n_levels, n_bands, rows_per_band, window_width, progress, epoch, xcd_local, ticket_base);
         else if (groups_per_pass == 16 && !profile) hipLaunchKernelGGL((ycge::k_atrous_stream<16, false>), grid, dim3(512 + 64), 0, stream, A, buf, statw, sky, d_pixels, d_offsets, d_pass_level, d_band_desc, n_levels, n_bands, rows_per_band, window_width, progress, epoch, xcd_local, ticket_base);
         else if (groups_per_pass == 16) hipLaunchKernelGGL((ycge::k_atrous_stream<16, true>), grid, dim3(512 + 64), 0, stream, A, buf, statw, sky, d_pixels, d_offsets, d_pass_level, d_band_desc, n_levels, n_bands, rows_per_band, window_width, progress, epoch, xcd_local, ticket_base);
         else return (int)hipErrorInvalidValue;
@@ -1229,7 +1255,8 @@ int ycge_atrous_persist_resident(int groups_per_pass, int split, int level_hando
     hipError_t e = hipErrorInvalidValue;
     if (level_handover) {
         if (groups_per_pass == 8) e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, ycge::k_atrous_stream<8, false>, 256 + 64, 0);
-        else if (groups_per_pass == 16 && split && !profile) e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, ycge::k_atrous_stream<16, false, true>, 512 + 64, 0);
+        else if (groups_per_pass == 16 && split && !profile) e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, ycge::k_atrous_stream<16, false, true>, 512 + 64, (size_t)g_duo_pad_lds);
+        else if (groups_per_pass == 16 && split) e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, ycge::k_atrous_stream<16, true, true>, 512 + 64, (size_t)g_duo_pad_lds);
         else if (groups_per_pass == 16 && !profile) e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, ycge::k_atrous_stream<16, false>, 512 + 64, 0);
         else if (groups_per_pass == 16) e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, ycge::k_atrous_stream<16, true>, 512 + 64, 0);
     } else {
