@@ -343,6 +343,24 @@ def main():
             mov["with_sdr"] = {"frames": len(a), "trace_ms": dist3(a[:, 0]), "post_ms": dist3(a[:, 1]), "frame_ms_with_sdr_readback": dist3(a[:, 2])}
         r.SetCamera(pose["pos"], pose["yaw"], pose["pitch"])
 
+    flight = None
+    if single and not moving:        # frames in flight (ycge_render_frame_async; no counterpart in the reference): the same frames, queued without waiting
+        n = min(args.steps, 300)
+        for _ in range(args.warmup):
+            r.RenderAsync()
+        r.async_trace_ms()
+        tf0 = time.perf_counter()
+        for _ in range(n):
+            r.RenderAsync()
+        r.Wait()
+        tf = time.perf_counter() - tf0
+        ft = r.async_trace_ms()
+        flight = {"frames": n, "ms_per_step": round(tf / n * 1e3, 4), "value": round(per_frame["n_rays"] * n / tf / 1e6, 2), "unit": "Mrays/s",
+                  "trace_ms": dist3([float(x) for x in ft]) if len(ft) else None,
+                  "what": "the same frames queued with ycge_render_frame_async: no host wait between frames, TAA of frame N and the schedule of frame N + 2 on a second "
+                          "(low-priority) stream beside the trace of frame N + 1, trace outputs double-buffered; bit-identical frames (tests/test_gpu_timed_variants.py). "
+                          "The headline `value` stays the synchronous call, which is the reference's TryFlipAndBlit; trace_ms here is the launch with TAA running beside it"}
+
     post = None
     if not args.no_post and not multi:        # the frame the C# wrapper asks for (SDR out); outside the headline metric, which SURVEY 8d times through TAA
         ms = []
@@ -411,6 +429,8 @@ def main():
             "work_per_frame": {k: round(v, 1) for k, v in per_frame.items()},
             "roofline": roof, "cpu_baseline": cpu,
         }
+        if flight:
+            out["frames_in_flight"] = flight
         if frame_ms and frame_ms[0] > 0:
             out["frame_ms"] = dist3(frame_ms)
         if trace_ms and trace_ms[0] > 0:

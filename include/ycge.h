@@ -35,7 +35,7 @@
 extern "C" {
 #endif
 
-#define YCGE_ABI_VERSION 5
+#define YCGE_ABI_VERSION 6
 #define YCGE_MAX_DEVICES 8
 
 typedef enum ycge_status {
@@ -331,6 +331,17 @@ int ycge_set_camera(ycge_ctx *ctx, const float pos[3], float yaw, float pitch, f
  * top, bottom)) unchanged (RaytraceRenderer.cs:260-261).  May be NULL (frame is
  * still rendered; read buffers with ycge_read_buffer).  stats may be NULL. */
 int ycge_render_frame(ycge_ctx *ctx, float *out_top_bottom_sdr, ycge_frame_stats *stats);
+/* Frames in flight (no counterpart in the reference, whose TryFlipAndBlit returns a finished frame): queues steps 1-5 and 9 of the
+ * next frame - camera snapshot, trace, TAA, camera commit - and returns without waiting.  The trace of frame N + 1 runs beside the
+ * TAA of frame N (two streams, two sets of trace outputs), so a sequence of such calls costs max(trace, TAA + schedule) per frame
+ * instead of their sum plus the host's wake-up.  The frames are the ones the same sequence of ycge_render_frame(ctx, NULL, NULL)
+ * calls produces, bit for bit.  Single device, no debug captures, no per-frame counters.  Every other entry point (and
+ * ycge_wait) first waits for the frames in flight; ycge_set_camera between two calls moves the camera of the next frame. */
+int ycge_render_frame_async(ycge_ctx *ctx);
+int ycge_wait(ycge_ctx *ctx);
+/* measurement: durations (ms) of the trace launches of the frames queued since the last call, oldest first (at most the last 1024);
+ * waits for the frames in flight */
+int ycge_async_trace_times(ycge_ctx *ctx, float *ms_out, int32_t capacity, int32_t *n_out);
 
 /* --- multi-GPU halves of a frame (one process per GPU; the exchange between
  * them is one all-gather of the tile slabs, done by the caller with RCCL).

@@ -315,6 +315,73 @@ def test_pipelined_tiled_frames_with_a_moving_camera(product_lib):
     seq.close(); pip.close()
 
 
+@pytest.mark.parametrize("cfg_n,w,h", [(3, None, None), (5, 96, 27), (2, 160, 45)])
+def test_frames_in_flight_are_the_frames_of_the_synchronous_calls(product_lib, cfg_n, w, h):
+    """ycge_render_frame_async: the trace of frame N + 1 beside the TAA of frame N, trace outputs alternating between two sets of
+    buffers.  Reference behaviour = the same frames by TryFlipAndBlit one after the other (RaytraceRenderer.cs:157-267): every
+    buffer the newest frame left and the history, bit for bit - after a burst, after single frames, and with synchronous SDR
+    frames in between (their post stage reads whichever set is current); the camera moves, sometimes past the TAA reset threshold."""
+    sc, w0, h0, ss, pose = scenes.config_scene(cfg_n)
+    flat = flatten(sc)
+    w, h = w or w0, h or h0
+    moves = [0.0, 0.001, 0.0012, 0.02, 0.0201, 0.0201, 0.05, 0.0505, 0.0505, 0.051]
+    plan = "aaasaasaaa"            # a: in flight, s: a synchronous frame with SDR output
+    watch = (abi.BUF_CURRENT_HDR, abi.BUF_G_ALBEDO, abi.BUF_G_NORMAL, abi.BUF_G_DEPTH, abi.BUF_SKY_MASK, abi.BUF_TAA_HISTORY, abi.BUF_PREV_DEPTH)
+
+    def cam(r, i):
+        r.SetCamera((pose["pos"][0] + moves[i], pose["pos"][1], pose["pos"][2]), pose["yaw"] + 0.3 * moves[i], pose["pitch"])
+
+    seq = RaytraceRenderer(flat, w, h, pose["fov"], ss)
+    want, want_sdr = [], {}
+    for i, kind in enumerate(plan):
+        cam(seq, i)
+        if kind == "s":
+            want_sdr[i] = seq.TryFlipAndBlit(want_sdr=True)
+        else:
+            seq.TryFlipAndBlit()
+        want.append([seq.read(b) for b in watch])
+    seq.close()
+    # (1) everything queued back to back, looked at only where the plan has a synchronous frame and at the end
+    burst = RaytraceRenderer(flat, w, h, pose["fov"], ss)
+    for i, kind in enumerate(plan):
+        cam(burst, i)
+        if kind == "s":
+            sdr = burst.TryFlipAndBlit(want_sdr=True)
+            assert pu.bits_equal(sdr, want_sdr[i]), f"SDR of frame {i + 1} after frames in flight"
+            for b, a in zip(watch, want[i]):
+                assert pu.bits_equal(burst.read(b), a), (i, b)
+        else:
+            burst.RenderAsync()
+    for b, a in zip(watch, want[-1]):
+        assert pu.bits_equal(burst.read(b), a), ("burst end", b)
+    burst.Wait()
+    burst.close()
+    # (2) a read-back after every frame: each one joins, the next frame starts from a quiet context again
+    single = RaytraceRenderer(flat, w, h, pose["fov"], ss)
+    for i, kind in enumerate(plan):
+        cam(single, i)
+        if kind == "s":
+            single.TryFlipAndBlit(want_sdr=True)
+        else:
+            single.RenderAsync()
+        for b, a in zip(watch, want[i]):
+            assert pu.bits_equal(single.read(b), a), (i, b)
+    single.close()
+
+
+def test_frames_in_flight_refuse_what_they_cannot_keep(product_lib):
+    sc, _, _, ss, pose = scenes.config_scene(2)
+    flat = flatten(sc)
+    r = RaytraceRenderer(flat, 64, 18, pose["fov"], ss, count_work=True)
+    with pytest.raises(abi.YcgeError, match="ycge_render_frame"):
+        r.RenderAsync()
+    r.close()
+    r = RaytraceRenderer(flat, 64, 18, pose["fov"], ss, rank=0, world_size=2)
+    with pytest.raises(abi.YcgeError, match="single-device"):
+        r.RenderAsync()
+    r.close()
+
+
 def test_textured_material_and_bad_indices_are_refused(product_lib):
     """A textured material whose texture index points nowhere, a texture without pixels, an object with a material index out of
     range: refused loudly, with the reason."""

@@ -12,7 +12,7 @@ import ctypes as C
 import os
 from pathlib import Path
 
-YCGE_ABI_VERSION = 5
+YCGE_ABI_VERSION = 6
 YCGE_MAX_DEVICES = 8
 
 # ycge_status
@@ -179,6 +179,9 @@ _PROTOTYPES = {
     "ycge_resize": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.c_int32]),
     "ycge_set_camera": (C.c_int, [C.c_void_p, C.POINTER(C.c_float), C.c_float, C.c_float, C.c_float]),
     "ycge_render_frame": (C.c_int, [C.c_void_p, C.POINTER(C.c_float), C.POINTER(FrameStats)]),
+    "ycge_render_frame_async": (C.c_int, [C.c_void_p]),
+    "ycge_wait": (C.c_int, [C.c_void_p]),
+    "ycge_async_trace_times": (C.c_int, [C.c_void_p, C.POINTER(C.c_float), C.c_int32, C.POINTER(C.c_int32)]),
     "ycge_tile_slab_bytes": (C.c_int, [C.c_void_p, C.POINTER(C.c_size_t)]),
     "ycge_trace_tiles": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.POINTER(FrameStats)]),
     "ycge_resolve_gathered": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.POINTER(C.c_float), C.POINTER(FrameStats)]),

@@ -30,7 +30,7 @@ int ycge_launch_trace(const ycge::SceneDev *S, const ycge::FrameParams *P, const
                       hipStream_t stream);
 int ycge_launch_wavefront(const ycge::SceneDev *S, const ycge::FrameParams *P, const ycge::TraceOut *O, void *const bufs[7], int rounds,
                           int has_grid, int flat, int count, int persistent_waves, hipStream_t stream);
-int ycge_launch_order_blocks(uint32_t *cost, uint32_t n, uint32_t policy, uint32_t split_top, uint32_t fan_class, uint32_t fan_cap, uint32_t next_slot, uint32_t *order_ws,
+int ycge_launch_order_blocks(uint32_t *cost, uint32_t n, uint32_t policy, uint32_t split_top, uint32_t fan_class, uint32_t fan_cap, uint32_t next_slot, uint32_t skip_slot, uint32_t *order_ws,
                              uint32_t *order, hipStream_t stream);
 int ycge_launch_trace_fan(const ycge::SceneDev *S, const ycge::FrameParams *P, const ycge::TraceOut *O, int count, int flat, uint32_t fan_cap,
                           hipStream_t stream);
@@ -121,6 +121,7 @@ struct Knobs {
     int post_probe_band = -1;        // YCGE_POST_PROBE_BAND: this band and the next record a per-pass timeline (profiles/post_bands.py)
     int post_assume_resident = 0;    // YCGE_POST_ASSUME_RESIDENT (tests): take this for the runtime's answer - more bands than fit, to exercise the order-of-arrival numbering
     bool post_dbg_free = false;      // YCGE_POST_DBG_FREE (timing experiment, WRONG pixels): no band of the persistent in-place A-trous waits for the band above
+    bool flight_same_priority = false, flight_no_begin = false;      // experiments on ycge_render_frame_async: second stream at normal priority; no begin-of-trace timing event
     int post_pad_lds = 0;            // YCGE_POST_PAD_LDS (experiment): bytes of unused LDS per band workgroup of the two-set form - fewer of them on a CU
     int post_resident_per_cu = 3;    // YCGE_POST_RESIDENT: band workgroups of the persistent in-place A-trous a CU may hold (3 fit: 576 threads, 46 KB of LDS each)
     bool post_hash = false;          // YCGE_POST_HASH_FORM=1: the hash form of k_atrous_band even where the window fits
@@ -155,6 +156,7 @@ struct Knobs {
         post_assume_resident = geti("YCGE_POST_ASSUME_RESIDENT", 0);
         if (post_resident_per_cu < 1 || post_resident_per_cu > 3) post_resident_per_cu = 3;
         post_pad_lds = geti("YCGE_POST_PAD_LDS", 0);
+        flight_same_priority = geti("YCGE_FLIGHT_SAME_PRIORITY", 0) != 0; flight_no_begin = geti("YCGE_FLIGHT_NO_BEGIN", 0) != 0;
         post_dbg_free = geti("YCGE_POST_DBG_FREE", 0) != 0;
         exposure_serial = getenv("YCGE_EXPOSURE_SERIAL") != nullptr;
         no_coop = getenv("YCGE_NO_COOP") != nullptr;
@@ -171,6 +173,7 @@ struct FrameState {
     bool reset;
     int64_t frame;
     uint32_t fan_blocks;
+    bool scheduled = false;      // the trace ran the single-launch kernel with a longest-first schedule (cost ring in use)
 };
 
 struct MeshHost {
@@ -234,6 +237,22 @@ struct ycge_ctx {
     // so the trace of frame N+1 may run beside the all-gather and resolve of frame N (two streams, caller-ordered)
     DevBuf<float> t_hdr, t_albedo, t_normal, t_depth;
     DevBuf<uint8_t> t_sky;
+    // frames in flight (ycge_render_frame_async): the trace of frame N + 1 runs beside the TAA of frame N, so a frame's trace outputs
+    // alternate between the five buffers above and these (swapped before the trace: the names above are always the newest frame's)
+    DevBuf<float> alt_hdr, alt_albedo, alt_normal, alt_depth;
+    DevBuf<uint8_t> alt_sky;
+    hipStream_t taa_stream = nullptr;
+    hipEvent_t set_resolved_ev[2] = {nullptr, nullptr};
+    bool set_read[2] = {false, false};             // a TAA launch on taa_stream has read this set: the next trace into it waits for set_resolved_ev
+    int out_set = 0;                               // which set the names above hold
+    bool async_outstanding = false;
+    // ... and their schedules: the one for frame N + 1 is built WHILE frame N is traced, from the costs up to frame N - 1 (a frame
+    // staler than the synchronous path's, which builds it between the two traces), into the buffers frame N is not reading
+    DevBuf<uint32_t> flight_order[2], flight_ws[2];
+    int64_t flight_order_frame[2] = {-1, -1};      // the frame number each buffer's schedule was built for (-1: none)
+    bool in_flight_call = false;                   // trace_frame is called by ycge_render_frame_async
+    std::vector<hipEvent_t> flight_ev;             // begin / end of the trace launches of the frames in flight, a ring (ycge_async_trace_times)
+    uint64_t flight_frames = 0;                    // queued since the last ycge_async_trace_times
     DevBuf<float> dbg_rays, dbg_hit_t;
     DevBuf<int32_t> dbg_prim, dbg_sub;
     DevBuf<uint64_t> dbg_rng;
@@ -314,6 +333,8 @@ struct ycge_ctx {
                                                  "%s failed: %s", #call, hipGetErrorString(e_));            \
     } while (0)
 
+#define YCGE_FLIGHT_RING 1024u       // frames in flight whose trace launches keep their timing events (ycge_async_trace_times)
+
 namespace {
 
 int alloc_frame_buffers(ycge_ctx *c)
@@ -352,6 +373,7 @@ int alloc_tile_buffers(ycge_ctx *c)
         HIP_TRY(c, hipMemset(c->order_ws.p, 0, 96 * sizeof(uint32_t)));
         HIP_TRY(c, hipMemset(c->block_cost.p, 0, nb * YCGE_COST_FRAMES * sizeof(uint32_t)));
         c->block_order_valid = false;
+        for (int k = 0; k < 2; k++) { c->flight_order[k].release(); c->flight_ws[k].release(); c->flight_order_frame[k] = -1; }      // (allocated by the first frame in flight)
     }
     {   // XCD-aware block -> tile table: bucket the owned tiles by image strip (4 tiles = 128 px wide, strip s -> XCD s % 8),
         // then deal the buckets out round-robin so that block b (which lands on XCD b % 8) draws from bucket b % 8
@@ -400,6 +422,8 @@ int set_geometry(ycge_ctx *c, int fbw, int fbh, int ss)
     c->wave_prof.release();                                     // sized for the tile grid
     c->pending.clear();
     c->t_hdr.release(); c->t_albedo.release(); c->t_normal.release(); c->t_depth.release(); c->t_sky.release();
+    c->alt_hdr.release(); c->alt_albedo.release(); c->alt_normal.release(); c->alt_depth.release(); c->alt_sky.release();      // (callers have quiesced the device)
+    c->set_read[0] = c->set_read[1] = false; c->out_set = 0; c->async_outstanding = false;
     for (auto *sc : c->schedules) delete sc;      // level schedules are per size: rebuilt on demand (the destructor frees the device lists)
     c->schedules.clear();
     int rc = alloc_frame_buffers(c);
@@ -578,6 +602,16 @@ static int create_one(const ycge_config *cfg, ycge_ctx *parent, ycge_ctx **out)
         if (hipEventCreate(&ev) != hipSuccess) { c->err = "hipEventCreate failed"; return bail(YCGE_ERR_DEVICE); }
     {
         if (hipStreamCreateWithFlags(&c->fan_stream, hipStreamNonBlocking) != hipSuccess) { c->err = "hipStreamCreate failed"; return bail(YCGE_ERR_DEVICE); }
+        if (c->cfg.world_size == 1 && c->cfg.n_devices <= 1) {
+            // The second stream of the frames in flight (ycge_render_frame_async), created HERE, next to the other two: the runtime deals
+            // streams onto a few hardware queues in order of creation, and a stream created later - after another context of the process
+            // has come and gone - landed on the queue of this context's own stream: TAA and trace in ONE queue, 0.65 instead of 0.53 ms
+            // a frame on config 4.  At the LOWEST priority: its kernels - TAA of the frame just traced, the schedule of the frame after
+            // next - yield to the running trace's workgroups (measured neutral: 0.548 against 0.551 ms at normal priority)
+            int lo = 0, hi = 0;
+            if (hipDeviceGetStreamPriorityRange(&lo, &hi) != hipSuccess ||
+                hipStreamCreateWithPriority(&c->taa_stream, hipStreamNonBlocking, c->knobs.flight_same_priority ? 0 : lo) != hipSuccess) { c->err = "hipStreamCreate failed"; return bail(YCGE_ERR_DEVICE); }
+        }
         for (hipEvent_t *ev : {&c->fan_ev[0], &c->fan_ev[1], &c->traced_ev, &c->order_ev, &c->pushed_ev})
             if (hipEventCreateWithFlags(ev, hipEventDisableTiming) != hipSuccess) { c->err = "hipEventCreate failed"; return bail(YCGE_ERR_DEVICE); }
         // Query fan-out (k_trace_fan).  On a rank's share of a tiled frame wavefront slots are plentiful and the rank's time is the
@@ -679,6 +713,12 @@ void ycge_destroy(ycge_ctx *c)
     c->dbg_rays.release(); c->dbg_hit_t.release(); c->dbg_prim.release(); c->dbg_sub.release(); c->dbg_rng.release();
     c->counters.release(); c->wave_prof.release(); c->own_slab.release(); c->dbg_counters.release();
     c->t_hdr.release(); c->t_albedo.release(); c->t_normal.release(); c->t_depth.release(); c->t_sky.release();
+    if (c->taa_stream) { (void)hipStreamSynchronize(c->taa_stream); (void)hipStreamDestroy(c->taa_stream); c->taa_stream = nullptr; }
+    for (int k = 0; k < 2; k++) if (c->set_resolved_ev[k]) (void)hipEventDestroy(c->set_resolved_ev[k]);
+    for (int k = 0; k < 2; k++) { c->flight_order[k].release(); c->flight_ws[k].release(); }
+    for (hipEvent_t ev : c->flight_ev) (void)hipEventDestroy(ev);
+    c->flight_ev.clear();
+    c->alt_hdr.release(); c->alt_albedo.release(); c->alt_normal.release(); c->alt_depth.release(); c->alt_sky.release();
     c->den_a.release(); c->den_b.release(); c->unit_n.release(); c->exp_terms.release(); c->exp_scratch.release(); c->d_sdr.release(); c->atrous_statw.release(); c->tone_state.release();
     for (auto *sc : c->schedules) delete sc;
     c->schedules.clear();
@@ -731,6 +771,7 @@ int quiesce(ycge_ctx *c)
     // scene updates rewrite live allocations in place (DevBuf::upload), so wait for the whole device - this is a per-scene-change
     // call, never part of a frame
     HIP_TRY(c, hipDeviceSynchronize());
+    c->async_outstanding = false; c->set_read[0] = c->set_read[1] = false;        // (frames in flight included)
     return YCGE_OK;
 }
 
@@ -914,7 +955,7 @@ int install_objects(ycge_ctx *c, const ObjectsHost &oh)
     sd.scene_nodes = c->d_scene_nodes.p; sd.scene_leaf_prims = c->d_scene_leaf.p; sd.prims = c->d_prims.p;
     sd.scene_root_ref = oh.scene_root;
     for (int a = 0; a < 3; a++) { sd.scene_root_min[a] = oh.root_min[a]; sd.scene_root_max[a] = oh.root_max[a]; }
-    c->block_order_valid = false;
+    c->block_order_valid = false; c->flight_order_frame[0] = c->flight_order_frame[1] = -1;
     return YCGE_OK;
 }
 
@@ -1009,7 +1050,7 @@ int install_scene(ycge_ctx *c, const SceneArrays &A, const ObjectsHost &oh, cons
     rc = upload_lights(c, s->lights, s->n_lights);
     if (rc != YCGE_OK) return rc;
     c->have_scene = true;
-    c->block_order_valid = false;
+    c->block_order_valid = false; c->flight_order_frame[0] = c->flight_order_frame[1] = -1;
     return YCGE_OK;
 }
 
@@ -1515,8 +1556,22 @@ void snapshot_frame(ycge_ctx *c, FrameState &fs)
     fs.fan_blocks = 0;
 }
 
+// How the longest-first schedule cuts blocks into parts.  policy, octal: digit c = log2(parts) a block of class c
+// (policy_class_of_order_class) is split into, class 7 leftmost.  A whole frame splits by rank instead (split_top: a per-class split
+// costs more slots than it saves there).  On a rank's tiles slots are plentiful, thin wavefronts step faster and
+// see a smaller maximum over their lanes, so the heavier classes are split, deeper the fewer blocks a rank holds.  Per-rank trace on
+// config 4, maximum over ranks (profiles/rank_times.py): 8 ranks 0.359 -> 0.289 ms, 4 ranks 0.381 -> 0.351, 2 ranks 0.485 -> 0.441;
+// one class deeper loses at every rank count (8 ranks 55543000: 0.356; 4 ranks 44432000: 0.420; 2 ranks 44320000: 0.471).
+void schedule_policy(const ycge_ctx *c, uint32_t &policy, uint32_t &split_top)
+{
+    const uint32_t world_policy = c->cfg.world_size >= 8 ? 044433000u : c->cfg.world_size >= 4 ? 044320000u : c->cfg.world_size >= 2 ? 033220000u : 0u;
+    policy = c->knobs.split_set ? c->knobs.split_policy : world_policy;
+    // ... or, on a whole frame, the split_top blocks at the head of the schedule whatever their class (k_cost_scatter)
+    split_top = (c->knobs.split_set || policy || c->knobs.split_top <= 0) ? 0u : ((uint32_t)c->knobs.split_top & 0xffffu) | ((uint32_t)c->knobs.split_top_lg << 16);
+}
+
 // step 4 (RaytraceRenderer.cs:183-216): ray-gen + trace of this context's tiles for the frame `fs`
-int trace_frame(ycge_ctx *c, float *d_slab, hipStream_t stream, FrameState &fs, bool timed)
+int trace_frame(ycge_ctx *c, float *d_slab, hipStream_t stream, FrameState &fs, bool timed, hipEvent_t launch_begin = nullptr, hipEvent_t launch_end = nullptr /* frames in flight: around the trace launches alone */)
 {
     if (!c->have_scene) return c->fail(YCGE_ERR_NO_SCENE, "Scene BVH not built; call ycge_scene_upload first (Scene.cs:73)");
     FrameParams P;
@@ -1560,15 +1615,28 @@ int trace_frame(ycge_ctx *c, float *d_slab, hipStream_t stream, FrameState &fs, 
         const uint32_t n_blocks = (uint32_t)c->n_owned * 4u;
         const uint32_t cost_slot = (uint32_t)((uint64_t)fs.frame % YCGE_COST_FRAMES);       // this frame's array of the cost ring
         O.block_cost = lpt ? c->block_cost.p + (size_t)cost_slot * n_blocks : nullptr;
+        const int fk = (int)(fs.frame & 1);
+        const bool flight = c->in_flight_call && lpt;
+        fs.scheduled = lpt;
+        uint32_t policy, split_top;
+        schedule_policy(c, policy, split_top);
+        if (lpt && c->flight_order_frame[fk] == fs.frame) {          // a schedule built in flight for exactly this frame (also the first synchronous frame after a burst);
+            O.block_order = c->flight_order[fk].p;                   // ycge_render_frame_async has made the stream wait for it (set_resolved_ev), a synchronous caller has joined
+            O.n_order = c->flight_ws[fk].p + 16;
+            if (c->order_pending) { HIP_TRY(c, hipStreamWaitEvent(stream, c->order_ev, 0)); c->order_pending = false; }        // (an older synchronous schedule still on the side stream: it cleared this frame's cost slot)
+        } else {
         if (c->order_pending) { HIP_TRY(c, hipStreamWaitEvent(stream, c->order_ev, 0)); c->order_pending = false; }     // the schedule built beside the last frame's TAA
         O.block_order = (lpt && c->block_order_valid) ? c->block_order.p : nullptr;
         O.n_order = c->order_ws.p + 16;
+        }
+        const bool flight_order = O.block_order != nullptr && O.block_order != c->block_order.p;
         // the schedule's head (the heaviest blocks of the previous frame) goes to k_trace_fan, launched first and beside k_trace
         const int refill_steps = c->knobs.refill_steps;   // k_trace_refill: steps between refills (0 = k_trace)
         // a schedule without fanned blocks (analytic scenes, small frames) skips k_trace_fan and the side stream altogether: the count
         // comes back through pinned memory and is a frame or two old when read here - either answer traces every block exactly once,
         // because k_trace is told (n_fan pointer or null) which convention this frame uses
-        const bool fan = O.block_order != nullptr && c->fan_cap > 0 && !(flat && refill_steps > 0) && c->h_n_fan && *(volatile uint32_t *)c->h_n_fan > 0;
+        const bool fan = O.block_order != nullptr && !flight_order && c->fan_cap > 0 && !(flat && refill_steps > 0) && c->h_n_fan && *(volatile uint32_t *)c->h_n_fan > 0;       // (schedules built in flight have no fanned head)
+        if (launch_begin) HIP_TRY(c, hipEventRecord(launch_begin, stream));       // (behind the wait for the schedule)
         if (fan) {
             fs.fan_blocks = *(volatile uint32_t *)c->h_n_fan;      // what the last finished schedule handed to k_trace_fan (this frame's may differ by a few)
             // k_trace_fan goes FIRST and on the frame's stream, so that its blocks - the frame's longest chains - are resident from
@@ -1585,23 +1653,16 @@ int trace_frame(ycge_ctx *c, float *d_slab, hipStream_t stream, FrameState &fs, 
             HIP_TRY(c, hipStreamWaitEvent(stream, c->fan_ev[1], 0));
         } else
             e = ycge_launch_trace(&c->sd, &P, &O, c->cfg.count_work, flat, refill_steps, stream);
-        if (e == 0 && lpt) {
-            // octal: digit c = log2(parts) a block of class c (policy_class_of_order_class) is split into, class 7 leftmost.  A whole
-            // frame splits by rank instead (split_top below: a per-class split costs more slots than it saves there).
-            // On a rank's tiles slots are plentiful, thin wavefronts step faster and see a smaller maximum over their lanes, so the
-            // heavier classes are split, deeper the fewer blocks a rank holds.  Per-rank trace on config 4, maximum over ranks
-            // (profiles/rank_times.py): 8 ranks 0.359 -> 0.289 ms, 4 ranks 0.381 -> 0.351, 2 ranks 0.485 -> 0.441; one class deeper
-            // loses at every rank count (8 ranks 55543000: 0.356; 4 ranks 44432000: 0.420; 2 ranks 44320000: 0.471).
-            const uint32_t world_policy = c->cfg.world_size >= 8 ? 044433000u : c->cfg.world_size >= 4 ? 044320000u
-                                        : c->cfg.world_size >= 2 ? 033220000u : 0u;
-            const uint32_t policy = c->knobs.split_set ? c->knobs.split_policy : world_policy;
+        if (launch_end) HIP_TRY(c, hipEventRecord(launch_end, stream));
+        if (e == 0 && flight) {
+            // (frames in flight: the schedule of frame N + 2 follows this frame's TAA on the second stream, ycge_render_frame_async)
+        } else if (e == 0 && lpt) {
             // the next frame's schedule needs this frame's trace and nothing else: built on the side stream, beside TAA (or the slab
             // pack and all-gather), instead of 25 us in front of it; the next trace waits for it (order_ev)
             HIP_TRY(c, hipEventRecord(c->traced_ev, stream));
             HIP_TRY(c, hipStreamWaitEvent(c->fan_stream, c->traced_ev, 0));
-            // ... or, on a whole frame, the split_top blocks at the head of the schedule whatever their class (k_cost_scatter)
-            const uint32_t split_top = (c->knobs.split_set || policy || c->knobs.split_top <= 0) ? 0u : ((uint32_t)c->knobs.split_top & 0xffffu) | ((uint32_t)c->knobs.split_top_lg << 16);
-            e = ycge_launch_order_blocks(c->block_cost.p, n_blocks, policy, split_top, c->fan_class, c->fan_cap, (cost_slot + 1u) % YCGE_COST_FRAMES, c->order_ws.p, c->block_order.p, c->fan_stream);
+            e = ycge_launch_order_blocks(c->block_cost.p, n_blocks, policy, split_top, c->fan_class, c->fan_cap, (cost_slot + 1u) % YCGE_COST_FRAMES, 0xffffffffu, c->order_ws.p, c->block_order.p, c->fan_stream);
+
             c->block_order_valid = true;
             if (e == 0 && c->h_n_fan && c->fan_cap > 0) HIP_TRY(c, hipMemcpyAsync(c->h_n_fan, c->order_ws.p + 18, sizeof(uint32_t), hipMemcpyDeviceToHost, c->fan_stream));
             HIP_TRY(c, hipEventRecord(c->order_ev, c->fan_stream));
@@ -1614,7 +1675,9 @@ int trace_frame(ycge_ctx *c, float *d_slab, hipStream_t stream, FrameState &fs, 
         int pw = c->knobs.no_refill ? 0 : c->compute_units * c->knobs.pw_per_cu;
         if ((size_t)pw * 64 > O.stack_lanes) pw = (int)(O.stack_lanes / 64);
         if ((size_t)pw > nt * 4) pw = (int)(nt * 4);            // never more wavefronts than the round can have rays for
+        if (launch_begin) HIP_TRY(c, hipEventRecord(launch_begin, stream));
         e = ycge_launch_wavefront(&c->sd, &P, &O, bufs, c->wf_rounds, c->has_grid ? 1 : 0, flat, c->cfg.count_work, pw, stream);
+        if (launch_end) HIP_TRY(c, hipEventRecord(launch_end, stream));
     }
     if (e != 0) return c->fail(YCGE_ERR_DEVICE, "trace launch failed: %s", hipGetErrorString((hipError_t)e));
     if (slab) {
@@ -2062,10 +2125,119 @@ static int trace_on_all_devices(ycge_ctx *c, FrameState &fs)
     return YCGE_OK;
 }
 
+// Frames in flight.  ycge_render_frame is the reference's call: one frame, finished when it returns.  A caller that only wants
+// frames per second (a benchmark, a recorder, a render thread that flips when a frame is there) loses the gap between two traces
+// to it: TAA, the schedule of the next frame and the host's wake-up stand between them (57 us of a 0.55 ms frame on config 4) although
+// the trace of frame N + 1 needs nothing of frame N's TAA.  ycge_render_frame_async queues steps 1-5 and 9 of a frame and returns:
+// the trace on the context's stream, TAA on a second one, a frame's trace outputs alternating between two sets of buffers so that
+// TAA of frame N reads one set while the trace of frame N + 1 writes the other.  Same kernels, same order of frames, same bits
+// (tests/test_gpu_timed_variants.py); every other entry point first waits for what is in flight (join_async).
+static int join_async(ycge_ctx *c)
+{
+    if (!c->async_outstanding) return YCGE_OK;
+    HIP_TRY(c, hipSetDevice(c->device));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    HIP_TRY(c, hipStreamSynchronize(c->taa_stream));
+    c->async_outstanding = false;
+    c->set_read[0] = c->set_read[1] = false;
+    return YCGE_OK;
+}
+
+int ycge_wait(ycge_ctx *c)
+{
+    if (!c) return YCGE_ERR_INVALID_ARG;
+    return join_async(c);
+}
+
+// measurement: how long the trace launches of the frames queued since the last call took (HIP events around them on the context's
+// stream, behind the wait for the schedule), oldest first, at most the last YCGE_FLIGHT_RING of them.  Waits for the frames in flight.
+int ycge_async_trace_times(ycge_ctx *c, float *ms_out, int32_t capacity, int32_t *n_out)
+{
+    if (!c || !n_out || (capacity > 0 && !ms_out)) return YCGE_ERR_INVALID_ARG;
+    { const int jr = join_async(c); if (jr != YCGE_OK) return jr; }
+    if (c->knobs.flight_no_begin) { *n_out = 0; c->flight_frames = 0; return YCGE_OK; }
+    const uint64_t have = c->flight_frames < YCGE_FLIGHT_RING ? c->flight_frames : YCGE_FLIGHT_RING;
+    const uint64_t n = have < (uint64_t)(capacity > 0 ? capacity : 0) ? have : (uint64_t)(capacity > 0 ? capacity : 0);
+    for (uint64_t i = 0; i < n; i++) {
+        const size_t slot = (size_t)((c->flight_frames - n + i) % YCGE_FLIGHT_RING);
+        HIP_TRY(c, hipEventElapsedTime(&ms_out[i], c->flight_ev[2 * slot], c->flight_ev[2 * slot + 1]));
+    }
+    *n_out = (int32_t)n;
+    c->flight_frames = 0;
+    return YCGE_OK;
+}
+
+int ycge_render_frame_async(ycge_ctx *c)
+{
+    if (!c) return YCGE_ERR_INVALID_ARG;
+    if (c->parent || !c->peers.empty() || c->cfg.world_size != 1)
+        return c->fail(YCGE_ERR_INVALID_ARG, "ycge_render_frame_async is the single-device form (tiled frames overlap through ycge_trace_tiles / ycge_resolve_gathered on two streams)");
+    if (c->cfg.capture_debug || c->cfg.count_work) return c->fail(YCGE_ERR_INVALID_ARG, "ycge_render_frame_async keeps neither debug captures nor per-frame counters: use ycge_render_frame");
+    HIP_TRY(c, hipSetDevice(c->device));
+    if (!c->taa_stream) return c->fail(YCGE_ERR_INVALID_ARG, "no second stream: frames in flight need a single-device context");
+    for (int k = 0; k < 2; k++) if (!c->set_resolved_ev[k]) HIP_TRY(c, hipEventCreateWithFlags(&c->set_resolved_ev[k], hipEventDisableTiming));
+    if (c->flight_ev.empty()) {
+        c->flight_ev.resize(2 * YCGE_FLIGHT_RING, nullptr);
+        for (hipEvent_t &ev : c->flight_ev) HIP_TRY(c, hipEventCreate(&ev));
+    }
+    const size_t npx = (size_t)c->hiW * c->hiH;
+    if (!c->alt_hdr.p) {
+        HIP_TRY(c, c->alt_hdr.alloc(3 * npx)); HIP_TRY(c, c->alt_albedo.alloc(3 * npx)); HIP_TRY(c, c->alt_normal.alloc(3 * npx));
+        HIP_TRY(c, c->alt_depth.alloc(npx)); HIP_TRY(c, c->alt_sky.alloc(npx));
+    }
+    const uint32_t n_blocks = (uint32_t)c->n_owned * 4u;
+    for (int k = 0; k < 2; k++)
+        if (!c->flight_order[k].p) { HIP_TRY(c, c->flight_order[k].alloc((size_t)n_blocks * YCGE_SCHEDULE_SLACK)); HIP_TRY(c, c->flight_ws[k].alloc(96)); HIP_TRY(c, hipMemset(c->flight_ws[k].p, 0, 96 * sizeof(uint32_t))); }
+    FrameState fs;
+    snapshot_frame(c, fs);
+    if (!c->async_outstanding) {
+        // the first frame in flight after synchronous calls.  Whatever they left on the context's stream (a TAA, a post stage that reads
+        // the current set) is ahead of this trace in stream order, and the second stream's first TAA waits for this trace.  The
+        // synchronous schedule cleared THIS frame's cost slot; the next frame's would have been cleared between the two traces
+        HIP_TRY(c, hipMemsetAsync(c->block_cost.p + (size_t)((uint64_t)(fs.frame + 1) % YCGE_COST_FRAMES) * n_blocks, 0, (size_t)n_blocks * sizeof(uint32_t), c->stream));
+    }
+    // the other set becomes "the current frame's": every later reader (TAA below, a read-back, a synchronous frame's post stage) goes by these names
+    std::swap(c->current_hdr, c->alt_hdr); std::swap(c->g_albedo, c->alt_albedo); std::swap(c->g_normal, c->alt_normal);
+    std::swap(c->g_depth, c->alt_depth); std::swap(c->sky, c->alt_sky);
+    c->out_set ^= 1;
+    const int k = c->out_set;
+    // ONE wait per frame on the trace's stream: the second stream's work of two frames ago - TAA (it read this set of buffers) and
+    // behind it the schedule for THIS frame (it wrote the order buffer of this parity and cleared this frame's cost slot)
+    if (c->set_read[k]) HIP_TRY(c, hipStreamWaitEvent(c->stream, c->set_resolved_ev[k], 0));
+    const size_t slot = (size_t)(c->flight_frames % YCGE_FLIGHT_RING);
+    hipEvent_t ev_begin = c->knobs.flight_no_begin ? nullptr : c->flight_ev[2 * slot], ev_end = c->flight_ev[2 * slot + 1];
+    c->in_flight_call = true;
+    int rc = trace_frame(c, nullptr, c->stream, fs, false, ev_begin, nullptr);
+    c->in_flight_call = false;
+    if (rc != YCGE_OK) return rc;
+    HIP_TRY(c, hipEventRecord(ev_end, c->stream));          // end of the trace: the timing ring's event is also what the second stream waits for
+    c->flight_frames++;
+    HIP_TRY(c, hipStreamWaitEvent(c->taa_stream, ev_end, 0));
+    bool did_reset = false;
+    rc = taa_and_commit(c, c->taa_stream, fs, did_reset, false);
+    if (rc != YCGE_OK) return rc;
+    if (fs.scheduled) {
+        // the schedule of frame N + 2, from the costs up to this frame's: the slot frame N + 1's trace is writing meanwhile is left out,
+        // the one frame N + 2's will write is cleared; into the order buffer this frame's trace has just finished reading
+        uint32_t policy, split_top;
+        schedule_policy(c, policy, split_top);
+        const uint32_t next_writes = (uint32_t)((uint64_t)(fs.frame + 1) % YCGE_COST_FRAMES), target = (uint32_t)((uint64_t)(fs.frame + 2) % YCGE_COST_FRAMES);
+        const int fk = (int)(fs.frame & 1);
+        const int e = ycge_launch_order_blocks(c->block_cost.p, n_blocks, policy, split_top, 0u, 0u, target, next_writes, c->flight_ws[fk].p, c->flight_order[fk].p, c->taa_stream);
+        if (e != 0) return c->fail(YCGE_ERR_DEVICE, "schedule launch failed: %s", hipGetErrorString((hipError_t)e));
+        c->flight_order_frame[fk] = fs.frame + 2;
+    }
+    HIP_TRY(c, hipEventRecord(c->set_resolved_ev[k], c->taa_stream));
+    c->set_read[k] = true;
+    c->async_outstanding = true;
+    return YCGE_OK;
+}
+
 int ycge_render_frame(ycge_ctx *c, float *out_sdr, ycge_frame_stats *st)
 {
     if (!c) return YCGE_ERR_INVALID_ARG;
     if (c->parent) return c->fail(YCGE_ERR_INVALID_ARG, "peer contexts are driven by their root");
+    { const int jr = join_async(c); if (jr != YCGE_OK) return jr; }
     const bool multi_dev = !c->peers.empty();
     if (c->cfg.world_size != 1 && !multi_dev)
         return c->fail(YCGE_ERR_INVALID_ARG, "ycge_render_frame is the one-process entry: set config.n_devices / devices[] to drive several GPUs from it, "
@@ -2110,6 +2282,7 @@ int ycge_trace_tiles(ycge_ctx *c, void *d_slab, void *hip_stream, ycge_frame_sta
 {
     if (!c) return YCGE_ERR_INVALID_ARG;
     if (c->parent || !c->peers.empty()) return c->fail(YCGE_ERR_INVALID_ARG, "ycge_trace_tiles is the one-process-per-GPU form; this context drives its devices through ycge_render_frame");
+    { const int jr = join_async(c); if (jr != YCGE_OK) return jr; }
     HIP_TRY(c, hipSetDevice(c->device));
     hipStream_t stream = hip_stream ? (hipStream_t)hip_stream : c->stream;
     c->last_stream = stream;
@@ -2135,6 +2308,7 @@ int ycge_resolve_gathered(ycge_ctx *c, const void *d_all_slabs, void *hip_stream
     if (!c) return YCGE_ERR_INVALID_ARG;
     if (!d_all_slabs) return c->fail(YCGE_ERR_INVALID_ARG, "null gathered slabs");
     if (c->pending.empty()) return c->fail(YCGE_ERR_INVALID_ARG, "no traced frame to resolve: every ycge_resolve_gathered follows its own ycge_trace_tiles");
+    { const int jr = join_async(c); if (jr != YCGE_OK) return jr; }
     HIP_TRY(c, hipSetDevice(c->device));
     hipStream_t stream = hip_stream ? (hipStream_t)hip_stream : c->stream;
     c->last_stream = stream;
@@ -2206,6 +2380,7 @@ int ycge_read_buffer(ycge_ctx *c, int32_t which, void *dst, size_t bytes)
     }
     if (!src) return c->fail(YCGE_ERR_INVALID_ARG, "buffer %d needs config.capture_debug", which);
     if (bytes != want) return c->fail(YCGE_ERR_INVALID_ARG, "buffer %d is %zu bytes, caller passed %zu", which, want, bytes);
+    { const int jr = join_async(c); if (jr != YCGE_OK) return jr; }
     HIP_TRY(c, hipStreamSynchronize(c->stream));
     HIP_TRY(c, hipMemcpy(dst, src, want, hipMemcpyDeviceToHost));
     return YCGE_OK;

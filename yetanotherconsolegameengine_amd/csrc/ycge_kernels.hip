@@ -1166,20 +1166,21 @@ __device__ __forceinline__ uint32_t class_lg_parts(uint32_t policy, int cls) { r
 // which blocks run long is a property of the image region (silhouettes seen at grazing angles), how long a given one runs in a
 // given frame depends on that frame's random bounce directions - the 40 longest-running blocks of a frame are found among the
 // top 200 of the previous frame's costs 58 % of the time, among the top 200 of max-over-four-frames 90 % (profiles/cost_persistence.py).
-__device__ __forceinline__ uint32_t smoothed_cost(const uint32_t *cost, uint32_t n, uint32_t i)
+// (skip_slot: the ring slot a trace that is RUNNING beside this schedule writes - frames in flight, ycge_render_frame_async - or none)
+__device__ __forceinline__ uint32_t smoothed_cost(const uint32_t *cost, uint32_t n, uint32_t i, uint32_t skip_slot)
 {
     uint32_t m = 0;
 #pragma unroll
-    for (int f = 0; f < YCGE_COST_FRAMES; f++) { const uint32_t v = cost[(size_t)f * n + i]; m = v > m ? v : m; }
+    for (int f = 0; f < YCGE_COST_FRAMES; f++) { const uint32_t v = (uint32_t)f == skip_slot ? 0u : cost[(size_t)f * n + i]; m = v > m ? v : m; }
     return m;
 }
-__global__ __launch_bounds__(1024) void k_cost_hist(const uint32_t *__restrict__ cost, uint32_t n, uint32_t *__restrict__ ws)
+__global__ __launch_bounds__(1024) void k_cost_hist(const uint32_t *__restrict__ cost, uint32_t n, uint32_t skip_slot, uint32_t *__restrict__ ws)
 {
     __shared__ uint32_t h[YCGE_ORDER_CLASSES];
     if (threadIdx.x < YCGE_ORDER_CLASSES) h[threadIdx.x] = 0;
     __syncthreads();
     const uint32_t i = blockIdx.x * 1024u + threadIdx.x;
-    if (i < n) { const int cls = order_class(smoothed_cost(cost, n, i)); atomicAdd(&h[cls], 1u); }
+    if (i < n) { const int cls = order_class(smoothed_cost(cost, n, i, skip_slot)); atomicAdd(&h[cls], 1u); }
     __syncthreads();
     if (threadIdx.x < YCGE_ORDER_CLASSES && h[threadIdx.x]) atomicAdd(&ws[32 + threadIdx.x], h[threadIdx.x]);
 }
@@ -1204,7 +1205,7 @@ __device__ __forceinline__ ClassLayout class_layout(const uint32_t *ws, int cls,
     return L;
 }
 __global__ __launch_bounds__(1024) void k_cost_scatter(uint32_t *__restrict__ cost, uint32_t n, uint32_t capacity, uint32_t policy, uint32_t split_top,
-                                                       uint32_t fan_class, uint32_t fan_cap, uint32_t next_slot, uint32_t *__restrict__ ws, uint32_t *__restrict__ order)
+                                                       uint32_t fan_class, uint32_t fan_cap, uint32_t next_slot, uint32_t skip_slot, uint32_t *__restrict__ ws, uint32_t *__restrict__ order)
 {
     __shared__ uint32_t h[YCGE_ORDER_CLASSES], rank0[YCGE_ORDER_CLASSES];
     __shared__ ClassLayout lay[YCGE_ORDER_CLASSES];
@@ -1231,7 +1232,7 @@ __global__ __launch_bounds__(1024) void k_cost_scatter(uint32_t *__restrict__ co
     int cls = -1;
     uint32_t local = 0;
     if (i < n) {
-        cls = order_class(smoothed_cost(cost, n, i));
+        cls = order_class(smoothed_cost(cost, n, i, skip_slot));
         cost[(size_t)next_slot * n + i] = 0;         // the ring slot the next frame's atomicMax goes to
         local = atomicAdd(&h[cls], 1u);
     }
@@ -1251,6 +1252,14 @@ __global__ __launch_bounds__(1024) void k_cost_scatter(uint32_t *__restrict__ co
 // ---------------------------------------------------------------------------------- K_taa
 __device__ __forceinline__ float luma(float r, float g, float b) { return 0.2126f * r + 0.7152f * g + 0.0722f * b; }
 
+#ifndef YCGE_TAA_NT
+#define YCGE_TAA_NT 1
+#endif
+// What TAA touches once per frame - the history and the guide planes it reads and rewrites, this frame's normal and depth - goes past
+// the caches' keep lists (non-temporal): 230 MB a 1080p frame that would otherwise push the trace's tree out of the L2s just
+// before the next trace (or while it runs: frames in flight).  The 3 x 3 colour taps stay ordinary loads, they are shared.
+template <class T> __device__ __forceinline__ T taa_ld(const T *p) { return YCGE_TAA_NT ? __builtin_nontemporal_load(p) : *p; }
+template <class T> __device__ __forceinline__ void taa_st(T *p, T v) { if (YCGE_TAA_NT) __builtin_nontemporal_store(v, p); else *p = v; }
 // TemporalBlendWithClamp, RaytraceRenderer.cs:274-398.  One thread per pixel; the history and
 // guide updates touch only the thread's own pixel, so the serial loops of the C# fuse into one pass.
 __global__ __launch_bounds__(256) void k_taa(const TaaParams T, const float *__restrict__ current, const float *__restrict__ normal,
@@ -1262,24 +1271,24 @@ __global__ __launch_bounds__(256) void k_taa(const TaaParams T, const float *__r
     if (x >= T.w || y >= T.h) return;
     const size_t i = (size_t)x + (size_t)y * T.w;
     const float cr = current[3 * i], cg = current[3 * i + 1], cb = current[3 * i + 2];
-    const float nx = normal[3 * i], ny = normal[3 * i + 1], nz = normal[3 * i + 2];
-    const float z_now = depth[i];
+    const float nx = taa_ld(normal + 3 * i), ny = taa_ld(normal + 3 * i + 1), nz = taa_ld(normal + 3 * i + 2);
+    const float z_now = taa_ld(depth + i);
     const uint8_t sky_now = sky[i];
     if (T.reset) {
-        hist[3 * i] = cr; hist[3 * i + 1] = cg; hist[3 * i + 2] = cb;
-        prev_normal[3 * i] = nx; prev_normal[3 * i + 1] = ny; prev_normal[3 * i + 2] = nz;
-        prev_depth[i] = z_now;
-        prev_sky[i] = sky_now;
+        taa_st(hist + 3 * i, cr); taa_st(hist + 3 * i + 1, cg); taa_st(hist + 3 * i + 2, cb);
+        taa_st(prev_normal + 3 * i, nx); taa_st(prev_normal + 3 * i + 1, ny); taa_st(prev_normal + 3 * i + 2, nz);
+        taa_st(prev_depth + i, z_now);
+        taa_st(prev_sky + i, sky_now);
         return;
     }
-    float pr = hist[3 * i], pg = hist[3 * i + 1], pb = hist[3 * i + 2];
+    float pr = taa_ld(hist + 3 * i), pg = taa_ld(hist + 3 * i + 1), pb = taa_ld(hist + 3 * i + 2);
     float local_alpha = T.alpha;
-    if ((sky_now != 0) != (prev_sky[i] != 0)) {
+    if ((sky_now != 0) != (taa_ld(prev_sky + i) != 0)) {
         local_alpha = 1.0f;
     } else {
-        const float z_prev = prev_depth[i];
+        const float z_prev = taa_ld(prev_depth + i);
         F3 n_now = normalized(f3(nx, ny, nz));
-        F3 n_prev = normalized(f3(prev_normal[3 * i], prev_normal[3 * i + 1], prev_normal[3 * i + 2]));
+        F3 n_prev = normalized(f3(taa_ld(prev_normal + 3 * i), taa_ld(prev_normal + 3 * i + 1), taa_ld(prev_normal + 3 * i + 2)));
         if (!cs_isfinite(z_now) || !cs_isfinite(z_prev)) {
             local_alpha = 1.0f;
         } else {
@@ -1334,12 +1343,12 @@ __global__ __launch_bounds__(256) void k_taa(const TaaParams T, const float *__r
         float s = l_min / cs_max(1e-6f, prev_l);
         pr = pr * s; pg = pg * s; pb = pb * s;
     }
-    hist[3 * i] = pr * (1.0f - local_alpha) + cr * local_alpha;
-    hist[3 * i + 1] = pg * (1.0f - local_alpha) + cg * local_alpha;
-    hist[3 * i + 2] = pb * (1.0f - local_alpha) + cb * local_alpha;
-    prev_normal[3 * i] = nx; prev_normal[3 * i + 1] = ny; prev_normal[3 * i + 2] = nz;
-    prev_depth[i] = z_now;
-    prev_sky[i] = sky_now;
+    taa_st(hist + 3 * i, pr * (1.0f - local_alpha) + cr * local_alpha);
+    taa_st(hist + 3 * i + 1, pg * (1.0f - local_alpha) + cg * local_alpha);
+    taa_st(hist + 3 * i + 2, pb * (1.0f - local_alpha) + cb * local_alpha);
+    taa_st(prev_normal + 3 * i, nx); taa_st(prev_normal + 3 * i + 1, ny); taa_st(prev_normal + 3 * i + 2, nz);
+    taa_st(prev_depth + i, z_now);
+    taa_st(prev_sky + i, sky_now);
 }
 
 // ---------------------------------------------------------------------------------- tile slabs (multi-GPU)
@@ -1496,15 +1505,15 @@ int ycge_launch_wavefront(const ycge::SceneDev *S, const ycge::FrameParams *P, c
 }
 
 // builds next frame's k_trace schedule from this frame's per-block step counts.  ws: 18 uint32 (see k_cost_hist)
-int ycge_launch_order_blocks(uint32_t *cost, uint32_t n, uint32_t policy, uint32_t split_top, uint32_t fan_class, uint32_t fan_cap, uint32_t next_slot, uint32_t *ws,
-                             uint32_t *order, hipStream_t stream)
+int ycge_launch_order_blocks(uint32_t *cost, uint32_t n, uint32_t policy, uint32_t split_top, uint32_t fan_class, uint32_t fan_cap, uint32_t next_slot, uint32_t skip_slot,
+                             uint32_t *ws, uint32_t *order, hipStream_t stream)
 {
     if (n == 0) return 0;
     hipError_t e = hipMemsetAsync(ws, 0, 96 * sizeof(uint32_t), stream);     // ws[16] / ws[18] (entries, n_fan) are rewritten by k_cost_scatter before anyone reads them
     if (e != hipSuccess) return (int)e;
     const dim3 grid((n + 1023u) / 1024u), block(1024);
-    hipLaunchKernelGGL(ycge::k_cost_hist, grid, block, 0, stream, cost, n, ws);
-    hipLaunchKernelGGL(ycge::k_cost_scatter, grid, block, 0, stream, cost, n, n * YCGE_SCHEDULE_SLACK, policy, split_top, fan_class, fan_cap, next_slot, ws, order);
+    hipLaunchKernelGGL(ycge::k_cost_hist, grid, block, 0, stream, cost, n, skip_slot, ws);
+    hipLaunchKernelGGL(ycge::k_cost_scatter, grid, block, 0, stream, cost, n, n * YCGE_SCHEDULE_SLACK, policy, split_top, fan_class, fan_cap, next_slot, skip_slot, ws, order);
     return (int)hipGetLastError();
 }
 

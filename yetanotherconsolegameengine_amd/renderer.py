@@ -156,6 +156,21 @@ class RaytraceRenderer:
         self._check(self.L.ycge_render_frame(self.ctx, ptr, C.byref(self.stats)))
         return (sdr.copy() if copy else sdr) if want_sdr else self.stats
 
+    def RenderAsync(self):
+        """Frames in flight (ycge_render_frame_async): queues the next frame through TAA and returns; the trace of the frame after it
+        runs beside this one's TAA.  Same frames as TryFlipAndBlit() in the same order.  Wait() - or any other call - joins."""
+        self._check(self.L.ycge_render_frame_async(self.ctx))
+
+    def Wait(self):
+        self._check(self.L.ycge_wait(self.ctx))
+
+    def async_trace_ms(self, capacity: int = 1024) -> np.ndarray:
+        """Durations (ms) of the trace launches of the frames queued since the last call (waits for them), oldest first."""
+        a = np.zeros(capacity, dtype=np.float32)
+        n = C.c_int32()
+        self._check(self.L.ycge_async_trace_times(self.ctx, a.ctypes.data_as(C.POINTER(C.c_float)), capacity, C.byref(n)))
+        return a[:n.value].copy()
+
     # ---------------------------------------------------------------- multi-GPU halves
     def tile_slab_bytes(self) -> int:
         n = C.c_size_t()
