@@ -115,6 +115,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
     ap.add_argument("--no-post", action="store_true", help="skip the frames WITH the denoise/exposure/tonemap stage (reported apart as post_stage)")
+    ap.add_argument("--no-flight", action="store_true", help="skip the frames-in-flight leg (ycge_render_frame_async; reported apart as frames_in_flight)")
     ap.add_argument("--no-moving", action="store_true", help="skip the moving-camera leg (reported apart as moving_camera)")
     args = ap.parse_args()
 
@@ -344,7 +345,7 @@ def main():
         r.SetCamera(pose["pos"], pose["yaw"], pose["pitch"])
 
     flight = None
-    if single and not moving:        # frames in flight (ycge_render_frame_async; no counterpart in the reference): the same frames, queued without waiting
+    if single and not moving and not args.no_flight:        # frames in flight (ycge_render_frame_async; no counterpart in the reference): the same frames, queued without waiting
         n = min(args.steps, 300)
         for _ in range(args.warmup):
             r.RenderAsync()

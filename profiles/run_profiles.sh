@@ -8,7 +8,7 @@ REPO=${GRAFT_REPO_ROOT:-/root/repo}
 OUT=$REPO/gpurun_out/prof_$TAG
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
-BENCH="python3 $REPO/bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-post $*"
+BENCH="python3 $REPO/bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-post --no-flight $*"
 timeout 600 rocprofv3 --kernel-trace --stats -f csv -d $OUT/trace -o trace -- $BENCH > $OUT/trace.log 2>&1
 echo "trace rc=$?"
 i=0
@@ -29,5 +29,5 @@ if [ -x $REPO/profiles/micro/copycal ]; then
   timeout 300 rocprofv3 --kernel-trace --pmc WRITE_SIZE -f csv -d $OUT/pmc_calw -o calw -- $REPO/profiles/micro/copycal > $OUT/copycal_w.log 2>&1
 fi
 CFG=4; prev=""; for a in "$@"; do if [ "$prev" = "--config" ]; then CFG=$a; fi; prev=$a; done
-python3 $REPO/profiles/summarize.py $OUT --json $OUT/pmc_config$CFG.json --config $CFG --source "timeout 600 rocprofv3 --kernel-trace --stats + separate --pmc passes of: bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-post $* (tag $TAG)" > $OUT/summary.txt 2>&1
+python3 $REPO/profiles/summarize.py $OUT --json $OUT/pmc_config$CFG.json --config $CFG --source "timeout 600 rocprofv3 --kernel-trace --stats + separate --pmc passes of: bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-post --no-flight $* (tag $TAG)" > $OUT/summary.txt 2>&1
 cat $OUT/summary.txt
