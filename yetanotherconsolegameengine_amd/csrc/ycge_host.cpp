@@ -250,6 +250,8 @@ struct ycge_ctx {
     // staler than the synchronous path's, which builds it between the two traces), into the buffers frame N is not reading
     DevBuf<uint32_t> flight_order[2], flight_ws[2];
     int64_t flight_order_frame[2] = {-1, -1};      // the frame number each buffer's schedule was built for (-1: none)
+    hipEvent_t flight_order_ev[2] = {nullptr, nullptr};     // tiled frames: the schedule in each buffer is complete (side stream)
+    int64_t last_frame_deferred = -2;              // the newest tiled frame whose trace was followed by a deferred schedule
     bool in_flight_call = false;                   // trace_frame is called by ycge_render_frame_async
     std::vector<hipEvent_t> flight_ev;             // begin / end of the trace launches of the frames in flight, a ring (ycge_async_trace_times)
     uint64_t flight_frames = 0;                    // queued since the last ycge_async_trace_times
@@ -715,7 +717,7 @@ void ycge_destroy(ycge_ctx *c)
     c->t_hdr.release(); c->t_albedo.release(); c->t_normal.release(); c->t_depth.release(); c->t_sky.release();
     if (c->taa_stream) { (void)hipStreamSynchronize(c->taa_stream); (void)hipStreamDestroy(c->taa_stream); c->taa_stream = nullptr; }
     for (int k = 0; k < 2; k++) if (c->set_resolved_ev[k]) (void)hipEventDestroy(c->set_resolved_ev[k]);
-    for (int k = 0; k < 2; k++) { c->flight_order[k].release(); c->flight_ws[k].release(); }
+    for (int k = 0; k < 2; k++) { c->flight_order[k].release(); c->flight_ws[k].release(); if (c->flight_order_ev[k]) (void)hipEventDestroy(c->flight_order_ev[k]); }
     for (hipEvent_t ev : c->flight_ev) (void)hipEventDestroy(ev);
     c->flight_ev.clear();
     c->alt_hdr.release(); c->alt_albedo.release(); c->alt_normal.release(); c->alt_depth.release(); c->alt_sky.release();
@@ -1617,11 +1619,27 @@ int trace_frame(ycge_ctx *c, float *d_slab, hipStream_t stream, FrameState &fs, 
         O.block_cost = lpt ? c->block_cost.p + (size_t)cost_slot * n_blocks : nullptr;
         const int fk = (int)(fs.frame & 1);
         const bool flight = c->in_flight_call && lpt;
+        // A rank's share of a tiled frame (ycge_trace_tiles): callers queue the trace of frame N + 1 before frame N is gathered and
+        // resolved (bench.py's two streams), and then the schedule built BETWEEN the two traces is all that stands between them
+        // (34 us of kernels + two cross-stream hops against a rank's 0.29 ms at 8 ranks).  So a tiled frame's trace is followed by the
+        // schedule of frame N + 2 - it leaves out the cost slot frame N + 1's trace may be writing and clears frame N + 2's - and
+        // frame N + 1 runs with the order built behind frame N - 1.  The same buffers and rules as the frames in flight.
+        const bool deferred = slab && lpt && !flight;
         fs.scheduled = lpt;
         uint32_t policy, split_top;
         schedule_policy(c, policy, split_top);
+        if (deferred) {
+            for (int k = 0; k < 2; k++) {
+                if (!c->flight_order[k].p) { HIP_TRY(c, c->flight_order[k].alloc((size_t)n_blocks * YCGE_SCHEDULE_SLACK)); HIP_TRY(c, c->flight_ws[k].alloc(96)); HIP_TRY(c, hipMemset(c->flight_ws[k].p, 0, 96 * sizeof(uint32_t))); }
+                if (!c->flight_order_ev[k]) HIP_TRY(c, hipEventCreateWithFlags(&c->flight_order_ev[k], hipEventDisableTiming));
+            }
+            if (c->last_frame_deferred != fs.frame - 1)      // the frame before was not a tiled one: nobody has cleared the NEXT frame's cost slot
+                HIP_TRY(c, hipMemsetAsync(c->block_cost.p + (size_t)((cost_slot + 1u) % YCGE_COST_FRAMES) * n_blocks, 0, (size_t)n_blocks * sizeof(uint32_t), stream));
+            c->last_frame_deferred = fs.frame;
+        }
         if (lpt && c->flight_order_frame[fk] == fs.frame) {          // a schedule built in flight for exactly this frame (also the first synchronous frame after a burst);
             O.block_order = c->flight_order[fk].p;                   // ycge_render_frame_async has made the stream wait for it (set_resolved_ev), a synchronous caller has joined
+            if (deferred) HIP_TRY(c, hipStreamWaitEvent(stream, c->flight_order_ev[fk], 0));       // (built two frames ago on the side stream)
             O.n_order = c->flight_ws[fk].p + 16;
             if (c->order_pending) { HIP_TRY(c, hipStreamWaitEvent(stream, c->order_ev, 0)); c->order_pending = false; }        // (an older synchronous schedule still on the side stream: it cleared this frame's cost slot)
         } else {
@@ -1635,13 +1653,13 @@ int trace_frame(ycge_ctx *c, float *d_slab, hipStream_t stream, FrameState &fs, 
         // a schedule without fanned blocks (analytic scenes, small frames) skips k_trace_fan and the side stream altogether: the count
         // comes back through pinned memory and is a frame or two old when read here - either answer traces every block exactly once,
         // because k_trace is told (n_fan pointer or null) which convention this frame uses
-        const bool fan = O.block_order != nullptr && !flight_order && c->fan_cap > 0 && !(flat && refill_steps > 0) && c->h_n_fan && *(volatile uint32_t *)c->h_n_fan > 0;       // (schedules built in flight have no fanned head)
+        const bool fan = O.block_order != nullptr && (!flight_order || deferred) && c->fan_cap > 0 && !(flat && refill_steps > 0) && c->h_n_fan && *(volatile uint32_t *)c->h_n_fan > 0;       // (schedules of ycge_render_frame_async have no fanned head)
         if (launch_begin) HIP_TRY(c, hipEventRecord(launch_begin, stream));       // (behind the wait for the schedule)
         if (fan) {
             fs.fan_blocks = *(volatile uint32_t *)c->h_n_fan;      // what the last finished schedule handed to k_trace_fan (this frame's may differ by a few)
             // k_trace_fan goes FIRST and on the frame's stream, so that its blocks - the frame's longest chains - are resident from
             // t = 0; the rest of the schedule follows on the side stream (forked before, joined after) and fills in around them
-            O.n_fan = c->order_ws.p + 18;
+            O.n_fan = O.n_order + 2;          // (word 18 of the schedule's work space, whichever buffer this frame reads)
             TraceOut OF = O;
             OF.lane_base = trace_lanes;
             HIP_TRY(c, hipEventRecord(c->fan_ev[0], stream));
@@ -1656,6 +1674,14 @@ int trace_frame(ycge_ctx *c, float *d_slab, hipStream_t stream, FrameState &fs, 
         if (launch_end) HIP_TRY(c, hipEventRecord(launch_end, stream));
         if (e == 0 && flight) {
             // (frames in flight: the schedule of frame N + 2 follows this frame's TAA on the second stream, ycge_render_frame_async)
+        } else if (e == 0 && deferred) {
+            HIP_TRY(c, hipEventRecord(c->traced_ev, stream));
+            HIP_TRY(c, hipStreamWaitEvent(c->fan_stream, c->traced_ev, 0));
+            e = ycge_launch_order_blocks(c->block_cost.p, n_blocks, policy, split_top, c->fan_class, c->fan_cap, (cost_slot + 2u) % YCGE_COST_FRAMES, (cost_slot + 1u) % YCGE_COST_FRAMES,
+                                         c->flight_ws[fk].p, c->flight_order[fk].p, c->fan_stream);
+            if (e == 0 && c->h_n_fan && c->fan_cap > 0) HIP_TRY(c, hipMemcpyAsync(c->h_n_fan, c->flight_ws[fk].p + 18, sizeof(uint32_t), hipMemcpyDeviceToHost, c->fan_stream));
+            HIP_TRY(c, hipEventRecord(c->flight_order_ev[fk], c->fan_stream));
+            c->flight_order_frame[fk] = fs.frame + 2;
         } else if (e == 0 && lpt) {
             // the next frame's schedule needs this frame's trace and nothing else: built on the side stream, beside TAA (or the slab
             // pack and all-gather), instead of 25 us in front of it; the next trace waits for it (order_ev)

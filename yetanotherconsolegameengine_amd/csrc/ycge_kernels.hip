@@ -134,6 +134,14 @@ __device__ __forceinline__ uint32_t block_compact(bool want, uint32_t *s_cnt /* 
     return base + prefix;
 }
 
+// A frame's per-pixel results - G-buffer planes, the sky flag, the HDR colour of the single-launch kernel - are written once and read
+// after the launch (TAA, the post stage): non-temporal stores, so that they do not push the tree out of the L2s while the trace runs
+// (config 3: trace 0.291 -> 0.280 ms; config 4 0.492 -> 0.490, in flight 0.535 -> 0.530).
+#ifndef YCGE_OUT_NT
+#define YCGE_OUT_NT 1
+#endif
+template <class T> __device__ __forceinline__ void out_st(T *p, T v) { if (YCGE_OUT_NT) __builtin_nontemporal_store(v, p); else *p = v; }
+
 // ---------------------------------------------------------------------------------- k_wf_primary
 // one workgroup per owned 32x8 tile: the hardware dispatcher balances the (very uneven) tiles
 template <bool COUNT, bool HAS_GRID, bool FLAT>
@@ -362,10 +370,10 @@ __global__ __launch_bounds__(256) void k_wf_shade(const SceneDev S, const FrameP
             F3 sky = lerp3(f3(S.bg_bottom), f3(S.bg_top), tbg);
             rad = rad + f3(beta.x * sky.x, beta.y * sky.y, beta.z * sky.z);
             if (ROUND0) {           // item.IsPrimary && !primaryHitSomething: sky G-buffer, :476-484
-                O.g_albedo[3 * (size_t)pixel] = 0.0f; O.g_albedo[3 * (size_t)pixel + 1] = 0.0f; O.g_albedo[3 * (size_t)pixel + 2] = 0.0f;
-                O.g_normal[3 * (size_t)pixel] = 0.0f; O.g_normal[3 * (size_t)pixel + 1] = 0.0f; O.g_normal[3 * (size_t)pixel + 2] = 0.0f;
-                O.g_depth[pixel] = YCGE_FLT_MAX;
-                O.sky[pixel] = 1;
+                out_st(O.g_albedo + 3 * (size_t)pixel, 0.0f); out_st(O.g_albedo + 3 * (size_t)pixel + 1, 0.0f); out_st(O.g_albedo + 3 * (size_t)pixel + 2, 0.0f);
+                out_st(O.g_normal + 3 * (size_t)pixel, 0.0f); out_st(O.g_normal + 3 * (size_t)pixel + 1, 0.0f); out_st(O.g_normal + 3 * (size_t)pixel + 2, 0.0f);
+                out_st(O.g_depth + pixel, YCGE_FLT_MAX);
+                out_st(O.sky + pixel, (uint8_t)1);
                 if (DEBUG) { if (O.prim_id) O.prim_id[pixel] = -1; if (O.sub_id) O.sub_id[pixel] = 0; if (O.hit_t) O.hit_t[pixel] = YCGE_FLT_MAX; }
             }
         } else {
@@ -373,10 +381,10 @@ __global__ __launch_bounds__(256) void k_wf_shade(const SceneDev S, const FrameP
             resolve_hit<HAS_GRID>(S, hit_prim, hit_sub, t_hit, o, d, h);
             if (YCGE_TEXTURES && S.any_textured) apply_texture(S, hit_prim, hit_sub, o, d, h);
             if (ROUND0) {           // primary G-buffer, :488-499
-                O.g_albedo[3 * (size_t)pixel] = h.m.albedo.x; O.g_albedo[3 * (size_t)pixel + 1] = h.m.albedo.y; O.g_albedo[3 * (size_t)pixel + 2] = h.m.albedo.z;
-                O.g_normal[3 * (size_t)pixel] = h.n.x; O.g_normal[3 * (size_t)pixel + 1] = h.n.y; O.g_normal[3 * (size_t)pixel + 2] = h.n.z;
-                O.g_depth[pixel] = t_hit;
-                O.sky[pixel] = 0;
+                out_st(O.g_albedo + 3 * (size_t)pixel, h.m.albedo.x); out_st(O.g_albedo + 3 * (size_t)pixel + 1, h.m.albedo.y); out_st(O.g_albedo + 3 * (size_t)pixel + 2, h.m.albedo.z);
+                out_st(O.g_normal + 3 * (size_t)pixel, h.n.x); out_st(O.g_normal + 3 * (size_t)pixel + 1, h.n.y); out_st(O.g_normal + 3 * (size_t)pixel + 2, h.n.z);
+                out_st(O.g_depth + pixel, t_hit);
+                out_st(O.sky + pixel, (uint8_t)0);
                 if (DEBUG) { if (O.prim_id) O.prim_id[pixel] = hit_prim; if (O.sub_id) O.sub_id[pixel] = h.sub_public; if (O.hit_t) O.hit_t[pixel] = t_hit; }
             }
             if (h.m.emission.x != 0.0f || h.m.emission.y != 0.0f || h.m.emission.z != 0.0f) {
@@ -706,10 +714,11 @@ __device__ __forceinline__ void trace_block(const SceneDev &S, const FrameParams
     auto pixel_index = [&]() { int x = px, y = py; asm volatile("" : "+v"(x), "+v"(y)); return (size_t)x + (size_t)y * P.hiW; };
     auto write_gbuffer = [&](F3 g_albedo, F3 g_normal, float g_depth, int g_prim, int g_sub, bool is_sky) {
         const size_t i = pixel_index();
-        O.g_albedo[3 * i + 0] = g_albedo.x; O.g_albedo[3 * i + 1] = g_albedo.y; O.g_albedo[3 * i + 2] = g_albedo.z;
-        O.g_normal[3 * i + 0] = g_normal.x; O.g_normal[3 * i + 1] = g_normal.y; O.g_normal[3 * i + 2] = g_normal.z;
-        O.g_depth[i] = g_depth;
-        O.sky[i] = is_sky ? 1 : 0;
+        // (written once, read by TAA / the post stage after the launch: past the caches' keep lists, the tree stays in the L2s)
+        out_st(O.g_albedo + 3 * i + 0, g_albedo.x); out_st(O.g_albedo + 3 * i + 1, g_albedo.y); out_st(O.g_albedo + 3 * i + 2, g_albedo.z);
+        out_st(O.g_normal + 3 * i + 0, g_normal.x); out_st(O.g_normal + 3 * i + 1, g_normal.y); out_st(O.g_normal + 3 * i + 2, g_normal.z);
+        out_st(O.g_depth + i, g_depth);
+        out_st(O.sky + i, (uint8_t)(is_sky ? 1 : 0));
         if (DEBUG) {
             if (O.prim_id) O.prim_id[i] = g_prim;
             if (O.sub_id) O.sub_id[i] = g_sub;
@@ -743,7 +752,7 @@ __device__ __forceinline__ void trace_block(const SceneDev &S, const FrameParams
     auto finish_block = [&]() {
     if (in_image) {                                     // :210-215
         const size_t i = pixel_index();
-        O.current_hdr[3 * i + 0] = radiance.x; O.current_hdr[3 * i + 1] = radiance.y; O.current_hdr[3 * i + 2] = radiance.z;
+        out_st(O.current_hdr + 3 * i + 0, radiance.x); out_st(O.current_hdr + 3 * i + 1, radiance.y); out_st(O.current_hdr + 3 * i + 2, radiance.z);
         if (DEBUG && O.rng_state) O.rng_state[i] = rng;
     }
     // a part of a split block sees fewer lanes, hence fewer iterations than the whole block would: scaled so that the block
