@@ -29,6 +29,8 @@ for line in r.stderr.splitlines():
     elif ":" in t:
         k, v = t.split(":", 1)
         cur[k.strip()] = v.strip()
+if not rows:
+    sys.exit("no kernels found (did the compile fail?)\n" + r.stderr[-2000:])
 dem = subprocess.run(["c++filt"] + [r_["name"] for r_ in rows], capture_output=True, text=True).stdout.splitlines()
 for r_, d in zip(rows, dem):
     d = d.replace("ycge::", "").split("(")[0].replace("void ", "")

@@ -1,8 +1,4 @@
 #!/bin/bash
 REPO=${GRAFT_REPO_ROOT:-/root/repo}; cd $REPO
-python -m pytest tests/test_gpu_timed_variants.py -x -q -m gpu -k "voxel" 2>&1 | tail -2
-for rep in 1 2; do
-timeout 300 python profiles/flight_ab.py 5 100 2>&1 | tail -1
-echo "== ordinary stores"
-YCGE_LIB=$REPO/yetanotherconsolegameengine_amd/lib/libycge_hip_nt0.so timeout 300 python profiles/flight_ab.py 5 100 2>&1 | tail -1
-done
+timeout 900 python -m pytest tests/test_gpu_timed_variants.py -x -q -m gpu 2>&1 | tail -2
+for c in 4 3 2 5; do timeout 300 python profiles/flight_ab.py $c 300 2>&1 | tail -1; done

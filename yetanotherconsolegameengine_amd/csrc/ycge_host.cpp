@@ -31,11 +31,11 @@ int ycge_launch_trace(const ycge::SceneDev *S, const ycge::FrameParams *P, const
 int ycge_launch_wavefront(const ycge::SceneDev *S, const ycge::FrameParams *P, const ycge::TraceOut *O, void *const bufs[7], int rounds,
                           int has_grid, int flat, int count, int persistent_waves, hipStream_t stream);
 int ycge_launch_order_blocks(uint32_t *cost, uint32_t n, uint32_t policy, uint32_t split_top, uint32_t fan_class, uint32_t fan_cap, uint32_t next_slot, uint32_t skip_slot, uint32_t *order_ws,
-                             uint32_t *order, hipStream_t stream);
+                             uint32_t *order, hipStream_t stream, int small_groups = 0);
 int ycge_launch_trace_fan(const ycge::SceneDev *S, const ycge::FrameParams *P, const ycge::TraceOut *O, int count, int flat, uint32_t fan_cap,
                           hipStream_t stream);
 int ycge_launch_taa(const ycge::TaaParams *T, const float *current, const float *normal, const float *depth, const uint8_t *sky,
-                    float *hist, float *prev_normal, float *prev_depth, uint8_t *prev_sky, hipStream_t stream);
+                    float *hist, float *prev_normal, float *prev_depth, uint8_t *prev_sky, hipStream_t stream, int small_groups = 0);
 size_t ycge_post_state_bytes(void);
 int ycge_atrous_persist_resident(int groups_per_pass, int split, int level_handover, int profile);
 void ycge_atrous_duo_pad_lds(int bytes);
@@ -121,7 +121,10 @@ struct Knobs {
     int post_probe_band = -1;        // YCGE_POST_PROBE_BAND: this band and the next record a per-pass timeline (profiles/post_bands.py)
     int post_assume_resident = 0;    // YCGE_POST_ASSUME_RESIDENT (tests): take this for the runtime's answer - more bands than fit, to exercise the order-of-arrival numbering
     bool post_dbg_free = false;      // YCGE_POST_DBG_FREE (timing experiment, WRONG pixels): no band of the persistent in-place A-trous waits for the band above
-    bool flight_same_priority = false, flight_no_begin = false;      // experiments on ycge_render_frame_async: second stream at normal priority; no begin-of-trace timing event
+    bool flight_small_groups = true; // YCGE_FLIGHT_SMALL_GROUPS: TAA and schedule kernels of the frames in flight in small workgroups (they find room beside a running trace)
+    int flight_priority = 1;         // YCGE_FLIGHT_PRIORITY: the second stream's priority: 1 highest, 0 normal, -1 lowest
+    bool flight_overlap = true;      // YCGE_FLIGHT_OVERLAP: frames in flight alternate between two trace streams (two traces may overlap)
+    bool flight_no_begin = false;      // experiments on ycge_render_frame_async: second stream at normal priority; no begin-of-trace timing event
     int post_pad_lds = 0;            // YCGE_POST_PAD_LDS (experiment): bytes of unused LDS per band workgroup of the two-set form - fewer of them on a CU
     int post_resident_per_cu = 3;    // YCGE_POST_RESIDENT: band workgroups of the persistent in-place A-trous a CU may hold (3 fit: 576 threads, 46 KB of LDS each)
     bool post_hash = false;          // YCGE_POST_HASH_FORM=1: the hash form of k_atrous_band even where the window fits
@@ -156,7 +159,10 @@ struct Knobs {
         post_assume_resident = geti("YCGE_POST_ASSUME_RESIDENT", 0);
         if (post_resident_per_cu < 1 || post_resident_per_cu > 3) post_resident_per_cu = 3;
         post_pad_lds = geti("YCGE_POST_PAD_LDS", 0);
-        flight_same_priority = geti("YCGE_FLIGHT_SAME_PRIORITY", 0) != 0; flight_no_begin = geti("YCGE_FLIGHT_NO_BEGIN", 0) != 0;
+        flight_overlap = geti("YCGE_FLIGHT_OVERLAP", 1) != 0;
+        flight_small_groups = geti("YCGE_FLIGHT_SMALL_GROUPS", 1) != 0;
+        flight_priority = geti("YCGE_FLIGHT_PRIORITY", 1);
+        flight_no_begin = geti("YCGE_FLIGHT_NO_BEGIN", 0) != 0;
         post_dbg_free = geti("YCGE_POST_DBG_FREE", 0) != 0;
         exposure_serial = getenv("YCGE_EXPOSURE_SERIAL") != nullptr;
         no_coop = getenv("YCGE_NO_COOP") != nullptr;
@@ -241,7 +247,10 @@ struct ycge_ctx {
     // alternate between the five buffers above and these (swapped before the trace: the names above are always the newest frame's)
     DevBuf<float> alt_hdr, alt_albedo, alt_normal, alt_depth;
     DevBuf<uint8_t> alt_sky;
-    hipStream_t taa_stream = nullptr;
+    hipStream_t taa_stream = nullptr, stream2 = nullptr;      // stream2: the traces of odd frames in flight (two traces may overlap: the tail of one, the bulk of the next)
+    DevBuf<uint64_t> stack_spill2;                 // ... which then need a traversal-stack spill area of their own
+    uint64_t *spill_override = nullptr;            // set around trace_frame by ycge_render_frame_async
+    hipEvent_t flight_fork_ev = nullptr;
     hipEvent_t set_resolved_ev[2] = {nullptr, nullptr};
     bool set_read[2] = {false, false};             // a TAA launch on taa_stream has read this set: the next trace into it waits for set_resolved_ev
     int out_set = 0;                               // which set the names above hold
@@ -252,6 +261,7 @@ struct ycge_ctx {
     int64_t flight_order_frame[2] = {-1, -1};      // the frame number each buffer's schedule was built for (-1: none)
     hipEvent_t flight_order_ev[2] = {nullptr, nullptr};     // tiled frames: the schedule in each buffer is complete (side stream)
     int64_t last_frame_deferred = -2;              // the newest tiled frame whose trace was followed by a deferred schedule
+    bool in_flight_taa = false;                    // taa_and_commit is called by ycge_render_frame_async with two traces overlapping: one-wavefront workgroups
     bool in_flight_call = false;                   // trace_frame is called by ycge_render_frame_async
     std::vector<hipEvent_t> flight_ev;             // begin / end of the trace launches of the frames in flight, a ring (ycge_async_trace_times)
     uint64_t flight_frames = 0;                    // queued since the last ycge_async_trace_times
@@ -367,6 +377,7 @@ int alloc_tile_buffers(ycge_ctx *c)
     HIP_TRY(c, c->wf_seg.alloc(4));
     HIP_TRY(c, c->wf_counts.alloc((size_t)(c->n_owned > 0 ? c->n_owned : 1) * 8));
     HIP_TRY(c, c->stack_spill.alloc((size_t)(c->spill_levels > 0 ? c->spill_levels : 1) * stack_lanes));
+    c->stack_spill2.release();
     c->path_stack.release();
    
     {
@@ -612,7 +623,9 @@ static int create_one(const ycge_config *cfg, ycge_ctx *parent, ycge_ctx **out)
             // next - yield to the running trace's workgroups (measured neutral: 0.548 against 0.551 ms at normal priority)
             int lo = 0, hi = 0;
             if (hipDeviceGetStreamPriorityRange(&lo, &hi) != hipSuccess ||
-                hipStreamCreateWithPriority(&c->taa_stream, hipStreamNonBlocking, c->knobs.flight_same_priority ? 0 : lo) != hipSuccess) { c->err = "hipStreamCreate failed"; return bail(YCGE_ERR_DEVICE); }
+                hipStreamCreateWithPriority(&c->taa_stream, hipStreamNonBlocking, c->knobs.flight_priority > 0 ? hi : c->knobs.flight_priority < 0 ? lo : 0) != hipSuccess ||
+                hipStreamCreateWithFlags(&c->stream2, hipStreamNonBlocking) != hipSuccess ||
+                hipEventCreateWithFlags(&c->flight_fork_ev, hipEventDisableTiming) != hipSuccess) { c->err = "hipStreamCreate failed"; return bail(YCGE_ERR_DEVICE); }
         }
         for (hipEvent_t *ev : {&c->fan_ev[0], &c->fan_ev[1], &c->traced_ev, &c->order_ev, &c->pushed_ev})
             if (hipEventCreateWithFlags(ev, hipEventDisableTiming) != hipSuccess) { c->err = "hipEventCreate failed"; return bail(YCGE_ERR_DEVICE); }
@@ -716,6 +729,9 @@ void ycge_destroy(ycge_ctx *c)
     c->counters.release(); c->wave_prof.release(); c->own_slab.release(); c->dbg_counters.release();
     c->t_hdr.release(); c->t_albedo.release(); c->t_normal.release(); c->t_depth.release(); c->t_sky.release();
     if (c->taa_stream) { (void)hipStreamSynchronize(c->taa_stream); (void)hipStreamDestroy(c->taa_stream); c->taa_stream = nullptr; }
+    if (c->stream2) { (void)hipStreamSynchronize(c->stream2); (void)hipStreamDestroy(c->stream2); c->stream2 = nullptr; }
+    if (c->flight_fork_ev) (void)hipEventDestroy(c->flight_fork_ev);
+    c->stack_spill2.release();
     for (int k = 0; k < 2; k++) if (c->set_resolved_ev[k]) (void)hipEventDestroy(c->set_resolved_ev[k]);
     for (int k = 0; k < 2; k++) { c->flight_order[k].release(); c->flight_ws[k].release(); if (c->flight_order_ev[k]) (void)hipEventDestroy(c->flight_order_ev[k]); }
     for (hipEvent_t ev : c->flight_ev) (void)hipEventDestroy(ev);
@@ -1572,6 +1588,17 @@ void schedule_policy(const ycge_ctx *c, uint32_t &policy, uint32_t &split_top)
     split_top = (c->knobs.split_set || policy || c->knobs.split_top <= 0) ? 0u : ((uint32_t)c->knobs.split_top & 0xffffu) | ((uint32_t)c->knobs.split_top_lg << 16);
 }
 
+// (a scene with a textured material takes the generic kernels: the flat ones - configs 3 and 4 - are compiled without the texture
+// branch, which cost them 1.6 % when it was merely present, profiles/tex_ab.sh)
+int scene_is_flat(const ycge_ctx *c)
+{
+    return (YCGE_REF_KIND(c->sd.scene_root_ref) == REF_SCENE_LEAF && !c->knobs.generic_walk && !c->sd.any_textured) ? 1 : 0;      // YCGE_GENERIC_WALK: experiment knob, same pixels
+}
+bool frame_is_single_launch(const ycge_ctx *c)
+{
+    return c->sd.any_transparent || c->knobs.path_policy == 2 || (c->knobs.path_policy == 0 && scene_is_flat(c));
+}
+
 // step 4 (RaytraceRenderer.cs:183-216): ray-gen + trace of this context's tiles for the frame `fs`
 int trace_frame(ycge_ctx *c, float *d_slab, hipStream_t stream, FrameState &fs, bool timed, hipEvent_t launch_begin = nullptr, hipEvent_t launch_end = nullptr /* frames in flight: around the trace launches alone */)
 {
@@ -1597,18 +1624,16 @@ int trace_frame(ycge_ctx *c, float *d_slab, hipStream_t stream, FrameState &fs, 
     if (c->cfg.count_work) HIP_TRY(c, hipMemsetAsync(c->counters.p, 0, 6 * sizeof(unsigned long long), stream));
     if (timed) HIP_TRY(c, hipEventRecord(c->ev[0], stream));
     int e;
-    O.stack_spill = c->stack_spill.p;
+    O.stack_spill = c->spill_override ? c->spill_override : c->stack_spill.p;
     const uint32_t trace_lanes = (uint32_t)(c->n_owned > 0 ? c->n_owned : 1) * 256u * YCGE_SCHEDULE_SLACK;
     O.stack_lanes = trace_lanes + c->fan_cap * 192u;
     O.path_stack = c->path_stack.p;
-    // (a scene with a textured material takes the generic kernels: the flat ones - configs 3 and 4 - are compiled without the texture
-    // branch, which cost them 1.6 % when it was merely present, profiles/tex_ab.sh)
-    const int flat = (YCGE_REF_KIND(c->sd.scene_root_ref) == REF_SCENE_LEAF && !c->knobs.generic_walk && !c->sd.any_textured) ? 1 : 0;      // YCGE_GENERIC_WALK: experiment knob, same pixels
+    const int flat = scene_is_flat(c);
     // Path choice.  Refraction splits need TraceFull's per-pixel LIFO -> single launch.  Otherwise: scenes
     // that are one BVH leaf (mesh viewers) are bounded by the latency chain of their few heaviest tiles, and
     // one launch lets the chains of all stages overlap (measured 0.85 vs 1.24 ms on config 4); scenes with a
     // real top-level tree (voxel worlds) are throughput-bound and run 1.7x faster as occupancy-friendly stages.
-    const bool single_launch = c->sd.any_transparent || c->knobs.path_policy == 2 || (c->knobs.path_policy == 0 && flat);
+    const bool single_launch = frame_is_single_launch(c);
     if (single_launch) {
         // TraceFull's per-pixel LIFO is only ever touched at a refractive hit: scenes without transparent materials get none (0.5 GB at 1080p)
         if (!c->path_stack.p && c->sd.any_transparent) HIP_TRY(c, c->path_stack.alloc((size_t)3 * 11 * O.stack_lanes));
@@ -1726,7 +1751,7 @@ int taa_and_commit(ycge_ctx *c, hipStream_t stream, FrameState &fs, bool &did_re
     did_reset = !c->taa_valid || fs.reset;                        // :285
     T.reset = did_reset ? 1 : 0;
     int e = ycge_launch_taa(&T, c->current_hdr.p, c->g_normal.p, c->g_depth.p, c->sky.p, c->taa_hist.p, c->prev_normal.p, c->prev_depth.p,
-                            c->prev_sky.p, stream);
+                            c->prev_sky.p, stream, c->in_flight_taa ? 1 : 0);
     if (e != 0) return c->fail(YCGE_ERR_DEVICE, "k_taa launch failed: %s", hipGetErrorString((hipError_t)e));
     if (timed) HIP_TRY(c, hipEventRecord(c->ev[2], stream));
     c->taa_valid = true;
@@ -2163,6 +2188,7 @@ static int join_async(ycge_ctx *c)
     if (!c->async_outstanding) return YCGE_OK;
     HIP_TRY(c, hipSetDevice(c->device));
     HIP_TRY(c, hipStreamSynchronize(c->stream));
+    if (c->stream2) HIP_TRY(c, hipStreamSynchronize(c->stream2));
     HIP_TRY(c, hipStreamSynchronize(c->taa_stream));
     c->async_outstanding = false;
     c->set_read[0] = c->set_read[1] = false;
@@ -2187,6 +2213,16 @@ int ycge_async_trace_times(ycge_ctx *c, float *ms_out, int32_t capacity, int32_t
     for (uint64_t i = 0; i < n; i++) {
         const size_t slot = (size_t)((c->flight_frames - n + i) % YCGE_FLIGHT_RING);
         HIP_TRY(c, hipEventElapsedTime(&ms_out[i], c->flight_ev[2 * slot], c->flight_ev[2 * slot + 1]));
+    }
+    if (getenv("YCGE_FLIGHT_DEBUG") && n > 12) {        // profiling aid: how the last frames' traces lie to each other (negative end -> next begin: they overlap)
+        for (uint64_t i = n - 10; i + 1 < n; i++) {
+            const size_t s0 = (size_t)((c->flight_frames - n + i) % YCGE_FLIGHT_RING), s1 = (size_t)((c->flight_frames - n + i + 1) % YCGE_FLIGHT_RING);
+            float bb = 0, eb = 0, d = 0;
+            (void)hipEventElapsedTime(&bb, c->flight_ev[2 * s0], c->flight_ev[2 * s1]);
+            (void)hipEventElapsedTime(&eb, c->flight_ev[2 * s0 + 1], c->flight_ev[2 * s1]);
+            (void)hipEventElapsedTime(&d, c->flight_ev[2 * s0], c->flight_ev[2 * s0 + 1]);
+            fprintf(stderr, "frame %llu: duration %.4f begin->next begin %.4f end->next begin %.4f\n", (unsigned long long)i, d, bb, eb);
+        }
     }
     *n_out = (int32_t)n;
     c->flight_frames = 0;
@@ -2216,6 +2252,19 @@ int ycge_render_frame_async(ycge_ctx *c)
         if (!c->flight_order[k].p) { HIP_TRY(c, c->flight_order[k].alloc((size_t)n_blocks * YCGE_SCHEDULE_SLACK)); HIP_TRY(c, c->flight_ws[k].alloc(96)); HIP_TRY(c, hipMemset(c->flight_ws[k].p, 0, 96 * sizeof(uint32_t))); }
     FrameState fs;
     snapshot_frame(c, fs);
+    // Two traces at a time: odd frames go to a second stream, so that the bulk of frame N + 1 fills the wavefront slots the tail of frame
+    // N leaves empty (a third of a trace's slot-time on config 4: its last chains).  Nothing else changes - frame N + 1's trace never
+    // needed frame N's: its order, its cost slot and its output set are ready once the second stream's work of frame N - 1 is done, which
+    // is the one event it waits for.  Only the single-launch kernel (the stage pipeline of voxel worlds shares its queues between frames)
+    // and only without refraction stacks.
+    const bool overlap = c->knobs.flight_overlap && c->stream2 && c->have_scene && frame_is_single_launch(c) && !c->sd.any_transparent && (fs.frame & 1);
+    hipStream_t ts = overlap ? c->stream2 : c->stream;
+    if (overlap && !c->stack_spill2.p) HIP_TRY(c, c->stack_spill2.alloc(c->stack_spill.n));
+    if (!c->async_outstanding) {
+        // (whatever the synchronous calls left on the context's stream is ahead of the second trace stream's first trace too)
+        HIP_TRY(c, hipEventRecord(c->flight_fork_ev, c->stream));
+        if (c->stream2) HIP_TRY(c, hipStreamWaitEvent(c->stream2, c->flight_fork_ev, 0));
+    }
     if (!c->async_outstanding) {
         // the first frame in flight after synchronous calls.  Whatever they left on the context's stream (a TAA, a post stage that reads
         // the current set) is ahead of this trace in stream order, and the second stream's first TAA waits for this trace.  The
@@ -2229,18 +2278,23 @@ int ycge_render_frame_async(ycge_ctx *c)
     const int k = c->out_set;
     // ONE wait per frame on the trace's stream: the second stream's work of two frames ago - TAA (it read this set of buffers) and
     // behind it the schedule for THIS frame (it wrote the order buffer of this parity and cleared this frame's cost slot)
-    if (c->set_read[k]) HIP_TRY(c, hipStreamWaitEvent(c->stream, c->set_resolved_ev[k], 0));
+    if (c->set_read[k]) HIP_TRY(c, hipStreamWaitEvent(ts, c->set_resolved_ev[k], 0));
     const size_t slot = (size_t)(c->flight_frames % YCGE_FLIGHT_RING);
     hipEvent_t ev_begin = c->knobs.flight_no_begin ? nullptr : c->flight_ev[2 * slot], ev_end = c->flight_ev[2 * slot + 1];
     c->in_flight_call = true;
-    int rc = trace_frame(c, nullptr, c->stream, fs, false, ev_begin, nullptr);
+    c->spill_override = overlap ? c->stack_spill2.p : nullptr;
+    int rc = trace_frame(c, nullptr, ts, fs, false, ev_begin, nullptr);
+    c->spill_override = nullptr;
     c->in_flight_call = false;
     if (rc != YCGE_OK) return rc;
-    HIP_TRY(c, hipEventRecord(ev_end, c->stream));          // end of the trace: the timing ring's event is also what the second stream waits for
+    HIP_TRY(c, hipEventRecord(ev_end, ts));          // end of the trace: the timing ring's event is also what the second stream waits for
     c->flight_frames++;
     HIP_TRY(c, hipStreamWaitEvent(c->taa_stream, ev_end, 0));
     bool did_reset = false;
+    const bool small = c->knobs.flight_overlap && c->knobs.flight_small_groups;
+    c->in_flight_taa = small;
     rc = taa_and_commit(c, c->taa_stream, fs, did_reset, false);
+    c->in_flight_taa = false;
     if (rc != YCGE_OK) return rc;
     if (fs.scheduled) {
         // the schedule of frame N + 2, from the costs up to this frame's: the slot frame N + 1's trace is writing meanwhile is left out,
@@ -2249,7 +2303,7 @@ int ycge_render_frame_async(ycge_ctx *c)
         schedule_policy(c, policy, split_top);
         const uint32_t next_writes = (uint32_t)((uint64_t)(fs.frame + 1) % YCGE_COST_FRAMES), target = (uint32_t)((uint64_t)(fs.frame + 2) % YCGE_COST_FRAMES);
         const int fk = (int)(fs.frame & 1);
-        const int e = ycge_launch_order_blocks(c->block_cost.p, n_blocks, policy, split_top, 0u, 0u, target, next_writes, c->flight_ws[fk].p, c->flight_order[fk].p, c->taa_stream);
+        const int e = ycge_launch_order_blocks(c->block_cost.p, n_blocks, policy, split_top, 0u, 0u, target, next_writes, c->flight_ws[fk].p, c->flight_order[fk].p, c->taa_stream, small ? 1 : 0);
         if (e != 0) return c->fail(YCGE_ERR_DEVICE, "schedule launch failed: %s", hipGetErrorString((hipError_t)e));
         c->flight_order_frame[fk] = fs.frame + 2;
     }

@@ -1188,7 +1188,7 @@ __global__ __launch_bounds__(1024) void k_cost_hist(const uint32_t *__restrict__
     __shared__ uint32_t h[YCGE_ORDER_CLASSES];
     if (threadIdx.x < YCGE_ORDER_CLASSES) h[threadIdx.x] = 0;
     __syncthreads();
-    const uint32_t i = blockIdx.x * 1024u + threadIdx.x;
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i < n) { const int cls = order_class(smoothed_cost(cost, n, i, skip_slot)); atomicAdd(&h[cls], 1u); }
     __syncthreads();
     if (threadIdx.x < YCGE_ORDER_CLASSES && h[threadIdx.x]) atomicAdd(&ws[32 + threadIdx.x], h[threadIdx.x]);
@@ -1237,7 +1237,7 @@ __global__ __launch_bounds__(1024) void k_cost_scatter(uint32_t *__restrict__ co
     __syncthreads();
     const bool split = s_split != 0;
     if (threadIdx.x < YCGE_ORDER_CLASSES) lay[threadIdx.x] = class_layout(ws, (int)threadIdx.x, policy, split_top, split);
-    const uint32_t i = blockIdx.x * 1024u + threadIdx.x;
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     int cls = -1;
     uint32_t local = 0;
     if (i < n) {
@@ -1271,12 +1271,10 @@ template <class T> __device__ __forceinline__ T taa_ld(const T *p) { return YCGE
 template <class T> __device__ __forceinline__ void taa_st(T *p, T v) { if (YCGE_TAA_NT) __builtin_nontemporal_store(v, p); else *p = v; }
 // TemporalBlendWithClamp, RaytraceRenderer.cs:274-398.  One thread per pixel; the history and
 // guide updates touch only the thread's own pixel, so the serial loops of the C# fuse into one pass.
-__global__ __launch_bounds__(256) void k_taa(const TaaParams T, const float *__restrict__ current, const float *__restrict__ normal,
+__device__ __forceinline__ void taa_pixel(const TaaParams &T, const int x, const int y, const float *__restrict__ current, const float *__restrict__ normal,
                                              const float *__restrict__ depth, const uint8_t *__restrict__ sky, float *__restrict__ hist,
                                              float *__restrict__ prev_normal, float *__restrict__ prev_depth, uint8_t *__restrict__ prev_sky)
 {
-    const int x = blockIdx.x * 32 + (threadIdx.x & 31);
-    const int y = blockIdx.y * 8 + (threadIdx.x >> 5);
     if (x >= T.w || y >= T.h) return;
     const size_t i = (size_t)x + (size_t)y * T.w;
     const float cr = current[3 * i], cg = current[3 * i + 1], cb = current[3 * i + 2];
@@ -1358,6 +1356,15 @@ __global__ __launch_bounds__(256) void k_taa(const TaaParams T, const float *__r
     taa_st(prev_normal + 3 * i, nx); taa_st(prev_normal + 3 * i + 1, ny); taa_st(prev_normal + 3 * i + 2, nz);
     taa_st(prev_depth + i, z_now);
     taa_st(prev_sky + i, sky_now);
+}
+
+__global__ __launch_bounds__(256) void k_taa(const TaaParams T, const float *__restrict__ current, const float *__restrict__ normal,
+                                             const float *__restrict__ depth, const uint8_t *__restrict__ sky, float *__restrict__ hist,
+                                             float *__restrict__ prev_normal, float *__restrict__ prev_depth, uint8_t *__restrict__ prev_sky)
+{
+    // 32 x 8 pixels a workgroup; 32 x 2 (one wavefront) for the frames in flight: such a workgroup takes the place of ONE retiring
+    // wavefront of the trace that runs beside it, a four-wavefront one waits until four places are free on one CU
+    taa_pixel(T, blockIdx.x * 32 + (threadIdx.x & 31), blockIdx.y * (int)(blockDim.x >> 5) + (threadIdx.x >> 5), current, normal, depth, sky, hist, prev_normal, prev_depth, prev_sky);
 }
 
 // ---------------------------------------------------------------------------------- tile slabs (multi-GPU)
@@ -1515,12 +1522,15 @@ int ycge_launch_wavefront(const ycge::SceneDev *S, const ycge::FrameParams *P, c
 
 // builds next frame's k_trace schedule from this frame's per-block step counts.  ws: 18 uint32 (see k_cost_hist)
 int ycge_launch_order_blocks(uint32_t *cost, uint32_t n, uint32_t policy, uint32_t split_top, uint32_t fan_class, uint32_t fan_cap, uint32_t next_slot, uint32_t skip_slot,
-                             uint32_t *ws, uint32_t *order, hipStream_t stream)
+                             uint32_t *ws, uint32_t *order, hipStream_t stream, int small_groups)
 {
     if (n == 0) return 0;
+    // small_groups (frames in flight): a 1024-thread workgroup needs a quarter of a CU cleared before it starts and so waited for the
+    // last third of the trace running beside it; four wavefronts find room far sooner (one-wavefront groups were no better)
+    const unsigned threads = small_groups ? 256u : 1024u;
     hipError_t e = hipMemsetAsync(ws, 0, 96 * sizeof(uint32_t), stream);     // ws[16] / ws[18] (entries, n_fan) are rewritten by k_cost_scatter before anyone reads them
     if (e != hipSuccess) return (int)e;
-    const dim3 grid((n + 1023u) / 1024u), block(1024);
+    const dim3 grid((n + threads - 1u) / threads), block(threads);
     hipLaunchKernelGGL(ycge::k_cost_hist, grid, block, 0, stream, cost, n, skip_slot, ws);
     hipLaunchKernelGGL(ycge::k_cost_scatter, grid, block, 0, stream, cost, n, n * YCGE_SCHEDULE_SLACK, policy, split_top, fan_class, fan_cap, next_slot, skip_slot, ws, order);
     return (int)hipGetLastError();
@@ -1539,9 +1549,11 @@ int ycge_launch_trace_fan(const ycge::SceneDev *S, const ycge::FrameParams *P, c
 }
 
 int ycge_launch_taa(const ycge::TaaParams *T, const float *current, const float *normal, const float *depth, const uint8_t *sky,
-                    float *hist, float *prev_normal, float *prev_depth, uint8_t *prev_sky, hipStream_t stream)
+                    float *hist, float *prev_normal, float *prev_depth, uint8_t *prev_sky, hipStream_t stream, int small_groups)
 {
-    dim3 grid((unsigned)((T->w + 31) / 32), (unsigned)((T->h + 7) / 8)), block(256);
+    // small_groups (frames in flight): one-wavefront workgroups take the place of a single retiring wavefront of the trace running beside them
+    const unsigned rows = small_groups ? 2u : 8u;
+    dim3 grid((unsigned)((T->w + 31) / 32), (unsigned)((T->h + (int)rows - 1) / (int)rows)), block(32u * rows);
     hipLaunchKernelGGL(ycge::k_taa, grid, block, 0, stream, *T, current, normal, depth, sky, hist, prev_normal, prev_depth, prev_sky);
     return (int)hipGetLastError();
 }
