@@ -292,3 +292,38 @@ def test_moved_objects_of_a_deep_mesh_scene_on_two_devices(product_lib, oracle):
         _frame_parity(o, g, f"deep mesh, two devices, frame after move {step}")
     assert g.scene_bvh_stats()["device_builds"] == 2
     o.close(); g.close()
+
+
+def test_frames_in_flight_with_entities_that_move_lights_that_change_and_a_resize(product_lib):
+    """RaytraceEntity.Update moves things between frames (RaytraceEntity.cs:221-232): every scene update waits for the frames in flight
+    (the uploads rewrite live device arrays) and the next queued frame sees the new scene.  Same frames as the synchronous calls, bit
+    for bit, through object moves (device-side rebuild), a light change and a Resize in the middle."""
+    from yetanotherconsolegameengine_amd.renderer import RaytraceRenderer
+    watch = (abi.BUF_CURRENT_HDR, abi.BUF_G_NORMAL, abi.BUF_G_DEPTH, abi.BUF_SKY_MASK, abi.BUF_TAA_HISTORY)
+
+    def run(in_flight):
+        scene = _crowd(300, 3)
+        rng = np.random.default_rng(9)
+        r = RaytraceRenderer(flatten(scene), 160, 90, POSE["fov"], 1)
+        r.SetCamera(POSE["pos"], POSE["yaw"], POSE["pitch"])
+        out = []
+        for step in range(14):
+            if step in (3, 4, 9):
+                _move(scene, rng, 0.3); r.UpdateObjects(flatten(scene))
+            if step == 6:
+                scene.Lights[0].Intensity = 250.0; r.UpdateLights(scene.Lights)
+            if step == 8:
+                r.Resize(128, 72, 1); r.SetCamera(POSE["pos"], POSE["yaw"], POSE["pitch"])
+            if in_flight:
+                r.RenderAsync()
+            else:
+                r.TryFlipAndBlit()
+            if step in (2, 5, 7, 10, 13):
+                out.append([r.read(b) for b in watch])
+        r.close()
+        return out
+
+    want, got = run(False), run(True)
+    for i, (a, b) in enumerate(zip(want, got)):
+        for wch, x, y in zip(watch, a, b):
+            assert x.shape == y.shape and pu.bits_equal(x, y), (i, wch)
