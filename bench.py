@@ -183,7 +183,11 @@ def main():
         slabs = [torch.empty(nb // 4, dtype=torch.float32, device="cuda") for _ in range(2)]
         gathered = [torch.empty(world * (nb // 4), dtype=torch.float32, device="cuda") for _ in range(2)]
         slab, all_slabs = slabs[0], gathered[0]
-        s_trace, s_comm = torch.cuda.Stream(), torch.cuda.Stream()
+        # two trace streams, taken in turn: consecutive frames' traces may overlap (the bulk of one in the wavefront slots the tail of the
+        # other leaves empty - on a rank's share of a frame that is most of the machine); the library keeps what a trace writes per frame parity
+        s_traces, s_comm = [torch.cuda.Stream(), torch.cuda.Stream()], torch.cuda.Stream()
+        if os.environ.get("YCGE_BENCH_ONE_TRACE_STREAM"):
+            s_traces[1] = s_traces[0]
         ev_traced = [torch.cuda.Event() for _ in range(2)]
         ev_resolved = [torch.cuda.Event() for _ in range(2)]
         n_issued = [0]
@@ -201,6 +205,7 @@ def main():
             return t, 0.0
         k = n_issued[0] & 1
         n_issued[0] += 1
+        s_trace = s_traces[k]
         with torch.cuda.stream(s_trace):
             s_trace.wait_event(ev_resolved[k])           # slab k was last read by the gather of two frames ago
             rr.trace_tiles(slabs[k].data_ptr(), s_trace.cuda_stream)
@@ -214,7 +219,7 @@ def main():
 
     def fence():
         if multi:
-            s_trace.synchronize(); s_comm.synchronize()
+            s_traces[0].synchronize(); s_traces[1].synchronize(); s_comm.synchronize()
             dist.barrier()
         if n_dev > 1:           # one process, several devices: drain them all (a rank of the RCCL form only ever touches its own device)
             for d in range(n_dev):
@@ -408,7 +413,7 @@ def main():
     if rank == 0:
         name, cus = r.device_info()
         how = ("one process, one ycge_render_frame call per frame drives all devices; peers push their tiles into device 0 over xGMI" if (form == "onecall" and n_dev > 1)
-               else "one process per GPU; one RCCL all-gather of the tile slabs per frame" + ("; trace of frame N+1 beside gather + resolve of frame N (two streams)" if pipelined else "") if multi else "single GPU")
+               else "one process per GPU; one RCCL all-gather of the tile slabs per frame" + ("; traces of consecutive frames on two streams (they may overlap), gather + resolve of frame N on a third" if pipelined else "") if multi else "single GPU")
         out = {
             "metric": f"Mrays/s (all rays: Scene.Hit + Scene.Occluded calls) and ms/frame, {METRIC_SHAPES[args.config]}",
             "value": round(mrays, 2), "unit": "Mrays/s", "n_gpus": n_gpus_used, "steps": args.steps, "warmup": args.warmup,

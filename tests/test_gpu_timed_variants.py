@@ -382,6 +382,55 @@ def test_frames_in_flight_refuse_what_they_cannot_keep(product_lib):
     r.close()
 
 
+@pytest.mark.parametrize("cfg_n,w,h", [(3, 320, 90), (5, 96, 27)])
+def test_tiled_traces_of_consecutive_frames_on_two_streams(product_lib, cfg_n, w, h):
+    """bench.py's RCCL form queues the traces of consecutive frames on two streams taken in turn, so that they may overlap; the
+    library keeps a trace's outputs, stack spill area and schedule per frame parity, and makes the stage pipeline of a voxel world
+    (shared queues) wait for the frame before.  Reference behaviour = the same frames issued strictly in sequence on one stream."""
+    import torch
+    sc, _, _, ss, pose = scenes.config_scene(cfg_n)
+    flat = flatten(sc)
+    moves = [0.0, 0.001, 0.0012, 0.02, 0.0201, 0.0201, 0.05, 0.0505, 0.0506, 0.0507]
+
+    def cam(r, i):
+        r.SetCamera((pose["pos"][0] + moves[i], pose["pos"][1], pose["pos"][2]), pose["yaw"] + 0.2 * moves[i], pose["pitch"])
+
+    seq = RaytraceRenderer(flat, w, h, pose["fov"], ss)
+    n = seq.tile_slab_bytes() // 4
+    slab = torch.empty(n, dtype=torch.float32, device="cuda")
+    want = []
+    for i in range(len(moves)):
+        cam(seq, i)
+        seq.trace_tiles(slab.data_ptr(), 0)
+        seq.resolve_gathered(slab.data_ptr(), 0)
+        want.append((seq.read(abi.BUF_TAA_HISTORY), seq.read(abi.BUF_CURRENT_HDR), seq.read(abi.BUF_G_DEPTH)))
+    seq.close()
+    two = RaytraceRenderer(flat, w, h, pose["fov"], ss)
+    slabs = [torch.empty(n, dtype=torch.float32, device="cuda") for _ in range(2)]
+    st = [torch.cuda.Stream(), torch.cuda.Stream()]
+    s_res = torch.cuda.Stream()
+    ev_t = [torch.cuda.Event() for _ in range(2)]; ev_r = [torch.cuda.Event() for _ in range(2)]
+    got = []
+    for i in range(len(moves)):
+        k = i & 1
+        cam(two, i)
+        with torch.cuda.stream(st[k]):
+            st[k].wait_event(ev_r[k])
+            two.trace_tiles(slabs[k].data_ptr(), st[k].cuda_stream)
+            ev_t[k].record(st[k])
+        with torch.cuda.stream(s_res):
+            s_res.wait_event(ev_t[k])
+            two.resolve_gathered(slabs[k].data_ptr(), s_res.cuda_stream)
+            ev_r[k].record(s_res)
+        if i in (3, 7, len(moves) - 1):          # a look in between drains everything; the pipeline starts again behind it
+            torch.cuda.synchronize()
+            got.append((i, two.read(abi.BUF_TAA_HISTORY), two.read(abi.BUF_CURRENT_HDR), two.read(abi.BUF_G_DEPTH)))
+    for i, hist, hdr, dep in got:
+        assert pu.bits_equal(hist, want[i][0]), ("history", i)
+        assert pu.bits_equal(hdr, want[i][1]) and pu.bits_equal(dep, want[i][2]), ("frame", i)
+    two.close()
+
+
 def test_textured_material_and_bad_indices_are_refused(product_lib):
     """A textured material whose texture index points nowhere, a texture without pixels, an object with a material index out of
     range: refused loudly, with the reason."""

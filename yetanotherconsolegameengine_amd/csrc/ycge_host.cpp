@@ -251,6 +251,8 @@ struct ycge_ctx {
     DevBuf<uint64_t> stack_spill2;                 // ... which then need a traversal-stack spill area of their own
     uint64_t *spill_override = nullptr;            // set around trace_frame by ycge_render_frame_async
     hipEvent_t flight_fork_ev = nullptr;
+    hipEvent_t tile_trace_ev[2] = {nullptr, nullptr};      // tiled frames: the trace (and slab pack) of the newest frame of each parity is done
+    bool tile_trace_used[2] = {false, false};
     hipEvent_t set_resolved_ev[2] = {nullptr, nullptr};
     bool set_read[2] = {false, false};             // a TAA launch on taa_stream has read this set: the next trace into it waits for set_resolved_ev
     int out_set = 0;                               // which set the names above hold
@@ -437,6 +439,7 @@ int set_geometry(ycge_ctx *c, int fbw, int fbh, int ss)
     c->t_hdr.release(); c->t_albedo.release(); c->t_normal.release(); c->t_depth.release(); c->t_sky.release();
     c->alt_hdr.release(); c->alt_albedo.release(); c->alt_normal.release(); c->alt_depth.release(); c->alt_sky.release();      // (callers have quiesced the device)
     c->set_read[0] = c->set_read[1] = false; c->out_set = 0; c->async_outstanding = false;
+    c->tile_trace_used[0] = c->tile_trace_used[1] = false;
     for (auto *sc : c->schedules) delete sc;      // level schedules are per size: rebuilt on demand (the destructor frees the device lists)
     c->schedules.clear();
     int rc = alloc_frame_buffers(c);
@@ -731,6 +734,7 @@ void ycge_destroy(ycge_ctx *c)
     if (c->taa_stream) { (void)hipStreamSynchronize(c->taa_stream); (void)hipStreamDestroy(c->taa_stream); c->taa_stream = nullptr; }
     if (c->stream2) { (void)hipStreamSynchronize(c->stream2); (void)hipStreamDestroy(c->stream2); c->stream2 = nullptr; }
     if (c->flight_fork_ev) (void)hipEventDestroy(c->flight_fork_ev);
+    for (int k = 0; k < 2; k++) if (c->tile_trace_ev[k]) (void)hipEventDestroy(c->tile_trace_ev[k]);
     c->stack_spill2.release();
     for (int k = 0; k < 2; k++) if (c->set_resolved_ev[k]) (void)hipEventDestroy(c->set_resolved_ev[k]);
     for (int k = 0; k < 2; k++) { c->flight_order[k].release(); c->flight_ws[k].release(); if (c->flight_order_ev[k]) (void)hipEventDestroy(c->flight_order_ev[k]); }
@@ -1616,6 +1620,24 @@ int trace_frame(ycge_ctx *c, float *d_slab, hipStream_t stream, FrameState &fs, 
             HIP_TRY(c, c->t_depth.alloc(npx)); HIP_TRY(c, c->t_sky.alloc(npx));
         }
         O.current_hdr = c->t_hdr.p; O.g_albedo = c->t_albedo.p; O.g_normal = c->t_normal.p; O.g_depth = c->t_depth.p; O.sky = c->t_sky.p;
+        // Two tiled traces at a time: a caller that queues frame N + 1 on another stream than frame N (bench.py alternates two) lets
+        // the bulk of one fill the wavefront slots the tail of the other leaves empty - on a rank's share of a frame, where the
+        // heaviest chains ARE the launch, that is most of the machine.  So what a trace writes or scratches exists per frame parity
+        // (trace outputs: the second set is the one the frames in flight use on a single-device context, never both; stack spill
+        // area), every tiled trace first waits for the trace of frame N - 2, whatever streams the caller uses, and a scene whose trace
+        // shares more than that between frames (stage pipeline queues, refraction stacks) also for frame N - 1.
+        const int par = (int)(fs.frame & 1);
+        for (int k = 0; k < 2; k++) if (!c->tile_trace_ev[k]) HIP_TRY(c, hipEventCreateWithFlags(&c->tile_trace_ev[k], hipEventDisableTiming));
+        if (par) {
+            if (!c->alt_hdr.p) {
+                HIP_TRY(c, c->alt_hdr.alloc(3 * npx)); HIP_TRY(c, c->alt_albedo.alloc(3 * npx)); HIP_TRY(c, c->alt_normal.alloc(3 * npx));
+                HIP_TRY(c, c->alt_depth.alloc(npx)); HIP_TRY(c, c->alt_sky.alloc(npx));
+            }
+            O.current_hdr = c->alt_hdr.p; O.g_albedo = c->alt_albedo.p; O.g_normal = c->alt_normal.p; O.g_depth = c->alt_depth.p; O.sky = c->alt_sky.p;
+            if (!c->stack_spill2.p) HIP_TRY(c, c->stack_spill2.alloc(c->stack_spill.n));
+        }
+        if (c->tile_trace_used[par]) HIP_TRY(c, hipStreamWaitEvent(stream, c->tile_trace_ev[par], 0));
+        if (c->tile_trace_used[par ^ 1] && (!frame_is_single_launch(c) || c->sd.any_transparent)) HIP_TRY(c, hipStreamWaitEvent(stream, c->tile_trace_ev[par ^ 1], 0));
     }
     const bool debug = c->cfg.capture_debug && !slab;
     if (debug) { O.rays = c->dbg_rays.p; O.prim_id = c->dbg_prim.p; O.sub_id = c->dbg_sub.p; O.hit_t = c->dbg_hit_t.p; O.rng_state = c->dbg_rng.p; }
@@ -1624,7 +1646,7 @@ int trace_frame(ycge_ctx *c, float *d_slab, hipStream_t stream, FrameState &fs, 
     if (c->cfg.count_work) HIP_TRY(c, hipMemsetAsync(c->counters.p, 0, 6 * sizeof(unsigned long long), stream));
     if (timed) HIP_TRY(c, hipEventRecord(c->ev[0], stream));
     int e;
-    O.stack_spill = c->spill_override ? c->spill_override : c->stack_spill.p;
+    O.stack_spill = c->spill_override ? c->spill_override : (slab && (fs.frame & 1)) ? c->stack_spill2.p : c->stack_spill.p;
     const uint32_t trace_lanes = (uint32_t)(c->n_owned > 0 ? c->n_owned : 1) * 256u * YCGE_SCHEDULE_SLACK;
     O.stack_lanes = trace_lanes + c->fan_cap * 192u;
     O.path_stack = c->path_stack.p;
@@ -1734,6 +1756,8 @@ int trace_frame(ycge_ctx *c, float *d_slab, hipStream_t stream, FrameState &fs, 
     if (slab) {
         e = ycge_launch_pack_slab(&P, O.current_hdr, O.g_albedo, O.g_normal, O.g_depth, O.sky, d_slab, (int)slab_floats(c), stream);
         if (e != 0) return c->fail(YCGE_ERR_DEVICE, "k_pack_slab launch failed: %s", hipGetErrorString((hipError_t)e));
+        HIP_TRY(c, hipEventRecord(c->tile_trace_ev[fs.frame & 1], stream));
+        c->tile_trace_used[fs.frame & 1] = true;
     }
     if (timed) HIP_TRY(c, hipEventRecord(c->ev[1], stream));
     return YCGE_OK;
