@@ -361,8 +361,20 @@ def main():
         r.Wait()
         tf = time.perf_counter() - tf0
         ft = r.async_trace_ms()
+        fsdr = None
+        if not args.no_post:      # ... and with the post stage + read-back (ycge_render_frame_async_sdr), three page-locked SDR arrays taken in turn
+            m = 60
+            for i in range(6):
+                r.RenderAsync(sdr_slot=i % 3)
+            r.Wait()
+            ts0 = time.perf_counter()
+            for i in range(m):
+                r.RenderAsync(sdr_slot=i % 3)
+            r.Wait()
+            fsdr = {"frames": m, "ms_per_step": round((time.perf_counter() - ts0) / m * 1e3, 4),
+                    "what": "ycge_render_frame_async_sdr: the post stage and read-back of frame N beside the traces and TAA of the frames after it; compare post_stage.frame_ms_with_sdr_readback"}
         flight = {"frames": n, "ms_per_step": round(tf / n * 1e3, 4), "value": round(per_frame["n_rays"] * n / tf / 1e6, 2), "unit": "Mrays/s",
-                  "trace_ms": dist3([float(x) for x in ft]) if len(ft) else None,
+                  "trace_ms": dist3([float(x) for x in ft]) if len(ft) else None, "with_sdr": fsdr,
                   "what": "the same frames queued with ycge_render_frame_async: no host wait between frames, TAA of frame N and the schedule of frame N + 2 on a second "
                           "(low-priority) stream beside the trace of frame N + 1, trace outputs double-buffered; bit-identical frames (tests/test_gpu_timed_variants.py). "
                           "The headline `value` stays the synchronous call, which is the reference's TryFlipAndBlit; trace_ms here is the launch with TAA running beside it"}

@@ -338,6 +338,11 @@ int ycge_render_frame(ycge_ctx *ctx, float *out_top_bottom_sdr, ycge_frame_stats
  * calls produces, bit for bit.  Single device, no debug captures, no per-frame counters.  Every other entry point (and
  * ycge_wait) first waits for the frames in flight; ycge_set_camera between two calls moves the camera of the next frame. */
 int ycge_render_frame_async(ycge_ctx *ctx);
+/* ... with steps 6-8 (denoise, exposure, tonemap + downsample) and the read-back: out_top_bottom_sdr (as for ycge_render_frame) is
+ * filled when the frame is complete - after ycge_wait or any other call - so a caller that queues several such frames passes one
+ * buffer per frame in flight (page-locked, ycge_pin_host_buffer, or the copy blocks the calling thread).  The post stage of frame N
+ * runs beside the traces and TAA of the frames after it; same pixels as ycge_render_frame(ctx, out, NULL) in the same order. */
+int ycge_render_frame_async_sdr(ycge_ctx *ctx, float *out_top_bottom_sdr);
 int ycge_wait(ycge_ctx *ctx);
 /* measurement: durations (ms) of the trace launches of the frames queued since the last call, oldest first (at most the last 1024);
  * waits for the frames in flight */

@@ -33,3 +33,18 @@ for rep in range(2):
     at = r.async_trace_ms()
     tail = f"(trace median {np.median(at):.4f}, min {at.min():.4f}, n {len(at)})" if len(at) else "(no timing events)"
     print(f"config {cfg}: synchronous {ts:.4f} ms/frame (trace median {np.median(tr):.4f}); in flight {ta:.4f} ms/frame {tail}")
+
+# the frame the wrapper asks for (SDR out): synchronous against in flight with the post stage (three page-locked arrays in turn)
+M = max(30, N // 5)
+for _ in range(4): r.TryFlipAndBlit(want_sdr=True, copy=False)
+torch.cuda.synchronize()
+t0 = time.perf_counter()
+for _ in range(M): r.TryFlipAndBlit(want_sdr=True, copy=False)
+ts = (time.perf_counter() - t0) / M * 1e3
+for i in range(6): r.RenderAsync(sdr_slot=i % 3)
+r.Wait()
+t0 = time.perf_counter()
+for i in range(M): r.RenderAsync(sdr_slot=i % 3)
+r.Wait()
+ta = (time.perf_counter() - t0) / M * 1e3
+print(f"config {cfg} with the post stage and the SDR read-back: synchronous {ts:.4f} ms/frame; in flight {ta:.4f} ms/frame")

@@ -11,7 +11,7 @@ for f in bench_$TAG bench_${TAG}_cfg1 bench_${TAG}_cfg2 bench_${TAG}_cfg3 bench_
 import json
 try:
     d = json.load(open("gpurun_out/$f.json"))
-    print("$f", d["value"], "Mrays/s", d["ms_per_step"], "ms/frame; trace", d.get("trace_ms"), "in flight", (d.get("frames_in_flight") or {}).get("ms_per_step"), (d.get("frames_in_flight") or {}).get("value"), "cpu", (d.get("cpu_baseline") or {}).get("value"), "x", d.get("gpu_over_cpu"), "moving", (d.get("moving_camera") or {}).get("trace_ms"), "post", (d.get("post_stage") or {}).get("post_ms"), (d.get("post_stage") or {}).get("frame_ms_with_sdr_readback"))
+    print("$f", d["value"], "Mrays/s", d["ms_per_step"], "ms/frame; trace", d.get("trace_ms"), "in flight", (d.get("frames_in_flight") or {}).get("ms_per_step"), (d.get("frames_in_flight") or {}).get("value"), "with sdr", ((d.get("frames_in_flight") or {}).get("with_sdr") or {}).get("ms_per_step"), "cpu", (d.get("cpu_baseline") or {}).get("value"), "x", d.get("gpu_over_cpu"), "moving", (d.get("moving_camera") or {}).get("trace_ms"), "post", (d.get("post_stage") or {}).get("post_ms"), (d.get("post_stage") or {}).get("frame_ms_with_sdr_readback"))
 except Exception as e:
     print("$f failed", e)
 PY
@@ -20,6 +20,6 @@ bash profiles/run_profiles.sh ${TAG}_c4 > gpurun_out/prof_${TAG}_c4.log 2>&1; ec
 bash profiles/run_profiles.sh ${TAG}_c5 --config 5 > gpurun_out/prof_${TAG}_c5.log 2>&1; echo "profiles c5 rc=$?"; head -12 gpurun_out/prof_${TAG}_c5/summary.txt
 for cfg in 4 3; do echo "== rank emulation config $cfg"; timeout 600 python profiles/rank_times.py $cfg 2>&1 | grep -E "world"; done
 echo "== a rank's period in the pipelined tiled loop"; for w in 8 4 2; do timeout 300 python profiles/rank_flight.py 4 $w 2>&1 | tail -1; done; timeout 300 python profiles/rank_flight.py 4 8 one 2>&1 | tail -1; timeout 300 python profiles/rank_flight.py 3 8 2>&1 | tail -1
-echo "== frames in flight against the synchronous call"; for cfg in 4 3 2 5; do timeout 300 python profiles/flight_ab.py $cfg 300 2>&1 | tail -1; done
+echo "== frames in flight against the synchronous call"; for cfg in 4 3 2 5; do timeout 300 python profiles/flight_ab.py $cfg 300 2>&1 | tail -2; done
 echo "== post stage bands"; for a in "4 1 270" "5 2 540"; do set -- $a; CFG=$1 SS=$2 NB=$3 timeout 300 python profiles/post_bands.py 2>&1 | grep -E "^post|launch span|chain:"; done
 timeout 300 python profiles/mega_prof.py 4 2>&1 | grep -v amdgpu.ids > gpurun_out/mega_prof_$TAG.txt; grep -E "trace_ms|span|slot time|>= 256" gpurun_out/mega_prof_$TAG.txt

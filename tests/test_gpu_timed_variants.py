@@ -369,6 +369,57 @@ def test_frames_in_flight_are_the_frames_of_the_synchronous_calls(product_lib, c
     single.close()
 
 
+@pytest.mark.parametrize("cfg_n,w,h", [(3, 320, 90), (5, 96, 27), (3, None, None)])
+def test_frames_in_flight_with_the_post_stage(product_lib, cfg_n, w, h):
+    """ycge_render_frame_async_sdr: denoise, exposure and tonemap of frame N beside the traces and TAA of the frames after it (the
+    denoiser reads frame N's G-buffer set and, in its first iteration, the TAA history; the exposure state passes from frame to frame).
+    Reference behaviour = TryFlipAndBlit(fb) frame after frame (RaytraceRenderer.cs:157-267): the same SDR chexels, exposure included,
+    bit for bit, three frames in flight, plain frames and synchronous ones in between, a moving camera."""
+    sc, w0, h0, ss, pose = scenes.config_scene(cfg_n)
+    flat = flatten(sc)
+    w, h = w or w0, h or h0
+    moves = [0.0, 0.001, 0.0012, 0.02, 0.0201, 0.0201, 0.05, 0.0505, 0.0505, 0.051, 0.0511, 0.0512]
+    plan = "pppappspppap"          # p: in flight with the post stage, a: in flight without, s: synchronous SDR frame
+
+    def cam(r, i):
+        r.SetCamera((pose["pos"][0] + moves[i], pose["pos"][1], pose["pos"][2]), pose["yaw"] + 0.3 * moves[i], pose["pitch"])
+
+    seq = RaytraceRenderer(flat, w, h, pose["fov"], ss)
+    want = {}
+    for i, kind in enumerate(plan):
+        cam(seq, i)
+        if kind == "a":
+            seq.TryFlipAndBlit()
+        else:
+            want[i] = seq.TryFlipAndBlit(want_sdr=True)
+    want_hist = seq.read(abi.BUF_TAA_HISTORY)
+    seq.close()
+    fl = RaytraceRenderer(flat, w, h, pose["fov"], ss)
+    held = {}
+    for i, kind in enumerate(plan):
+        cam(fl, i)
+        if kind == "p":
+            held[i] = fl.RenderAsync(sdr_slot=i % 3)
+            if len(held) == 3:                      # three frames in flight: look at them, then go on
+                fl.Wait()
+                for j, a in held.items():
+                    assert pu.bits_equal(a, want[j]), f"SDR of frame {j + 1} (in flight)"
+                held = {}
+        elif kind == "a":
+            fl.RenderAsync()
+        else:
+            sdr = fl.TryFlipAndBlit(want_sdr=True)          # joins: the frames queued before it are complete
+            for j, a in held.items():
+                assert pu.bits_equal(a, want[j]), f"SDR of frame {j + 1} (in flight, before a synchronous frame)"
+            held = {}
+            assert pu.bits_equal(sdr, want[i]), f"SDR of the synchronous frame {i + 1}"
+    fl.Wait()
+    for j, a in held.items():
+        assert pu.bits_equal(a, want[j]), f"SDR of frame {j + 1} (in flight, at the end)"
+    assert pu.bits_equal(fl.read(abi.BUF_TAA_HISTORY), want_hist)
+    fl.close()
+
+
 def test_frames_in_flight_refuse_what_they_cannot_keep(product_lib):
     sc, _, _, ss, pose = scenes.config_scene(2)
     flat = flatten(sc)

@@ -180,6 +180,7 @@ _PROTOTYPES = {
     "ycge_set_camera": (C.c_int, [C.c_void_p, C.POINTER(C.c_float), C.c_float, C.c_float, C.c_float]),
     "ycge_render_frame": (C.c_int, [C.c_void_p, C.POINTER(C.c_float), C.POINTER(FrameStats)]),
     "ycge_render_frame_async": (C.c_int, [C.c_void_p]),
+    "ycge_render_frame_async_sdr": (C.c_int, [C.c_void_p, C.POINTER(C.c_float)]),
     "ycge_wait": (C.c_int, [C.c_void_p]),
     "ycge_async_trace_times": (C.c_int, [C.c_void_p, C.POINTER(C.c_float), C.c_int32, C.POINTER(C.c_int32)]),
     "ycge_tile_slab_bytes": (C.c_int, [C.c_void_p, C.POINTER(C.c_size_t)]),

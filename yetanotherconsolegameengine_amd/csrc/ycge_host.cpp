@@ -123,6 +123,7 @@ struct Knobs {
     bool post_dbg_free = false;      // YCGE_POST_DBG_FREE (timing experiment, WRONG pixels): no band of the persistent in-place A-trous waits for the band above
     bool flight_small_groups = true; // YCGE_FLIGHT_SMALL_GROUPS: TAA and schedule kernels of the frames in flight in small workgroups (they find room beside a running trace)
     int flight_priority = 1;         // YCGE_FLIGHT_PRIORITY: the second stream's priority: 1 highest, 0 normal, -1 lowest
+    bool flight_post_gate = true;    // YCGE_FLIGHT_POST_GATE: a frame in flight traces only once the post stage before it has passed its first iteration
     bool flight_overlap = true;      // YCGE_FLIGHT_OVERLAP: frames in flight alternate between two trace streams (two traces may overlap)
     bool flight_no_begin = false;      // experiments on ycge_render_frame_async: second stream at normal priority; no begin-of-trace timing event
     int post_pad_lds = 0;            // YCGE_POST_PAD_LDS (experiment): bytes of unused LDS per band workgroup of the two-set form - fewer of them on a CU
@@ -160,6 +161,7 @@ struct Knobs {
         if (post_resident_per_cu < 1 || post_resident_per_cu > 3) post_resident_per_cu = 3;
         post_pad_lds = geti("YCGE_POST_PAD_LDS", 0);
         flight_overlap = geti("YCGE_FLIGHT_OVERLAP", 1) != 0;
+        flight_post_gate = geti("YCGE_FLIGHT_POST_GATE", 1) != 0;
         flight_small_groups = geti("YCGE_FLIGHT_SMALL_GROUPS", 1) != 0;
         flight_priority = geti("YCGE_FLIGHT_PRIORITY", 1);
         flight_no_begin = geti("YCGE_FLIGHT_NO_BEGIN", 0) != 0;
@@ -251,6 +253,9 @@ struct ycge_ctx {
     DevBuf<uint64_t> stack_spill2;                 // ... which then need a traversal-stack spill area of their own
     uint64_t *spill_override = nullptr;            // set around trace_frame by ycge_render_frame_async
     hipEvent_t flight_fork_ev = nullptr;
+    // frames in flight WITH the post stage (ycge_render_frame_async_sdr): post of frame N beside the traces and TAA of the frames after it
+    hipEvent_t flight_taa_ev = nullptr, post_hist_ev = nullptr, post_done_ev = nullptr, post_set_ev[2] = {nullptr, nullptr};
+    bool post_hist_pending = false, post_busy = false, post_set_pending[2] = {false, false};
     hipEvent_t tile_trace_ev[2] = {nullptr, nullptr};      // tiled frames: the trace (and slab pack) of the newest frame of each parity is done
     bool tile_trace_used[2] = {false, false};
     hipEvent_t set_resolved_ev[2] = {nullptr, nullptr};
@@ -277,7 +282,7 @@ struct ycge_ctx {
     DevBuf<uint32_t> wf_seg;                      // segment counter of the persistent extend stage
     DevBuf<uint32_t> wf_counts, tile_order;
     // denoise / exposure / tonemap stage (ycge_post.hip), allocated on the first frame that asks for SDR output
-    DevBuf<float> den_a, den_b, unit_n, exp_terms, d_sdr;
+    DevBuf<float> den_a, den_b, unit_n, exp_terms, d_sdr, d_sdr2;      // d_sdr2: SDR frames in flight read back one array while the next frame's tonemap fills the other
     DevBuf<float> atrous_statw;                // [pixel][25 taps][3]: colour-independent weight factors of an in-place A-trous iteration
     DevBuf<uint8_t> exp_scratch;                  // chunk records of the exposure sum (k_exposure_sum)
     DevBuf<uint32_t> post_progress;               // k_atrous_persist: groups finished per band, one 128-byte line each
@@ -432,7 +437,7 @@ int set_geometry(ycge_ctx *c, int fbw, int fbh, int ss)
     c->tiles_per_rank_padded = (c->n_tiles + world - 1) / world;
     c->taa_valid = false;                                       // Resize: taaHistoryValid = false (:137), taa.Resize (TemporalAA.cs:34-46)
     c->last_cam[0] = c->last_cam[1] = c->last_cam[2] = NAN; c->last_yaw = c->last_pitch = NAN;
-    c->den_a.release(); c->den_b.release(); c->unit_n.release(); c->exp_terms.release(); c->exp_scratch.release(); c->d_sdr.release(); c->atrous_statw.release();     // spatialA / spatialB, :129-130
+    c->den_a.release(); c->den_b.release(); c->unit_n.release(); c->exp_terms.release(); c->exp_scratch.release(); c->d_sdr.release(); c->d_sdr2.release(); c->atrous_statw.release();     // spatialA / spatialB, :129-130
     c->denoised = nullptr;
     c->wave_prof.release();                                     // sized for the tile grid
     c->pending.clear();
@@ -735,13 +740,14 @@ void ycge_destroy(ycge_ctx *c)
     if (c->stream2) { (void)hipStreamSynchronize(c->stream2); (void)hipStreamDestroy(c->stream2); c->stream2 = nullptr; }
     if (c->flight_fork_ev) (void)hipEventDestroy(c->flight_fork_ev);
     for (int k = 0; k < 2; k++) if (c->tile_trace_ev[k]) (void)hipEventDestroy(c->tile_trace_ev[k]);
+    for (hipEvent_t ev : {c->flight_taa_ev, c->post_hist_ev, c->post_done_ev, c->post_set_ev[0], c->post_set_ev[1]}) if (ev) (void)hipEventDestroy(ev);
     c->stack_spill2.release();
     for (int k = 0; k < 2; k++) if (c->set_resolved_ev[k]) (void)hipEventDestroy(c->set_resolved_ev[k]);
     for (int k = 0; k < 2; k++) { c->flight_order[k].release(); c->flight_ws[k].release(); if (c->flight_order_ev[k]) (void)hipEventDestroy(c->flight_order_ev[k]); }
     for (hipEvent_t ev : c->flight_ev) (void)hipEventDestroy(ev);
     c->flight_ev.clear();
     c->alt_hdr.release(); c->alt_albedo.release(); c->alt_normal.release(); c->alt_depth.release(); c->alt_sky.release();
-    c->den_a.release(); c->den_b.release(); c->unit_n.release(); c->exp_terms.release(); c->exp_scratch.release(); c->d_sdr.release(); c->atrous_statw.release(); c->tone_state.release();
+    c->den_a.release(); c->den_b.release(); c->unit_n.release(); c->exp_terms.release(); c->exp_scratch.release(); c->d_sdr.release(); c->d_sdr2.release(); c->atrous_statw.release(); c->tone_state.release();
     for (auto *sc : c->schedules) delete sc;
     c->schedules.clear();
     c->post_progress.release();
@@ -794,6 +800,7 @@ int quiesce(ycge_ctx *c)
     // call, never part of a frame
     HIP_TRY(c, hipDeviceSynchronize());
     c->async_outstanding = false; c->set_read[0] = c->set_read[1] = false;        // (frames in flight included)
+    c->post_hist_pending = c->post_busy = c->post_set_pending[0] = c->post_set_pending[1] = false;
     return YCGE_OK;
 }
 
@@ -1963,7 +1970,8 @@ int post_resident_per_cu(ycge_ctx *c, bool split)
     return q < c->knobs.post_resident_per_cu ? q : c->knobs.post_resident_per_cu;
 }
 
-int run_post(ycge_ctx *c, hipStream_t stream, float *out_sdr_host, bool timed)
+int run_post(ycge_ctx *c, hipStream_t stream, float *out_sdr_host, bool timed, hipEvent_t history_read = nullptr /* recorded once the TAA history has been read for the last time */,
+             hipEvent_t before_copy = nullptr /* recorded in front of the read-back: the next post stage may start */, bool second_sdr = false)
 {
     const int w = c->hiW, h = c->hiH;
     const size_t n = (size_t)w * h;
@@ -2090,6 +2098,7 @@ int run_post(ycge_ctx *c, hipStream_t stream, float *out_sdr_host, bool timed)
             e = ycge_launch_atrous(w, h, step, phi, cur, dst, c->g_albedo.p, c->unit_n.p, c->g_depth.p, c->sky.p, stream);
         }
         if (e != 0) return c->fail(YCGE_ERR_DEVICE, "A-trous launch failed: %s", hipGetErrorString((hipError_t)e));
+        if (it == 0 && iters > 1 && history_read) { HIP_TRY(c, hipEventRecord(history_read, stream)); history_read = nullptr; }        // (iteration 0 is the only reader of taa_hist when there are more)
         const float *tmp = cur; cur = dst; dst = (tmp == A) ? B : A;
     }
     if (static_pending) HIP_TRY(c, hipStreamWaitEvent(stream, c->fan_ev[1], 0));
@@ -2099,10 +2108,14 @@ int run_post(ycge_ctx *c, hipStream_t stream, float *out_sdr_host, bool timed)
     if (!c->exp_scratch.p) HIP_TRY(c, c->exp_scratch.alloc(ycge_exposure_scratch_bytes(w, h, step)));
     e = ycge_launch_exposure(cur, c->sky.p, w, h, step, c->exp_terms.p, c->tone_state.p, tone_consts, c->exp_scratch.p, c->knobs.exposure_serial ? 1 : 0, stream);
     if (e != 0) return c->fail(YCGE_ERR_DEVICE, "exposure launch failed: %s", hipGetErrorString((hipError_t)e));
-    e = ycge_launch_tonemap(cur, w, c->fbW, c->fbH, c->ss, 2.2f, 2.0f, 0.0f, c->tone_state.p, c->d_sdr.p, stream);   // toneGamma, toneSaturation, toneVibrance
+    if (second_sdr && !c->d_sdr2.p) HIP_TRY(c, c->d_sdr2.alloc((size_t)c->fbW * c->fbH * 6));
+    float *d_sdr = second_sdr ? c->d_sdr2.p : c->d_sdr.p;
+    e = ycge_launch_tonemap(cur, w, c->fbW, c->fbH, c->ss, 2.2f, 2.0f, 0.0f, c->tone_state.p, d_sdr, stream);   // toneGamma, toneSaturation, toneVibrance
     if (e != 0) return c->fail(YCGE_ERR_DEVICE, "tonemap launch failed: %s", hipGetErrorString((hipError_t)e));
     if (timed) HIP_TRY(c, hipEventRecord(c->ev[3], stream));
-    if (out_sdr_host) HIP_TRY(c, hipMemcpyAsync(out_sdr_host, c->d_sdr.p, (size_t)c->fbW * c->fbH * 6 * sizeof(float), hipMemcpyDeviceToHost, stream));
+    if (before_copy) HIP_TRY(c, hipEventRecord(before_copy, stream));
+    if (out_sdr_host) HIP_TRY(c, hipMemcpyAsync(out_sdr_host, d_sdr, (size_t)c->fbW * c->fbH * 6 * sizeof(float), hipMemcpyDeviceToHost, stream));
+    if (history_read) HIP_TRY(c, hipEventRecord(history_read, stream));        // (a single iteration: exposure and tonemap read the history itself)
     return YCGE_OK;
 }
 
@@ -2216,6 +2229,7 @@ static int join_async(ycge_ctx *c)
     HIP_TRY(c, hipStreamSynchronize(c->taa_stream));
     c->async_outstanding = false;
     c->set_read[0] = c->set_read[1] = false;
+    c->post_hist_pending = c->post_busy = c->post_set_pending[0] = c->post_set_pending[1] = false;
     return YCGE_OK;
 }
 
@@ -2253,9 +2267,21 @@ int ycge_async_trace_times(ycge_ctx *c, float *ms_out, int32_t capacity, int32_t
     return YCGE_OK;
 }
 
-int ycge_render_frame_async(ycge_ctx *c)
+static int render_frame_in_flight(ycge_ctx *c, float *out_sdr);
+int ycge_render_frame_async(ycge_ctx *c) { return c ? render_frame_in_flight(c, nullptr) : YCGE_ERR_INVALID_ARG; }
+// ... with steps 6-8 (denoise, exposure, tonemap + downsample) and the read-back into out_top_bottom_sdr, which is filled when the frame
+// is complete (ycge_wait, or any other call): page-locked memory (ycge_pin_host_buffer) keeps the copy off the caller's thread, and a
+// caller that queues several such frames passes a buffer per frame in flight.  The post stage of frame N runs beside the traces and TAA
+// of the frames after it (its in-place iteration is a dependent chain that leaves most of the chip idle).
+int ycge_render_frame_async_sdr(ycge_ctx *c, float *out_top_bottom_sdr)
 {
     if (!c) return YCGE_ERR_INVALID_ARG;
+    if (!out_top_bottom_sdr) return c->fail(YCGE_ERR_INVALID_ARG, "null SDR buffer");
+    return render_frame_in_flight(c, out_top_bottom_sdr);
+}
+
+static int render_frame_in_flight(ycge_ctx *c, float *out_sdr)
+{
     if (c->parent || !c->peers.empty() || c->cfg.world_size != 1)
         return c->fail(YCGE_ERR_INVALID_ARG, "ycge_render_frame_async is the single-device form (tiled frames overlap through ycge_trace_tiles / ycge_resolve_gathered on two streams)");
     if (c->cfg.capture_debug || c->cfg.count_work) return c->fail(YCGE_ERR_INVALID_ARG, "ycge_render_frame_async keeps neither debug captures nor per-frame counters: use ycge_render_frame");
@@ -2281,7 +2307,8 @@ int ycge_render_frame_async(ycge_ctx *c)
     // needed frame N's: its order, its cost slot and its output set are ready once the second stream's work of frame N - 1 is done, which
     // is the one event it waits for.  Only the single-launch kernel (the stage pipeline of voxel worlds shares its queues between frames)
     // and only without refraction stacks.
-    const bool overlap = c->knobs.flight_overlap && c->stream2 && c->have_scene && frame_is_single_launch(c) && !c->sd.any_transparent && (fs.frame & 1);
+    const bool overlap_scene = c->knobs.flight_overlap && c->stream2 && c->have_scene && frame_is_single_launch(c) && !c->sd.any_transparent;
+    const bool overlap = overlap_scene && (fs.frame & 1);
     hipStream_t ts = overlap ? c->stream2 : c->stream;
     if (overlap && !c->stack_spill2.p) HIP_TRY(c, c->stack_spill2.alloc(c->stack_spill.n));
     if (!c->async_outstanding) {
@@ -2303,6 +2330,11 @@ int ycge_render_frame_async(ycge_ctx *c)
     // ONE wait per frame on the trace's stream: the second stream's work of two frames ago - TAA (it read this set of buffers) and
     // behind it the schedule for THIS frame (it wrote the order buffer of this parity and cleared this frame's cost slot)
     if (c->set_read[k]) HIP_TRY(c, hipStreamWaitEvent(ts, c->set_resolved_ev[k], 0));
+    if (c->post_set_pending[k]) { HIP_TRY(c, hipStreamWaitEvent(ts, c->post_set_ev[k], 0)); c->post_set_pending[k] = false; }      // a post stage still reads this set's G-buffer
+    // ... and a trace does not start while the post stage of the frame before has yet to place its persistent in-place launch: behind a
+    // running trace's 64 800 pending workgroups its band workgroups (nine wavefronts each) find their CUs one by one, and every band
+    // waits for the slowest to arrive (config 4 with the post stage in flight: 4.7 ms a frame instead of 3.6 synchronous)
+    if (c->post_hist_pending && c->knobs.flight_post_gate) HIP_TRY(c, hipStreamWaitEvent(ts, c->post_hist_ev, 0));
     const size_t slot = (size_t)(c->flight_frames % YCGE_FLIGHT_RING);
     hipEvent_t ev_begin = c->knobs.flight_no_begin ? nullptr : c->flight_ev[2 * slot], ev_end = c->flight_ev[2 * slot + 1];
     c->in_flight_call = true;
@@ -2314,12 +2346,32 @@ int ycge_render_frame_async(ycge_ctx *c)
     HIP_TRY(c, hipEventRecord(ev_end, ts));          // end of the trace: the timing ring's event is also what the second stream waits for
     c->flight_frames++;
     HIP_TRY(c, hipStreamWaitEvent(c->taa_stream, ev_end, 0));
+    if (c->post_hist_pending) { HIP_TRY(c, hipStreamWaitEvent(c->taa_stream, c->post_hist_ev, 0)); c->post_hist_pending = false; }      // the post stage of the frame before reads the history this TAA rewrites
     bool did_reset = false;
     const bool small = c->knobs.flight_overlap && c->knobs.flight_small_groups;
     c->in_flight_taa = small;
     rc = taa_and_commit(c, c->taa_stream, fs, did_reset, false);
     c->in_flight_taa = false;
     if (rc != YCGE_OK) return rc;
+    if (out_sdr) {
+        for (hipEvent_t *ev : {&c->flight_taa_ev, &c->post_hist_ev, &c->post_done_ev, &c->post_set_ev[0], &c->post_set_ev[1]})
+            if (!*ev) HIP_TRY(c, hipEventCreateWithFlags(ev, hipEventDisableTiming));
+        // Steps 6-8 of this frame.  On the stream of this frame's trace where two traces run at a time (the next trace on that stream is
+        // frame N + 2's, which must wait for this post stage anyway: it overwrites the G-buffer set the denoiser reads); on the second
+        // trace stream where all traces share one (stage pipeline).  Post stages follow each other (one set of denoise buffers, one
+        // exposure state); TAA of frame N + 1 waits until iteration 0 has read this frame's history.
+        hipStream_t ps = overlap_scene ? ts : c->stream2 ? c->stream2 : ts;
+        HIP_TRY(c, hipEventRecord(c->flight_taa_ev, c->taa_stream));
+        HIP_TRY(c, hipStreamWaitEvent(ps, c->flight_taa_ev, 0));
+        if (c->post_busy) HIP_TRY(c, hipStreamWaitEvent(ps, c->post_done_ev, 0));
+        // (the read-back, 0.5 ms of PCIe for a 1920 x 540 console, is not part of what the next post stage waits for where the two run on
+        // different streams: two SDR arrays on the device, by frame parity)
+        rc = run_post(c, ps, out_sdr, false, c->post_hist_ev, overlap_scene ? c->post_done_ev : nullptr, overlap_scene && k == 1);
+        if (rc != YCGE_OK) return rc;
+        if (!overlap_scene) HIP_TRY(c, hipEventRecord(c->post_done_ev, ps));
+        HIP_TRY(c, hipEventRecord(c->post_set_ev[k], ps));
+        c->post_busy = true; c->post_hist_pending = true; c->post_set_pending[k] = true;
+    }
     if (fs.scheduled) {
         // the schedule of frame N + 2, from the costs up to this frame's: the slot frame N + 1's trace is writing meanwhile is left out,
         // the one frame N + 2's will write is cleared; into the order buffer this frame's trace has just finished reading

@@ -58,8 +58,10 @@ class RaytraceRenderer:
     def close(self):
         self._drop_sdr_buffer()
         if getattr(self, "ctx", None):
-            self.L.ycge_destroy(self.ctx)
+            self.L.ycge_destroy(self.ctx)          # (waits for the frames in flight: their SDR arrays are still the wrapper's)
             self.ctx = C.c_void_p()
+        for a in self.__dict__.pop("_sdr_ring", {}).values():
+            self.L.ycge_unpin_host_buffer(a.ctypes.data_as(C.c_void_p))
 
     def __enter__(self):
         return self
@@ -156,10 +158,23 @@ class RaytraceRenderer:
         self._check(self.L.ycge_render_frame(self.ctx, ptr, C.byref(self.stats)))
         return (sdr.copy() if copy else sdr) if want_sdr else self.stats
 
-    def RenderAsync(self):
+    def RenderAsync(self, sdr_slot=None):
         """Frames in flight (ycge_render_frame_async): queues the next frame through TAA and returns; the trace of the frame after it
-        runs beside this one's TAA.  Same frames as TryFlipAndBlit() in the same order.  Wait() - or any other call - joins."""
-        self._check(self.L.ycge_render_frame_async(self.ctx))
+        runs beside this one's TAA.  Same frames as TryFlipAndBlit() in the same order.  Wait() - or any other call - joins.
+        With sdr_slot = k the frame runs the post stage too (ycge_render_frame_async_sdr) into the wrapper's k-th page-locked SDR array,
+        which is returned and holds the frame once Wait() has returned: one slot per frame in flight."""
+        if sdr_slot is None:
+            self._check(self.L.ycge_render_frame_async(self.ctx))
+            return None
+        ring = self.__dict__.setdefault("_sdr_ring", {})
+        key = (int(sdr_slot), self.fbH, self.fbW)
+        if key not in ring:
+            a = np.zeros((self.fbH, self.fbW, 2, 3), dtype=np.float32)
+            self.L.ycge_pin_host_buffer(a.ctypes.data_as(C.c_void_p), a.nbytes)      # (best effort: an unpinned array only makes the copy block)
+            ring[key] = a
+        a = ring[key]
+        self._check(self.L.ycge_render_frame_async_sdr(self.ctx, a.ctypes.data_as(C.POINTER(C.c_float))))
+        return a
 
     def Wait(self):
         self._check(self.L.ycge_wait(self.ctx))
