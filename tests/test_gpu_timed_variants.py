@@ -431,6 +431,14 @@ def test_frames_in_flight_refuse_what_they_cannot_keep(product_lib):
     with pytest.raises(abi.YcgeError, match="single-device"):
         r.RenderAsync()
     r.close()
+    r = RaytraceRenderer(None, 64, 18, pose["fov"], ss)          # no scene yet: the reference throws (Scene.cs:73), so do both entry points
+    with pytest.raises(abi.YcgeError, match="Scene BVH not built"):
+        r.RenderAsync()
+    with pytest.raises(abi.YcgeError, match="Scene BVH not built"):
+        r.RenderAsync(sdr_slot=0)
+    r.UploadScene(flat)
+    r.RenderAsync(); r.RenderAsync(sdr_slot=0); r.Wait()          # ... and the context is none the worse for it
+    r.close()
 
 
 @pytest.mark.parametrize("cfg_n,w,h", [(3, 320, 90), (5, 96, 27)])
