@@ -123,6 +123,7 @@ struct Knobs {
     bool post_dbg_free = false;      // YCGE_POST_DBG_FREE (timing experiment, WRONG pixels): no band of the persistent in-place A-trous waits for the band above
     bool flight_small_groups = true; // YCGE_FLIGHT_SMALL_GROUPS: TAA and schedule kernels of the frames in flight in small workgroups (they find room beside a running trace)
     int flight_priority = 1;         // YCGE_FLIGHT_PRIORITY: the second stream's priority: 1 highest, 0 normal, -1 lowest
+    bool flight_post_pair = true;    // YCGE_FLIGHT_POST_PAIR: the post stages of consecutive frames in flight side by side (second set of denoise buffers)
     bool flight_post_gate = true;    // YCGE_FLIGHT_POST_GATE: a frame in flight traces only once the post stage before it has passed its first iteration
     bool flight_overlap = true;      // YCGE_FLIGHT_OVERLAP: frames in flight alternate between two trace streams (two traces may overlap)
     bool flight_no_begin = false;      // experiments on ycge_render_frame_async: second stream at normal priority; no begin-of-trace timing event
@@ -162,6 +163,7 @@ struct Knobs {
         post_pad_lds = geti("YCGE_POST_PAD_LDS", 0);
         flight_overlap = geti("YCGE_FLIGHT_OVERLAP", 1) != 0;
         flight_post_gate = geti("YCGE_FLIGHT_POST_GATE", 1) != 0;
+        flight_post_pair = geti("YCGE_FLIGHT_POST_PAIR", 1) != 0;
         flight_small_groups = geti("YCGE_FLIGHT_SMALL_GROUPS", 1) != 0;
         flight_priority = geti("YCGE_FLIGHT_PRIORITY", 1);
         flight_no_begin = geti("YCGE_FLIGHT_NO_BEGIN", 0) != 0;
@@ -288,6 +290,10 @@ struct ycge_ctx {
     DevBuf<uint32_t> post_progress;               // k_atrous_persist: groups finished per band, one 128-byte line each
     uint32_t post_epoch = 0;                      // ... counted from here in the next launch
     uint32_t post_ticket = 0;                     // k_atrous_stream, bands in order of arrival: numbers drawn so far (the counter lives in post_progress)
+    // a second set of everything the denoiser scratches, for the post stages of every other frame in flight: two of them run side by side
+    // (each is a dependent chain that leaves the chip idle); the exposure state passes from one to the next in frame order
+    struct PostSet { DevBuf<float> den_a, den_b, unit_n, exp_terms, atrous_statw; DevBuf<uint8_t> exp_scratch; DevBuf<uint32_t> post_progress; uint32_t post_epoch = 0, post_ticket = 0;
+                     void release() { den_a.release(); den_b.release(); unit_n.release(); exp_terms.release(); atrous_statw.release(); exp_scratch.release(); post_progress.release(); post_epoch = post_ticket = 0; } } alt_post;
     int post_resident_seen[2] = {-1, -1};         // post_resident_per_cu: the runtime's answer for the whole-band / split-band instantiation (-1: not asked yet)
     DevBuf<uint8_t> tone_state;                   // ToneMapper state; lives as long as the context (not reset by Resize)
     struct InplaceSchedule { ~InplaceSchedule() { pixels.release(); offsets.release(); pass_level.release(); band_desc.release(); } int w = 0, h = 0, step = 0, levels = 0, bands = 0, rows_per_band = 0, levels_per_launch = 0; uint32_t max_level_pixels = 0, window_width = 0; bool split = false; DevBuf<uint32_t> pixels, offsets, pass_level; DevBuf<int32_t> band_desc; };
@@ -439,6 +445,7 @@ int set_geometry(ycge_ctx *c, int fbw, int fbh, int ss)
     c->last_cam[0] = c->last_cam[1] = c->last_cam[2] = NAN; c->last_yaw = c->last_pitch = NAN;
     c->den_a.release(); c->den_b.release(); c->unit_n.release(); c->exp_terms.release(); c->exp_scratch.release(); c->d_sdr.release(); c->d_sdr2.release(); c->atrous_statw.release();     // spatialA / spatialB, :129-130
     c->denoised = nullptr;
+    c->alt_post.release();
     c->wave_prof.release();                                     // sized for the tile grid
     c->pending.clear();
     c->t_hdr.release(); c->t_albedo.release(); c->t_normal.release(); c->t_depth.release(); c->t_sky.release();
@@ -751,6 +758,7 @@ void ycge_destroy(ycge_ctx *c)
     for (auto *sc : c->schedules) delete sc;
     c->schedules.clear();
     c->post_progress.release();
+    c->alt_post.release();
     c->wf_q0.release(); c->wf_q1.release(); c->wf_hit.release(); c->wf_lq.release(); c->wf_seg.release(); c->wf_counts.release(); c->tile_order.release(); c->block_cost.release(); c->block_order.release(); c->order_ws.release(); c->stack_spill.release(); c->path_stack.release();
     c->d_scene_nodes.release(); c->d_mesh_arena.release(); c->d_scene_leaf.release(); c->d_prims.release();
     c->d_bvh_items.release(); c->d_bvh_scratch.release(); c->d_bvh_ref.release(); c->d_bvh_res.release();
@@ -1971,14 +1979,23 @@ int post_resident_per_cu(ycge_ctx *c, bool split)
 }
 
 int run_post(ycge_ctx *c, hipStream_t stream, float *out_sdr_host, bool timed, hipEvent_t history_read = nullptr /* recorded once the TAA history has been read for the last time */,
-             hipEvent_t before_copy = nullptr /* recorded in front of the read-back: the next post stage may start */, bool second_sdr = false)
+             hipEvent_t before_copy = nullptr /* recorded in front of the read-back: the exposure state is this frame's */, bool second_sdr = false,
+             hipEvent_t tone_wait = nullptr /* the frame before has left its exposure state: waited for in front of this frame's exposure step */, bool second_set = false)
 {
+    // (every other frame in flight: the names below stand for the second set of denoise buffers while this call queues its kernels)
+    struct SwapPost { ycge_ctx *c; bool on;
+        void swap() { std::swap(c->den_a, c->alt_post.den_a); std::swap(c->den_b, c->alt_post.den_b); std::swap(c->unit_n, c->alt_post.unit_n); std::swap(c->exp_terms, c->alt_post.exp_terms);
+                      std::swap(c->atrous_statw, c->alt_post.atrous_statw); std::swap(c->exp_scratch, c->alt_post.exp_scratch); std::swap(c->post_progress, c->alt_post.post_progress);
+                      std::swap(c->post_epoch, c->alt_post.post_epoch); std::swap(c->post_ticket, c->alt_post.post_ticket); }
+        SwapPost(ycge_ctx *c_, bool on_) : c(c_), on(on_) { if (on) swap(); }
+        ~SwapPost() { if (on) swap(); } } swap_post(c, second_set);
     const int w = c->hiW, h = c->hiH;
     const size_t n = (size_t)w * h;
     if (!c->den_a.p) {
         HIP_TRY(c, c->den_a.alloc(3 * n)); HIP_TRY(c, c->den_b.alloc(3 * n)); HIP_TRY(c, c->unit_n.alloc(3 * n));
-        HIP_TRY(c, c->exp_terms.alloc(n)); HIP_TRY(c, c->d_sdr.alloc((size_t)c->fbW * c->fbH * 6));
+        HIP_TRY(c, c->exp_terms.alloc(n));
     }
+    if (!c->d_sdr.p) HIP_TRY(c, c->d_sdr.alloc((size_t)c->fbW * c->fbH * 6));
     if (!c->tone_state.p) {
         HIP_TRY(c, c->tone_state.alloc(ycge_post_state_bytes()));
         const float init[4] = {1.0f, 1.0f, 0.0f, 0.0f};     // aeExposure = 1, effectiveExposure = 1 (ToneMapper.cs:13,17), count = 0
@@ -2106,6 +2123,7 @@ int run_post(ycge_ctx *c, hipStream_t stream, float *out_sdr_host, bool timed, h
     const int step = c->ss * 2 > 2 ? c->ss * 2 : 2;            // :226
     const float tone_consts[5] = {1.0f, 0.18f, 0.2f, 0.10f, 1.50f};     // toneExposure, aeKey, aeSpeed, aeMin, aeMax (ToneMapper.cs:8-16)
     if (!c->exp_scratch.p) HIP_TRY(c, c->exp_scratch.alloc(ycge_exposure_scratch_bytes(w, h, step)));
+    if (tone_wait) HIP_TRY(c, hipStreamWaitEvent(stream, tone_wait, 0));
     e = ycge_launch_exposure(cur, c->sky.p, w, h, step, c->exp_terms.p, c->tone_state.p, tone_consts, c->exp_scratch.p, c->knobs.exposure_serial ? 1 : 0, stream);
     if (e != 0) return c->fail(YCGE_ERR_DEVICE, "exposure launch failed: %s", hipGetErrorString((hipError_t)e));
     if (second_sdr && !c->d_sdr2.p) HIP_TRY(c, c->d_sdr2.alloc((size_t)c->fbW * c->fbH * 6));
@@ -2363,10 +2381,14 @@ static int render_frame_in_flight(ycge_ctx *c, float *out_sdr)
         hipStream_t ps = overlap_scene ? ts : c->stream2 ? c->stream2 : ts;
         HIP_TRY(c, hipEventRecord(c->flight_taa_ev, c->taa_stream));
         HIP_TRY(c, hipStreamWaitEvent(ps, c->flight_taa_ev, 0));
-        if (c->post_busy) HIP_TRY(c, hipStreamWaitEvent(ps, c->post_done_ev, 0));
-        // (the read-back, 0.5 ms of PCIe for a 1920 x 540 console, is not part of what the next post stage waits for where the two run on
-        // different streams: two SDR arrays on the device, by frame parity)
-        rc = run_post(c, ps, out_sdr, false, c->post_hist_ev, overlap_scene ? c->post_done_ev : nullptr, overlap_scene && k == 1);
+        // Where two traces run at a time the post stages of consecutive frames are on different streams and run SIDE BY SIDE: a set of
+        // denoise buffers and a device SDR array per frame parity (the read-back, 0.5 ms of PCIe for a 1920 x 540 console, is in nobody's
+        // way either); only the exposure step waits for the frame before - its state passes from frame to frame (ToneMapper.cs:49-91).
+        // Elsewhere the post stages follow each other.
+        const bool side_by_side = overlap_scene && c->knobs.flight_post_pair;
+        if (c->post_busy && !side_by_side) HIP_TRY(c, hipStreamWaitEvent(ps, c->post_done_ev, 0));
+        rc = run_post(c, ps, out_sdr, false, c->post_hist_ev, overlap_scene ? c->post_done_ev : nullptr, overlap_scene && k == 1,
+                      (side_by_side && c->post_busy) ? c->post_done_ev : nullptr, side_by_side && k == 1);
         if (rc != YCGE_OK) return rc;
         if (!overlap_scene) HIP_TRY(c, hipEventRecord(c->post_done_ev, ps));
         HIP_TRY(c, hipEventRecord(c->post_set_ev[k], ps));
