@@ -263,6 +263,10 @@ struct TraceOut {
     uint32_t *block_cost;
     const uint32_t *block_order;
     const uint32_t *n_order;
+    // frames in flight: the LAST workgroup of the launch stores placed_value here when it starts - every workgroup before it has a
+    // place then, and the next frame's trace (which waits for the value, hipStreamWaitValue32) gets what this launch leaves free
+    uint32_t *placed_flag;
+    uint32_t placed_value;
     const uint32_t *n_fan;              // the first *n_fan schedule entries are traced by k_trace_fan (null or 0: none)
     // traversal counters (may be null): rays, box, tri, prim, vox
     unsigned long long *counters;

@@ -30,7 +30,7 @@ int ycge_launch_trace(const ycge::SceneDev *S, const ycge::FrameParams *P, const
                       hipStream_t stream);
 int ycge_launch_wavefront(const ycge::SceneDev *S, const ycge::FrameParams *P, const ycge::TraceOut *O, void *const bufs[7], int rounds,
                           int has_grid, int flat, int count, int persistent_waves, hipStream_t stream);
-int ycge_launch_order_blocks(uint32_t *cost, uint32_t n, uint32_t policy, uint32_t split_top, uint32_t fan_class, uint32_t fan_cap, uint32_t next_slot, uint32_t skip_slot, uint32_t *order_ws,
+int ycge_launch_order_blocks(uint32_t *cost, uint32_t n, uint32_t policy, uint32_t split_top, uint32_t fan_class, uint32_t fan_cap, uint32_t next_slot, uint32_t skip_mask, uint32_t *order_ws,
                              uint32_t *order, hipStream_t stream, int small_groups = 0);
 int ycge_launch_trace_fan(const ycge::SceneDev *S, const ycge::FrameParams *P, const ycge::TraceOut *O, int count, int flat, uint32_t fan_cap,
                           hipStream_t stream);
@@ -124,6 +124,7 @@ struct Knobs {
     bool flight_small_groups = true; // YCGE_FLIGHT_SMALL_GROUPS: TAA and schedule kernels of the frames in flight in small workgroups (they find room beside a running trace)
     int flight_priority = 1;         // YCGE_FLIGHT_PRIORITY: the second stream's priority: 1 highest, 0 normal, -1 lowest
     bool flight_post_pair = true;    // YCGE_FLIGHT_POST_PAIR: the post stages of consecutive frames in flight side by side (second set of denoise buffers)
+    bool flight_placed_gate = true;  // YCGE_FLIGHT_PLACED_GATE: a frame in flight traces once the trace before it has placed its last workgroup (a value that kernel stores)
     bool flight_post_gate = true;    // YCGE_FLIGHT_POST_GATE: a frame in flight traces only once the post stage before it has passed its first iteration
     bool flight_overlap = true;      // YCGE_FLIGHT_OVERLAP: frames in flight alternate between two trace streams (two traces may overlap)
     bool flight_no_begin = false;      // experiments on ycge_render_frame_async: second stream at normal priority; no begin-of-trace timing event
@@ -163,6 +164,7 @@ struct Knobs {
         post_pad_lds = geti("YCGE_POST_PAD_LDS", 0);
         flight_overlap = geti("YCGE_FLIGHT_OVERLAP", 1) != 0;
         flight_post_gate = geti("YCGE_FLIGHT_POST_GATE", 1) != 0;
+        flight_placed_gate = geti("YCGE_FLIGHT_PLACED_GATE", 1) != 0;
         flight_post_pair = geti("YCGE_FLIGHT_POST_PAIR", 1) != 0;
         flight_small_groups = geti("YCGE_FLIGHT_SMALL_GROUPS", 1) != 0;
         flight_priority = geti("YCGE_FLIGHT_PRIORITY", 1);
@@ -251,24 +253,29 @@ struct ycge_ctx {
     // alternate between the five buffers above and these (swapped before the trace: the names above are always the newest frame's)
     DevBuf<float> alt_hdr, alt_albedo, alt_normal, alt_depth;
     DevBuf<uint8_t> alt_sky;
+    DevBuf<float> alt2_hdr, alt2_albedo, alt2_normal, alt2_depth;      // (three sets: the trace of frame N + 1 must not wait for the TAA of frame N - 1, which finds
+    DevBuf<uint8_t> alt2_sky;                                          //  its places among frame N's wavefronts late; it waits for TAA of frame N - 2)
+    int set_id[3] = {0, 1, 2};                     // which of the three sets the names current / alt / alt2 hold
     hipStream_t taa_stream = nullptr, stream2 = nullptr;      // stream2: the traces of odd frames in flight (two traces may overlap: the tail of one, the bulk of the next)
     DevBuf<uint64_t> stack_spill2;                 // ... which then need a traversal-stack spill area of their own
     uint64_t *spill_override = nullptr;            // set around trace_frame by ycge_render_frame_async
     hipEvent_t flight_fork_ev = nullptr;
+    uint32_t *placed_flag = nullptr;               // signal memory: the number of the newest frame in flight whose trace has placed its last workgroup
+    uint32_t placed_expect = 0, placed_next = 0;   // what the next trace waits for (0: nothing) / the value the next trace stores
     // frames in flight WITH the post stage (ycge_render_frame_async_sdr): post of frame N beside the traces and TAA of the frames after it
-    hipEvent_t flight_taa_ev = nullptr, post_hist_ev = nullptr, post_done_ev = nullptr, post_set_ev[2] = {nullptr, nullptr};
-    bool post_hist_pending = false, post_busy = false, post_set_pending[2] = {false, false};
+    hipEvent_t flight_taa_ev = nullptr, post_hist_ev = nullptr, post_done_ev = nullptr, post_set_ev[3] = {nullptr, nullptr, nullptr};
+    bool post_hist_pending = false, post_busy = false, post_set_pending[3] = {false, false, false};
     hipEvent_t tile_trace_ev[2] = {nullptr, nullptr};      // tiled frames: the trace (and slab pack) of the newest frame of each parity is done
     bool tile_trace_used[2] = {false, false};
-    hipEvent_t set_resolved_ev[2] = {nullptr, nullptr};
-    bool set_read[2] = {false, false};             // a TAA launch on taa_stream has read this set: the next trace into it waits for set_resolved_ev
+    hipEvent_t set_resolved_ev[3] = {nullptr, nullptr, nullptr};
+    bool set_read[3] = {false, false, false};             // a TAA launch on taa_stream has read this set: the next trace into it waits for set_resolved_ev
     int out_set = 0;                               // which set the names above hold
     bool async_outstanding = false;
     // ... and their schedules: the one for frame N + 1 is built WHILE frame N is traced, from the costs up to frame N - 1 (a frame
     // staler than the synchronous path's, which builds it between the two traces), into the buffers frame N is not reading
-    DevBuf<uint32_t> flight_order[2], flight_ws[2];
-    int64_t flight_order_frame[2] = {-1, -1};      // the frame number each buffer's schedule was built for (-1: none)
-    hipEvent_t flight_order_ev[2] = {nullptr, nullptr};     // tiled frames: the schedule in each buffer is complete (side stream)
+    DevBuf<uint32_t> flight_order[3], flight_ws[3];         // (frames in flight use all three, by frame number mod 3; tiled frames two, by parity)
+    int64_t flight_order_frame[3] = {-1, -1, -1};  // the frame number each buffer's schedule was built for (-1: none)
+    hipEvent_t flight_order_ev[3] = {nullptr, nullptr, nullptr};     // the schedule in each buffer is complete (side stream)
     int64_t last_frame_deferred = -2;              // the newest tiled frame whose trace was followed by a deferred schedule
     bool in_flight_taa = false;                    // taa_and_commit is called by ycge_render_frame_async with two traces overlapping: one-wavefront workgroups
     bool in_flight_call = false;                   // trace_frame is called by ycge_render_frame_async
@@ -399,7 +406,7 @@ int alloc_tile_buffers(ycge_ctx *c)
         HIP_TRY(c, hipMemset(c->order_ws.p, 0, 96 * sizeof(uint32_t)));
         HIP_TRY(c, hipMemset(c->block_cost.p, 0, nb * YCGE_COST_FRAMES * sizeof(uint32_t)));
         c->block_order_valid = false;
-        for (int k = 0; k < 2; k++) { c->flight_order[k].release(); c->flight_ws[k].release(); c->flight_order_frame[k] = -1; }      // (allocated by the first frame in flight)
+        for (int k = 0; k < 3; k++) { c->flight_order[k].release(); c->flight_ws[k].release(); c->flight_order_frame[k] = -1; }      // (allocated by the first frame in flight)
     }
     {   // XCD-aware block -> tile table: bucket the owned tiles by image strip (4 tiles = 128 px wide, strip s -> XCD s % 8),
         // then deal the buckets out round-robin so that block b (which lands on XCD b % 8) draws from bucket b % 8
@@ -450,7 +457,8 @@ int set_geometry(ycge_ctx *c, int fbw, int fbh, int ss)
     c->pending.clear();
     c->t_hdr.release(); c->t_albedo.release(); c->t_normal.release(); c->t_depth.release(); c->t_sky.release();
     c->alt_hdr.release(); c->alt_albedo.release(); c->alt_normal.release(); c->alt_depth.release(); c->alt_sky.release();      // (callers have quiesced the device)
-    c->set_read[0] = c->set_read[1] = false; c->out_set = 0; c->async_outstanding = false;
+    c->alt2_hdr.release(); c->alt2_albedo.release(); c->alt2_normal.release(); c->alt2_depth.release(); c->alt2_sky.release();
+    c->set_read[0] = c->set_read[1] = c->set_read[2] = false; c->out_set = 0; c->async_outstanding = false;
     c->tile_trace_used[0] = c->tile_trace_used[1] = false;
     for (auto *sc : c->schedules) delete sc;      // level schedules are per size: rebuilt on demand (the destructor frees the device lists)
     c->schedules.clear();
@@ -746,14 +754,16 @@ void ycge_destroy(ycge_ctx *c)
     if (c->taa_stream) { (void)hipStreamSynchronize(c->taa_stream); (void)hipStreamDestroy(c->taa_stream); c->taa_stream = nullptr; }
     if (c->stream2) { (void)hipStreamSynchronize(c->stream2); (void)hipStreamDestroy(c->stream2); c->stream2 = nullptr; }
     if (c->flight_fork_ev) (void)hipEventDestroy(c->flight_fork_ev);
+    if (c->placed_flag) (void)hipFree(c->placed_flag);
     for (int k = 0; k < 2; k++) if (c->tile_trace_ev[k]) (void)hipEventDestroy(c->tile_trace_ev[k]);
-    for (hipEvent_t ev : {c->flight_taa_ev, c->post_hist_ev, c->post_done_ev, c->post_set_ev[0], c->post_set_ev[1]}) if (ev) (void)hipEventDestroy(ev);
+    for (hipEvent_t ev : {c->flight_taa_ev, c->post_hist_ev, c->post_done_ev, c->post_set_ev[0], c->post_set_ev[1], c->post_set_ev[2]}) if (ev) (void)hipEventDestroy(ev);
     c->stack_spill2.release();
-    for (int k = 0; k < 2; k++) if (c->set_resolved_ev[k]) (void)hipEventDestroy(c->set_resolved_ev[k]);
-    for (int k = 0; k < 2; k++) { c->flight_order[k].release(); c->flight_ws[k].release(); if (c->flight_order_ev[k]) (void)hipEventDestroy(c->flight_order_ev[k]); }
+    for (int k = 0; k < 3; k++) if (c->set_resolved_ev[k]) (void)hipEventDestroy(c->set_resolved_ev[k]);
+    for (int k = 0; k < 3; k++) { c->flight_order[k].release(); c->flight_ws[k].release(); if (c->flight_order_ev[k]) (void)hipEventDestroy(c->flight_order_ev[k]); }
     for (hipEvent_t ev : c->flight_ev) (void)hipEventDestroy(ev);
     c->flight_ev.clear();
     c->alt_hdr.release(); c->alt_albedo.release(); c->alt_normal.release(); c->alt_depth.release(); c->alt_sky.release();
+    c->alt2_hdr.release(); c->alt2_albedo.release(); c->alt2_normal.release(); c->alt2_depth.release(); c->alt2_sky.release();
     c->den_a.release(); c->den_b.release(); c->unit_n.release(); c->exp_terms.release(); c->exp_scratch.release(); c->d_sdr.release(); c->d_sdr2.release(); c->atrous_statw.release(); c->tone_state.release();
     for (auto *sc : c->schedules) delete sc;
     c->schedules.clear();
@@ -807,8 +817,8 @@ int quiesce(ycge_ctx *c)
     // scene updates rewrite live allocations in place (DevBuf::upload), so wait for the whole device - this is a per-scene-change
     // call, never part of a frame
     HIP_TRY(c, hipDeviceSynchronize());
-    c->async_outstanding = false; c->set_read[0] = c->set_read[1] = false;        // (frames in flight included)
-    c->post_hist_pending = c->post_busy = c->post_set_pending[0] = c->post_set_pending[1] = false;
+    c->async_outstanding = false; c->set_read[0] = c->set_read[1] = c->set_read[2] = false;        // (frames in flight included)
+    c->post_hist_pending = c->post_busy = c->post_set_pending[0] = c->post_set_pending[1] = c->post_set_pending[2] = false;
     return YCGE_OK;
 }
 
@@ -992,7 +1002,7 @@ int install_objects(ycge_ctx *c, const ObjectsHost &oh)
     sd.scene_nodes = c->d_scene_nodes.p; sd.scene_leaf_prims = c->d_scene_leaf.p; sd.prims = c->d_prims.p;
     sd.scene_root_ref = oh.scene_root;
     for (int a = 0; a < 3; a++) { sd.scene_root_min[a] = oh.root_min[a]; sd.scene_root_max[a] = oh.root_max[a]; }
-    c->block_order_valid = false; c->flight_order_frame[0] = c->flight_order_frame[1] = -1;
+    c->block_order_valid = false; c->flight_order_frame[0] = c->flight_order_frame[1] = c->flight_order_frame[2] = -1;
     return YCGE_OK;
 }
 
@@ -1087,7 +1097,7 @@ int install_scene(ycge_ctx *c, const SceneArrays &A, const ObjectsHost &oh, cons
     rc = upload_lights(c, s->lights, s->n_lights);
     if (rc != YCGE_OK) return rc;
     c->have_scene = true;
-    c->block_order_valid = false; c->flight_order_frame[0] = c->flight_order_frame[1] = -1;
+    c->block_order_valid = false; c->flight_order_frame[0] = c->flight_order_frame[1] = c->flight_order_frame[2] = -1;
     return YCGE_OK;
 }
 
@@ -1658,6 +1668,7 @@ int trace_frame(ycge_ctx *c, float *d_slab, hipStream_t stream, FrameState &fs, 
     if (debug) { O.rays = c->dbg_rays.p; O.prim_id = c->dbg_prim.p; O.sub_id = c->dbg_sub.p; O.hit_t = c->dbg_hit_t.p; O.rng_state = c->dbg_rng.p; }
     if (c->knobs.wave_prof_stage >= 0) { if (!c->wave_prof.p) HIP_TRY(c, c->wave_prof.alloc((size_t)c->n_tiles * 16)); O.wave_prof = c->wave_prof.p; O.wave_prof_stage = c->knobs.wave_prof_stage; }
     O.counters = c->counters.p;
+    if (c->in_flight_call && c->placed_flag && c->placed_next) { O.placed_flag = c->placed_flag; O.placed_value = c->placed_next; }
     if (c->cfg.count_work) HIP_TRY(c, hipMemsetAsync(c->counters.p, 0, 6 * sizeof(unsigned long long), stream));
     if (timed) HIP_TRY(c, hipEventRecord(c->ev[0], stream));
     int e;
@@ -1699,10 +1710,12 @@ int trace_frame(ycge_ctx *c, float *d_slab, hipStream_t stream, FrameState &fs, 
                 HIP_TRY(c, hipMemsetAsync(c->block_cost.p + (size_t)((cost_slot + 1u) % YCGE_COST_FRAMES) * n_blocks, 0, (size_t)n_blocks * sizeof(uint32_t), stream));
             c->last_frame_deferred = fs.frame;
         }
-        if (lpt && c->flight_order_frame[fk] == fs.frame) {          // a schedule built in flight for exactly this frame (also the first synchronous frame after a burst);
-            O.block_order = c->flight_order[fk].p;                   // ycge_render_frame_async has made the stream wait for it (set_resolved_ev), a synchronous caller has joined
-            if (deferred) HIP_TRY(c, hipStreamWaitEvent(stream, c->flight_order_ev[fk], 0));       // (built two frames ago on the side stream)
-            O.n_order = c->flight_ws[fk].p + 16;
+        int fo = -1;            // a schedule built ahead for exactly this frame (frames in flight, tiled frames; also the first synchronous frame after a burst)
+        for (int q = 0; q < 3; q++) if (lpt && c->flight_order_frame[q] == fs.frame) fo = q;
+        if (fo >= 0) {
+            O.block_order = c->flight_order[fo].p;                   // (a synchronous caller has joined the frames in flight)
+            if (deferred || flight) HIP_TRY(c, hipStreamWaitEvent(stream, c->flight_order_ev[fo], 0));       // (built frames ago on a side stream)
+            O.n_order = c->flight_ws[fo].p + 16;
             if (c->order_pending) { HIP_TRY(c, hipStreamWaitEvent(stream, c->order_ev, 0)); c->order_pending = false; }        // (an older synchronous schedule still on the side stream: it cleared this frame's cost slot)
         } else {
         if (c->order_pending) { HIP_TRY(c, hipStreamWaitEvent(stream, c->order_ev, 0)); c->order_pending = false; }     // the schedule built beside the last frame's TAA
@@ -1739,7 +1752,7 @@ int trace_frame(ycge_ctx *c, float *d_slab, hipStream_t stream, FrameState &fs, 
         } else if (e == 0 && deferred) {
             HIP_TRY(c, hipEventRecord(c->traced_ev, stream));
             HIP_TRY(c, hipStreamWaitEvent(c->fan_stream, c->traced_ev, 0));
-            e = ycge_launch_order_blocks(c->block_cost.p, n_blocks, policy, split_top, c->fan_class, c->fan_cap, (cost_slot + 2u) % YCGE_COST_FRAMES, (cost_slot + 1u) % YCGE_COST_FRAMES,
+            e = ycge_launch_order_blocks(c->block_cost.p, n_blocks, policy, split_top, c->fan_class, c->fan_cap, (cost_slot + 2u) % YCGE_COST_FRAMES, 1u << ((cost_slot + 1u) % YCGE_COST_FRAMES),
                                          c->flight_ws[fk].p, c->flight_order[fk].p, c->fan_stream);
             if (e == 0 && c->h_n_fan && c->fan_cap > 0) HIP_TRY(c, hipMemcpyAsync(c->h_n_fan, c->flight_ws[fk].p + 18, sizeof(uint32_t), hipMemcpyDeviceToHost, c->fan_stream));
             HIP_TRY(c, hipEventRecord(c->flight_order_ev[fk], c->fan_stream));
@@ -1749,7 +1762,7 @@ int trace_frame(ycge_ctx *c, float *d_slab, hipStream_t stream, FrameState &fs, 
             // pack and all-gather), instead of 25 us in front of it; the next trace waits for it (order_ev)
             HIP_TRY(c, hipEventRecord(c->traced_ev, stream));
             HIP_TRY(c, hipStreamWaitEvent(c->fan_stream, c->traced_ev, 0));
-            e = ycge_launch_order_blocks(c->block_cost.p, n_blocks, policy, split_top, c->fan_class, c->fan_cap, (cost_slot + 1u) % YCGE_COST_FRAMES, 0xffffffffu, c->order_ws.p, c->block_order.p, c->fan_stream);
+            e = ycge_launch_order_blocks(c->block_cost.p, n_blocks, policy, split_top, c->fan_class, c->fan_cap, (cost_slot + 1u) % YCGE_COST_FRAMES, 0u, c->order_ws.p, c->block_order.p, c->fan_stream);
 
             c->block_order_valid = true;
             if (e == 0 && c->h_n_fan && c->fan_cap > 0) HIP_TRY(c, hipMemcpyAsync(c->h_n_fan, c->order_ws.p + 18, sizeof(uint32_t), hipMemcpyDeviceToHost, c->fan_stream));
@@ -2246,8 +2259,8 @@ static int join_async(ycge_ctx *c)
     if (c->stream2) HIP_TRY(c, hipStreamSynchronize(c->stream2));
     HIP_TRY(c, hipStreamSynchronize(c->taa_stream));
     c->async_outstanding = false;
-    c->set_read[0] = c->set_read[1] = false;
-    c->post_hist_pending = c->post_busy = c->post_set_pending[0] = c->post_set_pending[1] = false;
+    c->set_read[0] = c->set_read[1] = c->set_read[2] = false;
+    c->post_hist_pending = c->post_busy = c->post_set_pending[0] = c->post_set_pending[1] = c->post_set_pending[2] = false;
     return YCGE_OK;
 }
 
@@ -2305,7 +2318,8 @@ static int render_frame_in_flight(ycge_ctx *c, float *out_sdr)
     if (c->cfg.capture_debug || c->cfg.count_work) return c->fail(YCGE_ERR_INVALID_ARG, "ycge_render_frame_async keeps neither debug captures nor per-frame counters: use ycge_render_frame");
     HIP_TRY(c, hipSetDevice(c->device));
     if (!c->taa_stream) return c->fail(YCGE_ERR_INVALID_ARG, "no second stream: frames in flight need a single-device context");
-    for (int k = 0; k < 2; k++) if (!c->set_resolved_ev[k]) HIP_TRY(c, hipEventCreateWithFlags(&c->set_resolved_ev[k], hipEventDisableTiming));
+    for (int k = 0; k < 3; k++) if (!c->set_resolved_ev[k]) HIP_TRY(c, hipEventCreateWithFlags(&c->set_resolved_ev[k], hipEventDisableTiming));
+    for (int k = 0; k < 3; k++) if (!c->flight_order_ev[k]) HIP_TRY(c, hipEventCreateWithFlags(&c->flight_order_ev[k], hipEventDisableTiming));
     if (c->flight_ev.empty()) {
         c->flight_ev.resize(2 * YCGE_FLIGHT_RING, nullptr);
         for (hipEvent_t &ev : c->flight_ev) HIP_TRY(c, hipEventCreate(&ev));
@@ -2315,8 +2329,12 @@ static int render_frame_in_flight(ycge_ctx *c, float *out_sdr)
         HIP_TRY(c, c->alt_hdr.alloc(3 * npx)); HIP_TRY(c, c->alt_albedo.alloc(3 * npx)); HIP_TRY(c, c->alt_normal.alloc(3 * npx));
         HIP_TRY(c, c->alt_depth.alloc(npx)); HIP_TRY(c, c->alt_sky.alloc(npx));
     }
+    if (!c->alt2_hdr.p) {
+        HIP_TRY(c, c->alt2_hdr.alloc(3 * npx)); HIP_TRY(c, c->alt2_albedo.alloc(3 * npx)); HIP_TRY(c, c->alt2_normal.alloc(3 * npx));
+        HIP_TRY(c, c->alt2_depth.alloc(npx)); HIP_TRY(c, c->alt2_sky.alloc(npx));
+    }
     const uint32_t n_blocks = (uint32_t)c->n_owned * 4u;
-    for (int k = 0; k < 2; k++)
+    for (int k = 0; k < 3; k++)
         if (!c->flight_order[k].p) { HIP_TRY(c, c->flight_order[k].alloc((size_t)n_blocks * YCGE_SCHEDULE_SLACK)); HIP_TRY(c, c->flight_ws[k].alloc(96)); HIP_TRY(c, hipMemset(c->flight_ws[k].p, 0, 96 * sizeof(uint32_t))); }
     FrameState fs;
     snapshot_frame(c, fs);
@@ -2338,16 +2356,39 @@ static int render_frame_in_flight(ycge_ctx *c, float *out_sdr)
         // the first frame in flight after synchronous calls.  Whatever they left on the context's stream (a TAA, a post stage that reads
         // the current set) is ahead of this trace in stream order, and the second stream's first TAA waits for this trace.  The
         // synchronous schedule cleared THIS frame's cost slot; the next frame's would have been cleared between the two traces
-        HIP_TRY(c, hipMemsetAsync(c->block_cost.p + (size_t)((uint64_t)(fs.frame + 1) % YCGE_COST_FRAMES) * n_blocks, 0, (size_t)n_blocks * sizeof(uint32_t), c->stream));
+        for (int ahead = 1; ahead <= 2; ahead++)        // (the schedules queued in flight clear the slot of the frame three ahead)
+            HIP_TRY(c, hipMemsetAsync(c->block_cost.p + (size_t)((uint64_t)(fs.frame + ahead) % YCGE_COST_FRAMES) * n_blocks, 0, (size_t)n_blocks * sizeof(uint32_t), c->stream));
     }
     // the other set becomes "the current frame's": every later reader (TAA below, a read-back, a synchronous frame's post stage) goes by these names
-    std::swap(c->current_hdr, c->alt_hdr); std::swap(c->g_albedo, c->alt_albedo); std::swap(c->g_normal, c->alt_normal);
-    std::swap(c->g_depth, c->alt_depth); std::swap(c->sky, c->alt_sky);
-    c->out_set ^= 1;
-    const int k = c->out_set;
+    // (three sets: current <- alt2, frame N - 3's; alt2 <- alt, N - 2's; alt <- the old current, N - 1's)
+    auto rotate3 = [](auto &a, auto &b, auto &d) { std::swap(a, d); std::swap(b, d); };
+    rotate3(c->current_hdr, c->alt_hdr, c->alt2_hdr); rotate3(c->g_albedo, c->alt_albedo, c->alt2_albedo); rotate3(c->g_normal, c->alt_normal, c->alt2_normal);
+    rotate3(c->g_depth, c->alt_depth, c->alt2_depth); rotate3(c->sky, c->alt_sky, c->alt2_sky);
+    rotate3(c->set_id[0], c->set_id[1], c->set_id[2]);
+    const int k = c->out_set = c->set_id[0];
+    const int par = (int)(fs.frame & 1);          // the trace stream, the denoise buffers and the device SDR array go by frame parity
     // ONE wait per frame on the trace's stream: the second stream's work of two frames ago - TAA (it read this set of buffers) and
     // behind it the schedule for THIS frame (it wrote the order buffer of this parity and cleared this frame's cost slot)
     if (c->set_read[k]) HIP_TRY(c, hipStreamWaitEvent(ts, c->set_resolved_ev[k], 0));
+    // ... and (two traces at a time) for the moment the trace before has PLACED its last workgroup: started earlier, this frame's heaviest
+    // blocks take wavefront places from that frame's bulk - both frames' longest chains then start late - and started later the machine
+    // idles.  The last workgroup of a trace launch stores the frame's sequence number; this stream waits for the value.
+    if (overlap_scene && c->knobs.flight_placed_gate && c->knobs.refill_steps == 0 /* (k_trace_refill stores no value) */) {
+        if (!c->placed_flag) {
+            // (a runtime without signal memory: no gate - the frames come out the same, a little later)
+            if (hipExtMallocWithFlags((void **)&c->placed_flag, 8, hipMallocSignalMemory) != hipSuccess || hipMemset(c->placed_flag, 0, 8) != hipSuccess) {
+                (void)hipGetLastError();
+                if (c->placed_flag) { (void)hipFree(c->placed_flag); c->placed_flag = nullptr; }
+                c->knobs.flight_placed_gate = false;
+            }
+            c->placed_expect = 0; c->placed_next = 0;
+        }
+    }
+    if (overlap_scene && c->knobs.flight_placed_gate && c->knobs.refill_steps == 0 && c->placed_flag) {
+        if (c->placed_expect) HIP_TRY(c, hipStreamWaitValue32(ts, c->placed_flag, c->placed_expect, hipStreamWaitValueGte, 0xffffffffu));
+        c->placed_next = c->placed_expect + 1u;
+        if (c->placed_next == 0u) c->placed_next = 1u;
+    } else c->placed_next = 0;
     if (c->post_set_pending[k]) { HIP_TRY(c, hipStreamWaitEvent(ts, c->post_set_ev[k], 0)); c->post_set_pending[k] = false; }      // a post stage still reads this set's G-buffer
     // ... and a trace does not start while the post stage of the frame before has yet to place its persistent in-place launch: behind a
     // running trace's 64 800 pending workgroups its band workgroups (nine wavefronts each) find their CUs one by one, and every band
@@ -2361,18 +2402,32 @@ static int render_frame_in_flight(ycge_ctx *c, float *out_sdr)
     c->spill_override = nullptr;
     c->in_flight_call = false;
     if (rc != YCGE_OK) return rc;
+    if (c->placed_next && fs.scheduled) c->placed_expect = c->placed_next;       // (only the single-launch kernels store the value)
     HIP_TRY(c, hipEventRecord(ev_end, ts));          // end of the trace: the timing ring's event is also what the second stream waits for
     c->flight_frames++;
     HIP_TRY(c, hipStreamWaitEvent(c->taa_stream, ev_end, 0));
+    const bool small = c->knobs.flight_overlap && c->knobs.flight_small_groups;
+    if (fs.scheduled) {
+        // the schedule of frame N + 2, from the costs up to this frame's: the slot frame N + 1's trace is writing meanwhile is left out,
+        // the one frame N + 2's will write is cleared; into the order buffer this frame's trace has just finished reading
+        uint32_t policy, split_top;
+        schedule_policy(c, policy, split_top);
+        const uint32_t in_flight = (1u << ((uint64_t)(fs.frame + 1) % YCGE_COST_FRAMES)) | (1u << ((uint64_t)(fs.frame + 2) % YCGE_COST_FRAMES));
+        const uint32_t target = (uint32_t)((uint64_t)(fs.frame + 3) % YCGE_COST_FRAMES);
+        const int fk = (int)((uint64_t)fs.frame % 3u);
+        const int e = ycge_launch_order_blocks(c->block_cost.p, n_blocks, policy, split_top, 0u, 0u, target, in_flight, c->flight_ws[fk].p, c->flight_order[fk].p, c->taa_stream, small ? 1 : 0);
+        if (e != 0) return c->fail(YCGE_ERR_DEVICE, "schedule launch failed: %s", hipGetErrorString((hipError_t)e));
+        c->flight_order_frame[fk] = fs.frame + 3;
+        HIP_TRY(c, hipEventRecord(c->flight_order_ev[fk], c->taa_stream));
+    }
     if (c->post_hist_pending) { HIP_TRY(c, hipStreamWaitEvent(c->taa_stream, c->post_hist_ev, 0)); c->post_hist_pending = false; }      // the post stage of the frame before reads the history this TAA rewrites
     bool did_reset = false;
-    const bool small = c->knobs.flight_overlap && c->knobs.flight_small_groups;
     c->in_flight_taa = small;
     rc = taa_and_commit(c, c->taa_stream, fs, did_reset, false);
     c->in_flight_taa = false;
     if (rc != YCGE_OK) return rc;
     if (out_sdr) {
-        for (hipEvent_t *ev : {&c->flight_taa_ev, &c->post_hist_ev, &c->post_done_ev, &c->post_set_ev[0], &c->post_set_ev[1]})
+        for (hipEvent_t *ev : {&c->flight_taa_ev, &c->post_hist_ev, &c->post_done_ev, &c->post_set_ev[0], &c->post_set_ev[1], &c->post_set_ev[2]})
             if (!*ev) HIP_TRY(c, hipEventCreateWithFlags(ev, hipEventDisableTiming));
         // Steps 6-8 of this frame.  On the stream of this frame's trace where two traces run at a time (the next trace on that stream is
         // frame N + 2's, which must wait for this post stage anyway: it overwrites the G-buffer set the denoiser reads); on the second
@@ -2387,23 +2442,12 @@ static int render_frame_in_flight(ycge_ctx *c, float *out_sdr)
         // Elsewhere the post stages follow each other.
         const bool side_by_side = overlap_scene && c->knobs.flight_post_pair;
         if (c->post_busy && !side_by_side) HIP_TRY(c, hipStreamWaitEvent(ps, c->post_done_ev, 0));
-        rc = run_post(c, ps, out_sdr, false, c->post_hist_ev, overlap_scene ? c->post_done_ev : nullptr, overlap_scene && k == 1,
-                      (side_by_side && c->post_busy) ? c->post_done_ev : nullptr, side_by_side && k == 1);
+        rc = run_post(c, ps, out_sdr, false, c->post_hist_ev, overlap_scene ? c->post_done_ev : nullptr, overlap_scene && par == 1,
+                      (side_by_side && c->post_busy) ? c->post_done_ev : nullptr, side_by_side && par == 1);
         if (rc != YCGE_OK) return rc;
         if (!overlap_scene) HIP_TRY(c, hipEventRecord(c->post_done_ev, ps));
         HIP_TRY(c, hipEventRecord(c->post_set_ev[k], ps));
         c->post_busy = true; c->post_hist_pending = true; c->post_set_pending[k] = true;
-    }
-    if (fs.scheduled) {
-        // the schedule of frame N + 2, from the costs up to this frame's: the slot frame N + 1's trace is writing meanwhile is left out,
-        // the one frame N + 2's will write is cleared; into the order buffer this frame's trace has just finished reading
-        uint32_t policy, split_top;
-        schedule_policy(c, policy, split_top);
-        const uint32_t next_writes = (uint32_t)((uint64_t)(fs.frame + 1) % YCGE_COST_FRAMES), target = (uint32_t)((uint64_t)(fs.frame + 2) % YCGE_COST_FRAMES);
-        const int fk = (int)(fs.frame & 1);
-        const int e = ycge_launch_order_blocks(c->block_cost.p, n_blocks, policy, split_top, 0u, 0u, target, next_writes, c->flight_ws[fk].p, c->flight_order[fk].p, c->taa_stream, small ? 1 : 0);
-        if (e != 0) return c->fail(YCGE_ERR_DEVICE, "schedule launch failed: %s", hipGetErrorString((hipError_t)e));
-        c->flight_order_frame[fk] = fs.frame + 2;
     }
     HIP_TRY(c, hipEventRecord(c->set_resolved_ev[k], c->taa_stream));
     c->set_read[k] = true;

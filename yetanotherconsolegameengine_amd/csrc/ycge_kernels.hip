@@ -1103,6 +1103,7 @@ __device__ __forceinline__ void trace_block(const SceneDev &S, const FrameParams
 template <bool COUNT, bool FLAT>
 __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu((FLAT && !COUNT) ? YCGE_TRACE_WAVES : 2, 8))) void k_trace(const SceneDev S, const FrameParams P, const TraceOut O)
 {
+    if (O.placed_flag && blockIdx.x == gridDim.x - 1u && threadIdx.x == 0) __hip_atomic_store(O.placed_flag, O.placed_value, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
     uint32_t idx = blockIdx.x, ent = blockIdx.x;
     if (O.block_order) {
         if (O.n_fan) idx += *O.n_fan;           // the first n_fan entries belong to k_trace_fan
@@ -1115,6 +1116,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu((FLAT && !CO
 // peak): 125 registers, 4 wavefronts per SIMD - analytic scenes are throughput, not chains (config 2: 0.082 ms at 3 wavefronts, 0.068 at 4).
 __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 8))) void k_trace_nomesh(const SceneDev S, const FrameParams P, const TraceOut O)
 {
+    if (O.placed_flag && blockIdx.x == gridDim.x - 1u && threadIdx.x == 0) __hip_atomic_store(O.placed_flag, O.placed_value, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
     uint32_t idx = blockIdx.x, ent = blockIdx.x;
     if (O.block_order) {
         if (O.n_fan) idx += *O.n_fan;
@@ -1175,21 +1177,21 @@ __device__ __forceinline__ uint32_t class_lg_parts(uint32_t policy, int cls) { r
 // which blocks run long is a property of the image region (silhouettes seen at grazing angles), how long a given one runs in a
 // given frame depends on that frame's random bounce directions - the 40 longest-running blocks of a frame are found among the
 // top 200 of the previous frame's costs 58 % of the time, among the top 200 of max-over-four-frames 90 % (profiles/cost_persistence.py).
-// (skip_slot: the ring slot a trace that is RUNNING beside this schedule writes - frames in flight, ycge_render_frame_async - or none)
-__device__ __forceinline__ uint32_t smoothed_cost(const uint32_t *cost, uint32_t n, uint32_t i, uint32_t skip_slot)
+// (skip_mask: bit f set = ring slot f is being written by a trace that runs beside this schedule - frames in flight, tiled frames - and is left out)
+__device__ __forceinline__ uint32_t smoothed_cost(const uint32_t *cost, uint32_t n, uint32_t i, uint32_t skip_mask)
 {
     uint32_t m = 0;
 #pragma unroll
-    for (int f = 0; f < YCGE_COST_FRAMES; f++) { const uint32_t v = (uint32_t)f == skip_slot ? 0u : cost[(size_t)f * n + i]; m = v > m ? v : m; }
+    for (int f = 0; f < YCGE_COST_FRAMES; f++) { const uint32_t v = ((skip_mask >> f) & 1u) ? 0u : cost[(size_t)f * n + i]; m = v > m ? v : m; }
     return m;
 }
-__global__ __launch_bounds__(1024) void k_cost_hist(const uint32_t *__restrict__ cost, uint32_t n, uint32_t skip_slot, uint32_t *__restrict__ ws)
+__global__ __launch_bounds__(1024) void k_cost_hist(const uint32_t *__restrict__ cost, uint32_t n, uint32_t skip_mask, uint32_t *__restrict__ ws)
 {
     __shared__ uint32_t h[YCGE_ORDER_CLASSES];
     if (threadIdx.x < YCGE_ORDER_CLASSES) h[threadIdx.x] = 0;
     __syncthreads();
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < n) { const int cls = order_class(smoothed_cost(cost, n, i, skip_slot)); atomicAdd(&h[cls], 1u); }
+    if (i < n) { const int cls = order_class(smoothed_cost(cost, n, i, skip_mask)); atomicAdd(&h[cls], 1u); }
     __syncthreads();
     if (threadIdx.x < YCGE_ORDER_CLASSES && h[threadIdx.x]) atomicAdd(&ws[32 + threadIdx.x], h[threadIdx.x]);
 }
@@ -1214,7 +1216,7 @@ __device__ __forceinline__ ClassLayout class_layout(const uint32_t *ws, int cls,
     return L;
 }
 __global__ __launch_bounds__(1024) void k_cost_scatter(uint32_t *__restrict__ cost, uint32_t n, uint32_t capacity, uint32_t policy, uint32_t split_top,
-                                                       uint32_t fan_class, uint32_t fan_cap, uint32_t next_slot, uint32_t skip_slot, uint32_t *__restrict__ ws, uint32_t *__restrict__ order)
+                                                       uint32_t fan_class, uint32_t fan_cap, uint32_t next_slot, uint32_t skip_mask, uint32_t *__restrict__ ws, uint32_t *__restrict__ order)
 {
     __shared__ uint32_t h[YCGE_ORDER_CLASSES], rank0[YCGE_ORDER_CLASSES];
     __shared__ ClassLayout lay[YCGE_ORDER_CLASSES];
@@ -1241,7 +1243,7 @@ __global__ __launch_bounds__(1024) void k_cost_scatter(uint32_t *__restrict__ co
     int cls = -1;
     uint32_t local = 0;
     if (i < n) {
-        cls = order_class(smoothed_cost(cost, n, i, skip_slot));
+        cls = order_class(smoothed_cost(cost, n, i, skip_mask));
         cost[(size_t)next_slot * n + i] = 0;         // the ring slot the next frame's atomicMax goes to
         local = atomicAdd(&h[cls], 1u);
     }
@@ -1521,7 +1523,7 @@ int ycge_launch_wavefront(const ycge::SceneDev *S, const ycge::FrameParams *P, c
 }
 
 // builds next frame's k_trace schedule from this frame's per-block step counts.  ws: 18 uint32 (see k_cost_hist)
-int ycge_launch_order_blocks(uint32_t *cost, uint32_t n, uint32_t policy, uint32_t split_top, uint32_t fan_class, uint32_t fan_cap, uint32_t next_slot, uint32_t skip_slot,
+int ycge_launch_order_blocks(uint32_t *cost, uint32_t n, uint32_t policy, uint32_t split_top, uint32_t fan_class, uint32_t fan_cap, uint32_t next_slot, uint32_t skip_mask,
                              uint32_t *ws, uint32_t *order, hipStream_t stream, int small_groups)
 {
     if (n == 0) return 0;
@@ -1531,8 +1533,8 @@ int ycge_launch_order_blocks(uint32_t *cost, uint32_t n, uint32_t policy, uint32
     hipError_t e = hipMemsetAsync(ws, 0, 96 * sizeof(uint32_t), stream);     // ws[16] / ws[18] (entries, n_fan) are rewritten by k_cost_scatter before anyone reads them
     if (e != hipSuccess) return (int)e;
     const dim3 grid((n + threads - 1u) / threads), block(threads);
-    hipLaunchKernelGGL(ycge::k_cost_hist, grid, block, 0, stream, cost, n, skip_slot, ws);
-    hipLaunchKernelGGL(ycge::k_cost_scatter, grid, block, 0, stream, cost, n, n * YCGE_SCHEDULE_SLACK, policy, split_top, fan_class, fan_cap, next_slot, skip_slot, ws, order);
+    hipLaunchKernelGGL(ycge::k_cost_hist, grid, block, 0, stream, cost, n, skip_mask, ws);
+    hipLaunchKernelGGL(ycge::k_cost_scatter, grid, block, 0, stream, cost, n, n * YCGE_SCHEDULE_SLACK, policy, split_top, fan_class, fan_cap, next_slot, skip_mask, ws, order);
     return (int)hipGetLastError();
 }
 
