@@ -1,6 +1,6 @@
 """bench.py — headline benchmark of the MI355X ray-trace core (BASELINE.json metric).
 
-    python bench.py --gpus N --steps K --warmup W [--config 4] [--camera static|orbit] [--form auto|onecall|rccl]
+    python bench.py --gpus N --steps K --warmup W [--config 4] [--camera static|orbit] [--form auto|onecall|rccl] [--t01 0.25]
 
 A "step" is one frame of the hot path (ray-gen + per-pixel trace + TAA; with N > 1 also the reassembly of the tiles) over the
 configuration BASELINE.json quotes the metric on: config 4, the Dragon-class mesh (871,200-triangle procedural stand-in for the
@@ -16,9 +16,12 @@ How N GPUs are driven (`--form`):
            the tile slabs -> ycge_resolve_gathered on every rank.  What `auto` picks when WORLD_SIZE > 1.
 `n_gpus` in the line is the number of devices that traced tiles this run (`device_tiles` lists their tile counts), never the flag.
 
-value   = Mrays/s over ALL rays: calls to Scene.Hit + Scene.Occluded (primary, shadow, bounce) per frame / frame time, whole job.
-          Ray counts are exact: the timed frames are re-run with the counting kernel variant afterwards (same frame numbers and
-          poses, untimed).  `frame_ms` / `trace_ms` give median, min and mean over the timed steps (SURVEY 8d asks median + min).
+value   = Mrays/s over the rays the timed kernels TRACE: calls to Scene.Hit + Scene.Occluded (primary, shadow, bounce) per frame /
+          frame time, whole job.  Ray counts are exact: the timed frames are re-run with the counting kernel variant afterwards
+          (same frame numbers and poses, untimed).  Shadow rays towards a light of intensity 0 - which the reference traces and
+          the timed kernels do not (their contribution is a zero whatever they find) - are NOT in `value`; the rate with them
+          counted is printed beside it as `value_reference_ray_count` (config 5 at the survey's day phase --t01 0.25 has both
+          lights at 0; --t01 0.5 is noon, every ray traced).  `frame_ms` / `trace_ms`: median, min and mean over the timed steps.
 roofline= ALGORITHMIC bytes of the trace per launch (32*N_box + 48*N_tri + 64*N_prim + 1*N_vox + 118*pixels, counters
           of the REFERENCE's traversal from the counting replay) / its mean launch duration from HIP events on the kernel's own
           stream inside the timed region: `achieved` / `frac`.  That prices work, not memory traffic - most of those bytes are
@@ -72,13 +75,13 @@ METRIC_SHAPES = {1: "Cornell box 80x90 1spp", 2: "mirror spheres 640x360 1spp", 
                  4: "Dragon-class BVH 1920x1080 1spp", 5: "voxel volume grid 1920x1080 4spp + TAA"}
 
 
-def load_pmc(config, build_hash):
+def load_pmc(config, build_hash, tag=""):
     """Counter summary of the trace kernels of THIS config from the committed rocprofv3 PMC passes, newest round first.
     Returns (summary or None, stale): stale = a summary exists but was taken from another build of the kernels.
     Produced on the GPU box by profiles/run_profiles.sh -> summarize.py --json; bench.py itself never runs a profiler."""
     stale = False
-    for rnd in ("r03", "r02"):
-        p = ROOT / "profiles" / rnd / f"pmc_config{config}.json"
+    for rnd in ("r04", "r03", "r02"):
+        p = ROOT / "profiles" / rnd / f"pmc_config{config}{tag}.json"
         try:
             if p.exists():
                 d = json.loads(p.read_text())
@@ -112,6 +115,7 @@ def main():
     ap.add_argument("--config", type=int, default=4)
     ap.add_argument("--camera", choices=("static", "orbit"), default="static", help="orbit: the pose changes every frame of the timed region (the headline then is the moving-camera frame)")
     ap.add_argument("--form", choices=("auto", "onecall", "rccl"), default="auto", help="how N > 1 GPUs are driven (see the module docstring)")
+    ap.add_argument("--t01", type=float, default=0.25, help="config 5: day phase of the sun and moon (DayNightCycle.cs:48-82); 0.25 = SURVEY 8(d): sun on the horizon, BOTH lights at intensity 0; 0.5 = noon, 0.8 = night")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
     ap.add_argument("--no-post", action="store_true", help="skip the frames WITH the denoise/exposure/tonemap stage (reported apart as post_stage)")
@@ -152,7 +156,8 @@ def main():
     from yetanotherconsolegameengine_amd.renderer import RaytraceRenderer
     from yetanotherconsolegameengine_amd.scene import flatten
 
-    scene, fbw, fbh, ss, pose = scenes.config_scene(args.config)
+    scene, fbw, fbh, ss, pose = scenes.config_scene(args.config, t01=args.t01)
+    lit_tag = "" if (args.config != 5 or args.t01 == 0.25) else "_t%03d" % round(args.t01 * 100)
     flat = flatten(scene)
     hiW, hiH = fbw * ss, fbh * 2 * ss
     pixels = hiW * hiH
@@ -278,7 +283,9 @@ def main():
     rc.close()
 
     per_frame = {k: v / replay for k, v in tot.items()}
-    mrays = per_frame["n_rays"] * args.steps / elapsed / 1e6
+    traced_per_frame = per_frame["n_rays"] - per_frame["n_rays_dark"]     # what the timed kernels trace; n_rays is the reference's call count
+    mrays = traced_per_frame * args.steps / elapsed / 1e6
+    mrays_ref_count = per_frame["n_rays"] * args.steps / elapsed / 1e6
     ms_per_step = elapsed / args.steps * 1e3
     mean_trace_ms = float(np.mean(trace_ms)) if trace_ms and trace_ms[0] > 0 else None
     # roofline of the dominant kernel (k_trace) on THIS process's share of the frame
@@ -306,7 +313,7 @@ def main():
             roof["timed_work"] = {"lane_steps_per_launch": round(timed_lane_steps, 1), "bytes_per_launch": None,
                                   "what": "tree steps and voxel cell steps of the TIMED kernels, summed; the algorithmic figure above prices the REFERENCE's walk - every grid entered, every shadow ray traced - "
                                           "which the timed kernels do not make (solid-voxel cull, no ray towards a dark light): use the counter figures"}
-        pmc, stale = load_pmc(args.config, build_hash) if (world == 1 and n_dev == 1) else (None, False)
+        pmc, stale = load_pmc(args.config, build_hash, lit_tag) if (world == 1 and n_dev == 1) else (None, False)
         if pmc:
             # counters of the same kernels, same build, from the committed PMC passes; the rate uses THIS run's launch time
             t = pmc.get("traffic_bytes_per_launch")
@@ -373,10 +380,10 @@ def main():
             r.Wait()
             fsdr = {"frames": m, "ms_per_step": round((time.perf_counter() - ts0) / m * 1e3, 4),
                     "what": "ycge_render_frame_async_sdr: the post stage and read-back of frame N beside the traces and TAA of the frames after it; compare post_stage.frame_ms_with_sdr_readback"}
-        flight = {"frames": n, "ms_per_step": round(tf / n * 1e3, 4), "value": round(per_frame["n_rays"] * n / tf / 1e6, 2), "unit": "Mrays/s",
+        flight = {"frames": n, "ms_per_step": round(tf / n * 1e3, 4), "value": round(traced_per_frame * n / tf / 1e6, 2), "unit": "Mrays/s",
                   "trace_ms": dist3([float(x) for x in ft]) if len(ft) else None, "with_sdr": fsdr,
-                  "what": "the same frames queued with ycge_render_frame_async: no host wait between frames, TAA of frame N and the schedule of frame N + 2 on a second "
-                          "(low-priority) stream beside the trace of frame N + 1, trace outputs double-buffered; bit-identical frames (tests/test_gpu_timed_variants.py). "
+                  "what": "the same frames queued with ycge_render_frame_async: no host wait between frames, two traces at a time on two streams, TAA of frame N and the "
+                          "schedule of frame N + 3 on a third stream, three sets of trace outputs taken in turn; bit-identical frames (tests/test_gpu_timed_variants.py). "
                           "The headline `value` stays the synchronous call, which is the reference's TryFlipAndBlit; trace_ms here is the launch with TAA running beside it"}
 
     post = None
@@ -432,18 +439,20 @@ def main():
             "ms_per_step": round(ms_per_step, 4), "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
             "dtype": "f32", "data": "synthetic",
             "config": {"workload": f"config {args.config}: " + WORKLOADS[args.config],
-                       "trace_grid": f"{hiW}x{hiH}", "spp": ss * ss, "triangles": flat.n_triangles, "camera": args.camera,
+                       "trace_grid": f"{hiW}x{hiH}", "spp": ss * ss, "triangles": flat.n_triangles, "camera": args.camera, **({"t01": args.t01} if args.config == 5 else {}),
                        "lights": {"intensity": [float(l.Intensity) for l in scene.Lights],
                                   "note": "the timed kernels trace no shadow ray towards a light of intensity 0 (its contribution is a zero whatever the ray finds: bit-identical pixels); "
-                                          "`value` counts the reference's Scene.Hit / Scene.Occluded calls, which include those rays" if any(float(l.Intensity) == 0.0 for l in scene.Lights) else None},
+                                          "`value` counts traced rays only, `value_reference_ray_count` the reference's Scene.Hit / Scene.Occluded calls, which include those rays" if any(float(l.Intensity) == 0.0 for l in scene.Lights) else None},
                        "frame": "ray-gen + trace + TAA" + (" + RCCL all-gather of tile slabs + un-permute" if multi else " + peer tile push" if n_dev > 1 else ""),
                        "parallelism": f"framebuffer tiles 32x8 round-robin over {n_gpus_used} GPU(s): " + how, "form": form,
                        "gpus_requested": args.gpus, "device_tiles": device_tiles, "device": name, "compute_units": cus},
             "primary_mrays_per_s": round(pixels * args.steps / elapsed / 1e6, 2),
             "rays_per_frame": round(per_frame["n_rays"], 1),
-            # of which the timed kernels never trace: shadow rays towards lights of intensity 0 (bit-identical pixels); the rate over the rest beside `value`
+            # the reference's call count includes shadow rays towards lights of intensity 0, which the timed kernels never trace (bit-identical
+            # pixels): `value` is over traced rays, the rate with the reference's count is beside it
+            "rays_traced_per_frame": round(traced_per_frame, 1),
             "rays_to_dark_lights_per_frame": round(per_frame["n_rays_dark"], 1),
-            "value_traced_rays_only": round((per_frame["n_rays"] - per_frame["n_rays_dark"]) * args.steps / elapsed / 1e6, 2),
+            "value_reference_ray_count": round(mrays_ref_count, 2),
             "work_per_frame": {k: round(v, 1) for k, v in per_frame.items()},
             "roofline": roof, "cpu_baseline": cpu,
         }
@@ -455,8 +464,12 @@ def main():
             out["trace_ms"] = dist3(trace_ms)
         if n_gpus_used != args.gpus:
             out["warning"] = f"--gpus {args.gpus} asked for, {n_gpus_used} device(s) traced tiles"
-        if cpu:       # like for like: whole frames (trace + TAA) on both sides
-            out["gpu_over_cpu"] = round(mrays / cpu["whole_frame_serial_taa"]["value"], 2)
+        if cpu:       # like for like: whole frames (trace + TAA) on both sides, as a ratio of FRAME TIMES (the CPU side traces every ray of the
+            # reference, dark lights included, so a ratio of ray rates would credit the GPU with rays it never traces); 3 significant digits:
+            # the CPU side varies by a factor of two from frame to frame on a shared host (cpu_baseline.per_frame_mrays)
+            ratio = cpu["whole_frame_serial_taa"]["ms_per_frame"] / ms_per_step
+            out["gpu_over_cpu"] = float(f"{ratio:.3g}")
+            out["gpu_over_cpu_is"] = "cpu whole-frame ms (trace on all host threads + the reference's serial TAA) / gpu ms_per_step"
         if mov:
             out["moving_camera"] = mov
         if post:

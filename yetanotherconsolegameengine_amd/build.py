@@ -19,7 +19,7 @@ CSRC = PKG / "csrc"
 LIB_DIR = PKG / "lib"
 LIB = LIB_DIR / "libycge_hip.so"
 SOURCES = ["ycge_host.cpp", "ycge_accel.cpp", "ycge_kernels.hip", "ycge_post.hip", "ycge_bvh_build.hip"]
-HEADERS = ["ycge_device.h", "ycge_accel.h", "ycge_math.h", "ycge_rt.hip.h", "ycge_coop.hip.h", "ycge_keysort.h"]
+HEADERS = ["ycge_device.h", "ycge_accel.h", "ycge_math.h", "ycge_rt.hip.h", "ycge_coop.hip.h", "ycge_anyhit.hip.h", "ycge_keysort.h"]
 ARCH = "gfx950"
 
 FLAGS = [

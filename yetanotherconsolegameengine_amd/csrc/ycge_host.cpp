@@ -134,6 +134,7 @@ struct Knobs {
     int bvh_waves = 16;              // YCGE_BVH_WAVES: wavefronts of k_scene_bvh_build that take nodes (tests: the order nodes are split in must not matter)
     bool scene_bvh_host = false;     // YCGE_SCENE_BVH_HOST: ycge_scene_update_objects builds the scene BVH on the host, not on the device
     int scene_bvh_device_min = YCGE_BVH_DEV_MIN_ITEMS_DEFAULT;   // YCGE_SCENE_BVH_DEVICE_MIN: fewer objects than this are built on the host (measured crossover, profiles/r02/f2_update_objects_timing.txt)
+    bool no_bfs = false;             // YCGE_NO_BFS: occlusion queries keep the ordered walk (A/B of mesh_anyhit_bfs)
     bool no_coop = false;            // YCGE_NO_COOP: no treelets are built, sparse wavefronts keep the regular walk (A/B of the cooperative walk)
     bool exposure_serial = false;    // YCGE_EXPOSURE_SERIAL: the one-lane chain instead of the chunked exact evaluation
     void read()
@@ -172,6 +173,7 @@ struct Knobs {
         post_dbg_free = geti("YCGE_POST_DBG_FREE", 0) != 0;
         exposure_serial = getenv("YCGE_EXPOSURE_SERIAL") != nullptr;
         no_coop = getenv("YCGE_NO_COOP") != nullptr;
+        no_bfs = getenv("YCGE_NO_BFS") != nullptr;
         scene_bvh_host = getenv("YCGE_SCENE_BVH_HOST") != nullptr;
         bvh_waves = geti("YCGE_BVH_WAVES", 16);
         scene_bvh_device_min = geti("YCGE_SCENE_BVH_DEVICE_MIN", YCGE_BVH_DEV_MIN_ITEMS_DEFAULT);
@@ -1092,6 +1094,7 @@ int install_scene(ycge_ctx *c, const SceneArrays &A, const ObjectsHost &oh, cons
     sd.any_transparent = A.any_transparent ? 1 : 0;
     sd.any_textured = A.any_textured ? 1 : 0;
     sd.tl_offset = A.tl_offset;
+    sd.anyhit_bfs = c->knobs.no_bfs ? 0u : 1u;
     if (!c->dbg_counters.p) { HIP_TRY(c, c->dbg_counters.alloc(16 + 16 * 256)); HIP_TRY(c, hipMemset(c->dbg_counters.p, 0, (16 + 16 * 256) * sizeof(unsigned long long))); }
     sd.dbg_counters = c->dbg_counters.p;
     rc = upload_lights(c, s->lights, s->n_lights);

@@ -728,7 +728,7 @@ __device__ __forceinline__ bool is_wire_on_face(const GGrid &g, F3 p, int ix, in
 #define YCGE_LDS_STACK YCGE_LDS_STACK_LEVELS
 #define YCGE_BLOCK 256
 static __shared__ uint2 g_lds_stack[YCGE_LDS_STACK * YCGE_BLOCK];     // 256-thread workgroups (tile = workgroup)
-static __shared__ uint2 g_lds_stack64[YCGE_LDS_STACK * 64];           // 64-thread workgroups (8x8 block = workgroup)
+static __shared__ __attribute__((aligned(16))) uint2 g_lds_stack64[YCGE_LDS_STACK * 64];           // 64-thread workgroups (8x8 block = workgroup); while the stacks are empty: the work list of mesh_anyhit_bfs
 static __shared__ uint2 g_lds_stack192[YCGE_LDS_STACK * 192];         // 192-thread workgroups (k_trace_fan: a block's three wavefronts)
 
 // The LDS part is accessed with explicit ds_read_b64 / ds_write_b64: written as plain C++ the compiler merges the
@@ -1055,6 +1055,7 @@ __device__ __forceinline__ void load_record72(const uint8_t *base, uint32_t byte
 }
 } // namespace ycge
 #include "ycge_coop.hip.h"
+#include "ycge_anyhit.hip.h"
 namespace ycge {
 
 template <bool COUNT, bool BOUNDED = false, bool FULLWAVE = false, class STK>
@@ -1160,6 +1161,18 @@ __device__ __forceinline__ void traverse(const SceneDev &S, const RayQ &q, STK &
                 float tm;
                 if (COUNT) w.box++;
                 if (box_mesh(q1.x, q1.y, q1.z, q1.w, q2.x, q2.y, o, inv, sx, sy, sz, tmin, closest, tm)) start = root_ref;
+            }
+            if (FULLWAVE && !COUNT && STK::kBS == 64 && S.anyhit_bfs) {
+                // occlusion queries of this wavefront against the mesh: order-free, breadth-first from one shared work list (ycge_anyhit.hip.h);
+                // the stacks are empty here - between the objects of the flat scene - and lend it their LDS
+                const bool bfs = anyhit && start != YCGE_REF_NONE_VALUE;
+                if (__any(bfs)) {
+                    const unsigned long long occluded = mesh_anyhit_bfs(S, bfs, start, o, inv, d, tmin, closest, w);
+                    if (bfs) {
+                        start = YCGE_REF_NONE_VALUE;
+                        if ((occluded >> (threadIdx.x & 63u)) & 1ull) { hit_prim = pi; hit_sub = 0; }      // (an occlusion query's t and triangle are never looked at)
+                    }
+                }
             }
             mesh_walk<COUNT, false, FULLWAVE>(S, start, pi, st, o, inv, d, sx, sy, sz, tmin, closest, hit_prim, hit_sub, w, 0x7fffffff, anyhit);     // start is consumed
         } else if (type == 10) {

@@ -305,9 +305,11 @@ def BuildMinecraftLike(nx=544, ny=256, nz=544, chunk=32, seed=0, t01=0.25):
 
 # ------------------------------------------------------------------- registry
 
-def config_scene(n: int, small: bool = False):
+def config_scene(n: int, small: bool = False, t01: float = 0.25):
     """(scene, fbW, fbH, ss, pose) of BASELINE.json configs[n-1].
-    small=True shrinks the asset-sized inputs (mesh / world) for CPU-only tests."""
+    small=True shrinks the asset-sized inputs (mesh / world) for CPU-only tests.
+    t01 = day phase of config 5's sun and moon (DayNightCycle.cs:48-82).  SURVEY §8(d)'s 0.25 puts the sun ON the horizon: both
+    lights have intensity 0 there; 0.5 is noon (sun 300000 * sy^2, moon 0), 0.8 is night (moon 8000 * sqrt(-sy) * 0.1, sun 0)."""
     default_pose = dict(pos=(0.0, 1.0, 0.0), yaw=0.0, pitch=0.0, fov=45.0)
     if n == 1:
         return BuildCornellBox(), 80, 45, 1, default_pose
@@ -320,8 +322,8 @@ def config_scene(n: int, small: bool = False):
         return sc, 1920, 540, 1, dict(MESH_BENCH_POSE)
     if n == 5:
         if small:
-            sc, pose = BuildMinecraftLike(96, 128, 96, 32)
+            sc, pose = BuildMinecraftLike(96, 128, 96, 32, t01=t01)
         else:
-            sc, pose = BuildMinecraftLike()
+            sc, pose = BuildMinecraftLike(t01=t01)
         return sc, 1920, 540, 2, pose
     raise ValueError(n)
