@@ -35,7 +35,7 @@
 extern "C" {
 #endif
 
-#define YCGE_ABI_VERSION 6
+#define YCGE_ABI_VERSION 7
 #define YCGE_MAX_DEVICES 8
 
 typedef enum ycge_status {
@@ -65,8 +65,8 @@ typedef enum ycge_material_kind {
     YCGE_MAT_CHECKER = 1,        /* Scenes.cs:418-428: parity of floor(x/s)+floor(z/s) */
     YCGE_MAT_TEXTURED = 2        /* a constant Material with DiffuseTexture != null: SampleAlbedo blends the albedo with a
                                     bilinear sample of the texture at the hit's (U, V) (RaytraceRenderer.cs:724-735 ->
-                                    Renderer/Texture.cs:142-163, static textures; a live video texture - Texture.cs:113-140 -
-                                    is refused with YCGE_ERR_UNSUPPORTED by the host wrapper, it has no pixels to pass) */
+                                    Renderer/Texture.cs:142-163 for a static texture, Texture.cs:113-140 for a LIVE one - camera /
+                                    video frames, see ycge_texture.frame_bytes_per_pixel and ycge_scene_update_texture) */
 } ycge_material_kind;
 
 /* Renderer/Texture.cs:15,22-23: `pixels[y * width + x]` as RGBA32.ToInt() packs them (RGBA32.cs:14-31: byte 0 = r,
@@ -234,6 +234,12 @@ typedef struct ycge_config {
      * rank / world_size must then be 0 / 1.  n_devices 0 or 1 = the single GPU `device`. */
     int32_t n_devices;
     int32_t devices[YCGE_MAX_DEVICES];
+    /* ApplyAtrousDenoise's buffer swap (RaytraceRenderer.cs:718) makes iteration 1 run IN PLACE - scan-order dependent, a dependent chain of
+     * W/2 + 3H/2 pixel levels that costs 1.9 ms of a 1080p frame (8.8 ms at 3840x2160) however it is scheduled.  1 (default) reproduces it
+     * bit for bit.  0 WAIVES it (SURVEY 8-f1 allows "reproduce or explicitly waive"): iteration 1 reads A and writes B like any other
+     * iteration - the denoiser the C# text reads like, fully parallel (~0.2 ms).  The two differ by what INTEGRATION.md states (a filter
+     * tap that sees a neighbour's already-filtered value instead of its unfiltered one); everything up to TAA is unaffected. */
+    int32_t atrous_inplace_exact;
 } ycge_config;
 
 typedef struct ycge_frame_stats {
@@ -347,6 +353,21 @@ int ycge_wait(ycge_ctx *ctx);
 /* measurement: durations (ms) of the trace launches of the frames queued since the last call, oldest first (at most the last 1024);
  * waits for the frames in flight */
 int ycge_async_trace_times(ycge_ctx *ctx, float *ms_out, int32_t capacity, int32_t *n_out);
+
+/* What the frames-in-flight machinery of this context does (it decides timing only, never a pixel - a host or a benchmark reports it
+ * beside its numbers).  The placed-value gate - "a trace starts when the trace before it has placed its last workgroup" - rests on an
+ * OBSERVED property of the dispatcher (workgroups are placed in index order, so the last index is the last placed); where signal memory
+ * or hipStreamWaitValue32 is not available the gate switches itself off and says so here. */
+typedef struct ycge_flight_info {
+    int32_t two_trace_streams;   /* consecutive frames in flight alternate between two trace streams (single-launch scenes)        */
+    int32_t placed_gate;         /* 1: the placed-value gate is armed; 0: off (YCGE_FLIGHT_PLACED_GATE=0, no signal memory, ...) */
+    int32_t post_gate;           /* a trace waits until the post stage before it has placed its persistent launch                */
+    int32_t post_pair;           /* the post stages of consecutive frames run side by side                                      */
+    int32_t frames_outstanding;  /* 1: frames in flight have not been joined yet                                                 */
+    int32_t reserved;
+    uint64_t placed_waits;       /* traces that were queued behind a placed value since the context was created                 */
+} ycge_flight_info;
+int ycge_flight_query(ycge_ctx *ctx, ycge_flight_info *out);
 
 /* --- multi-GPU halves of a frame (one process per GPU; the exchange between
  * them is one all-gather of the tile slabs, done by the caller with RCCL).

@@ -580,7 +580,9 @@ struct Renderer {
                         dst[i] = c0;
                     }
                 }
-            const V3 *tmp = cur; cur = dst; dst = (tmp == scratch_a) ? scratch_b : scratch_a;
+            /* :718.  config.atrous_inplace_exact = 0 (include/ycge.h) is the WAIVED form: plain ping-pong, no iteration in place */
+            const V3 *tmp = cur; cur = dst;
+            dst = cfg.atrous_inplace_exact ? ((tmp == scratch_a) ? scratch_b : scratch_a) : ((cur == scratch_a) ? scratch_b : scratch_a);
         }
         return cur;
     }
@@ -943,6 +945,7 @@ int orc_post_probe(int fb_w, int fb_h, int ss, const float *hdr, const float *al
     Renderer r;
     ycge_config cfg{};
     cfg.atrous_iterations = iterations; cfg.atrous_c_phi = phi[0]; cfg.atrous_n_phi = phi[1]; cfg.atrous_z_phi = phi[2]; cfg.atrous_a_phi = phi[3];
+    cfg.atrous_inplace_exact = 1;        /* the reference's buffer walk (RaytraceRenderer.cs:718) */
     r.cfg = cfg;
     r.resize(fb_w, fb_h, ss);
     size_t n = (size_t)r.hiW * r.hiH;

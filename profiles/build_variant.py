@@ -6,9 +6,4 @@ ROOT = Path(__file__).resolve().parents[1]
 sys.path.insert(0, str(ROOT))
 from yetanotherconsolegameengine_amd import build as b
 name, flags = sys.argv[1], sys.argv[2:]
-out = b.LIB_DIR / f"var_{name}.so"
-cmd = [b.hipcc(), *b.FLAGS, *flags, "-x", "hip", *[str(b.CSRC / s) for s in b.SOURCES], "-o", str(out)]
-r = subprocess.run(cmd, capture_output=True, text=True)
-if r.returncode != 0:
-    sys.stderr.write(r.stdout + r.stderr); raise SystemExit(1)
-print("built", out)
+print("built", b.build_variant(name, flags, force=True))

@@ -1,4 +1,4 @@
-"""Regenerates the committed fixtures under tests/golden/.
+"""Regenerates the committed fixtures under tests/golden/ and the bunny asset of the package (yetanotherconsolegameengine_amd/assets/).
 
 Run in the authoring container only (needs /root/reference for the bunny asset):
     python tests/golden/make_fixtures.py bunny      # parse the reference's OBJ asset -> npz (data, not source)
@@ -23,7 +23,9 @@ def bunny():
     from yetanotherconsolegameengine_amd import mesh_loader
     pos, faces = mesh_loader.load_obj("/root/reference/ConsoleGame/assets/stanford-bunny.obj")
     assert faces.shape[0] == 69451, faces.shape
-    np.savez_compressed(HERE / "stanford_bunny_mesh.npz", positions=pos, faces=faces)
+    from yetanotherconsolegameengine_amd import scenes
+    scenes.ASSETS_DIR.mkdir(exist_ok=True)
+    np.savez_compressed(scenes.BUNNY_FIXTURE, positions=pos, faces=faces)
     print("bunny:", pos.shape, faces.shape)
 
 

@@ -11,6 +11,8 @@ import numpy as np
 import pytest
 
 import parity_util as pu
+from pathlib import Path as _Path
+GOLDEN_DIR = _Path(__file__).resolve().parent / "golden"          # committed golden buffers (tests/golden/make_fixtures.py)
 from yetanotherconsolegameengine_amd import abi, scenes, tiles
 from yetanotherconsolegameengine_amd.renderer import RaytraceRenderer
 from yetanotherconsolegameengine_amd.scene import (AmbientLight, Box, Checker, CylinderY, Disk, Material, Mesh, Plane, PointLight,
@@ -50,7 +52,7 @@ def test_analytic_scenes_three_frames(product_lib, oracle, path, cfg_n):
 
 def test_committed_goldens_on_gpu(product_lib, path):
     """The HIP path against the committed oracle fixture (no oracle run involved)."""
-    z = np.load(scenes.GOLDEN_DIR / "cornell_80x45_frames123.npz")
+    z = np.load(GOLDEN_DIR / "cornell_80x45_frames123.npz")
     sc, w, h, ss, pose = scenes.config_scene(1)
     with RaytraceRenderer(sc, w, h, pose["fov"], ss, capture_debug=True) as g:
         g.SetCamera(pose["pos"], pose["yaw"], pose["pitch"])
@@ -65,7 +67,7 @@ def test_committed_goldens_on_gpu(product_lib, path):
 
 def test_committed_post_goldens_on_gpu(product_lib, path):
     """The HIP post stage against the committed fixture (no oracle run involved)."""
-    z = np.load(scenes.GOLDEN_DIR / "cornell_80x45_post.npz")
+    z = np.load(GOLDEN_DIR / "cornell_80x45_post.npz")
     sc, w, h, ss, pose = scenes.config_scene(1)
     with RaytraceRenderer(sc, w, h, pose["fov"], ss) as g:
         g.SetCamera(pose["pos"], pose["yaw"], pose["pitch"])
@@ -371,6 +373,37 @@ def test_denoise_exposure_tonemap_bit_exact(product_lib, oracle, path, cfg_n):
     for f, (taa, den, expo, sdr, sdr_rms, post_ms) in enumerate(_post_pair(oracle, sc, w, h, ss, pose)):
         print(f"cfg{cfg_n} frame {f + 1}: taa {taa} denoised {den} exposure {expo} sdr {sdr} rms {sdr_rms} post_ms {post_ms:.3f}")
         assert taa == 0 and den == 0 and not expo and sdr == 0 and sdr_rms <= pu.RMS_TOL
+
+
+def test_waived_inplace_iteration_against_the_oracle_and_its_distance_to_the_exact_frame(product_lib, oracle):
+    """config.atrous_inplace_exact = 0 ("reproduce or explicitly waive"): iteration 1 of ApplyAtrousDenoise reads A and writes
+    B instead of running in place (RaytraceRenderer.cs:718).  The waived form is held to the ORACLE's waived form bit for bit (same
+    switch in oracle/orc_render.cpp: only the buffer walk differs), on configs 2 and 3 (a quarter of its size), three frames; and its
+    distance to the EXACT frame - what a host gives up for the ~2 ms - is measured here and stated in INTEGRATION.md: RMS over the SDR
+    chexel colours (values in [0, 1]) below 5e-3, largest single difference below 0.08."""
+    for cfg_n, (w, h) in ((2, (640, 180)), (3, (320, 90))):
+        sc, _, _, ss, pose = scenes.config_scene(cfg_n)
+        flat = flatten(sc)
+        cw = abi.default_config(); cw.atrous_inplace_exact = 0
+        co = abi.default_config(); co.atrous_inplace_exact = 0
+        o = oracle.OracleRenderer(sc, w, h, ss, pose, flat=flat, cfg=co)
+        g = RaytraceRenderer(flat, w, h, pose["fov"], ss, cfg=cw)
+        e = RaytraceRenderer(flat, w, h, pose["fov"], ss)
+        for r in (g, e):
+            r.SetCamera(pose["pos"], pose["yaw"], pose["pitch"])
+        for f in range(3):
+            so = o.render(stages=2, threads=8, want_sdr=True)
+            sg = g.TryFlipAndBlit(want_sdr=True)
+            se = e.TryFlipAndBlit(want_sdr=True)
+            assert pu.mismatch_count(o.read(abi.BUF_DENOISED), g.read(abi.BUF_DENOISED)) == 0, (cfg_n, f)
+            assert np.float32(o.stats.exposure).view(np.uint32) == np.float32(g.stats.exposure).view(np.uint32), (cfg_n, f)
+            assert pu.mismatch_count(so, sg) == 0, (cfg_n, f)
+            assert pu.bits_equal(g.read(abi.BUF_TAA_HISTORY), e.read(abi.BUF_TAA_HISTORY))          # everything up to TAA is untouched
+            d = np.abs(sg.astype(np.float64) - se.astype(np.float64))
+            print(f"cfg{cfg_n} frame {f + 1}: waived vs exact SDR rms {np.sqrt((d * d).mean()):.2e} max {d.max():.3f}; post_ms waived {g.stats.post_ms:.3f} exact {e.stats.post_ms:.3f}")
+            assert np.sqrt((d * d).mean()) < 5e-3 and d.max() < 0.08
+            assert d.max() > 0.0          # (the two forms do differ: the switch is not a no-op)
+        o.close(); g.close(); e.close()
 
 
 @pytest.mark.parametrize("mode", ["0", "2", "3", "4"])

@@ -56,6 +56,81 @@ def test_timed_mesh_kernels_full_size_steady_state(product_lib, oracle, monkeypa
     o.close(); g.close()
 
 
+def _two_mesh_scene():
+    """A plane, a bumpy sphere mesh and a one-leaf mesh (a floating quad: Mesh.Hit on a root that is a leaf) under two lights: shadow rays
+    of the plane cross both meshes, shadow rays of the sphere cross the quad."""
+    from yetanotherconsolegameengine_amd.scene import AmbientLight, Checker, Material, Mesh, Plane, PointLight, Scene, vec3
+    rng = np.random.default_rng(7)
+    th = np.linspace(0.05, np.pi - 0.05, 18); ph = np.linspace(0, 2 * np.pi, 28, endpoint=False)
+    P = np.array([[np.sin(t) * np.cos(p), np.cos(t), np.sin(t) * np.sin(p)] for t in th for p in ph], np.float32)
+    P = (P * (1.0 + rng.normal(0, 0.03, (len(P), 1)))).astype(np.float32) * np.float32(0.8) + np.array([0.0, 0.9, -3.0], np.float32)
+    tris = []
+    for i in range(len(th) - 1):
+        for j in range(len(ph)):
+            a, b = i * len(ph) + j, i * len(ph) + (j + 1) % len(ph)
+            c, d = a + len(ph), b + len(ph)
+            tris += [[P[a], P[b], P[c]], [P[b], P[d], P[c]]]
+    quad = np.array([[[-0.9, 2.3, -3.6], [0.7, 2.3, -3.6], [0.7, 2.5, -2.2]], [[-0.9, 2.3, -3.6], [0.7, 2.5, -2.2], [-0.9, 2.5, -2.2]]], np.float32)
+    s = Scene()
+    s.Ambient = AmbientLight(vec3(1, 1, 1), 0.05)
+    s.Objects.append(Plane(vec3(0, 0, 0), vec3(0, 1, 0), Checker(vec3(0.8, 0.8, 0.8), vec3(0.3, 0.3, 0.3), 0.5), 0.0, 0.0))
+    s.Objects.append(Mesh(np.array(tris, np.float32), Material(vec3(0.8, 0.45, 0.25))))
+    s.Objects.append(Mesh(quad, Material(vec3(0.3, 0.5, 0.9))))
+    s.Lights.append(PointLight(vec3(1.5, 6.0, -1.0), vec3(1, 1, 1), 80.0))
+    s.Lights.append(PointLight(vec3(-3.0, 3.0, -2.0), vec3(0.9, 0.95, 1.0), 40.0))
+    return s, dict(pos=(0.2, 1.3, 0.4), yaw=0.03, pitch=-0.12, fov=55.0)
+
+
+@pytest.mark.parametrize("variant", ["bfs64", "bfs112", "bfs8", "ordered"])
+def test_order_free_occlusion_queries_against_the_oracle(product_lib, oracle, monkeypatch, variant):
+    """mesh_anyhit_bfs (csrc/ycge_anyhit.hip.h): the shadow rays of a wavefront against a mesh, breadth-first from one shared work list - in
+    scenes without transparent materials an occlusion query is `OR over reachable leaves of OR over triangles` (RaytraceRenderer.cs:757-781,
+    MeshBVH.cs:132-304), whatever the order.  The product build, a build whose list holds 112 entries (wide rounds are cut back, one-item
+    dives happen: every mode of the list on ordinary scenes) and the ordered walk (YCGE_NO_BFS=1) against the oracle: the bunny under its
+    two lights at a quarter of config 3's size, three frames, and a scene with two meshes, one of them a single leaf.  (YCGE_BFS = the
+    number of asking lanes up to which a batch goes to the list: 64 = every batch.)"""
+    from yetanotherconsolegameengine_amd import build
+    monkeypatch.delenv("YCGE_PATH", raising=False)
+    lib = product_lib
+    monkeypatch.setenv("YCGE_BFS", {"bfs64": "64", "bfs112": "64", "bfs8": "8", "ordered": "0"}[variant])          # rays a batch may have for the list to take it
+    if variant == "bfs112":
+        lib = abi.load_library(build.build_variant("bfs112"))
+    steps = 0
+    for label, (sc, w, h, ss, pose) in (("bunny", scenes.config_scene(3)), ("two meshes", _two_mesh_scene()[:1] + (160, 45, 1) + _two_mesh_scene()[1:])):
+        if label == "bunny":
+            w, h = 320, 90
+        flat = flatten(sc)
+        o = oracle.OracleRenderer(sc, w, h, ss, pose, flat=flat)
+        g = RaytraceRenderer(flat, w, h, pose["fov"], ss, capture_debug=True, lib=lib)
+        g.SetCamera(pose["pos"], pose["yaw"], pose["pitch"])
+        for f in range(3):
+            o.render(stages=1, threads=16); g.TryFlipAndBlit()
+            _assert_frame(o, g, f"{variant}: {label} frame {f + 1}")
+        lit = g.read(abi.BUF_CURRENT_HDR).reshape(-1, 3).max(axis=1)
+        assert (lit > 0).mean() > 0.3
+        steps += g.timed_steps()
+        o.close(); g.close()
+    print(variant, "lane steps", steps)
+
+
+def test_order_free_occlusion_queries_full_size_small_list(product_lib, oracle, monkeypatch):
+    """Config 3 at full size through the 112-entry build: 14 400 wavefronts' shadow batches, two frames (the second in schedule order, its
+    heaviest blocks in parts)."""
+    from yetanotherconsolegameengine_amd import build
+    monkeypatch.delenv("YCGE_PATH", raising=False)
+    monkeypatch.setenv("YCGE_BFS", "64")
+    lib = abi.load_library(build.build_variant("bfs112"))
+    sc, w, h, ss, pose = scenes.config_scene(3)
+    flat = flatten(sc)
+    o = oracle.OracleRenderer(sc, w, h, ss, pose, flat=flat)
+    g = RaytraceRenderer(flat, w, h, pose["fov"], ss, capture_debug=True, lib=lib)
+    g.SetCamera(pose["pos"], pose["yaw"], pose["pitch"])
+    for f in range(2):
+        o.render(stages=1, threads=64); g.TryFlipAndBlit()
+        _assert_frame(o, g, f"bfs112 cfg3 frame {f + 1}")
+    o.close(); g.close()
+
+
 def test_timed_mesh_kernels_sdr_frame(product_lib, oracle, monkeypatch):
     """The frame the C# wrapper asks for (SDR out): non-counting trace kernels + TAA + post stage on config 3 at full size,
     three frames, against the oracle's stages=2."""

@@ -28,7 +28,7 @@ def test_library_exports_every_declared_symbol(product_lib):
 def test_ctypes_mirror_matches_header_layout(product_lib):
     product_lib.ycge_abi_sizeof.restype = C.c_size_t
     product_lib.ycge_abi_sizeof.argtypes = [C.c_int32]
-    for which, t in enumerate([abi.Vec3, abi.Material, abi.Prim, abi.Mesh, abi.VoxelLookup, abi.Grid, abi.Light, abi.Scene, abi.Config, abi.FrameStats]):
+    for which, t in enumerate([abi.Vec3, abi.Material, abi.Prim, abi.Mesh, abi.VoxelLookup, abi.Grid, abi.Light, abi.Scene, abi.Config, abi.FrameStats, abi.FlightInfo]):
         assert product_lib.ycge_abi_sizeof(which) == C.sizeof(t), t.__name__
     c = abi.Config()
     assert product_lib.ycge_config_default(C.byref(c)) == 0

@@ -11,6 +11,8 @@ import numpy as np
 import pytest
 
 import oracle_binding as ob
+from pathlib import Path as _Path
+GOLDEN_DIR = _Path(__file__).resolve().parent / "golden"          # committed golden buffers (tests/golden/make_fixtures.py)
 from yetanotherconsolegameengine_amd import abi, scenes
 from yetanotherconsolegameengine_amd.scene import (Box, CylinderY, Disk, Material, Plane, PointLight, Scene, Solid, Sphere,
                                                    Triangle, XYRect, XZRect, YZRect, vec3, ZERO)
@@ -241,7 +243,7 @@ GOLDEN_EQUAL_KEY_ORDER = [9, 17, 15, 13, 11, 7, 19, 5, 3, 1, 8, 18, 10, 4, 12, 1
 
 
 def test_committed_golden_buffers_cornell():
-    z = np.load(scenes.GOLDEN_DIR / "cornell_80x45_frames123.npz")
+    z = np.load(GOLDEN_DIR / "cornell_80x45_frames123.npz")
     sc, w, h, ss, pose = scenes.config_scene(1)
     with ob.OracleRenderer(sc, w, h, ss, pose) as r:
         for frame in (1, 2, 3):
@@ -388,7 +390,7 @@ def test_post_stage_against_python_restatement(fbw, fbh, ss, iters):
 
 def test_committed_golden_post_stage_cornell():
     """regression fixture of steps 6-8 (tests/golden/make_fixtures.py post)"""
-    z = np.load(scenes.GOLDEN_DIR / "cornell_80x45_post.npz")
+    z = np.load(GOLDEN_DIR / "cornell_80x45_post.npz")
     sc, w, h, ss, pose = scenes.config_scene(1)
     with ob.OracleRenderer(sc, w, h, ss, pose) as r:
         for frame in (1, 2, 3):

@@ -12,7 +12,7 @@ import ctypes as C
 import os
 from pathlib import Path
 
-YCGE_ABI_VERSION = 6
+YCGE_ABI_VERSION = 7
 YCGE_MAX_DEVICES = 8
 
 # ycge_status
@@ -128,6 +128,7 @@ class Config(C.Structure):
         ("count_work", C.c_int32),
         ("slab_albedo", C.c_int32),
         ("n_devices", C.c_int32), ("devices", C.c_int32 * YCGE_MAX_DEVICES),
+        ("atrous_inplace_exact", C.c_int32),
     ]
 
 
@@ -139,6 +140,11 @@ class FrameStats(C.Structure):
         ("n_vox", C.c_uint64), ("exposure", C.c_float), ("exposure_serial_chunks", C.c_float),
         ("n_rays_dark", C.c_uint64), ("n_devices_traced", C.c_int32), ("device_tiles", C.c_int32 * 8),
     ]
+
+
+class FlightInfo(C.Structure):
+    _fields_ = [("two_trace_streams", C.c_int32), ("placed_gate", C.c_int32), ("post_gate", C.c_int32), ("post_pair", C.c_int32),
+                ("frames_outstanding", C.c_int32), ("reserved", C.c_int32), ("placed_waits", C.c_uint64)]
 
 
 def default_config() -> Config:
@@ -158,6 +164,7 @@ def default_config() -> Config:
     c.atrous_c_phi, c.atrous_n_phi, c.atrous_z_phi, c.atrous_a_phi = 3.0, 0.35, 2.0, 0.20
     c.capture_debug, c.count_work = 0, 0
     c.slab_albedo, c.n_devices = 1, 0
+    c.atrous_inplace_exact = 1
     return c
 
 
@@ -183,6 +190,7 @@ _PROTOTYPES = {
     "ycge_render_frame_async_sdr": (C.c_int, [C.c_void_p, C.POINTER(C.c_float)]),
     "ycge_wait": (C.c_int, [C.c_void_p]),
     "ycge_async_trace_times": (C.c_int, [C.c_void_p, C.POINTER(C.c_float), C.c_int32, C.POINTER(C.c_int32)]),
+    "ycge_flight_query": (C.c_int, [C.c_void_p, C.POINTER(FlightInfo)]),
     "ycge_tile_slab_bytes": (C.c_int, [C.c_void_p, C.POINTER(C.c_size_t)]),
     "ycge_trace_tiles": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.POINTER(FrameStats)]),
     "ycge_resolve_gathered": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.POINTER(C.c_float), C.POINTER(FrameStats)]),

@@ -72,6 +72,33 @@ def build_library(force: bool = False, verbose: bool = False, extra_flags=()) ->
     return LIB
 
 
+# Test variants of the library (lib/var_<name>.so, loaded by path): the same sources with other -D settings.  Built by
+# __graft_entry__.build() next to the product so that they travel to the GPU box with it.
+VARIANTS = {
+    # the work list of the order-free occlusion queries cut to 112 entries (HIGH = 32): wide rounds are cut back and one-item dives happen
+    # on ordinary scenes, so the GPU tests see every mode of the list (csrc/ycge_anyhit.hip.h)
+    "bfs112": ["-DYCGE_BFS_LIST=112u"],
+}
+
+
+def variant_path(name: str) -> Path:
+    return LIB_DIR / f"var_{name}.so"
+
+
+def build_variant(name: str, flags=None, force: bool = False) -> Path:
+    flags = list(VARIANTS[name] if flags is None else flags)
+    out = variant_path(name)
+    deps = [CSRC / n for n in SOURCES + HEADERS] + [PKG.parent / "include" / "ycge.h", Path(__file__)]
+    if not force and out.exists() and all(d.stat().st_mtime <= out.stat().st_mtime for d in deps):
+        return out
+    LIB_DIR.mkdir(exist_ok=True)
+    r = subprocess.run([hipcc(), *FLAGS, *flags, "-x", "hip", *[str(CSRC / s) for s in SOURCES], "-o", str(out)], capture_output=True, text=True)
+    if r.returncode != 0:
+        sys.stderr.write(r.stdout + r.stderr)
+        raise RuntimeError(f"hipcc failed building {out.name}")
+    return out
+
+
 if __name__ == "__main__":
     if "--hash" in sys.argv:
         print(source_hash()); sys.exit(0)

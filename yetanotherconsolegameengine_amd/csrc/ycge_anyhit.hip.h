@@ -61,19 +61,32 @@ __device__ __forceinline__ uint32_t wave_prefix_incl(uint32_t x)
 // entries a child reference stands for: a node is one item, a leaf one item per pair record
 __device__ __forceinline__ uint32_t bfs_items_of(uint32_t ref) { return YCGE_REF_KIND(ref) == REF_MESH_NODE ? 1u : ((ref & 15u) + 1u) >> 1; }
 
-// Every lane of the wavefront enters; `mine`: this lane has an occlusion query whose mesh root box [tmin, tmax] is hit, `root_ref` its
-// mesh's root.  Returns the mask of lanes whose query is answered "occluded".  The caller's stacks must be empty (they are the list).
-__device__ __forceinline__ unsigned long long mesh_anyhit_bfs(const SceneDev &S, bool mine, uint32_t root_ref, F3 o, F3 inv, F3 d, float tmin, float tmax, Work &w)
+// A lane's ray in its slot of the rays' area - (o, tmin)(1/d, tmax)(d, -) - and back.  Every lane parks its ray before the list is worked
+// and takes it back afterwards: the slot IS where the work items read a ray from, and the twelve values are not live in registers across
+// the rounds (explicit ds instructions: the compiler cannot forward the stored registers to the loads; the same device as g_shade_ctx).
+__device__ __forceinline__ uint32_t bfs_ray_addr(uint32_t lane) { return (uint32_t)(uintptr_t)g_lds_stack64 + YCGE_LDS_STACK_LEVELS * 64u * 4u + lane * 48u; }
+__device__ __forceinline__ void bfs_park_ray(F3 o, F3 inv, F3 d, float tmin, float tmax)
+{
+    const f32x4 v0 = {o.x, o.y, o.z, tmin}, v1 = {inv.x, inv.y, inv.z, tmax}, v2 = {d.x, d.y, d.z, 0.0f};
+    asm volatile("ds_write_b128 %0, %1\n\tds_write_b128 %0, %2 offset:16\n\tds_write_b128 %0, %3 offset:32" : : "v"(bfs_ray_addr(threadIdx.x & 63u)), "v"(v0), "v"(v1), "v"(v2) : "memory");
+}
+__device__ __forceinline__ void bfs_unpark_ray(F3 &o, F3 &inv, F3 &d, float &tmin, float &tmax)
+{
+    f32x4 v0, v1, v2;
+    asm volatile("ds_read_b128 %0, %3\n\tds_read_b128 %1, %3 offset:16\n\tds_read_b128 %2, %3 offset:32\n\ts_waitcnt lgkmcnt(0)"
+                 : "=&v"(v0), "=&v"(v1), "=&v"(v2) : "v"(bfs_ray_addr(threadIdx.x & 63u)) : "memory");
+    o = f3(v0.x, v0.y, v0.z); tmin = v0.w; inv = f3(v1.x, v1.y, v1.z); tmax = v1.w; d = f3(v2.x, v2.y, v2.z);
+}
+
+// Every lane of the wavefront enters, its ray parked (bfs_park_ray); `mine`: this lane has an occlusion query whose mesh root box
+// [tmin, tmax] is hit, `root_ref` its mesh's root.  Returns the mask of lanes whose query is answered "occluded".  The caller's stacks
+// must be empty (they are the list).
+__device__ __forceinline__ unsigned long long mesh_anyhit_bfs(const SceneDev &S, bool mine, uint32_t root_ref, Work &w)
 {
     const uint32_t lane = threadIdx.x & 63u;
     uint32_t *list = (uint32_t *)g_lds_stack64;
-    f32x4 *rays = (f32x4 *)((uint8_t *)g_lds_stack64 + YCGE_LDS_STACK_LEVELS * 64u * 4u);
+    const f32x4 *rays = (const f32x4 *)((uint8_t *)g_lds_stack64 + YCGE_LDS_STACK_LEVELS * 64u * 4u);
     const unsigned long long asking = __ballot(mine);
-    if (mine) {
-        rays[lane * 3u + 0u] = f32x4{o.x, o.y, o.z, tmin};
-        rays[lane * 3u + 1u] = f32x4{inv.x, inv.y, inv.z, tmax};
-        rays[lane * 3u + 2u] = f32x4{d.x, d.y, d.z, 0.0f};
-    }
     // seeds: every asking ray's root (a root that is a leaf: its records) - at most 64 x 8 entries, below HIGH
     uint32_t occ;
     {

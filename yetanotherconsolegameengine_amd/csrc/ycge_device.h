@@ -209,7 +209,8 @@ struct SceneDev {
     // allocation, of the treelet region - the treelet of the internal node at 32-byte unit u is at tl_offset + u * YCGE_TL_BYTES_PER_UNIT.
     // 0 = none (no mesh, or the region would not fit 32-bit offsets): the regular walk serves everything.
     uint32_t tl_offset;
-    // occlusion queries against a mesh breadth-first from a shared work list (mesh_anyhit_bfs, ycge_anyhit.hip.h; YCGE_NO_BFS=1 keeps the ordered walk)
+    // occlusion queries against a mesh breadth-first from a shared work list (mesh_anyhit_bfs, ycge_anyhit.hip.h) when at most this many lanes
+    // of the wavefront ask (YCGE_BFS; 0: the ordered walk serves them all)
     uint32_t anyhit_bfs;
     unsigned long long *dbg_counters;   // profiling builds (-DYCGE_DBG_COOPSTAT): statistics of the cooperative walk, else unused
 };

@@ -134,7 +134,7 @@ struct Knobs {
     int bvh_waves = 16;              // YCGE_BVH_WAVES: wavefronts of k_scene_bvh_build that take nodes (tests: the order nodes are split in must not matter)
     bool scene_bvh_host = false;     // YCGE_SCENE_BVH_HOST: ycge_scene_update_objects builds the scene BVH on the host, not on the device
     int scene_bvh_device_min = YCGE_BVH_DEV_MIN_ITEMS_DEFAULT;   // YCGE_SCENE_BVH_DEVICE_MIN: fewer objects than this are built on the host (measured crossover, profiles/r02/f2_update_objects_timing.txt)
-    bool no_bfs = false;             // YCGE_NO_BFS: occlusion queries keep the ordered walk (A/B of mesh_anyhit_bfs)
+    int bfs_rays = 0;                // YCGE_BFS=<n>: a wavefront's occlusion queries against a mesh go breadth-first from one shared work list when at most n of its lanes ask (mesh_anyhit_bfs; 0 = never, 64 = always)
     bool no_coop = false;            // YCGE_NO_COOP: no treelets are built, sparse wavefronts keep the regular walk (A/B of the cooperative walk)
     bool exposure_serial = false;    // YCGE_EXPOSURE_SERIAL: the one-lane chain instead of the chunked exact evaluation
     void read()
@@ -173,7 +173,8 @@ struct Knobs {
         post_dbg_free = geti("YCGE_POST_DBG_FREE", 0) != 0;
         exposure_serial = getenv("YCGE_EXPOSURE_SERIAL") != nullptr;
         no_coop = getenv("YCGE_NO_COOP") != nullptr;
-        no_bfs = getenv("YCGE_NO_BFS") != nullptr;
+        bfs_rays = geti("YCGE_BFS", 0);
+        if (bfs_rays < 0 || bfs_rays > 64) bfs_rays = 0;
         scene_bvh_host = getenv("YCGE_SCENE_BVH_HOST") != nullptr;
         bvh_waves = geti("YCGE_BVH_WAVES", 16);
         scene_bvh_device_min = geti("YCGE_SCENE_BVH_DEVICE_MIN", YCGE_BVH_DEV_MIN_ITEMS_DEFAULT);
@@ -264,6 +265,7 @@ struct ycge_ctx {
     hipEvent_t flight_fork_ev = nullptr;
     uint32_t *placed_flag = nullptr;               // signal memory: the number of the newest frame in flight whose trace has placed its last workgroup
     uint32_t placed_expect = 0, placed_next = 0;   // what the next trace waits for (0: nothing) / the value the next trace stores
+    uint64_t placed_waits = 0;                     // traces queued behind a placed value so far (ycge_flight_query)
     // frames in flight WITH the post stage (ycge_render_frame_async_sdr): post of frame N beside the traces and TAA of the frames after it
     hipEvent_t flight_taa_ev = nullptr, post_hist_ev = nullptr, post_done_ev = nullptr, post_set_ev[3] = {nullptr, nullptr, nullptr};
     bool post_hist_pending = false, post_busy = false, post_set_pending[3] = {false, false, false};
@@ -336,6 +338,13 @@ struct ycge_ctx {
     DevBuf<uint8_t> d_cells;
     DevBuf<int32_t> d_lut;
     DevBuf<uint32_t> d_tex_pixels;             // textures of YCGE_MAT_TEXTURED materials
+    // a live texture's next frame travels through page-locked staging (two buffers taken in turn) and a stream-ordered copy on the
+    // context's stream: behind the traces that still read the old frame, ahead of the ones queued after the call
+    uint8_t *tex_stage[2] = {nullptr, nullptr};
+    size_t tex_stage_bytes[2] = {0, 0};
+    hipEvent_t tex_stage_ev[2] = {nullptr, nullptr};
+    bool tex_stage_busy[2] = {false, false};
+    int tex_stage_next = 0;
     DevBuf<int32_t> d_tex_info;
     std::vector<int32_t> tex_info_host;        // {first word, width, height, flags} per texture (ycge_scene_update_texture)
     DevBuf<GLight> d_lights;
@@ -596,6 +605,7 @@ int ycge_config_default(ycge_config *cfg)
     std::memset(cfg, 0, sizeof *cfg);
     cfg->abi_version = YCGE_ABI_VERSION;
     cfg->slab_albedo = 1; cfg->n_devices = 0;
+    cfg->atrous_inplace_exact = 1;
     cfg->fb_width = 80; cfg->fb_height = 45; cfg->super_sample = 1;
     cfg->fov_deg = 45.0f;
     cfg->device = 0; cfg->rank = 0; cfg->world_size = 1;
@@ -746,8 +756,12 @@ void ycge_destroy(ycge_ctx *c)
     for (ycge_ctx *p : c->peers) ycge_destroy(p);
     c->peers.clear();
     (void)hipSetDevice(c->device);
+    // frames in flight may still be on ANY of the context's streams (TAA, post stage and read-back on taa_stream / stream2): everything
+    // is drained before the first buffer goes (not left to hipFree's implicit synchronisation)
     if (c->fan_stream) (void)hipStreamSynchronize(c->fan_stream);
     if (c->stream) (void)hipStreamSynchronize(c->stream);
+    if (c->taa_stream) (void)hipStreamSynchronize(c->taa_stream);
+    if (c->stream2) (void)hipStreamSynchronize(c->stream2);
     c->current_hdr.release(); c->g_albedo.release(); c->g_normal.release(); c->g_depth.release(); c->taa_hist.release();
     c->prev_normal.release(); c->prev_depth.release(); c->sky.release(); c->prev_sky.release();
     c->dbg_rays.release(); c->dbg_hit_t.release(); c->dbg_prim.release(); c->dbg_sub.release(); c->dbg_rng.release();
@@ -775,6 +789,7 @@ void ycge_destroy(ycge_ctx *c)
     c->d_scene_nodes.release(); c->d_mesh_arena.release(); c->d_scene_leaf.release(); c->d_prims.release();
     c->d_bvh_items.release(); c->d_bvh_scratch.release(); c->d_bvh_ref.release(); c->d_bvh_res.release();
     c->d_materials.release(); c->d_meshes.release(); c->d_grids.release(); c->d_cells.release(); c->d_lut.release(); c->d_lights.release(); c->d_tex_pixels.release(); c->d_tex_info.release();
+    for (int k = 0; k < 2; k++) { if (c->tex_stage[k]) (void)hipHostFree(c->tex_stage[k]); if (c->tex_stage_ev[k]) (void)hipEventDestroy(c->tex_stage_ev[k]); }
     for (auto &ev : c->ev) if (ev) (void)hipEventDestroy(ev);
     for (hipEvent_t ev : {c->fan_ev[0], c->fan_ev[1], c->traced_ev, c->order_ev, c->pushed_ev}) if (ev) (void)hipEventDestroy(ev);
     if (c->fan_stream) (void)hipStreamDestroy(c->fan_stream);
@@ -1094,8 +1109,8 @@ int install_scene(ycge_ctx *c, const SceneArrays &A, const ObjectsHost &oh, cons
     sd.any_transparent = A.any_transparent ? 1 : 0;
     sd.any_textured = A.any_textured ? 1 : 0;
     sd.tl_offset = A.tl_offset;
-    sd.anyhit_bfs = c->knobs.no_bfs ? 0u : 1u;
-    if (!c->dbg_counters.p) { HIP_TRY(c, c->dbg_counters.alloc(16 + 16 * 256)); HIP_TRY(c, hipMemset(c->dbg_counters.p, 0, (16 + 16 * 256) * sizeof(unsigned long long))); }
+    sd.anyhit_bfs = (uint32_t)c->knobs.bfs_rays;
+    if (!c->dbg_counters.p) { HIP_TRY(c, c->dbg_counters.alloc(16 + 64 * 256)); HIP_TRY(c, hipMemset(c->dbg_counters.p, 0, (16 + 64 * 256) * sizeof(unsigned long long))); }
     sd.dbg_counters = c->dbg_counters.p;
     rc = upload_lights(c, s->lights, s->n_lights);
     if (rc != YCGE_OK) return rc;
@@ -1414,18 +1429,40 @@ int ycge_scene_update_lights(ycge_ctx *c, const ycge_light *lights, int32_t n_li
 int ycge_scene_update_texture(ycge_ctx *c, int32_t texture_index, const uint8_t *frame, size_t bytes)
 {
     if (!c) return YCGE_ERR_INVALID_ARG;
+    if (c->parent) return c->fail(YCGE_ERR_INVALID_ARG, "peer contexts are driven by their root");
     if (!c->have_scene) return c->fail(YCGE_ERR_NO_SCENE, "no scene uploaded");
     if (texture_index < 0 || (size_t)texture_index * 4 + 3 >= c->tex_info_host.size()) return c->fail(YCGE_ERR_INVALID_ARG, "texture index %d out of range", texture_index);
     const int32_t *info = c->tex_info_host.data() + (size_t)texture_index * 4;
     const int bpp = info[3] & 15;
     if (bpp == 0) return c->fail(YCGE_ERR_INVALID_ARG, "texture %d is static: upload the scene again to change it", texture_index);
     if (!frame || bytes != (size_t)info[1] * info[2] * bpp) return c->fail(YCGE_ERR_INVALID_ARG, "texture %d: a frame is %d x %d x %d bytes", texture_index, info[1], info[2], bpp);
-    int rc = quiesce(c);
+    int rc = YCGE_OK;
+    if (c->cfg.world_size == 1 && c->peers.empty()) {
+        // Single device: every trace of a textured scene is queued on the context's stream (such scenes never take the second trace stream:
+        // frame_is_single_launch / scene_is_flat), so a copy ON that stream is ordered against all of them - no device-wide wait, frames in
+        // flight stay in flight.  The caller's array is its own again when this returns: the frame is staged in page-locked memory first.
+        HIP_TRY(c, hipSetDevice(c->device));
+        const int k = c->tex_stage_next; c->tex_stage_next ^= 1;
+        if (c->tex_stage_busy[k]) { HIP_TRY(c, hipEventSynchronize(c->tex_stage_ev[k])); c->tex_stage_busy[k] = false; }      // (the copy of two updates ago)
+        if (c->tex_stage_bytes[k] < bytes) {
+            if (c->tex_stage[k]) { (void)hipHostFree(c->tex_stage[k]); c->tex_stage[k] = nullptr; c->tex_stage_bytes[k] = 0; }
+            HIP_TRY(c, hipHostMalloc((void **)&c->tex_stage[k], bytes, hipHostMallocDefault));
+            c->tex_stage_bytes[k] = bytes;
+        }
+        if (!c->tex_stage_ev[k]) HIP_TRY(c, hipEventCreateWithFlags(&c->tex_stage_ev[k], hipEventDisableTiming));
+        std::memcpy(c->tex_stage[k], frame, bytes);
+        HIP_TRY(c, hipMemcpyAsync(c->d_tex_pixels.p + info[0], c->tex_stage[k], bytes, hipMemcpyHostToDevice, c->stream));
+        HIP_TRY(c, hipEventRecord(c->tex_stage_ev[k], c->stream));
+        c->tex_stage_busy[k] = true;
+        return YCGE_OK;
+    }
+    // several devices / a rank of a tiled frame (the caller may run its own streams): the scene changes while nothing runs
+    rc = quiesce(c);
     if (rc != YCGE_OK) return rc;
     HIP_TRY(c, hipMemcpy(c->d_tex_pixels.p + info[0], frame, bytes, hipMemcpyHostToDevice));
     for (ycge_ctx *p : c->peers) {
-        rc = ycge_scene_update_texture(p, texture_index, frame, bytes);
-        if (rc != YCGE_OK) { c->err = p->err; break; }
+        if (hipSetDevice(p->device) != hipSuccess || hipDeviceSynchronize() != hipSuccess ||
+            hipMemcpy(p->d_tex_pixels.p + info[0], frame, bytes, hipMemcpyHostToDevice) != hipSuccess) { (void)hipGetLastError(); rc = c->fail(YCGE_ERR_DEVICE, "texture frame copy failed on device %d", p->device); break; }
     }
     (void)hipSetDevice(c->device);
     return rc;
@@ -1543,6 +1580,18 @@ int ycge_debug_read_coop_stats(ycge_ctx *c, uint64_t out[16])
     HIP_TRY(c, hipDeviceSynchronize());
     HIP_TRY(c, hipMemcpy(v.data(), c->dbg_counters.p, v.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost));
     for (int k = 0; k < 16; k++) { out[k] = 0; for (int i = 0; i < 256; i++) out[k] += v[16 + 8 * 256 * (k >> 3) + 8 * i + (k & 7)]; }
+    return YCGE_OK;
+}
+
+// profiling builds (-DYCGE_DBG_BATCHSTAT, mesh_walk): 8 banks of 8 sums, cumulative; banks 2-4 every batch by kind (occlusion / closest hit / mixed),
+// 5-7 the batches of >= 48 iterations
+int ycge_debug_read_batch_stats(ycge_ctx *c, uint64_t out[64])
+{
+    if (!c || !out || !c->dbg_counters.p) return YCGE_ERR_INVALID_ARG;
+    std::vector<unsigned long long> v(16 + 64 * 256);
+    HIP_TRY(c, hipDeviceSynchronize());
+    HIP_TRY(c, hipMemcpy(v.data(), c->dbg_counters.p, v.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost));
+    for (int k = 0; k < 64; k++) { out[k] = 0; for (int i = 0; i < 256; i++) out[k] += v[16 + 8 * 256 * (k >> 3) + 8 * i + (k & 7)]; }
     return YCGE_OK;
 }
 
@@ -2028,7 +2077,7 @@ int run_post(ycge_ctx *c, hipStream_t stream, float *out_sdr_host, bool timed, h
     // The in-place iteration (iteration 1, when there is one) reads colour-independent weight factors that need the G-buffer and the
     // unit normals only: they are computed on the side stream beside iteration 0 (fork here, join in front of the band launches)
     bool static_pending = false;
-    if (iters >= 2 && c->fan_stream) {
+    if (iters >= 2 && c->fan_stream && c->cfg.atrous_inplace_exact) {
         if (!c->atrous_statw.p) HIP_TRY(c, c->atrous_statw.alloc(n * 75));
         HIP_TRY(c, hipEventRecord(c->fan_ev[0], stream));
         HIP_TRY(c, hipStreamWaitEvent(c->fan_stream, c->fan_ev[0], 0));
@@ -2132,7 +2181,9 @@ int run_post(ycge_ctx *c, hipStream_t stream, float *out_sdr_host, bool timed, h
         }
         if (e != 0) return c->fail(YCGE_ERR_DEVICE, "A-trous launch failed: %s", hipGetErrorString((hipError_t)e));
         if (it == 0 && iters > 1 && history_read) { HIP_TRY(c, hipEventRecord(history_read, stream)); history_read = nullptr; }        // (iteration 0 is the only reader of taa_hist when there are more)
-        const float *tmp = cur; cur = dst; dst = (tmp == A) ? B : A;
+        // the reference's swap, :718 (`tmp` is the history after iteration 0, so iteration 1 gets dst = A = cur: in place); waived
+        // (config.atrous_inplace_exact = 0): plain ping-pong between A and B
+        const float *tmp = cur; cur = dst; dst = c->cfg.atrous_inplace_exact ? ((tmp == A) ? B : A) : ((cur == A) ? B : A);
     }
     if (static_pending) HIP_TRY(c, hipStreamWaitEvent(stream, c->fan_ev[1], 0));
     c->denoised = cur;
@@ -2301,6 +2352,22 @@ int ycge_async_trace_times(ycge_ctx *c, float *ms_out, int32_t capacity, int32_t
     return YCGE_OK;
 }
 
+// what the frames in flight of this context do (timing machinery only: DESIGN section 6); the gate's state is what render_frame_in_flight
+// last found - before the first frame in flight it is the knob's
+int ycge_flight_query(ycge_ctx *c, ycge_flight_info *out)
+{
+    if (!c || !out) return YCGE_ERR_INVALID_ARG;
+    std::memset(out, 0, sizeof *out);
+    const bool single_launch = c->have_scene && frame_is_single_launch(c) && !c->sd.any_transparent;
+    out->two_trace_streams = (c->knobs.flight_overlap && c->stream2 && single_launch) ? 1 : 0;
+    out->placed_gate = (out->two_trace_streams && c->knobs.flight_placed_gate && c->knobs.refill_steps == 0) ? 1 : 0;
+    out->post_gate = c->knobs.flight_post_gate ? 1 : 0;
+    out->post_pair = (out->two_trace_streams && c->knobs.flight_post_pair) ? 1 : 0;
+    out->frames_outstanding = c->async_outstanding ? 1 : 0;
+    out->placed_waits = c->placed_waits;
+    return YCGE_OK;
+}
+
 static int render_frame_in_flight(ycge_ctx *c, float *out_sdr);
 int ycge_render_frame_async(ycge_ctx *c) { return c ? render_frame_in_flight(c, nullptr) : YCGE_ERR_INVALID_ARG; }
 // ... with steps 6-8 (denoise, exposure, tonemap + downsample) and the read-back into out_top_bottom_sdr, which is filled when the frame
@@ -2351,16 +2418,17 @@ static int render_frame_in_flight(ycge_ctx *c, float *out_sdr)
     hipStream_t ts = overlap ? c->stream2 : c->stream;
     if (overlap && !c->stack_spill2.p) HIP_TRY(c, c->stack_spill2.alloc(c->stack_spill.n));
     if (!c->async_outstanding) {
-        // (whatever the synchronous calls left on the context's stream is ahead of the second trace stream's first trace too)
-        HIP_TRY(c, hipEventRecord(c->flight_fork_ev, c->stream));
-        if (c->stream2) HIP_TRY(c, hipStreamWaitEvent(c->stream2, c->flight_fork_ev, 0));
-    }
-    if (!c->async_outstanding) {
         // the first frame in flight after synchronous calls.  Whatever they left on the context's stream (a TAA, a post stage that reads
         // the current set) is ahead of this trace in stream order, and the second stream's first TAA waits for this trace.  The
-        // synchronous schedule cleared THIS frame's cost slot; the next frame's would have been cleared between the two traces
+        // synchronous schedule cleared THIS frame's cost slot; the next frame's would have been cleared between the two traces.
+        // ORDER matters here and must not depend on the placed-value gate (it may be off: YCGE_FLIGHT_PLACED_GATE=0, no signal memory,
+        // k_trace_refill): first the synchronous path's schedule still on the side stream (it writes the order buffer and its counters the
+        // second stream's first trace reads), then the cost-slot clears, THEN the fork the second trace stream waits for.
+        if (c->order_pending) { HIP_TRY(c, hipStreamWaitEvent(c->stream, c->order_ev, 0)); c->order_pending = false; }
         for (int ahead = 1; ahead <= 2; ahead++)        // (the schedules queued in flight clear the slot of the frame three ahead)
             HIP_TRY(c, hipMemsetAsync(c->block_cost.p + (size_t)((uint64_t)(fs.frame + ahead) % YCGE_COST_FRAMES) * n_blocks, 0, (size_t)n_blocks * sizeof(uint32_t), c->stream));
+        HIP_TRY(c, hipEventRecord(c->flight_fork_ev, c->stream));
+        if (c->stream2) HIP_TRY(c, hipStreamWaitEvent(c->stream2, c->flight_fork_ev, 0));
     }
     // the other set becomes "the current frame's": every later reader (TAA below, a read-back, a synchronous frame's post stage) goes by these names
     // (three sets: current <- alt2, frame N - 3's; alt2 <- alt, N - 2's; alt <- the old current, N - 1's)
@@ -2388,7 +2456,7 @@ static int render_frame_in_flight(ycge_ctx *c, float *out_sdr)
         }
     }
     if (overlap_scene && c->knobs.flight_placed_gate && c->knobs.refill_steps == 0 && c->placed_flag) {
-        if (c->placed_expect) HIP_TRY(c, hipStreamWaitValue32(ts, c->placed_flag, c->placed_expect, hipStreamWaitValueGte, 0xffffffffu));
+        if (c->placed_expect) { HIP_TRY(c, hipStreamWaitValue32(ts, c->placed_flag, c->placed_expect, hipStreamWaitValueGte, 0xffffffffu)); c->placed_waits++; }
         c->placed_next = c->placed_expect + 1u;
         if (c->placed_next == 0u) c->placed_next = 1u;
     } else c->placed_next = 0;
@@ -2798,7 +2866,7 @@ size_t ycge_abi_sizeof(int32_t which)
     switch (which) {
     case 0: return sizeof(ycge_vec3); case 1: return sizeof(ycge_material); case 2: return sizeof(ycge_prim); case 3: return sizeof(ycge_mesh);
     case 4: return sizeof(ycge_voxel_lookup); case 5: return sizeof(ycge_grid); case 6: return sizeof(ycge_light); case 7: return sizeof(ycge_scene);
-    case 8: return sizeof(ycge_config); case 9: return sizeof(ycge_frame_stats);
+    case 8: return sizeof(ycge_config); case 9: return sizeof(ycge_frame_stats); case 10: return sizeof(ycge_flight_info);
     }
     return 0;
 }

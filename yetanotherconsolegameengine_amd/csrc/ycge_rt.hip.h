@@ -1073,8 +1073,25 @@ __device__ __forceinline__ void mesh_walk(const SceneDev &S, uint32_t &cur, int 
     // answers, a third of the round trips.  The counting instances keep the lane-serial form (their counters are the reference's).
     // (only where the caller entered with every lane of the wavefront: the groups of the cooperative walk need them all)
     const bool cwalk = FULLWAVE && !COUNT && !BOUNDED && S.tl_offset != 0u;
+#if defined(YCGE_DBG_BATCHSTAT)
+    // profiling build: where a batch's iterations go - until 16 / 8 / 4 lanes are left, in the cooperative walk - by query kind
+    uint32_t bs_it = 0u, bs_16 = 0xffffffffu, bs_8 = 0xffffffffu, bs_n0 = 0u, bs_kind = 3u, bs_coop = 0u;
+    if (FULLWAVE && !COUNT && !BOUNDED) {
+        const unsigned long long all = __ballot(cur != YCGE_REF_NONE_VALUE), any = __ballot(cur != YCGE_REF_NONE_VALUE && anyhit);
+        bs_n0 = (uint32_t)__popcll(all);
+        bs_kind = all == 0ull ? 3u : any == all ? 0u : any == 0ull ? 1u : 2u;
+    }
+#endif
     for (;;) {
         const bool act = cur != YCGE_REF_NONE_VALUE && (!BOUNDED || budget > 0);      // budget: refill mode yields with the walk's state in (cur, stack)
+#if defined(YCGE_DBG_BATCHSTAT)
+        if (FULLWAVE && !COUNT && !BOUNDED) {
+            const uint32_t nn = (uint32_t)__popcll(__ballot(act));
+            if (nn <= 16u && bs_16 == 0xffffffffu) bs_16 = bs_it;
+            if (nn <= 8u && bs_8 == 0xffffffffu) bs_8 = bs_it;
+            if (nn > YCGE_COOP_RAYS || !cwalk) bs_it++;
+        }
+#endif
         if (!act) break;
         if (cwalk && __popcll(__ballot(act)) <= YCGE_COOP_RAYS) break;
         if (BOUNDED) budget--;
@@ -1115,7 +1132,28 @@ __device__ __forceinline__ void mesh_walk(const SceneDev &S, uint32_t &cur, int 
         }
     }
     if (FULLWAVE && !COUNT && !BOUNDED) {
+#if defined(YCGE_DBG_BATCHSTAT)
+        const uint32_t bs_steps0 = w.steps;
+#endif
         if (cwalk && __any(cur != YCGE_REF_NONE_VALUE)) coop_walk(S, cur, mesh_prim, st, o, inv, d, tmin, closest, hit_prim, hit_sub, w, anyhit);
+#if defined(YCGE_DBG_BATCHSTAT)
+        {
+            uint32_t cm = w.steps - bs_steps0;          // the cooperative walk's iterations = the largest step count it handed back
+            for (int off = 32; off >= 1; off >>= 1) { const uint32_t o2 = (uint32_t)__shfl_xor((int)cm, off, 64); cm = o2 > cm ? o2 : cm; }
+            bs_coop = cm;
+            if ((threadIdx.x & 63u) == 0u && S.dbg_counters && bs_kind < 3u) {
+                // bank 2 + kind: every batch; bank 5 + kind: batches of >= 48 iterations.  [0] batches [1] lanes at entry [2] serial iterations
+                // [3] ... until <= 16 lanes [4] ... until <= 8 lanes [5] cooperative iterations [6] (serial + cooperative)^2 / 16 [7] batches that reached the cooperative walk
+                const uint32_t tot = bs_it + bs_coop;
+                for (int rep = 0; rep < (tot >= 48u ? 2 : 1); rep++) {
+                    unsigned long long *dc = S.dbg_counters + 16 + (size_t)8 * 256 * (2 + bs_kind + 3 * rep) + (size_t)((blockIdx.x * 2654435761u) >> 24) * 8;
+                    atomicAdd(dc + 0, 1ull); atomicAdd(dc + 1, (unsigned long long)bs_n0); atomicAdd(dc + 2, (unsigned long long)bs_it);
+                    atomicAdd(dc + 3, (unsigned long long)(bs_16 < bs_it ? bs_16 : bs_it)); atomicAdd(dc + 4, (unsigned long long)(bs_8 < bs_it ? bs_8 : bs_it));
+                    atomicAdd(dc + 5, (unsigned long long)bs_coop); atomicAdd(dc + 6, (unsigned long long)tot * tot / 16ull); atomicAdd(dc + 7, bs_coop ? 1ull : 0ull);
+                }
+            }
+        }
+#endif
     }
 }
 
@@ -1124,10 +1162,10 @@ __device__ __forceinline__ void mesh_walk(const SceneDev &S, uint32_t &cur, int 
 // come through the scalar cache and only the per-lane mesh walk diverges.  Otherwise the generic walk
 // starts at the scene root.  Both give the reference's visit order.
 template <bool COUNT, bool HAS_GRID, bool FLAT, bool FULLWAVE = false, class STK>
-__device__ __forceinline__ void traverse(const SceneDev &S, const RayQ &q, STK &st, float &closest, int &hit_prim, int &hit_sub, Work &w)
+__device__ __forceinline__ void traverse(const SceneDev &S, RayQ &q, STK &st, float &closest, int &hit_prim, int &hit_sub, Work &w)
 {
-    const F3 o = q.o, d = q.d;
-    const float tmin = q.tmin;
+    F3 o = q.o, d = q.d;
+    float tmin = q.tmin;
     closest = q.tmax;
     hit_prim = -1;
     hit_sub = 0;
@@ -1135,7 +1173,7 @@ __device__ __forceinline__ void traverse(const SceneDev &S, const RayQ &q, STK &
     const bool live = !FULLWAVE || q.live;
     if (COUNT && live) w.rays++;
     if (S.scene_root_ref == YCGE_REF_NONE_VALUE) return;
-    const F3 inv = f3(1.0f / d.x, 1.0f / d.y, 1.0f / d.z);
+    F3 inv = f3(1.0f / d.x, 1.0f / d.y, 1.0f / d.z);
     const bool sx = inv.x < 0.0f, sy = inv.y < 0.0f, sz = inv.z < 0.0f;
     float tn;
     if (COUNT && live) w.box++;
@@ -1166,8 +1204,13 @@ __device__ __forceinline__ void traverse(const SceneDev &S, const RayQ &q, STK &
                 // occlusion queries of this wavefront against the mesh: order-free, breadth-first from one shared work list (ycge_anyhit.hip.h);
                 // the stacks are empty here - between the objects of the flat scene - and lend it their LDS
                 const bool bfs = anyhit && start != YCGE_REF_NONE_VALUE;
-                if (__any(bfs)) {
-                    const unsigned long long occluded = mesh_anyhit_bfs(S, bfs, start, o, inv, d, tmin, closest, w);
+                const uint32_t n_bfs = (uint32_t)__popcll(__ballot(bfs));
+                if (n_bfs != 0u && n_bfs <= S.anyhit_bfs) {
+                    // (every lane's ray waits in LDS meanwhile and comes back from there - the caller's copy too: nothing of it is live across the rounds)
+                    bfs_park_ray(o, inv, d, tmin, closest);
+                    const unsigned long long occluded = mesh_anyhit_bfs(S, bfs, start, w);
+                    bfs_unpark_ray(o, inv, d, tmin, closest);
+                    q.o = o; q.d = d; q.tmin = tmin;
                     if (bfs) {
                         start = YCGE_REF_NONE_VALUE;
                         if ((occluded >> (threadIdx.x & 63u)) & 1ull) { hit_prim = pi; hit_sub = 0; }      // (an occlusion query's t and triangle are never looked at)

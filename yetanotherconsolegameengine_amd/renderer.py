@@ -60,8 +60,7 @@ class RaytraceRenderer:
         if getattr(self, "ctx", None):
             self.L.ycge_destroy(self.ctx)          # (waits for the frames in flight: their SDR arrays are still the wrapper's)
             self.ctx = C.c_void_p()
-        for a in self.__dict__.pop("_sdr_ring", {}).values():
-            self.L.ycge_unpin_host_buffer(a.ctypes.data_as(C.c_void_p))
+        self._drop_sdr_ring()
 
     def __enter__(self):
         return self
@@ -119,8 +118,18 @@ class RaytraceRenderer:
                     sort_fallbacks=int(out[4]), max_depth=int(out[5]))
 
     def Resize(self, fb_width: int, fb_height: int, superSample: int):
-        self._check(self.L.ycge_resize(self.ctx, fb_width, fb_height, superSample))
+        self._check(self.L.ycge_resize(self.ctx, fb_width, fb_height, superSample))          # (joins the frames in flight: nothing writes the old arrays any more)
         self._set_dims(fb_width, fb_height, max(1, superSample))
+        self._drop_sdr_ring(keep_shape=(self.fbH, self.fbW, 2, 3))
+
+    def _drop_sdr_ring(self, keep_shape=None):
+        """The page-locked SDR arrays of the frames in flight: those of another console size are unpinned (only if pinning them had
+        succeeded) and released."""
+        ring = self.__dict__.get("_sdr_ring", {})
+        for key in [k for k, (a, _) in ring.items() if a.shape != keep_shape]:
+            a, pinned = ring.pop(key)
+            if pinned and getattr(self, "ctx", None) is not None:
+                self.L.ycge_unpin_host_buffer(a.ctypes.data_as(C.c_void_p))
 
     def SetCamera(self, pos, yaw: float, pitch: float):
         self._pos, self._yaw, self._pitch = tuple(pos), yaw, pitch
@@ -167,17 +176,25 @@ class RaytraceRenderer:
             self._check(self.L.ycge_render_frame_async(self.ctx))
             return None
         ring = self.__dict__.setdefault("_sdr_ring", {})
-        key = (int(sdr_slot), self.fbH, self.fbW)
+        key = int(sdr_slot)
+        if key in ring and ring[key][0].shape != (self.fbH, self.fbW, 2, 3):
+            self._drop_sdr_ring(keep_shape=(self.fbH, self.fbW, 2, 3))
         if key not in ring:
             a = np.zeros((self.fbH, self.fbW, 2, 3), dtype=np.float32)
-            self.L.ycge_pin_host_buffer(a.ctypes.data_as(C.c_void_p), a.nbytes)      # (best effort: an unpinned array only makes the copy block)
-            ring[key] = a
-        a = ring[key]
+            pinned = self.L.ycge_pin_host_buffer(a.ctypes.data_as(C.c_void_p), a.nbytes) == 0      # (best effort: an unpinned array only makes the copy block)
+            ring[key] = (a, pinned)
+        a = ring[key][0]
         self._check(self.L.ycge_render_frame_async_sdr(self.ctx, a.ctypes.data_as(C.POINTER(C.c_float))))
         return a
 
     def Wait(self):
         self._check(self.L.ycge_wait(self.ctx))
+
+    def flight_info(self) -> dict:
+        """What the frames-in-flight machinery of this context does (ycge_flight_query): timing only, never a pixel."""
+        fi = abi.FlightInfo()
+        self._check(self.L.ycge_flight_query(self.ctx, C.byref(fi)))
+        return {f: int(getattr(fi, f)) for f, _ in abi.FlightInfo._fields_ if f != "reserved"}
 
     def async_trace_ms(self, capacity: int = 1024) -> np.ndarray:
         """Durations (ms) of the trace launches of the frames queued since the last call (waits for them), oldest first."""

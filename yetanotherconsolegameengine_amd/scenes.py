@@ -99,15 +99,17 @@ def NewBaseScene() -> Scene:
     return s
 
 
-GOLDEN_DIR = Path(__file__).resolve().parent.parent / "tests" / "golden"
-BUNNY_FIXTURE = GOLDEN_DIR / "stanford_bunny_mesh.npz"
+# config 3's mesh: the reference's own data file (ConsoleGame/assets/stanford-bunny.obj) as parsed arrays - scene data of the package
+# (written by tests/golden/make_fixtures.py bunny in the authoring container, where /root/reference exists)
+ASSETS_DIR = Path(__file__).resolve().parent / "assets"
+BUNNY_FIXTURE = ASSETS_DIR / "stanford_bunny_mesh.npz"
 
 # benchmark pose for the mesh scenes (the reference default pose faces away from the mesh)
 MESH_BENCH_POSE = dict(pos=(0.0, 1.0, -1.0), yaw=float(f32(3.14159274)), pitch=0.0, fov=45.0)
 
 
 def load_bunny_arrays() -> Tuple[np.ndarray, np.ndarray]:
-    """positions/faces of assets/stanford-bunny.obj as parsed by MeshLoader (fixture; see tests/golden/make_fixtures.py)."""
+    """positions/faces of assets/stanford-bunny.obj as parsed by MeshLoader (assets/stanford_bunny_mesh.npz; see tests/golden/make_fixtures.py)."""
     z = np.load(BUNNY_FIXTURE)
     return z["positions"].astype(np.float32), z["faces"].astype(np.int32)
 
