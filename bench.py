@@ -14,6 +14,10 @@ How N GPUs are driven (`--form`):
            launcher).  Fails loudly when fewer than N devices are visible.
   rccl     one process per GPU under torchrun (RANK / WORLD_SIZE in the environment): ycge_trace_tiles -> one RCCL all-gather of
            the tile slabs -> ycge_resolve_gathered on every rank.  What `auto` picks when WORLD_SIZE > 1.
+  resident one process per GPU under torchrun, the tile-RESIDENT form: ycge_trace_tiles_resident (--ring traces in flight) -> one RCCL
+           all-to-all of the one-pixel halo records (1.4 MB per rank at 8 ranks) -> ycge_resolve_tiles_resident (TAA on the rank's own
+           tiles, history resident) -> all-gather of the resolved history (12 B per pixel) -> ycge_unpack_history.  3.1 MB leave a rank
+           per frame instead of 8.3, 25 MB arrive instead of 66.
 `n_gpus` in the line is the number of devices that traced tiles this run (`device_tiles` lists their tile counts), never the flag.
 
 value   = Mrays/s over the rays the timed kernels TRACE: calls to Scene.Hit + Scene.Occluded (primary, shadow, bounce) per frame /
@@ -114,7 +118,8 @@ def main():
     ap.add_argument("--warmup", type=int, default=8)
     ap.add_argument("--config", type=int, default=4)
     ap.add_argument("--camera", choices=("static", "orbit"), default="static", help="orbit: the pose changes every frame of the timed region (the headline then is the moving-camera frame)")
-    ap.add_argument("--form", choices=("auto", "onecall", "rccl"), default="auto", help="how N > 1 GPUs are driven (see the module docstring)")
+    ap.add_argument("--form", choices=("auto", "onecall", "rccl", "resident"), default="auto", help="how N > 1 GPUs are driven (see the module docstring)")
+    ap.add_argument("--ring", type=int, default=4, help="--form resident: frame sets in the ring = tiled traces in flight (config.tile_ring)")
     ap.add_argument("--t01", type=float, default=0.25, help="config 5: day phase of the sun and moon (DayNightCycle.cs:48-82); 0.25 = SURVEY 8(d): sun on the horizon, BOTH lights at intensity 0; 0.5 = noon, 0.8 = night")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
@@ -129,6 +134,9 @@ def main():
     form = args.form
     if form == "auto":
         form = "rccl" if world > 1 else "onecall"
+    resident = form == "resident"
+    if resident:
+        form = "rccl"          # (the same launcher, ranks and tile partition; only the per-frame exchange differs)
     if form == "rccl" and world != args.gpus and not (world == 1 and os.environ.get("YCGE_BENCH_FORCE_TILED")):
         raise SystemExit(f"--form rccl --gpus {args.gpus} needs one process per GPU (torchrun --nproc-per-node {args.gpus}); WORLD_SIZE={world}")
     if form == "onecall" and world > 1:
@@ -166,7 +174,7 @@ def main():
     def make(count):
         # the multi-GPU frame ends with TAA (the metric's frame): lean slabs, no albedo plane in the all-gather (32 instead of 44 B per pixel)
         r = RaytraceRenderer(flat, fbw, fbh, pose["fov"], ss, count_work=count, device=local_rank, rank=rank, world_size=world if multi else 1,
-                             slab_albedo=not multi, devices=list(range(n_dev)) if n_dev > 1 else None)
+                             slab_albedo=not multi, devices=list(range(n_dev)) if n_dev > 1 else None, tile_ring=args.ring if (resident and not count) else 0)
         r.SetCamera(pose["pos"], pose["yaw"], pose["pitch"])
         return r
 
@@ -196,12 +204,45 @@ def main():
         ev_traced = [torch.cuda.Event() for _ in range(2)]
         ev_resolved = [torch.cuda.Event() for _ in range(2)]
         n_issued = [0]
+    if multi and resident:
+        # the tile-resident form: K frame slots (send / receive halo records, history slab, gathered history), K trace streams taken in turn
+        K = args.ring
+        s_cnt, r_cnt = r.halo_counts()
+        hb = r.history_slab_bytes() // 4
+        h_send = [torch.zeros(max(1, sum(s_cnt)) * 4, dtype=torch.float32, device="cuda") for _ in range(K)]
+        h_recv = [torch.zeros(max(1, sum(r_cnt)) * 4, dtype=torch.float32, device="cuda") for _ in range(K)]
+        h_hist = [torch.zeros(hb, dtype=torch.float32, device="cuda") for _ in range(K)]
+        h_all = [torch.zeros(world * hb, dtype=torch.float32, device="cuda") for _ in range(K)]
+        rs_traces = [torch.cuda.Stream() for _ in range(K)]
+        rs_ev_t = [torch.cuda.Event() for _ in range(K)]; rs_ev_r = [torch.cuda.Event() for _ in range(K)]
+        rs_issued = []
+        s_traces = rs_traces[:2] if K >= 2 else [rs_traces[0], rs_traces[0]]
+
+        def rs_resolve(k):
+            with torch.cuda.stream(s_comm):
+                s_comm.wait_event(rs_ev_t[k])
+                dist.all_to_all_single(h_recv[k][:sum(r_cnt) * 4], h_send[k][:sum(s_cnt) * 4], output_split_sizes=[c * 4 for c in r_cnt], input_split_sizes=[c * 4 for c in s_cnt])
+                r.resolve_tiles_resident(h_recv[k].data_ptr(), h_hist[k].data_ptr(), s_comm.cuda_stream)
+                dist.all_gather_into_tensor(h_all[k], h_hist[k])          # whoever shows the frame: here every rank (a gather to rank 0 moves an eighth of it)
+                r.unpack_history(h_all[k].data_ptr(), s_comm.cuda_stream)
+                rs_ev_r[k].record(s_comm)
 
     def step(rr, want_stats=False):
         """One frame; returns (trace_ms, frame_ms) as the library measured them (0 where the pipelined form takes no per-step timing)."""
         if not multi:
             rr.TryFlipAndBlit()
             return float(rr.stats.trace_ms), float(rr.stats.total_ms)
+        if resident and rr is r and not want_stats:
+            if len(rs_issued) == K:
+                rs_resolve(rs_issued.pop(0))
+            k = n_issued[0] % K
+            n_issued[0] += 1
+            with torch.cuda.stream(rs_traces[k]):
+                rs_traces[k].wait_event(rs_ev_r[k])          # slot k's buffers were last read by the exchange of K frames ago
+                rr.trace_tiles_resident(h_send[k].data_ptr(), rs_traces[k].cuda_stream)
+                rs_ev_t[k].record(rs_traces[k])
+            rs_issued.append(k)
+            return 0.0, 0.0
         if not pipelined or want_stats:
             rr.trace_tiles(slab.data_ptr(), stream.cuda_stream, want_stats=want_stats)
             t = float(rr.stats.trace_ms) if want_stats else 0.0
@@ -223,6 +264,11 @@ def main():
         return 0.0, 0.0
 
     def fence():
+        if multi and resident:
+            while rs_issued:
+                rs_resolve(rs_issued.pop(0))
+            for s_ in rs_traces:
+                s_.synchronize()
         if multi:
             s_traces[0].synchronize(); s_traces[1].synchronize(); s_comm.synchronize()
             dist.barrier()
@@ -380,7 +426,9 @@ def main():
             r.Wait()
             fsdr = {"frames": m, "ms_per_step": round((time.perf_counter() - ts0) / m * 1e3, 4),
                     "what": "ycge_render_frame_async_sdr: the post stage and read-back of frame N beside the traces and TAA of the frames after it; compare post_stage.frame_ms_with_sdr_readback"}
-        flight = {"frames": n, "ms_per_step": round(tf / n * 1e3, 4), "value": round(traced_per_frame * n / tf / 1e6, 2), "unit": "Mrays/s",
+        fi = r.flight_info()
+        flight = {"frames": n, "ms_per_step": round(tf / n * 1e3, 4),
+                  "gate": "on" if fi["placed_gate"] else "off", "two_trace_streams": bool(fi["two_trace_streams"]), "placed_waits": fi["placed_waits"], "value": round(traced_per_frame * n / tf / 1e6, 2), "unit": "Mrays/s",
                   "trace_ms": dist3([float(x) for x in ft]) if len(ft) else None, "with_sdr": fsdr,
                   "what": "the same frames queued with ycge_render_frame_async: no host wait between frames, two traces at a time on two streams, TAA of frame N and the "
                           "schedule of frame N + 3 on a third stream, three sets of trace outputs taken in turn; bit-identical frames (tests/test_gpu_timed_variants.py). "
@@ -432,6 +480,7 @@ def main():
     if rank == 0:
         name, cus = r.device_info()
         how = ("one process, one ycge_render_frame call per frame drives all devices; peers push their tiles into device 0 over xGMI" if (form == "onecall" and n_dev > 1)
+               else f"one process per GPU, tile-resident TAA; per frame one RCCL all-to-all of the one-pixel halo records and one all-gather of the resolved history (12 B per pixel); {args.ring} traces in flight" if (multi and resident)
                else "one process per GPU; one RCCL all-gather of the tile slabs per frame" + ("; traces of consecutive frames on two streams (they may overlap), gather + resolve of frame N on a third" if pipelined else "") if multi else "single GPU")
         out = {
             "metric": f"Mrays/s (all rays: Scene.Hit + Scene.Occluded calls) and ms/frame, {METRIC_SHAPES[args.config]}",
@@ -443,8 +492,8 @@ def main():
                        "lights": {"intensity": [float(l.Intensity) for l in scene.Lights],
                                   "note": "the timed kernels trace no shadow ray towards a light of intensity 0 (its contribution is a zero whatever the ray finds: bit-identical pixels); "
                                           "`value` counts traced rays only, `value_reference_ray_count` the reference's Scene.Hit / Scene.Occluded calls, which include those rays" if any(float(l.Intensity) == 0.0 for l in scene.Lights) else None},
-                       "frame": "ray-gen + trace + TAA" + (" + RCCL all-gather of tile slabs + un-permute" if multi else " + peer tile push" if n_dev > 1 else ""),
-                       "parallelism": f"framebuffer tiles 32x8 round-robin over {n_gpus_used} GPU(s): " + how, "form": form,
+                       "frame": "ray-gen + trace + TAA" + (" on the rank's own tiles + RCCL all-to-all of halo records + all-gather of the history" if (multi and resident) else " + RCCL all-gather of tile slabs + un-permute" if multi else " + peer tile push" if n_dev > 1 else ""),
+                       "parallelism": f"framebuffer tiles 32x8 round-robin over {n_gpus_used} GPU(s): " + how, "form": "resident" if (multi and resident) else form,
                        "gpus_requested": args.gpus, "device_tiles": device_tiles, "device": name, "compute_units": cus},
             "primary_mrays_per_s": round(pixels * args.steps / elapsed / 1e6, 2),
             "rays_per_frame": round(per_frame["n_rays"], 1),

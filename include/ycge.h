@@ -240,6 +240,8 @@ typedef struct ycge_config {
      * iteration - the denoiser the C# text reads like, fully parallel (~0.2 ms).  The two differ by what INTEGRATION.md states (a filter
      * tap that sees a neighbour's already-filtered value instead of its unfiltered one); everything up to TAA is unaffected. */
     int32_t atrous_inplace_exact;
+    /* tile-resident form (ycge_trace_tiles_resident): frame sets in the ring = tiled traces that may be in flight at a time, 2..7; 0 = 2 */
+    int32_t tile_ring;
 } ycge_config;
 
 typedef struct ycge_frame_stats {
@@ -382,6 +384,25 @@ int ycge_trace_tiles(ycge_ctx *ctx, void *d_slab, void *hip_stream, ycge_frame_s
  * full-frame buffers, then steps 5-9 (TAA ... tonemap) on the full frame */
 int ycge_resolve_gathered(ycge_ctx *ctx, const void *d_all_slabs, void *hip_stream,
                           float *out_top_bottom_sdr, ycge_frame_stats *stats);
+
+/* --- the tile-RESIDENT form of the same partition (one process per GPU): TAA runs on every rank's OWN tiles and its history never
+ * leaves the rank.  TemporalBlendWithClamp reads a 3x3 window (clampRadius = 1, RaytraceRenderer.cs:218), so a rank needs {hdr, sky}
+ * of the one-pixel ring around each of its tiles from the ranks that own those pixels: one small all-to-all of halo records (4 floats
+ * each: 1.3 KB per tile instead of the 8-11 KB of its slab), then TAA, then - for whoever shows the frame - a gather of the RESOLVED
+ * history, 12 bytes per pixel.  Per frame and rank at 1920x1080 on 8 ranks: ~1.4 MB of halo records each way + 3.1 MB of history out,
+ * against 8.3 MB out / 66 MB in for the all-gather of lean slabs.  The frame ends with TAA (no G-buffer on the consumer: the post stage
+ * needs ycge_resolve_gathered).  K = config.tile_ring frame sets: K traces may be in flight, a trace waits for the resolve of frame
+ * N - K.  Same pixels as the single-device frame, bit for bit (the halo records are copies, the per-pixel arithmetic is k_taa's).
+ *
+ *   every frame, every rank:   ycge_trace_tiles_resident(ctx, d_send, stream)        trace + gather of the records other ranks need
+ *                              all_to_all(d_recv <- d_send) with ycge_halo_counts' split sizes (records of 4 floats)
+ *                              ycge_resolve_tiles_resident(ctx, d_recv, d_hist_slab, stream)   scatter, TAA on own tiles, history slab
+ *   the consumer:              all_gather / gather of the history slabs -> ycge_unpack_history(ctx, d_all_hist_slabs, stream) */
+int ycge_halo_counts(ycge_ctx *ctx, int64_t *send_counts /* [world_size] */, int64_t *recv_counts /* [world_size] */);
+int ycge_history_slab_bytes(const ycge_ctx *ctx, size_t *bytes);      /* padded per-rank size: equal on all ranks */
+int ycge_trace_tiles_resident(ycge_ctx *ctx, void *d_halo_send, void *hip_stream, ycge_frame_stats *stats);
+int ycge_resolve_tiles_resident(ycge_ctx *ctx, const void *d_halo_recv, void *d_history_slab /* may be NULL */, void *hip_stream, ycge_frame_stats *stats);
+int ycge_unpack_history(ycge_ctx *ctx, const void *d_all_history_slabs, void *hip_stream);
 
 /* A live texture's next frame (what IFrameReader.GetCurrentFramePtr() will return while the coming frames are traced): bytes =
  * width * height * frame_bytes_per_pixel of texture `texture_index` of the last ycge_scene_upload.  The host sets

@@ -28,6 +28,8 @@ if [ -x $REPO/profiles/micro/copycal ]; then
   timeout 300 rocprofv3 --kernel-trace --pmc FETCH_SIZE -f csv -d $OUT/pmc_calf -o calf -- $REPO/profiles/micro/copycal > $OUT/copycal_f.log 2>&1
   timeout 300 rocprofv3 --kernel-trace --pmc WRITE_SIZE -f csv -d $OUT/pmc_calw -o calw -- $REPO/profiles/micro/copycal > $OUT/copycal_w.log 2>&1
 fi
-CFG=4; prev=""; for a in "$@"; do if [ "$prev" = "--config" ]; then CFG=$a; fi; prev=$a; done
-python3 $REPO/profiles/summarize.py $OUT --json $OUT/pmc_config$CFG.json --config $CFG --source "timeout 600 rocprofv3 --kernel-trace --stats + separate --pmc passes of: bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-post --no-flight $* (tag $TAG)" > $OUT/summary.txt 2>&1
+CFG=4; T01=""; prev=""; for a in "$@"; do if [ "$prev" = "--config" ]; then CFG=$a; fi; if [ "$prev" = "--t01" ]; then T01=$a; fi; prev=$a; done
+# (a lit config-5 run - bench.py --t01 other than the survey's 0.25 - gets its own summary: pmc_config5_t050.json, what bench.py looks for)
+TAG01=""; if [ -n "$T01" ] && [ "$T01" != "0.25" ]; then TAG01=$(python3 -c "print('_t%03d' % round(float('$T01') * 100))"); fi
+python3 $REPO/profiles/summarize.py $OUT --json $OUT/pmc_config$CFG$TAG01.json --config $CFG --source "timeout 600 rocprofv3 --kernel-trace --stats + separate --pmc passes of: bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-post --no-flight $* (tag $TAG)" > $OUT/summary.txt 2>&1
 cat $OUT/summary.txt

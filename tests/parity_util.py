@@ -28,11 +28,11 @@ def mismatch_count(a, b):
     return int(np.count_nonzero(a != b))
 
 
-def run_pair(ob, scene, fb_w, fb_h, ss, pose, frames=1, oracle_threads=8, count=True):
-    """Returns (oracle renderer, product renderer) after `frames` frames each (oracle with TAA stage)."""
+def run_pair(ob, scene, fb_w, fb_h, ss, pose, frames=1, oracle_threads=8, count=True, lib=None):
+    """Returns (oracle renderer, product renderer) after `frames` frames each (oracle with TAA stage).  lib: a variant build of the library."""
     flat = flatten(scene)
     o = ob.OracleRenderer(scene, fb_w, fb_h, ss, pose, flat=flat)
-    g = RaytraceRenderer(flat, fb_w, fb_h, pose.get("fov", 45.0), ss, capture_debug=True, count_work=count)
+    g = RaytraceRenderer(flat, fb_w, fb_h, pose.get("fov", 45.0), ss, capture_debug=True, count_work=count, lib=lib)
     g.SetCamera(pose["pos"], pose["yaw"], pose["pitch"])
     g.SetFov(pose.get("fov", 45.0))
     for _ in range(frames):

@@ -332,6 +332,102 @@ def test_two_rank_tile_split_matches_single_gpu(product_lib, path, case, monkeyp
         r.close()
 
 
+def _exchange_halos(ranks, send_bufs, torch):
+    """What all_to_all_single does with ycge_halo_counts' split sizes, by device copies: rank q's segment for r lands in r's segment from q."""
+    world = len(ranks)
+    counts = [r.halo_counts() for r in ranks]
+    recv_bufs = [torch.zeros(max(1, sum(counts[r][1])) * 4, dtype=torch.float32, device="cuda") for r in range(world)]
+    for q in range(world):
+        so = np.concatenate([[0], np.cumsum(counts[q][0])])
+        for r in range(world):
+            assert counts[q][0][r] == counts[r][1][q], (q, r)
+            ro = np.concatenate([[0], np.cumsum(counts[r][1])])
+            n = counts[q][0][r]
+            if n:
+                recv_bufs[r][ro[q] * 4:(ro[q] + n) * 4] = send_bufs[q][so[r] * 4:(so[r] + n) * 4]
+    return recv_bufs
+
+
+@pytest.mark.parametrize("case,world,ring,depth", [("cornell", 2, 0, 1), ("bunny", 4, 4, 3), ("voxel", 3, 3, 2), ("bunny", 8, 6, 5)])
+def test_tile_resident_taa_with_halo_exchange_matches_single_gpu(product_lib, case, world, ring, depth, monkeypatch):
+    """The tile-RESIDENT form (include/ycge.h): every rank traces its tiles, the ranks exchange the one-pixel {hdr, sky} ring of their
+    tiles, each runs TAA on its OWN tiles (history resident), the history slabs are gathered.  `world` ranks emulated on one GPU, the
+    exchange by device copies with ycge_halo_counts' split sizes; `depth` + 1 traces are issued before the oldest frame is resolved
+    (ring of config.tile_ring sets).  The gathered history equals the single-context frame's, bit for bit, over 8 frames of a camera that
+    moves below and above the TAA reset thresholds (TemporalAA.cs:58-67) - and so do the halo lists the library hands out and tiles.py's."""
+    import torch
+    monkeypatch.delenv("YCGE_PATH", raising=False)
+    if case == "cornell":
+        sc, w, h, ss, pose = scenes.config_scene(1)
+    elif case == "bunny":
+        sc, _, _, ss, pose = scenes.config_scene(3); w, h = 320, 90
+    else:
+        sc, _, _, ss, pose = scenes.config_scene(5, small=True, t01=0.5); w, h = 96, 27
+    flat = flatten(sc)
+    moves = [0.0, 0.001, 0.0012, 0.02, 0.0201, 0.0201, 0.05, 0.0505]
+
+    def cam(r, i):
+        r.SetCamera((pose["pos"][0] + moves[i], pose["pos"][1], pose["pos"][2]), pose["yaw"] + 0.2 * moves[i], pose["pitch"])
+
+    single = RaytraceRenderer(flat, w, h, pose["fov"], ss)
+    want, want_reset = [], []
+    for i in range(len(moves)):
+        cam(single, i)
+        single.TryFlipAndBlit()
+        want.append(single.read(abi.BUF_TAA_HISTORY)); want_reset.append(int(single.stats.history_reset))
+    ranks = [RaytraceRenderer(flat, w, h, pose["fov"], ss, rank=i, world_size=world, tile_ring=ring) for i in range(world)]
+    for i, r in enumerate(ranks):          # the library's halo lists are the layout module's
+        s_cnt, r_cnt = r.halo_counts()
+        send, recv = tiles.halo_lists(i, world, single.hiW, single.hiH)
+        assert s_cnt == [len(v) for v in send] and r_cnt == [len(v) for v in recv]
+    hb = ranks[0].history_slab_bytes()
+    assert hb == tiles.history_slab_floats(world, tiles.tile_grid(single.hiW, single.hiH)[2]) * 4
+    n_send = [max(1, sum(r.halo_counts()[0])) for r in ranks]
+    pending = []          # (frame index, send buffers) of the traced, unresolved frames
+    # with a ring, the traces of consecutive frames go to different streams and the resolves to yet another (bench.py's loop): the library
+    # orders a set's trace, exchange, resolve and re-use by its own events, whatever streams the caller brings
+    t_streams = [torch.cuda.Stream() for _ in range(ring)] if ring else [None]
+    r_stream = torch.cuda.Stream() if ring else None
+    sp = lambda st: st.cuda_stream if st is not None else 0
+
+    def resolve_oldest():
+        i, send_bufs = pending.pop(0)
+        torch.cuda.synchronize()
+        recv_bufs = _exchange_halos(ranks, send_bufs, torch)
+        gathered = torch.zeros(world * hb // 4, dtype=torch.float32, device="cuda")
+        torch.cuda.synchronize()          # (the copies above ran on torch's stream; the resolves below run on a non-blocking one)
+        for k, r in enumerate(ranks):
+            r.resolve_tiles_resident(recv_bufs[k].data_ptr(), gathered[k * hb // 4:].data_ptr(), sp(r_stream), want_stats=True)
+            assert int(r.stats.history_reset) == want_reset[i] and int(r.stats.frame) == i + 1, (i, k)
+        torch.cuda.synchronize()
+        full = tiles.unpermute(gathered.cpu().numpy(), single.hiW, single.hiH, world, 3)
+        assert pu.bits_equal(full, want[i]), f"{case}: gathered history of frame {i + 1} differs"
+        ranks[0].unpack_history(gathered.data_ptr(), 0)
+        if not pending:          # (reading the consumer's frame joins everything: only where no traced frame waits)
+            assert pu.bits_equal(ranks[0].read(abi.BUF_TAA_HISTORY), want[i])
+
+    for i in range(len(moves)):
+        send_bufs = [torch.zeros(n * 4, dtype=torch.float32, device="cuda") for n in n_send]
+        torch.cuda.current_stream().synchronize()
+        for k, r in enumerate(ranks):
+            cam(r, i)
+            r.trace_tiles_resident(send_bufs[k].data_ptr(), sp(t_streams[i % len(t_streams)]))
+        pending.append((i, send_bufs))
+        if len(pending) > depth:
+            resolve_oldest()
+    while pending:
+        resolve_oldest()
+    # the ring refuses a trace when every set holds an unresolved frame
+    K = ring if ring else 2
+    send_bufs = [torch.zeros(n_send[0] * 4, dtype=torch.float32, device="cuda") for _ in range(K + 1)]
+    for j in range(K):
+        ranks[0].trace_tiles_resident(send_bufs[j].data_ptr(), 0)
+    with pytest.raises(abi.YcgeError, match="tile_ring"):
+        ranks[0].trace_tiles_resident(send_bufs[K].data_ptr(), 0)
+    for r in ranks + [single]:
+        r.close()
+
+
 def test_update_lights_per_frame(product_lib, oracle, path):
     """DayNightEntity-style per-frame light / sky animation through ycge_scene_update_lights."""
     sc, w, h, ss, pose = scenes.config_scene(5, small=True)
@@ -348,11 +444,18 @@ def test_update_lights_per_frame(product_lib, oracle, path):
     o.close(); g.close()
 
 
-def _post_pair(oracle, sc, w, h, ss, pose, frames=3):
+def _experiments_lib():
+    """lib/var_experiments.so: the product's sources with -DYCGE_EXPERIMENTS=1 - the measured-and-rejected kernel forms of csrc/experiments/
+    (k_trace_refill, the group hand-over A-trous) exist in that build only"""
+    from yetanotherconsolegameengine_amd import build
+    return abi.load_library(build.build_variant("experiments"))
+
+
+def _post_pair(oracle, sc, w, h, ss, pose, frames=3, lib=None):
     """oracle (stages=2) and product (SDR requested) over `frames` frames; yields per-frame comparison tuples"""
     flat = flatten(sc)
     o = oracle.OracleRenderer(sc, w, h, ss, pose, flat=flat)
-    g = RaytraceRenderer(flat, w, h, pose.get("fov", 45.0), ss)
+    g = RaytraceRenderer(flat, w, h, pose.get("fov", 45.0), ss, lib=lib)
     g.SetCamera(pose["pos"], pose["yaw"], pose["pitch"])
     out = []
     for f in range(frames):
@@ -413,9 +516,10 @@ def test_inplace_atrous_in_every_form_against_the_oracle(product_lib, oracle, mo
     denoised frame, the exposure and the SDR frame must equal the oracle's on every frame.  Sizes: several bands (the hand-over is
     exercised), an odd size (border clamps), a width that is not a multiple of a cache line's pixels (two bands share lines)."""
     monkeypatch.setenv("YCGE_POST_MODE", mode)
+    lib = _experiments_lib() if mode == "4" else None          # (the group hand-over form lives in csrc/experiments/)
     sc, _, _, _, pose = scenes.config_scene(2)
     for (w, h, ss) in ((192, 54, 1), (131, 37, 1), (64, 20, 2)):
-        for f, (taa, den, expo, sdr, sdr_rms, post_ms) in enumerate(_post_pair(oracle, sc, w, h, ss, pose, frames=3)):
+        for f, (taa, den, expo, sdr, sdr_rms, post_ms) in enumerate(_post_pair(oracle, sc, w, h, ss, pose, frames=3, lib=lib)):
             print(f"mode {mode} {w}x{h} ss{ss} frame {f + 1}: taa {taa} denoised {den} exposure {expo} sdr {sdr}")
             assert taa == 0 and den == 0 and not expo and sdr == 0
 
@@ -490,12 +594,13 @@ def test_query_fan_out_and_refill_kernels_bit_exact(product_lib, oracle, monkeyp
     for kv in knob.split(","):                  # the split variant runs fanned blocks in 4 parts of 16 pixels (the 8-rank default)
         name, value = kv.split("=")
         monkeypatch.setenv(name, value)
+    lib = _experiments_lib() if "REFILL" in knob else None          # (k_trace_refill lives in csrc/experiments/)
     sc3, w3, h3, ss3, pose3 = scenes.config_scene(3)
     sc1, w1, h1, ss1, pose1 = scenes.config_scene(1)
     cases = [("bunny", sc3, 320, 90, 1, pose3), ("zoo+glass", _zoo_scene(True), 192, 54, 1, dict(pos=(0.1, 1.2, 1.0), yaw=0.05, pitch=-0.12, fov=50.0)),
              ("cornell", sc1, w1, h1, ss1, pose1)]
     for label, sc, w, h, ss, pose in cases:
-        o, g = pu.run_pair(oracle, sc, w, h, ss, pose, frames=1)
+        o, g = pu.run_pair(oracle, sc, w, h, ss, pose, frames=1, lib=lib)
         _assert_parity(pu.compare_frame(o, g), f"{knob} {label} frame1")
         for f in (2, 3):
             o.render(stages=1, threads=8); g.TryFlipAndBlit()

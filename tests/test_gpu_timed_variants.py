@@ -552,6 +552,42 @@ def test_frames_in_flight_with_the_post_stage(product_lib, cfg_n, w, h):
     fl.close()
 
 
+@pytest.mark.parametrize("gate", ["1", "0"])
+def test_frames_in_flight_say_what_they_do_and_do_not_depend_on_the_placed_gate(product_lib, monkeypatch, gate):
+    """The placed-value gate ("a trace starts when the trace before it has placed its last workgroup": the last block INDEX of a launch stores
+    a value, the next trace's stream waits for it) rests on an observed dispatcher property and decides timing only.  Frames in flight
+    must be the synchronous frames, bit for bit, with the gate on and with YCGE_FLIGHT_PLACED_GATE=0 - where the order of the first frames
+    of a burst (synchronous schedule -> cost-slot clears -> fork of the second trace stream) must hold by itself - and on a frame that is
+    ONE 8x8 block (the last workgroup is the first: the value is stored before any pixel is traced).  ycge_flight_query reports the state."""
+    monkeypatch.setenv("YCGE_FLIGHT_PLACED_GATE", gate)
+    monkeypatch.delenv("YCGE_PATH", raising=False)
+    sc, _, _, ss, pose = scenes.config_scene(3)
+    flat = flatten(sc)
+    watch = (abi.BUF_CURRENT_HDR, abi.BUF_G_NORMAL, abi.BUF_G_DEPTH, abi.BUF_SKY_MASK, abi.BUF_TAA_HISTORY)
+    for (w, h) in ((320, 90), (8, 4)):
+        seq = RaytraceRenderer(flat, w, h, pose["fov"], ss)
+        fl = RaytraceRenderer(flat, w, h, pose["fov"], ss)
+        for r in (seq, fl):
+            r.SetCamera(pose["pos"], pose["yaw"], pose["pitch"])
+        info = fl.flight_info()
+        assert info["two_trace_streams"] == 1 and info["placed_gate"] == int(gate) and info["frames_outstanding"] == 0, info
+        n = 0
+        for burst in (1, 2, 5, 9):            # bursts of frames in flight between synchronous frames (each burst starts from a quiet context)
+            seq.TryFlipAndBlit(); fl.TryFlipAndBlit()
+            for _ in range(burst):
+                seq.TryFlipAndBlit(); fl.RenderAsync(); n += 1
+            assert fl.flight_info()["frames_outstanding"] == 1
+            for b in watch:
+                assert pu.bits_equal(fl.read(b), seq.read(b)), (w, h, burst, b)
+        info = fl.flight_info()
+        assert info["frames_outstanding"] == 0          # (a read-back joins)
+        if gate == "1":
+            assert 0 < info["placed_waits"] <= n, info          # every frame of a burst but its first waits for a placed value
+        else:
+            assert info["placed_waits"] == 0, info
+        seq.close(); fl.close()
+
+
 def test_frames_in_flight_refuse_what_they_cannot_keep(product_lib):
     sc, _, _, ss, pose = scenes.config_scene(2)
     flat = flatten(sc)

@@ -364,6 +364,104 @@ def test_two_process_all_gather_reassembles_the_frame(tmp_path, floats):
     assert r.stdout.count("ok") == 2
 
 
+# ---- tile-resident form: halo lists (TAA's 3x3 window across tile borders), host C++ against tiles.py, then 2 processes over gloo -----
+@pytest.mark.parametrize("W,H,world", [(200, 90, 2), (200, 90, 3), (1920, 1080, 8), (70, 50, 4), (33, 9, 2), (64, 16, 5)])
+def test_halo_lists_of_the_library_are_the_layout_module_s(product_lib, W, H, world):
+    """ycge_host_halo_layout (csrc/ycge_host.cpp: halo_layout, pure host code) and tiles.halo_lists state the same exchange: for every
+    rank the same counts per peer and the same pixel lists; what rank q sends to rank r is what r expects from q, record for record;
+    and the ring is complete - every pixel of a rank's tiles finds its whole (image-clamped) 3x3 window among the rank's own pixels and
+    the pixels it receives (TemporalBlendWithClamp, RaytraceRenderer.cs:218, 341-352)."""
+    fn = product_lib.ycge_host_halo_layout
+    fn.restype = C.c_int
+    fn.argtypes = [C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64]
+    tx, ty, n = tiles.tile_grid(W, H)
+    lists = []
+    for rank in range(world):
+        sc = np.zeros(world, np.int64); rc = np.zeros(world, np.int64)
+        cap = n * 84 + 16
+        spx = np.zeros(cap, np.uint32); rpx = np.zeros(cap, np.uint32)
+        assert fn(W, H, rank, world, sc.ctypes.data, rc.ctypes.data, spx.ctypes.data, rpx.ctypes.data, cap) == 0
+        send, recv = tiles.halo_lists(rank, world, W, H)
+        assert [len(v) for v in send] == sc.tolist() and [len(v) for v in recv] == rc.tolist(), rank
+        assert np.array_equal(np.concatenate(send) if sc.sum() else np.zeros(0, np.int64), spx[:sc.sum()].astype(np.int64))
+        assert np.array_equal(np.concatenate(recv) if rc.sum() else np.zeros(0, np.int64), rpx[:rc.sum()].astype(np.int64))
+        lists.append((send, recv))
+    for q in range(world):
+        for r in range(world):
+            if q != r:
+                assert np.array_equal(lists[q][0][r], lists[r][1][q]), (q, r)          # q's segment for r IS r's segment from q
+    # completeness of the ring, rank 0 (and the last rank): own pixels + received pixels cover every 3x3 window
+    for rank in {0, world - 1}:
+        have = np.zeros(W * H, bool)
+        for t in tiles.owned_tiles(rank, world, n):
+            x0, y0 = (t % tx) * 32, (t // tx) * 8
+            yy, xx = np.mgrid[y0:min(y0 + 8, H), x0:min(x0 + 32, W)]
+            have[(xx + yy * W).ravel()] = True
+        own = have.copy()
+        for v in lists[rank][1]:
+            have[v] = True
+        ys, xs = np.nonzero(own.reshape(H, W))
+        for dy in (-1, 0, 1):
+            for dx in (-1, 0, 1):
+                assert have[np.clip(xs + dx, 0, W - 1) + np.clip(ys + dy, 0, H - 1) * W].all(), (rank, dx, dy)
+
+
+_HALO_WORKER = r'''
+import os, sys
+sys.path.insert(0, sys.argv[1])
+import numpy as np, torch, torch.distributed as dist
+from yetanotherconsolegameengine_amd import tiles
+dist.init_process_group("gloo")
+rank, world = dist.get_rank(), dist.get_world_size()
+W, H = 200, 90
+tx, ty, n = tiles.tile_grid(W, H)
+yy, xx = np.mgrid[0:H, 0:W]
+frame = np.stack([(xx * 1000 + yy + c * 0.125).astype(np.float32) for c in range(4)], -1).reshape(-1, 4)     # {hdr rgb, sky} of the whole frame
+mine = np.full_like(frame, np.nan)                       # this rank "traces" its tiles only
+for tid in tiles.owned_tiles(rank, world, n):
+    x0, y0 = (tid % tx) * 32, (tid // tx) * 8
+    ys, xs = np.mgrid[y0:min(y0 + 8, H), x0:min(x0 + 32, W)]
+    mine[(xs + ys * W).ravel()] = frame[(xs + ys * W).ravel()]
+send, recv = tiles.halo_lists(rank, world, W, H)
+send_buf = torch.from_numpy(np.concatenate([mine[v] for v in send]).astype(np.float32).reshape(-1))
+recv_buf = torch.empty(sum(len(v) for v in recv) * 4, dtype=torch.float32)
+# the one exchange of the tile-resident form: all_to_all_single with ycge_halo_counts' split sizes (records of 4 floats)
+dist.all_to_all_single(recv_buf, send_buf, output_split_sizes=[len(v) * 4 for v in recv], input_split_sizes=[len(v) * 4 for v in send])
+got = recv_buf.numpy().reshape(-1, 4)
+mine[np.concatenate(recv)] = got                         # k_scatter_halo
+# every own pixel now finds its (image-clamped) 3x3 window, with the values the full frame holds
+for tid in tiles.owned_tiles(rank, world, n):
+    x0, y0 = (tid % tx) * 32, (tid // tx) * 8
+    ys, xs = np.mgrid[y0:min(y0 + 8, H), x0:min(x0 + 32, W)]
+    for dy in (-1, 0, 1):
+        for dx in (-1, 0, 1):
+            j = (np.clip(xs + dx, 0, W - 1) + np.clip(ys + dy, 0, H - 1) * W).ravel()
+            assert np.array_equal(mine[j], frame[j]), "rank %d tile %d tap (%d, %d)" % (rank, tid, dx, dy)
+# the history slabs: 12 bytes per pixel of the own tiles, gathered to whoever shows the frame
+hist = frame[:, :3].reshape(H, W, 3)
+slab = torch.from_numpy(tiles.pack_slab(np.where(np.isnan(mine[:, :3]), 0, mine[:, :3]).reshape(H, W, 3).astype(np.float32), rank, world))
+allh = torch.empty(world * slab.numel(), dtype=torch.float32)
+dist.all_gather_into_tensor(allh, slab)
+assert np.array_equal(tiles.unpermute(allh.numpy(), W, H, world, 3), hist)
+dist.barrier()
+dist.destroy_process_group()
+print("rank", rank, "ok")
+'''
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_halo_exchange_and_history_gather_over_gloo(tmp_path, world):
+    """The tile-resident form's two exchanges between `world` processes (gloo here, RCCL on the GPUs): every rank ends up with the {hdr, sky}
+    ring its TAA window needs, and the gathered history slabs reassemble the frame."""
+    script = tmp_path / "halo_worker.py"
+    script.write_text(_HALO_WORKER)
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1")
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={world}", "--master-addr", "127.0.0.1",
+                        "--master-port", str(29571 + world), str(script), str(ROOT)], capture_output=True, text=True, timeout=300, env=env)
+    assert r.returncode == 0, r.stdout + r.stderr
+    assert r.stdout.count("ok") == world
+
+
 @pytest.mark.parametrize("w,h,step", [(37, 23, 2), (64, 48, 2), (80, 90, 2), (9, 7, 2), (33, 40, 8), (5, 5, 2), (1, 13, 2)])
 def test_inplace_atrous_schedule_respects_scan_order(product_lib, w, h, step):
     """Levels of the in-place A-trous iteration (RaytraceRenderer.cs:648-650,718): for every stencil pair the

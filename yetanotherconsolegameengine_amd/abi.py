@@ -128,7 +128,7 @@ class Config(C.Structure):
         ("count_work", C.c_int32),
         ("slab_albedo", C.c_int32),
         ("n_devices", C.c_int32), ("devices", C.c_int32 * YCGE_MAX_DEVICES),
-        ("atrous_inplace_exact", C.c_int32),
+        ("atrous_inplace_exact", C.c_int32), ("tile_ring", C.c_int32),
     ]
 
 
@@ -165,6 +165,7 @@ def default_config() -> Config:
     c.capture_debug, c.count_work = 0, 0
     c.slab_albedo, c.n_devices = 1, 0
     c.atrous_inplace_exact = 1
+    c.tile_ring = 0
     return c
 
 
@@ -194,6 +195,11 @@ _PROTOTYPES = {
     "ycge_tile_slab_bytes": (C.c_int, [C.c_void_p, C.POINTER(C.c_size_t)]),
     "ycge_trace_tiles": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.POINTER(FrameStats)]),
     "ycge_resolve_gathered": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.POINTER(C.c_float), C.POINTER(FrameStats)]),
+    "ycge_halo_counts": (C.c_int, [C.c_void_p, C.POINTER(C.c_int64), C.POINTER(C.c_int64)]),
+    "ycge_history_slab_bytes": (C.c_int, [C.c_void_p, C.POINTER(C.c_size_t)]),
+    "ycge_trace_tiles_resident": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.POINTER(FrameStats)]),
+    "ycge_resolve_tiles_resident": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.POINTER(FrameStats)]),
+    "ycge_unpack_history": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p]),
     "ycge_read_buffer": (C.c_int, [C.c_void_p, C.c_int32, C.c_void_p, C.c_size_t]),
     "ycge_set_frame_counter": (C.c_int, [C.c_void_p, C.c_int64]),
     "ycge_read_timed_steps": (C.c_int, [C.c_void_p, C.POINTER(C.c_uint64)]),

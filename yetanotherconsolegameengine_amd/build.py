@@ -19,7 +19,8 @@ CSRC = PKG / "csrc"
 LIB_DIR = PKG / "lib"
 LIB = LIB_DIR / "libycge_hip.so"
 SOURCES = ["ycge_host.cpp", "ycge_accel.cpp", "ycge_kernels.hip", "ycge_post.hip", "ycge_bvh_build.hip"]
-HEADERS = ["ycge_device.h", "ycge_accel.h", "ycge_math.h", "ycge_rt.hip.h", "ycge_coop.hip.h", "ycge_anyhit.hip.h", "ycge_keysort.h"]
+HEADERS = ["ycge_device.h", "ycge_accel.h", "ycge_math.h", "ycge_rt.hip.h", "ycge_coop.hip.h", "ycge_anyhit.hip.h", "ycge_keysort.h",
+           "experiments/ycge_refill.hip.h", "experiments/ycge_atrous_persist_groups.hip.h"]
 ARCH = "gfx950"
 
 FLAGS = [
@@ -78,6 +79,9 @@ VARIANTS = {
     # the work list of the order-free occlusion queries cut to 112 entries (HIGH = 32): wide rounds are cut back and one-item dives happen
     # on ordinary scenes, so the GPU tests see every mode of the list (csrc/ycge_anyhit.hip.h)
     "bfs112": ["-DYCGE_BFS_LIST=112u"],
+    # the measured-and-rejected kernel forms of csrc/experiments/ (k_trace_refill, the group hand-over A-trous): out of the product build,
+    # kept bit-exact by their parity tests through this one
+    "experiments": ["-DYCGE_EXPERIMENTS=1"],
 }
 
 

@@ -46,9 +46,8 @@ static __shared__ __attribute__((aligned(16))) uint32_t g_coop_slots[4 * YCGE_CO
 __device__ __forceinline__ void coop_fetch(const uint8_t *base, uint32_t byte_offset, unsigned long long leaf_mask, f32x4 &a, f32x4 &b, f32x4 &c,
                                            f32x4 &e, f32x2 &f)
 {
+    // (c, e, f of a lane outside leaf_mask keep whatever the registers held: every use of them is masked by the lane's leaf_lane flag)
     unsigned long long saved;
-    c = e = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
-    f = f32x2{0.0f, 0.0f};
     asm volatile("global_load_dwordx4 %0, %6, %7\n\t"
                  "global_load_dwordx4 %1, %6, %7 offset:16\n\t"
                  "s_and_saveexec_b64 %5, %8\n\t"
@@ -57,7 +56,7 @@ __device__ __forceinline__ void coop_fetch(const uint8_t *base, uint32_t byte_of
                  "global_load_dwordx2 %4, %6, %7 offset:64\n\t"
                  "s_mov_b64 exec, %5\n\t"
                  "s_waitcnt vmcnt(0)"
-                 : "=&v"(a), "=&v"(b), "+v"(c), "+v"(e), "+v"(f), "=&s"(saved)
+                 : "=&v"(a), "=&v"(b), "=&v"(c), "=&v"(e), "=&v"(f), "=&s"(saved)
                  : "v"(byte_offset), "s"(base), "s"(leaf_mask)
                  : "memory", "scc");
 }
@@ -97,6 +96,15 @@ __device__ __forceinline__ void coop_walk(const SceneDev &S, uint32_t &cur, int 
     uint32_t c_steps = 0u;
     const bool sx = ix < 0.0f, sy = iy < 0.0f, sz = iz < 0.0f;
     const uint32_t sh = g * YCGE_COOP_GROUP;
+    // The near-first descent through the treelet as mask logic: the wavefront-wide 64-bit masks (hit, nearer, internal) live in scalar
+    // registers and serve all four groups at once; a lane looks at ITS group through three constants - the slots above it on its path
+    // (parent, grandparent), the slots below it in heap order, its group's 14 slots - in the half of the mask its group sits in.
+    const uint32_t sh32 = sh & 31u;                                     // the group's place in its 32-bit half
+    const bool hi_half = lane >= 32u;
+    const uint32_t p2 = gl >= 2u ? (gl - 2u) >> 1 : 0u, p1 = gl >= 6u ? (p2 - 2u) >> 1 : 0u;
+    const uint32_t anc32 = (gl >= 2u && gl < (uint32_t)YCGE_TL_SLOTS ? (1u << (sh32 + p2)) : 0u) | (gl >= 6u && gl < (uint32_t)YCGE_TL_SLOTS ? (1u << (sh32 + p1)) : 0u);
+    const uint32_t grp32 = YCGE_COOP_MASK << sh32;
+    const uint32_t below32 = ((1u << gl) - 1u) << sh32;
     // The entry a pop will take is asked for as soon as it is known (after the pushes of a node step, after a pop) and looked at
     // when the walk gets there: the LDS round trip is off the chain.  (LDS operations of a wavefront execute in order: a read
     // issued after the far children's writes sees them.)
@@ -104,7 +112,10 @@ __device__ __forceinline__ void coop_walk(const SceneDev &S, uint32_t &cur, int 
 #if defined(YCGE_DBG_COOPSTAT)
     const unsigned long long dbg_t0 = __builtin_amdgcn_s_memrealtime();
     uint32_t dbg_iters = 0, dbg_node = 0, dbg_leaf = 0;
-    unsigned long long dbg_fetch = 0, dbg_c0 = __builtin_amdgcn_s_memtime();
+    unsigned long long dbg_fetch = 0, dbg_c0 = __builtin_amdgcn_s_memtime(), dbg_tnode = 0, dbg_tleaf = 0, dbg_tpop = 0, dbg_thead = 0, dbg_mark = dbg_c0;
+#define YCGE_DBG_SECTION(acc) do { const unsigned long long t_ = __builtin_amdgcn_s_memtime(); acc += t_ - dbg_mark; dbg_mark = t_; } while (0)
+#else
+#define YCGE_DBG_SECTION(acc) do { } while (0)
 #endif
 
     for (;;) {
@@ -119,6 +130,7 @@ __device__ __forceinline__ void coop_walk(const SceneDev &S, uint32_t &cur, int 
         const uint32_t off = node_lane ? S.tl_offset + unit * YCGE_TL_BYTES_PER_UNIT + gl * 32u : leaf_lane ? (unit + 3u * gl) * 32u : 0u;
         f32x4 a, b, c, e;
         f32x2 f;
+        YCGE_DBG_SECTION(dbg_thead);
 #if defined(YCGE_DBG_COOPSTAT)
         const unsigned long long dbg_f0 = __builtin_amdgcn_s_memtime();
 #endif
@@ -132,6 +144,9 @@ __device__ __forceinline__ void coop_walk(const SceneDev &S, uint32_t &cur, int 
 #endif
 
         // ------------------------------------------------------------------ node step
+#if defined(YCGE_DBG_COOPSTAT)
+        dbg_mark = __builtin_amdgcn_s_memtime();
+#endif
         if (__any(at_node)) {
             // slot: a = (min x, min y, min z, max x), b = (max y, max z, reference, valid) - MeshBVH.BoxHitFast, box_mesh()'s operations
             const float tx_en = ((sx ? a.w : a.x) - ox) * ix, tx_ex = ((sx ? a.x : a.w) - ox) * ix;
@@ -145,37 +160,38 @@ __device__ __forceinline__ void coop_walk(const SceneDev &S, uint32_t &cur, int 
             // reaches it: which of the two is visited next (`near_me`: the only one hit, or of two the nearer - `if (lNear < rNear) left
             // first else right first`, MeshBVH.cs:213-223) and which is stacked (`far_me`).
             const float sib_tn = __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(tn), 0xB1, 0xf, 0xf, true));
-            const bool sib_hit = __builtin_amdgcn_mov_dpp(hit ? 1 : 0, 0xB1, 0xf, 0xf, true) != 0;
-            const bool is_left = (gl & 1u) == 0u;
-            const bool left_first = is_left ? tn < sib_tn : sib_tn < tn;
-            const bool near_me = hit && (!sib_hit || is_left == left_first);
-            const bool far_me = hit && sib_hit && is_left != left_first;
-            const bool internal = YCGE_REF_KIND(ref) == REF_MESH_NODE;
-            // a pair is reached when its parent slot was visited and is an internal node: three levels, one ballot each
-            const uint32_t parent = (gl - 2u) >> 1;
-            const bool vis1 = gl < 2u && near_me;
-            const uint32_t V1 = (uint32_t)(__ballot(vis1 && internal) >> sh);
-            const bool reach2 = gl >= 2u && gl < 6u && ((V1 >> parent) & 1u);
-            const bool vis2 = reach2 && near_me;
-            const uint32_t V2 = (uint32_t)(__ballot(vis2 && internal) >> sh);
-            const bool reach3 = YCGE_COOP_LEVELS == 3 && gl >= 6u && gl < (uint32_t)YCGE_TL_SLOTS && ((V2 >> parent) & 1u);
-            const bool vis3 = reach3 && near_me;
-            const bool reached = gl < 2u || reach2 || reach3;
+            const unsigned long long EVEN = 0x5555555555555555ull;            // left slots (a group starts on a multiple of 16)
+            const unsigned long long H = __ballot(hit);
+            const unsigned long long SH = ((H & EVEN) << 1) | ((H >> 1) & EVEN);          // the sibling's hit flag
+            // `if (lNear < rNear) left first else right first` (MeshBVH.cs:213-223), seen from either slot of the pair
+            const unsigned long long LF = (__ballot(tn < sib_tn) & EVEN) | (__ballot(sib_tn < tn) & ~EVEN);
+            const unsigned long long MINE = ~(LF ^ EVEN);                     // this slot is the one the pair's order puts first
+            const unsigned long long N = H & (~SH | MINE);                    // visited next once the walk reaches its pair: the only one hit, or of two the nearer
+            const unsigned long long F = H & SH & ~MINE;                      // ... stacked then
+            const unsigned long long I = __ballot(YCGE_REF_KIND(ref) == REF_MESH_NODE);
+            const unsigned long long NI = N & I;
+            // a pair is reached when every slot above it on its path was visited and is an internal node
+            const uint32_t ni32 = hi_half ? (uint32_t)(NI >> 32) : (uint32_t)NI;
+            const unsigned long long R = __ballot((ni32 & anc32) == anc32);
             // the far children, stacked by their own lanes: heap order is level order and a level stacks at most one, so a lane's
             // place is the number of stacking slots below it - the reference's push order
-            const uint32_t PUSH = (uint32_t)(__ballot(at_node && reached && far_me) >> sh) & YCGE_COOP_MASK;
+            const unsigned long long PUSHM = F & R;
             // the walk goes on at the one visited slot that is a leaf or sits on the last level; none: both children missed somewhere -> the stack
-            const bool last_level = YCGE_COOP_LEVELS == 3 ? vis3 : vis2;
-            const uint32_t EX = (uint32_t)(__ballot(at_node && ((vis1 || vis2) && !internal || last_level)) >> sh) & YCGE_COOP_MASK;
+            const unsigned long long L3 = YCGE_COOP_LEVELS == 3 ? 0x3fc03fc03fc03fc0ull : 0x3c3c3c3c3c3c3c3cull;       // the slots of the last level
+            const unsigned long long V = N & R;
+            const unsigned long long EXM = (V & ~I) | (V & L3);
+            const uint32_t push32 = (hi_half ? (uint32_t)(PUSHM >> 32) : (uint32_t)PUSHM) & grp32;
+            const uint32_t ex32 = (hi_half ? (uint32_t)(EXM >> 32) : (uint32_t)EXM) & grp32;
             if (at_node) {
-                if (reached && far_me) st.write_at(owner, c_sp + (int)__builtin_popcount(PUSH & ((1u << gl) - 1u)), ref, tn);
-                c_sp += (int)__builtin_popcount(PUSH);
+                if ((push32 >> (sh32 + gl)) & 1u) st.write_at(owner, c_sp + (int)__builtin_popcount(push32 & below32), ref, tn);
+                c_sp += (int)__builtin_popcount(push32);
             }
-            if (__any(PUSH != 0u)) top = st.read_early(owner, c_sp - 1);
-            const uint32_t next = (uint32_t)__builtin_amdgcn_ds_bpermute((int)((sh + (EX ? (uint32_t)__builtin_ctz(EX) : 0u)) << 2), (int)ref);
-            if (at_node) c_cur = EX ? next : YCGE_REF_NONE_VALUE;
+            if (__any(push32 != 0u)) top = st.read_early(owner, c_sp - 1);
+            const uint32_t next = (uint32_t)__builtin_amdgcn_ds_bpermute((int)(((lane & 32u) + (ex32 ? (uint32_t)__builtin_ctz(ex32) : 0u)) << 2), (int)ref);
+            if (at_node) c_cur = ex32 ? next : YCGE_REF_NONE_VALUE;
         }
 
+        YCGE_DBG_SECTION(dbg_tnode);
         // ------------------------------------------------------------------ leaf step
         if (__any(at_leaf)) {
             // TriHit for the lane's two triangles, every operation as in tri_pair_hit; the closest side of the range test against the
@@ -220,9 +236,12 @@ __device__ __forceinline__ void coop_walk(const SceneDev &S, uint32_t &cur, int 
                 const uint32_t cm = (uint32_t)(CM >> sh) & 0xffu;
                 const uint32_t pl = cm ? (uint32_t)__builtin_ctz(cm) : gl;           // groups without a candidate read themselves
                 if (cm && gl == pl) {
-                    // (TriHit's one division per accepted triangle, MeshBVH.cs:299: evaluated here, for the rare candidate only)
-                    if (cand0 && !(t_num_s.x > c_closest * det_abs.x)) { c_closest = t_num.x * (1.0f / det.x); c_hit_sub = first; }
-                    if (cand1 && !(t_num_s.y > c_closest * det_abs.y)) { c_closest = t_num.y * (1.0f / det.y); c_hit_sub = first + 1u; }
+                    // (TriHit's one division per accepted triangle, MeshBVH.cs:299: evaluated HERE, for the rare candidate only - the empty asm
+                    // keeps the compiler from hoisting the two IEEE divisions, 22 dependent instructions, in front of every leaf step)
+                    float d0 = det.x, d1 = det.y;
+                    asm volatile("" : "+v"(d0), "+v"(d1));
+                    if (cand0 && !(t_num_s.x > c_closest * det_abs.x)) { c_closest = t_num.x * (1.0f / d0); c_hit_sub = first; }
+                    if (cand1 && !(t_num_s.y > c_closest * det_abs.y)) { c_closest = t_num.y * (1.0f / d1); c_hit_sub = first + 1u; }
                     cand0 = cand1 = false;
                 }
                 const int src = (int)((sh + pl) << 2);
@@ -235,6 +254,7 @@ __device__ __forceinline__ void coop_walk(const SceneDev &S, uint32_t &cur, int 
             }
         }
 
+        YCGE_DBG_SECTION(dbg_tleaf);
         // ------------------------------------------------------------------ back to the stack (the reference's re-test on pop: closest >= tNear)
         const bool popping = g_act && c_cur == YCGE_REF_NONE_VALUE;
         if (popping) {
@@ -253,12 +273,15 @@ __device__ __forceinline__ void coop_walk(const SceneDev &S, uint32_t &cur, int 
             }
         }
         if (__any(popping)) top = st.read_early(owner, c_sp - 1);       // (a step without push or pop left the top where it was: already asked for)
+        YCGE_DBG_SECTION(dbg_tpop);
     }
 #if defined(YCGE_DBG_COOPSTAT)
     if (lane == 0u && S.dbg_counters) {       // [16 + 8 i]: invocations, loop iterations, group node steps, group leaf steps, 100 MHz ticks, rays
         unsigned long long *dc = S.dbg_counters + 16 + (size_t)((blockIdx.x * 2654435761u) >> 24) * 8;
         atomicAdd(dc + 0, 1ull); atomicAdd(dc + 1, (unsigned long long)dbg_iters); atomicAdd(dc + 2, (unsigned long long)dbg_node);
         atomicAdd(dc + 3, (unsigned long long)dbg_leaf); atomicAdd(dc + 4, __builtin_amdgcn_s_memrealtime() - dbg_t0); atomicAdd(dc + 5, (unsigned long long)n_live); atomicAdd(dc + 6, dbg_fetch); atomicAdd(dc + 7, __builtin_amdgcn_s_memtime() - dbg_c0);
+        unsigned long long *d2 = dc + 8 * 256;      // second bank: shader clocks by section - head (decode, addresses), node step, leaf step, stack
+        atomicAdd(d2 + 0, dbg_thead); atomicAdd(d2 + 1, dbg_tnode); atomicAdd(d2 + 2, dbg_tleaf); atomicAdd(d2 + 3, dbg_tpop);
     }
 #endif
     __builtin_amdgcn_wave_barrier();

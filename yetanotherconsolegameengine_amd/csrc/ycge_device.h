@@ -18,6 +18,10 @@
 #pragma once
 #include <stdint.h>
 
+#ifndef YCGE_EXPERIMENTS
+#define YCGE_EXPERIMENTS 0          // 1: the measured-and-rejected kernel forms of csrc/experiments/ are compiled in (lib/var_experiments.so; their parity tests load that build)
+#endif
+
 namespace ycge {
 
 // ---- child / stack reference encoding (uint32) ---------------------------

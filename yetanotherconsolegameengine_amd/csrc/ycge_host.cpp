@@ -31,7 +31,12 @@ int ycge_launch_trace(const ycge::SceneDev *S, const ycge::FrameParams *P, const
 int ycge_launch_wavefront(const ycge::SceneDev *S, const ycge::FrameParams *P, const ycge::TraceOut *O, void *const bufs[7], int rounds,
                           int has_grid, int flat, int count, int persistent_waves, hipStream_t stream);
 int ycge_launch_order_blocks(uint32_t *cost, uint32_t n, uint32_t policy, uint32_t split_top, uint32_t fan_class, uint32_t fan_cap, uint32_t next_slot, uint32_t skip_mask, uint32_t *order_ws,
-                             uint32_t *order, hipStream_t stream, int small_groups = 0);
+                             uint32_t *order, hipStream_t stream, int small_groups = 0, uint32_t n_frames = 0);
+int ycge_launch_taa_tiles(const ycge::TaaParams *T, const ycge::FrameParams *P, const float *current, const float *normal, const float *depth, const uint8_t *sky,
+                          float *hist, float *prev_normal, float *prev_depth, uint8_t *prev_sky, hipStream_t stream);
+int ycge_launch_halo(int scatter, float *hdr, uint8_t *sky, const uint32_t *px, uint32_t n, void *records, hipStream_t stream);
+int ycge_launch_pack_history(const ycge::FrameParams *P, const float *hist, float *slab, hipStream_t stream);
+int ycge_launch_unpack_history(const float *all_slabs, size_t slab_floats_per_rank, int hiW, int hiH, int tiles_x, int n_tiles, int world_size, float *hist, hipStream_t stream);
 int ycge_launch_trace_fan(const ycge::SceneDev *S, const ycge::FrameParams *P, const ycge::TraceOut *O, int count, int flat, uint32_t fan_cap,
                           hipStream_t stream);
 int ycge_launch_taa(const ycge::TaaParams *T, const float *current, const float *normal, const float *depth, const uint8_t *sky,
@@ -178,6 +183,11 @@ struct Knobs {
         scene_bvh_host = getenv("YCGE_SCENE_BVH_HOST") != nullptr;
         bvh_waves = geti("YCGE_BVH_WAVES", 16);
         scene_bvh_device_min = geti("YCGE_SCENE_BVH_DEVICE_MIN", YCGE_BVH_DEV_MIN_ITEMS_DEFAULT);
+#if !YCGE_EXPERIMENTS
+        // the kernel forms of csrc/experiments/ (k_trace_refill, the group hand-over A-trous) are not in this build
+        refill_steps = 0;
+        if (post_mode == 4) post_mode = 0;
+#endif
     }
 };
 
@@ -285,6 +295,27 @@ struct ycge_ctx {
     bool in_flight_call = false;                   // trace_frame is called by ycge_render_frame_async
     std::vector<hipEvent_t> flight_ev;             // begin / end of the trace launches of the frames in flight, a ring (ycge_async_trace_times)
     uint64_t flight_frames = 0;                    // queued since the last ycge_async_trace_times
+    // ---- tile-resident form (one process per GPU; ycge_trace_tiles_resident / ycge_resolve_tiles_resident): TAA on this rank's own tiles
+    // with a one-pixel halo of {hdr, sky} exchanged between the ranks, the history never leaves its rank; a ring of K frame sets so that K
+    // tiled traces may be in flight (a rank's launch is its longest chains: its period per frame becomes max(slot time, chain / K))
+    struct ResidentSet {
+        DevBuf<float> hdr, normal, depth;
+        DevBuf<uint8_t> sky;
+        DevBuf<uint64_t> spill;
+        hipEvent_t traced = nullptr, resolved = nullptr;
+        bool traced_used = false, resolved_used = false;
+    };
+    std::vector<ResidentSet *> rsets;
+    static constexpr uint32_t kResCostFrames = 8;  // the resident ring's own cost ring: K - 1 slots are being written, one is cleared, the rest are read
+    DevBuf<uint32_t> res_cost;
+    std::vector<DevBuf<uint32_t> *> res_order, res_ws;        // K + 1 schedule buffers: frame N reads buffer N % (K + 1), built behind the trace of frame N - K
+    std::vector<hipEvent_t> res_order_ev, res_order_read_ev;
+    std::vector<int64_t> res_order_frame;
+    hipEvent_t res_last_traced = nullptr;          // stage-pipeline scenes share their queues between frames: their traces follow each other
+    bool res_last_traced_used = false;
+    std::vector<int64_t> halo_send_counts, halo_recv_counts;          // records (4 floats) per peer rank
+    DevBuf<uint32_t> d_halo_send_px, d_halo_recv_px;
+    bool halo_ready = false;
     DevBuf<float> dbg_rays, dbg_hit_t;
     DevBuf<int32_t> dbg_prim, dbg_sub;
     DevBuf<uint64_t> dbg_rng;
@@ -445,6 +476,59 @@ int alloc_tile_buffers(ycge_ctx *c)
     return YCGE_OK;
 }
 
+// ---- tile-resident form: halo lists.  Rank r needs {hdr, sky} of the one-pixel ring around each of its tiles (TAA's 3x3 window,
+// TemporalBlendWithClamp clampRadius = 1, RaytraceRenderer.cs:218) from the ranks that own those pixels.  Both sides enumerate the ring
+// pixels of the RECEIVER's tiles - tiles ascending; per tile the row above (x0 - 1 .. x0 + 32), the row below, the column left (y0 .. y0 + 7),
+// the column right; pixels outside the image do not exist (TAA clamps its taps to the image) - and keep those the SENDER owns: the k-th such
+// pixel is the k-th record of the (sender -> receiver) segment.  A pixel that borders two tiles of the receiver appears twice.  The same
+// arithmetic in numpy: yetanotherconsolegameengine_amd/tiles.py (halo_lists); the CPU tests hold the two to each other.
+static void halo_ring_of(int tile, int tiles_x, int hiW, int hiH, std::vector<uint32_t> &px)
+{
+    const int x0 = (tile % tiles_x) * YCGE_TILE_W, y0 = (tile / tiles_x) * YCGE_TILE_H;
+    auto add = [&](int x, int y) { if (x >= 0 && y >= 0 && x < hiW && y < hiH) px.push_back((uint32_t)x + (uint32_t)y * (uint32_t)hiW); };
+    for (int x = x0 - 1; x <= x0 + YCGE_TILE_W; x++) add(x, y0 - 1);
+    for (int x = x0 - 1; x <= x0 + YCGE_TILE_W; x++) add(x, y0 + YCGE_TILE_H);
+    for (int y = y0; y < y0 + YCGE_TILE_H; y++) add(x0 - 1, y);
+    for (int y = y0; y < y0 + YCGE_TILE_H; y++) add(x0 + YCGE_TILE_W, y);
+}
+// send_px: pixels this rank gathers, segment by destination rank ascending; recv_px: pixels the received records scatter to, by source rank ascending
+static void halo_layout(int hiW, int hiH, int rank, int world, std::vector<int64_t> &send_counts, std::vector<int64_t> &recv_counts, std::vector<uint32_t> &send_px, std::vector<uint32_t> &recv_px)
+{
+    const int tiles_x = (hiW + YCGE_TILE_W - 1) / YCGE_TILE_W, tiles_y = (hiH + YCGE_TILE_H - 1) / YCGE_TILE_H, n_tiles = tiles_x * tiles_y;
+    auto owner = [&](uint32_t p) { const int x = (int)(p % (uint32_t)hiW), y = (int)(p / (uint32_t)hiW); return ((y / YCGE_TILE_H) * tiles_x + x / YCGE_TILE_W) % world; };
+    send_counts.assign((size_t)world, 0); recv_counts.assign((size_t)world, 0);
+    send_px.clear(); recv_px.clear();
+    std::vector<uint32_t> ring;
+    std::vector<std::vector<uint32_t>> from((size_t)world);
+    for (int t = rank; t < n_tiles; t += world) {          // what I receive: the ring of MY tiles, by owner
+        ring.clear(); halo_ring_of(t, tiles_x, hiW, hiH, ring);
+        for (uint32_t p : ring) { const int q = owner(p); if (q != rank) from[(size_t)q].push_back(p); }
+    }
+    for (int q = 0; q < world; q++) { recv_counts[(size_t)q] = (int64_t)from[(size_t)q].size(); recv_px.insert(recv_px.end(), from[(size_t)q].begin(), from[(size_t)q].end()); }
+    for (int r = 0; r < world; r++) {                      // what I send: the ring of rank r's tiles, the pixels I own
+        if (r == rank) continue;
+        for (int t = r; t < n_tiles; t += world) {
+            ring.clear(); halo_ring_of(t, tiles_x, hiW, hiH, ring);
+            for (uint32_t p : ring) if (owner(p) == rank) { send_px.push_back(p); send_counts[(size_t)r]++; }
+        }
+    }
+}
+static void release_resident(ycge_ctx *c)
+{
+    for (auto *rs : c->rsets) { if (rs->traced) (void)hipEventDestroy(rs->traced); if (rs->resolved) (void)hipEventDestroy(rs->resolved); delete rs; }
+    c->rsets.clear();
+    for (auto *b : c->res_order) delete b;
+    for (auto *b : c->res_ws) delete b;
+    c->res_order.clear(); c->res_ws.clear();
+    for (hipEvent_t ev : c->res_order_ev) if (ev) (void)hipEventDestroy(ev);
+    for (hipEvent_t ev : c->res_order_read_ev) if (ev) (void)hipEventDestroy(ev);
+    c->res_order_ev.clear(); c->res_order_read_ev.clear(); c->res_order_frame.clear();
+    if (c->res_last_traced) { (void)hipEventDestroy(c->res_last_traced); c->res_last_traced = nullptr; }
+    c->res_last_traced_used = false;
+    c->res_cost.release(); c->d_halo_send_px.release(); c->d_halo_recv_px.release();
+    c->halo_send_counts.clear(); c->halo_recv_counts.clear(); c->halo_ready = false;
+}
+
 // floats per slab pixel: hdr, [albedo,] normal, depth, sky
 static size_t slab_floats(const ycge_ctx *c) { return c->cfg.slab_albedo ? (size_t)YCGE_SLAB_FLOATS : (size_t)YCGE_SLAB_FLOATS - 3; }
 
@@ -471,6 +555,7 @@ int set_geometry(ycge_ctx *c, int fbw, int fbh, int ss)
     c->alt2_hdr.release(); c->alt2_albedo.release(); c->alt2_normal.release(); c->alt2_depth.release(); c->alt2_sky.release();
     c->set_read[0] = c->set_read[1] = c->set_read[2] = false; c->out_set = 0; c->async_outstanding = false;
     c->tile_trace_used[0] = c->tile_trace_used[1] = false;
+    release_resident(c);                                        // the ring of the tile-resident form and its halo lists are per size
     for (auto *sc : c->schedules) delete sc;      // level schedules are per size: rebuilt on demand (the destructor frees the device lists)
     c->schedules.clear();
     int rc = alloc_frame_buffers(c);
@@ -606,6 +691,7 @@ int ycge_config_default(ycge_config *cfg)
     cfg->abi_version = YCGE_ABI_VERSION;
     cfg->slab_albedo = 1; cfg->n_devices = 0;
     cfg->atrous_inplace_exact = 1;
+    cfg->tile_ring = 0;
     cfg->fb_width = 80; cfg->fb_height = 45; cfg->super_sample = 1;
     cfg->fov_deg = 45.0f;
     cfg->device = 0; cfg->rank = 0; cfg->world_size = 1;
@@ -774,6 +860,7 @@ void ycge_destroy(ycge_ctx *c)
     for (int k = 0; k < 2; k++) if (c->tile_trace_ev[k]) (void)hipEventDestroy(c->tile_trace_ev[k]);
     for (hipEvent_t ev : {c->flight_taa_ev, c->post_hist_ev, c->post_done_ev, c->post_set_ev[0], c->post_set_ev[1], c->post_set_ev[2]}) if (ev) (void)hipEventDestroy(ev);
     c->stack_spill2.release();
+    release_resident(c);
     for (int k = 0; k < 3; k++) if (c->set_resolved_ev[k]) (void)hipEventDestroy(c->set_resolved_ev[k]);
     for (int k = 0; k < 3; k++) { c->flight_order[k].release(); c->flight_ws[k].release(); if (c->flight_order_ev[k]) (void)hipEventDestroy(c->flight_order_ev[k]); }
     for (hipEvent_t ev : c->flight_ev) (void)hipEventDestroy(ev);
@@ -1681,7 +1768,15 @@ bool frame_is_single_launch(const ycge_ctx *c)
 }
 
 // step 4 (RaytraceRenderer.cs:183-216): ray-gen + trace of this context's tiles for the frame `fs`
-int trace_frame(ycge_ctx *c, float *d_slab, hipStream_t stream, FrameState &fs, bool timed, hipEvent_t launch_begin = nullptr, hipEvent_t launch_end = nullptr /* frames in flight: around the trace launches alone */)
+// where a trace of the tile-resident form writes and which schedule it follows (trace_frame's last argument)
+struct ResidentTarget {
+    ycge_ctx::ResidentSet *set;
+    uint32_t *cost;                 // this frame's slot of the resident cost ring
+    const uint32_t *order, *n_order;        // the schedule built for this frame (null: blocks in index order)
+};
+
+int trace_frame(ycge_ctx *c, float *d_slab, hipStream_t stream, FrameState &fs, bool timed, hipEvent_t launch_begin = nullptr, hipEvent_t launch_end = nullptr /* frames in flight: around the trace launches alone */,
+                const ResidentTarget *rt = nullptr)
 {
     if (!c->have_scene) return c->fail(YCGE_ERR_NO_SCENE, "Scene BVH not built; call ycge_scene_upload first (Scene.cs:73)");
     FrameParams P;
@@ -1716,7 +1811,11 @@ int trace_frame(ycge_ctx *c, float *d_slab, hipStream_t stream, FrameState &fs, 
         if (c->tile_trace_used[par]) HIP_TRY(c, hipStreamWaitEvent(stream, c->tile_trace_ev[par], 0));
         if (c->tile_trace_used[par ^ 1] && (!frame_is_single_launch(c) || c->sd.any_transparent)) HIP_TRY(c, hipStreamWaitEvent(stream, c->tile_trace_ev[par ^ 1], 0));
     }
-    const bool debug = c->cfg.capture_debug && !slab;
+    if (rt) {       // tile-resident form: the frame set of the ring (the albedo plane is not kept: the frame ends with TAA)
+        O.current_hdr = rt->set->hdr.p; O.g_normal = rt->set->normal.p; O.g_depth = rt->set->depth.p; O.sky = rt->set->sky.p;
+        O.g_albedo = c->g_albedo.p;          // (written, never read in this form: one shared plane)
+    }
+    const bool debug = c->cfg.capture_debug && !slab && !rt;
     if (debug) { O.rays = c->dbg_rays.p; O.prim_id = c->dbg_prim.p; O.sub_id = c->dbg_sub.p; O.hit_t = c->dbg_hit_t.p; O.rng_state = c->dbg_rng.p; }
     if (c->knobs.wave_prof_stage >= 0) { if (!c->wave_prof.p) HIP_TRY(c, c->wave_prof.alloc((size_t)c->n_tiles * 16)); O.wave_prof = c->wave_prof.p; O.wave_prof_stage = c->knobs.wave_prof_stage; }
     O.counters = c->counters.p;
@@ -1724,7 +1823,7 @@ int trace_frame(ycge_ctx *c, float *d_slab, hipStream_t stream, FrameState &fs, 
     if (c->cfg.count_work) HIP_TRY(c, hipMemsetAsync(c->counters.p, 0, 6 * sizeof(unsigned long long), stream));
     if (timed) HIP_TRY(c, hipEventRecord(c->ev[0], stream));
     int e;
-    O.stack_spill = c->spill_override ? c->spill_override : (slab && (fs.frame & 1)) ? c->stack_spill2.p : c->stack_spill.p;
+    O.stack_spill = rt ? rt->set->spill.p : c->spill_override ? c->spill_override : (slab && (fs.frame & 1)) ? c->stack_spill2.p : c->stack_spill.p;
     const uint32_t trace_lanes = (uint32_t)(c->n_owned > 0 ? c->n_owned : 1) * 256u * YCGE_SCHEDULE_SLACK;
     O.stack_lanes = trace_lanes + c->fan_cap * 192u;
     O.path_stack = c->path_stack.p;
@@ -1738,6 +1837,18 @@ int trace_frame(ycge_ctx *c, float *d_slab, hipStream_t stream, FrameState &fs, 
         // TraceFull's per-pixel LIFO is only ever touched at a refractive hit: scenes without transparent materials get none (0.5 GB at 1080p)
         if (!c->path_stack.p && c->sd.any_transparent) HIP_TRY(c, c->path_stack.alloc((size_t)3 * 11 * O.stack_lanes));
         O.path_stack = c->path_stack.p;
+        if (rt) {       // the ring's own cost slots and schedule buffers (ycge_trace_tiles_resident queues the schedule builds)
+            O.block_cost = c->knobs.no_lpt ? nullptr : rt->cost;
+            O.block_order = c->knobs.no_lpt ? nullptr : rt->order;
+            O.n_order = rt->n_order;
+            fs.scheduled = O.block_order != nullptr;
+            if (launch_begin) HIP_TRY(c, hipEventRecord(launch_begin, stream));
+            e = ycge_launch_trace(&c->sd, &P, &O, c->cfg.count_work, flat, 0, stream);
+            if (launch_end) HIP_TRY(c, hipEventRecord(launch_end, stream));
+            if (e != 0) return c->fail(YCGE_ERR_DEVICE, "trace launch failed: %s", hipGetErrorString((hipError_t)e));
+            if (timed) HIP_TRY(c, hipEventRecord(c->ev[1], stream));
+            return YCGE_OK;
+        }
         const bool lpt = !c->knobs.no_lpt;
         const uint32_t n_blocks = (uint32_t)c->n_owned * 4u;
         const uint32_t cost_slot = (uint32_t)((uint64_t)fs.frame % YCGE_COST_FRAMES);       // this frame's array of the cost ring
@@ -2642,6 +2753,217 @@ int ycge_resolve_gathered(ycge_ctx *c, const void *d_all_slabs, void *hip_stream
         st->total_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
     }
     return YCGE_OK;
+}
+
+// ---------------------------------------------------------------------------------------------- tile-resident form (include/ycge.h)
+static int ensure_resident(ycge_ctx *c)
+{
+    if (c->parent || !c->peers.empty()) return c->fail(YCGE_ERR_INVALID_ARG, "the tile-resident form is one process per GPU (rank / world_size); this context drives its devices through ycge_render_frame");
+    if (c->cfg.capture_debug) return c->fail(YCGE_ERR_INVALID_ARG, "the tile-resident form keeps no debug captures");
+    HIP_TRY(c, hipSetDevice(c->device));
+    const int K = c->cfg.tile_ring <= 0 ? 2 : c->cfg.tile_ring;
+    if (K < 2 || K > (int)ycge_ctx::kResCostFrames - 1) return c->fail(YCGE_ERR_INVALID_ARG, "config.tile_ring must be 2..%d", (int)ycge_ctx::kResCostFrames - 1);
+    if ((int)c->rsets.size() != K || !c->halo_ready) {
+        HIP_TRY(c, hipDeviceSynchronize());
+        release_resident(c);
+        {
+            std::vector<uint32_t> spx, rpx;
+            halo_layout(c->hiW, c->hiH, c->cfg.rank, c->cfg.world_size, c->halo_send_counts, c->halo_recv_counts, spx, rpx);
+            if (spx.empty()) spx.push_back(0u);
+            if (rpx.empty()) rpx.push_back(0u);
+            HIP_TRY(c, c->d_halo_send_px.upload(spx)); HIP_TRY(c, c->d_halo_recv_px.upload(rpx));
+            c->halo_ready = true;
+        }
+        const size_t n = (size_t)c->hiW * c->hiH;
+        for (int k = 0; k < K; k++) {
+            auto *rs = new ycge_ctx::ResidentSet();
+            c->rsets.push_back(rs);
+            HIP_TRY(c, rs->hdr.alloc(3 * n)); HIP_TRY(c, rs->normal.alloc(3 * n)); HIP_TRY(c, rs->depth.alloc(n)); HIP_TRY(c, rs->sky.alloc(n));
+            HIP_TRY(c, rs->spill.alloc(c->stack_spill.n));
+            HIP_TRY(c, hipEventCreateWithFlags(&rs->traced, hipEventDisableTiming)); HIP_TRY(c, hipEventCreateWithFlags(&rs->resolved, hipEventDisableTiming));
+        }
+        const size_t nb = (size_t)(c->n_owned > 0 ? c->n_owned : 1) * 4;
+        HIP_TRY(c, c->res_cost.alloc(nb * ycge_ctx::kResCostFrames));
+        HIP_TRY(c, hipMemset(c->res_cost.p, 0, nb * ycge_ctx::kResCostFrames * sizeof(uint32_t)));
+        for (int k = 0; k < K + 1; k++) {
+            auto *o = new DevBuf<uint32_t>(); auto *w = new DevBuf<uint32_t>();
+            c->res_order.push_back(o); c->res_ws.push_back(w);
+            HIP_TRY(c, o->alloc(nb * YCGE_SCHEDULE_SLACK)); HIP_TRY(c, w->alloc(96)); HIP_TRY(c, hipMemset(w->p, 0, 96 * sizeof(uint32_t)));
+            hipEvent_t e1 = nullptr, e2 = nullptr;
+            HIP_TRY(c, hipEventCreateWithFlags(&e1, hipEventDisableTiming)); HIP_TRY(c, hipEventCreateWithFlags(&e2, hipEventDisableTiming));
+            c->res_order_ev.push_back(e1); c->res_order_read_ev.push_back(e2);
+            c->res_order_frame.push_back(-1);
+        }
+        HIP_TRY(c, hipEventCreateWithFlags(&c->res_last_traced, hipEventDisableTiming));
+    }
+    return YCGE_OK;
+}
+
+int ycge_halo_counts(ycge_ctx *c, int64_t *send_counts, int64_t *recv_counts)
+{
+    if (!c) return YCGE_ERR_INVALID_ARG;
+    if (!send_counts || !recv_counts) return c->fail(YCGE_ERR_INVALID_ARG, "null count array");
+    { const int jr = join_async(c); if (jr != YCGE_OK) return jr; }
+    const int rc = ensure_resident(c);
+    if (rc != YCGE_OK) return rc;
+    for (int r = 0; r < c->cfg.world_size; r++) { send_counts[r] = c->halo_send_counts[(size_t)r]; recv_counts[r] = c->halo_recv_counts[(size_t)r]; }
+    return YCGE_OK;
+}
+
+int ycge_history_slab_bytes(const ycge_ctx *c, size_t *bytes)
+{
+    if (!c || !bytes) return YCGE_ERR_INVALID_ARG;
+    *bytes = (size_t)c->tiles_per_rank_padded * 256 * 3 * sizeof(float);
+    return YCGE_OK;
+}
+
+// steps 1-4 of TryFlipAndBlit on this rank's tiles into the frame set of the ring, then the halo records the other ranks need
+int ycge_trace_tiles_resident(ycge_ctx *c, void *d_halo_send, void *hip_stream, ycge_frame_stats *st)
+{
+    if (!c) return YCGE_ERR_INVALID_ARG;
+    { const int jr = join_async(c); if (jr != YCGE_OK) return jr; }
+    int rc = ensure_resident(c);
+    if (rc != YCGE_OK) return rc;
+    size_t n_send = 0;
+    for (int64_t v : c->halo_send_counts) n_send += (size_t)v;
+    if (n_send > 0 && !d_halo_send) return c->fail(YCGE_ERR_INVALID_ARG, "null halo send buffer (%zu records of 16 bytes)", n_send);
+    hipStream_t stream = hip_stream ? (hipStream_t)hip_stream : c->stream;
+    c->last_stream = stream;
+    const int K = (int)c->rsets.size();
+    if ((int)c->pending.size() >= K) return c->fail(YCGE_ERR_INVALID_ARG, "%d traced frames wait to be resolved: the ring holds config.tile_ring = %d", (int)c->pending.size(), K);
+    auto t0 = std::chrono::steady_clock::now();
+    FrameState fs;
+    snapshot_frame(c, fs);
+    ycge_ctx::ResidentSet *rs = c->rsets[(size_t)((uint64_t)fs.frame % (uint64_t)K)];
+    if (rs->resolved_used) HIP_TRY(c, hipStreamWaitEvent(stream, rs->resolved, 0));        // TAA of frame N - K has read this set
+    if (rs->traced_used) HIP_TRY(c, hipStreamWaitEvent(stream, rs->traced, 0));            // (its spill area: the trace of frame N - K, on whatever stream)
+    const bool single = frame_is_single_launch(c);
+    if ((!single || c->sd.any_transparent) && c->res_last_traced_used) HIP_TRY(c, hipStreamWaitEvent(stream, c->res_last_traced, 0));      // shared stage queues / refraction stacks: one trace at a time
+    const uint32_t n_blocks = (uint32_t)c->n_owned * 4u, RC = ycge_ctx::kResCostFrames;
+    const uint32_t cost_slot = (uint32_t)((uint64_t)fs.frame % RC);
+    ResidentTarget rt;
+    rt.set = rs;
+    rt.cost = c->res_cost.p + (size_t)cost_slot * n_blocks;
+    rt.order = nullptr; rt.n_order = nullptr;
+    const int NB = K + 1, ob = (int)((uint64_t)fs.frame % (uint64_t)NB);
+    if (single && !c->knobs.no_lpt && c->res_order_frame[(size_t)ob] == fs.frame) {
+        rt.order = c->res_order[(size_t)ob]->p; rt.n_order = c->res_ws[(size_t)ob]->p + 16;
+        HIP_TRY(c, hipStreamWaitEvent(stream, c->res_order_ev[(size_t)ob], 0));
+    }
+    if (single && !c->knobs.no_lpt && c->res_order_frame[(size_t)ob] != fs.frame)
+        // nobody has cleared this frame's cost slot (the first K frames, a frame after a gap): the kernel's atomicMax needs zeros
+        HIP_TRY(c, hipMemsetAsync(rt.cost, 0, (size_t)n_blocks * sizeof(uint32_t), stream));
+    rc = trace_frame(c, nullptr, stream, fs, st != nullptr, nullptr, nullptr, &rt);
+    if (rc != YCGE_OK) return rc;
+    if (rt.order) HIP_TRY(c, hipEventRecord(c->res_order_read_ev[(size_t)ob], stream));
+    int e = ycge_launch_halo(0, rs->hdr.p, rs->sky.p, c->d_halo_send_px.p, (uint32_t)n_send, d_halo_send, stream);
+    if (e != 0) return c->fail(YCGE_ERR_DEVICE, "k_gather_halo launch failed: %s", hipGetErrorString((hipError_t)e));
+    HIP_TRY(c, hipEventRecord(rs->traced, stream)); rs->traced_used = true;
+    HIP_TRY(c, hipEventRecord(c->res_last_traced, stream)); c->res_last_traced_used = true;
+    if (single && !c->knobs.no_lpt) {
+        // the schedule of frame N + K, behind this trace on the side stream: from the cost slots of the frames up to this one - the K - 1
+        // slots the traces of frames N + 1 .. N + K - 1 may be writing are left out, frame N + K's is cleared - into the buffer frame
+        // N + K will read, once the last trace that read that buffer (frame N - 1) is done
+        uint32_t policy, split_top;
+        schedule_policy(c, policy, split_top);
+        uint32_t skip = 0;
+        for (int a = 1; a < K; a++) skip |= 1u << ((cost_slot + (uint32_t)a) % RC);
+        const int64_t target_frame = fs.frame + K;
+        const int tb = (int)((uint64_t)target_frame % (uint64_t)NB);
+        HIP_TRY(c, hipStreamWaitEvent(c->fan_stream, rs->traced, 0));
+        if (c->res_order_frame[(size_t)tb] >= 0) HIP_TRY(c, hipStreamWaitEvent(c->fan_stream, c->res_order_read_ev[(size_t)tb], 0));
+        e = ycge_launch_order_blocks(c->res_cost.p, n_blocks, policy, split_top, 0u, 0u, (uint32_t)((uint64_t)target_frame % RC), skip, c->res_ws[(size_t)tb]->p, c->res_order[(size_t)tb]->p, c->fan_stream, 0, RC);
+        if (e != 0) return c->fail(YCGE_ERR_DEVICE, "schedule launch failed: %s", hipGetErrorString((hipError_t)e));
+        HIP_TRY(c, hipEventRecord(c->res_order_ev[(size_t)tb], c->fan_stream));
+        c->res_order_frame[(size_t)tb] = target_frame;
+    }
+    c->pending.push_back(fs);
+    if (st) {
+        HIP_TRY(c, hipStreamSynchronize(stream));
+        const double wall = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+        return fill_stats(c, st, fs, false, false, wall);
+    }
+    return YCGE_OK;
+}
+
+// the records of this frame's halo into its set, TAA on this rank's own tiles (steps 5 and 9), the resolved history of those tiles as a slab
+int ycge_resolve_tiles_resident(ycge_ctx *c, const void *d_halo_recv, void *d_history_slab, void *hip_stream, ycge_frame_stats *st)
+{
+    if (!c) return YCGE_ERR_INVALID_ARG;
+    if (c->pending.empty() || c->rsets.empty()) return c->fail(YCGE_ERR_INVALID_ARG, "no traced frame to resolve: every ycge_resolve_tiles_resident follows its own ycge_trace_tiles_resident");
+    HIP_TRY(c, hipSetDevice(c->device));
+    size_t n_recv = 0;
+    for (int64_t v : c->halo_recv_counts) n_recv += (size_t)v;
+    if (n_recv > 0 && !d_halo_recv) return c->fail(YCGE_ERR_INVALID_ARG, "null halo receive buffer (%zu records of 16 bytes)", n_recv);
+    hipStream_t stream = hip_stream ? (hipStream_t)hip_stream : c->stream;
+    c->last_stream = stream;
+    auto t0 = std::chrono::steady_clock::now();
+    FrameState fs = c->pending.front();
+    c->pending.pop_front();
+    const int K = (int)c->rsets.size();
+    ycge_ctx::ResidentSet *rs = c->rsets[(size_t)((uint64_t)fs.frame % (uint64_t)K)];
+    HIP_TRY(c, hipStreamWaitEvent(stream, rs->traced, 0));         // (the caller's exchange already follows the trace; this holds whatever streams it uses)
+    if (st) HIP_TRY(c, hipEventRecord(c->ev[1], stream));
+    int e = ycge_launch_halo(1, rs->hdr.p, rs->sky.p, c->d_halo_recv_px.p, (uint32_t)n_recv, const_cast<void *>(d_halo_recv), stream);
+    if (e != 0) return c->fail(YCGE_ERR_DEVICE, "k_scatter_halo launch failed: %s", hipGetErrorString((hipError_t)e));
+    fs.reset = should_reset_history(c, fs.pos, fs.yaw, fs.pitch) || c->has_dynamic_textures;
+    TaaParams T;
+    T.w = c->hiW; T.h = c->hiH;
+    T.alpha = cs_max(0.0f, cs_min(1.0f, c->cfg.taa_alpha));
+    T.radius = c->cfg.taa_clamp_radius > 0 ? c->cfg.taa_clamp_radius : 0;
+    T.pad_lum = c->cfg.taa_luminance_pad;
+    if (T.radius > 1) return c->fail(YCGE_ERR_UNSUPPORTED, "the tile-resident form exchanges a one-pixel halo: taa_clamp_radius %d needs ycge_resolve_gathered", T.radius);
+    const bool did_reset = !c->taa_valid || fs.reset;
+    T.reset = did_reset ? 1 : 0;
+    FrameParams P;
+    fill_frame_params(c, P, fs.frame, fs.pos, fs.yaw, fs.pitch, fs.fov);
+    e = ycge_launch_taa_tiles(&T, &P, rs->hdr.p, rs->normal.p, rs->depth.p, rs->sky.p, c->taa_hist.p, c->prev_normal.p, c->prev_depth.p, c->prev_sky.p, stream);
+    if (e != 0) return c->fail(YCGE_ERR_DEVICE, "k_taa_tiles launch failed: %s", hipGetErrorString((hipError_t)e));
+    if (st) HIP_TRY(c, hipEventRecord(c->ev[2], stream));
+    c->taa_valid = true;
+    c->last_cam[0] = fs.pos[0]; c->last_cam[1] = fs.pos[1]; c->last_cam[2] = fs.pos[2]; c->last_yaw = fs.yaw; c->last_pitch = fs.pitch;
+    HIP_TRY(c, hipEventRecord(rs->resolved, stream)); rs->resolved_used = true;
+    if (d_history_slab) {
+        e = ycge_launch_pack_history(&P, c->taa_hist.p, (float *)d_history_slab, stream);
+        if (e != 0) return c->fail(YCGE_ERR_DEVICE, "k_pack_history launch failed: %s", hipGetErrorString((hipError_t)e));
+    }
+    if (st) {
+        HIP_TRY(c, hipStreamSynchronize(stream));
+        std::memset(st, 0, sizeof *st);
+        st->frame = fs.frame; st->history_reset = did_reset ? 1 : 0;
+        float ms = 0.0f;
+        HIP_TRY(c, hipEventElapsedTime(&ms, c->ev[1], c->ev[2]));
+        st->taa_ms = ms;
+        st->exposure = 1.0f;
+        st->n_devices_traced = 1; st->device_tiles[0] = c->n_owned;
+        st->total_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+    }
+    return YCGE_OK;
+}
+
+// the consumer's half: world_size history slabs (rank-major, as an all-gather or a gather leaves them) into the full-frame history
+int ycge_unpack_history(ycge_ctx *c, const void *d_all_history_slabs, void *hip_stream)
+{
+    if (!c) return YCGE_ERR_INVALID_ARG;
+    if (!d_all_history_slabs) return c->fail(YCGE_ERR_INVALID_ARG, "null gathered history slabs");
+    HIP_TRY(c, hipSetDevice(c->device));
+    hipStream_t stream = hip_stream ? (hipStream_t)hip_stream : c->stream;
+    c->last_stream = stream;
+    const int e = ycge_launch_unpack_history((const float *)d_all_history_slabs, (size_t)c->tiles_per_rank_padded * 256 * 3, c->hiW, c->hiH, c->tiles_x, c->n_tiles, c->cfg.world_size, c->taa_hist.p, stream);
+    if (e != 0) return c->fail(YCGE_ERR_DEVICE, "k_unpack_history launch failed: %s", hipGetErrorString((hipError_t)e));
+    return YCGE_OK;
+}
+
+// the halo lists of (hiW, hiH, rank, world) as pure host code (CPU tests hold them to tiles.py): counts per peer, then the pixel lists
+int ycge_host_halo_layout(int32_t hiW, int32_t hiH, int32_t rank, int32_t world, int64_t *send_counts, int64_t *recv_counts, uint32_t *send_px, uint32_t *recv_px, int64_t capacity)
+{
+    if (hiW <= 0 || hiH <= 0 || world < 1 || rank < 0 || rank >= world || !send_counts || !recv_counts) return YCGE_ERR_INVALID_ARG;
+    std::vector<int64_t> sc, rcv; std::vector<uint32_t> spx, rpx;
+    halo_layout(hiW, hiH, rank, world, sc, rcv, spx, rpx);
+    for (int r = 0; r < world; r++) { send_counts[r] = sc[(size_t)r]; recv_counts[r] = rcv[(size_t)r]; }
+    if (send_px && (int64_t)spx.size() <= capacity) std::memcpy(send_px, spx.data(), spx.size() * 4);
+    if (recv_px && (int64_t)rpx.size() <= capacity) std::memcpy(recv_px, rpx.data(), rpx.size() * 4);
+    return ((int64_t)spx.size() <= capacity && (int64_t)rpx.size() <= capacity) || (!send_px && !recv_px) ? YCGE_OK : YCGE_ERR_INVALID_ARG;
 }
 
 int ycge_read_buffer(ycge_ctx *c, int32_t which, void *dst, size_t bytes)

@@ -1035,6 +1035,7 @@ __device__ __forceinline__ void trace_block(const SceneDev &S, const FrameParams
        wave_iters += wave_umax(w.steps - steps_before);
        __syncthreads();
    } else {
+#if YCGE_EXPERIMENTS
        if (!__any(phase != PH_DONE)) break;
        // ---- stage B: the posted queries as one list, lanes refill from it
        uint32_t n = 0;
@@ -1072,6 +1073,9 @@ __device__ __forceinline__ void trace_block(const SceneDev &S, const FrameParams
                has = false;
            }
        }
+#else
+       break;          // (MODE 2, k_trace_refill, exists in experiment builds only)
+#endif
    }
    parked = false;
    if (bounce_in_flight) {      // slot 0 is needed for the queries that go one at a time: keep the bounce answer in registers
@@ -1125,6 +1129,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 8))) void
     } else if (blockIdx.x >= (uint32_t)P.n_owned_tiles * 4u) return;
     trace_block<false, true, 0, false>(S, P, O, ent, idx, nullptr, 0);
 }
+#if YCGE_EXPERIMENTS
 template <bool COUNT>
 __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(COUNT ? 2 : 3, 8))) void k_trace_refill(const SceneDev S, const FrameParams P, const TraceOut O, const int refill_steps)
 {
@@ -1136,6 +1141,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(COUNT ? 2 : 
     } else if (blockIdx.x >= (uint32_t)P.n_owned_tiles * 4u) return;
     trace_block<COUNT, true, 2>(S, P, O, ent, idx, &F, refill_steps);
 }
+#endif
 template <bool COUNT, bool FLAT>
 __global__ __launch_bounds__(192) __attribute__((amdgpu_waves_per_eu((FLAT && !COUNT) ? YCGE_FAN_WAVES : 2, 8))) void k_trace_fan(const SceneDev S, const FrameParams P, const TraceOut O)
 {
@@ -1178,20 +1184,24 @@ __device__ __forceinline__ uint32_t class_lg_parts(uint32_t policy, int cls) { r
 // given frame depends on that frame's random bounce directions - the 40 longest-running blocks of a frame are found among the
 // top 200 of the previous frame's costs 58 % of the time, among the top 200 of max-over-four-frames 90 % (profiles/cost_persistence.py).
 // (skip_mask: bit f set = ring slot f is being written by a trace that runs beside this schedule - frames in flight, tiled frames - and is left out)
-__device__ __forceinline__ uint32_t smoothed_cost(const uint32_t *cost, uint32_t n, uint32_t i, uint32_t skip_mask)
+// (n_frames: slots of the ring - YCGE_COST_FRAMES everywhere but on the K-deep ring of the tile-resident form, which keeps 8)
+__device__ __forceinline__ uint32_t smoothed_cost(const uint32_t *cost, uint32_t n, uint32_t i, uint32_t skip_mask, uint32_t n_frames)
 {
     uint32_t m = 0;
+    if (n_frames == YCGE_COST_FRAMES) {
 #pragma unroll
-    for (int f = 0; f < YCGE_COST_FRAMES; f++) { const uint32_t v = ((skip_mask >> f) & 1u) ? 0u : cost[(size_t)f * n + i]; m = v > m ? v : m; }
+        for (int f = 0; f < YCGE_COST_FRAMES; f++) { const uint32_t v = ((skip_mask >> f) & 1u) ? 0u : cost[(size_t)f * n + i]; m = v > m ? v : m; }
+    } else
+        for (uint32_t f = 0; f < n_frames; f++) { const uint32_t v = ((skip_mask >> f) & 1u) ? 0u : cost[(size_t)f * n + i]; m = v > m ? v : m; }
     return m;
 }
-__global__ __launch_bounds__(1024) void k_cost_hist(const uint32_t *__restrict__ cost, uint32_t n, uint32_t skip_mask, uint32_t *__restrict__ ws)
+__global__ __launch_bounds__(1024) void k_cost_hist(const uint32_t *__restrict__ cost, uint32_t n, uint32_t skip_mask, uint32_t n_frames, uint32_t *__restrict__ ws)
 {
     __shared__ uint32_t h[YCGE_ORDER_CLASSES];
     if (threadIdx.x < YCGE_ORDER_CLASSES) h[threadIdx.x] = 0;
     __syncthreads();
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < n) { const int cls = order_class(smoothed_cost(cost, n, i, skip_mask)); atomicAdd(&h[cls], 1u); }
+    if (i < n) { const int cls = order_class(smoothed_cost(cost, n, i, skip_mask, n_frames)); atomicAdd(&h[cls], 1u); }
     __syncthreads();
     if (threadIdx.x < YCGE_ORDER_CLASSES && h[threadIdx.x]) atomicAdd(&ws[32 + threadIdx.x], h[threadIdx.x]);
 }
@@ -1216,7 +1226,7 @@ __device__ __forceinline__ ClassLayout class_layout(const uint32_t *ws, int cls,
     return L;
 }
 __global__ __launch_bounds__(1024) void k_cost_scatter(uint32_t *__restrict__ cost, uint32_t n, uint32_t capacity, uint32_t policy, uint32_t split_top,
-                                                       uint32_t fan_class, uint32_t fan_cap, uint32_t next_slot, uint32_t skip_mask, uint32_t *__restrict__ ws, uint32_t *__restrict__ order)
+                                                       uint32_t fan_class, uint32_t fan_cap, uint32_t next_slot, uint32_t skip_mask, uint32_t n_frames, uint32_t *__restrict__ ws, uint32_t *__restrict__ order)
 {
     __shared__ uint32_t h[YCGE_ORDER_CLASSES], rank0[YCGE_ORDER_CLASSES];
     __shared__ ClassLayout lay[YCGE_ORDER_CLASSES];
@@ -1243,7 +1253,7 @@ __global__ __launch_bounds__(1024) void k_cost_scatter(uint32_t *__restrict__ co
     int cls = -1;
     uint32_t local = 0;
     if (i < n) {
-        cls = order_class(smoothed_cost(cost, n, i, skip_mask));
+        cls = order_class(smoothed_cost(cost, n, i, skip_mask, n_frames));
         cost[(size_t)next_slot * n + i] = 0;         // the ring slot the next frame's atomicMax goes to
         local = atomicAdd(&h[cls], 1u);
     }
@@ -1369,6 +1379,63 @@ __global__ __launch_bounds__(256) void k_taa(const TaaParams T, const float *__r
     taa_pixel(T, blockIdx.x * 32 + (threadIdx.x & 31), blockIdx.y * (int)(blockDim.x >> 5) + (threadIdx.x >> 5), current, normal, depth, sky, hist, prev_normal, prev_depth, prev_sky);
 }
 
+// ---------------------------------------------------------------------------------- tile-resident TAA (multi-GPU, one process per GPU)
+// TemporalBlendWithClamp on this rank's OWN tiles only: the same per-pixel code on the same operands as k_taa - the 3x3 neighbourhood of a
+// tile's edge pixels reaches one pixel into tiles of other ranks, whose {hdr, sky} arrived as halo records (k_scatter_halo) - so the
+// history, the guide copies and the reset rule never leave the rank that owns the tile.
+__global__ __launch_bounds__(256) void k_taa_tiles(const TaaParams T, const FrameParams P, const float *__restrict__ current, const float *__restrict__ normal,
+                                                   const float *__restrict__ depth, const uint8_t *__restrict__ sky, float *__restrict__ hist,
+                                                   float *__restrict__ prev_normal, float *__restrict__ prev_depth, uint8_t *__restrict__ prev_sky)
+{
+    int px, py, lx, ly;
+    if (!tile_pixel(P, (int)blockIdx.x, px, py, lx, ly)) return;
+    taa_pixel(T, px, py, current, normal, depth, sky, hist, prev_normal, prev_depth, prev_sky);
+}
+// halo records {hdr rgb, sky} of the listed pixels: out of this rank's frame buffers for the ranks that need them (gather), and the
+// records received from the owners into this rank's frame buffers (scatter).  The lists are layout arithmetic (host: halo_layout; the
+// same arithmetic in tiles.py): both sides enumerate the ring pixels of the receiver's tiles in one fixed order.
+__global__ __launch_bounds__(256) void k_gather_halo(const float *__restrict__ hdr, const uint8_t *__restrict__ sky, const uint32_t *__restrict__ px, uint32_t n, float4 *__restrict__ out)
+{
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const size_t p = px[i];
+    out[i] = make_float4(hdr[3 * p], hdr[3 * p + 1], hdr[3 * p + 2], sky[p] ? 1.0f : 0.0f);
+}
+__global__ __launch_bounds__(256) void k_scatter_halo(const float4 *__restrict__ in, const uint32_t *__restrict__ px, uint32_t n, float *__restrict__ hdr, uint8_t *__restrict__ sky)
+{
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const size_t p = px[i];
+    const float4 v = in[i];
+    hdr[3 * p] = v.x; hdr[3 * p + 1] = v.y; hdr[3 * p + 2] = v.z;
+    sky[p] = v.w != 0.0f ? (uint8_t)1 : (uint8_t)0;
+}
+// the resolved history of this rank's tiles as a slab (3 floats per pixel, tile order as k_pack_slab) - what a consumer of the frame
+// gathers: 12 bytes per pixel instead of the 32-44 of the tile slabs - and back into a full-frame history on whoever shows the frame
+__global__ __launch_bounds__(256) void k_pack_history(const FrameParams P, const float *__restrict__ hist, float *__restrict__ slab)
+{
+    int px, py, lx, ly;
+    const int k = blockIdx.x;
+    if (!tile_pixel(P, k, px, py, lx, ly)) return;
+    const size_t i = (size_t)px + (size_t)py * P.hiW;
+    float *s = slab + ((size_t)k * 256 + (size_t)(ly * YCGE_TILE_W + lx)) * 3;
+    s[0] = hist[3 * i]; s[1] = hist[3 * i + 1]; s[2] = hist[3 * i + 2];
+}
+__global__ __launch_bounds__(256) void k_unpack_history(const float *__restrict__ all_slabs, size_t slab_floats_per_rank, int hiW, int hiH, int tiles_x, int n_tiles, int world_size,
+                                                       float *__restrict__ hist)
+{
+    const int tile_id = blockIdx.x;
+    if (tile_id >= n_tiles) return;
+    const int rank = tile_id % world_size, k = tile_id / world_size;
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int lx = wave * 8 + (lane & 7), ly = lane >> 3;
+    const int px = (tile_id % tiles_x) * YCGE_TILE_W + lx, py = (tile_id / tiles_x) * YCGE_TILE_H + ly;
+    if (px >= hiW || py >= hiH) return;
+    const float *s = all_slabs + (size_t)rank * slab_floats_per_rank + ((size_t)k * 256 + (size_t)(ly * YCGE_TILE_W + lx)) * 3;
+    const size_t i = (size_t)px + (size_t)py * hiW;
+    hist[3 * i] = s[0]; hist[3 * i + 1] = s[1]; hist[3 * i + 2] = s[2];
+}
+
 // ---------------------------------------------------------------------------------- tile slabs (multi-GPU)
 // pack this rank's tiles (tile_id % world == rank) from the full-frame buffers into its slab
 // slab pixel = {hdr rgb, [albedo rgb,] normal xyz, depth, sky}: sf = 11 floats with the albedo plane, 8 without (lean)
@@ -1461,11 +1528,13 @@ int ycge_launch_trace(const ycge::SceneDev *S, const ycge::FrameParams *P, const
     using namespace ycge;
     if (P->n_owned_tiles <= 0) return 0;
     const dim3 grid((unsigned)P->n_owned_tiles * 4u * YCGE_SCHEDULE_SLACK), block(64);   // schedule capacity; idle entries exit at once
+#if YCGE_EXPERIMENTS
     if (flat && refill_steps > 0) {
         if (count) hipLaunchKernelGGL((k_trace_refill<true>), grid, block, 0, stream, *S, *P, *O, refill_steps);
         else hipLaunchKernelGGL((k_trace_refill<false>), grid, block, 0, stream, *S, *P, *O, refill_steps);
         return (int)hipGetLastError();
     }
+#endif
     static const unsigned lds_pad = getenv("YCGE_LDS_PAD") ? (unsigned)atoi(getenv("YCGE_LDS_PAD")) : 0u;   // experiment knob: fewer resident wavefronts
     if (!count && flat && S->tl_offset == 0u) {         // no mesh (or the cooperative walk switched off): the lean instance
         hipLaunchKernelGGL(k_trace_nomesh, grid, block, lds_pad, stream, *S, *P, *O);
@@ -1524,17 +1593,18 @@ int ycge_launch_wavefront(const ycge::SceneDev *S, const ycge::FrameParams *P, c
 
 // builds next frame's k_trace schedule from this frame's per-block step counts.  ws: 18 uint32 (see k_cost_hist)
 int ycge_launch_order_blocks(uint32_t *cost, uint32_t n, uint32_t policy, uint32_t split_top, uint32_t fan_class, uint32_t fan_cap, uint32_t next_slot, uint32_t skip_mask,
-                             uint32_t *ws, uint32_t *order, hipStream_t stream, int small_groups)
+                             uint32_t *ws, uint32_t *order, hipStream_t stream, int small_groups, uint32_t n_frames)
 {
     if (n == 0) return 0;
+    if (n_frames == 0) n_frames = YCGE_COST_FRAMES;
     // small_groups (frames in flight): a 1024-thread workgroup needs a quarter of a CU cleared before it starts and so waited for the
     // last third of the trace running beside it; four wavefronts find room far sooner (one-wavefront groups were no better)
     const unsigned threads = small_groups ? 256u : 1024u;
     hipError_t e = hipMemsetAsync(ws, 0, 96 * sizeof(uint32_t), stream);     // ws[16] / ws[18] (entries, n_fan) are rewritten by k_cost_scatter before anyone reads them
     if (e != hipSuccess) return (int)e;
     const dim3 grid((n + threads - 1u) / threads), block(threads);
-    hipLaunchKernelGGL(ycge::k_cost_hist, grid, block, 0, stream, cost, n, skip_mask, ws);
-    hipLaunchKernelGGL(ycge::k_cost_scatter, grid, block, 0, stream, cost, n, n * YCGE_SCHEDULE_SLACK, policy, split_top, fan_class, fan_cap, next_slot, skip_mask, ws, order);
+    hipLaunchKernelGGL(ycge::k_cost_hist, grid, block, 0, stream, cost, n, skip_mask, n_frames, ws);
+    hipLaunchKernelGGL(ycge::k_cost_scatter, grid, block, 0, stream, cost, n, n * YCGE_SCHEDULE_SLACK, policy, split_top, fan_class, fan_cap, next_slot, skip_mask, n_frames, ws, order);
     return (int)hipGetLastError();
 }
 
@@ -1557,6 +1627,33 @@ int ycge_launch_taa(const ycge::TaaParams *T, const float *current, const float 
     const unsigned rows = small_groups ? 2u : 8u;
     dim3 grid((unsigned)((T->w + 31) / 32), (unsigned)((T->h + (int)rows - 1) / (int)rows)), block(32u * rows);
     hipLaunchKernelGGL(ycge::k_taa, grid, block, 0, stream, *T, current, normal, depth, sky, hist, prev_normal, prev_depth, prev_sky);
+    return (int)hipGetLastError();
+}
+
+int ycge_launch_taa_tiles(const ycge::TaaParams *T, const ycge::FrameParams *P, const float *current, const float *normal, const float *depth, const uint8_t *sky,
+                          float *hist, float *prev_normal, float *prev_depth, uint8_t *prev_sky, hipStream_t stream)
+{
+    if (P->n_owned_tiles <= 0) return 0;
+    hipLaunchKernelGGL(ycge::k_taa_tiles, dim3((unsigned)P->n_owned_tiles), dim3(256), 0, stream, *T, *P, current, normal, depth, sky, hist, prev_normal, prev_depth, prev_sky);
+    return (int)hipGetLastError();
+}
+int ycge_launch_halo(int scatter, float *hdr, uint8_t *sky, const uint32_t *px, uint32_t n, void *records, hipStream_t stream)
+{
+    if (n == 0) return 0;
+    const dim3 grid((n + 255u) / 256u), block(256);
+    if (scatter) hipLaunchKernelGGL(ycge::k_scatter_halo, grid, block, 0, stream, (const float4 *)records, px, n, hdr, sky);
+    else hipLaunchKernelGGL(ycge::k_gather_halo, grid, block, 0, stream, (const float *)hdr, (const uint8_t *)sky, px, n, (float4 *)records);
+    return (int)hipGetLastError();
+}
+int ycge_launch_pack_history(const ycge::FrameParams *P, const float *hist, float *slab, hipStream_t stream)
+{
+    if (P->n_owned_tiles <= 0) return 0;
+    hipLaunchKernelGGL(ycge::k_pack_history, dim3((unsigned)P->n_owned_tiles), dim3(256), 0, stream, *P, hist, slab);
+    return (int)hipGetLastError();
+}
+int ycge_launch_unpack_history(const float *all_slabs, size_t slab_floats_per_rank, int hiW, int hiH, int tiles_x, int n_tiles, int world_size, float *hist, hipStream_t stream)
+{
+    hipLaunchKernelGGL(ycge::k_unpack_history, dim3((unsigned)n_tiles), dim3(256), 0, stream, all_slabs, slab_floats_per_rank, hiW, hiH, tiles_x, n_tiles, world_size, hist);
     return (int)hipGetLastError();
 }
 

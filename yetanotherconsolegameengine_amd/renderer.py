@@ -22,13 +22,14 @@ NODE_DTYPE = np.dtype([("min", "<f4", 3), ("max", "<f4", 3), ("left", "<i4"), ("
 class RaytraceRenderer:
     def __init__(self, scene: Scene | FlatScene, fb_width: int, fb_height: int, fovDeg: float = 45.0, superSample: int = 1, *,
                  cfg: Optional[abi.Config] = None, capture_debug: bool = False, count_work: bool = False, device: int = 0,
-                 rank: int = 0, world_size: int = 1, slab_albedo: bool = True, devices=None, lib=None):
+                 rank: int = 0, world_size: int = 1, slab_albedo: bool = True, devices=None, lib=None, tile_ring: int = 0):
         self.L = lib if lib is not None else abi.load_library()
         c = cfg if cfg is not None else abi.default_config()
         c.fb_width, c.fb_height, c.super_sample = fb_width, fb_height, max(1, superSample)
         c.fov_deg = fovDeg
         c.capture_debug, c.count_work = int(capture_debug), int(count_work)
         c.device, c.rank, c.world_size = device, rank, world_size
+        c.tile_ring = int(tile_ring)              # tile-resident form: frame sets in the ring (0 = 2)
         c.slab_albedo = int(slab_albedo)          # tiled frame: lean 8-float slabs when the denoise stage will not run
         if devices is not None:                   # one process, several GPUs: TryFlipAndBlit drives them all (config.n_devices)
             c.n_devices = len(devices)
@@ -220,6 +221,29 @@ class RaytraceRenderer:
         ptr = sdr.ctypes.data_as(C.POINTER(C.c_float)) if want_sdr else None
         self._check(self.L.ycge_resolve_gathered(self.ctx, C.c_void_p(d_all_slabs_ptr), C.c_void_p(stream_ptr), ptr, st))
         return sdr
+
+    # the tile-resident form (include/ycge.h): TAA on this rank's own tiles, a halo exchange instead of the all-gather of slabs
+    def halo_counts(self):
+        w = self.cfg.world_size
+        s, r = (C.c_int64 * w)(), (C.c_int64 * w)()
+        self._check(self.L.ycge_halo_counts(self.ctx, s, r))
+        return list(s), list(r)
+
+    def history_slab_bytes(self) -> int:
+        n = C.c_size_t()
+        self._check(self.L.ycge_history_slab_bytes(self.ctx, C.byref(n)))
+        return n.value
+
+    def trace_tiles_resident(self, d_halo_send_ptr: int, stream_ptr: int = 0, want_stats: bool = False):
+        st = C.byref(self.stats) if want_stats else None
+        self._check(self.L.ycge_trace_tiles_resident(self.ctx, C.c_void_p(d_halo_send_ptr), C.c_void_p(stream_ptr), st))
+
+    def resolve_tiles_resident(self, d_halo_recv_ptr: int, d_history_slab_ptr: int = 0, stream_ptr: int = 0, want_stats: bool = False):
+        st = C.byref(self.stats) if want_stats else None
+        self._check(self.L.ycge_resolve_tiles_resident(self.ctx, C.c_void_p(d_halo_recv_ptr), C.c_void_p(d_history_slab_ptr), C.c_void_p(stream_ptr), st))
+
+    def unpack_history(self, d_all_history_slabs_ptr: int, stream_ptr: int = 0):
+        self._check(self.L.ycge_unpack_history(self.ctx, C.c_void_p(d_all_history_slabs_ptr), C.c_void_p(stream_ptr)))
 
     # ---------------------------------------------------------------- tests only
     def set_frame_counter(self, n: int):

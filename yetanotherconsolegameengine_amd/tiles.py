@@ -71,3 +71,50 @@ def unpermute(all_slabs: np.ndarray, hiW: int, hiH: int, world: int, floats: int
         ok = (px < hiW) & (py < hiH)
         frame[py[ok], px[ok]] = s[r, k, ok]
     return frame
+
+
+# ---------------------------------------------------------------------------------------------- tile-resident form: halo lists
+# TAA reads a 3x3 window (TemporalBlendWithClamp, clampRadius = 1, RaytraceRenderer.cs:218), so a rank that keeps the history of its own
+# tiles needs {hdr, sky} of the one-pixel ring around each of them from the ranks that own those pixels.  Sender and receiver enumerate
+# the ring pixels of the RECEIVER's tiles in one fixed order - tiles ascending; per tile the row above (x0 - 1 .. x0 + 32), the row below,
+# the column left (y0 .. y0 + 7), the column right; pixels outside the image do not exist - and keep those the sender owns.  This is the
+# statement of csrc/ycge_host.cpp: halo_layout (the CPU tests hold the two to each other, element for element).
+
+def halo_ring(tile: int, hiW: int, hiH: int) -> np.ndarray:
+    """pixel indices (x + y * hiW) of the one-pixel ring around `tile`, in the exchange's order"""
+    tx, _, _ = tile_grid(hiW, hiH)
+    x0, y0 = (tile % tx) * TILE_W, (tile // tx) * TILE_H
+    xs = np.arange(x0 - 1, x0 + TILE_W + 1)
+    ys = np.arange(y0, y0 + TILE_H)
+    pts = ([(x, y0 - 1) for x in xs] + [(x, y0 + TILE_H) for x in xs] + [(x0 - 1, y) for y in ys] + [(x0 + TILE_W, y) for y in ys])
+    return np.array([x + y * hiW for x, y in pts if 0 <= x < hiW and 0 <= y < hiH], dtype=np.int64)
+
+
+def pixel_owner(px: np.ndarray, hiW: int, hiH: int, world: int) -> np.ndarray:
+    tx, _, _ = tile_grid(hiW, hiH)
+    x, y = px % hiW, px // hiW
+    return ((y // TILE_H) * tx + x // TILE_W) % world
+
+
+def halo_lists(rank: int, world: int, hiW: int, hiH: int):
+    """(send_px per destination rank, recv_px per source rank): lists of pixel indices; send[r][k] on rank q IS recv[q][k] on rank r"""
+    _, _, n = tile_grid(hiW, hiH)
+    recv = [[] for _ in range(world)]
+    for t in owned_tiles(rank, world, n):
+        ring = halo_ring(int(t), hiW, hiH)
+        own = pixel_owner(ring, hiW, hiH, world)
+        for q in range(world):
+            if q != rank:
+                recv[q].extend(ring[own == q].tolist())
+    send = [[] for _ in range(world)]
+    for r in range(world):
+        if r == rank:
+            continue
+        for t in owned_tiles(r, world, n):
+            ring = halo_ring(int(t), hiW, hiH)
+            send[r].extend(ring[pixel_owner(ring, hiW, hiH, world) == rank].tolist())
+    return [np.array(v, dtype=np.int64) for v in send], [np.array(v, dtype=np.int64) for v in recv]
+
+
+def history_slab_floats(world: int, n_tiles: int) -> int:
+    return tiles_per_rank_padded(world, n_tiles) * 256 * 3
