@@ -156,20 +156,21 @@ static inline double m_exp_d(double x)
     int k = (int)(kf < 0.0 ? kf - 0.5 : kf + 0.5);
     double dk = (double)k;
     double r = (x - dk * ln2_hi) - dk * ln2_lo;
-    double p = 1.6059043836821614599e-10;                /* 1/13! */
-    p = p * r + 2.0876756987868098979e-09;               /* 1/12! */
-    p = p * r + 2.5052108385441718775e-08;               /* 1/11! */
-    p = p * r + 2.7557319223985890653e-07;               /* 1/10! */
-    p = p * r + 2.7557319223985890653e-06;               /* 1/9!  */
-    p = p * r + 2.4801587301587301587e-05;               /* 1/8!  */
-    p = p * r + 1.9841269841269841270e-04;               /* 1/7!  */
-    p = p * r + 1.3888888888888888889e-03;               /* 1/6!  */
-    p = p * r + 8.3333333333333333333e-03;               /* 1/5!  */
-    p = p * r + 4.1666666666666666667e-02;               /* 1/4!  */
-    p = p * r + 1.6666666666666666667e-01;               /* 1/3!  */
-    p = p * r + 5.0000000000000000000e-01;               /* 1/2!  */
-    p = p * r + 1.0;
-    p = p * r + 1.0;
+    /* Taylor degree 13 in Estrin form (round 4; Horner before): the same coefficients, a dependency chain of 8 operations instead of 26 - this
+     * polynomial sits on the in-place A-trous iteration's serial chain once per pixel level.  Every product and sum below is one binary64
+     * operation (no contraction), in this order, in the oracle and in the kernels alike.  exp(-0) is still exactly 1: r = -0 makes r2 = +0,
+     * every pair (c + c' * r) is its first coefficient and every higher term a zero. */
+    const double r2 = r * r, r4 = r2 * r2, r8 = r4 * r4;
+    const double a0 = 1.0 + 1.0 * r;
+    const double a1 = 5.0000000000000000000e-01 + 1.6666666666666666667e-01 * r;
+    const double a2 = 4.1666666666666666667e-02 + 8.3333333333333333333e-03 * r;
+    const double a3 = 1.3888888888888888889e-03 + 1.9841269841269841270e-04 * r;
+    const double a4 = 2.4801587301587301587e-05 + 2.7557319223985890653e-06 * r;
+    const double a5 = 2.7557319223985890653e-07 + 2.5052108385441718775e-08 * r;
+    const double a6 = 2.0876756987868098979e-09 + 1.6059043836821614599e-10 * r;
+    const double q0 = a0 + a1 * r2, q1 = a2 + a3 * r2, q2 = a4 + a5 * r2;
+    const double h0 = q0 + q1 * r4, h1 = q2 + a6 * r4;
+    double p = h0 + h1 * r8;
     /* multiply by 2^k in two steps so that subnormal results round once more
      * at most; k in [-1075, 1023] */
     int k1 = k / 2, k2 = k - k1;

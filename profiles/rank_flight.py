@@ -3,6 +3,7 @@ after the other): prints the period per frame of each rank.
 
     rank_flight.py CONFIG WORLD [one]           the slab form: frames on alternating trace streams, a copy standing in for the all-gather,
                                                 ycge_resolve_gathered on a third stream ("one": a single trace stream)
+    rank_flight.py CONFIG WORLD residentc K [RANKS]   the same loop driven from C inside the library (no scripting-language overhead per frame)
     rank_flight.py CONFIG WORLD resident K      the tile-resident form: K traces in flight over K streams (config.tile_ring = K), a copy of
                                                 the rank's halo records standing in for the all-to-all, ycge_resolve_tiles_resident (TAA on
                                                 the rank's own tiles + the 12-byte history slab) on another stream
@@ -25,7 +26,22 @@ sc, w, h, ss, pose = scenes.config_scene(cfg)
 flat = flatten(sc)
 N = 200
 periods = []
-for rank in range(world):
+issue = []
+ranks = range(world) if len(sys.argv) <= 5 else [int(x) for x in sys.argv[5].split(',')]
+for rank in ranks:
+    if mode == "residentc":
+        # the same loop driven from C inside the library (ycge_debug_resident_loop): the host cost per frame is the library's and the driver's,
+        # not Python's - what a C# / C++ host would see
+        import ctypes as C
+        r = RaytraceRenderer(flat, w, h, pose["fov"], ss, rank=rank, world_size=world, tile_ring=K)
+        r.SetCamera(pose["pos"], pose["yaw"], pose["pitch"])
+        fn = r.L.ycge_debug_resident_loop; fn.restype = C.c_int; fn.argtypes = [C.c_void_p, C.c_int32, C.POINTER(C.c_double), C.POINTER(C.c_double)]
+        per, iss = C.c_double(), C.c_double()
+        rc = fn(r.ctx, N, C.byref(per), C.byref(iss))
+        assert rc == 0, (rc, r.L.ycge_last_error(r.ctx))
+        periods.append(per.value); issue.append(iss.value)
+        r.close()
+        continue
     if mode == "resident":
         r = RaytraceRenderer(flat, w, h, pose["fov"], ss, rank=rank, world_size=world, tile_ring=K)
         r.SetCamera(pose["pos"], pose["yaw"], pose["pitch"])
@@ -85,8 +101,10 @@ for rank in range(world):
     t0 = time.perf_counter()
     for i in range(12, 12 + N): frame(i)
     drain()
+    t_issue = time.perf_counter() - t0          # what the HOST needed to queue the frames (the loop is host-bound where this is the period)
     torch.cuda.synchronize()
     periods.append((time.perf_counter() - t0) / N * 1e3)
+    issue.append(t_issue / N * 1e3)
     r.close()
-label = f"tile-resident form, {K} traces in flight" if mode == "resident" else ("one trace stream" if mode == "one" else "two trace streams")
-print(f"config {cfg} world {world} {label}: per-rank period ms/frame {[round(p, 3) for p in periods]}  max {max(periods):.3f}")
+label = f"tile-resident form, {K} traces in flight" + (" (loop driven from C)" if mode == "residentc" else "") if mode.startswith("resident") else ("one trace stream" if mode == "one" else "two trace streams")
+print(f"config {cfg} world {world} {label}: per-rank period ms/frame {[round(p, 3) for p in periods]}  max {max(periods):.3f}; host issue time per frame {[round(p, 3) for p in issue]}")

@@ -139,6 +139,7 @@ struct Knobs {
     int bvh_waves = 16;              // YCGE_BVH_WAVES: wavefronts of k_scene_bvh_build that take nodes (tests: the order nodes are split in must not matter)
     bool scene_bvh_host = false;     // YCGE_SCENE_BVH_HOST: ycge_scene_update_objects builds the scene BVH on the host, not on the device
     int scene_bvh_device_min = YCGE_BVH_DEV_MIN_ITEMS_DEFAULT;   // YCGE_SCENE_BVH_DEVICE_MIN: fewer objects than this are built on the host (measured crossover, profiles/r02/f2_update_objects_timing.txt)
+    int res_sched_every = 0;         // YCGE_RES_SCHED_EVERY: the tile-resident ring builds a new schedule behind every n-th frame (0 = the ring's depth)
     int bfs_rays = 0;                // YCGE_BFS=<n>: a wavefront's occlusion queries against a mesh go breadth-first from one shared work list when at most n of its lanes ask (mesh_anyhit_bfs; 0 = never, 64 = always)
     bool no_coop = false;            // YCGE_NO_COOP: no treelets are built, sparse wavefronts keep the regular walk (A/B of the cooperative walk)
     bool exposure_serial = false;    // YCGE_EXPOSURE_SERIAL: the one-lane chain instead of the chunked exact evaluation
@@ -178,6 +179,7 @@ struct Knobs {
         post_dbg_free = geti("YCGE_POST_DBG_FREE", 0) != 0;
         exposure_serial = getenv("YCGE_EXPOSURE_SERIAL") != nullptr;
         no_coop = getenv("YCGE_NO_COOP") != nullptr;
+        res_sched_every = geti("YCGE_RES_SCHED_EVERY", 0);
         bfs_rays = geti("YCGE_BFS", 0);
         if (bfs_rays < 0 || bfs_rays > 64) bfs_rays = 0;
         scene_bvh_host = getenv("YCGE_SCENE_BVH_HOST") != nullptr;
@@ -308,9 +310,12 @@ struct ycge_ctx {
     std::vector<ResidentSet *> rsets;
     static constexpr uint32_t kResCostFrames = 8;  // the resident ring's own cost ring: K - 1 slots are being written, one is cleared, the rest are read
     DevBuf<uint32_t> res_cost;
-    std::vector<DevBuf<uint32_t> *> res_order, res_ws;        // K + 1 schedule buffers: frame N reads buffer N % (K + 1), built behind the trace of frame N - K
+    // three schedule buffers taken in turn: one is built behind the trace of every R-th frame M (R = the ring's depth; YCGE_RES_SCHED_EVERY) and
+    // serves the frames from M + K on - a trace never waits for a trace younger than frame N - K - until a newer one does
+    std::vector<DevBuf<uint32_t> *> res_order, res_ws;
     std::vector<hipEvent_t> res_order_ev, res_order_read_ev;
-    std::vector<int64_t> res_order_frame;
+    std::vector<int64_t> res_order_frame;          // per buffer: the frame M its schedule was built behind (-1: none)
+    int res_order_next = 0;                        // the buffer the next build writes
     hipEvent_t res_last_traced = nullptr;          // stage-pipeline scenes share their queues between frames: their traces follow each other
     bool res_last_traced_used = false;
     std::vector<int64_t> halo_send_counts, halo_recv_counts;          // records (4 floats) per peer rank
@@ -2783,9 +2788,10 @@ static int ensure_resident(ycge_ctx *c)
             HIP_TRY(c, hipEventCreateWithFlags(&rs->traced, hipEventDisableTiming)); HIP_TRY(c, hipEventCreateWithFlags(&rs->resolved, hipEventDisableTiming));
         }
         const size_t nb = (size_t)(c->n_owned > 0 ? c->n_owned : 1) * 4;
-        HIP_TRY(c, c->res_cost.alloc(nb * ycge_ctx::kResCostFrames));
-        HIP_TRY(c, hipMemset(c->res_cost.p, 0, nb * ycge_ctx::kResCostFrames * sizeof(uint32_t)));
-        for (int k = 0; k < K + 1; k++) {
+        HIP_TRY(c, c->res_cost.alloc(nb * (ycge_ctx::kResCostFrames + 1)));          // (+ one slot nobody reads: what a schedule build "clears for the next frame")
+        HIP_TRY(c, hipMemset(c->res_cost.p, 0, nb * (ycge_ctx::kResCostFrames + 1) * sizeof(uint32_t)));
+        c->res_order_next = 0;
+        for (int k = 0; k < 3; k++) {
             auto *o = new DevBuf<uint32_t>(); auto *w = new DevBuf<uint32_t>();
             c->res_order.push_back(o); c->res_ws.push_back(w);
             HIP_TRY(c, o->alloc(nb * YCGE_SCHEDULE_SLACK)); HIP_TRY(c, w->alloc(96)); HIP_TRY(c, hipMemset(w->p, 0, 96 * sizeof(uint32_t)));
@@ -2845,37 +2851,42 @@ int ycge_trace_tiles_resident(ycge_ctx *c, void *d_halo_send, void *hip_stream, 
     rt.set = rs;
     rt.cost = c->res_cost.p + (size_t)cost_slot * n_blocks;
     rt.order = nullptr; rt.n_order = nullptr;
-    const int NB = K + 1, ob = (int)((uint64_t)fs.frame % (uint64_t)NB);
-    if (single && !c->knobs.no_lpt && c->res_order_frame[(size_t)ob] == fs.frame) {
+    const bool lpt = single && !c->knobs.no_lpt;
+    int ob = -1;          // the newest schedule this frame may follow: built behind a frame M <= N - K (anything younger would make this trace wait for a trace of its own ring)
+    if (lpt)
+        for (int b = 0; b < 3; b++)
+            if (c->res_order_frame[(size_t)b] >= 0 && c->res_order_frame[(size_t)b] + K <= fs.frame && (ob < 0 || c->res_order_frame[(size_t)b] > c->res_order_frame[(size_t)ob])) ob = b;
+    if (ob >= 0) {
         rt.order = c->res_order[(size_t)ob]->p; rt.n_order = c->res_ws[(size_t)ob]->p + 16;
         HIP_TRY(c, hipStreamWaitEvent(stream, c->res_order_ev[(size_t)ob], 0));
     }
-    if (single && !c->knobs.no_lpt && c->res_order_frame[(size_t)ob] != fs.frame)
-        // nobody has cleared this frame's cost slot (the first K frames, a frame after a gap): the kernel's atomicMax needs zeros
-        HIP_TRY(c, hipMemsetAsync(rt.cost, 0, (size_t)n_blocks * sizeof(uint32_t), stream));
+    if (lpt) HIP_TRY(c, hipMemsetAsync(rt.cost, 0, (size_t)n_blocks * sizeof(uint32_t), stream));          // this frame's cost slot (the kernel's atomicMax needs zeros)
     rc = trace_frame(c, nullptr, stream, fs, st != nullptr, nullptr, nullptr, &rt);
     if (rc != YCGE_OK) return rc;
-    if (rt.order) HIP_TRY(c, hipEventRecord(c->res_order_read_ev[(size_t)ob], stream));
+    if (ob >= 0) HIP_TRY(c, hipEventRecord(c->res_order_read_ev[(size_t)ob], stream));
     int e = ycge_launch_halo(0, rs->hdr.p, rs->sky.p, c->d_halo_send_px.p, (uint32_t)n_send, d_halo_send, stream);
     if (e != 0) return c->fail(YCGE_ERR_DEVICE, "k_gather_halo launch failed: %s", hipGetErrorString((hipError_t)e));
     HIP_TRY(c, hipEventRecord(rs->traced, stream)); rs->traced_used = true;
-    HIP_TRY(c, hipEventRecord(c->res_last_traced, stream)); c->res_last_traced_used = true;
-    if (single && !c->knobs.no_lpt) {
-        // the schedule of frame N + K, behind this trace on the side stream: from the cost slots of the frames up to this one - the K - 1
-        // slots the traces of frames N + 1 .. N + K - 1 may be writing are left out, frame N + K's is cleared - into the buffer frame
-        // N + K will read, once the last trace that read that buffer (frame N - 1) is done
+    if (!single || c->sd.any_transparent) { HIP_TRY(c, hipEventRecord(c->res_last_traced, stream)); c->res_last_traced_used = true; }
+    const int every = c->knobs.res_sched_every > 0 ? c->knobs.res_sched_every : K;
+    if (lpt && fs.frame % every == 0) {
+        // a new schedule, behind this trace on the side stream: from the cost slots of the frames up to this one (the K - 1 slots the traces of
+        // frames N + 1 .. N + K - 1 may be writing are left out), into the oldest of the three buffers once its last reader is done.  Built
+        // every `every`-th frame only: which blocks run long is a property of the image region, and a rank's host thread has ~25 driver
+        // calls a frame to make as it is
         uint32_t policy, split_top;
         schedule_policy(c, policy, split_top);
         uint32_t skip = 0;
         for (int a = 1; a < K; a++) skip |= 1u << ((cost_slot + (uint32_t)a) % RC);
-        const int64_t target_frame = fs.frame + K;
-        const int tb = (int)((uint64_t)target_frame % (uint64_t)NB);
+        const int tb = c->res_order_next;
+        c->res_order_next = (tb + 1) % 3;
         HIP_TRY(c, hipStreamWaitEvent(c->fan_stream, rs->traced, 0));
         if (c->res_order_frame[(size_t)tb] >= 0) HIP_TRY(c, hipStreamWaitEvent(c->fan_stream, c->res_order_read_ev[(size_t)tb], 0));
-        e = ycge_launch_order_blocks(c->res_cost.p, n_blocks, policy, split_top, 0u, 0u, (uint32_t)((uint64_t)target_frame % RC), skip, c->res_ws[(size_t)tb]->p, c->res_order[(size_t)tb]->p, c->fan_stream, 0, RC);
+        c->res_order_frame[(size_t)tb] = -1;          // (not to be picked while it is being rewritten ...)
+        e = ycge_launch_order_blocks(c->res_cost.p, n_blocks, policy, split_top, 0u, 0u, RC /* the slot nobody reads */, skip, c->res_ws[(size_t)tb]->p, c->res_order[(size_t)tb]->p, c->fan_stream, 0, RC);
         if (e != 0) return c->fail(YCGE_ERR_DEVICE, "schedule launch failed: %s", hipGetErrorString((hipError_t)e));
         HIP_TRY(c, hipEventRecord(c->res_order_ev[(size_t)tb], c->fan_stream));
-        c->res_order_frame[(size_t)tb] = target_frame;
+        c->res_order_frame[(size_t)tb] = fs.frame;          // (... and from frame N + K on it is the newest)
     }
     c->pending.push_back(fs);
     if (st) {
@@ -2951,6 +2962,76 @@ int ycge_unpack_history(ycge_ctx *c, const void *d_all_history_slabs, void *hip_
     c->last_stream = stream;
     const int e = ycge_launch_unpack_history((const float *)d_all_history_slabs, (size_t)c->tiles_per_rank_padded * 256 * 3, c->hiW, c->hiH, c->tiles_x, c->n_tiles, c->cfg.world_size, c->taa_hist.p, stream);
     if (e != 0) return c->fail(YCGE_ERR_DEVICE, "k_unpack_history launch failed: %s", hipGetErrorString((hipError_t)e));
+    return YCGE_OK;
+}
+
+// measurement (profiles/rank_flight.py): a rank's pipelined loop of the tile-resident form driven from C - K traces in flight over K streams,
+// a device copy of the rank's own records standing in for the all-to-all, resolve + history slab on another stream - so that what is timed
+// is the library's and the driver's host cost per frame, not a scripting language's.  period_ms: wall time per frame; issue_ms: host time
+// to queue a frame (where the two agree the loop is host-bound).
+int ycge_debug_resident_loop(ycge_ctx *c, int32_t frames, double *period_ms, double *issue_ms)
+{
+    if (!c || frames <= 0 || !period_ms || !issue_ms) return YCGE_ERR_INVALID_ARG;
+    { const int jr = join_async(c); if (jr != YCGE_OK) return jr; }
+    int rc = ensure_resident(c);
+    if (rc != YCGE_OK) return rc;
+    const int K = (int)c->rsets.size();
+    size_t ns = 0, nr = 0;
+    for (int64_t v : c->halo_send_counts) ns += (size_t)v;
+    for (int64_t v : c->halo_recv_counts) nr += (size_t)v;
+    const size_t sb = (ns ? ns : 1) * 16, rb = (nr ? nr : 1) * 16, hb = (size_t)c->tiles_per_rank_padded * 256 * 3 * sizeof(float);
+    std::vector<hipStream_t> st((size_t)K, nullptr);
+    std::vector<hipEvent_t> evt((size_t)K, nullptr), evr((size_t)K, nullptr);
+    std::vector<void *> send((size_t)K, nullptr), recv((size_t)K, nullptr), hist((size_t)K, nullptr);
+    hipStream_t comm = nullptr;
+    auto cleanup = [&]() {
+        (void)hipDeviceSynchronize();
+        for (int k = 0; k < K; k++) { if (st[k]) (void)hipStreamDestroy(st[k]); if (evt[k]) (void)hipEventDestroy(evt[k]); if (evr[k]) (void)hipEventDestroy(evr[k]);
+                                      if (send[k]) (void)hipFree(send[k]); if (recv[k]) (void)hipFree(recv[k]); if (hist[k]) (void)hipFree(hist[k]); }
+        if (comm) (void)hipStreamDestroy(comm);
+    };
+#define LOOP_TRY(call) do { if ((call) != hipSuccess) { cleanup(); return c->fail(YCGE_ERR_DEVICE, "%s failed", #call); } } while (0)
+    LOOP_TRY(hipStreamCreateWithFlags(&comm, hipStreamNonBlocking));
+    for (int k = 0; k < K; k++) {
+        LOOP_TRY(hipStreamCreateWithFlags(&st[k], hipStreamNonBlocking));
+        LOOP_TRY(hipEventCreateWithFlags(&evt[k], hipEventDisableTiming)); LOOP_TRY(hipEventCreateWithFlags(&evr[k], hipEventDisableTiming));
+        LOOP_TRY(hipMalloc(&send[k], sb)); LOOP_TRY(hipMalloc(&recv[k], rb)); LOOP_TRY(hipMalloc(&hist[k], hb));
+        LOOP_TRY(hipMemset(send[k], 0, sb)); LOOP_TRY(hipMemset(recv[k], 0, rb));
+    }
+    std::deque<int> issued;
+    auto resolve = [&](int k) -> int {
+        if (hipStreamWaitEvent(comm, evt[k], 0) != hipSuccess) return YCGE_ERR_DEVICE;
+        if (hipMemcpyAsync(recv[k], send[k], sb < rb ? sb : rb, hipMemcpyDeviceToDevice, comm) != hipSuccess) return YCGE_ERR_DEVICE;      // stands in for the all-to-all
+        const int r2 = ycge_resolve_tiles_resident(c, recv[k], hist[k], comm, nullptr);
+        if (r2 != YCGE_OK) return r2;
+        return hipEventRecord(evr[k], comm) == hipSuccess ? YCGE_OK : YCGE_ERR_DEVICE;
+    };
+    int64_t i = 0;
+    auto frame = [&]() -> int {
+        const int k = (int)(i++ % K);
+        if ((int)issued.size() == K) { const int r2 = resolve(issued.front()); issued.pop_front(); if (r2 != YCGE_OK) return r2; }
+        if (hipStreamWaitEvent(st[k], evr[k], 0) != hipSuccess) return YCGE_ERR_DEVICE;
+        const int r2 = ycge_trace_tiles_resident(c, send[k], st[k], nullptr);
+        if (r2 != YCGE_OK) return r2;
+        issued.push_back(k);
+        return hipEventRecord(evt[k], st[k]) == hipSuccess ? YCGE_OK : YCGE_ERR_DEVICE;
+    };
+    auto drain = [&]() -> int { while (!issued.empty()) { const int r2 = resolve(issued.front()); issued.pop_front(); if (r2 != YCGE_OK) return r2; } return YCGE_OK; };
+    for (int w = 0; w < 12 && rc == YCGE_OK; w++) rc = frame();
+    if (rc == YCGE_OK) rc = drain();
+    if (rc != YCGE_OK) { cleanup(); return rc; }
+    LOOP_TRY(hipDeviceSynchronize());
+    const auto t0 = std::chrono::steady_clock::now();
+    for (int f = 0; f < frames && rc == YCGE_OK; f++) rc = frame();
+    if (rc == YCGE_OK) rc = drain();
+    const auto t1 = std::chrono::steady_clock::now();
+    if (rc != YCGE_OK) { cleanup(); return rc; }
+    LOOP_TRY(hipDeviceSynchronize());
+    const auto t2 = std::chrono::steady_clock::now();
+#undef LOOP_TRY
+    *issue_ms = std::chrono::duration<double, std::milli>(t1 - t0).count() / frames;
+    *period_ms = std::chrono::duration<double, std::milli>(t2 - t0).count() / frames;
+    cleanup();
     return YCGE_OK;
 }
 
