@@ -1245,9 +1245,12 @@ static bool grid_hit(const SceneData &S, const Grid &g, const Ray &r, float t_mi
                     float dist2 = hit_t * hit_t * dir_len2;
                     within_wire = dist2 <= wire_max2;
                 }
-                /* centre-block highlight (VolumeGrid.cs:176-187) is a data race on shared
-                 * state in the reference and cannot trigger when hiW or hiH is even
-                 * (IsCenterUV needs u == v == 0.5 to 1e-6); not modelled. */
+                /* The centre-block highlight (VolumeGrid.cs:176-187) is DEAD CODE under this renderer, at every console size: it needs
+                 * a query with |screenV - 0.5| <= 1e-6 (IsCenterUV, :286-289); the tracer passes vCenter = (py + 0.5f) / hiH
+                 * (RaytraceRenderer.cs:204-205) with hiH = fbH * 2 * ss (:86-87, :119) - EVEN for every framebuffer, so vCenter misses
+                 * 0.5 by at least 0.5 / hiH (> 1e-6 below half a million rows) - and every other caller of Scene.Hit passes (0, 0)
+                 * (VolumeScenes.cs:288-525).  centerValid never becomes true; the wire colour is always WireColor.  (KAT:
+                 * tests/test_oracle_kats.py::test_center_block_highlight_is_unreachable.) */
                 int mi = g.default_material;
                 for (size_t k = 0; k < g.lookup.size(); k++)
                     if (g.lookup[k].mat_id == mat_id && g.lookup[k].meta_id == meta_id) { mi = g.lookup[k].material; break; }

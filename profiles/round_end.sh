@@ -1,25 +1,36 @@
 #!/bin/bash
-# round-end measurement on the GPU box: full GPU test suite, bench of every GPU config WITH the CPU baseline beside it, the moving-camera
-# headline, rocprofv3 kernel trace + PMC passes of configs 4 and 5 (every profiler run under its own timeout).  Everything lands in gpurun_out/.
+# round-end measurement on the GPU box: full GPU test suite, bench of every GPU config WITH the CPU baseline beside it (config 5 at the survey's
+# dark day phase AND at noon), the moving-camera headline, rocprofv3 kernel trace + PMC passes of config 4, config 5 dark and config 5 lit
+# (every profiler run under its own timeout), rank emulations (slab form, tile-resident ring), in-flight A/B, post stage exact / waived,
+# per-wavefront profile, cooperative-walk clocks.  Everything lands in gpurun_out/.
 REPO=${GRAFT_REPO_ROOT:-/root/repo}; cd $REPO; mkdir -p gpurun_out
-TAG=${1:-r03}
-timeout 1800 python -m pytest tests -m gpu -q > gpurun_out/pytest_gpu_$TAG.log 2>&1; echo "pytest rc=$?"; tail -3 gpurun_out/pytest_gpu_$TAG.log
+TAG=${1:-r04}
+timeout 2400 python -m pytest tests -m gpu -q > gpurun_out/pytest_gpu_$TAG.log 2>&1; echo "pytest rc=$?"; tail -3 gpurun_out/pytest_gpu_$TAG.log
 timeout 600 python bench.py > gpurun_out/bench_$TAG.json 2> gpurun_out/bench_$TAG.err; echo "bench rc=$?"
 for c in 1 2 3 5; do timeout 400 python bench.py --config $c --cpu-seconds 10 2>> gpurun_out/bench_$TAG.err > gpurun_out/bench_${TAG}_cfg$c.json; done
+timeout 500 python bench.py --config 5 --t01 0.5 --cpu-seconds 10 2>> gpurun_out/bench_$TAG.err > gpurun_out/bench_${TAG}_cfg5_t050.json
 timeout 300 python bench.py --camera orbit --no-cpu-baseline > gpurun_out/bench_${TAG}_orbit.json 2>> gpurun_out/bench_$TAG.err
-for f in bench_$TAG bench_${TAG}_cfg1 bench_${TAG}_cfg2 bench_${TAG}_cfg3 bench_${TAG}_cfg5 bench_${TAG}_orbit; do python - <<PY
+for f in bench_$TAG bench_${TAG}_cfg1 bench_${TAG}_cfg2 bench_${TAG}_cfg3 bench_${TAG}_cfg5 bench_${TAG}_cfg5_t050 bench_${TAG}_orbit; do python - <<PY
 import json
 try:
     d = json.load(open("gpurun_out/$f.json"))
-    print("$f", d["value"], "Mrays/s", d["ms_per_step"], "ms/frame; trace", d.get("trace_ms"), "in flight", (d.get("frames_in_flight") or {}).get("ms_per_step"), (d.get("frames_in_flight") or {}).get("value"), "with sdr", ((d.get("frames_in_flight") or {}).get("with_sdr") or {}).get("ms_per_step"), "cpu", (d.get("cpu_baseline") or {}).get("value"), "x", d.get("gpu_over_cpu"), "moving", (d.get("moving_camera") or {}).get("trace_ms"), "post", (d.get("post_stage") or {}).get("post_ms"), (d.get("post_stage") or {}).get("frame_ms_with_sdr_readback"))
+    fl = d.get("frames_in_flight") or {}
+    print("$f", d["value"], "Mrays/s (by the reference's count", d.get("value_reference_ray_count"), ")", d["ms_per_step"], "ms/frame; trace", d.get("trace_ms"), "in flight", fl.get("ms_per_step"), fl.get("value"), "gate", fl.get("gate"), "with sdr", (fl.get("with_sdr") or {}).get("ms_per_step"), "cpu", (d.get("cpu_baseline") or {}).get("value"), "x", d.get("gpu_over_cpu"), "moving", (d.get("moving_camera") or {}).get("trace_ms"), "post", (d.get("post_stage") or {}).get("post_ms"), (d.get("post_stage") or {}).get("frame_ms_with_sdr_readback"), "roofline frac", (d.get("roofline") or {}).get("frac"))
 except Exception as e:
     print("$f failed", e)
 PY
 done
 bash profiles/run_profiles.sh ${TAG}_c4 > gpurun_out/prof_${TAG}_c4.log 2>&1; echo "profiles c4 rc=$?"; head -12 gpurun_out/prof_${TAG}_c4/summary.txt
 bash profiles/run_profiles.sh ${TAG}_c5 --config 5 > gpurun_out/prof_${TAG}_c5.log 2>&1; echo "profiles c5 rc=$?"; head -12 gpurun_out/prof_${TAG}_c5/summary.txt
+bash profiles/run_profiles.sh ${TAG}_c5lit --config 5 --t01 0.5 > gpurun_out/prof_${TAG}_c5lit.log 2>&1; echo "profiles c5 lit rc=$?"; head -12 gpurun_out/prof_${TAG}_c5lit/summary.txt
 for cfg in 4 3; do echo "== rank emulation config $cfg"; timeout 600 python profiles/rank_times.py $cfg 2>&1 | grep -E "world"; done
-echo "== a rank's period in the pipelined tiled loop"; for w in 8 4 2; do timeout 300 python profiles/rank_flight.py 4 $w 2>&1 | tail -1; done; timeout 300 python profiles/rank_flight.py 4 8 one 2>&1 | tail -1; timeout 300 python profiles/rank_flight.py 3 8 2>&1 | tail -1
+echo "== a rank's period: slab form (two trace streams), tile-resident ring (loop driven from C)"
+for w in 8 4 2; do timeout 300 python profiles/rank_flight.py 4 $w two 2>&1 | tail -1; done
+for w in 8 4 2; do for k in 2 4; do timeout 300 python profiles/rank_flight.py 4 $w residentc $k 2>&1 | tail -1; done; done
+timeout 300 python profiles/rank_flight.py 3 8 residentc 4 2>&1 | tail -1; timeout 300 python profiles/rank_flight.py 5 8 residentc 2 2>&1 | tail -1
 echo "== frames in flight against the synchronous call"; for cfg in 4 3 2 5; do timeout 300 python profiles/flight_ab.py $cfg 300 2>&1 | tail -2; done
+echo "== post stage: exact and waived (config.atrous_inplace_exact)"; timeout 600 python profiles/post_waiver.py 2>&1 | grep -v amdgpu.ids
 echo "== post stage bands"; for a in "4 1 270" "5 2 540"; do set -- $a; CFG=$1 SS=$2 NB=$3 timeout 300 python profiles/post_bands.py 2>&1 | grep -E "^post|launch span|chain:"; done
 timeout 300 python profiles/mega_prof.py 4 2>&1 | grep -v amdgpu.ids > gpurun_out/mega_prof_$TAG.txt; grep -E "trace_ms|span|slot time|>= 256" gpurun_out/mega_prof_$TAG.txt
+if [ -f yetanotherconsolegameengine_amd/lib/var_coopstat.so ]; then YCGE_LIB=$REPO/yetanotherconsolegameengine_amd/lib/var_coopstat.so timeout 200 python profiles/coop_stats.py 4 2>&1 | grep -v amdgpu.ids; fi
+if [ -f yetanotherconsolegameengine_amd/lib/var_batchstat.so ]; then YCGE_LIB=$REPO/yetanotherconsolegameengine_amd/lib/var_batchstat.so timeout 300 python profiles/batch_stats.py 4 2>&1 | grep -v amdgpu.ids; fi

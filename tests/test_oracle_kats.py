@@ -617,3 +617,21 @@ def test_bvh_traversal_order_and_work_counters_against_python_restatement():
 
 def pr_rows(nodes):
     return _rows(nodes)
+
+
+def test_center_block_highlight_is_unreachable():
+    """VolumeGrid's "center block" highlight (VolumeGrid.cs:176-187) needs a query with |screenU - 0.5| <= 1e-6 AND |screenV - 0.5| <= 1e-6
+    (IsCenterUV, :286-289, binary32).  The tracer passes uCenter = (px + 0.5f) / hiW, vCenter = (py + 0.5f) / hiH (RaytraceRenderer.cs:204-205)
+    with hiH = fbH * 2 * ss (:86-87, :119): EVEN for every framebuffer height and supersampling factor, so no row has vCenter within 1e-6 of
+    0.5 - checked here in binary32 for every even hiH up to 8 192 rows and a sample beyond; every other caller of Scene.Hit passes (0, 0)
+    (VolumeScenes.cs:288, 313, 404, 411, 446, 525).  Hence neither the oracle nor the kernels model the (racy) shared state: it is never set."""
+    f32 = np.float32
+    half, win = f32(0.5), f32(0.000001)
+    for hiH in list(range(2, 8194, 2)) + [20000, 65536, 131072, 400000]:
+        py = np.arange(max(0, hiH // 2 - 2), min(hiH, hiH // 2 + 2), dtype=np.float32)          # the rows next to the middle: the only candidates
+        v = ((py + half) / f32(hiH)).astype(np.float32)
+        assert not (np.abs(v - half) <= win).any(), hiH
+    # (an odd row count WOULD have such a row - which is why the parity of hiH is the whole argument)
+    for hiH in (9, 45, 1079):
+        py = np.arange(hiH, dtype=np.float32)
+        assert (np.abs(((py + half) / f32(hiH)).astype(np.float32) - half) <= win).sum() == 1

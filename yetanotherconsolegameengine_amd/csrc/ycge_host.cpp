@@ -2991,7 +2991,13 @@ int ycge_debug_resident_loop(ycge_ctx *c, int32_t frames, double *period_ms, dou
         if (comm) (void)hipStreamDestroy(comm);
     };
 #define LOOP_TRY(call) do { if ((call) != hipSuccess) { cleanup(); return c->fail(YCGE_ERR_DEVICE, "%s failed", #call); } } while (0)
-    LOOP_TRY(hipStreamCreateWithFlags(&comm, hipStreamNonBlocking));
+    {   // the exchange + resolve stream at the highest priority (YCGE_RES_LOOP_PRIO=0: plain): its small kernels must not queue behind a
+        // trace that happens to share its hardware queue - a resolve held up that way holds up the trace K frames later
+        int lo = 0, hi = 0;
+        const char *pe = getenv("YCGE_RES_LOOP_PRIO");
+        if ((!pe || atoi(pe) != 0) && hipDeviceGetStreamPriorityRange(&lo, &hi) == hipSuccess && hi != lo) LOOP_TRY(hipStreamCreateWithPriority(&comm, hipStreamNonBlocking, hi));
+        else LOOP_TRY(hipStreamCreateWithFlags(&comm, hipStreamNonBlocking));
+    }
     for (int k = 0; k < K; k++) {
         LOOP_TRY(hipStreamCreateWithFlags(&st[k], hipStreamNonBlocking));
         LOOP_TRY(hipEventCreateWithFlags(&evt[k], hipEventDisableTiming)); LOOP_TRY(hipEventCreateWithFlags(&evr[k], hipEventDisableTiming));

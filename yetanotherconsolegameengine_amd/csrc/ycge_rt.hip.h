@@ -1287,8 +1287,9 @@ __device__ __forceinline__ void resolve_hit(const SceneDev &S, int prim_index, i
                     float dist2 = t * t * dir_len2;
                     within = dist2 <= wire_max2;
                 }
-                // centre-block highlight (VolumeGrid.cs:176-187): shared mutable state raced by all pixel
-                // threads in the reference; unreachable when hiW or hiH is even.  Not modelled.
+                // centre-block highlight (VolumeGrid.cs:176-187): dead code under this renderer at EVERY console size - it needs a query
+                // with |screenV - 0.5| <= 1e-6, and vCenter = (py + 0.5f) / hiH with hiH = fbH * 2 * ss always even (RaytraceRenderer.cs:86-87,
+                // 204-205) misses 0.5 by >= 0.5 / hiH; every other caller of Scene.Hit passes (0, 0).  The wire colour is always WireColor.
                 if (within && is_wire_on_face(g, h.p, ix, iy, iz, axis)) wire_black = true;
             }
         }
