@@ -1753,9 +1753,13 @@ void snapshot_frame(ycge_ctx *c, FrameState &fs)
 // see a smaller maximum over their lanes, so the heavier classes are split, deeper the fewer blocks a rank holds.  Per-rank trace on
 // config 4, maximum over ranks (profiles/rank_times.py): 8 ranks 0.359 -> 0.289 ms, 4 ranks 0.381 -> 0.351, 2 ranks 0.485 -> 0.441;
 // one class deeper loses at every rank count (8 ranks 55543000: 0.356; 4 ranks 44432000: 0.420; 2 ranks 44320000: 0.471).
-void schedule_policy(const ycge_ctx *c, uint32_t &policy, uint32_t &split_top)
+// With three or more traces of the tile-resident ring in flight the slots are no longer plentiful - the traces fill each other's tails - and
+// the shallow cut wins at every rank count (8 ranks, ring of 4, one-GPU emulation: 033220000 0.147-0.172 ms a rank-frame, 044433000
+// 0.186-0.20, unsplit 0.17-0.23; profiles/r04/g_resident_ring_emulation.txt).
+void schedule_policy(const ycge_ctx *c, uint32_t &policy, uint32_t &split_top, int resident_ring = 0)
 {
-    const uint32_t world_policy = c->cfg.world_size >= 8 ? 044433000u : c->cfg.world_size >= 4 ? 044320000u : c->cfg.world_size >= 2 ? 033220000u : 0u;
+    const uint32_t world_policy = (resident_ring >= 3 && c->cfg.world_size >= 2) ? 033220000u
+                                : c->cfg.world_size >= 8 ? 044433000u : c->cfg.world_size >= 4 ? 044320000u : c->cfg.world_size >= 2 ? 033220000u : 0u;
     policy = c->knobs.split_set ? c->knobs.split_policy : world_policy;
     // ... or, on a whole frame, the split_top blocks at the head of the schedule whatever their class (k_cost_scatter)
     split_top = (c->knobs.split_set || policy || c->knobs.split_top <= 0) ? 0u : ((uint32_t)c->knobs.split_top & 0xffffu) | ((uint32_t)c->knobs.split_top_lg << 16);
@@ -2875,7 +2879,7 @@ int ycge_trace_tiles_resident(ycge_ctx *c, void *d_halo_send, void *hip_stream, 
         // every `every`-th frame only: which blocks run long is a property of the image region, and a rank's host thread has ~25 driver
         // calls a frame to make as it is
         uint32_t policy, split_top;
-        schedule_policy(c, policy, split_top);
+        schedule_policy(c, policy, split_top, K);
         uint32_t skip = 0;
         for (int a = 1; a < K; a++) skip |= 1u << ((cost_slot + (uint32_t)a) % RC);
         const int tb = c->res_order_next;
@@ -3005,21 +3009,33 @@ int ycge_debug_resident_loop(ycge_ctx *c, int32_t frames, double *period_ms, dou
         LOOP_TRY(hipMemset(send[k], 0, sb)); LOOP_TRY(hipMemset(recv[k], 0, rb));
     }
     std::deque<int> issued;
+    // YCGE_RES_LOOP_COMM=slot: exchange and resolve of a frame on the stream of ITS ring slot (the next trace there waits for that resolve
+    // anyway) - K streams in all instead of K + 1: no stream shares a hardware queue with a trace while K <= 4
+    const char *ce = getenv("YCGE_RES_LOOP_COMM");
+    const bool comm_on_slot = ce && ce[0] == 's';
     auto resolve = [&](int k) -> int {
-        if (hipStreamWaitEvent(comm, evt[k], 0) != hipSuccess) return YCGE_ERR_DEVICE;
-        if (hipMemcpyAsync(recv[k], send[k], sb < rb ? sb : rb, hipMemcpyDeviceToDevice, comm) != hipSuccess) return YCGE_ERR_DEVICE;      // stands in for the all-to-all
-        const int r2 = ycge_resolve_tiles_resident(c, recv[k], hist[k], comm, nullptr);
+        hipStream_t cs = comm_on_slot ? st[k] : comm;
+        if (!comm_on_slot && hipStreamWaitEvent(cs, evt[k], 0) != hipSuccess) return YCGE_ERR_DEVICE;
+        if (hipMemcpyAsync(recv[k], send[k], sb < rb ? sb : rb, hipMemcpyDeviceToDevice, cs) != hipSuccess) return YCGE_ERR_DEVICE;      // stands in for the all-to-all
+        const int r2 = ycge_resolve_tiles_resident(c, recv[k], hist[k], cs, nullptr);
         if (r2 != YCGE_OK) return r2;
-        return hipEventRecord(evr[k], comm) == hipSuccess ? YCGE_OK : YCGE_ERR_DEVICE;
+        return hipEventRecord(evr[k], cs) == hipSuccess ? YCGE_OK : YCGE_ERR_DEVICE;
     };
     int64_t i = 0;
+    // YCGE_RES_LOOP_TIMELINE=1: timing events around the last 16 frames' traces (begin: behind the stream's waits; end: behind the halo
+    // gather), printed relative to the first - how the K traces in flight really lie to each other
+    const bool timeline = getenv("YCGE_RES_LOOP_TIMELINE") != nullptr;
+    std::vector<hipEvent_t> tl_b, tl_e;
     auto frame = [&]() -> int {
         const int k = (int)(i++ % K);
         if ((int)issued.size() == K) { const int r2 = resolve(issued.front()); issued.pop_front(); if (r2 != YCGE_OK) return r2; }
         if (hipStreamWaitEvent(st[k], evr[k], 0) != hipSuccess) return YCGE_ERR_DEVICE;
+        const bool mark = timeline && i > 12 + (int64_t)frames - 16;
+        if (mark) { hipEvent_t eb = nullptr; if (hipEventCreate(&eb) != hipSuccess || hipEventRecord(eb, st[k]) != hipSuccess) return YCGE_ERR_DEVICE; tl_b.push_back(eb); }
         const int r2 = ycge_trace_tiles_resident(c, send[k], st[k], nullptr);
         if (r2 != YCGE_OK) return r2;
         issued.push_back(k);
+        if (mark) { hipEvent_t ee = nullptr; if (hipEventCreate(&ee) != hipSuccess || hipEventRecord(ee, st[k]) != hipSuccess) return YCGE_ERR_DEVICE; tl_e.push_back(ee); }
         return hipEventRecord(evt[k], st[k]) == hipSuccess ? YCGE_OK : YCGE_ERR_DEVICE;
     };
     auto drain = [&]() -> int { while (!issued.empty()) { const int r2 = resolve(issued.front()); issued.pop_front(); if (r2 != YCGE_OK) return r2; } return YCGE_OK; };
@@ -3037,6 +3053,13 @@ int ycge_debug_resident_loop(ycge_ctx *c, int32_t frames, double *period_ms, dou
 #undef LOOP_TRY
     *issue_ms = std::chrono::duration<double, std::milli>(t1 - t0).count() / frames;
     *period_ms = std::chrono::duration<double, std::milli>(t2 - t0).count() / frames;
+    for (size_t q = 0; q < tl_b.size() && q < tl_e.size(); q++) {
+        float b = 0.0f, e2 = 0.0f;
+        (void)hipEventElapsedTime(&b, tl_b[0], tl_b[q]); (void)hipEventElapsedTime(&e2, tl_b[0], tl_e[q]);
+        fprintf(stderr, "  trace %2zu (slot %zu): begin %7.3f ms  end %7.3f ms  duration %6.3f\n", q, q % (size_t)K, b, e2, e2 - b);
+    }
+    for (hipEvent_t ev : tl_b) (void)hipEventDestroy(ev);
+    for (hipEvent_t ev : tl_e) (void)hipEventDestroy(ev);
     cleanup();
     return YCGE_OK;
 }
