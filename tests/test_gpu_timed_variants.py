@@ -764,3 +764,136 @@ def test_world_file_to_attached_chunks_against_oracle(product_lib, oracle, tmp_p
         _assert_frame(o, g, f"vg01 world frame {f}")
     assert (g.read(abi.BUF_SKY_MASK) == 0).mean() > 0.3
     o.close(); g.close()
+
+
+def _solid_box_of(obj):
+    """the box of an object's solid voxels as ycge_scene_upload derives it (GGrid::solid_lo / solid_hi: one voxel of margin); None for a
+    grid without a solid voxel, everything for any other object"""
+    from yetanotherconsolegameengine_amd.scene import VolumeGrid
+    f32 = np.float32
+    if not isinstance(obj, VolumeGrid):
+        return np.full(3, -np.inf, f32), np.full(3, np.inf, f32)
+    solid = np.argwhere(np.asarray(obj.Cells)[..., 0] != 0)
+    if solid.size == 0:
+        return None
+    mn, vs = np.array(obj.MinCorner, f32), np.array(obj.VoxelSize, f32)
+    return mn + (solid.min(0) - 1).astype(f32) * vs, mn + (solid.max(0) + 2).astype(f32) * vs
+
+
+WALK_LEAF_NODES = 6          # YCGE_WALK_LEAF_NODES
+
+
+def _check_walk_tree(g, sc):
+    """SceneDev::walk_nodes against the device's own scene nodes: the copies, the rewritten references, every leaf opened into nodes that
+    hold its objects in index order under the unions of their solid-voxel boxes, grid_owner"""
+    import ctypes as C
+    from yetanotherconsolegameengine_amd.scene import VolumeGrid
+    f = g.L.ycge_debug_read_walk_tree; f.restype = C.c_int
+    f.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p, C.c_int32, C.c_void_p]
+    grids = [k for k, o in enumerate(sc.Objects) if isinstance(o, VolumeGrid)]          # flatten() numbers grids in object order
+    cap = max(1, len(sc.Objects))
+    nodes = np.zeros((cap, 16), np.uint32); walk = np.zeros((cap * (1 + 2 * WALK_LEAF_NODES), 16), np.uint32)
+    owner = np.zeros(max(1, len(grids)), np.int32); root = np.zeros(2, np.uint32)
+    n = f(g.ctx, nodes.ctypes.data, walk.ctypes.data, cap, owner.ctypes.data, len(grids), root.ctypes.data)
+    assert n >= 0, n
+    if n == 0:
+        return 0
+    assert list(owner[:len(grids)]) == grids
+    assert root[0] == (5 << 29) | 0
+    leaf = np.asarray(g.accel(abi.ACCEL_SCENE_LEAF_INDEX)).view(np.int32).ravel()
+    boxes = [_solid_box_of(o) for o in sc.Objects]
+    grid_no = {k: i for i, k in enumerate(grids)}
+    wf = walk.view(np.float32)
+    PLANES = {0: ([0, 1, 2], [4, 5, 3]), 1: ([6, 7, 8], [10, 11, 9])}          # GNode: (x y)(z Z)(X Y) per child
+
+    def ref_of(obj):
+        return (6 << 29) | grid_no[obj] if obj in grid_no else (4 << 29) | obj
+
+    def objects_below(ref):
+        """objects under a walk reference in visit order (left first), checking every leaf node on the way"""
+        kind, pay = ref >> 29, ref & 0x1FFFFFFF
+        if kind == 6: return [grids[pay]]
+        if kind == 4: return [pay]
+        assert kind == 5 and pay >= n, ref
+        assert walk[pay, 14] == 1          # left child first
+        out = []
+        for side in range(2):
+            below = objects_below(int(walk[pay, 12 + side]))
+            parts = [boxes[o] for o in below if boxes[o] is not None]
+            lo_i, hi_i = PLANES[side]
+            assert parts, (pay, side)
+            assert (wf[pay, lo_i] == np.min([p[0] for p in parts], 0)).all() and (wf[pay, hi_i] == np.max([p[1] for p in parts], 0)).all(), (pay, side)
+            out += below
+        return out
+
+    opened = 0
+    for i in range(n):
+        assert (walk[i, :12] == nodes[i, :12]).all() and walk[i, 14] == 0
+        for side in range(2):
+            ref, wref = int(nodes[i, 12 + side]), int(walk[i, 12 + side])
+            kind, pay = ref >> 29, ref & 0x1FFFFFFF
+            if kind == 0:
+                assert wref == (5 << 29) | pay
+                continue
+            assert kind == 1
+            objs = [int(leaf[(pay >> 3) + k]) for k in range(pay & 7)]
+            keep = [o for o in objs if boxes[o] is not None] or objs[:1]
+            if len(keep) == 1:
+                assert wref == ref_of(keep[0]), (i, side)
+            else:
+                assert wref == (5 << 29) | (n + (2 * i + side) * WALK_LEAF_NODES), (i, side)
+                assert objects_below(wref) == keep, (i, side)
+                opened += 1
+    return n, opened
+
+
+def test_the_walk_tree_of_a_voxel_world(product_lib, oracle, monkeypatch):
+    """SceneDev::walk_nodes (k_scene_walk, ycge_bvh_build.hip): the scene tree with every leaf opened into nodes over the solid-voxel boxes
+    of its objects, built on the device from whichever tree is installed (host builder at upload; device builder after
+    ycge_scene_update_objects on a world of >= 1400 chunks) - and what it is for: frames walked down it and down the scene tree
+    (YCGE_NO_WALK_TREE) are the same bits, which the oracle parity of every voxel test then covers.  A world with other objects among
+    the grids (their boxes are everything; they keep the object step), grids of air only (left out of a leaf that has others), a
+    fractional lattice."""
+    from yetanotherconsolegameengine_amd.scene import Material, PointLight, Scene, Solid, Sphere, VolumeGrid, vec3
+    monkeypatch.delenv("YCGE_PATH", raising=False)
+    # (1) the small voxel world, host-built tree
+    sc, w, h, ss, pose = scenes.config_scene(5, small=True, t01=0.5)
+    g = RaytraceRenderer(sc, 96, 27, pose["fov"], 2)
+    n, opened = _check_walk_tree(g, sc)
+    assert n > 0 and opened > 0
+    g.close()
+    # (2) grids among other objects, all-air grids, voxels of 0.3 on an uneven corner
+    look = lambda m, meta: Material(vec3(0.2 + 0.1 * m, 0.5, 0.3))
+    rng = np.random.default_rng(5)
+    s = Scene()
+    s.IsVolumeScene = True
+    for k in range(40):
+        cells = np.zeros((8, 8, 8, 2), np.int32)
+        if k % 7 != 3 and k not in (16, 17, 18, 19):
+            m = rng.integers(0, 8, (rng.integers(1, 6), 3)); cells[m[:, 0], m[:, 1], m[:, 2], 0] = 1 + k % 3
+        s.Add(VolumeGrid(cells, vec3(0.37 + 2.4 * (k % 8), 0.11 + 2.4 * (k // 8), -20.0 + 0.3 * (k % 5)), vec3(0.3, 0.3, 0.3), look))
+    for k in range(6):
+        s.Add(Sphere(vec3(1.0 + 3.0 * k, 5.0, -14.0), 0.6, Solid(vec3(0.7, 0.3, 0.3))))
+    s.Lights.append(PointLight(vec3(8.0, 30.0, 0.0), vec3(1, 1, 1), 3000.0))
+    for ps in (dict(pos=(9.0, 6.0, 6.0), yaw=0.0, pitch=-0.1, fov=60.0), dict(pos=(9.0, 5.0, -19.0), yaw=1.5707964, pitch=0.0, fov=70.0)):
+        o, g = pu.run_pair(oracle, s, 96, 27, 2, ps, frames=2, count=False)
+        _assert_frame(o, g, "grids among spheres")
+        n, opened = _check_walk_tree(g, s)
+        assert n > 0 and opened > 0
+        monkeypatch.setenv("YCGE_NO_WALK_TREE", "1")
+        g2 = RaytraceRenderer(s, 96, 27, ps["fov"], 2)
+        g2.SetCamera(ps["pos"], ps["yaw"], ps["pitch"])
+        assert _check_walk_tree(g2, s) == 0
+        for _ in range(2): g2.TryFlipAndBlit()
+        for which in (abi.BUF_CURRENT_HDR, abi.BUF_G_ALBEDO, abi.BUF_G_NORMAL, abi.BUF_G_DEPTH, abi.BUF_SKY_MASK, abi.BUF_TAA_HISTORY):
+            assert pu.bits_equal(g.read(which), g2.read(which)), which
+        monkeypatch.delenv("YCGE_NO_WALK_TREE")
+        o.close(); g.close(); g2.close()
+    # (3) the full world: >= 1400 chunks, so ycge_scene_update_objects builds the tree on the device
+    sc, w, h, ss, pose = scenes.config_scene(5, t01=0.5)
+    flat = flatten(sc)
+    g = RaytraceRenderer(flat, 96, 27, pose["fov"], 2)
+    n_host, opened_host = _check_walk_tree(g, sc)
+    g.UpdateObjects(flat)
+    assert _check_walk_tree(g, sc) == (n_host, opened_host) and n_host > 300
+    g.close()

@@ -369,9 +369,91 @@ __global__ __launch_bounds__(1024) void k_scene_bvh_build(const float *__restric
     }
 }
 
+
+// ---------------------------------------------------------------------------------- SceneDev::walk_nodes
+// The walk tree of a world of voxel grids (ycge_device.h, SceneDev::walk_nodes) from whichever scene tree is installed: entry i < n is
+// scene node i with its child references rewritten, and each leaf child of 2..7 objects gets the YCGE_WALK_LEAF_NODES entries from
+// n + (2 i + side) * YCGE_WALK_LEAF_NODES on for its own nodes (a leaf of k objects uses k - 1).  One thread per (node, side): a leaf's
+// nodes depend on its own objects only.
+struct SolidBox { float lo[3], hi[3]; };
+__device__ __forceinline__ SolidBox solid_of(const GPrim &g)
+{
+    const float inf = __builtin_huge_valf();
+    SolidBox b;
+    if (g.type == 10) { for (int a = 0; a < 3; a++) { b.lo[a] = g.p[a]; b.hi[a] = g.p[3 + a]; } }
+    else { for (int a = 0; a < 3; a++) { b.lo[a] = -inf; b.hi[a] = inf; } }
+    return b;
+}
+__device__ __forceinline__ uint32_t walk_ref_of(const GPrim &g, uint32_t prim) { return g.type == 10 ? YCGE_REF(REF_GRID, (uint32_t)g.ref) : YCGE_REF(REF_PRIM, prim); }
+__global__ __launch_bounds__(256) void k_scene_walk(const GNode *__restrict__ nodes, int n_inner, const uint32_t *__restrict__ leaf_prims, const GPrim *__restrict__ prims,
+                                                    GNode *__restrict__ walk)
+{
+    const int t = (int)(blockIdx.x * blockDim.x + threadIdx.x);
+    if (t >= 2 * n_inner) return;
+    const int i = t >> 1, side = t & 1;
+    const GNode src = nodes[i];
+    const uint32_t ref = side ? src.rref : src.lref;
+    uint32_t out_ref;
+    if (YCGE_REF_KIND(ref) == REF_SCENE_NODE) out_ref = YCGE_REF(REF_WALK_NODE, YCGE_REF_PAYLOAD(ref));
+    else {
+        const uint32_t pay = YCGE_REF_PAYLOAD(ref), start = pay >> 3, count = pay & 7u;
+        // the leaf's objects in index order, grids without a solid voxel left out (the first one stays if nothing else does)
+        uint32_t obj[7]; int m = 0;
+        for (uint32_t k = 0; k < count; k++) {
+            const uint32_t pi = leaf_prims[start + k];
+            const GPrim &g = prims[pi];
+            if (g.type == 10 && g.p[3] < g.p[0]) continue;
+            obj[m++] = pi;
+        }
+        if (m == 0) obj[m++] = leaf_prims[start];
+        if (m == 1) out_ref = walk_ref_of(prims[obj[0]], obj[0]);
+        else {
+            // halve [a, b) until single: the node of a range is created before those of its halves, left half first
+            const uint32_t base = (uint32_t)n_inner + (uint32_t)t * YCGE_WALK_LEAF_NODES;
+            out_ref = YCGE_REF(REF_WALK_NODE, base);
+            int ra[8], rb[8], rslot[8], top = 0, next_slot = 1;
+            ra[0] = 0; rb[0] = m; rslot[0] = 0; top = 1;
+            while (top > 0) {
+                top--;
+                const int a = ra[top], b = rb[top], slot = rslot[top], mid = a + (b - a + 1) / 2;
+                const float inf = __builtin_huge_valf();
+                SolidBox L = {{inf, inf, inf}, {-inf, -inf, -inf}}, R = L;
+                for (int k = a; k < b; k++) {
+                    const SolidBox sb = solid_of(prims[obj[k]]);
+                    SolidBox &u = k < mid ? L : R;
+                    if (sb.hi[0] < sb.lo[0]) continue;
+                    for (int ax = 0; ax < 3; ax++) { u.lo[ax] = fminf(u.lo[ax], sb.lo[ax]); u.hi[ax] = fmaxf(u.hi[ax], sb.hi[ax]); }
+                }
+                GNode g;
+                g.lmin_x = L.lo[0]; g.lmin_y = L.lo[1]; g.lmin_z = L.lo[2]; g.lmax_x = L.hi[0]; g.lmax_y = L.hi[1]; g.lmax_z = L.hi[2];
+                g.rmin_x = R.lo[0]; g.rmin_y = R.lo[1]; g.rmin_z = R.lo[2]; g.rmax_x = R.hi[0]; g.rmax_y = R.hi[1]; g.rmax_z = R.hi[2];
+                if (mid - a == 1) g.lref = walk_ref_of(prims[obj[a]], obj[a]);
+                else { g.lref = YCGE_REF(REF_WALK_NODE, base + (uint32_t)next_slot); ra[top] = a; rb[top] = mid; rslot[top] = next_slot++; top++; }
+                if (b - mid == 1) g.rref = walk_ref_of(prims[obj[mid]], obj[mid]);
+                else { g.rref = YCGE_REF(REF_WALK_NODE, base + (uint32_t)next_slot); ra[top] = mid; rb[top] = b; rslot[top] = next_slot++; top++; }
+                g.pad[0] = 1u; g.pad[1] = 0u;
+                walk[base + (uint32_t)slot] = g;
+            }
+        }
+    }
+    // this side of the scene node's copy: planes and the other reference are written by the two threads of the node between them
+    GNode *dst = walk + i;
+    if (side == 0) { dst->lmin_x = src.lmin_x; dst->lmin_y = src.lmin_y; dst->lmin_z = src.lmin_z; dst->lmax_z = src.lmax_z; dst->lmax_x = src.lmax_x; dst->lmax_y = src.lmax_y; dst->lref = out_ref; dst->pad[0] = 0u; }
+    else { dst->rmin_x = src.rmin_x; dst->rmin_y = src.rmin_y; dst->rmin_z = src.rmin_z; dst->rmax_z = src.rmax_z; dst->rmax_x = src.rmax_x; dst->rmax_y = src.rmax_y; dst->rref = out_ref; dst->pad[1] = 0u; }
+}
+
 } // namespace ycge
 
 extern "C" {
+
+// walk: n_inner * (1 + 2 * YCGE_WALK_LEAF_NODES) records of 64 bytes (SceneDev::walk_nodes)
+int ycge_launch_scene_walk(const void *nodes, int n_inner, const uint32_t *leaf_prims, const void *prims, void *walk, hipStream_t stream)
+{
+    if (n_inner <= 0) return 0;
+    hipLaunchKernelGGL(ycge::k_scene_walk, dim3((unsigned)((2 * n_inner + 255) / 256)), dim3(256), 0, stream, (const ycge::GNode *)nodes, n_inner, leaf_prims, (const ycge::GPrim *)prims,
+                       (ycge::GNode *)walk);
+    return (int)hipGetLastError();
+}
 
 size_t ycge_bvh_build_scratch_bytes(int n) { return (size_t)(2 * n + 2) * sizeof(ycge::BvhBuildNode); }
 

@@ -32,6 +32,8 @@ enum : uint32_t {
     REF_MESH_NODE = 2u,    // payload = (32-byte unit of the GNode in the mesh arena) << 4
     REF_MESH_LEAF = 3u,    // payload = (unit of the leaf's first GTriPair << 4) | triangles left in the leaf (1..15; MeshBVH.cs:14 caps a leaf at 8)
     REF_PRIM = 4u,         // payload = index into prims
+    REF_WALK_NODE = 5u,    // payload = index into walk_nodes (SceneDev::walk_nodes)
+    REF_GRID = 6u,         // payload = index into grids (walk tree only)
     REF_NONE = 7u
 };
 #define YCGE_REF(kind, payload) (((uint32_t)(kind) << 29) | (uint32_t)(payload))
@@ -40,6 +42,7 @@ enum : uint32_t {
 #define YCGE_REF_NONE_VALUE 0xffffffffu
 
 // device-side build of the scene-level BVH (ycge_bvh_build.hip): what the kernel hands back to the host
+#define YCGE_WALK_LEAF_NODES 6          // walk tree: entries set aside per leaf child (a leaf holds at most 7 objects: 6 nodes)
 #define YCGE_BVH_DEV_MAX_ITEMS 2560     // one workgroup keeps the item order and its node queue in LDS
 #define YCGE_BVH_DEV_MIN_ITEMS_DEFAULT 1400     // below this ycge_scene_update_objects builds on the host: the measured crossover of the two builders
 struct BvhBuildResult {
@@ -59,7 +62,7 @@ struct alignas(16) GNode {
     float lmax_x, lmax_y, rmin_x, rmin_y;
     float rmin_z, rmax_z, rmax_x, rmax_y;
     uint32_t lref, rref;        // child references
-    uint32_t pad[2];
+    uint32_t pad[2];            // walk tree (SceneDev::walk_nodes): pad[0] bit 0 = left child first whatever the distances
 };
 static_assert(sizeof(GNode) == 64, "GNode must be 64 B");
 
@@ -216,6 +219,22 @@ struct SceneDev {
     // occlusion queries against a mesh breadth-first from a shared work list (mesh_anyhit_bfs, ycge_anyhit.hip.h) when at most this many lanes
     // of the wavefront ask (YCGE_BFS; 0: the ordered walk serves them all)
     uint32_t anyhit_bfs;
+    // The WALK TREE of a world of voxel grids (timed kernels; k_scene_walk, ycge_bvh_build.hip): the scene nodes again, every leaf of
+    // 2..7 objects opened into nodes of its own - so that one kind of step, a node visit, serves the whole way down to a grid.
+    //   [0, n)      the scene nodes, child boxes as they are (entry order and the entry test are the reference's), child references
+    //               rewritten: node j -> REF_WALK_NODE j; a leaf of one object -> that object; a leaf of more -> its first leaf node
+    //   [n, ...)    leaf nodes: the leaf's objects in index order, halved until single; a child's box is the union of the SOLID-voxel
+    //               boxes below it (GGrid::solid_lo / solid_hi; everything for an object that is no grid), pad[0] bit 0 = "left child
+    //               first" - a leaf's objects are asked in index order (BVH.cs:139-149), not by distance.
+    // A grid is referenced as REF_GRID (its index); grid_owner[grid] = the object that holds it (hit_prim).  Grids without a solid
+    // voxel are left out where a leaf has others.  What the walk skips is what the object step would cull one by one
+    // (solid_box_missed); visit order, hence every hit, is unchanged.  A ray is sent down this tree only if it leaves the scene's
+    // root box before walk_t_limit (the smallest GGrid::cull_t_limit: every verdict below holds), else down scene_nodes as before.
+    // Null: no walk tree (no grid, the root is a leaf, two objects share a grid, YCGE_NO_WALK_TREE).
+    const GNode *walk_nodes;
+    const int32_t *grid_owner;
+    uint32_t walk_root_ref;
+    float walk_t_limit;
     unsigned long long *dbg_counters;   // profiling builds (-DYCGE_DBG_COOPSTAT): statistics of the cooperative walk, else unused
 };
 

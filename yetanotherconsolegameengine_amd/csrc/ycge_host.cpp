@@ -30,6 +30,7 @@ int ycge_launch_trace(const ycge::SceneDev *S, const ycge::FrameParams *P, const
                       hipStream_t stream);
 int ycge_launch_wavefront(const ycge::SceneDev *S, const ycge::FrameParams *P, const ycge::TraceOut *O, void *const bufs[7], int rounds,
                           int has_grid, int flat, int count, int persistent_waves, hipStream_t stream);
+int ycge_launch_scene_walk(const void *nodes, int n_inner, const uint32_t *leaf_prims, const void *prims, void *walk, hipStream_t stream);
 int ycge_launch_order_blocks(uint32_t *cost, uint32_t n, uint32_t policy, uint32_t split_top, uint32_t fan_class, uint32_t fan_cap, uint32_t next_slot, uint32_t skip_mask, uint32_t *order_ws,
                              uint32_t *order, hipStream_t stream, int small_groups = 0, uint32_t n_frames = 0);
 int ycge_launch_taa_tiles(const ycge::TaaParams *T, const ycge::FrameParams *P, const float *current, const float *normal, const float *depth, const uint8_t *sky,
@@ -141,6 +142,7 @@ struct Knobs {
     int scene_bvh_device_min = YCGE_BVH_DEV_MIN_ITEMS_DEFAULT;   // YCGE_SCENE_BVH_DEVICE_MIN: fewer objects than this are built on the host (measured crossover, profiles/r02/f2_update_objects_timing.txt)
     int res_sched_every = 0;         // YCGE_RES_SCHED_EVERY: the tile-resident ring builds a new schedule behind every n-th frame (0 = the ring's depth)
     int bfs_rays = 0;                // YCGE_BFS=<n>: a wavefront's occlusion queries against a mesh go breadth-first from one shared work list when at most n of its lanes ask (mesh_anyhit_bfs; 0 = never, 64 = always)
+    bool no_walk_tree = false;       // YCGE_NO_WALK_TREE: voxel worlds are walked down the scene tree, leaves and object steps and all (A/B of SceneDev::walk_nodes)
     bool no_coop = false;            // YCGE_NO_COOP: no treelets are built, sparse wavefronts keep the regular walk (A/B of the cooperative walk)
     bool exposure_serial = false;    // YCGE_EXPOSURE_SERIAL: the one-lane chain instead of the chunked exact evaluation
     void read()
@@ -148,6 +150,7 @@ struct Knobs {
         auto geti = [](const char *n, int dflt) { const char *e = getenv(n); return e ? atoi(e) : dflt; };
         if (const char *e = getenv("YCGE_PATH")) path_policy = e[0] == 'w' ? 1 : e[0] == 'm' ? 2 : 0;
         xcd_strips = getenv("YCGE_XCD_STRIPS") != nullptr; generic_walk = getenv("YCGE_GENERIC_WALK") != nullptr;
+        no_walk_tree = getenv("YCGE_NO_WALK_TREE") != nullptr;
         no_lpt = getenv("YCGE_NO_LPT") != nullptr; no_refill = getenv("YCGE_NO_REFILL") != nullptr;
         if (const char *e = getenv("YCGE_WAVE_PROF")) wave_prof_stage = e[0] == 'e' ? 1 : e[0] == 'm' ? 2 : 0;
         refill_steps = geti("YCGE_REFILL", YCGE_REFILL_STEPS_DEFAULT);
@@ -365,6 +368,9 @@ struct ycge_ctx {
     bool have_scene = false;
     SceneDev sd{};
     DevBuf<GNode> d_scene_nodes;
+    DevBuf<GNode> d_walk_nodes;        // SceneDev::walk_nodes (worlds of voxel grids): the scene nodes + YCGE_WALK_LEAF_NODES entries per leaf child
+    DevBuf<int32_t> d_grid_owner;      // SceneDev::grid_owner
+    int walk_scene_nodes = 0;          // scene nodes the walk tree was made from (0: SceneDev::walk_nodes is null)
     DevBuf<uint8_t> d_mesh_arena;
     DevBuf<uint32_t> d_scene_leaf;
     DevBuf<GPrim> d_prims;
@@ -878,7 +884,7 @@ void ycge_destroy(ycge_ctx *c)
     c->post_progress.release();
     c->alt_post.release();
     c->wf_q0.release(); c->wf_q1.release(); c->wf_hit.release(); c->wf_lq.release(); c->wf_seg.release(); c->wf_counts.release(); c->tile_order.release(); c->block_cost.release(); c->block_order.release(); c->order_ws.release(); c->stack_spill.release(); c->path_stack.release();
-    c->d_scene_nodes.release(); c->d_mesh_arena.release(); c->d_scene_leaf.release(); c->d_prims.release();
+    c->d_scene_nodes.release(); c->d_walk_nodes.release(); c->d_grid_owner.release(); c->d_mesh_arena.release(); c->d_scene_leaf.release(); c->d_prims.release();
     c->d_bvh_items.release(); c->d_bvh_scratch.release(); c->d_bvh_ref.release(); c->d_bvh_res.release();
     c->d_materials.release(); c->d_meshes.release(); c->d_grids.release(); c->d_cells.release(); c->d_lut.release(); c->d_lights.release(); c->d_tex_pixels.release(); c->d_tex_info.release();
     for (int k = 0; k < 2; k++) { if (c->tex_stage[k]) (void)hipHostFree(c->tex_stage[k]); if (c->tex_stage_ev[k]) (void)hipEventDestroy(c->tex_stage_ev[k]); }
@@ -994,6 +1000,9 @@ struct ObjectsHost {
     uint32_t scene_root = YCGE_REF_NONE_VALUE;
     float root_min[3] = {0, 0, 0}, root_max[3] = {0, 0, 0};
     int wf_rounds = 2, spill_levels = 0;
+    std::vector<int32_t> grid_owner;       // per grid of the last upload: the object that holds it (-1: none), SceneDev::grid_owner
+    bool grid_owner_unique = true;         // false: two objects hold the same grid - no walk tree
+    float walk_t_limit = 0.0f;             // the smallest GGrid::cull_t_limit of the grids in Objects
 };
 
 // Scene.Objects as device records + what Scene.RebuildBVH gets from every object's TryGetBounds (BVH.cs:32-53); no tree yet
@@ -1002,6 +1011,7 @@ int flatten_objects(ycge_ctx *c, const ycge_prim *prims, int n_prims, ObjectsHos
     std::vector<GPrim> &gprims = oh.gprims;
     gprims.assign(n_prims, GPrim{});
     items.resize(n_prims);
+    oh.grid_owner.assign(c->grid_solid.size(), -1); oh.grid_owner_unique = true; oh.walk_t_limit = HUGE_VALF;
     for (int i = 0; i < n_prims; i++) {
         const ycge_prim &q = prims[i];
         GPrim &g = gprims[i];
@@ -1049,6 +1059,9 @@ int flatten_objects(ycge_ctx *c, const ycge_prim *prims, int n_prims, ObjectsHos
         case YCGE_PRIM_VOLUME_GRID:
             if (q.ref < 0 || q.ref >= (int)c->grid_bounds.size()) return c->fail(YCGE_ERR_INVALID_ARG, "prim %d: grid ref out of range", i);
             for (int k = 0; k < 7; k++) g.p[k] = c->grid_solid[q.ref][k];       // box of the grid's solid voxels + how far along a ray it may be trusted (grid_cull in the walk)
+            if (oh.grid_owner[(size_t)q.ref] >= 0) oh.grid_owner_unique = false;
+            oh.grid_owner[(size_t)q.ref] = i;
+            oh.walk_t_limit = cs_min(oh.walk_t_limit, c->grid_solid[q.ref][6]);
             break;
         default: return c->fail(YCGE_ERR_INVALID_ARG, "prim %d: unknown type %d", i, q.type);
         }
@@ -1097,6 +1110,28 @@ int build_scene_tree_host(ycge_ctx *c, const BoundsSoA &items, ObjectsHost &oh)
     return YCGE_OK;
 }
 
+// SceneDev::walk_nodes: the walk tree of a world of voxel grids, from the tree and the object records now on the device (k_scene_walk,
+// ycge_bvh_build.hip) - whichever builder made the tree.  None (null) without a grid, when the root is a leaf, when two objects hold
+// the same grid (grid_owner would be ambiguous) and under YCGE_NO_WALK_TREE.
+int install_walk_tree(ycge_ctx *c, const ObjectsHost &oh, int n_inner, uint32_t scene_root)
+{
+    SceneDev &sd = c->sd;
+    sd.walk_nodes = nullptr; sd.grid_owner = nullptr; sd.walk_root_ref = YCGE_REF_NONE_VALUE; sd.walk_t_limit = 0.0f; c->walk_scene_nodes = 0;
+    if (!c->has_grid || n_inner <= 0 || c->knobs.no_walk_tree || !oh.grid_owner_unique || YCGE_REF_KIND(scene_root) != REF_SCENE_NODE) return YCGE_OK;
+    HIP_TRY(c, c->d_grid_owner.upload(oh.grid_owner));
+    const size_t n_walk = (size_t)n_inner * (1 + 2 * YCGE_WALK_LEAF_NODES);
+    HIP_TRY(c, c->d_walk_nodes.reserve(n_walk));
+    HIP_TRY(c, hipMemsetAsync(c->d_walk_nodes.p, 0, n_walk * sizeof(GNode), c->stream));
+    const int e = ycge_launch_scene_walk(c->d_scene_nodes.p, n_inner, c->d_scene_leaf.p, c->d_prims.p, c->d_walk_nodes.p, c->stream);
+    if (e != 0) return c->fail(YCGE_ERR_DEVICE, "k_scene_walk launch failed: %s", hipGetErrorString((hipError_t)e));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    sd.walk_nodes = c->d_walk_nodes.p; sd.grid_owner = c->d_grid_owner.p;
+    sd.walk_root_ref = YCGE_REF(REF_WALK_NODE, YCGE_REF_PAYLOAD(scene_root));
+    sd.walk_t_limit = oh.walk_t_limit;
+    c->walk_scene_nodes = n_inner;
+    return YCGE_OK;
+}
+
 int install_objects(ycge_ctx *c, const ObjectsHost &oh)
 {
     HIP_TRY(c, hipSetDevice(c->device));
@@ -1112,7 +1147,7 @@ int install_objects(ycge_ctx *c, const ObjectsHost &oh)
     sd.scene_root_ref = oh.scene_root;
     for (int a = 0; a < 3; a++) { sd.scene_root_min[a] = oh.root_min[a]; sd.scene_root_max[a] = oh.root_max[a]; }
     c->block_order_valid = false; c->flight_order_frame[0] = c->flight_order_frame[1] = c->flight_order_frame[2] = -1;
-    return YCGE_OK;
+    return install_walk_tree(c, oh, (int)oh.scene_nodes.size(), oh.scene_root);
 }
 
 int build_objects(ycge_ctx *c, const ycge_prim *prims, int n_prims, ObjectsHost &oh)
@@ -1157,6 +1192,8 @@ int install_objects_device_built(ycge_ctx *c, ycge_ctx *root, const ObjectsHost 
     sd.scene_root_ref = res.root_ref;
     for (int a = 0; a < 3; a++) { sd.scene_root_min[a] = res.root_min[a]; sd.scene_root_max[a] = res.root_max[a]; }
     c->block_order_valid = false;
+    const int rc3 = install_walk_tree(c, oh, res.n_inner, res.root_ref);
+    if (rc3 != YCGE_OK) return rc3;
     if (c == root) { c->scene_tree_on_device = true; c->dev_tree_nodes = res.n_nodes; c->dev_tree_items = n; c->scene_tree.max_depth = res.max_depth; c->scene_tree.sort_fallbacks = (int32_t)res.sorts; }
     return YCGE_OK;
 }
@@ -1685,6 +1722,23 @@ int ycge_debug_read_batch_stats(ycge_ctx *c, uint64_t out[64])
     HIP_TRY(c, hipMemcpy(v.data(), c->dbg_counters.p, v.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost));
     for (int k = 0; k < 64; k++) { out[k] = 0; for (int i = 0; i < 256; i++) out[k] += v[16 + 8 * 256 * (k >> 3) + 8 * i + (k & 7)]; }
     return YCGE_OK;
+}
+
+// test hook: the scene nodes as the device holds them and SceneDev::walk_nodes (64 B each; the walk tree has 1 + 2 * YCGE_WALK_LEAF_NODES
+// entries per scene node) + grid_owner; returns the scene node count (0: no walk tree), < 0 on an error
+int ycge_debug_read_walk_tree(ycge_ctx *c, void *gnodes_out, void *walk_out, int32_t capacity_nodes, int32_t *grid_owner_out, int32_t n_grids, uint32_t *root_and_limit_out)
+{
+    if (!c || !c->have_scene) return YCGE_ERR_INVALID_ARG;
+    const int n = c->walk_scene_nodes;
+    if (n == 0) return 0;
+    if (!gnodes_out || !walk_out || capacity_nodes < n || !grid_owner_out || n_grids != (int)c->grid_solid.size() || !root_and_limit_out) return YCGE_ERR_INVALID_ARG;
+    HIP_TRY(c, hipSetDevice(c->device));
+    HIP_TRY(c, hipDeviceSynchronize());
+    HIP_TRY(c, hipMemcpy(gnodes_out, c->d_scene_nodes.p, (size_t)n * sizeof(GNode), hipMemcpyDeviceToHost));
+    HIP_TRY(c, hipMemcpy(walk_out, c->d_walk_nodes.p, (size_t)n * (1 + 2 * YCGE_WALK_LEAF_NODES) * sizeof(GNode), hipMemcpyDeviceToHost));
+    HIP_TRY(c, hipMemcpy(grid_owner_out, c->d_grid_owner.p, (size_t)n_grids * sizeof(int32_t), hipMemcpyDeviceToHost));
+    root_and_limit_out[0] = c->sd.walk_root_ref; std::memcpy(&root_and_limit_out[1], &c->sd.walk_t_limit, 4);
+    return n;
 }
 
 int ycge_pin_host_buffer(void *buffer, size_t bytes)

@@ -253,6 +253,12 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu((HAS_GRID &&
     D.step_x = D.step_y = D.step_z = D.last_axis = D.use_mask = 0; D.nx = D.ny = D.nz = D.nbx = D.nby = 1; D.cell_offset = D.mask_lo = D.mask_hi = 0; D.prim = -1;
     uint32_t tile = 0, next_ray = 0, end_ray = 0;          // wave-uniform: the segment being handed out
     bool exhausted = false;
+#if defined(YCGE_DBG_VOXSTAT)
+    unsigned long long vs_rounds = 0, vs_tree = 0, vs_dda = 0, vs_have = 0, vs_t_fill = 0, vs_t_tree = 0, vs_t_dda = 0, vs_mark = __builtin_amdgcn_s_memtime();
+#define YCGE_VS_SECTION(acc) do { const unsigned long long t_ = __builtin_amdgcn_s_memtime(); acc += t_ - vs_mark; vs_mark = t_; } while (0)
+#else
+#define YCGE_VS_SECTION(acc) do { } while (0)
+#endif
     for (;;) {
         // ---- hand new rays to the idle lanes
         unsigned long long idle = __ballot(!have);
@@ -283,11 +289,11 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu((HAS_GRID &&
                 if (S.scene_root_ref != YCGE_REF_NONE_VALUE) {
                     inv = f3(1.0f / d.x, 1.0f / d.y, 1.0f / d.z);
                     sx = inv.x < 0.0f; sy = inv.y < 0.0f; sz = inv.z < 0.0f;
-                    float tn;
+                    float tn, tf;
                     if (COUNT) w.box++;
                     if (box_scene(S.scene_root_min[0], S.scene_root_min[1], S.scene_root_min[2], S.scene_root_max[0], S.scene_root_max[1],
-                                  S.scene_root_max[2], o, inv, tmin, closest, tn))
-                        cur = S.scene_root_ref;
+                                  S.scene_root_max[2], o, inv, tmin, closest, tn, tf))
+                        cur = scene_entry<COUNT, HAS_GRID>(S, tf);
                 }
                 more = cur != YCGE_REF_NONE_VALUE;
                 in_dda = false;
@@ -297,6 +303,10 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu((HAS_GRID &&
             idle = __ballot(!have);
         }
         if (!__any(have)) break;
+        YCGE_VS_SECTION(vs_t_fill);
+#if defined(YCGE_DBG_VOXSTAT)
+        vs_rounds++; vs_have += (unsigned long long)__popcll(__ballot(have)); vs_tree += (unsigned long long)__popcll(__ballot(have && more && !in_dda));
+#endif
         // ---- one round: a bounded number of tree steps for the lanes in the tree, then a bounded number of cell
         // steps for the lanes inside a grid (their state persists in D); lanes that finish are refilled at the top
         if (have && more && !in_dda) {
@@ -307,17 +317,33 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu((HAS_GRID &&
             if (r == TREE_DONE) more = false;
             if (HAS_GRID && r == TREE_AT_GRID) in_dda = dda_begin<COUNT>(S, parked_grid, parked_prim, o, d, inv, tmin, COUNT ? closest : fminf(closest, parked_tend), D, w);
         }
+        YCGE_VS_SECTION(vs_t_tree);
+#if defined(YCGE_DBG_VOXSTAT)
+        vs_dda += (unsigned long long)__popcll(__ballot(in_dda));
+#endif
         if (HAS_GRID && in_dda) {
             bool in = true;
 #pragma unroll 1
             for (int k2 = 0; k2 < round_cell_steps && in; k2++) in = dda_step<COUNT>(S, D, tmin, closest, hit_prim, hit_sub, w);
             in_dda = in;
         }
+        YCGE_VS_SECTION(vs_t_dda);
         if (have && !more && !in_dda) {
             *(float4 *)(B.hit + src) = make_float4(closest, __int_as_float(hit_prim), __int_as_float(hit_sub), 0.0f);
             have = false;
         }
     }
+#if defined(YCGE_DBG_VOXSTAT)
+    if (!COUNT && S.dbg_counters) {      // banks 2 (per-lane sums) and 3 (per-wavefront sums) of the profiling counters
+        unsigned long long *dc = S.dbg_counters + 16 + (size_t)8 * 256 * 2 + (size_t)((blockIdx.x * 2654435761u) >> 24) * 8;
+        for (int i = 0; i < 8; i++) atomicAdd(dc + i, (unsigned long long)w.dbg[i]);
+        if (lane == 0) {
+            dc += 8 * 256;
+            atomicAdd(dc + 0, vs_rounds); atomicAdd(dc + 1, vs_have); atomicAdd(dc + 2, vs_tree); atomicAdd(dc + 3, vs_dda);
+            atomicAdd(dc + 4, vs_t_fill); atomicAdd(dc + 5, vs_t_tree); atomicAdd(dc + 6, vs_t_dda); atomicAdd(dc + 7, 1ull);
+        }
+    }
+#endif
     flush_work<COUNT>(w, O.counters);
 }
 

@@ -51,7 +51,15 @@ struct Work {              // SURVEY 8(d) counters (COUNT variants) + this lane'
     unsigned rays, box, tri, prim, vox;
     unsigned steps;
     unsigned dark;             // COUNT variants: shadow queries towards lights of zero intensity - traced here as the reference does, skipped by the timed kernels
+#if defined(YCGE_DBG_VOXSTAT)
+    unsigned dbg[8];           // profiling build: scene-tree steps by kind (node, leaf, object), objects culled by their solid box, grids asked / entered, cell steps, cell fetches
+#endif
 };
+#if defined(YCGE_DBG_VOXSTAT)
+#define YCGE_VOXSTAT(w, i) ((w).dbg[i]++)
+#else
+#define YCGE_VOXSTAT(w, i) do { } while (0)
+#endif
 
 // wave-level iteration counters (profiling aid, only touched by COUNT variants)
 static __shared__ unsigned int g_wave_iters[16];  // [wave][4 wave-level iteration counters] (profiling aid, COUNT variants)
@@ -258,7 +266,7 @@ __device__ __forceinline__ F3 sample_albedo(const SceneDev &S, F3 albedo, int te
 // rare ray with a zero component takes the reference's own sequence.  `inv` is constant over a query: the test is hoisted out of the
 // walk.  (A scene-level node visit is two of these: config 5 makes 676 M of them a frame.)
 __device__ __forceinline__ bool box_scene(float mnx, float mny, float mnz, float mxx, float mxy, float mxz, F3 o, F3 inv,
-                                          float tmin, float tmax, float &tnear)
+                                          float tmin, float tmax, float &tnear, float &tfar)
 {
     const bool plain = cs_abs(inv.x) < YCGE_INF && cs_abs(inv.y) < YCGE_INF && cs_abs(inv.z) < YCGE_INF;      // false for +-inf and NaN
     if (plain) {
@@ -269,7 +277,7 @@ __device__ __forceinline__ bool box_scene(float mnx, float mny, float mnz, float
         float t_exit = __builtin_fminf(__builtin_fmaxf(ax, bx), __builtin_fminf(__builtin_fmaxf(ay, by), __builtin_fmaxf(az, bz)));
         t_enter = __builtin_fmaxf(t_enter, tmin);
         t_exit = __builtin_fminf(t_exit, tmax);
-        tnear = t_enter;
+        tnear = t_enter; tfar = t_exit;
         return t_exit >= t_enter;
     }
     float en_x = (mnx - o.x) * inv.x, ex_x = (mxx - o.x) * inv.x;
@@ -282,8 +290,14 @@ __device__ __forceinline__ bool box_scene(float mnx, float mny, float mnz, float
     float t_exit = cs_min(ex_x, cs_min(ex_y, ex_z));
     if (t_enter < tmin) t_enter = tmin;
     if (t_exit > tmax) t_exit = tmax;
-    tnear = t_enter;
+    tnear = t_enter; tfar = t_exit;
     return t_exit >= t_enter;
+}
+__device__ __forceinline__ bool box_scene(float mnx, float mny, float mnz, float mxx, float mxy, float mxz, F3 o, F3 inv,
+                                          float tmin, float tmax, float &tnear)
+{
+    float tfar;
+    return box_scene(mnx, mny, mnz, mxx, mxy, mxz, o, inv, tmin, tmax, tnear, tfar);
 }
 // MeshBVH.BoxHitFast, MeshBVH.cs:308-332: sign-indexed slabs.  The C# updates the interval with
 // `if (tEnter > tMin) tMin = tEnter; if (tExit < tMax) tMax = tExit;` — a NaN candidate never wins and the
@@ -540,6 +554,7 @@ __device__ __forceinline__ void grid_dda(const SceneDev &S, int grid_index_, int
 {
     if (COUNT) { w.prim++; prof_tick(2); }
     const GGrid g = S.grids[grid_index_];
+    if (!COUNT && prim_index < 0) prim_index = S.grid_owner[grid_index_];       // (reached through the walk tree, which names grids: SceneDev::walk_nodes)
     float t_solid_out = YCGE_INF;
     if (!COUNT && grid_cull(g, o, inv, tmin, closest, t_solid_out)) return;
     const float min_x = g.min_corner[0], min_y = g.min_corner[1], min_z = g.min_corner[2];
@@ -620,7 +635,17 @@ __device__ __forceinline__ bool dda_begin(const SceneDev &S, int grid_index_, in
                                           DdaState &D, Work &w)
 {
     if (COUNT) { w.prim++; prof_tick(2); }
+    YCGE_VOXSTAT(w, 4);
     const GGrid g = S.grids[grid_index_];
+    if (!COUNT && prim_index < 0) {
+        // reached through the walk tree (SceneDev::walk_nodes), which names the grid and has tested the box of its solid voxels against
+        // the `closest` of that moment: the object it belongs to, and where the ray leaves that box - the walk ends there (the object
+        // step's own test, solid_box_missed, for the rays that come down the scene tree)
+        prim_index = S.grid_owner[grid_index_];
+        float t_solid_out;
+        if (grid_cull(g, o, inv, tmin, closest, t_solid_out)) return false;
+        closest = fminf(closest, t_solid_out);
+    }
     const float min_x = g.min_corner[0], min_y = g.min_corner[1], min_z = g.min_corner[2];
     const float size_x = g.voxel_size[0], size_y = g.voxel_size[1], size_z = g.voxel_size[2];
     const float max_x = min_x + (float)g.nx * size_x, max_y = min_y + (float)g.ny * size_y, max_z = min_z + (float)g.nz * size_z;
@@ -658,6 +683,9 @@ __device__ __forceinline__ bool dda_begin(const SceneDev &S, int grid_index_, in
     D.nx = g.nx; D.ny = g.ny; D.nz = g.nz; D.nbx = (g.nx + 7) >> 3; D.nby = (g.ny + 7) >> 3;
     D.cell_offset = g.cell_offset; D.mask_lo = g.brick_mask_lo; D.mask_hi = g.brick_mask_hi;
     D.prim = prim_index;
+#if defined(YCGE_DBG_VOXSTAT)
+    if (t <= t_exit && t <= tmax) w.dbg[5]++;
+#endif
     return t <= t_exit && t <= tmax;            // the while condition of VolumeGrid.cs:151 before the first cell
 }
 // one pass of the while loop of VolumeGrid.Hit (:151-228).  Returns false when the lane has left the grid (hit or exit).
@@ -670,7 +698,9 @@ __device__ __forceinline__ bool dda_step(const SceneDev &S, DdaState &D, float t
         if (COUNT) w.vox++;
         const int brick = grid_brick(D.ix, D.iy, D.iz, D.nbx, D.nby);
         const unsigned long long mask = ((unsigned long long)D.mask_hi << 32) | D.mask_lo;
+        YCGE_VOXSTAT(w, 6);
         if (!D.use_mask || ((mask >> brick) & 1ull)) {
+            YCGE_VOXSTAT(w, 7);
             if (S.grid_cells[D.cell_offset + (uint32_t)(brick * 512 + morton3_3bits(D.ix, D.iy, D.iz))] != 0) {
                 closest = cs_max(D.t, tmin);
                 hit_prim = D.prim;
@@ -954,8 +984,10 @@ __device__ __forceinline__ int tree_phase(const SceneDev &S, uint32_t &cur, int 
         const uint32_t kind = YCGE_REF_KIND(cur), pay = YCGE_REF_PAYLOAD(cur);
         if (COUNT) prof_tick(0);
         w.steps++;
-        if (kind == REF_MESH_NODE || kind == REF_SCENE_NODE) {
-            const float4 *np = kind == REF_MESH_NODE ? (const float4 *)(S.mesh_arena + (size_t)(pay >> 4) * 32u) : (const float4 *)(S.scene_nodes + pay);
+        if (kind == REF_MESH_NODE || kind == REF_SCENE_NODE || (HAS_GRID && !COUNT && kind == REF_WALK_NODE)) {
+            YCGE_VOXSTAT(w, 0);
+            const float4 *np = kind == REF_MESH_NODE ? (const float4 *)(S.mesh_arena + (size_t)(pay >> 4) * 32u)
+                             : (HAS_GRID && !COUNT && kind == REF_WALK_NODE) ? (const float4 *)(S.walk_nodes + pay) : (const float4 *)(S.scene_nodes + pay);
             const float4 a = np[0], b = np[1], c = np[2], e = np[3];
             float ln, rn;
             bool hl, hr;
@@ -968,8 +1000,10 @@ __device__ __forceinline__ int tree_phase(const SceneDev &S, uint32_t &cur, int 
                 hr = box_scene(b.z, b.w, c.x, c.z, c.w, c.y, o, inv, tmin, closest, rn);
             }
             const uint32_t lref = __float_as_uint(e.x), rref = __float_as_uint(e.y);
+            // (a leaf node of the walk tree: the leaf's objects in index order whatever the distances - GNode::pad[0], zero everywhere else)
+            const bool left_first = (HAS_GRID && !COUNT && kind == REF_WALK_NODE && (__float_as_uint(e.z) & 1u)) || ln < rn;
             if (hl & hr) {
-                if (ln < rn) { st.push(rref, rn); cur = lref; }
+                if (left_first) { st.push(rref, rn); cur = lref; }
                 else { st.push(lref, ln); cur = rref; }
             } else if (hl) cur = lref;
             else if (hr) cur = rref;
@@ -979,18 +1013,24 @@ __device__ __forceinline__ int tree_phase(const SceneDev &S, uint32_t &cur, int 
             cur = YCGE_REF_NONE_VALUE;
         } else if (kind == REF_SCENE_LEAF) {
             const uint32_t start = pay >> 3, count = pay & 7u;
+            YCGE_VOXSTAT(w, 1);
             for (uint32_t i = count - 1; i >= 1; i--) st.push(YCGE_REF(REF_PRIM, S.scene_leaf_prims[start + i]), -YCGE_INF);
             cur = YCGE_REF(REF_PRIM, S.scene_leaf_prims[start]);
+        } else if (HAS_GRID && !COUNT && kind == REF_GRID) {      // walk tree: the ray meets the box of this grid's solid voxels (the node above tested it)
+            cur = YCGE_REF_NONE_VALUE;
+            parked_grid = (int)pay; parked_prim = -1;       // (the cell walk finds the end of the solid box and the owning object itself: dda_begin, grid_dda)
+            return TREE_AT_GRID;
         } else {    // REF_PRIM: objectHit[objId](r, tMin, closest, ...), BVH.cs:139-149
             const float4 *pp = (const float4 *)(S.prims + pay);
             const float4 q0 = pp[0];
             const int type = __float_as_int(q0.x);
             cur = YCGE_REF_NONE_VALUE;
+            YCGE_VOXSTAT(w, 2);
             if (type == 10) {
                 if (HAS_GRID) {
                     // (the object record carries the box of the grid's solid voxels: a grid the ray cannot hit costs this test, not the
                     // rest of the lane's tree steps of the round plus a voxel phase spent waiting - see grid_cull)
-                    if (!COUNT) { const float4 q1 = pp[1], q2 = pp[2]; if (solid_box_missed(q1.x, q1.y, q1.z, q1.w, q2.x, q2.y, q2.z, o, inv, tmin, closest, parked_tend)) continue; }
+                    if (!COUNT) { const float4 q1 = pp[1], q2 = pp[2]; if (solid_box_missed(q1.x, q1.y, q1.z, q1.w, q2.x, q2.y, q2.z, o, inv, tmin, closest, parked_tend)) { YCGE_VOXSTAT(w, 3); continue; } }
                     parked_grid = __float_as_int(q0.z); parked_prim = (int)pay; return TREE_AT_GRID;
                 }
             } else {
@@ -1011,6 +1051,14 @@ __device__ __forceinline__ int tree_phase(const SceneDev &S, uint32_t &cur, int 
             }
         }
     }
+}
+
+// where a query enters the scene: the walk tree of a voxel world (SceneDev::walk_nodes) for a ray of the timed kernels that leaves the
+// root box (at t_far) before the smallest distance any grid's cull verdict holds to, else the scene tree
+template <bool COUNT, bool HAS_GRID>
+__device__ __forceinline__ uint32_t scene_entry(const SceneDev &S, float t_far)
+{
+    return (HAS_GRID && !COUNT && S.walk_nodes && t_far <= S.walk_t_limit) ? S.walk_root_ref : S.scene_root_ref;
 }
 
 template <bool COUNT, bool HAS_GRID, class STK>
@@ -1175,13 +1223,13 @@ __device__ __forceinline__ void traverse(const SceneDev &S, RayQ &q, STK &st, fl
     if (S.scene_root_ref == YCGE_REF_NONE_VALUE) return;
     F3 inv = f3(1.0f / d.x, 1.0f / d.y, 1.0f / d.z);
     const bool sx = inv.x < 0.0f, sy = inv.y < 0.0f, sz = inv.z < 0.0f;
-    float tn;
+    float tn, tf;
     if (COUNT && live) w.box++;
     const bool root_hit = box_scene(S.scene_root_min[0], S.scene_root_min[1], S.scene_root_min[2], S.scene_root_max[0], S.scene_root_max[1],
-                                    S.scene_root_max[2], o, inv, tmin, closest, tn) && live;
+                                    S.scene_root_max[2], o, inv, tmin, closest, tn, tf) && live;
     const bool anyhit = !COUNT && q.anyhit;
     if (!FLAT) {
-        walk<COUNT, HAS_GRID>(S, root_hit ? S.scene_root_ref : YCGE_REF_NONE_VALUE, -1, st, o, d, inv, sx, sy, sz, tmin, closest, hit_prim, hit_sub, w, anyhit);
+        walk<COUNT, HAS_GRID>(S, root_hit ? scene_entry<COUNT, HAS_GRID>(S, tf) : YCGE_REF_NONE_VALUE, -1, st, o, d, inv, sx, sy, sz, tmin, closest, hit_prim, hit_sub, w, anyhit);
         return;
     }
     const uint32_t leaf_start = YCGE_REF_PAYLOAD(S.scene_root_ref) >> 3;
