@@ -2,7 +2,7 @@
 # lit config 5 at the static bench pose: kernel durations of the stage pipeline, then the round / persistent-wave knobs
 REPO=${GRAFT_REPO_ROOT:-/root/repo}; cd $REPO; mkdir -p gpurun_out/vox
 cd /tmp && export TMPDIR=/tmp
-for t in 0.5 0.25; do
+for t in 0.5; do
 BENCH="python3 $REPO/bench.py --steps 20 --warmup 3 --no-cpu-baseline --no-post --no-flight --no-moving --config 5 --t01 $t"
 timeout 600 rocprofv3 --kernel-trace --stats -f csv -d $REPO/gpurun_out/vox/t$t -o trace -- $BENCH > $REPO/gpurun_out/vox/trace_$t.log 2>&1
 echo "== t01 $t trace rc=$?"
@@ -26,7 +26,7 @@ PY
 done
 cd $REPO
 echo "== knobs, lit"
-for v in "-" "YCGE_ROUND=16,32" "YCGE_ROUND=64,128" "YCGE_PW_PER_CU=16" "YCGE_PW_PER_CU=8" "YCGE_PATH=megakernel"; do
+for v in "-" "YCGE_ROUND=4,8" "YCGE_ROUND=4,12" "YCGE_ROUND=6,16" "YCGE_ROUND=8,10" "YCGE_ROUND=8,16" "YCGE_ROUND=10,20" "YCGE_ROUND=3,6" "YCGE_PW_PER_CU=24" "YCGE_PW_PER_CU=40"; do
   echo "-- $v"
   ( if [ "$v" != "-" ]; then for kv in ${v//;/ }; do export "$kv"; done; fi
     python bench.py --config 5 --t01 0.5 --steps 10 --warmup 3 --no-cpu-baseline --no-post --no-flight --no-moving 2>/dev/null | python -c "import sys,json; d=json.loads(sys.stdin.read()); print(d['value'],'Mrays/s', d['ms_per_step'],'ms/frame', d['roofline']['mean_launch_ms'])" )

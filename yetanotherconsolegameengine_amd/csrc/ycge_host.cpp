@@ -29,7 +29,8 @@ size_t ycge_wf_sizes(int which);
 int ycge_launch_trace(const ycge::SceneDev *S, const ycge::FrameParams *P, const ycge::TraceOut *O, int count, int flat, int refill_steps,
                       hipStream_t stream);
 int ycge_launch_wavefront(const ycge::SceneDev *S, const ycge::FrameParams *P, const ycge::TraceOut *O, void *const bufs[7], int rounds,
-                          int has_grid, int flat, int count, int persistent_waves, hipStream_t stream);
+                          int has_grid, int flat, int count, int persistent_waves, hipStream_t stream, hipStream_t side, hipEvent_t ev_fork, hipEvent_t ev_join,
+                          const ycge::TraceOut *O_side);
 int ycge_launch_scene_walk(const void *nodes, int n_inner, const uint32_t *leaf_prims, const void *prims, void *walk, hipStream_t stream);
 int ycge_launch_order_blocks(uint32_t *cost, uint32_t n, uint32_t policy, uint32_t split_top, uint32_t fan_class, uint32_t fan_cap, uint32_t next_slot, uint32_t skip_mask, uint32_t *order_ws,
                              uint32_t *order, hipStream_t stream, int small_groups = 0, uint32_t n_frames = 0);
@@ -142,6 +143,7 @@ struct Knobs {
     int scene_bvh_device_min = YCGE_BVH_DEV_MIN_ITEMS_DEFAULT;   // YCGE_SCENE_BVH_DEVICE_MIN: fewer objects than this are built on the host (measured crossover, profiles/r02/f2_update_objects_timing.txt)
     int res_sched_every = 0;         // YCGE_RES_SCHED_EVERY: the tile-resident ring builds a new schedule behind every n-th frame (0 = the ring's depth)
     int bfs_rays = 0;                // YCGE_BFS=<n>: a wavefront's occlusion queries against a mesh go breadth-first from one shared work list when at most n of its lanes ask (mesh_anyhit_bfs; 0 = never, 64 = always)
+    bool no_lights_beside = false;   // YCGE_NO_LIGHTS_BESIDE: the stage pipeline strictly in sequence (A/B of the light loop beside the next round's trace)
     bool no_walk_tree = false;       // YCGE_NO_WALK_TREE: voxel worlds are walked down the scene tree, leaves and object steps and all (A/B of SceneDev::walk_nodes)
     bool no_coop = false;            // YCGE_NO_COOP: no treelets are built, sparse wavefronts keep the regular walk (A/B of the cooperative walk)
     bool exposure_serial = false;    // YCGE_EXPOSURE_SERIAL: the one-lane chain instead of the chunked exact evaluation
@@ -150,7 +152,7 @@ struct Knobs {
         auto geti = [](const char *n, int dflt) { const char *e = getenv(n); return e ? atoi(e) : dflt; };
         if (const char *e = getenv("YCGE_PATH")) path_policy = e[0] == 'w' ? 1 : e[0] == 'm' ? 2 : 0;
         xcd_strips = getenv("YCGE_XCD_STRIPS") != nullptr; generic_walk = getenv("YCGE_GENERIC_WALK") != nullptr;
-        no_walk_tree = getenv("YCGE_NO_WALK_TREE") != nullptr;
+        no_walk_tree = getenv("YCGE_NO_WALK_TREE") != nullptr; no_lights_beside = getenv("YCGE_NO_LIGHTS_BESIDE") != nullptr;
         no_lpt = getenv("YCGE_NO_LPT") != nullptr; no_refill = getenv("YCGE_NO_REFILL") != nullptr;
         if (const char *e = getenv("YCGE_WAVE_PROF")) wave_prof_stage = e[0] == 'e' ? 1 : e[0] == 'm' ? 2 : 0;
         refill_steps = geti("YCGE_REFILL", YCGE_REFILL_STEPS_DEFAULT);
@@ -359,6 +361,8 @@ struct ycge_ctx {
     DevBuf<uint32_t> block_cost, block_order, order_ws;   // k_trace scheduling feedback (4 blocks of 8x8 px per tile)
     bool block_order_valid = false;
     DevBuf<uint64_t> stack_spill;                 // [YCGE_TRAVERSAL_STACK - 12][persistent lanes]
+    bool any_light_lit = false;                   // some light has a contribution (GLight::dark == 0): the timed light loop has shadow rays to trace
+    DevBuf<uint64_t> stack_spill_side;            // ... of the stage kernel that runs on the side stream beside another (the light loop beside the next round's trace)
     DevBuf<float> path_stack;                  // [3][11][persistent lanes], only for scenes with transparent materials
     int spill_levels = 0;                      // traversal depth beyond the 12 LDS levels, from the uploaded trees
     int wf_rounds = 2;                         // 2 = primary + diffuse bounce; 4 when a surface can mirror (<= 2 mirror bounces)
@@ -450,7 +454,7 @@ int alloc_tile_buffers(ycge_ctx *c)
     HIP_TRY(c, c->wf_seg.alloc(4));
     HIP_TRY(c, c->wf_counts.alloc((size_t)(c->n_owned > 0 ? c->n_owned : 1) * 8));
     HIP_TRY(c, c->stack_spill.alloc((size_t)(c->spill_levels > 0 ? c->spill_levels : 1) * stack_lanes));
-    c->stack_spill2.release();
+    c->stack_spill2.release(); c->stack_spill_side.release();
     c->path_stack.release();
    
     {
@@ -870,7 +874,7 @@ void ycge_destroy(ycge_ctx *c)
     if (c->placed_flag) (void)hipFree(c->placed_flag);
     for (int k = 0; k < 2; k++) if (c->tile_trace_ev[k]) (void)hipEventDestroy(c->tile_trace_ev[k]);
     for (hipEvent_t ev : {c->flight_taa_ev, c->post_hist_ev, c->post_done_ev, c->post_set_ev[0], c->post_set_ev[1], c->post_set_ev[2]}) if (ev) (void)hipEventDestroy(ev);
-    c->stack_spill2.release();
+    c->stack_spill2.release(); c->stack_spill_side.release();
     release_resident(c);
     for (int k = 0; k < 3; k++) if (c->set_resolved_ev[k]) (void)hipEventDestroy(c->set_resolved_ev[k]);
     for (int k = 0; k < 3; k++) { c->flight_order[k].release(); c->flight_ws[k].release(); if (c->flight_order_ev[k]) (void)hipEventDestroy(c->flight_order_ev[k]); }
@@ -909,11 +913,13 @@ int ycge_device_info(ycge_ctx *c, char *name, size_t name_bytes, int32_t *comput
 static int upload_lights(ycge_ctx *c, const ycge_light *lights, int n)
 {
     std::vector<GLight> L(n);
+    c->any_light_lit = false;
     for (int i = 0; i < n; i++) {
         L[i].pos[0] = lights[i].position.x; L[i].pos[1] = lights[i].position.y; L[i].pos[2] = lights[i].position.z;
         L[i].color[0] = lights[i].color.x; L[i].color[1] = lights[i].color.y; L[i].color[2] = lights[i].color.z;
         L[i].intensity = lights[i].intensity;
         L[i].dark = (lights[i].intensity == 0.0f && std::isfinite(lights[i].color.x) && std::isfinite(lights[i].color.y) && std::isfinite(lights[i].color.z)) ? 1.0f : 0.0f;
+        if (L[i].dark == 0.0f) c->any_light_lit = true;
     }
     HIP_TRY(c, c->d_lights.upload(L));
     c->sd.lights = c->d_lights.p;
@@ -2003,7 +2009,18 @@ int trace_frame(ycge_ctx *c, float *d_slab, hipStream_t stream, FrameState &fs, 
         if ((size_t)pw * 64 > O.stack_lanes) pw = (int)(O.stack_lanes / 64);
         if ((size_t)pw > nt * 4) pw = (int)(nt * 4);            // never more wavefronts than the round can have rays for
         if (launch_begin) HIP_TRY(c, hipEventRecord(launch_begin, stream));
-        e = ycge_launch_wavefront(&c->sd, &P, &O, bufs, c->wf_rounds, c->has_grid ? 1 : 0, flat, c->cfg.count_work, pw, stream);
+        // the light loop of a round beside the trace of the next (ycge_launch_wavefront): on the side stream, with a spill area of its own
+        // (not where the light loop has nothing to trace - every light dark, timed kernels - nor for the small frames of a burst in flight,
+        // where the two stream hops cost more than the overlap gives: config 2 in flight 0.053 -> 0.056 ms, config 5 lit 5.12 -> 4.87)
+        const bool beside = !c->knobs.no_lights_beside && c->fan_stream && c->fan_ev[0] && c->fan_ev[1] && c->wf_rounds >= 2 && (c->any_light_lit || c->cfg.count_work) &&
+                            (!c->in_flight_call || c->n_owned >= 8192);
+        TraceOut O_side = O;
+        if (beside) {
+            if (c->stack_spill_side.n != c->stack_spill.n) HIP_TRY(c, c->stack_spill_side.alloc(c->stack_spill.n));
+            O_side.stack_spill = c->stack_spill_side.p;
+        }
+        e = ycge_launch_wavefront(&c->sd, &P, &O, bufs, c->wf_rounds, c->has_grid ? 1 : 0, flat, c->cfg.count_work, pw, stream,
+                                  beside ? c->fan_stream : nullptr, beside ? c->fan_ev[0] : nullptr, beside ? c->fan_ev[1] : nullptr, beside ? &O_side : nullptr);
         if (launch_end) HIP_TRY(c, hipEventRecord(launch_end, stream));
     }
     if (e != 0) return c->fail(YCGE_ERR_DEVICE, "trace launch failed: %s", hipGetErrorString((hipError_t)e));

@@ -245,7 +245,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu((HAS_GRID &&
     bool have = false, more = false, in_dda = false;
     uint32_t src = 0, cur = YCGE_REF_NONE_VALUE;
     F3 o = f3(0, 0, 0), d = f3(0, 0, 1), inv = f3(0, 0, 0);
-    bool sx = false, sy = false, sz = false;
+    bool sx = false, sy = false, sz = false, fast = false;
     float closest = YCGE_FLT_MAX;
     int hit_prim = -1, hit_sub = 0, mesh_prim = -1;
     DdaState D;
@@ -294,6 +294,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu((HAS_GRID &&
                     if (box_scene(S.scene_root_min[0], S.scene_root_min[1], S.scene_root_min[2], S.scene_root_max[0], S.scene_root_max[1],
                                   S.scene_root_max[2], o, inv, tmin, closest, tn, tf))
                         cur = scene_entry<COUNT, HAS_GRID>(S, tf);
+                    fast = YCGE_WALK_PHASE && YCGE_REF_KIND(cur) == REF_WALK_NODE && cs_abs(inv.x) < YCGE_INF && cs_abs(inv.y) < YCGE_INF && cs_abs(inv.z) < YCGE_INF;
                 }
                 more = cur != YCGE_REF_NONE_VALUE;
                 in_dda = false;
@@ -312,8 +313,12 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu((HAS_GRID &&
         if (have && more && !in_dda) {
             int parked_grid = -1, parked_prim = -1;
             float parked_tend = YCGE_INF;       // where the ray leaves the box of the grid's solid voxels: the walk ends there (timed kernels)
-            const int r = tree_phase<COUNT, HAS_GRID>(S, cur, mesh_prim, st, o, d, inv, sx, sy, sz, tmin, closest, hit_prim, hit_sub, parked_grid,
-                                                      parked_prim, parked_tend, w, round_tree_steps);
+            // (a ray in the walk tree of a voxel world takes the loop that holds nothing else, and leaves it only for an object that is no grid)
+            int r = TREE_OTHER;
+            if (HAS_GRID && !COUNT && fast) r = walk_phase(S, cur, st, o, inv, tmin, closest, parked_grid, parked_prim, w, round_tree_steps);
+            if (r == TREE_OTHER)
+                r = tree_phase<COUNT, HAS_GRID>(S, cur, mesh_prim, st, o, d, inv, sx, sy, sz, tmin, closest, hit_prim, hit_sub, parked_grid,
+                                                parked_prim, parked_tend, w, round_tree_steps);
             if (r == TREE_DONE) more = false;
             if (HAS_GRID && r == TREE_AT_GRID) in_dda = dda_begin<COUNT>(S, parked_grid, parked_prim, o, d, inv, tmin, COUNT ? closest : fminf(closest, parked_tend), D, w);
         }
@@ -1574,8 +1579,13 @@ int ycge_launch_trace(const ycge::SceneDev *S, const ycge::FrameParams *P, const
 
 // wavefront path.  bufs = {q0, q1, hit, lq, n_q, n_lq}: queues segmented per owned tile (256 entries each),
 // n_q = (rounds + 1) x tiles counts, n_lq = tiles counts.  Every stage is one workgroup per tile.
+// side / ev_fork / ev_join (optional): the light loop of round r - shadow rays from the vertices shade(r) found - and the trace of round
+// r + 1 need nothing of each other (the one adds to current_hdr and reads the light queue, the other reads the ray queue and writes the
+// hit records), so the light loop runs on `side` beside the trace and shade(r + 1) - which adds to current_hdr AFTER it, the reference's
+// order, and refills the light queue - waits for both.
 int ycge_launch_wavefront(const ycge::SceneDev *S, const ycge::FrameParams *P, const ycge::TraceOut *O, void *const bufs[7], int rounds,
-                          int has_grid, int flat, int count, int persistent_waves, hipStream_t stream)
+                          int has_grid, int flat, int count, int persistent_waves, hipStream_t stream, hipStream_t side, hipEvent_t ev_fork, hipEvent_t ev_join,
+                          const ycge::TraceOut *O_side /* O with a traversal-stack spill area of its own: two kernels walk at the same time */)
 {
     using namespace ycge;
     if (P->n_owned_tiles <= 0) return 0;
@@ -1595,6 +1605,7 @@ int ycge_launch_wavefront(const ycge::SceneDev *S, const ycge::FrameParams *P, c
     sel3(count != 0, has_grid != 0, flat != 0, [&](auto C, auto G, auto F) {
         hipLaunchKernelGGL((k_wf_primary<decltype(C)::value, decltype(G)::value, decltype(F)::value>), tiles, block, 0, stream, *S, *P, *O, B);
     });
+    bool forked = false;
     for (int r = 0; r < rounds; r++) {
         const bool persistent = !flat && persistent_waves > 0;
         if (r > 0 && persistent) {
@@ -1607,13 +1618,18 @@ int ycge_launch_wavefront(const ycge::SceneDev *S, const ycge::FrameParams *P, c
             sel3(count != 0, has_grid != 0, flat != 0, [&](auto C, auto G, auto F) {
                 hipLaunchKernelGGL((k_wf_extend<decltype(C)::value, decltype(G)::value, decltype(F)::value>), tiles, block, 0, stream, *S, *O, B, r);
             });
+        if (forked) { (void)hipStreamWaitEvent(stream, ev_join, 0); forked = false; }
         sel3(r == 0, has_grid != 0, false, [&](auto R0, auto G, auto) {
             hipLaunchKernelGGL((k_wf_shade<decltype(R0)::value, decltype(G)::value>), tiles, block, 0, stream, *S, *P, *O, B, r);
         });
+        const bool fork = side && ev_fork && ev_join && O_side && r + 1 < rounds;
+        if (fork) { (void)hipEventRecord(ev_fork, stream); (void)hipStreamWaitEvent(side, ev_fork, 0); }
         sel3(count != 0, has_grid != 0, flat != 0, [&](auto C, auto G, auto F) {
-            hipLaunchKernelGGL((k_wf_lights<decltype(C)::value, decltype(G)::value, decltype(F)::value>), tiles, block, 0, stream, *S, *P, *O, B, r);
+            hipLaunchKernelGGL((k_wf_lights<decltype(C)::value, decltype(G)::value, decltype(F)::value>), tiles, block, 0, fork ? side : stream, *S, *P, fork ? *O_side : *O, B, r);
         });
+        if (fork) { (void)hipEventRecord(ev_join, side); forked = true; }
     }
+    if (forked) (void)hipStreamWaitEvent(stream, ev_join, 0);
     return (int)hipGetLastError();
 }
 

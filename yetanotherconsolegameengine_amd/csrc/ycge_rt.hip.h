@@ -1053,6 +1053,56 @@ __device__ __forceinline__ int tree_phase(const SceneDev &S, uint32_t &cur, int 
     }
 }
 
+// tree_phase for a lane in the walk tree of a voxel world (SceneDev::walk_nodes) and nothing else in the loop: a node visit (the plain
+// form of the entry test - the caller sends only rays whose three reciprocals are finite, box_scene) or a grid reached.  TREE_OTHER: the
+// lane stands at something else (an object that is no grid) with `cur` untouched - the caller goes on in tree_phase.  Operation for
+// operation what tree_phase does for these references; the point is the instruction stream a wavefront issues per step under partial
+// masks: tree_phase's loop body is 1 600 instructions of which a voxel world's lanes enter 200, and every block skipped costs its branch.
+enum : int { TREE_OTHER = 3 };
+#ifndef YCGE_WALK_PHASE
+#define YCGE_WALK_PHASE 1          // 0: A/B build - the walk tree through tree_phase's general loop
+#endif
+template <class STK>
+__device__ __forceinline__ int walk_phase(const SceneDev &S, uint32_t &cur, STK &st, F3 o, F3 inv, float tmin, float closest, int &parked_grid, int &parked_prim, Work &w, int budget)
+{
+    for (;;) {
+        if (budget-- <= 0) return TREE_YIELD;
+        if (cur == YCGE_REF_NONE_VALUE) {
+            float tn;
+            if (!st.pop(cur, tn)) { cur = YCGE_REF_NONE_VALUE; return TREE_DONE; }
+            if (!(closest >= tn)) { cur = YCGE_REF_NONE_VALUE; continue; }
+        }
+        const uint32_t kind = YCGE_REF_KIND(cur), pay = YCGE_REF_PAYLOAD(cur);
+        if (kind == REF_GRID) {
+            w.steps++;
+            cur = YCGE_REF_NONE_VALUE;
+            parked_grid = (int)pay; parked_prim = -1;
+            return TREE_AT_GRID;
+        }
+        if (kind != REF_WALK_NODE) return TREE_OTHER;
+        w.steps++;
+        YCGE_VOXSTAT(w, 0);
+        const float4 *np = (const float4 *)(S.walk_nodes + pay);
+        const float4 a = np[0], b = np[1], c = np[2], e = np[3];
+        // box_scene, plain form, both children
+        const float lax = (a.x - o.x) * inv.x, lbx = (b.x - o.x) * inv.x, lay = (a.y - o.y) * inv.y, lby = (b.y - o.y) * inv.y, laz = (a.z - o.z) * inv.z, lbz = (a.w - o.z) * inv.z;
+        const float rax = (b.z - o.x) * inv.x, rbx = (c.z - o.x) * inv.x, ray_ = (b.w - o.y) * inv.y, rby = (c.w - o.y) * inv.y, raz = (c.x - o.z) * inv.z, rbz = (c.y - o.z) * inv.z;
+        float ln = __builtin_fmaxf(__builtin_fminf(lax, lbx), __builtin_fmaxf(__builtin_fminf(lay, lby), __builtin_fminf(laz, lbz)));
+        float lf = __builtin_fminf(__builtin_fmaxf(lax, lbx), __builtin_fminf(__builtin_fmaxf(lay, lby), __builtin_fmaxf(laz, lbz)));
+        float rn = __builtin_fmaxf(__builtin_fminf(rax, rbx), __builtin_fmaxf(__builtin_fminf(ray_, rby), __builtin_fminf(raz, rbz)));
+        float rf = __builtin_fminf(__builtin_fmaxf(rax, rbx), __builtin_fminf(__builtin_fmaxf(ray_, rby), __builtin_fmaxf(raz, rbz)));
+        ln = __builtin_fmaxf(ln, tmin); lf = __builtin_fminf(lf, closest);
+        rn = __builtin_fmaxf(rn, tmin); rf = __builtin_fminf(rf, closest);
+        const bool hl = lf >= ln, hr = rf >= rn;
+        const uint32_t lref = __float_as_uint(e.x), rref = __float_as_uint(e.y);
+        const bool left_first = (__float_as_uint(e.z) & 1u) || ln < rn;
+        if (hl & hr) {
+            if (left_first) { st.push(rref, rn); cur = lref; }
+            else { st.push(lref, ln); cur = rref; }
+        } else cur = hl ? lref : hr ? rref : YCGE_REF_NONE_VALUE;
+    }
+}
+
 // where a query enters the scene: the walk tree of a voxel world (SceneDev::walk_nodes) for a ray of the timed kernels that leaves the
 // root box (at t_far) before the smallest distance any grid's cull verdict holds to, else the scene tree
 template <bool COUNT, bool HAS_GRID>
@@ -1066,11 +1116,22 @@ __device__ __forceinline__ void walk(const SceneDev &S, uint32_t cur, int mesh_p
                                      float tmin, float &closest, int &hit_prim, int &hit_sub, Work &w, bool anyhit = false)
 {
     bool more = cur != YCGE_REF_NONE_VALUE;      // the stack is empty at entry
+    // a ray that enters the walk tree of a voxel world with three finite reciprocals takes walk_phase - the loop that holds nothing else
+    const bool fast = YCGE_WALK_PHASE && HAS_GRID && !COUNT && more && YCGE_REF_KIND(cur) == REF_WALK_NODE && cs_abs(inv.x) < YCGE_INF && cs_abs(inv.y) < YCGE_INF && cs_abs(inv.z) < YCGE_INF;
     for (;;) {
         int parked_grid = -1, parked_prim = -1;
         float parked_tend = YCGE_INF;       // (grid_dda finds the end of the solid box itself)
         bool parked = false;
-        if (more) parked = tree_phase<COUNT, HAS_GRID>(S, cur, mesh_prim, st, o, d, inv, sx, sy, sz, tmin, closest, hit_prim, hit_sub, parked_grid, parked_prim, parked_tend, w, 0x7fffffff, anyhit) == TREE_AT_GRID;
+        if (more) {
+            int r = TREE_OTHER;
+            if (HAS_GRID && !COUNT && fast) {
+                if (anyhit && hit_prim >= 0) { st.reset(); cur = YCGE_REF_NONE_VALUE; r = TREE_DONE; }      // occlusion query answered (tree_phase's first line)
+                else r = walk_phase(S, cur, st, o, inv, tmin, closest, parked_grid, parked_prim, w, 0x7fffffff);
+            }
+            if (r == TREE_OTHER)
+                r = tree_phase<COUNT, HAS_GRID>(S, cur, mesh_prim, st, o, d, inv, sx, sy, sz, tmin, closest, hit_prim, hit_sub, parked_grid, parked_prim, parked_tend, w, 0x7fffffff, anyhit);
+            parked = r == TREE_AT_GRID;
+        }
         more = parked;
         if (!HAS_GRID) break;
         if (!__any(parked)) break;
