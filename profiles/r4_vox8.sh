@@ -1,0 +1,9 @@
+#!/bin/bash
+# A/B of the working tree against the previous commit's build (lib/var_prev.so), lit and dark config 5; voxel parity tests first
+REPO=${GRAFT_REPO_ROOT:-/root/repo}; cd $REPO; mkdir -p gpurun_out
+timeout 1500 python -m pytest tests/test_gpu_timed_variants.py tests/test_gpu_parity.py -m gpu -q -x -k "${1:-voxel or volume or grid or lit or cull or config5 or world or graze or walk_tree}" 2>&1 | tail -4
+for t in 0.5 0.25; do for v in "-" "YCGE_LIB=$REPO/yetanotherconsolegameengine_amd/lib/var_prev.so" "-" "YCGE_LIB=$REPO/yetanotherconsolegameengine_amd/lib/var_prev.so"; do
+  echo "-- t01 $t $v"
+  ( if [ "$v" != "-" ]; then export "$v"; fi
+    python bench.py --config 5 --t01 $t --steps 20 --warmup 3 --no-cpu-baseline --no-post 2>/dev/null | python -c "import sys,json; d=json.loads(sys.stdin.read()); print(d['value'],'Mrays/s', d['ms_per_step'],'ms/frame trace', d['roofline']['mean_launch_ms'], 'moving', d['moving_camera']['trace_ms']['median'], 'in flight', d['frames_in_flight']['ms_per_step'])" )
+done; done

@@ -781,6 +781,7 @@ def _solid_box_of(obj):
 
 
 WALK_LEAF_NODES = 6          # YCGE_WALK_LEAF_NODES
+IN_ORDER = 0x10000000        # YCGE_WALK_IN_ORDER
 
 
 def _check_walk_tree(g, sc):
@@ -814,8 +815,9 @@ def _check_walk_tree(g, sc):
         kind, pay = ref >> 29, ref & 0x1FFFFFFF
         if kind == 6: return [grids[pay]]
         if kind == 4: return [pay]
-        assert kind == 5 and pay >= n, ref
-        assert walk[pay, 14] == 1          # left child first
+        assert kind == 5 and pay & IN_ORDER, ref          # left child first
+        pay &= ~IN_ORDER
+        assert pay >= n and walk[pay, 14] == 0
         out = []
         for side in range(2):
             below = objects_below(int(walk[pay, 12 + side]))
@@ -841,7 +843,7 @@ def _check_walk_tree(g, sc):
             if len(keep) == 1:
                 assert wref == ref_of(keep[0]), (i, side)
             else:
-                assert wref == (5 << 29) | (n + (2 * i + side) * WALK_LEAF_NODES), (i, side)
+                assert wref == (5 << 29) | IN_ORDER | (n + (2 * i + side) * WALK_LEAF_NODES), (i, side)
                 assert objects_below(wref) == keep, (i, side)
                 opened += 1
     return n, opened

@@ -410,7 +410,7 @@ __global__ __launch_bounds__(256) void k_scene_walk(const GNode *__restrict__ no
         else {
             // halve [a, b) until single: the node of a range is created before those of its halves, left half first
             const uint32_t base = (uint32_t)n_inner + (uint32_t)t * YCGE_WALK_LEAF_NODES;
-            out_ref = YCGE_REF(REF_WALK_NODE, base);
+            out_ref = YCGE_REF(REF_WALK_NODE, base | YCGE_WALK_IN_ORDER);
             int ra[8], rb[8], rslot[8], top = 0, next_slot = 1;
             ra[0] = 0; rb[0] = m; rslot[0] = 0; top = 1;
             while (top > 0) {
@@ -428,10 +428,10 @@ __global__ __launch_bounds__(256) void k_scene_walk(const GNode *__restrict__ no
                 g.lmin_x = L.lo[0]; g.lmin_y = L.lo[1]; g.lmin_z = L.lo[2]; g.lmax_x = L.hi[0]; g.lmax_y = L.hi[1]; g.lmax_z = L.hi[2];
                 g.rmin_x = R.lo[0]; g.rmin_y = R.lo[1]; g.rmin_z = R.lo[2]; g.rmax_x = R.hi[0]; g.rmax_y = R.hi[1]; g.rmax_z = R.hi[2];
                 if (mid - a == 1) g.lref = walk_ref_of(prims[obj[a]], obj[a]);
-                else { g.lref = YCGE_REF(REF_WALK_NODE, base + (uint32_t)next_slot); ra[top] = a; rb[top] = mid; rslot[top] = next_slot++; top++; }
+                else { g.lref = YCGE_REF(REF_WALK_NODE, (base + (uint32_t)next_slot) | YCGE_WALK_IN_ORDER); ra[top] = a; rb[top] = mid; rslot[top] = next_slot++; top++; }
                 if (b - mid == 1) g.rref = walk_ref_of(prims[obj[mid]], obj[mid]);
-                else { g.rref = YCGE_REF(REF_WALK_NODE, base + (uint32_t)next_slot); ra[top] = mid; rb[top] = b; rslot[top] = next_slot++; top++; }
-                g.pad[0] = 1u; g.pad[1] = 0u;
+                else { g.rref = YCGE_REF(REF_WALK_NODE, (base + (uint32_t)next_slot) | YCGE_WALK_IN_ORDER); ra[top] = mid; rb[top] = b; rslot[top] = next_slot++; top++; }
+                g.pad[0] = 0u; g.pad[1] = 0u;
                 walk[base + (uint32_t)slot] = g;
             }
         }

@@ -32,7 +32,7 @@ enum : uint32_t {
     REF_MESH_NODE = 2u,    // payload = (32-byte unit of the GNode in the mesh arena) << 4
     REF_MESH_LEAF = 3u,    // payload = (unit of the leaf's first GTriPair << 4) | triangles left in the leaf (1..15; MeshBVH.cs:14 caps a leaf at 8)
     REF_PRIM = 4u,         // payload = index into prims
-    REF_WALK_NODE = 5u,    // payload = index into walk_nodes (SceneDev::walk_nodes)
+    REF_WALK_NODE = 5u,    // payload = index into walk_nodes (SceneDev::walk_nodes) | YCGE_WALK_IN_ORDER for a leaf node: left child first whatever the distances
     REF_GRID = 6u,         // payload = index into grids (walk tree only)
     REF_NONE = 7u
 };
@@ -40,6 +40,7 @@ enum : uint32_t {
 #define YCGE_REF_KIND(r) ((r) >> 29)
 #define YCGE_REF_PAYLOAD(r) ((r) & 0x1fffffffu)
 #define YCGE_REF_NONE_VALUE 0xffffffffu
+#define YCGE_WALK_IN_ORDER 0x10000000u      // in a REF_WALK_NODE payload (the rest is the index)
 
 // device-side build of the scene-level BVH (ycge_bvh_build.hip): what the kernel hands back to the host
 #define YCGE_WALK_LEAF_NODES 6          // walk tree: entries set aside per leaf child (a leaf holds at most 7 objects: 6 nodes)
@@ -62,7 +63,7 @@ struct alignas(16) GNode {
     float lmax_x, lmax_y, rmin_x, rmin_y;
     float rmin_z, rmax_z, rmax_x, rmax_y;
     uint32_t lref, rref;        // child references
-    uint32_t pad[2];            // walk tree (SceneDev::walk_nodes): pad[0] bit 0 = left child first whatever the distances
+    uint32_t pad[2];
 };
 static_assert(sizeof(GNode) == 64, "GNode must be 64 B");
 
@@ -224,8 +225,9 @@ struct SceneDev {
     //   [0, n)      the scene nodes, child boxes as they are (entry order and the entry test are the reference's), child references
     //               rewritten: node j -> REF_WALK_NODE j; a leaf of one object -> that object; a leaf of more -> its first leaf node
     //   [n, ...)    leaf nodes: the leaf's objects in index order, halved until single; a child's box is the union of the SOLID-voxel
-    //               boxes below it (GGrid::solid_lo / solid_hi; everything for an object that is no grid), pad[0] bit 0 = "left child
-    //               first" - a leaf's objects are asked in index order (BVH.cs:139-149), not by distance.
+    //               boxes below it (GGrid::solid_lo / solid_hi; everything for an object that is no grid); references to them carry
+    //               YCGE_WALK_IN_ORDER: left child first - a leaf's objects are asked in index order (BVH.cs:139-149), not by distance
+    //               (in the reference, not in the record: the record's last words would be a second fetch behind the box tests).
     // A grid is referenced as REF_GRID (its index); grid_owner[grid] = the object that holds it (hit_prim).  Grids without a solid
     // voxel are left out where a leaf has others.  What the walk skips is what the object step would cull one by one
     // (solid_box_missed); visit order, hence every hit, is unchanged.  A ray is sent down this tree only if it leaves the scene's

@@ -228,12 +228,13 @@ __global__ __launch_bounds__(256) void k_wf_extend(const SceneDev S, const Trace
 // at the same light, their lengths are alike, and k_wf_lights already keeps 53 % of its lanes busy.
 #define YCGE_ROUND_TREE_STEPS 6
 #define YCGE_ROUND_CELL_STEPS 10
+#define YCGE_ROUND_REFILL_MIN 16       // lanes that wait for a ray before rays are handed out (or all of them): lit config 5 4.06 -> 4.02 ms, its moving-camera leg 2.22 -> 2.06 (profiles/r04/h_voxel_walk_tree.txt)
 #ifndef YCGE_TRACEP_WAVES
 #define YCGE_TRACEP_WAVES 5          // persistent extend stage: 5 wavefronts per SIMD (102 registers, no scratch; round 3: as fast as 6 with its 10 spilled registers - 7.04 against 7.00 ms - and 0.46 GB less written per 4K frame) and 32 persistent wavefronts per CU
 #endif
 template <bool COUNT, bool HAS_GRID>
 __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu((HAS_GRID && !COUNT) ? YCGE_TRACEP_WAVES : 1, 8))) void k_wf_trace_p(const SceneDev S, const FrameParams P, const TraceOut O, const WfBuffers B, int round,
-                                                   uint32_t *__restrict__ chunk_ctr, int round_tree_steps, int round_cell_steps)
+                                                   uint32_t *__restrict__ chunk_ctr, int round_tree_steps, int round_cell_steps, int refill_min)
 {
     Work w = {0, 0, 0, 0, 0, 0, 0};
     StackT<64> st;
@@ -262,6 +263,8 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu((HAS_GRID &&
     for (;;) {
         // ---- hand new rays to the idle lanes
         unsigned long long idle = __ballot(!have);
+        // (new rays only once refill_min lanes wait for one - or all of them: handing out rays costs a pass over ~280 instructions)
+        if ((int)__popcll(idle) < refill_min && idle != __ballot(true)) idle = 0ull;
         while (idle && !exhausted) {
             if (next_ray == end_ray) {
                 uint32_t c = 0;
@@ -1597,10 +1600,10 @@ int ycge_launch_wavefront(const ycge::SceneDev *S, const ycge::FrameParams *P, c
     B.tile_order = P->tile_order;
     B.elide_dark = count ? 0u : 1u;
     const dim3 block(256), tiles((unsigned)P->n_owned_tiles);
-    static int round_steps[2] = {0, 0};
-    if (round_steps[0] == 0) {       // steps per round of k_wf_extend_p: YCGE_ROUND="tree,cell" overrides the tuned defaults
-        round_steps[0] = YCGE_ROUND_TREE_STEPS; round_steps[1] = YCGE_ROUND_CELL_STEPS;
-        if (const char *e = getenv("YCGE_ROUND")) { int a2 = 0, b2 = 0; if (sscanf(e, "%d,%d", &a2, &b2) == 2 && a2 > 0 && b2 > 0) { round_steps[0] = a2; round_steps[1] = b2; } }
+    static int round_steps[3] = {0, 0, 0};
+    if (round_steps[0] == 0) {       // steps per round of k_wf_extend_p: YCGE_ROUND="tree,cell[,lanes waiting before a refill]" overrides the tuned defaults
+        round_steps[0] = YCGE_ROUND_TREE_STEPS; round_steps[1] = YCGE_ROUND_CELL_STEPS; round_steps[2] = YCGE_ROUND_REFILL_MIN;
+        if (const char *e = getenv("YCGE_ROUND")) { int a2 = 0, b2 = 0, c2 = YCGE_ROUND_REFILL_MIN; if (sscanf(e, "%d,%d,%d", &a2, &b2, &c2) >= 2 && a2 > 0 && b2 > 0 && c2 > 0) { round_steps[0] = a2; round_steps[1] = b2; round_steps[2] = c2; } }
     }
     sel3(count != 0, has_grid != 0, flat != 0, [&](auto C, auto G, auto F) {
         hipLaunchKernelGGL((k_wf_primary<decltype(C)::value, decltype(G)::value, decltype(F)::value>), tiles, block, 0, stream, *S, *P, *O, B);
@@ -1612,7 +1615,7 @@ int ycge_launch_wavefront(const ycge::SceneDev *S, const ycge::FrameParams *P, c
             (void)hipMemsetAsync(B.chunk_ctr, 0, sizeof(uint32_t), stream);
             sel3(count != 0, has_grid != 0, false, [&](auto C, auto G, auto) {
                 hipLaunchKernelGGL((k_wf_trace_p<decltype(C)::value, decltype(G)::value>), dim3((unsigned)persistent_waves), dim3(64), 0, stream,
-                                   *S, *P, *O, B, r, B.chunk_ctr, round_steps[0], round_steps[1]);
+                                   *S, *P, *O, B, r, B.chunk_ctr, round_steps[0], round_steps[1], round_steps[2]);
             });
         } else if (r > 0)
             sel3(count != 0, has_grid != 0, flat != 0, [&](auto C, auto G, auto F) {

@@ -987,7 +987,7 @@ __device__ __forceinline__ int tree_phase(const SceneDev &S, uint32_t &cur, int 
         if (kind == REF_MESH_NODE || kind == REF_SCENE_NODE || (HAS_GRID && !COUNT && kind == REF_WALK_NODE)) {
             YCGE_VOXSTAT(w, 0);
             const float4 *np = kind == REF_MESH_NODE ? (const float4 *)(S.mesh_arena + (size_t)(pay >> 4) * 32u)
-                             : (HAS_GRID && !COUNT && kind == REF_WALK_NODE) ? (const float4 *)(S.walk_nodes + pay) : (const float4 *)(S.scene_nodes + pay);
+                             : (HAS_GRID && !COUNT && kind == REF_WALK_NODE) ? (const float4 *)(S.walk_nodes + (pay & ~YCGE_WALK_IN_ORDER)) : (const float4 *)(S.scene_nodes + pay);
             const float4 a = np[0], b = np[1], c = np[2], e = np[3];
             float ln, rn;
             bool hl, hr;
@@ -1000,8 +1000,8 @@ __device__ __forceinline__ int tree_phase(const SceneDev &S, uint32_t &cur, int 
                 hr = box_scene(b.z, b.w, c.x, c.z, c.w, c.y, o, inv, tmin, closest, rn);
             }
             const uint32_t lref = __float_as_uint(e.x), rref = __float_as_uint(e.y);
-            // (a leaf node of the walk tree: the leaf's objects in index order whatever the distances - GNode::pad[0], zero everywhere else)
-            const bool left_first = (HAS_GRID && !COUNT && kind == REF_WALK_NODE && (__float_as_uint(e.z) & 1u)) || ln < rn;
+            // (a leaf node of the walk tree: the leaf's objects in index order whatever the distances)
+            const bool left_first = (HAS_GRID && !COUNT && kind == REF_WALK_NODE && (pay & YCGE_WALK_IN_ORDER)) || ln < rn;
             if (hl & hr) {
                 if (left_first) { st.push(rref, rn); cur = lref; }
                 else { st.push(lref, ln); cur = rref; }
@@ -1082,7 +1082,7 @@ __device__ __forceinline__ int walk_phase(const SceneDev &S, uint32_t &cur, STK 
         if (kind != REF_WALK_NODE) return TREE_OTHER;
         w.steps++;
         YCGE_VOXSTAT(w, 0);
-        const float4 *np = (const float4 *)(S.walk_nodes + pay);
+        const float4 *np = (const float4 *)(S.walk_nodes + (pay & ~YCGE_WALK_IN_ORDER));
         const float4 a = np[0], b = np[1], c = np[2], e = np[3];
         // box_scene, plain form, both children
         const float lax = (a.x - o.x) * inv.x, lbx = (b.x - o.x) * inv.x, lay = (a.y - o.y) * inv.y, lby = (b.y - o.y) * inv.y, laz = (a.z - o.z) * inv.z, lbz = (a.w - o.z) * inv.z;
@@ -1095,11 +1095,9 @@ __device__ __forceinline__ int walk_phase(const SceneDev &S, uint32_t &cur, STK 
         rn = __builtin_fmaxf(rn, tmin); rf = __builtin_fminf(rf, closest);
         const bool hl = lf >= ln, hr = rf >= rn;
         const uint32_t lref = __float_as_uint(e.x), rref = __float_as_uint(e.y);
-        const bool left_first = (__float_as_uint(e.z) & 1u) || ln < rn;
-        if (hl & hr) {
-            if (left_first) { st.push(rref, rn); cur = lref; }
-            else { st.push(lref, ln); cur = rref; }
-        } else cur = hl ? lref : hr ? rref : YCGE_REF_NONE_VALUE;
+        const bool left_first = (pay & YCGE_WALK_IN_ORDER) || ln < rn;
+        if (hl & hr) st.push(left_first ? rref : lref, left_first ? rn : ln);          // (one push site: selects, not two copies of the spill test)
+        cur = (hl & hr) ? (left_first ? lref : rref) : hl ? lref : hr ? rref : YCGE_REF_NONE_VALUE;
     }
 }
 
