@@ -341,8 +341,10 @@ int ycge_set_camera(ycge_ctx *ctx, const float pos[3], float yaw, float pitch, f
 int ycge_render_frame(ycge_ctx *ctx, float *out_top_bottom_sdr, ycge_frame_stats *stats);
 /* Frames in flight (no counterpart in the reference, whose TryFlipAndBlit returns a finished frame): queues steps 1-5 and 9 of the
  * next frame - camera snapshot, trace, TAA, camera commit - and returns without waiting.  The trace of frame N + 1 runs beside the
- * TAA of frame N (two streams, two sets of trace outputs), so a sequence of such calls costs max(trace, TAA + schedule) per frame
- * instead of their sum plus the host's wake-up.  The frames are the ones the same sequence of ycge_render_frame(ctx, NULL, NULL)
+ * TAA of frame N (its own stream; three sets of trace outputs taken in turn) and two traces run at a time on two streams - the
+ * single-launch kernel always, the stage pipeline of voxel worlds from 4096 tiles on and with no post stage in flight (a second set
+ * of stage queues) - so a sequence of such calls costs max(trace, TAA + schedule) per frame or less, instead of their sum plus the
+ * host's wake-up.  The frames are the ones the same sequence of ycge_render_frame(ctx, NULL, NULL)
  * calls produces, bit for bit.  Single device, no debug captures, no per-frame counters.  Every other entry point (and
  * ycge_wait) first waits for the frames in flight; ycge_set_camera between two calls moves the camera of the next frame. */
 int ycge_render_frame_async(ycge_ctx *ctx);
@@ -361,7 +363,7 @@ int ycge_async_trace_times(ycge_ctx *ctx, float *ms_out, int32_t capacity, int32
  * OBSERVED property of the dispatcher (workgroups are placed in index order, so the last index is the last placed); where signal memory
  * or hipStreamWaitValue32 is not available the gate switches itself off and says so here. */
 typedef struct ycge_flight_info {
-    int32_t two_trace_streams;   /* consecutive frames in flight alternate between two trace streams (single-launch scenes)        */
+    int32_t two_trace_streams;   /* consecutive frames in flight alternate between two trace streams                               */
     int32_t placed_gate;         /* 1: the placed-value gate is armed; 0: off (YCGE_FLIGHT_PLACED_GATE=0, no signal memory, ...) */
     int32_t post_gate;           /* a trace waits until the post stage before it has placed its persistent launch                */
     int32_t post_pair;           /* the post stages of consecutive frames run side by side                                      */

@@ -447,10 +447,11 @@ def test_pipelined_tiled_frames_with_a_moving_camera(product_lib):
     seq.close(); pip.close()
 
 
-@pytest.mark.parametrize("cfg_n,w,h", [(3, None, None), (5, 96, 27), (2, 160, 45)])
+@pytest.mark.parametrize("cfg_n,w,h", [(3, None, None), (5, 96, 27), (2, 160, 45), (5, 1024, 288)])
 def test_frames_in_flight_are_the_frames_of_the_synchronous_calls(product_lib, cfg_n, w, h):
     """ycge_render_frame_async: the trace of frame N + 1 beside the TAA of frame N, trace outputs alternating between two sets of
-    buffers.  Reference behaviour = the same frames by TryFlipAndBlit one after the other (RaytraceRenderer.cs:157-267): every
+    buffers.  (The voxel world at 1024 x 288: from 4096 tiles on two frames of the stage pipeline are traced at a time - a second set
+    of stage queues - and their light loops run beside the next round's trace.)  Reference behaviour = the same frames by TryFlipAndBlit one after the other (RaytraceRenderer.cs:157-267): every
     buffer the newest frame left and the history, bit for bit - after a burst, after single frames, and with synchronous SDR
     frames in between (their post stage reads whichever set is current); the camera moves, sometimes past the TAA reset threshold."""
     sc, w0, h0, ss, pose = scenes.config_scene(cfg_n)
@@ -501,7 +502,7 @@ def test_frames_in_flight_are_the_frames_of_the_synchronous_calls(product_lib, c
     single.close()
 
 
-@pytest.mark.parametrize("cfg_n,w,h", [(3, 320, 90), (5, 96, 27), (3, None, None)])
+@pytest.mark.parametrize("cfg_n,w,h", [(3, 320, 90), (5, 96, 27), (3, None, None), (5, 1024, 288)])
 def test_frames_in_flight_with_the_post_stage(product_lib, cfg_n, w, h):
     """ycge_render_frame_async_sdr: denoise, exposure and tonemap of frame N beside the traces and TAA of the frames after it (the
     denoiser reads frame N's G-buffer set and, in its first iteration, the TAA history; the exposure state passes from frame to frame).

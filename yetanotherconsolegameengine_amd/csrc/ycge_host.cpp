@@ -143,6 +143,7 @@ struct Knobs {
     int scene_bvh_device_min = YCGE_BVH_DEV_MIN_ITEMS_DEFAULT;   // YCGE_SCENE_BVH_DEVICE_MIN: fewer objects than this are built on the host (measured crossover, profiles/r02/f2_update_objects_timing.txt)
     int res_sched_every = 0;         // YCGE_RES_SCHED_EVERY: the tile-resident ring builds a new schedule behind every n-th frame (0 = the ring's depth)
     int bfs_rays = 0;                // YCGE_BFS=<n>: a wavefront's occlusion queries against a mesh go breadth-first from one shared work list when at most n of its lanes ask (mesh_anyhit_bfs; 0 = never, 64 = always)
+    bool no_flight_stage_overlap = false;   // YCGE_NO_FLIGHT_STAGE_OVERLAP: frames in flight of the stage pipeline (voxel worlds) one trace at a time (A/B)
     bool no_lights_beside = false;   // YCGE_NO_LIGHTS_BESIDE: the stage pipeline strictly in sequence (A/B of the light loop beside the next round's trace)
     bool no_walk_tree = false;       // YCGE_NO_WALK_TREE: voxel worlds are walked down the scene tree, leaves and object steps and all (A/B of SceneDev::walk_nodes)
     bool no_coop = false;            // YCGE_NO_COOP: no treelets are built, sparse wavefronts keep the regular walk (A/B of the cooperative walk)
@@ -152,7 +153,7 @@ struct Knobs {
         auto geti = [](const char *n, int dflt) { const char *e = getenv(n); return e ? atoi(e) : dflt; };
         if (const char *e = getenv("YCGE_PATH")) path_policy = e[0] == 'w' ? 1 : e[0] == 'm' ? 2 : 0;
         xcd_strips = getenv("YCGE_XCD_STRIPS") != nullptr; generic_walk = getenv("YCGE_GENERIC_WALK") != nullptr;
-        no_walk_tree = getenv("YCGE_NO_WALK_TREE") != nullptr; no_lights_beside = getenv("YCGE_NO_LIGHTS_BESIDE") != nullptr;
+        no_walk_tree = getenv("YCGE_NO_WALK_TREE") != nullptr; no_lights_beside = getenv("YCGE_NO_LIGHTS_BESIDE") != nullptr; no_flight_stage_overlap = getenv("YCGE_NO_FLIGHT_STAGE_OVERLAP") != nullptr;
         no_lpt = getenv("YCGE_NO_LPT") != nullptr; no_refill = getenv("YCGE_NO_REFILL") != nullptr;
         if (const char *e = getenv("YCGE_WAVE_PROF")) wave_prof_stage = e[0] == 'e' ? 1 : e[0] == 'm' ? 2 : 0;
         refill_steps = geti("YCGE_REFILL", YCGE_REFILL_STEPS_DEFAULT);
@@ -335,6 +336,10 @@ struct ycge_ctx {
     DevBuf<uint8_t> wf_q0, wf_q1, wf_hit, wf_lq;
     DevBuf<uint32_t> wf_seg;                      // segment counter of the persistent extend stage
     DevBuf<uint32_t> wf_counts, tile_order;
+    // the stage pipeline's second set (frames in flight: two voxel-world traces at a time, ycge_render_frame_async): queues, counters, both spill areas
+    DevBuf<uint8_t> wf2_q0, wf2_q1, wf2_hit, wf2_lq;
+    DevBuf<uint32_t> wf2_seg, wf2_counts;
+    DevBuf<uint64_t> stack_spill_side2;
     // denoise / exposure / tonemap stage (ycge_post.hip), allocated on the first frame that asks for SDR output
     DevBuf<float> den_a, den_b, unit_n, exp_terms, d_sdr, d_sdr2;      // d_sdr2: SDR frames in flight read back one array while the next frame's tonemap fills the other
     DevBuf<float> atrous_statw;                // [pixel][25 taps][3]: colour-independent weight factors of an in-place A-trous iteration
@@ -454,7 +459,8 @@ int alloc_tile_buffers(ycge_ctx *c)
     HIP_TRY(c, c->wf_seg.alloc(4));
     HIP_TRY(c, c->wf_counts.alloc((size_t)(c->n_owned > 0 ? c->n_owned : 1) * 8));
     HIP_TRY(c, c->stack_spill.alloc((size_t)(c->spill_levels > 0 ? c->spill_levels : 1) * stack_lanes));
-    c->stack_spill2.release(); c->stack_spill_side.release();
+    c->stack_spill2.release(); c->stack_spill_side.release(); c->stack_spill_side2.release();
+    c->wf2_q0.release(); c->wf2_q1.release(); c->wf2_hit.release(); c->wf2_lq.release(); c->wf2_seg.release(); c->wf2_counts.release();
     c->path_stack.release();
    
     {
@@ -874,7 +880,8 @@ void ycge_destroy(ycge_ctx *c)
     if (c->placed_flag) (void)hipFree(c->placed_flag);
     for (int k = 0; k < 2; k++) if (c->tile_trace_ev[k]) (void)hipEventDestroy(c->tile_trace_ev[k]);
     for (hipEvent_t ev : {c->flight_taa_ev, c->post_hist_ev, c->post_done_ev, c->post_set_ev[0], c->post_set_ev[1], c->post_set_ev[2]}) if (ev) (void)hipEventDestroy(ev);
-    c->stack_spill2.release(); c->stack_spill_side.release();
+    c->stack_spill2.release(); c->stack_spill_side.release(); c->stack_spill_side2.release();
+    c->wf2_q0.release(); c->wf2_q1.release(); c->wf2_hit.release(); c->wf2_lq.release(); c->wf2_seg.release(); c->wf2_counts.release();
     release_resident(c);
     for (int k = 0; k < 3; k++) if (c->set_resolved_ev[k]) (void)hipEventDestroy(c->set_resolved_ev[k]);
     for (int k = 0; k < 3; k++) { c->flight_order[k].release(); c->flight_ws[k].release(); if (c->flight_order_ev[k]) (void)hipEventDestroy(c->flight_order_ev[k]); }
@@ -2003,7 +2010,14 @@ int trace_frame(ycge_ctx *c, float *d_slab, hipStream_t stream, FrameState &fs, 
         }
     } else {
         const size_t nt = (size_t)(c->n_owned > 0 ? c->n_owned : 1);
+        // (an odd frame in flight runs on the second trace stream beside the frame before it: the second set of stage queues)
+        const bool second = c->in_flight_call && c->spill_override != nullptr;
+        if (second && !c->wf2_q0.p) {
+            HIP_TRY(c, c->wf2_q0.alloc(c->wf_q0.n)); HIP_TRY(c, c->wf2_q1.alloc(c->wf_q1.n)); HIP_TRY(c, c->wf2_hit.alloc(c->wf_hit.n)); HIP_TRY(c, c->wf2_lq.alloc(c->wf_lq.n));
+            HIP_TRY(c, c->wf2_seg.alloc(c->wf_seg.n)); HIP_TRY(c, c->wf2_counts.alloc(c->wf_counts.n));
+        }
         void *bufs[7] = {c->wf_q0.p, c->wf_q1.p, c->wf_hit.p, c->wf_lq.p, c->wf_counts.p, c->wf_counts.p + 7 * nt, c->wf_seg.p};
+        if (second) { bufs[0] = c->wf2_q0.p; bufs[1] = c->wf2_q1.p; bufs[2] = c->wf2_hit.p; bufs[3] = c->wf2_lq.p; bufs[4] = c->wf2_counts.p; bufs[5] = c->wf2_counts.p + 7 * nt; bufs[6] = c->wf2_seg.p; }
         // persistent extend: 32 wavefronts per CU (6 per SIMD resident, the rest queue behind them; measured on the voxel world: 16 per CU 13.1 ms, 20 12.5, 24 12.2, 32 12.0, 40 12.1), within the stack-spill columns
         int pw = c->knobs.no_refill ? 0 : c->compute_units * c->knobs.pw_per_cu;
         if ((size_t)pw * 64 > O.stack_lanes) pw = (int)(O.stack_lanes / 64);
@@ -2013,11 +2027,12 @@ int trace_frame(ycge_ctx *c, float *d_slab, hipStream_t stream, FrameState &fs, 
         // (not where the light loop has nothing to trace - every light dark, timed kernels - nor for the small frames of a burst in flight,
         // where the two stream hops cost more than the overlap gives: config 2 in flight 0.053 -> 0.056 ms, config 5 lit 5.12 -> 4.87)
         const bool beside = !c->knobs.no_lights_beside && c->fan_stream && c->fan_ev[0] && c->fan_ev[1] && c->wf_rounds >= 2 && (c->any_light_lit || c->cfg.count_work) &&
-                            (!c->in_flight_call || c->n_owned >= 8192);
+                            (!c->in_flight_call || c->n_owned >= 4096);
         TraceOut O_side = O;
         if (beside) {
-            if (c->stack_spill_side.n != c->stack_spill.n) HIP_TRY(c, c->stack_spill_side.alloc(c->stack_spill.n));
-            O_side.stack_spill = c->stack_spill_side.p;
+            DevBuf<uint64_t> &side = second ? c->stack_spill_side2 : c->stack_spill_side;
+            if (side.n != c->stack_spill.n) HIP_TRY(c, side.alloc(c->stack_spill.n));
+            O_side.stack_spill = side.p;
         }
         e = ycge_launch_wavefront(&c->sd, &P, &O, bufs, c->wf_rounds, c->has_grid ? 1 : 0, flat, c->cfg.count_work, pw, stream,
                                   beside ? c->fan_stream : nullptr, beside ? c->fan_ev[0] : nullptr, beside ? c->fan_ev[1] : nullptr, beside ? &O_side : nullptr);
@@ -2550,8 +2565,9 @@ int ycge_flight_query(ycge_ctx *c, ycge_flight_info *out)
     if (!c || !out) return YCGE_ERR_INVALID_ARG;
     std::memset(out, 0, sizeof *out);
     const bool single_launch = c->have_scene && frame_is_single_launch(c) && !c->sd.any_transparent;
-    out->two_trace_streams = (c->knobs.flight_overlap && c->stream2 && single_launch) ? 1 : 0;
-    out->placed_gate = (out->two_trace_streams && c->knobs.flight_placed_gate && c->knobs.refill_steps == 0) ? 1 : 0;
+    const bool stage_pair = c->have_scene && !frame_is_single_launch(c) && !c->sd.any_transparent && !c->knobs.no_flight_stage_overlap && c->n_owned >= 4096;      // (the stage pipeline with its second set of queues)
+    out->two_trace_streams = (c->knobs.flight_overlap && c->stream2 && (single_launch || stage_pair)) ? 1 : 0;
+    out->placed_gate = (out->two_trace_streams && single_launch && c->knobs.flight_placed_gate && c->knobs.refill_steps == 0) ? 1 : 0;      // (only the single-launch kernels store the value)
     out->post_gate = c->knobs.flight_post_gate ? 1 : 0;
     out->post_pair = (out->two_trace_streams && c->knobs.flight_post_pair) ? 1 : 0;
     out->frames_outstanding = c->async_outstanding ? 1 : 0;
@@ -2604,7 +2620,11 @@ static int render_frame_in_flight(ycge_ctx *c, float *out_sdr)
     // needed frame N's: its order, its cost slot and its output set are ready once the second stream's work of frame N - 1 is done, which
     // is the one event it waits for.  Only the single-launch kernel (the stage pipeline of voxel worlds shares its queues between frames)
     // and only without refraction stacks.
-    const bool overlap_scene = c->knobs.flight_overlap && c->stream2 && c->have_scene && frame_is_single_launch(c) && !c->sd.any_transparent;
+    const bool overlap_scene = c->knobs.flight_overlap && c->stream2 && c->have_scene && !c->sd.any_transparent &&
+                               (frame_is_single_launch(c) || (!c->knobs.no_flight_stage_overlap && c->n_owned >= 4096 && !out_sdr && !c->post_busy));
+    // (the stage pipeline: a second set of queues, trace_frame; big frames only - small ones gain nothing from a second stream's hops; and not
+    // while a post stage is in flight: its persistent in-place launch needs its band workgroups placed, and behind TWO frames' persistent
+    // extend stages they are not - one run in four of `bench.py --config 5` stretched to 0.4 s a frame, profiles/r04/h_voxel_walk_tree.txt)
     const bool overlap = overlap_scene && (fs.frame & 1);
     hipStream_t ts = overlap ? c->stream2 : c->stream;
     if (overlap && !c->stack_spill2.p) HIP_TRY(c, c->stack_spill2.alloc(c->stack_spill.n));
