@@ -6,6 +6,11 @@
 REPO=${GRAFT_REPO_ROOT:-/root/repo}; cd $REPO; mkdir -p gpurun_out
 TAG=${1:-r04}
 timeout 2400 python -m pytest tests -m gpu -q > gpurun_out/pytest_gpu_$TAG.log 2>&1; echo "pytest rc=$?"; tail -3 gpurun_out/pytest_gpu_$TAG.log
+# the profiles FIRST: bench.py prints the counter-derived roofline fields only from a summary of the running build (profiles/r04/pmc_config*.json, source_hash)
+bash profiles/run_profiles.sh ${TAG}_c4 > gpurun_out/prof_${TAG}_c4.log 2>&1; echo "profiles c4 rc=$?"; head -12 gpurun_out/prof_${TAG}_c4/summary.txt
+bash profiles/run_profiles.sh ${TAG}_c5 --config 5 > gpurun_out/prof_${TAG}_c5.log 2>&1; echo "profiles c5 rc=$?"; head -12 gpurun_out/prof_${TAG}_c5/summary.txt
+bash profiles/run_profiles.sh ${TAG}_c5lit --config 5 --t01 0.5 > gpurun_out/prof_${TAG}_c5lit.log 2>&1; echo "profiles c5 lit rc=$?"; head -12 gpurun_out/prof_${TAG}_c5lit/summary.txt
+mkdir -p profiles/r04; for f in gpurun_out/prof_${TAG}_c4/pmc_config4.json gpurun_out/prof_${TAG}_c5/pmc_config5.json gpurun_out/prof_${TAG}_c5lit/pmc_config5_t050.json; do [ -f $f ] && cp $f profiles/r04/; done
 timeout 600 python bench.py > gpurun_out/bench_$TAG.json 2> gpurun_out/bench_$TAG.err; echo "bench rc=$?"
 for c in 1 2 3 5; do timeout 400 python bench.py --config $c --cpu-seconds 10 2>> gpurun_out/bench_$TAG.err > gpurun_out/bench_${TAG}_cfg$c.json; done
 timeout 500 python bench.py --config 5 --t01 0.5 --cpu-seconds 10 2>> gpurun_out/bench_$TAG.err > gpurun_out/bench_${TAG}_cfg5_t050.json
@@ -20,9 +25,6 @@ except Exception as e:
     print("$f failed", e)
 PY
 done
-bash profiles/run_profiles.sh ${TAG}_c4 > gpurun_out/prof_${TAG}_c4.log 2>&1; echo "profiles c4 rc=$?"; head -12 gpurun_out/prof_${TAG}_c4/summary.txt
-bash profiles/run_profiles.sh ${TAG}_c5 --config 5 > gpurun_out/prof_${TAG}_c5.log 2>&1; echo "profiles c5 rc=$?"; head -12 gpurun_out/prof_${TAG}_c5/summary.txt
-bash profiles/run_profiles.sh ${TAG}_c5lit --config 5 --t01 0.5 > gpurun_out/prof_${TAG}_c5lit.log 2>&1; echo "profiles c5 lit rc=$?"; head -12 gpurun_out/prof_${TAG}_c5lit/summary.txt
 for cfg in 4 3; do echo "== rank emulation config $cfg"; timeout 600 python profiles/rank_times.py $cfg 2>&1 | grep -E "world"; done
 echo "== a rank's period: slab form (two trace streams), tile-resident ring (loop driven from C)"
 for w in 8 4 2; do timeout 300 python profiles/rank_flight.py 4 $w two 2>&1 | tail -1; done

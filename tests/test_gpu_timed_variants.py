@@ -855,8 +855,8 @@ def test_the_walk_tree_of_a_voxel_world(product_lib, oracle, monkeypatch):
     of its objects, built on the device from whichever tree is installed (host builder at upload; device builder after
     ycge_scene_update_objects on a world of >= 1400 chunks) - and what it is for: frames walked down it and down the scene tree
     (YCGE_NO_WALK_TREE) are the same bits, which the oracle parity of every voxel test then covers.  A world with other objects among
-    the grids (their boxes are everything; they keep the object step), grids of air only (left out of a leaf that has others), a
-    fractional lattice."""
+    the grids - spheres and meshes: their boxes are everything, they keep the object step and `tree_phase` -, grids of air only (left
+    out of a leaf that has others), a fractional lattice."""
     from yetanotherconsolegameengine_amd.scene import Material, PointLight, Scene, Solid, Sphere, VolumeGrid, vec3
     monkeypatch.delenv("YCGE_PATH", raising=False)
     # (1) the small voxel world, host-built tree
@@ -877,6 +877,11 @@ def test_the_walk_tree_of_a_voxel_world(product_lib, oracle, monkeypatch):
         s.Add(VolumeGrid(cells, vec3(0.37 + 2.4 * (k % 8), 0.11 + 2.4 * (k // 8), -20.0 + 0.3 * (k % 5)), vec3(0.3, 0.3, 0.3), look))
     for k in range(6):
         s.Add(Sphere(vec3(1.0 + 3.0 * k, 5.0, -14.0), 0.6, Solid(vec3(0.7, 0.3, 0.3))))
+    # ... and two meshes (one with a tree of its own, one whose root is a leaf): a lane leaves walk_phase for them and comes back to it
+    two, _ = _two_mesh_scene()
+    from yetanotherconsolegameengine_amd.scene import Mesh
+    for k, m in enumerate(o for o in two.Objects if isinstance(o, Mesh)):
+        s.Add(Mesh((np.asarray(m.Triangles, np.float32) * np.float32(1.5) + np.array([6.0 + 5.0 * k, 2.0, -12.0], np.float32)).astype(np.float32), m.Mat))
     s.Lights.append(PointLight(vec3(8.0, 30.0, 0.0), vec3(1, 1, 1), 3000.0))
     for ps in (dict(pos=(9.0, 6.0, 6.0), yaw=0.0, pitch=-0.1, fov=60.0), dict(pos=(9.0, 5.0, -19.0), yaw=1.5707964, pitch=0.0, fov=70.0)):
         o, g = pu.run_pair(oracle, s, 96, 27, 2, ps, frames=2, count=False)
