@@ -900,8 +900,11 @@ def test_the_walk_tree_of_a_voxel_world(product_lib, oracle, monkeypatch):
     # (3) the full world: >= 1400 chunks, so ycge_scene_update_objects builds the tree on the device
     sc, w, h, ss, pose = scenes.config_scene(5, t01=0.5)
     flat = flatten(sc)
-    g = RaytraceRenderer(flat, 96, 27, pose["fov"], 2)
+    o, g = pu.run_pair(oracle, sc, 96, 27, 2, pose, frames=1, oracle_threads=16, count=False)
+    _assert_frame(o, g, "full world, host-built tree")
     n_host, opened_host = _check_walk_tree(g, sc)
     g.UpdateObjects(flat)
     assert _check_walk_tree(g, sc) == (n_host, opened_host) and n_host > 300
-    g.close()
+    o.render(stages=1, threads=16); g.TryFlipAndBlit()          # (the same objects: the oracle's tree stands) - the frame walked down the device-built trees
+    _assert_frame(o, g, "full world, device-built tree and its walk tree")
+    o.close(); g.close()
