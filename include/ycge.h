@@ -240,7 +240,7 @@ typedef struct ycge_config {
      * iteration - the denoiser the C# text reads like, fully parallel (~0.2 ms).  The two differ by what INTEGRATION.md states (a filter
      * tap that sees a neighbour's already-filtered value instead of its unfiltered one); everything up to TAA is unaffected. */
     int32_t atrous_inplace_exact;
-    /* tile-resident form (ycge_trace_tiles_resident): frame sets in the ring = tiled traces that may be in flight at a time, 2..7; 0 = 2 */
+    /* tile-resident form (ycge_trace_tiles_resident): frame sets in the ring = tiled traces that may be in flight at a time, 2..15; 0 = 2 */
     int32_t tile_ring;
 } ycge_config;
 
@@ -403,6 +403,13 @@ int ycge_resolve_gathered(ycge_ctx *ctx, const void *d_all_slabs, void *hip_stre
 int ycge_halo_counts(ycge_ctx *ctx, int64_t *send_counts /* [world_size] */, int64_t *recv_counts /* [world_size] */);
 int ycge_history_slab_bytes(const ycge_ctx *ctx, size_t *bytes);      /* padded per-rank size: equal on all ranks */
 int ycge_trace_tiles_resident(ycge_ctx *ctx, void *d_halo_send, void *hip_stream, ycge_frame_stats *stats);
+/* n (1..8, <= the free sets of the ring) CONSECUTIVE frames of this rank's tiles in ONE launch - for a caller that knows the next n camera
+ * poses (a recorder, a benchmark, a render thread that runs ahead): poses = n x {pos x y z, yaw, pitch, fov_deg}, as n ycge_set_camera
+ * calls would give them (the last stays the context's camera); d_halo_send = n buffers, filled as by n ycge_trace_tiles_resident calls.
+ * A rank's share of ONE frame is a few thousand blocks whose longest chains leave most of the machine idle; n frames' blocks in one
+ * launch are the work of a rank of world_size / n ranks - throughput approaches N-fold on N GPUs as n approaches N, at n frames of
+ * latency.  The frames are then exchanged and resolved one by one, oldest first, as after n single calls; same pixels. */
+int ycge_trace_tiles_resident_batch(ycge_ctx *ctx, int32_t n, const float *poses /* n x 6 */, void *const *d_halo_send /* n */, void *hip_stream);
 int ycge_resolve_tiles_resident(ycge_ctx *ctx, const void *d_halo_recv, void *d_history_slab /* may be NULL */, void *hip_stream, ycge_frame_stats *stats);
 int ycge_unpack_history(ycge_ctx *ctx, const void *d_all_history_slabs, void *hip_stream);
 

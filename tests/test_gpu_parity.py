@@ -348,13 +348,16 @@ def _exchange_halos(ranks, send_bufs, torch):
     return recv_bufs
 
 
-@pytest.mark.parametrize("case,world,ring,depth", [("cornell", 2, 0, 1), ("bunny", 4, 4, 3), ("voxel", 3, 3, 2), ("bunny", 8, 6, 5)])
-def test_tile_resident_taa_with_halo_exchange_matches_single_gpu(product_lib, case, world, ring, depth, monkeypatch):
+@pytest.mark.parametrize("case,world,ring,depth,batch", [("cornell", 2, 0, 1, 0), ("bunny", 4, 4, 3, 0), ("voxel", 3, 3, 2, 0), ("bunny", 8, 6, 5, 0),
+                                                         ("bunny", 8, 8, 7, 4), ("bunny", 4, 6, 5, 3), ("cornell", 2, 4, 3, 2), ("voxel", 3, 4, 3, 2)])
+def test_tile_resident_taa_with_halo_exchange_matches_single_gpu(product_lib, case, world, ring, depth, batch, monkeypatch):
     """The tile-RESIDENT form (include/ycge.h): every rank traces its tiles, the ranks exchange the one-pixel {hdr, sky} ring of their
     tiles, each runs TAA on its OWN tiles (history resident), the history slabs are gathered.  `world` ranks emulated on one GPU, the
     exchange by device copies with ycge_halo_counts' split sizes; `depth` + 1 traces are issued before the oldest frame is resolved
     (ring of config.tile_ring sets).  The gathered history equals the single-context frame's, bit for bit, over 8 frames of a camera that
-    moves below and above the TAA reset thresholds (TemporalAA.cs:58-67) - and so do the halo lists the library hands out and tiles.py's."""
+    moves below and above the TAA reset thresholds (TemporalAA.cs:58-67) - and so do the halo lists the library hands out and tiles.py's.
+    batch > 0: the frames are traced `batch` at a time in ONE launch per rank (ycge_trace_tiles_resident_batch: k_trace_batch for the
+    single-launch scenes, frame by frame for the stage pipeline of the voxel world), two batches in flight where the ring has room."""
     import torch
     monkeypatch.delenv("YCGE_PATH", raising=False)
     if case == "cornell":
@@ -406,14 +409,24 @@ def test_tile_resident_taa_with_halo_exchange_matches_single_gpu(product_lib, ca
         if not pending:          # (reading the consumer's frame joins everything: only where no traced frame waits)
             assert pu.bits_equal(ranks[0].read(abi.BUF_TAA_HISTORY), want[i])
 
-    for i in range(len(moves)):
-        send_bufs = [torch.zeros(n * 4, dtype=torch.float32, device="cuda") for n in n_send]
+    pose_of = lambda i: ((pose["pos"][0] + moves[i], pose["pos"][1], pose["pos"][2]), pose["yaw"] + 0.2 * moves[i], pose["pitch"], pose["fov"])
+    i = 0
+    while i < len(moves):
+        n = min(batch, len(moves) - i) if batch else 1
+        while len(pending) + n > max(depth + 1, n):          # room in the ring for the frames about to be traced
+            resolve_oldest()
+        frames_bufs = [[torch.zeros(m * 4, dtype=torch.float32, device="cuda") for m in n_send] for _ in range(n)]
         torch.cuda.current_stream().synchronize()
         for k, r in enumerate(ranks):
-            cam(r, i)
-            r.trace_tiles_resident(send_bufs[k].data_ptr(), sp(t_streams[i % len(t_streams)]))
-        pending.append((i, send_bufs))
-        if len(pending) > depth:
+            if batch:
+                r.trace_tiles_resident_batch([pose_of(i + j) for j in range(n)], [frames_bufs[j][k].data_ptr() for j in range(n)], sp(t_streams[(i // n) % len(t_streams)]))
+            else:
+                cam(r, i)
+                r.trace_tiles_resident(frames_bufs[0][k].data_ptr(), sp(t_streams[i % len(t_streams)]))
+        for j in range(n):
+            pending.append((i + j, frames_bufs[j]))
+        i += n
+        while len(pending) > depth:
             resolve_oldest()
     while pending:
         resolve_oldest()

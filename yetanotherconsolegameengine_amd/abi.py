@@ -198,6 +198,7 @@ _PROTOTYPES = {
     "ycge_halo_counts": (C.c_int, [C.c_void_p, C.POINTER(C.c_int64), C.POINTER(C.c_int64)]),
     "ycge_history_slab_bytes": (C.c_int, [C.c_void_p, C.POINTER(C.c_size_t)]),
     "ycge_trace_tiles_resident": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.POINTER(FrameStats)]),
+    "ycge_trace_tiles_resident_batch": (C.c_int, [C.c_void_p, C.c_int32, C.POINTER(C.c_float), C.POINTER(C.c_void_p), C.c_void_p]),
     "ycge_resolve_tiles_resident": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.POINTER(FrameStats)]),
     "ycge_unpack_history": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p]),
     "ycge_read_buffer": (C.c_int, [C.c_void_p, C.c_int32, C.c_void_p, C.c_size_t]),

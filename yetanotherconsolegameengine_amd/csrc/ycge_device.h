@@ -43,6 +43,7 @@ enum : uint32_t {
 #define YCGE_WALK_IN_ORDER 0x10000000u      // in a REF_WALK_NODE payload (the rest is the index)
 
 // device-side build of the scene-level BVH (ycge_bvh_build.hip): what the kernel hands back to the host
+#define YCGE_TRACE_BATCH_MAX 8          // frames in one launch of k_trace_batch: their parameter and output records ride in the kernel arguments
 #define YCGE_WALK_LEAF_NODES 6          // walk tree: entries set aside per leaf child (a leaf holds at most 7 objects: 6 nodes)
 #define YCGE_BVH_DEV_MAX_ITEMS 2560     // one workgroup keeps the item order and its node queue in LDS
 #define YCGE_BVH_DEV_MIN_ITEMS_DEFAULT 1400     // below this ycge_scene_update_objects builds on the host: the measured crossover of the two builders

@@ -31,9 +31,10 @@ int ycge_launch_trace(const ycge::SceneDev *S, const ycge::FrameParams *P, const
 int ycge_launch_wavefront(const ycge::SceneDev *S, const ycge::FrameParams *P, const ycge::TraceOut *O, void *const bufs[7], int rounds,
                           int has_grid, int flat, int count, int persistent_waves, hipStream_t stream, hipStream_t side, hipEvent_t ev_fork, hipEvent_t ev_join,
                           const ycge::TraceOut *O_side);
+int ycge_launch_trace_batch(const ycge::SceneDev *S, const ycge::FrameParams *P, const ycge::TraceOut *O, int n, int count, int flat, hipStream_t stream);
 int ycge_launch_scene_walk(const void *nodes, int n_inner, const uint32_t *leaf_prims, const void *prims, void *walk, hipStream_t stream);
 int ycge_launch_order_blocks(uint32_t *cost, uint32_t n, uint32_t policy, uint32_t split_top, uint32_t fan_class, uint32_t fan_cap, uint32_t next_slot, uint32_t skip_mask, uint32_t *order_ws,
-                             uint32_t *order, hipStream_t stream, int small_groups = 0, uint32_t n_frames = 0);
+                             uint32_t *order, hipStream_t stream, int small_groups = 0, uint32_t n_frames = 0, uint32_t *snap = nullptr);
 int ycge_launch_taa_tiles(const ycge::TaaParams *T, const ycge::FrameParams *P, const float *current, const float *normal, const float *depth, const uint8_t *sky,
                           float *hist, float *prev_normal, float *prev_depth, uint8_t *prev_sky, hipStream_t stream);
 int ycge_launch_halo(int scatter, float *hdr, uint8_t *sky, const uint32_t *px, uint32_t n, void *records, hipStream_t stream);
@@ -314,7 +315,17 @@ struct ycge_ctx {
         bool traced_used = false, resolved_used = false;
     };
     std::vector<ResidentSet *> rsets;
-    static constexpr uint32_t kResCostFrames = 8;  // the resident ring's own cost ring: K - 1 slots are being written, one is cleared, the rest are read
+    // ycge_trace_tiles_resident_batch: the frames of a batch leave their launch parameters here instead of launching (trace_frame), one
+    // launch traces them all (the records travel as its arguments)
+    bool batch_collect = false;
+    std::vector<FrameParams> batch_P;
+    std::vector<TraceOut> batch_O;
+    static constexpr int kBatchMax = YCGE_TRACE_BATCH_MAX;
+    DevBuf<uint64_t> batch_spill[2];               // a spill area kBatchMax times as wide as a frame's, per batch parity: two batches may run at a time
+    uint64_t batch_count = 0;
+    hipEvent_t batch_done[2] = {nullptr, nullptr}; // a batch's launch: the batch after the next may scratch its spill area after it
+    bool batch_spill_used[2] = {false, false};
+    static constexpr uint32_t kResCostFrames = 16; // the resident ring's own cost ring: K - 1 slots are being written, one is cleared, the rest are read
     DevBuf<uint32_t> res_cost;
     // three schedule buffers taken in turn: one is built behind the trace of every R-th frame M (R = the ring's depth; YCGE_RES_SCHED_EVERY) and
     // serves the frames from M + K on - a trace never waits for a trace younger than frame N - K - until a newer one does
@@ -364,6 +375,7 @@ struct ycge_ctx {
     bool has_dynamic_textures = false;           // Scene.HasDynamicTextures: every frame restarts the TAA history (RaytraceRenderer.cs:171)
     const float *denoised = nullptr;              // result of the last post stage (one of den_a / den_b / taa_hist)
     DevBuf<uint32_t> block_cost, block_order, order_ws;   // k_trace scheduling feedback (4 blocks of 8x8 px per tile)
+    DevBuf<uint32_t> cost_snap;                    // a schedule built while traces are in flight reads a copy of the cost ring (ycge_launch_order_blocks)
     bool block_order_valid = false;
     DevBuf<uint64_t> stack_spill;                 // [YCGE_TRAVERSAL_STACK - 12][persistent lanes]
     bool any_light_lit = false;                   // some light has a contribution (GLight::dark == 0): the timed light loop has shadow rays to trace
@@ -466,6 +478,7 @@ int alloc_tile_buffers(ycge_ctx *c)
     {
         const size_t nb = (size_t)(c->n_owned > 0 ? c->n_owned : 1) * 4;
         HIP_TRY(c, c->block_cost.alloc(nb * YCGE_COST_FRAMES)); HIP_TRY(c, c->block_order.alloc(nb * YCGE_SCHEDULE_SLACK)); HIP_TRY(c, c->order_ws.alloc(96));
+        HIP_TRY(c, c->cost_snap.alloc(nb * (ycge_ctx::kResCostFrames > YCGE_COST_FRAMES ? ycge_ctx::kResCostFrames : YCGE_COST_FRAMES)));
         HIP_TRY(c, hipMemset(c->order_ws.p, 0, 96 * sizeof(uint32_t)));
         HIP_TRY(c, hipMemset(c->block_cost.p, 0, nb * YCGE_COST_FRAMES * sizeof(uint32_t)));
         c->block_order_valid = false;
@@ -883,6 +896,8 @@ void ycge_destroy(ycge_ctx *c)
     c->stack_spill2.release(); c->stack_spill_side.release(); c->stack_spill_side2.release();
     c->wf2_q0.release(); c->wf2_q1.release(); c->wf2_hit.release(); c->wf2_lq.release(); c->wf2_seg.release(); c->wf2_counts.release();
     release_resident(c);
+    c->batch_spill[0].release(); c->batch_spill[1].release();
+    for (int k = 0; k < 2; k++) if (c->batch_done[k]) { (void)hipEventDestroy(c->batch_done[k]); c->batch_done[k] = nullptr; }
     for (int k = 0; k < 3; k++) if (c->set_resolved_ev[k]) (void)hipEventDestroy(c->set_resolved_ev[k]);
     for (int k = 0; k < 3; k++) { c->flight_order[k].release(); c->flight_ws[k].release(); if (c->flight_order_ev[k]) (void)hipEventDestroy(c->flight_order_ev[k]); }
     for (hipEvent_t ev : c->flight_ev) (void)hipEventDestroy(ev);
@@ -894,7 +909,7 @@ void ycge_destroy(ycge_ctx *c)
     c->schedules.clear();
     c->post_progress.release();
     c->alt_post.release();
-    c->wf_q0.release(); c->wf_q1.release(); c->wf_hit.release(); c->wf_lq.release(); c->wf_seg.release(); c->wf_counts.release(); c->tile_order.release(); c->block_cost.release(); c->block_order.release(); c->order_ws.release(); c->stack_spill.release(); c->path_stack.release();
+    c->wf_q0.release(); c->wf_q1.release(); c->wf_hit.release(); c->wf_lq.release(); c->wf_seg.release(); c->wf_counts.release(); c->tile_order.release(); c->block_cost.release(); c->cost_snap.release(); c->block_order.release(); c->order_ws.release(); c->stack_spill.release(); c->path_stack.release();
     c->d_scene_nodes.release(); c->d_walk_nodes.release(); c->d_grid_owner.release(); c->d_mesh_arena.release(); c->d_scene_leaf.release(); c->d_prims.release();
     c->d_bvh_items.release(); c->d_bvh_scratch.release(); c->d_bvh_ref.release(); c->d_bvh_res.release();
     c->d_materials.release(); c->d_meshes.release(); c->d_grids.release(); c->d_cells.release(); c->d_lut.release(); c->d_lights.release(); c->d_tex_pixels.release(); c->d_tex_info.release();
@@ -1918,6 +1933,7 @@ int trace_frame(ycge_ctx *c, float *d_slab, hipStream_t stream, FrameState &fs, 
             O.block_order = c->knobs.no_lpt ? nullptr : rt->order;
             O.n_order = rt->n_order;
             fs.scheduled = O.block_order != nullptr;
+            if (c->batch_collect) { c->batch_P.push_back(P); c->batch_O.push_back(O); return YCGE_OK; }      // (ycge_trace_tiles_resident_batch launches the frames of a batch together)
             if (launch_begin) HIP_TRY(c, hipEventRecord(launch_begin, stream));
             e = ycge_launch_trace(&c->sd, &P, &O, c->cfg.count_work, flat, 0, stream);
             if (launch_end) HIP_TRY(c, hipEventRecord(launch_end, stream));
@@ -1992,7 +2008,7 @@ int trace_frame(ycge_ctx *c, float *d_slab, hipStream_t stream, FrameState &fs, 
             HIP_TRY(c, hipEventRecord(c->traced_ev, stream));
             HIP_TRY(c, hipStreamWaitEvent(c->fan_stream, c->traced_ev, 0));
             e = ycge_launch_order_blocks(c->block_cost.p, n_blocks, policy, split_top, c->fan_class, c->fan_cap, (cost_slot + 2u) % YCGE_COST_FRAMES, 1u << ((cost_slot + 1u) % YCGE_COST_FRAMES),
-                                         c->flight_ws[fk].p, c->flight_order[fk].p, c->fan_stream);
+                                         c->flight_ws[fk].p, c->flight_order[fk].p, c->fan_stream, 0, 0, c->cost_snap.p);          // (the trace of frame N - 1 may still be writing its costs: a copy is read)
             if (e == 0 && c->h_n_fan && c->fan_cap > 0) HIP_TRY(c, hipMemcpyAsync(c->h_n_fan, c->flight_ws[fk].p + 18, sizeof(uint32_t), hipMemcpyDeviceToHost, c->fan_stream));
             HIP_TRY(c, hipEventRecord(c->flight_order_ev[fk], c->fan_stream));
             c->flight_order_frame[fk] = fs.frame + 2;
@@ -2697,7 +2713,7 @@ static int render_frame_in_flight(ycge_ctx *c, float *out_sdr)
         const uint32_t in_flight = (1u << ((uint64_t)(fs.frame + 1) % YCGE_COST_FRAMES)) | (1u << ((uint64_t)(fs.frame + 2) % YCGE_COST_FRAMES));
         const uint32_t target = (uint32_t)((uint64_t)(fs.frame + 3) % YCGE_COST_FRAMES);
         const int fk = (int)((uint64_t)fs.frame % 3u);
-        const int e = ycge_launch_order_blocks(c->block_cost.p, n_blocks, policy, split_top, 0u, 0u, target, in_flight, c->flight_ws[fk].p, c->flight_order[fk].p, c->taa_stream, small ? 1 : 0);
+        const int e = ycge_launch_order_blocks(c->block_cost.p, n_blocks, policy, split_top, 0u, 0u, target, in_flight, c->flight_ws[fk].p, c->flight_order[fk].p, c->taa_stream, small ? 1 : 0, 0, c->cost_snap.p);       // (the trace of frame N - 1, on the other stream, may still be writing the slot this build reads and clears: a copy is read)
         if (e != 0) return c->fail(YCGE_ERR_DEVICE, "schedule launch failed: %s", hipGetErrorString((hipError_t)e));
         c->flight_order_frame[fk] = fs.frame + 3;
         HIP_TRY(c, hipEventRecord(c->flight_order_ev[fk], c->taa_stream));
@@ -2978,7 +2994,7 @@ int ycge_trace_tiles_resident(ycge_ctx *c, void *d_halo_send, void *hip_stream, 
         HIP_TRY(c, hipStreamWaitEvent(c->fan_stream, rs->traced, 0));
         if (c->res_order_frame[(size_t)tb] >= 0) HIP_TRY(c, hipStreamWaitEvent(c->fan_stream, c->res_order_read_ev[(size_t)tb], 0));
         c->res_order_frame[(size_t)tb] = -1;          // (not to be picked while it is being rewritten ...)
-        e = ycge_launch_order_blocks(c->res_cost.p, n_blocks, policy, split_top, 0u, 0u, RC /* the slot nobody reads */, skip, c->res_ws[(size_t)tb]->p, c->res_order[(size_t)tb]->p, c->fan_stream, 0, RC);
+        e = ycge_launch_order_blocks(c->res_cost.p, n_blocks, policy, split_top, 0u, 0u, RC /* the slot nobody reads */, skip, c->res_ws[(size_t)tb]->p, c->res_order[(size_t)tb]->p, c->fan_stream, 0, RC, c->cost_snap.p);      // (traces in flight write their costs meanwhile: a copy is read)
         if (e != 0) return c->fail(YCGE_ERR_DEVICE, "schedule launch failed: %s", hipGetErrorString((hipError_t)e));
         HIP_TRY(c, hipEventRecord(c->res_order_ev[(size_t)tb], c->fan_stream));
         c->res_order_frame[(size_t)tb] = fs.frame;          // (... and from frame N + K on it is the newest)
@@ -2988,6 +3004,112 @@ int ycge_trace_tiles_resident(ycge_ctx *c, void *d_halo_send, void *hip_stream, 
         HIP_TRY(c, hipStreamSynchronize(stream));
         const double wall = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
         return fill_stats(c, st, fs, false, false, wall);
+    }
+    return YCGE_OK;
+}
+
+// n consecutive frames of this rank's tiles in ONE launch (k_trace_batch): what one frame's launch - a rank's share is a few thousand
+// blocks - leaves idle around its longest chains, the other frames' blocks fill.  poses: n x {pos xyz, yaw, pitch, fov} (the camera of each
+// frame, as n ycge_set_camera calls would set it; the last one stays the context's camera); d_halo_send: n buffers, filled as by n
+// ycge_trace_tiles_resident calls.  The frames are then exchanged and resolved one by one, oldest first, as ever.  Same pixels (the frames
+// never needed each other's traces).  Scenes that trace in stages or keep refraction stacks, and counting contexts, take the frames one
+// by one here too.
+int ycge_trace_tiles_resident_batch(ycge_ctx *c, int32_t n, const float *poses, void *const *d_halo_send, void *hip_stream)
+{
+    if (!c) return YCGE_ERR_INVALID_ARG;
+    if (n < 1 || n > ycge_ctx::kBatchMax || !poses) return c->fail(YCGE_ERR_INVALID_ARG, "a batch is 1..%d frames with their poses", ycge_ctx::kBatchMax);
+    { const int jr = join_async(c); if (jr != YCGE_OK) return jr; }
+    int rc = ensure_resident(c);
+    if (rc != YCGE_OK) return rc;
+    size_t n_send = 0;
+    for (int64_t v : c->halo_send_counts) n_send += (size_t)v;
+    if (n_send > 0) { if (!d_halo_send) return c->fail(YCGE_ERR_INVALID_ARG, "null halo send buffers"); for (int k = 0; k < n; k++) if (!d_halo_send[k]) return c->fail(YCGE_ERR_INVALID_ARG, "null halo send buffer of frame %d of the batch", k); }
+    const int K = (int)c->rsets.size();
+    if ((int)c->pending.size() + n > K) return c->fail(YCGE_ERR_INVALID_ARG, "%d traced frames wait to be resolved and %d more are asked for: the ring holds config.tile_ring = %d", (int)c->pending.size(), n, K);
+    auto set_pose = [&](int k) {
+        std::lock_guard<std::mutex> g(c->cam_lock);
+        const float *q = poses + 6 * k;
+        c->cam_pos[0] = q[0]; c->cam_pos[1] = q[1]; c->cam_pos[2] = q[2]; c->yaw = q[3]; c->pitch = q[4]; c->fov_deg = q[5];
+    };
+    const bool single = frame_is_single_launch(c);
+    if (!single || c->sd.any_transparent || c->cfg.count_work || n == 1) {
+        for (int k = 0; k < n; k++) {
+            set_pose(k);
+            rc = ycge_trace_tiles_resident(c, d_halo_send ? d_halo_send[k] : nullptr, hip_stream, nullptr);
+            if (rc != YCGE_OK) return rc;
+        }
+        return YCGE_OK;
+    }
+    hipStream_t stream = hip_stream ? (hipStream_t)hip_stream : c->stream;
+    c->last_stream = stream;
+    const uint32_t n_blocks = (uint32_t)c->n_owned * 4u, RC = ycge_ctx::kResCostFrames;
+    const bool lpt = !c->knobs.no_lpt;
+    std::vector<FrameState> fs((size_t)n);
+    std::vector<ycge_ctx::ResidentSet *> sets((size_t)n, nullptr);
+    c->batch_P.clear(); c->batch_O.clear();
+    int ob = -1;
+    for (int k = 0; k < n; k++) {
+        set_pose(k);
+        snapshot_frame(c, fs[(size_t)k]);
+        ycge_ctx::ResidentSet *rs = sets[(size_t)k] = c->rsets[(size_t)((uint64_t)fs[(size_t)k].frame % (uint64_t)K)];
+        if (rs->resolved_used) HIP_TRY(c, hipStreamWaitEvent(stream, rs->resolved, 0));
+        if (rs->traced_used) HIP_TRY(c, hipStreamWaitEvent(stream, rs->traced, 0));
+        const uint32_t cost_slot = (uint32_t)((uint64_t)fs[(size_t)k].frame % RC);
+        ResidentTarget rt;
+        rt.set = rs;
+        rt.cost = c->res_cost.p + (size_t)cost_slot * n_blocks;
+        rt.order = nullptr; rt.n_order = nullptr;
+        if (k == 0 && lpt) {        // ONE schedule for the whole batch: the newest the batch's first frame may follow (ycge_trace_tiles_resident's rule)
+            for (int b = 0; b < 3; b++)
+                if (c->res_order_frame[(size_t)b] >= 0 && c->res_order_frame[(size_t)b] + K <= fs[0].frame && (ob < 0 || c->res_order_frame[(size_t)b] > c->res_order_frame[(size_t)ob])) ob = b;
+            if (ob >= 0) HIP_TRY(c, hipStreamWaitEvent(stream, c->res_order_ev[(size_t)ob], 0));
+        }
+        if (ob >= 0) { rt.order = c->res_order[(size_t)ob]->p; rt.n_order = c->res_ws[(size_t)ob]->p + 16; }
+        if (lpt) HIP_TRY(c, hipMemsetAsync(rt.cost, 0, (size_t)n_blocks * sizeof(uint32_t), stream));
+        c->batch_collect = true;
+        rc = trace_frame(c, nullptr, stream, fs[(size_t)k], false, nullptr, nullptr, &rt);
+        c->batch_collect = false;
+        if (rc != YCGE_OK) return rc;
+    }
+    if ((int)c->batch_P.size() != n || (int)c->batch_O.size() != n) return c->fail(YCGE_ERR_DEVICE, "batch: %zu of %d frames left their launch parameters", c->batch_P.size(), n);
+    // one spill area for the launch, n frames wide: a workgroup's column is its index in the launch
+    const uint32_t lanes = c->batch_O[0].stack_lanes;
+    const size_t spill_words = (size_t)(c->spill_levels > 0 ? c->spill_levels : 1) * lanes * (size_t)ycge_ctx::kBatchMax;
+    const int bp = (int)(c->batch_count & 1u);
+    if (c->batch_spill[bp].n < spill_words) HIP_TRY(c, c->batch_spill[bp].alloc(spill_words));
+    for (int k = 0; k < n; k++) { c->batch_O[(size_t)k].stack_spill = c->batch_spill[bp].p; c->batch_O[(size_t)k].stack_lanes = lanes * (uint32_t)n; }
+    c->batch_count++;
+    if (c->batch_spill_used[bp]) HIP_TRY(c, hipStreamWaitEvent(stream, c->batch_done[bp], 0));          // (the batch before the last scratched this area)
+    int e = ycge_launch_trace_batch(&c->sd, c->batch_P.data(), c->batch_O.data(), n, 0, scene_is_flat(c), stream);
+    if (e != 0) return c->fail(YCGE_ERR_DEVICE, "k_trace_batch launch failed: %s", hipGetErrorString((hipError_t)e));
+    if (!c->batch_done[bp]) HIP_TRY(c, hipEventCreateWithFlags(&c->batch_done[bp], hipEventDisableTiming));
+    HIP_TRY(c, hipEventRecord(c->batch_done[bp], stream)); c->batch_spill_used[bp] = true;
+    if (ob >= 0) HIP_TRY(c, hipEventRecord(c->res_order_read_ev[(size_t)ob], stream));
+    for (int k = 0; k < n; k++) {
+        ycge_ctx::ResidentSet *rs = sets[(size_t)k];
+        e = ycge_launch_halo(0, rs->hdr.p, rs->sky.p, c->d_halo_send_px.p, (uint32_t)n_send, d_halo_send ? d_halo_send[k] : nullptr, stream);
+        if (e != 0) return c->fail(YCGE_ERR_DEVICE, "k_gather_halo launch failed: %s", hipGetErrorString((hipError_t)e));
+        HIP_TRY(c, hipEventRecord(rs->traced, stream)); rs->traced_used = true;
+        c->pending.push_back(fs[(size_t)k]);
+    }
+    const int every = c->knobs.res_sched_every > 0 ? c->knobs.res_sched_every : K;
+    bool build = false;
+    for (int k = 0; k < n; k++) if (fs[(size_t)k].frame % every == 0) build = true;
+    if (lpt && build) {         // a new schedule behind the batch, from the cost slots up to its last frame's (ycge_trace_tiles_resident's rule)
+        uint32_t policy, split_top;
+        schedule_policy(c, policy, split_top, K);
+        const uint32_t last_slot = (uint32_t)((uint64_t)fs[(size_t)n - 1].frame % RC);
+        uint32_t skip = 0;
+        for (int a = 1; a < K; a++) skip |= 1u << ((last_slot + (uint32_t)a) % RC);
+        const int tb = c->res_order_next;
+        c->res_order_next = (tb + 1) % 3;
+        HIP_TRY(c, hipStreamWaitEvent(c->fan_stream, sets[(size_t)n - 1]->traced, 0));
+        if (c->res_order_frame[(size_t)tb] >= 0) HIP_TRY(c, hipStreamWaitEvent(c->fan_stream, c->res_order_read_ev[(size_t)tb], 0));
+        c->res_order_frame[(size_t)tb] = -1;
+        e = ycge_launch_order_blocks(c->res_cost.p, n_blocks, policy, split_top, 0u, 0u, RC, skip, c->res_ws[(size_t)tb]->p, c->res_order[(size_t)tb]->p, c->fan_stream, 0, RC, c->cost_snap.p);      // (traces in flight write their costs meanwhile: a copy is read)
+        if (e != 0) return c->fail(YCGE_ERR_DEVICE, "schedule launch failed: %s", hipGetErrorString((hipError_t)e));
+        HIP_TRY(c, hipEventRecord(c->res_order_ev[(size_t)tb], c->fan_stream));
+        c->res_order_frame[(size_t)tb] = fs[(size_t)n - 1].frame;
     }
     return YCGE_OK;
 }
@@ -3130,6 +3252,44 @@ int ycge_debug_resident_loop(ycge_ctx *c, int32_t frames, double *period_ms, dou
         return hipEventRecord(evt[k], st[k]) == hipSuccess ? YCGE_OK : YCGE_ERR_DEVICE;
     };
     auto drain = [&]() -> int { while (!issued.empty()) { const int r2 = resolve(issued.front()); issued.pop_front(); if (r2 != YCGE_OK) return r2; } return YCGE_OK; };
+    // YCGE_RES_LOOP_BATCH=n: the frames n at a time in one launch (ycge_trace_tiles_resident_batch), consecutive batches on two streams
+    const int nb = getenv("YCGE_RES_LOOP_BATCH") ? atoi(getenv("YCGE_RES_LOOP_BATCH")) : 0;
+    if (nb > 1) {
+        if (nb > K || nb > ycge_ctx::kBatchMax) { cleanup(); return c->fail(YCGE_ERR_INVALID_ARG, "YCGE_RES_LOOP_BATCH=%d needs a ring of at least that many sets (and <= %d)", nb, ycge_ctx::kBatchMax); }
+        float pose[6 * ycge_ctx::kBatchMax];
+        { std::lock_guard<std::mutex> g(c->cam_lock); for (int k = 0; k < nb; k++) { pose[6 * k] = c->cam_pos[0]; pose[6 * k + 1] = c->cam_pos[1]; pose[6 * k + 2] = c->cam_pos[2]; pose[6 * k + 3] = c->yaw; pose[6 * k + 4] = c->pitch; pose[6 * k + 5] = c->fov_deg; } }
+        int64_t batches = 0;
+        auto batch = [&]() -> int {
+            while ((int)issued.size() + nb > K) { const int r2 = resolve(issued.front()); issued.pop_front(); if (r2 != YCGE_OK) return r2; }
+            hipStream_t bs = st[(size_t)((batches++ & 1) * (K >= 3 ? 2 : 1))];          // (streams 0 and 2 of the loop: neighbours share a hardware queue on this runtime - 4 queues, round robin)
+            void *sends[ycge_ctx::kBatchMax];
+            int slots[ycge_ctx::kBatchMax];
+            for (int k = 0; k < nb; k++) { slots[k] = (int)(i++ % K); sends[k] = send[(size_t)slots[k]]; if (hipStreamWaitEvent(bs, evr[(size_t)slots[k]], 0) != hipSuccess) return YCGE_ERR_DEVICE; }
+            const int r2 = ycge_trace_tiles_resident_batch(c, nb, pose, sends, bs);
+            if (r2 != YCGE_OK) return r2;
+            for (int k = 0; k < nb; k++) { issued.push_back(slots[k]); if (hipEventRecord(evt[(size_t)slots[k]], bs) != hipSuccess) return YCGE_ERR_DEVICE; }
+            // the frames of the batch before the last are resolved NOW (they run beside the launches in flight, starved: a batch that re-uses
+            // their sets should find them done - a ring of three batches' sets lets consecutive launches lie side by side)
+            while ((int)issued.size() > 2 * nb) { const int r3 = resolve(issued.front()); issued.pop_front(); if (r3 != YCGE_OK) return r3; }
+            return YCGE_OK;
+        };
+        const int nbat = (frames + nb - 1) / nb;
+        for (int w = 0; w < 4 && rc == YCGE_OK; w++) rc = batch();
+        if (rc == YCGE_OK) rc = drain();
+        if (rc != YCGE_OK) { cleanup(); return rc; }
+        LOOP_TRY(hipDeviceSynchronize());
+        const auto b0 = std::chrono::steady_clock::now();
+        for (int f = 0; f < nbat && rc == YCGE_OK; f++) rc = batch();
+        if (rc == YCGE_OK) rc = drain();
+        const auto b1 = std::chrono::steady_clock::now();
+        if (rc != YCGE_OK) { cleanup(); return rc; }
+        LOOP_TRY(hipDeviceSynchronize());
+        const auto b2 = std::chrono::steady_clock::now();
+        *issue_ms = std::chrono::duration<double, std::milli>(b1 - b0).count() / (nbat * nb);
+        *period_ms = std::chrono::duration<double, std::milli>(b2 - b0).count() / (nbat * nb);
+        cleanup();
+        return YCGE_OK;
+    }
     for (int w = 0; w < 12 && rc == YCGE_OK; w++) rc = frame();
     if (rc == YCGE_OK) rc = drain();
     if (rc != YCGE_OK) { cleanup(); return rc; }

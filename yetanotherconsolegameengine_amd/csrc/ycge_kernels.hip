@@ -1150,6 +1150,25 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu((FLAT && !CO
     } else if (blockIdx.x >= (uint32_t)P.n_owned_tiles * 4u) return;
     trace_block<COUNT, FLAT, 0>(S, P, O, ent, idx, nullptr, 0);
 }
+// SEVERAL frames' blocks in one launch (ycge_trace_tiles_resident_batch: a rank's tiles of n consecutive frames): workgroup b traces
+// schedule entry b / n of frame b % n - the frames share one schedule, so the heaviest blocks of every frame go first - with that frame's
+// parameters and outputs (records in the launch's own arguments, read with scalar loads: the index is wave-uniform).  What one frame's launch leaves
+// idle around its longest chains, the other frames' blocks fill without any help from the queues.  The frames' TraceOut records share ONE
+// spill area n times as wide (the column is the workgroup's index in the launch).
+struct TraceBatch { FrameParams P[YCGE_TRACE_BATCH_MAX]; TraceOut O[YCGE_TRACE_BATCH_MAX]; };        // kernel ARGUMENT (2.7 KB of the 4 KB a launch may carry): nothing to stage, nothing a host that runs ahead could overwrite
+template <bool COUNT, bool FLAT>
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu((FLAT && !COUNT) ? YCGE_TRACE_WAVES : 2, 8))) void k_trace_batch(const SceneDev S, const TraceBatch B, const uint32_t n)
+{
+    const uint32_t f = blockIdx.x % n, i = blockIdx.x / n;
+    const FrameParams &P = B.P[f];
+    const TraceOut &O = B.O[f];
+    uint32_t idx = i, ent = i;
+    if (O.block_order) {
+        if (idx >= *O.n_order) return;
+        ent = O.block_order[idx];
+    } else if (i >= (uint32_t)P.n_owned_tiles * 4u) return;
+    trace_block<COUNT, FLAT, 0>(S, P, O, ent, idx, nullptr, 0);
+}
 // The same kernel for scenes WITHOUT a mesh (nothing to walk cooperatively: the treelet code is compiled out and, with it, the register
 // peak): 125 registers, 4 wavefronts per SIMD - analytic scenes are throughput, not chains (config 2: 0.082 ms at 3 wavefronts, 0.068 at 4).
 __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 8))) void k_trace_nomesh(const SceneDev S, const FrameParams P, const TraceOut O)
@@ -1259,7 +1278,10 @@ __device__ __forceinline__ ClassLayout class_layout(const uint32_t *ws, int cls,
     }
     return L;
 }
-__global__ __launch_bounds__(1024) void k_cost_scatter(uint32_t *__restrict__ cost, uint32_t n, uint32_t capacity, uint32_t policy, uint32_t split_top,
+// cost: what k_cost_hist read - the SAME values, or a block's class here and its class in the histogram differ and the entries land
+// outside their class's range (holes of stale entries, writes past the list): where traces may still be writing costs while the schedule
+// is built (traces in flight), both kernels read a snapshot of the ring (ycge_launch_order_blocks) and `clear` is the live ring.
+__global__ __launch_bounds__(1024) void k_cost_scatter(const uint32_t *__restrict__ cost, uint32_t *__restrict__ clear, uint32_t n, uint32_t capacity, uint32_t policy, uint32_t split_top,
                                                        uint32_t fan_class, uint32_t fan_cap, uint32_t next_slot, uint32_t skip_mask, uint32_t n_frames, uint32_t *__restrict__ ws, uint32_t *__restrict__ order)
 {
     __shared__ uint32_t h[YCGE_ORDER_CLASSES], rank0[YCGE_ORDER_CLASSES];
@@ -1288,7 +1310,7 @@ __global__ __launch_bounds__(1024) void k_cost_scatter(uint32_t *__restrict__ co
     uint32_t local = 0;
     if (i < n) {
         cls = order_class(smoothed_cost(cost, n, i, skip_mask, n_frames));
-        cost[(size_t)next_slot * n + i] = 0;         // the ring slot the next frame's atomicMax goes to
+        clear[(size_t)next_slot * n + i] = 0;        // the ring slot the next frame's atomicMax goes to
         local = atomicAdd(&h[cls], 1u);
     }
     __syncthreads();
@@ -1580,6 +1602,20 @@ int ycge_launch_trace(const ycge::SceneDev *S, const ycge::FrameParams *P, const
     return (int)hipGetLastError();
 }
 
+// n frames' blocks in one launch (k_trace_batch); P / O: n records each (host memory: they travel as kernel arguments)
+int ycge_launch_trace_batch(const ycge::SceneDev *S, const ycge::FrameParams *P, const ycge::TraceOut *O, int n, int count, int flat, hipStream_t stream)
+{
+    using namespace ycge;
+    if (n <= 0 || n > YCGE_TRACE_BATCH_MAX || P[0].n_owned_tiles <= 0) return 0;
+    TraceBatch B = {};
+    for (int k = 0; k < n; k++) { B.P[k] = P[k]; B.O[k] = O[k]; }
+    const dim3 grid((unsigned)P[0].n_owned_tiles * 4u * YCGE_SCHEDULE_SLACK * (unsigned)n), block(64);
+    sel3(count != 0, flat != 0, false, [&](auto C, auto F, auto) {
+        hipLaunchKernelGGL((k_trace_batch<decltype(C)::value, decltype(F)::value>), grid, block, 0, stream, *S, B, (uint32_t)n);
+    });
+    return (int)hipGetLastError();
+}
+
 // wavefront path.  bufs = {q0, q1, hit, lq, n_q, n_lq}: queues segmented per owned tile (256 entries each),
 // n_q = (rounds + 1) x tiles counts, n_lq = tiles counts.  Every stage is one workgroup per tile.
 // side / ev_fork / ev_join (optional): the light loop of round r - shadow rays from the vertices shade(r) found - and the trace of round
@@ -1638,18 +1674,28 @@ int ycge_launch_wavefront(const ycge::SceneDev *S, const ycge::FrameParams *P, c
 
 // builds next frame's k_trace schedule from this frame's per-block step counts.  ws: 18 uint32 (see k_cost_hist)
 int ycge_launch_order_blocks(uint32_t *cost, uint32_t n, uint32_t policy, uint32_t split_top, uint32_t fan_class, uint32_t fan_cap, uint32_t next_slot, uint32_t skip_mask,
-                             uint32_t *ws, uint32_t *order, hipStream_t stream, int small_groups, uint32_t n_frames)
+                             uint32_t *ws, uint32_t *order, hipStream_t stream, int small_groups, uint32_t n_frames, uint32_t *snap)
 {
     if (n == 0) return 0;
     if (n_frames == 0) n_frames = YCGE_COST_FRAMES;
+    // snap (n x n_frames words of scratch, or null): the histogram and the scatter read a COPY of the cost ring taken first - wherever a
+    // trace may still be writing costs while this schedule is built (frames in flight, tiled frames on two streams, the tile-resident
+    // ring).  The two kernels must see the same class for every block (k_cost_scatter); a copy that is itself half-updated only costs
+    // the schedule a little of its quality.
+    const uint32_t *read = cost;
+    if (snap) {
+        const hipError_t e0 = hipMemcpyAsync(snap, cost, (size_t)n * n_frames * sizeof(uint32_t), hipMemcpyDeviceToDevice, stream);
+        if (e0 != hipSuccess) return (int)e0;
+        read = snap;
+    }
     // small_groups (frames in flight): a 1024-thread workgroup needs a quarter of a CU cleared before it starts and so waited for the
     // last third of the trace running beside it; four wavefronts find room far sooner (one-wavefront groups were no better)
     const unsigned threads = small_groups ? 256u : 1024u;
     hipError_t e = hipMemsetAsync(ws, 0, 96 * sizeof(uint32_t), stream);     // ws[16] / ws[18] (entries, n_fan) are rewritten by k_cost_scatter before anyone reads them
     if (e != hipSuccess) return (int)e;
     const dim3 grid((n + threads - 1u) / threads), block(threads);
-    hipLaunchKernelGGL(ycge::k_cost_hist, grid, block, 0, stream, cost, n, skip_mask, n_frames, ws);
-    hipLaunchKernelGGL(ycge::k_cost_scatter, grid, block, 0, stream, cost, n, n * YCGE_SCHEDULE_SLACK, policy, split_top, fan_class, fan_cap, next_slot, skip_mask, n_frames, ws, order);
+    hipLaunchKernelGGL(ycge::k_cost_hist, grid, block, 0, stream, read, n, skip_mask, n_frames, ws);
+    hipLaunchKernelGGL(ycge::k_cost_scatter, grid, block, 0, stream, read, cost, n, n * YCGE_SCHEDULE_SLACK, policy, split_top, fan_class, fan_cap, next_slot, skip_mask, n_frames, ws, order);
     return (int)hipGetLastError();
 }
 

@@ -238,6 +238,15 @@ class RaytraceRenderer:
         st = C.byref(self.stats) if want_stats else None
         self._check(self.L.ycge_trace_tiles_resident(self.ctx, C.c_void_p(d_halo_send_ptr), C.c_void_p(stream_ptr), st))
 
+    def trace_tiles_resident_batch(self, poses, d_halo_send_ptrs, stream_ptr: int = 0):
+        """n consecutive frames of this rank's tiles in one launch (ycge_trace_tiles_resident_batch): poses = n x (pos, yaw, pitch, fov)."""
+        n = len(poses)
+        flat = (C.c_float * (6 * n))()
+        for k, (pos, yaw, pitch, fov) in enumerate(poses):
+            flat[6 * k:6 * k + 6] = [pos[0], pos[1], pos[2], yaw, pitch, fov]
+        ptrs = (C.c_void_p * n)(*[C.c_void_p(p) for p in d_halo_send_ptrs])
+        self._check(self.L.ycge_trace_tiles_resident_batch(self.ctx, n, flat, ptrs, C.c_void_p(stream_ptr)))
+
     def resolve_tiles_resident(self, d_halo_recv_ptr: int, d_history_slab_ptr: int = 0, stream_ptr: int = 0, want_stats: bool = False):
         st = C.byref(self.stats) if want_stats else None
         self._check(self.L.ycge_resolve_tiles_resident(self.ctx, C.c_void_p(d_halo_recv_ptr), C.c_void_p(d_history_slab_ptr), C.c_void_p(stream_ptr), st))
