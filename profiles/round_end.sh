@@ -30,6 +30,9 @@ echo "== a rank's period: slab form (two trace streams), tile-resident ring (loo
 for w in 8 4 2; do timeout 300 python profiles/rank_flight.py 4 $w two 2>&1 | tail -1; done
 for w in 8 4 2; do for k in 2 4; do timeout 300 python profiles/rank_flight.py 4 $w residentc $k 2>&1 | tail -1; done; done
 timeout 300 python profiles/rank_flight.py 3 8 residentc 4 2>&1 | tail -1; timeout 300 python profiles/rank_flight.py 5 8 residentc 2 2>&1 | tail -1
+echo "== ... n frames of a rank's tiles in ONE launch (ycge_trace_tiles_resident_batch; ring = three batches' sets)"
+for spec in "8 6 2" "8 12 4" "8 15 5" "4 6 2" "4 12 4" "2 6 2" "2 12 4"; do set -- $spec; echo -n "batch $3: "; YCGE_RES_LOOP_BATCH=$3 timeout 300 python profiles/rank_flight.py 4 $1 residentc $2 2>&1 | tail -1; done
+echo -n "batch 4: "; YCGE_RES_LOOP_BATCH=4 timeout 300 python profiles/rank_flight.py 3 8 residentc 12 2>&1 | tail -1
 echo "== frames in flight against the synchronous call"; for cfg in 4 3 2 5; do timeout 300 python profiles/flight_ab.py $cfg 300 2>&1 | tail -2; done
 echo "== post stage: exact and waived (config.atrous_inplace_exact)"; timeout 600 python profiles/post_waiver.py 2>&1 | grep -v amdgpu.ids
 echo "== post stage bands"; for a in "4 1 270" "5 2 540"; do set -- $a; CFG=$1 SS=$2 NB=$3 timeout 300 python profiles/post_bands.py 2>&1 | grep -E "^post|launch span|chain:"; done
