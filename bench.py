@@ -13,8 +13,9 @@ How N GPUs are driven (`--form`):
            device 0's frame buffers over xGMI, TAA on device 0.  This is what a plain `python bench.py --gpus N` runs (auto, no
            launcher).  Fails loudly when fewer than N devices are visible.
   rccl     one process per GPU under torchrun (RANK / WORLD_SIZE in the environment): ycge_trace_tiles -> one RCCL all-gather of
-           the tile slabs -> ycge_resolve_gathered on every rank.  What `auto` picks when WORLD_SIZE > 1.
-  resident one process per GPU under torchrun, the tile-RESIDENT form: ycge_trace_tiles_resident (--ring traces in flight) -> one RCCL
+           the tile slabs -> ycge_resolve_gathered on every rank.
+  resident (what `auto` picks when WORLD_SIZE > 1) one process per GPU under torchrun, the tile-RESIDENT form: ycge_trace_tiles_resident_batch
+           (--batch frames of the rank's tiles per launch, a ring of --ring >= 3 x batch frame sets; --batch 0: frame by frame) -> one RCCL
            all-to-all of the one-pixel halo records (1.4 MB per rank at 8 ranks) -> ycge_resolve_tiles_resident (TAA on the rank's own
            tiles, history resident) -> all-gather of the resolved history (12 B per pixel) -> ycge_unpack_history.  3.1 MB leave a rank
            per frame instead of 8.3, 25 MB arrive instead of 66.
@@ -120,6 +121,7 @@ def main():
     ap.add_argument("--camera", choices=("static", "orbit"), default="static", help="orbit: the pose changes every frame of the timed region (the headline then is the moving-camera frame)")
     ap.add_argument("--form", choices=("auto", "onecall", "rccl", "resident"), default="auto", help="how N > 1 GPUs are driven (see the module docstring)")
     ap.add_argument("--ring", type=int, default=4, help="--form resident: frame sets in the ring = tiled traces in flight (config.tile_ring)")
+    ap.add_argument("--batch", type=int, default=4, help="--form resident: frames of a rank's tiles traced in ONE launch (ycge_trace_tiles_resident_batch; 0 or 1 = frame by frame); the ring is then at least three batches deep")
     ap.add_argument("--t01", type=float, default=0.25, help="config 5: day phase of the sun and moon (DayNightCycle.cs:48-82); 0.25 = SURVEY 8(d): sun on the horizon, BOTH lights at intensity 0; 0.5 = noon, 0.8 = night")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
@@ -133,10 +135,15 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     form = args.form
     if form == "auto":
-        form = "rccl" if world > 1 else "onecall"
+        # under a launcher: the tile-resident form with batched launches - by per-rank emulation 0.12 ms a rank-frame at 8 ranks on config 4
+        # against 0.28 for the slab form; both forms run under torchrun + RCCL on one rank (profiles/r4_forms.sh)
+        form = "resident" if world > 1 else "onecall"
     resident = form == "resident"
     if resident:
         form = "rccl"          # (the same launcher, ranks and tile partition; only the per-frame exchange differs)
+        if args.batch > 1:
+            args.batch = min(args.batch, 5)
+            args.ring = min(15, max(args.ring, 3 * args.batch))
     if form == "rccl" and world != args.gpus and not (world == 1 and os.environ.get("YCGE_BENCH_FORCE_TILED")):
         raise SystemExit(f"--form rccl --gpus {args.gpus} needs one process per GPU (torchrun --nproc-per-node {args.gpus}); WORLD_SIZE={world}")
     if form == "onecall" and world > 1:
@@ -217,6 +224,8 @@ def main():
         rs_ev_t = [torch.cuda.Event() for _ in range(K)]; rs_ev_r = [torch.cuda.Event() for _ in range(K)]
         rs_issued = []
         s_traces = rs_traces[:2] if K >= 2 else [rs_traces[0], rs_traces[0]]
+        B = args.batch if args.batch > 1 else 0
+        rs_poses, rs_batches = [], [0]
 
         def rs_resolve(k):
             with torch.cuda.stream(s_comm):
@@ -227,11 +236,36 @@ def main():
                 r.unpack_history(h_all[k].data_ptr(), s_comm.cuda_stream)
                 rs_ev_r[k].record(s_comm)
 
+    def rs_issue_batch(rr):
+        """the frames whose poses wait in rs_poses, in ONE launch; consecutive batches on two streams; resolves issued as soon as a batch is two batches old"""
+        n = len(rs_poses)
+        while len(rs_issued) + n > K:
+            rs_resolve(rs_issued.pop(0))
+        slots = [(n_issued[0] + j) % K for j in range(n)]
+        n_issued[0] += n
+        st = rs_traces[(rs_batches[0] & 1) * (2 if K >= 3 else 1)]          # (neighbouring streams tend to share a hardware queue: 4 queues, round robin)
+        rs_batches[0] += 1
+        with torch.cuda.stream(st):
+            for k in slots:
+                st.wait_event(rs_ev_r[k])
+            rr.trace_tiles_resident_batch(list(rs_poses), [h_send[k].data_ptr() for k in slots], st.cuda_stream)
+            for k in slots:
+                rs_ev_t[k].record(st)
+        rs_issued.extend(slots)
+        rs_poses.clear()
+        while len(rs_issued) > 2 * n:
+            rs_resolve(rs_issued.pop(0))
+
     def step(rr, want_stats=False):
         """One frame; returns (trace_ms, frame_ms) as the library measured them (0 where the pipelined form takes no per-step timing)."""
         if not multi:
             rr.TryFlipAndBlit()
             return float(rr.stats.trace_ms), float(rr.stats.total_ms)
+        if resident and rr is r and not want_stats and B:
+            rs_poses.append((tuple(rr._pos), rr._yaw, rr._pitch, rr._fov))
+            if len(rs_poses) == B:
+                rs_issue_batch(rr)
+            return 0.0, 0.0
         if resident and rr is r and not want_stats:
             if len(rs_issued) == K:
                 rs_resolve(rs_issued.pop(0))
@@ -265,6 +299,8 @@ def main():
 
     def fence():
         if multi and resident:
+            if B and rs_poses:
+                rs_issue_batch(r)
             while rs_issued:
                 rs_resolve(rs_issued.pop(0))
             for s_ in rs_traces:
@@ -480,7 +516,7 @@ def main():
     if rank == 0:
         name, cus = r.device_info()
         how = ("one process, one ycge_render_frame call per frame drives all devices; peers push their tiles into device 0 over xGMI" if (form == "onecall" and n_dev > 1)
-               else f"one process per GPU, tile-resident TAA; per frame one RCCL all-to-all of the one-pixel halo records and one all-gather of the resolved history (12 B per pixel); {args.ring} traces in flight" if (multi and resident)
+               else f"one process per GPU, tile-resident TAA; per frame one RCCL all-to-all of the one-pixel halo records and one all-gather of the resolved history (12 B per pixel); a ring of {args.ring} frame sets" + (f", {args.batch} frames of the rank's tiles per launch (ycge_trace_tiles_resident_batch)" if args.batch > 1 else ", frame by frame") if (multi and resident)
                else "one process per GPU; one RCCL all-gather of the tile slabs per frame" + ("; traces of consecutive frames on two streams (they may overlap), gather + resolve of frame N on a third" if pipelined else "") if multi else "single GPU")
         out = {
             "metric": f"Mrays/s (all rays: Scene.Hit + Scene.Occluded calls) and ms/frame, {METRIC_SHAPES[args.config]}",

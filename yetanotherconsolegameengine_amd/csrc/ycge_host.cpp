@@ -321,7 +321,7 @@ struct ycge_ctx {
     std::vector<FrameParams> batch_P;
     std::vector<TraceOut> batch_O;
     static constexpr int kBatchMax = YCGE_TRACE_BATCH_MAX;
-    DevBuf<uint64_t> batch_spill[2];               // a spill area kBatchMax times as wide as a frame's, per batch parity: two batches may run at a time
+    DevBuf<uint64_t> batch_spill[2];               // a spill area as wide as the batch's frames together, per batch parity: two batches may run at a time
     uint64_t batch_count = 0;
     hipEvent_t batch_done[2] = {nullptr, nullptr}; // a batch's launch: the batch after the next may scratch its spill area after it
     bool batch_spill_used[2] = {false, false};
@@ -3074,9 +3074,13 @@ int ycge_trace_tiles_resident_batch(ycge_ctx *c, int32_t n, const float *poses, 
     if ((int)c->batch_P.size() != n || (int)c->batch_O.size() != n) return c->fail(YCGE_ERR_DEVICE, "batch: %zu of %d frames left their launch parameters", c->batch_P.size(), n);
     // one spill area for the launch, n frames wide: a workgroup's column is its index in the launch
     const uint32_t lanes = c->batch_O[0].stack_lanes;
-    const size_t spill_words = (size_t)(c->spill_levels > 0 ? c->spill_levels : 1) * lanes * (size_t)ycge_ctx::kBatchMax;
+    const size_t spill_words = (size_t)(c->spill_levels > 0 ? c->spill_levels : 1) * lanes * (size_t)n;
     const int bp = (int)(c->batch_count & 1u);
-    if (c->batch_spill[bp].n < spill_words) HIP_TRY(c, c->batch_spill[bp].alloc(spill_words));
+    for (int q = 0; q < 2; q++)          // (both areas at the first batch of a size: an allocation of gigabytes is no part of a later frame)
+        if (c->batch_spill[q].n < spill_words) {
+            if (c->batch_spill_used[q]) HIP_TRY(c, hipEventSynchronize(c->batch_done[q]));
+            HIP_TRY(c, c->batch_spill[q].alloc(spill_words));
+        }
     for (int k = 0; k < n; k++) { c->batch_O[(size_t)k].stack_spill = c->batch_spill[bp].p; c->batch_O[(size_t)k].stack_lanes = lanes * (uint32_t)n; }
     c->batch_count++;
     if (c->batch_spill_used[bp]) HIP_TRY(c, hipStreamWaitEvent(stream, c->batch_done[bp], 0));          // (the batch before the last scratched this area)
