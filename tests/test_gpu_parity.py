@@ -437,6 +437,13 @@ def test_tile_resident_taa_with_halo_exchange_matches_single_gpu(product_lib, ca
         ranks[0].trace_tiles_resident(send_bufs[j].data_ptr(), 0)
     with pytest.raises(abi.YcgeError, match="tile_ring"):
         ranks[0].trace_tiles_resident(send_bufs[K].data_ptr(), 0)
+    # ... and so does a batch: more frames than the ring has free sets, more than a launch carries, none
+    with pytest.raises(abi.YcgeError, match="tile_ring"):
+        ranks[0].trace_tiles_resident_batch([pose_of(0)] * 2, [send_bufs[0].data_ptr()] * 2, 0)
+    with pytest.raises(abi.YcgeError, match="1..8"):
+        ranks[1].trace_tiles_resident_batch([pose_of(0)] * 9, [send_bufs[0].data_ptr()] * 9, 0)
+    with pytest.raises(abi.YcgeError, match="1..8"):
+        ranks[1].trace_tiles_resident_batch([], [], 0)
     for r in ranks + [single]:
         r.close()
 

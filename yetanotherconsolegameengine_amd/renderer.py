@@ -144,14 +144,30 @@ class RaytraceRenderer:
         p = (C.c_float * 3)(*self._pos)
         self._check(self.L.ycge_set_camera(self.ctx, p, self._yaw, self._pitch, self._fov))
 
+    _PAGE = 4096
+
+    def _page_locked_zeros(self, shape):
+        """A float32 array on WHOLE pages of its own, page-locked through ycge_pin_host_buffer (hipHostRegister): (array, pinned).
+        Registration is page-granular.  A numpy array straight from the heap shares its first and last page with whatever malloc put
+        next to it - another renderer's SDR array, the next slot of the ring - and unregistering ONE of two arrays that share a page
+        takes the page from the other: its next read-back is a GPU write to an unmapped host page ("Memory access fault by GPU" at a
+        heap address, once in a dozen runs of the GPU suite - round 4).  So: over-allocate, start on a page boundary, register whole
+        pages that belong to this array alone."""
+        n = int(np.prod(shape)) * 4
+        span = (n + self._PAGE - 1) // self._PAGE * self._PAGE
+        raw = np.zeros(span + self._PAGE, dtype=np.uint8)
+        off = (-raw.ctypes.data) % self._PAGE
+        a = raw[off:off + n].view(np.float32).reshape(shape)          # (keeps `raw` alive through .base)
+        pinned = self.L.ycge_pin_host_buffer(C.c_void_p(a.ctypes.data), span) == 0      # (best effort: an unpinned array only makes the copy block)
+        return a, pinned
+
     def _sdr_buffer(self):
         """The wrapper's ONE SDR buffer (the C# side keeps a float[] for the life of the renderer), page-locked
         once through ycge_pin_host_buffer so that the frame's read-back is a plain DMA."""
         shape = (self.fbH, self.fbW, 2, 3)
         if getattr(self, "_sdr", None) is None or self._sdr.shape != shape:
             self._drop_sdr_buffer()
-            self._sdr = np.zeros(shape, dtype=np.float32)
-            self._sdr_pinned = self.L.ycge_pin_host_buffer(self._sdr.ctypes.data_as(C.c_void_p), self._sdr.nbytes) == 0
+            self._sdr, self._sdr_pinned = self._page_locked_zeros(shape)
         return self._sdr
 
     def _drop_sdr_buffer(self):
@@ -181,9 +197,7 @@ class RaytraceRenderer:
         if key in ring and ring[key][0].shape != (self.fbH, self.fbW, 2, 3):
             self._drop_sdr_ring(keep_shape=(self.fbH, self.fbW, 2, 3))
         if key not in ring:
-            a = np.zeros((self.fbH, self.fbW, 2, 3), dtype=np.float32)
-            pinned = self.L.ycge_pin_host_buffer(a.ctypes.data_as(C.c_void_p), a.nbytes) == 0      # (best effort: an unpinned array only makes the copy block)
-            ring[key] = (a, pinned)
+            ring[key] = self._page_locked_zeros((self.fbH, self.fbW, 2, 3))
         a = ring[key][0]
         self._check(self.L.ycge_render_frame_async_sdr(self.ctx, a.ctypes.data_as(C.POINTER(C.c_float))))
         return a
