@@ -695,3 +695,41 @@ def test_desired_chunk_set_known_answer():
     assert neg == [(-1, 0, -1)]
     half = wf.build_desired_set((10.0, 0.0, 10.0), (0.0, 0.0, 0.0), (0.5, 0.5, 0.5), 16, 1, 2)       # 8-unit chunks: column 1
     assert len(half) == 3 * 3 * 2 and half[0] == (0, 0, 0) and half[-1] == (2, 1, 2)
+
+
+def test_page_locked_arrays_own_their_pages():
+    """renderer.py page-locks its SDR arrays with ycge_pin_host_buffer (hipHostRegister, page-granular): every registered range must start on a
+    page boundary, be whole pages, lie inside the array's own allocation and share no page with another array's - two registered heap arrays
+    that share a boundary page lose it when one of them is unregistered (the GPU memory fault of round 4, NOTEBOOK section 11)."""
+    import ctypes as C
+    from yetanotherconsolegameengine_amd.renderer import RaytraceRenderer
+
+    calls = []
+
+    class _Lib:
+        @staticmethod
+        def ycge_pin_host_buffer(ptr, n):
+            calls.append((ptr.value, n)); return 0
+
+    class _Self:
+        L = _Lib(); _PAGE = RaytraceRenderer._PAGE
+
+    arrays = []
+    for shape in [(27, 96, 2, 3), (27, 96, 2, 3), (360, 1280, 2, 3), (1, 1, 2, 3), (45, 160, 2, 3)] * 3:
+        a, pinned = RaytraceRenderer._page_locked_zeros(_Self(), shape)
+        assert pinned and a.shape == shape and a.dtype == np.float32 and a.flags["C_CONTIGUOUS"] and not a.any()
+        a[...] = 1.0          # (writable, its own memory)
+        arrays.append(a)
+    assert len(calls) == len(arrays)
+    page = RaytraceRenderer._PAGE
+    spans = []
+    for a, (ptr, n) in zip(arrays, calls):
+        assert ptr == a.ctypes.data and ptr % page == 0 and n % page == 0 and n >= a.nbytes
+        raw = a.base if a.base is not None else a
+        while getattr(raw, "base", None) is not None:
+            raw = raw.base
+        assert raw.ctypes.data <= ptr and ptr + n <= raw.ctypes.data + raw.nbytes          # the registered pages are the array's own
+        spans.append((ptr, ptr + n))
+    spans.sort()
+    for (a0, a1), (b0, b1) in zip(spans, spans[1:]):
+        assert a1 <= b0          # no page is registered twice
