@@ -7,18 +7,22 @@ configuration BASELINE.json quotes the metric on: config 4, the Dragon-class mes
 missing xyzrgb_dragon.obj) at a 1920x1080 trace grid, 1 spp.  Scene, BVH and all per-pixel buffers are resident in HBM before the
 timed region.  Prints ONE JSON line (rank 0).
 
-How N GPUs are driven (`--form`):
+How N GPUs are driven (`--form`; DESIGN.md section 7):
+  resident one process per GPU (RANK / WORLD_SIZE in the environment), the tile-RESIDENT form - the north_star's partition: 32x8 tiles dealt
+           round-robin, ycge_trace_tiles_resident -> one RCCL all-to-all of the one-pixel halo records (1.4 MB per rank at 8 ranks) ->
+           ycge_resolve_tiles_resident (TAA on the rank's own tiles, history resident) -> RCCL all-gather of the resolved history (12 B per
+           pixel: the frame reassembled on every rank) -> ycge_unpack_history.  --ring frame sets = traces in flight.  --batch n > 1: n
+           frames of the rank's tiles per launch (ycge_trace_tiles_resident_batch) - needs the next n poses, so it is opt-in.
+  rccl     one process per GPU: ycge_trace_tiles -> one RCCL all-gather of the tile slabs -> ycge_resolve_gathered on every rank.
   onecall  ONE process, ONE ycge_render_frame call per frame - the reference's shape (RaytraceEntity.cs:230): config.devices =
-           0..N-1, the library deals the 32x8 tiles round-robin, every device traces its share, the peers write their tiles into
-           device 0's frame buffers over xGMI, TAA on device 0.  This is what a plain `python bench.py --gpus N` runs (auto, no
-           launcher).  Fails loudly when fewer than N devices are visible.
-  rccl     one process per GPU under torchrun (RANK / WORLD_SIZE in the environment): ycge_trace_tiles -> one RCCL all-gather of
-           the tile slabs -> ycge_resolve_gathered on every rank.
-  resident (what `auto` picks when WORLD_SIZE > 1) one process per GPU under torchrun, the tile-RESIDENT form: ycge_trace_tiles_resident_batch
-           (--batch frames of the rank's tiles per launch, a ring of --ring >= 3 x batch frame sets; --batch 0: frame by frame) -> one RCCL
-           all-to-all of the one-pixel halo records (1.4 MB per rank at 8 ranks) -> ycge_resolve_tiles_resident (TAA on the rank's own
-           tiles, history resident) -> all-gather of the resolved history (12 B per pixel) -> ycge_unpack_history.  3.1 MB leave a rank
-           per frame instead of 8.3, 25 MB arrive instead of 66.
+           0..N-1, the peers write their tiles into device 0's frame buffers over xGMI, TAA on device 0.  No RCCL.
+  auto     under a launcher: resident, frame by frame.  WITHOUT a launcher and --gpus N > 1 (the plain `python bench.py --gpus N`):
+           this process touches no GPU; it starts N one-process-per-GPU children itself (`python -m torch.distributed.run
+           --nproc-per-node N bench.py ... --form resident`, a child process, never an exec), relays rank 0's line, and when the
+           children exit non-zero starts the next form in FRESH children: resident -> rccl -> onecall.  `forms_tried` in the line says
+           what ran; `rccl_world` is dist.get_world_size() after a checked all-reduce.  After a resident headline the batched
+           launches (--batch 4) run as a second job whose result is attached as `batched` - never the headline: `latency_frames`
+           says how many frames lie between a pose and its image.
 `n_gpus` in the line is the number of devices that traced tiles this run (`device_tiles` lists their tile counts), never the flag.
 
 value   = Mrays/s over the rays the timed kernels TRACE: calls to Scene.Hit + Scene.Occluded (primary, shadow, bounce) per frame /
@@ -112,6 +116,113 @@ def orbit_pose(pose, k):
     return (cx - r * math.sin(yaw) * math.cos(pitch), py, cz + r * math.cos(yaw) * math.cos(pitch)), yaw, pitch
 
 
+# ---------------------------------------------------------------------------------------------------------------------------------
+# Self-launch: `python bench.py --gpus N` with no launcher around it.  Nothing below imports torch, loads the library or makes a HIP
+# call: the parent only starts child processes and reads their output.
+
+FORM_CHAIN = (            # tried in this order, each in fresh children; the first that prints a line is the headline
+    ("resident", ["--form", "resident", "--batch", "0"]),
+    ("rccl", ["--form", "rccl"]),
+    ("onecall", ["--form", "onecall"]),
+)
+BATCHED_LEG = ("resident_batch4", ["--form", "resident", "--batch", "4"])
+LAUNCHER_FORMS = ("resident", "rccl", "resident_batch4")        # forms that need one process per GPU
+
+
+def free_port() -> int:
+    import socket
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        return sk.getsockname()[1]
+
+
+def strip_flag(argv, names):
+    """argv without the flags in `names` (each takes one value; `--flag v` and `--flag=v`)."""
+    out, skip = [], False
+    for a in argv:
+        if skip:
+            skip = False
+            continue
+        if a in names:
+            skip = True
+            continue
+        if any(a.startswith(n + "=") for n in names):
+            continue
+        out.append(a)
+    return out
+
+
+def last_json_line(text):
+    for line in reversed(text.splitlines()):
+        line = line.strip()
+        if line.startswith("{") and line.endswith("}"):
+            try:
+                d = json.loads(line)
+                if isinstance(d, dict) and "metric" in d:
+                    return d
+            except ValueError:
+                pass
+    return None
+
+
+def ranks_last_words(err, n=1200):
+    """the end of what the RANKS wrote: torch.distributed.run appends its own log lines and a long traceback after a rank fails"""
+    import re
+    m = re.search(r"^[EW]\d{4} [\d:.]+ +\d+ torch/distributed/", err, flags=re.M)
+    return err[:m.start()][-n:] if m and err[:m.start()].strip() else err[-n:]
+
+
+def child_command(form_name, n, port, script, python=None):
+    python = python or sys.executable
+    if form_name in LAUNCHER_FORMS:
+        return [python, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n), "--master-addr", "127.0.0.1",
+                "--master-port", str(port), str(script)]
+    return [python, str(script)]
+
+
+def launch_ranks(n, argv, chain=FORM_CHAIN, extra=BATCHED_LEG, script=None, timeout=1500, env=None, log=sys.stderr):
+    """Runs the forms of `chain` one after the other, each as FRESH child processes, until one prints the bench line; returns that line
+    (a dict) with `forms_tried` added, or None.  `argv` = this invocation's own arguments (forwarded; --form / --batch are replaced).
+    After a headline from the tile-resident form, `extra` runs as one more job and its figures are attached as `batched`."""
+    import subprocess
+    script = script or Path(__file__).resolve()
+    base = strip_flag(list(argv), ("--form", "--batch"))
+    env = dict(os.environ if env is None else env)
+    env["YCGE_BENCH_CHILD"] = "1"               # a child never launches children of its own
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    env.setdefault("MASTER_ADDR", "127.0.0.1")
+    tried, headline = [], None
+
+    def run(name, form_args):
+        cmd = child_command(name, n, free_port(), script) + base + form_args
+        t0 = time.perf_counter()
+        try:
+            r = subprocess.run(cmd, capture_output=True, text=True, timeout=timeout, env=env, start_new_session=True)
+            rc, out, err = r.returncode, r.stdout, r.stderr
+        except subprocess.TimeoutExpired as e:
+            rc, out, err = -9, (e.stdout or b"").decode(errors="replace") if isinstance(e.stdout, bytes) else (e.stdout or ""), f"timeout after {timeout} s"
+        line = last_json_line(out) if rc == 0 else None
+        rec = {"form": name, "rc": rc, "seconds": round(time.perf_counter() - t0, 1), "ok": line is not None}
+        if line is None:
+            rec["stderr_tail"] = ranks_last_words(err or "")
+            print(f"bench.py: form {name} failed (rc {rc}); " + (err or "")[-800:], file=log)
+        tried.append(rec)
+        return line
+
+    for name, form_args in chain:
+        headline = run(name, form_args)
+        if headline is not None:
+            break
+    if headline is None:
+        return None, tried
+    if extra and tried[-1]["form"] == "resident":
+        b = run(*extra)
+        headline["batched"] = ({k: b.get(k) for k in ("value", "unit", "ms_per_step", "n_gpus", "rccl_world", "latency_frames")} | {"parallelism": b["config"]["parallelism"]}) if b else {"failed": tried[-1]["rc"]}
+    headline["forms_tried"] = tried
+    headline["launched_by"] = "bench.py itself: " + " ".join(child_command(tried[0]["form"], n, "<port>", "bench.py", python="python")) + " ..."
+    return headline, tried
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -121,7 +232,7 @@ def main():
     ap.add_argument("--camera", choices=("static", "orbit"), default="static", help="orbit: the pose changes every frame of the timed region (the headline then is the moving-camera frame)")
     ap.add_argument("--form", choices=("auto", "onecall", "rccl", "resident"), default="auto", help="how N > 1 GPUs are driven (see the module docstring)")
     ap.add_argument("--ring", type=int, default=4, help="--form resident: frame sets in the ring = tiled traces in flight (config.tile_ring)")
-    ap.add_argument("--batch", type=int, default=4, help="--form resident: frames of a rank's tiles traced in ONE launch (ycge_trace_tiles_resident_batch; 0 or 1 = frame by frame); the ring is then at least three batches deep")
+    ap.add_argument("--batch", type=int, default=0, help="--form resident: frames of a rank's tiles traced in ONE launch (ycge_trace_tiles_resident_batch; 0 or 1 = frame by frame, the default: a batch needs the next n poses); the ring is then at least three batches deep")
     ap.add_argument("--t01", type=float, default=0.25, help="config 5: day phase of the sun and moon (DayNightCycle.cs:48-82); 0.25 = SURVEY 8(d): sun on the horizon, BOTH lights at intensity 0; 0.5 = noon, 0.8 = night")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
@@ -130,14 +241,30 @@ def main():
     ap.add_argument("--no-moving", action="store_true", help="skip the moving-camera leg (reported apart as moving_camera)")
     args = ap.parse_args()
 
+    under_launcher = "RANK" in os.environ and "WORLD_SIZE" in os.environ
+    force_tiled = bool(os.environ.get("YCGE_BENCH_FORCE_TILED"))        # runs the one-process-per-GPU forms with ONE rank (a one-GPU box)
+    if not under_launcher and not os.environ.get("YCGE_BENCH_CHILD") and (args.gpus > 1 or force_tiled) and args.form != "onecall":
+        # the plain `python bench.py --gpus N`: start the ranks ourselves (module docstring, `auto`); this process never touches a GPU
+        from yetanotherconsolegameengine_amd import build as _build           # (imports no torch; hipcc cross-compiles without a GPU)
+        _build.build_library()
+        chain = FORM_CHAIN if args.form == "auto" else tuple(f for f in FORM_CHAIN if f[0] == args.form)
+        if args.form == "resident" and args.batch > 1:
+            chain = (("resident", ["--form", "resident", "--batch", str(args.batch)]),)
+        if force_tiled and args.gpus == 1:
+            chain = tuple(f for f in chain if f[0] != "onecall")
+        line, tried = launch_ranks(args.gpus, sys.argv[1:], chain=chain, extra=BATCHED_LEG if args.form == "auto" else None)
+        if line is None:
+            raise SystemExit("bench.py --gpus %d: no form produced a line: %s" % (args.gpus, json.dumps(tried)))
+        print(json.dumps(line))
+        return
+
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     form = args.form
     if form == "auto":
-        # under a launcher: the tile-resident form with batched launches - by per-rank emulation 0.12 ms a rank-frame at 8 ranks on config 4
-        # against 0.28 for the slab form; both forms run under torchrun + RCCL on one rank (profiles/r4_forms.sh)
-        form = "resident" if world > 1 else "onecall"
+        # under a launcher: the tile-resident form, frame by frame (a batch of n frames a launch needs the next n poses: opt-in, --batch n)
+        form = "resident" if (world > 1 or (under_launcher and force_tiled)) else "onecall"
     resident = form == "resident"
     if resident:
         form = "rccl"          # (the same launcher, ranks and tile partition; only the per-frame exchange differs)
@@ -155,18 +282,29 @@ def main():
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: the ray-trace path has no CPU fallback")
     from yetanotherconsolegameengine_amd import abi, build, scenes
-    if rank == 0:
-        build.build_library()
-    L = abi.load_library()
-    visible = L.ycge_device_count()
-    if visible < (n_dev if form == "onecall" else local_rank + 1):
-        raise SystemExit(f"bench.py --gpus {args.gpus}: {visible} HIP device(s) visible - the ray-trace path has no CPU fallback and will not run on fewer GPUs than asked for")
+    if torch.cuda.device_count() <= local_rank:
+        raise SystemExit(f"bench.py --gpus {args.gpus}: rank {rank} has no device {local_rank} ({torch.cuda.device_count()} visible) - the ray-trace path has no CPU fallback and will not run on fewer GPUs than asked for")
     torch.cuda.set_device(local_rank)
+    rccl_world = None
     if multi:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        # a CHECKED all-reduce before anything is timed: every rank contributes rank + 1, every rank must see world (world + 1) / 2
+        chk = torch.tensor([rank + 1], dtype=torch.int64, device="cuda")
+        dist.all_reduce(chk)
+        if int(chk.item()) != world * (world + 1) // 2:
+            raise SystemExit(f"RCCL all-reduce over {world} rank(s) returned {int(chk.item())}, expected {world * (world + 1) // 2}")
+        rccl_world = dist.get_world_size()
+    # rank 0 builds (a no-op when the parent of a self-launch or __graft_entry__.build() already did), the others load only behind the barrier
+    if rank == 0:
+        build.build_library()
+    if multi:
         dist.barrier()
+    L = abi.load_library()
+    visible = L.ycge_device_count()
+    if visible < (n_dev if form == "onecall" else local_rank + 1):
+        raise SystemExit(f"bench.py --gpus {args.gpus}: {visible} HIP device(s) visible - the ray-trace path has no CPU fallback and will not run on fewer GPUs than asked for")
 
     from yetanotherconsolegameengine_amd.renderer import RaytraceRenderer
     from yetanotherconsolegameengine_amd.scene import flatten
@@ -226,6 +364,16 @@ def main():
         s_traces = rs_traces[:2] if K >= 2 else [rs_traces[0], rs_traces[0]]
         B = args.batch if args.batch > 1 else 0
         rs_poses, rs_batches = [], [0]
+        # the launches of the TIMED region, bracketed by HIP events on the stream each one is launched on (the roofline's launch duration)
+        rs_timing, rs_launches = [False], []
+
+        def rs_bracket(st, n_frames):
+            if not rs_timing[0]:
+                return None
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record(st)
+            rs_launches.append((e0, e1, n_frames))
+            return e1
 
         def rs_resolve(k):
             with torch.cuda.stream(s_comm):
@@ -248,7 +396,10 @@ def main():
         with torch.cuda.stream(st):
             for k in slots:
                 st.wait_event(rs_ev_r[k])
+            e1 = rs_bracket(st, n)
             rr.trace_tiles_resident_batch(list(rs_poses), [h_send[k].data_ptr() for k in slots], st.cuda_stream)
+            if e1 is not None:
+                e1.record(st)
             for k in slots:
                 rs_ev_t[k].record(st)
         rs_issued.extend(slots)
@@ -273,7 +424,10 @@ def main():
             n_issued[0] += 1
             with torch.cuda.stream(rs_traces[k]):
                 rs_traces[k].wait_event(rs_ev_r[k])          # slot k's buffers were last read by the exchange of K frames ago
+                e1 = rs_bracket(rs_traces[k], 1)
                 rr.trace_tiles_resident(h_send[k].data_ptr(), rs_traces[k].cuda_stream)
+                if e1 is not None:
+                    e1.record(rs_traces[k])
                 rs_ev_t[k].record(rs_traces[k])
             rs_issued.append(k)
             return 0.0, 0.0
@@ -321,6 +475,8 @@ def main():
     first_frame = args.warmup + 1
     steps0 = r.timed_steps() if not multi else 0
     per_step = []
+    if multi and resident:
+        rs_timing[0] = True
     t0 = time.perf_counter()
     for k in range(args.steps):
         # one process: ycge_render_frame times the trace with HIP events on its own stream as part of the (synchronous) call.  Several
@@ -333,9 +489,16 @@ def main():
     device_tiles = [int(r.stats.device_tiles[i]) for i in range(int(r.stats.n_devices_traced))] if not multi else None
     trace_ms = [p[0] for p in per_step]
     frame_ms = [p[1] for p in per_step]
-    if multi:       # kernel duration for the roofline line: a few extra, untimed frames with event timing
-        trace_ms = [step(r, want_stats=True)[0] for _ in range(4)][1:]
-        fence()
+    launch_frames = 1          # frames of this rank's tiles one launch of the dominant kernel traces
+    if multi:
+        if resident:    # the launches of the timed region themselves (HIP events on their own streams; traces in flight overlap, so a launch's
+            # duration includes what it shares the machine with)
+            rs_timing[0] = False
+            launch_frames = B or 1
+            trace_ms = [e0.elapsed_time(e1) for e0, e1, _ in rs_launches]
+        else:           # slab form: a few extra, untimed frames with the library's event timing
+            trace_ms = [step(r, want_stats=True)[0] for _ in range(4)][1:]
+            fence()
         te = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
         dist.all_reduce(te, op=dist.ReduceOp.MAX)
         elapsed = float(te.item())
@@ -372,7 +535,7 @@ def main():
     mean_trace_ms = float(np.mean(trace_ms)) if trace_ms and trace_ms[0] > 0 else None
     # roofline of the dominant kernel (k_trace) on THIS process's share of the frame
     share = world if multi else 1
-    my_alg = algorithmic_bytes({k: v / share for k, v in per_frame.items()}, pixels / share)
+    my_alg = algorithmic_bytes({k: v / share for k, v in per_frame.items()}, pixels / share) * launch_frames
     roof = None
     if mean_trace_ms:
         ach = my_alg / (mean_trace_ms * 1e-3) / 1e9
@@ -381,6 +544,8 @@ def main():
         # run k_trace alone), or the stage pipeline of scenes with a real top-level tree (config 5)
         fanned = int(r.stats.fan_blocks) > 0
         kernel = "k_wf_* stages" if args.config == 5 else "k_trace + k_trace_fan (concurrent)" if fanned else "k_trace"
+        if multi and resident:
+            kernel = (f"k_trace_batch ({launch_frames} frames of the rank's tiles per launch)" if launch_frames > 1 else "k_trace on the rank's tiles") + f", up to {args.ring} traces in flight (durations overlap)"
         roof = {"bound": "hbm", "kernel": kernel, "achieved": round(ach, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": round(ach / HBM_PEAK_GBS, 5), "traffic": None,
                 "achieved_is": "algorithmic bytes of the REFERENCE's traversal (SURVEY 8d counters) / launch time - mostly cache hits, NOT memory traffic",
@@ -531,6 +696,10 @@ def main():
                        "frame": "ray-gen + trace + TAA" + (" on the rank's own tiles + RCCL all-to-all of halo records + all-gather of the history" if (multi and resident) else " + RCCL all-gather of tile slabs + un-permute" if multi else " + peer tile push" if n_dev > 1 else ""),
                        "parallelism": f"framebuffer tiles 32x8 round-robin over {n_gpus_used} GPU(s): " + how, "form": "resident" if (multi and resident) else form,
                        "gpus_requested": args.gpus, "device_tiles": device_tiles, "device": name, "compute_units": cus},
+            # frames between a pose and its image: 1 = the synchronous call (TryFlipAndBlit); the one-process-per-GPU forms keep frames in
+            # flight (the ring of the tile-resident form: K traces, or three batches of n frames - a batch also NEEDS its n poses up front)
+            "latency_frames": (args.ring if resident else 2 if pipelined else 1) if multi else 1,
+            "rccl_world": rccl_world,
             "primary_mrays_per_s": round(pixels * args.steps / elapsed / 1e6, 2),
             "rays_per_frame": round(per_frame["n_rays"], 1),
             # the reference's call count includes shadow rays towards lights of intensity 0, which the timed kernels never trace (bit-identical

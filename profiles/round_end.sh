@@ -45,4 +45,4 @@ done
 if [ -f yetanotherconsolegameengine_amd/lib/var_voxstat.so ]; then YCGE_LIB=$REPO/yetanotherconsolegameengine_amd/lib/var_voxstat.so timeout 300 python profiles/vox_stats.py 0.5 2>&1 | grep -v amdgpu.ids; fi
 if [ -f yetanotherconsolegameengine_amd/lib/var_coopstat.so ]; then YCGE_LIB=$REPO/yetanotherconsolegameengine_amd/lib/var_coopstat.so timeout 200 python profiles/coop_stats.py 4 2>&1 | grep -v amdgpu.ids; fi
 if [ -f yetanotherconsolegameengine_amd/lib/var_batchstat.so ]; then YCGE_LIB=$REPO/yetanotherconsolegameengine_amd/lib/var_batchstat.so timeout 300 python profiles/batch_stats.py 4 2>&1 | grep -v amdgpu.ids; fi
-echo "== bench.py's one-process-per-GPU forms on one rank (torchrun + RCCL)"; bash profiles/r4_forms.sh 2>&1 | grep -v "^\[" | cut -c1-330
+echo "== bench.py's one-process-per-GPU forms on one rank (torchrun + RCCL)"; bash profiles/forms.sh 2>&1 | grep -v "^\[" | cut -c1-330

@@ -49,27 +49,58 @@ def source_hash() -> str:
     return h.hexdigest()[:16]
 
 
-def is_stale() -> bool:
-    if not LIB.exists():
+def stamp_path(lib: Path) -> Path:
+    return lib.with_name(lib.name + ".srchash")
+
+
+def is_stale(lib: Path = LIB, flags=()) -> bool:
+    """A library is current when the stamp written beside it names THIS content of the sources, headers and flags (content, not mtime:
+    a snapshot copied to another box keeps no useful timestamps)."""
+    try:
+        return not lib.exists() or stamp_path(lib).read_text().strip() != source_hash() + "".join(" " + f for f in flags)
+    except OSError:
         return True
-    t = LIB.stat().st_mtime
-    deps = [CSRC / n for n in SOURCES + HEADERS] + [PKG.parent / "include" / "ycge.h", Path(__file__)]
-    return any(d.stat().st_mtime > t for d in deps)
 
 
-def build_library(force: bool = False, verbose: bool = False, extra_flags=()) -> Path:
-    if not force and not is_stale():
-        return LIB
-    LIB_DIR.mkdir(exist_ok=True)
-    cmd = [hipcc(), *FLAGS, *extra_flags, "-x", "hip", *[str(CSRC / s) for s in SOURCES], "-o", str(LIB)]
+class build_lock:
+    """One builder at a time per checkout (ranks of a launcher, pytest workers): an exclusive flock on lib/.build.lock."""
+
+    def __enter__(self):
+        import fcntl
+        LIB_DIR.mkdir(exist_ok=True)
+        self.f = open(LIB_DIR / ".build.lock", "w")
+        fcntl.flock(self.f, fcntl.LOCK_EX)
+        return self
+
+    def __exit__(self, *a):
+        import fcntl
+        fcntl.flock(self.f, fcntl.LOCK_UN)
+        self.f.close()
+
+
+def compile_to(out: Path, flags=(), verbose: bool = False) -> None:
+    """hipcc into a temporary name, then an atomic rename: a process that loads `out` meanwhile sees the old or the new file, never half of one."""
+    tmp = out.with_name(out.name + f".tmp{os.getpid()}")
+    cmd = [hipcc(), *FLAGS, *flags, "-x", "hip", *[str(CSRC / s) for s in SOURCES], "-o", str(tmp)]
     if verbose:
         print(" ".join(cmd))
     r = subprocess.run(cmd, capture_output=True, text=True)
     if r.returncode != 0:
         sys.stderr.write(r.stdout + r.stderr)
-        raise RuntimeError("hipcc failed building libycge_hip.so")
+        tmp.unlink(missing_ok=True)
+        raise RuntimeError(f"hipcc failed building {out.name}")
     if verbose and r.stderr:
         print(r.stderr)
+    os.replace(tmp, out)
+    stamp_path(out).write_text(source_hash() + "".join(" " + f for f in flags) + "\n")
+
+
+def build_library(force: bool = False, verbose: bool = False, extra_flags=()) -> Path:
+    if not force and not is_stale(LIB, extra_flags):
+        return LIB
+    with build_lock():
+        if force or is_stale(LIB, extra_flags):          # (someone else may have built it while we waited for the lock)
+            compile_to(LIB, extra_flags, verbose)
     return LIB
 
 
@@ -92,14 +123,11 @@ def variant_path(name: str) -> Path:
 def build_variant(name: str, flags=None, force: bool = False) -> Path:
     flags = list(VARIANTS[name] if flags is None else flags)
     out = variant_path(name)
-    deps = [CSRC / n for n in SOURCES + HEADERS] + [PKG.parent / "include" / "ycge.h", Path(__file__)]
-    if not force and out.exists() and all(d.stat().st_mtime <= out.stat().st_mtime for d in deps):
+    if not force and not is_stale(out, flags):
         return out
-    LIB_DIR.mkdir(exist_ok=True)
-    r = subprocess.run([hipcc(), *FLAGS, *flags, "-x", "hip", *[str(CSRC / s) for s in SOURCES], "-o", str(out)], capture_output=True, text=True)
-    if r.returncode != 0:
-        sys.stderr.write(r.stdout + r.stderr)
-        raise RuntimeError(f"hipcc failed building {out.name}")
+    with build_lock():
+        if force or is_stale(out, flags):
+            compile_to(out, flags)
     return out
 
 
