@@ -35,7 +35,7 @@
 extern "C" {
 #endif
 
-#define YCGE_ABI_VERSION 7
+#define YCGE_ABI_VERSION 8
 #define YCGE_MAX_DEVICES 8
 
 typedef enum ycge_status {
@@ -428,9 +428,19 @@ int ycge_set_frame_counter(ycge_ctx *ctx, int64_t frame_counter);
  * context's stream; never called inside a timed region. */
 int ycge_read_timed_steps(ycge_ctx *ctx, uint64_t *lane_steps);
 /* The SDR frame leaves the device by one copy into the caller's buffer at the end of ycge_render_frame / ycge_resolve_gathered (24 bytes per
- * chexel: 25 MB at 1920x540).  A host that keeps ONE buffer for the life of the renderer (the C# wrapper's pinned float[]) registers it
- * here once: the copy then is a DMA into page-locked memory at the link's full rate instead of a staged copy into pageable pages.
- * Optional; unpin before the buffer is freed or moved.  (hipHostRegister / hipHostUnregister.) */
+ * chexel: 25 MB at 1920x540).  Into page-locked memory that copy is a DMA at the link's full rate instead of a staged copy into pageable
+ * pages, and a frame in flight (ycge_render_frame_async_sdr) never blocks the calling thread.  Two ways to get such memory:
+ *   ycge_alloc_host_buffer / ycge_free_host_buffer   the library's own (hipHostMalloc, zeroed): what a host should use for its SDR frames
+ *                                                     (the C# wrapper reads it through a Span<float>);
+ *   ycge_pin_host_buffer / ycge_unpin_host_buffer     registers memory the caller owns (hipHostRegister).  Registration is page-granular:
+ *                                                     two registered ranges that share a page lose it when one is unregistered, and the
+ *                                                     other's next read-back faults on the device.  So the range must be WHOLE PAGES OF ITS
+ *                                                     OWN: `buffer` aligned to ycge_host_page_size() and `bytes` a multiple of it, else
+ *                                                     YCGE_ERR_INVALID_ARG (a pinned managed array - GCHandle of a float[] - never qualifies).
+ * ABI 8.  Optional either way; unpin / free before the memory goes away, and only after ycge_wait. */
+size_t ycge_host_page_size(void);
+int ycge_alloc_host_buffer(size_t bytes, void **out_buffer);
+int ycge_free_host_buffer(void *buffer);
 int ycge_pin_host_buffer(void *buffer, size_t bytes);
 int ycge_unpin_host_buffer(void *buffer);
 /* visible HIP devices (hipGetDeviceCount; does not initialise a device context), < 0 on error: what a host checks before it

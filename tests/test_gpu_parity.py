@@ -764,3 +764,53 @@ def test_persistent_atrous_when_fewer_band_workgroups_fit(product_lib, monkeypat
     for other in ("profiling", "profiling, 28 bands too many"):
         for a, b in zip(out["two-set"], out[other]):
             assert np.array_equal(a.view(np.uint32), b.view(np.uint32)), other
+
+
+def test_page_locked_sdr_buffers_of_the_library(product_lib):
+    """ABI 8: ycge_alloc_host_buffer hands out page-locked memory of its own (what the C# wrapper's SDR frames live in); ycge_pin_host_buffer
+    accepts whole pages the caller owns and nothing else.  The SDR frame written into either kind of memory - by the synchronous call and by
+    frames in flight - is the frame an ordinary array receives (RaytraceRenderer.cs:229-264 fills the same chexels either way)."""
+    from yetanotherconsolegameengine_amd.renderer import RaytraceRenderer
+    L = abi.load_library()
+    page = L.ycge_host_page_size()
+    sc, w, h, ss, pose = scenes.config_scene(2)
+    w, h = 96, 27
+    n = w * h * 2 * 3
+    r = RaytraceRenderer(flatten(sc), w, h, pose["fov"], ss)
+    r.SetCamera(pose["pos"], pose["yaw"], pose["pitch"])
+    plain = np.zeros(n, dtype=np.float32)
+    r._check(L.ycge_render_frame(r.ctx, plain.ctypes.data_as(C.POINTER(C.c_float)), None))
+    # (1) the library's own memory
+    bufs = []
+    for _ in range(3):
+        p = C.c_void_p()
+        assert L.ycge_alloc_host_buffer(n * 4, C.byref(p)) == abi.YCGE_OK and p.value and p.value % page == 0
+        a = np.ctypeslib.as_array(C.cast(p, C.POINTER(C.c_float)), shape=(n,))
+        assert not a.any()
+        bufs.append((p, a))
+    r2 = RaytraceRenderer(flatten(sc), w, h, pose["fov"], ss)
+    r2.SetCamera(pose["pos"], pose["yaw"], pose["pitch"])
+    r2._check(L.ycge_render_frame(r2.ctx, C.cast(bufs[0][0], C.POINTER(C.c_float)), None))
+    assert pu.bits_equal(bufs[0][1], plain)
+    want = []
+    for k in range(3):
+        r._check(L.ycge_render_frame(r.ctx, plain.ctypes.data_as(C.POINTER(C.c_float)), None)); want.append(plain.copy())
+    for k in range(3):
+        r2._check(L.ycge_render_frame_async_sdr(r2.ctx, C.cast(bufs[k][0], C.POINTER(C.c_float))))
+    r2.Wait()
+    for k in range(3):
+        assert pu.bits_equal(bufs[k][1], want[k]), k
+    # (2) the caller's own whole pages: accepted, used, released; a range sharing its pages is refused
+    span = (n * 4 + page - 1) // page * page
+    raw = np.zeros(span + page, dtype=np.uint8)
+    off = (-raw.ctypes.data) % page
+    mine = raw[off:off + n * 4].view(np.float32)
+    assert L.ycge_pin_host_buffer(C.c_void_p(mine.ctypes.data), span) == abi.YCGE_OK
+    assert L.ycge_pin_host_buffer(C.c_void_p(mine.ctypes.data + 64), span - page) == abi.YCGE_ERR_INVALID_ARG
+    r._check(L.ycge_render_frame(r.ctx, plain.ctypes.data_as(C.POINTER(C.c_float)), None))
+    r2._check(L.ycge_render_frame(r2.ctx, mine.ctypes.data_as(C.POINTER(C.c_float)), None))
+    assert pu.bits_equal(mine, plain)
+    assert L.ycge_unpin_host_buffer(C.c_void_p(mine.ctypes.data)) == abi.YCGE_OK
+    r.close(); r2.close()
+    for p, _ in bufs:
+        assert L.ycge_free_host_buffer(p) == abi.YCGE_OK

@@ -908,3 +908,53 @@ def test_the_walk_tree_of_a_voxel_world(product_lib, oracle, monkeypatch):
     o.render(stages=1, threads=16); g.TryFlipAndBlit()          # (the same objects: the oracle's tree stands) - the frame walked down the device-built trees
     _assert_frame(o, g, "full world, device-built tree and its walk tree")
     o.close(); g.close()
+
+
+@pytest.mark.parametrize("burst", [3, 4, 7])
+def test_live_texture_updates_between_frames_in_flight(product_lib, burst):
+    """ycge_scene_update_texture between ycge_render_frame_async calls on a frame of >= 4 096 tiles: a textured scene is never 'flat', so
+    its frames in flight take the stage pipeline's TWO trace streams (odd frames on the second).  The copy of a live texture's next frame
+    must wait for the trace that still samples the old one - whichever stream holds it - and the next trace - on whichever stream - must
+    wait for the copy (Renderer/Texture.cs:113-116: a frame samples what GetCurrentFramePtr() showed when it was traced).  Reference
+    behaviour = the same updates and frames made synchronously.  An update AFTER the last frame must not reach it; bursts of 3, 4 and 7
+    frames end on either stream.  HasDynamicTextures restarts the history every frame, so the history IS the last frame."""
+    from yetanotherconsolegameengine_amd.scene import (AmbientLight, Box, LiveTexture, Material, PointLight, Scene, XYRect, XZRect, vec3)
+    rng = np.random.default_rng(5)
+    cam = LiveTexture(rng.integers(0, 256, (512, 512, 4), dtype=np.uint8))          # 1 MB a frame: a copy long enough to be caught half-way
+    video = LiveTexture(rng.integers(0, 256, (256, 384, 3), dtype=np.uint8), flipU=True)
+    s = Scene()
+    s.HasDynamicTextures = True
+    s.Ambient = AmbientLight(vec3(1, 1, 1), 0.1)
+    s.Add(XZRect(-8.0, 8.0, -14.0, 3.0, 0.0, Material(vec3(0.8, 0.8, 0.8), DiffuseTexture=cam, UVScale=0.1), 0.05, 0.0))
+    s.Add(XYRect(-8.0, 8.0, 0.0, 6.0, -12.0, Material(vec3(0.9, 0.9, 0.9), DiffuseTexture=video, UVScale=0.08), 0.0, 0.0))
+    s.Add(Box(vec3(1.5, 0.0, -5.0), vec3(3.0, 1.5, -3.5), Material(vec3(1, 1, 1), DiffuseTexture=cam, TextureWeight=0.8), 0.1, 0.0))
+    s.Lights.append(PointLight(vec3(-2.0, 5.0, -1.0), vec3(1.0, 0.95, 0.9), 90.0))
+    s.BackgroundTop, s.BackgroundBottom = vec3(0.5, 0.7, 1.0), vec3(0.9, 0.95, 1.0)
+    flat = flatten(s)
+    w, h, fov = 1536, 432, 55.0           # 1536 x 864 trace grid = 5 184 tiles of 32 x 8
+    frames = [[rng.integers(0, 256, t.frame.shape, dtype=np.uint8) for t in (cam, video)] for _ in range(burst + 1)]
+    watch = (abi.BUF_CURRENT_HDR, abi.BUF_G_ALBEDO, abi.BUF_TAA_HISTORY)
+
+    def drive(r, in_flight):
+        r.SetCamera((0.2, 1.7, 2.2), 0.04, -0.22)
+        for i in range(burst):
+            for t, f in zip((cam, video), frames[i]):
+                t.set_frame(f); r.UpdateTexture(t)
+            r.RenderAsync() if in_flight else r.TryFlipAndBlit()
+        if in_flight:           # the frames of the NEXT burst arrive while the last trace may still be running
+            for t, f in zip((cam, video), frames[burst]):
+                t.set_frame(f); r.UpdateTexture(t)
+        return [r.read(b) for b in watch]
+
+    seq = RaytraceRenderer(flat, w, h, fov, 1)
+    want = drive(seq, False)
+    seq.close()
+    for rep in range(3):
+        fl = RaytraceRenderer(flat, w, h, fov, 1)
+        got = drive(fl, True)
+        info = fl.flight_info()
+        fl.close()
+        for b, a, g_ in zip(watch, want, got):
+            assert pu.bits_equal(a, g_), (rep, b, int((a.view(np.uint32) != g_.view(np.uint32)).sum()))
+    assert info["two_trace_streams"], "this scene was meant to take both trace streams"
+    assert len(np.unique(want[1].reshape(-1, 3).round(3), axis=0)) > 1000, "the albedo is not textured"

@@ -733,3 +733,25 @@ def test_page_locked_arrays_own_their_pages():
     spans.sort()
     for (a0, a1), (b0, b1) in zip(spans, spans[1:]):
         assert a1 <= b0          # no page is registered twice
+
+
+def test_pin_refuses_what_is_not_whole_pages_of_its_own():
+    """ycge_pin_host_buffer (hipHostRegister is page-granular; ABI 8): a range that does not start on a page boundary or is not a whole number
+    of pages is refused with YCGE_ERR_INVALID_ARG before the runtime is asked anything - so this runs without a GPU.  (The accepted case, and
+    ycge_alloc_host_buffer, need the runtime: tests/test_gpu_parity.py.)"""
+    import ctypes as C
+    L = abi.load_library()
+    page = L.ycge_host_page_size()
+    assert page >= 4096 and page & (page - 1) == 0
+    raw = np.zeros(4 * page, dtype=np.uint8)
+    base = raw.ctypes.data + (-raw.ctypes.data) % page
+    assert L.ycge_pin_host_buffer(C.c_void_p(base + 16), page) == abi.YCGE_ERR_INVALID_ARG            # not on a page boundary
+    assert L.ycge_pin_host_buffer(C.c_void_p(base), page + 24) == abi.YCGE_ERR_INVALID_ARG             # not whole pages
+    assert L.ycge_pin_host_buffer(C.c_void_p(base), 0) == abi.YCGE_ERR_INVALID_ARG
+    assert L.ycge_pin_host_buffer(None, page) == abi.YCGE_ERR_INVALID_ARG
+    assert L.ycge_unpin_host_buffer(C.c_void_p(base + 8)) == abi.YCGE_ERR_INVALID_ARG
+    assert L.ycge_unpin_host_buffer(None) == abi.YCGE_ERR_INVALID_ARG
+    out = C.c_void_p(123)
+    assert L.ycge_alloc_host_buffer(0, C.byref(out)) == abi.YCGE_ERR_INVALID_ARG and not out.value
+    assert L.ycge_alloc_host_buffer(64, None) == abi.YCGE_ERR_INVALID_ARG
+    assert L.ycge_free_host_buffer(None) == abi.YCGE_OK

@@ -12,7 +12,7 @@ import ctypes as C
 import os
 from pathlib import Path
 
-YCGE_ABI_VERSION = 7
+YCGE_ABI_VERSION = 8
 YCGE_MAX_DEVICES = 8
 
 # ycge_status
@@ -205,6 +205,9 @@ _PROTOTYPES = {
     "ycge_set_frame_counter": (C.c_int, [C.c_void_p, C.c_int64]),
     "ycge_read_timed_steps": (C.c_int, [C.c_void_p, C.POINTER(C.c_uint64)]),
     "ycge_device_count": (C.c_int, []),
+    "ycge_host_page_size": (C.c_size_t, []),
+    "ycge_alloc_host_buffer": (C.c_int, [C.c_size_t, C.POINTER(C.c_void_p)]),
+    "ycge_free_host_buffer": (C.c_int, [C.c_void_p]),
     "ycge_pin_host_buffer": (C.c_int, [C.c_void_p, C.c_size_t]),
     "ycge_unpin_host_buffer": (C.c_int, [C.c_void_p]),
     "ycge_accel_size": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.POINTER(C.c_size_t)]),

@@ -3,6 +3,7 @@
 // multi-GPU, test read-backs.  All device work is in ycge_kernels.hip; there is no CPU
 // implementation of any per-pixel stage here.
 #include <hip/hip_runtime.h>
+#include <unistd.h>
 
 #include <array>
 #include <chrono>
@@ -406,6 +407,7 @@ struct ycge_ctx {
     uint8_t *tex_stage[2] = {nullptr, nullptr};
     size_t tex_stage_bytes[2] = {0, 0};
     hipEvent_t tex_stage_ev[2] = {nullptr, nullptr};
+    hipEvent_t tex_order_ev = nullptr;         // "everything queued on the second trace stream so far": a live texture's copy waits for it
     bool tex_stage_busy[2] = {false, false};
     int tex_stage_next = 0;
     DevBuf<int32_t> d_tex_info;
@@ -914,6 +916,7 @@ void ycge_destroy(ycge_ctx *c)
     c->d_bvh_items.release(); c->d_bvh_scratch.release(); c->d_bvh_ref.release(); c->d_bvh_res.release();
     c->d_materials.release(); c->d_meshes.release(); c->d_grids.release(); c->d_cells.release(); c->d_lut.release(); c->d_lights.release(); c->d_tex_pixels.release(); c->d_tex_info.release();
     for (int k = 0; k < 2; k++) { if (c->tex_stage[k]) (void)hipHostFree(c->tex_stage[k]); if (c->tex_stage_ev[k]) (void)hipEventDestroy(c->tex_stage_ev[k]); }
+    if (c->tex_order_ev) (void)hipEventDestroy(c->tex_order_ev);
     for (auto &ev : c->ev) if (ev) (void)hipEventDestroy(ev);
     for (hipEvent_t ev : {c->fan_ev[0], c->fan_ev[1], c->traced_ev, c->order_ev, c->pushed_ev}) if (ev) (void)hipEventDestroy(ev);
     if (c->fan_stream) (void)hipStreamDestroy(c->fan_stream);
@@ -1594,11 +1597,18 @@ int ycge_scene_update_texture(ycge_ctx *c, int32_t texture_index, const uint8_t 
     if (bpp == 0) return c->fail(YCGE_ERR_INVALID_ARG, "texture %d is static: upload the scene again to change it", texture_index);
     if (!frame || bytes != (size_t)info[1] * info[2] * bpp) return c->fail(YCGE_ERR_INVALID_ARG, "texture %d: a frame is %d x %d x %d bytes", texture_index, info[1], info[2], bpp);
     int rc = YCGE_OK;
-    if (c->cfg.world_size == 1 && c->peers.empty()) {
-        // Single device: every trace of a textured scene is queued on the context's stream (such scenes never take the second trace stream:
-        // frame_is_single_launch / scene_is_flat), so a copy ON that stream is ordered against all of them - no device-wide wait, frames in
-        // flight stay in flight.  The caller's array is its own again when this returns: the frame is staged in page-locked memory first.
+    if (c->cfg.world_size == 1 && c->peers.empty() && (!c->last_stream || c->last_stream == c->stream)) {
+        // Single device, no tiled call on a stream of the caller's: the traces of this context run on its own stream and - frames in flight of
+        // the stage pipeline (render_frame_in_flight: odd frames from 4 096 tiles on) or of YCGE_PATH=m - on its second trace stream.  The
+        // copy is queued on the first and ORDERED against the second both ways: it waits for what the second stream holds now (the trace that
+        // still samples the old frame), and the second stream's next trace waits for it.  No device-wide wait, frames in flight stay in flight.
+        // The caller's array is its own again when this returns: the frame is staged in page-locked memory first.
         HIP_TRY(c, hipSetDevice(c->device));
+        if (c->stream2) {
+            if (!c->tex_order_ev) HIP_TRY(c, hipEventCreateWithFlags(&c->tex_order_ev, hipEventDisableTiming));
+            HIP_TRY(c, hipEventRecord(c->tex_order_ev, c->stream2));
+            HIP_TRY(c, hipStreamWaitEvent(c->stream, c->tex_order_ev, 0));
+        }
         const int k = c->tex_stage_next; c->tex_stage_next ^= 1;
         if (c->tex_stage_busy[k]) { HIP_TRY(c, hipEventSynchronize(c->tex_stage_ev[k])); c->tex_stage_busy[k] = false; }      // (the copy of two updates ago)
         if (c->tex_stage_bytes[k] < bytes) {
@@ -1610,10 +1620,11 @@ int ycge_scene_update_texture(ycge_ctx *c, int32_t texture_index, const uint8_t 
         std::memcpy(c->tex_stage[k], frame, bytes);
         HIP_TRY(c, hipMemcpyAsync(c->d_tex_pixels.p + info[0], c->tex_stage[k], bytes, hipMemcpyHostToDevice, c->stream));
         HIP_TRY(c, hipEventRecord(c->tex_stage_ev[k], c->stream));
+        if (c->stream2) HIP_TRY(c, hipStreamWaitEvent(c->stream2, c->tex_stage_ev[k], 0));
         c->tex_stage_busy[k] = true;
         return YCGE_OK;
     }
-    // several devices / a rank of a tiled frame (the caller may run its own streams): the scene changes while nothing runs
+    // several devices / a rank of a tiled frame / tiled calls on the caller's own streams: the scene changes while nothing runs
     rc = quiesce(c);
     if (rc != YCGE_OK) return rc;
     HIP_TRY(c, hipMemcpy(c->d_tex_pixels.p + info[0], frame, bytes, hipMemcpyHostToDevice));
@@ -1769,15 +1780,47 @@ int ycge_debug_read_walk_tree(ycge_ctx *c, void *gnodes_out, void *walk_out, int
     return n;
 }
 
+// Page-locked host memory for the SDR frame.  hipHostRegister works on whole pages: two registered heap arrays that share a boundary page
+// lose it when ONE of them is unregistered, and the other's next read-back is a device write to an unmapped host page ("Memory access fault
+// by GPU" at a heap address, round 4).  So the library refuses a range that is not whole pages of its own - the caller proves it owns the
+// pages by handing over page-aligned memory - and offers memory that is (ycge_alloc_host_buffer: hipHostMalloc).
+size_t ycge_host_page_size(void)
+{
+    const long p = sysconf(_SC_PAGESIZE);
+    return p > 0 ? (size_t)p : (size_t)4096;
+}
 int ycge_pin_host_buffer(void *buffer, size_t bytes)
 {
-    if (!buffer || bytes == 0) return YCGE_ERR_INVALID_ARG;
-    return hipHostRegister(buffer, bytes, hipHostRegisterDefault) == hipSuccess ? YCGE_OK : YCGE_ERR_DEVICE;
+    const size_t page = ycge_host_page_size();
+    if (!buffer || bytes == 0 || ((uintptr_t)buffer % page) != 0 || (bytes % page) != 0) return YCGE_ERR_INVALID_ARG;
+    if (hipHostRegister(buffer, bytes, hipHostRegisterDefault) == hipSuccess) return YCGE_OK;
+    (void)hipGetLastError();
+    return YCGE_ERR_DEVICE;
 }
 int ycge_unpin_host_buffer(void *buffer)
 {
-    if (!buffer) return YCGE_ERR_INVALID_ARG;
-    return hipHostUnregister(buffer) == hipSuccess ? YCGE_OK : YCGE_ERR_DEVICE;
+    if (!buffer || ((uintptr_t)buffer % ycge_host_page_size()) != 0) return YCGE_ERR_INVALID_ARG;
+    if (hipHostUnregister(buffer) == hipSuccess) return YCGE_OK;
+    (void)hipGetLastError();
+    return YCGE_ERR_DEVICE;
+}
+int ycge_alloc_host_buffer(size_t bytes, void **out)
+{
+    if (!out) return YCGE_ERR_INVALID_ARG;
+    *out = nullptr;
+    if (bytes == 0) return YCGE_ERR_INVALID_ARG;
+    void *p = nullptr;
+    if (hipHostMalloc(&p, bytes, hipHostMallocDefault) != hipSuccess) { (void)hipGetLastError(); return YCGE_ERR_OUT_OF_MEMORY; }
+    std::memset(p, 0, bytes);
+    *out = p;
+    return YCGE_OK;
+}
+int ycge_free_host_buffer(void *buffer)
+{
+    if (!buffer) return YCGE_OK;
+    if (hipHostFree(buffer) == hipSuccess) return YCGE_OK;
+    (void)hipGetLastError();
+    return YCGE_ERR_INVALID_ARG;
 }
 
 int ycge_device_count(void)
@@ -2876,6 +2919,7 @@ static int ensure_resident(ycge_ctx *c)
 {
     if (c->parent || !c->peers.empty()) return c->fail(YCGE_ERR_INVALID_ARG, "the tile-resident form is one process per GPU (rank / world_size); this context drives its devices through ycge_render_frame");
     if (c->cfg.capture_debug) return c->fail(YCGE_ERR_INVALID_ARG, "the tile-resident form keeps no debug captures");
+    if (c->cfg.taa_clamp_radius > 1) return c->fail(YCGE_ERR_UNSUPPORTED, "the tile-resident form exchanges a one-pixel halo: taa_clamp_radius %d needs ycge_resolve_gathered", c->cfg.taa_clamp_radius);
     HIP_TRY(c, hipSetDevice(c->device));
     const int K = c->cfg.tile_ring <= 0 ? 2 : c->cfg.tile_ring;
     if (K < 2 || K > (int)ycge_ctx::kResCostFrames - 1) return c->fail(YCGE_ERR_INVALID_ARG, "config.tile_ring must be 2..%d", (int)ycge_ctx::kResCostFrames - 1);
@@ -3048,6 +3092,14 @@ int ycge_trace_tiles_resident_batch(ycge_ctx *c, int32_t n, const float *poses, 
     std::vector<ycge_ctx::ResidentSet *> sets((size_t)n, nullptr);
     c->batch_P.clear(); c->batch_O.clear();
     int ob = -1;
+    // A batch is all or nothing for the host-side state: frames enter the pending list only after the whole batch is queued, and a failure on
+    // the way (a launch refused, an allocation) puts the frame counter back and leaves the list as it was - the caller's exchange and the
+    // ring stay in step.  (What a failed HIP call leaves on the device is the device's business: the context reports YCGE_ERR_DEVICE.)
+    const int64_t frame_counter_before = c->frame_counter;
+    struct Rollback {
+        ycge_ctx *c; int64_t counter; bool armed = true;
+        ~Rollback() { if (armed) { c->frame_counter = counter; c->batch_collect = false; c->batch_P.clear(); c->batch_O.clear(); } }
+    } rollback{c, frame_counter_before};
     for (int k = 0; k < n; k++) {
         set_pose(k);
         snapshot_frame(c, fs[(size_t)k]);
@@ -3094,8 +3146,9 @@ int ycge_trace_tiles_resident_batch(ycge_ctx *c, int32_t n, const float *poses, 
         e = ycge_launch_halo(0, rs->hdr.p, rs->sky.p, c->d_halo_send_px.p, (uint32_t)n_send, d_halo_send ? d_halo_send[k] : nullptr, stream);
         if (e != 0) return c->fail(YCGE_ERR_DEVICE, "k_gather_halo launch failed: %s", hipGetErrorString((hipError_t)e));
         HIP_TRY(c, hipEventRecord(rs->traced, stream)); rs->traced_used = true;
-        c->pending.push_back(fs[(size_t)k]);
     }
+    for (int k = 0; k < n; k++) c->pending.push_back(fs[(size_t)k]);
+    rollback.armed = false;
     const int every = c->knobs.res_sched_every > 0 ? c->knobs.res_sched_every : K;
     bool build = false;
     for (int k = 0; k < n; k++) if (fs[(size_t)k].frame % every == 0) build = true;
@@ -3127,6 +3180,8 @@ int ycge_resolve_tiles_resident(ycge_ctx *c, const void *d_halo_recv, void *d_hi
     size_t n_recv = 0;
     for (int64_t v : c->halo_recv_counts) n_recv += (size_t)v;
     if (n_recv > 0 && !d_halo_recv) return c->fail(YCGE_ERR_INVALID_ARG, "null halo receive buffer (%zu records of 16 bytes)", n_recv);
+    // every refusal comes BEFORE the frame leaves the pending list: a refused call changes nothing, ring and caller stay in step
+    if (c->cfg.taa_clamp_radius > 1) return c->fail(YCGE_ERR_UNSUPPORTED, "the tile-resident form exchanges a one-pixel halo: taa_clamp_radius %d needs ycge_resolve_gathered", c->cfg.taa_clamp_radius);
     hipStream_t stream = hip_stream ? (hipStream_t)hip_stream : c->stream;
     c->last_stream = stream;
     auto t0 = std::chrono::steady_clock::now();
@@ -3144,7 +3199,6 @@ int ycge_resolve_tiles_resident(ycge_ctx *c, const void *d_halo_recv, void *d_hi
     T.alpha = cs_max(0.0f, cs_min(1.0f, c->cfg.taa_alpha));
     T.radius = c->cfg.taa_clamp_radius > 0 ? c->cfg.taa_clamp_radius : 0;
     T.pad_lum = c->cfg.taa_luminance_pad;
-    if (T.radius > 1) return c->fail(YCGE_ERR_UNSUPPORTED, "the tile-resident form exchanges a one-pixel halo: taa_clamp_radius %d needs ycge_resolve_gathered", T.radius);
     const bool did_reset = !c->taa_valid || fs.reset;
     T.reset = did_reset ? 1 : 0;
     FrameParams P;
