@@ -78,7 +78,7 @@ class RaytraceRenderer:
     # ---------------------------------------------------------------- reference surface
     def UploadScene(self, scene: Scene | FlatScene):
         """scene.RebuildBVH() + upload (RaytraceRenderer.cs:107, RaytraceEntity.cs:244)."""
-        self.flat = scene if isinstance(scene, FlatScene) else flatten(scene)
+        self.flat = scene if hasattr(scene, "byref") else flatten(scene)          # (a FlatScene, or a scene file read back: tools/scene_file.py)
         self._check(self.L.ycge_scene_upload(self.ctx, self.flat.byref()))
 
     def UpdateLights(self, lights, ambient=None, background_top=None, background_bottom=None):
