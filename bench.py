@@ -102,6 +102,48 @@ def load_pmc(config, build_hash, tag=""):
     return None, stale
 
 
+def timed_twin_work(flat, fbw, fbh, ss, pose, first_frame, frames, device, moving, warmup, set_pose):
+    """What the TIMED stage kernels of a voxel world walk, per frame, from their counting twin (build.VARIANTS['voxstat']: the non-counting
+    instances + per-lane counters; never timed).  None when the variant has not been built."""
+    import ctypes as C
+    from yetanotherconsolegameengine_amd import abi, build
+    from yetanotherconsolegameengine_amd.renderer import RaytraceRenderer
+    path = build.variant_path("voxstat")
+    if not path.exists() or build.is_stale(path, build.VARIANTS["voxstat"]):
+        return None
+    Lt = abi.load_library(path)
+    rt = RaytraceRenderer(flat, fbw, fbh, pose["fov"], ss, device=device, lib=Lt)
+    rt.SetCamera(pose["pos"], pose["yaw"], pose["pitch"])
+    f = Lt.ycge_debug_read_batch_stats
+    f.restype = C.c_int; f.argtypes = [C.c_void_p, C.c_void_p]
+
+    def read():
+        a = (C.c_uint64 * 64)()
+        if f(rt.ctx, a) != 0:
+            return None
+        return np.array(list(a), dtype=np.float64).reshape(8, 8)
+
+    rt.set_frame_counter(first_frame - 1)
+    a = read()
+    for k in range(frames):
+        set_pose(rt, warmup + k, moving)
+        rt.TryFlipAndBlit()
+    b = read()
+    rt.close()
+    if a is None or b is None:
+        return None
+    d = (b - a) / frames
+    pixels = fbw * ss * fbh * 2 * ss
+    tree = d[4, 0] + d[4, 1] + d[4, 2]
+    lrec, cont = d[5, 0], d[5, 1]
+    parts = {"scene_tree_steps_x64": 64 * tree, "cell_fetches_x1": d[4, 7], "light_records_64_w_r": 128 * lrec,
+             "continuation_rays_48_16_w_r": 128 * cont, "primary_hits_16_w_r": 32 * pixels, "per_pixel_118": 118 * pixels}
+    return {"bytes_per_launch": int(sum(parts.values())), "bytes_by_kind": {k: int(v) for k, v in parts.items()},
+            "scene_tree_steps": round(tree, 1), "objects_culled_by_their_solid_box": round(d[4, 3], 1), "grids_asked": round(d[4, 4], 1), "grids_entered": round(d[4, 5], 1),
+            "cell_steps": round(d[4, 6], 1), "cell_fetches": round(d[4, 7], 1), "light_records": round(lrec, 1), "continuation_rays": round(cont, 1),
+            "frames": frames, "what": "per frame, every stage kernel (k_wf_primary, k_wf_trace_p, k_wf_lights, k_wf_shade) of the timed build's counting twin on the timed frames"}
+
+
 def orbit_pose(pose, k):
     """Frame k of the moving camera: the eye circles the point it looks at (2 units ahead), the yaw follows.  Three steps in four
     are SMALL (0.0008 rad: 0.0016 units of translation - below MotionTransReset = MotionRotReset = 0.0025, TemporalAA.cs:58-67,
@@ -404,7 +446,10 @@ def main():
                 rs_ev_t[k].record(st)
         rs_issued.extend(slots)
         rs_poses.clear()
-        while len(rs_issued) > 2 * n:
+        # exchange + resolve of the batch's frames are queued NOW, behind its launch (they wait for its event on the exchange stream): the
+        # launch that takes these ring slots three batches later finds them done (queued only when the slots were needed, they ran starved
+        # beside the launches in flight and the next launch waited for them: profiles/r05, the gaps between k_trace_batch launches)
+        while rs_issued:
             rs_resolve(rs_issued.pop(0))
 
     def step(rr, want_stats=False):
@@ -418,8 +463,6 @@ def main():
                 rs_issue_batch(rr)
             return 0.0, 0.0
         if resident and rr is r and not want_stats:
-            if len(rs_issued) == K:
-                rs_resolve(rs_issued.pop(0))
             k = n_issued[0] % K
             n_issued[0] += 1
             with torch.cuda.stream(rs_traces[k]):
@@ -429,7 +472,7 @@ def main():
                 if e1 is not None:
                     e1.record(rs_traces[k])
                 rs_ev_t[k].record(rs_traces[k])
-            rs_issued.append(k)
+            rs_resolve(k)          # queued right behind its trace (waits for rs_ev_t[k] on the exchange stream): done long before slot k is taken again
             return 0.0, 0.0
         if not pipelined or want_stats:
             rr.trace_tiles(slab.data_ptr(), stream.cuda_stream, want_stats=want_stats)
@@ -556,10 +599,24 @@ def main():
                                   "achieved_gbs": round(tb / (mean_trace_ms * 1e-3) / 1e9, 2), "frac": round(tb / (mean_trace_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 5),
                                   "what": f"what the TIMED kernels walked: {STEP_FETCH_BYTES} B fetched per lane step (node / triangle-pair record; a cooperative step - a treelet or a whole leaf - counts as one) + 118 B per pixel"}
         elif timed_lane_steps is not None:
-            # a voxel world's lane steps mix tree steps (a 64-byte record each) and cell steps (one byte, mostly arithmetic): no byte figure is honest
-            roof["timed_work"] = {"lane_steps_per_launch": round(timed_lane_steps, 1), "bytes_per_launch": None,
-                                  "what": "tree steps and voxel cell steps of the TIMED kernels, summed; the algorithmic figure above prices the REFERENCE's walk - every grid entered, every shadow ray traced - "
-                                          "which the timed kernels do not make (solid-voxel cull, no ray towards a dark light): use the counter figures"}
+            # A voxel world: the figure above prices the REFERENCE's walk - every grid entered, every shadow ray traced - which the timed stage
+            # kernels do not make (solid-voxel cull, walk tree, no ray towards a dark light), so its `frac` can exceed 1 and says nothing about
+            # them.  The roofline of the timed kernels comes from their counting TWIN (lib/var_voxstat.so: the same non-counting instances with
+            # per-lane counters), replaying the timed frames: scene-tree steps x 64 B (one node / object record each), cell fetches x 1 B, the
+            # stage-queue records written and read back (light record 64 B, continuation ray 48 + 16 B, primary hit 16 B), 118 B per pixel.
+            tw = timed_twin_work(flat, fbw, fbh, ss, pose, first_frame, min(args.steps, 6), local_rank, moving, args.warmup, set_pose)
+            roof["reference_walk"] = {"algorithmic_bytes_per_launch": int(my_alg), "achieved": roof["achieved"], "frac": roof["frac"],
+                                      "what": "SURVEY 8d counters of the REFERENCE's traversal / the timed kernels' launch time: NOT the work they do (frac may exceed 1)"}
+            if tw:
+                tb = tw["bytes_per_launch"]
+                roof["achieved"] = round(tb / (mean_trace_ms * 1e-3) / 1e9, 2)
+                roof["frac"] = round(tb / (mean_trace_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 5)
+                roof["algorithmic_bytes_per_launch"] = int(tb)
+                roof["achieved_is"] = "bytes the TIMED stage kernels fetch and store by their own counters (counting twin of the timed instances, same frames) / launch time"
+                roof["timed_work"] = {"lane_steps_per_launch": round(timed_lane_steps, 1), **tw}
+            else:
+                roof["timed_work"] = {"lane_steps_per_launch": round(timed_lane_steps, 1), "bytes_per_launch": None,
+                                      "what": "lib/var_voxstat.so (the counting twin, built by __graft_entry__.build()) is missing: no byte figure for the timed kernels; `frac` above prices the reference's walk"}
         pmc, stale = load_pmc(args.config, build_hash, lit_tag) if (world == 1 and n_dev == 1) else (None, False)
         if pmc:
             # counters of the same kernels, same build, from the committed PMC passes; the rate uses THIS run's launch time

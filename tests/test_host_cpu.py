@@ -697,42 +697,60 @@ def test_desired_chunk_set_known_answer():
     assert len(half) == 3 * 3 * 2 and half[0] == (0, 0, 0) and half[-1] == (2, 1, 2)
 
 
-def test_page_locked_arrays_own_their_pages():
-    """renderer.py page-locks its SDR arrays with ycge_pin_host_buffer (hipHostRegister, page-granular): every registered range must start on a
-    page boundary, be whole pages, lie inside the array's own allocation and share no page with another array's - two registered heap arrays
-    that share a boundary page lose it when one of them is unregistered (the GPU memory fault of round 4, NOTEBOOK section 11)."""
+def test_sdr_arrays_of_the_python_mirror_live_in_the_librarys_page_locked_memory():
+    """renderer.py keeps its SDR frames - the wrapper's one buffer and the ring of the frames in flight - in memory ycge_alloc_host_buffer
+    hands out (hipHostMalloc) and gives every block back exactly once; it never registers numpy memory (hipHostRegister on process heap
+    was behind the GPU memory faults of round 4: csrc/ycge_host.cpp, copy_out).  Checked with a stand-in library: no GPU needed."""
     import ctypes as C
     from yetanotherconsolegameengine_amd.renderer import RaytraceRenderer
 
-    calls = []
+    live, freed, blocks = {}, [], []
 
     class _Lib:
         @staticmethod
-        def ycge_pin_host_buffer(ptr, n):
-            calls.append((ptr.value, n)); return 0
+        def ycge_alloc_host_buffer(n, out):
+            buf = (C.c_uint8 * n)()          # zeroed, like the library's
+            blocks.append(buf)
+            out._obj.value = C.addressof(buf)
+            live[C.addressof(buf)] = n
+            return 0
+
+        @staticmethod
+        def ycge_free_host_buffer(p):
+            assert p.value in live, "freed twice or never allocated"
+            freed.append(p.value); del live[p.value]
+            return 0
+
+        @staticmethod
+        def ycge_wait(ctx):
+            return 0
+
+        def __getattr__(self, name):
+            raise AssertionError("the mirror called " + name + ": SDR arrays must not be registered / pinned by hand")
 
     class _Self:
-        L = _Lib(); _PAGE = RaytraceRenderer._PAGE
+        L = _Lib(); ctx = None; fbH, fbW = 27, 96
 
-    arrays = []
-    for shape in [(27, 96, 2, 3), (27, 96, 2, 3), (360, 1280, 2, 3), (1, 1, 2, 3), (45, 160, 2, 3)] * 3:
-        a, pinned = RaytraceRenderer._page_locked_zeros(_Self(), shape)
-        assert pinned and a.shape == shape and a.dtype == np.float32 and a.flags["C_CONTIGUOUS"] and not a.any()
-        a[...] = 1.0          # (writable, its own memory)
-        arrays.append(a)
-    assert len(calls) == len(arrays)
-    page = RaytraceRenderer._PAGE
-    spans = []
-    for a, (ptr, n) in zip(arrays, calls):
-        assert ptr == a.ctypes.data and ptr % page == 0 and n % page == 0 and n >= a.nbytes
-        raw = a.base if a.base is not None else a
-        while getattr(raw, "base", None) is not None:
-            raw = raw.base
-        assert raw.ctypes.data <= ptr and ptr + n <= raw.ctypes.data + raw.nbytes          # the registered pages are the array's own
-        spans.append((ptr, ptr + n))
-    spans.sort()
-    for (a0, a1), (b0, b1) in zip(spans, spans[1:]):
-        assert a1 <= b0          # no page is registered twice
+    me = _Self()
+    for f in ("_page_locked_zeros", "_free_page_locked", "_sdr_buffer", "_drop_sdr_buffer", "_drop_sdr_ring"):
+        setattr(_Self, f, getattr(RaytraceRenderer, f))
+    a = me._sdr_buffer()
+    assert a.shape == (27, 96, 2, 3) and a.dtype == np.float32 and a.flags["C_CONTIGUOUS"] and not a.any() and a.ctypes.data in live
+    a[...] = 1.0
+    assert me._sdr_buffer() is a and len(live) == 1                     # one buffer for the life of the renderer
+    me.fbH, me.fbW = 45, 160
+    b = me._sdr_buffer()                                                # another console size: the old block goes back, a new one comes
+    assert b.shape == (45, 160, 2, 3) and len(live) == 1 and len(freed) == 1 and b.ctypes.data in live
+    ring = me.__dict__.setdefault("_sdr_ring", {})
+    for k in range(3):
+        ring[k] = me._page_locked_zeros((45, 160, 2, 3))
+    assert len(live) == 4
+    me._drop_sdr_ring(keep_shape=(45, 160, 2, 3))
+    assert len(live) == 4 and len(ring) == 3                            # same size: kept
+    me._drop_sdr_ring(keep_shape=(1, 1, 2, 3))
+    assert len(live) == 1 and not ring
+    me._drop_sdr_buffer(); me._drop_sdr_buffer()                        # idempotent
+    assert not live and len(freed) == 5 and len(set(freed)) == 5
 
 
 def test_pin_refuses_what_is_not_whole_pages_of_its_own():

@@ -113,6 +113,10 @@ VARIANTS = {
     # the measured-and-rejected kernel forms of csrc/experiments/ (k_trace_refill, the group hand-over A-trous): out of the product build,
     # kept bit-exact by their parity tests through this one
     "experiments": ["-DYCGE_EXPERIMENTS=1"],
+    # the counting TWIN of the timed stage kernels of voxel worlds: the same non-counting instances with per-lane counters of what they
+    # walk (scene-tree steps by kind, cell steps, cell fetches, queue records).  bench.py --config 5 replays its timed frames through it for
+    # `roofline.timed_work`; profiles/vox_stats.py reads the per-phase clocks of k_wf_trace_p from it
+    "voxstat": ["-DYCGE_DBG_VOXSTAT=1"],
 }
 
 

@@ -211,6 +211,7 @@ struct SceneDev {
     float bg_top[3], bg_bottom[3];
     int32_t is_volume_scene;
     int32_t any_transparent;            // some material has Transparency > 0
+    int32_t analytic_only;              // Scene.Objects holds neither a mesh nor a voxel grid: the scene tree is walked by analytic_walk (ycge_rt.hip.h)
     const uint32_t *tex_pixels;         // every texture's RGBA32 pixels (Renderer/Texture.cs:15), back to back
     const int32_t *tex_info;            // per texture: {first pixel, width, height, 0}
     int32_t any_textured;               // some material samples a texture (SampleAlbedo, RaytraceRenderer.cs:724-735)

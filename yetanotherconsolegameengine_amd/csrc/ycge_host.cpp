@@ -147,6 +147,9 @@ struct Knobs {
     int bfs_rays = 0;                // YCGE_BFS=<n>: a wavefront's occlusion queries against a mesh go breadth-first from one shared work list when at most n of its lanes ask (mesh_anyhit_bfs; 0 = never, 64 = always)
     bool no_flight_stage_overlap = false;   // YCGE_NO_FLIGHT_STAGE_OVERLAP: frames in flight of the stage pipeline (voxel worlds) one trace at a time (A/B)
     bool no_lights_beside = false;   // YCGE_NO_LIGHTS_BESIDE: the stage pipeline strictly in sequence (A/B of the light loop beside the next round's trace)
+    bool lpt_always = false;         // YCGE_LPT_ALWAYS: the longest-first schedule also for frames whose blocks are all resident at once
+    int persist_min_tiles = -1;      // YCGE_PERSIST_MIN_TILES: frames of fewer tiles take k_wf_extend instead of the persistent extend stage (-1: a quarter of the persistent wavefronts)
+    bool no_analytic_walk = false;   // YCGE_NO_ANALYTIC_WALK: scenes of analytic objects only are walked by tree_phase's general loop (A/B of analytic_walk; same pixels)
     bool no_walk_tree = false;       // YCGE_NO_WALK_TREE: voxel worlds are walked down the scene tree, leaves and object steps and all (A/B of SceneDev::walk_nodes)
     bool no_coop = false;            // YCGE_NO_COOP: no treelets are built, sparse wavefronts keep the regular walk (A/B of the cooperative walk)
     bool exposure_serial = false;    // YCGE_EXPOSURE_SERIAL: the one-lane chain instead of the chunked exact evaluation
@@ -155,6 +158,9 @@ struct Knobs {
         auto geti = [](const char *n, int dflt) { const char *e = getenv(n); return e ? atoi(e) : dflt; };
         if (const char *e = getenv("YCGE_PATH")) path_policy = e[0] == 'w' ? 1 : e[0] == 'm' ? 2 : 0;
         xcd_strips = getenv("YCGE_XCD_STRIPS") != nullptr; generic_walk = getenv("YCGE_GENERIC_WALK") != nullptr;
+        no_analytic_walk = getenv("YCGE_NO_ANALYTIC_WALK") != nullptr;
+        if (const char *e = getenv("YCGE_PERSIST_MIN_TILES")) persist_min_tiles = atoi(e);
+        lpt_always = getenv("YCGE_LPT_ALWAYS") != nullptr;
         no_walk_tree = getenv("YCGE_NO_WALK_TREE") != nullptr; no_lights_beside = getenv("YCGE_NO_LIGHTS_BESIDE") != nullptr; no_flight_stage_overlap = getenv("YCGE_NO_FLIGHT_STAGE_OVERLAP") != nullptr;
         no_lpt = getenv("YCGE_NO_LPT") != nullptr; no_refill = getenv("YCGE_NO_REFILL") != nullptr;
         if (const char *e = getenv("YCGE_WAVE_PROF")) wave_prof_stage = e[0] == 'e' ? 1 : e[0] == 'm' ? 2 : 0;
@@ -407,6 +413,9 @@ struct ycge_ctx {
     uint8_t *tex_stage[2] = {nullptr, nullptr};
     size_t tex_stage_bytes[2] = {0, 0};
     hipEvent_t tex_stage_ev[2] = {nullptr, nullptr};
+    // GPU -> host copies never target memory whose mapping the library does not control (copy_out below): page-locked staging of its own
+    void *out_stage = nullptr; size_t out_stage_bytes = 0;
+    float *staged_sdr_dst = nullptr; size_t staged_sdr_bytes = 0;       // a synchronous frame's SDR read-back into a pageable caller array: finished on the host after the stream
     hipEvent_t tex_order_ev = nullptr;         // "everything queued on the second trace stream so far": a live texture's copy waits for it
     bool tex_stage_busy[2] = {false, false};
     int tex_stage_next = 0;
@@ -917,6 +926,7 @@ void ycge_destroy(ycge_ctx *c)
     c->d_materials.release(); c->d_meshes.release(); c->d_grids.release(); c->d_cells.release(); c->d_lut.release(); c->d_lights.release(); c->d_tex_pixels.release(); c->d_tex_info.release();
     for (int k = 0; k < 2; k++) { if (c->tex_stage[k]) (void)hipHostFree(c->tex_stage[k]); if (c->tex_stage_ev[k]) (void)hipEventDestroy(c->tex_stage_ev[k]); }
     if (c->tex_order_ev) (void)hipEventDestroy(c->tex_order_ev);
+    if (c->out_stage) { (void)hipHostFree(c->out_stage); c->out_stage = nullptr; c->out_stage_bytes = 0; }
     for (auto &ev : c->ev) if (ev) (void)hipEventDestroy(ev);
     for (hipEvent_t ev : {c->fan_ev[0], c->fan_ev[1], c->traced_ev, c->order_ev, c->pushed_ev}) if (ev) (void)hipEventDestroy(ev);
     if (c->fan_stream) (void)hipStreamDestroy(c->fan_stream);
@@ -954,6 +964,52 @@ static int upload_lights(ycge_ctx *c, const ycge_light *lights, int n)
 
 }
 namespace {
+
+// ---- device -> host.  The device writes host memory in two places only: page-locked memory (the library's own - hipHostMalloc - or whole
+// pages the caller registered, ycge_pin_host_buffer) and the library's own staging buffer below; a PAGEABLE destination is filled by the CPU
+// from that staging buffer.  Handing a pageable pointer to hipMemcpy lets the runtime choose how the bytes get there, and for transfers of
+// a megabyte and more it page-locks the caller's pages on the fly and lets the copy engine write them: a mapping of process heap whose
+// lifetime neither the caller nor the library controls (the allocator trims and regrows the heap, the runtime caches what it pinned).
+// Twice in ~25 runs of the GPU suite in round 4 and once in the first full run of round 5 - AFTER the registered arrays of the Python
+// mirror had been given pages of their own - a read-back died with "Memory access fault by GPU ... Write access" at a heap address.
+bool host_memory_is_page_locked(const void *p)
+{
+    hipPointerAttribute_t a;
+    std::memset(&a, 0, sizeof a);
+    if (hipPointerGetAttributes(&a, p) != hipSuccess) { (void)hipGetLastError(); return false; }      // (older runtimes: an error for plain heap memory)
+    return a.type == hipMemoryTypeHost;
+}
+int ensure_out_stage(ycge_ctx *c, size_t bytes)
+{
+    if (c->out_stage_bytes >= bytes) return YCGE_OK;
+    if (c->out_stage) { (void)hipHostFree(c->out_stage); c->out_stage = nullptr; c->out_stage_bytes = 0; }
+    HIP_TRY(c, hipHostMalloc(&c->out_stage, bytes, hipHostMallocDefault));
+    c->out_stage_bytes = bytes;
+    return YCGE_OK;
+}
+// synchronous copy of `bytes` from device memory of the current device to `dst`; nothing of this context may be in flight on other streams
+int copy_out(ycge_ctx *c, void *dst, const void *src, size_t bytes)
+{
+    if (bytes == 0) return YCGE_OK;
+    if (host_memory_is_page_locked(dst)) { HIP_TRY(c, hipMemcpy(dst, src, bytes, hipMemcpyDeviceToHost)); return YCGE_OK; }
+    const size_t chunk = (size_t)32 << 20;
+    const int rc = ensure_out_stage(c, bytes < chunk ? bytes : chunk);
+    if (rc != YCGE_OK) return rc;
+    for (size_t off = 0; off < bytes; off += chunk) {
+        const size_t n = bytes - off < chunk ? bytes - off : chunk;
+        HIP_TRY(c, hipMemcpyAsync(c->out_stage, (const uint8_t *)src + off, n, hipMemcpyDeviceToHost, c->stream));
+        HIP_TRY(c, hipStreamSynchronize(c->stream));
+        std::memcpy((uint8_t *)dst + off, c->out_stage, n);
+    }
+    return YCGE_OK;
+}
+// the SDR frame of a SYNCHRONOUS call into a pageable array: the copy was queued into the staging buffer (run_post); the stream has been waited for
+void finish_staged_sdr(ycge_ctx *c)
+{
+    if (!c->staged_sdr_dst) return;
+    std::memcpy(c->staged_sdr_dst, c->out_stage, c->staged_sdr_bytes);
+    c->staged_sdr_dst = nullptr; c->staged_sdr_bytes = 0;
+}
 
 // every stream a frame of this context may still be running on
 int quiesce(ycge_ctx *c)
@@ -1034,6 +1090,7 @@ struct ObjectsHost {
     std::vector<int32_t> grid_owner;       // per grid of the last upload: the object that holds it (-1: none), SceneDev::grid_owner
     bool grid_owner_unique = true;         // false: two objects hold the same grid - no walk tree
     float walk_t_limit = 0.0f;             // the smallest GGrid::cull_t_limit of the grids in Objects
+    bool analytic_only = true;             // no mesh and no voxel grid among the objects (SceneDev::analytic_only)
 };
 
 // Scene.Objects as device records + what Scene.RebuildBVH gets from every object's TryGetBounds (BVH.cs:32-53); no tree yet
@@ -1043,8 +1100,10 @@ int flatten_objects(ycge_ctx *c, const ycge_prim *prims, int n_prims, ObjectsHos
     gprims.assign(n_prims, GPrim{});
     items.resize(n_prims);
     oh.grid_owner.assign(c->grid_solid.size(), -1); oh.grid_owner_unique = true; oh.walk_t_limit = HUGE_VALF;
+    oh.analytic_only = true;
     for (int i = 0; i < n_prims; i++) {
         const ycge_prim &q = prims[i];
+        if (q.type == YCGE_PRIM_MESH || q.type == YCGE_PRIM_VOLUME_GRID) oh.analytic_only = false;
         GPrim &g = gprims[i];
         std::memset(&g, 0, sizeof g);
         g.type = q.type; g.material = q.material; g.ref = q.ref; g.reflectivity = q.reflectivity;
@@ -1176,6 +1235,7 @@ int install_objects(ycge_ctx *c, const ObjectsHost &oh)
     SceneDev &sd = c->sd;
     sd.scene_nodes = c->d_scene_nodes.p; sd.scene_leaf_prims = c->d_scene_leaf.p; sd.prims = c->d_prims.p;
     sd.scene_root_ref = oh.scene_root;
+    sd.analytic_only = (oh.analytic_only && !c->knobs.no_analytic_walk) ? 1 : 0;
     for (int a = 0; a < 3; a++) { sd.scene_root_min[a] = oh.root_min[a]; sd.scene_root_max[a] = oh.root_max[a]; }
     c->block_order_valid = false; c->flight_order_frame[0] = c->flight_order_frame[1] = c->flight_order_frame[2] = -1;
     return install_walk_tree(c, oh, (int)oh.scene_nodes.size(), oh.scene_root);
@@ -1221,6 +1281,7 @@ int install_objects_device_built(ycge_ctx *c, ycge_ctx *root, const ObjectsHost 
     SceneDev &sd = c->sd;
     sd.scene_nodes = c->d_scene_nodes.p; sd.scene_leaf_prims = c->d_scene_leaf.p; sd.prims = c->d_prims.p;
     sd.scene_root_ref = res.root_ref;
+    sd.analytic_only = (oh.analytic_only && !c->knobs.no_analytic_walk) ? 1 : 0;
     for (int a = 0; a < 3; a++) { sd.scene_root_min[a] = res.root_min[a]; sd.scene_root_max[a] = res.root_max[a]; }
     c->block_order_valid = false;
     const int rc3 = install_walk_tree(c, oh, res.n_inner, res.root_ref);
@@ -1694,8 +1755,7 @@ int ycge_debug_read_post_progress(ycge_ctx *c, uint32_t *dst, size_t n_words)
 {
     if (!c || !dst || !c->post_progress.p || n_words > c->post_progress.n) return YCGE_ERR_INVALID_ARG;
     HIP_TRY(c, hipDeviceSynchronize());
-    HIP_TRY(c, hipMemcpy(dst, c->post_progress.p, n_words * 4, hipMemcpyDeviceToHost));
-    return YCGE_OK;
+    return copy_out(c, dst, c->post_progress.p, n_words * 4);
 }
 // test / profiling hook: {device builds, host rebuilds after the kernel declined (a tree deeper than the reference's stack), host builds,
 // microseconds of the last update's build + install, Array.Sort cases in the current tree (BVH.cs:389,419), depth of the current tree}
@@ -1746,7 +1806,7 @@ int ycge_debug_read_coop_stats(ycge_ctx *c, uint64_t out[16])
     if (!c || !out || !c->dbg_counters.p) return YCGE_ERR_INVALID_ARG;
     std::vector<unsigned long long> v(16 + 16 * 256);
     HIP_TRY(c, hipDeviceSynchronize());
-    HIP_TRY(c, hipMemcpy(v.data(), c->dbg_counters.p, v.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost));
+    { const int rc2 = copy_out(c, v.data(), c->dbg_counters.p, v.size() * sizeof(unsigned long long)); if (rc2 != YCGE_OK) return rc2; }
     for (int k = 0; k < 16; k++) { out[k] = 0; for (int i = 0; i < 256; i++) out[k] += v[16 + 8 * 256 * (k >> 3) + 8 * i + (k & 7)]; }
     return YCGE_OK;
 }
@@ -1758,7 +1818,7 @@ int ycge_debug_read_batch_stats(ycge_ctx *c, uint64_t out[64])
     if (!c || !out || !c->dbg_counters.p) return YCGE_ERR_INVALID_ARG;
     std::vector<unsigned long long> v(16 + 64 * 256);
     HIP_TRY(c, hipDeviceSynchronize());
-    HIP_TRY(c, hipMemcpy(v.data(), c->dbg_counters.p, v.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost));
+    { const int rc2 = copy_out(c, v.data(), c->dbg_counters.p, v.size() * sizeof(unsigned long long)); if (rc2 != YCGE_OK) return rc2; }
     for (int k = 0; k < 64; k++) { out[k] = 0; for (int i = 0; i < 256; i++) out[k] += v[16 + 8 * 256 * (k >> 3) + 8 * i + (k & 7)]; }
     return YCGE_OK;
 }
@@ -1773,9 +1833,9 @@ int ycge_debug_read_walk_tree(ycge_ctx *c, void *gnodes_out, void *walk_out, int
     if (!gnodes_out || !walk_out || capacity_nodes < n || !grid_owner_out || n_grids != (int)c->grid_solid.size() || !root_and_limit_out) return YCGE_ERR_INVALID_ARG;
     HIP_TRY(c, hipSetDevice(c->device));
     HIP_TRY(c, hipDeviceSynchronize());
-    HIP_TRY(c, hipMemcpy(gnodes_out, c->d_scene_nodes.p, (size_t)n * sizeof(GNode), hipMemcpyDeviceToHost));
-    HIP_TRY(c, hipMemcpy(walk_out, c->d_walk_nodes.p, (size_t)n * (1 + 2 * YCGE_WALK_LEAF_NODES) * sizeof(GNode), hipMemcpyDeviceToHost));
-    HIP_TRY(c, hipMemcpy(grid_owner_out, c->d_grid_owner.p, (size_t)n_grids * sizeof(int32_t), hipMemcpyDeviceToHost));
+    { int rc2 = copy_out(c, gnodes_out, c->d_scene_nodes.p, (size_t)n * sizeof(GNode)); if (rc2 != YCGE_OK) return rc2;
+      rc2 = copy_out(c, walk_out, c->d_walk_nodes.p, (size_t)n * (1 + 2 * YCGE_WALK_LEAF_NODES) * sizeof(GNode)); if (rc2 != YCGE_OK) return rc2;
+      rc2 = copy_out(c, grid_owner_out, c->d_grid_owner.p, (size_t)n_grids * sizeof(int32_t)); if (rc2 != YCGE_OK) return rc2; }
     root_and_limit_out[0] = c->sd.walk_root_ref; std::memcpy(&root_and_limit_out[1], &c->sd.walk_t_limit, 4);
     return n;
 }
@@ -1984,8 +2044,13 @@ int trace_frame(ycge_ctx *c, float *d_slab, hipStream_t stream, FrameState &fs, 
             if (timed) HIP_TRY(c, hipEventRecord(c->ev[1], stream));
             return YCGE_OK;
         }
-        const bool lpt = !c->knobs.no_lpt;
         const uint32_t n_blocks = (uint32_t)c->n_owned * 4u;
+        // Longest first only where there is a "first": a frame whose 8 x 8 blocks are all resident at once (one wavefront each; 4 per SIMD
+        // for the kernels without a mesh walk, 3 with) is placed whole whatever the order, and the schedule - two kernels, a memset and
+        // two stream hops behind every trace - is then a fifth of a small frame: config 2 (3 600 blocks) 0.094 -> see DESIGN section 8
+        // (YCGE_LPT_ALWAYS=1: build it anyway).
+        const uint32_t resident_blocks = (uint32_t)c->compute_units * 4u * (c->meshes.empty() ? 4u : 3u);
+        const bool lpt = !c->knobs.no_lpt && (n_blocks > resident_blocks || c->knobs.lpt_always);
         const uint32_t cost_slot = (uint32_t)((uint64_t)fs.frame % YCGE_COST_FRAMES);       // this frame's array of the cost ring
         O.block_cost = lpt ? c->block_cost.p + (size_t)cost_slot * n_blocks : nullptr;
         const int fk = (int)(fs.frame & 1);
@@ -2081,6 +2146,14 @@ int trace_frame(ycge_ctx *c, float *d_slab, hipStream_t stream, FrameState &fs, 
         int pw = c->knobs.no_refill ? 0 : c->compute_units * c->knobs.pw_per_cu;
         if ((size_t)pw * 64 > O.stack_lanes) pw = (int)(O.stack_lanes / 64);
         if ((size_t)pw > nt * 4) pw = (int)(nt * 4);            // never more wavefronts than the round can have rays for
+        // A persistent wavefront takes a WHOLE tile segment (up to 256 rays, four passes) before it asks for the next: with fewer tiles than
+        // wavefronts the round is as long as one wavefront's four passes while most of the machine idles - config 1's 29 tiles: 90 us of a
+        // 180 us frame.  Such frames take the plain extend stage instead, four wavefronts per tile side by side (YCGE_PERSIST_MIN_TILES).
+        {
+            const int pw_full = c->compute_units * c->knobs.pw_per_cu;
+            const size_t min_tiles = c->knobs.persist_min_tiles >= 0 ? (size_t)c->knobs.persist_min_tiles : (size_t)(pw_full > 0 ? pw_full / 4 : 0);
+            if (nt < min_tiles) pw = 0;
+        }
         if (launch_begin) HIP_TRY(c, hipEventRecord(launch_begin, stream));
         // the light loop of a round beside the trace of the next (ycge_launch_wavefront): on the side stream, with a spill area of its own
         // (not where the light loop has nothing to trace - every light dark, timed kernels - nor for the small frames of a burst in flight,
@@ -2464,7 +2537,17 @@ int run_post(ycge_ctx *c, hipStream_t stream, float *out_sdr_host, bool timed, h
     if (e != 0) return c->fail(YCGE_ERR_DEVICE, "tonemap launch failed: %s", hipGetErrorString((hipError_t)e));
     if (timed) HIP_TRY(c, hipEventRecord(c->ev[3], stream));
     if (before_copy) HIP_TRY(c, hipEventRecord(before_copy, stream));
-    if (out_sdr_host) HIP_TRY(c, hipMemcpyAsync(out_sdr_host, d_sdr, (size_t)c->fbW * c->fbH * 6 * sizeof(float), hipMemcpyDeviceToHost, stream));
+    if (out_sdr_host) {
+        const size_t sdr_bytes = (size_t)c->fbW * c->fbH * 6 * sizeof(float);
+        float *target = out_sdr_host;
+        if (!host_memory_is_page_locked(out_sdr_host)) {        // (synchronous callers only: the frames in flight refuse a pageable array up front)
+            const int rs = ensure_out_stage(c, sdr_bytes);
+            if (rs != YCGE_OK) return rs;
+            target = (float *)c->out_stage;
+            c->staged_sdr_dst = out_sdr_host; c->staged_sdr_bytes = sdr_bytes;
+        }
+        HIP_TRY(c, hipMemcpyAsync(target, d_sdr, sdr_bytes, hipMemcpyDeviceToHost, stream));
+    }
     if (history_read) HIP_TRY(c, hipEventRecord(history_read, stream));        // (a single iteration: exposure and tonemap read the history itself)
     return YCGE_OK;
 }
@@ -2653,6 +2736,8 @@ static int render_frame_in_flight(ycge_ctx *c, float *out_sdr)
         return c->fail(YCGE_ERR_INVALID_ARG, "ycge_render_frame_async is the single-device form (tiled frames overlap through ycge_trace_tiles / ycge_resolve_gathered on two streams)");
     if (c->cfg.capture_debug || c->cfg.count_work) return c->fail(YCGE_ERR_INVALID_ARG, "ycge_render_frame_async keeps neither debug captures nor per-frame counters: use ycge_render_frame");
     HIP_TRY(c, hipSetDevice(c->device));
+    if (out_sdr && !host_memory_is_page_locked(out_sdr))
+        return c->fail(YCGE_ERR_INVALID_ARG, "ycge_render_frame_async_sdr fills its array while the caller runs on: it must be page-locked memory (ycge_alloc_host_buffer, or whole pages registered with ycge_pin_host_buffer)");
     if (!c->taa_stream) return c->fail(YCGE_ERR_INVALID_ARG, "no second stream: frames in flight need a single-device context");
     for (int k = 0; k < 3; k++) if (!c->set_resolved_ev[k]) HIP_TRY(c, hipEventCreateWithFlags(&c->set_resolved_ev[k], hipEventDisableTiming));
     for (int k = 0; k < 3; k++) if (!c->flight_order_ev[k]) HIP_TRY(c, hipEventCreateWithFlags(&c->flight_order_ev[k], hipEventDisableTiming));
@@ -2819,6 +2904,7 @@ int ycge_render_frame(ycge_ctx *c, float *out_sdr, ycge_frame_stats *st)
         if (rc != YCGE_OK) return rc;
     }
     HIP_TRY(c, hipStreamSynchronize(c->stream));
+    finish_staged_sdr(c);
     double wall = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
     rc = fill_stats(c, st, fs, did_reset, true, wall);
     if (rc == YCGE_OK && st && c->cfg.count_work)
@@ -2892,10 +2978,11 @@ int ycge_resolve_gathered(ycge_ctx *c, const void *d_all_slabs, void *hip_stream
     if (out_sdr) {
         rc = run_post(c, stream, out_sdr, st != nullptr);
         if (rc != YCGE_OK) return rc;
-        if (!st) HIP_TRY(c, hipStreamSynchronize(stream));      // the caller's host buffer is filled when the call returns
+        if (!st) { HIP_TRY(c, hipStreamSynchronize(stream)); finish_staged_sdr(c); }      // the caller's host buffer is filled when the call returns
     }
     if (st) {
         HIP_TRY(c, hipStreamSynchronize(stream));
+        finish_staged_sdr(c);
         std::memset(st, 0, sizeof *st);
         st->frame = fs.frame; st->history_reset = did_reset ? 1 : 0;
         float ms = 0.0f;
@@ -3297,6 +3384,11 @@ int ycge_debug_resident_loop(ycge_ctx *c, int32_t frames, double *period_ms, dou
     // gather), printed relative to the first - how the K traces in flight really lie to each other
     const bool timeline = getenv("YCGE_RES_LOOP_TIMELINE") != nullptr;
     std::vector<hipEvent_t> tl_b, tl_e;
+    // YCGE_RES_LOOP_EAGER=0: a frame's exchange + resolve are queued only when its ring slot is needed again (round 4's loop).  Default: queued
+    // right behind its trace (they wait for the trace's event on their own stream) - the trace that takes the slot K frames later then finds
+    // the resolve done instead of waiting for one that was queued a moment ago and runs starved beside the traces in flight
+    const char *ee = getenv("YCGE_RES_LOOP_EAGER");
+    const bool eager = !(ee && atoi(ee) == 0);
     auto frame = [&]() -> int {
         const int k = (int)(i++ % K);
         if ((int)issued.size() == K) { const int r2 = resolve(issued.front()); issued.pop_front(); if (r2 != YCGE_OK) return r2; }
@@ -3306,8 +3398,10 @@ int ycge_debug_resident_loop(ycge_ctx *c, int32_t frames, double *period_ms, dou
         const int r2 = ycge_trace_tiles_resident(c, send[k], st[k], nullptr);
         if (r2 != YCGE_OK) return r2;
         issued.push_back(k);
-        if (mark) { hipEvent_t ee = nullptr; if (hipEventCreate(&ee) != hipSuccess || hipEventRecord(ee, st[k]) != hipSuccess) return YCGE_ERR_DEVICE; tl_e.push_back(ee); }
-        return hipEventRecord(evt[k], st[k]) == hipSuccess ? YCGE_OK : YCGE_ERR_DEVICE;
+        if (mark) { hipEvent_t ee2 = nullptr; if (hipEventCreate(&ee2) != hipSuccess || hipEventRecord(ee2, st[k]) != hipSuccess) return YCGE_ERR_DEVICE; tl_e.push_back(ee2); }
+        if (hipEventRecord(evt[k], st[k]) != hipSuccess) return YCGE_ERR_DEVICE;
+        if (eager) { const int r3 = resolve(issued.front()); issued.pop_front(); if (r3 != YCGE_OK) return r3; }
+        return YCGE_OK;
     };
     auto drain = [&]() -> int { while (!issued.empty()) { const int r2 = resolve(issued.front()); issued.pop_front(); if (r2 != YCGE_OK) return r2; } return YCGE_OK; };
     // YCGE_RES_LOOP_BATCH=n: the frames n at a time in one launch (ycge_trace_tiles_resident_batch), consecutive batches on two streams
@@ -3328,7 +3422,7 @@ int ycge_debug_resident_loop(ycge_ctx *c, int32_t frames, double *period_ms, dou
             for (int k = 0; k < nb; k++) { issued.push_back(slots[k]); if (hipEventRecord(evt[(size_t)slots[k]], bs) != hipSuccess) return YCGE_ERR_DEVICE; }
             // the frames of the batch before the last are resolved NOW (they run beside the launches in flight, starved: a batch that re-uses
             // their sets should find them done - a ring of three batches' sets lets consecutive launches lie side by side)
-            while ((int)issued.size() > 2 * nb) { const int r3 = resolve(issued.front()); issued.pop_front(); if (r3 != YCGE_OK) return r3; }
+            while ((int)issued.size() > (eager ? 0 : 2 * nb)) { const int r3 = resolve(issued.front()); issued.pop_front(); if (r3 != YCGE_OK) return r3; }
             return YCGE_OK;
         };
         const int nbat = (frames + nb - 1) / nb;
@@ -3416,8 +3510,7 @@ int ycge_read_buffer(ycge_ctx *c, int32_t which, void *dst, size_t bytes)
     if (bytes != want) return c->fail(YCGE_ERR_INVALID_ARG, "buffer %d is %zu bytes, caller passed %zu", which, want, bytes);
     { const int jr = join_async(c); if (jr != YCGE_OK) return jr; }
     HIP_TRY(c, hipStreamSynchronize(c->stream));
-    HIP_TRY(c, hipMemcpy(dst, src, want, hipMemcpyDeviceToHost));
-    return YCGE_OK;
+    return copy_out(c, dst, src, want);
 }
 
 static int accel_view(ycge_ctx *c, int32_t which, int32_t index, const void **p, size_t *n)
@@ -3427,8 +3520,8 @@ static int accel_view(ycge_ctx *c, int32_t which, int32_t index, const void **p,
         c->scene_tree.nodes.resize((size_t)c->dev_tree_nodes);
         c->scene_tree.leaf_index.resize((size_t)c->dev_tree_items);
         if (hipSetDevice(c->device) != hipSuccess || hipStreamSynchronize(c->stream) != hipSuccess ||
-            hipMemcpy(c->scene_tree.nodes.data(), c->d_bvh_ref.p, (size_t)c->dev_tree_nodes * sizeof(RefNode), hipMemcpyDeviceToHost) != hipSuccess ||
-            hipMemcpy(c->scene_tree.leaf_index.data(), c->d_scene_leaf.p, (size_t)c->dev_tree_items * 4, hipMemcpyDeviceToHost) != hipSuccess)
+            copy_out(c, c->scene_tree.nodes.data(), c->d_bvh_ref.p, (size_t)c->dev_tree_nodes * sizeof(RefNode)) != YCGE_OK ||
+            copy_out(c, c->scene_tree.leaf_index.data(), c->d_scene_leaf.p, (size_t)c->dev_tree_items * 4) != YCGE_OK)
             return -1;
         c->scene_tree.root = 0;
         c->scene_tree_on_device = false;
@@ -3598,8 +3691,7 @@ int ycge_debug_read_wave_prof(ycge_ctx *c, unsigned long long *dst, size_t n_u64
 {
     if (!c || !dst || !c->wave_prof.p || n_u64 > c->wave_prof.n) return YCGE_ERR_INVALID_ARG;
     HIP_TRY(c, hipDeviceSynchronize());
-    HIP_TRY(c, hipMemcpy(dst, c->wave_prof.p, n_u64 * 8, hipMemcpyDeviceToHost));
-    return YCGE_OK;
+    return copy_out(c, dst, c->wave_prof.p, n_u64 * 8);
 }
 // sizeof of each ABI struct, for the ctypes mirror check
 size_t ycge_abi_sizeof(int32_t which)

@@ -79,6 +79,25 @@ __device__ __forceinline__ void flush_work(const Work &w, unsigned long long *co
     }
 }
 
+#if defined(YCGE_DBG_VOXSTAT)
+// The counting TWIN of the timed stage kernels (lib/var_voxstat.so; bench.py --config 5 replays its frames through it): what the TIMED
+// instances walk, by kind, summed over every stage kernel - bank 4: scene-tree steps (node, leaf, object), objects culled, grids asked /
+// entered, cell steps, cell fetches; bank 5: light records and continuation rays the shade stage wrote.
+__device__ __forceinline__ void voxstat_flush_all(const SceneDev &S, const Work &w)
+{
+    if (!S.dbg_counters) return;
+    unsigned long long *dc = S.dbg_counters + 16 + (size_t)8 * 256 * 4 + (size_t)((blockIdx.x * 2654435761u) >> 24) * 8;
+    for (int i = 0; i < 8; i++) {
+        unsigned long long x = w.dbg[i];
+        for (int off = 32; off >= 1; off >>= 1) x += __shfl_xor(x, off, 64);
+        if ((threadIdx.x & 63) == 0 && x) atomicAdd(dc + i, x);
+    }
+}
+#define YCGE_VOXSTAT_FLUSH(S, w) do { if (!COUNT) voxstat_flush_all(S, w); } while (0)
+#else
+#define YCGE_VOXSTAT_FLUSH(S, w) do { } while (0)
+#endif
+
 // ---------------------------------------------------------------------------------- wavefront records
 struct alignas(16) QEntry {     // one live path ray between stages (48 B)
     float o[3];
@@ -177,6 +196,7 @@ __global__ __launch_bounds__(256) void k_wf_primary(const SceneDev S, const Fram
         dst[3] = COUNT ? (((unsigned long long)g_wave_iters[wv * 4 + 3] << 32) | g_wave_iters[wv * 4 + 2]) : 0;
     }
     flush_work<COUNT>(w, O.counters);
+    YCGE_VOXSTAT_FLUSH(S, w);
 }
 
 // ---------------------------------------------------------------------------------- k_wf_extend
@@ -213,6 +233,7 @@ __global__ __launch_bounds__(256) void k_wf_extend(const SceneDev S, const Trace
         dst[3] = COUNT ? (((unsigned long long)g_wave_iters[wv * 4 + 3] << 32) | g_wave_iters[wv * 4 + 2]) : 0;
     }
     flush_work<COUNT>(w, O.counters);
+    YCGE_VOXSTAT_FLUSH(S, w);
 }
 
 // ---------------------------------------------------------------------------------- persistent trace stages (ray refill)
@@ -353,6 +374,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu((HAS_GRID &&
     }
 #endif
     flush_work<COUNT>(w, O.counters);
+    YCGE_VOXSTAT_FLUSH(S, w);
 }
 
 // ---------------------------------------------------------------------------------- k_wf_shade
@@ -498,6 +520,13 @@ __global__ __launch_bounds__(256) void k_wf_shade(const SceneDev S, const FrameP
     if (threadIdx.x == 0) {
         B.n_lq[k] = n_l;
         B.n_q[(size_t)(round + 1) * B.tiles + k] = n_n;
+#if defined(YCGE_DBG_VOXSTAT)
+        if (S.dbg_counters) {       // bank 5 of the twin's counters: records this stage wrote
+            unsigned long long *dc = S.dbg_counters + 16 + (size_t)8 * 256 * 5 + (size_t)((blockIdx.x * 2654435761u) >> 24) * 8;
+            if (n_l) atomicAdd(dc + 0, (unsigned long long)n_l);
+            if (n_n) atomicAdd(dc + 1, (unsigned long long)n_n);
+        }
+#endif
     }
 }
 
@@ -602,6 +631,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu((HAS_GRID &
         }
     }
     flush_work<COUNT>(w, O.counters);
+    YCGE_VOXSTAT_FLUSH(S, w);
 }
 
 // ---------------------------------------------------------------------------------- K_trace (single launch)
@@ -1439,12 +1469,15 @@ __global__ __launch_bounds__(256) void k_taa(const TaaParams T, const float *__r
 // TemporalBlendWithClamp on this rank's OWN tiles only: the same per-pixel code on the same operands as k_taa - the 3x3 neighbourhood of a
 // tile's edge pixels reaches one pixel into tiles of other ranks, whose {hdr, sky} arrived as halo records (k_scatter_halo) - so the
 // history, the guide copies and the reset rule never leave the rank that owns the tile.
-__global__ __launch_bounds__(256) void k_taa_tiles(const TaaParams T, const FrameParams P, const float *__restrict__ current, const float *__restrict__ normal,
-                                                   const float *__restrict__ depth, const uint8_t *__restrict__ sky, float *__restrict__ hist,
-                                                   float *__restrict__ prev_normal, float *__restrict__ prev_depth, uint8_t *__restrict__ prev_sky)
+// ONE wavefront per workgroup (an 8 x 8 sub-tile): this kernel runs beside the traces in flight, whose wavefronts hold 3 of a SIMD's register
+// slots - a 256-thread workgroup needs room on all four SIMDs of ONE compute unit at once and waited for it (175-245 us for a 10 us kernel,
+// profiles/r05: the resolve that the next launch on the same ring slots waits for); a single wavefront takes any slot that frees.
+__global__ __launch_bounds__(64) void k_taa_tiles(const TaaParams T, const FrameParams P, const float *__restrict__ current, const float *__restrict__ normal,
+                                                  const float *__restrict__ depth, const uint8_t *__restrict__ sky, float *__restrict__ hist,
+                                                  float *__restrict__ prev_normal, float *__restrict__ prev_depth, uint8_t *__restrict__ prev_sky)
 {
     int px, py, lx, ly;
-    if (!tile_pixel(P, (int)blockIdx.x, px, py, lx, ly)) return;
+    if (!tile_pixel_wl(P, (int)(blockIdx.x >> 2), (int)(blockIdx.x & 3u), (int)threadIdx.x, px, py, lx, ly)) return;
     taa_pixel(T, px, py, current, normal, depth, sky, hist, prev_normal, prev_depth, prev_sky);
 }
 // halo records {hdr rgb, sky} of the listed pixels: out of this rank's frame buffers for the ranks that need them (gather), and the
@@ -1725,7 +1758,7 @@ int ycge_launch_taa_tiles(const ycge::TaaParams *T, const ycge::FrameParams *P, 
                           float *hist, float *prev_normal, float *prev_depth, uint8_t *prev_sky, hipStream_t stream)
 {
     if (P->n_owned_tiles <= 0) return 0;
-    hipLaunchKernelGGL(ycge::k_taa_tiles, dim3((unsigned)P->n_owned_tiles), dim3(256), 0, stream, *T, *P, current, normal, depth, sky, hist, prev_normal, prev_depth, prev_sky);
+    hipLaunchKernelGGL(ycge::k_taa_tiles, dim3((unsigned)P->n_owned_tiles * 4u), dim3(64), 0, stream, *T, *P, current, normal, depth, sky, hist, prev_normal, prev_depth, prev_sky);
     return (int)hipGetLastError();
 }
 int ycge_launch_halo(int scatter, float *hdr, uint8_t *sky, const uint32_t *px, uint32_t n, void *records, hipStream_t stream)

@@ -553,6 +553,7 @@ __device__ __forceinline__ void grid_dda(const SceneDev &S, int grid_index_, int
                                       int &hit_prim, int &hit_sub, Work &w)
 {
     if (COUNT) { w.prim++; prof_tick(2); }
+    YCGE_VOXSTAT(w, 4);
     const GGrid g = S.grids[grid_index_];
     if (!COUNT && prim_index < 0) prim_index = S.grid_owner[grid_index_];       // (reached through the walk tree, which names grids: SceneDev::walk_nodes)
     float t_solid_out = YCGE_INF;
@@ -592,14 +593,19 @@ __device__ __forceinline__ void grid_dda(const SceneDev &S, int grid_index_, int
     const uint8_t *cells = S.grid_cells + g.cell_offset;
     const unsigned long long mask = ((unsigned long long)g.brick_mask_hi << 32) | g.brick_mask_lo;
     const bool use_mask = g.has_brick_mask != 0;
+#if defined(YCGE_DBG_VOXSTAT)
+    if (t <= t_exit && t <= tmax) w.dbg[5]++;
+#endif
     while (t <= t_exit && t <= tmax) {
         if (COUNT) prof_tick(3);
         w.steps++;
         {   // (VolumeGrid.cs:153 tests the cell against the grid's bounds here: always true - the entry cell is clamped into the grid
             // and the walk leaves the loop the moment a step takes it outside, :224-227)
             if (COUNT) w.vox++;
+            YCGE_VOXSTAT(w, 6);
             const int brick = grid_brick(ix, iy, iz, g.nbx, g.nby);
             if (!use_mask || ((mask >> brick) & 1ull)) {
+                YCGE_VOXSTAT(w, 7);
                 if (cells[(uint32_t)(brick * 512 + morton3_3bits(ix, iy, iz))] != 0) {
                     closest = cs_max(t, tmin);
                     hit_prim = prim_index;
@@ -1101,6 +1107,60 @@ __device__ __forceinline__ int walk_phase(const SceneDev &S, uint32_t &cur, STK 
     }
 }
 
+// The scene tree of a scene that holds ANALYTIC objects only (SceneDev::analytic_only: no mesh, no voxel grid - configs 1 and 2 of the
+// benchmark, BVH.cs:99-198 over the objects of Scenes/Scenes.cs:269-335), as two loops that each hold ONE kind of step: node and leaf
+// steps until the lane stands at an object (or has nothing left), then - all lanes of the wavefront that stand at one together - the
+// object's own test.  tree_phase's single loop carries the node step, the leaf step, nine primitive tests, the mesh entry and the grid entry
+// through every iteration a wavefront makes (1 400 instructions of which a lane at a node enters 150), and a wavefront whose lanes stand at
+// nodes, leaves and objects at once pays for all of it each time.  Per lane the sequence of visits, tests and updates of `closest` is
+// tree_phase's, operation for operation: same hits, same counters, same step count.
+template <bool COUNT, class STK>
+__device__ __forceinline__ void analytic_walk(const SceneDev &S, uint32_t cur, STK &st, F3 o, F3 d, F3 inv, float tmin, float &closest, int &hit_prim,
+                                              int &hit_sub, Work &w, bool anyhit)
+{
+    uint32_t at_prim = YCGE_REF_NONE_VALUE;          // payload of the object this lane stands at
+    bool more = cur != YCGE_REF_NONE_VALUE;          // the stack is empty at entry
+    for (;;) {
+        while (more) {
+            if (!COUNT && anyhit && hit_prim >= 0) { st.reset(); cur = YCGE_REF_NONE_VALUE; more = false; break; }      // occlusion query answered
+            if (cur == YCGE_REF_NONE_VALUE) {
+                float tn;
+                if (!st.pop(cur, tn)) { cur = YCGE_REF_NONE_VALUE; more = false; break; }
+                if (!(closest >= tn)) { cur = YCGE_REF_NONE_VALUE; continue; }
+            }
+            const uint32_t kind = YCGE_REF_KIND(cur), pay = YCGE_REF_PAYLOAD(cur);
+            if (kind == REF_PRIM) { at_prim = pay; cur = YCGE_REF_NONE_VALUE; break; }
+            if (COUNT) prof_tick(0);
+            w.steps++;
+            if (kind == REF_SCENE_NODE) {
+                const float4 *np = (const float4 *)(S.scene_nodes + pay);
+                const float4 a = np[0], b = np[1], c = np[2], e = np[3];
+                float ln, rn;
+                if (COUNT) w.box += 2;
+                const bool hl = box_scene(a.x, a.y, a.z, b.x, b.y, a.w, o, inv, tmin, closest, ln);      // GNode plane order
+                const bool hr = box_scene(b.z, b.w, c.x, c.z, c.w, c.y, o, inv, tmin, closest, rn);
+                const uint32_t lref = __float_as_uint(e.x), rref = __float_as_uint(e.y);
+                const bool left_first = ln < rn;
+                if (hl & hr) st.push(left_first ? rref : lref, left_first ? rn : ln);
+                cur = (hl & hr) ? (left_first ? lref : rref) : hl ? lref : hr ? rref : YCGE_REF_NONE_VALUE;
+            } else {        // REF_SCENE_LEAF: its objects in index order (BVH.cs:139-149)
+                const uint32_t start = pay >> 3, count = pay & 7u;
+                for (uint32_t i = count - 1; i >= 1; i--) st.push(YCGE_REF(REF_PRIM, S.scene_leaf_prims[start + i]), -YCGE_INF);
+                cur = YCGE_REF(REF_PRIM, S.scene_leaf_prims[start]);
+            }
+        }
+        if (!__any(at_prim != YCGE_REF_NONE_VALUE)) break;
+        if (at_prim != YCGE_REF_NONE_VALUE) {       // objectHit[objId](r, tMin, closest, ...), BVH.cs:139-149
+            if (COUNT) prof_tick(0);
+            w.steps++;
+            const float4 *pp = (const float4 *)(S.prims + at_prim);
+            const float4 q0 = pp[0], q1 = pp[1], q2 = pp[2], q3 = pp[3];
+            analytic_prim<COUNT>(q0, q1, q2, q3, __float_as_int(q0.x), (int)at_prim, o, d, tmin, closest, hit_prim, hit_sub, w);
+            at_prim = YCGE_REF_NONE_VALUE;
+        }
+    }
+}
+
 // where a query enters the scene: the walk tree of a voxel world (SceneDev::walk_nodes) for a ray of the timed kernels that leaves the
 // root box (at t_far) before the smallest distance any grid's cull verdict holds to, else the scene tree
 template <bool COUNT, bool HAS_GRID>
@@ -1113,6 +1173,10 @@ template <bool COUNT, bool HAS_GRID, class STK>
 __device__ __forceinline__ void walk(const SceneDev &S, uint32_t cur, int mesh_prim, STK &st, F3 o, F3 d, F3 inv, bool sx, bool sy, bool sz,
                                      float tmin, float &closest, int &hit_prim, int &hit_sub, Work &w, bool anyhit = false)
 {
+    if (S.analytic_only) {       // (wave-uniform: a scalar branch)
+        analytic_walk<COUNT>(S, cur, st, o, d, inv, tmin, closest, hit_prim, hit_sub, w, anyhit);
+        return;
+    }
     bool more = cur != YCGE_REF_NONE_VALUE;      // the stack is empty at entry
     // a ray that enters the walk tree of a voxel world with three finite reciprocals takes walk_phase - the loop that holds nothing else
     const bool fast = YCGE_WALK_PHASE && HAS_GRID && !COUNT && more && YCGE_REF_KIND(cur) == REF_WALK_NODE && cs_abs(inv.x) < YCGE_INF && cs_abs(inv.y) < YCGE_INF && cs_abs(inv.z) < YCGE_INF;

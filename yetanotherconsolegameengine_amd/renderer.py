@@ -57,10 +57,10 @@ class RaytraceRenderer:
             raise abi.YcgeError(rc, (self.L.ycge_last_error(self.ctx) or b"").decode())
 
     def close(self):
-        self._drop_sdr_buffer()
         if getattr(self, "ctx", None):
             self.L.ycge_destroy(self.ctx)          # (waits for the frames in flight: their SDR arrays are still the wrapper's)
             self.ctx = C.c_void_p()
+        self._drop_sdr_buffer()
         self._drop_sdr_ring()
 
     def __enter__(self):
@@ -124,13 +124,12 @@ class RaytraceRenderer:
         self._drop_sdr_ring(keep_shape=(self.fbH, self.fbW, 2, 3))
 
     def _drop_sdr_ring(self, keep_shape=None):
-        """The page-locked SDR arrays of the frames in flight: those of another console size are unpinned (only if pinning them had
-        succeeded) and released."""
+        """The page-locked SDR arrays of the frames in flight: those of another console size go back to the library (nothing is in flight:
+        the callers are Resize, which joins first, and close, after ycge_destroy)."""
         ring = self.__dict__.get("_sdr_ring", {})
         for key in [k for k, (a, _) in ring.items() if a.shape != keep_shape]:
-            a, pinned = ring.pop(key)
-            if pinned and getattr(self, "ctx", None) is not None:
-                self.L.ycge_unpin_host_buffer(a.ctypes.data_as(C.c_void_p))
+            a, handle = ring.pop(key)
+            self._free_page_locked(handle)
 
     def SetCamera(self, pos, yaw: float, pitch: float):
         self._pos, self._yaw, self._pitch = tuple(pos), yaw, pitch
@@ -144,37 +143,41 @@ class RaytraceRenderer:
         p = (C.c_float * 3)(*self._pos)
         self._check(self.L.ycge_set_camera(self.ctx, p, self._yaw, self._pitch, self._fov))
 
-    _PAGE = 4096
-
     def _page_locked_zeros(self, shape):
-        """A float32 array on WHOLE pages of its own, page-locked through ycge_pin_host_buffer (hipHostRegister): (array, pinned).
-        Registration is page-granular.  A numpy array straight from the heap shares its first and last page with whatever malloc put
-        next to it - another renderer's SDR array, the next slot of the ring - and unregistering ONE of two arrays that share a page
-        takes the page from the other: its next read-back is a GPU write to an unmapped host page ("Memory access fault by GPU" at a
-        heap address, once in a dozen runs of the GPU suite - round 4).  So: over-allocate, start on a page boundary, register whole
-        pages that belong to this array alone."""
-        n = int(np.prod(shape)) * 4
-        span = (n + self._PAGE - 1) // self._PAGE * self._PAGE
-        raw = np.zeros(span + self._PAGE, dtype=np.uint8)
-        off = (-raw.ctypes.data) % self._PAGE
-        a = raw[off:off + n].view(np.float32).reshape(shape)          # (keeps `raw` alive through .base)
-        pinned = self.L.ycge_pin_host_buffer(C.c_void_p(a.ctypes.data), span) == 0      # (best effort: an unpinned array only makes the copy block)
-        return a, pinned
+        """A zeroed float32 array in page-locked memory OF THE LIBRARY (ycge_alloc_host_buffer: hipHostMalloc): (array, handle).  The
+        device writes SDR frames straight into it.  Round 4 registered numpy arrays instead (hipHostRegister) and met GPU memory faults
+        at heap addresses: registration is page-granular, and - more to the point - a mapping of process heap lives and dies with the
+        allocator, not with the array (csrc/ycge_host.cpp: copy_out).  The handle goes back through _free_page_locked; the array must
+        not be touched after that."""
+        n = int(np.prod(shape))
+        p = C.c_void_p()
+        rc = self.L.ycge_alloc_host_buffer(n * 4, C.byref(p))
+        if rc != 0 or not p.value:
+            raise abi.YcgeError(rc, f"no page-locked memory for an SDR frame of {n * 4} bytes")
+        a = np.ctypeslib.as_array(C.cast(p, C.POINTER(C.c_float)), shape=(n,)).reshape(shape)
+        return a, p
+
+    def _free_page_locked(self, handle):
+        if handle is not None and handle.value:
+            self.L.ycge_free_host_buffer(handle)
+            handle.value = None
 
     def _sdr_buffer(self):
-        """The wrapper's ONE SDR buffer (the C# side keeps a float[] for the life of the renderer), page-locked
-        once through ycge_pin_host_buffer so that the frame's read-back is a plain DMA."""
+        """The wrapper's ONE SDR buffer (the C# side keeps one for the life of the renderer, bindings/csharp/HipRaytraceWrapper.cs), page-locked
+        memory of the library: the frame's read-back is a plain DMA."""
         shape = (self.fbH, self.fbW, 2, 3)
         if getattr(self, "_sdr", None) is None or self._sdr.shape != shape:
+            if getattr(self, "_sdr", None) is not None and getattr(self, "ctx", None):
+                self.L.ycge_wait(self.ctx)
             self._drop_sdr_buffer()
-            self._sdr, self._sdr_pinned = self._page_locked_zeros(shape)
+            self._sdr, self._sdr_handle = self._page_locked_zeros(shape)
         return self._sdr
 
     def _drop_sdr_buffer(self):
-        if getattr(self, "_sdr", None) is not None and getattr(self, "_sdr_pinned", False):
-            self.L.ycge_unpin_host_buffer(self._sdr.ctypes.data_as(C.c_void_p))
+        if getattr(self, "_sdr", None) is not None:
+            self._free_page_locked(getattr(self, "_sdr_handle", None))
         self._sdr = None
-        self._sdr_pinned = False
+        self._sdr_handle = None
 
     def TryFlipAndBlit(self, want_sdr: bool = False, copy: bool = True):
         """One frame.  Returns the fbH x fbW x 2 x 3 SDR array (top, bottom per chexel) when want_sdr (a copy of the wrapper's
