@@ -215,6 +215,7 @@ struct FrameState {
     int64_t frame;
     uint32_t fan_blocks;
     bool scheduled = false;      // the trace ran the single-launch kernel with a longest-first schedule (cost ring in use)
+    bool single_launch = false;  // the trace ran the single-launch kernel (its last workgroup stores the placed value), scheduled or not
 };
 
 struct MeshHost {
@@ -2062,6 +2063,7 @@ int trace_frame(ycge_ctx *c, float *d_slab, hipStream_t stream, FrameState &fs, 
         // frame N + 1 runs with the order built behind frame N - 1.  The same buffers and rules as the frames in flight.
         const bool deferred = slab && lpt && !flight;
         fs.scheduled = lpt;
+        fs.single_launch = true;
         uint32_t policy, split_top;
         schedule_policy(c, policy, split_top);
         if (deferred) {
@@ -2828,7 +2830,7 @@ static int render_frame_in_flight(ycge_ctx *c, float *out_sdr)
     c->spill_override = nullptr;
     c->in_flight_call = false;
     if (rc != YCGE_OK) return rc;
-    if (c->placed_next && fs.scheduled) c->placed_expect = c->placed_next;       // (only the single-launch kernels store the value)
+    if (c->placed_next && fs.single_launch) c->placed_expect = c->placed_next;       // (only the single-launch kernels store the value)
     HIP_TRY(c, hipEventRecord(ev_end, ts));          // end of the trace: the timing ring's event is also what the second stream waits for
     c->flight_frames++;
     HIP_TRY(c, hipStreamWaitEvent(c->taa_stream, ev_end, 0));
