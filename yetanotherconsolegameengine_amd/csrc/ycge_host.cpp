@@ -1942,13 +1942,17 @@ void snapshot_frame(ycge_ctx *c, FrameState &fs)
 // With three or more traces of the tile-resident ring in flight the slots are no longer plentiful - the traces fill each other's tails - and
 // the shallow cut wins at every rank count (8 ranks, ring of 4, one-GPU emulation: 033220000 0.147-0.172 ms a rank-frame, 044433000
 // 0.186-0.20, unsplit 0.17-0.23; profiles/r04/g_resident_ring_emulation.txt).
-void schedule_policy(const ycge_ctx *c, uint32_t &policy, uint32_t &split_top, int resident_ring = 0)
+// BATCHED launches (n frames of a rank's tiles per launch, two launches in flight) are throughput-bound: two overlapping launches of four
+// eighth-frames are a whole frame's blocks and took 0.84 ms against the whole frame's 0.48 - the split's thin wavefronts (8 or 4 parts of a
+// block's 64 pixels) are slot time nobody gets back.  Unsplit: 8 ranks, batches of 4: 0.100-0.108 -> 0.086-0.088 ms a rank-frame
+// (011110000 0.087-0.093, 022110000 0.088-0.095, 022220000 0.101-0.112; profiles/r05/e_split_policy_by_form.txt).
+void schedule_policy(const ycge_ctx *c, uint32_t &policy, uint32_t &split_top, int resident_ring = 0, bool batched = false)
 {
-    const uint32_t world_policy = (resident_ring >= 3 && c->cfg.world_size >= 2) ? 033220000u
+    const uint32_t world_policy = batched ? 0u : (resident_ring >= 3 && c->cfg.world_size >= 2) ? 033220000u
                                 : c->cfg.world_size >= 8 ? 044433000u : c->cfg.world_size >= 4 ? 044320000u : c->cfg.world_size >= 2 ? 033220000u : 0u;
     policy = c->knobs.split_set ? c->knobs.split_policy : world_policy;
     // ... or, on a whole frame, the split_top blocks at the head of the schedule whatever their class (k_cost_scatter)
-    split_top = (c->knobs.split_set || policy || c->knobs.split_top <= 0) ? 0u : ((uint32_t)c->knobs.split_top & 0xffffu) | ((uint32_t)c->knobs.split_top_lg << 16);
+    split_top = (c->knobs.split_set || policy || batched || c->knobs.split_top <= 0) ? 0u : ((uint32_t)c->knobs.split_top & 0xffffu) | ((uint32_t)c->knobs.split_top_lg << 16);
 }
 
 // (a scene with a textured material takes the generic kernels: the flat ones - configs 3 and 4 - are compiled without the texture
@@ -1959,7 +1963,10 @@ int scene_is_flat(const ycge_ctx *c)
 }
 bool frame_is_single_launch(const ycge_ctx *c)
 {
-    return c->sd.any_transparent || c->knobs.path_policy == 2 || (c->knobs.path_policy == 0 && scene_is_flat(c));
+    // (auto: one-leaf scenes - the mesh viewers - and scenes of analytic objects only: a few dozen objects under a shallow tree are bound by
+    // the latency of a pixel's chain of queries, not by throughput, and one launch lets the chains overlap - config 1's scene at 80x45 ..
+    // 960x270 consoles: 0.080 / 0.083 / 0.106 / 0.199 ms against 0.101 / 0.110 / 0.145 / 0.218 as stages, profiles/r05)
+    return c->sd.any_transparent || c->knobs.path_policy == 2 || (c->knobs.path_policy == 0 && (scene_is_flat(c) || c->sd.analytic_only));
 }
 
 // step 4 (RaytraceRenderer.cs:183-216): ray-gen + trace of this context's tiles for the frame `fs`
@@ -3243,7 +3250,7 @@ int ycge_trace_tiles_resident_batch(ycge_ctx *c, int32_t n, const float *poses, 
     for (int k = 0; k < n; k++) if (fs[(size_t)k].frame % every == 0) build = true;
     if (lpt && build) {         // a new schedule behind the batch, from the cost slots up to its last frame's (ycge_trace_tiles_resident's rule)
         uint32_t policy, split_top;
-        schedule_policy(c, policy, split_top, K);
+        schedule_policy(c, policy, split_top, K, true);
         const uint32_t last_slot = (uint32_t)((uint64_t)fs[(size_t)n - 1].frame % RC);
         uint32_t skip = 0;
         for (int a = 1; a < K; a++) skip |= 1u << ((last_slot + (uint32_t)a) % RC);
@@ -3419,8 +3426,11 @@ int ycge_debug_resident_loop(ycge_ctx *c, int32_t frames, double *period_ms, dou
             void *sends[ycge_ctx::kBatchMax];
             int slots[ycge_ctx::kBatchMax];
             for (int k = 0; k < nb; k++) { slots[k] = (int)(i++ % K); sends[k] = send[(size_t)slots[k]]; if (hipStreamWaitEvent(bs, evr[(size_t)slots[k]], 0) != hipSuccess) return YCGE_ERR_DEVICE; }
+            const bool mark = timeline && batches > 4 + (int64_t)((frames + nb - 1) / nb) - 10;
+            if (mark) { hipEvent_t eb = nullptr; if (hipEventCreate(&eb) != hipSuccess || hipEventRecord(eb, bs) != hipSuccess) return YCGE_ERR_DEVICE; tl_b.push_back(eb); }
             const int r2 = ycge_trace_tiles_resident_batch(c, nb, pose, sends, bs);
             if (r2 != YCGE_OK) return r2;
+            if (mark) { hipEvent_t ee2 = nullptr; if (hipEventCreate(&ee2) != hipSuccess || hipEventRecord(ee2, bs) != hipSuccess) return YCGE_ERR_DEVICE; tl_e.push_back(ee2); }
             for (int k = 0; k < nb; k++) { issued.push_back(slots[k]); if (hipEventRecord(evt[(size_t)slots[k]], bs) != hipSuccess) return YCGE_ERR_DEVICE; }
             // the frames of the batch before the last are resolved NOW (they run beside the launches in flight, starved: a batch that re-uses
             // their sets should find them done - a ring of three batches' sets lets consecutive launches lie side by side)
@@ -3441,6 +3451,13 @@ int ycge_debug_resident_loop(ycge_ctx *c, int32_t frames, double *period_ms, dou
         const auto b2 = std::chrono::steady_clock::now();
         *issue_ms = std::chrono::duration<double, std::milli>(b1 - b0).count() / (nbat * nb);
         *period_ms = std::chrono::duration<double, std::milli>(b2 - b0).count() / (nbat * nb);
+        for (size_t q = 0; q < tl_b.size() && q < tl_e.size(); q++) {
+            float b = 0.0f, e2 = 0.0f;
+            (void)hipEventElapsedTime(&b, tl_b[0], tl_b[q]); (void)hipEventElapsedTime(&e2, tl_b[0], tl_e[q]);
+            fprintf(stderr, "  batch %2zu: begin %7.3f ms  end %7.3f ms  duration %6.3f\n", q, b, e2, e2 - b);
+        }
+        for (hipEvent_t ev : tl_b) (void)hipEventDestroy(ev);
+        for (hipEvent_t ev : tl_e) (void)hipEventDestroy(ev);
         cleanup();
         return YCGE_OK;
     }
