@@ -526,6 +526,7 @@ def main():
         # processes: no per-step host synchronisation inside the timed region (trace on one stream, all-gather -> resolve on another)
         set_pose(r, args.warmup + k, moving)
         per_step.append(step(r, want_stats=not multi))
+    issue_s = time.perf_counter() - t0          # host time to QUEUE the timed frames (several processes: nothing waits inside the loop)
     fence()
     elapsed = time.perf_counter() - t0
     timed_lane_steps = (r.timed_steps() - steps0) / args.steps if not multi else None
@@ -703,6 +704,18 @@ def main():
                 "post_ms": round(float(np.median(ms[:, 2])), 4), "frame_ms_with_sdr_readback": round(float(np.median(ms[:, 3])), 4),
                 "frame_ms_min": round(float(ms[:, 3].min()), 4),
                 "what": "ycge_render_frame with an SDR buffer: + A-trous denoise, auto-exposure, tonemap/downsample, read-back (medians of 10 frames, static camera)"}
+        # ... and the same frame with the in-place quirk of the denoiser's second iteration WAIVED (config.atrous_inplace_exact = 0, SURVEY 8-f1
+        # "reproduce or explicitly waive"; INTEGRATION.md section 2 states what a host gives up): the delivered frame, both ways, side by side
+        cfgw = abi.default_config(); cfgw.atrous_inplace_exact = 0
+        rw = RaytraceRenderer(flat, fbw, fbh, pose["fov"], ss, cfg=cfgw, device=local_rank)
+        rw.SetCamera(pose["pos"], pose["yaw"], pose["pitch"])
+        msw = []
+        for _ in range(12):
+            rw.TryFlipAndBlit(want_sdr=True, copy=False)
+            msw.append((float(rw.stats.post_ms), float(rw.stats.total_ms)))
+        rw.close()
+        msw = np.array(msw[2:])
+        post["waived"] = {"post_ms": round(float(np.median(msw[:, 0])), 4), "frame_ms_with_sdr_readback": round(float(np.median(msw[:, 1])), 4)}
 
     cpu = None
     if rank == 0 and single and not args.no_cpu_baseline:
@@ -757,6 +770,9 @@ def main():
             # flight (the ring of the tile-resident form: K traces, or three batches of n frames - a batch also NEEDS its n poses up front)
             "latency_frames": (args.ring if resident else 2 if pipelined else 1) if multi else 1,
             "rccl_world": rccl_world,
+            # one process per GPU: what this rank's host thread spent queueing a frame (Python + torch.distributed + the library's calls); a rank's
+            # period cannot be shorter, whatever its GPU does - compare DESIGN section 8's emulated periods, whose loop is driven from C
+            "host_issue_ms_per_frame": round(issue_s / args.steps * 1e3, 4) if multi else None,
             "primary_mrays_per_s": round(pixels * args.steps / elapsed / 1e6, 2),
             "rays_per_frame": round(per_frame["n_rays"], 1),
             # the reference's call count includes shadow rays towards lights of intensity 0, which the timed kernels never trace (bit-identical
@@ -767,6 +783,9 @@ def main():
             "work_per_frame": {k: round(v, 1) for k, v in per_frame.items()},
             "roofline": roof, "cpu_baseline": cpu,
         }
+        if post:        # the frame TryFlipAndBlit delivers (SDR chexels in host memory), beside the headline's trace + TAA
+            out["sdr_frame_ms"] = {"exact": post["frame_ms_with_sdr_readback"], "waived": post["waived"]["frame_ms_with_sdr_readback"],
+                                   "what": "ycge_render_frame with an SDR buffer, synchronous, median: exact = the reference's in-place A-trous iteration bit for bit; waived = config.atrous_inplace_exact 0"}
         if flight:
             out["frames_in_flight"] = flight
         if frame_ms and frame_ms[0] > 0:

@@ -249,13 +249,14 @@ __global__ __launch_bounds__(256) void k_wf_extend(const SceneDev S, const Trace
 // at the same light, their lengths are alike, and k_wf_lights already keeps 53 % of its lanes busy.
 #define YCGE_ROUND_TREE_STEPS 6
 #define YCGE_ROUND_CELL_STEPS 10
+#define YCGE_ROUND_PHASE_MODE 0        // 0: both phases every round; 1: only the phase most lanes wait for; 2: skip a phase with < 16 takers while the other has >= 16 (measured: see DESIGN section 8)
 #define YCGE_ROUND_REFILL_MIN 16       // lanes that wait for a ray before rays are handed out (or all of them): lit config 5 4.06 -> 4.02 ms, its moving-camera leg 2.22 -> 2.06 (profiles/r04/h_voxel_walk_tree.txt)
 #ifndef YCGE_TRACEP_WAVES
 #define YCGE_TRACEP_WAVES 5          // persistent extend stage: 5 wavefronts per SIMD (102 registers, no scratch; round 3: as fast as 6 with its 10 spilled registers - 7.04 against 7.00 ms - and 0.46 GB less written per 4K frame) and 32 persistent wavefronts per CU
 #endif
 template <bool COUNT, bool HAS_GRID>
 __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu((HAS_GRID && !COUNT) ? YCGE_TRACEP_WAVES : 1, 8))) void k_wf_trace_p(const SceneDev S, const FrameParams P, const TraceOut O, const WfBuffers B, int round,
-                                                   uint32_t *__restrict__ chunk_ctr, int round_tree_steps, int round_cell_steps, int refill_min)
+                                                   uint32_t *__restrict__ chunk_ctr, int round_tree_steps, int round_cell_steps, int refill_min, int phase_mode)
 {
     Work w = {0, 0, 0, 0, 0, 0, 0};
     StackT<64> st;
@@ -333,8 +334,18 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu((HAS_GRID &&
         vs_rounds++; vs_have += (unsigned long long)__popcll(__ballot(have)); vs_tree += (unsigned long long)__popcll(__ballot(have && more && !in_dda));
 #endif
         // ---- one round: a bounded number of tree steps for the lanes in the tree, then a bounded number of cell
-        // steps for the lanes inside a grid (their state persists in D); lanes that finish are refilled at the top
-        if (have && more && !in_dda) {
+        // steps for the lanes inside a grid (their state persists in D); lanes that finish are refilled at the top.
+        // Each phase is issued for the whole wavefront whatever the number of lanes in it (round 4's counters: 44 lanes in the tree phase, 28 in
+        // the cell phase of an average round - half of the issue slots idle), so a round may run only the phase MOST of its lanes wait for
+        // (phase_mode 1) or skip a phase that fewer than a quarter of the wavefront would take part in while the other has takers (2): the
+        // others wait a round, their state keeps.  Which round a ray's steps fall in never changes the ray's result.
+        bool run_tree = true, run_cell = true;
+        if (phase_mode) {
+            const int n_tree = (int)__popcll(__ballot(have && more && !in_dda)), n_dda = (int)__popcll(__ballot(in_dda));
+            if (phase_mode == 1) { if (n_dda > n_tree) run_tree = false; else if (n_dda > 0 && n_tree > 0) run_cell = false; }
+            else { if (n_tree < 16 && n_dda >= 16) run_tree = false; else if (n_dda < 16 && n_tree >= 16) run_cell = false; }
+        }
+        if (run_tree && have && more && !in_dda) {
             int parked_grid = -1, parked_prim = -1;
             float parked_tend = YCGE_INF;       // where the ray leaves the box of the grid's solid voxels: the walk ends there (timed kernels)
             // (a ray in the walk tree of a voxel world takes the loop that holds nothing else, and leaves it only for an object that is no grid)
@@ -350,7 +361,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu((HAS_GRID &&
 #if defined(YCGE_DBG_VOXSTAT)
         vs_dda += (unsigned long long)__popcll(__ballot(in_dda));
 #endif
-        if (HAS_GRID && in_dda) {
+        if (HAS_GRID && run_cell && in_dda) {
             bool in = true;
 #pragma unroll 1
             for (int k2 = 0; k2 < round_cell_steps && in; k2++) in = dda_step<COUNT>(S, D, tmin, closest, hit_prim, hit_sub, w);
@@ -1669,10 +1680,10 @@ int ycge_launch_wavefront(const ycge::SceneDev *S, const ycge::FrameParams *P, c
     B.tile_order = P->tile_order;
     B.elide_dark = count ? 0u : 1u;
     const dim3 block(256), tiles((unsigned)P->n_owned_tiles);
-    static int round_steps[3] = {0, 0, 0};
-    if (round_steps[0] == 0) {       // steps per round of k_wf_extend_p: YCGE_ROUND="tree,cell[,lanes waiting before a refill]" overrides the tuned defaults
-        round_steps[0] = YCGE_ROUND_TREE_STEPS; round_steps[1] = YCGE_ROUND_CELL_STEPS; round_steps[2] = YCGE_ROUND_REFILL_MIN;
-        if (const char *e = getenv("YCGE_ROUND")) { int a2 = 0, b2 = 0, c2 = YCGE_ROUND_REFILL_MIN; if (sscanf(e, "%d,%d,%d", &a2, &b2, &c2) >= 2 && a2 > 0 && b2 > 0 && c2 > 0) { round_steps[0] = a2; round_steps[1] = b2; round_steps[2] = c2; } }
+    static int round_steps[4] = {0, 0, 0, 0};
+    if (round_steps[0] == 0) {       // steps per round of k_wf_extend_p: YCGE_ROUND="tree,cell[,lanes waiting before a refill[,phase mode]]" overrides the tuned defaults
+        round_steps[0] = YCGE_ROUND_TREE_STEPS; round_steps[1] = YCGE_ROUND_CELL_STEPS; round_steps[2] = YCGE_ROUND_REFILL_MIN; round_steps[3] = YCGE_ROUND_PHASE_MODE;
+        if (const char *e = getenv("YCGE_ROUND")) { int a2 = 0, b2 = 0, c2 = YCGE_ROUND_REFILL_MIN, d2 = YCGE_ROUND_PHASE_MODE; if (sscanf(e, "%d,%d,%d,%d", &a2, &b2, &c2, &d2) >= 2 && a2 > 0 && b2 > 0 && c2 > 0 && d2 >= 0) { round_steps[0] = a2; round_steps[1] = b2; round_steps[2] = c2; round_steps[3] = d2; } }
     }
     sel3(count != 0, has_grid != 0, flat != 0, [&](auto C, auto G, auto F) {
         hipLaunchKernelGGL((k_wf_primary<decltype(C)::value, decltype(G)::value, decltype(F)::value>), tiles, block, 0, stream, *S, *P, *O, B);
@@ -1684,7 +1695,7 @@ int ycge_launch_wavefront(const ycge::SceneDev *S, const ycge::FrameParams *P, c
             (void)hipMemsetAsync(B.chunk_ctr, 0, sizeof(uint32_t), stream);
             sel3(count != 0, has_grid != 0, false, [&](auto C, auto G, auto) {
                 hipLaunchKernelGGL((k_wf_trace_p<decltype(C)::value, decltype(G)::value>), dim3((unsigned)persistent_waves), dim3(64), 0, stream,
-                                   *S, *P, *O, B, r, B.chunk_ctr, round_steps[0], round_steps[1], round_steps[2]);
+                                   *S, *P, *O, B, r, B.chunk_ctr, round_steps[0], round_steps[1], round_steps[2], round_steps[3]);
             });
         } else if (r > 0)
             sel3(count != 0, has_grid != 0, flat != 0, [&](auto C, auto G, auto F) {
