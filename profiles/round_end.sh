@@ -4,13 +4,13 @@
 # (every profiler run under its own timeout), rank emulations (slab form, tile-resident ring), in-flight A/B, post stage exact / waived,
 # per-wavefront profile, cooperative-walk clocks.  Everything lands in gpurun_out/.
 REPO=${GRAFT_REPO_ROOT:-/root/repo}; cd $REPO; mkdir -p gpurun_out
-TAG=${1:-r04}
+TAG=${1:-r05}; RND=${2:-r05}
 timeout 2400 python -m pytest tests -m gpu -q > gpurun_out/pytest_gpu_$TAG.log 2>&1; echo "pytest rc=$?"; tail -3 gpurun_out/pytest_gpu_$TAG.log
 # the profiles FIRST: bench.py prints the counter-derived roofline fields only from a summary of the running build (profiles/r04/pmc_config*.json, source_hash)
 bash profiles/run_profiles.sh ${TAG}_c4 > gpurun_out/prof_${TAG}_c4.log 2>&1; echo "profiles c4 rc=$?"; head -12 gpurun_out/prof_${TAG}_c4/summary.txt
 bash profiles/run_profiles.sh ${TAG}_c5 --config 5 > gpurun_out/prof_${TAG}_c5.log 2>&1; echo "profiles c5 rc=$?"; head -12 gpurun_out/prof_${TAG}_c5/summary.txt
 bash profiles/run_profiles.sh ${TAG}_c5lit --config 5 --t01 0.5 > gpurun_out/prof_${TAG}_c5lit.log 2>&1; echo "profiles c5 lit rc=$?"; head -12 gpurun_out/prof_${TAG}_c5lit/summary.txt
-mkdir -p profiles/r04; for f in gpurun_out/prof_${TAG}_c4/pmc_config4.json gpurun_out/prof_${TAG}_c5/pmc_config5.json gpurun_out/prof_${TAG}_c5lit/pmc_config5_t050.json; do [ -f $f ] && cp $f profiles/r04/; done
+mkdir -p profiles/$RND; for f in gpurun_out/prof_${TAG}_c4/pmc_config4.json gpurun_out/prof_${TAG}_c5/pmc_config5.json gpurun_out/prof_${TAG}_c5lit/pmc_config5_t050.json; do [ -f $f ] && cp $f profiles/$RND/; done
 timeout 600 python bench.py > gpurun_out/bench_$TAG.json 2> gpurun_out/bench_$TAG.err; echo "bench rc=$?"
 for c in 1 2 3 5; do timeout 400 python bench.py --config $c --cpu-seconds 10 2>> gpurun_out/bench_$TAG.err > gpurun_out/bench_${TAG}_cfg$c.json; done
 timeout 500 python bench.py --config 5 --t01 0.5 --cpu-seconds 10 2>> gpurun_out/bench_$TAG.err > gpurun_out/bench_${TAG}_cfg5_t050.json
