@@ -205,3 +205,51 @@ def test_wrapper_and_flattener_only_call_what_is_declared():
     for member in ("void SetCamera(Vec3", "void SetFov(float", "void TryFlipAndBlit(Framebuffer", "void Resize(Framebuffer"):      # RaytraceEntity.cs:12-18
         assert member in wrapper, member
     assert "ycge_pin_host_buffer" not in wrapper and "GCHandle" not in wrapper          # the SDR frame lives in the library's page-locked memory
+
+
+def test_flattener_passes_each_primitive_the_parameters_the_header_documents():
+    """SceneFlattener.cs: every `Prim(YPrimType.X, material, specular, reflectivity, ref, p...)` call passes as many floats as include/ycge.h
+    documents for that primitive (`p = cx,cy,cz,radius` ...), the overriding primitives (plane, disk, rects, box: Surfaces.cs:65-66 ...) pass
+    their own Specular / Reflectivity and the others zero - the same records yetanotherconsolegameengine_amd/scene.py builds."""
+    header = (ROOT / "include" / "ycge.h").read_text()
+    want = {}
+    for m in re.finditer(r"YCGE_PRIM_(\w+) = \d+,?\s*/\* p = (.*?)(?:\s{2,}|\*/)", header):
+        n = 0
+        for tok in m.group(2).split(","):
+            n += 3 if "xyz" in tok else 1
+        want[m.group(1).replace("_", "").lower()] = n
+    assert want == {"sphere": 4, "plane": 6, "disk": 7, "xyrect": 5, "xzrect": 5, "yzrect": 5, "box": 6, "cylindery": 7, "triangle": 9}, want
+    text = re.sub(r"//[^\n]*", "", (CS / "SceneFlattener.cs").read_text())
+    seen = {}
+    for m in re.finditer(r"Prim\(YPrimType\.(\w+),", text):
+        i, depth, args, cur = m.end(), 1, [], ""
+        while depth:
+            ch = text[i]
+            if ch in "([{":
+                depth += 1
+            elif ch in ")]}":
+                depth -= 1
+                if depth == 0:
+                    break
+            if ch == "," and depth == 1:
+                args.append(cur.strip()); cur = ""
+            else:
+                cur += ch
+            i += 1
+        args.append(cur.strip())
+        seen[m.group(1).lower()] = args
+    for name, n in want.items():
+        material, spec, refl, ref, *p = seen[name]
+        assert len(p) == n, (name, p)
+        assert ref == "-1"
+        overrides = name in ("plane", "disk", "xyrect", "xzrect", "yzrect", "box")
+        assert (spec, refl) != ("0", "0") if overrides else (spec, refl) == ("0", "0"), (name, spec, refl)
+    assert seen["mesh"][3] == "idx" and seen["volumegrid"][3] == "idx" and len(seen["mesh"]) == 4 and len(seen["volumegrid"]) == 4
+    # and the Python mirror passes the same counts (it is what the GPU tests flatten scenes with)
+    py = (ROOT / "yetanotherconsolegameengine_amd" / "scene.py").read_text()
+    for name, n in want.items():
+        cs_name = {"xyrect": "XYRECT", "xzrect": "XZRECT", "yzrect": "YZRECT", "cylindery": "CYLINDER_Y"}.get(name, name.upper())
+        m = re.search(r"prim\(abi\.PRIM_" + cs_name + r", mat_id\([^)]*\), \[(.*?)\]", py)
+        assert m, name
+        cnt = sum(3 if tok.strip().startswith("*") else 1 for tok in m.group(1).split(","))
+        assert cnt == n, (name, m.group(1))
