@@ -246,11 +246,13 @@ __global__ __launch_bounds__(256) void k_wf_extend(const SceneDev S, const Trace
 // so a short ray never waits for a long one.  Which lane traces a ray never changes the ray's result.
 // Used for the continuation (bounce / mirror) rays.  The shadow rays of the light loop were tried the same way
 // (one ray per (light record, light), contributions applied in light order afterwards): no gain - they all aim
-// at the same light, their lengths are alike, and k_wf_lights already keeps 53 % of its lanes busy.
+// at the same light, their lengths are alike, and k_wf_lights already keeps 53 % of its lanes busy.  Round 5 tried again with the
+// cheaper walk: a persistent light stage, a lane per VERTEX walking its light loop in these rounds (bit-exact on every voxel test):
+// 4.10 -> 4.095 ms at noon, and a LOSS where few or no vertices have a light to ask (dark 3.16 -> 4.05: 8 192 wavefronts draw 32 400
+// empty segments from one counter; night 3.70 -> 4.17).  Not kept (profiles/r05/j_voxel_stage_forms.txt).
 #define YCGE_ROUND_TREE_STEPS 6
 #define YCGE_ROUND_CELL_STEPS 10
-#define YCGE_LIGHTS_P_DEFAULT 0        // 1: k_wf_lights_p serves the light loop wherever the persistent extend stage runs and occlusion is first-hit (measured: DESIGN section 8)
-#define YCGE_ROUND_PHASE_MODE 0        // 0: both phases every round; 1: only the phase most lanes wait for; 2: skip a phase with < 16 takers while the other has >= 16 (measured: see DESIGN section 8)
+#define YCGE_ROUND_PHASE_MODE 1        // 0: both phases every round; 1: only the phase most lanes wait for; 2: skip a phase with < 16 takers while the other has >= 16.  Config 5 at full size, mode 0 / 1 / 2: lit 4.10 / 3.99 / 4.04 ms, dark 3.16 / 3.04 / 3.09, night 3.70 / 3.56 / 3.65 (profiles/r05/j_voxel_stage_forms.txt)
 #define YCGE_ROUND_REFILL_MIN 16       // lanes that wait for a ray before rays are handed out (or all of them): lit config 5 4.06 -> 4.02 ms, its moving-camera leg 2.22 -> 2.06 (profiles/r04/h_voxel_walk_tree.txt)
 #ifndef YCGE_TRACEP_WAVES
 #define YCGE_TRACEP_WAVES 5          // persistent extend stage: 5 wavefronts per SIMD (102 registers, no scratch; round 3: as fast as 6 with its 10 spilled registers - 7.04 against 7.00 ms - and 0.46 GB less written per 4K frame) and 32 persistent wavefronts per CU
@@ -640,149 +642,6 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu((HAS_GRID &
                 light++;
                 in_query = false;
             }
-        }
-    }
-    flush_work<COUNT>(w, O.counters);
-    YCGE_VOXSTAT_FLUSH(S, w);
-}
-
-// ---------------------------------------------------------------------------------- k_wf_lights_p (round 5)
-// The light loop for scenes whose shadow queries are ANSWERED BY THE FIRST HIT (a VolumeScene's binary Occluded, RaytraceRenderer.cs:761-765;
-// or no material with Transparency > 0: `tr <= 0` for whatever is hit, :779-781), timed kernels only, as a PERSISTENT stage like k_wf_trace_p:
-// wavefronts draw tile segments of light records from one counter and hand the records to their idle lanes; a lane walks the light loop of
-// ITS vertex - head (which light asks next), query in bounded rounds of tree steps and cell steps, contribution in light order - and takes
-// the next vertex when it is through.  k_wf_lights gives every vertex a lane of its tile's workgroup for the life of the workgroup: a
-// wavefront whose 64 shadow rays differ in length (towards a low sun: one chunk or a dozen) waits for its longest.  Which lane walks a
-// vertex never changes what is added to its pixel, nor the order of the additions (one vertex, one lane, lights in order).
-template <bool HAS_GRID>
-__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(HAS_GRID ? YCGE_TRACEP_WAVES : 1, 8))) void k_wf_lights_p(const SceneDev S, const FrameParams P, const TraceOut O, const WfBuffers B,
-                                                   uint32_t *__restrict__ chunk_ctr, int round_tree_steps, int round_cell_steps, int refill_min, int phase_mode)
-{
-    constexpr bool COUNT = false;
-    Work w = {0, 0, 0, 0, 0, 0, 0};
-    StackT<64> st;
-    st.init(O.stack_spill, O.stack_lanes);
-    const int lane = (int)threadIdx.x;
-    const uint32_t *counts = B.n_lq;
-    bool have = false, in_query = false, more = false, in_dda = false;
-    uint32_t src = 0, cur = YCGE_REF_NONE_VALUE;
-    int light = 0;
-    F3 o = f3(0, 0, 0), d = f3(0, 0, 1), inv = f3(0, 0, 0);
-    bool sx = false, sy = false, sz = false, fast = false;
-    float tmin = 0.0f, closest = YCGE_FLT_MAX;
-    int hit_prim = -1, hit_sub = 0, mesh_prim = -1;
-    DdaState D;
-    D.ix = D.iy = D.iz = 0; D.t = D.t_max_x = D.t_max_y = D.t_max_z = D.t_delta_x = D.t_delta_y = D.t_delta_z = D.t_exit = D.tmax = 0.0f;
-    D.step_x = D.step_y = D.step_z = D.last_axis = D.use_mask = 0; D.nx = D.ny = D.nz = D.nbx = D.nby = 1; D.cell_offset = D.mask_lo = D.mask_hi = 0; D.prim = -1;
-    uint32_t tile = 0, next_rec = 0, end_rec = 0;          // wave-uniform: the segment being handed out
-    bool exhausted = false;
-    for (;;) {
-        // ---- hand new vertices to the idle lanes
-        unsigned long long idle = __ballot(!have);
-        if ((int)__popcll(idle) < refill_min && idle != __ballot(true)) idle = 0ull;
-        while (idle && !exhausted) {
-            if (next_rec == end_rec) {
-                uint32_t c = 0;
-                if (lane == 0) c = atomicAdd(chunk_ctr, 1u);
-                c = (uint32_t)__builtin_amdgcn_readfirstlane((int)c);
-                if (c >= B.tiles) { exhausted = true; break; }
-                tile = B.tile_order ? B.tile_order[c] : c;
-                next_rec = 0;
-                end_rec = counts[tile];
-                continue;
-            }
-            const uint32_t avail = end_rec - next_rec, n_idle = (uint32_t)__popcll(idle);
-            const uint32_t take = avail < n_idle ? avail : n_idle;
-            const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(idle >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)idle, 0u));
-            if (!have && rank < take) { src = tile * 256u + next_rec + rank; light = 0; in_query = false; more = false; in_dda = false; have = true; }
-            next_rec += take;
-            idle = __ballot(!have);
-        }
-        if (!__any(have)) break;
-        // ---- light loop head (RaytraceRenderer.cs:578-591) for the lanes between two queries: the next light that asks, or the vertex is through
-        if (have && !in_query) {
-            const float4 *rec = (const float4 *)(B.lq + src);
-            const float4 a = rec[0], b = rec[1];
-            const F3 sh_p = f3(a.x, a.y, a.z), sh_n = f3(a.w, b.x, b.y);
-            for (; light < S.n_lights; light++) {
-                const GLight &L = S.lights[light];
-                F3 to_l = f3(L.pos) - sh_p;
-                const float dist2 = dot(to_l, to_l);
-                float dist = cs_sqrt(dist2);
-                const F3 ldir = vdiv(to_l, dist);
-                const float n_dot_l = cs_max(0.0f, dot(sh_n, ldir));
-                if (n_dot_l <= 0.0f) continue;
-                if (light_is_dark<COUNT>(L, dist2, w)) continue;
-                o = sh_p + sh_n * P.eps;
-                d = normalized(ldir);                       // new Ray(..., ldir)
-                tmin = S.is_volume_scene ? 0.001f : 0.0f + P.eps;
-                // traverse(): the query's entry into the scene
-                closest = dist - P.eps; hit_prim = -1; hit_sub = 0; mesh_prim = -1;
-                st.reset();
-                cur = YCGE_REF_NONE_VALUE;
-                if (S.scene_root_ref != YCGE_REF_NONE_VALUE) {
-                    inv = f3(1.0f / d.x, 1.0f / d.y, 1.0f / d.z);
-                    sx = inv.x < 0.0f; sy = inv.y < 0.0f; sz = inv.z < 0.0f;
-                    float tn, tf;
-                    if (box_scene(S.scene_root_min[0], S.scene_root_min[1], S.scene_root_min[2], S.scene_root_max[0], S.scene_root_max[1],
-                                  S.scene_root_max[2], o, inv, tmin, closest, tn, tf))
-                        cur = scene_entry<COUNT, HAS_GRID>(S, tf);
-                    fast = YCGE_WALK_PHASE && YCGE_REF_KIND(cur) == REF_WALK_NODE && cs_abs(inv.x) < YCGE_INF && cs_abs(inv.y) < YCGE_INF && cs_abs(inv.z) < YCGE_INF;
-                }
-                more = cur != YCGE_REF_NONE_VALUE;
-                in_dda = false;
-                in_query = true;
-                break;
-            }
-            if (!in_query) have = false;            // every light has been asked: the vertex is through
-        }
-        // ---- one round of the queries in flight (k_wf_trace_p's round; an occlusion query ends at its first hit)
-        bool run_tree = true, run_cell = true;
-        if (phase_mode) {
-            const int n_tree = (int)__popcll(__ballot(in_query && more && !in_dda)), n_dda = (int)__popcll(__ballot(in_dda));
-            if (phase_mode == 1) { if (n_dda > n_tree) run_tree = false; else if (n_dda > 0 && n_tree > 0) run_cell = false; }
-            else { if (n_tree < 16 && n_dda >= 16) run_tree = false; else if (n_dda < 16 && n_tree >= 16) run_cell = false; }
-        }
-        if (run_tree && in_query && more && !in_dda) {
-            int parked_grid = -1, parked_prim = -1;
-            float parked_tend = YCGE_INF;
-            int r = TREE_OTHER;
-            if (HAS_GRID && fast) r = walk_phase(S, cur, st, o, inv, tmin, closest, parked_grid, parked_prim, w, round_tree_steps);
-            if (r == TREE_OTHER)
-                r = tree_phase<COUNT, HAS_GRID>(S, cur, mesh_prim, st, o, d, inv, sx, sy, sz, tmin, closest, hit_prim, hit_sub, parked_grid,
-                                                parked_prim, parked_tend, w, round_tree_steps, true);
-            if (r == TREE_DONE) more = false;
-            if (HAS_GRID && r == TREE_AT_GRID) in_dda = dda_begin<COUNT>(S, parked_grid, parked_prim, o, d, inv, tmin, fminf(closest, parked_tend), D, w);
-        }
-        if (HAS_GRID && run_cell && in_dda) {
-            bool in = true;
-#pragma unroll 1
-            for (int k2 = 0; k2 < round_cell_steps && in; k2++) in = dda_step<COUNT>(S, D, tmin, closest, hit_prim, hit_sub, w);
-            in_dda = in;
-        }
-        if (in_query && hit_prim >= 0) { st.reset(); cur = YCGE_REF_NONE_VALUE; more = false; in_dda = false; }      // answered: the first hit (tree_phase's first line; walk())
-        // ---- a query that has its answer: the contribution (:592-602), then the next light
-        if (in_query && !more && !in_dda) {
-            if (!(hit_prim >= 0)) {             // transmittance 1 (binary occlusion / no transparent material): (1, 1, 1) > 1e-6
-                const float4 *rec = (const float4 *)(B.lq + src);
-                const float4 a = rec[0], b = rec[1], c = rec[2], e = rec[3];
-                const F3 sh_p = f3(a.x, a.y, a.z), sh_n = f3(a.w, b.x, b.y), sh_alb = f3(b.z, b.w, c.x), sh_wo = f3(c.y, c.z, c.w), beta = f3(e.x, e.y, e.z);
-                const GLight &L = S.lights[light];
-                F3 to_l = f3(L.pos) - sh_p;
-                const float dist2 = dot(to_l, to_l);
-                float dist = cs_sqrt(dist2);
-                const F3 ldir = vdiv(to_l, dist);
-                const float n_dot_l = cs_max(0.0f, dot(sh_n, ldir));
-                float atten = L.intensity / dist2;
-                F3 f_diffuse = oren_nayar(sh_alb, sh_n, sh_wo, ldir, P.on_a, P.on_b);
-                F3 Li = f3(L.color) * atten;
-                F3 contrib = (f_diffuse * n_dot_l) * Li;
-                contrib = f3(contrib.x * 1.0f, contrib.y * 1.0f, contrib.z * 1.0f);
-                float *rp = O.current_hdr + 3 * (size_t)__float_as_uint(e.w);
-                rp[0] = rp[0] + beta.x * contrib.x; rp[1] = rp[1] + beta.y * contrib.y; rp[2] = rp[2] + beta.z * contrib.z;
-            }
-            light++;
-            in_query = false;
         }
     }
     flush_work<COUNT>(w, O.counters);
@@ -1833,8 +1692,6 @@ int ycge_launch_wavefront(const ycge::SceneDev *S, const ycge::FrameParams *P, c
         hipLaunchKernelGGL((k_wf_primary<decltype(C)::value, decltype(G)::value, decltype(F)::value>), tiles, block, 0, stream, *S, *P, *O, B);
     });
     bool forked = false;
-    static int lights_persistent = -1;          // YCGE_LIGHTS_P=0/1: the persistent light stage (default: see YCGE_LIGHTS_P_DEFAULT)
-    if (lights_persistent < 0) { const char *e = getenv("YCGE_LIGHTS_P"); lights_persistent = e ? (atoi(e) != 0) : YCGE_LIGHTS_P_DEFAULT; }
     for (int r = 0; r < rounds; r++) {
         const bool persistent = !flat && persistent_waves > 0;
         if (r > 0 && persistent) {
@@ -1853,14 +1710,6 @@ int ycge_launch_wavefront(const ycge::SceneDev *S, const ycge::FrameParams *P, c
         });
         const bool fork = side && ev_fork && ev_join && O_side && r + 1 < rounds;
         if (fork) { (void)hipEventRecord(ev_fork, stream); (void)hipStreamWaitEvent(side, ev_fork, 0); }
-        // the persistent light stage (k_wf_lights_p): timed kernels, first-hit occlusion, frames big enough for the persistent extend stage
-        const bool lights_p = persistent && !count && lights_persistent && (S->is_volume_scene || !S->any_transparent);
-        if (lights_p) {
-            hipStream_t ls = fork ? side : stream;
-            (void)hipMemsetAsync(B.chunk_ctr + 1, 0, sizeof(uint32_t), ls);
-            if (has_grid) hipLaunchKernelGGL((k_wf_lights_p<true>), dim3((unsigned)persistent_waves), dim3(64), 0, ls, *S, *P, fork ? *O_side : *O, B, B.chunk_ctr + 1, round_steps[0], round_steps[1], round_steps[2], round_steps[3]);
-            else hipLaunchKernelGGL((k_wf_lights_p<false>), dim3((unsigned)persistent_waves), dim3(64), 0, ls, *S, *P, fork ? *O_side : *O, B, B.chunk_ctr + 1, round_steps[0], round_steps[1], round_steps[2], round_steps[3]);
-        } else
         sel3(count != 0, has_grid != 0, flat != 0, [&](auto C, auto G, auto F) {
             hipLaunchKernelGGL((k_wf_lights<decltype(C)::value, decltype(G)::value, decltype(F)::value>), tiles, block, 0, fork ? side : stream, *S, *P, fork ? *O_side : *O, B, r);
         });
