@@ -251,7 +251,7 @@ __global__ __launch_bounds__(256) void k_wf_extend(const SceneDev S, const Trace
 // 4.10 -> 4.095 ms at noon, and a LOSS where few or no vertices have a light to ask (dark 3.16 -> 4.05: 8 192 wavefronts draw 32 400
 // empty segments from one counter; night 3.70 -> 4.17).  Not kept (profiles/r05/j_voxel_stage_forms.txt).
 #define YCGE_ROUND_TREE_STEPS 6
-#define YCGE_ROUND_CELL_STEPS 10
+#define YCGE_ROUND_CELL_STEPS 20       // (round 5, with the phase gating: 10 / 16 / 20 / 24 / 32 cell steps a round: lit config 5 3.97 / 3.91 / 3.84 / 3.84 / 3.87 ms, dark 3.01 / 2.95 / 2.88 / 2.89 / 2.93)
 #define YCGE_ROUND_PHASE_MODE 1        // 0: both phases every round; 1: only the phase most lanes wait for; 2: skip a phase with < 16 takers while the other has >= 16.  Config 5 at full size, mode 0 / 1 / 2: lit 4.10 / 3.99 / 4.04 ms, dark 3.16 / 3.04 / 3.09, night 3.70 / 3.56 / 3.65 (profiles/r05/j_voxel_stage_forms.txt)
 #define YCGE_ROUND_REFILL_MIN 16       // lanes that wait for a ray before rays are handed out (or all of them): lit config 5 4.06 -> 4.02 ms, its moving-camera leg 2.22 -> 2.06 (profiles/r04/h_voxel_walk_tree.txt)
 #ifndef YCGE_TRACEP_WAVES
