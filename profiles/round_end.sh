@@ -4,9 +4,10 @@
 # (every profiler run under its own timeout), rank emulations (slab form, tile-resident ring), in-flight A/B, post stage exact / waived,
 # per-wavefront profile, cooperative-walk clocks.  Everything lands in gpurun_out/.
 REPO=${GRAFT_REPO_ROOT:-/root/repo}; cd $REPO; mkdir -p gpurun_out
-TAG=${1:-r05}; RND=${2:-r05}
+TAG=${1:-r05}; RND=${2:-r05}; PART=${3:-ab}          # part a: suite, profiles, benches; part b: emulations, A/Bs, forms (gpurun caps a call at one hour)
+if [[ $PART == *a* ]]; then
 timeout 2400 python -m pytest tests -m gpu -q > gpurun_out/pytest_gpu_$TAG.log 2>&1; echo "pytest rc=$?"; tail -3 gpurun_out/pytest_gpu_$TAG.log
-# the profiles FIRST: bench.py prints the counter-derived roofline fields only from a summary of the running build (profiles/r04/pmc_config*.json, source_hash)
+# the profiles FIRST: bench.py prints the counter-derived roofline fields only from a summary of the running build (profiles/$RND/pmc_config*.json, source_hash)
 bash profiles/run_profiles.sh ${TAG}_c4 > gpurun_out/prof_${TAG}_c4.log 2>&1; echo "profiles c4 rc=$?"; head -12 gpurun_out/prof_${TAG}_c4/summary.txt
 bash profiles/run_profiles.sh ${TAG}_c5 --config 5 > gpurun_out/prof_${TAG}_c5.log 2>&1; echo "profiles c5 rc=$?"; head -12 gpurun_out/prof_${TAG}_c5/summary.txt
 bash profiles/run_profiles.sh ${TAG}_c5lit --config 5 --t01 0.5 > gpurun_out/prof_${TAG}_c5lit.log 2>&1; echo "profiles c5 lit rc=$?"; head -12 gpurun_out/prof_${TAG}_c5lit/summary.txt
@@ -25,6 +26,8 @@ except Exception as e:
     print("$f failed", e)
 PY
 done
+fi
+if [[ $PART == *b* ]]; then
 for cfg in 4 3; do echo "== rank emulation config $cfg"; timeout 600 python profiles/rank_times.py $cfg 2>&1 | grep -E "world"; done
 echo "== a rank's period: slab form (two trace streams), tile-resident ring (loop driven from C)"
 for w in 8 4 2; do timeout 300 python profiles/rank_flight.py 4 $w two 2>&1 | tail -1; done
@@ -46,3 +49,4 @@ if [ -f yetanotherconsolegameengine_amd/lib/var_voxstat.so ]; then YCGE_LIB=$REP
 if [ -f yetanotherconsolegameengine_amd/lib/var_coopstat.so ]; then YCGE_LIB=$REPO/yetanotherconsolegameengine_amd/lib/var_coopstat.so timeout 200 python profiles/coop_stats.py 4 2>&1 | grep -v amdgpu.ids; fi
 if [ -f yetanotherconsolegameengine_amd/lib/var_batchstat.so ]; then YCGE_LIB=$REPO/yetanotherconsolegameengine_amd/lib/var_batchstat.so timeout 300 python profiles/batch_stats.py 4 2>&1 | grep -v amdgpu.ids; fi
 echo "== bench.py's one-process-per-GPU forms on one rank (torchrun + RCCL)"; bash profiles/forms.sh 2>&1 | grep -v "^\[" | cut -c1-330
+fi
