@@ -63,12 +63,16 @@ def is_stale(lib: Path = LIB, flags=()) -> bool:
 
 
 class build_lock:
-    """One builder at a time per checkout (ranks of a launcher, pytest workers): an exclusive flock on lib/.build.lock."""
+    """One builder at a time per OUTPUT FILE of a checkout (ranks of a launcher, pytest workers; different libraries build side by side):
+    an exclusive flock on lib/.build.<name>.lock."""
+
+    def __init__(self, out: Path = LIB):
+        self.name = out.name
 
     def __enter__(self):
         import fcntl
         LIB_DIR.mkdir(exist_ok=True)
-        self.f = open(LIB_DIR / ".build.lock", "w")
+        self.f = open(LIB_DIR / f".build.{self.name}.lock", "w")
         fcntl.flock(self.f, fcntl.LOCK_EX)
         return self
 
@@ -98,7 +102,7 @@ def compile_to(out: Path, flags=(), verbose: bool = False) -> None:
 def build_library(force: bool = False, verbose: bool = False, extra_flags=()) -> Path:
     if not force and not is_stale(LIB, extra_flags):
         return LIB
-    with build_lock():
+    with build_lock(LIB):
         if force or is_stale(LIB, extra_flags):          # (someone else may have built it while we waited for the lock)
             compile_to(LIB, extra_flags, verbose)
     return LIB
@@ -129,10 +133,18 @@ def build_variant(name: str, flags=None, force: bool = False) -> Path:
     out = variant_path(name)
     if not force and not is_stale(out, flags):
         return out
-    with build_lock():
+    with build_lock(out):
         if force or is_stale(out, flags):
             compile_to(out, flags)
     return out
+
+
+def build_all(verbose: bool = False):
+    """The product and every test variant, side by side (one hipcc each: ~1 minute of wall time instead of one per library)."""
+    from concurrent.futures import ThreadPoolExecutor
+    with ThreadPoolExecutor(max_workers=4) as ex:
+        futs = [ex.submit(build_library, False, verbose)] + [ex.submit(build_variant, v) for v in VARIANTS]
+        return [f.result() for f in futs]
 
 
 if __name__ == "__main__":
