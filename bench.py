@@ -214,6 +214,33 @@ def ranks_last_words(err, n=1200):
     return err[:m.start()][-n:] if m and err[:m.start()].strip() else err[-n:]
 
 
+def descendants(pid):
+    """pids of every process below `pid` (children, their children, ...), from /proc: what a job this process started consists of"""
+    kids = {}
+    for d in os.listdir("/proc"):
+        if d.isdigit():
+            try:
+                with open(f"/proc/{d}/stat") as f:
+                    st = f.read()
+                kids.setdefault(int(st[st.rindex(")") + 2:].split()[1]), []).append(int(d))
+            except (OSError, ValueError, IndexError):
+                pass
+    out, todo = [], [pid]
+    while todo:
+        for k in kids.get(todo.pop(), []):
+            out.append(k); todo.append(k)
+    return out
+
+
+def alive(pid):
+    try:
+        with open(f"/proc/{pid}/stat") as f:
+            st = f.read()
+        return st[st.rindex(")") + 2:].split()[0] != "Z"
+    except (OSError, ValueError, IndexError):
+        return False
+
+
 def child_command(form_name, n, port, script, python=None):
     python = python or sys.executable
     if form_name in LAUNCHER_FORMS:
@@ -223,9 +250,11 @@ def child_command(form_name, n, port, script, python=None):
 
 
 def launch_ranks(n, argv, chain=FORM_CHAIN, extra=BATCHED_LEG, script=None, timeout=1500, env=None, log=sys.stderr):
-    """Runs the forms of `chain` one after the other, each as FRESH child processes, until one prints the bench line; returns that line
-    (a dict) with `forms_tried` added, or None.  `argv` = this invocation's own arguments (forwarded; --form / --batch are replaced).
-    After a headline from the tile-resident form, `extra` runs as one more job and its figures are attached as `batched`."""
+    """Runs the forms of `chain` one after the other, each as FRESH child processes, until one prints the bench line; returns (that line
+    as a dict with `forms_tried` added - or None -, the list of attempts).  `argv` = this invocation's own arguments (forwarded; --form /
+    --batch are replaced).  After a headline from the tile-resident form, `extra` runs as one more job and its figures are attached as
+    `batched`.  A job that outlives `timeout` is ended as a whole: the launcher AND its ranks are one process group of their own."""
+    import signal
     import subprocess
     script = script or Path(__file__).resolve()
     base = strip_flag(list(argv), ("--form", "--batch"))
@@ -238,11 +267,31 @@ def launch_ranks(n, argv, chain=FORM_CHAIN, extra=BATCHED_LEG, script=None, time
     def run(name, form_args):
         cmd = child_command(name, n, free_port(), script) + base + form_args
         t0 = time.perf_counter()
+        proc = subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, env=env, start_new_session=True)
         try:
-            r = subprocess.run(cmd, capture_output=True, text=True, timeout=timeout, env=env, start_new_session=True)
-            rc, out, err = r.returncode, r.stdout, r.stderr
-        except subprocess.TimeoutExpired as e:
-            rc, out, err = -9, (e.stdout or b"").decode(errors="replace") if isinstance(e.stdout, bytes) else (e.stdout or ""), f"timeout after {timeout} s"
+            out, err = proc.communicate(timeout=timeout)
+            rc = proc.returncode
+        except subprocess.TimeoutExpired:
+            # end the job this call started - the launcher and every process below it (torch.distributed.run gives its ranks sessions of their
+            # own, so the launcher's process group alone would leave them running, holding their GPUs): SIGTERM to the launcher first (it takes
+            # its ranks down itself), then SIGKILL to whatever of ITS descendants is left
+            below = descendants(proc.pid)
+            proc.send_signal(signal.SIGTERM)
+            t_end = time.perf_counter() + 15.0
+            while time.perf_counter() < t_end and (proc.poll() is None or any(alive(q) for q in below)):
+                time.sleep(0.2)
+                below = sorted(set(below) | set(descendants(proc.pid)))
+            for q in below + [proc.pid]:
+                if alive(q):
+                    try:
+                        os.kill(q, signal.SIGKILL)
+                    except ProcessLookupError:
+                        pass
+            try:
+                out, err = proc.communicate(timeout=30)
+            except subprocess.TimeoutExpired:
+                out, err = "", "bench.py: the ended job's pipes stayed open"
+            rc, err = -9, (err or "") + f"\nbench.py: job ended after {timeout} s"
         line = last_json_line(out) if rc == 0 else None
         rec = {"form": name, "rc": rc, "seconds": round(time.perf_counter() - t0, 1), "ok": line is not None}
         if line is None:

@@ -151,3 +151,38 @@ def test_build_staleness_is_by_content(tmp_path):
     assert not build.is_stale(lib, ["-DX=1"])
     build.stamp_path(lib).write_text("0123456789abcdef\n")
     assert build.is_stale(lib, ["-DX=1"])
+
+
+def test_a_job_that_hangs_is_ended_with_its_ranks(tmp_path):
+    """a form whose ranks never finish: after the timeout the whole job - launcher and ranks, one process group - is gone and the next form runs"""
+    import time
+    stub = tmp_path / "stub_bench.py"
+    stub.write_text(textwrap.dedent('''
+        import json, os, sys, time
+        a = sys.argv[1:]; form = a[a.index("--form") + 1]
+        open(os.environ["STUB_LOG"], "a").write(json.dumps({"form": form, "pid": os.getpid(), "rank": int(os.environ.get("RANK", "0"))}) + "\\n")
+        if form == "resident":
+            time.sleep(600)
+        if int(os.environ.get("RANK", "0")) == 0:
+            print(json.dumps({"metric": "stub", "value": 1.0, "config": {"form": form, "parallelism": form}}))
+    '''))
+    log = tmp_path / "stub.log"
+    env = dict(os.environ, STUB_LOG=str(log))
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK"):
+        env.pop(k, None)
+    t0 = time.time()
+    line, tried = bench.launch_ranks(2, ["--gpus", "2"], script=stub, env=env, timeout=20, log=open(os.devnull, "w"), extra=None)
+    assert time.time() - t0 < 120
+    assert [(t["form"], t["ok"]) for t in tried] == [("resident", False), ("rccl", True)] and tried[0]["rc"] == -9 and line["config"]["form"] == "rccl"
+    hung = [json.loads(x)["pid"] for x in log.read_text().splitlines() if json.loads(x)["form"] == "resident"]
+    assert len(hung) == 2
+    time.sleep(1.0)
+    for pid in hung:           # the ranks of the ended job are gone (no stray process keeps a GPU)
+        gone = False
+        try:
+            os.kill(pid, 0)
+            with open(f"/proc/{pid}/stat") as f:
+                gone = f.read().split()[2] == "Z"
+        except (ProcessLookupError, FileNotFoundError):
+            gone = True
+        assert gone, pid
