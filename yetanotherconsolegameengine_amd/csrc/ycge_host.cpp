@@ -1,459 +1,8 @@
-// ycge_host.cpp — host side of the C-ABI in include/ycge.h: context, scene flattening
-// and upload, frame orchestration (TryFlipAndBlit steps 1-5, 9), tile partition for
-// multi-GPU, test read-backs.  All device work is in ycge_kernels.hip; there is no CPU
-// implementation of any per-pixel stage here.
-#include <hip/hip_runtime.h>
-#include <unistd.h>
+// ycge_host.cpp - host side of the C-ABI in include/ycge.h: context, scene flattening and upload, frame orchestration (TryFlipAndBlit
+// steps 1-9), frames in flight, the slab form of the tiled frame.  (The tile-resident multi-GPU form and the read-backs: ycge_resident.cpp.)
+#include "ycge_ctx.h"
 
-#include <array>
-#include <chrono>
-#include <cmath>
-#include <cstdarg>
-#include <cstdio>
-#include <cstdlib>
-#include <cstring>
-#include <deque>
-#include <condition_variable>
-#include <mutex>
-#include <thread>
-#include <string>
-#include <vector>
-#include <functional>
-
-#include "../../include/ycge.h"
-#include "ycge_accel.h"
-#include "ycge_device.h"
-#include "ycge_math.h"
-
-extern "C" {
-size_t ycge_wf_sizes(int which);
-int ycge_launch_trace(const ycge::SceneDev *S, const ycge::FrameParams *P, const ycge::TraceOut *O, int count, int flat, int refill_steps,
-                      hipStream_t stream);
-int ycge_launch_wavefront(const ycge::SceneDev *S, const ycge::FrameParams *P, const ycge::TraceOut *O, void *const bufs[7], int rounds,
-                          int has_grid, int flat, int count, int persistent_waves, hipStream_t stream, hipStream_t side, hipEvent_t ev_fork, hipEvent_t ev_join,
-                          const ycge::TraceOut *O_side);
-int ycge_launch_trace_batch(const ycge::SceneDev *S, const ycge::FrameParams *P, const ycge::TraceOut *O, int n, int count, int flat, hipStream_t stream);
-int ycge_launch_scene_walk(const void *nodes, int n_inner, const uint32_t *leaf_prims, const void *prims, void *walk, hipStream_t stream);
-int ycge_launch_order_blocks(uint32_t *cost, uint32_t n, uint32_t policy, uint32_t split_top, uint32_t fan_class, uint32_t fan_cap, uint32_t next_slot, uint32_t skip_mask, uint32_t *order_ws,
-                             uint32_t *order, hipStream_t stream, int small_groups = 0, uint32_t n_frames = 0, uint32_t *snap = nullptr);
-int ycge_launch_taa_tiles(const ycge::TaaParams *T, const ycge::FrameParams *P, const float *current, const float *normal, const float *depth, const uint8_t *sky,
-                          float *hist, float *prev_normal, float *prev_depth, uint8_t *prev_sky, hipStream_t stream);
-int ycge_launch_halo(int scatter, float *hdr, uint8_t *sky, const uint32_t *px, uint32_t n, void *records, hipStream_t stream);
-int ycge_launch_pack_history(const ycge::FrameParams *P, const float *hist, float *slab, hipStream_t stream);
-int ycge_launch_unpack_history(const float *all_slabs, size_t slab_floats_per_rank, int hiW, int hiH, int tiles_x, int n_tiles, int world_size, float *hist, hipStream_t stream);
-int ycge_launch_trace_fan(const ycge::SceneDev *S, const ycge::FrameParams *P, const ycge::TraceOut *O, int count, int flat, uint32_t fan_cap,
-                          hipStream_t stream);
-int ycge_launch_taa(const ycge::TaaParams *T, const float *current, const float *normal, const float *depth, const uint8_t *sky,
-                    float *hist, float *prev_normal, float *prev_depth, uint8_t *prev_sky, hipStream_t stream, int small_groups = 0);
-size_t ycge_post_state_bytes(void);
-int ycge_atrous_persist_resident(int groups_per_pass, int split, int level_handover, int profile);
-void ycge_atrous_duo_pad_lds(int bytes);
-int ycge_launch_unit_normals(const float *normal, float *unit, size_t n, hipStream_t stream);
-int ycge_launch_atrous(int w, int h, int step, const float phi[4], const float *cur, float *dst, const float *albedo, const float *unit_n,
-                       const float *depth, const uint8_t *sky, hipStream_t stream);
-int ycge_launch_atrous_static(int w, int h, int step, const float phi[4], const float *albedo, const float *unit_n, const float *depth,
-                              const uint8_t *sky, float *statw, hipStream_t stream);
-int ycge_launch_atrous_inplace(int w, int h, int step, const float phi[4], float *buf, const float *albedo, const float *unit_n,
-                               const float *depth, const uint8_t *sky, float *statw, const uint32_t *d_pixels, const uint32_t *d_offsets,
-                               int n_levels, int n_bands, int K, int groups_per_pass, int rows_per_band, unsigned window_width, hipStream_t stream);
-int ycge_launch_atrous_persist(int w, int h, int step, const float phi[4], float *buf, const uint8_t *sky, float *statw, const uint32_t *d_pixels,
-                               const uint32_t *d_offsets, const uint32_t *d_pass_level, const int32_t *d_band_desc, int n_levels, int n_bands, int K, int groups_per_pass, int rows_per_band, unsigned window_width,
-                               uint32_t *progress, uint32_t epoch, int xcd_local, int level_handover, int profile, uint32_t ticket_base, hipStream_t stream);
-size_t ycge_exposure_scratch_bytes(int w, int h, int step);
-size_t ycge_bvh_build_scratch_bytes(int n);
-int ycge_launch_scene_bvh_build(const float *items, int n, void *scratch, void *ref_out, void *gnodes_out, uint32_t *leaf_out, void *result,
-                                int active_waves, hipStream_t stream);
-int ycge_launch_exposure(const float *hdr, const uint8_t *sky, int w, int h, int step, float *terms, void *state, const float consts[5],
-                         void *scratch, int serial, hipStream_t stream);
-int ycge_launch_tonemap(const float *hdr, int hiW, int fbW, int fbH, int ss, float gamma, float saturation, float vibrance, const void *state,
-                        float *out, hipStream_t stream);
-int ycge_launch_pack_slab(const ycge::FrameParams *P, const float *hdr, const float *albedo, const float *normal, const float *depth,
-                          const uint8_t *sky, float *slab, int slab_floats, hipStream_t stream);
-int ycge_launch_push_tiles(const ycge::FrameParams *P, const ycge::PushPlanes *planes, hipStream_t stream);
-int ycge_launch_unpermute(const float *all_slabs, size_t slab_floats_per_rank, int hiW, int hiH, int tiles_x, int n_tiles, int world_size,
-                          int slab_floats, float *hdr, float *albedo, float *normal, float *depth, uint8_t *sky, hipStream_t stream);
-}
-
-using namespace ycge;
-
-namespace {
-
-std::string g_create_error;
-
-template <class T> struct DevBuf {
-    T *p = nullptr;
-    size_t n = 0, cap = 0;          // elements in use / elements allocated
-    void release() { if (p) { (void)hipFree(p); p = nullptr; } n = cap = 0; }
-    hipError_t alloc(size_t count)
-    {
-        release();
-        if (count == 0) return hipSuccess;
-        const hipError_t e = hipMalloc((void **)&p, count * sizeof(T) + 64);     // records are read with whole 64- / 72-byte fetches: room for the over-read past the last record
-        if (e != hipSuccess) { p = nullptr; return e; }
-        n = cap = count;
-        return hipSuccess;
-    }
-    // room for `count` elements, contents undefined; the allocation is kept when it is large enough
-    hipError_t reserve(size_t count)
-    {
-        if (count > cap || cap == 0) { const hipError_t e = alloc(count > 0 ? count : 1); if (e != hipSuccess) return e; }
-        n = count;
-        return hipSuccess;
-    }
-    // per-frame callers (lights, moved objects) reuse the allocation when the new contents fit
-    hipError_t upload(const std::vector<T> &v)
-    {
-        if (v.size() > cap || (v.empty() && cap == 0)) {
-            const hipError_t e = alloc(v.size());
-            if (e != hipSuccess) return e;
-        }
-        n = v.size();
-        if (v.empty()) return hipSuccess;
-        return hipMemcpy(p, v.data(), v.size() * sizeof(T), hipMemcpyHostToDevice);
-    }
-};
-
-// Experiment knobs (none changes a pixel): read ONCE, when the context is created.
-struct Knobs {
-    int path_policy = 0;             // YCGE_PATH: 0 auto, 1 wavefront, 2 single launch
-    bool xcd_strips = false, generic_walk = false, no_lpt = false, no_refill = false;
-    int wave_prof_stage = -1;        // YCGE_WAVE_PROF: -1 off, 0 primary, 1 extend, 2 mega
-    int refill_steps = YCGE_REFILL_STEPS_DEFAULT;
-    bool split_set = false; uint32_t split_policy = 0;
-    int split_top_lg = 2;                        // YCGE_SPLIT_TOP_LG: log2 of the parts such a block goes in (2 = 4 parts of 16 pixels)
-    int split_top = YCGE_SPLIT_TOP_DEFAULT;     // YCGE_SPLIT_TOP: this many blocks at the head of the schedule go in 4 parts of 16 pixels (0 = none)
-    int pw_per_cu = 32;
-    int post_band_rows = YCGE_POST_BAND_ROWS_DEFAULT, post_k = YCGE_POST_K_DEFAULT, post_groups = YCGE_POST_GROUPS_DEFAULT;
-    int fan_class = -1, fan_cap = -1;   // -1 = default by world size
-    int post_mode = 0;               // YCGE_POST_MODE: in-place A-trous: 0 = one persistent launch, level-granular hand-over (k_atrous_stream), 2 = a launch per level group, 3 = as 0 with bands in block order, 4 = persistent with group hand-over (k_atrous_persist)
-    bool post_no_split = false;      // YCGE_POST_NO_SPLIT: whole bands in the persistent in-place A-trous (no row-parity half-bands)
-    int post_probe_band = -1;        // YCGE_POST_PROBE_BAND: this band and the next record a per-pass timeline (profiles/post_bands.py)
-    int post_assume_resident = 0;    // YCGE_POST_ASSUME_RESIDENT (tests): take this for the runtime's answer - more bands than fit, to exercise the order-of-arrival numbering
-    bool post_dbg_free = false;      // YCGE_POST_DBG_FREE (timing experiment, WRONG pixels): no band of the persistent in-place A-trous waits for the band above
-    bool flight_small_groups = true; // YCGE_FLIGHT_SMALL_GROUPS: TAA and schedule kernels of the frames in flight in small workgroups (they find room beside a running trace)
-    int flight_priority = 1;         // YCGE_FLIGHT_PRIORITY: the second stream's priority: 1 highest, 0 normal, -1 lowest
-    bool flight_post_pair = true;    // YCGE_FLIGHT_POST_PAIR: the post stages of consecutive frames in flight side by side (second set of denoise buffers)
-    bool flight_placed_gate = true;  // YCGE_FLIGHT_PLACED_GATE: a frame in flight traces once the trace before it has placed its last workgroup (a value that kernel stores)
-    bool flight_post_gate = true;    // YCGE_FLIGHT_POST_GATE: a frame in flight traces only once the post stage before it has passed its first iteration
-    bool flight_overlap = true;      // YCGE_FLIGHT_OVERLAP: frames in flight alternate between two trace streams (two traces may overlap)
-    bool flight_no_begin = false;      // experiments on ycge_render_frame_async: second stream at normal priority; no begin-of-trace timing event
-    int post_pad_lds = 0;            // YCGE_POST_PAD_LDS (experiment): bytes of unused LDS per band workgroup of the two-set form - fewer of them on a CU
-    int post_resident_per_cu = 3;    // YCGE_POST_RESIDENT: band workgroups of the persistent in-place A-trous a CU may hold (3 fit: 576 threads, 46 KB of LDS each)
-    bool post_hash = false;          // YCGE_POST_HASH_FORM=1: the hash form of k_atrous_band even where the window fits
-    int bvh_waves = 16;              // YCGE_BVH_WAVES: wavefronts of k_scene_bvh_build that take nodes (tests: the order nodes are split in must not matter)
-    bool scene_bvh_host = false;     // YCGE_SCENE_BVH_HOST: ycge_scene_update_objects builds the scene BVH on the host, not on the device
-    int scene_bvh_device_min = YCGE_BVH_DEV_MIN_ITEMS_DEFAULT;   // YCGE_SCENE_BVH_DEVICE_MIN: fewer objects than this are built on the host (measured crossover, profiles/r02/f2_update_objects_timing.txt)
-    int res_sched_every = 0;         // YCGE_RES_SCHED_EVERY: the tile-resident ring builds a new schedule behind every n-th frame (0 = the ring's depth)
-    int bfs_rays = 0;                // YCGE_BFS=<n>: a wavefront's occlusion queries against a mesh go breadth-first from one shared work list when at most n of its lanes ask (mesh_anyhit_bfs; 0 = never, 64 = always)
-    bool no_flight_stage_overlap = false;   // YCGE_NO_FLIGHT_STAGE_OVERLAP: frames in flight of the stage pipeline (voxel worlds) one trace at a time (A/B)
-    bool no_lights_beside = false;   // YCGE_NO_LIGHTS_BESIDE: the stage pipeline strictly in sequence (A/B of the light loop beside the next round's trace)
-    bool lpt_always = false;         // YCGE_LPT_ALWAYS: the longest-first schedule also for frames whose blocks are all resident at once
-    int persist_min_tiles = -1;      // YCGE_PERSIST_MIN_TILES: frames of fewer tiles take k_wf_extend instead of the persistent extend stage (-1: a quarter of the persistent wavefronts)
-    bool no_analytic_walk = false;   // YCGE_NO_ANALYTIC_WALK: scenes of analytic objects only are walked by tree_phase's general loop (A/B of analytic_walk; same pixels)
-    bool no_walk_tree = false;       // YCGE_NO_WALK_TREE: voxel worlds are walked down the scene tree, leaves and object steps and all (A/B of SceneDev::walk_nodes)
-    bool no_coop = false;            // YCGE_NO_COOP: no treelets are built, sparse wavefronts keep the regular walk (A/B of the cooperative walk)
-    bool exposure_serial = false;    // YCGE_EXPOSURE_SERIAL: the one-lane chain instead of the chunked exact evaluation
-    void read()
-    {
-        auto geti = [](const char *n, int dflt) { const char *e = getenv(n); return e ? atoi(e) : dflt; };
-        if (const char *e = getenv("YCGE_PATH")) path_policy = e[0] == 'w' ? 1 : e[0] == 'm' ? 2 : 0;
-        xcd_strips = getenv("YCGE_XCD_STRIPS") != nullptr; generic_walk = getenv("YCGE_GENERIC_WALK") != nullptr;
-        no_analytic_walk = getenv("YCGE_NO_ANALYTIC_WALK") != nullptr;
-        if (const char *e = getenv("YCGE_PERSIST_MIN_TILES")) persist_min_tiles = atoi(e);
-        lpt_always = getenv("YCGE_LPT_ALWAYS") != nullptr;
-        no_walk_tree = getenv("YCGE_NO_WALK_TREE") != nullptr; no_lights_beside = getenv("YCGE_NO_LIGHTS_BESIDE") != nullptr; no_flight_stage_overlap = getenv("YCGE_NO_FLIGHT_STAGE_OVERLAP") != nullptr;
-        no_lpt = getenv("YCGE_NO_LPT") != nullptr; no_refill = getenv("YCGE_NO_REFILL") != nullptr;
-        if (const char *e = getenv("YCGE_WAVE_PROF")) wave_prof_stage = e[0] == 'e' ? 1 : e[0] == 'm' ? 2 : 0;
-        refill_steps = geti("YCGE_REFILL", YCGE_REFILL_STEPS_DEFAULT);
-        if (const char *e = getenv("YCGE_SPLIT")) { split_set = true; split_policy = (uint32_t)strtoul(e, nullptr, 8); }
-        split_top = geti("YCGE_SPLIT_TOP", YCGE_SPLIT_TOP_DEFAULT);
-        if (split_top < 0) split_top = 0;
-        split_top_lg = geti("YCGE_SPLIT_TOP_LG", 2);
-        if (split_top_lg < 1 || split_top_lg > 6) split_top_lg = 2;
-        pw_per_cu = geti("YCGE_PW_PER_CU", 32);
-        post_band_rows = geti("YCGE_POST_BAND_ROWS", YCGE_POST_BAND_ROWS_DEFAULT); post_k = geti("YCGE_POST_K", YCGE_POST_K_DEFAULT);
-        post_groups = geti("YCGE_POST_GROUPS", YCGE_POST_GROUPS_DEFAULT);
-        if (post_groups != 8 && post_groups != 16 && post_groups != 32) post_groups = YCGE_POST_GROUPS_DEFAULT;
-        fan_class = geti("YCGE_FAN", -1); fan_cap = geti("YCGE_FAN_CAP", -1);
-        post_mode = geti("YCGE_POST_MODE", 0);
-        post_hash = geti("YCGE_POST_HASH_FORM", 0) != 0;
-        post_no_split = getenv("YCGE_POST_NO_SPLIT") != nullptr;
-        post_probe_band = geti("YCGE_POST_PROBE_BAND", -1);
-        post_resident_per_cu = geti("YCGE_POST_RESIDENT", 3);
-        post_assume_resident = geti("YCGE_POST_ASSUME_RESIDENT", 0);
-        if (post_resident_per_cu < 1 || post_resident_per_cu > 3) post_resident_per_cu = 3;
-        post_pad_lds = geti("YCGE_POST_PAD_LDS", 0);
-        flight_overlap = geti("YCGE_FLIGHT_OVERLAP", 1) != 0;
-        flight_post_gate = geti("YCGE_FLIGHT_POST_GATE", 1) != 0;
-        flight_placed_gate = geti("YCGE_FLIGHT_PLACED_GATE", 1) != 0;
-        flight_post_pair = geti("YCGE_FLIGHT_POST_PAIR", 1) != 0;
-        flight_small_groups = geti("YCGE_FLIGHT_SMALL_GROUPS", 1) != 0;
-        flight_priority = geti("YCGE_FLIGHT_PRIORITY", 1);
-        flight_no_begin = geti("YCGE_FLIGHT_NO_BEGIN", 0) != 0;
-        post_dbg_free = geti("YCGE_POST_DBG_FREE", 0) != 0;
-        exposure_serial = getenv("YCGE_EXPOSURE_SERIAL") != nullptr;
-        no_coop = getenv("YCGE_NO_COOP") != nullptr;
-        res_sched_every = geti("YCGE_RES_SCHED_EVERY", 0);
-        bfs_rays = geti("YCGE_BFS", 0);
-        if (bfs_rays < 0 || bfs_rays > 64) bfs_rays = 0;
-        scene_bvh_host = getenv("YCGE_SCENE_BVH_HOST") != nullptr;
-        bvh_waves = geti("YCGE_BVH_WAVES", 16);
-        scene_bvh_device_min = geti("YCGE_SCENE_BVH_DEVICE_MIN", YCGE_BVH_DEV_MIN_ITEMS_DEFAULT);
-#if !YCGE_EXPERIMENTS
-        // the kernel forms of csrc/experiments/ (k_trace_refill, the group hand-over A-trous) are not in this build
-        refill_steps = 0;
-        if (post_mode == 4) post_mode = 0;
-#endif
-    }
-};
-
-// One frame's identity from snapshot to commit (TryFlipAndBlit steps 1-3, RaytraceRenderer.cs:159-176): the pose the
-// frame is traced with is the pose its reset decision and CommitCamera use.
-struct FrameState {
-    float pos[3], yaw, pitch, fov;
-    bool reset;
-    int64_t frame;
-    uint32_t fan_blocks;
-    bool scheduled = false;      // the trace ran the single-launch kernel with a longest-first schedule (cost ring in use)
-    bool single_launch = false;  // the trace ran the single-launch kernel (its last workgroup stores the placed value), scheduled or not
-};
-
-struct MeshHost {
-    BuiltTree tree;
-};
-
-} // namespace
-
-struct ycge_ctx {
-    ycge_config cfg;
-    Knobs knobs;
-    std::string err;
-    int device = 0;
-    // one process, several GPUs (config.n_devices >= 2): this context is rank 0 and owns one context per further device
-    std::vector<ycge_ctx *> peers;
-    ycge_ctx *parent = nullptr;
-    hipEvent_t pushed_ev = nullptr;            // a peer's tiles have arrived in the parent's frame buffers
-    // A peer's share of a frame is ISSUED by a thread of its own (trace launches, tile push, event): eight devices driven one after the
-    // other from the caller's thread would put 7 x ~0.1 ms of launch calls in front of the last device's first kernel - as long as
-    // the frame itself.  The worker sleeps between frames; the root posts a frame, issues its own share, then collects the peers'.
-    struct PeerWorker {
-        std::thread th;
-        std::mutex m;
-        std::condition_variable cv;
-        int job = 0;                           // 0 idle, 1 frame posted, 2 done, -1 quit
-        FrameState fs{};
-        int rc = 0;
-    } *worker = nullptr;
-    std::deque<FrameState> pending;            // frames traced by ycge_trace_tiles and not yet resolved (pipelined callers)
-    hipStream_t last_stream = nullptr;         // the stream the last tiled call ran on (scene updates wait for it too)
-    hipStream_t stream = nullptr;
-    hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
-    // k_trace runs beside k_trace_fan on a side stream, forked from and joined to the frame's stream
-    hipStream_t fan_stream = nullptr;
-    hipEvent_t fan_ev[2] = {nullptr, nullptr};
-    hipEvent_t traced_ev = nullptr, order_ev = nullptr;   // the next frame's schedule is built on the side stream, beside TAA
-    bool order_pending = false;
-    uint32_t fan_class = 0, fan_cap = 0;       // schedule classes >= fan_class are fanned, at most fan_cap blocks (0 = off)
-    uint32_t *h_n_fan = nullptr;               // pinned: how many entries the last finished schedule gave k_trace_fan (read without waiting)
-    char device_name[256] = {0};
-    int compute_units = 0;
-
-    // geometry of the trace grid
-    int fbW = 0, fbH = 0, ss = 1, hiW = 0, hiH = 0;
-    int tiles_x = 0, tiles_y = 0, n_tiles = 0, n_owned = 0, tiles_per_rank_padded = 0;
-
-    // camera (lock(camLock), RaytraceRenderer.cs:142-147)
-    std::mutex cam_lock;
-    float cam_pos[3] = {0.0f, 1.0f, 0.0f};
-    float yaw = 0.0f, pitch = 0.0f, fov_deg = 45.0f;
-
-    int64_t frame_counter = 0;                 // RaytraceRenderer.cs:24
-    // TemporalAA camera memory (TemporalAA.cs:11-15) and history validity
-    float last_cam[3] = {NAN, NAN, NAN}, last_yaw = NAN, last_pitch = NAN;
-    bool taa_valid = false;
-
-    // per-pixel buffers in HBM (row-major, x + y*hiW)
-    DevBuf<float> current_hdr, g_albedo, g_normal, g_depth, taa_hist, prev_normal, prev_depth;
-    DevBuf<uint8_t> sky, prev_sky;
-    // tiled frame: the trace writes its tiles here (same full-frame indexing), ycge_resolve_gathered writes the buffers above -
-    // so the trace of frame N+1 may run beside the all-gather and resolve of frame N (two streams, caller-ordered)
-    DevBuf<float> t_hdr, t_albedo, t_normal, t_depth;
-    DevBuf<uint8_t> t_sky;
-    // frames in flight (ycge_render_frame_async): the trace of frame N + 1 runs beside the TAA of frame N, so a frame's trace outputs
-    // alternate between the five buffers above and these (swapped before the trace: the names above are always the newest frame's)
-    DevBuf<float> alt_hdr, alt_albedo, alt_normal, alt_depth;
-    DevBuf<uint8_t> alt_sky;
-    DevBuf<float> alt2_hdr, alt2_albedo, alt2_normal, alt2_depth;      // (three sets: the trace of frame N + 1 must not wait for the TAA of frame N - 1, which finds
-    DevBuf<uint8_t> alt2_sky;                                          //  its places among frame N's wavefronts late; it waits for TAA of frame N - 2)
-    int set_id[3] = {0, 1, 2};                     // which of the three sets the names current / alt / alt2 hold
-    hipStream_t taa_stream = nullptr, stream2 = nullptr;      // stream2: the traces of odd frames in flight (two traces may overlap: the tail of one, the bulk of the next)
-    DevBuf<uint64_t> stack_spill2;                 // ... which then need a traversal-stack spill area of their own
-    uint64_t *spill_override = nullptr;            // set around trace_frame by ycge_render_frame_async
-    hipEvent_t flight_fork_ev = nullptr;
-    uint32_t *placed_flag = nullptr;               // signal memory: the number of the newest frame in flight whose trace has placed its last workgroup
-    uint32_t placed_expect = 0, placed_next = 0;   // what the next trace waits for (0: nothing) / the value the next trace stores
-    uint64_t placed_waits = 0;                     // traces queued behind a placed value so far (ycge_flight_query)
-    // frames in flight WITH the post stage (ycge_render_frame_async_sdr): post of frame N beside the traces and TAA of the frames after it
-    hipEvent_t flight_taa_ev = nullptr, post_hist_ev = nullptr, post_done_ev = nullptr, post_set_ev[3] = {nullptr, nullptr, nullptr};
-    bool post_hist_pending = false, post_busy = false, post_set_pending[3] = {false, false, false};
-    hipEvent_t tile_trace_ev[2] = {nullptr, nullptr};      // tiled frames: the trace (and slab pack) of the newest frame of each parity is done
-    bool tile_trace_used[2] = {false, false};
-    hipEvent_t set_resolved_ev[3] = {nullptr, nullptr, nullptr};
-    bool set_read[3] = {false, false, false};             // a TAA launch on taa_stream has read this set: the next trace into it waits for set_resolved_ev
-    int out_set = 0;                               // which set the names above hold
-    bool async_outstanding = false;
-    // ... and their schedules: the one for frame N + 1 is built WHILE frame N is traced, from the costs up to frame N - 1 (a frame
-    // staler than the synchronous path's, which builds it between the two traces), into the buffers frame N is not reading
-    DevBuf<uint32_t> flight_order[3], flight_ws[3];         // (frames in flight use all three, by frame number mod 3; tiled frames two, by parity)
-    int64_t flight_order_frame[3] = {-1, -1, -1};  // the frame number each buffer's schedule was built for (-1: none)
-    hipEvent_t flight_order_ev[3] = {nullptr, nullptr, nullptr};     // the schedule in each buffer is complete (side stream)
-    int64_t last_frame_deferred = -2;              // the newest tiled frame whose trace was followed by a deferred schedule
-    bool in_flight_taa = false;                    // taa_and_commit is called by ycge_render_frame_async with two traces overlapping: one-wavefront workgroups
-    bool in_flight_call = false;                   // trace_frame is called by ycge_render_frame_async
-    std::vector<hipEvent_t> flight_ev;             // begin / end of the trace launches of the frames in flight, a ring (ycge_async_trace_times)
-    uint64_t flight_frames = 0;                    // queued since the last ycge_async_trace_times
-    // ---- tile-resident form (one process per GPU; ycge_trace_tiles_resident / ycge_resolve_tiles_resident): TAA on this rank's own tiles
-    // with a one-pixel halo of {hdr, sky} exchanged between the ranks, the history never leaves its rank; a ring of K frame sets so that K
-    // tiled traces may be in flight (a rank's launch is its longest chains: its period per frame becomes max(slot time, chain / K))
-    struct ResidentSet {
-        DevBuf<float> hdr, normal, depth;
-        DevBuf<uint8_t> sky;
-        DevBuf<uint64_t> spill;
-        hipEvent_t traced = nullptr, resolved = nullptr;
-        bool traced_used = false, resolved_used = false;
-    };
-    std::vector<ResidentSet *> rsets;
-    // ycge_trace_tiles_resident_batch: the frames of a batch leave their launch parameters here instead of launching (trace_frame), one
-    // launch traces them all (the records travel as its arguments)
-    bool batch_collect = false;
-    std::vector<FrameParams> batch_P;
-    std::vector<TraceOut> batch_O;
-    static constexpr int kBatchMax = YCGE_TRACE_BATCH_MAX;
-    DevBuf<uint64_t> batch_spill[2];               // a spill area as wide as the batch's frames together, per batch parity: two batches may run at a time
-    uint64_t batch_count = 0;
-    hipEvent_t batch_done[2] = {nullptr, nullptr}; // a batch's launch: the batch after the next may scratch its spill area after it
-    bool batch_spill_used[2] = {false, false};
-    static constexpr uint32_t kResCostFrames = 16; // the resident ring's own cost ring: K - 1 slots are being written, one is cleared, the rest are read
-    DevBuf<uint32_t> res_cost;
-    // three schedule buffers taken in turn: one is built behind the trace of every R-th frame M (R = the ring's depth; YCGE_RES_SCHED_EVERY) and
-    // serves the frames from M + K on - a trace never waits for a trace younger than frame N - K - until a newer one does
-    std::vector<DevBuf<uint32_t> *> res_order, res_ws;
-    std::vector<hipEvent_t> res_order_ev, res_order_read_ev;
-    std::vector<int64_t> res_order_frame;          // per buffer: the frame M its schedule was built behind (-1: none)
-    int res_order_next = 0;                        // the buffer the next build writes
-    hipEvent_t res_last_traced = nullptr;          // stage-pipeline scenes share their queues between frames: their traces follow each other
-    bool res_last_traced_used = false;
-    std::vector<int64_t> halo_send_counts, halo_recv_counts;          // records (4 floats) per peer rank
-    DevBuf<uint32_t> d_halo_send_px, d_halo_recv_px;
-    bool halo_ready = false;
-    DevBuf<float> dbg_rays, dbg_hit_t;
-    DevBuf<int32_t> dbg_prim, dbg_sub;
-    DevBuf<uint64_t> dbg_rng;
-    DevBuf<unsigned long long> counters, wave_prof, dbg_counters;
-    DevBuf<float> own_slab;                    // used when world_size > 1 and the caller passes no slab
-    // wavefront pipeline storage (ycge_kernels.hip: QEntry / HitRec / LEntry), sized for one ray per pixel
-    DevBuf<uint8_t> wf_q0, wf_q1, wf_hit, wf_lq;
-    DevBuf<uint32_t> wf_seg;                      // segment counter of the persistent extend stage
-    DevBuf<uint32_t> wf_counts, tile_order;
-    // the stage pipeline's second set (frames in flight: two voxel-world traces at a time, ycge_render_frame_async): queues, counters, both spill areas
-    DevBuf<uint8_t> wf2_q0, wf2_q1, wf2_hit, wf2_lq;
-    DevBuf<uint32_t> wf2_seg, wf2_counts;
-    DevBuf<uint64_t> stack_spill_side2;
-    // denoise / exposure / tonemap stage (ycge_post.hip), allocated on the first frame that asks for SDR output
-    DevBuf<float> den_a, den_b, unit_n, exp_terms, d_sdr, d_sdr2;      // d_sdr2: SDR frames in flight read back one array while the next frame's tonemap fills the other
-    DevBuf<float> atrous_statw;                // [pixel][25 taps][3]: colour-independent weight factors of an in-place A-trous iteration
-    DevBuf<uint8_t> exp_scratch;                  // chunk records of the exposure sum (k_exposure_sum)
-    DevBuf<uint32_t> post_progress;               // k_atrous_persist: groups finished per band, one 128-byte line each
-    uint32_t post_epoch = 0;                      // ... counted from here in the next launch
-    uint32_t post_ticket = 0;                     // k_atrous_stream, bands in order of arrival: numbers drawn so far (the counter lives in post_progress)
-    // a second set of everything the denoiser scratches, for the post stages of every other frame in flight: two of them run side by side
-    // (each is a dependent chain that leaves the chip idle); the exposure state passes from one to the next in frame order
-    struct PostSet { DevBuf<float> den_a, den_b, unit_n, exp_terms, atrous_statw; DevBuf<uint8_t> exp_scratch; DevBuf<uint32_t> post_progress; uint32_t post_epoch = 0, post_ticket = 0;
-                     void release() { den_a.release(); den_b.release(); unit_n.release(); exp_terms.release(); atrous_statw.release(); exp_scratch.release(); post_progress.release(); post_epoch = post_ticket = 0; } } alt_post;
-    int post_resident_seen[2] = {-1, -1};         // post_resident_per_cu: the runtime's answer for the whole-band / split-band instantiation (-1: not asked yet)
-    DevBuf<uint8_t> tone_state;                   // ToneMapper state; lives as long as the context (not reset by Resize)
-    struct InplaceSchedule { ~InplaceSchedule() { pixels.release(); offsets.release(); pass_level.release(); band_desc.release(); } int w = 0, h = 0, step = 0, levels = 0, bands = 0, rows_per_band = 0, levels_per_launch = 0; uint32_t max_level_pixels = 0, window_width = 0; bool split = false; DevBuf<uint32_t> pixels, offsets, pass_level; DevBuf<int32_t> band_desc; };
-    std::vector<InplaceSchedule *> schedules;     // level schedules of the in-place A-trous iterations, by (w, h, step)
-    // what ycge_scene_update_objects needs from the last full upload
-    std::vector<GMesh> gmeshes_host;
-    std::vector<std::array<float, 6>> grid_bounds;   // VolumeGrid.TryGetBounds per grid; max < min marks an empty grid
-    std::vector<std::array<float, 7>> grid_solid;    // GGrid::solid_lo / solid_hi per grid (copied into the grid's object record: the walk culls before it enters)
-    int n_materials = 0, max_mesh_depth = 0;
-    bool materials_can_mirror = false;
-    bool has_dynamic_textures = false;           // Scene.HasDynamicTextures: every frame restarts the TAA history (RaytraceRenderer.cs:171)
-    const float *denoised = nullptr;              // result of the last post stage (one of den_a / den_b / taa_hist)
-    DevBuf<uint32_t> block_cost, block_order, order_ws;   // k_trace scheduling feedback (4 blocks of 8x8 px per tile)
-    DevBuf<uint32_t> cost_snap;                    // a schedule built while traces are in flight reads a copy of the cost ring (ycge_launch_order_blocks)
-    bool block_order_valid = false;
-    DevBuf<uint64_t> stack_spill;                 // [YCGE_TRAVERSAL_STACK - 12][persistent lanes]
-    bool any_light_lit = false;                   // some light has a contribution (GLight::dark == 0): the timed light loop has shadow rays to trace
-    DevBuf<uint64_t> stack_spill_side;            // ... of the stage kernel that runs on the side stream beside another (the light loop beside the next round's trace)
-    DevBuf<float> path_stack;                  // [3][11][persistent lanes], only for scenes with transparent materials
-    int spill_levels = 0;                      // traversal depth beyond the 12 LDS levels, from the uploaded trees
-    int wf_rounds = 2;                         // 2 = primary + diffuse bounce; 4 when a surface can mirror (<= 2 mirror bounces)
-    bool has_grid = false;
-
-    // scene
-    bool have_scene = false;
-    SceneDev sd{};
-    DevBuf<GNode> d_scene_nodes;
-    DevBuf<GNode> d_walk_nodes;        // SceneDev::walk_nodes (worlds of voxel grids): the scene nodes + YCGE_WALK_LEAF_NODES entries per leaf child
-    DevBuf<int32_t> d_grid_owner;      // SceneDev::grid_owner
-    int walk_scene_nodes = 0;          // scene nodes the walk tree was made from (0: SceneDev::walk_nodes is null)
-    DevBuf<uint8_t> d_mesh_arena;
-    DevBuf<uint32_t> d_scene_leaf;
-    DevBuf<GPrim> d_prims;
-    DevBuf<GMaterial> d_materials;
-    DevBuf<GMesh> d_meshes;
-    DevBuf<GGrid> d_grids;
-    DevBuf<uint8_t> d_cells;
-    DevBuf<int32_t> d_lut;
-    DevBuf<uint32_t> d_tex_pixels;             // textures of YCGE_MAT_TEXTURED materials
-    // a live texture's next frame travels through page-locked staging (two buffers taken in turn) and a stream-ordered copy on the
-    // context's stream: behind the traces that still read the old frame, ahead of the ones queued after the call
-    uint8_t *tex_stage[2] = {nullptr, nullptr};
-    size_t tex_stage_bytes[2] = {0, 0};
-    hipEvent_t tex_stage_ev[2] = {nullptr, nullptr};
-    // GPU -> host copies never target memory whose mapping the library does not control (copy_out below): page-locked staging of its own
-    void *out_stage = nullptr; size_t out_stage_bytes = 0;
-    float *staged_sdr_dst = nullptr; size_t staged_sdr_bytes = 0;       // a synchronous frame's SDR read-back into a pageable caller array: finished on the host after the stream
-    hipEvent_t tex_order_ev = nullptr;         // "everything queued on the second trace stream so far": a live texture's copy waits for it
-    bool tex_stage_busy[2] = {false, false};
-    int tex_stage_next = 0;
-    DevBuf<int32_t> d_tex_info;
-    std::vector<int32_t> tex_info_host;        // {first word, width, height, flags} per texture (ycge_scene_update_texture)
-    DevBuf<GLight> d_lights;
-    BuiltTree scene_tree;                      // host copy of the scene BVH in the reference's format (ycge_read_accel)
-    bool scene_tree_on_device = false;         // ... not fetched yet from the last device-side build (accel_view does it on demand)
-    int32_t dev_tree_nodes = 0, dev_tree_items = 0;
-    DevBuf<float> d_bvh_items;                 // device-side scene BVH build (ycge_bvh_build.hip): item boxes + centroids, nine planes
-    DevBuf<uint8_t> d_bvh_scratch, d_bvh_ref, d_bvh_res;
-    int64_t bvh_device_builds = 0, bvh_host_fallbacks = 0, bvh_host_builds = 0;
-    double bvh_last_build_us = 0.0;
-    std::vector<MeshHost> meshes;
-
-    int fail(int code, const char *fmt, ...)
-    {
-        char buf[512];
-        va_list ap;
-        va_start(ap, fmt);
-        vsnprintf(buf, sizeof buf, fmt, ap);
-        va_end(ap);
-        err = buf;
-        return code;
-    }
-};
-
-#define HIP_TRY(ctx, call)                                                                                   \
-    do {                                                                                                      \
-        hipError_t e_ = (call);                                                                               \
-        if (e_ != hipSuccess) return (ctx)->fail(e_ == hipErrorOutOfMemory ? YCGE_ERR_OUT_OF_MEMORY : YCGE_ERR_DEVICE, \
-                                                 "%s failed: %s", #call, hipGetErrorString(e_));            \
-    } while (0)
-
-#define YCGE_FLIGHT_RING 1024u       // frames in flight whose trace launches keep their timing events (ycge_async_trace_times)
-
-namespace {
+namespace ycge_host {
 
 int alloc_frame_buffers(ycge_ctx *c)
 {
@@ -538,7 +87,7 @@ static void halo_ring_of(int tile, int tiles_x, int hiW, int hiH, std::vector<ui
     for (int y = y0; y < y0 + YCGE_TILE_H; y++) add(x0 + YCGE_TILE_W, y);
 }
 // send_px: pixels this rank gathers, segment by destination rank ascending; recv_px: pixels the received records scatter to, by source rank ascending
-static void halo_layout(int hiW, int hiH, int rank, int world, std::vector<int64_t> &send_counts, std::vector<int64_t> &recv_counts, std::vector<uint32_t> &send_px, std::vector<uint32_t> &recv_px)
+void halo_layout(int hiW, int hiH, int rank, int world, std::vector<int64_t> &send_counts, std::vector<int64_t> &recv_counts, std::vector<uint32_t> &send_px, std::vector<uint32_t> &recv_px)
 {
     const int tiles_x = (hiW + YCGE_TILE_W - 1) / YCGE_TILE_W, tiles_y = (hiH + YCGE_TILE_H - 1) / YCGE_TILE_H, n_tiles = tiles_x * tiles_y;
     auto owner = [&](uint32_t p) { const int x = (int)(p % (uint32_t)hiW), y = (int)(p / (uint32_t)hiW); return ((y / YCGE_TILE_H) * tiles_x + x / YCGE_TILE_W) % world; };
@@ -559,7 +108,7 @@ static void halo_layout(int hiW, int hiH, int rank, int world, std::vector<int64
         }
     }
 }
-static void release_resident(ycge_ctx *c)
+void release_resident(ycge_ctx *c)
 {
     for (auto *rs : c->rsets) { if (rs->traced) (void)hipEventDestroy(rs->traced); if (rs->resolved) (void)hipEventDestroy(rs->resolved); delete rs; }
     c->rsets.clear();
@@ -725,7 +274,7 @@ int morton3(int x, int y, int z)
     return ((x & 1) << 0) | ((y & 1) << 1) | ((z & 1) << 2) | ((x & 2) << 2) | ((y & 2) << 3) | ((z & 2) << 4) | ((x & 4) << 4) | ((y & 4) << 5) | ((z & 4) << 6);
 }
 
-} // namespace
+} // namespace ycge_host
 
 // =========================================================================== C-ABI
 extern "C" {
@@ -964,7 +513,7 @@ static int upload_lights(ycge_ctx *c, const ycge_light *lights, int n)
 }
 
 }
-namespace {
+namespace ycge_host {
 
 // ---- device -> host.  The device writes host memory in two places only: page-locked memory (the library's own - hipHostMalloc - or whole
 // pages the caller registered, ycge_pin_host_buffer) and the library's own staging buffer below; a PAGEABLE destination is filled by the CPU
@@ -1341,7 +890,7 @@ int install_scene(ycge_ctx *c, const SceneArrays &A, const ObjectsHost &oh, cons
     return YCGE_OK;
 }
 
-} // namespace
+} // namespace ycge_host
 extern "C" {
 // A mesh's device records appended to the arena (32-byte units): depth-first - an internal node (GNode, both child boxes),
 // then its left child's records (a leaf's triangle pair records or the whole left subtree), then the right child's - so a
@@ -1916,7 +1465,7 @@ int ycge_tile_slab_bytes(const ycge_ctx *c, size_t *bytes)
 
 } // extern "C"
 
-namespace {
+namespace ycge_host {
 
 // steps 1-3 of TryFlipAndBlit (RaytraceRenderer.cs:159-176): camera snapshot under the lock, frame = ++frameCounter.
 // The reset decision (step 2) compares this pose with the camera the LAST RESOLVED frame committed, so it is taken where
@@ -1946,7 +1495,7 @@ void snapshot_frame(ycge_ctx *c, FrameState &fs)
 // eighth-frames are a whole frame's blocks and took 0.84 ms against the whole frame's 0.48 - the split's thin wavefronts (8 or 4 parts of a
 // block's 64 pixels) are slot time nobody gets back.  Unsplit: 8 ranks, batches of 4: 0.100-0.108 -> 0.086-0.088 ms a rank-frame
 // (011110000 0.087-0.093, 022110000 0.088-0.095, 022220000 0.101-0.112; profiles/r05/e_split_policy_by_form.txt).
-void schedule_policy(const ycge_ctx *c, uint32_t &policy, uint32_t &split_top, int resident_ring = 0, bool batched = false)
+void schedule_policy(const ycge_ctx *c, uint32_t &policy, uint32_t &split_top, int resident_ring, bool batched)
 {
     const uint32_t world_policy = batched ? 0u : (resident_ring >= 3 && c->cfg.world_size >= 2) ? 033220000u
                                 : c->cfg.world_size >= 8 ? 044433000u : c->cfg.world_size >= 4 ? 044320000u : c->cfg.world_size >= 2 ? 033220000u : 0u;
@@ -1970,15 +1519,9 @@ bool frame_is_single_launch(const ycge_ctx *c)
 }
 
 // step 4 (RaytraceRenderer.cs:183-216): ray-gen + trace of this context's tiles for the frame `fs`
-// where a trace of the tile-resident form writes and which schedule it follows (trace_frame's last argument)
-struct ResidentTarget {
-    ycge_ctx::ResidentSet *set;
-    uint32_t *cost;                 // this frame's slot of the resident cost ring
-    const uint32_t *order, *n_order;        // the schedule built for this frame (null: blocks in index order)
-};
-
-int trace_frame(ycge_ctx *c, float *d_slab, hipStream_t stream, FrameState &fs, bool timed, hipEvent_t launch_begin = nullptr, hipEvent_t launch_end = nullptr /* frames in flight: around the trace launches alone */,
-                const ResidentTarget *rt = nullptr)
+// (ResidentTarget - where a trace of the tile-resident form writes and which schedule it follows - is trace_frame's last argument: ycge_ctx.h)
+int trace_frame(ycge_ctx *c, float *d_slab, hipStream_t stream, FrameState &fs, bool timed, hipEvent_t launch_begin, hipEvent_t launch_end /* frames in flight: around the trace launches alone */,
+                const ResidentTarget *rt)
 {
     if (!c->have_scene) return c->fail(YCGE_ERR_NO_SCENE, "Scene BVH not built; call ycge_scene_upload first (Scene.cs:73)");
     FrameParams P;
@@ -2585,7 +2128,23 @@ int fill_stats(ycge_ctx *c, ycge_frame_stats *st, const FrameState &fs, bool did
     return YCGE_OK;
 }
 
-} // namespace
+} // namespace ycge_host
+
+namespace ycge_host {
+// every other entry point first waits for what ycge_render_frame_async left in flight (the frames-in-flight machinery is below)
+int join_async(ycge_ctx *c)
+{
+    if (!c->async_outstanding) return YCGE_OK;
+    HIP_TRY(c, hipSetDevice(c->device));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    if (c->stream2) HIP_TRY(c, hipStreamSynchronize(c->stream2));
+    HIP_TRY(c, hipStreamSynchronize(c->taa_stream));
+    c->async_outstanding = false;
+    c->set_read[0] = c->set_read[1] = c->set_read[2] = false;
+    c->post_hist_pending = c->post_busy = c->post_set_pending[0] = c->post_set_pending[1] = c->post_set_pending[2] = false;
+    return YCGE_OK;
+}
+} // namespace ycge_host
 
 extern "C" {
 
@@ -2662,18 +2221,6 @@ static int trace_on_all_devices(ycge_ctx *c, FrameState &fs)
 // the trace on the context's stream, TAA on a second one, a frame's trace outputs alternating between two sets of buffers so that
 // TAA of frame N reads one set while the trace of frame N + 1 writes the other.  Same kernels, same order of frames, same bits
 // (tests/test_gpu_timed_variants.py); every other entry point first waits for what is in flight (join_async).
-static int join_async(ycge_ctx *c)
-{
-    if (!c->async_outstanding) return YCGE_OK;
-    HIP_TRY(c, hipSetDevice(c->device));
-    HIP_TRY(c, hipStreamSynchronize(c->stream));
-    if (c->stream2) HIP_TRY(c, hipStreamSynchronize(c->stream2));
-    HIP_TRY(c, hipStreamSynchronize(c->taa_stream));
-    c->async_outstanding = false;
-    c->set_read[0] = c->set_read[1] = c->set_read[2] = false;
-    c->post_hist_pending = c->post_busy = c->post_set_pending[0] = c->post_set_pending[1] = c->post_set_pending[2] = false;
-    return YCGE_OK;
-}
 
 int ycge_wait(ycge_ctx *c)
 {
@@ -3007,572 +2554,6 @@ int ycge_resolve_gathered(ycge_ctx *c, const void *d_all_slabs, void *hip_stream
         }
         st->total_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
     }
-    return YCGE_OK;
-}
-
-// ---------------------------------------------------------------------------------------------- tile-resident form (include/ycge.h)
-static int ensure_resident(ycge_ctx *c)
-{
-    if (c->parent || !c->peers.empty()) return c->fail(YCGE_ERR_INVALID_ARG, "the tile-resident form is one process per GPU (rank / world_size); this context drives its devices through ycge_render_frame");
-    if (c->cfg.capture_debug) return c->fail(YCGE_ERR_INVALID_ARG, "the tile-resident form keeps no debug captures");
-    if (c->cfg.taa_clamp_radius > 1) return c->fail(YCGE_ERR_UNSUPPORTED, "the tile-resident form exchanges a one-pixel halo: taa_clamp_radius %d needs ycge_resolve_gathered", c->cfg.taa_clamp_radius);
-    HIP_TRY(c, hipSetDevice(c->device));
-    const int K = c->cfg.tile_ring <= 0 ? 2 : c->cfg.tile_ring;
-    if (K < 2 || K > (int)ycge_ctx::kResCostFrames - 1) return c->fail(YCGE_ERR_INVALID_ARG, "config.tile_ring must be 2..%d", (int)ycge_ctx::kResCostFrames - 1);
-    if ((int)c->rsets.size() != K || !c->halo_ready) {
-        HIP_TRY(c, hipDeviceSynchronize());
-        release_resident(c);
-        {
-            std::vector<uint32_t> spx, rpx;
-            halo_layout(c->hiW, c->hiH, c->cfg.rank, c->cfg.world_size, c->halo_send_counts, c->halo_recv_counts, spx, rpx);
-            if (spx.empty()) spx.push_back(0u);
-            if (rpx.empty()) rpx.push_back(0u);
-            HIP_TRY(c, c->d_halo_send_px.upload(spx)); HIP_TRY(c, c->d_halo_recv_px.upload(rpx));
-            c->halo_ready = true;
-        }
-        const size_t n = (size_t)c->hiW * c->hiH;
-        for (int k = 0; k < K; k++) {
-            auto *rs = new ycge_ctx::ResidentSet();
-            c->rsets.push_back(rs);
-            HIP_TRY(c, rs->hdr.alloc(3 * n)); HIP_TRY(c, rs->normal.alloc(3 * n)); HIP_TRY(c, rs->depth.alloc(n)); HIP_TRY(c, rs->sky.alloc(n));
-            HIP_TRY(c, rs->spill.alloc(c->stack_spill.n));
-            HIP_TRY(c, hipEventCreateWithFlags(&rs->traced, hipEventDisableTiming)); HIP_TRY(c, hipEventCreateWithFlags(&rs->resolved, hipEventDisableTiming));
-        }
-        const size_t nb = (size_t)(c->n_owned > 0 ? c->n_owned : 1) * 4;
-        HIP_TRY(c, c->res_cost.alloc(nb * (ycge_ctx::kResCostFrames + 1)));          // (+ one slot nobody reads: what a schedule build "clears for the next frame")
-        HIP_TRY(c, hipMemset(c->res_cost.p, 0, nb * (ycge_ctx::kResCostFrames + 1) * sizeof(uint32_t)));
-        c->res_order_next = 0;
-        for (int k = 0; k < 3; k++) {
-            auto *o = new DevBuf<uint32_t>(); auto *w = new DevBuf<uint32_t>();
-            c->res_order.push_back(o); c->res_ws.push_back(w);
-            HIP_TRY(c, o->alloc(nb * YCGE_SCHEDULE_SLACK)); HIP_TRY(c, w->alloc(96)); HIP_TRY(c, hipMemset(w->p, 0, 96 * sizeof(uint32_t)));
-            hipEvent_t e1 = nullptr, e2 = nullptr;
-            HIP_TRY(c, hipEventCreateWithFlags(&e1, hipEventDisableTiming)); HIP_TRY(c, hipEventCreateWithFlags(&e2, hipEventDisableTiming));
-            c->res_order_ev.push_back(e1); c->res_order_read_ev.push_back(e2);
-            c->res_order_frame.push_back(-1);
-        }
-        HIP_TRY(c, hipEventCreateWithFlags(&c->res_last_traced, hipEventDisableTiming));
-    }
-    return YCGE_OK;
-}
-
-int ycge_halo_counts(ycge_ctx *c, int64_t *send_counts, int64_t *recv_counts)
-{
-    if (!c) return YCGE_ERR_INVALID_ARG;
-    if (!send_counts || !recv_counts) return c->fail(YCGE_ERR_INVALID_ARG, "null count array");
-    { const int jr = join_async(c); if (jr != YCGE_OK) return jr; }
-    const int rc = ensure_resident(c);
-    if (rc != YCGE_OK) return rc;
-    for (int r = 0; r < c->cfg.world_size; r++) { send_counts[r] = c->halo_send_counts[(size_t)r]; recv_counts[r] = c->halo_recv_counts[(size_t)r]; }
-    return YCGE_OK;
-}
-
-int ycge_history_slab_bytes(const ycge_ctx *c, size_t *bytes)
-{
-    if (!c || !bytes) return YCGE_ERR_INVALID_ARG;
-    *bytes = (size_t)c->tiles_per_rank_padded * 256 * 3 * sizeof(float);
-    return YCGE_OK;
-}
-
-// steps 1-4 of TryFlipAndBlit on this rank's tiles into the frame set of the ring, then the halo records the other ranks need
-int ycge_trace_tiles_resident(ycge_ctx *c, void *d_halo_send, void *hip_stream, ycge_frame_stats *st)
-{
-    if (!c) return YCGE_ERR_INVALID_ARG;
-    { const int jr = join_async(c); if (jr != YCGE_OK) return jr; }
-    int rc = ensure_resident(c);
-    if (rc != YCGE_OK) return rc;
-    size_t n_send = 0;
-    for (int64_t v : c->halo_send_counts) n_send += (size_t)v;
-    if (n_send > 0 && !d_halo_send) return c->fail(YCGE_ERR_INVALID_ARG, "null halo send buffer (%zu records of 16 bytes)", n_send);
-    hipStream_t stream = hip_stream ? (hipStream_t)hip_stream : c->stream;
-    c->last_stream = stream;
-    const int K = (int)c->rsets.size();
-    if ((int)c->pending.size() >= K) return c->fail(YCGE_ERR_INVALID_ARG, "%d traced frames wait to be resolved: the ring holds config.tile_ring = %d", (int)c->pending.size(), K);
-    auto t0 = std::chrono::steady_clock::now();
-    FrameState fs;
-    snapshot_frame(c, fs);
-    ycge_ctx::ResidentSet *rs = c->rsets[(size_t)((uint64_t)fs.frame % (uint64_t)K)];
-    if (rs->resolved_used) HIP_TRY(c, hipStreamWaitEvent(stream, rs->resolved, 0));        // TAA of frame N - K has read this set
-    if (rs->traced_used) HIP_TRY(c, hipStreamWaitEvent(stream, rs->traced, 0));            // (its spill area: the trace of frame N - K, on whatever stream)
-    const bool single = frame_is_single_launch(c);
-    if ((!single || c->sd.any_transparent) && c->res_last_traced_used) HIP_TRY(c, hipStreamWaitEvent(stream, c->res_last_traced, 0));      // shared stage queues / refraction stacks: one trace at a time
-    const uint32_t n_blocks = (uint32_t)c->n_owned * 4u, RC = ycge_ctx::kResCostFrames;
-    const uint32_t cost_slot = (uint32_t)((uint64_t)fs.frame % RC);
-    ResidentTarget rt;
-    rt.set = rs;
-    rt.cost = c->res_cost.p + (size_t)cost_slot * n_blocks;
-    rt.order = nullptr; rt.n_order = nullptr;
-    const bool lpt = single && !c->knobs.no_lpt;
-    int ob = -1;          // the newest schedule this frame may follow: built behind a frame M <= N - K (anything younger would make this trace wait for a trace of its own ring)
-    if (lpt)
-        for (int b = 0; b < 3; b++)
-            if (c->res_order_frame[(size_t)b] >= 0 && c->res_order_frame[(size_t)b] + K <= fs.frame && (ob < 0 || c->res_order_frame[(size_t)b] > c->res_order_frame[(size_t)ob])) ob = b;
-    if (ob >= 0) {
-        rt.order = c->res_order[(size_t)ob]->p; rt.n_order = c->res_ws[(size_t)ob]->p + 16;
-        HIP_TRY(c, hipStreamWaitEvent(stream, c->res_order_ev[(size_t)ob], 0));
-    }
-    if (lpt) HIP_TRY(c, hipMemsetAsync(rt.cost, 0, (size_t)n_blocks * sizeof(uint32_t), stream));          // this frame's cost slot (the kernel's atomicMax needs zeros)
-    rc = trace_frame(c, nullptr, stream, fs, st != nullptr, nullptr, nullptr, &rt);
-    if (rc != YCGE_OK) return rc;
-    if (ob >= 0) HIP_TRY(c, hipEventRecord(c->res_order_read_ev[(size_t)ob], stream));
-    int e = ycge_launch_halo(0, rs->hdr.p, rs->sky.p, c->d_halo_send_px.p, (uint32_t)n_send, d_halo_send, stream);
-    if (e != 0) return c->fail(YCGE_ERR_DEVICE, "k_gather_halo launch failed: %s", hipGetErrorString((hipError_t)e));
-    HIP_TRY(c, hipEventRecord(rs->traced, stream)); rs->traced_used = true;
-    if (!single || c->sd.any_transparent) { HIP_TRY(c, hipEventRecord(c->res_last_traced, stream)); c->res_last_traced_used = true; }
-    const int every = c->knobs.res_sched_every > 0 ? c->knobs.res_sched_every : K;
-    if (lpt && fs.frame % every == 0) {
-        // a new schedule, behind this trace on the side stream: from the cost slots of the frames up to this one (the K - 1 slots the traces of
-        // frames N + 1 .. N + K - 1 may be writing are left out), into the oldest of the three buffers once its last reader is done.  Built
-        // every `every`-th frame only: which blocks run long is a property of the image region, and a rank's host thread has ~25 driver
-        // calls a frame to make as it is
-        uint32_t policy, split_top;
-        schedule_policy(c, policy, split_top, K);
-        uint32_t skip = 0;
-        for (int a = 1; a < K; a++) skip |= 1u << ((cost_slot + (uint32_t)a) % RC);
-        const int tb = c->res_order_next;
-        c->res_order_next = (tb + 1) % 3;
-        HIP_TRY(c, hipStreamWaitEvent(c->fan_stream, rs->traced, 0));
-        if (c->res_order_frame[(size_t)tb] >= 0) HIP_TRY(c, hipStreamWaitEvent(c->fan_stream, c->res_order_read_ev[(size_t)tb], 0));
-        c->res_order_frame[(size_t)tb] = -1;          // (not to be picked while it is being rewritten ...)
-        e = ycge_launch_order_blocks(c->res_cost.p, n_blocks, policy, split_top, 0u, 0u, RC /* the slot nobody reads */, skip, c->res_ws[(size_t)tb]->p, c->res_order[(size_t)tb]->p, c->fan_stream, 0, RC, c->cost_snap.p);      // (traces in flight write their costs meanwhile: a copy is read)
-        if (e != 0) return c->fail(YCGE_ERR_DEVICE, "schedule launch failed: %s", hipGetErrorString((hipError_t)e));
-        HIP_TRY(c, hipEventRecord(c->res_order_ev[(size_t)tb], c->fan_stream));
-        c->res_order_frame[(size_t)tb] = fs.frame;          // (... and from frame N + K on it is the newest)
-    }
-    c->pending.push_back(fs);
-    if (st) {
-        HIP_TRY(c, hipStreamSynchronize(stream));
-        const double wall = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
-        return fill_stats(c, st, fs, false, false, wall);
-    }
-    return YCGE_OK;
-}
-
-// n consecutive frames of this rank's tiles in ONE launch (k_trace_batch): what one frame's launch - a rank's share is a few thousand
-// blocks - leaves idle around its longest chains, the other frames' blocks fill.  poses: n x {pos xyz, yaw, pitch, fov} (the camera of each
-// frame, as n ycge_set_camera calls would set it; the last one stays the context's camera); d_halo_send: n buffers, filled as by n
-// ycge_trace_tiles_resident calls.  The frames are then exchanged and resolved one by one, oldest first, as ever.  Same pixels (the frames
-// never needed each other's traces).  Scenes that trace in stages or keep refraction stacks, and counting contexts, take the frames one
-// by one here too.
-int ycge_trace_tiles_resident_batch(ycge_ctx *c, int32_t n, const float *poses, void *const *d_halo_send, void *hip_stream)
-{
-    if (!c) return YCGE_ERR_INVALID_ARG;
-    if (n < 1 || n > ycge_ctx::kBatchMax || !poses) return c->fail(YCGE_ERR_INVALID_ARG, "a batch is 1..%d frames with their poses", ycge_ctx::kBatchMax);
-    { const int jr = join_async(c); if (jr != YCGE_OK) return jr; }
-    int rc = ensure_resident(c);
-    if (rc != YCGE_OK) return rc;
-    size_t n_send = 0;
-    for (int64_t v : c->halo_send_counts) n_send += (size_t)v;
-    if (n_send > 0) { if (!d_halo_send) return c->fail(YCGE_ERR_INVALID_ARG, "null halo send buffers"); for (int k = 0; k < n; k++) if (!d_halo_send[k]) return c->fail(YCGE_ERR_INVALID_ARG, "null halo send buffer of frame %d of the batch", k); }
-    const int K = (int)c->rsets.size();
-    if ((int)c->pending.size() + n > K) return c->fail(YCGE_ERR_INVALID_ARG, "%d traced frames wait to be resolved and %d more are asked for: the ring holds config.tile_ring = %d", (int)c->pending.size(), n, K);
-    auto set_pose = [&](int k) {
-        std::lock_guard<std::mutex> g(c->cam_lock);
-        const float *q = poses + 6 * k;
-        c->cam_pos[0] = q[0]; c->cam_pos[1] = q[1]; c->cam_pos[2] = q[2]; c->yaw = q[3]; c->pitch = q[4]; c->fov_deg = q[5];
-    };
-    const bool single = frame_is_single_launch(c);
-    if (!single || c->sd.any_transparent || c->cfg.count_work || n == 1) {
-        for (int k = 0; k < n; k++) {
-            set_pose(k);
-            rc = ycge_trace_tiles_resident(c, d_halo_send ? d_halo_send[k] : nullptr, hip_stream, nullptr);
-            if (rc != YCGE_OK) return rc;
-        }
-        return YCGE_OK;
-    }
-    hipStream_t stream = hip_stream ? (hipStream_t)hip_stream : c->stream;
-    c->last_stream = stream;
-    const uint32_t n_blocks = (uint32_t)c->n_owned * 4u, RC = ycge_ctx::kResCostFrames;
-    const bool lpt = !c->knobs.no_lpt;
-    std::vector<FrameState> fs((size_t)n);
-    std::vector<ycge_ctx::ResidentSet *> sets((size_t)n, nullptr);
-    c->batch_P.clear(); c->batch_O.clear();
-    int ob = -1;
-    // A batch is all or nothing for the host-side state: frames enter the pending list only after the whole batch is queued, and a failure on
-    // the way (a launch refused, an allocation) puts the frame counter back and leaves the list as it was - the caller's exchange and the
-    // ring stay in step.  (What a failed HIP call leaves on the device is the device's business: the context reports YCGE_ERR_DEVICE.)
-    const int64_t frame_counter_before = c->frame_counter;
-    struct Rollback {
-        ycge_ctx *c; int64_t counter; bool armed = true;
-        ~Rollback() { if (armed) { c->frame_counter = counter; c->batch_collect = false; c->batch_P.clear(); c->batch_O.clear(); } }
-    } rollback{c, frame_counter_before};
-    for (int k = 0; k < n; k++) {
-        set_pose(k);
-        snapshot_frame(c, fs[(size_t)k]);
-        ycge_ctx::ResidentSet *rs = sets[(size_t)k] = c->rsets[(size_t)((uint64_t)fs[(size_t)k].frame % (uint64_t)K)];
-        if (rs->resolved_used) HIP_TRY(c, hipStreamWaitEvent(stream, rs->resolved, 0));
-        if (rs->traced_used) HIP_TRY(c, hipStreamWaitEvent(stream, rs->traced, 0));
-        const uint32_t cost_slot = (uint32_t)((uint64_t)fs[(size_t)k].frame % RC);
-        ResidentTarget rt;
-        rt.set = rs;
-        rt.cost = c->res_cost.p + (size_t)cost_slot * n_blocks;
-        rt.order = nullptr; rt.n_order = nullptr;
-        if (k == 0 && lpt) {        // ONE schedule for the whole batch: the newest the batch's first frame may follow (ycge_trace_tiles_resident's rule)
-            for (int b = 0; b < 3; b++)
-                if (c->res_order_frame[(size_t)b] >= 0 && c->res_order_frame[(size_t)b] + K <= fs[0].frame && (ob < 0 || c->res_order_frame[(size_t)b] > c->res_order_frame[(size_t)ob])) ob = b;
-            if (ob >= 0) HIP_TRY(c, hipStreamWaitEvent(stream, c->res_order_ev[(size_t)ob], 0));
-        }
-        if (ob >= 0) { rt.order = c->res_order[(size_t)ob]->p; rt.n_order = c->res_ws[(size_t)ob]->p + 16; }
-        if (lpt) HIP_TRY(c, hipMemsetAsync(rt.cost, 0, (size_t)n_blocks * sizeof(uint32_t), stream));
-        c->batch_collect = true;
-        rc = trace_frame(c, nullptr, stream, fs[(size_t)k], false, nullptr, nullptr, &rt);
-        c->batch_collect = false;
-        if (rc != YCGE_OK) return rc;
-    }
-    if ((int)c->batch_P.size() != n || (int)c->batch_O.size() != n) return c->fail(YCGE_ERR_DEVICE, "batch: %zu of %d frames left their launch parameters", c->batch_P.size(), n);
-    // one spill area for the launch, n frames wide: a workgroup's column is its index in the launch
-    const uint32_t lanes = c->batch_O[0].stack_lanes;
-    const size_t spill_words = (size_t)(c->spill_levels > 0 ? c->spill_levels : 1) * lanes * (size_t)n;
-    const int bp = (int)(c->batch_count & 1u);
-    for (int q = 0; q < 2; q++)          // (both areas at the first batch of a size: an allocation of gigabytes is no part of a later frame)
-        if (c->batch_spill[q].n < spill_words) {
-            if (c->batch_spill_used[q]) HIP_TRY(c, hipEventSynchronize(c->batch_done[q]));
-            HIP_TRY(c, c->batch_spill[q].alloc(spill_words));
-        }
-    for (int k = 0; k < n; k++) { c->batch_O[(size_t)k].stack_spill = c->batch_spill[bp].p; c->batch_O[(size_t)k].stack_lanes = lanes * (uint32_t)n; }
-    c->batch_count++;
-    if (c->batch_spill_used[bp]) HIP_TRY(c, hipStreamWaitEvent(stream, c->batch_done[bp], 0));          // (the batch before the last scratched this area)
-    int e = ycge_launch_trace_batch(&c->sd, c->batch_P.data(), c->batch_O.data(), n, 0, scene_is_flat(c), stream);
-    if (e != 0) return c->fail(YCGE_ERR_DEVICE, "k_trace_batch launch failed: %s", hipGetErrorString((hipError_t)e));
-    if (!c->batch_done[bp]) HIP_TRY(c, hipEventCreateWithFlags(&c->batch_done[bp], hipEventDisableTiming));
-    HIP_TRY(c, hipEventRecord(c->batch_done[bp], stream)); c->batch_spill_used[bp] = true;
-    if (ob >= 0) HIP_TRY(c, hipEventRecord(c->res_order_read_ev[(size_t)ob], stream));
-    for (int k = 0; k < n; k++) {
-        ycge_ctx::ResidentSet *rs = sets[(size_t)k];
-        e = ycge_launch_halo(0, rs->hdr.p, rs->sky.p, c->d_halo_send_px.p, (uint32_t)n_send, d_halo_send ? d_halo_send[k] : nullptr, stream);
-        if (e != 0) return c->fail(YCGE_ERR_DEVICE, "k_gather_halo launch failed: %s", hipGetErrorString((hipError_t)e));
-        HIP_TRY(c, hipEventRecord(rs->traced, stream)); rs->traced_used = true;
-    }
-    for (int k = 0; k < n; k++) c->pending.push_back(fs[(size_t)k]);
-    rollback.armed = false;
-    const int every = c->knobs.res_sched_every > 0 ? c->knobs.res_sched_every : K;
-    bool build = false;
-    for (int k = 0; k < n; k++) if (fs[(size_t)k].frame % every == 0) build = true;
-    if (lpt && build) {         // a new schedule behind the batch, from the cost slots up to its last frame's (ycge_trace_tiles_resident's rule)
-        uint32_t policy, split_top;
-        schedule_policy(c, policy, split_top, K, true);
-        const uint32_t last_slot = (uint32_t)((uint64_t)fs[(size_t)n - 1].frame % RC);
-        uint32_t skip = 0;
-        for (int a = 1; a < K; a++) skip |= 1u << ((last_slot + (uint32_t)a) % RC);
-        const int tb = c->res_order_next;
-        c->res_order_next = (tb + 1) % 3;
-        HIP_TRY(c, hipStreamWaitEvent(c->fan_stream, sets[(size_t)n - 1]->traced, 0));
-        if (c->res_order_frame[(size_t)tb] >= 0) HIP_TRY(c, hipStreamWaitEvent(c->fan_stream, c->res_order_read_ev[(size_t)tb], 0));
-        c->res_order_frame[(size_t)tb] = -1;
-        e = ycge_launch_order_blocks(c->res_cost.p, n_blocks, policy, split_top, 0u, 0u, RC, skip, c->res_ws[(size_t)tb]->p, c->res_order[(size_t)tb]->p, c->fan_stream, 0, RC, c->cost_snap.p);      // (traces in flight write their costs meanwhile: a copy is read)
-        if (e != 0) return c->fail(YCGE_ERR_DEVICE, "schedule launch failed: %s", hipGetErrorString((hipError_t)e));
-        HIP_TRY(c, hipEventRecord(c->res_order_ev[(size_t)tb], c->fan_stream));
-        c->res_order_frame[(size_t)tb] = fs[(size_t)n - 1].frame;
-    }
-    return YCGE_OK;
-}
-
-// the records of this frame's halo into its set, TAA on this rank's own tiles (steps 5 and 9), the resolved history of those tiles as a slab
-int ycge_resolve_tiles_resident(ycge_ctx *c, const void *d_halo_recv, void *d_history_slab, void *hip_stream, ycge_frame_stats *st)
-{
-    if (!c) return YCGE_ERR_INVALID_ARG;
-    if (c->pending.empty() || c->rsets.empty()) return c->fail(YCGE_ERR_INVALID_ARG, "no traced frame to resolve: every ycge_resolve_tiles_resident follows its own ycge_trace_tiles_resident");
-    HIP_TRY(c, hipSetDevice(c->device));
-    size_t n_recv = 0;
-    for (int64_t v : c->halo_recv_counts) n_recv += (size_t)v;
-    if (n_recv > 0 && !d_halo_recv) return c->fail(YCGE_ERR_INVALID_ARG, "null halo receive buffer (%zu records of 16 bytes)", n_recv);
-    // every refusal comes BEFORE the frame leaves the pending list: a refused call changes nothing, ring and caller stay in step
-    if (c->cfg.taa_clamp_radius > 1) return c->fail(YCGE_ERR_UNSUPPORTED, "the tile-resident form exchanges a one-pixel halo: taa_clamp_radius %d needs ycge_resolve_gathered", c->cfg.taa_clamp_radius);
-    hipStream_t stream = hip_stream ? (hipStream_t)hip_stream : c->stream;
-    c->last_stream = stream;
-    auto t0 = std::chrono::steady_clock::now();
-    FrameState fs = c->pending.front();
-    c->pending.pop_front();
-    const int K = (int)c->rsets.size();
-    ycge_ctx::ResidentSet *rs = c->rsets[(size_t)((uint64_t)fs.frame % (uint64_t)K)];
-    HIP_TRY(c, hipStreamWaitEvent(stream, rs->traced, 0));         // (the caller's exchange already follows the trace; this holds whatever streams it uses)
-    if (st) HIP_TRY(c, hipEventRecord(c->ev[1], stream));
-    int e = ycge_launch_halo(1, rs->hdr.p, rs->sky.p, c->d_halo_recv_px.p, (uint32_t)n_recv, const_cast<void *>(d_halo_recv), stream);
-    if (e != 0) return c->fail(YCGE_ERR_DEVICE, "k_scatter_halo launch failed: %s", hipGetErrorString((hipError_t)e));
-    fs.reset = should_reset_history(c, fs.pos, fs.yaw, fs.pitch) || c->has_dynamic_textures;
-    TaaParams T;
-    T.w = c->hiW; T.h = c->hiH;
-    T.alpha = cs_max(0.0f, cs_min(1.0f, c->cfg.taa_alpha));
-    T.radius = c->cfg.taa_clamp_radius > 0 ? c->cfg.taa_clamp_radius : 0;
-    T.pad_lum = c->cfg.taa_luminance_pad;
-    const bool did_reset = !c->taa_valid || fs.reset;
-    T.reset = did_reset ? 1 : 0;
-    FrameParams P;
-    fill_frame_params(c, P, fs.frame, fs.pos, fs.yaw, fs.pitch, fs.fov);
-    e = ycge_launch_taa_tiles(&T, &P, rs->hdr.p, rs->normal.p, rs->depth.p, rs->sky.p, c->taa_hist.p, c->prev_normal.p, c->prev_depth.p, c->prev_sky.p, stream);
-    if (e != 0) return c->fail(YCGE_ERR_DEVICE, "k_taa_tiles launch failed: %s", hipGetErrorString((hipError_t)e));
-    if (st) HIP_TRY(c, hipEventRecord(c->ev[2], stream));
-    c->taa_valid = true;
-    c->last_cam[0] = fs.pos[0]; c->last_cam[1] = fs.pos[1]; c->last_cam[2] = fs.pos[2]; c->last_yaw = fs.yaw; c->last_pitch = fs.pitch;
-    HIP_TRY(c, hipEventRecord(rs->resolved, stream)); rs->resolved_used = true;
-    if (d_history_slab) {
-        e = ycge_launch_pack_history(&P, c->taa_hist.p, (float *)d_history_slab, stream);
-        if (e != 0) return c->fail(YCGE_ERR_DEVICE, "k_pack_history launch failed: %s", hipGetErrorString((hipError_t)e));
-    }
-    if (st) {
-        HIP_TRY(c, hipStreamSynchronize(stream));
-        std::memset(st, 0, sizeof *st);
-        st->frame = fs.frame; st->history_reset = did_reset ? 1 : 0;
-        float ms = 0.0f;
-        HIP_TRY(c, hipEventElapsedTime(&ms, c->ev[1], c->ev[2]));
-        st->taa_ms = ms;
-        st->exposure = 1.0f;
-        st->n_devices_traced = 1; st->device_tiles[0] = c->n_owned;
-        st->total_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
-    }
-    return YCGE_OK;
-}
-
-// the consumer's half: world_size history slabs (rank-major, as an all-gather or a gather leaves them) into the full-frame history
-int ycge_unpack_history(ycge_ctx *c, const void *d_all_history_slabs, void *hip_stream)
-{
-    if (!c) return YCGE_ERR_INVALID_ARG;
-    if (!d_all_history_slabs) return c->fail(YCGE_ERR_INVALID_ARG, "null gathered history slabs");
-    HIP_TRY(c, hipSetDevice(c->device));
-    hipStream_t stream = hip_stream ? (hipStream_t)hip_stream : c->stream;
-    c->last_stream = stream;
-    const int e = ycge_launch_unpack_history((const float *)d_all_history_slabs, (size_t)c->tiles_per_rank_padded * 256 * 3, c->hiW, c->hiH, c->tiles_x, c->n_tiles, c->cfg.world_size, c->taa_hist.p, stream);
-    if (e != 0) return c->fail(YCGE_ERR_DEVICE, "k_unpack_history launch failed: %s", hipGetErrorString((hipError_t)e));
-    return YCGE_OK;
-}
-
-// measurement (profiles/rank_flight.py): a rank's pipelined loop of the tile-resident form driven from C - K traces in flight over K streams,
-// a device copy of the rank's own records standing in for the all-to-all, resolve + history slab on another stream - so that what is timed
-// is the library's and the driver's host cost per frame, not a scripting language's.  period_ms: wall time per frame; issue_ms: host time
-// to queue a frame (where the two agree the loop is host-bound).
-int ycge_debug_resident_loop(ycge_ctx *c, int32_t frames, double *period_ms, double *issue_ms)
-{
-    if (!c || frames <= 0 || !period_ms || !issue_ms) return YCGE_ERR_INVALID_ARG;
-    { const int jr = join_async(c); if (jr != YCGE_OK) return jr; }
-    int rc = ensure_resident(c);
-    if (rc != YCGE_OK) return rc;
-    const int K = (int)c->rsets.size();
-    size_t ns = 0, nr = 0;
-    for (int64_t v : c->halo_send_counts) ns += (size_t)v;
-    for (int64_t v : c->halo_recv_counts) nr += (size_t)v;
-    const size_t sb = (ns ? ns : 1) * 16, rb = (nr ? nr : 1) * 16, hb = (size_t)c->tiles_per_rank_padded * 256 * 3 * sizeof(float);
-    std::vector<hipStream_t> st((size_t)K, nullptr);
-    std::vector<hipEvent_t> evt((size_t)K, nullptr), evr((size_t)K, nullptr);
-    std::vector<void *> send((size_t)K, nullptr), recv((size_t)K, nullptr), hist((size_t)K, nullptr);
-    hipStream_t comm = nullptr;
-    auto cleanup = [&]() {
-        (void)hipDeviceSynchronize();
-        for (int k = 0; k < K; k++) { if (st[k]) (void)hipStreamDestroy(st[k]); if (evt[k]) (void)hipEventDestroy(evt[k]); if (evr[k]) (void)hipEventDestroy(evr[k]);
-                                      if (send[k]) (void)hipFree(send[k]); if (recv[k]) (void)hipFree(recv[k]); if (hist[k]) (void)hipFree(hist[k]); }
-        if (comm) (void)hipStreamDestroy(comm);
-    };
-#define LOOP_TRY(call) do { if ((call) != hipSuccess) { cleanup(); return c->fail(YCGE_ERR_DEVICE, "%s failed", #call); } } while (0)
-    {   // the exchange + resolve stream at the highest priority (YCGE_RES_LOOP_PRIO=0: plain): its small kernels must not queue behind a
-        // trace that happens to share its hardware queue - a resolve held up that way holds up the trace K frames later
-        int lo = 0, hi = 0;
-        const char *pe = getenv("YCGE_RES_LOOP_PRIO");
-        if ((!pe || atoi(pe) != 0) && hipDeviceGetStreamPriorityRange(&lo, &hi) == hipSuccess && hi != lo) LOOP_TRY(hipStreamCreateWithPriority(&comm, hipStreamNonBlocking, hi));
-        else LOOP_TRY(hipStreamCreateWithFlags(&comm, hipStreamNonBlocking));
-    }
-    for (int k = 0; k < K; k++) {
-        LOOP_TRY(hipStreamCreateWithFlags(&st[k], hipStreamNonBlocking));
-        LOOP_TRY(hipEventCreateWithFlags(&evt[k], hipEventDisableTiming)); LOOP_TRY(hipEventCreateWithFlags(&evr[k], hipEventDisableTiming));
-        LOOP_TRY(hipMalloc(&send[k], sb)); LOOP_TRY(hipMalloc(&recv[k], rb)); LOOP_TRY(hipMalloc(&hist[k], hb));
-        LOOP_TRY(hipMemset(send[k], 0, sb)); LOOP_TRY(hipMemset(recv[k], 0, rb));
-    }
-    std::deque<int> issued;
-    // YCGE_RES_LOOP_COMM=slot: exchange and resolve of a frame on the stream of ITS ring slot (the next trace there waits for that resolve
-    // anyway) - K streams in all instead of K + 1: no stream shares a hardware queue with a trace while K <= 4
-    const char *ce = getenv("YCGE_RES_LOOP_COMM");
-    const bool comm_on_slot = ce && ce[0] == 's';
-    auto resolve = [&](int k) -> int {
-        hipStream_t cs = comm_on_slot ? st[k] : comm;
-        if (!comm_on_slot && hipStreamWaitEvent(cs, evt[k], 0) != hipSuccess) return YCGE_ERR_DEVICE;
-        if (hipMemcpyAsync(recv[k], send[k], sb < rb ? sb : rb, hipMemcpyDeviceToDevice, cs) != hipSuccess) return YCGE_ERR_DEVICE;      // stands in for the all-to-all
-        const int r2 = ycge_resolve_tiles_resident(c, recv[k], hist[k], cs, nullptr);
-        if (r2 != YCGE_OK) return r2;
-        return hipEventRecord(evr[k], cs) == hipSuccess ? YCGE_OK : YCGE_ERR_DEVICE;
-    };
-    int64_t i = 0;
-    // YCGE_RES_LOOP_TIMELINE=1: timing events around the last 16 frames' traces (begin: behind the stream's waits; end: behind the halo
-    // gather), printed relative to the first - how the K traces in flight really lie to each other
-    const bool timeline = getenv("YCGE_RES_LOOP_TIMELINE") != nullptr;
-    std::vector<hipEvent_t> tl_b, tl_e;
-    // YCGE_RES_LOOP_EAGER=0: a frame's exchange + resolve are queued only when its ring slot is needed again (round 4's loop).  Default: queued
-    // right behind its trace (they wait for the trace's event on their own stream) - the trace that takes the slot K frames later then finds
-    // the resolve done instead of waiting for one that was queued a moment ago and runs starved beside the traces in flight
-    const char *ee = getenv("YCGE_RES_LOOP_EAGER");
-    const bool eager = !(ee && atoi(ee) == 0);
-    auto frame = [&]() -> int {
-        const int k = (int)(i++ % K);
-        if ((int)issued.size() == K) { const int r2 = resolve(issued.front()); issued.pop_front(); if (r2 != YCGE_OK) return r2; }
-        if (hipStreamWaitEvent(st[k], evr[k], 0) != hipSuccess) return YCGE_ERR_DEVICE;
-        const bool mark = timeline && i > 12 + (int64_t)frames - 16;
-        if (mark) { hipEvent_t eb = nullptr; if (hipEventCreate(&eb) != hipSuccess || hipEventRecord(eb, st[k]) != hipSuccess) return YCGE_ERR_DEVICE; tl_b.push_back(eb); }
-        const int r2 = ycge_trace_tiles_resident(c, send[k], st[k], nullptr);
-        if (r2 != YCGE_OK) return r2;
-        issued.push_back(k);
-        if (mark) { hipEvent_t ee2 = nullptr; if (hipEventCreate(&ee2) != hipSuccess || hipEventRecord(ee2, st[k]) != hipSuccess) return YCGE_ERR_DEVICE; tl_e.push_back(ee2); }
-        if (hipEventRecord(evt[k], st[k]) != hipSuccess) return YCGE_ERR_DEVICE;
-        if (eager) { const int r3 = resolve(issued.front()); issued.pop_front(); if (r3 != YCGE_OK) return r3; }
-        return YCGE_OK;
-    };
-    auto drain = [&]() -> int { while (!issued.empty()) { const int r2 = resolve(issued.front()); issued.pop_front(); if (r2 != YCGE_OK) return r2; } return YCGE_OK; };
-    // YCGE_RES_LOOP_BATCH=n: the frames n at a time in one launch (ycge_trace_tiles_resident_batch), consecutive batches on two streams
-    const int nb = getenv("YCGE_RES_LOOP_BATCH") ? atoi(getenv("YCGE_RES_LOOP_BATCH")) : 0;
-    if (nb > 1) {
-        if (nb > K || nb > ycge_ctx::kBatchMax) { cleanup(); return c->fail(YCGE_ERR_INVALID_ARG, "YCGE_RES_LOOP_BATCH=%d needs a ring of at least that many sets (and <= %d)", nb, ycge_ctx::kBatchMax); }
-        float pose[6 * ycge_ctx::kBatchMax];
-        { std::lock_guard<std::mutex> g(c->cam_lock); for (int k = 0; k < nb; k++) { pose[6 * k] = c->cam_pos[0]; pose[6 * k + 1] = c->cam_pos[1]; pose[6 * k + 2] = c->cam_pos[2]; pose[6 * k + 3] = c->yaw; pose[6 * k + 4] = c->pitch; pose[6 * k + 5] = c->fov_deg; } }
-        int64_t batches = 0;
-        auto batch = [&]() -> int {
-            while ((int)issued.size() + nb > K) { const int r2 = resolve(issued.front()); issued.pop_front(); if (r2 != YCGE_OK) return r2; }
-            hipStream_t bs = st[(size_t)((batches++ & 1) * (K >= 3 ? 2 : 1))];          // (streams 0 and 2 of the loop: neighbours share a hardware queue on this runtime - 4 queues, round robin)
-            void *sends[ycge_ctx::kBatchMax];
-            int slots[ycge_ctx::kBatchMax];
-            for (int k = 0; k < nb; k++) { slots[k] = (int)(i++ % K); sends[k] = send[(size_t)slots[k]]; if (hipStreamWaitEvent(bs, evr[(size_t)slots[k]], 0) != hipSuccess) return YCGE_ERR_DEVICE; }
-            const bool mark = timeline && batches > 4 + (int64_t)((frames + nb - 1) / nb) - 10;
-            if (mark) { hipEvent_t eb = nullptr; if (hipEventCreate(&eb) != hipSuccess || hipEventRecord(eb, bs) != hipSuccess) return YCGE_ERR_DEVICE; tl_b.push_back(eb); }
-            const int r2 = ycge_trace_tiles_resident_batch(c, nb, pose, sends, bs);
-            if (r2 != YCGE_OK) return r2;
-            if (mark) { hipEvent_t ee2 = nullptr; if (hipEventCreate(&ee2) != hipSuccess || hipEventRecord(ee2, bs) != hipSuccess) return YCGE_ERR_DEVICE; tl_e.push_back(ee2); }
-            for (int k = 0; k < nb; k++) { issued.push_back(slots[k]); if (hipEventRecord(evt[(size_t)slots[k]], bs) != hipSuccess) return YCGE_ERR_DEVICE; }
-            // the frames of the batch before the last are resolved NOW (they run beside the launches in flight, starved: a batch that re-uses
-            // their sets should find them done - a ring of three batches' sets lets consecutive launches lie side by side)
-            while ((int)issued.size() > (eager ? 0 : 2 * nb)) { const int r3 = resolve(issued.front()); issued.pop_front(); if (r3 != YCGE_OK) return r3; }
-            return YCGE_OK;
-        };
-        const int nbat = (frames + nb - 1) / nb;
-        for (int w = 0; w < 4 && rc == YCGE_OK; w++) rc = batch();
-        if (rc == YCGE_OK) rc = drain();
-        if (rc != YCGE_OK) { cleanup(); return rc; }
-        LOOP_TRY(hipDeviceSynchronize());
-        const auto b0 = std::chrono::steady_clock::now();
-        for (int f = 0; f < nbat && rc == YCGE_OK; f++) rc = batch();
-        if (rc == YCGE_OK) rc = drain();
-        const auto b1 = std::chrono::steady_clock::now();
-        if (rc != YCGE_OK) { cleanup(); return rc; }
-        LOOP_TRY(hipDeviceSynchronize());
-        const auto b2 = std::chrono::steady_clock::now();
-        *issue_ms = std::chrono::duration<double, std::milli>(b1 - b0).count() / (nbat * nb);
-        *period_ms = std::chrono::duration<double, std::milli>(b2 - b0).count() / (nbat * nb);
-        for (size_t q = 0; q < tl_b.size() && q < tl_e.size(); q++) {
-            float b = 0.0f, e2 = 0.0f;
-            (void)hipEventElapsedTime(&b, tl_b[0], tl_b[q]); (void)hipEventElapsedTime(&e2, tl_b[0], tl_e[q]);
-            fprintf(stderr, "  batch %2zu: begin %7.3f ms  end %7.3f ms  duration %6.3f\n", q, b, e2, e2 - b);
-        }
-        for (hipEvent_t ev : tl_b) (void)hipEventDestroy(ev);
-        for (hipEvent_t ev : tl_e) (void)hipEventDestroy(ev);
-        cleanup();
-        return YCGE_OK;
-    }
-    for (int w = 0; w < 12 && rc == YCGE_OK; w++) rc = frame();
-    if (rc == YCGE_OK) rc = drain();
-    if (rc != YCGE_OK) { cleanup(); return rc; }
-    LOOP_TRY(hipDeviceSynchronize());
-    const auto t0 = std::chrono::steady_clock::now();
-    for (int f = 0; f < frames && rc == YCGE_OK; f++) rc = frame();
-    if (rc == YCGE_OK) rc = drain();
-    const auto t1 = std::chrono::steady_clock::now();
-    if (rc != YCGE_OK) { cleanup(); return rc; }
-    LOOP_TRY(hipDeviceSynchronize());
-    const auto t2 = std::chrono::steady_clock::now();
-#undef LOOP_TRY
-    *issue_ms = std::chrono::duration<double, std::milli>(t1 - t0).count() / frames;
-    *period_ms = std::chrono::duration<double, std::milli>(t2 - t0).count() / frames;
-    for (size_t q = 0; q < tl_b.size() && q < tl_e.size(); q++) {
-        float b = 0.0f, e2 = 0.0f;
-        (void)hipEventElapsedTime(&b, tl_b[0], tl_b[q]); (void)hipEventElapsedTime(&e2, tl_b[0], tl_e[q]);
-        fprintf(stderr, "  trace %2zu (slot %zu): begin %7.3f ms  end %7.3f ms  duration %6.3f\n", q, q % (size_t)K, b, e2, e2 - b);
-    }
-    for (hipEvent_t ev : tl_b) (void)hipEventDestroy(ev);
-    for (hipEvent_t ev : tl_e) (void)hipEventDestroy(ev);
-    cleanup();
-    return YCGE_OK;
-}
-
-// the halo lists of (hiW, hiH, rank, world) as pure host code (CPU tests hold them to tiles.py): counts per peer, then the pixel lists
-int ycge_host_halo_layout(int32_t hiW, int32_t hiH, int32_t rank, int32_t world, int64_t *send_counts, int64_t *recv_counts, uint32_t *send_px, uint32_t *recv_px, int64_t capacity)
-{
-    if (hiW <= 0 || hiH <= 0 || world < 1 || rank < 0 || rank >= world || !send_counts || !recv_counts) return YCGE_ERR_INVALID_ARG;
-    std::vector<int64_t> sc, rcv; std::vector<uint32_t> spx, rpx;
-    halo_layout(hiW, hiH, rank, world, sc, rcv, spx, rpx);
-    for (int r = 0; r < world; r++) { send_counts[r] = sc[(size_t)r]; recv_counts[r] = rcv[(size_t)r]; }
-    if (send_px && (int64_t)spx.size() <= capacity) std::memcpy(send_px, spx.data(), spx.size() * 4);
-    if (recv_px && (int64_t)rpx.size() <= capacity) std::memcpy(recv_px, rpx.data(), rpx.size() * 4);
-    return ((int64_t)spx.size() <= capacity && (int64_t)rpx.size() <= capacity) || (!send_px && !recv_px) ? YCGE_OK : YCGE_ERR_INVALID_ARG;
-}
-
-int ycge_read_buffer(ycge_ctx *c, int32_t which, void *dst, size_t bytes)
-{
-    if (!c) return YCGE_ERR_INVALID_ARG;
-    if (!dst) return c->fail(YCGE_ERR_INVALID_ARG, "null destination");
-    HIP_TRY(c, hipSetDevice(c->device));
-    const size_t n = (size_t)c->hiW * c->hiH;
-    const void *src = nullptr; size_t want = 0;
-    switch (which) {
-    case YCGE_BUF_RAYS: src = c->dbg_rays.p; want = n * 24; break;
-    case YCGE_BUF_PRIM_ID: src = c->dbg_prim.p; want = n * 4; break;
-    case YCGE_BUF_SUB_ID: src = c->dbg_sub.p; want = n * 4; break;
-    case YCGE_BUF_HIT_T: src = c->dbg_hit_t.p; want = n * 4; break;
-    case YCGE_BUF_RNG_STATE: src = c->dbg_rng.p; want = n * 8; break;
-    case YCGE_BUF_CURRENT_HDR: src = c->current_hdr.p; want = n * 12; break;
-    case YCGE_BUF_G_ALBEDO: src = c->g_albedo.p; want = n * 12; break;
-    case YCGE_BUF_G_NORMAL: src = c->g_normal.p; want = n * 12; break;
-    case YCGE_BUF_G_DEPTH: src = c->g_depth.p; want = n * 4; break;
-    case YCGE_BUF_SKY_MASK: src = c->sky.p; want = n; break;
-    case YCGE_BUF_TAA_HISTORY: src = c->taa_hist.p; want = n * 12; break;
-    case YCGE_BUF_PREV_NORMAL: src = c->prev_normal.p; want = n * 12; break;
-    case YCGE_BUF_PREV_DEPTH: src = c->prev_depth.p; want = n * 4; break;
-    case YCGE_BUF_PREV_SKY: src = c->prev_sky.p; want = n; break;
-    case YCGE_BUF_DENOISED:
-        if (!c->denoised) return c->fail(YCGE_ERR_INVALID_ARG, "no denoised frame yet: render with an SDR output buffer first");
-        src = c->denoised; want = n * 12; break;
-    default: return c->fail(YCGE_ERR_INVALID_ARG, "unknown buffer %d", which);
-    }
-    if (!src) return c->fail(YCGE_ERR_INVALID_ARG, "buffer %d needs config.capture_debug", which);
-    if (bytes != want) return c->fail(YCGE_ERR_INVALID_ARG, "buffer %d is %zu bytes, caller passed %zu", which, want, bytes);
-    { const int jr = join_async(c); if (jr != YCGE_OK) return jr; }
-    HIP_TRY(c, hipStreamSynchronize(c->stream));
-    return copy_out(c, dst, src, want);
-}
-
-static int accel_view(ycge_ctx *c, int32_t which, int32_t index, const void **p, size_t *n)
-{
-    if (c->scene_tree_on_device && (which == YCGE_ACCEL_SCENE_NODES || which == YCGE_ACCEL_SCENE_LEAF_INDEX)) {
-        // the tree was built on the device: fetch the reference-format copy the first time somebody asks for it
-        c->scene_tree.nodes.resize((size_t)c->dev_tree_nodes);
-        c->scene_tree.leaf_index.resize((size_t)c->dev_tree_items);
-        if (hipSetDevice(c->device) != hipSuccess || hipStreamSynchronize(c->stream) != hipSuccess ||
-            copy_out(c, c->scene_tree.nodes.data(), c->d_bvh_ref.p, (size_t)c->dev_tree_nodes * sizeof(RefNode)) != YCGE_OK ||
-            copy_out(c, c->scene_tree.leaf_index.data(), c->d_scene_leaf.p, (size_t)c->dev_tree_items * 4) != YCGE_OK)
-            return -1;
-        c->scene_tree.root = 0;
-        c->scene_tree_on_device = false;
-    }
-    switch (which) {
-    case YCGE_ACCEL_SCENE_NODES: *p = c->scene_tree.nodes.data(); *n = c->scene_tree.nodes.size() * sizeof(RefNode); return 0;
-    case YCGE_ACCEL_SCENE_LEAF_INDEX: *p = c->scene_tree.leaf_index.data(); *n = c->scene_tree.leaf_index.size() * 4; return 0;
-    case YCGE_ACCEL_MESH_NODES:
-        if (index < 0 || index >= (int)c->meshes.size()) return -1;
-        *p = c->meshes[index].tree.nodes.data(); *n = c->meshes[index].tree.nodes.size() * sizeof(RefNode); return 0;
-    case YCGE_ACCEL_MESH_LEAF_INDEX:
-        if (index < 0 || index >= (int)c->meshes.size()) return -1;
-        *p = c->meshes[index].tree.leaf_index.data(); *n = c->meshes[index].tree.leaf_index.size() * 4; return 0;
-    }
-    return -1;
-}
-int ycge_accel_size(ycge_ctx *c, int32_t which, int32_t index, size_t *bytes)
-{
-    const void *p; size_t n;
-    if (!c || !bytes) return YCGE_ERR_INVALID_ARG;
-    if (!c->have_scene) return c->fail(YCGE_ERR_NO_SCENE, "no scene uploaded");
-    if (accel_view(c, which, index, &p, &n)) return c->fail(YCGE_ERR_INVALID_ARG, "bad accel selector");
-    *bytes = n;
-    return YCGE_OK;
-}
-int ycge_read_accel(ycge_ctx *c, int32_t which, int32_t index, void *dst, size_t bytes)
-{
-    const void *p; size_t n;
-    if (!c || !dst) return YCGE_ERR_INVALID_ARG;
-    if (!c->have_scene) return c->fail(YCGE_ERR_NO_SCENE, "no scene uploaded");
-    if (accel_view(c, which, index, &p, &n) || n != bytes) return c->fail(YCGE_ERR_INVALID_ARG, "bad accel selector or size");
-    std::memcpy(dst, p, n);
     return YCGE_OK;
 }
 
