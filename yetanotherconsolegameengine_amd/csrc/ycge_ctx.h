@@ -41,7 +41,7 @@ int ycge_launch_scene_walk(const void *nodes, int n_inner, const uint32_t *leaf_
 int ycge_launch_order_blocks(uint32_t *cost, uint32_t n, uint32_t policy, uint32_t split_top, uint32_t fan_class, uint32_t fan_cap, uint32_t next_slot, uint32_t skip_mask, uint32_t *order_ws,
                              uint32_t *order, hipStream_t stream, int small_groups = 0, uint32_t n_frames = 0, uint32_t *snap = nullptr);
 int ycge_launch_taa_tiles(const ycge::TaaParams *T, const ycge::FrameParams *P, const float *current, const float *normal, const float *depth, const uint8_t *sky,
-                          float *hist, float *prev_normal, float *prev_depth, uint8_t *prev_sky, hipStream_t stream);
+                          float *hist, float *prev_normal, float *prev_depth, uint8_t *prev_sky, float *slab, hipStream_t stream);
 int ycge_launch_halo(int scatter, float *hdr, uint8_t *sky, const uint32_t *px, uint32_t n, void *records, hipStream_t stream);
 int ycge_launch_pack_history(const ycge::FrameParams *P, const float *hist, float *slab, hipStream_t stream);
 int ycge_launch_unpack_history(const float *all_slabs, size_t slab_floats_per_rank, int hiW, int hiH, int tiles_x, int n_tiles, int world_size, float *hist, hipStream_t stream);

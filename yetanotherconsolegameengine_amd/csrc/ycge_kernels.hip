@@ -1488,11 +1488,18 @@ __global__ __launch_bounds__(256) void k_taa(const TaaParams T, const float *__r
 // profiles/r05: the resolve that the next launch on the same ring slots waits for); a single wavefront takes any slot that frees.
 __global__ __launch_bounds__(64) void k_taa_tiles(const TaaParams T, const FrameParams P, const float *__restrict__ current, const float *__restrict__ normal,
                                                   const float *__restrict__ depth, const uint8_t *__restrict__ sky, float *__restrict__ hist,
-                                                  float *__restrict__ prev_normal, float *__restrict__ prev_depth, uint8_t *__restrict__ prev_sky)
+                                                  float *__restrict__ prev_normal, float *__restrict__ prev_depth, uint8_t *__restrict__ prev_sky,
+                                                  float *__restrict__ slab /* or null: the resolved history of the rank's tiles, k_pack_history's layout - one launch less in the resolve chain */)
 {
     int px, py, lx, ly;
-    if (!tile_pixel_wl(P, (int)(blockIdx.x >> 2), (int)(blockIdx.x & 3u), (int)threadIdx.x, px, py, lx, ly)) return;
+    const int k = (int)(blockIdx.x >> 2);
+    if (!tile_pixel_wl(P, k, (int)(blockIdx.x & 3u), (int)threadIdx.x, px, py, lx, ly)) return;
     taa_pixel(T, px, py, current, normal, depth, sky, hist, prev_normal, prev_depth, prev_sky);
+    if (slab) {         // (this thread's own stores, read back in program order)
+        const size_t i = (size_t)px + (size_t)py * P.hiW;
+        float *s = slab + ((size_t)k * 256 + (size_t)(ly * YCGE_TILE_W + lx)) * 3;
+        s[0] = hist[3 * i]; s[1] = hist[3 * i + 1]; s[2] = hist[3 * i + 2];
+    }
 }
 // halo records {hdr rgb, sky} of the listed pixels: out of this rank's frame buffers for the ranks that need them (gather), and the
 // records received from the owners into this rank's frame buffers (scatter).  The lists are layout arithmetic (host: halo_layout; the
@@ -1769,10 +1776,10 @@ int ycge_launch_taa(const ycge::TaaParams *T, const float *current, const float 
 }
 
 int ycge_launch_taa_tiles(const ycge::TaaParams *T, const ycge::FrameParams *P, const float *current, const float *normal, const float *depth, const uint8_t *sky,
-                          float *hist, float *prev_normal, float *prev_depth, uint8_t *prev_sky, hipStream_t stream)
+                          float *hist, float *prev_normal, float *prev_depth, uint8_t *prev_sky, float *slab, hipStream_t stream)
 {
     if (P->n_owned_tiles <= 0) return 0;
-    hipLaunchKernelGGL(ycge::k_taa_tiles, dim3((unsigned)P->n_owned_tiles * 4u), dim3(64), 0, stream, *T, *P, current, normal, depth, sky, hist, prev_normal, prev_depth, prev_sky);
+    hipLaunchKernelGGL(ycge::k_taa_tiles, dim3((unsigned)P->n_owned_tiles * 4u), dim3(64), 0, stream, *T, *P, current, normal, depth, sky, hist, prev_normal, prev_depth, prev_sky, slab);
     return (int)hipGetLastError();
 }
 int ycge_launch_halo(int scatter, float *hdr, uint8_t *sky, const uint32_t *px, uint32_t n, void *records, hipStream_t stream)

@@ -292,16 +292,12 @@ int ycge_resolve_tiles_resident(ycge_ctx *c, const void *d_halo_recv, void *d_hi
     T.reset = did_reset ? 1 : 0;
     FrameParams P;
     fill_frame_params(c, P, fs.frame, fs.pos, fs.yaw, fs.pitch, fs.fov);
-    e = ycge_launch_taa_tiles(&T, &P, rs->hdr.p, rs->normal.p, rs->depth.p, rs->sky.p, c->taa_hist.p, c->prev_normal.p, c->prev_depth.p, c->prev_sky.p, stream);
+    e = ycge_launch_taa_tiles(&T, &P, rs->hdr.p, rs->normal.p, rs->depth.p, rs->sky.p, c->taa_hist.p, c->prev_normal.p, c->prev_depth.p, c->prev_sky.p, (float *)d_history_slab /* packed by the same launch */, stream);
     if (e != 0) return c->fail(YCGE_ERR_DEVICE, "k_taa_tiles launch failed: %s", hipGetErrorString((hipError_t)e));
     if (st) HIP_TRY(c, hipEventRecord(c->ev[2], stream));
     c->taa_valid = true;
     c->last_cam[0] = fs.pos[0]; c->last_cam[1] = fs.pos[1]; c->last_cam[2] = fs.pos[2]; c->last_yaw = fs.yaw; c->last_pitch = fs.pitch;
     HIP_TRY(c, hipEventRecord(rs->resolved, stream)); rs->resolved_used = true;
-    if (d_history_slab) {
-        e = ycge_launch_pack_history(&P, c->taa_hist.p, (float *)d_history_slab, stream);
-        if (e != 0) return c->fail(YCGE_ERR_DEVICE, "k_pack_history launch failed: %s", hipGetErrorString((hipError_t)e));
-    }
     if (st) {
         HIP_TRY(c, hipStreamSynchronize(stream));
         std::memset(st, 0, sizeof *st);
