@@ -607,6 +607,15 @@ def test_frames_in_flight_refuse_what_they_cannot_keep(product_lib):
         r.RenderAsync(sdr_slot=0)
     r.UploadScene(flat)
     r.RenderAsync(); r.RenderAsync(sdr_slot=0); r.Wait()          # ... and the context is none the worse for it
+    # a frame in flight fills its SDR array while the caller runs on: a PAGEABLE array is refused (the device never writes memory whose
+    # mapping the library does not control) - the synchronous call takes one and stages it
+    import ctypes as C
+    plain = np.zeros((18, 64, 2, 3), dtype=np.float32)
+    rc = r.L.ycge_render_frame_async_sdr(r.ctx, plain.ctypes.data_as(C.POINTER(C.c_float)))
+    assert rc == abi.YCGE_ERR_INVALID_ARG and b"page-locked" in r.L.ycge_last_error(r.ctx)
+    held = r.RenderAsync(sdr_slot=1); r.Wait()
+    r._check(r.L.ycge_render_frame(r.ctx, plain.ctypes.data_as(C.POINTER(C.c_float)), None))
+    assert plain.any() and held.any() and plain.shape == held.shape
     r.close()
 
 
