@@ -466,14 +466,22 @@ def main():
             rs_launches.append((e0, e1, n_frames))
             return e1
 
+        # everything a frame's exchange needs, made ONCE: the host's cost per frame is part of a rank's period (0.12 ms a frame with views, split
+        # lists and stream contexts rebuilt per call - more than the 0.09 ms the GPU needs in the batched form; `host_issue_ms_per_frame`)
+        rs_recv_v = [t[:sum(r_cnt) * 4] for t in h_recv]; rs_send_v = [t[:sum(s_cnt) * 4] for t in h_send]
+        rs_out_split = [c * 4 for c in r_cnt]; rs_in_split = [c * 4 for c in s_cnt]
+        rs_recv_p = [t.data_ptr() for t in h_recv]; rs_send_p = [t.data_ptr() for t in h_send]
+        rs_hist_p = [t.data_ptr() for t in h_hist]; rs_all_p = [t.data_ptr() for t in h_all]
+        rs_trace_sp = [st.cuda_stream for st in rs_traces]; s_comm_p = s_comm.cuda_stream
+        torch.cuda.set_stream(s_comm)          # the collectives below run on torch's CURRENT stream: the exchange stream for the life of the loop (the library's calls take their stream as an argument)
+
         def rs_resolve(k):
-            with torch.cuda.stream(s_comm):
-                s_comm.wait_event(rs_ev_t[k])
-                dist.all_to_all_single(h_recv[k][:sum(r_cnt) * 4], h_send[k][:sum(s_cnt) * 4], output_split_sizes=[c * 4 for c in r_cnt], input_split_sizes=[c * 4 for c in s_cnt])
-                r.resolve_tiles_resident(h_recv[k].data_ptr(), h_hist[k].data_ptr(), s_comm.cuda_stream)
-                dist.all_gather_into_tensor(h_all[k], h_hist[k])          # whoever shows the frame: here every rank (a gather to rank 0 moves an eighth of it)
-                r.unpack_history(h_all[k].data_ptr(), s_comm.cuda_stream)
-                rs_ev_r[k].record(s_comm)
+            s_comm.wait_event(rs_ev_t[k])
+            dist.all_to_all_single(rs_recv_v[k], rs_send_v[k], output_split_sizes=rs_out_split, input_split_sizes=rs_in_split)
+            r.resolve_tiles_resident(rs_recv_p[k], rs_hist_p[k], s_comm_p)
+            dist.all_gather_into_tensor(h_all[k], h_hist[k])          # whoever shows the frame: here every rank (a gather to rank 0 moves an eighth of it)
+            r.unpack_history(rs_all_p[k], s_comm_p)
+            rs_ev_r[k].record(s_comm)
 
     def rs_issue_batch(rr):
         """the frames whose poses wait in rs_poses, in ONE launch; consecutive batches on two streams; resolves issued as soon as a batch is two batches old"""
@@ -484,15 +492,14 @@ def main():
         n_issued[0] += n
         st = rs_traces[(rs_batches[0] & 1) * (2 if K >= 3 else 1)]          # (neighbouring streams tend to share a hardware queue: 4 queues, round robin)
         rs_batches[0] += 1
-        with torch.cuda.stream(st):
-            for k in slots:
-                st.wait_event(rs_ev_r[k])
-            e1 = rs_bracket(st, n)
-            rr.trace_tiles_resident_batch(list(rs_poses), [h_send[k].data_ptr() for k in slots], st.cuda_stream)
-            if e1 is not None:
-                e1.record(st)
-            for k in slots:
-                rs_ev_t[k].record(st)
+        for k in slots:
+            st.wait_event(rs_ev_r[k])
+        e1 = rs_bracket(st, n)
+        rr.trace_tiles_resident_batch(list(rs_poses), [rs_send_p[k] for k in slots], st.cuda_stream)
+        if e1 is not None:
+            e1.record(st)
+        for k in slots:
+            rs_ev_t[k].record(st)
         rs_issued.extend(slots)
         rs_poses.clear()
         # exchange + resolve of the batch's frames are queued NOW, behind its launch (they wait for its event on the exchange stream): the
@@ -514,13 +521,13 @@ def main():
         if resident and rr is r and not want_stats:
             k = n_issued[0] % K
             n_issued[0] += 1
-            with torch.cuda.stream(rs_traces[k]):
-                rs_traces[k].wait_event(rs_ev_r[k])          # slot k's buffers were last read by the exchange of K frames ago
-                e1 = rs_bracket(rs_traces[k], 1)
-                rr.trace_tiles_resident(h_send[k].data_ptr(), rs_traces[k].cuda_stream)
-                if e1 is not None:
-                    e1.record(rs_traces[k])
-                rs_ev_t[k].record(rs_traces[k])
+            st = rs_traces[k]
+            st.wait_event(rs_ev_r[k])          # slot k's buffers were last read by the exchange of K frames ago
+            e1 = rs_bracket(st, 1)
+            rr.trace_tiles_resident(rs_send_p[k], rs_trace_sp[k])
+            if e1 is not None:
+                e1.record(st)
+            rs_ev_t[k].record(st)
             rs_resolve(k)          # queued right behind its trace (waits for rs_ev_t[k] on the exchange stream): done long before slot k is taken again
             return 0.0, 0.0
         if not pipelined or want_stats:
