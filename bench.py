@@ -249,13 +249,21 @@ def child_command(form_name, n, port, script, python=None):
     return [python, str(script)]
 
 
-def launch_ranks(n, argv, chain=FORM_CHAIN, extra=BATCHED_LEG, script=None, timeout=1500, env=None, log=sys.stderr):
+FORM_TIMEOUT_S = 420
+
+
+def launch_ranks(n, argv, chain=FORM_CHAIN, extra=BATCHED_LEG, script=None, timeout=None, env=None, log=sys.stderr):
     """Runs the forms of `chain` one after the other, each as FRESH child processes, until one prints the bench line; returns (that line
     as a dict with `forms_tried` added - or None -, the list of attempts).  `argv` = this invocation's own arguments (forwarded; --form /
     --batch are replaced).  After a headline from the tile-resident form, `extra` runs as one more job and its figures are attached as
-    `batched`.  A job that outlives `timeout` is ended as a whole: the launcher AND its ranks are one process group of their own."""
+    `batched`.  A job that outlives `timeout` is ended as a whole: the launcher AND its ranks are one process group of their own.
+    The default, FORM_TIMEOUT_S, is a hang detector and not a budget: a form's job takes 7-10 s on a warm one-GPU box
+    (profiles/r05/a_forms_self_launch.txt) and a cold box adds a minute or two of first `import torch`; a form that deadlocks on its first
+    real node must leave the forms after it the time to produce the line (YCGE_BENCH_FORM_TIMEOUT overrides, seconds)."""
     import signal
     import subprocess
+    if timeout is None:
+        timeout = float(os.environ.get("YCGE_BENCH_FORM_TIMEOUT", FORM_TIMEOUT_S))
     script = script or Path(__file__).resolve()
     base = strip_flag(list(argv), ("--form", "--batch"))
     env = dict(os.environ if env is None else env)
