@@ -41,7 +41,7 @@ echo "== post stage: exact and waived (config.atrous_inplace_exact)"; timeout 60
 echo "== post stage bands"; for a in "4 1 270" "5 2 540"; do set -- $a; CFG=$1 SS=$2 NB=$3 timeout 300 python profiles/post_bands.py 2>&1 | grep -E "^post|launch span|chain:"; done
 timeout 300 python profiles/mega_prof.py 4 2>&1 | grep -v amdgpu.ids > gpurun_out/mega_prof_$TAG.txt; grep -E "trace_ms|span|slot time|>= 256" gpurun_out/mega_prof_$TAG.txt
 echo "== voxel worlds: the walk tree against the scene tree, the light loop beside the trace, walk_phase (lit config 5, same call)"
-for v in "-" "YCGE_NO_WALK_TREE=1" "YCGE_NO_LIGHTS_BESIDE=1" "YCGE_LIB=$REPO/yetanotherconsolegameengine_amd/lib/var_nowalkphase.so" "-"; do
+for v in "-" "YCGE_NO_WALK_TREE=1" "YCGE_NO_LIGHTS_BESIDE=1" "YCGE_LIB=$REPO/yetanotherconsolegameengine_amd/lib/var_nowalkphase.so" "YCGE_LIB=$REPO/yetanotherconsolegameengine_amd/lib/var_walk1.so" "-"; do
   ( if [ "$v" != "-" ]; then export "$v"; fi; echo -n "$v: "
     timeout 300 python bench.py --config 5 --t01 0.5 --steps 20 --warmup 3 --no-cpu-baseline --no-post 2>/dev/null | python -c "import sys,json; d=json.loads(sys.stdin.read()); print(d['ms_per_step'],'ms/frame trace', d['roofline']['mean_launch_ms'], 'moving', d['moving_camera']['trace_ms']['median'], 'in flight', d['frames_in_flight']['ms_per_step'])" )
 done

@@ -1066,8 +1066,62 @@ __device__ __forceinline__ int tree_phase(const SceneDev &S, uint32_t &cur, int 
 // masks: tree_phase's loop body is 1 600 instructions of which a voxel world's lanes enter 200, and every block skipped costs its branch.
 enum : int { TREE_OTHER = 3 };
 #ifndef YCGE_WALK_PHASE
-#define YCGE_WALK_PHASE 1          // 0: A/B build - the walk tree through tree_phase's general loop
+#define YCGE_WALK_PHASE 2          // 0: A/B build - the walk tree through tree_phase's general loop; 1: round 4's loop (a pop or a node visit per iteration); 2: below
 #endif
+#if YCGE_WALK_PHASE == 2
+// Round 5's form of the loop.  What changed, and why it is the same walk:
+//  * the stack entries a closer hit has made useless (`closest >= tNear` fails, BVH.cs:120-123) are discarded in a loop of their own - a
+//    dozen instructions a pop - instead of one iteration of the whole body each: a ray that comes back from a grid with a hit finds
+//    its three to five stacked siblings all farther than the hit, and round 4's loop spent a node step's issue slots on each;
+//  * the twelve slab products of a node as six packed operations (v_pk_add_f32 / v_pk_mul_f32 - a - o is a + (-o) bit for bit), as mesh_walk
+//    does for the mesh tree: WalkNode keeps its planes in the pairs this needs;
+//  * no result code carried through the loop: why a lane left is read off (cur, sp) afterwards.
+// (A lane may now report a grid, or the end of its walk, in the round its budget ran out in instead of the next: which round a step
+// falls in never changes a result.)
+template <class STK>
+__device__ __forceinline__ int walk_phase(const SceneDev &S, uint32_t &cur, STK &st, F3 o, F3 inv, float tmin, float closest, int &parked_grid, int &parked_prim, Work &w, int budget)
+{
+    const f32x2 oxy = {o.x, o.y}, ozz = {o.z, o.z}, ixy = {inv.x, inv.y}, izz = {inv.z, inv.z};
+    for (; budget > 0; budget--) {
+        if (cur == YCGE_REF_NONE_VALUE) {
+            for (;;) {
+                uint32_t r; float tn;
+                if (!st.pop(r, tn)) break;
+                if (closest >= tn) { cur = r; break; }
+            }
+            if (cur == YCGE_REF_NONE_VALUE) break;          // nothing left
+        }
+        if (YCGE_REF_KIND(cur) != REF_WALK_NODE) break;     // a grid, or an object that is none
+        const uint32_t pay = YCGE_REF_PAYLOAD(cur);
+        w.steps++;
+        YCGE_VOXSTAT(w, 0);
+        const f32x4 *np = (const f32x4 *)(S.walk_nodes + (pay & ~YCGE_WALK_IN_ORDER));
+        const f32x4 a = np[0], b = np[1], c = np[2], e = np[3];
+        // box_scene, plain form, both children: left (a.x a.y a.z | b.x b.y a.w), right (b.z b.w c.x | c.z c.w c.y)
+        const f32x2 la = (a.xy - oxy) * ixy, lb = (b.xy - oxy) * ixy, lz = (a.zw - ozz) * izz;
+        const f32x2 ra = (b.zw - oxy) * ixy, rb = (c.zw - oxy) * ixy, rz = (c.xy - ozz) * izz;
+        float ln = __builtin_fmaxf(__builtin_fminf(la.x, lb.x), __builtin_fmaxf(__builtin_fminf(la.y, lb.y), __builtin_fminf(lz.x, lz.y)));
+        float lf = __builtin_fminf(__builtin_fmaxf(la.x, lb.x), __builtin_fminf(__builtin_fmaxf(la.y, lb.y), __builtin_fmaxf(lz.x, lz.y)));
+        float rn = __builtin_fmaxf(__builtin_fminf(ra.x, rb.x), __builtin_fmaxf(__builtin_fminf(ra.y, rb.y), __builtin_fminf(rz.x, rz.y)));
+        float rf = __builtin_fminf(__builtin_fmaxf(ra.x, rb.x), __builtin_fminf(__builtin_fmaxf(ra.y, rb.y), __builtin_fmaxf(rz.x, rz.y)));
+        ln = __builtin_fmaxf(ln, tmin); lf = __builtin_fminf(lf, closest);
+        rn = __builtin_fmaxf(rn, tmin); rf = __builtin_fminf(rf, closest);
+        const bool hl = lf >= ln, hr = rf >= rn;
+        const uint32_t lref = __float_as_uint(e.x), rref = __float_as_uint(e.y);
+        const bool left_first = (pay & YCGE_WALK_IN_ORDER) || ln < rn;
+        if (hl & hr) st.push(left_first ? rref : lref, left_first ? rn : ln);
+        cur = (hl & hr) ? (left_first ? lref : rref) : hl ? lref : hr ? rref : YCGE_REF_NONE_VALUE;
+    }
+    if (cur == YCGE_REF_NONE_VALUE) return st.sp == 0 ? TREE_DONE : TREE_YIELD;
+    const uint32_t kind = YCGE_REF_KIND(cur);
+    if (kind == REF_WALK_NODE) return TREE_YIELD;
+    if (kind != REF_GRID) return TREE_OTHER;
+    w.steps++;
+    parked_grid = (int)YCGE_REF_PAYLOAD(cur); parked_prim = -1;
+    cur = YCGE_REF_NONE_VALUE;
+    return TREE_AT_GRID;
+}
+#else
 template <class STK>
 __device__ __forceinline__ int walk_phase(const SceneDev &S, uint32_t &cur, STK &st, F3 o, F3 inv, float tmin, float closest, int &parked_grid, int &parked_prim, Work &w, int budget)
 {
@@ -1106,6 +1160,7 @@ __device__ __forceinline__ int walk_phase(const SceneDev &S, uint32_t &cur, STK 
         cur = (hl & hr) ? (left_first ? lref : rref) : hl ? lref : hr ? rref : YCGE_REF_NONE_VALUE;
     }
 }
+#endif
 
 // The scene tree of a scene that holds ANALYTIC objects only (SceneDev::analytic_only: no mesh, no voxel grid - configs 1 and 2 of the
 // benchmark, BVH.cs:99-198 over the objects of Scenes/Scenes.cs:269-335), as two loops that each hold ONE kind of step: node and leaf
