@@ -186,3 +186,25 @@ def test_a_job_that_hangs_is_ended_with_its_ranks(tmp_path):
         except (ProcessLookupError, FileNotFoundError):
             gone = True
         assert gone, pid
+
+
+def test_the_hang_detector_is_a_default_the_environment_can_change(tmp_path):
+    """launch_ranks without a timeout takes FORM_TIMEOUT_S (a hang detector: minutes, not the 25 of round 4) or YCGE_BENCH_FORM_TIMEOUT"""
+    import time
+    assert 120 <= bench.FORM_TIMEOUT_S <= 600
+    stub = tmp_path / "stub_bench.py"
+    stub.write_text("import time\ntime.sleep(600)\n")
+    env = dict(os.environ, YCGE_BENCH_FORM_TIMEOUT="4")
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK"):
+        env.pop(k, None)
+    old = os.environ.get("YCGE_BENCH_FORM_TIMEOUT")
+    os.environ["YCGE_BENCH_FORM_TIMEOUT"] = "4"
+    try:
+        t0 = time.time()
+        line, tried = bench.launch_ranks(1, ["--gpus", "1"], chain=(("onecall", ["--form", "onecall"]),), script=stub, env=env, log=open(os.devnull, "w"), extra=None)
+        assert line is None and tried[0]["rc"] == -9 and time.time() - t0 < 60
+    finally:
+        if old is None:
+            os.environ.pop("YCGE_BENCH_FORM_TIMEOUT", None)
+        else:
+            os.environ["YCGE_BENCH_FORM_TIMEOUT"] = old
