@@ -4,11 +4,11 @@
 //
 // Per frame k = 1..frames (frameCounter starts at 0 and is incremented before use, RaytraceRenderer.cs:24, 175), little-endian, row-major
 // x + y * hiW as Fast2D stores them (Fast2D.cs:21-24):
-//     f<k>_rays.f32          6 per pixel: origin, direction          RaytraceRenderer.cs:63   (private Fast2D<Ray> rays)
+//     f<k>_rays.f32          6 per pixel: origin, direction          RaytraceRenderer.cs:45   (private Fast2D<Ray> rays)
 //     f<k>_current_hdr.f32   3 per pixel                             :155  currentHdr
-//     f<k>_g_albedo.f32, f<k>_g_normal.f32   3 per pixel, f<k>_g_depth.f32   1 per pixel      :64-66
-//     f<k>_sky.u8            1 per pixel                             :72   skyMask
-//     f<k>_taa_history.f32   3 per pixel                             :85   taaHistory (after TemporalBlendWithClamp)
+//     f<k>_g_albedo.f32, f<k>_g_normal.f32   3 per pixel, f<k>_g_depth.f32   1 per pixel      :46-48
+//     f<k>_sky.u8            1 per pixel                             :54   skyMask
+//     f<k>_taa_history.f32   3 per pixel                             :68   taaHistory (after TemporalBlendWithClamp)
 //     f<k>_sdr.f32           6 per chexel: top rgb, bottom rgb       what fb.SetChexel received (:260-261; ChexelColor keeps the Vec3)
 // Once: the scene BVH and every mesh BVH as the reference built them (private SoA arrays of Objects/BVH.cs:11-25, MeshBVH.cs:18-39), in the
 // record layout of ycge_read_accel (10 x 4 bytes per node: min xyz, max xyz, left, right, start, count; then the leaf index array):
