@@ -160,11 +160,11 @@ namespace ConsoleGame.RayTracing.Native
     [StructLayout(LayoutKind.Sequential)]
     public struct YFlightInfo         // ycge_flight_info
     {
-        public int TwoTraceStreams, PlacedGate, PostGate, PostPair, FramesOutstanding, Reserved;
+        public int TwoTraceStreams, PlacedGate, PostGate, PostPair, FramesOutstanding, StagePipeline;
         public ulong PlacedWaits;
     }
 
-    public enum YStatus { Ok = 0, InvalidArg = -1, NoScene = -2, Device = -3, Unsupported = -4, OutOfMemory = -5, StackDepth = -6, NoDeviceCode = -7 }
+    public enum YStatus { Ok = 0, InvalidArg = -1, NoScene = -2, Device = -3, Unsupported = -4, OutOfMemory = -5, StackDepth = -6, NoDeviceCode = -7, Internal = -8 }
     public enum YMaterialKind { Constant = 0, Checker = 1, Textured = 2 }
     public enum YPrimType { Sphere = 0, Plane = 1, Disk = 2, XYRect = 3, XZRect = 4, YZRect = 5, Box = 6, CylinderY = 7, Triangle = 8, Mesh = 9, VolumeGrid = 10 }
     public enum YBuffer { Rays = 0, PrimId = 1, SubId = 2, HitT = 3, CurrentHdr = 4, GAlbedo = 5, GNormal = 6, GDepth = 7, SkyMask = 8, TaaHistory = 9, PrevNormal = 10, PrevDepth = 11, PrevSky = 12, Denoised = 13, RngState = 14 }

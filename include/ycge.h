@@ -47,7 +47,11 @@ typedef enum ycge_status {
     YCGE_ERR_OUT_OF_MEMORY = -5,
     YCGE_ERR_STACK_DEPTH = -6,   /* BVH deeper than the reference's fixed stacks
                                     (BVH.cs:118 = 128, MeshBVH.cs:150 = 64)     */
-    YCGE_ERR_NO_DEVICE_CODE = -7 /* HIP kernels missing / no gfx950 device      */
+    YCGE_ERR_NO_DEVICE_CODE = -7,/* HIP kernels missing / no gfx950 device      */
+    YCGE_ERR_INTERNAL = -8       /* a C++ exception other than std::bad_alloc (which is
+                                    YCGE_ERR_OUT_OF_MEMORY) was stopped at the boundary:
+                                    every export is a function-try-block, nothing unwinds
+                                    into the caller (csrc/ycge_ctx.h: abi_catch)        */
 } ycge_status;
 
 typedef struct ycge_vec3 { float x, y, z; } ycge_vec3;
@@ -368,7 +372,7 @@ typedef struct ycge_flight_info {
     int32_t post_gate;           /* a trace waits until the post stage before it has placed its persistent launch                */
     int32_t post_pair;           /* the post stages of consecutive frames run side by side                                      */
     int32_t frames_outstanding;  /* 1: frames in flight have not been joined yet                                                 */
-    int32_t reserved;
+    int32_t stage_pipeline;      /* 1: this scene's frames are traced by the stage kernels (k_wf_*), 0: by the single launch      */
     uint64_t placed_waits;       /* traces that were queued behind a placed value since the context was created                 */
 } ycge_flight_info;
 int ycge_flight_query(ycge_ctx *ctx, ycge_flight_info *out);

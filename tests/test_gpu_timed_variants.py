@@ -920,9 +920,12 @@ def test_the_walk_tree_of_a_voxel_world(product_lib, oracle, monkeypatch):
 
 
 @pytest.mark.parametrize("burst", [3, 4, 7])
-def test_live_texture_updates_between_frames_in_flight(product_lib, burst):
-    """ycge_scene_update_texture between ycge_render_frame_async calls on a frame of >= 4 096 tiles: a textured scene is never 'flat', so
-    its frames in flight take the stage pipeline's TWO trace streams (odd frames on the second).  The copy of a live texture's next frame
+@pytest.mark.parametrize("path", ["auto", "wavefront"])
+def test_live_texture_updates_between_frames_in_flight(product_lib, burst, path, monkeypatch):
+    """ycge_scene_update_texture between ycge_render_frame_async calls on a frame of >= 4 096 tiles, on BOTH device paths: the scene is
+    analytic objects only, so `auto` traces it with the single launch (k_trace on two streams, frame_is_single_launch since round 5), and
+    YCGE_PATH=wavefront sends the same frames through the stage pipeline's TWO trace streams and second set of queues (odd frames on the
+    second) - ycge_flight_query says which ran.  The copy of a live texture's next frame
     must wait for the trace that still samples the old one - whichever stream holds it - and the next trace - on whichever stream - must
     wait for the copy (Renderer/Texture.cs:113-116: a frame samples what GetCurrentFramePtr() showed when it was traced).  Reference
     behaviour = the same updates and frames made synchronously.  An update AFTER the last frame must not reach it; bursts of 3, 4 and 7
@@ -940,6 +943,8 @@ def test_live_texture_updates_between_frames_in_flight(product_lib, burst):
     s.Lights.append(PointLight(vec3(-2.0, 5.0, -1.0), vec3(1.0, 0.95, 0.9), 90.0))
     s.BackgroundTop, s.BackgroundBottom = vec3(0.5, 0.7, 1.0), vec3(0.9, 0.95, 1.0)
     flat = flatten(s)
+    if path == "wavefront": monkeypatch.setenv("YCGE_PATH", "wavefront")
+    else: monkeypatch.delenv("YCGE_PATH", raising=False)
     w, h, fov = 1536, 432, 55.0           # 1536 x 864 trace grid = 5 184 tiles of 32 x 8
     frames = [[rng.integers(0, 256, t.frame.shape, dtype=np.uint8) for t in (cam, video)] for _ in range(burst + 1)]
     watch = (abi.BUF_CURRENT_HDR, abi.BUF_G_ALBEDO, abi.BUF_TAA_HISTORY)
@@ -966,4 +971,5 @@ def test_live_texture_updates_between_frames_in_flight(product_lib, burst):
         for b, a, g_ in zip(watch, want, got):
             assert pu.bits_equal(a, g_), (rep, b, int((a.view(np.uint32) != g_.view(np.uint32)).sum()))
     assert info["two_trace_streams"], "this scene was meant to take both trace streams"
+    assert info["stage_pipeline"] == (1 if path == "wavefront" else 0), (path, info)
     assert len(np.unique(want[1].reshape(-1, 3).round(3), axis=0)) > 1000, "the albedo is not textured"

@@ -739,17 +739,21 @@ def test_sdr_arrays_of_the_python_mirror_live_in_the_librarys_page_locked_memory
     a[...] = 1.0
     assert me._sdr_buffer() is a and len(live) == 1                     # one buffer for the life of the renderer
     me.fbH, me.fbW = 45, 160
-    b = me._sdr_buffer()                                                # another console size: the old block goes back, a new one comes
-    assert b.shape == (45, 160, 2, 3) and len(live) == 1 and len(freed) == 1 and b.ctypes.data in live
+    b = me._sdr_buffer()                                                # another console size: a new block comes; the old one goes back ...
+    assert b.shape == (45, 160, 2, 3) and len(live) == 2 and not freed and float(a[0, 0, 0, 0]) == 1.0     # ... not under a caller who still holds the array
+    import gc
+    del a; gc.collect()                                                 # ... but when its last view dies (round 6: the array owns its pages)
+    assert len(live) == 1 and len(freed) == 1 and b.ctypes.data in live
     ring = me.__dict__.setdefault("_sdr_ring", {})
     for k in range(3):
         ring[k] = me._page_locked_zeros((45, 160, 2, 3))
     assert len(live) == 4
     me._drop_sdr_ring(keep_shape=(45, 160, 2, 3))
     assert len(live) == 4 and len(ring) == 3                            # same size: kept
-    me._drop_sdr_ring(keep_shape=(1, 1, 2, 3))
+    me._drop_sdr_ring(keep_shape=(1, 1, 2, 3)); gc.collect()
     assert len(live) == 1 and not ring
     me._drop_sdr_buffer(); me._drop_sdr_buffer()                        # idempotent
+    del b; gc.collect()
     assert not live and len(freed) == 5 and len(set(freed)) == 5
 
 
@@ -773,3 +777,124 @@ def test_pin_refuses_what_is_not_whole_pages_of_its_own():
     assert L.ycge_alloc_host_buffer(0, C.byref(out)) == abi.YCGE_ERR_INVALID_ARG and not out.value
     assert L.ycge_alloc_host_buffer(64, None) == abi.YCGE_ERR_INVALID_ARG
     assert L.ycge_free_host_buffer(None) == abi.YCGE_OK
+
+
+def test_no_exception_crosses_the_c_abi(product_lib):
+    """"no exceptions/longjmp across the ABI".  Every export's body is a function-try-block that ends in abi_catch
+    (csrc/ycge_ctx.h): std::bad_alloc -> YCGE_ERR_OUT_OF_MEMORY, anything else -> YCGE_ERR_INTERNAL, the text in ycge_last_error.  Raised
+    here by the test hook from inside such a body, with no context (the message then goes where ycge_create's failures go).  The n-th
+    allocation failing inside ycge_scene_upload / ycge_create is the GPU test tests/test_gpu_abi_barrier.py (they need a context)."""
+    L = product_lib
+    L.ycge_debug_throw.restype = C.c_int
+    L.ycge_debug_throw.argtypes = [C.c_void_p, C.c_int32]
+    assert L.ycge_debug_throw(None, 0) == abi.YCGE_OK
+    want = {1: (abi.YCGE_ERR_OUT_OF_MEMORY, b"std::bad_alloc"), 2: (abi.YCGE_ERR_INTERNAL, b"requested by ycge_debug_throw"),
+            3: (abi.YCGE_ERR_INTERNAL, b"unknown C++ exception"), 4: (abi.YCGE_ERR_INTERNAL, b"internal error"), 5: (abi.YCGE_ERR_INTERNAL, b"thread")}
+    for kind, (code, text) in want.items():
+        assert L.ycge_debug_throw(None, kind) == code, kind
+        msg = L.ycge_last_error(None)
+        assert text in msg and b"C-ABI" in msg, (kind, msg)
+    assert abi.STATUS_NAMES[abi.YCGE_ERR_INTERNAL] == "YCGE_ERR_INTERNAL"
+
+
+def test_every_export_of_the_host_sources_is_guarded():
+    """The barrier is mechanical: in csrc/ycge_host.cpp and csrc/ycge_resident.cpp (the translation units with std containers, threads and
+    `new`) every function defined inside an extern "C" block is a function-try-block whose handler calls abi_catch - except the one that
+    cannot throw (ycge_last_error returns a pointer)."""
+    import re
+    csrc = Path(abi.__file__).resolve().parent / "csrc"
+    for name in ("ycge_host.cpp", "ycge_resident.cpp"):
+        lines = (csrc / name).read_text().split("\n")
+        in_c, n = False, 0
+        for i, line in enumerate(lines):
+            if line.startswith('extern "C" {'): in_c = True
+            if line.startswith('} // extern "C"'): in_c = False
+            m = re.match(r"^(int|size_t|void|const char \*)\s*(ycge_\w+)\(", line) if in_c else None
+            if not m or line.rstrip().endswith(";"):
+                continue
+            if m.group(2) in ("ycge_last_error", "ycge_debug_fail_allocation"):
+                continue
+            j = i
+            while lines[j] not in ("try {", "{") and j < i + 6: j += 1
+            assert lines[j] == "try {", f"{name}:{i + 1} {m.group(2)} is not a function-try-block"
+            k = j + 1
+            while lines[k] != "}": k += 1
+            assert lines[k + 1].startswith("catch (...) {") and "abi_catch(" in lines[k + 1], f"{name}:{k + 2} {m.group(2)}"
+            n += 1
+        assert n >= 10, (name, n)
+
+
+def test_the_nth_allocation_fails_inside_host_side_exports():
+    """lib/var_faultinject.so (-DYCGE_FAULT_INJECTION=1: the library's own operator new throws std::bad_alloc on the n-th call after
+    ycge_debug_fail_allocation(n)): n walks through the mesh-BVH builder and the scene validator - the host-side code ycge_scene_upload runs
+    before it touches a device, reachable without one - and every call returns YCGE_ERR_OUT_OF_MEMORY or the full answer, bit-equal to the
+    answer without a failure.  (With a context: tests/test_gpu_abi_barrier.py.)"""
+    from yetanotherconsolegameengine_amd import build
+    L = abi.load_library(build.build_variant("faultinject"))
+    L.ycge_debug_fail_allocation.restype = C.c_int
+    L.ycge_debug_fail_allocation.argtypes = [C.c_int64]
+    rng = np.random.default_rng(5)
+    tris = rng.uniform(-1, 1, size=(300, 9)).astype(np.float32)
+    want_nodes, want_leaf, _ = _product_mesh(L, tris)
+    L.ycge_host_build_mesh.restype = C.c_int
+    failed, n = 0, 0
+    while True:
+        nodes = np.zeros(600, dtype=ob.NODE_DTYPE); leaf = np.zeros(300, dtype=np.int32); st = np.zeros(3, dtype=np.int32)
+        L.ycge_debug_fail_allocation(n)
+        rc = L.ycge_host_build_mesh(tris.ctypes.data, 300, nodes.ctypes.data, leaf.ctypes.data, st.ctypes.data)
+        left = L.ycge_debug_fail_allocation(-1)
+        if rc == abi.YCGE_ERR_OUT_OF_MEMORY:
+            failed += 1
+            assert b"bad_alloc" in L.ycge_last_error(None)
+        else:
+            assert rc == len(want_nodes) and _same(nodes[:rc], want_nodes) and _same(leaf, want_leaf), n
+            if left >= 0: break
+        n += 1 if n < 64 else n // 4
+    assert failed >= 5, failed
+    # the validator (std::string messages, index tables) on a real scene
+    from yetanotherconsolegameengine_amd import scenes
+    from yetanotherconsolegameengine_amd.scene import flatten
+    flat = flatten(scenes.config_scene(1)[0])
+    msg = C.create_string_buffer(256)
+    codes = set()
+    for n in range(24):
+        L.ycge_debug_fail_allocation(n)
+        codes.add(L.ycge_validate_scene(flat.byref(), msg, 256))
+        L.ycge_debug_fail_allocation(-1)
+    assert codes <= {abi.YCGE_OK, abi.YCGE_ERR_OUT_OF_MEMORY} and abi.YCGE_OK in codes, codes
+
+
+def test_page_locked_sdr_arrays_own_their_pages():
+    """TryFlipAndBlit(copy=False) and RenderAsync(sdr_slot=k) hand out numpy views over pages of the library; close(),
+    Resize() and a new console size used to free them under a caller who still held the array.  Now the allocation's life is the array's:
+    the pages go back (ycge_free_host_buffer, once) when the LAST view dies, whatever the renderer did meanwhile.  Stub allocator, no GPU."""
+    import gc
+    from yetanotherconsolegameengine_amd.renderer import RaytraceRenderer
+    libc = C.CDLL(None)
+    libc.malloc.restype = C.c_void_p; libc.malloc.argtypes = [C.c_size_t]; libc.free.argtypes = [C.c_void_p]
+
+    class Stub:
+        freed = []
+        def ycge_alloc_host_buffer(self, n, out):
+            out._obj.value = libc.malloc(n); C.memset(out._obj.value, 0, n); return 0
+        def ycge_free_host_buffer(self, p):
+            Stub.freed.append(p.value); libc.free(p); return 0
+        def ycge_wait(self, ctx): return 0
+        def ycge_destroy(self, ctx): return None
+
+    r = RaytraceRenderer.__new__(RaytraceRenderer)
+    r.L, r.ctx, r.fbW, r.fbH = Stub(), C.c_void_p(), 5, 3
+    a = r._sdr_buffer()
+    addr = a.ctypes.data
+    a[...] = 7.0
+    view = a[1:, :, 0]
+    r.fbW = 6                       # a new console size: the renderer lets go of the old buffer ...
+    b = r._sdr_buffer()
+    del a; gc.collect()
+    assert Stub.freed == [] and float(view.sum()) == 7.0 * view.size          # ... which the caller's view keeps alive and readable
+    r.close(); gc.collect()
+    assert Stub.freed == [] and b.shape == (3, 6, 2, 3) and float(b.sum()) == 0.0   # close() frees nothing a caller still holds
+    del view; gc.collect()
+    assert Stub.freed == [addr]
+    del b; gc.collect()
+    assert len(Stub.freed) == 2 and len(set(Stub.freed)) == 2

@@ -24,11 +24,13 @@ YCGE_ERR_UNSUPPORTED = -4
 YCGE_ERR_OUT_OF_MEMORY = -5
 YCGE_ERR_STACK_DEPTH = -6
 YCGE_ERR_NO_DEVICE_CODE = -7
+YCGE_ERR_INTERNAL = -8
 
 STATUS_NAMES = {
     0: "YCGE_OK", -1: "YCGE_ERR_INVALID_ARG", -2: "YCGE_ERR_NO_SCENE", -3: "YCGE_ERR_DEVICE",
     -4: "YCGE_ERR_UNSUPPORTED", -5: "YCGE_ERR_OUT_OF_MEMORY", -6: "YCGE_ERR_STACK_DEPTH",
     -7: "YCGE_ERR_NO_DEVICE_CODE",
+    -8: "YCGE_ERR_INTERNAL",
 }
 
 # ycge_material_kind
@@ -144,7 +146,7 @@ class FrameStats(C.Structure):
 
 class FlightInfo(C.Structure):
     _fields_ = [("two_trace_streams", C.c_int32), ("placed_gate", C.c_int32), ("post_gate", C.c_int32), ("post_pair", C.c_int32),
-                ("frames_outstanding", C.c_int32), ("reserved", C.c_int32), ("placed_waits", C.c_uint64)]
+                ("frames_outstanding", C.c_int32), ("stage_pipeline", C.c_int32), ("placed_waits", C.c_uint64)]
 
 
 def default_config() -> Config:

@@ -121,6 +121,9 @@ VARIANTS = {
     # walk (scene-tree steps by kind, cell steps, cell fetches, queue records).  bench.py --config 5 replays its timed frames through it for
     # `roofline.timed_work`; profiles/vox_stats.py reads the per-phase clocks of k_wf_trace_p from it
     "voxstat": ["-DYCGE_DBG_VOXSTAT=1"],
+    # the exception barrier of the C-ABI under allocation failure: the library's own operator new (-Bsymbolic: bound inside the library) throws std::bad_alloc on
+    # the n-th call after ycge_debug_fail_allocation(n) - tests/test_gpu_abi_barrier.py walks n through ycge_scene_upload and ycge_create
+    "faultinject": ["-DYCGE_FAULT_INJECTION=1", "-Wl,-Bsymbolic"],
 }
 
 

@@ -475,6 +475,13 @@ int ycge_launch_scene_bvh_build(const float *items, int n, void *scratch, void *
 }
 
 
+static bool staged_copy_out(void *stage, void *dst, const void *src, size_t bytes)       // device -> page-locked staging -> caller memory (a CPU copy)
+{
+    if (hipMemcpy(stage, src, bytes, hipMemcpyDeviceToHost) != hipSuccess) return false;
+    for (size_t i = 0; i < bytes; i++) ((unsigned char *)dst)[i] = ((const unsigned char *)stage)[i];
+    return true;
+}
+
 // test hook (no context): the kernel on caller-supplied boxes - bounds = n x 6 (min xyz, max xyz), centroids = n x 3.  nodes_out
 // holds 2 n records of 40 bytes (reference format, pre-order), leaf_out n, result_out 16 words (BvhBuildResult), build_out (optional)
 // 2 n build records of 64 bytes in creation order.  Returns the node count, -1 on a device error, -2 when the kernel fell back.
@@ -484,20 +491,22 @@ int ycge_debug_device_bvh(const float *bounds, const float *centroids, int32_t n
     float *planes = (float *)malloc((size_t)9 * n * sizeof(float));
     for (int i = 0; i < n; i++)
         for (int a = 0; a < 3; a++) { planes[(size_t)a * n + i] = bounds[6 * i + a]; planes[(size_t)(3 + a) * n + i] = bounds[6 * i + 3 + a]; planes[(size_t)(6 + a) * n + i] = centroids[3 * i + a]; }
-    float *d_items = nullptr; void *d_scratch = nullptr, *d_ref = nullptr, *d_g = nullptr, *d_res = nullptr; uint32_t *d_leaf = nullptr;
+    float *d_items = nullptr; void *d_scratch = nullptr, *d_ref = nullptr, *d_g = nullptr, *d_res = nullptr, *stage = nullptr; uint32_t *d_leaf = nullptr;
     int rc = -1;
+    struct Out { void *stage; bool operator()(void *dst, const void *src, size_t bytes) const { return staged_copy_out(stage, dst, src, bytes); } } out{nullptr};
     if (hipMalloc((void **)&d_items, (size_t)9 * n * 4) == hipSuccess && hipMalloc(&d_scratch, ycge_bvh_build_scratch_bytes(n)) == hipSuccess &&
         hipMalloc(&d_ref, (size_t)2 * n * 40) == hipSuccess && hipMalloc(&d_g, (size_t)n * 64 + 64) == hipSuccess && hipMalloc(&d_res, 64) == hipSuccess &&
         hipMalloc((void **)&d_leaf, (size_t)n * 4) == hipSuccess && hipMemcpy(d_items, planes, (size_t)9 * n * 4, hipMemcpyHostToDevice) == hipSuccess &&
         hipMemset(d_scratch, 0, ycge_bvh_build_scratch_bytes(n)) == hipSuccess &&
         ycge_launch_scene_bvh_build(d_items, n, d_scratch, d_ref, d_g, d_leaf, d_res, getenv("YCGE_BVH_WAVES") ? atoi(getenv("YCGE_BVH_WAVES")) : 16, nullptr) == 0 && hipDeviceSynchronize() == hipSuccess &&
-        hipMemcpy(result_out, d_res, 64, hipMemcpyDeviceToHost) == hipSuccess) {
+        hipHostMalloc(&stage, (size_t)2 * n * 64 + 64, hipHostMallocDefault) == hipSuccess && ((out.stage = stage), out(result_out, d_res, 64))) {
+        // (every read-back through page-locked staging of this function's own and a CPU copy: the device writes no caller memory - DESIGN section 6)
         const ycge::BvhBuildResult *r = (const ycge::BvhBuildResult *)result_out;
-        if (build_out) (void)hipMemcpy(build_out, d_scratch, (size_t)2 * n * 64, hipMemcpyDeviceToHost);
+        if (build_out) (void)out(build_out, d_scratch, (size_t)2 * n * 64);
         if (r->fallback) rc = -2;
-        else if (hipMemcpy(nodes_out, d_ref, (size_t)r->n_nodes * 40, hipMemcpyDeviceToHost) == hipSuccess &&
-                 hipMemcpy(leaf_out, d_leaf, (size_t)n * 4, hipMemcpyDeviceToHost) == hipSuccess) rc = r->n_nodes;
+        else if (out(nodes_out, d_ref, (size_t)r->n_nodes * 40) && out(leaf_out, d_leaf, (size_t)n * 4)) rc = r->n_nodes;
     }
+    if (stage) (void)hipHostFree(stage);
     (void)hipFree(d_items); (void)hipFree(d_scratch); (void)hipFree(d_ref); (void)hipFree(d_g); (void)hipFree(d_res); (void)hipFree(d_leaf);
     free(planes);
     return rc;

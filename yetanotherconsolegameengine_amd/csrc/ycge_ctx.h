@@ -19,6 +19,9 @@
 #include <deque>
 #include <condition_variable>
 #include <mutex>
+#include <new>
+#include <stdexcept>
+#include <system_error>
 #include <thread>
 #include <string>
 #include <vector>
@@ -83,6 +86,11 @@ using namespace ycge;
 namespace ycge_host {
 
 inline std::string g_create_error;          // (one per library: C++17 inline variable)
+// THE EXCEPTION BARRIER of the C-ABI (round 6): every exported function's body is a function-try-block whose handler ends here, so that no
+// C++ exception - std::bad_alloc from a vector that flattens an 871 200-triangle mesh, std::system_error from a thread constructor - unwinds
+// into the P/Invoke frame of the CLR host ("no exceptions/longjmp across the ABI").  Called INSIDE a catch (...) handler:
+// rethrows to classify.  std::bad_alloc -> YCGE_ERR_OUT_OF_MEMORY, anything else -> YCGE_ERR_INTERNAL; the text goes to ycge_last_error.
+int abi_catch(const ycge_ctx *c) noexcept;
 
 template <class T> struct DevBuf {
     T *p = nullptr;

@@ -2,6 +2,15 @@
 // steps 1-9), frames in flight, the slab form of the tiled frame.  (The tile-resident multi-GPU form and the read-backs: ycge_resident.cpp.)
 #include "ycge_ctx.h"
 
+#ifndef YCGE_FAULT_INJECTION
+#define YCGE_FAULT_INJECTION 0
+#endif
+#if YCGE_FAULT_INJECTION
+#include <atomic>
+#include <cstdlib>
+#include <new>
+static std::atomic<long long> g_fail_alloc_countdown{-1};      // < 0: off; n: the allocation n from now throws std::bad_alloc (ycge_debug_fail_allocation)
+#endif
 namespace ycge_host {
 
 int alloc_frame_buffers(ycge_ctx *c)
@@ -274,13 +283,27 @@ int morton3(int x, int y, int z)
     return ((x & 1) << 0) | ((y & 1) << 1) | ((z & 1) << 2) | ((x & 2) << 2) | ((y & 2) << 3) | ((z & 2) << 4) | ((x & 4) << 4) | ((y & 4) << 5) | ((z & 4) << 6);
 }
 
+int abi_catch(const ycge_ctx *cc) noexcept
+{
+    ycge_ctx *c = const_cast<ycge_ctx *>(cc);
+    int code = YCGE_ERR_INTERNAL;
+    char text[320];
+    std::snprintf(text, sizeof text, "internal error: unknown C++ exception stopped at the C-ABI");
+    try { throw; }
+    catch (const std::bad_alloc &) { code = YCGE_ERR_OUT_OF_MEMORY; std::snprintf(text, sizeof text, "out of host memory (std::bad_alloc stopped at the C-ABI)"); }
+    catch (const std::exception &e) { std::snprintf(text, sizeof text, "internal error: %s (C++ exception stopped at the C-ABI)", e.what()); }
+    catch (...) { }
+    try { if (c) c->err = text; else g_create_error = text; } catch (...) { }      // (the message itself may not fit any more: the code still says what happened)
+    return code;
+}
+
 } // namespace ycge_host
 
 // =========================================================================== C-ABI
 extern "C" {
 
 int ycge_config_default(ycge_config *cfg)
-{
+try {
     if (!cfg) return YCGE_ERR_INVALID_ARG;
     std::memset(cfg, 0, sizeof *cfg);
     cfg->abi_version = YCGE_ABI_VERSION;
@@ -299,6 +322,7 @@ int ycge_config_default(ycge_config *cfg)
     cfg->atrous_iterations = 3; cfg->atrous_c_phi = 3.0f; cfg->atrous_n_phi = 0.35f; cfg->atrous_z_phi = 2.0f; cfg->atrous_a_phi = 0.20f;
     return YCGE_OK;
 }
+catch (...) { return ycge_host::abi_catch(nullptr); }
 
 static void peer_worker_main(ycge_ctx *root, ycge_ctx *peer);
 static int create_one(const ycge_config *cfg, ycge_ctx *parent, ycge_ctx **out)
@@ -310,13 +334,15 @@ static int create_one(const ycge_config *cfg, ycge_ctx *parent, ycge_ctx **out)
         return YCGE_ERR_NO_DEVICE_CODE;
     }
     if (cfg->device < 0 || cfg->device >= n_dev) { g_create_error = "device ordinal out of range"; return YCGE_ERR_INVALID_ARG; }
-    ycge_ctx *c = new ycge_ctx();
+    struct Owner { ycge_ctx *p; ~Owner() { if (p) ycge_destroy(p); } } owner{new ycge_ctx()};      // (an exception on the way out of this function must not leak the context and its streams)
+    ycge_ctx *c = owner.p;
+    c->err.reserve(320);
     c->cfg = *cfg;
     c->device = cfg->device;
     c->fov_deg = cfg->fov_deg;
     c->parent = parent;
     c->knobs.read();                // every YCGE_* knob is read here, once
-    auto bail = [&](int code) { g_create_error = c->err; ycge_destroy(c); return code; };
+    auto bail = [&](int code) { g_create_error = c->err; owner.p = nullptr; ycge_destroy(c); return code; };
     if (hipSetDevice(c->device) != hipSuccess) { c->err = "hipSetDevice failed"; return bail(YCGE_ERR_DEVICE); }
     hipDeviceProp_t prop;
     if (hipGetDeviceProperties(&prop, c->device) != hipSuccess) { c->err = "hipGetDeviceProperties failed"; return bail(YCGE_ERR_DEVICE); }
@@ -363,12 +389,13 @@ static int create_one(const ycge_config *cfg, ycge_ctx *parent, ycge_ctx **out)
     }
     int rc = set_geometry(c, cfg->fb_width, cfg->fb_height, cfg->super_sample);
     if (rc != YCGE_OK) return bail(rc);
+    owner.p = nullptr;
     *out = c;
     return YCGE_OK;
 }
 
 int ycge_create(const ycge_config *cfg, ycge_ctx **out)
-{
+try {
     if (!cfg || !out) { g_create_error = "null argument"; return YCGE_ERR_INVALID_ARG; }
     *out = nullptr;
     if (cfg->abi_version != YCGE_ABI_VERSION) { g_create_error = "abi_version mismatch"; return YCGE_ERR_INVALID_ARG; }
@@ -394,24 +421,28 @@ int ycge_create(const ycge_config *cfg, ycge_ctx **out)
     ycge_ctx *root = nullptr;
     int rc = create_one(&base, nullptr, &root);
     if (rc != YCGE_OK) return rc;
+    // (whatever throws below - a vector that grows, a thread that cannot start - takes the root, its peers and their threads with it)
+    struct Owner { ycge_ctx *root, *peer; ~Owner() { if (peer) ycge_destroy(peer); if (root) ycge_destroy(root); } } owner{root, nullptr};
     root->cfg.n_devices = cfg->n_devices;
+    root->peers.reserve((size_t)cfg->n_devices);
     for (int r = 1; r < cfg->n_devices; r++) {
         ycge_config pc = base;
         pc.rank = r; pc.device = cfg->devices[r];
         ycge_ctx *peer = nullptr;
         rc = create_one(&pc, root, &peer);
-        if (rc != YCGE_OK) { ycge_destroy(root); return rc; }
+        if (rc != YCGE_OK) return rc;
+        owner.peer = peer;
         root->peers.push_back(peer);
+        owner.peer = nullptr;
         if (peer->device != root->device) {        // the peer's kernels write into the root's frame buffers over xGMI
             int can = 0;
             if (hipDeviceCanAccessPeer(&can, peer->device, root->device) != hipSuccess || !can) {
                 g_create_error = "devices cannot access each other's memory (no xGMI / PCIe peer path)";
-                ycge_destroy(root);
                 return YCGE_ERR_DEVICE;
             }
             (void)hipSetDevice(peer->device);
             const hipError_t pe = hipDeviceEnablePeerAccess(root->device, 0);
-            if (pe != hipSuccess && pe != hipErrorPeerAccessAlreadyEnabled) { g_create_error = "hipDeviceEnablePeerAccess failed"; ycge_destroy(root); return YCGE_ERR_DEVICE; }
+            if (pe != hipSuccess && pe != hipErrorPeerAccessAlreadyEnabled) { g_create_error = "hipDeviceEnablePeerAccess failed"; return YCGE_ERR_DEVICE; }
             (void)hipGetLastError();
         }
     }
@@ -420,12 +451,14 @@ int ycge_create(const ycge_config *cfg, ycge_ctx **out)
         peer->worker->th = std::thread(peer_worker_main, root, peer);
     }
     (void)hipSetDevice(root->device);
+    owner.root = nullptr;
     *out = root;
     return YCGE_OK;
 }
+catch (...) { return ycge_host::abi_catch(nullptr); }
 
 void ycge_destroy(ycge_ctx *c)
-{
+try {
     if (!c) return;
     if (c->worker) {
         { std::lock_guard<std::mutex> g(c->worker->m); c->worker->job = -1; }
@@ -484,16 +517,18 @@ void ycge_destroy(ycge_ctx *c)
     if (c->stream) (void)hipStreamDestroy(c->stream);
     delete c;
 }
+catch (...) { (void)ycge_host::abi_catch(nullptr); }
 
 const char *ycge_last_error(const ycge_ctx *c) { return c ? c->err.c_str() : g_create_error.c_str(); }
 
 int ycge_device_info(ycge_ctx *c, char *name, size_t name_bytes, int32_t *compute_units)
-{
+try {
     if (!c) return YCGE_ERR_INVALID_ARG;
     if (name && name_bytes) { std::strncpy(name, c->device_name, name_bytes - 1); name[name_bytes - 1] = 0; }
     if (compute_units) *compute_units = c->compute_units;
     return YCGE_OK;
 }
+catch (...) { return ycge_host::abi_catch(c); }
 
 static int upload_lights(ycge_ctx *c, const ycge_light *lights, int n)
 {
@@ -522,12 +557,31 @@ namespace ycge_host {
 // lifetime neither the caller nor the library controls (the allocator trims and regrows the heap, the runtime caches what it pinned).
 // Twice in ~25 runs of the GPU suite in round 4 and once in the first full run of round 5 - AFTER the registered arrays of the Python
 // mirror had been given pages of their own - a read-back died with "Memory access fault by GPU ... Write access" at a heap address.
-bool host_memory_is_page_locked(const void *p)
+// (the WHOLE range [p, p + bytes): a destination that starts inside a page-locked block and runs past its end - a registered sub-range, an
+// array sized for an older console - would let the copy engine write pageable heap behind it, the very fault class this exists to exclude.
+// The runtime is asked for the allocation the first byte lies in (hipMemGetAddressRange on its device alias: base and size of the block
+// hipHostMalloc / hipHostRegister made) and the range must end inside it; a runtime that cannot say is asked about the last byte too, and
+// the two ends must be page-locked host memory whose device aliases lie exactly as far apart as the host addresses.  Anything else is
+// answered "no": the staging copy is always right.)
+bool host_memory_is_page_locked(const void *p, size_t bytes)
 {
-    hipPointerAttribute_t a;
-    std::memset(&a, 0, sizeof a);
-    if (hipPointerGetAttributes(&a, p) != hipSuccess) { (void)hipGetLastError(); return false; }      // (older runtimes: an error for plain heap memory)
-    return a.type == hipMemoryTypeHost;
+    auto locked = [](const void *q, hipPointerAttribute_t &a) {
+        std::memset(&a, 0, sizeof a);
+        if (hipPointerGetAttributes(&a, q) != hipSuccess) { (void)hipGetLastError(); return false; }      // (older runtimes: an error for plain heap memory)
+        return a.type == hipMemoryTypeHost;
+    };
+    hipPointerAttribute_t a0, a1;
+    if (!locked(p, a0)) return false;
+    if (bytes <= 1) return true;
+    hipDeviceptr_t base = nullptr;
+    size_t block = 0;
+    if (a0.devicePointer && hipMemGetAddressRange(&base, &block, (hipDeviceptr_t)a0.devicePointer) == hipSuccess && base && block) {
+        const uint8_t *b = (const uint8_t *)base, *d = (const uint8_t *)a0.devicePointer;
+        return d >= b && (size_t)(d - b) <= block && bytes <= block - (size_t)(d - b);
+    }
+    (void)hipGetLastError();
+    if (!locked((const uint8_t *)p + (bytes - 1), a1)) return false;
+    return a0.devicePointer && a1.devicePointer && (const uint8_t *)a1.devicePointer - (const uint8_t *)a0.devicePointer == (ptrdiff_t)(bytes - 1);
 }
 int ensure_out_stage(ycge_ctx *c, size_t bytes)
 {
@@ -541,7 +595,7 @@ int ensure_out_stage(ycge_ctx *c, size_t bytes)
 int copy_out(ycge_ctx *c, void *dst, const void *src, size_t bytes)
 {
     if (bytes == 0) return YCGE_OK;
-    if (host_memory_is_page_locked(dst)) { HIP_TRY(c, hipMemcpy(dst, src, bytes, hipMemcpyDeviceToHost)); return YCGE_OK; }
+    if (host_memory_is_page_locked(dst, bytes)) { HIP_TRY(c, hipMemcpy(dst, src, bytes, hipMemcpyDeviceToHost)); return YCGE_OK; }
     const size_t chunk = (size_t)32 << 20;
     const int rc = ensure_out_stage(c, bytes < chunk ? bytes : chunk);
     if (rc != YCGE_OK) return rc;
@@ -816,8 +870,8 @@ int install_objects_device_built(ycge_ctx *c, ycge_ctx *root, const ObjectsHost 
     const int e = ycge_launch_scene_bvh_build(c->d_bvh_items.p, n, c->d_bvh_scratch.p, c->d_bvh_ref.p, c->d_scene_nodes.p, c->d_scene_leaf.p, c->d_bvh_res.p, c->knobs.bvh_waves, c->stream);
     if (e != 0) return c->fail(YCGE_ERR_DEVICE, "k_scene_bvh_build launch failed: %s", hipGetErrorString((hipError_t)e));
     BvhBuildResult res;
-    HIP_TRY(c, hipMemcpyAsync(&res, c->d_bvh_res.p, sizeof res, hipMemcpyDeviceToHost, c->stream));
     HIP_TRY(c, hipStreamSynchronize(c->stream));
+    { const int cr = copy_out(c, &res, c->d_bvh_res.p, sizeof res); if (cr != YCGE_OK) return cr; }       // (through the library's page-locked staging: the device writes no caller or stack memory)
     if (res.fallback) return 1;
     int spill = 0;
     const int rc = check_scene_depth(c, res.max_depth, spill);
@@ -979,15 +1033,16 @@ static uint32_t append_treelets(std::vector<uint8_t> &arena, const std::vector<G
 }
 
 int ycge_validate_scene(const ycge_scene *scene, char *msg, size_t msg_bytes)
-{
+try {
     std::string m;
     const int rc = validate_scene(scene, m);
     if (msg && msg_bytes) { std::strncpy(msg, m.c_str(), msg_bytes - 1); msg[msg_bytes - 1] = 0; }
     return rc;
 }
+catch (...) { return ycge_host::abi_catch(nullptr); }
 
 int ycge_scene_upload(ycge_ctx *c, const ycge_scene *s)
-{
+try {
     if (!c) return YCGE_ERR_INVALID_ARG;
     if (c->parent) return c->fail(YCGE_ERR_INVALID_ARG, "peer contexts are driven by their root");
     {
@@ -1174,10 +1229,11 @@ int ycge_scene_upload(ycge_ctx *c, const ycge_scene *s)
     (void)hipSetDevice(c->device);
     return rc;
 }
+catch (...) { return ycge_host::abi_catch(c); }
 
 int ycge_scene_update_lights(ycge_ctx *c, const ycge_light *lights, int32_t n_lights, const ycge_vec3 *ambient_color,
                              float ambient_intensity, const ycge_vec3 *top, const ycge_vec3 *bottom)
-{
+try {
     if (!c) return YCGE_ERR_INVALID_ARG;
     if (!c->have_scene) return c->fail(YCGE_ERR_NO_SCENE, "no scene uploaded");
     if (n_lights < 0 || (n_lights > 0 && !lights)) return c->fail(YCGE_ERR_INVALID_ARG, "bad light array");
@@ -1195,10 +1251,11 @@ int ycge_scene_update_lights(ycge_ctx *c, const ycge_light *lights, int32_t n_li
     (void)hipSetDevice(c->device);
     return rc;
 }
+catch (...) { return ycge_host::abi_catch(c); }
 
 // The next frame of a live texture (Renderer/Texture.cs:113-116: SampleBilinear reads IFrameReader.GetCurrentFramePtr())
 int ycge_scene_update_texture(ycge_ctx *c, int32_t texture_index, const uint8_t *frame, size_t bytes)
-{
+try {
     if (!c) return YCGE_ERR_INVALID_ARG;
     if (c->parent) return c->fail(YCGE_ERR_INVALID_ARG, "peer contexts are driven by their root");
     if (!c->have_scene) return c->fail(YCGE_ERR_NO_SCENE, "no scene uploaded");
@@ -1246,12 +1303,13 @@ int ycge_scene_update_texture(ycge_ctx *c, int32_t texture_index, const uint8_t 
     (void)hipSetDevice(c->device);
     return rc;
 }
+catch (...) { return ycge_host::abi_catch(c); }
 
 // Scene.Update -> RebuildBVH when an entity moved (Scenes/Scene.cs:122-127, e.g. BobbingSphereEntity,
 // TestScenesRandom.cs:708-714): new Scene.Objects records against the meshes, grids and materials of the last
 // ycge_scene_upload.  Only the scene-level BVH is rebuilt (as in the reference: a Mesh keeps its own BVH).
 int ycge_scene_update_objects(ycge_ctx *c, const ycge_prim *prims, int32_t n_prims)
-{
+try {
     if (!c) return YCGE_ERR_INVALID_ARG;
     if (c->parent) return c->fail(YCGE_ERR_INVALID_ARG, "peer contexts are driven by their root");
     if (!c->have_scene) return c->fail(YCGE_ERR_NO_SCENE, "no scene uploaded");
@@ -1298,27 +1356,30 @@ int ycge_scene_update_objects(ycge_ctx *c, const ycge_prim *prims, int32_t n_pri
     c->have_scene = true;
     return YCGE_OK;
 }
+catch (...) { return ycge_host::abi_catch(c); }
 
 // profiling aid: the progress lines of the persistent in-place A-trous launch (32 words per band: [0] progress, [4..7] begin / end
 // timestamps at 100 MHz, [8] passes) of the last frame with a post stage
 int ycge_debug_read_post_progress(ycge_ctx *c, uint32_t *dst, size_t n_words)
-{
+try {
     if (!c || !dst || !c->post_progress.p || n_words > c->post_progress.n) return YCGE_ERR_INVALID_ARG;
     HIP_TRY(c, hipDeviceSynchronize());
     return copy_out(c, dst, c->post_progress.p, n_words * 4);
 }
+catch (...) { return ycge_host::abi_catch(c); }
 // test / profiling hook: {device builds, host rebuilds after the kernel declined (a tree deeper than the reference's stack), host builds,
 // microseconds of the last update's build + install, Array.Sort cases in the current tree (BVH.cs:389,419), depth of the current tree}
 int ycge_debug_scene_bvh_stats(ycge_ctx *c, int64_t *out6)
-{
+try {
     if (!c || !out6) return YCGE_ERR_INVALID_ARG;
     out6[0] = c->bvh_device_builds; out6[1] = c->bvh_host_fallbacks; out6[2] = c->bvh_host_builds; out6[3] = (int64_t)c->bvh_last_build_us;
     out6[4] = c->scene_tree.sort_fallbacks; out6[5] = c->scene_tree.max_depth;
     return YCGE_OK;
 }
+catch (...) { return ycge_host::abi_catch(c); }
 
 int ycge_resize(ycge_ctx *c, int32_t fbw, int32_t fbh, int32_t ss)
-{
+try {
     if (!c) return YCGE_ERR_INVALID_ARG;
     int rc = quiesce(c);
     if (rc != YCGE_OK) return rc;
@@ -1331,9 +1392,10 @@ int ycge_resize(ycge_ctx *c, int32_t fbw, int32_t fbh, int32_t ss)
     (void)hipSetDevice(c->device);
     return rc;
 }
+catch (...) { return ycge_host::abi_catch(c); }
 
 int ycge_set_camera(ycge_ctx *c, const float pos[3], float yaw, float pitch, float fov_deg)
-{
+try {
     if (!c) return YCGE_ERR_INVALID_ARG;
     if (!pos) return c->fail(YCGE_ERR_INVALID_ARG, "null position");
     std::lock_guard<std::mutex> g(c->cam_lock);
@@ -1341,18 +1403,20 @@ int ycge_set_camera(ycge_ctx *c, const float pos[3], float yaw, float pitch, flo
     c->yaw = yaw; c->pitch = pitch; c->fov_deg = fov_deg;
     return YCGE_OK;
 }
+catch (...) { return ycge_host::abi_catch(c); }
 
 int ycge_set_frame_counter(ycge_ctx *c, int64_t fc)
-{
+try {
     if (!c) return YCGE_ERR_INVALID_ARG;
     if (fc < 0 || fc == INT64_MAX) return c->fail(YCGE_ERR_INVALID_ARG, "frame counter must be in [0, 2^63 - 2] (the reference's counter starts at 0 and only grows, RaytraceRenderer.cs:24,175)");
     c->frame_counter = fc;
     return YCGE_OK;
 }
+catch (...) { return ycge_host::abi_catch(c); }
 
 // profiling builds: the 6 sums of the cooperative walk's statistics (ycge_coop.hip.h, -DYCGE_DBG_COOPSTAT), cumulative
 int ycge_debug_read_coop_stats(ycge_ctx *c, uint64_t out[16])
-{
+try {
     if (!c || !out || !c->dbg_counters.p) return YCGE_ERR_INVALID_ARG;
     std::vector<unsigned long long> v(16 + 16 * 256);
     HIP_TRY(c, hipDeviceSynchronize());
@@ -1360,11 +1424,12 @@ int ycge_debug_read_coop_stats(ycge_ctx *c, uint64_t out[16])
     for (int k = 0; k < 16; k++) { out[k] = 0; for (int i = 0; i < 256; i++) out[k] += v[16 + 8 * 256 * (k >> 3) + 8 * i + (k & 7)]; }
     return YCGE_OK;
 }
+catch (...) { return ycge_host::abi_catch(c); }
 
 // profiling builds (-DYCGE_DBG_BATCHSTAT, mesh_walk): 8 banks of 8 sums, cumulative; banks 2-4 every batch by kind (occlusion / closest hit / mixed),
 // 5-7 the batches of >= 48 iterations
 int ycge_debug_read_batch_stats(ycge_ctx *c, uint64_t out[64])
-{
+try {
     if (!c || !out || !c->dbg_counters.p) return YCGE_ERR_INVALID_ARG;
     std::vector<unsigned long long> v(16 + 64 * 256);
     HIP_TRY(c, hipDeviceSynchronize());
@@ -1372,11 +1437,12 @@ int ycge_debug_read_batch_stats(ycge_ctx *c, uint64_t out[64])
     for (int k = 0; k < 64; k++) { out[k] = 0; for (int i = 0; i < 256; i++) out[k] += v[16 + 8 * 256 * (k >> 3) + 8 * i + (k & 7)]; }
     return YCGE_OK;
 }
+catch (...) { return ycge_host::abi_catch(c); }
 
 // test hook: the scene nodes as the device holds them and SceneDev::walk_nodes (64 B each; the walk tree has 1 + 2 * YCGE_WALK_LEAF_NODES
 // entries per scene node) + grid_owner; returns the scene node count (0: no walk tree), < 0 on an error
 int ycge_debug_read_walk_tree(ycge_ctx *c, void *gnodes_out, void *walk_out, int32_t capacity_nodes, int32_t *grid_owner_out, int32_t n_grids, uint32_t *root_and_limit_out)
-{
+try {
     if (!c || !c->have_scene) return YCGE_ERR_INVALID_ARG;
     const int n = c->walk_scene_nodes;
     if (n == 0) return 0;
@@ -1389,33 +1455,37 @@ int ycge_debug_read_walk_tree(ycge_ctx *c, void *gnodes_out, void *walk_out, int
     root_and_limit_out[0] = c->sd.walk_root_ref; std::memcpy(&root_and_limit_out[1], &c->sd.walk_t_limit, 4);
     return n;
 }
+catch (...) { return ycge_host::abi_catch(c); }
 
 // Page-locked host memory for the SDR frame.  hipHostRegister works on whole pages: two registered heap arrays that share a boundary page
 // lose it when ONE of them is unregistered, and the other's next read-back is a device write to an unmapped host page ("Memory access fault
 // by GPU" at a heap address, round 4).  So the library refuses a range that is not whole pages of its own - the caller proves it owns the
 // pages by handing over page-aligned memory - and offers memory that is (ycge_alloc_host_buffer: hipHostMalloc).
 size_t ycge_host_page_size(void)
-{
+try {
     const long p = sysconf(_SC_PAGESIZE);
     return p > 0 ? (size_t)p : (size_t)4096;
 }
+catch (...) { (void)ycge_host::abi_catch(nullptr); return 0; }
 int ycge_pin_host_buffer(void *buffer, size_t bytes)
-{
+try {
     const size_t page = ycge_host_page_size();
     if (!buffer || bytes == 0 || ((uintptr_t)buffer % page) != 0 || (bytes % page) != 0) return YCGE_ERR_INVALID_ARG;
     if (hipHostRegister(buffer, bytes, hipHostRegisterDefault) == hipSuccess) return YCGE_OK;
     (void)hipGetLastError();
     return YCGE_ERR_DEVICE;
 }
+catch (...) { return ycge_host::abi_catch(nullptr); }
 int ycge_unpin_host_buffer(void *buffer)
-{
+try {
     if (!buffer || ((uintptr_t)buffer % ycge_host_page_size()) != 0) return YCGE_ERR_INVALID_ARG;
     if (hipHostUnregister(buffer) == hipSuccess) return YCGE_OK;
     (void)hipGetLastError();
     return YCGE_ERR_DEVICE;
 }
+catch (...) { return ycge_host::abi_catch(nullptr); }
 int ycge_alloc_host_buffer(size_t bytes, void **out)
-{
+try {
     if (!out) return YCGE_ERR_INVALID_ARG;
     *out = nullptr;
     if (bytes == 0) return YCGE_ERR_INVALID_ARG;
@@ -1425,22 +1495,25 @@ int ycge_alloc_host_buffer(size_t bytes, void **out)
     *out = p;
     return YCGE_OK;
 }
+catch (...) { return ycge_host::abi_catch(nullptr); }
 int ycge_free_host_buffer(void *buffer)
-{
+try {
     if (!buffer) return YCGE_OK;
     if (hipHostFree(buffer) == hipSuccess) return YCGE_OK;
     (void)hipGetLastError();
     return YCGE_ERR_INVALID_ARG;
 }
+catch (...) { return ycge_host::abi_catch(nullptr); }
 
 int ycge_device_count(void)
-{
+try {
     int n = 0;
     return hipGetDeviceCount(&n) == hipSuccess ? n : -1;
 }
+catch (...) { return ycge_host::abi_catch(nullptr); }
 
 int ycge_read_timed_steps(ycge_ctx *c, uint64_t *lane_steps)
-{
+try {
     if (!c || !lane_steps) return YCGE_ERR_INVALID_ARG;
     unsigned long long total = 0;
     std::vector<ycge_ctx *> all{c};
@@ -1448,20 +1521,22 @@ int ycge_read_timed_steps(ycge_ctx *c, uint64_t *lane_steps)
     for (ycge_ctx *d : all) {
         std::vector<unsigned long long> v(YCGE_COUNTER_WORDS);
         if (hipSetDevice(d->device) != hipSuccess || hipDeviceSynchronize() != hipSuccess ||
-            hipMemcpy(v.data(), d->counters.p, v.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost) != hipSuccess) { (void)hipSetDevice(c->device); return c->fail(YCGE_ERR_DEVICE, "timed-step read-back failed on device %d", d->device); }
+            copy_out(d, v.data(), d->counters.p, v.size() * sizeof(unsigned long long)) != YCGE_OK) { (void)hipSetDevice(c->device); return c->fail(YCGE_ERR_DEVICE, "timed-step read-back failed on device %d", d->device); }
         for (size_t i = 8; i < v.size(); i += 8) total += v[i];
     }
     (void)hipSetDevice(c->device);
     *lane_steps = total;
     return YCGE_OK;
 }
+catch (...) { return ycge_host::abi_catch(c); }
 
 int ycge_tile_slab_bytes(const ycge_ctx *c, size_t *bytes)
-{
+try {
     if (!c || !bytes) return YCGE_ERR_INVALID_ARG;
     *bytes = (size_t)c->tiles_per_rank_padded * 256 * slab_floats(c) * sizeof(float);
     return YCGE_OK;
 }
+catch (...) { return ycge_host::abi_catch(c); }
 
 } // extern "C"
 
@@ -2092,7 +2167,7 @@ int run_post(ycge_ctx *c, hipStream_t stream, float *out_sdr_host, bool timed, h
     if (out_sdr_host) {
         const size_t sdr_bytes = (size_t)c->fbW * c->fbH * 6 * sizeof(float);
         float *target = out_sdr_host;
-        if (!host_memory_is_page_locked(out_sdr_host)) {        // (synchronous callers only: the frames in flight refuse a pageable array up front)
+        if (!host_memory_is_page_locked(out_sdr_host, sdr_bytes)) {        // (synchronous callers only: the frames in flight refuse a pageable array up front)
             const int rs = ensure_out_stage(c, sdr_bytes);
             if (rs != YCGE_OK) return rs;
             target = (float *)c->out_stage;
@@ -2121,7 +2196,7 @@ int fill_stats(ycge_ctx *c, ycge_frame_stats *st, const FrameState &fs, bool did
     for (size_t i = 0; i < c->peers.size() && i + 1 < YCGE_MAX_DEVICES; i++) st->device_tiles[i + 1] = c->peers[i]->n_owned;
     if (c->cfg.count_work) {
         unsigned long long h[8];
-        HIP_TRY(c, hipMemcpy(h, c->counters.p, sizeof h, hipMemcpyDeviceToHost));
+        { const int cr = copy_out(c, h, c->counters.p, sizeof h); if (cr != YCGE_OK) return cr; }
         st->n_rays = h[0]; st->n_box = h[1]; st->n_tri = h[2]; st->n_prim = h[3]; st->n_vox = h[4]; st->n_rays_dark = h[5];
     }
     st->exposure = 1.0f;
@@ -2181,7 +2256,8 @@ static void peer_worker_main(ycge_ctx *c, ycge_ctx *p)
         if (w.job == -1) return;
         FrameState pfs = w.fs;
         lk.unlock();
-        const int rc = peer_trace_and_push(c, p, pfs);
+        int rc;
+        try { rc = peer_trace_and_push(c, p, pfs); } catch (...) { rc = abi_catch(p); }     // (an exception that left a thread function would end the process)
         lk.lock();
         w.fs = pfs; w.rc = rc; w.job = 2;
         lk.unlock();
@@ -2223,15 +2299,16 @@ static int trace_on_all_devices(ycge_ctx *c, FrameState &fs)
 // (tests/test_gpu_timed_variants.py); every other entry point first waits for what is in flight (join_async).
 
 int ycge_wait(ycge_ctx *c)
-{
+try {
     if (!c) return YCGE_ERR_INVALID_ARG;
     return join_async(c);
 }
+catch (...) { return ycge_host::abi_catch(c); }
 
 // measurement: how long the trace launches of the frames queued since the last call took (HIP events around them on the context's
 // stream, behind the wait for the schedule), oldest first, at most the last YCGE_FLIGHT_RING of them.  Waits for the frames in flight.
 int ycge_async_trace_times(ycge_ctx *c, float *ms_out, int32_t capacity, int32_t *n_out)
-{
+try {
     if (!c || !n_out || (capacity > 0 && !ms_out)) return YCGE_ERR_INVALID_ARG;
     { const int jr = join_async(c); if (jr != YCGE_OK) return jr; }
     if (c->knobs.flight_no_begin) { *n_out = 0; c->flight_frames = 0; return YCGE_OK; }
@@ -2255,11 +2332,12 @@ int ycge_async_trace_times(ycge_ctx *c, float *ms_out, int32_t capacity, int32_t
     c->flight_frames = 0;
     return YCGE_OK;
 }
+catch (...) { return ycge_host::abi_catch(c); }
 
 // what the frames in flight of this context do (timing machinery only: DESIGN section 6); the gate's state is what render_frame_in_flight
 // last found - before the first frame in flight it is the knob's
 int ycge_flight_query(ycge_ctx *c, ycge_flight_info *out)
-{
+try {
     if (!c || !out) return YCGE_ERR_INVALID_ARG;
     std::memset(out, 0, sizeof *out);
     const bool single_launch = c->have_scene && frame_is_single_launch(c) && !c->sd.any_transparent;
@@ -2269,22 +2347,29 @@ int ycge_flight_query(ycge_ctx *c, ycge_flight_info *out)
     out->post_gate = c->knobs.flight_post_gate ? 1 : 0;
     out->post_pair = (out->two_trace_streams && c->knobs.flight_post_pair) ? 1 : 0;
     out->frames_outstanding = c->async_outstanding ? 1 : 0;
+    out->stage_pipeline = (c->have_scene && !frame_is_single_launch(c)) ? 1 : 0;
     out->placed_waits = c->placed_waits;
     return YCGE_OK;
 }
+catch (...) { return ycge_host::abi_catch(c); }
 
 static int render_frame_in_flight(ycge_ctx *c, float *out_sdr);
-int ycge_render_frame_async(ycge_ctx *c) { return c ? render_frame_in_flight(c, nullptr) : YCGE_ERR_INVALID_ARG; }
+int ycge_render_frame_async(ycge_ctx *c)
+try {
+    return c ? render_frame_in_flight(c, nullptr) : YCGE_ERR_INVALID_ARG;
+}
+catch (...) { return ycge_host::abi_catch(c); }
 // ... with steps 6-8 (denoise, exposure, tonemap + downsample) and the read-back into out_top_bottom_sdr, which is filled when the frame
 // is complete (ycge_wait, or any other call): page-locked memory (ycge_pin_host_buffer) keeps the copy off the caller's thread, and a
 // caller that queues several such frames passes a buffer per frame in flight.  The post stage of frame N runs beside the traces and TAA
 // of the frames after it (its in-place iteration is a dependent chain that leaves most of the chip idle).
 int ycge_render_frame_async_sdr(ycge_ctx *c, float *out_top_bottom_sdr)
-{
+try {
     if (!c) return YCGE_ERR_INVALID_ARG;
     if (!out_top_bottom_sdr) return c->fail(YCGE_ERR_INVALID_ARG, "null SDR buffer");
     return render_frame_in_flight(c, out_top_bottom_sdr);
 }
+catch (...) { return ycge_host::abi_catch(c); }
 
 static int render_frame_in_flight(ycge_ctx *c, float *out_sdr)
 {
@@ -2292,7 +2377,7 @@ static int render_frame_in_flight(ycge_ctx *c, float *out_sdr)
         return c->fail(YCGE_ERR_INVALID_ARG, "ycge_render_frame_async is the single-device form (tiled frames overlap through ycge_trace_tiles / ycge_resolve_gathered on two streams)");
     if (c->cfg.capture_debug || c->cfg.count_work) return c->fail(YCGE_ERR_INVALID_ARG, "ycge_render_frame_async keeps neither debug captures nor per-frame counters: use ycge_render_frame");
     HIP_TRY(c, hipSetDevice(c->device));
-    if (out_sdr && !host_memory_is_page_locked(out_sdr))
+    if (out_sdr && !host_memory_is_page_locked(out_sdr, (size_t)c->fbW * c->fbH * 6 * sizeof(float)))
         return c->fail(YCGE_ERR_INVALID_ARG, "ycge_render_frame_async_sdr fills its array while the caller runs on: it must be page-locked memory (ycge_alloc_host_buffer, or whole pages registered with ycge_pin_host_buffer)");
     if (!c->taa_stream) return c->fail(YCGE_ERR_INVALID_ARG, "no second stream: frames in flight need a single-device context");
     for (int k = 0; k < 3; k++) if (!c->set_resolved_ev[k]) HIP_TRY(c, hipEventCreateWithFlags(&c->set_resolved_ev[k], hipEventDisableTiming));
@@ -2438,7 +2523,7 @@ static int render_frame_in_flight(ycge_ctx *c, float *out_sdr)
 }
 
 int ycge_render_frame(ycge_ctx *c, float *out_sdr, ycge_frame_stats *st)
-{
+try {
     if (!c) return YCGE_ERR_INVALID_ARG;
     if (c->parent) return c->fail(YCGE_ERR_INVALID_ARG, "peer contexts are driven by their root");
     { const int jr = join_async(c); if (jr != YCGE_OK) return jr; }
@@ -2466,7 +2551,7 @@ int ycge_render_frame(ycge_ctx *c, float *out_sdr, ycge_frame_stats *st)
     if (rc == YCGE_OK && st && c->cfg.count_work)
         for (ycge_ctx *p : c->peers) {          // the counters of the peers' tiles
             unsigned long long h[8];
-            if (hipSetDevice(p->device) != hipSuccess || hipMemcpy(h, p->counters.p, sizeof h, hipMemcpyDeviceToHost) != hipSuccess) { (void)hipSetDevice(c->device); return c->fail(YCGE_ERR_DEVICE, "counter read-back failed on device %d", p->device); }
+            if (hipSetDevice(p->device) != hipSuccess || hipDeviceSynchronize() != hipSuccess || copy_out(p, h, p->counters.p, sizeof h) != YCGE_OK) { (void)hipSetDevice(c->device); return c->fail(YCGE_ERR_DEVICE, "counter read-back failed on device %d", p->device); }
             st->n_rays += h[0]; st->n_box += h[1]; st->n_tri += h[2]; st->n_prim += h[3]; st->n_vox += h[4]; st->n_rays_dark += h[5];
         }
     if (multi_dev) HIP_TRY(c, hipSetDevice(c->device));
@@ -2475,16 +2560,17 @@ int ycge_render_frame(ycge_ctx *c, float *out_sdr, ycge_frame_stats *st)
         HIP_TRY(c, hipEventElapsedTime(&ms, c->ev[2], c->ev[3]));
         st->post_ms = ms;
         float tone[3];
-        HIP_TRY(c, hipMemcpy(tone, c->tone_state.p, sizeof tone, hipMemcpyDeviceToHost));
+        { const int cr = copy_out(c, tone, c->tone_state.p, sizeof tone); if (cr != YCGE_OK) return cr; }
         st->exposure = tone[1];
         uint32_t n_serial; std::memcpy(&n_serial, &tone[2], 4);
         st->exposure_serial_chunks = (float)n_serial;
     }
     return rc;
 }
+catch (...) { return ycge_host::abi_catch(c); }
 
 int ycge_trace_tiles(ycge_ctx *c, void *d_slab, void *hip_stream, ycge_frame_stats *st)
-{
+try {
     if (!c) return YCGE_ERR_INVALID_ARG;
     if (c->parent || !c->peers.empty()) return c->fail(YCGE_ERR_INVALID_ARG, "ycge_trace_tiles is the one-process-per-GPU form; this context drives its devices through ycge_render_frame");
     { const int jr = join_async(c); if (jr != YCGE_OK) return jr; }
@@ -2507,9 +2593,10 @@ int ycge_trace_tiles(ycge_ctx *c, void *d_slab, void *hip_stream, ycge_frame_sta
     }
     return YCGE_OK;
 }
+catch (...) { return ycge_host::abi_catch(c); }
 
 int ycge_resolve_gathered(ycge_ctx *c, const void *d_all_slabs, void *hip_stream, float *out_sdr, ycge_frame_stats *st)
-{
+try {
     if (!c) return YCGE_ERR_INVALID_ARG;
     if (!d_all_slabs) return c->fail(YCGE_ERR_INVALID_ARG, "null gathered slabs");
     if (c->pending.empty()) return c->fail(YCGE_ERR_INVALID_ARG, "no traced frame to resolve: every ycge_resolve_gathered follows its own ycge_trace_tiles");
@@ -2549,13 +2636,14 @@ int ycge_resolve_gathered(ycge_ctx *c, const void *d_all_slabs, void *hip_stream
             HIP_TRY(c, hipEventElapsedTime(&ms, c->ev[2], c->ev[3]));
             st->post_ms = ms;
             float tone[2];
-            HIP_TRY(c, hipMemcpy(tone, c->tone_state.p, sizeof tone, hipMemcpyDeviceToHost));
+            { const int cr = copy_out(c, tone, c->tone_state.p, sizeof tone); if (cr != YCGE_OK) return cr; }
             st->exposure = tone[1];
         }
         st->total_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
     }
     return YCGE_OK;
 }
+catch (...) { return ycge_host::abi_catch(c); }
 
 // ---- host-only helpers exported for the `-m "not gpu"` tests (no device needed) -------------
 // Build a tree over caller-supplied boxes with the product builder: bounds = n*6 (min xyz, max xyz),
@@ -2563,7 +2651,7 @@ int ycge_resolve_gathered(ycge_ctx *c, const void *d_all_slabs, void *hip_stream
 // nodes_out must hold 2*n records of 10 x 4 B, leaf_out n int32.  Returns node count or <0.
 int ycge_host_build_tree(const float *bounds, const float *centroids, int32_t n, int32_t flavour, void *nodes_out, int32_t *leaf_out,
                          int32_t *stats_out /* [root, max_depth, sort_fallbacks] */)
-{
+try {
     if (n < 0 || (n > 0 && (!bounds || !centroids || !nodes_out || !leaf_out))) return YCGE_ERR_INVALID_ARG;
     BoundsSoA it;
     it.resize(n);
@@ -2576,10 +2664,11 @@ int ycge_host_build_tree(const float *bounds, const float *centroids, int32_t n,
     if (stats_out) { stats_out[0] = t.root; stats_out[1] = t.max_depth; stats_out[2] = t.sort_fallbacks; }
     return (int)t.nodes.size();
 }
+catch (...) { return ycge_host::abi_catch(nullptr); }
 // Same for a triangle soup (MeshBVH ctor path incl. TryComputeBounds).
 // test hook: the device records of one mesh (single material 0) as emit_mesh_records lays them out
 int ycge_host_mesh_arena(const float *tris9, int32_t n, void *out, int64_t capacity_bytes, uint32_t *root_ref_out)
-{
+try {
     if (n < 0 || (n > 0 && !tris9) || !root_ref_out) return YCGE_ERR_INVALID_ARG;
     BoundsSoA it;
     triangle_items(tris9, n, it);
@@ -2592,10 +2681,11 @@ int ycge_host_mesh_arena(const float *tris9, int32_t n, void *out, int64_t capac
     if (out && (int64_t)arena.size() <= capacity_bytes && !arena.empty()) std::memcpy(out, arena.data(), arena.size());
     return (int)arena.size();
 }
+catch (...) { return ycge_host::abi_catch(nullptr); }
 
 // ... with the treelet region of the cooperative walk appended (append_treelets): returns the total size, *tl_offset_out = where it starts
 int ycge_host_mesh_arena_treelets(const float *tris9, int32_t n, void *out, int64_t capacity_bytes, uint32_t *root_ref_out, uint32_t *tl_offset_out)
-{
+try {
     if (n < 0 || (n > 0 && !tris9) || !root_ref_out || !tl_offset_out) return YCGE_ERR_INVALID_ARG;
     BoundsSoA it;
     triangle_items(tris9, n, it);
@@ -2611,9 +2701,10 @@ int ycge_host_mesh_arena_treelets(const float *tris9, int32_t n, void *out, int6
     if (out && (int64_t)arena.size() <= capacity_bytes && !arena.empty()) std::memcpy(out, arena.data(), arena.size());
     return (int)arena.size();
 }
+catch (...) { return ycge_host::abi_catch(nullptr); }
 
 int ycge_host_build_mesh(const float *tris9, int32_t n, void *nodes_out, int32_t *leaf_out, int32_t *stats_out)
-{
+try {
     if (n < 0 || (n > 0 && (!tris9 || !nodes_out || !leaf_out))) return YCGE_ERR_INVALID_ARG;
     BoundsSoA it;
     triangle_items(tris9, n, it);
@@ -2624,10 +2715,11 @@ int ycge_host_build_mesh(const float *tris9, int32_t n, void *nodes_out, int32_t
     if (stats_out) { stats_out[0] = t.root; stats_out[1] = t.max_depth; stats_out[2] = t.sort_fallbacks; }
     return (int)t.nodes.size();
 }
+catch (...) { return ycge_host::abi_catch(nullptr); }
 // Level schedule of an in-place A-trous iteration (host only).  pixels_out: w*h uint32, offsets_out: capacity
 // uint32.  Returns the number of levels (offsets_out holds levels + 1 entries) or <0.
 int ycge_host_inplace_schedule(int32_t w, int32_t h, int32_t step, uint32_t *pixels_out, uint32_t *offsets_out, int32_t capacity)
-{
+try {
     if (w <= 0 || h <= 0 || step <= 0 || !pixels_out || !offsets_out) return YCGE_ERR_INVALID_ARG;
     std::vector<uint32_t> px, off;
     build_inplace_schedule(w, h, step, px, off);
@@ -2636,11 +2728,12 @@ int ycge_host_inplace_schedule(int32_t w, int32_t h, int32_t step, uint32_t *pix
     std::memcpy(offsets_out, off.data(), off.size() * 4);
     return (int)off.size() - 1;
 }
+catch (...) { return ycge_host::abi_catch(nullptr); }
 // test hook: the banded pass lists of an in-place iteration as k_atrous_band reads them.  Returns the number of passes (entries = 32 x
 // passes, x | y << 16 or 0xffffffff); offsets_out gets n_bands x (levels + 1) pass offsets; info_out = {levels, n_bands, max_level_pixels}
 int ycge_host_inplace_bands(int32_t w, int32_t h, int32_t step, int32_t rows_per_band, uint32_t *entries_out, int64_t entries_capacity,
                             uint32_t *offsets_out, int64_t offsets_capacity, int32_t *info_out)
-{
+try {
     if (w <= 0 || h <= 0 || step <= 0 || rows_per_band <= 0 || !info_out) return YCGE_ERR_INVALID_ARG;
     std::vector<uint32_t> px, off, bpx, boff;
     build_inplace_schedule(w, h, step, px, off);
@@ -2652,11 +2745,12 @@ int ycge_host_inplace_bands(int32_t w, int32_t h, int32_t step, int32_t rows_per
     if (offsets_out && (int64_t)boff.size() <= offsets_capacity) std::memcpy(offsets_out, boff.data(), boff.size() * 4);
     return (int)(bpx.size() / 32);
 }
+catch (...) { return ycge_host::abi_catch(nullptr); }
 // test hook: the row-parity band layout of the persistent in-place A-trous launch (split_band_layout) and, per band, the most pixels a
 // level holds.  row_band_out: h ints; desc_out: 8 ints a band (first row, rows, stride, groups, up0, up1, dn0, dn1); max_px_out: a band.
 // Returns the number of bands, 0 where the layout does not apply.
 int ycge_host_split_bands(int32_t w, int32_t h, int32_t step, int32_t *row_band_out, int32_t *desc_out, int32_t desc_capacity, int32_t *max_px_out)
-{
+try {
     if (w <= 0 || h <= 0 || step <= 0 || !row_band_out || !desc_out) return YCGE_ERR_INVALID_ARG;
     std::vector<int32_t> row_band, desc;
     int n_bands = 0;
@@ -2675,9 +2769,10 @@ int ycge_host_split_bands(int32_t w, int32_t h, int32_t step, int32_t *row_band_
     }
     return n_bands;
 }
+catch (...) { return ycge_host::abi_catch(nullptr); }
 // test hook: the window width run_post would hand k_atrous_band for this schedule (0 = hash form)
 int ycge_host_band_window_width(int32_t w, int32_t h, int32_t step, int32_t rows_per_band, int32_t K, int32_t G)
-{
+try {
     if (w <= 0 || h <= 0 || step <= 0 || rows_per_band <= 0 || K <= 0 || (G != 8 && G != 16 && G != 32)) return YCGE_ERR_INVALID_ARG;
     std::vector<uint32_t> px, off, bpx, boff;
     build_inplace_schedule(w, h, step, px, off);
@@ -2686,16 +2781,18 @@ int ycge_host_band_window_width(int32_t w, int32_t h, int32_t step, int32_t rows
     band_inplace_schedule(w, h, rows_per_band, px, off, bpx, boff, n_bands, max_level_pixels, (uint32_t)G);
     return (int)band_window_width(bpx, boff, n_bands, (int)off.size() - 1, K, rows_per_band, (uint32_t)G, 2048u);
 }
+catch (...) { return ycge_host::abi_catch(nullptr); }
 // profiling aid: per-wavefront {start, end, node iterations, leaf phases} of the last counted k_wf_primary launch
 int ycge_debug_read_wave_prof(ycge_ctx *c, unsigned long long *dst, size_t n_u64)
-{
+try {
     if (!c || !dst || !c->wave_prof.p || n_u64 > c->wave_prof.n) return YCGE_ERR_INVALID_ARG;
     HIP_TRY(c, hipDeviceSynchronize());
     return copy_out(c, dst, c->wave_prof.p, n_u64 * 8);
 }
+catch (...) { return ycge_host::abi_catch(c); }
 // sizeof of each ABI struct, for the ctypes mirror check
 size_t ycge_abi_sizeof(int32_t which)
-{
+try {
     switch (which) {
     case 0: return sizeof(ycge_vec3); case 1: return sizeof(ycge_material); case 2: return sizeof(ycge_prim); case 3: return sizeof(ycge_mesh);
     case 4: return sizeof(ycge_voxel_lookup); case 5: return sizeof(ycge_grid); case 6: return sizeof(ycge_light); case 7: return sizeof(ycge_scene);
@@ -2703,5 +2800,53 @@ size_t ycge_abi_sizeof(int32_t which)
     }
     return 0;
 }
+catch (...) { (void)ycge_host::abi_catch(nullptr); return 0; }
+
+// tests: what copy_out / run_post / ycge_render_frame_async_sdr decide about a destination (1: the device may write [p, p + bytes) directly)
+int ycge_debug_is_page_locked(const void *p, size_t bytes)
+try {
+    return (p && host_memory_is_page_locked(p, bytes)) ? 1 : 0;
+}
+catch (...) { return ycge_host::abi_catch(nullptr); }
+
+// tests (tests/test_host_cpu.py, no GPU needed): an exception of the given kind raised INSIDE an exported body - what comes back is the
+// barrier's answer (abi_catch): 1 std::bad_alloc, 2 std::runtime_error, 3 something that is no std::exception, 4 std::length_error out of a
+// vector, 5 std::system_error as a failing std::thread constructor raises it; 0 nothing
+int ycge_debug_throw(ycge_ctx *c, int32_t kind)
+try {
+    if (kind == 1) throw std::bad_alloc();
+    if (kind == 2) throw std::runtime_error("requested by ycge_debug_throw");
+    if (kind == 3) throw 42;
+    if (kind == 4) { std::vector<uint64_t> v; v.resize(v.max_size() + (size_t)kind); }
+    if (kind == 5) throw std::system_error(std::make_error_code(std::errc::resource_unavailable_try_again), "thread");
+    return YCGE_OK;
+}
+catch (...) { return ycge_host::abi_catch(c); }
+
+#if YCGE_FAULT_INJECTION
+// lib/var_faultinject.so only (tests/test_gpu_abi_barrier.py): the n-th allocation from now fails.  The replaced operators serve this
+// library's own code (every std::vector, std::string and `new` of the host side is compiled into it; -Bsymbolic binds them here).
+int ycge_debug_fail_allocation(int64_t nth)
+{
+    const long long left = g_fail_alloc_countdown.exchange((long long)nth);
+    return left < 0 ? -1 : (int)(left > 0x7fffffff ? 0x7fffffff : left);
+}
+#endif
 
 } // extern "C"
+#if YCGE_FAULT_INJECTION && !defined(__HIP_DEVICE_COMPILE__)
+// (the variant is linked -Wl,-Bsymbolic: the library's own references bind to these definitions, whatever else the process has loaded)
+static void *fi_alloc(std::size_t n)
+{
+    if (g_fail_alloc_countdown.load(std::memory_order_relaxed) >= 0 && g_fail_alloc_countdown.fetch_sub(1) == 0) throw std::bad_alloc();
+    void *p = std::malloc(n ? n : 1);
+    if (!p) throw std::bad_alloc();
+    return p;
+}
+void *operator new(std::size_t n) { return fi_alloc(n); }
+void *operator new[](std::size_t n) { return fi_alloc(n); }
+void operator delete(void *p) noexcept { std::free(p); }
+void operator delete[](void *p) noexcept { std::free(p); }
+void operator delete(void *p, std::size_t) noexcept { std::free(p); }
+void operator delete[](void *p, std::size_t) noexcept { std::free(p); }
+#endif

@@ -703,13 +703,22 @@ struct FanShared {
     int alive;
     uint8_t list[192];          // refill mode: the posted queries, compacted (slot * 64 + lane)
 };
-__device__ __forceinline__ void fan_post(FanShared *F, int slot, int lane, F3 o, F3 d, float tmin, float tmax, bool anyhit)
+// The same slots for ONE wavefront that traces a PART of a split block (trace_block MODE 3): at most 16 pixel lanes post, the wavefront's
+// 64 lanes answer - lane = slot * (pixels of the part) + pixel.  1.9 KB beside the 10 KB a k_trace wavefront holds anyway.
+struct FanPart {
+    float o[3][16];
+    float q[3][6][16];
+    float r[4][3][16];          // (answer slot 3: the bounce ray's, kept while slot 0 serves the queries that go one at a time)
+};
+template <class FS>
+__device__ __forceinline__ void fan_post(FS *F, int slot, int lane, F3 o, F3 d, float tmin, float tmax, bool anyhit)
 {
     F->o[0][lane] = o.x; F->o[1][lane] = o.y; F->o[2][lane] = o.z;
     F->q[slot][0][lane] = d.x; F->q[slot][1][lane] = d.y; F->q[slot][2][lane] = d.z;
     F->q[slot][3][lane] = tmin; F->q[slot][4][lane] = tmax; F->q[slot][5][lane] = anyhit ? 1.0f : 0.0f;
 }
-__device__ __forceinline__ RayQ fan_query(const FanShared *F, int slot, int lane)
+template <class FS>
+__device__ __forceinline__ RayQ fan_query(const FS *F, int slot, int lane)
 {
     RayQ q;
     q.o = f3(F->o[0][lane], F->o[1][lane], F->o[2][lane]);
@@ -743,18 +752,40 @@ __device__ __forceinline__ void shade_ctx_load(uint32_t addr, F3 &p, F3 &n, F3 &
     p = f3(v0.x, v0.y, v0.z); n = f3(v0.w, v1.x, v1.y); alb = f3(v1.z, v1.w, v2.x); wo = f3(v2.y, v2.z, v2.w);
 }
 
+#ifndef YCGE_PARTFAN
+// k_trace / k_trace_batch: 0 = round 5's loop (MODE 0), the product.  1 = MODE 3 for every entry, 2 = MODE 3 for the parts of split blocks and
+// MODE 0 for whole blocks (two copies of the loop in one kernel).  Round 6 built MODE 3 - the parts of split blocks fan their queries out over
+// their idle lanes - and measured it (profiles/r06/a_partfan.txt): a rank of 8 / 4 in the tile-resident ring 0.173 -> 0.157 / 0.267 -> 0.231 ms,
+// config 3 at 256 split blocks 0.280 -> 0.275 ms; config 4's whole frame LOSES (0.480 -> 0.499 ms at 32 split blocks, more with more: the
+// machine is within 15 % of full, every part is a wavefront slot, and MODE 3's loop runs whole blocks 4 % slower - 168 registers against 157).
+// And the build with MODE 3 in it dies with a GPU memory fault where two contexts trace on one device (test_one_call_drives_several_devices,
+// 9 of 9 runs; not with the register path alone, -DYCGE_PARTFAN_NOFAN=1, nor with the slots zeroed first, -DYCGE_PARTFAN_ZEROLDS=1): cause
+// not found.  Not in the product; the variants stay buildable for whoever follows it up.
+#define YCGE_PARTFAN 0
+#endif
+#ifndef YCGE_PARTFAN_COST_NUM
+#define YCGE_PARTFAN_COST_NUM 6  // quarters: the iterations a fanned part reports are scaled by this / 4 so that its block keeps its schedule class
+#endif
 // MODE 0: one wavefront per block, queries traced where TraceFull asks for them.
 // MODE 1: k_trace_fan, three wavefronts per block (see above).
 // MODE 2: k_trace_refill, ONE wavefront per block and the same posting of a hit's queries, but stage B is a refill loop:
 //         the block's posted queries (up to 192) form a list, a lane that finishes its query takes the next one whichever
 //         pixel it belongs to, and the walk yields every `refill_steps` steps so that idle lanes can do so.  A block then
 //         costs about max(its longest query, its steps / 64) per stage instead of the sum of the stage's longest lanes.
-template <bool COUNT, bool FLAT, int MODE, bool FULLW = true>
+// MODE 3: k_trace since round 6.  ONE wavefront per schedule entry as in MODE 0, and the query fan-out of MODE 1 INSIDE that wavefront
+//         where the entry is a PART of a split block (lg >= 2: at most 16 of the 64 lanes hold a pixel): the part's pixels post the
+//         queries of a diffuse hit - first shadow segment towards each of the first two lit lights, the bounce ray - into three slots
+//         and lane = slot * pixels + pixel answers them in ONE pass of the traversal loop, on lanes that idled before.  A part's chain
+//         becomes primary + max(shadow, shadow, bounce) + max(shadow, shadow) with no wavefront slot more than the split already took
+//         (k_trace_fan paid two helper wavefronts a block, which is why it lost on whole frames).  Entries that are whole blocks
+//         (lg < 2) run the same loop with the pixel's own query in registers: stage B traces `q`, stage A consumes - MODE 0's order.
+template <bool COUNT, bool FLAT, int MODE, bool FULLW = true, class FS = FanShared>
 __device__ __forceinline__ void trace_block(const SceneDev &S, const FrameParams &P, const TraceOut &O, const uint32_t ent, const uint32_t sched_index,
-                                            FanShared *F, const int refill_steps)
+                                            FS *F, const int refill_steps)
 {
     constexpr bool FAN = MODE != 0;          // queries are posted to LDS slots and answered in stage B
     constexpr bool WAVES3 = MODE == 1;
+    constexpr bool INW = MODE == 3;
     const bool DEBUG = O.prim_id != nullptr;
     Work w = {0, 0, 0, 0, 0, 0, 0};
     StackT<WAVES3 ? 192 : 64> st;
@@ -764,6 +795,10 @@ __device__ __forceinline__ void trace_block(const SceneDev &S, const FrameParams
     const uint32_t bid = YCGE_ENT_BLOCK(ent), lg = YCGE_ENT_LG(ent);
     const int k = (int)(bid >> 2), wave_in_tile = (int)(bid & 3);
     const int live_lanes = 64 >> lg;
+#ifndef YCGE_PARTFAN_NOFAN
+#define YCGE_PARTFAN_NOFAN 0            // debugging aid: MODE 3's loop with every entry on the register path
+#endif
+    const bool fanrt = !INW || (lg >= 2u && !YCGE_PARTFAN_NOFAN);        // (wave-uniform) MODE 3: this entry fans its queries out over its idle lanes
     const int pix_in_block = (int)YCGE_ENT_PART(ent) * live_lanes + lane;
     int px, py, lx, ly;
     const bool in_image = tile_pixel_wl(P, k, wave_in_tile, pix_in_block & 63, px, py, lx, ly) && lane < live_lanes;
@@ -820,9 +855,14 @@ __device__ __forceinline__ void trace_block(const SceneDev &S, const FrameParams
     // the block's cost for the next frame's schedule: loop iterations its wavefront(s) spend in traversal = sum over the
     // query batches of the longest lane's steps.  The same scale whether the block is fanned or not.
     uint32_t wave_iters = 0;
-    if (FAN) {
+    float ans_t = 0.0f;                     // MODE 3, whole-block entries: the answer to the lane's own query, from stage B to stage A
+    int ans_prim = -1, ans_sub = 0;
+#if defined(YCGE_PARTFAN_ZEROLDS)
+    if constexpr (INW) { for (int z = lane; z < (int)(sizeof(FS) / 4); z += 64) ((float *)F)[z] = 0.0f; }
+#endif
+    if (FAN && fanrt) {
         if (WAVES3) F->q[wave][3][lane] = -1.0f;
-        else { F->q[0][3][lane] = -1.0f; F->q[1][3][lane] = -1.0f; F->q[2][3][lane] = -1.0f; }
+        else if (!INW || lane < live_lanes) { F->q[0][3][lane] = -1.0f; F->q[1][3][lane] = -1.0f; F->q[2][3][lane] = -1.0f; }
         if (phase != PH_DONE) fan_post(F, 0, lane, q.o, q.d, q.tmin, q.tmax, false);      // the primary query
     }
 
@@ -835,8 +875,11 @@ __device__ __forceinline__ void trace_block(const SceneDev &S, const FrameParams
     }
     // a part of a split block sees fewer lanes, hence fewer iterations than the whole block would: scaled so that the block
     // stays in its schedule class from frame to frame (x 1.5 for 4 parts, x 2 for 16, x 2.5 for 64: measured ratios are 1.3-2)
-    const uint32_t part_iters = WAVES3 ? F->iters[0] + F->iters[1] + F->iters[2] : wave_iters;
-    const uint32_t wave_max_steps = part_iters + ((part_iters * lg) >> 2);
+    uint32_t part_iters = wave_iters;
+    if constexpr (WAVES3) part_iters = F->iters[0] + F->iters[1] + F->iters[2];
+    // (MODE 3: a part that fans its queries out walks max(shadow, shadow, bounce) where the block walked their sum: x YCGE_PARTFAN_COST_NUM / 4 on top)
+    const uint32_t part_scaled = part_iters + ((part_iters * lg) >> 2);
+    const uint32_t wave_max_steps = (INW && fanrt) ? (part_scaled * YCGE_PARTFAN_COST_NUM) >> 2 : part_scaled;
     if (O.block_cost && lane == 0) atomicMax(O.block_cost + bid, wave_max_steps);      // feedback for the next frame's schedule
     if (prof && lane == 0 && YCGE_ENT_PART(ent) == 0) {
         unsigned long long *dst = O.wave_prof + ((size_t)k * 4 + wave_in_tile) * 4;
@@ -858,7 +901,8 @@ __device__ __forceinline__ void trace_block(const SceneDev &S, const FrameParams
             q.live = phase != PH_DONE;
             traverse<COUNT, true, FLAT, true>(S, q, st, t_hit, hit_prim, hit_sub, w);
         } else if (phase != PH_DONE && !parked) {
-            if (want == 3) { t_hit = pre_b_t; hit_prim = pre_b_prim; hit_sub = pre_b_sub; }
+            if (INW && !fanrt) { t_hit = ans_t; hit_prim = ans_prim; hit_sub = ans_sub; }
+            else if (want == 3 && !INW) { t_hit = pre_b_t; hit_prim = pre_b_prim; hit_sub = pre_b_sub; }
             else { t_hit = F->r[want][0][lane]; hit_prim = __float_as_int(F->r[want][1][lane]); hit_sub = __float_as_int(F->r[want][2][lane]); }
         }
         if (!FAN) wave_iters += wave_umax(w.steps - steps_before);
@@ -955,7 +999,7 @@ __device__ __forceinline__ void trace_block(const SceneDev &S, const FrameParams
                     shade_ctx_store(ctx_addr, sh_p, sh_n, sh_alb, sh_wo);
                     light = 0;
                     go_lights = true;
-                    if (FAN) {          // post this hit's independent queries: the expressions of the light loop head and the bounce below
+                    if (FAN && fanrt) { // post this hit's independent queries: the expressions of the light loop head and the bounce below
                         int ns = 0;
                         pre_l1 = pre_l2 = -1;
                         pre_b = false;
@@ -1083,7 +1127,8 @@ __device__ __forceinline__ void trace_block(const SceneDev &S, const FrameParams
             }
         }
 
-        if (FAN && phase != PH_DONE) {                  // where is the answer to the query just set up?
+        if (INW && !fanrt) parked = true;               // (a whole block: the query just set up waits in `q` for stage B)
+        else if (FAN && phase != PH_DONE) {             // where is the answer to the query just set up?
             if (new_kind == 1 && light == pre_l1) { want = 1; pre_l1 = -1; }
             else if (new_kind == 1 && light == pre_l2) { want = 2; pre_l2 = -1; }
             else if (new_kind == 2 && (pre_b || bounce_in_flight)) { want = 3; pre_b = false; }
@@ -1091,10 +1136,10 @@ __device__ __forceinline__ void trace_block(const SceneDev &S, const FrameParams
             if (fanned) parked = true;
         }
     }
-    if (WAVES3) { const bool alive = __any(phase != PH_DONE); if (lane == 0) F->alive = alive ? 1 : 0; }
+    if constexpr (WAVES3) { const bool alive = __any(phase != PH_DONE); if (lane == 0) F->alive = alive ? 1 : 0; }
    }
    if (!FAN) break;
-   if (WAVES3) {
+   if constexpr (WAVES3) {
        __syncthreads();
        if (!F->alive) break;
        // ---- stage B: wavefront w answers slot w
@@ -1112,6 +1157,32 @@ __device__ __forceinline__ void trace_block(const SceneDev &S, const FrameParams
        }
        wave_iters += wave_umax(w.steps - steps_before);
        __syncthreads();
+   } else if constexpr (INW) {
+       if (!__any(phase != PH_DONE)) break;
+       // ---- stage B inside the one wavefront: lane = slot * pixels + pixel answers that pixel's slot (a part), or its own query (a whole block)
+       __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+       __builtin_amdgcn_wave_barrier();
+       const uint32_t steps_before = w.steps;
+       const int b_slot = lane >> (6 - (int)lg), b_src = lane & (live_lanes - 1);
+       const bool b_valid = fanrt && b_slot < 3;
+       // (`q` itself carries the slot's query through the walk - a second ray beside it cost the kernel its last free registers - and the
+       // pixel lanes take their pending query back from its slot afterwards: origin, direction, range, kind; tmin is set anew by whoever walks on)
+       q.live = phase != PH_DONE;
+       if (fanrt) {
+           q = fan_query(F, b_valid ? b_slot : 0, b_src);
+           q.live = b_valid && q.tmin >= 0.0f;
+       }
+       traverse<COUNT, true, FLAT, true>(S, q, st, ans_t, ans_prim, ans_sub, w);
+       if (fanrt) {
+           if (q.live) {
+               F->r[b_slot][0][b_src] = ans_t; F->r[b_slot][1][b_src] = __int_as_float(ans_prim); F->r[b_slot][2][b_src] = __int_as_float(ans_sub);
+               F->q[b_slot][3][b_src] = -1.0f;
+           }
+           __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+           __builtin_amdgcn_wave_barrier();
+           if (phase != PH_DONE) q = fan_query(F, want == 3 ? 0 : want, lane);
+       }
+       wave_iters += wave_umax(w.steps - steps_before);
    } else {
 #if YCGE_EXPERIMENTS
        if (!__any(phase != PH_DONE)) break;
@@ -1156,13 +1227,14 @@ __device__ __forceinline__ void trace_block(const SceneDev &S, const FrameParams
 #endif
    }
    parked = false;
-   if (bounce_in_flight) {      // slot 0 is needed for the queries that go one at a time: keep the bounce answer in registers
-        pre_b_t = F->r[0][0][lane]; pre_b_prim = __float_as_int(F->r[0][1][lane]); pre_b_sub = __float_as_int(F->r[0][2][lane]);
+   if (bounce_in_flight) {      // slot 0 is needed for the queries that go one at a time: keep the bounce answer in registers (MODE 3: in a fourth answer slot)
+        if constexpr (INW) { F->r[3][0][lane] = F->r[0][0][lane]; F->r[3][1][lane] = F->r[0][1][lane]; F->r[3][2][lane] = F->r[0][2][lane]; }
+        else { pre_b_t = F->r[0][0][lane]; pre_b_prim = __float_as_int(F->r[0][1][lane]); pre_b_sub = __float_as_int(F->r[0][2][lane]); }
         bounce_in_flight = false; pre_b = true;
    }
   }
 
-    if (WAVES3) {
+    if constexpr (WAVES3) {
         if (lane == 0) F->iters[wave] = wave_iters;
         __syncthreads();
         if (wave != 0) { flush_work<COUNT>(w, O.counters); return; }
@@ -1192,7 +1264,16 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu((FLAT && !CO
         if (idx >= *O.n_order) return;
         ent = O.block_order[idx];
     } else if (blockIdx.x >= (uint32_t)P.n_owned_tiles * 4u) return;
-    trace_block<COUNT, FLAT, 0>(S, P, O, ent, idx, nullptr, 0);
+#if YCGE_PARTFAN == 2      // parts through MODE 3, whole blocks through round 5's MODE 0: two copies of the loop in one kernel (A/B)
+    __shared__ FanPart F;
+    if (YCGE_ENT_LG(ent) >= 2u) trace_block<COUNT, FLAT, 3, true, FanPart>(S, P, O, ent, idx, &F, 0);
+    else trace_block<COUNT, FLAT, 0>(S, P, O, ent, idx, (FanShared *)nullptr, 0);
+#elif YCGE_PARTFAN
+    __shared__ FanPart F;
+    trace_block<COUNT, FLAT, 3, true, FanPart>(S, P, O, ent, idx, &F, 0);
+#else
+    trace_block<COUNT, FLAT, 0>(S, P, O, ent, idx, (FanShared *)nullptr, 0);
+#endif
 }
 // SEVERAL frames' blocks in one launch (ycge_trace_tiles_resident_batch: a rank's tiles of n consecutive frames): workgroup b traces
 // schedule entry b / n of frame b % n - the frames share one schedule, so the heaviest blocks of every frame go first - with that frame's
@@ -1211,7 +1292,16 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu((FLAT && !CO
         if (idx >= *O.n_order) return;
         ent = O.block_order[idx];
     } else if (i >= (uint32_t)P.n_owned_tiles * 4u) return;
-    trace_block<COUNT, FLAT, 0>(S, P, O, ent, idx, nullptr, 0);
+#if YCGE_PARTFAN == 2      // parts through MODE 3, whole blocks through round 5's MODE 0: two copies of the loop in one kernel (A/B)
+    __shared__ FanPart F;
+    if (YCGE_ENT_LG(ent) >= 2u) trace_block<COUNT, FLAT, 3, true, FanPart>(S, P, O, ent, idx, &F, 0);
+    else trace_block<COUNT, FLAT, 0>(S, P, O, ent, idx, (FanShared *)nullptr, 0);
+#elif YCGE_PARTFAN
+    __shared__ FanPart F;
+    trace_block<COUNT, FLAT, 3, true, FanPart>(S, P, O, ent, idx, &F, 0);
+#else
+    trace_block<COUNT, FLAT, 0>(S, P, O, ent, idx, (FanShared *)nullptr, 0);
+#endif
 }
 // The same kernel for scenes WITHOUT a mesh (nothing to walk cooperatively: the treelet code is compiled out and, with it, the register
 // peak): 125 registers, 4 wavefronts per SIMD - analytic scenes are throughput, not chains (config 2: 0.082 ms at 3 wavefronts, 0.068 at 4).
@@ -1224,7 +1314,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 8))) void
         if (idx >= *O.n_order) return;
         ent = O.block_order[idx];
     } else if (blockIdx.x >= (uint32_t)P.n_owned_tiles * 4u) return;
-    trace_block<false, true, 0, false>(S, P, O, ent, idx, nullptr, 0);
+    trace_block<false, true, 0, false>(S, P, O, ent, idx, (FanShared *)nullptr, 0);
 }
 #if YCGE_EXPERIMENTS
 template <bool COUNT>

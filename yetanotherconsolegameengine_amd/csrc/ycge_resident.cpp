@@ -50,7 +50,7 @@ static int ensure_resident(ycge_ctx *c)
 }
 
 int ycge_halo_counts(ycge_ctx *c, int64_t *send_counts, int64_t *recv_counts)
-{
+try {
     if (!c) return YCGE_ERR_INVALID_ARG;
     if (!send_counts || !recv_counts) return c->fail(YCGE_ERR_INVALID_ARG, "null count array");
     { const int jr = join_async(c); if (jr != YCGE_OK) return jr; }
@@ -59,17 +59,19 @@ int ycge_halo_counts(ycge_ctx *c, int64_t *send_counts, int64_t *recv_counts)
     for (int r = 0; r < c->cfg.world_size; r++) { send_counts[r] = c->halo_send_counts[(size_t)r]; recv_counts[r] = c->halo_recv_counts[(size_t)r]; }
     return YCGE_OK;
 }
+catch (...) { return ycge_host::abi_catch(c); }
 
 int ycge_history_slab_bytes(const ycge_ctx *c, size_t *bytes)
-{
+try {
     if (!c || !bytes) return YCGE_ERR_INVALID_ARG;
     *bytes = (size_t)c->tiles_per_rank_padded * 256 * 3 * sizeof(float);
     return YCGE_OK;
 }
+catch (...) { return ycge_host::abi_catch(c); }
 
 // steps 1-4 of TryFlipAndBlit on this rank's tiles into the frame set of the ring, then the halo records the other ranks need
 int ycge_trace_tiles_resident(ycge_ctx *c, void *d_halo_send, void *hip_stream, ycge_frame_stats *st)
-{
+try {
     if (!c) return YCGE_ERR_INVALID_ARG;
     { const int jr = join_async(c); if (jr != YCGE_OK) return jr; }
     int rc = ensure_resident(c);
@@ -140,6 +142,7 @@ int ycge_trace_tiles_resident(ycge_ctx *c, void *d_halo_send, void *hip_stream, 
     }
     return YCGE_OK;
 }
+catch (...) { return ycge_host::abi_catch(c); }
 
 // n consecutive frames of this rank's tiles in ONE launch (k_trace_batch): what one frame's launch - a rank's share is a few thousand
 // blocks - leaves idle around its longest chains, the other frames' blocks fill.  poses: n x {pos xyz, yaw, pitch, fov} (the camera of each
@@ -148,7 +151,7 @@ int ycge_trace_tiles_resident(ycge_ctx *c, void *d_halo_send, void *hip_stream, 
 // never needed each other's traces).  Scenes that trace in stages or keep refraction stacks, and counting contexts, take the frames one
 // by one here too.
 int ycge_trace_tiles_resident_batch(ycge_ctx *c, int32_t n, const float *poses, void *const *d_halo_send, void *hip_stream)
-{
+try {
     if (!c) return YCGE_ERR_INVALID_ARG;
     if (n < 1 || n > ycge_ctx::kBatchMax || !poses) return c->fail(YCGE_ERR_INVALID_ARG, "a batch is 1..%d frames with their poses", ycge_ctx::kBatchMax);
     { const int jr = join_async(c); if (jr != YCGE_OK) return jr; }
@@ -164,6 +167,27 @@ int ycge_trace_tiles_resident_batch(ycge_ctx *c, int32_t n, const float *poses, 
         const float *q = poses + 6 * k;
         c->cam_pos[0] = q[0]; c->cam_pos[1] = q[1]; c->cam_pos[2] = q[2]; c->yaw = q[3]; c->pitch = q[4]; c->fov_deg = q[5];
     };
+    // A batch is all or nothing for the HOST-side state, on both ways through this function: frames enter the pending list for good only
+    // once the whole batch is queued, and a failure on the way (a launch refused, an allocation, an exception) puts the frame counter, the
+    // pending list, the camera and the batch parity back where they were - the caller's exchange ring and the library stay in step.
+    // (What a failed HIP call leaves on the device is the device's business: the context reports YCGE_ERR_DEVICE.)
+    struct Rollback {
+        ycge_ctx *c; int64_t counter; size_t pending; uint64_t batches; float pos[3], yaw, pitch, fov; bool armed = true;
+        Rollback(ycge_ctx *c_) : c(c_), counter(c_->frame_counter), pending(c_->pending.size()), batches(c_->batch_count)
+        {
+            std::lock_guard<std::mutex> g(c->cam_lock);
+            pos[0] = c->cam_pos[0]; pos[1] = c->cam_pos[1]; pos[2] = c->cam_pos[2]; yaw = c->yaw; pitch = c->pitch; fov = c->fov_deg;
+        }
+        ~Rollback()
+        {
+            if (!armed) return;
+            c->frame_counter = counter; c->batch_count = batches;
+            while (c->pending.size() > pending) c->pending.pop_back();
+            c->batch_collect = false; c->batch_P.clear(); c->batch_O.clear();
+            std::lock_guard<std::mutex> g(c->cam_lock);
+            c->cam_pos[0] = pos[0]; c->cam_pos[1] = pos[1]; c->cam_pos[2] = pos[2]; c->yaw = yaw; c->pitch = pitch; c->fov_deg = fov;
+        }
+    } rollback(c);
     const bool single = frame_is_single_launch(c);
     if (!single || c->sd.any_transparent || c->cfg.count_work || n == 1) {
         for (int k = 0; k < n; k++) {
@@ -171,6 +195,7 @@ int ycge_trace_tiles_resident_batch(ycge_ctx *c, int32_t n, const float *poses, 
             rc = ycge_trace_tiles_resident(c, d_halo_send ? d_halo_send[k] : nullptr, hip_stream, nullptr);
             if (rc != YCGE_OK) return rc;
         }
+        rollback.armed = false;
         return YCGE_OK;
     }
     hipStream_t stream = hip_stream ? (hipStream_t)hip_stream : c->stream;
@@ -181,14 +206,6 @@ int ycge_trace_tiles_resident_batch(ycge_ctx *c, int32_t n, const float *poses, 
     std::vector<ycge_ctx::ResidentSet *> sets((size_t)n, nullptr);
     c->batch_P.clear(); c->batch_O.clear();
     int ob = -1;
-    // A batch is all or nothing for the host-side state: frames enter the pending list only after the whole batch is queued, and a failure on
-    // the way (a launch refused, an allocation) puts the frame counter back and leaves the list as it was - the caller's exchange and the
-    // ring stay in step.  (What a failed HIP call leaves on the device is the device's business: the context reports YCGE_ERR_DEVICE.)
-    const int64_t frame_counter_before = c->frame_counter;
-    struct Rollback {
-        ycge_ctx *c; int64_t counter; bool armed = true;
-        ~Rollback() { if (armed) { c->frame_counter = counter; c->batch_collect = false; c->batch_P.clear(); c->batch_O.clear(); } }
-    } rollback{c, frame_counter_before};
     for (int k = 0; k < n; k++) {
         set_pose(k);
         snapshot_frame(c, fs[(size_t)k]);
@@ -259,10 +276,11 @@ int ycge_trace_tiles_resident_batch(ycge_ctx *c, int32_t n, const float *poses, 
     }
     return YCGE_OK;
 }
+catch (...) { return ycge_host::abi_catch(c); }
 
 // the records of this frame's halo into its set, TAA on this rank's own tiles (steps 5 and 9), the resolved history of those tiles as a slab
 int ycge_resolve_tiles_resident(ycge_ctx *c, const void *d_halo_recv, void *d_history_slab, void *hip_stream, ycge_frame_stats *st)
-{
+try {
     if (!c) return YCGE_ERR_INVALID_ARG;
     if (c->pending.empty() || c->rsets.empty()) return c->fail(YCGE_ERR_INVALID_ARG, "no traced frame to resolve: every ycge_resolve_tiles_resident follows its own ycge_trace_tiles_resident");
     HIP_TRY(c, hipSetDevice(c->device));
@@ -311,10 +329,11 @@ int ycge_resolve_tiles_resident(ycge_ctx *c, const void *d_halo_recv, void *d_hi
     }
     return YCGE_OK;
 }
+catch (...) { return ycge_host::abi_catch(c); }
 
 // the consumer's half: world_size history slabs (rank-major, as an all-gather or a gather leaves them) into the full-frame history
 int ycge_unpack_history(ycge_ctx *c, const void *d_all_history_slabs, void *hip_stream)
-{
+try {
     if (!c) return YCGE_ERR_INVALID_ARG;
     if (!d_all_history_slabs) return c->fail(YCGE_ERR_INVALID_ARG, "null gathered history slabs");
     HIP_TRY(c, hipSetDevice(c->device));
@@ -324,13 +343,14 @@ int ycge_unpack_history(ycge_ctx *c, const void *d_all_history_slabs, void *hip_
     if (e != 0) return c->fail(YCGE_ERR_DEVICE, "k_unpack_history launch failed: %s", hipGetErrorString((hipError_t)e));
     return YCGE_OK;
 }
+catch (...) { return ycge_host::abi_catch(c); }
 
 // measurement (profiles/rank_flight.py): a rank's pipelined loop of the tile-resident form driven from C - K traces in flight over K streams,
 // a device copy of the rank's own records standing in for the all-to-all, resolve + history slab on another stream - so that what is timed
 // is the library's and the driver's host cost per frame, not a scripting language's.  period_ms: wall time per frame; issue_ms: host time
 // to queue a frame (where the two agree the loop is host-bound).
 int ycge_debug_resident_loop(ycge_ctx *c, int32_t frames, double *period_ms, double *issue_ms)
-{
+try {
     if (!c || frames <= 0 || !period_ms || !issue_ms) return YCGE_ERR_INVALID_ARG;
     { const int jr = join_async(c); if (jr != YCGE_OK) return jr; }
     int rc = ensure_resident(c);
@@ -474,10 +494,11 @@ int ycge_debug_resident_loop(ycge_ctx *c, int32_t frames, double *period_ms, dou
     cleanup();
     return YCGE_OK;
 }
+catch (...) { return ycge_host::abi_catch(c); }
 
 // the halo lists of (hiW, hiH, rank, world) as pure host code (CPU tests hold them to tiles.py): counts per peer, then the pixel lists
 int ycge_host_halo_layout(int32_t hiW, int32_t hiH, int32_t rank, int32_t world, int64_t *send_counts, int64_t *recv_counts, uint32_t *send_px, uint32_t *recv_px, int64_t capacity)
-{
+try {
     if (hiW <= 0 || hiH <= 0 || world < 1 || rank < 0 || rank >= world || !send_counts || !recv_counts) return YCGE_ERR_INVALID_ARG;
     std::vector<int64_t> sc, rcv; std::vector<uint32_t> spx, rpx;
     halo_layout(hiW, hiH, rank, world, sc, rcv, spx, rpx);
@@ -486,9 +507,10 @@ int ycge_host_halo_layout(int32_t hiW, int32_t hiH, int32_t rank, int32_t world,
     if (recv_px && (int64_t)rpx.size() <= capacity) std::memcpy(recv_px, rpx.data(), rpx.size() * 4);
     return ((int64_t)spx.size() <= capacity && (int64_t)rpx.size() <= capacity) || (!send_px && !recv_px) ? YCGE_OK : YCGE_ERR_INVALID_ARG;
 }
+catch (...) { return ycge_host::abi_catch(nullptr); }
 
 int ycge_read_buffer(ycge_ctx *c, int32_t which, void *dst, size_t bytes)
-{
+try {
     if (!c) return YCGE_ERR_INVALID_ARG;
     if (!dst) return c->fail(YCGE_ERR_INVALID_ARG, "null destination");
     HIP_TRY(c, hipSetDevice(c->device));
@@ -520,6 +542,7 @@ int ycge_read_buffer(ycge_ctx *c, int32_t which, void *dst, size_t bytes)
     HIP_TRY(c, hipStreamSynchronize(c->stream));
     return copy_out(c, dst, src, want);
 }
+catch (...) { return ycge_host::abi_catch(c); }
 
 static int accel_view(ycge_ctx *c, int32_t which, int32_t index, const void **p, size_t *n)
 {
@@ -547,7 +570,7 @@ static int accel_view(ycge_ctx *c, int32_t which, int32_t index, const void **p,
     return -1;
 }
 int ycge_accel_size(ycge_ctx *c, int32_t which, int32_t index, size_t *bytes)
-{
+try {
     const void *p; size_t n;
     if (!c || !bytes) return YCGE_ERR_INVALID_ARG;
     if (!c->have_scene) return c->fail(YCGE_ERR_NO_SCENE, "no scene uploaded");
@@ -555,8 +578,9 @@ int ycge_accel_size(ycge_ctx *c, int32_t which, int32_t index, size_t *bytes)
     *bytes = n;
     return YCGE_OK;
 }
+catch (...) { return ycge_host::abi_catch(c); }
 int ycge_read_accel(ycge_ctx *c, int32_t which, int32_t index, void *dst, size_t bytes)
-{
+try {
     const void *p; size_t n;
     if (!c || !dst) return YCGE_ERR_INVALID_ARG;
     if (!c->have_scene) return c->fail(YCGE_ERR_NO_SCENE, "no scene uploaded");
@@ -564,5 +588,6 @@ int ycge_read_accel(ycge_ctx *c, int32_t which, int32_t index, void *dst, size_t
     std::memcpy(dst, p, n);
     return YCGE_OK;
 }
+catch (...) { return ycge_host::abi_catch(c); }
 
 } // extern "C"

@@ -19,6 +19,21 @@ from .scene import FlatScene, Scene, flatten
 NODE_DTYPE = np.dtype([("min", "<f4", 3), ("max", "<f4", 3), ("left", "<i4"), ("right", "<i4"), ("start", "<i4"), ("count", "<i4")])
 
 
+class _PageLockedOwner:
+    """Owns one ycge_alloc_host_buffer allocation; frees it when collected (after the last numpy view over it)."""
+
+    def __init__(self, lib, address: int):
+        self._lib, self.address = lib, address
+
+    def __del__(self):
+        try:
+            if self.address:
+                self._lib.ycge_free_host_buffer(C.c_void_p(self.address))
+                self.address = 0
+        except Exception:
+            pass
+
+
 class RaytraceRenderer:
     def __init__(self, scene: Scene | FlatScene, fb_width: int, fb_height: int, fovDeg: float = 45.0, superSample: int = 1, *,
                  cfg: Optional[abi.Config] = None, capture_debug: bool = False, count_work: bool = False, device: int = 0,
@@ -144,23 +159,28 @@ class RaytraceRenderer:
         self._check(self.L.ycge_set_camera(self.ctx, p, self._yaw, self._pitch, self._fov))
 
     def _page_locked_zeros(self, shape):
-        """A zeroed float32 array in page-locked memory OF THE LIBRARY (ycge_alloc_host_buffer: hipHostMalloc): (array, handle).  The
+        """A zeroed float32 array in page-locked memory OF THE LIBRARY (ycge_alloc_host_buffer: hipHostMalloc): (array, owner).  The
         device writes SDR frames straight into it.  Round 4 registered numpy arrays instead (hipHostRegister) and met GPU memory faults
         at heap addresses: registration is page-granular, and - more to the point - a mapping of process heap lives and dies with the
-        allocator, not with the array (csrc/ycge_host.cpp: copy_out).  The handle goes back through _free_page_locked; the array must
-        not be touched after that."""
+        allocator, not with the array (csrc/ycge_host.cpp: copy_out).
+        LIFETIME: the allocation belongs to the ARRAY, not to the renderer - the ctypes buffer under the numpy array carries a
+        _PageLockedOwner whose finaliser hands the pages back (ycge_free_host_buffer) when the last view of the array dies.  close(),
+        Resize() and a change of console size only drop the renderer's own reference (after joining the frames in flight, so the device
+        is done with the pages): an array a caller still holds - TryFlipAndBlit(copy=False), RenderAsync(sdr_slot=k) - stays readable."""
         n = int(np.prod(shape))
         p = C.c_void_p()
         rc = self.L.ycge_alloc_host_buffer(n * 4, C.byref(p))
         if rc != 0 or not p.value:
             raise abi.YcgeError(rc, f"no page-locked memory for an SDR frame of {n * 4} bytes")
-        a = np.ctypeslib.as_array(C.cast(p, C.POINTER(C.c_float)), shape=(n,)).reshape(shape)
-        return a, p
+        owner = _PageLockedOwner(self.L, p.value)
+        buf = (C.c_float * n).from_address(p.value)
+        buf._ycge_owner = owner          # (numpy keeps `buf` alive through the buffer protocol; `buf` keeps the owner)
+        a = np.ctypeslib.as_array(buf).reshape(shape)
+        return a, owner
 
     def _free_page_locked(self, handle):
-        if handle is not None and handle.value:
-            self.L.ycge_free_host_buffer(handle)
-            handle.value = None
+        """Drops the renderer's reference; the pages go back when no array over them is left (see _page_locked_zeros)."""
+        return None
 
     def _sdr_buffer(self):
         """The wrapper's ONE SDR buffer (the C# side keeps one for the life of the renderer, bindings/csharp/HipRaytraceWrapper.cs), page-locked
@@ -181,7 +201,8 @@ class RaytraceRenderer:
 
     def TryFlipAndBlit(self, want_sdr: bool = False, copy: bool = True):
         """One frame.  Returns the fbH x fbW x 2 x 3 SDR array (top, bottom per chexel) when want_sdr (a copy of the wrapper's
-        buffer; copy=False hands out the buffer itself, overwritten by the next frame), else the frame statistics."""
+        buffer; copy=False hands out the buffer itself: OVERWRITTEN by the next frame of this size, left alone - and valid for as long as
+        the caller holds it - after Resize() to another size or close()), else the frame statistics."""
         sdr = self._sdr_buffer() if want_sdr else None
         ptr = sdr.ctypes.data_as(C.POINTER(C.c_float)) if want_sdr else None
         self._check(self.L.ycge_render_frame(self.ctx, ptr, C.byref(self.stats)))
@@ -212,7 +233,7 @@ class RaytraceRenderer:
         """What the frames-in-flight machinery of this context does (ycge_flight_query): timing only, never a pixel."""
         fi = abi.FlightInfo()
         self._check(self.L.ycge_flight_query(self.ctx, C.byref(fi)))
-        return {f: int(getattr(fi, f)) for f, _ in abi.FlightInfo._fields_ if f != "reserved"}
+        return {f: int(getattr(fi, f)) for f, _ in abi.FlightInfo._fields_}
 
     def async_trace_ms(self, capacity: int = 1024) -> np.ndarray:
         """Durations (ms) of the trace launches of the frames queued since the last call (waits for them), oldest first."""
