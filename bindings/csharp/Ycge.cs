@@ -142,6 +142,7 @@ namespace ConsoleGame.RayTracing.Native
         public fixed int Devices[8];
         public int AtrousInplaceExact;
         public int TileRing;
+        public int MultiDeviceExchange;   // YExchange: 0 = the peers push their tiles (default), 1 = RCCL all-gather inside ycge_render_frame
     }
 
     [StructLayout(LayoutKind.Sequential)]
@@ -166,13 +167,14 @@ namespace ConsoleGame.RayTracing.Native
 
     public enum YStatus { Ok = 0, InvalidArg = -1, NoScene = -2, Device = -3, Unsupported = -4, OutOfMemory = -5, StackDepth = -6, NoDeviceCode = -7, Internal = -8 }
     public enum YMaterialKind { Constant = 0, Checker = 1, Textured = 2 }
+    public enum YExchange { PeerPush = 0, Rccl = 1 }
     public enum YPrimType { Sphere = 0, Plane = 1, Disk = 2, XYRect = 3, XZRect = 4, YZRect = 5, Box = 6, CylinderY = 7, Triangle = 8, Mesh = 9, VolumeGrid = 10 }
     public enum YBuffer { Rays = 0, PrimId = 1, SubId = 2, HitT = 3, CurrentHdr = 4, GAlbedo = 5, GNormal = 6, GDepth = 7, SkyMask = 8, TaaHistory = 9, PrevNormal = 10, PrevDepth = 11, PrevSky = 12, Denoised = 13, RngState = 14 }
     public enum YAccel { SceneNodes = 0, SceneLeafIndex = 1, MeshNodes = 2, MeshLeafIndex = 3 }
 
     internal static unsafe class Ycge
     {
-        public const int AbiVersion = 8;
+        public const int AbiVersion = 9;
         public const int MaxDevices = 8;
         private const string Lib = "ycge_hip";       // libycge_hip.so
 
@@ -193,6 +195,7 @@ namespace ConsoleGame.RayTracing.Native
         [DllImport(Lib)] public static extern int ycge_wait(IntPtr ctx);
         [DllImport(Lib)] public static extern int ycge_async_trace_times(IntPtr ctx, float* msOut, int capacity, out int nOut);
         [DllImport(Lib)] public static extern int ycge_flight_query(IntPtr ctx, out YFlightInfo info);
+        [DllImport(Lib)] public static extern int ycge_exchange_query(IntPtr ctx, out int mode, out int world);
         // one process per GPU (INTEGRATION.md section 5): device pointers and HIP streams travel as IntPtr
         [DllImport(Lib)] public static extern int ycge_tile_slab_bytes(IntPtr ctx, out UIntPtr bytes);
         [DllImport(Lib)] public static extern int ycge_trace_tiles(IntPtr ctx, IntPtr dSlab, IntPtr stream, YFrameStats* stats);

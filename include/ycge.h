@@ -35,7 +35,7 @@
 extern "C" {
 #endif
 
-#define YCGE_ABI_VERSION 8
+#define YCGE_ABI_VERSION 9
 #define YCGE_MAX_DEVICES 8
 
 typedef enum ycge_status {
@@ -246,7 +246,18 @@ typedef struct ycge_config {
     int32_t atrous_inplace_exact;
     /* tile-resident form (ycge_trace_tiles_resident): frame sets in the ring = tiled traces that may be in flight at a time, 2..15; 0 = 2 */
     int32_t tile_ring;
+    /* One process, several GPUs (n_devices >= 1): how the devices' tiles come together on devices[0] (ABI 9).
+     * YCGE_EXCHANGE_PEER_PUSH (0, default): the peers write their tiles straight into devices[0]'s frame buffers (k_push_tiles, no collective).
+     * YCGE_EXCHANGE_RCCL (1): every device packs its tiles into a slab, ONE ncclAllGather over the devices' in-process communicators
+     * (ncclCommInitAll; librccl.so is dlopen'ed, the library does not link it) reassembles the frame, devices[0] un-permutes it and runs
+     * TAA and the post stage - the all-gather of SURVEY 8(e) behind the one TryFlipAndBlit call a single-process host makes.  Same pixels.
+     * Where librccl.so or its symbols are missing the context falls back to the peer push; ycge_exchange_query says which is in use.
+     * n_devices = 1 with YCGE_EXCHANGE_RCCL is a world of one (the frame goes through slab, all-gather and un-permute): what a one-GPU
+     * box can test.  RCCL refuses two ranks on one device: devices[] must then be distinct. */
+    int32_t multi_device_exchange;
 } ycge_config;
+
+typedef enum ycge_exchange { YCGE_EXCHANGE_PEER_PUSH = 0, YCGE_EXCHANGE_RCCL = 1 } ycge_exchange;
 
 typedef struct ycge_frame_stats {
     int64_t frame;               /* frameCounter after the increment            */
@@ -376,6 +387,9 @@ typedef struct ycge_flight_info {
     uint64_t placed_waits;       /* traces that were queued behind a placed value since the context was created                 */
 } ycge_flight_info;
 int ycge_flight_query(ycge_ctx *ctx, ycge_flight_info *out);
+/* which exchange the one-process multi-device frame uses: *mode_out = YCGE_EXCHANGE_PEER_PUSH or YCGE_EXCHANGE_RCCL (the latter only when
+ * config.multi_device_exchange asked for it AND librccl.so was found and its communicators came up); *world_out = devices that trace */
+int ycge_exchange_query(ycge_ctx *ctx, int32_t *mode_out, int32_t *world_out);
 
 /* --- multi-GPU halves of a frame (one process per GPU; the exchange between
  * them is one all-gather of the tile slabs, done by the caller with RCCL).

@@ -166,6 +166,7 @@ def test_enums_and_constants_match_the_header():
     assert norm(cs_enum("YPrimType")) == norm(c_enum("YCGE_PRIM_"))
     assert norm(cs_enum("YBuffer")) == norm(c_enum("YCGE_BUF_"))
     assert norm(cs_enum("YAccel")) == norm(c_enum("YCGE_ACCEL_"))
+    assert norm(cs_enum("YExchange")) == norm(c_enum("YCGE_EXCHANGE_"))
     assert int(re.search(r"#define YCGE_ABI_VERSION (\d+)", header).group(1)) == abi.YCGE_ABI_VERSION == int(re.search(r"public const int AbiVersion = (\d+);", SRC).group(1))
     assert int(re.search(r"#define YCGE_MAX_DEVICES (\d+)", header).group(1)) == int(re.search(r"public const int MaxDevices = (\d+);", SRC).group(1))
 

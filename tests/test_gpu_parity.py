@@ -471,6 +471,31 @@ def _experiments_lib():
     return abi.load_library(build.build_variant("experiments"))
 
 
+@pytest.mark.parametrize("cfg_n", [1, 3, 4])
+def test_taa_inside_the_trace_launch_is_bit_exact(oracle, monkeypatch, cfg_n):
+    """csrc/experiments/ycge_taa_in_trace.hip.h (round 6, measured and rejected: slower - profiles/r06/b_taa_in_trace.txt): TemporalBlendWithClamp
+    resolved by the trace launch itself - written-through stores, neighbourhood counters, the last finisher of a 3 x 3 block neighbourhood stages
+    the 10 x 10 window in LDS with device-coherent loads.  Same reads, same arithmetic, same writes as k_taa: history and guide copies equal the
+    oracle's over four frames (the first resets, the others blend), whole blocks and - config 4 at full size, steady state - the parts of split
+    blocks, with a sky / mesh boundary and the image's right and bottom edges in the windows."""
+    monkeypatch.setenv("YCGE_TAA_FUSE", "1")
+    monkeypatch.setenv("YCGE_PATH", "megakernel")
+    lib = _experiments_lib()
+    sc, w, h, ss, pose = scenes.config_scene(cfg_n)
+    if cfg_n == 3: w, h = 323, 91          # a trace grid that is no multiple of the 8 x 8 block: partial blocks on two sides
+    flat = flatten(sc)
+    o = oracle.OracleRenderer(sc, w, h, ss, pose, flat=flat)
+    g = RaytraceRenderer(flat, w, h, pose["fov"], ss, lib=lib)
+    g.SetCamera(pose["pos"], pose["yaw"], pose["pitch"])
+    for f in range(4 if cfg_n != 4 else 6):
+        o.render(stages=1, threads=8); g.TryFlipAndBlit()
+        if cfg_n == 4:          # (k_taa takes 33 us at 1080p; two event records back to back are ~5 us apart)
+            assert float(g.stats.taa_ms) < 0.02, "a TAA launch ran: the build or the knob did not take"
+        for b in (abi.BUF_CURRENT_HDR, abi.BUF_TAA_HISTORY, abi.BUF_PREV_NORMAL, abi.BUF_PREV_DEPTH, abi.BUF_PREV_SKY):
+            assert pu.mismatch_count(o.read(b), g.read(b)) == 0, (cfg_n, f, b)
+    o.close(); g.close()
+
+
 def _post_pair(oracle, sc, w, h, ss, pose, frames=3, lib=None):
     """oracle (stages=2) and product (SDR requested) over `frames` frames; yields per-frame comparison tuples"""
     flat = flatten(sc)
@@ -812,5 +837,18 @@ def test_page_locked_sdr_buffers_of_the_library(product_lib):
     assert pu.bits_equal(mine, plain)
     assert L.ycge_unpin_host_buffer(C.c_void_p(mine.ctypes.data)) == abi.YCGE_OK
     r.close(); r2.close()
+    # (3) the verdict covers the WHOLE range: a destination that starts inside a page-locked block and runs past its end is
+    #     pageable for the library's purposes - staged, or refused by the frames in flight - and so is plain heap memory
+    L.ycge_debug_is_page_locked.restype = C.c_int
+    L.ycge_debug_is_page_locked.argtypes = [C.c_void_p, C.c_size_t]
+    base, nbytes = bufs[0][0].value, n * 4
+    assert L.ycge_debug_is_page_locked(C.c_void_p(base), nbytes) == 1
+    assert L.ycge_debug_is_page_locked(C.c_void_p(base + 256), nbytes - 512) == 1
+    assert L.ycge_debug_is_page_locked(C.c_void_p(base + nbytes - 4096), 64 << 20) == 0, "a range that leaves the block was called page-locked"
+    assert L.ycge_debug_is_page_locked(C.c_void_p(plain.ctypes.data), plain.nbytes) == 0
+    assert L.ycge_pin_host_buffer(C.c_void_p(mine.ctypes.data), span) == abi.YCGE_OK
+    assert L.ycge_debug_is_page_locked(C.c_void_p(mine.ctypes.data), span) == 1
+    assert L.ycge_debug_is_page_locked(C.c_void_p(mine.ctypes.data + span - 4096), 2 * 4096 + 4096) == 0 or raw.nbytes >= off + span + 4096
+    assert L.ycge_unpin_host_buffer(C.c_void_p(mine.ctypes.data)) == abi.YCGE_OK
     for p, _ in bufs:
         assert L.ycge_free_host_buffer(p) == abi.YCGE_OK

@@ -153,3 +153,38 @@ def test_the_csharp_dump_tool_writes_what_the_harness_reads():
         assert t in ("YScene", "YMaterial", "YPrim", "YLight", "YMesh", "YGrid", "YVoxelLookup", "YTexture"), t
     csproj = (ROOT / "tools" / "ReferenceDump" / "ReferenceDump.csproj").read_text()
     assert "bindings/csharp/Ycge.cs" in csproj and "ConsoleGame.csproj" in csproj and "net8.0" in csproj
+
+
+def test_committed_scene_files_and_the_one_command_recipe(tmp_path, oracle):
+    """the scene files that are small live under tests/golden/reference/<name>/scene.ysc (gzip; sha256 in the
+    README there), tools/ReferenceDump/run_all.sh renders them with the reference and ends in tools/compare_dump.py - numpy + g++ only -
+    which holds a dump to the ORACLE and says PINNED or not.  Here, without .NET: every committed file is the one the README names and
+    loads; a dump made by the oracle compares clean through the CLI (exit 0), a perturbed one does not (exit 1)."""
+    import hashlib
+    import shutil
+    import subprocess
+    ref = ROOT / "tests" / "golden" / "reference"
+    readme = (ref / "README.md").read_text()
+    names = sorted(p.parent.name for p in ref.glob("*/scene.ysc"))
+    assert names == ["config1", "config2", "config3_320x90", "config4_reduced_320x90", "config5_reduced_96x27", "config5_reduced_noon_96x27"]
+    for n in names:
+        f = ref / n / "scene.ysc"
+        assert f.stat().st_size < 2_000_000, n
+        assert hashlib.sha256(f.read_bytes()).hexdigest() in readme, f"{n}: sha256 not in the README"
+        back = scene_file.LoadedScene(f)
+        assert back.fb_width > 0 and back.struct.n_prims > 0, n
+    sh = (ROOT / "tools" / "ReferenceDump" / "run_all.sh").read_text()
+    assert "tests/golden/reference" in sh and "compare_dump.py" in sh and "dotnet run" in sh and "TryFlipAndBlit" in sh
+    d = tmp_path / "config1"
+    d.mkdir()
+    shutil.copy(ref / "config1" / "scene.ysc", d / "scene.ysc")
+    back = scene_file.LoadedScene(d / "scene.ysc")
+    o = oracle.OracleRenderer(None, back.fb_width, back.fb_height, back.super_sample, back.pose, flat=back)
+    rd.write_dump(d, o, 2, lambda k: o.render(stages=2, threads=4, want_sdr=True), n_meshes=0)
+    o.close()
+    cli = [sys.executable, str(ROOT / "tools" / "compare_dump.py"), str(d)]
+    r = subprocess.run(cli, capture_output=True, text=True)
+    assert r.returncode == 0 and "PINNED" in r.stdout and "bit-exact" in r.stdout, r.stdout + r.stderr
+    hdr = np.fromfile(d / "f2_current_hdr.f32", dtype="<f4"); (hdr + np.float32(0.01)).astype("<f4").tofile(d / "f2_current_hdr.f32")
+    r = subprocess.run(cli, capture_output=True, text=True)
+    assert r.returncode == 1 and "NOT pinned" in r.stdout and "current_hdr" in r.stdout, r.stdout + r.stderr

@@ -45,7 +45,15 @@ namespace ReferenceDump
 
         public static LoadedScene Load(string path)
         {
-            var r = new Reader(File.ReadAllBytes(path));
+            byte[] raw = File.ReadAllBytes(path);
+            if (raw.Length > 2 && raw[0] == 0x1f && raw[1] == 0x8b)       // gzip (scene.ysc.gz: voxel worlds are mostly air)
+            {
+                using var src = new System.IO.Compression.GZipStream(new MemoryStream(raw), System.IO.Compression.CompressionMode.Decompress);
+                using var dst = new MemoryStream();
+                src.CopyTo(dst);
+                raw = dst.ToArray();
+            }
+            var r = new Reader(raw);
             if (r.Take<uint>() != 0x31435359u /* "YSC1" */ || r.Take<uint>() != 1u) throw new InvalidDataException(path + ": not a YSC1 version 1 file");
             var ls = new LoadedScene();
             ls.FbWidth = r.Take<int>(); ls.FbHeight = r.Take<int>(); ls.SuperSample = r.Take<int>(); ls.FovDeg = r.Take<float>();

@@ -44,7 +44,7 @@ def _zeroed(s, *pointer_fields):
     return bytes(t)
 
 
-def write_ysc(path, flat, fb_width, fb_height, super_sample, pose):
+def write_ysc(path, flat, fb_width, fb_height, super_sample, pose, compress=None):
     """`flat`: a FlatScene (yetanotherconsolegameengine_amd.scene.flatten); pose: {"pos", "yaw", "pitch", "fov"}."""
     sc = flat.struct
     out = [MAGIC, struct.pack("<I", 1),
@@ -75,7 +75,11 @@ def write_ysc(path, flat, fb_width, fb_height, super_sample, pose):
             out.append(bytes(n) if not t.frame else np.ctypeslib.as_array(t.frame, shape=(n,)).tobytes())
         else:
             out.append(np.ctypeslib.as_array(t.pixels, shape=(t.width * t.height,)).astype("<u4").tobytes())
-    Path(path).write_bytes(b"".join(out))
+    data = b"".join(out)
+    if compress or (compress is None and str(path).endswith(".gz")):           # (voxel worlds are mostly air: 8 MB -> ~100 KB; both readers take either form, told apart by gzip's magic number)
+        import gzip
+        data = gzip.compress(data, compresslevel=9, mtime=0)
+    Path(path).write_bytes(data)
 
 
 class LoadedScene:
@@ -84,6 +88,9 @@ class LoadedScene:
 
     def __init__(self, path):
         b = Path(path).read_bytes()
+        if b[:2] == b"\x1f\x8b":
+            import gzip
+            b = gzip.decompress(b)
         if b[:4] != MAGIC or struct.unpack_from("<I", b, 4)[0] != 1:
             raise ValueError(f"{path}: not a YSC1 version 1 file")
         o = 8
@@ -157,11 +164,13 @@ def main(argv):
     ap.add_argument("out")
     ap.add_argument("--t01", type=float, default=0.25, help="config 5: day phase (0.25 = the survey's; 0.5 = noon)")
     ap.add_argument("--size", default=None, help="console size WxH instead of the configuration's (e.g. 96x27 for a quick run)")
+    ap.add_argument("--gzip", action="store_true", help="write the file gzip-compressed whatever its name (both readers tell by the magic number)")
+    ap.add_argument("--small", action="store_true", help="configs 4 and 5: the reduced scene of the test suite (8 712 triangles; a 96 x 128 x 96 voxel world) - files small enough to commit")
     a = ap.parse_args(argv)
-    sc, w, h, ss, pose = scenes.config_scene(a.config, t01=a.t01)
+    sc, w, h, ss, pose = scenes.config_scene(a.config, small=a.small, t01=a.t01)
     if a.size:
         w, h = (int(v) for v in a.size.lower().split("x"))
-    write_ysc(a.out, flatten(sc), w, h, ss, pose)
+    write_ysc(a.out, flatten(sc), w, h, ss, pose, compress=True if a.gzip else None)
     print(f"{a.out}: config {a.config}, console {w}x{h}, ss {ss}, {Path(a.out).stat().st_size} bytes")
 
 

@@ -12,7 +12,7 @@ import ctypes as C
 import os
 from pathlib import Path
 
-YCGE_ABI_VERSION = 8
+YCGE_ABI_VERSION = 9
 YCGE_MAX_DEVICES = 8
 
 # ycge_status
@@ -33,6 +33,8 @@ STATUS_NAMES = {
     -8: "YCGE_ERR_INTERNAL",
 }
 
+# ycge_exchange
+EXCHANGE_PEER_PUSH, EXCHANGE_RCCL = 0, 1
 # ycge_material_kind
 MAT_CONSTANT, MAT_CHECKER, MAT_TEXTURED = 0, 1, 2
 # ycge_prim_type
@@ -130,7 +132,7 @@ class Config(C.Structure):
         ("count_work", C.c_int32),
         ("slab_albedo", C.c_int32),
         ("n_devices", C.c_int32), ("devices", C.c_int32 * YCGE_MAX_DEVICES),
-        ("atrous_inplace_exact", C.c_int32), ("tile_ring", C.c_int32),
+        ("atrous_inplace_exact", C.c_int32), ("tile_ring", C.c_int32), ("multi_device_exchange", C.c_int32),
     ]
 
 
@@ -168,6 +170,7 @@ def default_config() -> Config:
     c.slab_albedo, c.n_devices = 1, 0
     c.atrous_inplace_exact = 1
     c.tile_ring = 0
+    c.multi_device_exchange = EXCHANGE_PEER_PUSH
     return c
 
 
@@ -194,6 +197,7 @@ _PROTOTYPES = {
     "ycge_wait": (C.c_int, [C.c_void_p]),
     "ycge_async_trace_times": (C.c_int, [C.c_void_p, C.POINTER(C.c_float), C.c_int32, C.POINTER(C.c_int32)]),
     "ycge_flight_query": (C.c_int, [C.c_void_p, C.POINTER(FlightInfo)]),
+    "ycge_exchange_query": (C.c_int, [C.c_void_p, C.POINTER(C.c_int32), C.POINTER(C.c_int32)]),
     "ycge_tile_slab_bytes": (C.c_int, [C.c_void_p, C.POINTER(C.c_size_t)]),
     "ycge_trace_tiles": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.POINTER(FrameStats)]),
     "ycge_resolve_gathered": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.POINTER(C.c_float), C.POINTER(FrameStats)]),

@@ -137,6 +137,7 @@ struct Knobs {
     int pw_per_cu = 32;
     int post_band_rows = YCGE_POST_BAND_ROWS_DEFAULT, post_k = YCGE_POST_K_DEFAULT, post_groups = YCGE_POST_GROUPS_DEFAULT;
     int fan_class = -1, fan_cap = -1;   // -1 = default by world size
+    bool taa_fuse = false;           // YCGE_TAA_FUSE=1: the synchronous single-launch frame resolves TAA inside the trace launch - experiment builds only (csrc/experiments/ycge_taa_in_trace.hip.h: bit-exact, slower)
     int post_mode = 0;               // YCGE_POST_MODE: in-place A-trous: 0 = one persistent launch, level-granular hand-over (k_atrous_stream), 2 = a launch per level group, 3 = as 0 with bands in block order, 4 = persistent with group hand-over (k_atrous_persist)
     bool post_no_split = false;      // YCGE_POST_NO_SPLIT: whole bands in the persistent in-place A-trous (no row-parity half-bands)
     int post_probe_band = -1;        // YCGE_POST_PROBE_BAND: this band and the next record a per-pass timeline (profiles/post_bands.py)
@@ -187,6 +188,7 @@ struct Knobs {
         post_groups = geti("YCGE_POST_GROUPS", YCGE_POST_GROUPS_DEFAULT);
         if (post_groups != 8 && post_groups != 16 && post_groups != 32) post_groups = YCGE_POST_GROUPS_DEFAULT;
         fan_class = geti("YCGE_FAN", -1); fan_cap = geti("YCGE_FAN_CAP", -1);
+        taa_fuse = YCGE_EXPERIMENTS && geti("YCGE_TAA_FUSE", 0) != 0;
         post_mode = geti("YCGE_POST_MODE", 0);
         post_hash = geti("YCGE_POST_HASH_FORM", 0) != 0;
         post_no_split = getenv("YCGE_POST_NO_SPLIT") != nullptr;
@@ -246,6 +248,11 @@ struct ycge_ctx {
     std::vector<ycge_ctx *> peers;
     ycge_ctx *parent = nullptr;
     hipEvent_t pushed_ev = nullptr;            // a peer's tiles have arrived in the parent's frame buffers
+    // config.multi_device_exchange = YCGE_EXCHANGE_RCCL (root only): the in-process communicators (ncclCommInitAll over devices[]), rank r's
+    // on device r's stream; exchange_mode says what the frames really use (0 = peer push: not asked for, or librccl.so / its symbols absent)
+    int exchange_mode = 0;
+    std::vector<void *> nccl_comms;
+    DevBuf<float> all_slabs;                   // every context of an RCCL frame: the gathered slabs of all ranks (the root un-permutes its copy)
     // A peer's share of a frame is ISSUED by a thread of its own (trace launches, tile push, event): eight devices driven one after the
     // other from the caller's thread would put 7 x ~0.1 ms of launch calls in front of the last device's first kernel - as long as
     // the frame itself.  The worker sleeps between frames; the root posts a frame, issues its own share, then collects the peers'.
@@ -398,6 +405,11 @@ struct ycge_ctx {
     DevBuf<uint32_t> block_cost, block_order, order_ws;   // k_trace scheduling feedback (4 blocks of 8x8 px per tile)
     DevBuf<uint32_t> cost_snap;                    // a schedule built while traces are in flight reads a copy of the cost ring (ycge_launch_order_blocks)
     bool block_order_valid = false;
+    // TemporalBlendWithClamp inside the trace launch (ycge::TaaFuse): neighbourhood counters per 8 x 8 block (monotonic, zeroed when allocated) and
+    // what ycge_render_frame asks of / hears back from trace_frame for the frame at hand
+    DevBuf<uint32_t> taa_block_ctr, taa_part_ctr;
+    bool fuse_request = false, fuse_done = false;
+    ycge::TaaParams fuse_T;
     DevBuf<uint64_t> stack_spill;                 // [YCGE_TRAVERSAL_STACK - 12][persistent lanes]
     bool any_light_lit = false;                   // some light has a contribution (GLight::dark == 0): the timed light loop has shadow rays to trace
     DevBuf<uint64_t> stack_spill_side;            // ... of the stage kernel that runs on the side stream beside another (the light loop beside the next round's trace)

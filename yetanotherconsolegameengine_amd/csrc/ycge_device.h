@@ -266,6 +266,25 @@ struct FrameParams {
     const uint32_t *tile_order;
 };
 
+struct TaaParams {
+    int32_t w, h;
+    float alpha;
+    int32_t radius;
+    float pad_lum;
+    int32_t reset;
+};
+
+// TemporalBlendWithClamp INSIDE the trace launch (round 6, measured and rejected: csrc/experiments/ycge_taa_in_trace.hip.h; honoured only by
+// -DYCGE_EXPERIMENTS=1 builds): a block that finishes counts itself in at the blocks of its 3 x 3 neighbourhood, and whoever completes a
+// neighbourhood resolves its centre block.  block_ctr == null - always, in the product: TAA is a launch of its own behind the trace.
+struct TaaFuse {
+    uint32_t *block_ctr;                // [8x8 block of the frame] finished blocks of its neighbourhood, itself included; monotonic: a frame adds the neighbourhood's size
+    uint32_t *part_ctr;                 // [block] finished parts of a split block; the last part puts it back to 0
+    float *hist, *prev_normal, *prev_depth;
+    uint8_t *prev_sky;
+    TaaParams T;
+};
+
 struct TraceOut {
     // full-frame buffers (row-major x + y*hiW); with several GPUs only the owned tiles are written
     float *current_hdr;     // 3 f32 / px
@@ -300,6 +319,7 @@ struct TraceOut {
     const uint32_t *n_fan;              // the first *n_fan schedule entries are traced by k_trace_fan (null or 0: none)
     // traversal counters (may be null): rays, box, tri, prim, vox
     unsigned long long *counters;
+    TaaFuse taa;                        // the single-launch kernels only
 };
 
 // planes a peer device copies from its own frame buffers into rank 0's (one process, several GPUs): its tiles only
@@ -308,14 +328,6 @@ struct PushPlanes {
     uint8_t *dst[12];
     int32_t bytes_per_pixel[12];
     int32_t n;
-};
-
-struct TaaParams {
-    int32_t w, h;
-    float alpha;
-    int32_t radius;
-    float pad_lum;
-    int32_t reset;
 };
 
 } // namespace ycge

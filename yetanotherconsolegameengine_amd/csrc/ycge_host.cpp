@@ -1,6 +1,7 @@
 // ycge_host.cpp - host side of the C-ABI in include/ycge.h: context, scene flattening and upload, frame orchestration (TryFlipAndBlit
 // steps 1-9), frames in flight, the slab form of the tiled frame.  (The tile-resident multi-GPU form and the read-backs: ycge_resident.cpp.)
 #include "ycge_ctx.h"
+#include <dlfcn.h>
 
 #ifndef YCGE_FAULT_INJECTION
 #define YCGE_FAULT_INJECTION 0
@@ -166,7 +167,9 @@ int set_geometry(ycge_ctx *c, int fbw, int fbh, int ss)
     if (rc != YCGE_OK) return rc;
     rc = alloc_tile_buffers(c);
     if (rc != YCGE_OK) return rc;
-    if (world > 1) HIP_TRY(c, c->own_slab.alloc((size_t)c->tiles_per_rank_padded * 256 * slab_floats(c)));
+    const bool rccl_frame = c->cfg.multi_device_exchange == YCGE_EXCHANGE_RCCL;      // (ycge_create leaves the field set only on the contexts of a one-process multi-device frame)
+    if (world > 1 || rccl_frame) HIP_TRY(c, c->own_slab.alloc((size_t)c->tiles_per_rank_padded * 256 * slab_floats(c)));
+    if (rccl_frame) HIP_TRY(c, c->all_slabs.alloc((size_t)world * c->tiles_per_rank_padded * 256 * slab_floats(c))); else c->all_slabs.release();
     return YCGE_OK;
 }
 
@@ -283,6 +286,44 @@ int morton3(int x, int y, int z)
     return ((x & 1) << 0) | ((y & 1) << 1) | ((z & 1) << 2) | ((x & 2) << 2) | ((y & 2) << 3) | ((z & 2) << 4) | ((x & 4) << 4) | ((y & 4) << 5) | ((z & 4) << 6);
 }
 
+// librccl.so, dlopen'ed on first use (the library does not link it: a host without RCCL loses nothing but this option).  An instance the
+// process already holds - bench.py's torch.distributed brings its own - is preferred over loading a second one.
+struct RcclApi {
+    void *h = nullptr;
+    int (*CommInitAll)(void **comms, int ndev, const int *devlist) = nullptr;
+    int (*CommDestroy)(void *comm) = nullptr;
+    int (*AllGather)(const void *send, void *recv, size_t count, int dtype, void *comm, hipStream_t stream) = nullptr;
+    int (*GroupStart)() = nullptr;
+    int (*GroupEnd)() = nullptr;
+    const char *(*GetErrorString)(int) = nullptr;
+    bool ok = false, tried = false;
+};
+static RcclApi g_rccl;
+static const RcclApi &load_rccl()
+{
+    static std::mutex m;
+    std::lock_guard<std::mutex> g(m);
+    if (g_rccl.tried) return g_rccl;
+    g_rccl.tried = true;
+    const char *forced = getenv("YCGE_RCCL_LIB");             // (tests: a name that does not exist = "RCCL absent")
+    const char *names[] = {forced ? forced : "librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"};
+    for (int pass = 0; pass < 2 && !g_rccl.h; pass++)
+        for (const char *n : names) {
+            g_rccl.h = dlopen(n, RTLD_NOW | RTLD_LOCAL | (pass == 0 ? RTLD_NOLOAD : 0));
+            if (g_rccl.h || forced) break;
+        }
+    if (!g_rccl.h) return g_rccl;
+    auto sym = [&](const char *n) { return dlsym(g_rccl.h, n); };
+    g_rccl.CommInitAll = (int (*)(void **, int, const int *))sym("ncclCommInitAll");
+    g_rccl.CommDestroy = (int (*)(void *))sym("ncclCommDestroy");
+    g_rccl.AllGather = (int (*)(const void *, void *, size_t, int, void *, hipStream_t))sym("ncclAllGather");
+    g_rccl.GroupStart = (int (*)())sym("ncclGroupStart");
+    g_rccl.GroupEnd = (int (*)())sym("ncclGroupEnd");
+    g_rccl.GetErrorString = (const char *(*)(int))sym("ncclGetErrorString");
+    g_rccl.ok = g_rccl.CommInitAll && g_rccl.CommDestroy && g_rccl.AllGather && g_rccl.GroupStart && g_rccl.GroupEnd;
+    return g_rccl;
+}
+
 int abi_catch(const ycge_ctx *cc) noexcept
 {
     ycge_ctx *c = const_cast<ycge_ctx *>(cc);
@@ -310,6 +351,7 @@ try {
     cfg->slab_albedo = 1; cfg->n_devices = 0;
     cfg->atrous_inplace_exact = 1;
     cfg->tile_ring = 0;
+    cfg->multi_device_exchange = YCGE_EXCHANGE_PEER_PUSH;
     cfg->fb_width = 80; cfg->fb_height = 45; cfg->super_sample = 1;
     cfg->fov_deg = 45.0f;
     cfg->device = 0; cfg->rank = 0; cfg->world_size = 1;
@@ -407,10 +449,14 @@ try {
         return YCGE_ERR_UNSUPPORTED;
     }
     if (cfg->n_devices < 0 || cfg->n_devices > YCGE_MAX_DEVICES) { g_create_error = "n_devices out of range"; return YCGE_ERR_INVALID_ARG; }
-    if (cfg->n_devices <= 1) {
+    if (cfg->multi_device_exchange != YCGE_EXCHANGE_PEER_PUSH && cfg->multi_device_exchange != YCGE_EXCHANGE_RCCL) { g_create_error = "multi_device_exchange: unknown mode"; return YCGE_ERR_INVALID_ARG; }
+    // the collective behind the one call (ABI 9): asked for, with a device list, and librccl.so there - else the peers push their tiles as before
+    const bool want_rccl = cfg->multi_device_exchange == YCGE_EXCHANGE_RCCL && cfg->n_devices >= 1 && cfg->world_size == 1 && load_rccl().ok;
+    if (cfg->n_devices <= 1 && !want_rccl) {
         ycge_config one = *cfg;
         if (cfg->n_devices == 1) one.device = cfg->devices[0];
         one.n_devices = 0;
+        one.multi_device_exchange = YCGE_EXCHANGE_PEER_PUSH;
         return create_one(&one, nullptr, out);
     }
     // ---- one process, n_devices GPUs: this context is rank 0 on devices[0]; ranks 1.. live in peer contexts it owns
@@ -418,6 +464,11 @@ try {
     ycge_config base = *cfg;
     base.world_size = cfg->n_devices; base.n_devices = 0;
     base.rank = 0; base.device = cfg->devices[0];
+    base.multi_device_exchange = want_rccl ? YCGE_EXCHANGE_RCCL : YCGE_EXCHANGE_PEER_PUSH;
+    if (want_rccl)
+        for (int a = 0; a < cfg->n_devices; a++)
+            for (int b = a + 1; b < cfg->n_devices; b++)
+                if (cfg->devices[a] == cfg->devices[b]) { g_create_error = "multi_device_exchange = RCCL needs distinct devices (RCCL refuses two ranks on one GPU)"; return YCGE_ERR_INVALID_ARG; }
     ycge_ctx *root = nullptr;
     int rc = create_one(&base, nullptr, &root);
     if (rc != YCGE_OK) return rc;
@@ -446,6 +497,18 @@ try {
             (void)hipGetLastError();
         }
     }
+    if (want_rccl) {            // one communicator per device, all in this process (ncclCommInitAll); rank r = devices[r]
+        const RcclApi &R = load_rccl();
+        root->nccl_comms.assign((size_t)cfg->n_devices, nullptr);
+        const int nr = R.CommInitAll(root->nccl_comms.data(), cfg->n_devices, cfg->devices);
+        if (nr != 0) {
+            g_create_error = std::string("ncclCommInitAll failed: ") + (R.GetErrorString ? R.GetErrorString(nr) : "?");
+            root->nccl_comms.clear();
+            return YCGE_ERR_DEVICE;
+        }
+        root->exchange_mode = YCGE_EXCHANGE_RCCL;
+        (void)hipSetDevice(root->device);
+    }
     for (ycge_ctx *peer : root->peers) {        // each peer's share of a frame is issued by its own thread (trace_on_all_devices)
         peer->worker = new ycge_ctx::PeerWorker;
         peer->worker->th = std::thread(peer_worker_main, root, peer);
@@ -469,6 +532,12 @@ try {
     }
     for (ycge_ctx *p : c->peers) ycge_destroy(p);
     c->peers.clear();
+    if (!c->nccl_comms.empty()) {
+        const RcclApi &R = load_rccl();
+        for (void *cm : c->nccl_comms) if (cm && R.CommDestroy) (void)R.CommDestroy(cm);
+        c->nccl_comms.clear();
+    }
+    c->all_slabs.release();
     (void)hipSetDevice(c->device);
     // frames in flight may still be on ANY of the context's streams (TAA, post stage and read-back on taa_stream / stream2): everything
     // is drained before the first buffer goes (not left to hipFree's implicit synchronisation)
@@ -479,7 +548,7 @@ try {
     c->current_hdr.release(); c->g_albedo.release(); c->g_normal.release(); c->g_depth.release(); c->taa_hist.release();
     c->prev_normal.release(); c->prev_depth.release(); c->sky.release(); c->prev_sky.release();
     c->dbg_rays.release(); c->dbg_hit_t.release(); c->dbg_prim.release(); c->dbg_sub.release(); c->dbg_rng.release();
-    c->counters.release(); c->wave_prof.release(); c->own_slab.release(); c->dbg_counters.release();
+    c->counters.release(); c->wave_prof.release(); c->own_slab.release(); c->dbg_counters.release(); c->taa_block_ctr.release(); c->taa_part_ctr.release();
     c->t_hdr.release(); c->t_albedo.release(); c->t_normal.release(); c->t_depth.release(); c->t_sky.release();
     if (c->taa_stream) { (void)hipStreamSynchronize(c->taa_stream); (void)hipStreamDestroy(c->taa_stream); c->taa_stream = nullptr; }
     if (c->stream2) { (void)hipStreamSynchronize(c->stream2); (void)hipStreamDestroy(c->stream2); c->stream2 = nullptr; }
@@ -1734,8 +1803,20 @@ int trace_frame(ycge_ctx *c, float *d_slab, hipStream_t stream, FrameState &fs, 
             e = ycge_launch_trace(&c->sd, &P, &O, c->cfg.count_work, flat, 0, c->fan_stream);
             HIP_TRY(c, hipEventRecord(c->fan_ev[1], c->fan_stream));
             HIP_TRY(c, hipStreamWaitEvent(stream, c->fan_ev[1], 0));
-        } else
+        } else {
+            if (c->fuse_request && !slab && !rt && !c->in_flight_call && refill_steps == 0 && c->cfg.world_size == 1) {
+                const size_t nb = (size_t)c->n_tiles * 4;
+                if (c->taa_block_ctr.n != nb) {
+                    HIP_TRY(c, c->taa_block_ctr.alloc(nb)); HIP_TRY(c, c->taa_part_ctr.alloc(nb));
+                    HIP_TRY(c, hipMemsetAsync(c->taa_block_ctr.p, 0, nb * sizeof(uint32_t), stream)); HIP_TRY(c, hipMemsetAsync(c->taa_part_ctr.p, 0, nb * sizeof(uint32_t), stream));
+                }
+                O.taa.block_ctr = c->taa_block_ctr.p; O.taa.part_ctr = c->taa_part_ctr.p;
+                O.taa.hist = c->taa_hist.p; O.taa.prev_normal = c->prev_normal.p; O.taa.prev_depth = c->prev_depth.p; O.taa.prev_sky = c->prev_sky.p;
+                O.taa.T = c->fuse_T;
+                c->fuse_done = true;
+            }
             e = ycge_launch_trace(&c->sd, &P, &O, c->cfg.count_work, flat, refill_steps, stream);
+        }
         if (launch_end) HIP_TRY(c, hipEventRecord(launch_end, stream));
         if (e == 0 && flight) {
             // (frames in flight: the schedule of frame N + 2 follows this frame's TAA on the second stream, ycge_render_frame_async)
@@ -1808,20 +1889,27 @@ int trace_frame(ycge_ctx *c, float *d_slab, hipStream_t stream, FrameState &fs, 
     return YCGE_OK;
 }
 
-// steps 5 and 9: TemporalBlendWithClamp + CommitCamera
-int taa_and_commit(ycge_ctx *c, hipStream_t stream, FrameState &fs, bool &did_reset, bool timed)
+// step 5's parameters for the frame `fs` (RaytraceRenderer.cs:218, :285, :305) - what TemporalBlendWithClamp will be called with, known before the trace
+void taa_decide(ycge_ctx *c, FrameState &fs, TaaParams &T, bool &did_reset)
 {
     fs.reset = should_reset_history(c, fs.pos, fs.yaw, fs.pitch) || c->has_dynamic_textures;      // step 2 (:171): this frame's pose against the last committed one; a scene with live textures restarts every frame
-    TaaParams T;
     T.w = c->hiW; T.h = c->hiH;
     T.alpha = cs_max(0.0f, cs_min(1.0f, c->cfg.taa_alpha));      // :305
     T.radius = c->cfg.taa_clamp_radius > 0 ? c->cfg.taa_clamp_radius : 0;
     T.pad_lum = c->cfg.taa_luminance_pad;
     did_reset = !c->taa_valid || fs.reset;                        // :285
     T.reset = did_reset ? 1 : 0;
-    int e = ycge_launch_taa(&T, c->current_hdr.p, c->g_normal.p, c->g_depth.p, c->sky.p, c->taa_hist.p, c->prev_normal.p, c->prev_depth.p,
-                            c->prev_sky.p, stream, c->in_flight_taa ? 1 : 0);
-    if (e != 0) return c->fail(YCGE_ERR_DEVICE, "k_taa launch failed: %s", hipGetErrorString((hipError_t)e));
+}
+// steps 5 and 9: TemporalBlendWithClamp + CommitCamera.  (fused: the trace launch resolved TAA itself - ycge::TaaFuse - and only the commit is left)
+int taa_and_commit(ycge_ctx *c, hipStream_t stream, FrameState &fs, bool &did_reset, bool timed, bool fused)
+{
+    TaaParams T;
+    taa_decide(c, fs, T, did_reset);
+    if (!fused) {
+        int e = ycge_launch_taa(&T, c->current_hdr.p, c->g_normal.p, c->g_depth.p, c->sky.p, c->taa_hist.p, c->prev_normal.p, c->prev_depth.p,
+                                c->prev_sky.p, stream, c->in_flight_taa ? 1 : 0);
+        if (e != 0) return c->fail(YCGE_ERR_DEVICE, "k_taa launch failed: %s", hipGetErrorString((hipError_t)e));
+    }
     if (timed) HIP_TRY(c, hipEventRecord(c->ev[2], stream));
     c->taa_valid = true;
     c->last_cam[0] = fs.pos[0]; c->last_cam[1] = fs.pos[1]; c->last_cam[2] = fs.pos[2]; c->last_yaw = fs.yaw; c->last_pitch = fs.pitch;   // :266
@@ -2228,20 +2316,23 @@ static int peer_trace_and_push(ycge_ctx *c, ycge_ctx *p, FrameState &pfs)
 {
     if (hipSetDevice(p->device) != hipSuccess) return p->fail(YCGE_ERR_DEVICE, "hipSetDevice(%d) failed", p->device);
     p->frame_counter = pfs.frame;
-    int rc = trace_frame(p, nullptr, p->stream, pfs, false);
+    const bool rccl = c->exchange_mode == YCGE_EXCHANGE_RCCL;       // the tiles leave as a slab for the all-gather the root queues (trace_on_all_devices); only debug captures are still pushed
+    int rc = trace_frame(p, rccl ? p->own_slab.p : nullptr, p->stream, pfs, false);
     if (rc != YCGE_OK) return rc;
     PushPlanes L;
     std::memset(&L, 0, sizeof L);
     auto plane = [&](const void *src, void *dst, int bpp) { if (src && dst) { L.src[L.n] = (const uint8_t *)src; L.dst[L.n] = (uint8_t *)dst; L.bytes_per_pixel[L.n] = bpp; L.n++; } };
+    if (!rccl) {
     plane(p->current_hdr.p, c->current_hdr.p, 12); plane(p->g_albedo.p, c->g_albedo.p, 12); plane(p->g_normal.p, c->g_normal.p, 12);
     plane(p->g_depth.p, c->g_depth.p, 4); plane(p->sky.p, c->sky.p, 1);
+    }
     if (c->cfg.capture_debug) {
         plane(p->dbg_rays.p, c->dbg_rays.p, 24); plane(p->dbg_prim.p, c->dbg_prim.p, 4); plane(p->dbg_sub.p, c->dbg_sub.p, 4);
         plane(p->dbg_hit_t.p, c->dbg_hit_t.p, 4); plane(p->dbg_rng.p, c->dbg_rng.p, 8);
     }
     FrameParams P;
     fill_frame_params(p, P, pfs.frame, pfs.pos, pfs.yaw, pfs.pitch, pfs.fov);
-    const int e = ycge_launch_push_tiles(&P, &L, p->stream);
+    const int e = L.n > 0 ? ycge_launch_push_tiles(&P, &L, p->stream) : 0;
     if (e != 0) return p->fail(YCGE_ERR_DEVICE, "k_push_tiles launch failed: %s", hipGetErrorString((hipError_t)e));
     if (hipEventRecord(p->pushed_ev, p->stream) != hipSuccess) return p->fail(YCGE_ERR_DEVICE, "hipEventRecord failed on device %d", p->device);
     return YCGE_OK;
@@ -2275,7 +2366,8 @@ static int trace_on_all_devices(ycge_ctx *c, FrameState &fs)
         { std::lock_guard<std::mutex> g(w.m); w.fs = fs; w.job = 1; }
         w.cv.notify_all();
     }
-    int rc = trace_frame(c, nullptr, c->stream, fs, false);
+    const bool rccl = c->exchange_mode == YCGE_EXCHANGE_RCCL;
+    int rc = trace_frame(c, rccl ? c->own_slab.p : nullptr, c->stream, fs, false);
     for (ycge_ctx *p : c->peers) {          // (every posted frame is collected, whatever the root's own share returned)
         ycge_ctx::PeerWorker &w = *p->worker;
         std::unique_lock<std::mutex> lk(w.m);
@@ -2285,6 +2377,25 @@ static int trace_on_all_devices(ycge_ctx *c, FrameState &fs)
         fs.fan_blocks += w.fs.fan_blocks;
     }
     if (rc != YCGE_OK) return rc;
+    if (rccl) {
+        // ONE all-gather of the tile slabs over xGMI (north_star), rank r's call on device r's stream behind its trace and pack,
+        // all of them in one group from this thread; then the root's copy is un-permuted into the frame buffers TAA and the post stage read
+        const RcclApi &R = load_rccl();
+        const size_t per_rank = (size_t)c->tiles_per_rank_padded * 256 * slab_floats(c);
+        std::vector<ycge_ctx *> ranks{c};
+        ranks.insert(ranks.end(), c->peers.begin(), c->peers.end());
+        int nr = R.GroupStart();
+        for (size_t r = 0; r < ranks.size() && nr == 0; r++) {
+            (void)hipSetDevice(ranks[r]->device);
+            nr = R.AllGather(ranks[r]->own_slab.p, ranks[r]->all_slabs.p, per_rank, 7 /* ncclFloat32 */, c->nccl_comms[r], ranks[r]->stream);
+        }
+        const int ne = R.GroupEnd();
+        (void)hipSetDevice(c->device);
+        if (nr != 0 || ne != 0) return c->fail(YCGE_ERR_DEVICE, "ncclAllGather failed: %s", R.GetErrorString ? R.GetErrorString(nr != 0 ? nr : ne) : "?");
+        const int e = ycge_launch_unpermute(c->all_slabs.p, per_rank, c->hiW, c->hiH, c->tiles_x, c->n_tiles, c->cfg.world_size, (int)slab_floats(c),
+                                            c->current_hdr.p, c->g_albedo.p, c->g_normal.p, c->g_depth.p, c->sky.p, c->stream);
+        if (e != 0) return c->fail(YCGE_ERR_DEVICE, "k_unpermute launch failed: %s", hipGetErrorString((hipError_t)e));
+    }
     for (ycge_ctx *p : c->peers) HIP_TRY(c, hipStreamWaitEvent(c->stream, p->pushed_ev, 0));
     HIP_TRY(c, hipEventRecord(c->ev[1], c->stream));        // trace_ms of a multi-device frame: until the last tile has arrived
     return YCGE_OK;
@@ -2349,6 +2460,15 @@ try {
     out->frames_outstanding = c->async_outstanding ? 1 : 0;
     out->stage_pipeline = (c->have_scene && !frame_is_single_launch(c)) ? 1 : 0;
     out->placed_waits = c->placed_waits;
+    return YCGE_OK;
+}
+catch (...) { return ycge_host::abi_catch(c); }
+
+int ycge_exchange_query(ycge_ctx *c, int32_t *mode_out, int32_t *world_out)
+try {
+    if (!c || !mode_out) return YCGE_ERR_INVALID_ARG;
+    *mode_out = c->exchange_mode;
+    if (world_out) *world_out = 1 + (int32_t)c->peers.size();
     return YCGE_OK;
 }
 catch (...) { return ycge_host::abi_catch(c); }
@@ -2490,7 +2610,7 @@ static int render_frame_in_flight(ycge_ctx *c, float *out_sdr)
     if (c->post_hist_pending) { HIP_TRY(c, hipStreamWaitEvent(c->taa_stream, c->post_hist_ev, 0)); c->post_hist_pending = false; }      // the post stage of the frame before reads the history this TAA rewrites
     bool did_reset = false;
     c->in_flight_taa = small;
-    rc = taa_and_commit(c, c->taa_stream, fs, did_reset, false);
+    rc = taa_and_commit(c, c->taa_stream, fs, did_reset, false, false);
     c->in_flight_taa = false;
     if (rc != YCGE_OK) return rc;
     if (out_sdr) {
@@ -2527,7 +2647,7 @@ try {
     if (!c) return YCGE_ERR_INVALID_ARG;
     if (c->parent) return c->fail(YCGE_ERR_INVALID_ARG, "peer contexts are driven by their root");
     { const int jr = join_async(c); if (jr != YCGE_OK) return jr; }
-    const bool multi_dev = !c->peers.empty();
+    const bool multi_dev = !c->peers.empty() || c->exchange_mode == YCGE_EXCHANGE_RCCL;
     if (c->cfg.world_size != 1 && !multi_dev)
         return c->fail(YCGE_ERR_INVALID_ARG, "ycge_render_frame is the one-process entry: set config.n_devices / devices[] to drive several GPUs from it, "
                                              "or use ycge_trace_tiles + ycge_resolve_gathered with one process per GPU (rank / world_size)");
@@ -2535,10 +2655,15 @@ try {
     auto t0 = std::chrono::steady_clock::now();
     FrameState fs;
     snapshot_frame(c, fs);
-    int rc = multi_dev ? trace_on_all_devices(c, fs) : trace_frame(c, nullptr, c->stream, fs, true);
-    if (rc != YCGE_OK) return rc;
     bool did_reset = false;
-    rc = taa_and_commit(c, c->stream, fs, did_reset, true);
+    // (experiment builds, YCGE_TAA_FUSE=1: TemporalBlendWithClamp inside the trace launch where the frame is ONE launch on ONE device - ycge::TaaFuse; trace_frame decides and says so)
+    c->fuse_done = false;
+    c->fuse_request = c->knobs.taa_fuse && !multi_dev && c->cfg.taa_clamp_radius == 1;          // (the reference's call, RaytraceRenderer.cs:218: clampRadius 1 - the window the block resolve stages)
+    if (c->fuse_request) taa_decide(c, fs, c->fuse_T, did_reset);
+    int rc = multi_dev ? trace_on_all_devices(c, fs) : trace_frame(c, nullptr, c->stream, fs, true);
+    c->fuse_request = false;
+    if (rc != YCGE_OK) return rc;
+    rc = taa_and_commit(c, c->stream, fs, did_reset, true, c->fuse_done);
     if (rc != YCGE_OK) return rc;
     if (out_sdr) {      // steps 6-8; with NULL the frame stops after TAA (trace-only callers, benchmarks of the hot path)
         rc = run_post(c, c->stream, out_sdr, true);
@@ -2616,7 +2741,7 @@ try {
     FrameState fs = c->pending.front();
     c->pending.pop_front();
     bool did_reset = false;
-    int rc = taa_and_commit(c, stream, fs, did_reset, st != nullptr);
+    int rc = taa_and_commit(c, stream, fs, did_reset, st != nullptr, false);
     if (rc != YCGE_OK) return rc;
     if (out_sdr) {
         rc = run_post(c, stream, out_sdr, st != nullptr);

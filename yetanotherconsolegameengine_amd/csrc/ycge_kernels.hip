@@ -160,6 +160,8 @@ __device__ __forceinline__ uint32_t block_compact(bool want, uint32_t *s_cnt /* 
 #define YCGE_OUT_NT 1
 #endif
 template <class T> __device__ __forceinline__ void out_st(T *p, T v) { if (YCGE_OUT_NT) __builtin_nontemporal_store(v, p); else *p = v; }
+// ... or written THROUGH (device-coherent, sc1) where the launch itself reads them again on another XCD: the trace kernel's own TAA (TaaFuse)
+template <class T> __device__ __forceinline__ void out_st(T *p, T v, bool through) { if (through) __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); else out_st(p, v); }
 
 // ---------------------------------------------------------------------------------- k_wf_primary
 // one workgroup per owned 32x8 tile: the hardware dispatcher balances the (very uneven) tiles
@@ -677,6 +679,116 @@ struct PathStack {
     }
 };
 
+// ---------------------------------------------------------------------------------- TemporalBlendWithClamp, one pixel (k_taa, k_taa_tiles, trace_block)
+__device__ __forceinline__ float luma(float r, float g, float b) { return 0.2126f * r + 0.7152f * g + 0.0722f * b; }
+
+#ifndef YCGE_TAA_NT
+#define YCGE_TAA_NT 1
+#endif
+// What TAA touches once per frame - the history and the guide planes it reads and rewrites, this frame's normal and depth - goes past
+// the caches' keep lists (non-temporal): 230 MB a 1080p frame that would otherwise push the trace's tree out of the L2s just
+// before the next trace (or while it runs: frames in flight).  The 3 x 3 colour taps stay ordinary loads, they are shared.
+template <class T> __device__ __forceinline__ T taa_ld(const T *p) { return YCGE_TAA_NT ? __builtin_nontemporal_load(p) : *p; }
+template <class T> __device__ __forceinline__ void taa_st(T *p, T v) { if (YCGE_TAA_NT) __builtin_nontemporal_store(v, p); else *p = v; }
+// TemporalBlendWithClamp, RaytraceRenderer.cs:274-398.  One thread per pixel; the history and
+// guide updates touch only the thread's own pixel, so the serial loops of the C# fuse into one pass.
+// taa_blend: everything behind the pixel's own values of this frame and the luminance range of its window - the reset copy (:285-300), the
+// per-pixel alpha (:318-340), the clamp of the history's luminance (:362-378), the blend and the guide copies (:380-396).
+__device__ __forceinline__ void taa_blend(const TaaParams &T, const size_t i, const float cr, const float cg, const float cb, const float nx, const float ny, const float nz,
+                                          const float z_now, const uint8_t sky_now, const float min_l, const float max_l, float *__restrict__ hist,
+                                          float *__restrict__ prev_normal, float *__restrict__ prev_depth, uint8_t *__restrict__ prev_sky)
+{
+    float pr = taa_ld(hist + 3 * i), pg = taa_ld(hist + 3 * i + 1), pb = taa_ld(hist + 3 * i + 2);
+    float local_alpha = T.alpha;
+    if ((sky_now != 0) != (taa_ld(prev_sky + i) != 0)) {
+        local_alpha = 1.0f;
+    } else {
+        const float z_prev = taa_ld(prev_depth + i);
+        F3 n_now = normalized(f3(nx, ny, nz));
+        F3 n_prev = normalized(f3(taa_ld(prev_normal + 3 * i), taa_ld(prev_normal + 3 * i + 1), taa_ld(prev_normal + 3 * i + 2)));
+        if (!cs_isfinite(z_now) || !cs_isfinite(z_prev)) {
+            local_alpha = 1.0f;
+        } else {
+            float dz = cs_abs(z_now - z_prev);
+            float rel = dz / cs_max(1e-4f, cs_min(z_now, z_prev));
+            float ndot = dot(n_now, n_prev);
+            if (rel > 0.05f || ndot < 0.8f) local_alpha = 1.0f;
+        }
+    }
+    float range = max_l - min_l;
+    float l_min = min_l - range * T.pad_lum;
+    float l_max = max_l + range * T.pad_lum;
+    float prev_l = luma(pr, pg, pb);
+    if (prev_l > l_max) {
+        float s = l_max / cs_max(1e-6f, prev_l);
+        pr = pr * s; pg = pg * s; pb = pb * s;
+    } else if (prev_l < l_min) {
+        float s = l_min / cs_max(1e-6f, prev_l);
+        pr = pr * s; pg = pg * s; pb = pb * s;
+    }
+    taa_st(hist + 3 * i, pr * (1.0f - local_alpha) + cr * local_alpha);
+    taa_st(hist + 3 * i + 1, pg * (1.0f - local_alpha) + cg * local_alpha);
+    taa_st(hist + 3 * i + 2, pb * (1.0f - local_alpha) + cb * local_alpha);
+    taa_st(prev_normal + 3 * i, nx); taa_st(prev_normal + 3 * i + 1, ny); taa_st(prev_normal + 3 * i + 2, nz);
+    taa_st(prev_depth + i, z_now);
+    taa_st(prev_sky + i, sky_now);
+}
+__device__ __forceinline__ void taa_reset(const size_t i, const float cr, const float cg, const float cb, const float nx, const float ny, const float nz, const float z_now,
+                                          const uint8_t sky_now, float *__restrict__ hist, float *__restrict__ prev_normal, float *__restrict__ prev_depth, uint8_t *__restrict__ prev_sky)
+{
+    taa_st(hist + 3 * i, cr); taa_st(hist + 3 * i + 1, cg); taa_st(hist + 3 * i + 2, cb);
+    taa_st(prev_normal + 3 * i, nx); taa_st(prev_normal + 3 * i + 1, ny); taa_st(prev_normal + 3 * i + 2, nz);
+    taa_st(prev_depth + i, z_now);
+    taa_st(prev_sky + i, sky_now);
+}
+__device__ __forceinline__ void taa_pixel(const TaaParams &T, const int x, const int y, const float *__restrict__ current, const float *__restrict__ normal,
+                                             const float *__restrict__ depth, const uint8_t *__restrict__ sky, float *__restrict__ hist,
+                                             float *__restrict__ prev_normal, float *__restrict__ prev_depth, uint8_t *__restrict__ prev_sky)
+{
+    if (x >= T.w || y >= T.h) return;
+    const size_t i = (size_t)x + (size_t)y * T.w;
+    const float cr = current[3 * i], cg = current[3 * i + 1], cb = current[3 * i + 2];
+    const float nx = taa_ld(normal + 3 * i), ny = taa_ld(normal + 3 * i + 1), nz = taa_ld(normal + 3 * i + 2);
+    const float z_now = taa_ld(depth + i);
+    const uint8_t sky_now = sky[i];
+    if (T.reset) { taa_reset(i, cr, cg, cb, nx, ny, nz, z_now, sky_now, hist, prev_normal, prev_depth, prev_sky); return; }
+    float min_l = YCGE_INF, max_l = -YCGE_INF;
+    const int r = T.radius;
+    if (r == 1) {       // the default window: all nine taps fetched before any is looked at (the loop below waits for a tap's sky flag
+                        // before it asks for the colour, nine times in a row); same comparisons in the same order
+        size_t js[9];
+#pragma unroll
+        for (int k = 0; k < 9; k++) {
+            int sy = y + k / 3 - 1; if (sy < 0) sy = 0; else if (sy >= T.h) sy = T.h - 1;
+            int sx = x + k % 3 - 1; if (sx < 0) sx = 0; else if (sx >= T.w) sx = T.w - 1;
+            js[k] = (size_t)sx + (size_t)sy * T.w;
+        }
+        uint8_t sk[9];
+        float lr[9], lg[9], lb[9];
+#pragma unroll
+        for (int k = 0; k < 9; k++) { sk[k] = sky[js[k]]; lr[k] = current[3 * js[k]]; lg[k] = current[3 * js[k] + 1]; lb[k] = current[3 * js[k] + 2]; }
+#pragma unroll
+        for (int k = 0; k < 9; k++) {
+            const float l = luma(lr[k], lg[k], lb[k]);
+            const bool use = sk[k] == sky_now;
+            if (use && l < min_l) min_l = l;
+            if (use && l > max_l) max_l = l;
+        }
+    } else
+    for (int oy = -r; oy <= r; oy++) {
+        int sy = y + oy; if (sy < 0) sy = 0; else if (sy >= T.h) sy = T.h - 1;
+        for (int ox = -r; ox <= r; ox++) {
+            int sx = x + ox; if (sx < 0) sx = 0; else if (sx >= T.w) sx = T.w - 1;
+            const size_t j = (size_t)sx + (size_t)sy * T.w;
+            if (sky[j] != sky_now) continue;
+            float l = luma(current[3 * j], current[3 * j + 1], current[3 * j + 2]);
+            if (l < min_l) min_l = l;
+            if (l > max_l) max_l = l;
+        }
+    }
+    taa_blend(T, i, cr, cg, cb, nx, ny, nz, z_now, sky_now, min_l, max_l, hist, prev_normal, prev_depth, prev_sky);
+}
+
 // One 64-thread workgroup per schedule entry, listed longest first (k_cost_scatter).  An entry is an 8x8 pixel block
 // (4 per tile) or - experiment knob YCGE_SPLIT, off by default - one PART of a block: a wavefront with few live lanes
 // steps faster than a full one (one lane's path through the node / triangle / pop code instead of all of them,
@@ -752,6 +864,11 @@ __device__ __forceinline__ void shade_ctx_load(uint32_t addr, F3 &p, F3 &n, F3 &
     p = f3(v0.x, v0.y, v0.z); n = f3(v0.w, v1.x, v1.y); alb = f3(v1.z, v1.w, v2.x); wo = f3(v2.y, v2.z, v2.w);
 }
 
+#if YCGE_EXPERIMENTS
+} // namespace ycge
+#include "experiments/ycge_taa_in_trace.hip.h"
+namespace ycge {
+#endif
 #ifndef YCGE_PARTFAN
 // k_trace / k_trace_batch: 0 = round 5's loop (MODE 0), the product.  1 = MODE 3 for every entry, 2 = MODE 3 for the parts of split blocks and
 // MODE 0 for whole blocks (two copies of the loop in one kernel).  Round 6 built MODE 3 - the parts of split blocks fan their queries out over
@@ -825,13 +942,18 @@ __device__ __forceinline__ void trace_block(const SceneDev &S, const FrameParams
     // (the pixel index goes through an empty asm at every use: otherwise the compiler computes the six 64-bit store addresses of a
     // pixel once, in the prologue, keeps them live through the whole kernel - and spills them)
     auto pixel_index = [&]() { int x = px, y = py; asm volatile("" : "+v"(x), "+v"(y)); return (size_t)x + (size_t)y * P.hiW; };
+#if YCGE_EXPERIMENTS
+    const bool fuse = !FAN && O.taa.block_ctr != nullptr;          // (wave-uniform) experiments/ycge_taa_in_trace.hip.h: this launch resolves TAA itself, the planes TAA reads are written through
+#else
+    constexpr bool fuse = false;
+#endif
     auto write_gbuffer = [&](F3 g_albedo, F3 g_normal, float g_depth, int g_prim, int g_sub, bool is_sky) {
         const size_t i = pixel_index();
         // (written once, read by TAA / the post stage after the launch: past the caches' keep lists, the tree stays in the L2s)
         out_st(O.g_albedo + 3 * i + 0, g_albedo.x); out_st(O.g_albedo + 3 * i + 1, g_albedo.y); out_st(O.g_albedo + 3 * i + 2, g_albedo.z);
-        out_st(O.g_normal + 3 * i + 0, g_normal.x); out_st(O.g_normal + 3 * i + 1, g_normal.y); out_st(O.g_normal + 3 * i + 2, g_normal.z);
-        out_st(O.g_depth + i, g_depth);
-        out_st(O.sky + i, (uint8_t)(is_sky ? 1 : 0));
+        out_st(O.g_normal + 3 * i + 0, g_normal.x, fuse); out_st(O.g_normal + 3 * i + 1, g_normal.y, fuse); out_st(O.g_normal + 3 * i + 2, g_normal.z, fuse);
+        out_st(O.g_depth + i, g_depth, fuse);
+        out_st(O.sky + i, (uint8_t)(is_sky ? 1 : 0), fuse);
         if (DEBUG) {
             if (O.prim_id) O.prim_id[i] = g_prim;
             if (O.sub_id) O.sub_id[i] = g_sub;
@@ -870,9 +992,12 @@ __device__ __forceinline__ void trace_block(const SceneDev &S, const FrameParams
     auto finish_block = [&]() {
     if (in_image) {                                     // :210-215
         const size_t i = pixel_index();
-        out_st(O.current_hdr + 3 * i + 0, radiance.x); out_st(O.current_hdr + 3 * i + 1, radiance.y); out_st(O.current_hdr + 3 * i + 2, radiance.z);
+        out_st(O.current_hdr + 3 * i + 0, radiance.x, fuse); out_st(O.current_hdr + 3 * i + 1, radiance.y, fuse); out_st(O.current_hdr + 3 * i + 2, radiance.z, fuse);
         if (DEBUG && O.rng_state) O.rng_state[i] = rng;
     }
+#if YCGE_EXPERIMENTS
+    if (fuse) taa_in_trace(P, O, bid, lg, lane);
+#endif
     // a part of a split block sees fewer lanes, hence fewer iterations than the whole block would: scaled so that the block
     // stays in its schedule class from frame to frame (x 1.5 for 4 parts, x 2 for 16, x 2.5 for 64: measured ratios are 1.3-2)
     uint32_t part_iters = wave_iters;
@@ -1460,106 +1585,7 @@ __global__ __launch_bounds__(1024) void k_cost_scatter(const uint32_t *__restric
     }
 }
 
-// ---------------------------------------------------------------------------------- K_taa
-__device__ __forceinline__ float luma(float r, float g, float b) { return 0.2126f * r + 0.7152f * g + 0.0722f * b; }
-
-#ifndef YCGE_TAA_NT
-#define YCGE_TAA_NT 1
-#endif
-// What TAA touches once per frame - the history and the guide planes it reads and rewrites, this frame's normal and depth - goes past
-// the caches' keep lists (non-temporal): 230 MB a 1080p frame that would otherwise push the trace's tree out of the L2s just
-// before the next trace (or while it runs: frames in flight).  The 3 x 3 colour taps stay ordinary loads, they are shared.
-template <class T> __device__ __forceinline__ T taa_ld(const T *p) { return YCGE_TAA_NT ? __builtin_nontemporal_load(p) : *p; }
-template <class T> __device__ __forceinline__ void taa_st(T *p, T v) { if (YCGE_TAA_NT) __builtin_nontemporal_store(v, p); else *p = v; }
-// TemporalBlendWithClamp, RaytraceRenderer.cs:274-398.  One thread per pixel; the history and
-// guide updates touch only the thread's own pixel, so the serial loops of the C# fuse into one pass.
-__device__ __forceinline__ void taa_pixel(const TaaParams &T, const int x, const int y, const float *__restrict__ current, const float *__restrict__ normal,
-                                             const float *__restrict__ depth, const uint8_t *__restrict__ sky, float *__restrict__ hist,
-                                             float *__restrict__ prev_normal, float *__restrict__ prev_depth, uint8_t *__restrict__ prev_sky)
-{
-    if (x >= T.w || y >= T.h) return;
-    const size_t i = (size_t)x + (size_t)y * T.w;
-    const float cr = current[3 * i], cg = current[3 * i + 1], cb = current[3 * i + 2];
-    const float nx = taa_ld(normal + 3 * i), ny = taa_ld(normal + 3 * i + 1), nz = taa_ld(normal + 3 * i + 2);
-    const float z_now = taa_ld(depth + i);
-    const uint8_t sky_now = sky[i];
-    if (T.reset) {
-        taa_st(hist + 3 * i, cr); taa_st(hist + 3 * i + 1, cg); taa_st(hist + 3 * i + 2, cb);
-        taa_st(prev_normal + 3 * i, nx); taa_st(prev_normal + 3 * i + 1, ny); taa_st(prev_normal + 3 * i + 2, nz);
-        taa_st(prev_depth + i, z_now);
-        taa_st(prev_sky + i, sky_now);
-        return;
-    }
-    float pr = taa_ld(hist + 3 * i), pg = taa_ld(hist + 3 * i + 1), pb = taa_ld(hist + 3 * i + 2);
-    float local_alpha = T.alpha;
-    if ((sky_now != 0) != (taa_ld(prev_sky + i) != 0)) {
-        local_alpha = 1.0f;
-    } else {
-        const float z_prev = taa_ld(prev_depth + i);
-        F3 n_now = normalized(f3(nx, ny, nz));
-        F3 n_prev = normalized(f3(taa_ld(prev_normal + 3 * i), taa_ld(prev_normal + 3 * i + 1), taa_ld(prev_normal + 3 * i + 2)));
-        if (!cs_isfinite(z_now) || !cs_isfinite(z_prev)) {
-            local_alpha = 1.0f;
-        } else {
-            float dz = cs_abs(z_now - z_prev);
-            float rel = dz / cs_max(1e-4f, cs_min(z_now, z_prev));
-            float ndot = dot(n_now, n_prev);
-            if (rel > 0.05f || ndot < 0.8f) local_alpha = 1.0f;
-        }
-    }
-    float min_l = YCGE_INF, max_l = -YCGE_INF;
-    const int r = T.radius;
-    if (r == 1) {       // the default window: all nine taps fetched before any is looked at (the loop below waits for a tap's sky flag
-                        // before it asks for the colour, nine times in a row); same comparisons in the same order
-        size_t js[9];
-#pragma unroll
-        for (int k = 0; k < 9; k++) {
-            int sy = y + k / 3 - 1; if (sy < 0) sy = 0; else if (sy >= T.h) sy = T.h - 1;
-            int sx = x + k % 3 - 1; if (sx < 0) sx = 0; else if (sx >= T.w) sx = T.w - 1;
-            js[k] = (size_t)sx + (size_t)sy * T.w;
-        }
-        uint8_t sk[9];
-        float lr[9], lg[9], lb[9];
-#pragma unroll
-        for (int k = 0; k < 9; k++) { sk[k] = sky[js[k]]; lr[k] = current[3 * js[k]]; lg[k] = current[3 * js[k] + 1]; lb[k] = current[3 * js[k] + 2]; }
-#pragma unroll
-        for (int k = 0; k < 9; k++) {
-            const float l = luma(lr[k], lg[k], lb[k]);
-            const bool use = sk[k] == sky_now;
-            if (use && l < min_l) min_l = l;
-            if (use && l > max_l) max_l = l;
-        }
-    } else
-    for (int oy = -r; oy <= r; oy++) {
-        int sy = y + oy; if (sy < 0) sy = 0; else if (sy >= T.h) sy = T.h - 1;
-        for (int ox = -r; ox <= r; ox++) {
-            int sx = x + ox; if (sx < 0) sx = 0; else if (sx >= T.w) sx = T.w - 1;
-            const size_t j = (size_t)sx + (size_t)sy * T.w;
-            if (sky[j] != sky_now) continue;
-            float l = luma(current[3 * j], current[3 * j + 1], current[3 * j + 2]);
-            if (l < min_l) min_l = l;
-            if (l > max_l) max_l = l;
-        }
-    }
-    float range = max_l - min_l;
-    float l_min = min_l - range * T.pad_lum;
-    float l_max = max_l + range * T.pad_lum;
-    float prev_l = luma(pr, pg, pb);
-    if (prev_l > l_max) {
-        float s = l_max / cs_max(1e-6f, prev_l);
-        pr = pr * s; pg = pg * s; pb = pb * s;
-    } else if (prev_l < l_min) {
-        float s = l_min / cs_max(1e-6f, prev_l);
-        pr = pr * s; pg = pg * s; pb = pb * s;
-    }
-    taa_st(hist + 3 * i, pr * (1.0f - local_alpha) + cr * local_alpha);
-    taa_st(hist + 3 * i + 1, pg * (1.0f - local_alpha) + cg * local_alpha);
-    taa_st(hist + 3 * i + 2, pb * (1.0f - local_alpha) + cb * local_alpha);
-    taa_st(prev_normal + 3 * i, nx); taa_st(prev_normal + 3 * i + 1, ny); taa_st(prev_normal + 3 * i + 2, nz);
-    taa_st(prev_depth + i, z_now);
-    taa_st(prev_sky + i, sky_now);
-}
-
+// ---------------------------------------------------------------------------------- K_taa (taa_pixel: above, in front of trace_block)
 __global__ __launch_bounds__(256) void k_taa(const TaaParams T, const float *__restrict__ current, const float *__restrict__ normal,
                                              const float *__restrict__ depth, const uint8_t *__restrict__ sky, float *__restrict__ hist,
                                              float *__restrict__ prev_normal, float *__restrict__ prev_depth, uint8_t *__restrict__ prev_sky)
