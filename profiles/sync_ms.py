@@ -14,10 +14,13 @@ label = sys.argv[3] if len(sys.argv) > 3 else ""
 sc, w, h, ss, pose = scenes.config_scene(cfg)
 r = RaytraceRenderer(flatten(sc), w, h, pose["fov"], ss)
 r.SetCamera(pose["pos"], pose["yaw"], pose["pitch"])
+import os
+same = int(os.environ.get("SAME_FRAME", "0"))          # SAME_FRAME=k: every timed frame is frame number k again - the same rays, the same chains: what is left of the spread is the machine's
 for _ in range(12):
     r.TryFlipAndBlit()
 tr, fr = [], []
 for _ in range(N):
+    if same: r.set_frame_counter(same - 1)
     t0 = time.perf_counter(); r.TryFlipAndBlit(); fr.append((time.perf_counter() - t0) * 1e3); tr.append(r.stats.trace_ms)
 tr, fr = np.array(tr), np.array(fr)
 q = lambda a: "median %.4f min %.4f mean %.4f p95 %.4f p99 %.4f max %.4f" % (np.median(a), a.min(), a.mean(), np.percentile(a, 95), np.percentile(a, 99), a.max())

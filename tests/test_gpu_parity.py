@@ -350,7 +350,8 @@ def _exchange_halos(ranks, send_bufs, torch):
 
 @pytest.mark.parametrize("case,world,ring,depth,batch", [("cornell", 2, 0, 1, 0), ("bunny", 4, 4, 3, 0), ("voxel", 3, 3, 2, 0), ("bunny", 8, 6, 5, 0),
                                                          ("bunny", 8, 8, 7, 4), ("bunny", 4, 6, 5, 3), ("cornell", 2, 4, 3, 2), ("voxel", 3, 4, 3, 2)])
-def test_tile_resident_taa_with_halo_exchange_matches_single_gpu(product_lib, case, world, ring, depth, batch, monkeypatch):
+@pytest.mark.parametrize("resolve", ["one_launch", "two_launches"])
+def test_tile_resident_taa_with_halo_exchange_matches_single_gpu(product_lib, case, world, ring, depth, batch, resolve, monkeypatch):
     """The tile-RESIDENT form (include/ycge.h): every rank traces its tiles, the ranks exchange the one-pixel {hdr, sky} ring of their
     tiles, each runs TAA on its OWN tiles (history resident), the history slabs are gathered.  `world` ranks emulated on one GPU, the
     exchange by device copies with ycge_halo_counts' split sizes; `depth` + 1 traces are issued before the oldest frame is resolved
@@ -360,6 +361,13 @@ def test_tile_resident_taa_with_halo_exchange_matches_single_gpu(product_lib, ca
     single-launch scenes, frame by frame for the stage pipeline of the voxel world), two batches in flight where the ring has room."""
     import torch
     monkeypatch.delenv("YCGE_PATH", raising=False)
+    # the resolve: ONE launch that reads the halo taps from the records where the exchange left them (k_resolve_tiles, round 6, the default) or
+    # round 5's two (k_scatter_halo into the planes, then k_taa_tiles)
+    if resolve == "two_launches":
+        if (case, world, ring) not in (("cornell", 2, 0), ("bunny", 8, 6), ("voxel", 3, 3)): pytest.skip("the two-launch resolve is held on three of the cases")
+        monkeypatch.setenv("YCGE_RES_SPLIT_RESOLVE", "1")
+    else:
+        monkeypatch.delenv("YCGE_RES_SPLIT_RESOLVE", raising=False)
     if case == "cornell":
         sc, w, h, ss, pose = scenes.config_scene(1)
     elif case == "bunny":

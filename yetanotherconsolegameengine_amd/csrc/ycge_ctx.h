@@ -45,6 +45,8 @@ int ycge_launch_order_blocks(uint32_t *cost, uint32_t n, uint32_t policy, uint32
                              uint32_t *order, hipStream_t stream, int small_groups = 0, uint32_t n_frames = 0, uint32_t *snap = nullptr);
 int ycge_launch_taa_tiles(const ycge::TaaParams *T, const ycge::FrameParams *P, const float *current, const float *normal, const float *depth, const uint8_t *sky,
                           float *hist, float *prev_normal, float *prev_depth, uint8_t *prev_sky, float *slab, hipStream_t stream);
+int ycge_launch_resolve_tiles(const ycge::TaaParams *T, const ycge::FrameParams *P, const float *current, const float *normal, const float *depth, const uint8_t *sky,
+                              const void *records, const uint32_t *halo_index, float *hist, float *prev_normal, float *prev_depth, uint8_t *prev_sky, float *slab, hipStream_t stream);
 int ycge_launch_halo(int scatter, float *hdr, uint8_t *sky, const uint32_t *px, uint32_t n, void *records, hipStream_t stream);
 int ycge_launch_pack_history(const ycge::FrameParams *P, const float *hist, float *slab, hipStream_t stream);
 int ycge_launch_unpack_history(const float *all_slabs, size_t slab_floats_per_rank, int hiW, int hiH, int tiles_x, int n_tiles, int world_size, float *hist, hipStream_t stream);
@@ -133,10 +135,12 @@ struct Knobs {
     int refill_steps = YCGE_REFILL_STEPS_DEFAULT;
     bool split_set = false; uint32_t split_policy = 0;
     int split_top_lg = 2;                        // YCGE_SPLIT_TOP_LG: log2 of the parts such a block goes in (2 = 4 parts of 16 pixels)
+    bool split_top_set = false;                  // YCGE_SPLIT_TOP / YCGE_SPLIT_TOP_LG given: they decide; else schedule_policy picks by the frame's block count
     int split_top = YCGE_SPLIT_TOP_DEFAULT;     // YCGE_SPLIT_TOP: this many blocks at the head of the schedule go in 4 parts of 16 pixels (0 = none)
     int pw_per_cu = 32;
     int post_band_rows = YCGE_POST_BAND_ROWS_DEFAULT, post_k = YCGE_POST_K_DEFAULT, post_groups = YCGE_POST_GROUPS_DEFAULT;
     int fan_class = -1, fan_cap = -1;   // -1 = default by world size
+    bool split_resolve = false;      // YCGE_RES_SPLIT_RESOLVE=1: the tile-resident resolve as round 5's two launches (k_scatter_halo, k_taa_tiles) instead of k_resolve_tiles (A/B)
     bool taa_fuse = false;           // YCGE_TAA_FUSE=1: the synchronous single-launch frame resolves TAA inside the trace launch - experiment builds only (csrc/experiments/ycge_taa_in_trace.hip.h: bit-exact, slower)
     int post_mode = 0;               // YCGE_POST_MODE: in-place A-trous: 0 = one persistent launch, level-granular hand-over (k_atrous_stream), 2 = a launch per level group, 3 = as 0 with bands in block order, 4 = persistent with group hand-over (k_atrous_persist)
     bool post_no_split = false;      // YCGE_POST_NO_SPLIT: whole bands in the persistent in-place A-trous (no row-parity half-bands)
@@ -179,6 +183,7 @@ struct Knobs {
         if (const char *e = getenv("YCGE_WAVE_PROF")) wave_prof_stage = e[0] == 'e' ? 1 : e[0] == 'm' ? 2 : 0;
         refill_steps = geti("YCGE_REFILL", YCGE_REFILL_STEPS_DEFAULT);
         if (const char *e = getenv("YCGE_SPLIT")) { split_set = true; split_policy = (uint32_t)strtoul(e, nullptr, 8); }
+        split_top_set = getenv("YCGE_SPLIT_TOP") != nullptr || getenv("YCGE_SPLIT_TOP_LG") != nullptr;
         split_top = geti("YCGE_SPLIT_TOP", YCGE_SPLIT_TOP_DEFAULT);
         if (split_top < 0) split_top = 0;
         split_top_lg = geti("YCGE_SPLIT_TOP_LG", 2);
@@ -189,6 +194,7 @@ struct Knobs {
         if (post_groups != 8 && post_groups != 16 && post_groups != 32) post_groups = YCGE_POST_GROUPS_DEFAULT;
         fan_class = geti("YCGE_FAN", -1); fan_cap = geti("YCGE_FAN_CAP", -1);
         taa_fuse = YCGE_EXPERIMENTS && geti("YCGE_TAA_FUSE", 0) != 0;
+        split_resolve = geti("YCGE_RES_SPLIT_RESOLVE", 0) != 0;
         post_mode = geti("YCGE_POST_MODE", 0);
         post_hash = geti("YCGE_POST_HASH_FORM", 0) != 0;
         post_no_split = getenv("YCGE_POST_NO_SPLIT") != nullptr;
@@ -365,6 +371,7 @@ struct ycge_ctx {
     bool res_last_traced_used = false;
     std::vector<int64_t> halo_send_counts, halo_recv_counts;          // records (4 floats) per peer rank
     DevBuf<uint32_t> d_halo_send_px, d_halo_recv_px;
+    DevBuf<uint32_t> d_halo_index;             // [pixel of the frame] place of its halo record in the receive buffer (pixels other ranks own that border this rank's tiles; others: unused) - k_resolve_tiles
     bool halo_ready = false;
     DevBuf<float> dbg_rays, dbg_hit_t;
     DevBuf<int32_t> dbg_prim, dbg_sub;

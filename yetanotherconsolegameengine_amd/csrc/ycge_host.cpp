@@ -130,7 +130,7 @@ void release_resident(ycge_ctx *c)
     c->res_order_ev.clear(); c->res_order_read_ev.clear(); c->res_order_frame.clear();
     if (c->res_last_traced) { (void)hipEventDestroy(c->res_last_traced); c->res_last_traced = nullptr; }
     c->res_last_traced_used = false;
-    c->res_cost.release(); c->d_halo_send_px.release(); c->d_halo_recv_px.release();
+    c->res_cost.release(); c->d_halo_send_px.release(); c->d_halo_recv_px.release(); c->d_halo_index.release();
     c->halo_send_counts.clear(); c->halo_recv_counts.clear(); c->halo_ready = false;
 }
 
@@ -1646,6 +1646,15 @@ void schedule_policy(const ycge_ctx *c, uint32_t &policy, uint32_t &split_top, i
     policy = c->knobs.split_set ? c->knobs.split_policy : world_policy;
     // ... or, on a whole frame, the split_top blocks at the head of the schedule whatever their class (k_cost_scatter)
     split_top = (c->knobs.split_set || policy || batched || c->knobs.split_top <= 0) ? 0u : ((uint32_t)c->knobs.split_top & 0xffffu) | ((uint32_t)c->knobs.split_top_lg << 16);
+    // Round 6: in TWO parts of 32 pixels, more blocks of them where the frame leaves the machine room.  A part is a wavefront slot for the
+    // length of its chain (~0.7 of the block's in two parts, ~0.6 in four) and the bulk of a 1080p frame fills the slots to within 15 %
+    // (slot time 0.39 of 0.48 ms): config 4 (32 400 blocks) 32 x 4 parts 0.4765 ms, 64 x 2 0.4716, 128 x 2 0.4757, 256 x 2 0.4848, 512 x 2 0.4969;
+    // config 3 (14 400 blocks) 32 x 4 0.2781, 64 x 2 0.2769, 128 x 2 0.2716, 256 x 2 0.2671, 512 x 2 0.2693 (same call, profiles/r06/c_split_in_two.txt).
+    // YCGE_SPLIT_TOP / YCGE_SPLIT_TOP_LG override.
+    if (split_top && !c->knobs.split_top_set) {
+        const uint32_t n_blocks = (uint32_t)c->n_owned * 4u;
+        split_top = (n_blocks > 24000u ? 64u : 256u) | (1u << 16);
+    }
 }
 
 // (a scene with a textured material takes the generic kernels: the flat ones - configs 3 and 4 - are compiled without the texture

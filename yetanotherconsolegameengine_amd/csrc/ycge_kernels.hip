@@ -741,32 +741,41 @@ __device__ __forceinline__ void taa_reset(const size_t i, const float cr, const 
     taa_st(prev_depth + i, z_now);
     taa_st(prev_sky + i, sky_now);
 }
-__device__ __forceinline__ void taa_pixel(const TaaParams &T, const int x, const int y, const float *__restrict__ current, const float *__restrict__ normal,
-                                             const float *__restrict__ depth, const uint8_t *__restrict__ sky, float *__restrict__ hist,
-                                             float *__restrict__ prev_normal, float *__restrict__ prev_depth, uint8_t *__restrict__ prev_sky)
+// (TAP: where this frame's colour and sky flag of a window pixel come from - the frame's planes (PlaneTap: k_taa, k_taa_tiles) or, for the
+// pixels other ranks own, the halo records as they arrived (HaloTap: k_resolve_tiles))
+struct PlaneTap {
+    const float *__restrict__ current; const uint8_t *__restrict__ sky; int w;
+    __device__ __forceinline__ void operator()(int sx, int sy, float &r, float &g, float &b, uint8_t &s) const
+    {
+        const size_t j = (size_t)sx + (size_t)sy * w;
+        s = sky[j]; r = current[3 * j]; g = current[3 * j + 1]; b = current[3 * j + 2];
+    }
+};
+template <class TAP>
+__device__ __forceinline__ void taa_pixel_t(const TaaParams &T, const int x, const int y, const TAP &tap, const float *__restrict__ normal,
+                                            const float *__restrict__ depth, float *__restrict__ hist,
+                                            float *__restrict__ prev_normal, float *__restrict__ prev_depth, uint8_t *__restrict__ prev_sky)
 {
     if (x >= T.w || y >= T.h) return;
     const size_t i = (size_t)x + (size_t)y * T.w;
-    const float cr = current[3 * i], cg = current[3 * i + 1], cb = current[3 * i + 2];
+    float cr, cg, cb;
+    uint8_t sky_now;
+    tap(x, y, cr, cg, cb, sky_now);
     const float nx = taa_ld(normal + 3 * i), ny = taa_ld(normal + 3 * i + 1), nz = taa_ld(normal + 3 * i + 2);
     const float z_now = taa_ld(depth + i);
-    const uint8_t sky_now = sky[i];
     if (T.reset) { taa_reset(i, cr, cg, cb, nx, ny, nz, z_now, sky_now, hist, prev_normal, prev_depth, prev_sky); return; }
     float min_l = YCGE_INF, max_l = -YCGE_INF;
     const int r = T.radius;
     if (r == 1) {       // the default window: all nine taps fetched before any is looked at (the loop below waits for a tap's sky flag
                         // before it asks for the colour, nine times in a row); same comparisons in the same order
-        size_t js[9];
+        uint8_t sk[9];
+        float lr[9], lg[9], lb[9];
 #pragma unroll
         for (int k = 0; k < 9; k++) {
             int sy = y + k / 3 - 1; if (sy < 0) sy = 0; else if (sy >= T.h) sy = T.h - 1;
             int sx = x + k % 3 - 1; if (sx < 0) sx = 0; else if (sx >= T.w) sx = T.w - 1;
-            js[k] = (size_t)sx + (size_t)sy * T.w;
+            tap(sx, sy, lr[k], lg[k], lb[k], sk[k]);
         }
-        uint8_t sk[9];
-        float lr[9], lg[9], lb[9];
-#pragma unroll
-        for (int k = 0; k < 9; k++) { sk[k] = sky[js[k]]; lr[k] = current[3 * js[k]]; lg[k] = current[3 * js[k] + 1]; lb[k] = current[3 * js[k] + 2]; }
 #pragma unroll
         for (int k = 0; k < 9; k++) {
             const float l = luma(lr[k], lg[k], lb[k]);
@@ -779,14 +788,22 @@ __device__ __forceinline__ void taa_pixel(const TaaParams &T, const int x, const
         int sy = y + oy; if (sy < 0) sy = 0; else if (sy >= T.h) sy = T.h - 1;
         for (int ox = -r; ox <= r; ox++) {
             int sx = x + ox; if (sx < 0) sx = 0; else if (sx >= T.w) sx = T.w - 1;
-            const size_t j = (size_t)sx + (size_t)sy * T.w;
-            if (sky[j] != sky_now) continue;
-            float l = luma(current[3 * j], current[3 * j + 1], current[3 * j + 2]);
+            float tr, tg, tb; uint8_t ts;
+            tap(sx, sy, tr, tg, tb, ts);
+            if (ts != sky_now) continue;
+            float l = luma(tr, tg, tb);
             if (l < min_l) min_l = l;
             if (l > max_l) max_l = l;
         }
     }
     taa_blend(T, i, cr, cg, cb, nx, ny, nz, z_now, sky_now, min_l, max_l, hist, prev_normal, prev_depth, prev_sky);
+}
+__device__ __forceinline__ void taa_pixel(const TaaParams &T, const int x, const int y, const float *__restrict__ current, const float *__restrict__ normal,
+                                             const float *__restrict__ depth, const uint8_t *__restrict__ sky, float *__restrict__ hist,
+                                             float *__restrict__ prev_normal, float *__restrict__ prev_depth, uint8_t *__restrict__ prev_sky)
+{
+    const PlaneTap tap = {current, sky, T.w};
+    taa_pixel_t(T, x, y, tap, normal, depth, hist, prev_normal, prev_depth, prev_sky);
 }
 
 // One 64-thread workgroup per schedule entry, listed longest first (k_cost_scatter).  An entry is an 8x8 pixel block
@@ -1617,6 +1634,37 @@ __global__ __launch_bounds__(64) void k_taa_tiles(const TaaParams T, const Frame
         s[0] = hist[3 * i]; s[1] = hist[3 * i + 1]; s[2] = hist[3 * i + 2];
     }
 }
+// The resolve of a tile-resident frame as ONE launch (round 6): k_scatter_halo + k_taa_tiles + k_pack_history.  The halo
+// records are not scattered into the frame's planes first - a tap that falls on a pixel another rank owns reads its record where the exchange
+// left it (halo_index[pixel] = the record's place in the receive buffer; host: ensure_resident, from the same halo_layout the exchange follows).
+// A record holds the four floats k_gather_halo made of the owner's pixel, sky as 1.0 / 0.0: the values k_scatter_halo would have stored.
+struct HaloTap {
+    const float *__restrict__ current; const uint8_t *__restrict__ sky; const float4 *__restrict__ records; const uint32_t *__restrict__ halo_index;
+    int w, tiles_x, rank, world;
+    __device__ __forceinline__ void operator()(int sx, int sy, float &r, float &g, float &b, uint8_t &s) const
+    {
+        const size_t j = (size_t)sx + (size_t)sy * w;
+        const int owner = ((sy / YCGE_TILE_H) * tiles_x + sx / YCGE_TILE_W) % world;
+        if (owner == rank) { s = sky[j]; r = current[3 * j]; g = current[3 * j + 1]; b = current[3 * j + 2]; }
+        else { const float4 v = records[halo_index[j]]; r = v.x; g = v.y; b = v.z; s = v.w != 0.0f ? (uint8_t)1 : (uint8_t)0; }
+    }
+};
+__global__ __launch_bounds__(64) void k_resolve_tiles(const TaaParams T, const FrameParams P, const float *__restrict__ current, const float *__restrict__ normal,
+                                                      const float *__restrict__ depth, const uint8_t *__restrict__ sky, const float4 *__restrict__ records,
+                                                      const uint32_t *__restrict__ halo_index, float *__restrict__ hist, float *__restrict__ prev_normal,
+                                                      float *__restrict__ prev_depth, uint8_t *__restrict__ prev_sky, float *__restrict__ slab)
+{
+    int px, py, lx, ly;
+    const int k = (int)(blockIdx.x >> 2);
+    if (!tile_pixel_wl(P, k, (int)(blockIdx.x & 3u), (int)threadIdx.x, px, py, lx, ly)) return;
+    const HaloTap tap = {current, sky, records, halo_index, P.hiW, P.tiles_x, P.rank, P.world_size};
+    taa_pixel_t(T, px, py, tap, normal, depth, hist, prev_normal, prev_depth, prev_sky);
+    if (slab) {
+        const size_t i = (size_t)px + (size_t)py * P.hiW;
+        float *s = slab + ((size_t)k * 256 + (size_t)(ly * YCGE_TILE_W + lx)) * 3;
+        s[0] = hist[3 * i]; s[1] = hist[3 * i + 1]; s[2] = hist[3 * i + 2];
+    }
+}
 // halo records {hdr rgb, sky} of the listed pixels: out of this rank's frame buffers for the ranks that need them (gather), and the
 // records received from the owners into this rank's frame buffers (scatter).  The lists are layout arithmetic (host: halo_layout; the
 // same arithmetic in tiles.py): both sides enumerate the ring pixels of the receiver's tiles in one fixed order.
@@ -1896,6 +1944,14 @@ int ycge_launch_taa_tiles(const ycge::TaaParams *T, const ycge::FrameParams *P, 
 {
     if (P->n_owned_tiles <= 0) return 0;
     hipLaunchKernelGGL(ycge::k_taa_tiles, dim3((unsigned)P->n_owned_tiles * 4u), dim3(64), 0, stream, *T, *P, current, normal, depth, sky, hist, prev_normal, prev_depth, prev_sky, slab);
+    return (int)hipGetLastError();
+}
+int ycge_launch_resolve_tiles(const ycge::TaaParams *T, const ycge::FrameParams *P, const float *current, const float *normal, const float *depth, const uint8_t *sky,
+                              const void *records, const uint32_t *halo_index, float *hist, float *prev_normal, float *prev_depth, uint8_t *prev_sky, float *slab, hipStream_t stream)
+{
+    if (P->n_owned_tiles <= 0) return 0;
+    hipLaunchKernelGGL(ycge::k_resolve_tiles, dim3((unsigned)P->n_owned_tiles * 4u), dim3(64), 0, stream, *T, *P, current, normal, depth, sky, (const float4 *)records, halo_index,
+                       hist, prev_normal, prev_depth, prev_sky, slab);
     return (int)hipGetLastError();
 }
 int ycge_launch_halo(int scatter, float *hdr, uint8_t *sky, const uint32_t *px, uint32_t n, void *records, hipStream_t stream)

@@ -21,6 +21,13 @@ static int ensure_resident(ycge_ctx *c)
             if (spx.empty()) spx.push_back(0u);
             if (rpx.empty()) rpx.push_back(0u);
             HIP_TRY(c, c->d_halo_send_px.upload(spx)); HIP_TRY(c, c->d_halo_recv_px.upload(rpx));
+            {   // k_resolve_tiles: pixel -> its record (a pixel that borders two of this rank's tiles arrives twice, with the same four floats: either will do)
+                std::vector<uint32_t> index((size_t)c->hiW * c->hiH, 0u);
+                size_t n_recv = 0;
+                for (int64_t v : c->halo_recv_counts) n_recv += (size_t)v;
+                for (size_t r = 0; r < n_recv; r++) index[rpx[r]] = (uint32_t)r;
+                HIP_TRY(c, c->d_halo_index.upload(index));
+            }
             c->halo_ready = true;
         }
         const size_t n = (size_t)c->hiW * c->hiH;
@@ -298,8 +305,11 @@ try {
     ycge_ctx::ResidentSet *rs = c->rsets[(size_t)((uint64_t)fs.frame % (uint64_t)K)];
     HIP_TRY(c, hipStreamWaitEvent(stream, rs->traced, 0));         // (the caller's exchange already follows the trace; this holds whatever streams it uses)
     if (st) HIP_TRY(c, hipEventRecord(c->ev[1], stream));
-    int e = ycge_launch_halo(1, rs->hdr.p, rs->sky.p, c->d_halo_recv_px.p, (uint32_t)n_recv, const_cast<void *>(d_halo_recv), stream);
-    if (e != 0) return c->fail(YCGE_ERR_DEVICE, "k_scatter_halo launch failed: %s", hipGetErrorString((hipError_t)e));
+    int e = 0;
+    if (c->knobs.split_resolve) {
+        e = ycge_launch_halo(1, rs->hdr.p, rs->sky.p, c->d_halo_recv_px.p, (uint32_t)n_recv, const_cast<void *>(d_halo_recv), stream);
+        if (e != 0) return c->fail(YCGE_ERR_DEVICE, "k_scatter_halo launch failed: %s", hipGetErrorString((hipError_t)e));
+    }
     fs.reset = should_reset_history(c, fs.pos, fs.yaw, fs.pitch) || c->has_dynamic_textures;
     TaaParams T;
     T.w = c->hiW; T.h = c->hiH;
@@ -310,8 +320,12 @@ try {
     T.reset = did_reset ? 1 : 0;
     FrameParams P;
     fill_frame_params(c, P, fs.frame, fs.pos, fs.yaw, fs.pitch, fs.fov);
-    e = ycge_launch_taa_tiles(&T, &P, rs->hdr.p, rs->normal.p, rs->depth.p, rs->sky.p, c->taa_hist.p, c->prev_normal.p, c->prev_depth.p, c->prev_sky.p, (float *)d_history_slab /* packed by the same launch */, stream);
-    if (e != 0) return c->fail(YCGE_ERR_DEVICE, "k_taa_tiles launch failed: %s", hipGetErrorString((hipError_t)e));
+    // ONE launch: the halo taps read from the records where the exchange left them, TAA on this rank's tiles, the resolved history packed (k_resolve_tiles)
+    if (c->knobs.split_resolve)
+        e = ycge_launch_taa_tiles(&T, &P, rs->hdr.p, rs->normal.p, rs->depth.p, rs->sky.p, c->taa_hist.p, c->prev_normal.p, c->prev_depth.p, c->prev_sky.p, (float *)d_history_slab /* packed by the same launch */, stream);
+    else
+        e = ycge_launch_resolve_tiles(&T, &P, rs->hdr.p, rs->normal.p, rs->depth.p, rs->sky.p, d_halo_recv, c->d_halo_index.p, c->taa_hist.p, c->prev_normal.p, c->prev_depth.p, c->prev_sky.p, (float *)d_history_slab, stream);
+    if (e != 0) return c->fail(YCGE_ERR_DEVICE, "resolve launch failed: %s", hipGetErrorString((hipError_t)e));
     if (st) HIP_TRY(c, hipEventRecord(c->ev[2], stream));
     c->taa_valid = true;
     c->last_cam[0] = fs.pos[0]; c->last_cam[1] = fs.pos[1]; c->last_cam[2] = fs.pos[2]; c->last_yaw = fs.yaw; c->last_pitch = fs.pitch;
