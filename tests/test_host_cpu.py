@@ -798,12 +798,12 @@ def test_no_exception_crosses_the_c_abi(product_lib):
 
 
 def test_every_export_of_the_host_sources_is_guarded():
-    """The barrier is mechanical: in csrc/ycge_host.cpp and csrc/ycge_resident.cpp (the translation units with std containers, threads and
+    """The barrier is mechanical: in csrc/ycge_host.cpp, ycge_frame.cpp, ycge_post_host.cpp and ycge_resident.cpp (the translation units with std containers, threads and
     `new`) every function defined inside an extern "C" block is a function-try-block whose handler calls abi_catch - except the one that
     cannot throw (ycge_last_error returns a pointer)."""
     import re
     csrc = Path(abi.__file__).resolve().parent / "csrc"
-    for name in ("ycge_host.cpp", "ycge_resident.cpp"):
+    for name in ("ycge_host.cpp", "ycge_frame.cpp", "ycge_post_host.cpp", "ycge_resident.cpp"):
         lines = (csrc / name).read_text().split("\n")
         in_c, n = False, 0
         for i, line in enumerate(lines):
@@ -812,7 +812,7 @@ def test_every_export_of_the_host_sources_is_guarded():
             m = re.match(r"^(int|size_t|void|const char \*)\s*(ycge_\w+)\(", line) if in_c else None
             if not m or line.rstrip().endswith(";"):
                 continue
-            if m.group(2) in ("ycge_last_error", "ycge_debug_fail_allocation"):
+            if m.group(2) in ("ycge_last_error", "ycge_debug_fail_allocation", "ycge_peer_worker_main"):      # (the last: a thread's main, not an entry point - its body catches for itself)
                 continue
             j = i
             while lines[j] not in ("try {", "{") and j < i + 6: j += 1
@@ -821,7 +821,7 @@ def test_every_export_of_the_host_sources_is_guarded():
             while lines[k] != "}": k += 1
             assert lines[k + 1].startswith("catch (...) {") and "abi_catch(" in lines[k + 1], f"{name}:{k + 2} {m.group(2)}"
             n += 1
-        assert n >= 10, (name, n)
+        assert n >= (4 if name == "ycge_post_host.cpp" else 10), (name, n)
 
 
 def test_the_nth_allocation_fails_inside_host_side_exports():

@@ -18,7 +18,7 @@ PKG = Path(__file__).resolve().parent
 CSRC = PKG / "csrc"
 LIB_DIR = PKG / "lib"
 LIB = LIB_DIR / "libycge_hip.so"
-SOURCES = ["ycge_host.cpp", "ycge_resident.cpp", "ycge_accel.cpp", "ycge_kernels.hip", "ycge_post.hip", "ycge_bvh_build.hip"]
+SOURCES = ["ycge_host.cpp", "ycge_frame.cpp", "ycge_post_host.cpp", "ycge_resident.cpp", "ycge_accel.cpp", "ycge_kernels.hip", "ycge_post.hip", "ycge_bvh_build.hip"]
 HEADERS = ["ycge_ctx.h", "ycge_device.h", "ycge_accel.h", "ycge_math.h", "ycge_rt.hip.h", "ycge_coop.hip.h", "ycge_anyhit.hip.h", "ycge_keysort.h",
            "experiments/ycge_refill.hip.h", "experiments/ycge_atrous_persist_groups.hip.h", "experiments/ycge_taa_in_trace.hip.h"]
 ARCH = "gfx950"

@@ -485,6 +485,7 @@ struct ycge_ctx {
 
 #define YCGE_FLIGHT_RING 1024u       // frames in flight whose trace launches keep their timing events (ycge_async_trace_times)
 
+extern "C" void ycge_peer_worker_main(ycge_ctx *root, ycge_ctx *peer);      // ycge_frame.cpp: a peer device's thread (ycge_create starts it)
 // ---- what the other translation units of the library call in ycge_host.cpp (defined there, in this namespace)
 namespace ycge_host {
 // where a trace of the tile-resident form writes and which schedule it follows (trace_frame's last argument)
@@ -493,6 +494,26 @@ struct ResidentTarget {
     uint32_t *cost;                 // this frame's slot of the resident cost ring
     const uint32_t *order, *n_order;        // the schedule built for this frame (null: blocks in index order)
 };
+// librccl.so, dlopen'ed on first use (the library does not link it: a host without RCCL loses nothing but this option).  An instance the
+// process already holds - bench.py's torch.distributed brings its own - is preferred over loading a second one.
+struct RcclApi {
+    void *h = nullptr;
+    int (*CommInitAll)(void **comms, int ndev, const int *devlist) = nullptr;
+    int (*CommDestroy)(void *comm) = nullptr;
+    int (*AllGather)(const void *send, void *recv, size_t count, int dtype, void *comm, hipStream_t stream) = nullptr;
+    int (*GroupStart)() = nullptr;
+    int (*GroupEnd)() = nullptr;
+    const char *(*GetErrorString)(int) = nullptr;
+    bool ok = false, tried = false;
+};
+const RcclApi &load_rccl();
+size_t slab_floats(const ycge_ctx *c);
+bool host_memory_is_page_locked(const void *p, size_t bytes);
+int ensure_out_stage(ycge_ctx *c, size_t bytes);
+void finish_staged_sdr(ycge_ctx *c);
+int run_post(ycge_ctx *c, hipStream_t stream, float *out_sdr_host, bool timed, hipEvent_t history_read = nullptr /* recorded once the TAA history has been read for the last time */,
+             hipEvent_t before_copy = nullptr /* recorded in front of the read-back: the exposure state is this frame's */, bool second_sdr = false,
+             hipEvent_t tone_wait = nullptr /* the frame before has left its exposure state: waited for in front of this frame's exposure step */, bool second_set = false);
 int join_async(ycge_ctx *c);
 int copy_out(ycge_ctx *c, void *dst, const void *src, size_t bytes);
 int fill_stats(ycge_ctx *c, ycge_frame_stats *st, const FrameState &fs, bool did_reset, bool have_taa, double wall_ms);
