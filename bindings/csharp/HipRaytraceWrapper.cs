@@ -8,6 +8,15 @@
 //
 // One TryFlipAndBlit = one ycge_render_frame: ray generation, trace, TAA, denoise, exposure, tonemap and downsample on the GPU
 // (RaytraceRenderer.cs:157-267), then the SetChexel loop of :260-261 on the host, unchanged.
+//
+// Options (HipRaytraceOptions, all off by default = the reference's behaviour call for call):
+//   FrameLate  - TryFlipAndBlit queues frame N with ycge_render_frame_async_sdr and blits frame N - 1, which it waited for first: the GPU's
+//                3.6 ms (trace + TAA + the exact post stage at 1080p) run beside the host's Update / input / presenter instead of in front
+//                of them.  One frame of latency; the frames themselves are the same, in the same order (tests/test_gpu_timed_variants.py).
+//   Devices    - one process, several GPUs: the ONE call drives them all (config.n_devices / devices[]).
+//   Exchange   - how their tiles come together on Devices[0]: YExchange.PeerPush (xGMI peer writes) or YExchange.Rccl (ONE ncclAllGather of
+//                the tile slabs inside ycge_render_frame - SURVEY 8(e); the library dlopens librccl.so and falls back to PeerPush without it;
+//                ExchangeInUse says which).
 using System;
 using System.Runtime.CompilerServices;
 using ConsoleGame.RayTracing;
@@ -15,6 +24,13 @@ using ConsoleGame.RayTracing.Native;
 using ConsoleGame.RayTracing.Objects;
 using ConsoleGame.RayTracing.Scenes;
 using ConsoleGame.Renderer;
+
+public sealed class HipRaytraceOptions
+{
+    public bool FrameLate;
+    public int[] Devices;
+    public YExchange Exchange = YExchange.PeerPush;
+}
 
 public partial class RaytraceEntity
 {
@@ -26,28 +42,46 @@ public partial class RaytraceEntity
         private float fov;
         private Vec3 pos; private float yaw, pitch;
         private float* sdr;                         // fbW * fbH * {top rgb, bottom rgb}: page-locked memory of the library (ycge_alloc_host_buffer)
+        private float* sdrLate;                     // FrameLate: the second array - the frame in flight fills one while the host blits the other
+        private readonly bool frameLate;
+        private bool inFlight;                      // FrameLate: a frame queued by the last TryFlipAndBlit has not been waited for yet
         private FlatScene uploaded;                 // what the device holds (records only; its pins are released after the upload)
         private ulong objectsSignature;
         private bool forceUpload;
         private YLight[] lightsSent = Array.Empty<YLight>();
         private YVec3 ambientSent, topSent, bottomSent; private float ambientIntensitySent;
 
-        public HipRaytraceWrapper(Framebuffer fb, Scene scene, float fovDeg, int superSample)
+        public HipRaytraceWrapper(Framebuffer fb, Scene scene, float fovDeg, int superSample, HipRaytraceOptions options = null)
         {
             this.scene = scene ?? throw new ArgumentNullException(nameof(scene));
             var cfg = new YConfig();
             Ycge.Check(IntPtr.Zero, Ycge.ycge_config_default(ref cfg));
             cfg.FbWidth = fbW = fb.Width; cfg.FbHeight = fbH = fb.Height; cfg.SuperSample = ss = Math.Max(1, superSample); cfg.FovDeg = fov = fovDeg;
+            if (options?.Devices != null && options.Devices.Length > 0)
+            {
+                if (options.Devices.Length > 8) throw new ArgumentException("at most 8 devices (YCGE_MAX_DEVICES)");
+                cfg.NDevices = options.Devices.Length;
+                for (int i = 0; i < options.Devices.Length; i++) cfg.Devices[i] = options.Devices[i];
+                cfg.MultiDeviceExchange = (int)options.Exchange;
+            }
+            frameLate = options != null && options.FrameLate && cfg.NDevices <= 1;      // (frames in flight are the single-device form)
             Ycge.Check(IntPtr.Zero, Ycge.ycge_create(ref cfg, out ctx));
             AllocSdr();
             Upload();                               // the reference ctor ends with scene.RebuildBVH() (RaytraceRenderer.cs:107)
         }
 
+        /// <summary>What the devices' tiles really travel by (the library falls back to the peer push where librccl.so is missing).</summary>
+        public YExchange ExchangeInUse { get { Ycge.Check(ctx, Ycge.ycge_exchange_query(ctx, out int mode, out _)); return (YExchange)mode; } }
+
         private void AllocSdr()
         {
-            if (sdr != null) { Ycge.ycge_wait(ctx); Ycge.ycge_free_host_buffer((IntPtr)sdr); sdr = null; }
-            Ycge.Check(ctx, Ycge.ycge_alloc_host_buffer((UIntPtr)((ulong)fbW * (ulong)fbH * 6 * sizeof(float)), out IntPtr p));
+            if (sdr != null || sdrLate != null) { Ycge.ycge_wait(ctx); inFlight = false; }
+            if (sdr != null) { Ycge.ycge_free_host_buffer((IntPtr)sdr); sdr = null; }
+            if (sdrLate != null) { Ycge.ycge_free_host_buffer((IntPtr)sdrLate); sdrLate = null; }
+            UIntPtr bytes = (UIntPtr)((ulong)fbW * (ulong)fbH * 6 * sizeof(float));
+            Ycge.Check(ctx, Ycge.ycge_alloc_host_buffer(bytes, out IntPtr p));
             sdr = (float*)p;
+            if (frameLate) { Ycge.Check(ctx, Ycge.ycge_alloc_host_buffer(bytes, out IntPtr q)); sdrLate = (float*)q; }
         }
 
         // ---- scene: full upload, and what changes between frames (Scene.Update: entities move objects, DayNightCycle.cs:80-89 moves lights and sky)
@@ -142,8 +176,22 @@ public partial class RaytraceEntity
         public void TryFlipAndBlit(Framebuffer fb)
         {
             if (fb.Width != fbW || fb.Height != fbH) Resize(fb, ss);       // RaytraceRenderer.cs:119-120 does the same check
-            SyncScene();
-            Ycge.Check(ctx, Ycge.ycge_render_frame(ctx, sdr, null));
+            if (frameLate)
+            {
+                // the frame queued by the LAST call is finished first (it ran beside the host's Update in between), then this call's frame is queued
+                // into the other array and the finished one is blitted: one frame late, never torn (the device writes `sdrLate`, the host reads `sdr`)
+                bool have = inFlight;
+                if (inFlight) { Ycge.Check(ctx, Ycge.ycge_wait(ctx)); inFlight = false; float* t = sdr; sdr = sdrLate; sdrLate = t; }
+                SyncScene();
+                Ycge.Check(ctx, Ycge.ycge_render_frame_async_sdr(ctx, sdrLate));
+                inFlight = true;
+                if (!have) return;                                             // (the very first call has nothing to show yet: the framebuffer keeps what it had)
+            }
+            else
+            {
+                SyncScene();
+                Ycge.Check(ctx, Ycge.ycge_render_frame(ctx, sdr, null));
+            }
             for (int cy = 0; cy < fbH; cy++)
                 for (int cx = 0; cx < fbW; cx++)
                 {
@@ -156,6 +204,7 @@ public partial class RaytraceEntity
         {
             if (ctx != IntPtr.Zero) { Ycge.ycge_destroy(ctx); ctx = IntPtr.Zero; }      // (waits for everything in flight)
             if (sdr != null) { Ycge.ycge_free_host_buffer((IntPtr)sdr); sdr = null; }
+            if (sdrLate != null) { Ycge.ycge_free_host_buffer((IntPtr)sdrLate); sdrLate = null; }
             uploaded?.Dispose();
         }
     }

@@ -232,6 +232,7 @@ namespace ConsoleGame.RayTracing.Native
                 case YStatus.InvalidArg: throw new ArgumentException(msg);
                 case YStatus.Unsupported: throw new NotSupportedException(msg);
                 case YStatus.OutOfMemory: throw new OutOfMemoryException(msg);
+                case YStatus.Internal: throw new InvalidOperationException("ycge internal error (a C++ exception was stopped at the C-ABI): " + msg);
                 default: throw new Exception("ycge " + ((YStatus)rc) + ": " + msg);
             }
         }

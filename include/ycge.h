@@ -416,7 +416,8 @@ int ycge_resolve_gathered(ycge_ctx *ctx, const void *d_all_slabs, void *hip_stre
  *
  *   every frame, every rank:   ycge_trace_tiles_resident(ctx, d_send, stream)        trace + gather of the records other ranks need
  *                              all_to_all(d_recv <- d_send) with ycge_halo_counts' split sizes (records of 4 floats)
- *                              ycge_resolve_tiles_resident(ctx, d_recv, d_hist_slab, stream)   scatter, TAA on own tiles, history slab
+ *                              ycge_resolve_tiles_resident(ctx, d_recv, d_hist_slab, stream)   ONE launch: TAA on own tiles with the halo taps read from
+ *                                                                                 d_recv where the exchange left them, history slab
  *   the consumer:              all_gather / gather of the history slabs -> ycge_unpack_history(ctx, d_all_hist_slabs, stream) */
 int ycge_halo_counts(ycge_ctx *ctx, int64_t *send_counts /* [world_size] */, int64_t *recv_counts /* [world_size] */);
 int ycge_history_slab_bytes(const ycge_ctx *ctx, size_t *bytes);      /* padded per-rank size: equal on all ranks */
