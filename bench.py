@@ -92,7 +92,7 @@ def load_pmc(config, build_hash, tag=""):
     Returns (summary or None, stale): stale = a summary exists but was taken from another build of the kernels.
     Produced on the GPU box by profiles/run_profiles.sh -> summarize.py --json; bench.py itself never runs a profiler."""
     stale = False
-    for rnd in ("r05", "r04", "r03", "r02"):
+    for rnd in ("r06", "r05", "r04", "r03", "r02"):
         p = ROOT / "profiles" / rnd / f"pmc_config{config}{tag}.json"
         try:
             if p.exists():

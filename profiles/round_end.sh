@@ -4,7 +4,7 @@
 # (every profiler run under its own timeout), rank emulations (slab form, tile-resident ring), in-flight A/B, post stage exact / waived,
 # per-wavefront profile, cooperative-walk clocks.  Everything lands in gpurun_out/.
 REPO=${GRAFT_REPO_ROOT:-/root/repo}; cd $REPO; mkdir -p gpurun_out
-TAG=${1:-r05}; RND=${2:-r05}; PART=${3:-ab}          # part a: suite, profiles, benches; part b: emulations, A/Bs, forms (gpurun caps a call at one hour)
+TAG=${1:-r06}; RND=${2:-r06}; PART=${3:-ab}          # part a: suite, profiles, benches; part b: emulations, A/Bs, forms (gpurun caps a call at one hour)
 if [[ $PART == *a* ]]; then
 timeout 2400 python -m pytest tests -m gpu -q > gpurun_out/pytest_gpu_$TAG.log 2>&1; echo "pytest rc=$?"; tail -3 gpurun_out/pytest_gpu_$TAG.log
 # the profiles FIRST: bench.py prints the counter-derived roofline fields only from a summary of the running build (profiles/$RND/pmc_config*.json, source_hash)
@@ -41,12 +41,15 @@ echo "== post stage: exact and waived (config.atrous_inplace_exact)"; timeout 60
 echo "== post stage bands"; for a in "4 1 270" "5 2 540"; do set -- $a; CFG=$1 SS=$2 NB=$3 timeout 300 python profiles/post_bands.py 2>&1 | grep -E "^post|launch span|chain:"; done
 timeout 300 python profiles/mega_prof.py 4 2>&1 | grep -v amdgpu.ids > gpurun_out/mega_prof_$TAG.txt; grep -E "trace_ms|span|slot time|>= 256" gpurun_out/mega_prof_$TAG.txt
 echo "== voxel worlds: the walk tree against the scene tree, the light loop beside the trace, walk_phase (lit config 5, same call)"
-for v in "-" "YCGE_NO_WALK_TREE=1" "YCGE_NO_LIGHTS_BESIDE=1" "YCGE_LIB=$REPO/yetanotherconsolegameengine_amd/lib/var_nowalkphase.so" "YCGE_LIB=$REPO/yetanotherconsolegameengine_amd/lib/var_walk1.so" "-"; do
+for v in "-" "YCGE_NO_WALK_TREE=1" "YCGE_NO_LIGHTS_BESIDE=1" "-"; do
   ( if [ "$v" != "-" ]; then export "$v"; fi; echo -n "$v: "
     timeout 300 python bench.py --config 5 --t01 0.5 --steps 20 --warmup 3 --no-cpu-baseline --no-post 2>/dev/null | python -c "import sys,json; d=json.loads(sys.stdin.read()); print(d['ms_per_step'],'ms/frame trace', d['roofline']['mean_launch_ms'], 'moving', d['moving_camera']['trace_ms']['median'], 'in flight', d['frames_in_flight']['ms_per_step'])" )
 done
 if [ -f yetanotherconsolegameengine_amd/lib/var_voxstat.so ]; then YCGE_LIB=$REPO/yetanotherconsolegameengine_amd/lib/var_voxstat.so timeout 300 python profiles/vox_stats.py 0.5 2>&1 | grep -v amdgpu.ids; fi
 if [ -f yetanotherconsolegameengine_amd/lib/var_coopstat.so ]; then YCGE_LIB=$REPO/yetanotherconsolegameengine_amd/lib/var_coopstat.so timeout 200 python profiles/coop_stats.py 4 2>&1 | grep -v amdgpu.ids; fi
 if [ -f yetanotherconsolegameengine_amd/lib/var_batchstat.so ]; then YCGE_LIB=$REPO/yetanotherconsolegameengine_amd/lib/var_batchstat.so timeout 300 python profiles/batch_stats.py 4 2>&1 | grep -v amdgpu.ids; fi
+echo "== round 6: the synchronous frame, p95 / p99 / max (config 4, 3); the all-gather behind the one call as a world of one against the plain frame"
+for cfg in 4 3; do timeout 200 python profiles/sync_ms.py $cfg 300 "final build" 2>&1 | tail -1; done
+timeout 300 python profiles/exchange_ms.py 4 2>&1 | tail -3
 echo "== bench.py's one-process-per-GPU forms on one rank (torchrun + RCCL)"; bash profiles/forms.sh 2>&1 | grep -v "^\[" | cut -c1-330
 fi
