@@ -149,7 +149,22 @@ mode_costframes() {
   done
 }
 
+# round 6: the schedule's last class is cost ZERO alone (sky) - against round 5's classes (var_order5.so: -DYCGE_ORDER_ZERO_LAST=0); timing events only with statistics
+mode_zerolast() {
+  for cfg in 4 3; do
+    echo "== config $cfg"
+    for rep in 1 2; do
+      YCGE_LIB=$L/var_order5.so timeout 200 python profiles/sync_ms.py $cfg 300 "round 5's order classes" 2>&1 | tail -1
+      timeout 200 python profiles/sync_ms.py $cfg 300 "zero-cost blocks last" 2>&1 | tail -1
+    done
+    NO_STATS=1 timeout 200 python profiles/sync_ms.py $cfg 300 "zero-cost blocks last, no statistics asked for (no timing events)" 2>&1 | tail -1
+    timeout 200 python profiles/sync_ms.py $cfg 300 "zero-cost blocks last" 2>&1 | tail -1
+  done
+  timeout 300 python profiles/mega_prof.py 4 2>&1 | grep -v amdgpu.ids > gpurun_out/r6_mega_prof_zerolast.txt; grep -E "trace_ms|span|slot time|>= 256|blocks split" gpurun_out/r6_mega_prof_zerolast.txt; sed -n 7,16p gpurun_out/r6_mega_prof_zerolast.txt
+  timeout 600 python -m pytest tests/test_gpu_timed_variants.py -m gpu -x -q -k "steady or mesh or frames_in_flight" 2>&1 | tail -2
+}
+
 case "$1" in
-  partfan|partfan2|dbg|taafuse|taafuse2|taafuse3|suite|resolve|split2|costframes) mode_$1 ;;
+  partfan|partfan2|dbg|taafuse|taafuse2|taafuse3|suite|resolve|split2|costframes|zerolast) mode_$1 ;;
   *) echo "usage: bash profiles/experiments.sh <partfan|partfan2|dbg|taafuse|taafuse2|taafuse3|suite|resolve|split2|costframes>"; exit 2 ;;
 esac

@@ -35,7 +35,7 @@
 extern "C" {
 size_t ycge_wf_sizes(int which);
 int ycge_launch_trace(const ycge::SceneDev *S, const ycge::FrameParams *P, const ycge::TraceOut *O, int count, int flat, int refill_steps,
-                      hipStream_t stream);
+                      hipStream_t stream, hipEvent_t start = nullptr, hipEvent_t stop = nullptr);
 int ycge_launch_wavefront(const ycge::SceneDev *S, const ycge::FrameParams *P, const ycge::TraceOut *O, void *const bufs[7], int rounds,
                           int has_grid, int flat, int count, int persistent_waves, hipStream_t stream, hipStream_t side, hipEvent_t ev_fork, hipEvent_t ev_join,
                           const ycge::TraceOut *O_side);
@@ -53,7 +53,7 @@ int ycge_launch_unpack_history(const float *all_slabs, size_t slab_floats_per_ra
 int ycge_launch_trace_fan(const ycge::SceneDev *S, const ycge::FrameParams *P, const ycge::TraceOut *O, int count, int flat, uint32_t fan_cap,
                           hipStream_t stream);
 int ycge_launch_taa(const ycge::TaaParams *T, const float *current, const float *normal, const float *depth, const uint8_t *sky,
-                    float *hist, float *prev_normal, float *prev_depth, uint8_t *prev_sky, hipStream_t stream, int small_groups = 0);
+                    float *hist, float *prev_normal, float *prev_depth, uint8_t *prev_sky, hipStream_t stream, int small_groups = 0, hipEvent_t stop = nullptr);
 size_t ycge_post_state_bytes(void);
 int ycge_atrous_persist_resident(int groups_per_pass, int split, int level_handover, int profile);
 void ycge_atrous_duo_pad_lds(int bytes);

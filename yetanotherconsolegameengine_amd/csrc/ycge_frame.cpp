@@ -113,6 +113,11 @@ int trace_frame(ycge_ctx *c, float *d_slab, hipStream_t stream, FrameState &fs, 
     O.counters = c->counters.p;
     if (c->in_flight_call && c->placed_flag && c->placed_next) { O.placed_flag = c->placed_flag; O.placed_value = c->placed_next; }
     if (c->cfg.count_work) HIP_TRY(c, hipMemsetAsync(c->counters.p, 0, 6 * sizeof(unsigned long long), stream));
+    // A timed synchronous frame that is ONE plain launch: ev[1] rides on the launch itself (the kernel's own end time, ycge_launch_trace) -
+    // an event recorded on the stream is a packet of its own, and the one between the trace and TAA cost every such frame 8 us (round 6)
+    // (only ev[1]: with ev[0] as the launch's start event and ev[2] as k_taa's stop event the frames got SLOWER again - config 4 0.5217 -> 0.5289 ms,
+    // config 1 0.0845 -> 0.0885; recorded at the frame's two ends they wait behind nothing)
+    const bool kernel_stop = timed && !slab && !rt && !c->in_flight_call && frame_is_single_launch(c) && c->knobs.refill_steps == 0 && c->fan_cap == 0;
     if (timed) HIP_TRY(c, hipEventRecord(c->ev[0], stream));
     int e;
     O.stack_spill = rt ? rt->set->spill.p : c->spill_override ? c->spill_override : (slab && (fs.frame & 1)) ? c->stack_spill2.p : c->stack_spill.p;
@@ -218,7 +223,7 @@ int trace_frame(ycge_ctx *c, float *d_slab, hipStream_t stream, FrameState &fs, 
                 O.taa.T = c->fuse_T;
                 c->fuse_done = true;
             }
-            e = ycge_launch_trace(&c->sd, &P, &O, c->cfg.count_work, flat, refill_steps, stream);
+            e = ycge_launch_trace(&c->sd, &P, &O, c->cfg.count_work, flat, refill_steps, stream, nullptr, kernel_stop ? c->ev[1] : nullptr);
         }
         if (launch_end) HIP_TRY(c, hipEventRecord(launch_end, stream));
         if (e == 0 && flight) {
@@ -288,7 +293,7 @@ int trace_frame(ycge_ctx *c, float *d_slab, hipStream_t stream, FrameState &fs, 
         HIP_TRY(c, hipEventRecord(c->tile_trace_ev[fs.frame & 1], stream));
         c->tile_trace_used[fs.frame & 1] = true;
     }
-    if (timed) HIP_TRY(c, hipEventRecord(c->ev[1], stream));
+    if (timed && !kernel_stop) HIP_TRY(c, hipEventRecord(c->ev[1], stream));
     return YCGE_OK;
 }
 
@@ -712,13 +717,16 @@ try {
     c->fuse_done = false;
     c->fuse_request = c->knobs.taa_fuse && !multi_dev && c->cfg.taa_clamp_radius == 1;          // (the reference's call, RaytraceRenderer.cs:218: clampRadius 1 - the window the block resolve stages)
     if (c->fuse_request) taa_decide(c, fs, c->fuse_T, did_reset);
-    int rc = multi_dev ? trace_on_all_devices(c, fs) : trace_frame(c, nullptr, c->stream, fs, true);
+    // (timing events only where the caller asks for statistics: an event between two kernels is a packet of its own that the next launch waits behind -
+    // the C# wrapper passes no statistics and gets the frame without them; bench.py asks, its line is measured WITH them)
+    const bool timed = st != nullptr;
+    int rc = multi_dev ? trace_on_all_devices(c, fs) : trace_frame(c, nullptr, c->stream, fs, timed);
     c->fuse_request = false;
     if (rc != YCGE_OK) return rc;
-    rc = taa_and_commit(c, c->stream, fs, did_reset, true, c->fuse_done);
+    rc = taa_and_commit(c, c->stream, fs, did_reset, timed, c->fuse_done);
     if (rc != YCGE_OK) return rc;
     if (out_sdr) {      // steps 6-8; with NULL the frame stops after TAA (trace-only callers, benchmarks of the hot path)
-        rc = run_post(c, c->stream, out_sdr, true);
+        rc = run_post(c, c->stream, out_sdr, timed);
         if (rc != YCGE_OK) return rc;
     }
     HIP_TRY(c, hipStreamSynchronize(c->stream));

@@ -24,6 +24,7 @@
 // K_taa = TemporalBlendWithClamp (RaytraceRenderer.cs:274-398); K_unpermute / K_pack_slab move tile
 // slabs for the multi-GPU all-gather.  No MFMA anywhere: this is branchy pointer chasing.
 #include <hip/hip_runtime.h>
+#include <hip/hip_ext.h>
 
 #include "ycge_rt.hip.h"
 
@@ -1495,8 +1496,17 @@ __device__ __forceinline__ int cost_class(uint32_t c)
 }
 // 0..7: eight steps of 8 below 64; then four steps per octave-ish policy class pair: [64,128) by 16, [128,256) by 32, [256,512) by 64,
 // [512,1024) by 128, [1024, ...) by 256 up to class 31.  Every policy-class boundary (64, 128, 192, 256, 384, 512, 768) is a boundary here.
+// Round 6: class 0 is cost ZERO alone - blocks whose rays met nothing to walk (sky: a wavefront of 2-3 us, every frame) - and [1, 16) is class 1.
+// The schedule ends on its lowest class, and with [0, 8) as one class in index order the LAST entries of config 4 were floor blocks whose four-frame
+// maximum was a handful of iterations and whose bounce rays, this frame, found the mesh: 60-80 us wavefronts that started at 0.40 ms and ended the
+// launch at 0.483 ms, 17 us behind the longest chain (profiles/r06/z_mega_prof_config4.txt).  With the sky last they start while half the
+// frame's (trivial) entries are still to come.  -DYCGE_ORDER_ZERO_LAST=0: round 5's classes (A/B).
+#ifndef YCGE_ORDER_ZERO_LAST
+#define YCGE_ORDER_ZERO_LAST 1
+#endif
 __device__ __forceinline__ int order_class(uint32_t c)
 {
+    if (YCGE_ORDER_ZERO_LAST) { if (c == 0u) return 0; if (c < 16u) return 1; }
     if (c < 64u) return (int)(c >> 3);
     if (c < 128u) return 8 + (int)((c - 64u) >> 4);
     if (c < 256u) return 12 + (int)((c - 128u) >> 5);
@@ -1796,8 +1806,11 @@ size_t ycge_wf_sizes(int which)
 }
 
 // single-launch path
+// (start / stop: events that take the KERNEL's own begin and end times - hipExtLaunchKernelGGL hangs it on the dispatch's completion signal, so nothing stands
+// between this launch and the next one on the stream; an event recorded behind the launch is a packet of its own that the next launch waits
+// behind: 8 us of every synchronous frame, round 6)
 int ycge_launch_trace(const ycge::SceneDev *S, const ycge::FrameParams *P, const ycge::TraceOut *O, int count, int flat, int refill_steps,
-                      hipStream_t stream)
+                      hipStream_t stream, hipEvent_t start, hipEvent_t stop)
 {
     using namespace ycge;
     if (P->n_owned_tiles <= 0) return 0;
@@ -1811,11 +1824,13 @@ int ycge_launch_trace(const ycge::SceneDev *S, const ycge::FrameParams *P, const
 #endif
     static const unsigned lds_pad = getenv("YCGE_LDS_PAD") ? (unsigned)atoi(getenv("YCGE_LDS_PAD")) : 0u;   // experiment knob: fewer resident wavefronts
     if (!count && flat && S->tl_offset == 0u) {         // no mesh (or the cooperative walk switched off): the lean instance
-        hipLaunchKernelGGL(k_trace_nomesh, grid, block, lds_pad, stream, *S, *P, *O);
+        if (stop) hipExtLaunchKernelGGL(k_trace_nomesh, grid, block, lds_pad, stream, start, stop, 0, *S, *P, *O);
+        else hipLaunchKernelGGL(k_trace_nomesh, grid, block, lds_pad, stream, *S, *P, *O);
         return (int)hipGetLastError();
     }
     sel3(count != 0, flat != 0, false, [&](auto C, auto F, auto) {
-        hipLaunchKernelGGL((k_trace<decltype(C)::value, decltype(F)::value>), grid, block, lds_pad, stream, *S, *P, *O);
+        if (stop) hipExtLaunchKernelGGL((k_trace<decltype(C)::value, decltype(F)::value>), grid, block, lds_pad, stream, start, stop, 0, *S, *P, *O);
+        else hipLaunchKernelGGL((k_trace<decltype(C)::value, decltype(F)::value>), grid, block, lds_pad, stream, *S, *P, *O);
     });
     return (int)hipGetLastError();
 }
@@ -1930,12 +1945,13 @@ int ycge_launch_trace_fan(const ycge::SceneDev *S, const ycge::FrameParams *P, c
 }
 
 int ycge_launch_taa(const ycge::TaaParams *T, const float *current, const float *normal, const float *depth, const uint8_t *sky,
-                    float *hist, float *prev_normal, float *prev_depth, uint8_t *prev_sky, hipStream_t stream, int small_groups)
+                    float *hist, float *prev_normal, float *prev_depth, uint8_t *prev_sky, hipStream_t stream, int small_groups, hipEvent_t stop)
 {
     // small_groups (frames in flight): one-wavefront workgroups take the place of a single retiring wavefront of the trace running beside them
     const unsigned rows = small_groups ? 2u : 8u;
     dim3 grid((unsigned)((T->w + 31) / 32), (unsigned)((T->h + (int)rows - 1) / (int)rows)), block(32u * rows);
-    hipLaunchKernelGGL(ycge::k_taa, grid, block, 0, stream, *T, current, normal, depth, sky, hist, prev_normal, prev_depth, prev_sky);
+    if (stop) hipExtLaunchKernelGGL(ycge::k_taa, grid, block, 0, stream, nullptr, stop, 0, *T, current, normal, depth, sky, hist, prev_normal, prev_depth, prev_sky);
+    else hipLaunchKernelGGL(ycge::k_taa, grid, block, 0, stream, *T, current, normal, depth, sky, hist, prev_normal, prev_depth, prev_sky);
     return (int)hipGetLastError();
 }
 
