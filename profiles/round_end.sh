@@ -49,7 +49,7 @@ if [ -f yetanotherconsolegameengine_amd/lib/var_voxstat.so ]; then YCGE_LIB=$REP
 if [ -f yetanotherconsolegameengine_amd/lib/var_coopstat.so ]; then YCGE_LIB=$REPO/yetanotherconsolegameengine_amd/lib/var_coopstat.so timeout 200 python profiles/coop_stats.py 4 2>&1 | grep -v amdgpu.ids; fi
 if [ -f yetanotherconsolegameengine_amd/lib/var_batchstat.so ]; then YCGE_LIB=$REPO/yetanotherconsolegameengine_amd/lib/var_batchstat.so timeout 300 python profiles/batch_stats.py 4 2>&1 | grep -v amdgpu.ids; fi
 echo "== round 6: the synchronous frame, p95 / p99 / max (config 4, 3); the all-gather behind the one call as a world of one against the plain frame"
-for cfg in 4 3; do timeout 200 python profiles/sync_ms.py $cfg 300 "final build" 2>&1 | tail -1; done
-timeout 300 python profiles/exchange_ms.py 4 2>&1 | tail -3
+for cfg in 4 3 2 1; do timeout 200 python profiles/sync_ms.py $cfg 300 "final build" 2>&1 | tail -1; NO_STATS=1 timeout 200 python profiles/sync_ms.py $cfg 300 "final build, no statistics asked for" 2>&1 | tail -1; done
+timeout 300 python profiles/exchange_ms.py 4 2>&1 | grep "^config"
 echo "== bench.py's one-process-per-GPU forms on one rank (torchrun + RCCL)"; bash profiles/forms.sh 2>&1 | grep -v "^\[" | cut -c1-330
 fi
