@@ -8,7 +8,7 @@ REPO=${GRAFT_REPO_ROOT:-/root/repo}
 OUT=$REPO/gpurun_out/prof_$TAG
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
-BENCH="python3 $REPO/bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-post --no-flight --no-moving $*"
+BENCH="python3 $REPO/bench.py --steps 30 --warmup 6 --no-cpu-baseline --no-post --no-flight --no-moving $*"
 timeout 600 rocprofv3 --kernel-trace --stats -f csv -d $OUT/trace -o trace -- $BENCH > $OUT/trace.log 2>&1
 echo "trace rc=$?"
 i=0
@@ -31,5 +31,5 @@ fi
 CFG=4; T01=""; prev=""; for a in "$@"; do if [ "$prev" = "--config" ]; then CFG=$a; fi; if [ "$prev" = "--t01" ]; then T01=$a; fi; prev=$a; done
 # (a lit config-5 run - bench.py --t01 other than the survey's 0.25 - gets its own summary: pmc_config5_t050.json, what bench.py looks for)
 TAG01=""; if [ -n "$T01" ] && [ "$T01" != "0.25" ]; then TAG01=$(python3 -c "print('_t%03d' % round(float('$T01') * 100))"); fi
-python3 $REPO/profiles/summarize.py $OUT --json $OUT/pmc_config$CFG$TAG01.json --config $CFG --source "timeout 600 rocprofv3 --kernel-trace --stats + separate --pmc passes of: bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-post --no-flight --no-moving $* (tag $TAG)" > $OUT/summary.txt 2>&1
+python3 $REPO/profiles/summarize.py $OUT --json $OUT/pmc_config$CFG$TAG01.json --config $CFG --source "timeout 600 rocprofv3 --kernel-trace --stats + separate --pmc passes of: bench.py --steps 30 --warmup 6 --no-cpu-baseline --no-post --no-flight --no-moving $* (tag $TAG)" > $OUT/summary.txt 2>&1
 cat $OUT/summary.txt
