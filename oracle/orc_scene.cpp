@@ -829,6 +829,7 @@ bool SceneData::prim_hit(int32_t pi, const Ray &r, float t_min, float t_max, Hit
         float hit_t = kFloatMax;
         V3 hit_n = v3(0.0f, 0.0f, 0.0f);
         bool hit = false;
+        int part = 0;                          /* debug capture only (YCGE_BUF_SUB_ID): 0 side, 1 top cap, 2 bottom cap */
         if (a > 1e-12f) {
             float half_b = ox * dx + oz * dz;
             float c = ox * ox + oz * oz - P.radius2;
@@ -868,14 +869,14 @@ bool SceneData::prim_hit(int32_t pi, const Ray &r, float t_min, float t_max, Hit
             if (t_top > t_min && t_top < t_max) {
                 float rx = ox + t_top * dx, rz = oz + t_top * dz;
                 if (rx * rx + rz * rz <= P.radius2) {
-                    if (t_top < hit_t) { hit_t = t_top; hit_n = v3(0.0f, 1.0f, 0.0f); hit = true; }
+                    if (t_top < hit_t) { hit_t = t_top; hit_n = v3(0.0f, 1.0f, 0.0f); hit = true; part = 1; }
                 }
             }
             float t_bot = (P.y_min - oy) / dy;
             if (t_bot > t_min && t_bot < t_max) {
                 float rx = ox + t_bot * dx, rz = oz + t_bot * dz;
                 if (rx * rx + rz * rz <= P.radius2) {
-                    if (t_bot < hit_t) { hit_t = t_bot; hit_n = v3(0.0f, -1.0f, 0.0f); hit = true; }
+                    if (t_bot < hit_t) { hit_t = t_bot; hit_n = v3(0.0f, -1.0f, 0.0f); hit = true; part = 2; }
                 }
             }
         }
@@ -885,7 +886,7 @@ bool SceneData::prim_hit(int32_t pi, const Ray &r, float t_min, float t_max, Hit
         rec.n = dot(hit_n, r.d) < 0.0f ? hit_n : -hit_n;
         rec.m = eval_material(P.material, rec.p);
         rec.u = 0.0f; rec.v = 0.0f;
-        rec.prim = pi; rec.sub = 0;
+        rec.prim = pi; rec.sub = part;
         return true;
     }
     case YCGE_PRIM_TRIANGLE: { /* Triangle.cs:131-175 (scalar path; the SSE4.1 path 71-128 computes the same products) */

@@ -70,7 +70,7 @@ struct Hit {
     Mat m;
     float u, v;
     int32_t prim;           /* index in Scene.Objects */
-    int32_t sub;            /* triangle index / box face / voxel cell */
+    int32_t sub;            /* triangle index / box face / cylinder part (0 side, 1 top cap, 2 bottom cap) / voxel cell */
 };
 
 struct Counters {

@@ -1,0 +1,43 @@
+"""Soak of tests/test_gpu_random_scenes.py: seeds lo .. hi - 1 of its two scene generators (plain, and pushed one way: glass-heavy, many lights,
+thousands of objects, camera inside an object, degenerate objects, scaled by 1e-2 .. 1e3) on both device paths, two frames each, every buffer
+and counter against the oracle bit for bit.  Prints the frames that differ and a total; exit status 1 if there is one.
+
+    gpurun -- python profiles/fuzz_scenes.py 100 500        (round 6: 4 160 frames over seeds 0 .. 699, none differs - profiles/r06/g_fuzz_scenes.txt)
+"""
+import os
+import sys
+from pathlib import Path
+
+ROOT = Path(__file__).resolve().parents[1]
+sys.path.insert(0, str(ROOT / "tests")); sys.path.insert(0, str(ROOT))
+import oracle_binding as ob          # noqa: E402  (the checker; this script is a test driver, not a product path)
+import parity_util as pu             # noqa: E402
+import test_gpu_random_scenes as T   # noqa: E402
+
+lo, hi = int(sys.argv[1]), int(sys.argv[2])
+SIZES = [(160, 45, 1), (97, 31, 1), (64, 20, 2), (200, 60, 1)]
+n_frames = n_bad = 0
+for pushed in (False, True):
+    for path in ("wavefront", "megakernel"):
+        os.environ["YCGE_PATH"] = path
+        for seed in range(lo, hi):
+            s, pose = T.random_scene(seed)
+            tag = T.harden(s, pose, seed) if pushed else "plain"
+            try:
+                o, g = pu.run_pair(ob, s, *SIZES[seed % 4], pose, frames=1)
+            except Exception as e:      # a scene the library refuses the oracle must refuse too: print, go on
+                print("REFUSED", path, seed, tag, repr(e)[:200], flush=True)
+                continue
+            for f in range(2):
+                if f:
+                    o.render(stages=1, threads=8); g.TryFlipAndBlit()
+                st = pu.compare_frame(o, g)
+                bad = {k: v for k, v in st.items() if k.endswith("_mismatch") and v}
+                cnt = {k: st[k] for k in ("n_rays", "n_box", "n_tri", "n_prim", "n_vox") if st[k][0] != st[k][1]}
+                n_frames += 1
+                if bad or cnt:
+                    n_bad += 1
+                    print("MISMATCH", path, seed, tag, "frame", f, len(s.Objects), "objects", bad, cnt, flush=True)
+            o.close(); g.close()
+        print(f"{'pushed' if pushed else 'plain'} scenes, {path}: seeds {lo}..{hi - 1} done; {n_bad} of {n_frames} frames differ so far", flush=True)
+sys.exit(1 if n_bad else 0)
