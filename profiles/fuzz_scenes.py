@@ -1,8 +1,8 @@
 """Soak of tests/test_gpu_random_scenes.py: seeds lo .. hi - 1 of its two scene generators (plain, and pushed one way: glass-heavy, many lights,
 thousands of objects, camera inside an object, degenerate objects, scaled by 1e-2 .. 1e3) on both device paths, two frames each, every buffer
-and counter against the oracle bit for bit.  Prints the frames that differ and a total; exit status 1 if there is one.
+and counter against the oracle bit for bit; then its drawn CALL SEQUENCES (16 steps each).  Prints the frames that differ and a total; exit status 1 if there is one.
 
-    gpurun -- python profiles/fuzz_scenes.py 100 500        (round 6: 4 160 frames over seeds 0 .. 699, none differs - profiles/r06/g_fuzz_scenes.txt)
+    gpurun -- python profiles/fuzz_scenes.py 100 500        (round 6: 12 160 frames over seeds 0 .. 899, none differs - profiles/r06/g_fuzz_scenes.txt)
 """
 import os
 import sys
@@ -40,4 +40,13 @@ for pushed in (False, True):
                     print("MISMATCH", path, seed, tag, "frame", f, len(s.Objects), "objects", bad, cnt, flush=True)
             o.close(); g.close()
         print(f"{'pushed' if pushed else 'plain'} scenes, {path}: seeds {lo}..{hi - 1} done; {n_bad} of {n_frames} frames differ so far", flush=True)
+# call sequences (camera moves around the TAA thresholds, lights, moved objects, new scenes, resizes, frame-counter jumps, SDR frames in between)
+for path in ("wavefront", "megakernel"):
+    os.environ["YCGE_PATH"] = path
+    for seed in range(lo, hi):
+        found = T.run_sequence(ob, seed, steps=16, log=lambda *a: None)
+        n_frames += 16; n_bad += len(found)
+        for label, bad in found:
+            print("MISMATCH", path, label, bad, flush=True)
+    print(f"call sequences, {path}: seeds {lo}..{hi - 1} done; {n_bad} of {n_frames} frames differ so far", flush=True)
 sys.exit(1 if n_bad else 0)

@@ -126,6 +126,12 @@ class OracleRenderer:
         f = texture.frame
         _check(self.L, self.ctx, self.L.orc_scene_update_texture(self.ctx, idx, f.ctypes.data_as(C.c_void_p), f.nbytes))
 
+    def resize(self, fb_w: int, fb_h: int, ss: int):
+        """Resize(fb, ss) (RaytraceEntity.cs:289): new buffers, TAA history dropped (RaytraceRenderer.cs:137)"""
+        _check(self.L, self.ctx, self.L.orc_resize(self.ctx, fb_w, fb_h, ss))
+        self.fbW, self.fbH = fb_w, fb_h
+        self.hiW, self.hiH = fb_w * ss, fb_h * 2 * ss
+
     def set_frame_counter(self, n: int):
         _check(self.L, self.ctx, self.L.orc_set_frame_counter(self.ctx, n))
 

@@ -8,6 +8,7 @@ accidents a drawn scene has that a designed one avoids: objects inside one anoth
 boxes sharing a face), slivers, objects behind the camera and around it.  Bar: every buffer bit for bit, counters equal, on both device paths,
 over a reset frame and two blended ones.
 """
+import ctypes as C
 import dataclasses
 
 import numpy as np
@@ -216,3 +217,104 @@ def test_random_scene_with_supersampling_and_post_stage(product_lib, oracle, pat
         assert np.float32(o.stats.exposure).view(np.uint32) == np.float32(g.stats.exposure).view(np.uint32), f"frame {f}: exposure"
         assert pu.mismatch_count(so, sg) == 0, f"frame {f}: SDR"
     o.close(); g.close()
+
+
+# ---- call sequences ---------------------------------------------------------------------------------------------------------------------------
+# The frames above start from a fresh context.  A caller does not: RaytraceEntity moves the camera every frame (RaytraceEntity.cs:221-232), entities
+# move objects (Scene.cs:122-127) and lights (DayNightCycle.cs:80-89), the terminal is resized (RaytraceEntity.cs:289), scenes are switched.  A
+# drawn SEQUENCE of those calls goes to the oracle and to the library, with a frame - sometimes the delivered SDR frame - compared after each.
+SEQ_SIZES = [(160, 45, 1), (97, 31, 1), (64, 20, 2), (33, 9, 3), (120, 40, 1)]
+FRAME_COUNTERS = [0, 5, (1 << 31) - 3, (1 << 31) - 1, (1 << 32) - 2, 1 << 40, (1 << 62) + 12345]      # frameIdx = frame & 0x7fffffff (RaytraceRenderer.cs:175)
+
+
+def _moved(s, rng):
+    """a few objects of the scene somewhere else (geometry only: materials, meshes and grids stay what the upload made them)"""
+    d = lambda: _f(rng.uniform(-0.6, 0.6))
+    sh = lambda v: vec3(_f(v[0] + dx), _f(v[1] + dy), _f(v[2] + dz))
+    cand = [o for o in s.Objects if isinstance(o, (Sphere, Box, CylinderY, Triangle, Disk))]
+    for o in rng.choice(np.array(cand, dtype=object), size=min(len(cand), int(rng.integers(1, 9))), replace=False):
+        dx, dy, dz = d(), d(), d()
+        if isinstance(o, (Sphere, Disk)): o.Center = sh(o.Center)
+        elif isinstance(o, Box): o.Min, o.Max = sh(o.Min), sh(o.Max)
+        elif isinstance(o, CylinderY): o.Center = sh(o.Center); o.YMin = _f(o.YMin + dy); o.YMax = _f(o.YMax + dy)
+        else: o.A, o.B, o.C = sh(o.A), sh(o.B), sh(o.C)
+
+
+def run_sequence(oracle, seed, steps=12, log=print):
+    """Returns the list of differences found (empty = the library followed the oracle through the whole sequence)."""
+    rng = np.random.default_rng(77_000 + seed)
+    u = lambda lo, hi: _f(rng.uniform(lo, hi))
+    s, pose = random_scene(seed)
+    w, h, ss = SEQ_SIZES[seed % len(SEQ_SIZES)]
+    flat = flatten(s)
+    keep = [flat]                    # (the oracle and the library copy during the call; kept anyway until the contexts are gone)
+    o = oracle.OracleRenderer(s, w, h, ss, pose, flat=flat)
+    g = RaytraceRenderer(flat, w, h, pose["fov"], ss, capture_debug=True, count_work=True)
+    g.SetCamera(pose["pos"], pose["yaw"], pose["pitch"])
+    found = []
+    for step in range(steps):
+        ops = []
+        if rng.random() < 0.45:
+            k = [1e-4, 1e-3, 0.02, 0.5][int(rng.integers(0, 4))]          # below and above TemporalAA's reset thresholds (TemporalAA.cs:58-67)
+            pose = dict(pose, pos=tuple(_f(c + rng.uniform(-k, k)) for c in pose["pos"]), yaw=_f(pose["yaw"] + rng.uniform(-k, k) * 0.3), pitch=_f(pose["pitch"] + rng.uniform(-k, k) * 0.1))
+            ops.append(f"camera {k}")
+        if rng.random() < 0.1:
+            pose = dict(pose, fov=u(30, 90)); ops.append("fov")
+        if ops:
+            o.set_camera(pose["pos"], pose["yaw"], pose["pitch"], pose["fov"])
+            g.SetCamera(pose["pos"], pose["yaw"], pose["pitch"]); g.SetFov(pose["fov"])
+        if rng.random() < 0.2:
+            lights = [PointLight(vec3(u(-8, 8), u(0.5, 9), u(-20, 4)), vec3(u(0.5, 1), u(0.5, 1), u(0.5, 1)), 0.0 if rng.random() < 0.2 else u(5, 120)) for _ in range(int(rng.integers(0, 5)))]
+            amb, top, bot = AmbientLight(vec3(u(0.5, 1), u(0.5, 1), u(0.5, 1)), u(0, 0.2)), vec3(u(0, 1), u(0, 1), u(0, 1)), vec3(u(0, 1), u(0, 1), u(0, 1))
+            g.UpdateLights(lights, amb, top, bot)
+            s.Lights, s.Ambient, s.BackgroundTop, s.BackgroundBottom = lights, amb, top, bot      # (the oracle takes moved objects as a full upload: the scene it is flattened from carries the lights of the moment)
+            arr = (abi.Light * max(1, len(lights)))()
+            for i, l in enumerate(lights):
+                arr[i].position, arr[i].color, arr[i].intensity = abi.Vec3(*l.Position), abi.Vec3(*l.Color), float(l.Intensity)
+            a_, t_, b_ = abi.Vec3(*amb.Color), abi.Vec3(*top), abi.Vec3(*bot)
+            assert o.L.orc_scene_update_lights(o.ctx, arr, len(lights), C.byref(a_), float(amb.Intensity), C.byref(t_), C.byref(b_)) == 0
+            ops.append(f"{len(lights)} lights")
+        if rng.random() < 0.3:
+            _moved(s, rng)
+            flat = flatten(s); keep.append(flat)
+            assert o.L.orc_scene_upload(o.ctx, flat.byref()) == 0
+            g.UpdateObjects(flat)
+            ops.append("objects moved")
+        if rng.random() < 0.08:
+            s, _ = random_scene(1000 + 50 * seed + step)
+            flat = flatten(s); keep.append(flat)
+            assert o.L.orc_scene_upload(o.ctx, flat.byref()) == 0
+            g.UploadScene(flat)
+            ops.append(f"new scene ({len(s.Objects)} objects)")
+        if rng.random() < 0.12:
+            w, h, ss = SEQ_SIZES[int(rng.integers(0, len(SEQ_SIZES)))]
+            o.resize(w, h, ss); g.Resize(w, h, ss)
+            ops.append(f"resize {w}x{h} ss {ss}")
+        if rng.random() < 0.1:
+            n = FRAME_COUNTERS[int(rng.integers(0, len(FRAME_COUNTERS)))]
+            o.set_frame_counter(n); g.set_frame_counter(n)
+            ops.append(f"frame counter {n}")
+        with_sdr = rng.random() < 0.35
+        label = f"sequence {seed} step {step} [{', '.join(ops) or 'nothing'}{', SDR' if with_sdr else ''}]"
+        if with_sdr:
+            so = o.render(stages=2, threads=8, want_sdr=True); sg = g.TryFlipAndBlit(want_sdr=True)
+        else:
+            o.render(stages=1, threads=8); g.TryFlipAndBlit()
+        st = pu.compare_frame(o, g)
+        bad = {k: v for k, v in st.items() if k.endswith("_mismatch") and v}
+        bad.update({k: st[k] for k in ("n_rays", "n_box", "n_tri", "n_prim", "n_vox") if st[k][0] != st[k][1]})
+        if int(o.stats.history_reset) != int(g.stats.history_reset): bad["history_reset"] = (int(o.stats.history_reset), int(g.stats.history_reset))
+        if with_sdr:
+            if pu.mismatch_count(o.read(abi.BUF_DENOISED), g.read(abi.BUF_DENOISED)): bad["denoised"] = True
+            if np.float32(o.stats.exposure).view(np.uint32) != np.float32(g.stats.exposure).view(np.uint32): bad["exposure"] = (float(o.stats.exposure), float(g.stats.exposure))
+            if pu.mismatch_count(so, sg): bad["sdr"] = pu.mismatch_count(so, sg)
+        log(label, "reset", int(g.stats.history_reset), "DIFFERS " + repr(bad) if bad else "equal")
+        if bad: found.append((label, bad))
+    o.close(); g.close()
+    return found
+
+
+@pytest.mark.parametrize("seed", [1, 2, 3, 4, 5, 6])
+def test_random_call_sequences_follow_the_oracle(product_lib, oracle, path, seed):
+    found = run_sequence(oracle, seed, steps=14)
+    assert not found, found
