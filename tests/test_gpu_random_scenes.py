@@ -18,7 +18,7 @@ import parity_util as pu
 from yetanotherconsolegameengine_amd import abi, scenes
 from yetanotherconsolegameengine_amd.renderer import RaytraceRenderer
 from yetanotherconsolegameengine_amd.scene import (AmbientLight, Box, Checker, CylinderY, Disk, Material, Mesh, Plane, PointLight, Scene, Solid,
-                                                   Sphere, Triangle, VolumeGrid, XYRect, XZRect, YZRect, flatten, vec3, ZERO)
+                                                   Sphere, Texture, Triangle, VolumeGrid, XYRect, XZRect, YZRect, flatten, vec3, ZERO)
 
 pytestmark = pytest.mark.gpu
 
@@ -109,17 +109,19 @@ def random_scene(seed: int):
     return s, pose
 
 
-HARD_MODES = ["glass-heavy", "many-lights", "many-objects", "camera-inside", "degenerate", "scaled"]
+HARD_MODES = ["glass-heavy", "many-lights", "many-objects", "camera-inside", "degenerate", "scaled", "textured", "voxel-chunks"]
 
 
 def harden(s, pose, seed):
-    """random_scene(seed) pushed one way (seed % 6): most materials glass of random index (the 16-entry path stack and the transmittance walk,
+    """random_scene(seed) pushed one way (seed % 8): most materials glass of random index (the 16-entry path stack and the transmittance walk,
     RaytraceRenderer.cs:439-446, 757-798); 4 - 12 more lights; 1 500 - 5 000 more small objects (a deep top-level tree, the device builder's
     large-input path); the camera INSIDE a sphere / box / cylinder; degenerate objects (zero-area and collinear triangles, radius 0, flat and
     point boxes, a zero-height cylinder, a zero-width rectangle, a light at the eye and one in the floor plane); everything scaled by 1e-2 /
-    1e2 / 1e3 (tMin = 0.001 and the 1e-4 / 1e-6 epsilons of the hit routines against other magnitudes).  Returns the mode's name."""
+    1e2 / 1e3 (tMin = 0.001 and the 1e-4 / 1e-6 epsilons of the hit routines against other magnitudes); static textures of several sizes, weights
+    and UV scales on half the objects (SampleAlbedo, RaytraceRenderer.cs:724-735, Texture.cs:142-163); a VolumeScene of 3 - 8 voxel chunks side by
+    side with lit lights (VolumeGrid.cs:99-231, the binary transmittance of RaytraceRenderer.cs:761).  Returns the mode's name."""
     rng = np.random.default_rng(10_000 + seed)
-    mode = seed % 6
+    mode = seed % 8
     tag = HARD_MODES[mode]
     if mode == 0:
         for o in s.Objects:
@@ -155,8 +157,29 @@ def harden(s, pose, seed):
         s.Add(Disk(c(), vec3(0, 1, 0), 0.0, Solid(vec3(0.9, 0.2, 0.2)), 0.0, 0.0))
         s.Lights.append(PointLight(tuple(pose["pos"]), vec3(1, 1, 1), 30.0))                                           # a light AT the eye
         if s.Objects and isinstance(s.Objects[0], Plane): s.Lights.append(PointLight(vec3(0.5, s.Objects[0].Point[1], -4.0), vec3(1, 1, 1), 30.0))   # a light IN the floor plane
+    elif mode == 6:
+        pool = [Texture(rng.integers(0, 256, shape, dtype=np.uint8)) for shape in ((1, 1, 3), (2, 3, 4), (32, 48, 4), (7, 5, 3))]
+        for o in s.Objects:
+            if rng.random() < 0.5 and not isinstance(o, VolumeGrid):
+                m = Material(vec3(_f(rng.uniform(0, 1)), _f(rng.uniform(0, 1)), _f(rng.uniform(0, 1))), _f(rng.uniform(0, 0.3)), 0.0,
+                             DiffuseTexture=pool[int(rng.integers(0, len(pool)))], TextureWeight=1.0 if rng.random() < 0.4 else _f(rng.uniform(0, 1)), UVScale=_f(rng.uniform(0.1, 6)))
+                if hasattr(o, "Mat"): o.Mat = m
+                else: o.MaterialFunc = m
+    elif mode == 7:
+        s.IsVolumeScene = True
+        n = int(rng.integers(8, 17)); vs = _f(rng.uniform(0.15, 0.4)); base = (_f(rng.uniform(-4, 0)), _f(rng.uniform(-1, 0)), _f(rng.uniform(-14, -6)))
+        for c in range(int(rng.integers(3, 9))):
+            cx, cz = c % 3, c // 3
+            cells = np.zeros((n, n, n, 2), np.int32)
+            height = rng.integers(1, n, (n, n))
+            solid = np.arange(n)[None, :, None] < height[:, None, :]
+            cells[..., 0] = np.where(solid & (rng.random((n, n, n)) < 0.9), rng.integers(1, 12, (n, n, n)), 0)
+            cells[..., 1] = rng.integers(0, 3, (n, n, n))
+            s.Add(VolumeGrid(cells, vec3(_f(base[0] + cx * n * vs), base[1], _f(base[2] + cz * n * vs)), vec3(vs, vs, vs), scenes.VoxelMaterialLookup, bool(rng.random() < 0.6), 0.06, 16.0))
+        for _ in range(2):
+            s.Lights.append(PointLight(vec3(_f(rng.uniform(-6, 6)), _f(rng.uniform(4, 12)), _f(rng.uniform(-14, 0))), vec3(1.0, 0.95, 0.9), _f(rng.uniform(40, 200))))
     else:
-        k = np.float32([1e-2, 1e2, 1e3][seed // 6 % 3])
+        k = np.float32([1e-2, 1e2, 1e3][seed // 8 % 3])
         sc3 = lambda v: tuple(_f(np.float32(x) * k) for x in v)
         for o in s.Objects:
             for fld in dataclasses.fields(o):
