@@ -1,8 +1,8 @@
 """Soak of tests/test_gpu_random_scenes.py: seeds lo .. hi - 1 of its two scene generators (plain, and pushed one way: glass-heavy, many lights,
 thousands of objects, camera inside an object, degenerate objects, scaled by 1e-2 .. 1e3, textured, voxel chunks) on both device paths, two frames each, every buffer
-and counter against the oracle bit for bit; then its drawn CALL SEQUENCES (16 steps each).  Prints the frames that differ and a total; exit status 1 if there is one.
+and counter against the oracle bit for bit; then its drawn CALL SEQUENCES (16 steps each; synchronous, then with frames in flight) and its draws on 2 - 8 emulated ranks (both tiled forms).  Prints the frames that differ and a total; exit status 1 if there is one.
 
-    gpurun -- python profiles/fuzz_scenes.py 100 500        (round 6: 18 560 frames over seeds 0 .. 1059, none differs - profiles/r06/g_fuzz_scenes.txt)
+    gpurun -- python profiles/fuzz_scenes.py 100 500        (round 6: 36 240 frames over seeds 0 .. 1299, none differs - profiles/r06/g_fuzz_scenes.txt)
 """
 import os
 import sys
@@ -10,6 +10,8 @@ from pathlib import Path
 
 ROOT = Path(__file__).resolve().parents[1]
 sys.path.insert(0, str(ROOT / "tests")); sys.path.insert(0, str(ROOT))
+import torch                         # noqa: E402  (first, as tests/conftest.py and bench.py do: torch and the library then share ONE libamdhip64)
+torch.zeros(1, device="cuda")
 import oracle_binding as ob          # noqa: E402  (the checker; this script is a test driver, not a product path)
 import parity_util as pu             # noqa: E402
 import test_gpu_random_scenes as T   # noqa: E402
@@ -41,12 +43,20 @@ for pushed in (False, True):
             o.close(); g.close()
         print(f"{'pushed' if pushed else 'plain'} scenes, {path}: seeds {lo}..{hi - 1} done; {n_bad} of {n_frames} frames differ so far", flush=True)
 # call sequences (camera moves around the TAA thresholds, lights, moved objects, new scenes, resizes, frame-counter jumps, SDR frames in between)
-for path in ("wavefront", "megakernel"):
-    os.environ["YCGE_PATH"] = path
-    for seed in range(lo, hi):
-        found = T.run_sequence(ob, seed, steps=16, log=lambda *a: None)
-        n_frames += 16; n_bad += len(found)
-        for label, bad in found:
-            print("MISMATCH", path, label, bad, flush=True)
-    print(f"call sequences, {path}: seeds {lo}..{hi - 1} done; {n_bad} of {n_frames} frames differ so far", flush=True)
+for flight in (False, True):          # (True: through ycge_render_frame_async / _async_sdr, one to three frames queued before ycge_wait)
+    for path in ("wavefront", "megakernel"):
+        os.environ["YCGE_PATH"] = path
+        for seed in range(lo, hi):
+            found = T.run_sequence(ob, seed, steps=16, log=lambda *a: None, flight=flight)
+            n_frames += 16; n_bad += len(found)
+            for label, bad in found:
+                print("MISMATCH", path, "in flight" if flight else "", label, bad, flush=True)
+        print(f"call sequences{' with frames in flight' if flight else ''}, {path}: seeds {lo}..{hi - 1} done; {n_bad} of {n_frames} frames differ so far", flush=True)
+os.environ.pop("YCGE_PATH", None)
+for seed in range(lo, hi):          # the tiled forms on 2 - 8 emulated ranks against one context
+    found = T.run_tile_split(seed, log=lambda *a: None)
+    n_frames += 4; n_bad += len(found)
+    for label, bad in found:
+        print("MISMATCH", label, bad, flush=True)
+print(f"tiled forms on emulated ranks: seeds {lo}..{hi - 1} done; {n_bad} of {n_frames} frames differ so far", flush=True)
 sys.exit(1 if n_bad else 0)

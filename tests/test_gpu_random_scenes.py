@@ -263,8 +263,10 @@ def _moved(s, rng):
         else: o.A, o.B, o.C = sh(o.A), sh(o.B), sh(o.C)
 
 
-def run_sequence(oracle, seed, steps=12, log=print):
-    """Returns the list of differences found (empty = the library followed the oracle through the whole sequence)."""
+def run_sequence(oracle, seed, steps=12, log=print, flight=False):
+    """Returns the list of differences found (empty = the library followed the oracle through the whole sequence).
+    flight: the library renders through ycge_render_frame_async / _async_sdr, one to three frames queued before ycge_wait - the calls between them
+    (camera, lights, moved objects, resize ..) arrive while frames are in flight; the last frame of a burst and every SDR array held are compared."""
     rng = np.random.default_rng(77_000 + seed)
     u = lambda lo, hi: _f(rng.uniform(lo, hi))
     s, pose = random_scene(seed)
@@ -272,9 +274,9 @@ def run_sequence(oracle, seed, steps=12, log=print):
     flat = flatten(s)
     keep = [flat]                    # (the oracle and the library copy during the call; kept anyway until the contexts are gone)
     o = oracle.OracleRenderer(s, w, h, ss, pose, flat=flat)
-    g = RaytraceRenderer(flat, w, h, pose["fov"], ss, capture_debug=True, count_work=True)
+    g = RaytraceRenderer(flat, w, h, pose["fov"], ss, capture_debug=not flight, count_work=not flight)     # (frames in flight keep neither debug captures nor counters)
     g.SetCamera(pose["pos"], pose["yaw"], pose["pitch"])
-    found = []
+    found, held, burst_left = [], [], 0
     for step in range(steps):
         ops = []
         if rng.random() < 0.45:
@@ -319,19 +321,39 @@ def run_sequence(oracle, seed, steps=12, log=print):
             ops.append(f"frame counter {n}")
         with_sdr = rng.random() < 0.35
         label = f"sequence {seed} step {step} [{', '.join(ops) or 'nothing'}{', SDR' if with_sdr else ''}]"
-        if with_sdr:
-            so = o.render(stages=2, threads=8, want_sdr=True); sg = g.TryFlipAndBlit(want_sdr=True)
+        if flight:
+            if not burst_left: burst_left = int(rng.integers(1, 4))
+            so = o.render(stages=2, threads=8, want_sdr=True) if with_sdr else o.render(stages=1, threads=8)
+            if held and held[0][2].shape != (h, w, 2, 3): held = []          # (a resize joined the frames and retired the arrays of the old size; their frames were compared below or are skipped)
+            arr = g.RenderAsync(sdr_slot=len(held) if with_sdr else None)
+            if with_sdr: held.append((label, so, arr))
+            burst_left -= 1
+            if burst_left and step + 1 < steps:
+                log(label, "in flight")
+                continue
+            g.Wait()
+            bad = {}
+            for name, which in (("current_hdr", abi.BUF_CURRENT_HDR), ("g_albedo", abi.BUF_G_ALBEDO), ("g_normal", abi.BUF_G_NORMAL), ("g_depth", abi.BUF_G_DEPTH),
+                                ("sky", abi.BUF_SKY_MASK), ("taa_history", abi.BUF_TAA_HISTORY)):
+                n = pu.mismatch_count(o.read(which), g.read(which))
+                if n: bad[name] = n
+            for lab, want, got in held:
+                if pu.mismatch_count(want, got): bad["sdr of " + lab] = pu.mismatch_count(want, got)
+            held = []
         else:
-            o.render(stages=1, threads=8); g.TryFlipAndBlit()
-        st = pu.compare_frame(o, g)
-        bad = {k: v for k, v in st.items() if k.endswith("_mismatch") and v}
-        bad.update({k: st[k] for k in ("n_rays", "n_box", "n_tri", "n_prim", "n_vox") if st[k][0] != st[k][1]})
-        if int(o.stats.history_reset) != int(g.stats.history_reset): bad["history_reset"] = (int(o.stats.history_reset), int(g.stats.history_reset))
-        if with_sdr:
-            if pu.mismatch_count(o.read(abi.BUF_DENOISED), g.read(abi.BUF_DENOISED)): bad["denoised"] = True
-            if np.float32(o.stats.exposure).view(np.uint32) != np.float32(g.stats.exposure).view(np.uint32): bad["exposure"] = (float(o.stats.exposure), float(g.stats.exposure))
-            if pu.mismatch_count(so, sg): bad["sdr"] = pu.mismatch_count(so, sg)
-        log(label, "reset", int(g.stats.history_reset), "DIFFERS " + repr(bad) if bad else "equal")
+            if with_sdr:
+                so = o.render(stages=2, threads=8, want_sdr=True); sg = g.TryFlipAndBlit(want_sdr=True)
+            else:
+                o.render(stages=1, threads=8); g.TryFlipAndBlit()
+            st = pu.compare_frame(o, g)
+            bad = {k: v for k, v in st.items() if k.endswith("_mismatch") and v}
+            bad.update({k: st[k] for k in ("n_rays", "n_box", "n_tri", "n_prim", "n_vox") if st[k][0] != st[k][1]})
+            if int(o.stats.history_reset) != int(g.stats.history_reset): bad["history_reset"] = (int(o.stats.history_reset), int(g.stats.history_reset))
+            if with_sdr:
+                if pu.mismatch_count(o.read(abi.BUF_DENOISED), g.read(abi.BUF_DENOISED)): bad["denoised"] = True
+                if np.float32(o.stats.exposure).view(np.uint32) != np.float32(g.stats.exposure).view(np.uint32): bad["exposure"] = (float(o.stats.exposure), float(g.stats.exposure))
+                if pu.mismatch_count(so, sg): bad["sdr"] = pu.mismatch_count(so, sg)
+        log(label, "DIFFERS " + repr(bad) if bad else "equal")
         if bad: found.append((label, bad))
     o.close(); g.close()
     return found
@@ -340,4 +362,82 @@ def run_sequence(oracle, seed, steps=12, log=print):
 @pytest.mark.parametrize("seed", [1, 2, 3, 4, 5, 6])
 def test_random_call_sequences_follow_the_oracle(product_lib, oracle, path, seed):
     found = run_sequence(oracle, seed, steps=14)
+    assert not found, found
+
+
+@pytest.mark.parametrize("seed", [11, 12, 13, 14, 15, 16])
+def test_random_call_sequences_with_frames_in_flight(product_lib, oracle, path, seed):
+    found = run_sequence(oracle, seed, steps=16, flight=True)
+    assert not found, found
+
+
+# ---- the multi-GPU entry points on drawn scenes ----------------------------------------------------------------------------------------------------
+def run_tile_split(seed, log=print):
+    """`world` ranks emulated on one GPU (2 - 8, drawn), both tiled forms of include/ycge.h against ONE context rendering whole frames, over four
+    frames of a camera that moves below and above the TAA thresholds: (a) ycge_trace_tiles -> slabs side by side as an all-gather leaves them ->
+    ycge_resolve_gathered on every rank: radiance, G-buffer and history of every rank equal the single context's; (b) the tile-resident form:
+    ycge_trace_tiles_resident -> the halo exchange by device copies (ycge_halo_counts' split sizes) -> ycge_resolve_tiles_resident -> the gathered
+    history slabs un-permuted equal the single context's history.  Returns the differences found."""
+    import torch
+    from test_gpu_parity import _exchange_halos
+    from yetanotherconsolegameengine_amd import tiles
+    rng = np.random.default_rng(55_000 + seed)
+    s, pose = random_scene(seed)
+    tag = harden(s, pose, seed) if seed % 3 == 2 else "plain"
+    w, h, ss = SEQ_SIZES[int(rng.integers(0, len(SEQ_SIZES)))]
+    world = int(rng.integers(2, 9))
+    lean = bool(rng.random() < 0.3)
+    flat = flatten(s)
+    mk = lambda rank, n, **kw: RaytraceRenderer(flat, w, h, pose["fov"], ss, rank=rank, world_size=n, **kw)
+    single = mk(0, 1)
+    gath = [mk(i, world, slab_albedo=not lean) for i in range(world)]
+    resi = [mk(i, world) for i in range(world)]
+    nb, hb = gath[0].tile_slab_bytes(), resi[0].history_slab_bytes()
+    n_send = [max(1, sum(r.halo_counts()[0])) for r in resi]
+    found = []
+    for frame in range(4):
+        k = [0.0, 1e-3, 0.02, 0.3][int(rng.integers(0, 4))]
+        pose = dict(pose, pos=tuple(_f(c + rng.uniform(-k, k)) for c in pose["pos"]), yaw=_f(pose["yaw"] + rng.uniform(-k, k) * 0.3))
+        for r in [single] + gath + resi:
+            r.SetCamera(pose["pos"], pose["yaw"], pose["pitch"])
+        single.TryFlipAndBlit()
+        label = f"tiles {seed} ({tag}, {w}x{h} ss {ss}, world {world}{', lean slabs' if lean else ''}) frame {frame} move {k}"
+        bad = {}
+        gathered = torch.zeros(world * nb // 4, dtype=torch.float32, device="cuda")
+        for i, r in enumerate(gath):
+            r.trace_tiles(gathered[i * nb // 4:].data_ptr(), 0, want_stats=True)
+        torch.cuda.synchronize()
+        for i, r in enumerate(gath):
+            r.resolve_gathered(gathered.data_ptr(), 0, want_stats=True)
+            if int(r.stats.history_reset) != int(single.stats.history_reset): bad[f"gathered form, rank {i}: history_reset"] = int(r.stats.history_reset)
+            for name, which in (("current_hdr", abi.BUF_CURRENT_HDR), ("g_albedo", abi.BUF_G_ALBEDO), ("g_normal", abi.BUF_G_NORMAL), ("g_depth", abi.BUF_G_DEPTH),
+                                ("sky", abi.BUF_SKY_MASK), ("taa_history", abi.BUF_TAA_HISTORY)):
+                if lean and which == abi.BUF_G_ALBEDO: continue
+                n = pu.mismatch_count(single.read(which), r.read(which))
+                if n: bad[f"gathered form, rank {i}: {name}"] = n
+        send = [torch.zeros(m * 4, dtype=torch.float32, device="cuda") for m in n_send]
+        torch.cuda.synchronize()
+        for i, r in enumerate(resi):
+            r.trace_tiles_resident(send[i].data_ptr(), 0)
+        torch.cuda.synchronize()
+        recv = _exchange_halos(resi, send, torch)
+        hist = torch.zeros(world * hb // 4, dtype=torch.float32, device="cuda")
+        torch.cuda.synchronize()
+        for i, r in enumerate(resi):
+            r.resolve_tiles_resident(recv[i].data_ptr(), hist[i * hb // 4:].data_ptr(), 0, want_stats=True)
+            if int(r.stats.history_reset) != int(single.stats.history_reset): bad[f"resident form, rank {i}: history_reset"] = int(r.stats.history_reset)
+        torch.cuda.synchronize()
+        n = pu.mismatch_count(tiles.unpermute(hist.cpu().numpy(), single.hiW, single.hiH, world, 3), single.read(abi.BUF_TAA_HISTORY))
+        if n: bad["resident form: gathered history"] = n
+        log(label, "DIFFERS " + repr(bad) if bad else "equal")
+        if bad: found.append((label, bad))
+    for r in [single] + gath + resi:
+        r.close()
+    return found
+
+
+@pytest.mark.parametrize("seed", [1, 2, 3, 4, 5, 6, 7, 8])
+def test_random_scenes_on_emulated_ranks(product_lib, seed, monkeypatch):
+    monkeypatch.delenv("YCGE_PATH", raising=False)
+    found = run_tile_split(seed)
     assert not found, found
