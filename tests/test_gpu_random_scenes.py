@@ -441,3 +441,63 @@ def test_random_scenes_on_emulated_ranks(product_lib, seed, monkeypatch):
     monkeypatch.delenv("YCGE_PATH", raising=False)
     found = run_tile_split(seed)
     assert not found, found
+
+
+# ---- mesh viewers: the scenes the timed single-launch kernels are for ------------------------------------------------------------------------------
+def run_mesh_viewer(oracle, seed, log=print):
+    """MeshScenes.BuildBunnyScene's pattern (MeshScenes.cs:117-124: floor, two lights, ONE auto-grounded mesh - the scenes that reach the flat
+    single-launch kernels, their longest-first schedule, split blocks and cooperative walk) with a drawn mesh of 60 - 80 000 triangles, a drawn
+    material (matte, partial mirror, true mirror, glass), lights moved / dimmed / switched off, a drawn camera around the mesh (sometimes inside its
+    bounds, sometimes far off), a drawn size.  Three frames of a slightly moving camera, once with debug capture and counters (the counting kernel
+    instances) and once without (the instances the benchmark times), on whatever path YCGE_PATH selects.  Returns the differences found."""
+    rng = np.random.default_rng(33_000 + seed)
+    u = lambda lo, hi: _f(rng.uniform(lo, hi))
+    nu, nv = int(rng.integers(6, 400)), int(rng.integers(5, 100))
+    pos, faces = scenes.make_torus_knot(nu, nv, seed=int(rng.integers(1, 1 << 20)))
+    k = int(rng.integers(0, 4))
+    mat = [scenes.Matte(vec3(u(0, 1), u(0, 1), u(0, 1)), u(0, 0.5), 0.0), scenes.MirrorMat(vec3(u(0.5, 1), u(0.5, 1), u(0.5, 1)), u(0.3, 0.89)),
+           Material(vec3(0.95, 0.95, 0.95), 0.0, u(0.9, 1.0)), Material(vec3(1, 1, 1), 0.05, u(0, 0.1), ZERO, u(0.4, 0.95), u(1.1, 2.0), vec3(u(0.6, 1), u(0.6, 1), u(0.6, 1)))][k]
+    target = (u(-0.5, 0.5), u(0.3, 0.8), u(0.5, 1.5))
+    s = scenes.BuildMeshScene(pos, faces, mat, target)
+    if rng.random() < 0.3: s.Lights[int(rng.integers(0, 2))].Intensity = 0.0
+    if rng.random() < 0.3: s.Lights[0].Position = vec3(u(-3, 3), u(1, 6), u(-3, 3))
+    if rng.random() < 0.2: s.Lights.pop()
+    if rng.random() < 0.2: s.BackgroundTop, s.BackgroundBottom = vec3(u(0, 1), u(0, 1), u(0, 1)), vec3(u(0, 1), u(0, 1), u(0, 1))
+    dist = [0.2, 0.6, 1.2, 2.0, 8.0][int(rng.integers(0, 5))]
+    ang = u(0, 6.2831)
+    cam = (_f(target[0] + dist * np.sin(ang)), _f(target[1] + u(0.0, 0.9)), _f(target[2] + dist * np.cos(ang)))
+    d = np.array([target[0] - cam[0], target[1] + 0.4 - cam[1], target[2] - cam[2]], np.float64)          # towards the mesh, give or take: fwd = (sin yaw cos pitch, sin pitch, -cos yaw cos pitch)
+    pose = dict(pos=cam, yaw=_f(np.arctan2(d[0], -d[2]) + rng.uniform(-0.2, 0.2)), pitch=_f(np.arcsin(d[1] / np.linalg.norm(d)) + rng.uniform(-0.1, 0.1)), fov=u(22, 60))
+    w, h, ss = [(320, 90, 1), (640, 180, 1), (200, 60, 1), (480, 135, 1), (160, 45, 2)][int(rng.integers(0, 5))]
+    flat = flatten(s)
+    o = oracle.OracleRenderer(s, w, h, ss, pose, flat=flat)
+    gs = [RaytraceRenderer(flat, w, h, pose["fov"], ss, capture_debug=True, count_work=True), RaytraceRenderer(flat, w, h, pose["fov"], ss)]
+    found = []
+    for f in range(3):
+        p = tuple(_f(c + f * 0.0007) for c in pose["pos"])
+        o.set_camera(p, pose["yaw"], pose["pitch"], pose["fov"]); o.render(stages=1, threads=8)
+        label = f"mesh viewer {seed} ({2 * nu * nv} triangles, material {k}, distance {dist}, {w}x{h} ss {ss}) frame {f}"
+        bad = {}
+        for gi, g in enumerate(gs):
+            g.SetCamera(p, pose["yaw"], pose["pitch"]); g.TryFlipAndBlit()
+            if gi == 0:
+                st = pu.compare_frame(o, g)
+                bad.update({k_: v for k_, v in st.items() if k_.endswith("_mismatch") and v})
+                bad.update({k_: st[k_] for k_ in ("n_rays", "n_box", "n_tri", "n_prim", "n_vox") if st[k_][0] != st[k_][1]})
+            else:
+                for name, which in (("current_hdr", abi.BUF_CURRENT_HDR), ("g_albedo", abi.BUF_G_ALBEDO), ("g_normal", abi.BUF_G_NORMAL), ("g_depth", abi.BUF_G_DEPTH),
+                                    ("sky", abi.BUF_SKY_MASK), ("taa_history", abi.BUF_TAA_HISTORY)):
+                    n = pu.mismatch_count(o.read(which), g.read(which))
+                    if n: bad["timed instances: " + name] = n
+        seen = float((o.read(abi.BUF_PRIM_ID) == 1).mean())
+        log(label, f"mesh in {seen:.0%} of the pixels", "DIFFERS " + repr(bad) if bad else "equal")
+        if bad: found.append((label, bad))
+    o.close()
+    for g in gs: g.close()
+    return found
+
+
+@pytest.mark.parametrize("seed", [1, 2, 3, 4, 5, 6, 7, 8, 9, 10])
+def test_random_mesh_viewers(product_lib, oracle, path, seed):
+    found = run_mesh_viewer(oracle, seed)
+    assert not found, found
