@@ -951,6 +951,27 @@ class BvhScene:
                 bb = [f32(o.X0), f32(f32(o.Y) - f32(1e-4)), f32(o.Z0), f32(o.X1), f32(f32(o.Y) + f32(1e-4)), f32(o.Z1)]
             elif isinstance(o, Box):
                 bb = [f32(v) for v in (*o.Min, *o.Max)]
+            elif isinstance(o, Disk):                   # Surfaces.cs:97-105: Center -+ (Radius, Radius, Radius) - a cube, whatever the normal
+                c3, rr = [f32(v) for v in o.Center], f32(o.Radius)
+                bb = [f32(c3[0] - rr), f32(c3[1] - rr), f32(c3[2] - rr), f32(c3[0] + rr), f32(c3[1] + rr), f32(c3[2] + rr)]
+            elif isinstance(o, XYRect):                 # Surfaces.cs:174-181
+                bb = [f32(o.X0), f32(o.Y0), f32(f32(o.Z) - f32(1e-4)), f32(o.X1), f32(o.Y1), f32(f32(o.Z) + f32(1e-4))]
+            elif isinstance(o, YZRect):                 # Surfaces.cs:318-325
+                bb = [f32(f32(o.X) - f32(1e-4)), f32(o.Y0), f32(o.Z0), f32(f32(o.X) + f32(1e-4)), f32(o.Y1), f32(o.Z1)]
+            elif isinstance(o, CylinderY):              # BoundedObjects.cs:140-145 (YMin / YMax as the ctor ordered them, :128-137)
+                cx, cz, rr = f32(o.Center[0]), f32(o.Center[2]), f32(o.Radius)
+                y0, y1 = fmin(f32(o.YMin), f32(o.YMax)), fmax(f32(o.YMin), f32(o.YMax))
+                bb = [f32(cx - rr), y0, f32(cz - rr), f32(cx + rr), y1, f32(cz + rr)]
+            elif isinstance(o, Triangle):               # Triangle.cs:54-64: the vertices' box grown by BoundEps = 1e-4
+                A, B, C_ = ([f32(v) for v in q] for q in (o.A, o.B, o.C))
+                mn = [fmin(A[k], fmin(B[k], C_[k])) for k in range(3)]
+                mx = [fmax(A[k], fmax(B[k], C_[k])) for k in range(3)]
+                bb = [f32(mn[k] - f32(1e-4)) for k in range(3)] + [f32(mx[k] + f32(1e-4)) for k in range(3)]
+            elif isinstance(o, VolumeGrid):             # VolumeGrid.cs:387-404 (voxelSize clamped to >= 1e-6 by the ctor, :76)
+                nxyz = np.asarray(o.Cells).shape[:3]
+                mc = [f32(v) for v in o.MinCorner]
+                vs = [fmax(f32(1e-6), f32(v)) for v in o.VoxelSize]
+                bb = mc + [f32(mc[k] + f32(f32(nxyz[k]) * vs[k])) for k in range(3)]
             else:
                 raise TypeError(type(o).__name__)
             bounds.append(bb); cents.append([f32(f32(0.5) * f32(bb[k] + bb[3 + k])) for k in range(3)])

@@ -1,0 +1,177 @@
+"""Drawn scenes for the parity tests (test infrastructure): `random_scene(seed)` and `harden(scene, pose, seed)`.
+
+Used by tests/test_gpu_random_scenes.py (the HIP path against the oracle, -m gpu), tests/test_oracle_kats.py (the oracle against the
+independent Python restatement, CPU) and profiles/fuzz_scenes.py (the soak).  Everything is drawn from one numpy Generator per seed.
+"""
+import dataclasses
+
+import numpy as np
+
+from yetanotherconsolegameengine_amd import scenes
+from yetanotherconsolegameengine_amd.scene import (AmbientLight, Box, Checker, CylinderY, Disk, Material, Mesh, Plane, PointLight, Scene, Solid,
+                                                   Sphere, Texture, Triangle, VolumeGrid, XYRect, XZRect, YZRect, vec3, ZERO)
+
+
+def _f(v):
+    return float(np.float32(v))
+
+
+def random_scene(seed: int, n_range=(30, 260), ties=True, mesh_nu=(12, 70), mesh_nv=(5, 14), max_meshes=3, grid=True):
+    """(scene, pose).  Everything comes from one numpy Generator, rounded to binary32 here; oracle and library read the SAME flattened scene
+    (parity_util.run_pair), so a mesh generator's sin / cos differing in the last place between machines changes the draw, not the comparison.
+    The keyword arguments shrink the draw for the slow checkers (the pure-Python restatement): fewer objects, smaller meshes, no engineered
+    ties (`ties=False`: no duplicated sphere, no boxes sharing a face - a brute-force closest hit and a tree walk may then visit in any order)."""
+    rng = np.random.default_rng(seed)
+    u = lambda lo, hi: _f(rng.uniform(lo, hi))
+    col = lambda lo=0.05, hi=0.98: vec3(u(lo, hi), u(lo, hi), u(lo, hi))
+
+    def material():
+        k = int(rng.integers(0, 10))
+        if k == 0: return Material(col(0.8, 0.99), u(0, 0.3), u(0.9, 1.0))                                  # true mirror
+        if k == 1: return Material(col(), u(0, 0.5), u(0.05, 0.89))                                          # partial reflectivity
+        if k == 2: return Material(vec3(1, 1, 1), u(0, 0.2), u(0, 0.1), ZERO, u(0.3, 0.95), u(1.05, 2.2), col(0.6, 1.0))     # glass
+        if k == 3: return Material(col(0, 0.3), 0.0, 0.0, vec3(u(0.5, 3), u(0.5, 3), u(0.5, 3)))            # emissive
+        return Material(col(), u(0, 0.6), 0.0)
+
+    def surface_material():
+        return Checker(col(), col(), u(0.3, 4.0)) if rng.random() < 0.3 else Solid(col())
+
+    def point(behind=False):
+        return vec3(u(-9, 9), u(-0.5, 6), u(1.5, 8) if behind else u(-24, -1.5))
+
+    s = Scene()
+    s.Ambient = AmbientLight(col(0.5, 1.0), u(0.0, 0.2) if rng.random() < 0.8 else 0.0)
+    s.BackgroundTop, s.BackgroundBottom = col(0, 1), col(0, 1)
+    s.IsVolumeScene = bool(rng.random() < 0.25)
+    if rng.random() < 0.6:
+        s.Add(Plane(vec3(0, u(-0.6, 0.0), 0), vec3(0, 1, 0), surface_material(), u(0, 0.2), u(0, 0.3)))
+    n = int(rng.integers(*n_range))
+    for i in range(n):
+        k = int(rng.integers(0, 11))
+        c = point(behind=rng.random() < 0.08)
+        if k <= 1:
+            sp = s.Add(Sphere(c, u(0.05, 1.6), material()))
+            if rng.random() < 0.1 and ties: s.Add(Sphere(sp.Center, sp.Radius, material()))                          # the same sphere twice: every t a tie
+        elif k == 2:
+            e = vec3(u(0.05, 2.0), u(0.05, 2.0), u(0.05, 2.0))
+            b = s.Add(Box(c, vec3(_f(c[0] + e[0]), _f(c[1] + e[1]), _f(c[2] + e[2])), surface_material(), u(0, 0.3), u(0, 1.0) if rng.random() < 0.3 else 0.0))
+            if rng.random() < 0.2 and ties:                                                                    # a neighbour sharing the +X face
+                s.Add(Box(vec3(b.Max[0], b.Min[1], b.Min[2]), vec3(_f(b.Max[0] + e[0]), b.Max[1], b.Max[2]), surface_material(), 0.0, 0.0))
+        elif k == 3:
+            y0 = c[1]
+            s.Add(CylinderY(c, u(0.05, 1.2), y0, _f(y0 + u(0.05, 3.0)), bool(rng.random() < 0.7), material()))
+        elif k == 4:
+            nrm = vec3(u(-1, 1), u(-1, 1), u(-1, 1)) if rng.random() < 0.7 else vec3(0, 1, 0)
+            s.Add(Disk(c, nrm, u(0.1, 2.0), surface_material(), u(0, 0.3), u(0, 0.5) if rng.random() < 0.3 else 0.0))
+        elif k == 5:
+            s.Add(XYRect(c[0], _f(c[0] + u(0.05, 3)), c[1], _f(c[1] + u(0.05, 3)), c[2], surface_material(), u(0, 0.3), 0.95 if rng.random() < 0.15 else 0.0))
+        elif k == 6:
+            s.Add(XZRect(c[0], _f(c[0] + u(0.05, 3)), c[2], _f(c[2] + u(0.05, 3)), c[1], surface_material(), u(0, 0.3), 0.0))
+        elif k == 7:
+            s.Add(YZRect(c[1], _f(c[1] + u(0.05, 3)), c[2], _f(c[2] + u(0.05, 3)), c[0], surface_material(), u(0, 0.3), 0.0))
+        elif k <= 9:
+            a = np.array(c, np.float32)
+            thin = np.float32(1e-3) if rng.random() < 0.15 else np.float32(1.0)                               # a sliver now and then
+            b = a + rng.uniform(-1.5, 1.5, 3).astype(np.float32)
+            d = a + (rng.uniform(-1.5, 1.5, 3).astype(np.float32) * thin if thin != 1.0 else rng.uniform(-1.5, 1.5, 3).astype(np.float32))
+            if thin != 1.0: d = (a + (b - a) * np.float32(0.5) + (d - a)).astype(np.float32)
+            s.Add(Triangle(tuple(map(_f, a)), tuple(map(_f, b)), tuple(map(_f, d)), material()))
+        else:
+            if sum(isinstance(o, Mesh) for o in s.Objects) < max_meshes:
+                pos, faces = scenes.make_torus_knot(int(rng.integers(*mesh_nu)), int(rng.integers(*mesh_nv)), seed=int(rng.integers(1, 1 << 20)))
+                tri = (pos[faces] * np.float32(u(0.1, 0.5)) + np.array(c, np.float32)).astype(np.float32)
+                s.Add(Mesh(tri, material()))
+    if rng.random() < 0.4 and grid:                                                                            # a small voxel volume among the rest
+        nx, ny, nz = (int(v) for v in rng.integers(3, 9, 3))
+        cells = np.zeros((nx, ny, nz, 2), np.int32)
+        cells[..., 0] = np.where(rng.random((nx, ny, nz)) < 0.45, rng.integers(1, 12, (nx, ny, nz)), 0)
+        cells[..., 1] = rng.integers(0, 3, (nx, ny, nz))
+        vs = u(0.2, 0.6)
+        s.Add(VolumeGrid(cells, point(), vec3(vs, vs, vs), scenes.VoxelMaterialLookup, bool(rng.random() < 0.7), 0.06, 16.0))
+    for _ in range(int(rng.integers(0, 5))):
+        s.Lights.append(PointLight(vec3(u(-8, 8), u(0.5, 9), u(-20, 4)), col(0.6, 1.0), 0.0 if rng.random() < 0.15 else u(5, 120)))
+    pose = dict(pos=(u(-1.5, 1.5), u(0.4, 3.0), u(0.0, 2.0)), yaw=u(-0.5, 0.5), pitch=u(-0.35, 0.15), fov=u(35, 80))
+    return s, pose
+
+
+HARD_MODES = ["glass-heavy", "many-lights", "many-objects", "camera-inside", "degenerate", "scaled", "textured", "voxel-chunks"]
+
+
+def harden(s, pose, seed):
+    """random_scene(seed) pushed one way (seed % 8): most materials glass of random index (the 16-entry path stack and the transmittance walk,
+    RaytraceRenderer.cs:439-446, 757-798); 4 - 12 more lights; 1 500 - 5 000 more small objects (a deep top-level tree, the device builder's
+    large-input path); the camera INSIDE a sphere / box / cylinder; degenerate objects (zero-area and collinear triangles, radius 0, flat and
+    point boxes, a zero-height cylinder, a zero-width rectangle, a light at the eye and one in the floor plane); everything scaled by 1e-2 /
+    1e2 / 1e3 (tMin = 0.001 and the 1e-4 / 1e-6 epsilons of the hit routines against other magnitudes); static textures of several sizes, weights
+    and UV scales on half the objects (SampleAlbedo, RaytraceRenderer.cs:724-735, Texture.cs:142-163); a VolumeScene of 3 - 8 voxel chunks side by
+    side with lit lights (VolumeGrid.cs:99-231, the binary transmittance of RaytraceRenderer.cs:761).  Returns the mode's name."""
+    rng = np.random.default_rng(10_000 + seed)
+    mode = seed % 8
+    tag = HARD_MODES[mode]
+    if mode == 0:
+        for o in s.Objects:
+            if hasattr(o, "Mat") and rng.random() < 0.6:
+                o.Mat = Material(vec3(1, 1, 1), 0.05, _f(rng.uniform(0, 0.2)), ZERO, _f(rng.uniform(0.3, 0.98)), _f(rng.uniform(1.0, 2.4)), vec3(_f(rng.uniform(0.5, 1)), _f(rng.uniform(0.5, 1)), _f(rng.uniform(0.5, 1))))
+    elif mode == 1:
+        for _ in range(int(rng.integers(4, 12))):
+            s.Lights.append(PointLight(vec3(_f(rng.uniform(-8, 8)), _f(rng.uniform(0.5, 9)), _f(rng.uniform(-20, 4))), vec3(1, 1, 1), _f(rng.uniform(0, 60))))
+    elif mode == 2:
+        for _ in range(int(rng.integers(1500, 5000))):
+            c = vec3(_f(rng.uniform(-12, 12)), _f(rng.uniform(-0.5, 8)), _f(rng.uniform(-30, -1.5)))
+            k = rng.integers(0, 3)
+            m = Material(vec3(_f(rng.uniform(0, 1)), _f(rng.uniform(0, 1)), _f(rng.uniform(0, 1))), 0.1, 0.95 if rng.random() < 0.1 else 0.0)
+            if k == 0: s.Add(Sphere(c, _f(rng.uniform(0.02, 0.4)), m))
+            elif k == 1: s.Add(Box(c, vec3(_f(c[0] + rng.uniform(0.02, 0.5)), _f(c[1] + rng.uniform(0.02, 0.5)), _f(c[2] + rng.uniform(0.02, 0.5))), Solid(m.Albedo), 0.0, 0.0))
+            else: s.Add(CylinderY(c, _f(rng.uniform(0.02, 0.3)), c[1], _f(c[1] + rng.uniform(0.02, 0.8)), True, m))
+    elif mode == 3:
+        cand = [o for o in s.Objects if isinstance(o, (Sphere, Box, CylinderY))]
+        o = cand[int(rng.integers(0, len(cand)))]
+        if isinstance(o, Sphere): pose["pos"] = tuple(o.Center)
+        elif isinstance(o, Box): pose["pos"] = tuple(_f((a + b) * 0.5) for a, b in zip(o.Min, o.Max))
+        else: pose["pos"] = (o.Center[0], _f((o.YMin + o.YMax) * 0.5), o.Center[2])
+    elif mode == 4:
+        c = lambda: vec3(_f(rng.uniform(-4, 4)), _f(rng.uniform(0, 3)), _f(rng.uniform(-12, -2)))
+        m = Material(vec3(0.7, 0.6, 0.5), 0.1, 0.0)
+        p = c(); s.Add(Triangle(p, p, c(), m))                       # zero area
+        p = c(); q = c(); mid = tuple(_f((a + b) * 0.5) for a, b in zip(p, q)); s.Add(Triangle(p, mid, q, m))      # collinear
+        s.Add(Sphere(c(), 0.0, m))
+        p = c(); s.Add(Box(p, vec3(p[0], _f(p[1] + 1), _f(p[2] + 1)), Solid(vec3(0.2, 0.9, 0.2)), 0.0, 0.0))       # flat box
+        p = c(); s.Add(Box(p, p, Solid(vec3(0.2, 0.9, 0.2)), 0.0, 0.0))                                                 # a point
+        p = c(); s.Add(CylinderY(p, 0.5, p[1], p[1], True, m))                                                          # zero height
+        p = c(); s.Add(XYRect(p[0], p[0], p[1], _f(p[1] + 1), p[2], Solid(vec3(0.9, 0.2, 0.2)), 0.0, 0.0))           # zero width
+        s.Add(Disk(c(), vec3(0, 1, 0), 0.0, Solid(vec3(0.9, 0.2, 0.2)), 0.0, 0.0))
+        s.Lights.append(PointLight(tuple(pose["pos"]), vec3(1, 1, 1), 30.0))                                           # a light AT the eye
+        if s.Objects and isinstance(s.Objects[0], Plane): s.Lights.append(PointLight(vec3(0.5, s.Objects[0].Point[1], -4.0), vec3(1, 1, 1), 30.0))   # a light IN the floor plane
+    elif mode == 6:
+        pool = [Texture(rng.integers(0, 256, shape, dtype=np.uint8)) for shape in ((1, 1, 3), (2, 3, 4), (32, 48, 4), (7, 5, 3))]
+        for o in s.Objects:
+            if rng.random() < 0.5 and not isinstance(o, VolumeGrid):
+                m = Material(vec3(_f(rng.uniform(0, 1)), _f(rng.uniform(0, 1)), _f(rng.uniform(0, 1))), _f(rng.uniform(0, 0.3)), 0.0,
+                             DiffuseTexture=pool[int(rng.integers(0, len(pool)))], TextureWeight=1.0 if rng.random() < 0.4 else _f(rng.uniform(0, 1)), UVScale=_f(rng.uniform(0.1, 6)))
+                if hasattr(o, "Mat"): o.Mat = m
+                else: o.MaterialFunc = m
+    elif mode == 7:
+        s.IsVolumeScene = True
+        n = int(rng.integers(8, 17)); vs = _f(rng.uniform(0.15, 0.4)); base = (_f(rng.uniform(-4, 0)), _f(rng.uniform(-1, 0)), _f(rng.uniform(-14, -6)))
+        for c in range(int(rng.integers(3, 9))):
+            cx, cz = c % 3, c // 3
+            cells = np.zeros((n, n, n, 2), np.int32)
+            height = rng.integers(1, n, (n, n))
+            solid = np.arange(n)[None, :, None] < height[:, None, :]
+            cells[..., 0] = np.where(solid & (rng.random((n, n, n)) < 0.9), rng.integers(1, 12, (n, n, n)), 0)
+            cells[..., 1] = rng.integers(0, 3, (n, n, n))
+            s.Add(VolumeGrid(cells, vec3(_f(base[0] + cx * n * vs), base[1], _f(base[2] + cz * n * vs)), vec3(vs, vs, vs), scenes.VoxelMaterialLookup, bool(rng.random() < 0.6), 0.06, 16.0))
+        for _ in range(2):
+            s.Lights.append(PointLight(vec3(_f(rng.uniform(-6, 6)), _f(rng.uniform(4, 12)), _f(rng.uniform(-14, 0))), vec3(1.0, 0.95, 0.9), _f(rng.uniform(40, 200))))
+    else:
+        k = np.float32([1e-2, 1e2, 1e3][seed // 8 % 3])
+        sc3 = lambda v: tuple(_f(np.float32(x) * k) for x in v)
+        for o in s.Objects:
+            for fld in dataclasses.fields(o):
+                v = getattr(o, fld.name)
+                if fld.name in ("Center", "Point", "Min", "Max", "A", "B", "C", "MinCorner", "VoxelSize"): setattr(o, fld.name, sc3(v))
+                elif fld.name in ("Radius", "X0", "X1", "Y0", "Y1", "Z0", "Z1", "X", "Y", "Z", "YMin", "YMax"): setattr(o, fld.name, _f(np.float32(v) * k))
+                elif fld.name == "Triangles": setattr(o, fld.name, (v * k).astype(np.float32))
+        for l in s.Lights: l.Position = sc3(l.Position); l.Intensity = _f(np.float32(l.Intensity) * k * k)
+        pose["pos"] = sc3(pose["pos"])
+    return tag

@@ -431,14 +431,18 @@ def test_whole_pixel_path_against_python_restatement():
             assert set(np.unique(p["prim"])) >= {0, 1, 2, 3}                         # floor, diffuse, mirror and glass spheres are all seen
 
 
-def _check_frames_against_restatement(scene, fbw, fbh, pose, frames, need_objects):
+def _check_frames_against_restatement(scene, fbw, fbh, pose, frames, need_objects, bvh=False):
+    """bvh: the restatement answers Scene.Hit through ITS OWN restated tree (builder + walk) instead of the brute-force loop - needed wherever
+    an object's bounds do not cover what its Hit accepts (a tilted Disk: the reference bounds it by a cube of its radius, Surfaces.cs:97-105,
+    and tests the radius in x and z only, :108-142 - the tree then never reaches hits a loop over all objects finds) or two hits tie."""
     import py_restatement as pr
     taa = {}
+    scene_for_pr = pr.BvhScene(scene) if bvh else scene
     with ob.OracleRenderer(scene, fbw, fbh, 1, pose) as o:
         seen = set()
         for frame in range(1, frames + 1):
             o.render(stages=1)
-            p = pr.render_frame(o.L, scene, o.hiW, o.hiH, pose, frame)
+            p = pr.render_frame(o.L, scene_for_pr, o.hiW, o.hiH, pose, frame)
             for name, which, key in (("rays", abi.BUF_RAYS, "rays"), ("radiance", abi.BUF_CURRENT_HDR, "hdr"), ("albedo", abi.BUF_G_ALBEDO, "albedo"),
                                      ("normal", abi.BUF_G_NORMAL, "normal"), ("depth", abi.BUF_G_DEPTH, "depth")):
                 a, b = o.read(which), np.ascontiguousarray(p[key], f32)
@@ -468,6 +472,36 @@ def test_every_analytic_primitive_and_taa_against_python_restatement():
     s.Lights.append(PointLight(vec3(-1.5, 3.0, -0.5), vec3(1.0, 0.95, 0.9), 50.0))
     pose = dict(pos=(0.0, 1.1, 0.8), yaw=-0.03, pitch=-0.12, fov=60.0)
     _check_frames_against_restatement(s, 16, 6, pose, 3, {0, 1, 2, 3, 4, 5, 6})
+
+
+@pytest.mark.parametrize("seed", list(range(1, 17)))
+def test_drawn_scenes_against_python_restatement(seed):
+    """tests/random_scenes.py (the draws the HIP path is held to in tests/test_gpu_random_scenes.py), shrunk to what pure Python walks in a
+    second: 12 - 40 objects of every Hittable class incl. one small mesh and sometimes a voxel volume, every material branch, duplicated spheres
+    and boxes sharing a face (ties), 0 - 4 lights.  The oracle against the second restatement - its own tree builder, walk and per-class bounds -
+    over two frames incl. TemporalBlendWithClamp: rays, primary hit, radiance, G-buffer, sky mask, RNG state, history, bit for bit."""
+    import random_scenes
+    s, pose = random_scenes.random_scene(seed, n_range=(12, 40), mesh_nu=(5, 9), mesh_nv=(3, 5), max_meshes=1)
+    _check_frames_against_restatement(s, 12, 5, pose, 2, set(), bvh=True)
+
+
+def test_a_tilted_disk_is_missed_by_the_tree_as_in_the_reference():
+    """A quirk the drawn scenes found (it is the REFERENCE's, and the oracle keeps it): Disk.TryGetBounds is a cube of the radius around the
+    centre (Surfaces.cs:97-105) while Disk.Hit tests the radius in x and z only (:119-121) - on a steep disk the accepted
+    points reach far above and below that cube, and Scene.Hit, which only ever goes through the tree (Scene.cs:71-76), never tries them.
+    The oracle's tree walk misses where its own brute-force loop (and a loop over Scene.Objects in any restatement) hits."""
+    s = Scene()
+    s.Add(Sphere(vec3(6.0, 0.0, -6.0), 0.5, Material(vec3(0.5, 0.5, 0.5), 0.0, 0.0, ZERO)))             # (two more objects: a tree with an inner node)
+    s.Add(Sphere(vec3(-6.0, 0.0, -6.0), 0.5, Material(vec3(0.5, 0.5, 0.5), 0.0, 0.0, ZERO)))
+    s.Add(Disk(vec3(0.0, 0.0, -5.0), vec3(0.0, 0.05, 1.0), 1.0, Solid(vec3(0.8, 0.2, 0.2)), 0.0, 0.0))   # nearly vertical: y = -20 (z + 5) on the plane
+    pose = dict(pos=(0.0, 0.0, 0.0), yaw=0.0, pitch=0.0, fov=45.0)
+    with ob.OracleRenderer(s, 4, 2, 1, pose) as o:
+        inside = o.scene_hit((0.0, 0.0, 0.0), (0.0, 0.0, -1.0))             # through the centre: inside the cube, found by both
+        assert inside[0] == 1.0 and inside[1] == 2.0 and o.scene_hit((0.0, 0.0, 0.0), (0.0, 0.0, -1.0), brute=True)[1] == 2.0
+        d = np.float32([0.0, 4.0, -4.8]); d = d / np.float32(np.sqrt(np.float32(d @ d)))
+        tree, loop = o.scene_hit((0.0, 0.0, 0.0), d), o.scene_hit((0.0, 0.0, 0.0), d, brute=True)
+        assert loop[0] == 1.0 and loop[1] == 2.0, "x, z within the radius: Disk.Hit accepts the point 4 above the centre"
+        assert tree[0] == 0.0, "... and the tree, whose box for the disk ends 1 above the centre, never asks"
 
 
 def test_voxel_grid_walk_against_python_restatement():
