@@ -341,3 +341,46 @@ def run_mesh_viewer(oracle, seed, log=print):
 def test_random_mesh_viewers(product_lib, oracle, path, seed):
     found = run_mesh_viewer(oracle, seed)
     assert not found, found
+
+
+# ---- the one call that may come from another thread ------------------------------------------------------------------------------------------------
+def test_set_camera_from_another_thread_never_tears_a_frame(product_lib, oracle, path):
+    """include/ycge.h: calls on a context come from one thread EXCEPT ycge_set_camera, which is safe against a concurrent ycge_render_frame - the
+    reference takes `lock (camLock)` on both sides (RaytraceRenderer.cs:142-147, 159-166: the input thread moves the camera while the terminal
+    loop renders).  A second thread flips the camera between two poses that differ in every component as fast as it can while 150 frames are
+    rendered: every frame's rays are - bit for bit - the oracle's rays of that frame number for ONE of the two poses, never a mixture, and both
+    poses turn up."""
+    import threading
+    s, pose_a = random_scene(4)
+    pose_b = dict(pos=tuple(_f(c + 1.25) for c in pose_a["pos"]), yaw=_f(pose_a["yaw"] + 0.7), pitch=_f(pose_a["pitch"] - 0.2), fov=_f(pose_a["fov"] + 11.0))
+    flat = flatten(s)
+    o = oracle.OracleRenderer(s, 16, 4, 1, pose_a, flat=flat)
+    g = RaytraceRenderer(flat, 16, 4, pose_a["fov"], 1, capture_debug=True)
+    g.SetCamera(pose_a["pos"], pose_a["yaw"], pose_a["pitch"])
+    stop = threading.Event()
+    L, ctx = g.L, g.ctx
+    pa, pb = (C.c_float * 3)(*pose_a["pos"]), (C.c_float * 3)(*pose_b["pos"])
+
+    def flip():          # (ctypes drops the GIL for the length of a foreign call: the two threads really are inside the library at once)
+        while not stop.is_set():
+            L.ycge_set_camera(ctx, pa, pose_a["yaw"], pose_a["pitch"], pose_a["fov"])
+            L.ycge_set_camera(ctx, pb, pose_b["yaw"], pose_b["pitch"], pose_b["fov"])
+
+    th = threading.Thread(target=flip, daemon=True)
+    th.start()
+    seen = [0, 0]
+    try:
+        for frame in range(1, 151):
+            g._check(L.ycge_render_frame(ctx, None, C.byref(g.stats)))
+            rays = g.read(abi.BUF_RAYS)
+            want = []
+            for pz in (pose_a, pose_b):
+                o.set_frame_counter(frame - 1); o.set_camera(pz["pos"], pz["yaw"], pz["pitch"], pz["fov"]); o.render(stages=0)
+                want.append(o.read(abi.BUF_RAYS))
+            which = [pu.bits_equal(rays, w) for w in want]
+            assert any(which), f"frame {frame}: the rays are neither pose's - a torn camera snapshot (origin {rays[0, 0, :3]})"
+            seen[which.index(True)] += 1
+    finally:
+        stop.set(); th.join()
+    assert min(seen) > 0, f"one pose never turned up in 150 frames ({seen}): the second thread did not run beside the frames"
+    o.close(); g.close()
