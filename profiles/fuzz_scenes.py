@@ -1,8 +1,8 @@
 """Soak of tests/test_gpu_random_scenes.py: seeds lo .. hi - 1 of its two scene generators (plain, and pushed one way: glass-heavy, many lights,
 thousands of objects, camera inside an object, degenerate objects, scaled by 1e-2 .. 1e3, textured, voxel chunks) on both device paths, two frames each, every buffer
-and counter against the oracle bit for bit; then its drawn CALL SEQUENCES (16 steps each; synchronous, then with frames in flight) its mesh viewers and its draws on 2 - 8 emulated ranks (both tiled forms).  Prints the frames that differ and a total; exit status 1 if there is one.
+and counter against the oracle bit for bit; then its drawn CALL SEQUENCES (16 steps each; synchronous, then with frames in flight) its drawn renderer constants, its mesh viewers and its draws on 2 - 8 emulated ranks (both tiled forms).  Prints the frames that differ and a total; exit status 1 if there is one.
 
-    gpurun -- python profiles/fuzz_scenes.py 100 500        (round 6: 45 040 frames over seeds 0 .. 1399, none differs - profiles/r06/g_fuzz_scenes.txt)
+    gpurun -- python profiles/fuzz_scenes.py 100 500        (round 6: 54 840 frames over seeds 0 .. 1499, none differs - profiles/r06/g_fuzz_scenes.txt)
 """
 import os
 import sys
@@ -52,6 +52,14 @@ for flight in (False, True):          # (True: through ycge_render_frame_async /
             for label, bad in found:
                 print("MISMATCH", path, "in flight" if flight else "", label, bad, flush=True)
         print(f"call sequences{' with frames in flight' if flight else ''}, {path}: seeds {lo}..{hi - 1} done; {n_bad} of {n_frames} frames differ so far", flush=True)
+for path in ("wavefront", "megakernel"):          # drawn renderer constants (ycge_config), five frames each, every other one through the post stage
+    os.environ["YCGE_PATH"] = path
+    for seed in range(lo, hi):
+        found = T.run_drawn_config(ob, seed, log=lambda *a: None)
+        n_frames += 5; n_bad += len(found)
+        for label, bad in found:
+            print("MISMATCH", path, label, bad, flush=True)
+    print(f"drawn renderer constants, {path}: seeds {lo}..{hi - 1} done; {n_bad} of {n_frames} frames differ so far", flush=True)
 for path in ("wavefront", "megakernel"):          # mesh viewers (the flat single-launch kernels' scenes), counting and timed kernel instances
     os.environ["YCGE_PATH"] = path
     for seed in range(lo, hi):

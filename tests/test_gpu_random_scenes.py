@@ -343,6 +343,74 @@ def test_random_mesh_viewers(product_lib, oracle, path, seed):
     assert not found, found
 
 
+# ---- the renderer's constants ------------------------------------------------------------------------------------------------------------------------
+def drawn_config(seed):
+    """ycge_config with the constants of RaytraceRenderer.cs:31-43, 65, 218, 221-227 DRAWN instead of defaulted (the three the library fixes -
+    diffuse bounces 1, mirror bounces 2, refractions 2: they size TraceFull's path stack - stay)."""
+    rng = np.random.default_rng(91_000 + seed)
+    u = lambda lo, hi: _f(rng.uniform(lo, hi))
+    c = abi.default_config()
+    c.mirror_threshold = u(0.3, 0.99)
+    c.eps = _f(10.0 ** rng.uniform(-5.5, -2.5))
+    c.seed_salt = int(rng.integers(0, 1 << 63)) * 2 + int(rng.integers(0, 2))
+    c.taa_alpha = u(0.005, 1.0)
+    c.motion_trans_reset = _f(10.0 ** rng.uniform(-4, -1))
+    c.motion_rot_reset = _f(10.0 ** rng.uniform(-4, -1))
+    c.diffuse_sigma_deg = u(0.0, 80.0)
+    c.taa_clamp_radius = int(rng.integers(0, 4))
+    c.taa_luminance_pad = u(0.0, 0.6)
+    c.atrous_iterations = int(rng.integers(0, 6))
+    c.atrous_c_phi, c.atrous_n_phi, c.atrous_z_phi, c.atrous_a_phi = u(0.2, 8.0), u(0.05, 1.5), u(0.2, 6.0), u(0.02, 1.0)
+    return c
+
+
+def _copy_config(c):
+    d = abi.Config()
+    C.memmove(C.byref(d), C.byref(c), C.sizeof(c))
+    return d
+
+
+def run_drawn_config(oracle, seed, log=print):
+    """A drawn scene under a drawn ycge_config, five frames of a camera that moves by amounts around the DRAWN reset thresholds, every other frame
+    through the post stage (the drawn iteration count and phis, iteration 1 in place).  Returns the differences found."""
+    rng = np.random.default_rng(92_000 + seed)
+    s, pose = random_scene(seed)
+    w, h, ss = SEQ_SIZES[seed % len(SEQ_SIZES)]
+    cfg = drawn_config(seed)
+    flat = flatten(s)
+    o = oracle.OracleRenderer(s, w, h, ss, pose, cfg=_copy_config(cfg), flat=flat)
+    g = RaytraceRenderer(flat, w, h, pose["fov"], ss, cfg=_copy_config(cfg), capture_debug=True, count_work=True)
+    found = []
+    for f in range(5):
+        k = float(cfg.motion_trans_reset) * [0.0, 0.5, 1.5, 0.9, 3.0][f]
+        pose = dict(pose, pos=(_f(pose["pos"][0] + k), pose["pos"][1], pose["pos"][2]), yaw=_f(pose["yaw"] + float(cfg.motion_rot_reset) * [0.0, 0.5, 0.0, 1.2, 0.3][f]))
+        o.set_camera(pose["pos"], pose["yaw"], pose["pitch"], pose["fov"]); g.SetCamera(pose["pos"], pose["yaw"], pose["pitch"])
+        with_sdr = f % 2 == 1
+        label = f"drawn config {seed} frame {f}{' SDR' if with_sdr else ''} (threshold {float(cfg.mirror_threshold):.2f}, eps {float(cfg.eps):.1e}, alpha {float(cfg.taa_alpha):.3f}, sigma {float(cfg.diffuse_sigma_deg):.0f}, clamp radius {cfg.taa_clamp_radius}, {cfg.atrous_iterations} iterations)"
+        if with_sdr:
+            so = o.render(stages=2, threads=8, want_sdr=True); sg = g.TryFlipAndBlit(want_sdr=True)
+        else:
+            o.render(stages=1, threads=8); g.TryFlipAndBlit()
+        st = pu.compare_frame(o, g)
+        bad = {k_: v for k_, v in st.items() if k_.endswith("_mismatch") and v}
+        bad.update({k_: st[k_] for k_ in ("n_rays", "n_box", "n_tri", "n_prim", "n_vox") if st[k_][0] != st[k_][1]})
+        if int(o.stats.history_reset) != int(g.stats.history_reset): bad["history_reset"] = (int(o.stats.history_reset), int(g.stats.history_reset))
+        if with_sdr:
+            if pu.mismatch_count(o.read(abi.BUF_DENOISED), g.read(abi.BUF_DENOISED)): bad["denoised"] = pu.mismatch_count(o.read(abi.BUF_DENOISED), g.read(abi.BUF_DENOISED))
+            if np.float32(o.stats.exposure).view(np.uint32) != np.float32(g.stats.exposure).view(np.uint32): bad["exposure"] = (float(o.stats.exposure), float(g.stats.exposure))
+            if pu.mismatch_count(so, sg): bad["sdr"] = pu.mismatch_count(so, sg)
+        log(label, "reset", int(g.stats.history_reset), "DIFFERS " + repr(bad) if bad else "equal")
+        if bad: found.append((label, bad))
+    o.close(); g.close()
+    return found
+
+
+@pytest.mark.parametrize("seed", [1, 2, 3, 4, 5, 6, 7, 8])
+def test_drawn_renderer_constants(product_lib, oracle, path, seed):
+    found = run_drawn_config(oracle, seed)
+    assert not found, found
+
+
 # ---- the one call that may come from another thread ------------------------------------------------------------------------------------------------
 def test_set_camera_from_another_thread_never_tears_a_frame(product_lib, oracle, path):
     """include/ycge.h: calls on a context come from one thread EXCEPT ycge_set_camera, which is safe against a concurrent ycge_render_frame - the
