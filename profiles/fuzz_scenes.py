@@ -18,6 +18,29 @@ import test_gpu_random_scenes as T   # noqa: E402
 
 lo, hi = int(sys.argv[1]), int(sys.argv[2])
 SIZES = [(160, 45, 1), (97, 31, 1), (64, 20, 2), (200, 60, 1)]
+if len(sys.argv) > 3 and sys.argv[3] == "large":          # the drawn scenes (plain and pushed) at BASELINE's frame sizes, two frames each, then stop: a few seeds take minutes of oracle time
+    import time
+    n_bad = 0
+    for pushed in (False, True):
+        for path in ("wavefront", "megakernel"):
+            os.environ["YCGE_PATH"] = path
+            for seed in range(lo, hi):
+                s, pose = T.random_scene(seed)
+                tag = T.harden(s, pose, seed) if pushed else "plain"
+                w, h, ss = [(1920, 540, 1), (960, 270, 2)][seed % 2]
+                t0 = time.time()
+                o, g = pu.run_pair(ob, s, w, h, ss, pose, frames=1)
+                for f in range(2):
+                    if f:
+                        o.render(stages=1, threads=32); g.TryFlipAndBlit()
+                    st = pu.compare_frame(o, g)
+                    bad = {k: v for k, v in st.items() if k.endswith("_mismatch") and v}
+                    bad.update({k: st[k] for k in ("n_rays", "n_box", "n_tri", "n_prim", "n_vox") if st[k][0] != st[k][1]})
+                    n_bad += bool(bad)
+                    print(path, "seed", seed, tag, f"{w}x{h} ss {ss}", "frame", f, len(s.Objects), "objects", int(g.stats.n_rays), "rays", f"trace {float(g.stats.trace_ms):.3f} ms",
+                          "DIFFERS " + repr(bad) if bad else "equal", f"({time.time() - t0:.0f} s)", flush=True)
+                o.close(); g.close()
+    sys.exit(1 if n_bad else 0)
 n_frames = n_bad = 0
 for pushed in (False, True):
     for path in ("wavefront", "megakernel"):
