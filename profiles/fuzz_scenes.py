@@ -18,6 +18,17 @@ import test_gpu_random_scenes as T   # noqa: E402
 
 lo, hi = int(sys.argv[1]), int(sys.argv[2])
 SIZES = [(160, 45, 1), (97, 31, 1), (64, 20, 2), (200, 60, 1)]
+if len(sys.argv) > 3 and sys.argv[3] == "poison":          # values no scene should hold: what equals the oracle's and what merely survives (tests/test_gpu_random_scenes.py)
+    for values, what in (("all", "lights"), ("all", "materials"), ("tame", "geometry"), (1e9, "geometry"), (1e17, "geometry"), (1e19, "geometry"), (1e30, "geometry"),
+                         (3.4028234663852886e38, "geometry"), (float("inf"), "geometry"), (float("nan"), "geometry")):
+        n_frames = n_bad = 0
+        for path in ("wavefront", "megakernel"):
+            os.environ["YCGE_PATH"] = path
+            for seed in range(lo, hi):
+                found, n = T.run_poisoned(ob, seed, values, what, log=lambda *a: None)
+                n_frames += n; n_bad += len(found)
+        print(f"poisoned {what}, values {values}: {n_bad} of {n_frames} frames differ from the oracle's somewhere (every one was rendered)", flush=True)
+    sys.exit(0)
 if len(sys.argv) > 3 and sys.argv[3] == "large":          # the drawn scenes (plain and pushed) at BASELINE's frame sizes, two frames each, then stop: a few seeds take minutes of oracle time
     import time
     n_bad = 0

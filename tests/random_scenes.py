@@ -175,3 +175,47 @@ def harden(s, pose, seed):
         for l in s.Lights: l.Position = sc3(l.Position); l.Intensity = _f(np.float32(l.Intensity) * k * k)
         pose["pos"] = sc3(pose["pos"])
     return tag
+
+
+# ---- values no scene should hold ------------------------------------------------------------------------------------------------------------------
+POISON_VALUES = {"all": [float("nan"), float("inf"), float("-inf"), 1e30, -1e30, 1e-40, -0.0, 3.4028234663852886e38],
+                 "tame": [1e-40, -1e-40, 1e-20, -0.0, 1e9, -1e9],          # denormals, signed zero, large but nowhere near overflow
+                 "wild": [float("nan"), float("inf"), float("-inf"), 1e30, -1e30, 3.4028234663852886e38, 1e19]}
+
+
+def poison(s, pose, seed, values="all", what="all"):
+    """Writes a few values from POISON_VALUES[values] (or the one float given) into the drawn scene: `what` = "geometry" (1 - 4 coordinates, radii,
+    extents of random objects), "lights" (an intensity or a position), "materials" (an albedo, index of refraction 0 / negative / poisoned,
+    transparency or reflectivity out of range), or "all".  Returns what was touched."""
+    vals = POISON_VALUES[values] if isinstance(values, str) else [float(values)]
+    rng = np.random.default_rng(66_000 + seed)
+    pick = lambda: vals[int(rng.integers(0, len(vals)))]
+    tags = []
+    for _ in range(int(rng.integers(1, 5)) if what in ('all', 'geometry') else 0):
+        o = s.Objects[int(rng.integers(0, len(s.Objects)))]
+        fields = [f.name for f in dataclasses.fields(o) if f.name in ("Center", "Point", "Normal", "Min", "Max", "A", "B", "C", "Radius", "X0", "X1", "Y0", "Y1", "Z0", "Z1", "X", "Y", "Z", "YMin", "YMax")]
+        if not fields: continue
+        f = fields[int(rng.integers(0, len(fields)))]
+        v = getattr(o, f)
+        if isinstance(v, tuple):
+            v = list(v); v[int(rng.integers(0, 3))] = pick(); setattr(o, f, tuple(v))
+        else:
+            setattr(o, f, pick())
+        tags.append(f"{type(o).__name__}.{f}")
+    if (rng.random() < 0.3 or what == 'lights') and s.Lights and what in ('all', 'lights'):
+        l = s.Lights[int(rng.integers(0, len(s.Lights)))]
+        if rng.random() < 0.5: l.Intensity = pick()
+        else: p = list(l.Position); p[int(rng.integers(0, 3))] = pick(); l.Position = tuple(p)
+        tags.append("light")
+    if (rng.random() < 0.3 or what == 'materials') and what in ('all', 'materials'):
+        cand = [o for o in s.Objects if hasattr(o, "Mat")]
+        if cand:
+            o = cand[int(rng.integers(0, len(cand)))]
+            m = o.Mat
+            k = int(rng.integers(0, 4))
+            if k == 0: m.Albedo = (pick(), m.Albedo[1], m.Albedo[2])
+            elif k == 1: m.IndexOfRefraction = [0.0, -1.0, pick()][int(rng.integers(0, 3))]; m.Transparency = 0.7
+            elif k == 2: m.Transparency = [2.0, -0.5, pick()][int(rng.integers(0, 3))]
+            else: m.Reflectivity = [5.0, pick()][int(rng.integers(0, 2))]
+            tags.append("material")
+    return tags

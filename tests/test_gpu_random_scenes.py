@@ -29,7 +29,7 @@ def path(request, monkeypatch):
     return request.param
 
 
-from random_scenes import HARD_MODES, _f, harden, random_scene      # noqa: E402,F401  (the generators: tests/random_scenes.py)
+from random_scenes import HARD_MODES, _f, harden, poison, random_scene      # noqa: E402,F401  (the generators: tests/random_scenes.py)
 
 
 def _frames_equal(oracle, s, pose, size, label, frames=3):
@@ -452,3 +452,74 @@ def test_set_camera_from_another_thread_never_tears_a_frame(product_lib, oracle,
         stop.set(); th.join()
     assert min(seen) > 0, f"one pose never turned up in 150 frames ({seen}): the second thread did not run beside the frames"
     o.close(); g.close()
+
+
+# ---- values no scene should hold --------------------------------------------------------------------------------------------------------------------
+def nan_aware_mismatches(a, b):
+    """elements that differ, every NaN counting as equal to every other NaN (x86 and the GPU hand out different default NaNs)"""
+    a = np.ascontiguousarray(a); b = np.ascontiguousarray(b)
+    if a.dtype.kind != "f": return int(np.count_nonzero(a != b))
+    na, nb = np.isnan(a), np.isnan(b)
+    return int(np.count_nonzero(na != nb) + np.count_nonzero((a.view(np.uint32) != b.view(np.uint32)) & ~na & ~nb))
+
+
+def run_poisoned(oracle, seed, values, what, log=print):
+    """A drawn scene with a few poisoned values (random_scenes.poison), two frames.  Returns (differences, frames rendered): the library must take
+    the scene and finish its frames whatever the values; what of it must EQUAL the oracle's is the callers' business."""
+    s, pose = random_scene(seed, n_range=(20, 120))
+    tags = poison(s, pose, seed, values, what)
+    flat = flatten(s)
+    o = oracle.OracleRenderer(s, 97, 31, 1, pose, flat=flat)
+    g = RaytraceRenderer(flat, 97, 31, pose["fov"], 1, capture_debug=True, count_work=True)
+    g.SetCamera(pose["pos"], pose["yaw"], pose["pitch"])
+    found = []
+    for f in range(2):
+        o.render(stages=1, threads=8); g.TryFlipAndBlit()
+        bad = {}
+        for name, which in (("rays", abi.BUF_RAYS), ("prim_id", abi.BUF_PRIM_ID), ("sub_id", abi.BUF_SUB_ID), ("hit_t", abi.BUF_HIT_T), ("rng_state", abi.BUF_RNG_STATE),
+                            ("current_hdr", abi.BUF_CURRENT_HDR), ("g_albedo", abi.BUF_G_ALBEDO), ("g_normal", abi.BUF_G_NORMAL), ("g_depth", abi.BUF_G_DEPTH),
+                            ("sky", abi.BUF_SKY_MASK), ("taa_history", abi.BUF_TAA_HISTORY)):
+            n = nan_aware_mismatches(o.read(which), g.read(which))
+            if n: bad[name] = n
+        for k in ("n_rays", "n_box", "n_tri", "n_prim", "n_vox"):
+            if int(getattr(o.stats, k)) != int(getattr(g.stats, k)): bad[k] = (int(getattr(o.stats, k)), int(getattr(g.stats, k)))
+        label = f"poisoned {seed} ({values}, {what}: {tags}) frame {f}, NaN in {int(np.isnan(o.read(abi.BUF_CURRENT_HDR)).any(-1).sum())} pixels"
+        log(label, "DIFFERS " + repr(bad) if bad else "equal")
+        if bad: found.append((label, bad))
+    o.close(); g.close()
+    return found, 2
+
+
+@pytest.mark.parametrize("values,what", [("all", "lights"), ("all", "materials"), ("tame", "geometry")])
+def test_poisoned_lights_materials_and_tame_geometry_equal_the_oracle(product_lib, oracle, path, values, what):
+    """What IS held bit for bit (NaN for NaN) beyond sane scenes: lights and materials with NaN, +-inf, 1e30, FLT_MAX, denormals, -0.0 in them -
+    an intensity, a position, an albedo, an index of refraction of 0 or below, transparency / reflectivity out of range - and GEOMETRY with
+    denormal, signed-zero and 1e9 coordinates."""
+    for seed in range(12):
+        found, _ = run_poisoned(oracle, seed, values, what)
+        assert not found, found
+
+
+def test_wild_geometry_is_survived(product_lib, oracle, path):
+    """What is NOT held, and says so: geometry with NaN, +-inf or coordinates whose squares overflow binary32 (>= 1e17 was seen
+    to matter).  The trees are still the reference's (the builders follow it through inf and NaN, bit for bit) - but a NaN discriminant makes a NaN
+    `t` that the reference's comparisons then ACCEPT as the closest hit, and from there every `t < closest` goes the way the C# happens to be
+    written; the kernels' fast forms (hardware min / max in the slab test of a ray with finite reciprocals, ycge_rt.hip.h: box_scene) assume finite
+    boxes.  A measured 25-70 % of such frames differ somewhere (profiles/r06/g_fuzz_scenes.txt).  What the library owes such a scene: it takes
+    it, renders, returns - no fault, no hang, no error - and rays and RNG state, which no geometry touches, still equal the oracle's."""
+    n_diff = 0
+    for seed in range(24):
+        s, pose = random_scene(seed, n_range=(20, 120))
+        poison(s, pose, seed, "wild", "geometry")
+        flat = flatten(s)
+        o = oracle.OracleRenderer(s, 97, 31, 1, pose, flat=flat)
+        g = RaytraceRenderer(flat, 97, 31, pose["fov"], 1, capture_debug=True)
+        g.SetCamera(pose["pos"], pose["yaw"], pose["pitch"])
+        for f in range(2):
+            o.render(stages=1, threads=8); g.TryFlipAndBlit()
+            assert pu.bits_equal(o.read(abi.BUF_RAYS), g.read(abi.BUF_RAYS))
+            n_diff += bool(nan_aware_mismatches(o.read(abi.BUF_CURRENT_HDR), g.read(abi.BUF_CURRENT_HDR)))
+        sdr = g.TryFlipAndBlit(want_sdr=True)          # ... and the post stage finishes on whatever TAA left (NaN radiance included)
+        assert sdr.shape == (31, 97, 2, 3)
+        o.close(); g.close()
+    print(f"wild geometry: radiance differs somewhere in {n_diff} of 48 frames")
