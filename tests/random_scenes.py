@@ -94,19 +94,20 @@ def random_scene(seed: int, n_range=(30, 260), ties=True, mesh_nu=(12, 70), mesh
     return s, pose
 
 
-HARD_MODES = ["glass-heavy", "many-lights", "many-objects", "camera-inside", "degenerate", "scaled", "textured", "voxel-chunks"]
+HARD_MODES = ["glass-heavy", "many-lights", "many-objects", "camera-inside", "degenerate", "scaled", "textured", "voxel-chunks", "triangle-materials"]
 
 
 def harden(s, pose, seed):
-    """random_scene(seed) pushed one way (seed % 8): most materials glass of random index (the 16-entry path stack and the transmittance walk,
+    """random_scene(seed) pushed one way (seed % 9): most materials glass of random index (the 16-entry path stack and the transmittance walk,
     RaytraceRenderer.cs:439-446, 757-798); 4 - 12 more lights; 1 500 - 5 000 more small objects (a deep top-level tree, the device builder's
     large-input path); the camera INSIDE a sphere / box / cylinder; degenerate objects (zero-area and collinear triangles, radius 0, flat and
     point boxes, a zero-height cylinder, a zero-width rectangle, a light at the eye and one in the floor plane); everything scaled by 1e-2 /
     1e2 / 1e3 (tMin = 0.001 and the 1e-4 / 1e-6 epsilons of the hit routines against other magnitudes); static textures of several sizes, weights
     and UV scales on half the objects (SampleAlbedo, RaytraceRenderer.cs:724-735, Texture.cs:142-163); a VolumeScene of 3 - 8 voxel chunks side by
-    side with lit lights (VolumeGrid.cs:99-231, the binary transmittance of RaytraceRenderer.cs:761).  Returns the mode's name."""
+    side with lit lights (VolumeGrid.cs:99-231, the binary transmittance of RaytraceRenderer.cs:761); every mesh (and two more, larger ones) with a
+    material PER TRIANGLE out of a palette of every kind - the ABI's `ycge_mesh.tri_material`.  Returns the mode's name."""
     rng = np.random.default_rng(10_000 + seed)
-    mode = seed % 8
+    mode = seed % 9
     tag = HARD_MODES[mode]
     if mode == 0:
         for o in s.Objects:
@@ -163,8 +164,22 @@ def harden(s, pose, seed):
             s.Add(VolumeGrid(cells, vec3(_f(base[0] + cx * n * vs), base[1], _f(base[2] + cz * n * vs)), vec3(vs, vs, vs), scenes.VoxelMaterialLookup, bool(rng.random() < 0.6), 0.06, 16.0))
         for _ in range(2):
             s.Lights.append(PointLight(vec3(_f(rng.uniform(-6, 6)), _f(rng.uniform(4, 12)), _f(rng.uniform(-14, 0))), vec3(1.0, 0.95, 0.9), _f(rng.uniform(40, 200))))
+    elif mode == 8:
+        tex = Texture(rng.integers(0, 256, (8, 8, 4), dtype=np.uint8))
+        palette = [Material(vec3(0.9, 0.2, 0.2), 0.1, 0.0), Material(vec3(0.95, 0.95, 0.95), 0.0, 0.95), Material(vec3(0.3, 0.5, 0.9), 0.3, 0.5),
+                   Material(vec3(1, 1, 1), 0.0, 0.05, ZERO, 0.85, 1.45, vec3(0.8, 1.0, 0.85)), Material(vec3(0.1, 0.1, 0.1), 0.0, 0.0, vec3(1.5, 1.2, 0.6)),
+                   Material(vec3(1, 1, 1), 0.1, 0.0, DiffuseTexture=tex, UVScale=2.0)]
+        for _ in range(2):
+            pos, faces = scenes.make_torus_knot(int(rng.integers(40, 160)), int(rng.integers(8, 24)), seed=int(rng.integers(1, 1 << 20)))
+            c = np.array([rng.uniform(-3, 3), rng.uniform(0.5, 2.5), rng.uniform(-9, -3)], np.float32)
+            s.Add(Mesh((pos[faces] * np.float32(rng.uniform(0.5, 1.2)) + c).astype(np.float32), palette[0]))
+        for o in s.Objects:
+            if isinstance(o, Mesh):
+                n = len(np.asarray(o.Triangles).reshape(-1, 9))
+                o.TriMaterials = palette
+                o.TriMaterialIndex = rng.integers(0, len(palette), n) if rng.random() < 0.5 else (np.arange(n) // max(1, n // 12)) % len(palette)
     else:
-        k = np.float32([1e-2, 1e2, 1e3][seed // 8 % 3])
+        k = np.float32([1e-2, 1e2, 1e3][seed // 9 % 3])
         sc3 = lambda v: tuple(_f(np.float32(x) * k) for x in v)
         for o in s.Objects:
             for fld in dataclasses.fields(o):

@@ -198,9 +198,12 @@ class Triangle(Hittable):         # Objects/Triangle.cs:30-35
 
 @dataclass
 class Mesh(Hittable):             # RayTracing/Mesh.cs:16-21
-    """triangles: float32 array [n,3,3] (A,B,C per triangle), already transformed."""
+    """triangles: float32 array [n,3,3] (A,B,C per triangle), already transformed.  TriMaterials / TriMaterialIndex: the ABI's optional
+    per-triangle material (`ycge_mesh.tri_material`, include/ycge.h) - a palette of Materials and, per triangle, an index into it."""
     Triangles: np.ndarray
     Mat: Material
+    TriMaterials: Optional[List[Material]] = None
+    TriMaterialIndex: Optional[np.ndarray] = None
 
 
 @dataclass
@@ -301,6 +304,12 @@ class FlatScene:
                 m.n_triangles = tris.shape[0]
                 m.material = mat_id(o.Mat)
                 m.tri_material = None
+                if o.TriMaterials is not None:
+                    ids = np.array([mat_id(mm) for mm in o.TriMaterials], np.int32)
+                    tm = np.ascontiguousarray(ids[np.asarray(o.TriMaterialIndex, np.int64)], dtype=np.int32)
+                    assert tm.shape == (tris.shape[0],)
+                    self._keep.append(tm)
+                    m.tri_material = tm.ctypes.data_as(C.POINTER(C.c_int32))
                 prim(abi.PRIM_MESH, -1, [], ref=len(meshes))
                 meshes.append(m)
             elif isinstance(o, VolumeGrid):
