@@ -350,6 +350,35 @@ def test_random_mesh_viewers(product_lib, oracle, path, seed):
     assert not found, found
 
 
+def test_voxel_lookup_misses_take_the_default_material(product_lib, oracle, path):
+    """ycge_grid.default_material (include/ycge.h: the material of a (matId, metaId) pair the lookup does not list - the `default:` arm of the
+    reference's palette switch, VoxelMaterialPalette.cs:35-98): half of every grid's lookup entries are dropped and their voxels fall to a drawn
+    default; and with default_material < 0 such a voxel is an error from ycge_scene_upload, not a guess."""
+    s, pose = random_scene(7)
+    harden(s, pose, 7)          # voxel chunks
+    flat = flatten(s)
+    assert flat.struct.n_grids >= 3
+    dropped = 0
+    for i in range(flat.struct.n_grids):
+        g = flat.grids[i]
+        dropped += g.n_lookup - g.n_lookup // 2
+        g.n_lookup //= 2
+        g.default_material = i % flat.struct.n_materials
+    assert dropped >= 6
+    o = oracle.OracleRenderer(s, 160, 45, 1, pose, flat=flat)
+    g_ = RaytraceRenderer(flat, 160, 45, pose["fov"], 1, capture_debug=True, count_work=True)
+    g_.SetCamera(pose["pos"], pose["yaw"], pose["pitch"])
+    for f in range(2):
+        o.render(stages=1, threads=8); g_.TryFlipAndBlit()
+        st = pu.compare_frame(o, g_)
+        bad = {k: v for k, v in st.items() if k.endswith("_mismatch") and v}
+        assert not bad and int(g_.stats.n_vox) == int(o.stats.n_vox) > 1000, (f, bad)
+    flat.grids[0].default_material = -1
+    with pytest.raises(abi.YcgeError, match="no material for"):
+        g_.UploadScene(flat)
+    o.close(); g_.close()
+
+
 # ---- the renderer's constants ------------------------------------------------------------------------------------------------------------------------
 def drawn_config(seed):
     """ycge_config with the constants of RaytraceRenderer.cs:31-43, 65, 218, 221-227 DRAWN instead of defaulted (the three the library fixes -
