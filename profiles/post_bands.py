@@ -103,7 +103,8 @@ l60, l61 = tl[0, :, 3].astype(int), tl[1, :, 3].astype(int)
 # same-level offset: when band 61 starts level L vs band 60
 m60 = {int(l): t for l, t in zip(l60, t60) if t > 0}
 offs = [t - m60[int(l)] for l, t in zip(l61, t61) if t > 0 and int(l) in m60]
-print(f"band {PB+1} starts a level {np.median(offs):.2f} us (median) after band {PB} starts the same level; min {np.min(offs):.2f} max {np.max(offs):.2f}")
+if offs:          # (only the profiling instantiation records a timeline: YCGE_POST_PROBE_BAND)
+    print(f"band {PB+1} starts a level {np.median(offs):.2f} us (median) after band {PB} starts the same level; min {np.min(offs):.2f} max {np.max(offs):.2f}")
 big = [(int(bb + 1), round(float(x), 1)) for bb, x in enumerate(end_lag) if x > 40]
 print("end lags above 40 us (band, us):", big)
 print("end lag by band, every 8th:", [round(float(x), 1) for x in end_lag[::8]])
