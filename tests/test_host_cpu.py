@@ -25,6 +25,24 @@ def test_library_exports_every_declared_symbol(product_lib):
         assert hasattr(product_lib, name), name
 
 
+def test_every_other_export_is_listed_as_a_hook(product_lib):
+    """include/ycge_hooks.h: what the library exports BESIDE the boundary - test and profiling hooks, host-side builders, the functions that
+    cross from the host translation units into the kernel ones - is written down, prototype by prototype, and is all of it: `nm -D` of the
+    library = include/ycge.h + include/ycge_hooks.h + the kernel launchers (ycge_launch_*).  (ycge_debug_fail_allocation exists in the
+    fault-injection variant only.)"""
+    import subprocess
+    from yetanotherconsolegameengine_amd import build
+    out = subprocess.run(["nm", "-D", "--defined-only", str(build.LIB)], capture_output=True, text=True, check=True).stdout
+    exported = {ln.split()[-1] for ln in out.splitlines() if " T " in ln and ln.split()[-1].startswith("ycge_")}
+    boundary = set(re.findall(r"\b(ycge_[a-z0-9_]+)\s*\(", (ROOT / "include" / "ycge.h").read_text()))
+    hooks = set(re.findall(r"\b(ycge_[a-z0-9_]+)\s*\(", (ROOT / "include" / "ycge_hooks.h").read_text())) - {"ycge_debug_fail_allocation"}
+    launchers = {s for s in exported if s.startswith("ycge_launch_")}
+    assert not (boundary & hooks), boundary & hooks
+    assert exported - boundary - launchers == hooks, (sorted(exported - boundary - launchers - hooks), sorted(hooks - exported))
+    for name in hooks:
+        assert hasattr(product_lib, name), name
+
+
 def test_ctypes_mirror_matches_header_layout(product_lib):
     product_lib.ycge_abi_sizeof.restype = C.c_size_t
     product_lib.ycge_abi_sizeof.argtypes = [C.c_int32]
