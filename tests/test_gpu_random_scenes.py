@@ -379,6 +379,28 @@ def test_voxel_lookup_misses_take_the_default_material(product_lib, oracle, path
     o.close(); g_.close()
 
 
+@pytest.mark.parametrize("size", [(24, 7, 4), (17, 5, 5), (9, 4, 7), (8, 3, 8), (5, 2, 12), (1, 1, 16), (640, 2, 1), (2, 300, 1), (1, 1, 1), (3, 1, 2)])
+def test_unusual_sizes_and_supersampling_through_the_post_stage(product_lib, oracle, path, size):
+    """Super-sampling factors up to 16 (ToneMapper's box downsample over ss x 2 ss samples a half-cell, RaytraceRenderer.cs:229-264), consoles of one row,
+    one column, one cell: three frames of a drawn scene through TAA, the A-trous iterations (the in-place schedule of a 2-pixel-high grid), exposure
+    and tone map - every buffer, the exposure and the SDR cells equal the oracle's."""
+    w, h, ss = size
+    s, pose = random_scene(50 + w + ss)
+    flat = flatten(s)
+    o = oracle.OracleRenderer(s, w, h, ss, pose, flat=flat)
+    g = RaytraceRenderer(flat, w, h, pose["fov"], ss, capture_debug=True, count_work=True)
+    g.SetCamera(pose["pos"], pose["yaw"], pose["pitch"])
+    for f in range(3):
+        so = o.render(stages=2, threads=8, want_sdr=True); sg = g.TryFlipAndBlit(want_sdr=True)
+        st = pu.compare_frame(o, g)
+        bad = {k: v for k, v in st.items() if k.endswith("_mismatch") and v}
+        assert not bad, (size, f, bad)
+        assert pu.mismatch_count(o.read(abi.BUF_DENOISED), g.read(abi.BUF_DENOISED)) == 0, (size, f)
+        assert np.float32(o.stats.exposure).view(np.uint32) == np.float32(g.stats.exposure).view(np.uint32), (size, f)
+        assert pu.mismatch_count(so, sg) == 0, (size, f)
+    o.close(); g.close()
+
+
 # ---- the renderer's constants ------------------------------------------------------------------------------------------------------------------------
 def drawn_config(seed):
     """ycge_config with the constants of RaytraceRenderer.cs:31-43, 65, 218, 221-227 DRAWN instead of defaulted (the three the library fixes -
