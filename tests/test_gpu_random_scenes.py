@@ -401,6 +401,38 @@ def test_unusual_sizes_and_supersampling_through_the_post_stage(product_lib, ora
     o.close(); g.close()
 
 
+def test_the_exact_post_stage_says_where_it_ends(product_lib, oracle):
+    """The in-place A-trous iteration addresses its 300 bytes of static weights a pixel by 32-bit offsets: above 14.3 M pixels (or 65 535 a side) the
+    EXACT post stage refuses the frame - YCGE_ERR_UNSUPPORTED, a message that says why - instead of wrapping around; nothing else ends there.  On a
+    5120 x 2880 trace grid (14.7 M pixels; BASELINE's largest is 8.3 M): frames up to TAA equal the oracle's, the refusal leaves the context
+    usable, and the waived form (config.atrous_inplace_exact = 0) delivers its SDR frame."""
+    s = Scene()
+    s.Add(Sphere(vec3(0.0, 0.5, -3.0), 0.8, Material(vec3(0.8, 0.3, 0.2), 0.1, 0.0)))
+    s.Add(Plane(vec3(0, 0, 0), vec3(0, 1, 0), Checker(vec3(0.8, 0.8, 0.8), vec3(0.2, 0.2, 0.2), 1.0), 0.0, 0.0))
+    s.Lights.append(PointLight(vec3(2.0, 4.0, 0.0), vec3(1, 1, 1), 40.0))
+    pose = dict(pos=(0.0, 1.0, 1.0), yaw=0.0, pitch=-0.1, fov=50.0)
+    w, h, ss = 2560, 720, 2
+    flat = flatten(s)
+    o = oracle.OracleRenderer(s, w, h, ss, pose, flat=flat)
+    g = RaytraceRenderer(flat, w, h, pose["fov"], ss)
+    g.SetCamera(pose["pos"], pose["yaw"], pose["pitch"])
+    o.render(stages=1, threads=32); g.TryFlipAndBlit()
+    assert pu.mismatch_count(o.read(abi.BUF_TAA_HISTORY), g.read(abi.BUF_TAA_HISTORY)) == 0
+    with pytest.raises(abi.YcgeError, match="14.3 M pixels") as e:
+        g.TryFlipAndBlit(want_sdr=True)
+    assert e.value.status == abi.YCGE_ERR_UNSUPPORTED
+    g.set_frame_counter(1); o.set_frame_counter(1)                          # (the refused call may have counted a frame: both sides start the next one from the same number)
+    o.render(stages=1, threads=32); g.TryFlipAndBlit()                      # the context is none the worse for it
+    assert pu.mismatch_count(o.read(abi.BUF_CURRENT_HDR), g.read(abi.BUF_CURRENT_HDR)) == 0
+    o.close(); g.close()
+    cfg = abi.default_config(); cfg.atrous_inplace_exact = 0
+    g = RaytraceRenderer(flat, w, h, pose["fov"], ss, cfg=cfg)
+    g.SetCamera(pose["pos"], pose["yaw"], pose["pitch"])
+    sdr = g.TryFlipAndBlit(want_sdr=True)
+    assert sdr.shape == (h, w, 2, 3) and np.isfinite(sdr).all() and float(sdr.max()) > 0.2
+    g.close()
+
+
 # ---- the renderer's constants ------------------------------------------------------------------------------------------------------------------------
 def drawn_config(seed):
     """ycge_config with the constants of RaytraceRenderer.cs:31-43, 65, 218, 221-227 DRAWN instead of defaulted (the three the library fixes -
