@@ -433,6 +433,34 @@ def test_the_exact_post_stage_says_where_it_ends(product_lib, oracle):
     g.close()
 
 
+@pytest.mark.parametrize("what", ["lights", "meshes", "textures", "objects"])
+def test_counts_far_beyond_the_configurations(product_lib, oracle, path, what):
+    """300 lights (every diffuse vertex walks them all, RaytraceRenderer.cs:560-590), 600 meshes, 400 textures, 40 000 objects with a material each:
+    the arrays behind the scene records have no small fixed sizes.  Two frames, every buffer and counter against the oracle."""
+    rng = np.random.default_rng(5)
+    u = lambda lo, hi: _f(rng.uniform(lo, hi))
+    s, pose = random_scene(6)
+    size = (120, 34, 1)
+    if what == "lights":
+        for _ in range(300): s.Lights.append(PointLight(vec3(u(-8, 8), u(0.5, 9), u(-20, 4)), vec3(1, 1, 1), u(0, 5)))
+        size = (64, 20, 1)
+    elif what == "meshes":
+        for k in range(600):
+            pos, faces = scenes.make_torus_knot(int(rng.integers(6, 14)), int(rng.integers(4, 7)), seed=k + 1)
+            c = np.array([rng.uniform(-9, 9), rng.uniform(0, 6), rng.uniform(-24, -2)], np.float32)
+            s.Add(Mesh((pos[faces] * np.float32(0.3) + c).astype(np.float32), Material(vec3(u(0, 1), u(0, 1), u(0, 1)), 0.1, 0.95 if k % 7 == 0 else 0.0)))
+    elif what == "textures":
+        texs = [Texture(rng.integers(0, 256, (int(rng.integers(1, 9)), int(rng.integers(1, 9)), 4), dtype=np.uint8)) for _ in range(400)]
+        for k in range(400):
+            c = vec3(u(-9, 9), u(0, 6), u(-24, -2))
+            s.Add(XYRect(c[0], _f(c[0] + 0.8), c[1], _f(c[1] + 0.8), c[2], Material(vec3(1, 1, 1), DiffuseTexture=texs[k], UVScale=1.0), 0.0, 0.0))
+    else:
+        for k in range(40000):
+            s.Add(Sphere(vec3(u(-30, 30), u(0, 20), u(-80, -2)), u(0.05, 0.4), Material(vec3(u(0, 1), u(0, 1), u(0, 1)), 0.1, 0.0)))
+    o, g = _frames_equal(oracle, s, pose, size, f"{what} beyond the configurations", frames=2)
+    o.close(); g.close()
+
+
 # ---- the renderer's constants ------------------------------------------------------------------------------------------------------------------------
 def drawn_config(seed):
     """ycge_config with the constants of RaytraceRenderer.cs:31-43, 65, 218, 221-227 DRAWN instead of defaulted (the three the library fixes -
