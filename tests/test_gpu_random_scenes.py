@@ -8,7 +8,9 @@ accidents a drawn scene has that a designed one avoids: objects inside one anoth
 boxes sharing a face), slivers, objects behind the camera and around it.  Bar: every buffer bit for bit, counters equal, on both device paths,
 over a reset frame and two blended ones.
 """
+import copy
 import ctypes as C
+import os
 import dataclasses
 
 import numpy as np
@@ -111,12 +113,13 @@ def run_sequence(oracle, seed, steps=12, log=print, flight=False):
     u = lambda lo, hi: _f(rng.uniform(lo, hi))
     s, pose = random_scene(seed)
     w, h, ss = SEQ_SIZES[seed % len(SEQ_SIZES)]
-    flat = flatten(s)
+    flat = uploaded = flatten(s)
+    gone = []
     keep = [flat]                    # (the oracle and the library copy during the call; kept anyway until the contexts are gone)
     o = oracle.OracleRenderer(s, w, h, ss, pose, flat=flat)
     g = RaytraceRenderer(flat, w, h, pose["fov"], ss, capture_debug=not flight, count_work=not flight)     # (frames in flight keep neither debug captures nor counters)
     g.SetCamera(pose["pos"], pose["yaw"], pose["pitch"])
-    found, held, burst_left = [], [], 0
+    found, held, burst_left, lights_now = [], [], 0, None
     for step in range(steps):
         ops = []
         if rng.random() < 0.45:
@@ -137,17 +140,24 @@ def run_sequence(oracle, seed, steps=12, log=print, flight=False):
             for i, l in enumerate(lights):
                 arr[i].position, arr[i].color, arr[i].intensity = abi.Vec3(*l.Position), abi.Vec3(*l.Color), float(l.Intensity)
             a_, t_, b_ = abi.Vec3(*amb.Color), abi.Vec3(*top), abi.Vec3(*bot)
-            assert o.L.orc_scene_update_lights(o.ctx, arr, len(lights), C.byref(a_), float(amb.Intensity), C.byref(t_), C.byref(b_)) == 0
+            lights_now = (arr, len(lights), C.byref(a_), float(amb.Intensity), C.byref(t_), C.byref(b_)); keep.append((arr, a_, t_, b_))
+            assert o.L.orc_scene_update_lights(o.ctx, *lights_now) == 0
             ops.append(f"{len(lights)} lights")
         if rng.random() < 0.3:
             _moved(s, rng)
-            flat = flatten(s); keep.append(flat)
+            k = int(rng.integers(0, 5))          # ... and sometimes some leave, some come back, copies appear, the order changes (Scene.Objects is a list entities add to and remove from)
+            if k == 1 and len(s.Objects) > 4: gone += [s.Objects.pop(int(i)) for i in sorted(rng.choice(len(s.Objects), size=len(s.Objects) // 3, replace=False).tolist(), reverse=True)]
+            elif k == 2 and gone: s.Objects += gone; gone = []
+            elif k == 3: s.Objects += [copy.copy(s.Objects[int(i)]) for i in rng.integers(0, len(s.Objects), 20) if not isinstance(s.Objects[int(i)], (Mesh, VolumeGrid))]
+            elif k == 4: s.Objects = [s.Objects[int(i)] for i in rng.permutation(len(s.Objects))]
+            flat = flatten(s, against=uploaded); keep.append(flat)          # the moved objects against the tables of the last UPLOAD: what the library holds
             assert o.L.orc_scene_upload(o.ctx, flat.byref()) == 0
+            if lights_now is not None: assert o.L.orc_scene_update_lights(o.ctx, *lights_now) == 0          # (the oracle took a full upload: the uploaded lights came back with it)
             g.UpdateObjects(flat)
-            ops.append("objects moved")
+            ops.append(["objects moved", "objects moved, a third left", "objects moved, the leavers back", "objects moved, 20 copies", "objects moved, another order"][k])
         if rng.random() < 0.08:
             s, _ = random_scene(1000 + 50 * seed + step)
-            flat = flatten(s); keep.append(flat)
+            flat = uploaded = flatten(s); keep.append(flat); gone = []; lights_now = None
             assert o.L.orc_scene_upload(o.ctx, flat.byref()) == 0
             g.UploadScene(flat)
             ops.append(f"new scene ({len(s.Objects)} objects)")
@@ -161,6 +171,7 @@ def run_sequence(oracle, seed, steps=12, log=print, flight=False):
             ops.append(f"frame counter {n}")
         with_sdr = rng.random() < 0.35
         label = f"sequence {seed} step {step} [{', '.join(ops) or 'nothing'}{', SDR' if with_sdr else ''}]"
+        if os.environ.get("YCGE_SEQ_VERBOSE"): log("next:", label, f"({len(s.Objects)} objects, {w}x{h} ss {ss})")
         if flight:
             if not burst_left: burst_left = int(rng.integers(1, 4))
             so = o.render(stages=2, threads=8, want_sdr=True) if with_sdr else o.render(stages=1, threads=8)
@@ -458,6 +469,44 @@ def test_counts_far_beyond_the_configurations(product_lib, oracle, path, what):
         for k in range(40000):
             s.Add(Sphere(vec3(u(-30, 30), u(0, 20), u(-80, -2)), u(0.05, 0.4), Material(vec3(u(0, 1), u(0, 1), u(0, 1)), 0.1, 0.0)))
     o, g = _frames_equal(oracle, s, pose, size, f"{what} beyond the configurations", frames=2)
+    o.close(); g.close()
+
+
+@pytest.mark.parametrize("debug", [False, True])
+def test_tables_that_no_object_uses(product_lib, oracle, path, debug):
+    """Found by the drawn call sequences (round 6, seed 2204: `Memory access fault by GPU` in the timed k_trace): every mesh and voxel entity LEFT
+    Scene.Objects (ycge_scene_update_objects with analytic objects only) while the scene's tables - the last upload's - still list three meshes and
+    a grid.  The objects were then `analytic_only`, the context still `has_grid`, and a walk tree installed beside that flag sent the non-counting
+    kernel out of bounds (install_walk_tree, csrc/ycge_host.cpp: now only with a grid OBJECT).  Here: the entities leave, come back, leave again;
+    and a scene is UPLOADED whose tables list a mesh and a grid nothing uses - on the timed instances (debug False) and the counting ones."""
+    s, pose = random_scene(3)          # three meshes, a voxel volume, 230 analytic objects
+    assert sum(isinstance(o_, Mesh) for o_ in s.Objects) == 3 and sum(isinstance(o_, VolumeGrid) for o_ in s.Objects) == 1
+    everything = list(s.Objects)
+    analytic = [o_ for o_ in everything if not isinstance(o_, (Mesh, VolumeGrid))]
+    uploaded = flatten(s)
+    o = oracle.OracleRenderer(s, 120, 40, 1, pose, flat=uploaded)
+    g = RaytraceRenderer(uploaded, 120, 40, pose["fov"], 1, capture_debug=debug, count_work=debug)
+    g.SetCamera(pose["pos"], pose["yaw"], pose["pitch"])
+    keep = []
+
+    def frame(label):
+        o.render(stages=1, threads=8); g.TryFlipAndBlit()
+        for which in (abi.BUF_CURRENT_HDR, abi.BUF_G_NORMAL, abi.BUF_G_DEPTH, abi.BUF_SKY_MASK, abi.BUF_TAA_HISTORY):
+            assert pu.mismatch_count(o.read(which), g.read(which)) == 0, (label, which)
+
+    frame("as uploaded")
+    for label, objs in (("entities left", analytic), ("entities back", everything), ("left again, another order", analytic[::-1]), ("one sphere", analytic[:1])):
+        s.Objects = objs
+        f = flatten(s, against=uploaded); keep.append(f)
+        assert o.L.orc_scene_upload(o.ctx, f.byref()) == 0
+        g.UpdateObjects(f)
+        frame(label); frame(label)
+    s.Objects = analytic
+    unused = flatten(s, against=uploaded); keep.append(unused)          # a scene whose tables list three meshes and a grid that NO object uses, uploaded whole
+    assert unused.struct.n_meshes == 3 and unused.struct.n_grids == 1
+    assert o.L.orc_scene_upload(o.ctx, unused.byref()) == 0
+    g.UploadScene(unused)
+    frame("uploaded with unused tables"); frame("uploaded with unused tables")
     o.close(); g.close()
 
 

@@ -749,6 +749,7 @@ struct ObjectsHost {
     int wf_rounds = 2, spill_levels = 0;
     std::vector<int32_t> grid_owner;       // per grid of the last upload: the object that holds it (-1: none), SceneDev::grid_owner
     bool grid_owner_unique = true;         // false: two objects hold the same grid - no walk tree
+    bool any_grid_object = false;          // some object of the list IS a voxel grid (the scene's grid TABLE may hold grids no object uses: their entity left)
     float walk_t_limit = 0.0f;             // the smallest GGrid::cull_t_limit of the grids in Objects
     bool analytic_only = true;             // no mesh and no voxel grid among the objects (SceneDev::analytic_only)
 };
@@ -759,7 +760,7 @@ int flatten_objects(ycge_ctx *c, const ycge_prim *prims, int n_prims, ObjectsHos
     std::vector<GPrim> &gprims = oh.gprims;
     gprims.assign(n_prims, GPrim{});
     items.resize(n_prims);
-    oh.grid_owner.assign(c->grid_solid.size(), -1); oh.grid_owner_unique = true; oh.walk_t_limit = HUGE_VALF;
+    oh.grid_owner.assign(c->grid_solid.size(), -1); oh.grid_owner_unique = true; oh.any_grid_object = false; oh.walk_t_limit = HUGE_VALF;
     oh.analytic_only = true;
     for (int i = 0; i < n_prims; i++) {
         const ycge_prim &q = prims[i];
@@ -811,6 +812,7 @@ int flatten_objects(ycge_ctx *c, const ycge_prim *prims, int n_prims, ObjectsHos
             for (int k = 0; k < 7; k++) g.p[k] = c->grid_solid[q.ref][k];       // box of the grid's solid voxels + how far along a ray it may be trusted (grid_cull in the walk)
             if (oh.grid_owner[(size_t)q.ref] >= 0) oh.grid_owner_unique = false;
             oh.grid_owner[(size_t)q.ref] = i;
+            oh.any_grid_object = true;
             oh.walk_t_limit = cs_min(oh.walk_t_limit, c->grid_solid[q.ref][6]);
             break;
         default: return c->fail(YCGE_ERR_INVALID_ARG, "prim %d: unknown type %d", i, q.type);
@@ -862,12 +864,14 @@ int build_scene_tree_host(ycge_ctx *c, const BoundsSoA &items, ObjectsHost &oh)
 
 // SceneDev::walk_nodes: the walk tree of a world of voxel grids, from the tree and the object records now on the device (k_scene_walk,
 // ycge_bvh_build.hip) - whichever builder made the tree.  None (null) without a grid, when the root is a leaf, when two objects hold
-// the same grid (grid_owner would be ambiguous) and under YCGE_NO_WALK_TREE.
+// the same grid (grid_owner would be ambiguous), when NO object holds a grid although the scene's table has some (every voxel entity left
+// through ycge_scene_update_objects, or the upload listed grids nothing uses: the objects are then analytic_only, and a walk tree beside
+// that flag sent the timed k_trace out of bounds - a GPU memory fault found by the drawn call sequences of round 6) and under YCGE_NO_WALK_TREE.
 int install_walk_tree(ycge_ctx *c, const ObjectsHost &oh, int n_inner, uint32_t scene_root)
 {
     SceneDev &sd = c->sd;
     sd.walk_nodes = nullptr; sd.grid_owner = nullptr; sd.walk_root_ref = YCGE_REF_NONE_VALUE; sd.walk_t_limit = 0.0f; c->walk_scene_nodes = 0;
-    if (!c->has_grid || n_inner <= 0 || c->knobs.no_walk_tree || !oh.grid_owner_unique || YCGE_REF_KIND(scene_root) != REF_SCENE_NODE) return YCGE_OK;
+    if (!c->has_grid || !oh.any_grid_object || n_inner <= 0 || c->knobs.no_walk_tree || !oh.grid_owner_unique || YCGE_REF_KIND(scene_root) != REF_SCENE_NODE) return YCGE_OK;
     HIP_TRY(c, c->d_grid_owner.upload(oh.grid_owner));
     const size_t n_walk = (size_t)n_inner * (1 + 2 * YCGE_WALK_LEAF_NODES);
     HIP_TRY(c, c->d_walk_nodes.reserve(n_walk));

@@ -118,7 +118,7 @@ class RaytraceRenderer:
     def UpdateObjects(self, scene: Scene | FlatScene):
         """Scene.Update() -> RebuildBVH() after entities moved (Scene.cs:122-127): same materials, meshes and grids
         as the uploaded scene (in the same first-use order), new object records; only the scene BVH is rebuilt."""
-        f = scene if isinstance(scene, FlatScene) else flatten(scene)
+        f = scene if isinstance(scene, FlatScene) else flatten(scene, against=self.flat if hasattr(self.flat, "_mat_index") else None)          # (a Scene: numbered against the upload; NeedsUpload if it holds something new)
         self._check(self.L.ycge_scene_update_objects(self.ctx, C.cast(f.prims, C.POINTER(abi.Prim)), f.struct.n_prims))
         self.flat = f
 

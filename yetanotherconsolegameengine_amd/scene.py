@@ -251,17 +251,27 @@ class Scene:
         return h
 
 
+class NeedsUpload(ValueError):
+    """flatten(scene, against=uploaded): the objects use a record the uploaded scene does not hold - upload the scene again"""
+
+
 class FlatScene:
     """A `ycge_scene` plus the ctypes/numpy storage that keeps its pointers alive."""
 
-    def __init__(self, scene: Scene):
+    def __init__(self, scene: Scene, against: "FlatScene | None" = None):
+        """against: only Scene.Objects again, numbered against the materials / meshes / grids of an UPLOADED scene - what
+        ycge_scene_update_objects wants after entities moved, appeared or left (bindings/csharp/SceneFlattener.cs: ObjectsAgainst).  Raises
+        NeedsUpload when the objects use a Material, Mesh or VolumeGrid object the uploaded scene did not hold."""
         self._keep = []
         mats: List[Material] = []
-        mat_index = {}
+        mat_index = {} if against is None else dict(against._mat_index)
+        self._mat_index, self._mesh_index, self._grid_index = mat_index, {}, {}
 
         def mat_id(m: Material) -> int:
             key = id(m)
             if key not in mat_index:
+                if against is not None:
+                    raise NeedsUpload("a material the uploaded scene does not hold")
                 mat_index[key] = len(mats)
                 mats.append(m)
                 self._keep.append(m)
@@ -296,7 +306,14 @@ class FlatScene:
                 prim(abi.PRIM_CYLINDER_Y, mat_id(o.Mat), [*o.Center, o.Radius, o.YMin, o.YMax, 1.0 if o.Capped else 0.0])
             elif isinstance(o, Triangle):
                 prim(abi.PRIM_TRIANGLE, mat_id(o.Mat), [*o.A, *o.B, *o.C])
+            elif isinstance(o, Mesh) and against is not None:
+                if id(o) not in against._mesh_index: raise NeedsUpload("a mesh the uploaded scene does not hold")
+                prim(abi.PRIM_MESH, -1, [], ref=against._mesh_index[id(o)])
+            elif isinstance(o, VolumeGrid) and against is not None:
+                if id(o) not in against._grid_index: raise NeedsUpload("a voxel grid the uploaded scene does not hold")
+                prim(abi.PRIM_VOLUME_GRID, -1, [], ref=against._grid_index[id(o)])
             elif isinstance(o, Mesh):
+                self._mesh_index[id(o)] = len(meshes)
                 tris = np.ascontiguousarray(o.Triangles, dtype=np.float32).reshape(-1, 9)
                 self._keep.append(tris)
                 m = abi.Mesh()
@@ -313,6 +330,7 @@ class FlatScene:
                 prim(abi.PRIM_MESH, -1, [], ref=len(meshes))
                 meshes.append(m)
             elif isinstance(o, VolumeGrid):
+                self._grid_index[id(o)] = len(grids)
                 cells = np.ascontiguousarray(o.Cells, dtype=np.int32)
                 assert cells.ndim == 4 and cells.shape[3] == 2
                 self._keep.append(cells)
@@ -346,6 +364,18 @@ class FlatScene:
             a = (ctype * max(1, len(items)))(*items)
             self._keep.append(a)
             return a
+
+        if against is not None:          # the uploaded scene's tables with these objects: what the library holds after ycge_scene_update_objects
+            self._keep.append(against)
+            self._mesh_index, self._grid_index = against._mesh_index, against._grid_index
+            self.materials, self.meshes, self.grids, self.lights, self.textures = against.materials, against.meshes, against.grids, against.lights, against.textures
+            self.texture_objects, self.n_triangles = against.texture_objects, against.n_triangles
+            self.prims = arr(abi.Prim, prims)
+            sc = abi.Scene()
+            C.memmove(C.byref(sc), C.byref(against.struct), C.sizeof(sc))
+            sc.prims, sc.n_prims = C.cast(self.prims, C.POINTER(abi.Prim)), len(prims)
+            self.struct = sc
+            return
 
         mat_structs = []
         textures: List[Texture] = []
@@ -416,5 +446,5 @@ class FlatScene:
         return C.byref(self.struct)
 
 
-def flatten(scene: Scene) -> FlatScene:
-    return FlatScene(scene)
+def flatten(scene: Scene, against: "FlatScene | None" = None) -> FlatScene:
+    return FlatScene(scene, against)
