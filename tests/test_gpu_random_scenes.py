@@ -495,7 +495,10 @@ def test_tables_that_no_object_uses(product_lib, oracle, path, debug):
             assert pu.mismatch_count(o.read(which), g.read(which)) == 0, (label, which)
 
     frame("as uploaded")
-    for label, objs in (("entities left", analytic), ("entities back", everything), ("left again, another order", analytic[::-1]), ("one sphere", analytic[:1])):
+    no_grid = [o_ for o_ in everything if not isinstance(o_, VolumeGrid)]
+    no_mesh = [o_ for o_ in everything if not isinstance(o_, Mesh)]
+    for label, objs in (("entities left", analytic), ("entities back", everything), ("left again, another order", analytic[::-1]), ("only the voxel entity left", no_grid),
+                        ("only the meshes left", no_mesh), ("one sphere", analytic[:1])):
         s.Objects = objs
         f = flatten(s, against=uploaded); keep.append(f)
         assert o.L.orc_scene_upload(o.ctx, f.byref()) == 0
