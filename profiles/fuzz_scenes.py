@@ -2,7 +2,7 @@
 thousands of objects, camera inside an object, degenerate objects, scaled by 1e-2 .. 1e3, textured, voxel chunks, a material per triangle) on both device paths, two frames each, every buffer
 and counter against the oracle bit for bit; then its drawn CALL SEQUENCES (16 steps each; synchronous, then with frames in flight) its drawn renderer constants, its mesh viewers and its draws on 2 - 8 emulated ranks (both tiled forms).  Prints the frames that differ and a total; exit status 1 if there is one.
 
-    gpurun -- python profiles/fuzz_scenes.py 100 500        (round 6: 143 104 frames over seeds 0 .. 2399, none differs - profiles/r06/g_fuzz_scenes.txt)
+    gpurun -- python profiles/fuzz_scenes.py 100 500        (round 6: 150 904 frames over seeds 0 .. 2459, none differs - profiles/r06/g_fuzz_scenes.txt)
 """
 import os
 import sys
@@ -103,6 +103,13 @@ for path in ("wavefront", "megakernel"):          # mesh viewers (the flat singl
             print("MISMATCH", path, label, bad, flush=True)
     print(f"mesh viewers, {path}: seeds {lo}..{hi - 1} done; {n_bad} of {n_frames} frames differ so far", flush=True)
 os.environ.pop("YCGE_PATH", None)
+for form, kw in (("three contexts on the one GPU (peer push)", dict(devices=[0, 0, 0])), ("the all-gather form, a world of one", dict(rccl=True))):          # the one-process multi-GPU context of the C# host
+    for seed in range(lo, hi):
+        found = T.run_sequence(ob, seed, steps=16, log=lambda *a: None, **kw)
+        n_frames += 16; n_bad += len(found)
+        for label, bad in found:
+            print("MISMATCH", form, label, bad, flush=True)
+    print(f"call sequences, {form}: seeds {lo}..{hi - 1} done; {n_bad} of {n_frames} frames differ so far", flush=True)
 for seed in range(lo, hi):          # the tiled forms on 2 - 8 emulated ranks against one context
     found = T.run_tile_split(seed, log=lambda *a: None)
     n_frames += 4; n_bad += len(found)

@@ -105,10 +105,13 @@ def _moved(s, rng):
         else: o.A, o.B, o.C = sh(o.A), sh(o.B), sh(o.C)
 
 
-def run_sequence(oracle, seed, steps=12, log=print, flight=False):
+def run_sequence(oracle, seed, steps=12, log=print, flight=False, devices=None, rccl=False):
     """Returns the list of differences found (empty = the library followed the oracle through the whole sequence).
     flight: the library renders through ycge_render_frame_async / _async_sdr, one to three frames queued before ycge_wait - the calls between them
-    (camera, lights, moved objects, resize ..) arrive while frames are in flight; the last frame of a burst and every SDR array held are compared."""
+    (camera, lights, moved objects, resize ..) arrive while frames are in flight; the last frame of a burst and every SDR array held are compared.
+    devices: the one-process multi-GPU context of the C# host (config.n_devices; [0, 0, 0] = three contexts sharing the one GPU of the box: the root
+    and two peers with their threads, tiles pushed into the root's buffers) - every call has to reach all of them; rccl: its all-gather form
+    (config.multi_device_exchange = YCGE_EXCHANGE_RCCL) as a world of one."""
     rng = np.random.default_rng(77_000 + seed)
     u = lambda lo, hi: _f(rng.uniform(lo, hi))
     s, pose = random_scene(seed)
@@ -117,7 +120,10 @@ def run_sequence(oracle, seed, steps=12, log=print, flight=False):
     gone = []
     keep = [flat]                    # (the oracle and the library copy during the call; kept anyway until the contexts are gone)
     o = oracle.OracleRenderer(s, w, h, ss, pose, flat=flat)
-    g = RaytraceRenderer(flat, w, h, pose["fov"], ss, capture_debug=not flight, count_work=not flight)     # (frames in flight keep neither debug captures nor counters)
+    cfg = abi.default_config()
+    if rccl: cfg.multi_device_exchange = abi.EXCHANGE_RCCL
+    debug = not flight and not rccl          # frames in flight keep neither debug captures nor counters; the all-gather form gathers the frame's planes, NOT the debug capture's (rays, hit ids, RNG state stay unwritten on devices[0]: a known gap of a debug feature)
+    g = RaytraceRenderer(flat, w, h, pose["fov"], ss, cfg=cfg, capture_debug=debug, count_work=not flight, devices=[0] if rccl else devices)
     g.SetCamera(pose["pos"], pose["yaw"], pose["pitch"])
     found, held, burst_left, lights_now = [], [], 0, None
     for step in range(steps):
@@ -196,9 +202,17 @@ def run_sequence(oracle, seed, steps=12, log=print, flight=False):
                 so = o.render(stages=2, threads=8, want_sdr=True); sg = g.TryFlipAndBlit(want_sdr=True)
             else:
                 o.render(stages=1, threads=8); g.TryFlipAndBlit()
-            st = pu.compare_frame(o, g)
-            bad = {k: v for k, v in st.items() if k.endswith("_mismatch") and v}
-            bad.update({k: st[k] for k in ("n_rays", "n_box", "n_tri", "n_prim", "n_vox") if st[k][0] != st[k][1]})
+            if debug:
+                st = pu.compare_frame(o, g)
+                bad = {k: v for k, v in st.items() if k.endswith("_mismatch") and v}
+                bad.update({k: st[k] for k in ("n_rays", "n_box", "n_tri", "n_prim", "n_vox") if st[k][0] != st[k][1]})
+            else:
+                bad = {}
+                for name, which in (("current_hdr", abi.BUF_CURRENT_HDR), ("g_albedo", abi.BUF_G_ALBEDO), ("g_normal", abi.BUF_G_NORMAL), ("g_depth", abi.BUF_G_DEPTH),
+                                    ("sky", abi.BUF_SKY_MASK), ("taa_history", abi.BUF_TAA_HISTORY)):
+                    n = pu.mismatch_count(o.read(which), g.read(which))
+                    if n: bad[name] = n
+                bad.update({k: (int(getattr(o.stats, k)), int(getattr(g.stats, k))) for k in ("n_rays", "n_box", "n_tri", "n_prim", "n_vox") if int(getattr(o.stats, k)) != int(getattr(g.stats, k))})
             if int(o.stats.history_reset) != int(g.stats.history_reset): bad["history_reset"] = (int(o.stats.history_reset), int(g.stats.history_reset))
             if with_sdr:
                 if pu.mismatch_count(o.read(abi.BUF_DENOISED), g.read(abi.BUF_DENOISED)): bad["denoised"] = True
@@ -213,6 +227,14 @@ def run_sequence(oracle, seed, steps=12, log=print, flight=False):
 @pytest.mark.parametrize("seed", [1, 2, 3, 4, 5, 6])
 def test_random_call_sequences_follow_the_oracle(product_lib, oracle, path, seed):
     found = run_sequence(oracle, seed, steps=14)
+    assert not found, found
+
+
+@pytest.mark.parametrize("seed", [21, 22, 23, 24])
+@pytest.mark.parametrize("form", ["three contexts on the one GPU", "all-gather, a world of one"])
+def test_random_call_sequences_on_the_one_process_multi_gpu_context(product_lib, oracle, seed, form, monkeypatch):
+    monkeypatch.delenv("YCGE_PATH", raising=False)
+    found = run_sequence(oracle, seed, steps=14, devices=[0, 0, 0] if form.startswith("three") else None, rccl=form.startswith("all-gather"))
     assert not found, found
 
 
