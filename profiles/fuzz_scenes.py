@@ -112,7 +112,7 @@ for form, kw in (("three contexts on the one GPU (peer push)", dict(devices=[0, 
     print(f"call sequences, {form}: seeds {lo}..{hi - 1} done; {n_bad} of {n_frames} frames differ so far", flush=True)
 for seed in range(lo, hi):          # the tiled forms on 2 - 8 emulated ranks against one context
     found = T.run_tile_split(seed, log=lambda *a: None)
-    n_frames += 4; n_bad += len(found)
+    n_frames += 6; n_bad += len(found)
     for label, bad in found:
         print("MISMATCH", label, bad, flush=True)
 print(f"tiled forms on emulated ranks: seeds {lo}..{hi - 1} done; {n_bad} of {n_frames} frames differ so far", flush=True)
