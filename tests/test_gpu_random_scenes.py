@@ -537,7 +537,7 @@ def test_tables_that_no_object_uses(product_lib, oracle, path, debug):
     no_grid = [o_ for o_ in everything if not isinstance(o_, VolumeGrid)]
     no_mesh = [o_ for o_ in everything if not isinstance(o_, Mesh)]
     for label, objs in (("entities left", analytic), ("entities back", everything), ("left again, another order", analytic[::-1]), ("only the voxel entity left", no_grid),
-                        ("only the meshes left", no_mesh), ("one sphere", analytic[:1])):
+                        ("only the meshes left", no_mesh), ("one sphere", analytic[:1]), ("nobody", []), ("everybody back", everything)):
         s.Objects = objs
         f = flatten(s, against=uploaded); keep.append(f)
         assert o.L.orc_scene_upload(o.ctx, f.byref()) == 0
