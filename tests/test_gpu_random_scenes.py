@@ -552,6 +552,46 @@ def test_tables_that_no_object_uses(product_lib, oracle, path, debug):
     o.close(); g.close()
 
 
+@pytest.mark.parametrize("debug", [False, True])
+def test_object_lists_around_a_mesh_viewer(product_lib, oracle, path, debug):
+    """MeshScenes' pattern - floor and ONE mesh: the scenes of the flat single-launch kernels - taken through ycge_scene_update_objects: ten more
+    objects (a real tree), back to two, the mesh alone, the floor alone, the order swapped, the mesh TWICE, five objects, four (the flat loop's
+    limit), two again.  Whatever decides between the flat and the generic kernels has to be decided again at every update: two frames after each,
+    against the oracle (the timed instances with debug False, the counting ones with counters)."""
+    pos, faces = scenes.make_torus_knot(120, 30)
+    s = scenes.BuildMeshScene(pos, faces, scenes.Matte(scenes.Emerald, 0.12, 0.0))
+    pose = scenes.MESH_BENCH_POSE
+    floor, mesh = s.Objects[0], s.Objects[1]
+
+    def planes(n):
+        out = []
+        for k in range(n):
+            q = copy.copy(floor); q.Point = vec3(0.0, 0.3 + 0.2 * k, 2.0 + k); q.Normal = vec3(0.0, 0.3, -1.0); out.append(q)
+        return out
+
+    uploaded = flatten(s)
+    o = oracle.OracleRenderer(s, 320, 90, 1, pose, flat=uploaded)
+    g = RaytraceRenderer(uploaded, 320, 90, pose["fov"], 1, capture_debug=debug, count_work=debug)
+    g.SetCamera(pose["pos"], pose["yaw"], pose["pitch"])
+    keep = []
+    for label, objs in (("as uploaded", None), ("+ 10 planes", [floor, mesh] + planes(10)), ("floor + mesh again", [floor, mesh]), ("mesh only", [mesh]), ("floor only", [floor]),
+                        ("order swapped", [mesh, floor]), ("the mesh twice", [mesh, floor, mesh]), ("5 objects", [floor, mesh] + planes(3)), ("4 objects", [floor, mesh] + planes(2)),
+                        ("floor + mesh", [floor, mesh])):
+        if objs is not None:
+            s.Objects = objs
+            f = flatten(s, against=uploaded); keep.append(f)
+            assert o.L.orc_scene_upload(o.ctx, f.byref()) == 0
+            g.UpdateObjects(f)
+        for fr in range(2):
+            o.render(stages=1, threads=16); g.TryFlipAndBlit()
+            for which in (abi.BUF_CURRENT_HDR, abi.BUF_G_NORMAL, abi.BUF_G_DEPTH, abi.BUF_SKY_MASK, abi.BUF_TAA_HISTORY):
+                assert pu.mismatch_count(o.read(which), g.read(which)) == 0, (label, fr, which)
+            if debug:
+                for k in ("n_rays", "n_box", "n_tri", "n_prim"):
+                    assert int(getattr(o.stats, k)) == int(getattr(g.stats, k)), (label, fr, k)
+    o.close(); g.close()
+
+
 # ---- the renderer's constants ------------------------------------------------------------------------------------------------------------------------
 def drawn_config(seed):
     """ycge_config with the constants of RaytraceRenderer.cs:31-43, 65, 218, 221-227 DRAWN instead of defaulted (the three the library fixes -
