@@ -592,6 +592,40 @@ def test_object_lists_around_a_mesh_viewer(product_lib, oracle, path, debug):
     o.close(); g.close()
 
 
+@pytest.mark.parametrize("debug", [False, True])
+def test_voxel_chunks_streaming_in_and_out(product_lib, oracle, path, debug):
+    """What WorldManager does to a VolumeScene while the player walks (WorldManager.cs:372-397, 696-731: chunks attach and detach): the reduced voxel
+    world's chunk entities leave and return through ycge_scene_update_objects - a drawn third gone, back, all but one gone, NONE left (the state that
+    faulted: tables of grids, no grid object), everybody back, a drawn half - at noon, with the sun's shadow rays through the culled grids and the walk
+    tree rebuilt at every step.  Two frames after each, against the oracle."""
+    sc, _, _, _, pose = scenes.config_scene(5, small=True, t01=0.5)
+    rng = np.random.default_rng(9)
+    chunks = list(sc.Objects)
+    assert len(chunks) > 20 and all(isinstance(c_, VolumeGrid) for c_ in chunks)
+    uploaded = flatten(sc)
+    o = oracle.OracleRenderer(sc, 128, 36, 1, pose, flat=uploaded)
+    g = RaytraceRenderer(uploaded, 128, 36, pose["fov"], 1, capture_debug=debug, count_work=debug)
+    g.SetCamera(pose["pos"], pose["yaw"], pose["pitch"])
+    keep = []
+    third = [c_ for c_ in chunks if rng.random() < 0.67]
+    half = [c_ for c_ in chunks if rng.random() < 0.5]
+    for label, objs in (("as uploaded", None), ("a third detached", third), ("all attached", chunks), ("one chunk", chunks[len(chunks) // 2:len(chunks) // 2 + 1]), ("no chunk", []),
+                        ("all attached again", chunks), ("half, another order", half[::-1])):
+        if objs is not None:
+            sc.Objects = objs
+            f = flatten(sc, against=uploaded); keep.append(f)
+            assert o.L.orc_scene_upload(o.ctx, f.byref()) == 0
+            g.UpdateObjects(f)
+        for fr in range(2):
+            o.render(stages=1, threads=16); g.TryFlipAndBlit()
+            for which in (abi.BUF_CURRENT_HDR, abi.BUF_G_NORMAL, abi.BUF_G_DEPTH, abi.BUF_SKY_MASK, abi.BUF_TAA_HISTORY):
+                assert pu.mismatch_count(o.read(which), g.read(which)) == 0, (label, fr, which)
+            if debug:
+                for k in ("n_rays", "n_box", "n_vox"):
+                    assert int(getattr(o.stats, k)) == int(getattr(g.stats, k)), (label, fr, k)
+    o.close(); g.close()
+
+
 # ---- the renderer's constants ------------------------------------------------------------------------------------------------------------------------
 def drawn_config(seed):
     """ycge_config with the constants of RaytraceRenderer.cs:31-43, 65, 218, 221-227 DRAWN instead of defaulted (the three the library fixes -
