@@ -626,6 +626,25 @@ def test_voxel_chunks_streaming_in_and_out(product_lib, oracle, path, debug):
     o.close(); g.close()
 
 
+def test_destroy_with_frames_in_flight(product_lib):
+    """ycge_destroy while frames are queued (ycge_render_frame_async / _async_sdr, after a resize or an upload or neither): it joins them, nothing
+    faults or hangs, and the page-locked SDR arrays handed out outlive the context (they own their pages) with the frames they were promised."""
+    import gc
+    for rep in range(9):
+        s, pose = random_scene(rep)
+        flat = flatten(s)
+        g = RaytraceRenderer(flat, 320, 90, pose["fov"], 1)
+        g.SetCamera(pose["pos"], pose["yaw"], pose["pitch"])
+        held = [g.RenderAsync(sdr_slot=k) if k % 2 == 0 else g.RenderAsync() for k in range(3)]
+        if rep % 3 == 0: g.Resize(200, 60, 1)
+        elif rep % 3 == 1: g.UploadScene(flat)
+        g.RenderAsync(); last = g.RenderAsync(sdr_slot=0)
+        g.close()
+        arrays = [a for a in held + [last] if a is not None]
+        assert all(np.isfinite(a).all() for a in arrays) and float(last.max()) > 0.0
+        del held, arrays, last; gc.collect()
+
+
 # ---- the renderer's constants ------------------------------------------------------------------------------------------------------------------------
 def drawn_config(seed):
     """ycge_config with the constants of RaytraceRenderer.cs:31-43, 65, 218, 221-227 DRAWN instead of defaulted (the three the library fixes -
