@@ -645,6 +645,35 @@ def test_destroy_with_frames_in_flight(product_lib):
         del held, arrays, last; gc.collect()
 
 
+@pytest.mark.parametrize("seed", [0, 1, 2])
+def test_refused_updates_change_nothing(product_lib, oracle, path, seed):
+    """ycge_scene_update_objects and ycge_scene_upload given a record the validator refuses (a material index out of range, an unknown type, a mesh
+    or grid reference that does not exist): an error code and a message - and the context renders on with what it held, frame for frame the
+    oracle's (which was never told)."""
+    rng = np.random.default_rng(seed)
+    s, pose = random_scene(seed)
+    flat = flatten(s)
+    o = oracle.OracleRenderer(s, 97, 31, 1, pose, flat=flat)
+    g = RaytraceRenderer(flat, 97, 31, pose["fov"], 1, capture_debug=True, count_work=True)
+    g.SetCamera(pose["pos"], pose["yaw"], pose["pitch"])
+    o.render(stages=1, threads=8); g.TryFlipAndBlit()
+    for step in range(5):
+        broken = flatten(s, against=flat) if step < 4 else flatten(s)
+        i = int(rng.integers(0, broken.struct.n_prims))
+        if step % 4 == 0: broken.prims[i].material = 10_000 if broken.prims[i].type < 9 else broken.prims[i].material; broken.prims[0].type, broken.prims[0].material = 0, 10_000
+        elif step % 4 == 1: broken.prims[i].type = 77
+        elif step % 4 == 2: broken.prims[i].type, broken.prims[i].ref = 9, 999
+        else: broken.prims[i].type, broken.prims[i].ref = 10, -3
+        with pytest.raises(abi.YcgeError):
+            g.UpdateObjects(broken) if step < 4 else g.UploadScene(broken)
+        o.render(stages=1, threads=8); g.TryFlipAndBlit()
+        st = pu.compare_frame(o, g)
+        bad = {k: v for k, v in st.items() if k.endswith("_mismatch") and v}
+        bad.update({k: st[k] for k in ("n_rays", "n_box", "n_prim") if st[k][0] != st[k][1]})
+        assert not bad, (step, bad)
+    o.close(); g.close()
+
+
 # ---- the renderer's constants ------------------------------------------------------------------------------------------------------------------------
 def drawn_config(seed):
     """ycge_config with the constants of RaytraceRenderer.cs:31-43, 65, 218, 221-227 DRAWN instead of defaulted (the three the library fixes -
