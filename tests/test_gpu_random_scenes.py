@@ -674,6 +674,33 @@ def test_refused_updates_change_nothing(product_lib, oracle, path, seed):
     o.close(); g.close()
 
 
+@pytest.mark.parametrize("debug", [False, True])
+def test_light_counts_through_update_lights(product_lib, oracle, path, debug):
+    """ycge_scene_update_lights with light counts far from the upload's (a scene uploaded with two): 500, none, 3, 1 200, 1, 65 - the device array
+    grows and shrinks with them.  Two frames after each, against the oracle."""
+    rng = np.random.default_rng(1)
+    s, pose = random_scene(5)
+    flat = flatten(s)
+    o = oracle.OracleRenderer(s, 64, 20, 1, pose, flat=flat)
+    g = RaytraceRenderer(flat, 64, 20, pose["fov"], 1, capture_debug=debug, count_work=debug)
+    g.SetCamera(pose["pos"], pose["yaw"], pose["pitch"])
+    o.render(stages=1, threads=8); g.TryFlipAndBlit()
+    for n in (500, 0, 3, 1200, 1, 65):
+        lights = [PointLight(vec3(_f(rng.uniform(-8, 8)), _f(rng.uniform(0.5, 9)), _f(rng.uniform(-20, 4))), vec3(1, 1, 1), _f(rng.uniform(0, 3))) for _ in range(n)]
+        g.UpdateLights(lights, s.Ambient, s.BackgroundTop, s.BackgroundBottom)
+        arr = (abi.Light * max(1, n))()
+        for i, l in enumerate(lights):
+            arr[i].position, arr[i].color, arr[i].intensity = abi.Vec3(*l.Position), abi.Vec3(*l.Color), float(l.Intensity)
+        a_, t_, b_ = abi.Vec3(*s.Ambient.Color), abi.Vec3(*s.BackgroundTop), abi.Vec3(*s.BackgroundBottom)
+        assert o.L.orc_scene_update_lights(o.ctx, arr, n, C.byref(a_), float(s.Ambient.Intensity), C.byref(t_), C.byref(b_)) == 0
+        for fr in range(2):
+            o.render(stages=1, threads=8); g.TryFlipAndBlit()
+            for which in (abi.BUF_CURRENT_HDR, abi.BUF_TAA_HISTORY):
+                assert pu.mismatch_count(o.read(which), g.read(which)) == 0, (n, fr, which)
+            if debug: assert int(o.stats.n_rays) == int(g.stats.n_rays), (n, fr)
+    o.close(); g.close()
+
+
 # ---- the renderer's constants ------------------------------------------------------------------------------------------------------------------------
 def drawn_config(seed):
     """ycge_config with the constants of RaytraceRenderer.cs:31-43, 65, 218, 221-227 DRAWN instead of defaulted (the three the library fixes -
