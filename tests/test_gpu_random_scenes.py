@@ -265,29 +265,34 @@ def run_tile_split(seed, log=print):
     single = mk(0, 1)
     gath = [mk(i, world, slab_albedo=not lean) for i in range(world)]
     resi = [mk(i, world) for i in range(world)]
-    nb, hb = gath[0].tile_slab_bytes(), resi[0].history_slab_bytes()
-    n_send = [max(1, sum(r.halo_counts()[0])) for r in resi]
     found = []
     keep, gone, what = [flat], [], ""
     for frame in range(6):
         k = [0.0, 1e-3, 0.02, 0.3][int(rng.integers(0, 4))]
         pose = dict(pose, pos=tuple(_f(c + rng.uniform(-k, k)) for c in pose["pos"]), yaw=_f(pose["yaw"] + rng.uniform(-k, k) * 0.3))
         everyone = [single] + gath + resi
-        if frame >= 2:          # between frames, on EVERY context alike: entities move / leave / come back (ycge_scene_update_objects), lights change
-            op = int(rng.integers(0, 4))
+        if frame >= 2:          # between frames, on EVERY context alike: entities move / leave / come back (ycge_scene_update_objects), lights change, the console is resized
+            op = int(rng.integers(0, 5))
+            if op == 4:
+                w, h, ss = SEQ_SIZES[int(rng.integers(0, len(SEQ_SIZES)))]
+                for r in everyone: r.Resize(w, h, ss)
+                what = f", resized to {w}x{h} ss {ss}"
+                op = 9
             if op == 0:
                 _moved(s, rng); what = ", objects moved"
             elif op == 1 and len(s.Objects) > 6:
                 gone += [s.Objects.pop(int(i)) for i in sorted(rng.choice(len(s.Objects), size=len(s.Objects) // 3, replace=False).tolist(), reverse=True)]; what = ", a third left"
             elif op == 2 and gone:
                 s.Objects += gone; gone = []; what = ", the leavers back"
-            else:
+            elif op != 9:
                 lights = [PointLight(vec3(_f(rng.uniform(-8, 8)), _f(rng.uniform(0.5, 9)), _f(rng.uniform(-20, 4))), vec3(1, 1, 1), _f(rng.uniform(0, 90))) for _ in range(int(rng.integers(0, 4)))]
                 for r in everyone: r.UpdateLights(lights, s.Ambient, s.BackgroundTop, s.BackgroundBottom)
                 what = f", {len(lights)} lights"
             if op <= 2:
                 f2 = flatten(s, against=flat); keep.append(f2)
                 for r in everyone: r.UpdateObjects(f2)
+        nb, hb = gath[0].tile_slab_bytes(), resi[0].history_slab_bytes()          # (of the size of the moment)
+        n_send = [max(1, sum(r.halo_counts()[0])) for r in resi]
         for r in everyone:
             r.SetCamera(pose["pos"], pose["yaw"], pose["pitch"])
         single.TryFlipAndBlit()
