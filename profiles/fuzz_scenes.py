@@ -2,7 +2,7 @@
 thousands of objects, camera inside an object, degenerate objects, scaled by 1e-2 .. 1e3, textured, voxel chunks, a material per triangle) on both device paths, two frames each, every buffer
 and counter against the oracle bit for bit; then its drawn CALL SEQUENCES (16 steps each; synchronous, then with frames in flight) its drawn renderer constants, its mesh viewers and its draws on 2 - 8 emulated ranks (both tiled forms).  Prints the frames that differ and a total; exit status 1 if there is one.
 
-    gpurun -- python profiles/fuzz_scenes.py 100 500        (round 6: 150 904 frames over seeds 0 .. 2459, none differs - profiles/r06/g_fuzz_scenes.txt)
+    gpurun -- python profiles/fuzz_scenes.py 100 500        (round 6: 194 704 frames over seeds 0 .. 2759, none differs - profiles/r06/g_fuzz_scenes.txt)
 """
 import os
 import sys
