@@ -650,6 +650,32 @@ def temporal_blend(state, cur, normal, depth, sky, force_reset, alpha=0.01, radi
     return hist
 
 
+class FrameState:
+    """What the renderer carries from frame to frame beside the history itself: TemporalAA's last COMMITTED camera (TemporalAA.cs:12-16: NaN until
+    the first CommitCamera, and again after Resize, :34-45), its two thresholds (:52-56), and the frame counter (RaytraceRenderer.cs:24, 175).
+    TryFlipAndBlit asks ShouldResetHistory BEFORE the frame (:171) and commits the snapshot AFTER it (:266)."""
+
+    def __init__(self, trans_reset=0.0025, rot_reset=0.0025):
+        self.trans_reset, self.rot_reset = fmax(f32(0), f32(trans_reset)), fmax(f32(0), f32(rot_reset))
+        self.frame = 0
+        self.forget_camera()
+
+    def forget_camera(self):                # TemporalAA.Resize, :34-45
+        self.last = [f32(np.nan)] * 3
+        self.last_yaw = self.last_pitch = f32(np.nan)
+
+    def should_reset(self, pos, yaw, pitch):        # TemporalAA.ShouldResetHistory, :58-67
+        dx, dy, dz = (f32(f32(pos[k]) - self.last[k]) for k in range(3))
+        trans = f32(0) if np.isnan(dx) else f32(np.sqrt(f32(f32(f32(dx * dx) + f32(dy * dy)) + f32(dz * dz))))
+        dyaw = f32(0) if np.isnan(self.last_yaw) else f32(abs(f32(f32(yaw) - self.last_yaw)))
+        dpitch = f32(0) if np.isnan(self.last_pitch) else f32(abs(f32(f32(pitch) - self.last_pitch)))
+        return bool(trans > self.trans_reset or dyaw > self.rot_reset or dpitch > self.rot_reset)
+
+    def commit(self, pos, yaw, pitch):              # TemporalAA.CommitCamera, :69-76
+        self.last = [f32(v) for v in pos]
+        self.last_yaw, self.last_pitch = f32(yaw), f32(pitch)
+
+
 # ---- the two BVH builders (Objects/BVH.cs:258-459, Objects/MeshBVH.cs:371-576), restated from the C# text ----------------
 def _f2i(v):
     """(int)float on x64: cvttss2si - truncation, 0x80000000 for NaN / out of range"""

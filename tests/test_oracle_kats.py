@@ -497,6 +497,47 @@ def test_pushed_drawn_scenes_against_python_restatement(seed):
         _check_frames_against_restatement(s, 12, 5, pose, 2, set(), bvh=True)
 
 
+@pytest.mark.parametrize("seed", [1, 2, 3, 4])
+def test_frame_to_frame_state_against_python_restatement(seed):
+    """The renderer's state BETWEEN frames, oracle against the restatement (py_restatement.FrameState + temporal_blend): a drawn camera walk whose steps
+    straddle the two reset thresholds (TemporalAA.cs:58-67: translation, yaw, pitch, each in binary32), a Resize in the middle (history invalid, the
+    committed camera forgotten: TemporalAA.cs:34-45, RaytraceRenderer.cs:128-137 - so the frame after it is a reset by VALIDITY, and the one after that
+    compares with a camera committed since), frame-counter jumps.  Every frame: the oracle's `history_reset`, its radiance and its history, bit for bit."""
+    import py_restatement as pr
+    import random_scenes
+    rng = np.random.default_rng(40 + seed)
+    s, pose = random_scenes.random_scene(seed, n_range=(10, 24), mesh_nu=(5, 8), mesh_nv=(3, 5), max_meshes=1)
+    w, h = 10, 4
+    st, taa = pr.FrameState(), {}
+    ps = pr.BvhScene(s)
+    with ob.OracleRenderer(s, w, h, 1, pose) as o:
+        resets = []
+        for step in range(9):
+            k = [0.0, 0.0017, 0.0024, 0.0026, 0.004, 0.3][int(rng.integers(0, 6))]         # around TemporalAA's 0.0025
+            which = int(rng.integers(0, 3))
+            if which == 0: pose = dict(pose, pos=(f32(f32(pose["pos"][0]) + f32(k)), pose["pos"][1], pose["pos"][2]))
+            elif which == 1: pose = dict(pose, yaw=float(f32(f32(pose["yaw"]) + f32(k))))
+            else: pose = dict(pose, pitch=float(f32(f32(pose["pitch"]) - f32(k))))
+            if step == 4:
+                w, h = 8, 5
+                o.resize(w, h, 1); taa.clear(); st.forget_camera()
+            if step == 6:
+                o.set_frame_counter((1 << 31) - 2); st.frame = (1 << 31) - 2
+            o.set_camera(pose["pos"], pose["yaw"], pose["pitch"], pose["fov"])
+            o.render(stages=1)
+            st.frame += 1
+            want_reset = st.should_reset(pose["pos"], pose["yaw"], pose["pitch"])
+            p = pr.render_frame(o.L, ps, o.hiW, o.hiH, pose, st.frame)
+            first = not taa
+            hist = pr.temporal_blend(taa, p["hdr"], p["normal"], p["depth"], p["sky"], force_reset=want_reset)
+            st.commit(pose["pos"], pose["yaw"], pose["pitch"])
+            assert int(o.stats.history_reset) == int(want_reset or first), (step, k, which, want_reset, first)
+            assert np.array_equal(o.read(abi.BUF_CURRENT_HDR).view(np.uint32), np.ascontiguousarray(p["hdr"], f32).view(np.uint32)), (step, "radiance")
+            assert np.array_equal(o.read(abi.BUF_TAA_HISTORY).view(np.uint32), np.ascontiguousarray(hist, f32).view(np.uint32)), (step, "history")
+            resets.append(int(want_reset or first))
+        assert 0 < sum(resets) < len(resets), resets          # the walk did both: frames that blend and frames that start over
+
+
 def test_a_tilted_disk_is_missed_by_the_tree_as_in_the_reference():
     """A quirk the drawn scenes found (it is the REFERENCE's, and the oracle keeps it): Disk.TryGetBounds is a cube of the radius around the
     centre (Surfaces.cs:97-105) while Disk.Hit tests the radius in x and z only (:119-121) - on a steep disk the accepted
