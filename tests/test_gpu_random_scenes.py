@@ -706,6 +706,56 @@ def test_light_counts_through_update_lights(product_lib, oracle, path, debug):
     o.close(); g.close()
 
 
+@pytest.mark.parametrize("debug", [False, True])
+def test_every_short_object_list_over_a_small_universe(product_lib, oracle, path, debug):
+    """DESIGN section 11.6(c), as far as a test can take it: the host-side decisions ycge_scene_update_objects makes again at every call - objects
+    analytic_only or not, a grid OBJECT or only a grid table, a walk tree or none (one owner per grid), the flat loop of up to four objects or a real
+    tree, the mirror rounds - depend on WHICH objects are in the list.  Universe: a floor, a mirror sphere, a mesh, two voxel grids.  EVERY list of
+    0 - 4 of them (repeats allowed: 781 lists) and a few longer ones is installed in turn on one context - each state reached from the one before - and
+    a frame compared with the oracle's."""
+    import itertools
+    rng = np.random.default_rng(2)
+    floor = Plane(vec3(0, 0, 0), vec3(0, 1, 0), Checker(vec3(0.8, 0.8, 0.8), vec3(0.2, 0.2, 0.2), 1.0), 0.0, 0.0)
+    ball = Sphere(vec3(-1.2, 0.7, -3.0), 0.7, Material(vec3(0.95, 0.95, 0.95), 0.0, 0.95))
+    pos, faces = scenes.make_torus_knot(24, 8)
+    mesh = Mesh((pos[faces] * np.float32(0.35) + np.float32([0.8, 0.9, -3.2])).astype(np.float32), Material(vec3(0.2, 0.7, 0.3), 0.1, 0.0))
+
+    def grid(corner, seed):
+        r_ = np.random.default_rng(seed)
+        cells = np.zeros((6, 6, 6, 2), np.int32)
+        cells[..., 0] = np.where(r_.random((6, 6, 6)) < 0.5, r_.integers(1, 12, (6, 6, 6)), 0)
+        return VolumeGrid(cells, corner, vec3(0.3, 0.3, 0.3), scenes.VoxelMaterialLookup, True, 0.06, 16.0)
+
+    g1, g2 = grid(vec3(-0.4, 0.0, -2.2), 1), grid(vec3(1.6, 0.0, -4.5), 2)
+    universe = [floor, ball, mesh, g1, g2]
+    s = Scene()
+    s.Objects = list(universe)
+    s.Ambient = AmbientLight(vec3(1, 1, 1), 0.1)
+    s.Lights.append(PointLight(vec3(1.0, 4.0, 0.0), vec3(1, 1, 1), 50.0))
+    pose = dict(pos=(0.2, 1.1, 0.8), yaw=0.05, pitch=-0.15, fov=55.0)
+    uploaded = flatten(s)
+    o = oracle.OracleRenderer(s, 64, 18, 1, pose, flat=uploaded)
+    g = RaytraceRenderer(uploaded, 64, 18, pose["fov"], 1, capture_debug=debug, count_work=debug)
+    g.SetCamera(pose["pos"], pose["yaw"], pose["pitch"])
+    lists = [list(c_) for n in range(5) for c_ in itertools.product(universe, repeat=n)]
+    lists += [universe, universe[::-1], universe + universe, [floor, ball, mesh, g1], [g1, g2, g1, g2, mesh], [floor] * 5, [mesh] * 5, [g1] * 5]
+    order = rng.permutation(len(lists))
+    keep = []
+    for n_done, li in enumerate(order):
+        s.Objects = lists[int(li)]
+        f = flatten(s, against=uploaded); keep = [f]
+        assert o.L.orc_scene_upload(o.ctx, f.byref()) == 0
+        g.UpdateObjects(f)
+        o.render(stages=1, threads=8); g.TryFlipAndBlit()
+        names = [type(x).__name__[0] + ("1" if x is g1 else "2" if x is g2 else "") for x in s.Objects]
+        for which in (abi.BUF_CURRENT_HDR, abi.BUF_G_NORMAL, abi.BUF_G_DEPTH, abi.BUF_SKY_MASK, abi.BUF_TAA_HISTORY):
+            assert pu.mismatch_count(o.read(which), g.read(which)) == 0, (n_done, names, which)
+        if debug:
+            for k in ("n_rays", "n_box", "n_tri", "n_prim", "n_vox"):
+                assert int(getattr(o.stats, k)) == int(getattr(g.stats, k)), (n_done, names, k)
+    o.close(); g.close()
+
+
 # ---- the renderer's constants ------------------------------------------------------------------------------------------------------------------------
 def drawn_config(seed):
     """ycge_config with the constants of RaytraceRenderer.cs:31-43, 65, 218, 221-227 DRAWN instead of defaulted (the three the library fixes -
